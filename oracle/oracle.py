@@ -1,0 +1,168 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  The product path (``quilt_amd/``) must never do so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.qo_haploid_dosage_versus_refs.restype = C.c_int
+        _LIB.qo_simple_binary_search.restype = C.c_int
+        _LIB.qo_simple_binary_matrix_search.restype = C.c_int
+        _LIB.qo_get_top_K_or_more_matches_while_building_gamma.restype = C.c_int
+    return _LIB
+
+
+def _p(a, ctype=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _Panel(C.Structure):
+    _fields_ = [
+        ("K", C.c_int), ("nGrids", C.c_int), ("nSNPs", C.c_int), ("nMaxDH", C.c_int),
+        ("rhb_t", C.c_void_p), ("hapMatcher", C.c_void_p), ("hapMatcherR", C.c_void_p),
+        ("distinctHapsB", C.c_void_p), ("distinctHapsIE", C.c_void_p),
+        ("eMatDH_special_grid_which", C.c_void_p), ("special_values_ptr", C.c_void_p),
+        ("special_values", C.c_void_p), ("eMatDH_special_matrix_helper", C.c_void_p),
+        ("eMatDH_special_matrix", C.c_void_p), ("eMatDH_special_matrix_nrow", C.c_int),
+        ("use_eMatDH_special_symbols", C.c_int), ("transMatRate_t", C.c_void_p),
+        ("ref_error", C.c_double),
+    ]
+
+
+class _FullOpts(C.Structure):
+    _fields_ = [
+        ("K_top_matches", C.c_int), ("min_emission_prob_normalization_threshold", C.c_double),
+        ("return_betaHat_t", C.c_int), ("return_dosage", C.c_int), ("return_gamma_t", C.c_int),
+        ("return_gammaSmall_t", C.c_int), ("get_best_haps_from_thinned_sites", C.c_int),
+        ("always_normalize", C.c_int), ("normalize_emissions", C.c_int),
+    ]
+
+
+def panel_struct(panel, use_eMatDH_special_symbols: Optional[bool] = None):
+    """Returns (struct, keepalive)."""
+    ptr, vals = panel.special_csr()
+    if use_eMatDH_special_symbols is None:
+        use_eMatDH_special_symbols = panel.rhb_t is None
+    keep = [ptr, vals]
+    s = _Panel(
+        panel.K, panel.nGrids, panel.nSNPs, panel.nMaxDH,
+        _p(panel.rhb_t), _p(panel.hapMatcher), _p(panel.hapMatcherR),
+        _p(panel.distinctHapsB), _p(panel.distinctHapsIE),
+        _p(panel.eMatDH_special_grid_which), _p(ptr), _p(vals),
+        _p(panel.eMatDH_special_matrix_helper), _p(panel.eMatDH_special_matrix),
+        int(panel.eMatDH_special_matrix.shape[0]), int(bool(use_eMatDH_special_symbols)),
+        _p(panel.transMatRate_t), float(panel.ref_error),
+    )
+    return s, keep
+
+
+def make_gl_from_u_bq(u, bq, nSNPs, minGLValue=1e-10):
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    bq = np.ascontiguousarray(bq, dtype=np.int32)
+    gl = np.ones((2, nSNPs), dtype=np.float64, order="F")
+    lib().qo_make_gl_from_u_bq(_p(u), _p(bq), C.c_int(len(u)), C.c_int(nSNPs), C.c_double(minGLValue), _p(gl))
+    return gl
+
+
+def make_gl_bound(gl, minGLValue, to_fix):
+    to_fix = np.ascontiguousarray(to_fix, dtype=np.int32)
+    lib().qo_make_gl_bound(_p(gl), C.c_double(minGLValue), _p(to_fix), C.c_int(len(to_fix)))
+    return gl
+
+
+def build_eMatDH(distinctHapsB, gl, nGrids, nSNPs, ref_error, add_zero_row=False):
+    nMaxDH = distinctHapsB.shape[0]
+    out = np.zeros((nMaxDH + int(add_zero_row), nGrids), dtype=np.float64, order="F")
+    lib().qo_build_eMatDH(_p(distinctHapsB), _p(gl), C.c_int(nMaxDH), C.c_int(nGrids), C.c_int(nSNPs),
+                          C.c_double(ref_error), C.c_int(int(add_zero_row)), _p(out))
+    return out
+
+
+def simple_binary_search(val, vec):
+    vec = np.ascontiguousarray(vec, dtype=np.int32)
+    return lib().qo_simple_binary_search(C.c_int(int(val)), _p(vec), C.c_int(len(vec)))
+
+
+def simple_binary_matrix_search(val, mat, s1, e1):
+    mat = np.asfortranarray(mat, dtype=np.int32)
+    return lib().qo_simple_binary_matrix_search(C.c_int(int(val)), _p(mat), C.c_int(mat.shape[0]),
+                                                C.c_int(int(s1)), C.c_int(int(e1)))
+
+
+def get_top_K_or_more_matches(alpha_col, beta_col, K_top_matches, mult=1.0):
+    a = np.ascontiguousarray(alpha_col, dtype=np.float64)
+    b = np.ascontiguousarray(beta_col, dtype=np.float64)
+    K = len(a)
+    g = np.zeros(K)
+    idx = np.zeros(K, dtype=np.int32)
+    val = np.zeros(K)
+    n = lib().qo_get_top_K_or_more_matches_while_building_gamma(
+        _p(a), _p(b), _p(g), C.c_int(K), C.c_int(K_top_matches), C.c_double(mult), _p(idx), _p(val))
+    return idx[:n].copy(), val[:n].copy(), g
+
+
+def haploid_dosage_versus_refs(panel, gl, gammaSmall_cols_to_get=None, *, K_top_matches=5,
+                               return_betaHat_t=False, return_dosage=True, return_gamma_t=False,
+                               return_gammaSmall_t=False, get_best_haps_from_thinned_sites=False,
+                               always_normalize=False, normalize_emissions=True,
+                               min_emission_prob_normalization_threshold=1e-100,
+                               use_eMatDH_special_symbols=None):
+    """Oracle twin of ``Rcpp_haploid_dosage_versus_refs`` (reference-single.cpp:2189-2413).
+
+    Returns a dict with alphaHat_t, c, dosage and whichever optional outputs were asked for;
+    ``best_haps`` is a list (one per thinned column) of (top_matches 0-based, values).
+    """
+    K, G, T = panel.K, panel.nGrids, panel.nSNPs
+    if gammaSmall_cols_to_get is None:
+        gammaSmall_cols_to_get = np.full(G, -1, dtype=np.int32)
+    cols = np.ascontiguousarray(gammaSmall_cols_to_get, dtype=np.int32)
+    n_thin = int((cols >= 0).sum())
+    ps, keep = panel_struct(panel, use_eMatDH_special_symbols)
+    opts = _FullOpts(K_top_matches, min_emission_prob_normalization_threshold, int(return_betaHat_t),
+                     int(return_dosage), int(return_gamma_t), int(return_gammaSmall_t),
+                     int(get_best_haps_from_thinned_sites), int(always_normalize), int(normalize_emissions))
+    gl = np.asfortranarray(gl, dtype=np.float64)
+    alpha = np.zeros((K, G), dtype=np.float64, order="F")
+    beta = np.zeros((K, G), dtype=np.float64, order="F") if return_betaHat_t else None
+    gamma = np.zeros((K, G), dtype=np.float64, order="F") if return_gamma_t else None
+    gsmall = np.zeros((K, max(n_thin, 1)), dtype=np.float64, order="F") if return_gammaSmall_t else None
+    c = np.ones(G, dtype=np.float64)
+    dosage = np.zeros(T, dtype=np.float64)
+    cap = max(1, n_thin) * K if get_best_haps_from_thinned_sites else 1
+    cap = min(cap, 1 << 27)
+    bptr = np.zeros(n_thin + 1, dtype=np.int32)
+    bidx = np.zeros(cap, dtype=np.int32)
+    bval = np.zeros(cap, dtype=np.float64)
+    st = lib().qo_haploid_dosage_versus_refs(
+        C.byref(ps), C.byref(opts), _p(gl), _p(cols), _p(alpha), _p(beta), _p(c), _p(gamma), _p(gsmall),
+        _p(dosage), _p(bptr), _p(bidx), _p(bval), C.c_int64(cap))
+    if st != 0:
+        raise RuntimeError("oracle best-haps capacity too small")
+    best = [(bidx[bptr[i]:bptr[i + 1]].copy(), bval[bptr[i]:bptr[i + 1]].copy()) for i in range(n_thin)]
+    return dict(alphaHat_t=alpha, betaHat_t=beta, gamma_t=gamma, gammaSmall_t=gsmall, c=c, dosage=dosage,
+                best_haps=best if get_best_haps_from_thinned_sites else None)

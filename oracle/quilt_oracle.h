@@ -1,0 +1,112 @@
+/*
+ * quilt_oracle.h -- CPU oracle for the QUILT hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is a plain-C fp64 restatement of the reference's Rcpp kernels, written
+ * from reading the reference; every function cites the reference file:line it
+ * follows.  It exists so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg have something to check the HIP path against.  Nothing in
+ * the product path (quilt_amd/) may import, link or call it.
+ *
+ * PARITY PINNING: the reference (R + Rcpp + RcppArmadillo/RcppEigen + STITCH)
+ * cannot be built or run in this image and stores no golden vectors.  The
+ * oracle is pinned against (i) the RNG-independent known-answer tests the
+ * reference's testthat suite holds (binary searches, quantile, H_class
+ * log-probabilities, label-permutation table, gl bounding rule, top-K picker
+ * definition) and (ii) the structural invariants those tests assert
+ * (SURVEY.md 8(c) (1)-(14)).  For the bulk forward/backward and Gibbs
+ * arithmetic that is all that exists: "parity unpinned" beyond those.
+ *
+ * All matrices are column-major (R layout).  Indices are 0-based unless a
+ * parameter name ends in "_1based".
+ */
+#ifndef QUILT_ORACLE_H
+#define QUILT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- small helpers ------------------------------------------------------ */
+
+/* reference-single.cpp:68-94 */
+void qo_make_gl_bound(double *gl, double minGLValue, const int *to_fix, int n_to_fix);
+
+/* reference-single.R:19-42 (+ STITCH convertScaledBQtoProbs, restated from
+ * copied-from-stitch.cpp:166-175).  u is 0-based here. */
+void qo_make_gl_from_u_bq(const int *u, const int *bq, int n, int nSNPs,
+                          double minGLValue, double *gl /* 2 x nSNPs */);
+
+/* reference-single.cpp:272-329 */
+void qo_build_eMatDH(const int32_t *distinctHapsB, const double *gl, int nMaxDH,
+                     int nGrids, int nSNPs, double ref_error, int add_zero_row,
+                     double *eMatDH /* (nMaxDH + add_zero_row) x nGrids */);
+
+/* gibbs-small.cpp:26-59 ; returns 0-based position */
+int qo_simple_binary_search(int val, const int32_t *vec, int n);
+
+/* gibbs-small.cpp:69-105 ; mat is nrow x 2 column-major, s1/e1 1-based rows */
+int qo_simple_binary_matrix_search(int val, const int32_t *mat, int nrow, int s1, int e1);
+
+/* reference-single.cpp:100-108 */
+void qo_nth_partial_sort(const double *x, int n, int nth, double *y);
+
+/* reference-single.cpp:129-194.  Returns the number of matches written.
+ * top_idx/top_val need capacity K. */
+int qo_get_top_K_or_more_matches_while_building_gamma(
+    const double *alpha_col, const double *beta_col, double *gamma_col, int K,
+    int K_top_matches, double special_multiplication_value, int32_t *top_idx,
+    double *top_val);
+
+/* ---- full-panel haploid forward/backward -------------------------------- */
+
+typedef struct {
+    /* panel (read-only) */
+    int K, nGrids, nSNPs, nMaxDH;
+    const int32_t *rhb_t;            /* K x nGrids, may be NULL when special symbols are used */
+    const int32_t *hapMatcher;       /* K x nGrids int32, or NULL */
+    const uint8_t *hapMatcherR;      /* K x nGrids uint8, or NULL */
+    const int32_t *distinctHapsB;    /* nMaxDH x nGrids */
+    const double *distinctHapsIE;    /* nMaxDH x nSNPs */
+    const int32_t *eMatDH_special_grid_which;      /* nGrids ; 0 = none, else 1-based list id */
+    const int32_t *special_values_ptr;             /* CSR offsets over lists (n_lists + 1) */
+    const int32_t *special_values;                 /* concatenated 0-based k */
+    const int32_t *eMatDH_special_matrix_helper;   /* nGrids x 2, 1-based first/last row */
+    const int32_t *eMatDH_special_matrix;          /* nrow x 2: col0 = k (0-based), col1 = word */
+    int eMatDH_special_matrix_nrow;
+    int use_eMatDH_special_symbols;
+    const double *transMatRate_t;    /* 2 x (nGrids-1) */
+    double ref_error;
+} qo_panel_t;
+
+typedef struct {
+    int K_top_matches;
+    double min_emission_prob_normalization_threshold;
+    int return_betaHat_t, return_dosage, return_gamma_t, return_gammaSmall_t;
+    int get_best_haps_from_thinned_sites;
+    int always_normalize, normalize_emissions;
+} qo_fullpass_opts_t;
+
+/*
+ * reference-single.cpp:2189-2413 (orchestration), :878-1131 (forward, v3 ==
+ * v2 arithmetic), :1781-2179 (backward, v3 == v2 arithmetic), use_eMatDH=TRUE.
+ *
+ * alphaHat_t: K x nGrids (always full size; when only_store_alpha_at_gamma_small
+ *             applies, only column 0 and the thinned columns are written, as in
+ *             the reference).
+ * best_ptr (n_thin + 1), best_idx / best_val (capacity best_cap): CSR form of
+ *             best_haps_stuff_list, entry i = thinned column i.
+ * Returns 0, or -1 if best_cap was too small (best_ptr still holds the sizes).
+ */
+int qo_haploid_dosage_versus_refs(
+    const qo_panel_t *p, const qo_fullpass_opts_t *o, const double *gl /* 2 x nSNPs */,
+    const int32_t *gammaSmall_cols_to_get /* nGrids, -1 or 0-based col */,
+    double *alphaHat_t, double *betaHat_t, double *c, double *gamma_t,
+    double *gammaSmall_t /* K x n_thin */, double *dosage /* nSNPs */,
+    int32_t *best_ptr, int32_t *best_idx, double *best_val, int64_t best_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

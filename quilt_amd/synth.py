@@ -1,0 +1,178 @@
+"""Seeded synthetic panels and low-coverage read sets (no R, no BAMs, no network).
+
+Mimics the reference's own test-data recipes:
+
+* panel: ``make_reference_single_test_package`` (QUILT/R/test-drivers.R:324-462): per
+  32-SNP grid a few "founder" words with Beta(0.1, 0.1) allele frequencies, a Poisson
+  number of derived words with 4 flipped bits, every panel haplotype assigned to one of
+  them; a couple of "stress" grids with more than ``nMaxDH`` distinct words exercise the
+  special-haplotype tables.
+* reads: ``make_quilt_fb_test_package`` (QUILT/R/test-drivers.R:127-319) /
+  STITCH ``sampleReads`` convention (copied-from-stitch.cpp:153-160): per read
+  ``J`` (= #SNPs - 1), ``wif`` (0-based grid of the central SNP), signed base
+  qualities ``bq`` (< 0 REF, > 0 ALT, |bq| = phred) and 0-based SNP indices ``u``.
+
+Reads are kept flattened (CSR) because that is what the C ABI takes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .panel import Panel, int_expand, make_rhb_t_equality
+
+
+def _sigma_from_positions(L_grid, nGen, expRate, minRate=0.1, maxRate=100.0):
+    """prepare_reference_functions.R:89-108 with a flat genetic map of ``expRate`` cM/Mb."""
+    dl = np.diff(L_grid).astype(np.float64)
+    rate = nGen * dl / 1e6 * (expRate / 100.0)
+    lo = nGen * dl / 1e6 * (minRate / 100.0)
+    hi = nGen * dl / 1e6 * (maxRate / 100.0)
+    rate = np.minimum(np.maximum(rate, lo), hi)
+    return np.exp(-rate)
+
+
+def make_synthetic_panel(K: int, nSNPs: int, seed: int = 4916, nMaxDH: int = 255,
+                         ref_error: float = 1e-3, nGen: float = 100.0, expRate: float = 1.0,
+                         region_bp: Optional[int] = None, stress_grids: Sequence[int] = (2, 9),
+                         use_hapMatcherR: bool = True, keep_rhb_t: bool = True) -> Panel:
+    rng = np.random.default_rng(seed)
+    G = (nSNPs + 31) // 32
+    if region_bp is None:
+        region_bp = nSNPs * 47  # ~64 000 SNPs on 3 Mb
+    L = np.sort(rng.choice(np.arange(1, region_bp + 1), size=nSNPs, replace=False)).astype(np.int64)
+    grid = (np.arange(nSNPs) // 32).astype(np.int32)
+    starts = np.arange(0, nSNPs, 32)
+    L_grid = (np.add.reduceat(L, starts) // np.diff(np.r_[starts, nSNPs])).astype(np.int64)
+    sigma = _sigma_from_positions(L_grid, nGen, expRate)
+    transMatRate_t = np.asfortranarray(np.stack([sigma, 1.0 - sigma], axis=0))
+
+    rhb_t = np.zeros((K, G), dtype=np.int32, order="F")
+    weights = (np.uint64(1) << np.arange(32, dtype=np.uint64))
+    for g in range(G):
+        stress = g in stress_grids and K > nMaxDH + 20
+        y = rng.poisson(10, size=K)
+        nLocal = 4
+        if stress:
+            pick = rng.choice(K, size=nMaxDH + 20, replace=False)
+            y[pick] = np.arange(1, nMaxDH + 21)
+            nLocal = 6
+        n = int(y.max()) + 1
+        z = max(int(rng.poisson(6)), nLocal)
+        z = min(z, n)
+        af = rng.beta(1, 1, size=32) if stress else rng.beta(0.1, 0.1, size=32)
+        y2 = np.zeros((32, n), dtype=np.uint8)
+        y2[:, :z] = (rng.random((32, z)) < af[:, None]).astype(np.uint8)
+        for i in range(z, n):
+            y2[:, i] = y2[:, rng.integers(0, z)]
+            flip = rng.choice(32, size=nLocal, replace=False)
+            y2[flip, i] = rng.integers(0, 2, size=nLocal)
+        nbits = min(32, nSNPs - 32 * g)
+        y2[nbits:, :] = 0
+        words = (y2.astype(np.uint64) * weights[:, None]).sum(axis=0).astype(np.uint32).view(np.int32)
+        rhb_t[:, g] = words[y]
+    t = make_rhb_t_equality(rhb_t, nMaxDH, nSNPs, ref_error, use_hapMatcherR=use_hapMatcherR)
+    return Panel(
+        K=K, nSNPs=nSNPs, nGrids=G, nMaxDH=t["nMaxDH"], ref_error=ref_error,
+        rhb_t=rhb_t if keep_rhb_t else None,
+        hapMatcher=t["hapMatcher"], hapMatcherR=t["hapMatcherR"],
+        distinctHapsB=t["distinctHapsB"], distinctHapsIE=t["distinctHapsIE"],
+        eMatDH_special_grid_which=t["eMatDH_special_grid_which"],
+        eMatDH_special_values_list=t["eMatDH_special_values_list"],
+        eMatDH_special_matrix=t["eMatDH_special_matrix"],
+        eMatDH_special_matrix_helper=t["eMatDH_special_matrix_helper"],
+        transMatRate_t=transMatRate_t, L=L, L_grid=L_grid, grid=grid,
+        extra=dict(seed=seed, nGen=nGen, expRate=expRate),
+    )
+
+
+@dataclass
+class SampleReads:
+    """Flattened ``sampleReads`` (one sample)."""
+
+    read_ptr: np.ndarray   # int32 R+1
+    u: np.ndarray          # int32 sum(J+1): 0-based SNP index
+    bq: np.ndarray         # int32 sum(J+1): signed phred
+    wif: np.ndarray        # int32 R: 0-based grid of the central SNP (non-decreasing)
+    truth_label: Optional[np.ndarray] = None  # int32 R: 1-based generating haplotype
+    truth_haps: Optional[np.ndarray] = None   # int8 H x T
+    ff: float = 0.0
+
+    @property
+    def nReads(self) -> int:
+        return len(self.wif)
+
+    def as_list(self):
+        """R-style list of (J, wif, bq, u) for readability in tests."""
+        out = []
+        for r in range(self.nReads):
+            s, e = self.read_ptr[r], self.read_ptr[r + 1]
+            out.append((int(e - s - 1), int(self.wif[r]), self.bq[s:e].copy(), self.u[s:e].copy()))
+        return out
+
+
+def panel_hap_bits(panel: Panel, k: int) -> np.ndarray:
+    """0/1 alleles of panel haplotype ``k`` over all SNPs."""
+    assert panel.rhb_t is not None
+    return int_expand(panel.rhb_t[k, :]).reshape(-1)[: panel.nSNPs]
+
+
+def make_truth_haplotype(panel: Panel, rng, n_segments=(3, 6)) -> np.ndarray:
+    nseg = int(rng.integers(n_segments[0], n_segments[1] + 1))
+    cuts = np.sort(rng.choice(np.arange(1, panel.nSNPs), size=nseg - 1, replace=False)) if nseg > 1 else np.array([], dtype=int)
+    bounds = np.r_[0, cuts, panel.nSNPs]
+    hap = np.zeros(panel.nSNPs, dtype=np.int8)
+    for i in range(nseg):
+        k = int(rng.integers(0, panel.K))
+        hap[bounds[i]:bounds[i + 1]] = panel_hap_bits(panel, k)[bounds[i]:bounds[i + 1]]
+    return hap
+
+
+def make_synthetic_sample(panel: Panel, seed: int, mode: str = "short", n_reads: Optional[int] = None,
+                          ff: float = 0.0) -> SampleReads:
+    """One sample's reads.  ``mode``: "short" (1x Illumina-like), "ont" (long noisy reads);
+    ``ff`` > 0 makes an NIPT read mixture over (mat-T, mat-U, pat-T) as functions.R:586."""
+    rng = np.random.default_rng(seed)
+    T = panel.nSNPs
+    H = 3 if ff > 0 else 2
+    truth = np.stack([make_truth_haplotype(panel, rng) for _ in range(H)], axis=0)
+    if mode == "short":
+        if n_reads is None:
+            n_reads = max(2, int(round(T * 20000 / 64000)))
+        nsnp = np.minimum(1 + rng.poisson(2, size=n_reads), 8)
+        phred_lo, phred_hi = 20, 40
+    elif mode == "ont":
+        if n_reads is None:
+            n_reads = max(2, int(round(T * 300 / 64000)))
+        nsnp = rng.integers(200, 801, size=n_reads)
+        phred_lo, phred_hi = 5, 15
+    else:
+        raise ValueError(mode)
+    nsnp = np.minimum(nsnp, T)
+    start = np.array([rng.integers(0, T - n + 1) for n in nsnp], dtype=np.int64)
+    central = start + (nsnp - 1) // 2
+    order = np.argsort(central, kind="stable")
+    start, nsnp, central = start[order], nsnp[order], central[order]
+    if H == 2:
+        label = rng.integers(1, 3, size=n_reads)
+    else:
+        label = rng.choice([1, 2, 3], p=[0.5, 0.5 - ff / 2, ff / 2], size=n_reads)
+    read_ptr = np.zeros(n_reads + 1, dtype=np.int32)
+    read_ptr[1:] = np.cumsum(nsnp)
+    total = int(read_ptr[-1])
+    u = np.zeros(total, dtype=np.int32)
+    bq = np.zeros(total, dtype=np.int32)
+    for r in range(n_reads):
+        s, e = read_ptr[r], read_ptr[r + 1]
+        idx = np.arange(start[r], start[r] + nsnp[r])
+        u[s:e] = idx
+        phred = rng.integers(phred_lo, phred_hi + 1, size=nsnp[r])
+        allele = truth[label[r] - 1, idx].astype(np.int32)
+        err = rng.random(nsnp[r]) < 10.0 ** (-phred / 10.0)
+        allele = np.where(err, 1 - allele, allele)
+        bq[s:e] = np.where(allele == 1, phred, -phred)
+    wif = (central // 32).astype(np.int32)
+    return SampleReads(read_ptr=read_ptr, u=u, bq=bq, wif=wif, truth_label=label.astype(np.int32),
+                       truth_haps=truth, ff=ff)
