@@ -1,0 +1,147 @@
+/*
+ * quilt_amd.h -- C ABI of the MI355X-native QUILT hot path (libquilt_amd.so).
+ *
+ * This is the drop-in boundary: the entry points below are what the reference's
+ * R -> native `.Call` layer binds for its per-sample hot path
+ * (QUILT/src/RcppExports.cpp:1703-1782 registers them; QUILT/R/RcppExports.R holds
+ * the R stubs).  Each declaration cites the reference interface it replaces.
+ * INTEGRATION.md shows the R-side shim a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every matrix is column-major (R layout);
+ *   - indices are 0-based unless the parameter name says `_1based`;
+ *   - host pointers unless the name starts with `d_`;
+ *   - every function returns a status: QA_OK (0), QA_UNDERFLOW (1, soft failure the
+ *     R driver retries on: functions.R:2704-2715), or a negative hard error whose
+ *     text is available from qa_last_error();
+ *   - the library never keeps a caller pointer past the call (R owns its buffers,
+ *     SURVEY.md 8(b) "Ownership"); device mirrors live behind the opaque handles;
+ *   - no CPU fallback exists: every compute entry point fails with QA_ERR_NO_DEVICE
+ *     when no gfx950 device is usable.
+ */
+#ifndef QUILT_AMD_H
+#define QUILT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QA_OK 0
+#define QA_UNDERFLOW 1
+#define QA_ERR_NO_DEVICE (-1)
+#define QA_ERR_INVALID (-2)
+#define QA_ERR_UNSUPPORTED (-3)
+#define QA_ERR_HIP (-4)
+#define QA_ERR_CAPACITY (-5)
+
+/* ---- library ------------------------------------------------------------ */
+
+/* ABI version of this header (bumped on any signature change). */
+int qa_abi_version(void);
+/* Text of the last error on the calling thread (never NULL). */
+const char *qa_last_error(void);
+/* Number of usable gfx950 devices (0 when none: compute entry points then fail). */
+int qa_device_count(void);
+/* Bind the calling thread (and the objects it creates) to a device.  Must be called
+ * in the worker process itself: HIP contexts do not survive fork (quilt.R:692). */
+int qa_set_device(int device);
+
+/* ---- prepared reference panel (upload once per process) ------------------ */
+
+typedef struct qa_panel qa_panel_t;
+
+/* The objects QUILT() loads from the prepared-reference RData
+ * (QUILT/R/quilt.R:389; produced by quilt-prepare-reference.R:416-428). */
+typedef struct {
+    int32_t K, nGrids, nSNPs, nMaxDH;
+    const uint8_t *hapMatcherR;   /* K x nGrids raw, or NULL                          */
+    const int32_t *hapMatcher;    /* K x nGrids int, used when hapMatcherR is NULL    */
+    const int32_t *rhb_t;         /* K x nGrids packed panel, or NULL (msPBWT mode)   */
+    const int32_t *distinctHapsB; /* nMaxDH x nGrids                                  */
+    const double *distinctHapsIE; /* nMaxDH x nSNPs, or NULL (derived from B, eps)    */
+    const int32_t *eMatDH_special_grid_which;    /* nGrids                             */
+    const int32_t *eMatDH_special_matrix_helper; /* nGrids x 2, 1-based first/last    */
+    const int32_t *eMatDH_special_matrix;        /* nrow x 2: k (0-based), word       */
+    int32_t eMatDH_special_matrix_nrow;
+    int32_t use_eMatDH_special_symbols; /* 1: decode specials from the matrix (with the
+                                           reference's search, gibbs-small.cpp:69-105);
+                                           0: from rhb_t                               */
+    const double *transMatRate_t; /* 2 x (nGrids-1): sigma, 1 - sigma                  */
+    double ref_error;
+} qa_panel_desc_t;
+
+int qa_panel_create(const qa_panel_desc_t *desc, qa_panel_t **out);
+void qa_panel_destroy(qa_panel_t *panel);
+
+/* ---- full-panel haploid forward/backward -------------------------------- */
+
+/* Flags of Rcpp_haploid_dosage_versus_refs (QUILT/src/reference-single.cpp:2214-2227). */
+typedef struct {
+    int32_t K_top_matches;
+    int32_t return_betaHat_t, return_dosage, return_gamma_t, return_gammaSmall_t;
+    int32_t get_best_haps_from_thinned_sites;
+    int32_t always_normalize;     /* accepted; the device path always normalises per grid,
+                                     which the reference proves equivalent for dosage,
+                                     gamma and sum(log c) (test-unit-reference-single.R:588-642) */
+    int32_t normalize_emissions;
+    double min_emission_prob_normalization_threshold; /* accepted, unused (see above) */
+    int32_t suppressOutput;
+} qa_fullpass_opts_t;
+
+/*
+ * Replaces `_QUILT_Rcpp_haploid_dosage_versus_refs`
+ * (QUILT/src/RcppExports.cpp:1580-1625; kernel QUILT/src/reference-single.cpp:2189-2413;
+ * called from QUILT/R/functions.R:2034-2070) for use_eMatDH = TRUE.
+ *
+ * Like the reference it returns nothing and writes into the caller's buffers; any
+ * output pointer may be NULL when the matching flag is 0.
+ *   gl                      2 x nSNPs
+ *   gammaSmall_cols_to_get  nGrids, -1 or the 0-based thinned column
+ *   alphaHat_t              K x nGrids (NULL: not copied back).  Columns are normalised
+ *                           to sum 1 (always_normalize semantics).  When only thinned
+ *                           outputs are requested only column 0 and the thinned columns
+ *                           are written (reference-single.cpp:2264-2268).
+ *   betaHat_t, gamma_t      K x nGrids
+ *   c                       nGrids
+ *   gammaSmall_t            K x n_thin
+ *   dosage                  nSNPs
+ *   best_ptr/idx/val        CSR form of best_haps_stuff_list: entry i (thinned column
+ *                           i) = top_matches (0-based, ascending k) and
+ *                           top_matches_values.  best_cap = capacity of idx/val; on
+ *                           QA_ERR_CAPACITY best_ptr holds the needed sizes.
+ */
+int qa_Rcpp_haploid_dosage_versus_refs(
+    qa_panel_t *panel, const double *gl, const int32_t *gammaSmall_cols_to_get,
+    const qa_fullpass_opts_t *opts, double *alphaHat_t, double *betaHat_t, double *c,
+    double *gamma_t, double *gammaSmall_t, double *dosage, int32_t *best_ptr,
+    int32_t *best_idx, double *best_val, int64_t best_cap);
+
+/* Replaces `_QUILT_Rcpp_make_gl_bound` (RcppExports.cpp:1263-1273;
+ * reference-single.cpp:68-94).  Host arithmetic on a 2 x nSNPs matrix (O(n_to_fix)). */
+int qa_Rcpp_make_gl_bound(double *gl, double minGLValue, const int32_t *to_fix, int32_t n_to_fix);
+
+/*
+ * Batched form used by the per-sample driver: n_pass independent passes (one per
+ * (sample, Gibbs chain, read label)) in one launch set.  gl is n_pass stacked 2 x nSNPs
+ * matrices; want_dosage[i] selects a "dosage" pass (else a "thin" pass: only
+ * best-haps at the thinned grids, functions.R:748).  Outputs are stacked per pass:
+ * dosage n_pass x nSNPs (rows of skipped passes untouched); best_* as above with
+ * n_pass * n_thin entries (pass-major).
+ */
+int qa_fullpass_batch(
+    qa_panel_t *panel, int32_t n_pass, const double *gl, const int32_t *want_dosage,
+    const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double *dosage,
+    int32_t *best_ptr, int32_t *best_idx, double *best_val, int64_t best_cap);
+
+/* Timing of the most recent full-pass launch set on this thread, measured with HIP
+ * events on the launch stream (ms): [0] emission build, [1] forward, [2] backward,
+ * [3] dosage mat-vec, [4] total device.  Replaces print_times()
+ * (copied-from-stitch.cpp:31-45). */
+int qa_last_fullpass_timing_ms(double out[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+// common.hpp -- shared host-side plumbing of libquilt_amd (error state, device buffers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/quilt_amd.h"
+
+namespace qa {
+
+void set_error(const char *fmt, ...);
+bool device_ready();
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define QA_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            char _b[512];                                                                    \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                     __FILE__, __LINE__);                                                    \
+            throw qa::HipError(_b);                                                          \
+        }                                                                                    \
+    } while (0)
+
+// RAII device buffer
+template <typename T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    explicit DBuf(size_t n_) { alloc(n_); }
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DBuf &operator=(DBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DBuf() { release(); }
+    void alloc(size_t n_) {
+        release();
+        n = n_;
+        if (n) QA_HIP(hipMalloc((void **)&p, n * sizeof(T)));
+    }
+    void ensure(size_t n_) { if (n_ > n) alloc(n_); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void upload(const T *h, size_t cnt, hipStream_t s = nullptr) {
+        if (cnt) QA_HIP(hipMemcpyAsync(p, h, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T *h, size_t cnt, hipStream_t s = nullptr) const {
+        if (cnt) QA_HIP(hipMemcpyAsync(h, p, cnt * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+    void zero(hipStream_t s = nullptr) {
+        if (n) QA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    }
+};
+
+// translate exceptions at the C boundary
+template <typename F>
+int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const HipError &e) {
+        set_error("%s", e.what());
+        return QA_ERR_HIP;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return QA_ERR_INVALID;
+    }
+}
+
+}  // namespace qa

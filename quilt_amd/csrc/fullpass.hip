@@ -1,0 +1,1026 @@
+// fullpass.hip -- full-panel haploid Li-Stephens forward/backward on gfx950 (MI355X).
+//
+// What it computes: QUILT/src/reference-single.cpp `Rcpp_haploid_dosage_versus_refs`
+// (:2189-2413) = `Rcpp_build_eMatDH` (:272-329) + forward v3 (:878-1131) + backward v3
+// (:1781-2179) + top-K picker (:129-194), for use_eMatDH = TRUE.
+//
+// How (MI355X-first, not the reference's loop nest):
+//   * the recursion is sequential in the grid index g and needs one all-K sum per grid, so ONE
+//     workgroup owns one (sample, chain, label) pass and keeps all K alpha (resp. beta) values in
+//     VGPRs (fp32, 16 * NCH per lane); the per-grid sum is a wave-shuffle + LDS reduce with a single
+//     s_barrier.  Hundreds of independent passes fill the 256 CUs -- no inter-workgroup traffic.
+//   * per grid each lane streams 16 haplotype codes with one aligned 16-byte load of the uint8
+//     `hapMatcherR` row (coalesced 1 KiB per wave instruction), gathers the emission of its code
+//     from a <=256-entry fp32 table staged in LDS, and (dosage passes) checkpoints alpha to HBM in
+//     a lane-interleaved order that makes every store a fully coalesced 1 KiB dwordx4 store.
+//   * the backward pass re-reads that checkpoint, forms gamma = alpha * beta in registers, and
+//     histograms gamma by haplotype code with conflict-free LDS float atomics (32 bank-private
+//     copies); the 32 x nMaxDH dosage mat-vec is taken off the serial path (k_dosage).
+//   * alpha/beta are renormalised every grid (the reference's always_normalize = TRUE semantics,
+//     equivalent for dosage / gamma / sum(log c): test-unit-reference-single.R:588-642), which is
+//     what makes fp32 state safe; emissions are built in fp64 and rounded once.
+//
+// Algorithmic HBM bytes: dosage pass 10 * K * G (1 B code + 4 B alpha store
+// forward; 1 B code + 4 B alpha load backward), thin pass 2.8 * K * G.
+#include "panel.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <utility>
+
+namespace {
+
+constexpr int kMaxRow = 256;      // nMaxDH + 1 <= 256
+constexpr int kHistCopies = 32;   // bank-private copies of the gamma histogram
+constexpr int kMaxTop = 8;        // K_top_matches supported in registers
+
+struct PassParams {
+    // panel
+    const uint8_t *hm;       // [G][Kp]
+    const int32_t *B;        // [G][nMaxDH]
+    const int32_t *sp_off;   // [G+1]
+    const int32_t *sp_k;
+    const uint32_t *sp_word;
+    const double *sigma;     // [G-1]
+    const double *IE;        // [T][nMaxDH] or null
+    int K, Kp, G, T, nMaxDH, nrow, n_special;
+    double ref_error;
+    // per launch
+    int P;                   // passes
+    const double *gl;        // [P][T][2]
+    const int32_t *thin_col; // [G]  -1 or thinned column
+    int n_thin;
+    const int32_t *flags;    // [P] bit0: dosage pass; bit1: store all alpha; bit2: store gamma; bit3: store beta
+    int normalize_emissions;
+    // scratch / outputs
+    float *emat;             // [P][G][kMaxRow]
+    float *esp;              // [P][n_special]
+    double *escale0;         // [P] factor applied to the grid-0 emissions (folded back into c[0])
+    float *alpha;            // [P][n_alpha_cols][Kq]   (lane-interleaved order)
+    const int32_t *alpha_slot; // [P][G] -> column slot in alpha, or -1
+    size_t alpha_pass_stride; // floats
+    int Kq;                  // NT * NCH * 16 (padded K of the launch geometry)
+    double *c;               // [P][G]
+    float *mg;               // [P][G][kMaxRow]  raw gamma histogram (dosage passes)
+    float *gsp;              // [P][n_special]   gamma of special haplotypes
+    float *gamma_out;        // [P][G][Kq] or null
+    float *beta_out;         // [P][G][Kq] or null
+    float *beta_thin;        // [P][n_thin][Kq] unscaled beta at the thinned grids, or null
+    double *dosage;          // [P][T]
+    int K_top;
+    int top_cap;             // capacity per (pass, thinned column)
+    int32_t *top_cnt;        // [P][n_thin]
+    int32_t *top_idx;        // [P][n_thin][top_cap]
+    float *top_val;          // [P][n_thin][top_cap]
+};
+
+// ---------------------------------------------------------------------------------------------
+// k_emat: emission tables.  One block per (grid, pass); thread d computes the fp64 emission of
+// distinct word d-1 (reference-single.cpp:294-327), the block finds min / max, applies
+// normalize_emissions (:985-990) and writes fp32.  Row 0 is written as 0: haplotypes with code 0
+// ("specials") get their own emission from `esp` (:1002-1042).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double word_emission(uint32_t w, const double2 *gl, int nLocal, double eps) {
+    double prob = 1.0;
+    const double ome = 1.0 - eps;
+    for (int b = 0; b < nLocal; b++) {
+        double2 v = gl[b];  // x = P(reads | ref), y = P(reads | alt)
+        prob *= ((w >> b) & 1u) ? (v.x * eps + v.y * ome) : (v.x * ome + v.y * eps);
+    }
+    return prob;
+}
+
+__global__ __launch_bounds__(256) void k_emat(PassParams prm) {
+    const int g = blockIdx.x, p = blockIdx.y, t = threadIdx.x;
+    __shared__ double2 s_gl[32];
+    __shared__ double s_red[256];
+    __shared__ int s_var;
+    const int s = 32 * g;
+    const int nLocal = min(32, prm.T - s);
+    const double2 *gl = reinterpret_cast<const double2 *>(prm.gl) + (size_t)p * prm.T + s;
+    if (t == 0) s_var = 0;
+    __syncthreads();
+    if (t < nLocal) {
+        double2 v = gl[t];
+        s_gl[t] = v;
+        if (v.x != 1.0 || v.y != 1.0) s_var = 1;  // benign race: all writers store 1
+    }
+    __syncthreads();
+    const bool has_variant = s_var != 0 || g == 1 || g == 0;
+    float *out = prm.emat + ((size_t)p * prm.G + g) * kMaxRow;
+    const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
+    if (!has_variant) {
+        // reference shortcut (:1078-1088): emission is 1 for every haplotype
+        if (t < prm.nrow) out[t] = (t == 0) ? (sn > 0 ? 1.f : 0.f) : 1.f;
+        for (int i = t; i < sn; i += 256) prm.esp[(size_t)p * prm.n_special + so + i] = 1.f;
+        return;  // (never taken for g == 0)
+    }
+    double e = 0;
+    if (t >= 1 && t < prm.nrow) {
+        uint32_t w = (uint32_t)prm.B[(size_t)g * prm.nMaxDH + (t - 1)];
+        e = word_emission(w, s_gl, nLocal, prm.ref_error);
+    }
+    // min over rows 1..nMaxDH (row 0 of the reference's table starts at 1 and takes the min)
+    s_red[t] = (t >= 1 && t < prm.nrow) ? e : 1.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) s_red[t] = fmin(s_red[t], s_red[t + o]);
+        __syncthreads();
+    }
+    const double row0 = s_red[0];
+    __syncthreads();
+    s_red[t] = (t >= 1 && t < prm.nrow) ? e : row0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) s_red[t] = fmax(s_red[t], s_red[t + o]);
+        __syncthreads();
+    }
+    const double emax = s_red[0];
+    double scale = 1.0, sp_scale = 1.0;
+    if (prm.normalize_emissions) {
+        if (emax < 1.0) scale = 1.0 / emax;
+        sp_scale = 1.0 / emax;  // specials are always divided by emission_max (:1034)
+    }
+    if (g == 0) {
+        // the reference initialises alpha(0) from the raw emissions (:2314-2347); fp32 state cannot,
+        // so scale by 1 / max here and fold the factor back into c[0] in k_fwd
+        scale = sp_scale = 1.0 / emax;
+        if (t == 0) prm.escale0[p] = scale;
+    }
+    // row 0 (code 0): 0 normally, so the zero padding K..Kq and any stray code drop out; 1 on grids
+    // that hold specials, whose own emission `esp` is applied by the kernels' rare path
+    if (t < prm.nrow) out[t] = (t == 0) ? (sn > 0 ? 1.f : 0.f) : (float)(e * scale);
+    for (int i = t; i < sn; i += 256) {
+        double es = word_emission(prm.sp_word[so + i], s_gl, nLocal, prm.ref_error) * sp_scale;
+        prm.esp[(size_t)p * prm.n_special + so + i] = (float)es;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// first position in grid g's ascending special list whose haplotype index is >= k (rare path)
+__device__ __noinline__ int special_lower_bound(const int32_t *sp_k, int lo, int hi, int k) {
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (sp_k[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ bool has_zero_byte(uint32_t v) { return ((v - 0x01010101u) & ~v & 0x80808080u) != 0; }
+__device__ __forceinline__ bool any_zero_code(const uint4 &d) {
+    return has_zero_byte(d.x) || has_zero_byte(d.y) || has_zero_byte(d.z) || has_zero_byte(d.w);
+}
+
+// float4 index of (chunk j, vector q) of this thread in the lane-interleaved alpha checkpoint:
+// each (wave, j, q) owns 64 consecutive float4 (1 KiB) => every dwordx4 store/load is coalesced.
+__device__ __forceinline__ size_t alpha_vec_index(int j, int q, int NT, int t) {
+    return (size_t)j * NT * 4 + (size_t)((t >> 6) * 4 + q) * 64 + (t & 63);
+}
+
+// block-wide sum of one double per thread: wave shuffle, then LDS across waves.  `buf` is one of two
+// alternating 16-entry buffers so that one barrier per call suffices.
+__device__ __forceinline__ double block_sum(double v, double *buf, int t, int nwaves) {
+    v = wave_sum(v);
+    if ((t & 63) == 0) buf[t >> 6] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < nwaves; w++) s += buf[w];
+    return s;
+}
+
+// Multiply the state of the haplotypes with code 0 ("specials": grids with more than nMaxDH distinct
+// words) by their own emission (reference-single.cpp:1002-1042 / :1902-1964).  Row 0 of the LDS table
+// is 1 on such grids, so x holds the un-emitted value.  A chunk's specials are consecutive entries of
+// the grid's ascending list: one lower_bound per chunk that holds a zero code, then in order.
+template <int NCH>
+__device__ __forceinline__ void apply_special_emissions(float (&x)[NCH][16], const uint4 (&dh)[NCH], const PassParams &prm,
+                                                        const float *esp, int g, int NT, int t) {
+    const int lo = prm.sp_off[g], hi = prm.sp_off[g + 1];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        if (!any_zero_code(dh[j])) continue;
+        const int k0 = (j * NT + t) * 16;
+        if (k0 >= prm.K) continue;
+        int at = special_lower_bound(prm.sp_k, lo, hi, k0);
+        const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+            if (code == 0 && k0 + i < prm.K) {
+                x[j][i] *= esp[at];
+                at++;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fwd: forward recursion.  alpha_k <- (alpha_k + psi/sigma) * e_k, renormalised every grid
+// (reference-single.cpp:935-1107 with always_normalize).  One block per pass.
+// ---------------------------------------------------------------------------------------------
+template <int NCH, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *etab = reinterpret_cast<float *>(smem);                     // [2][256]
+    double *red = reinterpret_cast<double *>(smem + 2 * kMaxRow * 4);  // [2][16]
+    const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
+    const int K = prm.K, G = prm.G;
+    const int flags = prm.flags[p];
+    const bool store_all = (flags & 15) != 0;
+    const float *emat = prm.emat + (size_t)p * G * kMaxRow;
+    const float *esp = prm.esp + (size_t)p * prm.n_special;
+    float4 *aout = reinterpret_cast<float4 *>(prm.alpha + (size_t)p * prm.alpha_pass_stride);
+    const int32_t *slot = prm.alpha_slot + (size_t)p * G;
+    const size_t col_vecs = (size_t)prm.Kq / 4;
+
+    float a[NCH][16];
+    uint4 dh[NCH];
+    const float invK = 1.0f / (float)K;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int k0 = (j * NT + t) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[j][i] = (k0 + i < K) ? invK : 0.f;
+        dh[j] = make_uint4(0, 0, 0, 0);
+        if (k0 < K) dh[j] = *reinterpret_cast<const uint4 *>(prm.hm + k0);
+    }
+    for (int i = t; i < kMaxRow; i += NT) etab[i] = (i < prm.nrow) ? emat[i] : 0.f;
+    __syncthreads();
+
+    for (int g = 0; g < G; g++) {
+        const float *et = etab + (g & 1) * kMaxRow;
+        float etn[4] = {0.f, 0.f, 0.f, 0.f};  // next grid's table: rows t, t+NT, .. (NT >= 64, nrow <= 256)
+        if (g + 1 < G) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (t + r * NT < prm.nrow) etn[r] = emat[(size_t)(g + 1) * kMaxRow + t + r * NT];
+        }
+        double sg = 0.0, sig = 1.0;
+        if (g > 0) {
+            sig = prm.sigma[g - 1];
+            sg = (1.0 - sig) / (double)K / sig;  // psi / sigma with A_prev = 1
+        }
+        const float s = (float)sg;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+                a[j][i] = (a[j][i] + s) * et[code];
+            }
+        }
+        if (prm.sp_off[g + 1] > prm.sp_off[g]) apply_special_emissions<NCH>(a, dh, prm, esp, g, NT, t);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            const int k0 = (j * NT + t) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (k0 + 16 > K && k0 + i >= K) a[j][i] = 0.f;  // padding K..Kq (only the tail chunk pays)
+                psum += a[j][i];
+            }
+        }
+        if (g + 1 < G) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (t + r * NT < kMaxRow) etab[((g + 1) & 1) * kMaxRow + t + r * NT] = etn[r];
+        }
+        const double A = block_sum((double)psum, red + (g & 1) * 16, t, nwaves);
+        // the codes of the next grid: issued as early as the registers allow (temporaries are dead)
+        if (g + 1 < G) {
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const int k0 = (j * NT + t) * 16;
+                if (k0 < K) dh[j] = *reinterpret_cast<const uint4 *>(prm.hm + (size_t)(g + 1) * prm.Kp + k0);
+            }
+        }
+        const double invA = 1.0 / A;
+        const float inv = (float)invA;
+        if (t == 0) prm.c[(size_t)p * G + g] = (g == 0) ? invA * prm.escale0[p] : invA / sig;
+        const int sl = store_all ? g : slot[g];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[j][i] *= inv;
+            if (sl >= 0 && (j * NT + t) * 16 < K) {
+                float4 *dst = aout + (size_t)sl * col_vecs;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    dst[alpha_vec_index(j, q, NT, t)] =
+                        make_float4(a[j][4 * q], a[j][4 * q + 1], a[j][4 * q + 2], a[j][4 * q + 3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_bwd: backward recursion + gamma + histogram (dosage passes) + top-K (thinned grids).
+// reference-single.cpp:1854-2177.
+// ---------------------------------------------------------------------------------------------
+template <int NCH, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *etab = reinterpret_cast<float *>(smem);                          // [2][256]
+    double *red = reinterpret_cast<double *>(smem + 2 * kMaxRow * 4);       // [2][16]
+    float *hist = reinterpret_cast<float *>(smem + 2 * kMaxRow * 4 + 2 * 16 * 8);  // [2][kMaxRow][32]
+    const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
+    const int lane = t & 63;
+    const int K = prm.K, G = prm.G;
+    const int flags = prm.flags[p];
+    const bool want_dosage = (flags & 1) != 0;
+    const bool store_all = (flags & 15) != 0;
+    const bool want_gamma = (flags & 4) != 0, want_beta = (flags & 8) != 0;
+    const float *emat = prm.emat + (size_t)p * G * kMaxRow;
+    const float *esp = prm.esp + (size_t)p * prm.n_special;
+    const float4 *ain = reinterpret_cast<const float4 *>(prm.alpha + (size_t)p * prm.alpha_pass_stride);
+    const int32_t *slot = prm.alpha_slot + (size_t)p * G;
+    const size_t col_vecs = (size_t)prm.Kq / 4;
+    const double *cvec = prm.c + (size_t)p * G;
+
+    float b[NCH][16];
+    uint4 dh[NCH];  // codes of grid g+1 during the emission phase, then reloaded with grid g's
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int k0 = (j * NT + t) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) b[j][i] = (k0 + i < K) ? 1.f : 0.f;
+        dh[j] = make_uint4(0, 0, 0, 0);
+    }
+    if (want_dosage)
+        for (int i = t; i < 2 * kMaxRow * kHistCopies; i += NT) hist[i] = 0.f;
+    for (int i = t; i < kMaxRow; i += NT)
+        etab[((G - 1) & 1) * kMaxRow + i] = (i < prm.nrow) ? emat[(size_t)(G - 1) * kMaxRow + i] : 0.f;
+    __syncthreads();
+
+    for (int g = G - 1; g >= 0; --g) {
+        double sig = 1.0;  // "not_jump_prob" of the reference: sigma_g, or 1 at the last grid
+        if (g < G - 1) {
+            float etn[4] = {0.f, 0.f, 0.f, 0.f};  // table of grid g (the emission side of iteration g-1)
+            if (g > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (t + r * NT < prm.nrow) etn[r] = emat[(size_t)g * kMaxRow + t + r * NT];
+            }
+            sig = prm.sigma[g];
+            const float *et = etab + ((g + 1) & 1) * kMaxRow;
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+                    b[j][i] *= et[code];
+                }
+            }
+            if (prm.sp_off[g + 2] > prm.sp_off[g + 1]) apply_special_emissions<NCH>(b, dh, prm, esp, g + 1, NT, t);
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; j++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) psum += b[j][i];
+            // codes of grid g: histogram side below (dosage passes), emission side of the next iteration.
+            // Issued here, after the last use of grid g+1's codes, so one register set serves both.
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const int k0 = (j * NT + t) * 16;
+                if (k0 < K) dh[j] = *reinterpret_cast<const uint4 *>(prm.hm + (size_t)g * prm.Kp + k0);
+            }
+            // buffer (g & 1) was last read in iteration g + 1, before that iteration's barrier
+            if (g > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (t + r * NT < kMaxRow) etab[(g & 1) * kMaxRow + t + r * NT] = etn[r];
+            }
+            const double S = block_sum((double)psum, red + (g & 1) * 16, t, nwaves);
+            const float add = (float)((1.0 - sig) / (double)K / sig * S);
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const int k0 = (j * NT + t) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    b[j][i] += add;
+                    if (k0 + 16 > K && k0 + i >= K) b[j][i] = 0.f;
+                }
+            }
+        }
+
+        if (g == G - 1) {
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const int k0 = (j * NT + t) * 16;
+                if (k0 < K) dh[j] = *reinterpret_cast<const uint4 *>(prm.hm + (size_t)g * prm.Kp + k0);
+            }
+        }
+        const int tcol = prm.thin_col[g];
+        const int sl = store_all ? g : slot[g];
+        const bool need_gamma = (want_dosage || want_gamma) && sl >= 0;
+        if (need_gamma) {
+            const float4 *src = ain + (size_t)sl * col_vecs;
+            const bool has_sp = prm.sp_off[g + 1] > prm.sp_off[g];
+            float *h = hist + (g & 1) * kMaxRow * kHistCopies;
+            const float fs = (float)sig;
+            // alpha is streamed through a 2-chunk register pipeline: chunk j+1 is in flight while chunk
+            // j is consumed (holding all 16 * NCH values would double the register footprint)
+            float4 av[2][4];
+            if (t * 16 < K) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) av[0][q] = src[alpha_vec_index(0, q, NT, t)];
+            }
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                const int k0 = (j * NT + t) * 16;
+                if (j + 1 < NCH && ((j + 1) * NT + t) * 16 < K) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) av[(j + 1) & 1][q] = src[alpha_vec_index(j + 1, q, NT, t)];
+                }
+                if (k0 < K) {
+                    const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+                    int sp_at = 0;
+                    if (want_dosage && has_sp && any_zero_code(dh[j]))
+                        sp_at = special_lower_bound(prm.sp_k, prm.sp_off[g], prm.sp_off[g + 1], k0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 a4 = av[j & 1][q];
+                        const float al[4] = {a4.x, a4.y, a4.z, a4.w};
+                        float gq[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int i = 4 * q + r;
+                            const float gk = al[r] * b[j][i];  // 0 beyond K: b is 0 there
+                            gq[r] = gk;
+                            if (want_dosage) {
+                                const uint32_t code = (w[q] >> (r * 8)) & 0xffu;
+                                atomicAdd(&h[code * kHistCopies + (lane & 31)], gk);
+                                if (has_sp && code == 0 && k0 + i < K) {
+                                    // gamma of a special haplotype goes to its own list (:2096-2128)
+                                    prm.gsp[(size_t)p * prm.n_special + sp_at] = gk;
+                                    sp_at++;
+                                }
+                            }
+                        }
+                        if (want_gamma) {
+                            float4 *dst = reinterpret_cast<float4 *>(prm.gamma_out) + ((size_t)p * G + g) * col_vecs;
+                            dst[alpha_vec_index(j, q, NT, t)] = make_float4(gq[0] * fs, gq[1] * fs, gq[2] * fs, gq[3] * fs);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (want_dosage) {
+                __syncthreads();
+                // fold the 32 bank-private copies (one half-wave per code), re-zeroing as we go
+                float *mgo = prm.mg + ((size_t)p * G + g) * kMaxRow;
+                for (int base = 0; base < prm.nrow; base += 2 * nwaves) {
+                    const int code = base + 2 * (t >> 6) + (lane >> 5);
+                    float v = 0.f;
+                    if (code < prm.nrow) {
+                        v = h[code * kHistCopies + (lane & 31)];
+                        h[code * kHistCopies + (lane & 31)] = 0.f;
+                    }
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if (code < prm.nrow && (lane & 31) == 0) mgo[code] = v;
+                }
+            }
+        }
+        if (tcol >= 0 && prm.beta_thin) {
+            // thinned grid: hand the (unscaled) beta column to k_topk, which forms gamma = alpha * beta
+            // and picks the top matches off the serial path (:2020-2031)
+            float4 *dst = reinterpret_cast<float4 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                if ((j * NT + t) * 16 >= K) continue;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    dst[alpha_vec_index(j, q, NT, t)] =
+                        make_float4(b[j][4 * q], b[j][4 * q + 1], b[j][4 * q + 2], b[j][4 * q + 3]);
+            }
+        }
+        // beta *= c_g * sigma_g   (:2165-2166)
+        const float x = (float)(cvec[g] * sig);
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) b[j][i] *= x;
+        }
+        if (want_beta) {
+            float4 *dst = reinterpret_cast<float4 *>(prm.beta_out) + ((size_t)p * G + g) * col_vecs;
+#pragma unroll
+            for (int j = 0; j < NCH; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    dst[alpha_vec_index(j, q, NT, t)] =
+                        make_float4(b[j][4 * q], b[j][4 * q + 1], b[j][4 * q + 2], b[j][4 * q + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// k_topk: best haplotypes at one thinned grid of one pass (reference-single.cpp:129-194, :2020-2031).
+// threshold = K_top-th largest gamma counted with multiplicity; every k with gamma >= threshold is
+// reported with gamma * not_jump_prob.  One block per (thinned column, pass); alpha and beta columns
+// are in the same lane-interleaved order, so gamma is an elementwise product of two coalesced streams.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
+    const int tcol = blockIdx.x, p = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    __shared__ float s_top[4][kMaxTop];
+    __shared__ int s_cnt;
+    __shared__ int s_g;
+    if (t == 0) {
+        s_cnt = 0;
+        int g = 0;
+        for (int i = 0; i < prm.G; i++) if (prm.thin_col[i] == tcol) g = i;
+        s_g = g;
+    }
+    __syncthreads();
+    const int g = s_g;
+    const int flags = prm.flags[p];
+    const int sl = (flags & 15) ? g : prm.alpha_slot[(size_t)p * prm.G + g];
+    const size_t col_vecs = (size_t)prm.Kq / 4;
+    const float4 *av = reinterpret_cast<const float4 *>(prm.alpha + (size_t)p * prm.alpha_pass_stride) + (size_t)sl * col_vecs;
+    const float4 *bv = reinterpret_cast<const float4 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
+    const int Ktop = prm.K_top;
+    const int nvec = prm.Kq / 4;
+    float ltop[kMaxTop];
+#pragma unroll
+    for (int q = 0; q < kMaxTop; q++) ltop[q] = 0.f;
+    auto k_of = [&](int v, int r) {
+        const int j = v / (NT * 4), rem = v % (NT * 4);
+        const int tt = (rem >> 8) * 64 + (rem & 63), q = (rem >> 6) & 3;
+        return (j * NT + tt) * 16 + 4 * q + r;
+    };
+    for (int v = t; v < nvec; v += 256) {
+        if (k_of(v, 0) >= prm.K) continue;
+        const float4 a4 = av[v], b4 = bv[v];
+        const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float x = (k_of(v, r) < prm.K) ? gq[r] : 0.f;
+#pragma unroll
+            for (int z = 0; z < kMaxTop; z++) {
+                if (z < Ktop) {
+                    const float hi = fmaxf(ltop[z], x);
+                    x = fminf(ltop[z], x);
+                    ltop[z] = hi;
+                }
+            }
+        }
+    }
+    // wave merge: pop the maximum Ktop times
+    for (int r = 0; r < Ktop; r++) {
+        const float m = wave_max(ltop[0]);
+        const unsigned long long owners = __ballot(ltop[0] == m);
+        const int first = __ffsll((long long)owners) - 1;
+        if (lane == first) {
+#pragma unroll
+            for (int q = 0; q < kMaxTop - 1; q++) ltop[q] = ltop[q + 1];
+            ltop[kMaxTop - 1] = 0.f;
+        }
+        if (lane == 0) s_top[t >> 6][r] = m;
+    }
+    __syncthreads();
+    float thr = 0.f;
+    {
+        float head = 0.f;
+        int pos = 0;
+        if (lane < 4) head = s_top[lane][0];
+        for (int r = 0; r < Ktop; r++) {
+            const float m = wave_max(head);
+            thr = m;
+            const unsigned long long owners = __ballot(lane < 4 && head == m);
+            const int first = __ffsll((long long)owners) - 1;
+            if (lane == first) {
+                pos++;
+                head = (pos < Ktop) ? s_top[lane][pos] : 0.f;
+            }
+        }
+    }
+    const float fs = (g < prm.G - 1) ? (float)prm.sigma[g] : 1.f;
+    int32_t *oi = prm.top_idx + ((size_t)p * prm.n_thin + tcol) * prm.top_cap;
+    float *ov = prm.top_val + ((size_t)p * prm.n_thin + tcol) * prm.top_cap;
+    for (int v = t; v < nvec; v += 256) {
+        if (k_of(v, 0) >= prm.K) continue;
+        const float4 a4 = av[v], b4 = bv[v];
+        const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int kk = k_of(v, r);
+            if (kk < prm.K && gq[r] >= thr) {
+                const int at = atomicAdd(&s_cnt, 1);
+                if (at < prm.top_cap) { oi[at] = kk; ov[at] = gq[r] * fs; }
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) prm.top_cnt[(size_t)p * prm.n_thin + tcol] = s_cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dosage: dosage[32g + b] = sigma_g * ( sum_d IE[d, 32g+b] * mg[d] + sum_specials gamma * (bit ? 1-eps : eps) )
+// (reference-single.cpp:2092-2139).  One block of 32 x 8 threads per (grid, pass).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
+    const int g = blockIdx.x, p = blockIdx.y;
+    if (!(prm.flags[p] & 1)) return;
+    const int b = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts
+    __shared__ double s_acc[8][32];
+    const int s = 32 * g;
+    const int nLocal = min(32, prm.T - s);
+    const float *mg = prm.mg + ((size_t)p * prm.G + g) * kMaxRow;
+    const double eps = prm.ref_error, ome = 1.0 - eps;
+    double acc = 0;
+    if (b < nLocal) {
+        for (int d = 1 + part; d < prm.nrow; d += 8) {
+            double ie;
+            if (prm.IE) {
+                ie = prm.IE[(size_t)(s + b) * prm.nMaxDH + (d - 1)];
+            } else {
+                const uint32_t w = (uint32_t)prm.B[(size_t)g * prm.nMaxDH + (d - 1)];
+                ie = ((w >> b) & 1u) ? ome : eps;
+            }
+            acc += ie * (double)mg[d];
+        }
+        const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
+        for (int i = part; i < sn; i += 8) {
+            const double gk = (double)prm.gsp[(size_t)p * prm.n_special + so + i];
+            acc += gk * (((prm.sp_word[so + i] >> b) & 1u) ? ome : eps);
+        }
+    }
+    s_acc[part][b] = acc;
+    __syncthreads();
+    if (part == 0 && b < nLocal) {
+        double tot = 0;
+        for (int q = 0; q < 8; q++) tot += s_acc[q][b];
+        const double sig = (g < prm.G - 1) ? prm.sigma[g] : 1.0;
+        prm.dosage[(size_t)p * prm.T + s + b] = tot * sig;
+    }
+}
+
+// un-permute a lane-interleaved [cols][Kq] float matrix into a K x cols double matrix (column-major)
+__global__ void k_unpermute(const float *src, double *dst, int K, int Kq, int NT, int cols, size_t dst_ld) {
+    const int col = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K || col >= cols) return;
+    const int chunk = k >> 4, e = k & 15;
+    const int j = chunk / NT, t = chunk % NT;
+    const size_t vec = (size_t)j * NT * 4 + (size_t)((t >> 6) * 4 + (e >> 2)) * 64 + (t & 63);
+    dst[(size_t)col * dst_ld + k] = (double)src[(size_t)col * Kq + vec * 4 + (e & 3)];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct qa_panel::Scratch {
+    qa::DBuf<double> gl, c, dosage, escale0;
+    qa::DBuf<float> emat, esp, alpha, mg, gsp, gamma, beta, beta_thin, top_val;
+    qa::DBuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
+    qa::DBuf<double> unperm;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~Scratch() {
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+qa_panel::~qa_panel() {
+    delete scratch;
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+namespace {
+
+thread_local double g_timing[5] = {0, 0, 0, 0, 0};
+
+struct Geometry { int NT, NCH; };
+
+// Register-resident geometry: NT threads (multiple of 64, <= 512 so that each wave may use 256
+// VGPRs) x NCH chunks of 16 haplotypes per lane.  The smallest NCH that covers K gives the most
+// waves; tiny panels still get >= 2 chunks per lane for ILP.
+constexpr int kNchList[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
+Geometry pick_geometry(int K) {
+    const int chunks = (K + 15) / 16;
+    for (int nch : kNchList) {
+        int nt = (chunks + nch - 1) / nch;
+        nt = std::max((nt + 63) / 64 * 64, 64);
+        if (nt > 512) continue;
+        if (nch == 1 && chunks > 128) continue;
+        return {nt, nch};
+    }
+    return {0, 0};
+}
+
+template <int NCH, int MAXT>
+void launch_fb(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
+    const size_t lds_f = 2 * kMaxRow * 4 + 2 * 16 * 8;
+    const size_t lds_b = lds_f + (size_t)2 * kMaxRow * kHistCopies * 4;
+    hipLaunchKernelGGL((k_fwd<NCH, MAXT>), dim3(prm.P), dim3(NT), lds_f, s, prm);
+    QA_HIP(hipGetLastError());
+    QA_HIP(hipEventRecord(e_mid, s));
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd<NCH, MAXT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    hipLaunchKernelGGL((k_bwd<NCH, MAXT>), dim3(prm.P), dim3(NT), lds_b, s, prm);
+    QA_HIP(hipGetLastError());
+}
+
+struct BatchOut {
+    double *dosage = nullptr;        // [P][T]
+    double *c = nullptr;             // [P][G]
+    double *alphaHat_t = nullptr;    // single-pass API only
+    double *betaHat_t = nullptr;
+    double *gamma_t = nullptr;
+    double *gammaSmall_t = nullptr;
+    bool gamma_small_unscaled = false;  // gammaSmall_t without return_gamma_t: no sigma factor (:2170-2176)
+    int32_t *best_ptr = nullptr;
+    int32_t *best_idx = nullptr;
+    double *best_val = nullptr;
+    int64_t best_cap = 0;
+};
+
+// runs P passes; flags per pass as in PassParams
+int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, const int32_t *thin_col_h,
+               int K_top, int normalize_emissions, const BatchOut &out) {
+    if (K_top > kMaxTop) {
+        qa::set_error("K_top_matches = %d > %d not supported", K_top, kMaxTop);
+        return QA_ERR_UNSUPPORTED;
+    }
+    const Geometry geo = pick_geometry(pn->K);
+    if (geo.NT == 0) {
+        qa::set_error("K = %d exceeds the register-resident capacity (98304 haplotypes) of the full-pass kernels", pn->K);
+        return QA_ERR_UNSUPPORTED;
+    }
+    QA_HIP(hipSetDevice(pn->device));
+    if (!pn->scratch) pn->scratch = new qa_panel::Scratch();
+    auto &S = *pn->scratch;
+    hipStream_t st = pn->stream;
+    for (auto &e : S.ev) if (!e) QA_HIP(hipEventCreate(&e));
+    const int G = pn->G, T = pn->T, K = pn->K;
+    const int Kq = geo.NT * geo.NCH * 16;
+    int n_thin = 0;
+    for (int g = 0; g < G; g++) if (thin_col_h[g] >= 0) n_thin = std::max(n_thin, thin_col_h[g] + 1);
+
+    // alpha checkpoint slots: all grids for dosage / gamma / beta passes, thinned grids otherwise
+    std::vector<int32_t> slot((size_t)P * G, -1);
+    size_t max_cols = 0;
+    bool any_gamma = false, any_beta = false;
+    for (int p = 0; p < P; p++) {
+        const int f = h_flags[p];
+        size_t cols;
+        if (f & 15) {
+            for (int g = 0; g < G; g++) slot[(size_t)p * G + g] = g;
+            cols = G;
+        } else {
+            int n = 0;
+            for (int g = 0; g < G; g++) if (thin_col_h[g] >= 0) slot[(size_t)p * G + g] = n++;
+            cols = std::max(n, 1);
+        }
+        max_cols = std::max(max_cols, cols);
+        any_gamma |= (f & 4) != 0;
+        any_beta |= (f & 8) != 0;
+    }
+    const bool any_top = n_thin > 0 && K_top > 0;
+    const size_t alpha_stride = max_cols * (size_t)Kq;
+
+    S.gl.ensure((size_t)P * T * 2);
+    S.gl.upload(gl, (size_t)P * T * 2, st);
+    S.thin_col.ensure(G);
+    S.thin_col.upload(thin_col_h, G, st);
+    S.flags.ensure(P);
+    S.flags.upload(h_flags, P, st);
+    S.alpha_slot.ensure((size_t)P * G);
+    S.alpha_slot.upload(slot.data(), (size_t)P * G, st);
+    S.emat.ensure((size_t)P * G * kMaxRow);
+    S.escale0.ensure(P);
+    S.esp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1));
+    S.gsp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1));
+    S.alpha.ensure((size_t)P * alpha_stride);
+    S.c.ensure((size_t)P * G);
+    S.mg.ensure((size_t)P * G * kMaxRow);
+    S.dosage.ensure((size_t)P * T);
+    if (any_gamma) S.gamma.ensure((size_t)P * G * Kq);
+    if (any_beta) S.beta.ensure((size_t)P * G * Kq);
+    if (any_top) S.beta_thin.ensure((size_t)P * n_thin * Kq);
+    int top_cap = 64;
+    S.top_cnt.ensure(std::max<size_t>((size_t)P * std::max(n_thin, 1), 1));
+
+    PassParams prm{};
+    prm.hm = pn->hm.p; prm.B = pn->B.p; prm.sp_off = pn->sp_off.p; prm.sp_k = pn->sp_k.p;
+    prm.sp_word = pn->sp_word.p; prm.sigma = pn->sigma.p; prm.IE = pn->ie_derived ? nullptr : pn->IE.p;
+    prm.K = K; prm.Kp = pn->Kp; prm.G = G; prm.T = T; prm.nMaxDH = pn->nMaxDH; prm.nrow = pn->nrow;
+    prm.n_special = pn->n_special; prm.ref_error = pn->ref_error;
+    prm.P = P; prm.gl = S.gl.p; prm.thin_col = S.thin_col.p; prm.n_thin = n_thin; prm.flags = S.flags.p;
+    prm.normalize_emissions = normalize_emissions;
+    prm.emat = S.emat.p; prm.esp = S.esp.p; prm.escale0 = S.escale0.p; prm.alpha = S.alpha.p; prm.alpha_slot = S.alpha_slot.p;
+    prm.alpha_pass_stride = alpha_stride; prm.Kq = Kq; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;
+    prm.gamma_out = any_gamma ? S.gamma.p : nullptr; prm.beta_out = any_beta ? S.beta.p : nullptr;
+    prm.dosage = S.dosage.p; prm.K_top = any_top ? K_top : 0;
+    prm.beta_thin = any_top ? S.beta_thin.p : nullptr;
+
+    QA_HIP(hipEventRecord(S.ev[0], st));
+    hipLaunchKernelGGL(k_emat, dim3(G, P), dim3(256), 0, st, prm);
+    QA_HIP(hipGetLastError());
+    QA_HIP(hipEventRecord(S.ev[1], st));
+    switch (geo.NCH) {
+#ifndef QA_FAST_BUILD
+        case 1: launch_fb<1, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 3: launch_fb<3, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 4: launch_fb<4, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 5: launch_fb<5, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 6: launch_fb<6, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 8: launch_fb<8, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 10: launch_fb<10, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 12: launch_fb<12, 512>(prm, geo.NT, st, S.ev[2]); break;
+#endif
+        case 2: launch_fb<2, 512>(prm, geo.NT, st, S.ev[2]); break;
+        case 7: launch_fb<7, 512>(prm, geo.NT, st, S.ev[2]); break;
+        default: throw std::runtime_error("geometry not built");
+    }
+    QA_HIP(hipEventRecord(S.ev[3], st));
+    hipLaunchKernelGGL(k_dosage, dim3(G, P), dim3(256), 0, st, prm);
+    QA_HIP(hipGetLastError());
+    std::vector<int32_t> cnt;
+    for (int attempt = 0; any_top && attempt < 2; attempt++) {
+        prm.top_cap = top_cap;
+        S.top_idx.ensure((size_t)P * n_thin * top_cap);
+        S.top_val.ensure((size_t)P * n_thin * top_cap);
+        prm.top_cnt = S.top_cnt.p; prm.top_idx = S.top_idx.p; prm.top_val = S.top_val.p;
+        hipLaunchKernelGGL(k_topk, dim3(n_thin, P), dim3(256), 0, st, prm, geo.NT);
+        QA_HIP(hipGetLastError());
+        cnt.resize((size_t)P * n_thin);
+        S.top_cnt.download(cnt.data(), cnt.size(), st);
+        QA_HIP(hipStreamSynchronize(st));
+        int mx = 0;
+        for (int32_t v : cnt) mx = std::max(mx, v);
+        if (mx <= top_cap) break;
+        top_cap = mx;  // pathological ties (e.g. a label without reads): redo with room for all
+    }
+    QA_HIP(hipEventRecord(S.ev[4], st));
+    QA_HIP(hipStreamSynchronize(st));
+    float ms;
+    for (int i = 0; i < 4; i++) {
+        QA_HIP(hipEventElapsedTime(&ms, S.ev[i], S.ev[i + 1]));
+        g_timing[i] = ms;
+    }
+    QA_HIP(hipEventElapsedTime(&ms, S.ev[0], S.ev[4]));
+    g_timing[4] = ms;
+
+    // ---- copy results back
+    if (out.c) S.c.download(out.c, (size_t)P * G, st);
+    if (out.dosage) {
+        for (int p = 0; p < P; p++)
+            if (h_flags[p] & 1)
+                QA_HIP(hipMemcpyAsync(out.dosage + (size_t)p * T, S.dosage.p + (size_t)p * T, sizeof(double) * T,
+                                      hipMemcpyDeviceToHost, st));
+    }
+    auto unpermute_to_host = [&](const float *src, int cols, double *dst) {
+        S.unperm.ensure((size_t)K * cols);
+        hipLaunchKernelGGL(k_unpermute, dim3((K + 255) / 256, cols), dim3(256), 0, st, src, S.unperm.p, K, Kq,
+                           geo.NT, cols, (size_t)K);
+        QA_HIP(hipGetLastError());
+        S.unperm.download(dst, (size_t)K * cols, st);
+        QA_HIP(hipStreamSynchronize(st));
+    };
+    if (P == 1) {
+        if (out.alphaHat_t) {
+            if (h_flags[0] & 15) {
+                unpermute_to_host(S.alpha.p, G, out.alphaHat_t);
+            } else {
+                // only column 0 and the thinned columns exist (reference-single.cpp:2264-2268)
+                std::vector<double> col(K);
+                for (int g = 0; g < G; g++) {
+                    const int sl = slot[g];
+                    if (sl < 0) continue;
+                    unpermute_to_host(S.alpha.p + (size_t)sl * Kq, 1, col.data());
+                    memcpy(out.alphaHat_t + (size_t)g * K, col.data(), sizeof(double) * K);
+                }
+            }
+        }
+        if (out.gamma_t && any_gamma) unpermute_to_host(S.gamma.p, G, out.gamma_t);
+        if (out.betaHat_t && any_beta) unpermute_to_host(S.beta.p, G, out.betaHat_t);
+        if (out.gammaSmall_t && any_gamma) {
+            std::vector<double> col(K);
+            for (int g = 0; g < G; g++) {
+                if (thin_col_h[g] < 0) continue;
+                unpermute_to_host(S.gamma.p + (size_t)g * Kq, 1, col.data());
+                if (out.gamma_small_unscaled && g < G - 1)
+                    for (int k = 0; k < K; k++) col[k] /= pn->h_sigma[g];
+                memcpy(out.gammaSmall_t + (size_t)thin_col_h[g] * K, col.data(), sizeof(double) * K);
+            }
+        }
+    }
+    int status = QA_OK;
+    if (any_top && out.best_ptr) {
+        const size_t n = (size_t)P * n_thin;
+        std::vector<int32_t> idx(n * top_cap);
+        std::vector<float> val(n * top_cap);
+        S.top_idx.download(idx.data(), idx.size(), st);
+        S.top_val.download(val.data(), val.size(), st);
+        QA_HIP(hipStreamSynchronize(st));
+        int64_t total = 0;
+        out.best_ptr[0] = 0;
+        for (size_t i = 0; i < n; i++) {
+            total += cnt[i];
+            out.best_ptr[i + 1] = (int32_t)total;
+        }
+        if (total > out.best_cap || !out.best_idx || !out.best_val) {
+            qa::set_error("best-haps capacity %lld < needed %lld", (long long)out.best_cap, (long long)total);
+            status = QA_ERR_CAPACITY;
+        } else {
+            std::vector<std::pair<int32_t, float>> tmp;
+            for (size_t i = 0; i < n; i++) {
+                tmp.clear();
+                for (int q = 0; q < cnt[i]; q++) tmp.emplace_back(idx[i * top_cap + q], val[i * top_cap + q]);
+                std::sort(tmp.begin(), tmp.end());  // ascending k, the reference's emission order
+                int32_t *oi = out.best_idx + out.best_ptr[i];
+                double *ov = out.best_val + out.best_ptr[i];
+                for (size_t q = 0; q < tmp.size(); q++) { oi[q] = tmp[q].first; ov[q] = (double)tmp[q].second; }
+            }
+        }
+    }
+    QA_HIP(hipStreamSynchronize(st));
+    return status;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qa_last_fullpass_timing_ms(double out[5]) {
+    if (!out) return QA_ERR_INVALID;
+    for (int i = 0; i < 5; i++) out[i] = g_timing[i];
+    return QA_OK;
+}
+
+int qa_Rcpp_haploid_dosage_versus_refs(
+    qa_panel_t *panel, const double *gl, const int32_t *gammaSmall_cols_to_get,
+    const qa_fullpass_opts_t *o, double *alphaHat_t, double *betaHat_t, double *c, double *gamma_t,
+    double *gammaSmall_t, double *dosage, int32_t *best_ptr, int32_t *best_idx, double *best_val,
+    int64_t best_cap) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!panel || !gl || !o || !gammaSmall_cols_to_get) {
+        qa::set_error("qa_Rcpp_haploid_dosage_versus_refs: null argument");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        const int G = panel->G;
+        std::vector<int32_t> thin(G, -1);
+        const bool use_thin = o->get_best_haps_from_thinned_sites || o->return_gammaSmall_t;
+        if (use_thin) for (int g = 0; g < G; g++) thin[g] = gammaSmall_cols_to_get[g];
+        int32_t f = 0;
+        if (o->return_dosage) f |= 1;
+        // reference-single.cpp:2264-2268: alpha is kept everywhere unless only thinned outputs are wanted
+        const bool only_thin = use_thin && !o->return_gamma_t && !o->return_dosage && !o->return_betaHat_t;
+        if (!only_thin) f |= 2;
+        if (o->return_gamma_t || o->return_gammaSmall_t) f |= 4;
+        if (o->return_betaHat_t) f |= 8;
+        BatchOut out;
+        out.dosage = o->return_dosage ? dosage : nullptr;
+        out.c = c;
+        out.alphaHat_t = alphaHat_t;
+        out.betaHat_t = o->return_betaHat_t ? betaHat_t : nullptr;
+        out.gamma_t = o->return_gamma_t ? gamma_t : nullptr;
+        out.gammaSmall_t = o->return_gammaSmall_t ? gammaSmall_t : nullptr;
+        out.gamma_small_unscaled = !o->return_gamma_t;
+        if (o->get_best_haps_from_thinned_sites) {
+            out.best_ptr = best_ptr; out.best_idx = best_idx; out.best_val = best_val; out.best_cap = best_cap;
+        }
+        return run_passes(panel, 1, gl, &f, thin.data(),
+                          o->get_best_haps_from_thinned_sites ? o->K_top_matches : 0, o->normalize_emissions, out);
+    });
+}
+
+int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const int32_t *want_dosage,
+                      const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double *dosage,
+                      int32_t *best_ptr, int32_t *best_idx, double *best_val, int64_t best_cap) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!panel || !gl || n_pass <= 0 || !want_dosage || !gammaSmall_cols_to_get) {
+        qa::set_error("qa_fullpass_batch: bad argument");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        std::vector<int32_t> f(n_pass);
+        for (int i = 0; i < n_pass; i++) f[i] = want_dosage[i] ? 1 : 0;
+        BatchOut out;
+        out.dosage = dosage;
+        out.best_ptr = best_ptr; out.best_idx = best_idx; out.best_val = best_val; out.best_cap = best_cap;
+        return run_passes(panel, n_pass, gl, f.data(), gammaSmall_cols_to_get, K_top_matches, 1, out);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// panel.hip -- library state, error reporting and panel upload.
+#include "panel.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+namespace qa {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+static int usable_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+bool device_ready() {
+    static thread_local int cached = -1;
+    if (cached < 0) cached = usable_devices() > 0 ? 1 : 0;
+    if (!cached) set_error("no usable gfx950 (MI355X) device: libquilt_amd has no CPU fallback");
+    return cached == 1;
+}
+
+// the reference's clamped halving search over rows s1..e1 (1-based) of the special matrix
+// (QUILT/src/gibbs-small.cpp:69-105), quirks included: this is how the device tables inherit
+// exactly the word the reference would decode.
+static int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, int s1, int e1) {
+    int nori = e1 - s1 + 1;
+    if (nori == 1) return 0;
+    int n = nori, i = n / 2;
+    n /= 4;
+    for (int c = 0; c < 100; c++) {
+        int32_t key = mat[s1 - 1 + i];
+        if (key == val) return mat[(size_t)nrow + s1 - 1 + i];
+        i += (key < val) ? n : -n;
+        n = std::max(n / 2, 1);
+        i = std::min(std::max(i, 0), nori - 1);
+    }
+    return mat[(size_t)nrow + s1];
+}
+
+}  // namespace qa
+
+extern "C" {
+
+int qa_abi_version(void) { return 1; }
+
+const char *qa_last_error(void) { return qa::g_err; }
+
+int qa_device_count(void) { return qa::usable_devices(); }
+
+int qa_set_device(int device) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(device));
+        return QA_OK;
+    });
+}
+
+int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
+    if (!out) return QA_ERR_INVALID;
+    *out = nullptr;
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!d || d->K <= 0 || d->nGrids <= 0 || d->nSNPs <= 0 || d->nMaxDH <= 0 || !d->distinctHapsB ||
+        !d->transMatRate_t || !d->eMatDH_special_grid_which || (!d->hapMatcherR && !d->hapMatcher)) {
+        qa::set_error("qa_panel_create: missing panel table");
+        return QA_ERR_INVALID;
+    }
+    if (d->nMaxDH > 255) {
+        qa::set_error("qa_panel_create: nMaxDH = %d > 255 is not supported (hapMatcherR layout only)", d->nMaxDH);
+        return QA_ERR_UNSUPPORTED;
+    }
+    if ((d->nSNPs + 31) / 32 != d->nGrids) {
+        qa::set_error("qa_panel_create: nGrids must be ceil(nSNPs / 32)");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        auto *p = new qa_panel();
+        std::unique_ptr<qa_panel> guard(p);
+        QA_HIP(hipGetDevice(&p->device));
+        QA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        const int K = d->K, G = d->nGrids;
+        p->K = K; p->G = G; p->T = d->nSNPs; p->nMaxDH = d->nMaxDH; p->nrow = d->nMaxDH + 1;
+        p->Kp = (K + 63) / 64 * 64;
+        p->ref_error = d->ref_error;
+        // hapMatcher -> uint8 [G][Kp]
+        p->hm.alloc((size_t)G * p->Kp);
+        p->hm.zero(p->stream);
+        std::vector<uint8_t> tmp;
+        const uint8_t *src = d->hapMatcherR;
+        if (!src) {
+            tmp.resize((size_t)K * G);
+            for (size_t i = 0; i < (size_t)K * G; i++) {
+                int32_t v = d->hapMatcher[i];
+                if (v < 0 || v > 255) throw std::runtime_error("hapMatcher value outside 0..255");
+                tmp[i] = (uint8_t)v;
+            }
+            src = tmp.data();
+        }
+        QA_HIP(hipMemcpy2DAsync(p->hm.p, p->Kp, src, K, K, G, hipMemcpyHostToDevice, p->stream));
+        p->B.alloc((size_t)d->nMaxDH * G);
+        p->B.upload(d->distinctHapsB, (size_t)d->nMaxDH * G, p->stream);
+        // specials
+        std::vector<int32_t> off(G + 1, 0), sk;
+        std::vector<uint32_t> sw;
+        for (int g = 0; g < G; g++) {
+            off[g] = (int32_t)sk.size();
+            if (d->eMatDH_special_grid_which[g] <= 0) continue;
+            if (d->use_eMatDH_special_symbols) {
+                if (!d->eMatDH_special_matrix || !d->eMatDH_special_matrix_helper)
+                    throw std::runtime_error("special symbols requested without the special matrix");
+                int s1 = d->eMatDH_special_matrix_helper[g];
+                int e1 = d->eMatDH_special_matrix_helper[(size_t)G + g];
+                for (int r = s1; r <= e1; r++) {
+                    int k = d->eMatDH_special_matrix[r - 1];
+                    sk.push_back(k);
+                    sw.push_back((uint32_t)qa::reference_matrix_search(
+                        k, d->eMatDH_special_matrix, d->eMatDH_special_matrix_nrow, s1, e1));
+                }
+            } else {
+                if (!d->rhb_t) throw std::runtime_error("special haplotypes need rhb_t or the special matrix");
+                for (int k = 0; k < K; k++) {
+                    if (src[(size_t)K * g + k] == 0) {
+                        sk.push_back(k);
+                        sw.push_back((uint32_t)d->rhb_t[(size_t)K * g + k]);
+                    }
+                }
+            }
+        }
+        off[G] = (int32_t)sk.size();
+        p->n_special = (int)sk.size();
+        p->h_sp_off = off;
+        p->sp_off.alloc(G + 1);
+        p->sp_off.upload(off.data(), G + 1, p->stream);
+        p->sp_k.alloc(std::max<size_t>(sk.size(), 1));
+        p->sp_word.alloc(std::max<size_t>(sw.size(), 1));
+        p->sp_k.upload(sk.data(), sk.size(), p->stream);
+        p->sp_word.upload(sw.data(), sw.size(), p->stream);
+        // transitions
+        p->h_sigma.resize(std::max(G - 1, 1));
+        for (int g = 0; g < G - 1; g++) p->h_sigma[g] = d->transMatRate_t[2 * (size_t)g];
+        p->sigma.alloc(std::max(G - 1, 1));
+        p->sigma.upload(p->h_sigma.data(), std::max(G - 1, 0), p->stream);
+        // distinctHapsIE: by construction (STITCH make_rhb_t_equality) the per-SNP expansion of
+        // distinctHapsB with ref_error / 1 - ref_error.  Verify; keep a device copy only if not.
+        p->ie_derived = true;
+        if (d->distinctHapsIE) {
+            const double lo = d->ref_error, hi = 1 - d->ref_error;
+            for (int t = 0; t < d->nSNPs && p->ie_derived; t++) {
+                int g = t / 32, b = t % 32;
+                for (int r = 0; r < d->nMaxDH; r++) {
+                    uint32_t w = (uint32_t)d->distinctHapsB[(size_t)d->nMaxDH * g + r];
+                    double want = ((w >> b) & 1u) ? hi : lo;
+                    if (d->distinctHapsIE[(size_t)d->nMaxDH * t + r] != want) { p->ie_derived = false; break; }
+                }
+            }
+            if (!p->ie_derived) {
+                p->IE.alloc((size_t)d->nMaxDH * d->nSNPs);
+                p->IE.upload(d->distinctHapsIE, (size_t)d->nMaxDH * d->nSNPs, p->stream);
+            }
+        }
+        QA_HIP(hipStreamSynchronize(p->stream));
+        *out = guard.release();
+        return QA_OK;
+    });
+}
+
+void qa_panel_destroy(qa_panel_t *panel) { delete panel; }
+
+int qa_Rcpp_make_gl_bound(double *gl, double minGLValue, const int32_t *to_fix, int32_t n_to_fix) {
+    // reference-single.cpp:68-94; O(n_to_fix) host arithmetic, not worth a launch
+    if (!gl || (n_to_fix > 0 && !to_fix)) return QA_ERR_INVALID;
+    for (int i = 0; i < n_to_fix; i++) {
+        double *p = gl + 2 * (size_t)to_fix[i];
+        double a = p[0], b = p[1];
+        if (a > b) { b = b / a; a = 1; if (b < minGLValue) b = minGLValue; }
+        else       { a = a / b; b = 1; if (a < minGLValue) a = minGLValue; }
+        p[0] = a; p[1] = b;
+    }
+    return QA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// panel.hpp -- device-resident prepared reference panel.
+#pragma once
+
+#include "common.hpp"
+
+// HBM layout (all resident for the life of the handle):
+//   hm     uint8  [nGrids][Kp]      hapMatcherR, grid-major, haplotypes contiguous, row pitch Kp =
+//                                   K rounded up to 64 B so that every 16-haplotype chunk is one
+//                                   aligned 16-byte load (K=50 000, G=2 000: 100 MB)
+//   B      int32  [nGrids][nMaxDH]  distinctHapsB (same bytes as R's nMaxDH x nGrids matrix)
+//   sp_*   CSR over grids of the "special" haplotypes (hapMatcher == 0): ascending k and the 32-bit
+//          word the reference would decode for it
+//   sigma  double [nGrids-1]        transMatRate_t row 0
+struct qa_panel {
+    int K = 0, G = 0, T = 0, nMaxDH = 0, nrow = 0;  // nrow = nMaxDH + 1
+    int Kp = 0;
+    double ref_error = 0;
+    int device = 0;
+    qa::DBuf<uint8_t> hm;
+    qa::DBuf<int32_t> B;
+    qa::DBuf<int32_t> sp_off;   // G + 1
+    qa::DBuf<int32_t> sp_k;     // n_special
+    qa::DBuf<uint32_t> sp_word; // n_special
+    qa::DBuf<double> sigma;     // G - 1
+    qa::DBuf<double> IE;        // only when the caller's distinctHapsIE is not the (B, eps) expansion
+    bool ie_derived = true;
+    int n_special = 0;
+    std::vector<double> h_sigma;
+    std::vector<int32_t> h_sp_off;
+    hipStream_t stream = nullptr;
+    // scratch owned by the panel handle, grown on demand (see fullpass.hip)
+    struct Scratch;
+    Scratch *scratch = nullptr;
+    ~qa_panel();
+};

@@ -1,0 +1,128 @@
+"""Loader of ``libquilt_amd.so`` (the C-ABI HIP library) -- there is no fallback.
+
+If the shared library is missing or no gfx950 device is visible, every compute entry point
+raises: the product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libquilt_amd.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "quilt_amd.h")
+
+QA_OK = 0
+QA_UNDERFLOW = 1
+QA_ERR_NO_DEVICE = -1
+QA_ERR_INVALID = -2
+QA_ERR_UNSUPPORTED = -3
+QA_ERR_HIP = -4
+QA_ERR_CAPACITY = -5
+
+
+class QuiltAmdError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libquilt_amd status {status}: {message}")
+        self.status = status
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QuiltAmdError(QA_ERR_NO_DEVICE, f"{LIB_PATH} is missing: run quilt_amd.native.build() "
+                                "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.qa_last_error.restype = C.c_char_p
+        for name in ("qa_abi_version", "qa_device_count", "qa_set_device", "qa_panel_create",
+                     "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
+                     "qa_last_fullpass_timing_ms"):
+            getattr(L, name).restype = C.c_int
+        L.qa_panel_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> int:
+    if status < 0:
+        raise QuiltAmdError(status, lib().qa_last_error().decode())
+    return status
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class PanelDesc(C.Structure):
+    _fields_ = [
+        ("K", C.c_int32), ("nGrids", C.c_int32), ("nSNPs", C.c_int32), ("nMaxDH", C.c_int32),
+        ("hapMatcherR", C.c_void_p), ("hapMatcher", C.c_void_p), ("rhb_t", C.c_void_p),
+        ("distinctHapsB", C.c_void_p), ("distinctHapsIE", C.c_void_p),
+        ("eMatDH_special_grid_which", C.c_void_p), ("eMatDH_special_matrix_helper", C.c_void_p),
+        ("eMatDH_special_matrix", C.c_void_p), ("eMatDH_special_matrix_nrow", C.c_int32),
+        ("use_eMatDH_special_symbols", C.c_int32), ("transMatRate_t", C.c_void_p),
+        ("ref_error", C.c_double),
+    ]
+
+
+class FullpassOpts(C.Structure):
+    _fields_ = [
+        ("K_top_matches", C.c_int32), ("return_betaHat_t", C.c_int32), ("return_dosage", C.c_int32),
+        ("return_gamma_t", C.c_int32), ("return_gammaSmall_t", C.c_int32),
+        ("get_best_haps_from_thinned_sites", C.c_int32), ("always_normalize", C.c_int32),
+        ("normalize_emissions", C.c_int32), ("min_emission_prob_normalization_threshold", C.c_double),
+        ("suppressOutput", C.c_int32),
+    ]
+
+
+class DevicePanel:
+    """Device-resident copy of a :class:`quilt_amd.panel.Panel` (upload once per process)."""
+
+    def __init__(self, panel, use_eMatDH_special_symbols=None):
+        self.panel = panel
+        if use_eMatDH_special_symbols is None:
+            use_eMatDH_special_symbols = panel.rhb_t is None
+        d = PanelDesc(
+            panel.K, panel.nGrids, panel.nSNPs, panel.nMaxDH,
+            ptr(panel.hapMatcherR), ptr(panel.hapMatcher), ptr(panel.rhb_t),
+            ptr(panel.distinctHapsB), ptr(panel.distinctHapsIE),
+            ptr(panel.eMatDH_special_grid_which), ptr(panel.eMatDH_special_matrix_helper),
+            ptr(panel.eMatDH_special_matrix), int(panel.eMatDH_special_matrix.shape[0]),
+            int(bool(use_eMatDH_special_symbols)), ptr(panel.transMatRate_t), float(panel.ref_error))
+        h = C.c_void_p()
+        check(lib().qa_panel_create(C.byref(d), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().qa_panel_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def last_fullpass_timing_ms():
+    out = (C.c_double * 5)()
+    check(lib().qa_last_fullpass_timing_ms(out))
+    return dict(emat=out[0], forward=out[1], backward=out[2], dosage=out[3], total=out[4])

@@ -1,0 +1,135 @@
+"""GPU parity: HIP full-panel forward/backward (through the C ABI) vs the fp64 CPU oracle.
+
+Tolerances (stated, fp32 device state vs fp64 oracle): dosage |diff| <= 2e-4 and r2 >= 0.99999;
+colSums(gamma) = 1 +- 1e-4; sum(log c) relative 1e-5; top-match values relative 2e-4.
+"""
+import numpy as np
+import pytest
+
+from tests.util import check_best_haps, label_gl, r2, thin_cols
+
+pytestmark = pytest.mark.gpu
+
+DOSAGE_ATOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _run_gpu(dev, gl, cols, **kw):
+    from quilt_amd.reference_single import Rcpp_haploid_dosage_versus_refs
+    P = dev.panel
+    K, G, T = P.K, P.nGrids, P.nSNPs
+    n_thin = int((cols >= 0).sum())
+    out = dict(alphaHat_t=np.zeros((K, G), order="F"), c=np.ones(G), dosage=np.zeros(T),
+               best_haps_stuff_list=[None] * n_thin)
+    if kw.get("return_gamma_t"):
+        out["gamma_t"] = np.zeros((K, G), order="F")
+    if kw.get("return_betaHat_t"):
+        out["betaHat_t"] = np.zeros((K, G), order="F")
+    if kw.get("return_gammaSmall_t"):
+        out["gammaSmall_t"] = np.zeros((K, n_thin), order="F")
+    kw.setdefault("return_gamma_t", False)
+    kw.setdefault("return_betaHat_t", False)
+    Rcpp_haploid_dosage_versus_refs(dev, gl, gammaSmall_cols_to_get=cols, **out, **kw)
+    return out
+
+
+@pytest.mark.parametrize("panel_name,symbols", [("small_panel", False), ("small_panel", True),
+                                                ("ragged_panel", False), ("ragged_panel", True),
+                                                ("medium_panel", False)])
+def test_dosage_pass_matches_oracle(request, oracle, panel_name, symbols):
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = request.getfixturevalue(panel_name)
+    dev = DevicePanel(panel, use_eMatDH_special_symbols=symbols)
+    sample = make_synthetic_sample(panel, seed=1001, n_reads=max(40, panel.nSNPs // 4))
+    cols = thin_cols(panel.nGrids)
+    for label in (1, 2):
+        gl = label_gl(panel, sample, label, oracle)
+        ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, return_gamma_t=True, return_betaHat_t=True,
+                                                always_normalize=True, get_best_haps_from_thinned_sites=True,
+                                                use_eMatDH_special_symbols=symbols)
+        got = _run_gpu(dev, gl, cols, return_dosage=True, return_gamma_t=True, return_betaHat_t=True,
+                       get_best_haps_from_thinned_sites=True)
+        assert np.abs(got["dosage"] - ref["dosage"]).max() <= DOSAGE_ATOL
+        assert r2(got["dosage"], ref["dosage"]) >= 0.99999
+        np.testing.assert_allclose(got["gamma_t"].sum(axis=0), 1.0, atol=1e-4)
+        np.testing.assert_allclose(got["gamma_t"], ref["gamma_t"], atol=2e-5, rtol=2e-3)
+        np.testing.assert_allclose(got["alphaHat_t"], ref["alphaHat_t"], atol=1e-6, rtol=2e-3)
+        np.testing.assert_allclose(got["betaHat_t"], ref["betaHat_t"], atol=1e-30, rtol=2e-3)
+        np.testing.assert_allclose(np.log(got["c"]).sum(), np.log(ref["c"]).sum(), rtol=1e-5)
+        np.testing.assert_allclose(got["c"], ref["c"], rtol=1e-4)
+        check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
+    dev.close()
+
+
+def test_thin_pass_matches_oracle(small_panel, oracle):
+    """return_dosage = FALSE: only best-haps at the thinned grids (functions.R:748)."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = small_panel
+    dev = DevicePanel(panel)
+    sample = make_synthetic_sample(panel, seed=5, n_reads=150)
+    cols = thin_cols(panel.nGrids, every=3)
+    gl = label_gl(panel, sample, 1, oracle)
+    ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, return_dosage=False,
+                                            get_best_haps_from_thinned_sites=True)
+    got = _run_gpu(dev, gl, cols, return_dosage=False, get_best_haps_from_thinned_sites=True)
+    check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
+    # alpha only at column 0 and the thinned columns (reference-single.cpp:2264-2268); normalised
+    for g in np.nonzero(cols >= 0)[0]:
+        a = got["alphaHat_t"][:, g]
+        b = ref["alphaHat_t"][:, g]
+        np.testing.assert_allclose(a, b / b.sum(), atol=1e-6, rtol=2e-3)
+    assert np.all(got["alphaHat_t"][:, np.nonzero(cols < 0)[0][1:]] == 0)
+
+
+def test_label_without_reads_returns_all_haplotypes(small_panel, oracle):
+    """gl == 1 everywhere: all gammas tie, every haplotype is a top match (reference-single.cpp:150-151)."""
+    from quilt_amd.native import DevicePanel
+    panel = small_panel
+    dev = DevicePanel(panel)
+    gl = np.ones((2, panel.nSNPs), order="F")
+    cols = thin_cols(panel.nGrids, every=5)
+    got = _run_gpu(dev, gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True)
+    ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, get_best_haps_from_thinned_sites=True)
+    assert np.abs(got["dosage"] - ref["dosage"]).max() <= DOSAGE_ATOL
+    for e in got["best_haps_stuff_list"]:
+        assert len(e["top_matches"]) == panel.K
+
+
+def test_batch_matches_single(medium_panel, oracle):
+    """qa_fullpass_batch: mixed dosage / thin passes in one launch set == one-at-a-time results."""
+    import ctypes as C
+    from quilt_amd.native import DevicePanel, check, lib, ptr
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    cols = thin_cols(panel.nGrids, every=10)
+    n_thin = int((cols >= 0).sum())
+    gls, want = [], []
+    for i in range(6):
+        s = make_synthetic_sample(panel, seed=100 + i, n_reads=1000)
+        gls.append(label_gl(panel, s, 1 + i % 2, oracle))
+        want.append(i % 3 != 0)
+    gl = np.ascontiguousarray(np.stack([np.ascontiguousarray(g.T) for g in gls]))  # [P][T][2]
+    wd = np.array(want, dtype=np.int32)
+    dosage = np.zeros((len(gls), panel.nSNPs))
+    bptr = np.zeros(len(gls) * n_thin + 1, dtype=np.int32)
+    cap = len(gls) * n_thin * 64
+    bidx = np.zeros(cap, dtype=np.int32)
+    bval = np.zeros(cap)
+    check(lib().qa_fullpass_batch(dev.handle, C.c_int32(len(gls)), ptr(gl), ptr(wd), ptr(cols), C.c_int32(5),
+                                  ptr(dosage), ptr(bptr), ptr(bidx), ptr(bval), C.c_int64(cap)))
+    for i, g in enumerate(gls):
+        ref = oracle.haploid_dosage_versus_refs(panel, g, cols, return_dosage=bool(want[i]),
+                                                get_best_haps_from_thinned_sites=True)
+        if want[i]:
+            assert np.abs(dosage[i] - ref["dosage"]).max() <= DOSAGE_ATOL
+        got = [dict(top_matches=bidx[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]],
+                    top_matches_values=bval[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]]) for j in range(n_thin)]
+        check_best_haps(got, ref["best_haps"])
