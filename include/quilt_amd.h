@@ -141,6 +141,63 @@ int qa_fullpass_batch(
  * (copied-from-stitch.cpp:31-45). */
 int qa_last_fullpass_timing_ms(double out[5]);
 
+
+/* ---- small-panel Gibbs read-label sampler -------------------------------- */
+
+/* The scalar arguments and param_list flags of rcpp_forwardBackwardGibbsNIPT that the production
+ * caller varies (QUILT/R/functions.R:2566-2678).  Everything the caller holds constant is fixed at
+ * the reference's production value: S = 1, n_gibbs_starts = 1, priorCurrent_m and
+ * alphaMatCurrent_tc = 1/Ks, use_small_eHapsCurrent_tc = FALSE, calculate_gamma_on_the_fly = TRUE,
+ * pass_in_alphaBeta = TRUE, record_read_set = TRUE, shard_check_every_pair = TRUE,
+ * haploid_gibbs_equal_weighting = TRUE, use_starting_read_labels = TRUE. */
+typedef struct {
+    int32_t Ks;                      /* length(which_haps_to_use) (Ksubset) */
+    double ff;                       /* fetal fraction; 0 = diploid */
+    int32_t sample_is_diploid;
+    int32_t Jmax;                    /* Jmax_local */
+    double maxDifferenceBetweenReads;
+    int32_t rescale_eMatRead_t;
+    int32_t n_gibbs_burn_in_its, n_gibbs_sample_its;
+    const int32_t *block_gibbs_iterations; /* 0-based sweep numbers */
+    int32_t n_block_gibbs_iterations;
+    int32_t perform_block_gibbs, do_shard_block_gibbs;
+    int32_t gibbs_initialize_iteratively;
+    int32_t disable_read_category_usage;
+    double class_sum_cutoff;
+} qa_gibbs_opts_t;
+
+/*
+ * Replaces `_QUILT_rcpp_forwardBackwardGibbsNIPT` (QUILT/src/RcppExports.cpp:966-1105; kernel
+ * QUILT/src/gibbs-nipt.cpp:2395-3307; called from QUILT/R/functions.R:2614-2678), batched over
+ * n_chain independent (sample, Gibbs chain) problems against the same panel.
+ *
+ *   which_haps_to_use_1based  n_chain x Ks (1-based panel rows, as in R)
+ *   read_off                  n_chain + 1: reads of chain c are read_off[c] .. read_off[c+1]-1
+ *   read_ptr                  per chain R_c + 1 offsets (starting at 0) into that chain's bases,
+ *                             chain c's block starts at read_ptr[read_off[c] + c]
+ *   u, bq                     bases of all chains back to back: 0-based SNP index and signed base
+ *                             quality (sampleReads[[r]][[4]] and [[3]]); wif = [[2]] (0-based grid)
+ *   runif_reads               per chain R_c * n_its uniforms, chain c at offset read_off[c] * n_its:
+ *                             what `Rcpp::runif(nReads * n_gibbs_full_its)` returns (gibbs-nipt.cpp:2845)
+ *   first_read                per chain `Rcpp::sample(nReads, 1) - 1` (gibbs-nipt.cpp:2846-2848)
+ *   runif_shard               n_chain x n_block_gibbs_iterations x (nGrids - 1): the
+ *                             `Rcpp::runif(n_blocks - 1)` of each shard pass (gibbs-nipt-block.cpp:2054)
+ *   H                         in: starting read labels (double_list_of_starting_read_labels), 1-based;
+ *                             out: ending labels (double_list_of_ending_read_labels)
+ *   H_class                   out (may be NULL)
+ *   hapProbs_t, genProbs*_t   out, per chain 3 x nSNPs (may be NULL)
+ *   underflow_problem         out per chain (may be NULL); the call returns QA_UNDERFLOW if any is set
+ *   state_out                 NULL, or (n_chain == 1 only) 6 * Ks * nGrids + 3 * nGrids doubles:
+ *                             alphaHat_t1, alphaHat_t2, betaHat_t1, betaHat_t2, eMatGrid_t1, eMatGrid_t2,
+ *                             c1, c2, c3 -- the matrices the reference mutates in place
+ */
+int qa_gibbs_batch(qa_panel_t *panel, const qa_gibbs_opts_t *opts, int32_t n_chain,
+                   const int32_t *which_haps_to_use_1based, const int32_t *read_off,
+                   const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif,
+                   const double *runif_reads, const int32_t *first_read, const double *runif_shard,
+                   int32_t *H, int32_t *H_class, double *hapProbs_t, double *genProbsM_t,
+                   double *genProbsF_t, int32_t *underflow_problem, double *state_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,689 @@
+/*
+ * oracle/gibbs.c -- CPU oracle (TEST INFRASTRUCTURE ONLY; see quilt_oracle.h).
+ *
+ * fp64 restatement, in the reference's operation order, of the small-panel Gibbs
+ * read-label sampler: QUILT/src/gibbs-nipt.cpp (rcpp_forwardBackwardGibbsNIPT and
+ * its helpers), QUILT/src/gibbs-small.cpp (packed-panel emissions and
+ * hapProbs/genProbs), QUILT/src/copied-from-stitch.cpp (haploid forward/backward)
+ * and the shard resampler of QUILT/src/gibbs-nipt-block.cpp, for the production
+ * argument values: S = 1, n_gibbs_starts = 1, priorCurrent_m and
+ * alphaMatCurrent_tc constant 1/Ks, use_small_eHapsCurrent_tc = FALSE,
+ * calculate_gamma_on_the_fly = TRUE, pass_in_alphaBeta = TRUE, record_read_set = TRUE.
+ *
+ * R's RNG cannot be reproduced here; every uniform the reference draws
+ * (gibbs-nipt.cpp:2845-2848, gibbs-nipt-block.cpp:2054) is an INPUT.
+ *
+ * Block Gibbs, diploid (ff = 0, sample_is_diploid): Rcpp_block_gibbs_resampler
+ * (gibbs-nipt-block.cpp:1636-1967) cannot relabel in this mode: c3 is all zero
+ * (gibbs-nipt.cpp:2678 and the !sample_is_diploid guards), so logC_after(2) =
+ * sum(log(c3)) = -inf and "logC_after(2) -= log(c3(g))" is NaN
+ * (gibbs-nipt-block.cpp:1819-1821, :1896-1898); every choice_log_probs entry is
+ * NaN (:661-675), every "chance < cumsum" test fails, ir_chosen stays 0 (:741-752)
+ * and the "No change warranted" branch is taken (:830).  What remains is the
+ * final backward re-run (:1947-1954), which reproduces the beta the sweep already
+ * holds bit for bit.  The oracle therefore treats the diploid block resampler as
+ * the identity and runs the shard resampler (:1975-2355), which is active.
+ * Block Gibbs for ff > 0 (NIPT) is not restated yet: qo_gibbs returns -2 if asked.
+ */
+#include "quilt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- packed-panel read emissions (gibbs-small.cpp:116-265) ----------------- */
+
+static inline int panel_code(const qo_panel_t *p, int k, int g)
+{
+    if (p->hapMatcherR) return p->hapMatcherR[(size_t)p->K * g + k];
+    return p->hapMatcher[(size_t)p->K * g + k];
+}
+
+static uint32_t panel_special_word(const qo_panel_t *p, int k, int g)
+{
+    if (p->use_eMatDH_special_symbols) {
+        int s1 = p->eMatDH_special_matrix_helper[g];
+        int e1 = p->eMatDH_special_matrix_helper[(size_t)p->nGrids + g];
+        return (uint32_t)qo_simple_binary_matrix_search(k, p->eMatDH_special_matrix,
+                                                        p->eMatDH_special_matrix_nrow, s1, e1);
+    }
+    return (uint32_t)p->rhb_t[(size_t)p->K * g + k];
+}
+
+void qo_make_eMatRead_t_for_gibbs_using_objects(
+    const qo_panel_t *p, const int32_t *which_haps_to_use_1based, int Ks, int nReads,
+    const int32_t *read_ptr, const int32_t *u, const int32_t *bq, int rescale_eMatRead_t, int Jmax,
+    double maxDifferenceBetweenReads, double *eMatRead_t /* Ks x nReads, pre-filled (normally 1) */)
+{
+    double pR = 1, pA = 1; /* NB: carried over between reads when bq == 0 (:139-140) */
+    const double d2 = 1 / maxDifferenceBetweenReads;
+    int *codes = (int *)malloc(sizeof(int) * (size_t)Ks);
+    for (int r = 0; r < nReads; r++) {
+        const int32_t *ru = u + read_ptr[r], *rbq = bq + read_ptr[r];
+        int J = read_ptr[r + 1] - read_ptr[r] - 1;
+        double *col = eMatRead_t + (size_t)Ks * r;
+        int g_prev = ru[0] / 32;
+        for (int k = 0; k < Ks; k++) codes[k] = panel_code(p, which_haps_to_use_1based[k] - 1, g_prev);
+        if (J >= Jmax) J = Jmax;
+        for (int j = 0; j <= J; j++) {
+            if (rbq[j] < 0) {
+                double eps = pow(10, (double)rbq[j] / 10);
+                pR = 1 - eps;
+                pA = eps / 3;
+            }
+            if (rbq[j] > 0) {
+                double eps = pow(10, -(double)rbq[j] / 10);
+                pR = eps / 3;
+                pA = 1 - eps;
+            }
+            int g = ru[j] / 32;
+            if (g != g_prev)
+                for (int k = 0; k < Ks; k++) codes[k] = panel_code(p, which_haps_to_use_1based[k] - 1, g);
+            g_prev = g;
+            for (int k = 0; k < Ks; k++) {
+                double e;
+                if (codes[k] > 0) {
+                    e = p->distinctHapsIE[(size_t)p->nMaxDH * ru[j] + (codes[k] - 1)];
+                } else {
+                    uint32_t w = panel_special_word(p, which_haps_to_use_1based[k] - 1, g);
+                    e = ((w >> (ru[j] % 32)) & 1u) ? 1 - p->ref_error : p->ref_error;
+                }
+                col[k] *= (e * pA + (1 - e) * pR);
+            }
+        }
+        if (rescale_eMatRead_t) {
+            double x = 0;
+            for (int k = 0; k < Ks; k++) if (col[k] > x) x = col[k];
+            double d1 = 1 / x;
+            if (isinf(x) || x == 0 || isinf(d1)) { /* the NaN comparisons of :244 are never true */
+                for (int k = 0; k < Ks; k++) col[k] = 1;
+            } else {
+                for (int k = 0; k < Ks; k++) {
+                    col[k] *= d1;
+                    if (col[k] < d2) col[k] = d2;
+                }
+            }
+        }
+    }
+    free(codes);
+}
+
+/* gibbs-nipt.cpp:338-382 */
+void qo_evaluate_read_variability(const double *eMatRead_t, int Ks, int nReads,
+                                  int32_t *number_of_non_1_reads, int32_t *indices_of_non_1_reads,
+                                  int32_t *read_category)
+{
+    const double thresh = 1 - pow(10, -12);
+    const int thresh2 = (int)(Ks * 0.20);
+    for (int r = 0; r < nReads; r++) {
+        const double *col = eMatRead_t + (size_t)Ks * r;
+        int c = 0, more_than_two = 0;
+        double val = -1;
+        for (int k = 0; k < Ks; k++) {
+            if (col[k] < thresh) {
+                indices_of_non_1_reads[(size_t)Ks * r + c] = k;
+                c++;
+                if (val == -1) val = col[k];
+                else if (val != col[k]) more_than_two = 1;
+            }
+        }
+        number_of_non_1_reads[r] = c;
+        if (c == 0) read_category[r] = 1;
+        else if (!more_than_two) read_category[r] = 2;
+        else if (c < thresh2) read_category[r] = 3;
+        else read_category[r] = 0;
+    }
+}
+
+/* ---- haploid forward / backward (copied-from-stitch.cpp) ------------------- */
+
+static double col_sum(const double *x, int n)
+{
+    double s = 0;
+    for (int i = 0; i < n; i++) s += x[i];
+    return s;
+}
+
+/* Rcpp_run_forward_haploid, copied-from-stitch.cpp:340-387, prior = alphaMat = 1/Ks */
+static void run_forward_haploid(double *alpha, double *c, const double *eMatGrid, const double *tm,
+                                int Ks, int G, int initialize_only)
+{
+    const double prior = 1.0 / Ks;
+    for (int k = 0; k < Ks; k++) alpha[k] = prior * eMatGrid[k];
+    c[0] = 1 / col_sum(alpha, Ks);
+    for (int k = 0; k < Ks; k++) alpha[k] = alpha[k] * c[0];
+    if (initialize_only) return;
+    for (int g = 1; g < G; g++) {
+        const double s0 = tm[2 * (size_t)(g - 1)], s1 = tm[2 * (size_t)(g - 1) + 1];
+        double *a = alpha + (size_t)Ks * g;
+        const double *ap = alpha + (size_t)Ks * (g - 1), *e = eMatGrid + (size_t)Ks * g;
+        for (int k = 0; k < Ks; k++) a[k] = e[k] * (s0 * ap[k] + s1 * prior);
+        c[g] = 1 / col_sum(a, Ks);
+        for (int k = 0; k < Ks; k++) a[k] *= c[g];
+    }
+}
+
+/* Rcpp_run_backward_haploid, copied-from-stitch.cpp:392-409 (alphaMat = 1/Ks) */
+static void run_backward_haploid(double *beta, const double *c, const double *eMatGrid, const double *tm,
+                                 int Ks, int G, double *etb)
+{
+    const double am = 1.0 / Ks;
+    for (int g = G - 2; g >= 0; --g) {
+        const double *e = eMatGrid + (size_t)Ks * (g + 1), *bn = beta + (size_t)Ks * (g + 1);
+        double *b = beta + (size_t)Ks * g;
+        double s = 0;
+        for (int k = 0; k < Ks; k++) etb[k] = e[k] * bn[k];
+        for (int k = 0; k < Ks; k++) s += am * etb[k];
+        double x = tm[2 * (size_t)g + 1] * s;
+        for (int k = 0; k < Ks; k++) b[k] = c[g] * (x + tm[2 * (size_t)g] * etb[k]);
+    }
+}
+
+/* Rcpp_run_backward_haploid_QUILT_faster, copied-from-stitch.cpp:417-440 */
+static void run_backward_haploid_faster(double *beta, const double *c, const double *eMatGrid,
+                                        const double *tm, const uint8_t *grid_has_read, int Ks, int G,
+                                        double *etb)
+{
+    const double one_over_K = 1 / (double)Ks;
+    for (int g = G - 2; g >= 0; --g) {
+        const double *bn = beta + (size_t)Ks * (g + 1);
+        double *b = beta + (size_t)Ks * g;
+        if (grid_has_read[g + 1]) {
+            const double *e = eMatGrid + (size_t)Ks * (g + 1);
+            for (int k = 0; k < Ks; k++) etb[k] = e[k] * bn[k];
+            double x = tm[2 * (size_t)g + 1] * col_sum(etb, Ks) * one_over_K;
+            for (int k = 0; k < Ks; k++) b[k] = c[g] * (x + tm[2 * (size_t)g] * etb[k]);
+        } else {
+            double x = tm[2 * (size_t)g + 1] * col_sum(bn, Ks) * one_over_K;
+            for (int k = 0; k < Ks; k++) b[k] = c[g] * (x + tm[2 * (size_t)g] * bn[k]);
+        }
+    }
+}
+
+/* rcpp_alpha_forward_one_QUILT_faster, gibbs-nipt.cpp:671-707 (normalize = true) */
+static void alpha_forward_one_faster(int g, int Ks, double *alpha, const double *tm, const double *eMatGrid,
+                                     double *c, const uint8_t *grid_has_read)
+{
+    const double one_over_K = 1 / (double)Ks;
+    const double *ap = alpha + (size_t)Ks * (g - 1);
+    double *a = alpha + (size_t)Ks * g;
+    double alphaConst = tm[2 * (size_t)(g - 1) + 1] * col_sum(ap, Ks);
+    double x = tm[2 * (size_t)(g - 1)];
+    double c2 = c[g];
+    if (grid_has_read[g]) {
+        const double *e = eMatGrid + (size_t)Ks * g;
+        for (int k = 0; k < Ks; k++) a[k] = e[k] * (x * ap[k] + alphaConst * one_over_K);
+    } else {
+        for (int k = 0; k < Ks; k++) a[k] = (x * ap[k] + alphaConst * one_over_K);
+    }
+    double aa = 1 / (c2 * col_sum(a, Ks));
+    c[g] *= aa;
+    aa *= c2;
+    for (int k = 0; k < Ks; k++) a[k] *= aa;
+}
+
+/* rcpp_alpha_forward_one, gibbs-nipt.cpp:627-657 (normalize = true, alphaMat = 1/Ks) */
+static void alpha_forward_one(int g, int Ks, double *alpha, const double *tm, const double *eMatGrid, double *c)
+{
+    const double am = 1.0 / Ks;
+    const double *ap = alpha + (size_t)Ks * (g - 1), *e = eMatGrid + (size_t)Ks * g;
+    double *a = alpha + (size_t)Ks * g;
+    double alphaConst = tm[2 * (size_t)(g - 1) + 1] * col_sum(ap, Ks);
+    double x = tm[2 * (size_t)(g - 1)];
+    double c2 = c[g];
+    for (int k = 0; k < Ks; k++) a[k] = c2 * e[k] * (x * ap[k] + alphaConst * am);
+    double aa = 1 / col_sum(a, Ks);
+    c[g] *= aa;
+    for (int k = 0; k < Ks; k++) a[k] *= aa;
+}
+
+/* ---- one Gibbs sweep (gibbs-nipt.cpp:1756-1956 + :733-1295) ---------------- */
+
+typedef struct {
+    int Ks, G, R, nH;               /* nH = 2 (sample_is_diploid) or 3 */
+    double *alpha[3], *beta[3], *eg[3], *c[3];
+    const double *eMatRead;
+    const int32_t *wif;
+    const uint8_t *grid_has_read;
+    const double *tm;
+    int32_t *H, *H_class;
+    const int32_t *read_category, *n_non1, *idx_non1;
+    double prior_probs[3];
+    double rlc[7][3];
+    double class_sum_cutoff;
+    int sample_is_diploid;
+} sweep_t;
+
+static void sample_reads_in_grid(sweep_t *S, int *iRead_io, int g, int *done_reads, int *read_wif,
+                                 int iteration, const double *runif_reads, int init_iteratively, int first_read,
+                                 double *am /* Ks x nH */, double *bm, double *ab, double *pC, double *pA1,
+                                 double *pA2)
+{
+    const int Ks = S->Ks, nH = S->nH, R = S->R;
+    int iRead = *iRead_io;
+    int h_rC = 0, h_rA1 = 1, h_rA2 = 2, h_rN = 0;
+    int this_grid_has_at_least_one_read = 0, at_least_one_read_has_changed = 0;
+    int normal = 0, ginit = 0, pass = 0;
+    while (!*done_reads && *read_wif == g) {
+        if (!S->sample_is_diploid || S->read_category[iRead] != 1) {
+            if (!init_iteratively) {
+                normal = 1;
+            } else if (iRead < first_read && iteration == 0) {
+                pass = 1;
+            } else if (first_read <= iRead && iteration == 0) {
+                pass = 0; ginit = 1;
+            } else if (iRead < first_read && iteration == 1) {
+                pass = 0; ginit = 1;
+            } else {
+                ginit = 0; normal = 1;
+            }
+            if (!this_grid_has_at_least_one_read) {
+                for (int h = 0; h < 3; h++) pC[h] = pA1[h] = pA2[h] = 1;
+                for (int h = 0; h < nH; h++) {
+                    memcpy(am + (size_t)Ks * h, S->alpha[h] + (size_t)Ks * g, sizeof(double) * Ks);
+                    memcpy(bm + (size_t)Ks * h, S->beta[h] + (size_t)Ks * g, sizeof(double) * Ks);
+                }
+                for (int i = 0; i < Ks * nH; i++) ab[i] = am[i] * bm[i];
+                for (int h = 0; h < nH; h++) pC[h] = col_sum(ab + (size_t)Ks * h, Ks);
+                this_grid_has_at_least_one_read = 1;
+            }
+            const double *er = S->eMatRead + (size_t)Ks * iRead;
+            if (normal) {
+                h_rC = S->H[iRead] - 1;
+                if (h_rC == 0) { h_rA1 = 1; h_rA2 = 2; }
+                else if (h_rC == 1) { h_rA1 = 0; h_rA2 = 2; }
+                else { h_rA1 = 0; h_rA2 = 1; }
+                for (int h = 0; h < 3; h++) pA1[h] = pA2[h] = pC[h];
+                const int cat = S->read_category[iRead];
+                double *abC = ab + (size_t)Ks * h_rC, *abA1 = ab + (size_t)Ks * h_rA1;
+                double *abA2 = (nH == 3) ? ab + (size_t)Ks * h_rA2 : NULL;
+                if (cat == 0) {
+                    double s1 = 0, s2 = 0, s3 = 0;
+                    for (int k = 0; k < Ks; k++) s1 += abC[k] / er[k];
+                    for (int k = 0; k < Ks; k++) s2 += abA1[k] * er[k];
+                    pA1[h_rC] = s1;
+                    pA1[h_rA1] = s2;
+                    if (!S->sample_is_diploid) {
+                        for (int k = 0; k < Ks; k++) s3 += abA2[k] * er[k];
+                        pA2[h_rA2] = s3;
+                    }
+                } else if (cat == 2) {
+                    double v1 = 0, v2 = 0, v3 = 0;
+                    int k = 0;
+                    const int32_t *idx = S->idx_non1 + (size_t)Ks * iRead;
+                    for (int ik = 0; ik < S->n_non1[iRead]; ik++) {
+                        k = idx[ik];
+                        v1 += abC[k];
+                        v2 += abA1[k];
+                        if (!S->sample_is_diploid) v3 += abA2[k];
+                    }
+                    pA1[h_rC] += v1 * (1 / er[k] - 1);   /* k = last listed index (:926-927) */
+                    pA1[h_rA1] += v2 * (er[k] - 1);
+                    if (!S->sample_is_diploid) pA2[h_rA2] += v3 * (er[k] - 1);
+                } else if (cat == 3) {
+                    const int32_t *idx = S->idx_non1 + (size_t)Ks * iRead;
+                    for (int ik = 0; ik < S->n_non1[iRead]; ik++) {
+                        int k = idx[ik];
+                        pA1[h_rC] += abC[k] * (1 / er[k] - 1);
+                        pA1[h_rA1] += abA1[k] * (er[k] - 1);
+                        if (!S->sample_is_diploid) pA2[h_rA2] += abA2[k] * (er[k] - 1);
+                    }
+                }
+                /* cat == 1 (only reachable when not diploid): nothing changes */
+                pA2[h_rA1] = pC[h_rA1];
+                pA2[h_rC] = pA1[h_rC];
+            } else if (ginit) {
+                h_rC = 0; h_rA1 = 1; h_rA2 = 2;
+                for (int h = 0; h < 3; h++) pA1[h] = pA2[h] = pC[h];
+                double s1 = 0, s2 = 0, s3 = 0;
+                for (int k = 0; k < Ks; k++) s1 += ab[k] * er[k];
+                for (int k = 0; k < Ks; k++) s2 += ab[(size_t)Ks + k] * er[k];
+                pC[h_rC] = s1;
+                pA1[h_rA1] = s2;
+                if (!S->sample_is_diploid) {
+                    for (int k = 0; k < Ks; k++) s3 += ab[(size_t)2 * Ks + k] * er[k];
+                    pA2[h_rA2] = s3;
+                }
+            } else {
+                for (int h = 0; h < 3; h++) pA1[h] = pA2[h] = pC[h];
+            }
+            double prod_pC = (pC[0] * pC[1] * pC[2]) * S->prior_probs[h_rC];
+            double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * S->prior_probs[h_rA1];
+            double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * S->prior_probs[h_rA2];
+            double denom = prod_pC + prod_pA1 + prod_pA2;
+            double norm_pC = prod_pC / denom, norm_pA1 = prod_pA1 / denom, norm_pA2 = prod_pA2 / denom;
+            double chance = runif_reads[(size_t)R * iteration + iRead];
+            double cs[3] = {0, 0, 0};
+            cs[h_rC] = norm_pC;
+            cs[h_rA1] = norm_pA1;
+            cs[h_rA2] = norm_pA2;
+            cs[1] += cs[0];
+            cs[2] += cs[1];
+            h_rN = 0;
+            for (int i = 2; i >= 0; i--) if (chance < cs[i]) h_rN = i;
+            if (((h_rN != h_rC) || ginit) && !pass) {
+                at_least_one_read_has_changed = 1;
+                S->H[iRead] = h_rN + 1;
+                if (normal) {
+                    double *x = am + (size_t)Ks * h_rC, *y = ab + (size_t)Ks * h_rC;
+                    for (int k = 0; k < Ks; k++) x[k] /= er[k];
+                    for (int k = 0; k < Ks; k++) y[k] /= er[k];
+                }
+                {
+                    double *x = am + (size_t)Ks * h_rN, *y = ab + (size_t)Ks * h_rN;
+                    for (int k = 0; k < Ks; k++) x[k] *= er[k];
+                    for (int k = 0; k < Ks; k++) y[k] *= er[k];
+                }
+                if (normal && (h_rC < 2 || !S->sample_is_diploid)) {
+                    double *e = S->eg[h_rC] + (size_t)Ks * g;
+                    for (int k = 0; k < Ks; k++) e[k] /= er[k];
+                }
+                if (h_rN < 2 || !S->sample_is_diploid) {
+                    double *e = S->eg[h_rN] + (size_t)Ks * g;
+                    for (int k = 0; k < Ks; k++) e[k] *= er[k];
+                }
+                if (normal) {
+                    /* the A1 move goes to the lower of the two other labels, A2 to the higher (:1103-1117) */
+                    const double *src = (h_rN == h_rA1) ? pA1 : pA2;
+                    for (int i = 0; i < 3; i++) pC[i] = src[i];
+                } else if (ginit) {
+                    if (h_rN == 1) for (int i = 0; i < 3; i++) pC[i] = pA1[i];
+                    if (h_rN == 2) for (int i = 0; i < 3; i++) pC[i] = pA2[i];
+                }
+            }
+            /* record_read_set (:1142-1165) */
+            {
+                double x[3];
+                x[h_rC] = norm_pC;
+                x[h_rA1] = norm_pA1;
+                x[h_rA2] = norm_pA2;
+                double local_min = 2;
+                int which = 8;
+                for (int i = 0; i < 7; i++) {
+                    double y = fabs(S->rlc[i][0] - x[0]) + fabs(S->rlc[i][1] - x[1]) + fabs(S->rlc[i][2] - x[2]);
+                    if (y < local_min) { local_min = y; which = i; }
+                }
+                S->H_class[iRead] = (local_min < S->class_sum_cutoff) ? which + 1 : 0;
+            }
+        }
+        iRead++;
+        if (R - 1 < iRead) { *done_reads = 1; *read_wif = -1; }
+        else *read_wif = S->wif[iRead];
+    }
+    if (at_least_one_read_has_changed) {
+        for (int h = 0; h < nH; h++) {
+            double *a = S->alpha[h] + (size_t)Ks * g;
+            memcpy(a, am + (size_t)Ks * h, sizeof(double) * Ks);
+            double alphaConst = 1 / col_sum(am + (size_t)Ks * h, Ks);
+            S->c[h][g] *= alphaConst;
+            for (int k = 0; k < Ks; k++) a[k] *= alphaConst;
+        }
+    }
+    *iRead_io = iRead;
+}
+
+static void gibbs_iterate(sweep_t *S, int iteration, const double *runif_reads, int init_iteratively,
+                          int first_read, double *work)
+{
+    const int Ks = S->Ks, G = S->G, nH = S->nH;
+    double *am = work, *bm = work + (size_t)3 * Ks, *ab = work + (size_t)6 * Ks, *etb = work + (size_t)9 * Ks;
+    double pC[3] = {1, 1, 1}, pA1[3] = {1, 1, 1}, pA2[3] = {1, 1, 1};
+    int done_reads = 0, iRead = -1, read_wif = -1;
+    const double prior = 1.0 / Ks;
+    for (int g = 0; g < G; g++) {
+        if (g > 0) {
+            for (int h = 0; h < nH; h++) alpha_forward_one_faster(g, Ks, S->alpha[h], S->tm, S->eg[h], S->c[h], S->grid_has_read);
+        } else {
+            /* rcpp_reinitialize_in_iterations (:712-727) */
+            for (int h = 0; h < nH; h++) {
+                double *a = S->alpha[h];
+                for (int k = 0; k < Ks; k++) a[k] = prior * S->eg[h][k];
+                S->c[h][0] = 1 / col_sum(a, Ks);
+                for (int k = 0; k < Ks; k++) a[k] *= S->c[h][0];
+            }
+        }
+        iRead++;
+        if (!done_reads) {
+            if (iRead < S->R) read_wif = S->wif[iRead];
+            else { done_reads = 1; read_wif = -1; }
+        } else {
+            read_wif = -1;
+        }
+        if (read_wif == g)
+            sample_reads_in_grid(S, &iRead, g, &done_reads, &read_wif, iteration, runif_reads, init_iteratively,
+                                 first_read, am, bm, ab, pC, pA1, pA2);
+        iRead = iRead - 1;
+    }
+    for (int h = 0; h < nH; h++) {
+        double *b = S->beta[h] + (size_t)Ks * (G - 1);
+        for (int k = 0; k < Ks; k++) b[k] = S->c[h][G - 1];
+        run_backward_haploid_faster(S->beta[h], S->c[h], S->eg[h], S->tm, S->grid_has_read, Ks, G, etb);
+    }
+}
+
+/* Rcpp_shard_block_gibbs_resampler (gibbs-nipt-block.cpp:1975-2355), ff == 0,
+ * shard_check_every_pair = TRUE. */
+static void shard_block_gibbs_diploid(sweep_t *S, const double *runif_block /* G - 1 */, double *work)
+{
+    const int Ks = S->Ks, G = S->G, R = S->R;
+    double *etb = work;
+    double mlc1 = 0, mlc2 = 0, mloc1 = 0, mloc2 = 0;
+    for (int g = 0; g < G; g++) {
+        mloc1 -= log(S->c[0][g]);
+        mloc2 -= log(S->c[1][g]);
+    }
+    int in_flip_mode = 0, iRead = 0;
+    const double prior = 1.0 / Ks;
+    for (int g = 0; g < G; g++) {
+        double oc1 = S->c[0][g], oc2 = S->c[1][g];
+        double *a1 = S->alpha[0] + (size_t)Ks * g, *a2 = S->alpha[1] + (size_t)Ks * g;
+        double *e1 = S->eg[0] + (size_t)Ks * g, *e2 = S->eg[1] + (size_t)Ks * g;
+        if (g == 0) {
+            for (int k = 0; k < Ks; k++) a1[k] = prior * e1[k];
+            S->c[0][0] = 1 / col_sum(a1, Ks);
+            for (int k = 0; k < Ks; k++) a1[k] *= S->c[0][0];
+            for (int k = 0; k < Ks; k++) a2[k] = prior * e2[k];
+            S->c[1][0] = 1 / col_sum(a2, Ks);
+            for (int k = 0; k < Ks; k++) a2[k] *= S->c[1][0];
+        } else {
+            if (in_flip_mode) {
+                for (int k = 0; k < Ks; k++) { double t = e1[k]; e1[k] = e2[k]; e2[k] = t; }
+            }
+            alpha_forward_one(g, Ks, S->alpha[0], S->tm, S->eg[0], S->c[0]);
+            alpha_forward_one(g, Ks, S->alpha[1], S->tm, S->eg[1], S->c[1]);
+        }
+        mlc1 -= log(S->c[0][g]);
+        mlc2 -= log(S->c[1][g]);
+        int done_reads = 0;
+        while (!done_reads) {
+            if (iRead > R - 1) {
+                done_reads = 1;
+            } else {
+                if (S->wif[iRead] == g) {
+                    if (in_flip_mode) S->H[iRead] = 3 - S->H[iRead];
+                    iRead++;
+                }
+                if (iRead > R - 1) done_reads = 1;
+                else if (S->wif[iRead] > g) done_reads = 1;
+            }
+        }
+        if (g < G - 1) {
+            const double *b1 = S->beta[0] + (size_t)Ks * g, *b2 = S->beta[1] + (size_t)Ks * g;
+            double s11 = 0, s22 = 0, s21 = 0, s12 = 0;
+            for (int k = 0; k < Ks; k++) s11 += a1[k] * b1[k];
+            for (int k = 0; k < Ks; k++) s22 += a2[k] * b2[k];
+            for (int k = 0; k < Ks; k++) s21 += a2[k] * b1[k];
+            for (int k = 0; k < Ks; k++) s12 += a1[k] * b2[k];
+            double pA1 = mlc1 + mloc1 + log(s11);
+            double pA2 = mlc2 + mloc2 + log(s22);
+            double pB1 = mlc2 + mloc1 + log(s21);
+            double pB2 = mlc1 + mloc2 + log(s12);
+            double diff = pB1 + pB2 - pA1 - pA2;
+            double probs1 = 1, probs2 = exp(diff);
+            double ps = probs1 + probs2;
+            probs1 /= ps;
+            in_flip_mode = runif_block[g] > probs1;
+        }
+        mloc1 += log(oc1);
+        mloc2 += log(oc2);
+    }
+    for (int h = 0; h < 2; h++) {
+        double *b = S->beta[h] + (size_t)Ks * (G - 1);
+        for (int k = 0; k < Ks; k++) b[k] = S->c[h][G - 1];
+        run_backward_haploid(S->beta[h], S->c[h], S->eg[h], S->tm, Ks, G, etb);
+    }
+}
+
+/* rcpp_calculate_gibbs_small_genProbs_and_hapProbs_using_binary_objects
+ * (gibbs-small.cpp:472-635), calculate_gamma_on_the_fly = TRUE */
+static void calc_hapProbs(const qo_panel_t *p, const int32_t *which_1based, sweep_t *S, double *genProbsM,
+                          double *genProbsF, double *hapProbs)
+{
+    const int Ks = S->Ks, G = S->G, T = p->nSNPs;
+    const double eps = p->ref_error, ome = 1 - eps;
+    double *gam = (double *)calloc((size_t)3 * Ks, sizeof(double));
+    for (int g = 0; g < G; g++) {
+        int s = 32 * g, e = 32 * (g + 1) - 1;
+        if (e > T - 1) e = T - 1;
+        int nLocal = e - s + 1;
+        double g0[32] = {0}, g1[32] = {0}, g2[32] = {0}, h0[32] = {0}, h1[32] = {0}, h2[32] = {0};
+        for (int h = 0; h < S->nH; h++) {
+            double x = 1 / S->c[h][g];
+            const double *a = S->alpha[h] + (size_t)Ks * g, *b = S->beta[h] + (size_t)Ks * g;
+            for (int k = 0; k < Ks; k++) gam[(size_t)Ks * h + k] = (a[k] * b[k]) * x;
+        }
+        for (int k = 0; k < Ks; k++) {
+            double gk0 = gam[k], gk1 = gam[(size_t)Ks + k], gk2 = gam[(size_t)2 * Ks + k];
+            int kk = panel_code(p, which_1based[k] - 1, g);
+            uint32_t w = kk > 0 ? (uint32_t)p->distinctHapsB[(size_t)p->nMaxDH * g + (kk - 1)]
+                                : panel_special_word(p, which_1based[k] - 1, g);
+            for (int b = 0; b < nLocal; b++, w >>= 1) {
+                if ((w & 1u) == 0) { h0[b] += gk0; h1[b] += gk1; h2[b] += gk2; }
+                else { g0[b] += gk0; g1[b] += gk1; g2[b] += gk2; }
+            }
+        }
+        for (int b = 0; b < nLocal; b++) {
+            g0[b] = g0[b] * ome + h0[b] * eps;
+            g1[b] = g1[b] * ome + h1[b] * eps;
+            g2[b] = g2[b] * ome + h2[b] * eps;
+        }
+        for (int b = 0; b < nLocal; b++) {
+            double *gm = genProbsM + 3 * (size_t)(s + b), *gf = genProbsF + 3 * (size_t)(s + b);
+            double *hp = hapProbs + 3 * (size_t)(s + b);
+            gm[0] = (1 - g0[b]) * (1 - g1[b]);
+            gm[1] = (g0[b] * (1 - g1[b]) + (1 - g0[b]) * g1[b]);
+            gm[2] = g0[b] * g1[b];
+            gf[0] = (1 - g0[b]) * (1 - g2[b]);
+            gf[1] = (g0[b] * (1 - g2[b]) + (1 - g0[b]) * g2[b]);
+            gf[2] = g0[b] * g2[b];
+            hp[0] = g0[b]; hp[1] = g1[b]; hp[2] = g2[b];
+        }
+    }
+    free(gam);
+}
+
+/*
+ * rcpp_forwardBackwardGibbsNIPT (gibbs-nipt.cpp:2395-3307), production path.
+ * Returns 0 ok, 1 underflow_problem (:2959-2969), -2 unsupported (NIPT block Gibbs).
+ */
+int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t *H_class,
+             double *alphaHat_t[3], double *betaHat_t[3], double *eMatGrid_t[3], double *c_out[3],
+             double *eMatRead_t, int32_t *read_category_out, double *hapProbs_t, double *genProbsM_t,
+             double *genProbsF_t)
+{
+    const int Ks = a->Ks, G = p->nGrids, R = a->nReads, T = p->nSNPs;
+    const int nH = a->sample_is_diploid ? 2 : 3;
+    const int n_its = a->n_gibbs_burn_in_its + a->n_gibbs_sample_its;
+    sweep_t S;
+    memset(&S, 0, sizeof S);
+    S.Ks = Ks; S.G = G; S.R = R; S.nH = nH;
+    S.eMatRead = eMatRead_t; S.wif = a->wif; S.grid_has_read = a->grid_has_read; S.tm = p->transMatRate_t;
+    S.H = H; S.H_class = H_class; S.sample_is_diploid = a->sample_is_diploid;
+    S.class_sum_cutoff = a->class_sum_cutoff;
+    const double ff = a->ff;
+    S.prior_probs[0] = 0.5; S.prior_probs[1] = (1 - ff) * 0.5; S.prior_probs[2] = ff * 0.5;
+    {
+        const double *pp = S.prior_probs;
+        double r[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1},
+                          {pp[0] / (pp[0] + pp[1]), pp[1] / (pp[0] + pp[1]), 0},
+                          {pp[0] / (pp[0] + pp[2]), 0, pp[2] / (pp[0] + pp[2])},
+                          {0, pp[1] / (pp[1] + pp[2]), pp[2] / (pp[1] + pp[2])},
+                          {pp[0], pp[1], pp[2]}};
+        memcpy(S.rlc, r, sizeof r);
+    }
+    double *c3_local = NULL;
+    for (int h = 0; h < 3; h++) {
+        S.alpha[h] = alphaHat_t[h]; S.beta[h] = betaHat_t[h]; S.eg[h] = eMatGrid_t[h]; S.c[h] = c_out[h];
+    }
+    for (int h = 0; h < 3; h++) for (int g = 0; g < G; g++) S.c[h][g] = 0; /* arma::zeros (:2676-2678) */
+    for (int i = 0; i < R; i++) H_class[i] = 0;
+
+    /* emissions (pass_in_eMatRead_t = FALSE: ones, then multiply) */
+    for (size_t i = 0; i < (size_t)Ks * R; i++) eMatRead_t[i] = 1;
+    qo_make_eMatRead_t_for_gibbs_using_objects(p, a->which_haps_to_use_1based, Ks, R, a->read_ptr, a->u, a->bq,
+                                               a->rescale_eMatRead_t, a->Jmax, a->maxDifferenceBetweenReads,
+                                               eMatRead_t);
+    int32_t *n_non1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+    int32_t *idx_non1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)Ks * (R > 0 ? R : 1));
+    int32_t *cat = (int32_t *)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+    qo_evaluate_read_variability(eMatRead_t, Ks, R, n_non1, idx_non1, cat);
+    if (a->disable_read_category_usage) for (int i = 0; i < R; i++) cat[i] = 0;
+    if (read_category_out) memcpy(read_category_out, cat, sizeof(int32_t) * (size_t)R);
+    S.read_category = cat; S.n_non1 = n_non1; S.idx_non1 = idx_non1;
+
+    double *work = (double *)malloc(sizeof(double) * (size_t)10 * Ks);
+
+    /* rcpp_gibbs_nipt_initialize (:1629-1750) */
+    for (int h = 0; h < 3; h++) for (size_t i = 0; i < (size_t)Ks * G; i++) S.eg[h][i] = 1;
+    if (!a->gibbs_initialize_iteratively) {
+        for (int r = 0; r < R; r++) { /* rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281), bound = false */
+            int h = H[r] - 1;
+            double *e = S.eg[h] + (size_t)Ks * a->wif[r];
+            const double *er = eMatRead_t + (size_t)Ks * r;
+            for (int k = 0; k < Ks; k++) e[k] *= er[k];
+        }
+        for (int h = 0; h < nH; h++) { /* rcpp_initialize_gibbs_forward_backward (:453-487) */
+            run_forward_haploid(S.alpha[h], S.c[h], S.eg[h], S.tm, Ks, G, 0);
+            double *b = S.beta[h] + (size_t)Ks * (G - 1);
+            for (int k = 0; k < Ks; k++) b[k] = S.c[h][G - 1];
+            run_backward_haploid(S.beta[h], S.c[h], S.eg[h], S.tm, Ks, G, work);
+        }
+    } else {
+        for (int h = 0; h < nH; h++) {
+            for (size_t i = 0; i < (size_t)Ks * G; i++) { S.alpha[h][i] = 1; S.beta[h][i] = 1; }
+            for (int g = 0; g < G; g++) S.c[h][g] = 1;
+            run_forward_haploid(S.alpha[h], S.c[h], S.eg[h], S.tm, Ks, G, 1);
+        }
+    }
+
+    int status = 0;
+    int shard_it = 0;
+    for (int it = 0; it < n_its; it++) {
+        gibbs_iterate(&S, it, a->runif_reads, a->gibbs_initialize_iteratively, a->first_read, work);
+        /* underflow check (:2959-2969): sum(c3) is only looked at when ff == 0 */
+        for (int h = 0; h < 3; h++) {
+            if (h == 2 && ff != 0) continue;
+            double s = 0;
+            for (int g = 0; g < G; g++) s += S.c[h][g];
+            if (!isfinite(s)) status = 1;
+        }
+        if (status == 1) break;
+        int to_block = 0;
+        if (a->perform_block_gibbs)
+            for (int i = 0; i < a->n_block_gibbs_iterations; i++) if (a->block_gibbs_iterations[i] == it) to_block = 1;
+        if (to_block) {
+            if (!(a->sample_is_diploid && ff == 0)) { status = -2; break; }
+            /* diploid: Rcpp_block_gibbs_resampler is the identity (see header) */
+            if (a->do_shard_block_gibbs) {
+                shard_block_gibbs_diploid(&S, a->runif_shard + (size_t)shard_it * (G - 1), work);
+                shard_it++;
+            }
+        }
+        if (it + 1 > a->n_gibbs_burn_in_its) {
+            calc_hapProbs(p, a->which_haps_to_use_1based, &S, genProbsM_t, genProbsF_t, hapProbs_t);
+        }
+    }
+    (void)T; (void)c3_local;
+    free(work); free(n_non1); free(idx_non1); free(cat);
+    return status;
+}

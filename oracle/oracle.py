@@ -166,3 +166,95 @@ def haploid_dosage_versus_refs(panel, gl, gammaSmall_cols_to_get=None, *, K_top_
     best = [(bidx[bptr[i]:bptr[i + 1]].copy(), bval[bptr[i]:bptr[i + 1]].copy()) for i in range(n_thin)]
     return dict(alphaHat_t=alpha, betaHat_t=beta, gamma_t=gamma, gammaSmall_t=gsmall, c=c, dosage=dosage,
                 best_haps=best if get_best_haps_from_thinned_sites else None)
+
+
+class _GibbsArgs(C.Structure):
+    _fields_ = [
+        ("Ks", C.c_int), ("nReads", C.c_int), ("which_haps_to_use_1based", C.c_void_p),
+        ("read_ptr", C.c_void_p), ("u", C.c_void_p), ("bq", C.c_void_p), ("wif", C.c_void_p),
+        ("grid_has_read", C.c_void_p), ("ff", C.c_double), ("Jmax", C.c_int),
+        ("maxDifferenceBetweenReads", C.c_double), ("n_gibbs_burn_in_its", C.c_int),
+        ("n_gibbs_sample_its", C.c_int), ("block_gibbs_iterations", C.c_void_p),
+        ("n_block_gibbs_iterations", C.c_int), ("perform_block_gibbs", C.c_int),
+        ("do_shard_block_gibbs", C.c_int), ("gibbs_initialize_iteratively", C.c_int),
+        ("sample_is_diploid", C.c_int), ("disable_read_category_usage", C.c_int),
+        ("rescale_eMatRead_t", C.c_int), ("class_sum_cutoff", C.c_double),
+        ("runif_reads", C.c_void_p), ("first_read", C.c_int), ("runif_shard", C.c_void_p),
+    ]
+
+
+def grid_has_read_of(sample, nGrids):
+    g = np.zeros(nGrids, dtype=np.uint8)
+    g[sample.wif] = 1
+    return g
+
+
+def make_eMatRead_t(panel, sample, which_haps_to_use, maxDifferenceBetweenReads=1e10, Jmax=10000,
+                    rescale_eMatRead_t=True, use_eMatDH_special_symbols=None):
+    which = np.ascontiguousarray(which_haps_to_use, dtype=np.int32)
+    Ks, R = len(which), sample.nReads
+    ps, keep = panel_struct(panel, use_eMatDH_special_symbols)
+    e = np.ones((Ks, R), dtype=np.float64, order="F")
+    lib().qo_make_eMatRead_t_for_gibbs_using_objects(
+        C.byref(ps), _p(which), C.c_int(Ks), C.c_int(R), _p(sample.read_ptr), _p(sample.u), _p(sample.bq),
+        C.c_int(int(rescale_eMatRead_t)), C.c_int(Jmax), C.c_double(maxDifferenceBetweenReads), _p(e))
+    return e
+
+
+def evaluate_read_variability(eMatRead_t):
+    Ks, R = eMatRead_t.shape
+    n = np.zeros(R, dtype=np.int32)
+    idx = np.zeros((Ks, R), dtype=np.int32, order="F")
+    cat = np.zeros(R, dtype=np.int32)
+    lib().qo_evaluate_read_variability(_p(np.asfortranarray(eMatRead_t)), C.c_int(Ks), C.c_int(R), _p(n), _p(idx), _p(cat))
+    return n, idx, cat
+
+
+def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, first_read, runif_shard, *,
+                             ff=0.0, n_gibbs_burn_in_its=20, n_gibbs_sample_its=1,
+                             block_gibbs_iterations=(3, 6, 9), perform_block_gibbs=True,
+                             gibbs_initialize_iteratively=False, sample_is_diploid=None,
+                             disable_read_category_usage=False, maxDifferenceBetweenReads=1e10, Jmax=10000,
+                             class_sum_cutoff=0.06, use_eMatDH_special_symbols=None):
+    """Oracle twin of ``rcpp_forwardBackwardGibbsNIPT`` (gibbs-nipt.cpp:2395-3307), production path.
+
+    ``H``: starting labels (1-based); returns a dict holding the ending labels and every state
+    matrix the reference mutates in place.
+    """
+    lib().qo_gibbs.restype = C.c_int
+    which = np.ascontiguousarray(which_haps_to_use, dtype=np.int32)
+    Ks, R, G, T = len(which), sample.nReads, panel.nGrids, panel.nSNPs
+    if sample_is_diploid is None:
+        sample_is_diploid = ff == 0
+    blocks = np.ascontiguousarray(block_gibbs_iterations, dtype=np.int32)
+    ghr = grid_has_read_of(sample, G)
+    runif_reads = np.ascontiguousarray(runif_reads, dtype=np.float64)
+    runif_shard = np.ascontiguousarray(runif_shard, dtype=np.float64)
+    n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
+    assert runif_reads.size >= R * n_its
+    assert runif_shard.size >= len(blocks) * (G - 1)
+    args = _GibbsArgs(Ks, R, _p(which), _p(sample.read_ptr), _p(sample.u), _p(sample.bq), _p(sample.wif),
+                      _p(ghr), float(ff), int(Jmax), float(maxDifferenceBetweenReads), int(n_gibbs_burn_in_its),
+                      int(n_gibbs_sample_its), _p(blocks), len(blocks), int(perform_block_gibbs),
+                      int(ff == 0), int(gibbs_initialize_iteratively), int(sample_is_diploid),
+                      int(disable_read_category_usage), 1, float(class_sum_cutoff), _p(runif_reads),
+                      int(first_read), _p(runif_shard))
+    ps, keep = panel_struct(panel, use_eMatDH_special_symbols)
+    Hout = np.array(H, dtype=np.int32).copy()
+    Hc = np.zeros(R, dtype=np.int32)
+    mats = {n: [np.zeros((Ks, G), order="F") for _ in range(3)] for n in ("alpha", "beta", "eg")}
+    cs = [np.zeros(G) for _ in range(3)]
+
+    def arr3(lst):
+        return (C.c_void_p * 3)(*[a.ctypes.data for a in lst])
+
+    eMatRead = np.zeros((Ks, R), order="F")
+    cat = np.zeros(R, dtype=np.int32)
+    hap = np.zeros((3, T), order="F")
+    gm = np.zeros((3, T), order="F")
+    gf = np.zeros((3, T), order="F")
+    st = lib().qo_gibbs(C.byref(ps), C.byref(args), _p(Hout), _p(Hc), arr3(mats["alpha"]), arr3(mats["beta"]),
+                        arr3(mats["eg"]), arr3(cs), _p(eMatRead), _p(cat), _p(hap), _p(gm), _p(gf))
+    return dict(status=st, underflow_problem=(st == 1), H=Hout, H_class=Hc, alphaHat_t=mats["alpha"],
+                betaHat_t=mats["beta"], eMatGrid_t=mats["eg"], c=cs, eMatRead_t=eMatRead, read_category=cat,
+                hapProbs_t=hap, genProbsM_t=gm, genProbsF_t=gf)

@@ -106,6 +106,49 @@ int qo_haploid_dosage_versus_refs(
     double *gammaSmall_t /* K x n_thin */, double *dosage /* nSNPs */,
     int32_t *best_ptr, int32_t *best_idx, double *best_val, int64_t best_cap);
 
+
+/* ---- small-panel Gibbs read-label sampler -------------------------------- */
+
+/* gibbs-small.cpp:116-265.  eMatRead_t (Ks x nReads) must be pre-filled (normally 1). */
+void qo_make_eMatRead_t_for_gibbs_using_objects(
+    const qo_panel_t *p, const int32_t *which_haps_to_use_1based, int Ks, int nReads,
+    const int32_t *read_ptr, const int32_t *u, const int32_t *bq, int rescale_eMatRead_t, int Jmax,
+    double maxDifferenceBetweenReads, double *eMatRead_t);
+
+/* gibbs-nipt.cpp:338-382 */
+void qo_evaluate_read_variability(const double *eMatRead_t, int Ks, int nReads,
+                                  int32_t *number_of_non_1_reads, int32_t *indices_of_non_1_reads,
+                                  int32_t *read_category);
+
+typedef struct {
+    int Ks, nReads;
+    const int32_t *which_haps_to_use_1based; /* Ks */
+    const int32_t *read_ptr, *u, *bq, *wif;  /* flattened sampleReads (a0 in SURVEY.md 8(a)) */
+    const uint8_t *grid_has_read;            /* nGrids */
+    double ff;
+    int Jmax;
+    double maxDifferenceBetweenReads;
+    int n_gibbs_burn_in_its, n_gibbs_sample_its;
+    const int32_t *block_gibbs_iterations;
+    int n_block_gibbs_iterations;
+    int perform_block_gibbs, do_shard_block_gibbs;
+    int gibbs_initialize_iteratively, sample_is_diploid, disable_read_category_usage, rescale_eMatRead_t;
+    double class_sum_cutoff;
+    /* the uniforms the reference draws from R's RNG, as inputs */
+    const double *runif_reads;   /* nReads * n_its   (gibbs-nipt.cpp:2845) */
+    int first_read;              /* 0-based          (gibbs-nipt.cpp:2846-2848) */
+    const double *runif_shard;   /* n_block_its * (nGrids - 1)  (gibbs-nipt-block.cpp:2054) */
+} qo_gibbs_args_t;
+
+/* rcpp_forwardBackwardGibbsNIPT (gibbs-nipt.cpp:2395-3307), production argument values.
+ * H (1-based labels) is updated in place; alphaHat_t/betaHat_t/eMatGrid_t are Ks x nGrids each,
+ * c_out nGrids each, eMatRead_t Ks x nReads (output), hapProbs_t / genProbs* 3 x nSNPs.
+ * Returns 0, 1 (underflow_problem) or -2 (unsupported mode). */
+int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t *H_class,
+             double *alphaHat_t[3], double *betaHat_t[3], double *eMatGrid_t[3], double *c_out[3],
+             double *eMatRead_t, int32_t *read_category_out, double *hapProbs_t, double *genProbsM_t,
+             double *genProbsF_t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,7 +152,11 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
         p->sp_word.upload(sw.data(), sw.size(), p->stream);
         // transitions
         p->h_sigma.resize(std::max(G - 1, 1));
-        for (int g = 0; g < G - 1; g++) p->h_sigma[g] = d->transMatRate_t[2 * (size_t)g];
+        p->h_tm1.resize(std::max(G - 1, 1));
+        for (int g = 0; g < G - 1; g++) {
+            p->h_sigma[g] = d->transMatRate_t[2 * (size_t)g];
+            p->h_tm1[g] = d->transMatRate_t[2 * (size_t)g + 1];
+        }
         p->sigma.alloc(std::max(G - 1, 1));
         p->sigma.upload(p->h_sigma.data(), std::max(G - 1, 0), p->stream);
         // distinctHapsIE: by construction (STITCH make_rhb_t_equality) the per-SNP expansion of

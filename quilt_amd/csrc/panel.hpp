@@ -25,7 +25,7 @@ struct qa_panel {
     qa::DBuf<double> IE;        // only when the caller's distinctHapsIE is not the (B, eps) expansion
     bool ie_derived = true;
     int n_special = 0;
-    std::vector<double> h_sigma;
+    std::vector<double> h_sigma, h_tm1;  // transMatRate_t rows 0 and 1 as passed
     std::vector<int32_t> h_sp_off;
     hipStream_t stream = nullptr;
     // scratch owned by the panel handle, grown on demand (see fullpass.hip)

@@ -1,0 +1,110 @@
+"""Host-side mirror of the reference's Gibbs entry point (QUILT/R/RcppExports.R stub of
+``rcpp_forwardBackwardGibbsNIPT``; kernel QUILT/src/gibbs-nipt.cpp:2395-3307).
+
+Same argument names and meaning for what the production caller varies
+(QUILT/R/functions.R:2566-2678); the panel tables are replaced by the device handle and the
+uniforms the reference draws from R's RNG inside the call are explicit arguments (SURVEY.md
+8(b)): the caller draws them in the same order (``runif(nReads * n_its)``, ``sample(nReads, 1)``,
+then per block-Gibbs sweep ``runif(nGrids - 1)`` for the shard pass).  Returns a dict with the
+reference's list names.  All arithmetic runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import native
+from .native import DevicePanel, check, lib, ptr
+
+
+class GibbsOpts(C.Structure):
+    _fields_ = [
+        ("Ks", C.c_int32), ("ff", C.c_double), ("sample_is_diploid", C.c_int32), ("Jmax", C.c_int32),
+        ("maxDifferenceBetweenReads", C.c_double), ("rescale_eMatRead_t", C.c_int32),
+        ("n_gibbs_burn_in_its", C.c_int32), ("n_gibbs_sample_its", C.c_int32),
+        ("block_gibbs_iterations", C.c_void_p), ("n_block_gibbs_iterations", C.c_int32),
+        ("perform_block_gibbs", C.c_int32), ("do_shard_block_gibbs", C.c_int32),
+        ("gibbs_initialize_iteratively", C.c_int32), ("disable_read_category_usage", C.c_int32),
+        ("class_sum_cutoff", C.c_double),
+    ]
+
+
+def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_haps_to_use: Sequence[np.ndarray],
+                                   starting_read_labels: Sequence[np.ndarray], runif_reads: Sequence[np.ndarray],
+                                   first_read: Sequence[int], runif_shard: Sequence[np.ndarray], *,
+                                   ff: float = 0.0, n_gibbs_burn_in_its: int = 20, n_gibbs_sample_its: int = 1,
+                                   block_gibbs_iterations=(3, 6, 9), perform_block_gibbs: bool = True,
+                                   gibbs_initialize_iteratively: bool = False,
+                                   disable_read_category_usage: bool = False,
+                                   maxDifferenceBetweenReads: float = 1e10, Jmax_local: int = 10000,
+                                   class_sum_cutoff: float = 0.06, return_state: bool = False):
+    """``n_chain`` independent calls of ``rcpp_forwardBackwardGibbsNIPT`` in one launch set.
+
+    ``samples[c]`` is a :class:`quilt_amd.synth.SampleReads`-like object (``read_ptr``, ``u``, ``bq``,
+    ``wif``); the other sequences hold one entry per chain.  Returns a list of dicts.
+    """
+    lib().qa_gibbs_batch.restype = C.c_int
+    P = panel.panel
+    G, T = P.nGrids, P.nSNPs
+    Cn = len(samples)
+    Ks = len(which_haps_to_use[0])
+    n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
+    blocks = np.ascontiguousarray(block_gibbs_iterations, dtype=np.int32)
+    nb = len(blocks) if perform_block_gibbs else 0
+    read_off = np.zeros(Cn + 1, dtype=np.int32)
+    for c, s in enumerate(samples):
+        read_off[c + 1] = read_off[c] + s.nReads
+    which = np.ascontiguousarray(np.stack([np.asarray(w, dtype=np.int32) for w in which_haps_to_use]))
+    assert which.shape == (Cn, Ks)
+    read_ptr = np.concatenate([np.asarray(s.read_ptr, dtype=np.int32) for s in samples])
+    u = np.concatenate([np.asarray(s.u, dtype=np.int32) for s in samples])
+    bq = np.concatenate([np.asarray(s.bq, dtype=np.int32) for s in samples])
+    wif = np.concatenate([np.asarray(s.wif, dtype=np.int32) for s in samples])
+    ru = np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: samples[c].nReads * n_its]
+                         for c, r in enumerate(runif_reads)])
+    fr = np.ascontiguousarray(first_read, dtype=np.int32)
+    rs = (np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: nb * (G - 1)] for r in runif_shard])
+          if nb > 0 else np.zeros(1))
+    H = np.concatenate([np.asarray(h, dtype=np.int32) for h in starting_read_labels]).copy()
+    if ff == 0 and H.size and (H.min() < 1 or H.max() > 2):
+        raise ValueError("diploid read labels must be 1 or 2")
+    Hc = np.zeros_like(H)
+    hap = np.zeros((Cn, T, 3))
+    gm = np.zeros((Cn, T, 3))
+    gf = np.zeros((Cn, T, 3))
+    uf = np.zeros(Cn, dtype=np.int32)
+    state = np.zeros(6 * Ks * G + 3 * G) if (return_state and Cn == 1) else None
+    opts = GibbsOpts(Ks, float(ff), int(ff == 0), int(Jmax_local), float(maxDifferenceBetweenReads), 1,
+                     int(n_gibbs_burn_in_its), int(n_gibbs_sample_its), ptr(blocks), int(len(blocks)),
+                     int(perform_block_gibbs), int(ff == 0), int(gibbs_initialize_iteratively),
+                     int(disable_read_category_usage), float(class_sum_cutoff))
+    st = lib().qa_gibbs_batch(panel.handle, C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr),
+                              ptr(u), ptr(bq), ptr(wif), ptr(ru), ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap),
+                              ptr(gm), ptr(gf), ptr(uf), ptr(state))
+    check(st)
+    out = []
+    for c in range(Cn):
+        s, e = read_off[c], read_off[c + 1]
+        d = dict(underflow_problem=bool(uf[c]),
+                 hapProbs_t=np.asfortranarray(hap[c].T), genProbsM_t=np.asfortranarray(gm[c].T),
+                 genProbsF_t=np.asfortranarray(gf[c].T), H=H[s:e].copy(),
+                 double_list_of_ending_read_labels=[[H[s:e].copy()]], H_class=Hc[s:e].copy())
+        if state is not None:
+            m = state[: 6 * Ks * G].reshape(6, G, Ks)
+            names = ("alphaHat_t1", "alphaHat_t2", "betaHat_t1", "betaHat_t2", "eMatGrid_t1", "eMatGrid_t2")
+            for i, n in enumerate(names):
+                d[n] = np.asfortranarray(m[i].T)
+            cs = state[6 * Ks * G:].reshape(3, G)
+            d["c1"], d["c2"], d["c3"] = cs[0].copy(), cs[1].copy(), cs[2].copy()
+        out.append(d)
+    return out
+
+
+def rcpp_forwardBackwardGibbsNIPT(panel: DevicePanel, sampleReads, which_haps_to_use, starting_read_labels,
+                                  runif_reads, first_read_for_gibbs_initialization, runif_shard, **kw):
+    """Single-chain form with the reference's name; see :func:`forwardBackwardGibbsNIPT_batch`."""
+    return forwardBackwardGibbsNIPT_batch(panel, [sampleReads], [which_haps_to_use], [starting_read_labels],
+                                          [runif_reads], [first_read_for_gibbs_initialization], [runif_shard],
+                                          **kw)[0]

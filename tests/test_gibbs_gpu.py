@@ -1,0 +1,105 @@
+"""GPU parity: HIP Gibbs read-label sampler (through the C ABI) vs the fp64 CPU oracle.
+
+Bar: sampled read labels and H_class IDENTICAL under the same uniforms; fp64 state (alpha, beta,
+eMatGrid, c) and hapProbs / genProbs within 1e-9 relative (only the order of the Ks-wide sums differs).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _setup(panel, seed, Ks, n_reads, mode="short"):
+    from quilt_amd.synth import make_synthetic_sample
+    s = make_synthetic_sample(panel, seed=seed, n_reads=n_reads, mode=mode)
+    rng = np.random.default_rng(seed + 17)
+    which = np.sort(rng.choice(panel.K, Ks, replace=False)).astype(np.int32) + 1
+    H0 = rng.integers(1, 3, size=s.nReads).astype(np.int32)
+    ru = rng.random(s.nReads * 21)
+    rs = rng.random(3 * (panel.nGrids - 1))
+    fr = int(rng.integers(0, s.nReads))
+    return s, which, H0, ru, rs, fr
+
+
+def _compare(got, ref, Ks):
+    assert not got["underflow_problem"] and ref["status"] == 0
+    assert np.array_equal(got["H"], ref["H"]), f"{(got['H'] != ref['H']).sum()} labels differ"
+    assert np.array_equal(got["H_class"], ref["H_class"])
+    for h in range(2):
+        np.testing.assert_allclose(got[f"eMatGrid_t{h + 1}"], ref["eMatGrid_t"][h], rtol=RTOL)
+        np.testing.assert_allclose(got[f"alphaHat_t{h + 1}"], ref["alphaHat_t"][h], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(got[f"betaHat_t{h + 1}"], ref["betaHat_t"][h], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(got[f"c{h + 1}"], ref["c"][h], rtol=RTOL)
+    np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(got["genProbsM_t"], ref["genProbsM_t"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(got["genProbsF_t"], ref["genProbsF_t"], rtol=RTOL, atol=1e-14)
+
+
+@pytest.mark.parametrize("init_iter", [False, True])
+@pytest.mark.parametrize("panel_name,Ks,n_reads", [("small_panel", 100, 100), ("ragged_panel", 77, 250),
+                                                   ("medium_panel", 600, 1500)])
+def test_gibbs_matches_oracle(request, oracle, panel_name, Ks, n_reads, init_iter):
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    panel = request.getfixturevalue(panel_name)
+    dev = DevicePanel(panel)
+    s, which, H0, ru, rs, fr = _setup(panel, 11, Ks, n_reads)
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter,
+                                        return_state=True)
+    _compare(got, ref, Ks)
+    dev.close()
+
+
+def test_gibbs_ont_reads_and_category_switch(medium_panel, oracle):
+    """Long noisy reads (ONT-like) and disable_read_category_usage (rare/common default)."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    s, which, H0, ru, rs, fr = _setup(panel, 5, 200, 40, mode="ont")
+    for dis in (False, True):
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs, disable_read_category_usage=dis)
+        got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, disable_read_category_usage=dis,
+                                            return_state=True)
+        _compare(got, ref, 200)
+
+
+def test_gibbs_batch_of_chains(small_panel, oracle):
+    """Several chains (different samples, haplotype subsets, uniforms) in one launch == one at a time."""
+    from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+    from quilt_amd.native import DevicePanel
+    panel = small_panel
+    dev = DevicePanel(panel)
+    setups = [_setup(panel, 100 + i, 64, 60 + 13 * i) for i in range(5)]
+    got = forwardBackwardGibbsNIPT_batch(dev, [x[0] for x in setups], [x[1] for x in setups], [x[2] for x in setups],
+                                         [x[3] for x in setups], [x[5] for x in setups], [x[4] for x in setups])
+    for g, (s, which, H0, ru, rs, fr) in zip(got, setups):
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs)
+        assert np.array_equal(g["H"], ref["H"])
+        np.testing.assert_allclose(g["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+
+
+def test_gibbs_no_block_no_burn(small_panel, oracle):
+    """n_its = 0: initialisation only leaves the labels untouched."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    panel = small_panel
+    dev = DevicePanel(panel)
+    s, which, H0, ru, rs, fr = _setup(panel, 3, 50, 80)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, n_gibbs_burn_in_its=0, n_gibbs_sample_its=0,
+                                        perform_block_gibbs=False, return_state=True)
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs, n_gibbs_burn_in_its=0,
+                                          n_gibbs_sample_its=0, perform_block_gibbs=False)
+    assert np.array_equal(got["H"], H0)
+    for h in range(2):
+        np.testing.assert_allclose(got[f"alphaHat_t{h + 1}"], ref["alphaHat_t"][h], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(got[f"betaHat_t{h + 1}"], ref["betaHat_t"][h], rtol=RTOL, atol=1e-300)
