@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py -- samples/sec of the QUILT per-sample hot path on MI355X ("Measurement").
+
+One "step" = one batch of synthetic 1x samples taken through the whole per-sample driver (7 + 1 Gibbs
+chains x 3 rounds of [small-panel Gibbs -> full-panel forward/backward per read label -> haplotype
+re-selection], reference defaults) against a synthetic K-haplotype panel.  Samples are independent:
+with N GPUs every rank imputes its own batch (weak scaling), no collective on the data path.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, HIP-event
+timed inside the library on its launch stream) and `cpu_baseline` (the fp64 C oracle pipeline, one
+sample per host core, on a bounded share of the same workload; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNEL_NAMES = ["k_emat", "k_fwd", "k_bwd", "k_dosage+k_topk", "k_ematread", "k_gibbs", "k_happrobs"]
+
+
+def _cpu_worker(args):
+    """One host core: the oracle pipeline for one sample with `chains` of the 8 Gibbs chains."""
+    K, T, seed, n_reads, i, n_gibbs, params = args
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=K, nSNPs=T, seed=seed)
+    s = make_synthetic_sample(panel, seed=1000 + i, n_reads=n_reads)
+    prm = DriverParams(**dict(params, nGibbsSamples=n_gibbs))
+    t0 = time.perf_counter()
+    Driver(panel, OracleBackend(panel), prm).run([s])
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(K, T, n_reads, params, full_chains, budget_s=25.0):
+    """Time the oracle on every host core (one sample each, mirroring mclapply: quilt.R:691-692) with a
+    reduced number of Gibbs chains, then scale by chains: cost is linear in chains (README_QUILT1.md:189-196)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    n_gibbs = 1                                   # 1 Gibbs chain + the phasing chain = 2 of (full_chains) chains
+    # shrink the problem if even that would blow the budget on this host (estimated from cell counts)
+    est = 2 * 3 * (2 * 2.5e-9 * K * (T / 32) * 2 + 21 * 2.5e-8 * n_reads * params["Ksubset"] / 600 * 600)
+    if est > budget_s:
+        return None
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        times = pool.map(_cpu_worker, [(K, T, 4916, n_reads, i, n_gibbs, params) for i in range(cores)])
+    wall = max(times)
+    scale = full_chains / 2.0
+    return dict(value=cores / (wall * scale), unit="samples/sec", cores=cores, kind="port",
+                sample=f"{cores} samples (one per host core), 2 of {full_chains} Gibbs chains each "
+                       f"(nGibbsSamples=1 + phasing pass), scaled x{scale:g}; {wall:.1f} s of CPU wall time")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--K", type=int, default=50000)
+    ap.add_argument("--nsnps", type=int, default=64000)
+    ap.add_argument("--batch", type=int, default=32, help="samples per step per GPU")
+    ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    params = dict(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
+    full_chains = params["nGibbsSamples"] + 1
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.K, a.nsnps, a.reads, params, full_chains)   # before any HIP context exists (fork)
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from quilt_amd import native
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    native.check(native.lib().qa_set_device(local_rank))
+    panel = make_synthetic_panel(K=a.K, nSNPs=a.nsnps, seed=4916)
+    dev = native.DevicePanel(panel)
+    n_steps = a.warmup + a.steps
+    samples = [[make_synthetic_sample(panel, seed=1000 + (rank * n_steps + st) * a.batch + i, n_reads=a.reads)
+                for i in range(a.batch)] for st in range(n_steps)]
+    drv = Driver(panel, HipBackend(dev), DriverParams(**params))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for st in range(a.warmup):
+        drv.run(samples[st])
+    native.lib().qa_profile_reset()
+    drv.timing = {k: 0.0 for k in drv.timing}
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for st in range(a.warmup, n_steps):
+        last = drv.run(samples[st])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        import ctypes as C
+        prof = []
+        for k in range(len(KERNEL_NAMES)):
+            ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+            native.lib().qa_profile_get(k, C.byref(ms), C.byref(n), C.byref(b))
+            prof.append(dict(kernel=KERNEL_NAMES[k], ms=ms.value, launches=n.value, alg_bytes=b.value))
+        dom = max(prof, key=lambda p: p["ms"])
+        ach = dom["alg_bytes"] / 1e9 / (dom["ms"] / 1e3) if dom["ms"] > 0 else 0.0
+        truth = samples[-1][0].truth_haps.sum(axis=0)
+        r2_truth = float(np.corrcoef(last[0].dosage, truth)[0, 1] ** 2)
+        value = a.batch * world * a.steps / elapsed
+        out = {
+            "metric": "samples/sec on 2Mb region, K=50k haps, 1x coverage; dosage r2 vs CPU ref",
+            "value": value, "unit": "samples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (Gibbs) / f32 state, f64 emissions (full-panel pass)",
+            "data": "synthetic",
+            "config": {"workload": f"{a.batch} synthetic 1x short-read samples per GPU per step, {a.nsnps} SNPs "
+                                   f"({panel.nGrids} grids, 2 Mb + buffers), K={a.K} haplotypes, {a.reads} reads/sample, "
+                                   "QUILT defaults (nGibbsSamples=7, n_seek_its=3, Ksubset=600), use_mspbwt=FALSE",
+                       "K": a.K, "nSNPs": a.nsnps, "samples_per_step_per_gpu": a.batch,
+                       "parallelism": f"samples sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
+                         "alg_bytes_per_launch": dom["alg_bytes"] / max(dom["launches"], 1)},
+            "kernels": [{"kernel": p["kernel"], "ms": round(p["ms"], 2), "launches": p["launches"],
+                         "GBps": (p["alg_bytes"] / 1e9 / (p["ms"] / 1e3)) if p["ms"] > 0 else 0.0} for p in prof],
+            "host_seconds": {k: round(v, 3) for k, v in drv.timing.items()},
+            "dosage_r2_vs_truth_sample0": r2_truth,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,13 @@ int qa_device_count(void);
  * in the worker process itself: HIP contexts do not survive fork (quilt.R:692). */
 int qa_set_device(int device);
 
+/* Per-kernel accumulators since the last reset, measured with HIP events on the launch stream
+ * (replaces print_times(), copied-from-stitch.cpp:31-45).  kernel: 0 emission tables, 1 full-panel
+ * forward, 2 full-panel backward, 3 dosage mat-vec + top-K, 4 read emissions, 5 Gibbs sweeps,
+ * 6 hapProbs.  alg_bytes = algorithmic HBM bytes of those launches. */
+int qa_profile_reset(void);
+int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_bytes);
+
 /* ---- prepared reference panel (upload once per process) ------------------ */
 
 typedef struct qa_panel qa_panel_t;
@@ -197,6 +204,20 @@ int qa_gibbs_batch(qa_panel_t *panel, const qa_gibbs_opts_t *opts, int32_t n_cha
                    const double *runif_reads, const int32_t *first_read, const double *runif_shard,
                    int32_t *H, int32_t *H_class, double *hapProbs_t, double *genProbsM_t,
                    double *genProbsF_t, int32_t *underflow_problem, double *state_out);
+
+
+/*
+ * Replaces `_QUILT_rcpp_make_eMatRead_t` (QUILT/src/RcppExports.cpp:15-37; kernel
+ * QUILT/src/copied-from-stitch.cpp:115-229) as the driver uses it: read likelihoods against K = 2-3
+ * dense per-SNP haplotype dosages (calculate_eMatRead_t_vs_haplotypes, QUILT/R/functions.R:2975-3020),
+ * batched over n_chain (sample, haplotype-set) problems.  eHaps: n_chain stacked K x nSNPs matrices
+ * (eHapsCurrent_tc[, , 1]); reads as in qa_gibbs_batch; eMatRead_t: per chain K x R_c, chains
+ * back to back.
+ */
+int qa_rcpp_make_eMatRead_t(qa_panel_t *panel, int32_t n_chain, int32_t K, const double *eHaps,
+                            const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
+                            const int32_t *bq, double maxDifferenceBetweenReads, int32_t Jmax,
+                            int32_t rescale_eMatRead_t, double *eMatRead_t);
 
 #ifdef __cplusplus
 }

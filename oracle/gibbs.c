@@ -687,3 +687,35 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
     free(work); free(n_non1); free(idx_non1); free(cat);
     return status;
 }
+
+/* rcpp_make_eMatRead_t (copied-from-stitch.cpp:115-229) for dense haplotype dosages, run_pseudo_haploid
+ * = false.  eHaps is K x nSNPs (column-major); eMatRead_t K x nReads must be pre-filled with 1. */
+void qo_make_eMatRead_t_dense(const double *eHaps, int K, int nReads, const int32_t *read_ptr, const int32_t *u,
+                              const int32_t *bq, double maxDifferenceBetweenReads, int Jmax,
+                              int rescale_eMatRead_t, double *eMatRead_t)
+{
+    double pR = 1, pA = 1;
+    const double d2 = 1 / maxDifferenceBetweenReads;
+    for (int r = 0; r < nReads; r++) {
+        const int32_t *ru = u + read_ptr[r], *rbq = bq + read_ptr[r];
+        int J = read_ptr[r + 1] - read_ptr[r] - 1;
+        double *col = eMatRead_t + (size_t)K * r;
+        if (J >= Jmax) J = Jmax;
+        for (int j = 0; j <= J; j++) {
+            if (rbq[j] < 0) { double eps = pow(10, (double)rbq[j] / 10); pR = 1 - eps; pA = eps / 3; }
+            if (rbq[j] > 0) { double eps = pow(10, -(double)rbq[j] / 10); pR = eps / 3; pA = 1 - eps; }
+            const double *e = eHaps + (size_t)K * ru[j];
+            for (int k = 0; k < K; k++) col[k] *= (e[k] * pA + (1 - e[k]) * pR);
+        }
+        if (rescale_eMatRead_t) {
+            double x = 0;
+            for (int k = 0; k < K; k++) if (col[k] > x) x = col[k];
+            double d1 = 1 / x;
+            if (isinf(x) || x == 0 || isinf(d1)) {
+                for (int k = 0; k < K; k++) col[k] = 1;
+            } else {
+                for (int k = 0; k < K; k++) { col[k] *= d1; if (col[k] < d2) col[k] = d2; }
+            }
+        }
+    }
+}

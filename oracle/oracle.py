@@ -258,3 +258,14 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
     return dict(status=st, underflow_problem=(st == 1), H=Hout, H_class=Hc, alphaHat_t=mats["alpha"],
                 betaHat_t=mats["beta"], eMatGrid_t=mats["eg"], c=cs, eMatRead_t=eMatRead, read_category=cat,
                 hapProbs_t=hap, genProbsM_t=gm, genProbsF_t=gf)
+
+
+def calculate_eMatRead_t_vs_haplotypes(sample, haps, maxDifferenceBetweenReads, rescale_eMatRead_t=False, Jmax=1000):
+    """``calculate_eMatRead_t_vs_haplotypes`` (functions.R:2975-3020) via the dense ``rcpp_make_eMatRead_t``."""
+    K = len(haps)
+    e = np.asfortranarray(np.stack([np.asarray(h, dtype=np.float64) for h in haps], axis=0))
+    out = np.ones((K, sample.nReads), order="F")
+    lib().qo_make_eMatRead_t_dense(_p(e), C.c_int(K), C.c_int(sample.nReads), _p(sample.read_ptr), _p(sample.u),
+                                   _p(sample.bq), C.c_double(maxDifferenceBetweenReads), C.c_int(Jmax),
+                                   C.c_int(int(rescale_eMatRead_t)), _p(out))
+    return out

@@ -18,6 +18,10 @@ namespace qa {
 void set_error(const char *fmt, ...);
 bool device_ready();
 
+// per-kernel accumulators (HIP-event time on the launch stream, launches, algorithmic HBM bytes)
+enum ProfileKernel { PK_EMAT = 0, PK_FWD, PK_BWD, PK_POST, PK_EMATREAD, PK_GIBBS, PK_HAPPROBS, PK_COUNT };
+void profile_add(int kernel, double ms, double alg_bytes);
+
 struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };

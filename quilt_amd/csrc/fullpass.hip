@@ -694,10 +694,17 @@ struct qa_panel::Scratch {
     qa::DBuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
     qa::DBuf<double> unperm;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t bytes() const {
+        return (gl.n + c.n + dosage.n + escale0.n + unperm.n) * 8 +
+               (emat.n + esp.n + alpha.n + mg.n + gsp.n + gamma.n + beta.n + beta_thin.n + top_val.n) * 4 +
+               (thin_col.n + flags.n + alpha_slot.n + top_cnt.n + top_idx.n) * 4;
+    }
     ~Scratch() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
+
+size_t qa_panel::scratch_bytes() const { return scratch ? scratch->bytes() : 0; }
 
 qa_panel::~qa_panel() {
     delete scratch;
@@ -747,10 +754,8 @@ struct BatchOut {
     double *gamma_t = nullptr;
     double *gammaSmall_t = nullptr;
     bool gamma_small_unscaled = false;  // gammaSmall_t without return_gamma_t: no sigma factor (:2170-2176)
-    int32_t *best_ptr = nullptr;
-    int32_t *best_idx = nullptr;
-    double *best_val = nullptr;
-    int64_t best_cap = 0;
+    // best_haps_stuff_list of every (pass, thinned column), appended in pass-major order
+    std::vector<std::vector<std::pair<int32_t, float>>> *lists = nullptr;
 };
 
 // runs P passes; flags per pass as in PassParams
@@ -879,6 +884,20 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     }
     QA_HIP(hipEventElapsedTime(&ms, S.ev[0], S.ev[4]));
     g_timing[4] = ms;
+    {
+        // algorithmic HBM bytes of this launch set: per cell 1 B code + 4 B alpha on
+        // every stored column, forward (store) and backward (load) alike
+        double cells_all = 0, cells_thin = 0;
+        for (int p = 0; p < P; p++) {
+            if (h_flags[p] & 15) cells_all += (double)K * G; else cells_thin += (double)K * G;
+        }
+        const double frac = G > 0 ? (double)n_thin / G : 0;
+        const double per_dir = cells_all * 5.0 + cells_thin * (1.0 + 4.0 * frac);
+        qa::profile_add(qa::PK_EMAT, g_timing[0], 0);
+        qa::profile_add(qa::PK_FWD, g_timing[1], per_dir);
+        qa::profile_add(qa::PK_BWD, g_timing[2], per_dir);
+        qa::profile_add(qa::PK_POST, g_timing[3], 0);
+    }
 
     // ---- copy results back
     if (out.c) S.c.download(out.c, (size_t)P * G, st);
@@ -925,32 +944,19 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         }
     }
     int status = QA_OK;
-    if (any_top && out.best_ptr) {
+    if (any_top && out.lists) {
         const size_t n = (size_t)P * n_thin;
         std::vector<int32_t> idx(n * top_cap);
         std::vector<float> val(n * top_cap);
         S.top_idx.download(idx.data(), idx.size(), st);
         S.top_val.download(val.data(), val.size(), st);
         QA_HIP(hipStreamSynchronize(st));
-        int64_t total = 0;
-        out.best_ptr[0] = 0;
         for (size_t i = 0; i < n; i++) {
-            total += cnt[i];
-            out.best_ptr[i + 1] = (int32_t)total;
-        }
-        if (total > out.best_cap || !out.best_idx || !out.best_val) {
-            qa::set_error("best-haps capacity %lld < needed %lld", (long long)out.best_cap, (long long)total);
-            status = QA_ERR_CAPACITY;
-        } else {
             std::vector<std::pair<int32_t, float>> tmp;
-            for (size_t i = 0; i < n; i++) {
-                tmp.clear();
-                for (int q = 0; q < cnt[i]; q++) tmp.emplace_back(idx[i * top_cap + q], val[i * top_cap + q]);
-                std::sort(tmp.begin(), tmp.end());  // ascending k, the reference's emission order
-                int32_t *oi = out.best_idx + out.best_ptr[i];
-                double *ov = out.best_val + out.best_ptr[i];
-                for (size_t q = 0; q < tmp.size(); q++) { oi[q] = tmp[q].first; ov[q] = (double)tmp[q].second; }
-            }
+            tmp.reserve(cnt[i]);
+            for (int q = 0; q < cnt[i]; q++) tmp.emplace_back(idx[i * top_cap + q], val[i * top_cap + q]);
+            std::sort(tmp.begin(), tmp.end());  // ascending k, the reference's emission order
+            out.lists->push_back(std::move(tmp));
         }
     }
     QA_HIP(hipStreamSynchronize(st));
@@ -964,6 +970,28 @@ extern "C" {
 int qa_last_fullpass_timing_ms(double out[5]) {
     if (!out) return QA_ERR_INVALID;
     for (int i = 0; i < 5; i++) out[i] = g_timing[i];
+    return QA_OK;
+}
+
+// pack best-haps lists into the caller's CSR arrays
+static int pack_lists(const std::vector<std::vector<std::pair<int32_t, float>>> &lists, int32_t *best_ptr,
+                      int32_t *best_idx, double *best_val, int64_t best_cap) {
+    if (!best_ptr) return QA_OK;
+    int64_t total = 0;
+    best_ptr[0] = 0;
+    for (size_t i = 0; i < lists.size(); i++) {
+        total += (int64_t)lists[i].size();
+        best_ptr[i + 1] = (int32_t)total;
+    }
+    if (total > best_cap || !best_idx || !best_val) {
+        qa::set_error("best-haps capacity %lld < needed %lld", (long long)best_cap, (long long)total);
+        return QA_ERR_CAPACITY;
+    }
+    for (size_t i = 0; i < lists.size(); i++)
+        for (size_t q = 0; q < lists[i].size(); q++) {
+            best_idx[best_ptr[i] + q] = lists[i][q].first;
+            best_val[best_ptr[i] + q] = (double)lists[i][q].second;
+        }
     return QA_OK;
 }
 
@@ -997,11 +1025,12 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         out.gamma_t = o->return_gamma_t ? gamma_t : nullptr;
         out.gammaSmall_t = o->return_gammaSmall_t ? gammaSmall_t : nullptr;
         out.gamma_small_unscaled = !o->return_gamma_t;
-        if (o->get_best_haps_from_thinned_sites) {
-            out.best_ptr = best_ptr; out.best_idx = best_idx; out.best_val = best_val; out.best_cap = best_cap;
-        }
-        return run_passes(panel, 1, gl, &f, thin.data(),
-                          o->get_best_haps_from_thinned_sites ? o->K_top_matches : 0, o->normalize_emissions, out);
+        std::vector<std::vector<std::pair<int32_t, float>>> lists;
+        if (o->get_best_haps_from_thinned_sites) out.lists = &lists;
+        int st = run_passes(panel, 1, gl, &f, thin.data(),
+                            o->get_best_haps_from_thinned_sites ? o->K_top_matches : 0, o->normalize_emissions, out);
+        if (st != QA_OK || !o->get_best_haps_from_thinned_sites) return st;
+        return pack_lists(lists, best_ptr, best_idx, best_val, best_cap);
     });
 }
 
@@ -1016,10 +1045,41 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
     return qa::guarded([&] {
         std::vector<int32_t> f(n_pass);
         for (int i = 0; i < n_pass; i++) f[i] = want_dosage[i] ? 1 : 0;
-        BatchOut out;
-        out.dosage = dosage;
-        out.best_ptr = best_ptr; out.best_idx = best_idx; out.best_val = best_val; out.best_cap = best_cap;
-        return run_passes(panel, n_pass, gl, f.data(), gammaSmall_cols_to_get, K_top_matches, 1, out);
+        // chunk the passes so that the alpha checkpoints fit in free HBM (K = 50 000, G = 2 000: 0.4 GB
+        // per dosage pass, 0.04 GB per thin pass)
+        const Geometry geo = pick_geometry(panel->K);
+        const int G = panel->G, T = panel->T;
+        int n_thin = 0;
+        for (int g = 0; g < G; g++) n_thin = std::max(n_thin, gammaSmall_cols_to_get[g] + 1);
+        size_t free_b = 0, total_b = 0;
+        QA_HIP(hipSetDevice(panel->device));
+        QA_HIP(hipMemGetInfo(&free_b, &total_b));
+        size_t have = free_b + (panel->scratch ? panel->scratch_bytes() : 0);
+        const size_t Kq = (size_t)geo.NT * geo.NCH * 16;
+        const size_t per_dosage = Kq * 4 * ((size_t)G + n_thin) + (size_t)G * 256 * 8 + (size_t)T * 32;
+        const size_t per_thin = Kq * 4 * (2 * (size_t)std::max(n_thin, 1)) + (size_t)G * 256 * 8 + (size_t)T * 32;
+        std::vector<std::vector<std::pair<int32_t, float>>> lists;
+        int done = 0;
+        int status = QA_OK;
+        while (done < n_pass && status == QA_OK) {
+            size_t used = 0;
+            int n = 0;
+            const bool dos = f[done] != 0;  // homogeneous chunks: a mixed chunk would size every pass as a dosage pass
+            while (done + n < n_pass && (f[done + n] != 0) == dos) {
+                const size_t need = dos ? per_dosage : per_thin;
+                if (n > 0 && used + need > have * 8 / 10) break;
+                used += need;
+                n++;
+            }
+            BatchOut out;
+            out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
+            out.lists = &lists;
+            status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, gammaSmall_cols_to_get,
+                                K_top_matches, 1, out);
+            done += n;
+        }
+        if (status != QA_OK) return status;
+        return pack_lists(lists, best_ptr, best_idx, best_val, best_cap);
     });
 }
 

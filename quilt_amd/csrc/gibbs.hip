@@ -21,9 +21,11 @@
 //     lets the sampled read labels match the CPU path under the same uniforms.
 //   * the uniforms the reference draws from R's RNG are inputs.
 //
-// Block Gibbs: for diploid samples `Rcpp_block_gibbs_resampler` is the identity (its label-3 terms
-// are NaN, nothing is ever relabelled and the final backward reproduces beta: see oracle/gibbs.c
-// header for the derivation); the shard resampler is the active step and is implemented here.
+// Block Gibbs: for diploid samples `Rcpp_block_gibbs_resampler` (gibbs-nipt-block.cpp:1636-1967) is the
+// identity: c3 is all zero (gibbs-nipt.cpp:2678), so logC_after(2) is -inf and then NaN (:1819-1821,
+// :1896-1898), every choice_log_probs entry is NaN (:661-675), ir_chosen stays 0 (:741-752), the
+// "No change warranted" branch is taken (:830) and the final backward (:1947-1954) reproduces the beta
+// the sweep already holds.  The shard resampler is the active step and is implemented here.
 // NIPT (ff > 0) block Gibbs is not implemented yet (QA_ERR_UNSUPPORTED).
 #include "panel.hpp"
 
@@ -731,6 +733,58 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_ematread_dense: `rcpp_make_eMatRead_t` (copied-from-stitch.cpp:115-229) for dense per-SNP
+// haplotype dosages (the 2-3 "haplotypes" of calculate_eMatRead_t_vs_haplotypes, functions.R:2975-3020).
+// One thread per (read, chain): K is 2 or 3, the products run over the read's bases in order.
+// ---------------------------------------------------------------------------------------------
+struct DenseParams {
+    int C, K, T, Jmax, rescale;
+    double inv_maxdiff;
+    const double *eHaps;      // [C][T][K]
+    const int32_t *read_off, *read_ptr, *base_off, *u, *bq;
+    const double *pR_tab, *pA_tab;
+    double *out;              // [sum R][K]
+};
+
+__global__ __launch_bounds__(64) void k_ematread_dense(DenseParams p) {
+    const int c = blockIdx.y;
+    const int R = p.read_off[c + 1] - p.read_off[c];
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    const int32_t *rp = p.read_ptr + p.read_off[c] + c;
+    const int32_t *u = p.u + p.base_off[c], *bq = p.bq + p.base_off[c];
+    const double *eh = p.eHaps + (size_t)c * p.T * p.K;
+    double v[3] = {1, 1, 1};
+    const int s = rp[r];
+    int J = rp[r + 1] - s - 1;
+    if (J >= p.Jmax) J = p.Jmax;
+    for (int j = 0; j <= J; j++) {
+        const int b = bq[s + j];
+        if (b == 0) continue;
+        const int ab = b < 0 ? -b : b;
+        const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
+        const double *e = eh + (size_t)u[s + j] * p.K;
+        for (int k = 0; k < p.K; k++) v[k] *= (e[k] * pA + (1 - e[k]) * pR);
+    }
+    if (p.rescale) {
+        double x = 0;
+        for (int k = 0; k < p.K; k++) if (v[k] > x) x = v[k];
+        const double d1 = 1 / x;
+        if (isinf(x) || x == 0 || isinf(d1)) {
+            for (int k = 0; k < p.K; k++) v[k] = 1;
+        } else {
+            for (int k = 0; k < p.K; k++) {
+                v[k] *= d1;
+                if (v[k] < p.inv_maxdiff) v[k] = p.inv_maxdiff;
+            }
+        }
+    }
+    double *o = p.out + (size_t)(p.read_off[c] + r) * p.K;
+    for (int k = 0; k < p.K; k++) o[k] = v[k];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -749,20 +803,59 @@ struct GibbsScratch {
 
 struct GibbsHolder {
     qa::GibbsScratch s;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
 
 thread_local std::unique_ptr<GibbsHolder> g_gibbs;
 
+// the reference carries pR / pA over bases with bq == 0, even across reads (gibbs-small.cpp:139-181,
+// copied-from-stitch.cpp:139-175): fold that rule into an "effective" base quality (input marshalling)
+void fold_zero_base_qualities(std::vector<int32_t> &bq_eff, int C, const int32_t *read_off, const int32_t *read_ptr,
+                              const std::vector<int32_t> &base_off, int Jmax) {
+    for (int c = 0; c < C; c++) {
+        const int R = read_off[c + 1] - read_off[c];
+        const int32_t *rp = read_ptr + read_off[c] + c;
+        int last = 0;
+        for (int r = 0; r < R; r++) {
+            int J = rp[r + 1] - rp[r] - 1;
+            if (J >= Jmax) J = Jmax;
+            for (int j = 0; j <= J; j++) {
+                int32_t &b = bq_eff[(size_t)base_off[c] + rp[r] + j];
+                if (b == 0) b = last; else last = b;
+                if (b > 255 || b < -255) throw std::runtime_error("|base quality| > 255");
+            }
+        }
+    }
+}
+
+// eps tables with the host libm (what the reference's pow() is), so the device needs no pow:
+// [0..255] pR for bq < 0, [256..511] pR for bq > 0, [512..767] pA for bq < 0, [768..1023] pA for bq > 0
+std::vector<double> base_quality_tables() {
+    std::vector<double> tabs(4 * 256);
+    for (int q = 0; q < 256; q++) {
+        const double en = std::pow(10, (double)(-q) / 10), ep = std::pow(10, -(double)q / 10);
+        tabs[q] = 1 - en;
+        tabs[256 + q] = ep / 3;
+        tabs[512 + q] = en / 3;
+        tabs[768 + q] = 1 - ep;
+    }
+    return tabs;
+}
+
 template <int NE>
-void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st) {
+void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev) {
+    QA_HIP(hipEventRecord(ev[0], st));
     hipLaunchKernelGGL(k_ematread<NE>, dim3(maxR, prm.C), dim3(64), 0, st, prm);
     QA_HIP(hipGetLastError());
+    QA_HIP(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(k_gibbs<NE>, dim3(prm.C), dim3(64), 0, st, prm);
     QA_HIP(hipGetLastError());
+    QA_HIP(hipEventRecord(ev[2], st));
     hipLaunchKernelGGL(k_happrobs, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
     QA_HIP(hipGetLastError());
+    QA_HIP(hipEventRecord(ev[3], st));
 }
 
 }  // namespace
@@ -823,32 +916,9 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
             }
         }
         const int totB = base_off[C];
-        // the reference carries pR / pA over bases with bq == 0, even across reads (gibbs-small.cpp:139-181):
-        // fold that rule into an "effective" base quality here (input marshalling, O(bases))
         bq_eff.assign(bq, bq + totB);
-        for (int c = 0; c < C; c++) {
-            const int R = read_off[c + 1] - read_off[c];
-            const int32_t *rp = read_ptr + read_off[c] + c;
-            int last = 0;
-            for (int r = 0; r < R; r++) {
-                int J = rp[r + 1] - rp[r] - 1;
-                if (J >= o->Jmax) J = o->Jmax;
-                for (int j = 0; j <= J; j++) {
-                    int32_t &b = bq_eff[(size_t)base_off[c] + rp[r] + j];
-                    if (b == 0) b = last; else last = b;
-                    if (b > 255 || b < -255) throw std::runtime_error("|base quality| > 255");
-                }
-            }
-        }
-        // eps tables with the host libm (what the reference's pow() is), so the device needs no pow
-        std::vector<double> tabs(4 * 256);
-        for (int q = 0; q < 256; q++) {
-            const double en = std::pow(10, (double)(-q) / 10), ep = std::pow(10, -(double)q / 10);
-            tabs[q] = 1 - en;          // pR, bq < 0
-            tabs[256 + q] = ep / 3;    // pR, bq > 0
-            tabs[512 + q] = en / 3;    // pA, bq < 0
-            tabs[768 + q] = 1 - ep;    // pA, bq > 0
-        }
+        fold_zero_base_qualities(bq_eff, C, read_off, read_ptr, base_off, o->Jmax);
+        const std::vector<double> tabs = base_quality_tables();
         std::vector<double> tm((size_t)2 * std::max(G - 1, 1));
         for (int g = 0; g < G - 1; g++) { tm[g] = pn->h_sigma[g]; tm[(size_t)G - 1 + g] = pn->h_tm1[g]; }
 
@@ -902,19 +972,20 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         prm.H = S.H.p; prm.H_class = S.H_class.p; prm.status = S.status.p;
         prm.hapProbs = S.hap.p; prm.genProbsM = S.gm.p; prm.genProbsF = S.gf.p;
 
+        for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
         switch (NE) {
-            case 1: launch_gibbs<1>(prm, maxR, st); break;
-            case 2: launch_gibbs<2>(prm, maxR, st); break;
-            case 3: launch_gibbs<3>(prm, maxR, st); break;
-            case 4: launch_gibbs<4>(prm, maxR, st); break;
-            case 5: launch_gibbs<5>(prm, maxR, st); break;
-            case 6: launch_gibbs<6>(prm, maxR, st); break;
-            case 7: launch_gibbs<7>(prm, maxR, st); break;
-            case 8: launch_gibbs<8>(prm, maxR, st); break;
-            case 9: launch_gibbs<9>(prm, maxR, st); break;
-            case 10: launch_gibbs<10>(prm, maxR, st); break;
-            case 12: launch_gibbs<12>(prm, maxR, st); break;
-            case 16: launch_gibbs<16>(prm, maxR, st); break;
+            case 1: launch_gibbs<1>(prm, maxR, st, g_gibbs->ev); break;
+            case 2: launch_gibbs<2>(prm, maxR, st, g_gibbs->ev); break;
+            case 3: launch_gibbs<3>(prm, maxR, st, g_gibbs->ev); break;
+            case 4: launch_gibbs<4>(prm, maxR, st, g_gibbs->ev); break;
+            case 5: launch_gibbs<5>(prm, maxR, st, g_gibbs->ev); break;
+            case 6: launch_gibbs<6>(prm, maxR, st, g_gibbs->ev); break;
+            case 7: launch_gibbs<7>(prm, maxR, st, g_gibbs->ev); break;
+            case 8: launch_gibbs<8>(prm, maxR, st, g_gibbs->ev); break;
+            case 9: launch_gibbs<9>(prm, maxR, st, g_gibbs->ev); break;
+            case 10: launch_gibbs<10>(prm, maxR, st, g_gibbs->ev); break;
+            case 12: launch_gibbs<12>(prm, maxR, st, g_gibbs->ev); break;
+            case 16: launch_gibbs<16>(prm, maxR, st, g_gibbs->ev); break;
             default: throw std::runtime_error("Ksubset geometry not built (NE must be 1..10, 12 or 16)");
         }
         S.H.download(H, totR, st);
@@ -925,6 +996,18 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         if (genProbsM_t) S.gm.download(genProbsM_t, (size_t)C * T * 3, st);
         if (genProbsF_t) S.gf.download(genProbsF_t, (size_t)C * T * 3, st);
         QA_HIP(hipStreamSynchronize(st));
+        {
+            float ms[3];
+            for (int i = 0; i < 3; i++) QA_HIP(hipEventElapsedTime(&ms[i], g_gibbs->ev[i], g_gibbs->ev[i + 1]));
+            // algorithmic bytes: per sweep and label 6 column streams of Ks x G fp64, plus every
+            // read's emission column once per sweep; initialisation and each shard pass ~ one sweep without reads
+            const double col = 2.0 * Ks * (double)G * 48.0;
+            const double sweeps = (double)n_its * (C * col + (double)totR * Ks * 8.0) +
+                                  (1.0 + 2.0 * prm.n_block) * C * col;
+            qa::profile_add(qa::PK_EMATREAD, ms[0], (double)totR * Ks * 8.0);
+            qa::profile_add(qa::PK_GIBBS, ms[1], sweeps);
+            qa::profile_add(qa::PK_HAPPROBS, ms[2], C * 2.0 * Ks * (double)G * 16.0);
+        }
         int rc = QA_OK;
         for (int c = 0; c < C; c++) {
             if (underflow_problem) underflow_problem[c] = status[c];
@@ -946,6 +1029,49 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
             QA_HIP(hipMemcpy(state_out + o2, S.cvec.p, sizeof(double) * 3 * G, hipMemcpyDeviceToHost));
         }
         return rc;
+    });
+}
+
+
+int qa_rcpp_make_eMatRead_t(qa_panel_t *pn, int32_t n_chain, int32_t K, const double *eHaps, const int32_t *read_off,
+                            const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                            double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                            double *eMatRead_t) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!pn || n_chain <= 0 || K < 1 || K > 3 || !eHaps || !read_off || !read_ptr || !u || !bq || !eMatRead_t) {
+        qa::set_error("qa_rcpp_make_eMatRead_t: bad argument");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(pn->device));
+        hipStream_t st = pn->stream;
+        const int C = n_chain, T = pn->T;
+        std::vector<int32_t> base_off(C + 1, 0);
+        int maxR = 0;
+        for (int c = 0; c < C; c++) {
+            const int R = read_off[c + 1] - read_off[c];
+            maxR = std::max(maxR, R);
+            base_off[c + 1] = base_off[c] + (read_ptr + read_off[c] + c)[R];
+        }
+        const int totR = read_off[C], totB = base_off[C];
+        std::vector<int32_t> bq_eff(bq, bq + totB);
+        fold_zero_base_qualities(bq_eff, C, read_off, read_ptr, base_off, Jmax);
+        const std::vector<double> tabs = base_quality_tables();
+        qa::DBuf<double> d_e((size_t)C * T * K), d_tabs(tabs.size()), d_out(std::max<size_t>((size_t)totR * K, 1));
+        qa::DBuf<int32_t> d_ro(C + 1), d_rp(totR + C), d_bo(C + 1), d_u(std::max(totB, 1)), d_bq(std::max(totB, 1));
+        d_e.upload(eHaps, (size_t)C * T * K, st); d_tabs.upload(tabs.data(), tabs.size(), st);
+        d_ro.upload(read_off, C + 1, st); d_rp.upload(read_ptr, totR + C, st); d_bo.upload(base_off.data(), C + 1, st);
+        d_u.upload(u, totB, st); d_bq.upload(bq_eff.data(), totB, st);
+        DenseParams prm{};
+        prm.C = C; prm.K = K; prm.T = T; prm.Jmax = Jmax; prm.rescale = rescale_eMatRead_t;
+        prm.inv_maxdiff = 1 / maxDifferenceBetweenReads; prm.eHaps = d_e.p; prm.read_off = d_ro.p;
+        prm.read_ptr = d_rp.p; prm.base_off = d_bo.p; prm.u = d_u.p; prm.bq = d_bq.p;
+        prm.pR_tab = d_tabs.p; prm.pA_tab = d_tabs.p + 512; prm.out = d_out.p;
+        hipLaunchKernelGGL(k_ematread_dense, dim3((maxR + 63) / 64, C), dim3(64), 0, st, prm);
+        QA_HIP(hipGetLastError());
+        d_out.download(eMatRead_t, (size_t)totR * K, st);
+        QA_HIP(hipStreamSynchronize(st));
+        return QA_OK;
     });
 }
 

@@ -53,9 +53,32 @@ static int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, in
     return mat[(size_t)nrow + s1];
 }
 
+struct ProfileSlot { double ms = 0, bytes = 0; long long launches = 0; };
+static ProfileSlot g_profile[PK_COUNT];
+
+void profile_add(int kernel, double ms, double alg_bytes) {
+    if (kernel < 0 || kernel >= PK_COUNT) return;
+    g_profile[kernel].ms += ms;
+    g_profile[kernel].bytes += alg_bytes;
+    g_profile[kernel].launches += 1;
+}
+
 }  // namespace qa
 
 extern "C" {
+
+int qa_profile_reset(void) {
+    for (auto &s : qa::g_profile) s = qa::ProfileSlot();
+    return QA_OK;
+}
+
+int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_bytes) {
+    if (kernel < 0 || kernel >= qa::PK_COUNT) return QA_ERR_INVALID;
+    if (ms) *ms = qa::g_profile[kernel].ms;
+    if (launches) *launches = qa::g_profile[kernel].launches;
+    if (alg_bytes) *alg_bytes = qa::g_profile[kernel].bytes;
+    return QA_OK;
+}
 
 int qa_abi_version(void) { return 1; }
 

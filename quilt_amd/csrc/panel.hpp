@@ -31,5 +31,6 @@ struct qa_panel {
     // scratch owned by the panel handle, grown on demand (see fullpass.hip)
     struct Scratch;
     Scratch *scratch = nullptr;
+    size_t scratch_bytes() const;
     ~qa_panel();
 };

@@ -1,0 +1,448 @@
+"""Per-sample driver loop: host-side mirror of ``get_and_impute_one_sample`` (QUILT/R/functions.R:3-1500),
+``impute_using_everything`` (:1922-2157) and their helpers, restructured for a GPU.
+
+The reference walks one sample at a time through ``(nGibbsSamples + 1) x n_seek_its`` rounds of
+[small-panel Gibbs -> full-panel pass per read label -> choose new haplotypes].  The Gibbs samples
+of one sample are independent until the consensus "phasing" pass (functions.R:1170-1205), and
+samples are independent of each other, so this driver advances *all chains of a batch of samples in
+lock-step*: every round is ONE batched Gibbs launch set and ONE batched full-pass launch set over
+``n_samples x nGibbsSamples`` chains (then ``n_samples`` chains for the phasing pass).  The host keeps
+only what the reference keeps on the R side: read labels, haplotype subsets, the selection logic and
+the dosage / genotype-probability accumulators.
+
+The compute is delegated to a *backend* (``gibbs_batch`` / ``fullpass_batch``): the product backend is
+:class:`HipBackend` (the C-ABI HIP library; no fallback).  Tests plug in a CPU-oracle backend to check
+the whole pipeline.
+
+R's Mersenne-Twister stream cannot be reproduced without R; every random draw the reference makes
+(functions.R:580, 584, 746, 2294, 2301; gibbs-nipt.cpp:2845-2848; gibbs-nipt-block.cpp:2054) comes
+from a counter-based stream keyed by (seed, sample, chain) -- see :func:`chain_rng`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class DriverParams:
+    """Defaults of ``QUILT()`` (QUILT/R/quilt.R:97-186) for the arguments the hot path sees."""
+
+    nGibbsSamples: int = 7
+    n_seek_its: int = 3
+    n_burn_in_seek_its: Optional[int] = None      # NA -> n_seek_its - 1 (quilt.R:248-250)
+    Ksubset: int = 600
+    Knew: int = 600
+    K_top_matches: int = 5
+    heuristic_match_thin: float = 0.1
+    small_ref_panel_gibbs_iterations: int = 20
+    n_gibbs_sample_its: int = 1
+    small_ref_panel_block_gibbs_iterations: Sequence[int] = (3, 6, 9)
+    maxDifferenceBetweenReads: float = 1e10
+    minGLValue: float = 1e-10
+    Jmax: int = 10000
+    seed: int = 1
+
+    def resolved(self, K: int) -> "DriverParams":
+        p = DriverParams(**self.__dict__)
+        if p.n_burn_in_seek_its is None:
+            p.n_burn_in_seek_its = p.n_seek_its - 1
+        if K < p.Ksubset:                           # quilt.R:453-463
+            p.n_seek_its, p.n_burn_in_seek_its, p.Ksubset, p.Knew = 1, 0, K, K
+        if p.Knew > p.Ksubset:                      # quilt.R:467-471
+            p.Knew = p.Ksubset
+        return p
+
+
+def thinned_grid_columns(nGrids: int, heuristic_match_thin: float) -> np.ndarray:
+    """``full_gammaSmall_cols_to_get`` (quilt.R:719-721): R's ``seq(1, nGrids, length.out = n)`` used as
+    an index vector (fractional indices truncate)."""
+    n = max(1, int(round(heuristic_match_thin * nGrids)))
+    ww = np.linspace(1, nGrids, n) if n > 1 else np.array([1.0])
+    idx = np.floor(ww + 1e-9).astype(np.int64) - 1
+    cols = np.full(nGrids, -1, dtype=np.int32)
+    for i, g in enumerate(idx):   # later duplicates overwrite, as R's assignment would
+        cols[g] = i
+    # R: cols[ww] <- 0:(n-1); duplicated indices keep the last value, unused column numbers vanish.
+    # Re-number densely so that column ids are 0..n_thin-1 in grid order (what the kernels expect).
+    used = np.nonzero(cols >= 0)[0]
+    cols[used] = np.arange(len(used), dtype=np.int32)
+    return cols
+
+
+def chain_rng(seed: int, i_sample: int, i_chain: int) -> np.random.Generator:
+    """Counter-based stream of one (sample, Gibbs chain): Philox keyed by the triple."""
+    return np.random.Generator(np.random.Philox(key=[(seed << 20) ^ i_sample, i_chain]))
+
+
+# ---------------------------------------------------------------------------------------------
+# host logic restated from the R driver
+# ---------------------------------------------------------------------------------------------
+
+def make_gl_from_u_bq(u: np.ndarray, bq: np.ndarray, nSNPs: int, minGLValue: float, make_gl_bound) -> np.ndarray:
+    """reference-single.R:19-42: per-label genotype likelihoods from the reads' bases (host code in the
+    reference too); ``make_gl_bound`` is the native ``Rcpp_make_gl_bound``."""
+    gl = np.ones((2, nSNPs), dtype=np.float64, order="F")
+    if len(u) == 0:
+        return gl
+    eps = 10.0 ** (-np.abs(bq) / 10.0)
+    ref = bq < 0
+    pR = np.where(ref, 1 - eps, eps / 3)
+    pA = np.where(ref, eps / 3, 1 - eps)
+    np.multiply.at(gl[0], u, pR)
+    np.multiply.at(gl[1], u, pA)
+    if minGLValue > 0:
+        to_fix = np.nonzero((gl < minGLValue).any(axis=0))[0].astype(np.int32)
+        if len(to_fix):
+            make_gl_bound(gl, minGLValue, to_fix)
+    return gl
+
+
+def everything_per_hap_rejig_haps(best_haps_stuff_list) -> List[np.ndarray]:
+    """functions.R:2161-2170: per thinned grid, 1-based haplotypes by descending value (stable)."""
+    out = []
+    for x in best_haps_stuff_list:
+        tm = np.asarray(x["top_matches"]) + 1
+        order = np.argsort(-np.asarray(x["top_matches_values"]), kind="stable")
+        out.append(tm[order])
+    return out
+
+
+def _unique_in_order(a: np.ndarray) -> np.ndarray:
+    _, idx = np.unique(a, return_index=True)
+    return a[np.sort(idx)]
+
+
+def everything_select_good_haps(Knew: int, K_top_matches: int, new_haps: List[List[np.ndarray]],
+                                previously_selected_haplotypes: np.ndarray, K: int,
+                                rng: np.random.Generator) -> np.ndarray:
+    """functions.R:2262-2310.  ``new_haps[label][thinned grid]`` = 1-based haplotypes, best first."""
+    i = 1
+    to_keep = np.zeros(0, dtype=np.int64)
+    prev = np.asarray(previously_selected_haplotypes, dtype=np.int64)
+    done = False
+    while not done:
+        if i <= K_top_matches:
+            vals = [y[i - 1] for x in new_haps for y in x if len(y) >= i]
+            new = _unique_in_order(np.asarray(vals, dtype=np.int64)) if vals else np.zeros(0, dtype=np.int64)
+        else:
+            allv = [y for x in new_haps for y in x]
+            new = _unique_in_order(np.concatenate(allv).astype(np.int64)) if allv else np.zeros(0, dtype=np.int64)
+            done = True
+        new = new[~np.isin(new, prev)]
+        new = new[~np.isin(new, to_keep)]
+        if len(new) < Knew - len(to_keep):
+            to_keep = np.concatenate([to_keep, new])
+            i += 1
+        else:
+            toadd = Knew - len(to_keep)
+            pick = rng.permutation(len(new))[:toadd]
+            to_keep = np.concatenate([to_keep, new[pick]])
+            done = True
+    if len(to_keep) < Knew:
+        pool = np.setdiff1d(np.arange(1, K + 1), np.concatenate([to_keep, prev]))
+        extra = pool[rng.permutation(len(pool))[: Knew - len(to_keep)]]
+        to_keep = np.concatenate([to_keep, extra])
+    if len(to_keep) != Knew:
+        raise RuntimeError("Have returned too many haps")
+    return to_keep.astype(np.int32)
+
+
+def assess_ability_of_reads_to_be_confident(p: np.ndarray, minrp: float = 0.95) -> np.ndarray:
+    """functions.R:1615-1660 (diploid): ``p`` = 2 x nReads read likelihoods against (hap1, hap2)."""
+    p1, p2 = p[0], p[1]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mp = p1 / (p1 + p2)
+    mp[np.isnan(mp)] = 0.5
+    mp = np.where(mp < 0.5, 1 - mp, mp)
+    return mp > minrp
+
+
+def determine_best_read_label_so_far(read_label_matrix_all: np.ndarray, read_label_matrix_conf: np.ndarray,
+                                     nReads: int, nGibbsSamples: int, can_hap: int) -> np.ndarray:
+    """functions.R:1680-1784, line by line (including that the final flips start at the LAST change point,
+    counted in the filtered row space: ``w <- s1[i]:nReads`` with the leftover loop variable)."""
+    rl = read_label_matrix_all.astype(np.int64).copy()
+    default = rl[:, can_hap - 1].astype(np.int32)
+    a = rl.astype(np.float64)
+    a[~read_label_matrix_conf] = np.nan
+    a = a[~np.isnan(a).any(axis=1)]
+    if a.shape[0] < 10:
+        return default
+    can = a[:, can_hap - 1].copy()
+    a = a - can[:, None]
+    s = np.nonzero(np.diff(np.abs(a).sum(axis=1)) != 0)[0] + 1  # R's which(), 1-based
+    if len(s) == 0:
+        return default
+    s1 = np.concatenate([[1], s + 1])
+    e1 = np.concatenate([s1[1:] - 1, [a.shape[0]]])
+    flip = np.zeros((len(s1), nGibbsSamples), dtype=bool)
+    nrow = a.shape[0]
+    for i in range(2, len(s1) + 1):           # R: for(i in 2:length(s1))
+        cur = a[s1[i - 1] - 1, :]
+        changed = np.nonzero(cur != 0)[0]     # 0-based columns
+        w = np.arange(s1[i - 1] - 1, nrow)
+        if len(changed) > 0:
+            if len(changed) <= nGibbsSamples / 2:
+                for c1 in changed:
+                    reverted = 3 - (a[w, c1] + can[w])
+                    a[w, c1] = reverted - can[w]
+            else:
+                changed = np.nonzero(cur == 0)[0]
+                for c1 in changed:
+                    reverted = 3 - (a[w, c1] + can[w])
+                    a[w, c1] = reverted - can[w]
+                reverted = a[w, :] + can[w][:, None]
+                can[w] = 3 - can[w]
+                a[w, :] = reverted - can[w][:, None]
+        flip[i - 1, changed] = True
+    i_last = len(s1)                          # value of R's `i` after the loop
+    for col in range(nGibbsSamples):
+        if flip[:, col].any():
+            w0 = s1[i_last - 1] - 1           # s1[i], 1-based -> 0-based row of the read matrix
+            if w0 < nReads:
+                rl[w0:nReads, col] = 3 - rl[w0:nReads, col]
+    return rl[:, can_hap - 1].astype(np.int32)
+
+
+def recast_haps(hd1: np.ndarray, hd2: np.ndarray, gp: np.ndarray):
+    """functions.R:3180-3209: make the phased haplotype dosages agree with argmax genotype probability.
+    ``gp`` is nSNPs x 3."""
+    hd1 = hd1.copy()
+    hd2 = hd2.copy()
+    r_round = lambda x: np.round(x)  # R rounds half to even, as numpy does
+    gt1 = r_round(hd1) + r_round(hd2)
+    max_val = gp[:, 0].copy()
+    gt3 = np.zeros(len(hd1))
+    for i in (1, 2):
+        w = gp[:, i] > max_val
+        gt3[w] = i
+        max_val[w] = gp[w, i]
+    ch = gt3 != gt1
+    z = ch & (gt3 == 0)
+    hd1[z] = 0; hd2[z] = 0
+    t = ch & (gt3 == 2)
+    hd1[t] = 1; hd2[t] = 1
+    o = ch & (gt3 == 1)
+    a1, a2 = hd1[o].copy(), hd2[o].copy()
+    hd1[o] = np.where(a1 > a2, 1.0, 0.0)
+    hd2[o] = np.where(a1 > a2, 0.0, 1.0)
+    return hd1, hd2
+
+
+# ---------------------------------------------------------------------------------------------
+# the lock-step driver
+# ---------------------------------------------------------------------------------------------
+
+@dataclass
+class ChainState:
+    i_sample: int
+    i_chain: int                      # 1..nGibbsSamples, nGibbsSamples + 1 = phasing
+    rng: np.random.Generator
+    which_haps_to_use: Optional[np.ndarray] = None   # 1-based
+    read_labels: Optional[np.ndarray] = None
+    hap: Optional[List[np.ndarray]] = None           # dosage1, dosage2 of the latest full pass
+
+
+@dataclass
+class SampleResult:
+    dosage: np.ndarray
+    gp_t: np.ndarray                  # 3 x nSNPs
+    phasing_haps: np.ndarray          # nSNPs x 2
+    read_labels: np.ndarray           # consensus labels used by the phasing pass
+    nDosage: int
+    n_underflow_retries: int = 0
+
+
+class Driver:
+    """Runs ``get_and_impute_one_sample`` for a batch of samples, chains in lock-step."""
+
+    def __init__(self, panel, backend, params: Optional[DriverParams] = None):
+        self.panel = panel
+        self.backend = backend
+        self.params = (params or DriverParams()).resolved(panel.K)
+        self.cols = thinned_grid_columns(panel.nGrids, self.params.heuristic_match_thin)
+        self.n_thin = int((self.cols >= 0).sum())
+        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0}
+
+    # -- one [Gibbs -> full pass -> select] round over a set of chains
+    def _round(self, chains: List[ChainState], samples, i_it: int, phasing: bool):
+        import time
+        P = self.params
+        K, G, T = self.panel.K, self.panel.nGrids, self.panel.nSNPs
+        n_its = P.small_ref_panel_gibbs_iterations + P.n_gibbs_sample_its
+        nb = len(P.small_ref_panel_block_gibbs_iterations)
+        t0 = time.perf_counter()
+        first = (i_it == 1) and not phasing
+        starts, runif_reads, first_reads, runif_shards = [], [], [], []
+        for ch in chains:
+            R = samples[ch.i_sample].nReads
+            if first:
+                # functions.R:579-585
+                ch.which_haps_to_use = np.sort(ch.rng.permutation(K)[: P.Ksubset] + 1).astype(np.int32)
+                H0 = ch.rng.integers(1, 3, size=R).astype(np.int32)
+            else:
+                H0 = ch.read_labels
+            starts.append(H0)
+            runif_reads.append(ch.rng.random(R * n_its))
+            first_reads.append(int(ch.rng.integers(0, R)))
+            runif_shards.append(ch.rng.random(nb * (G - 1)))
+        t1 = time.perf_counter()
+        self.timing["host"] += t1 - t0
+        # ---- small-panel Gibbs (impute_one_sample, functions.R:2313-2774), with the underflow retry
+        pending = list(range(len(chains)))
+        maxdiff = [P.maxDifferenceBetweenReads] * len(chains)
+        results = [None] * len(chains)
+        n_try = 0
+        while pending:
+            groups = {}
+            for i in pending:
+                groups.setdefault(maxdiff[i], []).append(i)
+            nxt = []
+            for md, idx in groups.items():
+                out = self.backend.gibbs_batch(
+                    [samples[chains[i].i_sample] for i in idx], [chains[i].which_haps_to_use for i in idx],
+                    [starts[i] for i in idx], [runif_reads[i] for i in idx], [first_reads[i] for i in idx],
+                    [runif_shards[i] for i in idx], n_gibbs_burn_in_its=P.small_ref_panel_gibbs_iterations,
+                    n_gibbs_sample_its=P.n_gibbs_sample_its,
+                    block_gibbs_iterations=P.small_ref_panel_block_gibbs_iterations,
+                    gibbs_initialize_iteratively=first, maxDifferenceBetweenReads=md, Jmax_local=P.Jmax)
+                for i, o in zip(idx, out):
+                    if o["underflow_problem"]:
+                        maxdiff[i] = max(1.0, maxdiff[i] / 10)   # functions.R:2704-2715
+                        nxt.append(i)
+                    else:
+                        results[i] = o
+            pending = nxt
+            n_try += 1
+            if n_try > 10 and pending:
+                raise RuntimeError("There were consecutive underflow problems (functions.R:2710)")
+        t2 = time.perf_counter()
+        self.timing["gibbs"] += t2 - t1
+        # ---- full-panel pass per read label (impute_using_everything, functions.R:1922-2157)
+        return_dosage = i_it > P.n_burn_in_seek_its
+        gls, want = [], []
+        for ch, res in zip(chains, results):
+            ch.read_labels = res["double_list_of_ending_read_labels"][0][0].astype(np.int32)
+            s = samples[ch.i_sample]
+            per_base = np.repeat(ch.read_labels, np.diff(s.read_ptr))
+            for i_hap in (1, 2):
+                sel = (per_base == i_hap) & (s.bq != 0)
+                gls.append(make_gl_from_u_bq(s.u[sel], s.bq[sel], T, P.minGLValue, self.backend.make_gl_bound))
+                want.append(return_dosage)
+        t3 = time.perf_counter()
+        self.timing["host"] += t3 - t2
+        dosages, best = self.backend.fullpass_batch(gls, want, self.cols, P.K_top_matches)
+        t4 = time.perf_counter()
+        self.timing["fullpass"] += t4 - t3
+        for ci, ch in enumerate(chains):
+            new_haps = []
+            ch.hap = []
+            for i_hap in (0, 1):
+                pi = 2 * ci + i_hap
+                d = dosages[pi]
+                if return_dosage:
+                    if d.min() < -1e-5 or d.max() > 1 + 1e-5:   # functions.R:2072-2075
+                        raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
+                ch.hap.append(d)
+                new_haps.append(everything_per_hap_rejig_haps(best[pi]))
+            prev_sel = ch.which_haps_to_use[ch.rng.permutation(len(ch.which_haps_to_use))[: P.Ksubset - P.Knew]]
+            sel = everything_select_good_haps(P.Knew, P.K_top_matches, new_haps, prev_sel, K, ch.rng)
+            ch.which_haps_to_use = np.concatenate([prev_sel, sel]).astype(np.int32)
+        self.timing["host"] += time.perf_counter() - t4
+        return return_dosage
+
+    def run(self, samples) -> List[SampleResult]:
+        P = self.params
+        T = self.panel.nSNPs
+        N = len(samples)
+        chains = [ChainState(i, c, chain_rng(P.seed, i, c)) for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
+        dosage = np.zeros((N, T))
+        gp_t = np.zeros((N, 3, T))
+        nDosage = np.zeros(N, dtype=np.int64)
+        for i_it in range(1, P.n_seek_its + 1):
+            stored = self._round(chains, samples, i_it, phasing=False)
+            if stored:   # functions.R:999-1020
+                for ch in chains:
+                    h1, h2 = ch.hap
+                    dosage[ch.i_sample] += h1 + h2
+                    gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
+                    nDosage[ch.i_sample] += 1
+        # ---- read confidence per chain and consensus labels (functions.R:1144-1205)
+        conf = self.backend.read_confidence_batch([samples[ch.i_sample] for ch in chains], [ch.hap for ch in chains],
+                                                  P.maxDifferenceBetweenReads)
+        phasing = []
+        for i in range(N):
+            R = samples[i].nReads
+            mine = [k for k, ch in enumerate(chains) if ch.i_sample == i]
+            rl_all = np.stack([chains[k].read_labels for k in mine], axis=1)
+            rl_conf = np.stack([assess_ability_of_reads_to_be_confident(conf[k]) for k in mine], axis=1)
+            labels = determine_best_read_label_so_far(rl_all, rl_conf, R, P.nGibbsSamples, can_hap=P.nGibbsSamples)
+            last = chains[mine[-1]]
+            ph = ChainState(i, P.nGibbsSamples + 1, chain_rng(P.seed, i, P.nGibbsSamples + 1),
+                            which_haps_to_use=last.which_haps_to_use.copy(), read_labels=labels)
+            phasing.append(ph)
+        consensus = [ph.read_labels.copy() for ph in phasing]
+        for i_it in range(1, P.n_seek_its + 1):
+            self._round(phasing, samples, i_it, phasing=True)
+        out = []
+        for i in range(N):
+            d = dosage[i] / nDosage[i]
+            g = gp_t[i] / nDosage[i]
+            h1, h2 = recast_haps(phasing[i].hap[0], phasing[i].hap[1], g.T)   # functions.R:1207-1217
+            out.append(SampleResult(d, g, np.stack([h1, h2], axis=1), consensus[i], int(nDosage[i])))
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# product backend: the HIP library (no fallback)
+# ---------------------------------------------------------------------------------------------
+
+class HipBackend:
+    def __init__(self, device_panel):
+        self.dev = device_panel
+
+    def make_gl_bound(self, gl, minGLValue, to_fix):
+        from .reference_single import Rcpp_make_gl_bound
+        Rcpp_make_gl_bound(gl, minGLValue, to_fix)
+
+    def gibbs_batch(self, samples, which, starts, runif_reads, first_reads, runif_shards, **kw):
+        from .gibbs_nipt import forwardBackwardGibbsNIPT_batch
+        return forwardBackwardGibbsNIPT_batch(self.dev, samples, which, starts, runif_reads, first_reads,
+                                              runif_shards, **kw)
+
+    def fullpass_batch(self, gls, want_dosage, cols, K_top_matches):
+        import ctypes as C
+        from .native import QA_ERR_CAPACITY, check, lib, ptr
+        P = self.dev.panel
+        n = len(gls)
+        T = P.nSNPs
+        n_thin = int((cols >= 0).sum())
+        gl = np.ascontiguousarray(np.stack([np.ascontiguousarray(g.T) for g in gls]))
+        wd = np.ascontiguousarray(want_dosage, dtype=np.int32)
+        dosage = np.zeros((n, T))
+        bptr = np.zeros(n * n_thin + 1, dtype=np.int32)
+        cap = n * n_thin * 16
+        for _ in range(2):
+            bidx = np.zeros(cap, dtype=np.int32)
+            bval = np.zeros(cap)
+            st = lib().qa_fullpass_batch(self.dev.handle, C.c_int32(n), ptr(gl), ptr(wd), ptr(np.ascontiguousarray(cols, dtype=np.int32)),
+                                         C.c_int32(K_top_matches), ptr(dosage), ptr(bptr), ptr(bidx), ptr(bval),
+                                         C.c_int64(cap))
+            if st == QA_ERR_CAPACITY:
+                cap = int(bptr[-1])
+                continue
+            check(st)
+            break
+        best = []
+        for p in range(n):
+            best.append([dict(top_matches=bidx[bptr[p * n_thin + j]:bptr[p * n_thin + j + 1]],
+                              top_matches_values=bval[bptr[p * n_thin + j]:bptr[p * n_thin + j + 1]])
+                         for j in range(n_thin)])
+        return list(dosage), best
+
+    def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):
+        from .gibbs_nipt import calculate_eMatRead_t_vs_haplotypes_batch
+        return calculate_eMatRead_t_vs_haplotypes_batch(self.dev, samples, haps, maxDifferenceBetweenReads)

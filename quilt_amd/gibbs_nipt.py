@@ -108,3 +108,27 @@ def rcpp_forwardBackwardGibbsNIPT(panel: DevicePanel, sampleReads, which_haps_to
     return forwardBackwardGibbsNIPT_batch(panel, [sampleReads], [which_haps_to_use], [starting_read_labels],
                                           [runif_reads], [first_read_for_gibbs_initialization], [runif_shard],
                                           **kw)[0]
+
+
+def calculate_eMatRead_t_vs_haplotypes_batch(panel: DevicePanel, samples: Sequence, haps: Sequence,
+                                             maxDifferenceBetweenReads: float, rescale_eMatRead_t: bool = False,
+                                             Jmax: int = 1000):
+    """``calculate_eMatRead_t_vs_haplotypes`` (QUILT/R/functions.R:2975-3020) for a batch: ``haps[c]`` is the
+    list of K dense haplotype dosages of chain ``c``.  Returns one K x nReads matrix per chain."""
+    lib().qa_rcpp_make_eMatRead_t.restype = C.c_int
+    Cn = len(samples)
+    K = len(haps[0])
+    T = panel.panel.nSNPs
+    e = np.ascontiguousarray(np.stack([np.stack([np.asarray(h, dtype=np.float64) for h in hs], axis=1) for hs in haps]))
+    assert e.shape == (Cn, T, K)
+    read_off = np.zeros(Cn + 1, dtype=np.int32)
+    for c, s in enumerate(samples):
+        read_off[c + 1] = read_off[c] + s.nReads
+    read_ptr = np.concatenate([np.asarray(s.read_ptr, dtype=np.int32) for s in samples])
+    u = np.concatenate([np.asarray(s.u, dtype=np.int32) for s in samples])
+    bq = np.concatenate([np.asarray(s.bq, dtype=np.int32) for s in samples])
+    out = np.zeros((int(read_off[-1]), K))
+    check(lib().qa_rcpp_make_eMatRead_t(panel.handle, C.c_int32(Cn), C.c_int32(K), ptr(e), ptr(read_off), ptr(read_ptr),
+                                        ptr(u), ptr(bq), C.c_double(maxDifferenceBetweenReads), C.c_int32(Jmax),
+                                        C.c_int32(int(rescale_eMatRead_t)), ptr(out)))
+    return [np.asfortranarray(out[read_off[c]:read_off[c + 1]].T) for c in range(Cn)]

@@ -1,0 +1,61 @@
+"""CPU tests of the host-side driver logic restated from QUILT/R/functions.R."""
+import numpy as np
+
+from quilt_amd import driver as D
+
+
+def test_thinned_columns_default():
+    cols = D.thinned_grid_columns(2000, 0.1)
+    idx = np.nonzero(cols >= 0)[0]
+    assert len(idx) == 200 and idx[0] == 0 and idx[-1] == 1999
+    assert np.array_equal(cols[idx], np.arange(200))
+    assert np.array_equal(np.nonzero(D.thinned_grid_columns(5, 0.1) >= 0)[0], [0])
+
+
+def test_select_good_haps_takes_rank_by_rank():
+    rng = np.random.default_rng(0)
+    # two labels, three grids; rank-1 haplotypes first, then rank-2, ...
+    new_haps = [[np.array([5, 9, 1, 2, 3]), np.array([7, 5, 4, 6, 8]), np.array([5, 7, 10, 11, 12])],
+                [np.array([20, 21, 22, 23, 24]), np.array([20, 5, 25, 26, 27]), np.array([30, 31, 32, 33, 34])]]
+    out = D.everything_select_good_haps(4, 5, new_haps, np.zeros(0, dtype=np.int64), 100, rng)
+    assert set(out.tolist()) == {5, 7, 20, 30}           # exactly the distinct rank-1 entries
+    out = D.everything_select_good_haps(6, 5, new_haps, np.array([7]), 100, rng)
+    assert {5, 20, 30} <= set(out.tolist()) and 7 not in out and len(set(out.tolist())) == 6
+    # not enough candidates: filled at random from the rest of the panel
+    out = D.everything_select_good_haps(40, 5, new_haps, np.zeros(0, dtype=np.int64), 100, rng)
+    assert len(set(out.tolist())) == 40 and out.min() >= 1 and out.max() <= 100
+
+
+def test_recast_haps():
+    hd1 = np.array([0.9, 0.2, 0.6, 0.4])
+    hd2 = np.array([0.8, 0.1, 0.3, 0.45])
+    gp = np.array([[0.0, 0.1, 0.9], [0.8, 0.2, 0.0], [0.1, 0.8, 0.1], [0.2, 0.7, 0.1]])
+    h1, h2 = D.recast_haps(hd1, hd2, gp)
+    assert np.allclose(h1, [0.9, 0.2, 0.6, 0.0]) and np.allclose(h2, [0.8, 0.1, 0.3, 1.0])
+
+
+def test_best_read_labels_majority_flip():
+    # 7 runs that agree except that runs 0 and 1 are phase-flipped after read 20
+    R, n = 60, 7
+    rng = np.random.default_rng(1)
+    base = rng.integers(1, 3, size=R)
+    m = np.tile(base[:, None], (1, n))
+    m[20:, 0] = 3 - m[20:, 0]
+    m[20:, 1] = 3 - m[20:, 1]
+    conf = np.ones((R, n), dtype=bool)
+    out = D.determine_best_read_label_so_far(m, conf, R, n, can_hap=n)
+    assert np.array_equal(out, base)                       # canonical run is trusted, nothing to change in it
+    # canonical run itself is the odd one out: it gets flipped back
+    m2 = np.tile(base[:, None], (1, n))
+    m2[30:, n - 1] = 3 - m2[30:, n - 1]
+    out2 = D.determine_best_read_label_so_far(m2, conf, R, n, can_hap=n)
+    assert np.array_equal(out2, base)
+    # too few confident reads: canonical labels unchanged
+    out3 = D.determine_best_read_label_so_far(m2, np.zeros((R, n), dtype=bool), R, n, can_hap=n)
+    assert np.array_equal(out3, m2[:, n - 1])
+
+
+def test_params_small_panel_reset():
+    p = D.DriverParams().resolved(K=100)
+    assert (p.n_seek_its, p.n_burn_in_seek_its, p.Ksubset, p.Knew) == (1, 0, 100, 100)
+    assert D.DriverParams().resolved(K=5000).n_burn_in_seek_its == 2

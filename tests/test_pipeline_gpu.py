@@ -1,0 +1,53 @@
+"""GPU end-to-end: the whole per-sample driver (Gibbs + full-panel passes + selection + consensus
+phasing) on the HIP backend vs the same driver on the fp64 CPU oracle, same seeds.
+
+Bar (BASELINE.json): dosage r2 >= 0.999 against the CPU path; genotype probabilities sum to 1.
+Read labels are compared too: they are identical as long as the fp32 full-panel pass ranks the top
+haplotypes like the fp64 oracle does (near-ties can reorder them; the r2 bar is what must hold).
+"""
+import numpy as np
+import pytest
+
+from tests.util import r2
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(panel, samples, prm):
+    from quilt_amd.driver import Driver, HipBackend
+    from quilt_amd.native import DevicePanel
+    from tests.oracle_backend import OracleBackend
+    dev = DevicePanel(panel)
+    got = Driver(panel, HipBackend(dev), prm).run(samples)
+    ref = Driver(panel, OracleBackend(panel), prm).run(samples)
+    dev.close()
+    return got, ref
+
+
+def test_pipeline_matches_oracle(medium_panel):
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=1000) for i in range(3)]
+    prm = DriverParams(nGibbsSamples=3, Ksubset=200, Knew=200, seed=5)
+    got, ref = _run_both(panel, samples, prm)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g.nDosage == r.nDosage == 3
+        np.testing.assert_allclose(g.gp_t.sum(axis=0), 1.0, atol=2e-3)   # check_quilt_output (test-drivers.R:38-61)
+        assert r2(g.dosage, r.dosage) >= 0.999, (i, r2(g.dosage, r.dosage))
+        truth = samples[i].truth_haps.sum(axis=0)
+        assert r2(g.dosage, truth) >= 0.9 and abs(r2(g.dosage, truth) - r2(r.dosage, truth)) < 0.02
+        same = np.array_equal(g.read_labels, r.read_labels)
+        print(f"sample {i}: r2(gpu, oracle) = {r2(g.dosage, r.dosage):.6f}, max|d| = {np.abs(g.dosage - r.dosage).max():.2e}, "
+              f"consensus labels identical: {same}")
+
+
+def test_pipeline_default_parameters_small(small_panel):
+    """K < Ksubset path (quilt.R:453-463): n_seek_its = 1, Ksubset = K."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    panel = small_panel
+    samples = [make_synthetic_sample(panel, seed=7, n_reads=150)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=2000, Knew=2000, seed=3)
+    got, ref = _run_both(panel, samples, prm)
+    assert r2(got[0].dosage, ref[0].dosage) >= 0.999
