@@ -142,6 +142,29 @@ int qa_fullpass_batch(
     const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double *dosage,
     int32_t *best_ptr, int32_t *best_idx, double *best_val, int64_t best_cap);
 
+
+/*
+ * The full-panel step of the per-sample driver in one call: `impute_using_everything`
+ * (QUILT/R/functions.R:1922-2157) for n_chain (sample, Gibbs chain) pairs.  For every chain and read label
+ * it builds the label's genotype likelihoods from the sample's reads on the device
+ * (make_gl_from_u_bq, QUILT/R/reference-single.R:19-42, + Rcpp_make_gl_bound), runs the full-panel
+ * forward/backward (dosage pass when want_dosage[chain], else thin pass) and returns, per thinned grid, the
+ * top matches already ordered as `everything_per_hap_rejig_haps` orders them (functions.R:2161-2170).
+ *
+ *   chain_sample      n_chain: sample of each chain (several chains share one sample's reads)
+ *   read_off, read_ptr, u, bq   reads of the n_sample samples, laid out as in qa_gibbs_batch (per sample)
+ *   H                 read labels (1-based) of the chains back to back, chain c holding R_{chain_sample[c]} labels
+ *   dosage            n_chain x n_label x nSNPs (rows of thin passes untouched); may be NULL
+ *   top_idx/top_val   n_chain x n_label x n_thin x top_width: 0-based haplotypes / values, best first, -1 padded
+ *   top_cnt           n_chain x n_label x n_thin: full length of each list (> top_width means truncated)
+ */
+int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
+                            const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
+                            const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
+                            const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double minGLValue,
+                            double *dosage, int32_t top_width, int32_t *top_idx, float *top_val,
+                            int32_t *top_cnt);
+
 /* Timing of the most recent full-pass launch set on this thread, measured with HIP
  * events on the launch stream (ms): [0] emission build, [1] forward, [2] backward,
  * [3] dosage mat-vec, [4] total device.  Replaces print_times()
@@ -194,6 +217,11 @@ typedef struct {
  *   H_class                   out (may be NULL)
  *   hapProbs_t, genProbs*_t   out, per chain 3 x nSNPs (may be NULL)
  *   underflow_problem         out per chain (may be NULL); the call returns QA_UNDERFLOW if any is set
+ *   seed_reads, seed_shard    NULL, or per chain the seed of a counter-based uniform stream that replaces
+ *                             runif_reads / runif_shard (element i = splitmix64 finaliser of
+ *                             seed + (i + 1) * 0x9E3779B97F4A7C15, top 53 bits / 2^53): lets a batched driver
+ *                             avoid shipping R_c * n_its uniforms per chain.  With R in the loop the explicit
+ *                             arrays keep `set.seed` semantics.
  *   state_out                 NULL, or (n_chain == 1 only) 6 * Ks * nGrids + 3 * nGrids doubles:
  *                             alphaHat_t1, alphaHat_t2, betaHat_t1, betaHat_t2, eMatGrid_t1, eMatGrid_t2,
  *                             c1, c2, c3 -- the matrices the reference mutates in place
@@ -203,7 +231,8 @@ int qa_gibbs_batch(qa_panel_t *panel, const qa_gibbs_opts_t *opts, int32_t n_cha
                    const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif,
                    const double *runif_reads, const int32_t *first_read, const double *runif_shard,
                    int32_t *H, int32_t *H_class, double *hapProbs_t, double *genProbsM_t,
-                   double *genProbsF_t, int32_t *underflow_problem, double *state_out);
+                   double *genProbsF_t, int32_t *underflow_problem, double *state_out,
+                   const uint64_t *seed_reads, const uint64_t *seed_shard);
 
 
 /*

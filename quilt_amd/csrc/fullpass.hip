@@ -628,7 +628,22 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
         }
     }
     __syncthreads();
-    if (t == 0) prm.top_cnt[(size_t)p * prm.n_thin + tcol] = s_cnt;
+    if (t == 0) {
+        const int n = s_cnt;
+        prm.top_cnt[(size_t)p * prm.n_thin + tcol] = n;
+        // order as everything_per_hap_rejig_haps does (functions.R:2161-2170): value descending, ties by
+        // ascending haplotype (R's stable order() on the k-ascending list).  Lists are ~K_top long.
+        if (n <= prm.top_cap && n <= 64) {
+            for (int i = 1; i < n; i++) {
+                const int ki = oi[i];
+                const float vi = ov[i];
+                int j = i - 1;
+                while (j >= 0 && (ov[j] < vi || (ov[j] == vi && oi[j] > ki))) { oi[j + 1] = oi[j]; ov[j + 1] = ov[j]; j--; }
+                oi[j + 1] = ki;
+                ov[j + 1] = vi;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -670,6 +685,51 @@ __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
         const double sig = (g < prm.G - 1) ? prm.sigma[g] : 1.0;
         prm.dosage[(size_t)p * prm.T + s + b] = tot * sig;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_make_gl: per-label genotype likelihoods of a pass from the sample's reads and the current read
+// labels: make_gl_from_u_bq (QUILT/R/reference-single.R:19-42) + Rcpp_make_gl_bound
+// (reference-single.cpp:68-94).  One thread per (SNP, pass); the bases covering a SNP come from a
+// per-sample SNP-major index (built once on the host), in read order, so the product order is the
+// reference's.
+// ---------------------------------------------------------------------------------------------
+struct GlParams {
+    int P, T;
+    const int32_t *pass_sample;  // [P]
+    const int32_t *pass_label;   // [P] 1-based
+    const int32_t *pass_hoff;    // [P] offset of the pass's chain into H
+    const int32_t *snp_ptr;      // [n_sample][T + 1] (local offsets)
+    const int32_t *ent_off;      // [n_sample] offset into ent_*
+    const int32_t *ent_read;     // read index (within the sample) of each base
+    const int32_t *ent_bq;       // its signed base quality
+    const int32_t *H;            // labels
+    const double *pR_tab, *pA_tab;
+    double minGLValue;
+    double *gl;                  // [P][T][2]
+};
+
+__global__ __launch_bounds__(256) void k_make_gl(GlParams p) {
+    const int t = blockIdx.x * 256 + threadIdx.x, pi = blockIdx.y;
+    if (t >= p.T) return;
+    const int s = p.pass_sample[pi], lab = p.pass_label[pi];
+    const int32_t *sp = p.snp_ptr + (size_t)s * (p.T + 1);
+    const int32_t *er = p.ent_read + p.ent_off[s], *eb = p.ent_bq + p.ent_off[s];
+    const int32_t *H = p.H + p.pass_hoff[pi];
+    double a = 1.0, b = 1.0;
+    for (int i = sp[t]; i < sp[t + 1]; i++) {
+        const int bq = eb[i];
+        if (bq == 0 || H[er[i]] != lab) continue;
+        const int ab = bq < 0 ? -bq : bq;
+        a *= p.pR_tab[(bq > 0 ? 256 : 0) + ab];
+        b *= p.pA_tab[(bq > 0 ? 256 : 0) + ab];
+    }
+    if (p.minGLValue > 0 && (a < p.minGLValue || b < p.minGLValue)) {
+        if (a > b) { b = b / a; a = 1; if (b < p.minGLValue) b = p.minGLValue; }
+        else       { a = a / b; b = 1; if (a < p.minGLValue) a = p.minGLValue; }
+    }
+    double2 *out = reinterpret_cast<double2 *>(p.gl) + (size_t)pi * p.T + t;
+    *out = make_double2(a, b);
 }
 
 // un-permute a lane-interleaved [cols][Kq] float matrix into a K x cols double matrix (column-major)
@@ -756,6 +816,7 @@ struct BatchOut {
     bool gamma_small_unscaled = false;  // gammaSmall_t without return_gamma_t: no sigma factor (:2170-2176)
     // best_haps_stuff_list of every (pass, thinned column), appended in pass-major order
     std::vector<std::vector<std::pair<int32_t, float>>> *lists = nullptr;
+    bool order_by_value = false;  // lists ordered as everything_per_hap_rejig_haps wants (else ascending k)
 };
 
 // runs P passes; flags per pass as in PassParams
@@ -802,8 +863,10 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     const bool any_top = n_thin > 0 && K_top > 0;
     const size_t alpha_stride = max_cols * (size_t)Kq;
 
-    S.gl.ensure((size_t)P * T * 2);
-    S.gl.upload(gl, (size_t)P * T * 2, st);
+    if (gl) {   // host gl; otherwise the caller has filled S.gl on the device already (k_make_gl)
+        S.gl.ensure((size_t)P * T * 2);
+        S.gl.upload(gl, (size_t)P * T * 2, st);
+    }
     S.thin_col.ensure(G);
     S.thin_col.upload(thin_col_h, G, st);
     S.flags.ensure(P);
@@ -955,7 +1018,13 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
             std::vector<std::pair<int32_t, float>> tmp;
             tmp.reserve(cnt[i]);
             for (int q = 0; q < cnt[i]; q++) tmp.emplace_back(idx[i * top_cap + q], val[i * top_cap + q]);
-            std::sort(tmp.begin(), tmp.end());  // ascending k, the reference's emission order
+            if (!out.order_by_value) {
+                std::sort(tmp.begin(), tmp.end());  // ascending k, the reference's emission order
+            } else if (cnt[i] > 64) {               // (k_topk orders lists of up to 64 entries itself)
+                std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) {
+                    return a.second > b.second || (a.second == b.second && a.first < b.first);
+                });
+            }
             out.lists->push_back(std::move(tmp));
         }
     }
@@ -1080,6 +1149,134 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
         }
         if (status != QA_OK) return status;
         return pack_lists(lists, best_ptr, best_idx, best_val, best_cap);
+    });
+}
+
+
+int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
+                            const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
+                            const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
+                            const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double minGLValue,
+                            double *dosage, int32_t top_width, int32_t *top_idx, float *top_val, int32_t *top_cnt) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!panel || n_chain <= 0 || n_label < 1 || n_label > 3 || n_sample <= 0 || !chain_sample || !read_off || !read_ptr ||
+        !u || !bq || !H || !want_dosage || !gammaSmall_cols_to_get || top_width < K_top_matches) {
+        qa::set_error("qa_fullpass_reads_batch: bad argument");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(panel->device));
+        if (!panel->scratch) panel->scratch = new qa_panel::Scratch();
+        auto &S = *panel->scratch;
+        hipStream_t st = panel->stream;
+        const int G = panel->G, T = panel->T;
+        int n_thin = 0;
+        for (int g = 0; g < G; g++) n_thin = std::max(n_thin, gammaSmall_cols_to_get[g] + 1);
+        // ---- per-sample SNP-major index of the bases (input marshalling, O(bases))
+        std::vector<int32_t> base_off(n_sample + 1, 0), snp_ptr((size_t)n_sample * (T + 1), 0), ent_off(n_sample, 0);
+        for (int s = 0; s < n_sample; s++) {
+            const int R = read_off[s + 1] - read_off[s];
+            base_off[s + 1] = base_off[s] + (read_ptr + read_off[s] + s)[R];
+        }
+        const int totB = base_off[n_sample];
+        std::vector<int32_t> ent_read(std::max(totB, 1)), ent_bq(std::max(totB, 1));
+        for (int s = 0; s < n_sample; s++) {
+            const int R = read_off[s + 1] - read_off[s];
+            const int32_t *rp = read_ptr + read_off[s] + s;
+            const int32_t *su = u + base_off[s], *sb = bq + base_off[s];
+            int32_t *sp = snp_ptr.data() + (size_t)s * (T + 1);
+            ent_off[s] = base_off[s];
+            for (int i = 0; i < rp[R]; i++) {
+                if (su[i] < 0 || su[i] >= T) throw std::runtime_error("SNP index out of range");
+                if (sb[i] > 255 || sb[i] < -255) throw std::runtime_error("|base quality| > 255");
+                sp[su[i] + 1]++;
+            }
+            for (int t = 0; t < T; t++) sp[t + 1] += sp[t];
+            std::vector<int32_t> fill(sp, sp + T);
+            for (int r = 0; r < R; r++)
+                for (int i = rp[r]; i < rp[r + 1]; i++) {
+                    const int at = fill[su[i]]++;
+                    ent_read[(size_t)base_off[s] + at] = r;
+                    ent_bq[(size_t)base_off[s] + at] = sb[i];
+                }
+        }
+        // chain -> offset of its labels in H (chains are laid out back to back, each with its sample's R)
+        std::vector<int32_t> hoff(n_chain + 1, 0);
+        for (int c = 0; c < n_chain; c++) {
+            const int s = chain_sample[c];
+            if (s < 0 || s >= n_sample) throw std::runtime_error("chain_sample out of range");
+            hoff[c + 1] = hoff[c] + (read_off[s + 1] - read_off[s]);
+        }
+        const int P = n_chain * n_label;
+        std::vector<int32_t> ps(P), pl(P), ph(P), flags(P);
+        for (int c = 0; c < n_chain; c++)
+            for (int l = 0; l < n_label; l++) {
+                ps[c * n_label + l] = chain_sample[c];
+                pl[c * n_label + l] = l + 1;
+                ph[c * n_label + l] = hoff[c];
+                flags[c * n_label + l] = want_dosage[c] ? 1 : 0;
+            }
+        // eps tables from the host libm (convertScaledBQtoProbs, as copied-from-stitch.cpp:166-175)
+        std::vector<double> tabs(4 * 256);
+        for (int q = 0; q < 256; q++) {
+            const double e = std::pow(10, -(double)q / 10);
+            tabs[q] = 1 - e; tabs[256 + q] = e / 3; tabs[512 + q] = e / 3; tabs[768 + q] = 1 - e;
+        }
+        qa::DBuf<int32_t> d_ps(P), d_pl(P), d_ph(P), d_sp(snp_ptr.size()), d_eo(n_sample), d_er(ent_read.size()),
+            d_eb(ent_bq.size()), d_H(std::max(hoff[n_chain], 1));
+        qa::DBuf<double> d_tabs(tabs.size());
+        d_ps.upload(ps.data(), P, st); d_pl.upload(pl.data(), P, st); d_ph.upload(ph.data(), P, st);
+        d_sp.upload(snp_ptr.data(), snp_ptr.size(), st); d_eo.upload(ent_off.data(), n_sample, st);
+        d_er.upload(ent_read.data(), ent_read.size(), st); d_eb.upload(ent_bq.data(), ent_bq.size(), st);
+        d_H.upload(H, hoff[n_chain], st); d_tabs.upload(tabs.data(), tabs.size(), st);
+
+        const Geometry geo = pick_geometry(panel->K);
+        if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
+        size_t free_b = 0, total_b = 0;
+        QA_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = free_b + panel->scratch_bytes();
+        const size_t Kq = (size_t)geo.NT * geo.NCH * 16;
+        const size_t per_dosage = Kq * 4 * ((size_t)G + n_thin) + (size_t)G * 256 * 8 + (size_t)T * 32;
+        const size_t per_thin = Kq * 4 * (2 * (size_t)std::max(n_thin, 1)) + (size_t)G * 256 * 8 + (size_t)T * 32;
+        int done = 0, status = QA_OK;
+        std::vector<std::vector<std::pair<int32_t, float>>> lists;
+        while (done < P && status == QA_OK) {
+            size_t used = 0;
+            int n = 0;
+            const bool dos = flags[done] != 0;
+            while (done + n < P && (flags[done + n] != 0) == dos) {
+                const size_t need = dos ? per_dosage : per_thin;
+                if (n > 0 && used + need > have * 8 / 10) break;
+                used += need;
+                n++;
+            }
+            S.gl.ensure((size_t)n * T * 2);
+            GlParams gp{};
+            gp.P = n; gp.T = T; gp.pass_sample = d_ps.p + done; gp.pass_label = d_pl.p + done; gp.pass_hoff = d_ph.p + done;
+            gp.snp_ptr = d_sp.p; gp.ent_off = d_eo.p; gp.ent_read = d_er.p; gp.ent_bq = d_eb.p; gp.H = d_H.p;
+            gp.pR_tab = d_tabs.p; gp.pA_tab = d_tabs.p + 512; gp.minGLValue = minGLValue; gp.gl = S.gl.p;
+            hipLaunchKernelGGL(k_make_gl, dim3((T + 255) / 256, n), dim3(256), 0, st, gp);
+            QA_HIP(hipGetLastError());
+            BatchOut out;
+            out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
+            lists.clear();
+            out.lists = &lists;
+            out.order_by_value = true;
+            status = run_passes(panel, n, nullptr, flags.data() + done, gammaSmall_cols_to_get, K_top_matches, 1, out);
+            if (status != QA_OK) break;
+            // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
+            for (int i = 0; i < n * n_thin; i++) {
+                const auto &l = lists[i];
+                const size_t o = ((size_t)done * n_thin + i);
+                if (top_cnt) top_cnt[o] = (int32_t)l.size();
+                for (int q = 0; q < top_width; q++) {
+                    if (top_idx) top_idx[o * top_width + q] = q < (int)l.size() ? l[q].first : -1;
+                    if (top_val) top_val[o * top_width + q] = q < (int)l.size() ? l[q].second : 0.f;
+                }
+            }
+            done += n;
+        }
+        return status;
     });
 }
 

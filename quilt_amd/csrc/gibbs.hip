@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 namespace {
@@ -72,6 +73,7 @@ struct GibbsParams {
     const double *runif_reads; // [C][R_c * n_its] at offset read_off[c] * n_its
     const int32_t *first_read; // [C]
     const double *runif_shard; // [C][n_block][G-1]
+    const uint64_t *seed_reads, *seed_shard;  // [C] or null: uniforms from the counter-based stream instead
     // state (per chain)
     double *eMatRead;        // at eread_off[c] doubles: [R_c][Ksp]
     const size_t *eread_off; // [C]
@@ -85,15 +87,40 @@ struct GibbsParams {
     double *hapProbs, *genProbsM, *genProbsF;  // [C][T][3]
 };
 
+// 64-lane sum of doubles by DPP row shifts / row broadcasts (no LDS traffic), result broadcast to every
+// lane through a scalar register.  Deterministic order: within 16-lane rows, then rows 0+1, 2+3, then all.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_get<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_get<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_get<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_get<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row total
+    v += dpp_get<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_get<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wmax(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// Counter-based uniform stream (splitmix64 finaliser of seed + (i + 1) * golden ratio), 53-bit mantissa in
+// [0, 1): element i of stream `seed`.  The host restates it exactly (quilt_amd/rng.py).
+__device__ __forceinline__ double stream_uniform(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
 // word of haplotype k (panel index) at grid g with code `code`
@@ -185,7 +212,8 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gibbs: one wave per chain; initialisation, all sweeps, shard passes.
+// k_gibbs: NW wavefronts (one workgroup) per chain; initialisation, all sweeps, shard passes.
+// Thread t of the NT = 64 * NW threads owns small-panel rows t, t + NT, ... (NE of them).
 // ---------------------------------------------------------------------------------------------
 template <int NE>
 struct Col {
@@ -193,27 +221,28 @@ struct Col {
 };
 
 template <int NE>
-__device__ __forceinline__ void load_col(Col<NE> &c, const double *src, int lane) {
+__device__ __forceinline__ void load_col(Col<NE> &c, const double *src, int t, int NT) {
 #pragma unroll
-    for (int i = 0; i < NE; i++) c.v[i] = src[lane + 64 * i];
+    for (int i = 0; i < NE; i++) c.v[i] = src[t + NT * i];
 }
 template <int NE>
-__device__ __forceinline__ void store_col(const Col<NE> &c, double *dst, int lane) {
+__device__ __forceinline__ void store_col(const Col<NE> &c, double *dst, int t, int NT) {
 #pragma unroll
-    for (int i = 0; i < NE; i++) dst[lane + 64 * i] = c.v[i];
-}
-template <int NE>
-__device__ __forceinline__ double sum_col(const Col<NE> &c) {
-    double s = 0;
-#pragma unroll
-    for (int i = 0; i < NE; i++) s += c.v[i];
-    return wsum(s);
+    for (int i = 0; i < NE; i++) dst[t + NT * i] = c.v[i];
 }
 
-template <int NE>
+__device__ __forceinline__ double rl_f64(double v, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int rl_i32(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+
+template <int NE, int NW>
 struct Chain {
+    static constexpr int NT = 64 * NW;
     const GibbsParams &p;
-    int c, lane, R, G, Ks, Ksp;
+    int c, t, lane, wave, R, G, Ks, Ksp;
     double *alpha[2], *beta[2], *eg[2], *cv[3];
     const double *eMatRead;
     const int32_t *wif;
@@ -221,8 +250,11 @@ struct Chain {
     int32_t *H, *Hc;
     double prior;  // 1 / Ks
     bool valid[NE];
+    double *red;   // LDS [2][NW][4]
+    int par;
 
-    __device__ Chain(const GibbsParams &p_, int c_, int lane_) : p(p_), c(c_), lane(lane_) {
+    __device__ Chain(const GibbsParams &p_, int c_, int t_, double *red_)
+        : p(p_), c(c_), t(t_), lane(t_ & 63), wave(t_ >> 6), red(red_), par(0) {
         G = p.G; Ks = p.Ks; Ksp = p.Ksp;
         R = p.read_off[c + 1] - p.read_off[c];
         const size_t mat = (size_t)G * Ksp;
@@ -240,92 +272,240 @@ struct Chain {
         Hc = p.H_class + p.read_off[c];
         prior = 1.0 / Ks;
 #pragma unroll
-        for (int i = 0; i < NE; i++) valid[i] = (lane + 64 * i) < Ks;
-    }
-
-    // Rcpp_run_forward_haploid (copied-from-stitch.cpp:340-387), prior = alphaMat = 1/Ks
-    __device__ void forward_full(int h) {
-        Col<NE> a, e;
-        load_col(e, eg[h], lane);
-#pragma unroll
-        for (int i = 0; i < NE; i++) a.v[i] = valid[i] ? prior * e.v[i] : 0.0;
-        double cc = 1 / sum_col(a);
-#pragma unroll
-        for (int i = 0; i < NE; i++) a.v[i] = a.v[i] * cc;
-        if (lane == 0) cv[h][0] = cc;
-        store_col(a, alpha[h], lane);
-        for (int g = 1; g < G; g++) {
-            const double sig = tm0(g - 1);
-            load_col(e, eg[h] + (size_t)g * Ksp, lane);
-            const double t1 = tm1(g - 1);
-#pragma unroll
-            for (int i = 0; i < NE; i++) a.v[i] = valid[i] ? e.v[i] * (sig * a.v[i] + t1 * prior) : 0.0;
-            cc = 1 / sum_col(a);
-#pragma unroll
-            for (int i = 0; i < NE; i++) a.v[i] *= cc;
-            if (lane == 0) cv[h][g] = cc;
-            store_col(a, alpha[h] + (size_t)g * Ksp, lane);
-        }
+        for (int i = 0; i < NE; i++) valid[i] = (t + NT * i) < Ks;
     }
     __device__ __forceinline__ double tm0(int g) const { return p.sigma[g]; }
-    // transMatRate_t row 1 is stored by the reference as (1 - sigma) computed in R; the host passes it
+    // transMatRate_t row 1 as the caller passed it (the reference never recomputes 1 - sigma)
     __device__ __forceinline__ double tm1(int g) const { return p.sigma[p.G - 1 + g]; }
 
-    // Rcpp_run_backward_haploid (copied-from-stitch.cpp:392-409); beta(G-1) must be set
-    __device__ void backward_generic(int h) {
-        Col<NE> b, e;
-        load_col(b, beta[h] + (size_t)(G - 1) * Ksp, lane);
-        for (int g = G - 2; g >= 0; --g) {
-            load_col(e, eg[h] + (size_t)(g + 1) * Ksp, lane);
+    // workgroup-wide sums of N values per thread; every thread gets the totals.  Waves reduce by DPP, then
+    // exchange through a parity-alternating LDS buffer with a bare s_barrier (lgkmcnt only: the column
+    // prefetches in flight on vmcnt must not be drained here, which __syncthreads() would do).
+    template <int N>
+    __device__ __forceinline__ void bsum(double (&x)[N]) {
+#pragma unroll
+        for (int q = 0; q < N; q++) x[q] = wsum(x[q]);
+        if (NW == 1) return;
+        double *buf = red + (size_t)par * NW * 4;
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < N; q++) buf[wave * 4 + q] = x[q];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < N; q++) {
             double s = 0;
 #pragma unroll
-            for (int i = 0; i < NE; i++) {
-                b.v[i] = e.v[i] * b.v[i];
-                s += valid[i] ? prior * b.v[i] : 0.0;
-            }
-            s = wsum(s);
-            const double x = tm1(g) * s, cg = cv[h][g], s0 = tm0(g);
-#pragma unroll
-            for (int i = 0; i < NE; i++) b.v[i] = valid[i] ? cg * (x + s0 * b.v[i]) : 0.0;
-            store_col(b, beta[h] + (size_t)g * Ksp, lane);
+            for (int w = 0; w < NW; w++) s += buf[w * 4 + q];
+            x[q] = s;
         }
+        par ^= 1;
     }
-    // Rcpp_run_backward_haploid_QUILT_faster (copied-from-stitch.cpp:417-440)
-    __device__ void backward_faster(int h) {
-        Col<NE> b, e;
-        const double one_over_K = 1 / (double)Ks;
-        const double cl = cv[h][G - 1];
+    __device__ __forceinline__ double bsum1(double v) {
+        double x[1] = {v};
+        bsum<1>(x);
+        return x[0];
+    }
+    __device__ __forceinline__ double sum_col(const Col<NE> &c) {
+        double s = 0;
 #pragma unroll
-        for (int i = 0; i < NE; i++) b.v[i] = valid[i] ? cl : 0.0;
-        store_col(b, beta[h] + (size_t)(G - 1) * Ksp, lane);
-        for (int g = G - 2; g >= 0; --g) {
-            if (ghr[g + 1]) {
-                load_col(e, eg[h] + (size_t)(g + 1) * Ksp, lane);
+        for (int i = 0; i < NE; i++) s += c.v[i];
+        return bsum1(s);
+    }
+    __device__ __forceinline__ void sum_col2(const Col<NE> &c0, const Col<NE> &c1, double &s0, double &s1) {
+        double x[2] = {0, 0};
 #pragma unroll
-                for (int i = 0; i < NE; i++) b.v[i] = e.v[i] * b.v[i];
-            }
-            const double x = tm1(g) * sum_col(b) * one_over_K, cg = cv[h][g], s0 = tm0(g);
-#pragma unroll
-            for (int i = 0; i < NE; i++) b.v[i] = valid[i] ? cg * (x + s0 * b.v[i]) : 0.0;
-            store_col(b, beta[h] + (size_t)g * Ksp, lane);
-        }
+        for (int i = 0; i < NE; i++) { x[0] += c0.v[i]; x[1] += c1.v[i]; }
+        bsum<2>(x);
+        s0 = x[0]; s1 = x[1];
+    }
+    __device__ __forceinline__ void ld(Col<NE> &c, const double *src) const { load_col(c, src, t, NT); }
+    __device__ __forceinline__ void st(const Col<NE> &c, double *dst) const { store_col(c, dst, t, NT); }
+};
+
+// ---- lane-held scalar streams --------------------------------------------------------------
+// The per-grid / per-read scalars of a chain (c, sigma, grid_has_read; wif, category, label) are uniform,
+// and a uniform value loaded through the vector memory path has to be waited for before it can steer
+// control flow -- which would expose one memory round trip per grid and per read and also drain the
+// column prefetches (in-order vmcnt).  Instead lane j of every wave holds element base + j of each
+// stream: ONE vector load per 64 elements, then v_readlane (no memory) per element, and one store per 64
+// elements (by wave 0) for the streams the sampler updates.
+template <class CH>
+struct GridStreams {   // lane j <-> grid base + j
+    double t0, t1;     // transition INTO the grid (forward) or OUT of it (backward)
+    double c0, c1;
+    int has;           // grid_has_read of the grid (forward) or of grid + 1 (backward)
+    int base;
+    __device__ void load_fwd(const CH &ch, int b) {
+        base = b;
+        const int g = b + ch.lane;
+        const bool ok = g < ch.G;
+        t0 = (ok && g > 0) ? ch.tm0(g - 1) : 1.0;
+        t1 = (ok && g > 0) ? ch.tm1(g - 1) : 0.0;
+        c0 = ok ? ch.cv[0][g] : 1.0;
+        c1 = ok ? ch.cv[1][g] : 1.0;
+        has = ok ? ch.ghr[g] : 0;
+    }
+    __device__ void load_bwd(const CH &ch, int b) {
+        base = b;
+        const int g = b + ch.lane;
+        const bool ok = g < ch.G - 1;
+        t0 = ok ? ch.tm0(g) : 1.0;
+        t1 = ok ? ch.tm1(g) : 0.0;
+        c0 = (g < ch.G) ? ch.cv[0][g] : 1.0;
+        c1 = (g < ch.G) ? ch.cv[1][g] : 1.0;
+        has = ok ? ch.ghr[g + 1] : 0;
+    }
+    __device__ void store_c(const CH &ch) const {
+        const int g = base + ch.lane;
+        if (ch.wave == 0 && g < ch.G) { ch.cv[0][g] = c0; ch.cv[1][g] = c1; }
+    }
+    __device__ __forceinline__ void set_c(int lane, int j, double a, double b) {
+        if (lane == j) { c0 = a; c1 = b; }
     }
 };
 
-template <int NE>
-__global__ __launch_bounds__(64) void k_gibbs(GibbsParams p) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    Chain<NE> ch(p, c, lane);
+template <class CH>
+struct ReadStreams {   // lane j <-> read base + j
+    int wif, cat1, H, Hc, base;
+    double u;
+    __device__ void load(const CH &ch, int b, const double *runif, int it) {
+        base = b;
+        const int r = b + ch.lane;
+        const bool ok = r < ch.R;
+        wif = ok ? ch.wif[r] : -1;
+        cat1 = ok ? ch.cat1[r] : 1;
+        H = ok ? ch.H[r] : 1;
+        Hc = ok ? ch.Hc[r] : 0;
+        u = (ok && runif) ? runif[(size_t)ch.R * it + r] : 0.0;
+    }
+    __device__ void store(const CH &ch) const {
+        const int r = base + ch.lane;
+        if (ch.wave == 0 && r < ch.R) { ch.H[r] = H; ch.Hc[r] = Hc; }
+    }
+};
+
+// all waves of the chain must see the global-memory stores of the other waves (columns are private to their
+// owning thread, but cv / H / Hc written by wave 0 are re-read by every wave at the next block refill)
+template <int NW>
+__device__ __forceinline__ void chain_sync() {
+    if (NW > 1) __syncthreads();
+}
+
+// Rcpp_run_forward_haploid (copied-from-stitch.cpp:340-387) for both labels, prior = alphaMat = 1/Ks
+template <int NE, int NW>
+__device__ void forward_full_both(Chain<NE, NW> &ch) {
+    const int G = ch.G, Ksp = ch.Ksp;
+    Col<NE> a[2], e[2];
+    GridStreams<Chain<NE, NW>> gs;
+    for (int g = 0; g < G; g++) {
+        if ((g & 63) == 0) {
+            if (g) gs.store_c(ch);
+            gs.load_fwd(ch, g);
+        }
+        const int j = g & 63;
+        ch.ld(e[0], ch.eg[0] + (size_t)g * Ksp);
+        ch.ld(e[1], ch.eg[1] + (size_t)g * Ksp);
+        const double s0 = rl_f64(gs.t0, j), s1 = rl_f64(gs.t1, j);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int i = 0; i < NE; i++) {
+                if (g == 0) a[h].v[i] = ch.valid[i] ? ch.prior * e[h].v[i] : 0.0;
+                else a[h].v[i] = ch.valid[i] ? e[h].v[i] * (s0 * a[h].v[i] + s1 * ch.prior) : 0.0;
+            }
+        }
+        double sm[2];
+        ch.sum_col2(a[0], a[1], sm[0], sm[1]);
+        const double cc[2] = {1 / sm[0], 1 / sm[1]};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * cc[h];
+            ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+        }
+        gs.set_c(ch.lane, j, cc[0], cc[1]);
+    }
+    gs.store_c(ch);
+    chain_sync<NW>();
+}
+
+// Rcpp_run_backward_haploid (copied-from-stitch.cpp:392-409; FASTER = false) or
+// Rcpp_run_backward_haploid_QUILT_faster (:417-440; FASTER = true), both labels; beta(G-1) = c(G-1)
+template <int NE, int NW, bool FASTER>
+__device__ void backward_both(Chain<NE, NW> &ch) {
+    const int G = ch.G, Ksp = ch.Ksp;
+    const double one_over_K = 1 / (double)ch.Ks;
+    Col<NE> b[2], e[2];
+    GridStreams<Chain<NE, NW>> gs;
+    gs.load_bwd(ch, (G - 1) & ~63);
+    {
+        const int j = (G - 1) & 63;
+        const double cl[2] = {rl_f64(gs.c0, j), rl_f64(gs.c1, j)};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int i = 0; i < NE; i++) b[h].v[i] = ch.valid[i] ? cl[h] : 0.0;
+            ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
+        }
+    }
+    if (G >= 2) {
+        ch.ld(e[0], ch.eg[0] + (size_t)(G - 1) * Ksp);
+        ch.ld(e[1], ch.eg[1] + (size_t)(G - 1) * Ksp);
+    }
+    for (int g = G - 2; g >= 0; --g) {
+        if ((g & 63) == 63) gs.load_bwd(ch, g & ~63);
+        const int j = g & 63;
+        Col<NE> en[2];   // next iteration's emission columns (grid g) while this one computes
+        ch.ld(en[0], ch.eg[0] + (size_t)g * Ksp);
+        ch.ld(en[1], ch.eg[1] + (size_t)g * Ksp);
+        const double s0 = rl_f64(gs.t0, j), s1 = rl_f64(gs.t1, j);
+        const double cg[2] = {rl_f64(gs.c0, j), rl_f64(gs.c1, j)};
+        const bool has = !FASTER || rl_i32(gs.has, j) != 0;
+        double x[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int i = 0; i < NE; i++) {
+                if (has) b[h].v[i] = e[h].v[i] * b[h].v[i];
+                if (FASTER) x[h] += b[h].v[i];
+                else x[h] += ch.valid[i] ? ch.prior * b[h].v[i] : 0.0;
+            }
+        }
+        ch.template bsum<2>(x);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const double xx = FASTER ? s1 * x[h] * one_over_K : s1 * x[h];
+#pragma unroll
+            for (int i = 0; i < NE; i++) b[h].v[i] = ch.valid[i] ? cg[h] * (xx + s0 * b[h].v[i]) : 0.0;
+            ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
+        }
+        e[0] = en[0];
+        e[1] = en[1];
+    }
+}
+
+template <int NE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
+    __shared__ double s_red[2 * NW * 4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    using CH = Chain<NE, NW>;
+    CH ch(p, c, t, s_red);
+    constexpr int NT = CH::NT;
+    const int lane = ch.lane;
     const int G = ch.G, Ksp = ch.Ksp, R = ch.R, Ks = ch.Ks;
     const double prior = ch.prior;
     bool (&valid)[NE] = ch.valid;
-    const double *runif = p.runif_reads + (size_t)p.read_off[c] * p.n_its;
+    const double *runif = p.seed_reads ? nullptr : p.runif_reads + (size_t)p.read_off[c] * p.n_its;
+    const uint64_t seed_reads = p.seed_reads ? p.seed_reads[c] : 0, seed_shard = p.seed_shard ? p.seed_shard[c] : 0;
     const int first_read = p.first_read[c];
 
     // ---- c = 0 (arma::zeros, gibbs-nipt.cpp:2676-2678), H_class = 0
     for (int h = 0; h < 3; h++)
-        for (int g = lane; g < G; g += 64) ch.cv[h][g] = 0.0;
-    for (int r = lane; r < R; r += 64) ch.Hc[r] = 0;
+        for (int g = t; g < G; g += NT) ch.cv[h][g] = 0.0;
+    for (int r = t; r < R; r += NT) ch.Hc[r] = 0;
 
     // ---- rcpp_gibbs_nipt_initialize (:1629-1750)
     {
@@ -333,21 +513,27 @@ __global__ __launch_bounds__(64) void k_gibbs(GibbsParams p) {
 #pragma unroll
         for (int i = 0; i < NE; i++) one.v[i] = 1.0;
         for (int h = 0; h < 2; h++)
-            for (int g = 0; g < G; g++) store_col(one, ch.eg[h] + (size_t)g * Ksp, lane);
+            for (int g = 0; g < G; g++) ch.st(one, ch.eg[h] + (size_t)g * Ksp);
     }
+    chain_sync<NW>();
     if (!p.init_iteratively) {
         // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281): reads are sorted by grid, so the
         // products of one grid are formed in registers in read order
+        ReadStreams<CH> rs;
+        rs.base = -1;
         int r = 0;
         while (r < R) {
-            const int g = ch.wif[r];
+            if ((r & 63) == 0 && rs.base != r) rs.load(ch, r, nullptr, 0);
+            const int g = rl_i32(rs.wif, r & 63);
             Col<NE> e[2];
 #pragma unroll
             for (int i = 0; i < NE; i++) e[0].v[i] = e[1].v[i] = 1.0;
-            while (r < R && ch.wif[r] == g) {
+            while (r < R) {
+                if ((r & 63) == 0 && rs.base != r) rs.load(ch, r, nullptr, 0);
+                if (rl_i32(rs.wif, r & 63) != g) break;
                 Col<NE> er;
-                load_col(er, ch.eMatRead + (size_t)r * Ksp, lane);
-                const int h = ch.H[r] - 1;
+                ch.ld(er, ch.eMatRead + (size_t)r * Ksp);
+                const int h = rl_i32(rs.H, r & 63) - 1;
 #pragma unroll
                 for (int i = 0; i < NE; i++) {
                     if (h == 0) e[0].v[i] *= er.v[i];
@@ -355,18 +541,11 @@ __global__ __launch_bounds__(64) void k_gibbs(GibbsParams p) {
                 }
                 r++;
             }
-            store_col(e[0], ch.eg[0] + (size_t)g * Ksp, lane);
-            store_col(e[1], ch.eg[1] + (size_t)g * Ksp, lane);
+            ch.st(e[0], ch.eg[0] + (size_t)g * Ksp);
+            ch.st(e[1], ch.eg[1] + (size_t)g * Ksp);
         }
-        for (int h = 0; h < 2; h++) {
-            ch.forward_full(h);
-            Col<NE> b;
-            const double cl = ch.cv[h][G - 1];
-#pragma unroll
-            for (int i = 0; i < NE; i++) b.v[i] = valid[i] ? cl : 0.0;
-            store_col(b, ch.beta[h] + (size_t)(G - 1) * Ksp, lane);
-            ch.backward_generic(h);
-        }
+        forward_full_both(ch);
+        backward_both<NE, NW, false>(ch);   // rcpp_initialize_gibbs_forward_backward (:453-487)
     } else {
         // alpha = beta = 1, c = 1, then only column 0 of alpha is initialised (:1725-1740)
         Col<NE> one;
@@ -374,48 +553,85 @@ __global__ __launch_bounds__(64) void k_gibbs(GibbsParams p) {
         for (int i = 0; i < NE; i++) one.v[i] = valid[i] ? 1.0 : 0.0;
         for (int h = 0; h < 2; h++) {
             for (int g = 0; g < G; g++) {
-                store_col(one, ch.alpha[h] + (size_t)g * Ksp, lane);
-                store_col(one, ch.beta[h] + (size_t)g * Ksp, lane);
+                ch.st(one, ch.alpha[h] + (size_t)g * Ksp);
+                ch.st(one, ch.beta[h] + (size_t)g * Ksp);
             }
-            for (int g = lane; g < G; g += 64) ch.cv[h][g] = 1.0;
+            for (int g = t; g < G; g += NT) ch.cv[h][g] = 1.0;
+        }
+        chain_sync<NW>();
+        for (int h = 0; h < 2; h++) {
             Col<NE> a;
 #pragma unroll
             for (int i = 0; i < NE; i++) a.v[i] = valid[i] ? prior * 1.0 : 0.0;
-            const double cc = 1 / sum_col(a);
+            const double cc = 1 / ch.sum_col(a);
 #pragma unroll
             for (int i = 0; i < NE; i++) a.v[i] = a.v[i] * cc;
-            store_col(a, ch.alpha[h], lane);
-            if (lane == 0) ch.cv[h][0] = cc;
+            ch.st(a, ch.alpha[h]);
+            if (t == 0) ch.cv[h][0] = cc;
         }
     }
+    chain_sync<NW>();
 
-    const double rlc3_0 = 0.5 / (0.5 + 0.5), rlc3_1 = 0.5 / (0.5 + 0.5);  // ff = 0 prototypes (:2707-2729)
     int shard_it = 0;
     int status = 0;
     for (int it = 0; it < p.n_its && status == 0; it++) {
         // ================= rcpp_gibbs_nipt_iterate (:1756-1956) =================
-        Col<NE> a[2];   // alpha of the current grid, both labels
+        // H_class (record_read_set, :1142-1165) is overwritten for every sampled read in every sweep, so only
+        // the last sweep's value is observable: it is computed there only.
+        const bool last_sweep = it == p.n_its - 1;
+        Col<NE> a[2];   // alpha of the current grid, both labels (also the reference's alphaHat_m)
         int iRead = 0;  // next unprocessed read
+        // software pipeline over reads: the emission column of read iRead is always in flight one read
+        // ahead of its use; all per-read scalars come from the lane-held streams
+        Col<NE> pre_er;
+        if (R > 0) ch.ld(pre_er, ch.eMatRead);
+        ReadStreams<CH> rs;
+        rs.base = -1;
+        GridStreams<CH> gs;
+        Col<NE> e[2], bt[2];
+        ch.ld(e[0], ch.eg[0]);
+        ch.ld(e[1], ch.eg[1]);
+        ch.ld(bt[0], ch.beta[0]);
+        ch.ld(bt[1], ch.beta[1]);
         for (int g = 0; g < G; g++) {
-            Col<NE> e[2];
-            const bool has = ch.ghr[g] != 0;
-            load_col(e[0], ch.eg[0] + (size_t)g * Ksp, lane);
-            load_col(e[1], ch.eg[1] + (size_t)g * Ksp, lane);
+            if ((g & 63) == 0) {
+                if (g) gs.store_c(ch);
+                gs.load_fwd(ch, g);
+            }
+            const int jg = g & 63;
+            const bool has = rl_i32(gs.has, jg) != 0;
+            // next grid's eMatGrid and beta columns: issued now, used after this grid's reads
+            Col<NE> en[2], bn[2];
+            {
+                const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: loads stay unconditional
+                ch.ld(en[0], ch.eg[0] + gn);
+                ch.ld(en[1], ch.eg[1] + gn);
+                ch.ld(bn[0], ch.beta[0] + gn);
+                ch.ld(bn[1], ch.beta[1] + gn);
+            }
             double cg[2];
             if (g > 0) {
                 // rcpp_alpha_forward_one_QUILT_faster (:671-707), normalize = true
-                const double x = ch.tm0(g - 1), t1 = ch.tm1(g - 1);
+                const double x = rl_f64(gs.t0, jg), t1 = rl_f64(gs.t1, jg);
                 const double one_over_K = 1 / (double)Ks;
+                const double c2v[2] = {rl_f64(gs.c0, jg), rl_f64(gs.c1, jg)};
+                double sp[2];
+                ch.sum_col2(a[0], a[1], sp[0], sp[1]);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const double alphaConst = t1 * sum_col(a[h]);
-                    const double c2 = ch.cv[h][g];
+                    const double alphaConst = t1 * sp[h];
 #pragma unroll
                     for (int i = 0; i < NE; i++) {
                         const double inner = (x * a[h].v[i] + alphaConst * one_over_K);
                         a[h].v[i] = valid[i] ? (has ? e[h].v[i] * inner : inner) : 0.0;
                     }
-                    double aa = 1 / (c2 * sum_col(a[h]));
+                }
+                double sn[2];
+                ch.sum_col2(a[0], a[1], sn[0], sn[1]);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const double c2 = c2v[h];
+                    double aa = 1 / (c2 * sn[h]);
                     cg[h] = c2 * aa;
                     aa *= c2;
 #pragma unroll
@@ -427,116 +643,105 @@ __global__ __launch_bounds__(64) void k_gibbs(GibbsParams p) {
                 for (int h = 0; h < 2; h++) {
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] = valid[i] ? prior * e[h].v[i] : 0.0;
-                    cg[h] = 1 / sum_col(a[h]);
+                }
+                double sn[2];
+                ch.sum_col2(a[0], a[1], sn[0], sn[1]);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    cg[h] = 1 / sn[h];
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] *= cg[h];
                 }
             }
-            // ---- sample_reads_in_grid (:733-1295)
+            // ---- sample_reads_in_grid (:733-1295), diploid: labels 0 / 1, the third label has prior 0, pC(2) = 1
             bool grid_started = false, changed = false;
-            Col<NE> am[2], ab[2];
-            double pC[3] = {1, 1, 1}, pA1[3] = {1, 1, 1}, pA2[3] = {1, 1, 1};
-            int h_rC = 0, h_rA1 = 1, h_rA2 = 2;
+            Col<NE> ab[2];
+            double pC[2] = {1, 1};
+            int h_rC = 0, h_rA1 = 1;
             bool normal = false, ginit = false, pass = false;
-            while (iRead < R && ch.wif[iRead] == g) {
+            while (iRead < R) {
+                if ((iRead & 63) == 0 && rs.base != iRead) {
+                    if (rs.base >= 0) rs.store(ch);
+                    rs.load(ch, iRead, runif, it);
+                }
+                const int jr = iRead & 63;
+                if (rl_i32(rs.wif, jr) != g) break;
                 const int r = iRead;
+                const Col<NE> er = pre_er;
                 iRead++;
-                if (ch.cat1[r]) continue;  // diploid: reads that cannot discriminate are skipped (:815)
+                // unconditional (clamped) so that no control-flow join forces the in-order vmcnt to drain
+                ch.ld(pre_er, ch.eMatRead + (size_t)min(iRead, R - 1) * Ksp);
+                if (rl_i32(rs.cat1, jr) != 0) continue;  // reads that cannot discriminate are skipped (:815)
                 if (!p.init_iteratively) normal = true;
                 else if (r < first_read && it == 0) pass = true;
                 else if (first_read <= r && it == 0) { pass = false; ginit = true; }
                 else if (r < first_read && it == 1) { pass = false; ginit = true; }
                 else { ginit = false; normal = true; }
                 if (!grid_started) {
-                    Col<NE> b;
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        load_col(b, ch.beta[h] + (size_t)g * Ksp, lane);
 #pragma unroll
-                        for (int i = 0; i < NE; i++) {
-                            am[h].v[i] = a[h].v[i];
-                            ab[h].v[i] = a[h].v[i] * b.v[i];
-                        }
-                        pC[h] = sum_col(ab[h]);
+                        for (int i = 0; i < NE; i++) ab[h].v[i] = a[h].v[i] * bt[h].v[i];
                     }
-                    pC[2] = 1;
+                    ch.sum_col2(ab[0], ab[1], pC[0], pC[1]);
                     grid_started = true;
                 }
-                Col<NE> er;
-                load_col(er, ch.eMatRead + (size_t)r * Ksp, lane);
+                double pA1[2] = {pC[0], pC[1]};
                 if (normal) {
-                    h_rC = ch.H[r] - 1;
-                    h_rA1 = (h_rC == 0) ? 1 : 0;
-                    h_rA2 = (h_rC == 2) ? 1 : 2;
-                    for (int h = 0; h < 3; h++) pA1[h] = pA2[h] = pC[h];
+                    h_rC = rl_i32(rs.H, jr) - 1;
+                    h_rA1 = 1 - h_rC;
                     // dense form for every category (the reference's sparse category-2/3 updates are
                     // algebraically the same sums: test-unit-gibbs-diploid.R:114-124)
-                    double s1 = 0, s2 = 0;
+                    double s[2] = {0, 0};
 #pragma unroll
                     for (int i = 0; i < NE; i++) {
                         const double xc = (h_rC == 0) ? ab[0].v[i] : ab[1].v[i];
                         const double xa = (h_rC == 0) ? ab[1].v[i] : ab[0].v[i];
-                        s1 += xc / er.v[i];
-                        s2 += xa * er.v[i];
+                        s[0] += xc / er.v[i];
+                        s[1] += xa * er.v[i];
                     }
-                    pA1[h_rC] = wsum(s1);
-                    pA1[h_rA1] = wsum(s2);
-                    pA2[h_rA1] = pC[h_rA1];
-                    pA2[h_rC] = pA1[h_rC];
+                    ch.template bsum<2>(s);
+                    pA1[h_rC] = s[0];     // the current label loses the read
+                    pA1[h_rA1] = s[1];    // the other label gains it
                 } else if (ginit) {
-                    h_rC = 0; h_rA1 = 1; h_rA2 = 2;
-                    for (int h = 0; h < 3; h++) pA1[h] = pA2[h] = pC[h];
-                    double s1 = 0, s2 = 0;
+                    h_rC = 0; h_rA1 = 1;
+                    double s[2] = {0, 0};
 #pragma unroll
                     for (int i = 0; i < NE; i++) {
-                        s1 += ab[0].v[i] * er.v[i];
-                        s2 += ab[1].v[i] * er.v[i];
+                        s[0] += ab[0].v[i] * er.v[i];
+                        s[1] += ab[1].v[i] * er.v[i];
                     }
-                    pC[0] = wsum(s1);
-                    pA1[1] = wsum(s2);
-                } else {
-                    for (int h = 0; h < 3; h++) pA1[h] = pA2[h] = pC[h];
+                    ch.template bsum<2>(s);
+                    pC[0] = s[0];
+                    pA1[1] = s[1];
                 }
-                const double prior_probs[3] = {0.5, (1 - 0.0) * 0.5, 0.0 * 0.5};
-                const double prod_pC = (pC[0] * pC[1] * pC[2]) * prior_probs[h_rC];
-                const double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * prior_probs[h_rA1];
-                const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * prior_probs[h_rA2];
-                const double denom = prod_pC + prod_pA1 + prod_pA2;
-                const double norm_pC = prod_pC / denom, norm_pA1 = prod_pA1 / denom, norm_pA2 = prod_pA2 / denom;
-                const double chance = runif[(size_t)R * it + r];
-                double cs[3] = {0, 0, 0};
-                cs[h_rC] = norm_pC;
-                cs[h_rA1] = norm_pA1;
-                cs[h_rA2] = norm_pA2;
-                cs[1] += cs[0];
-                cs[2] += cs[1];
-                int h_rN = 0;
-                for (int i = 2; i >= 0; i--) if (chance < cs[i]) h_rN = i;
-                if (((h_rN != h_rC) || ginit) && !pass && h_rN < 2) {
+                // (:998-1046) prior_probs = (0.5, 0.5, 0) and pC(2) = pA(2) = 1: the factors 1 and 0.5 are exact,
+                // so the normalised probabilities are P / (P + Q) and Q / (P + Q) bit for bit; label 3 has weight 0
+                const double P = pC[0] * pC[1], Q = pA1[0] * pA1[1];
+                const double denom = P + Q;
+                const double norm_pC = P / denom, norm_pA1 = Q / denom;
+                const double chance = runif ? rl_f64(rs.u, jr) : stream_uniform(seed_reads, (uint64_t)R * it + r);
+                const double p0 = (h_rC == 0) ? norm_pC : norm_pA1, p1 = (h_rC == 0) ? norm_pA1 : norm_pC;
+                const double cs0 = p0, cs1 = p1 + p0;
+                const int h_rN = (chance < cs0) ? 0 : ((chance < cs1) ? 1 : 0);
+                if (((h_rN != h_rC) || ginit) && !pass) {
                     changed = true;
-                    if (lane == 0) ch.H[r] = h_rN + 1;
+                    if (lane == jr) rs.H = h_rN + 1;
 #pragma unroll
                     for (int i = 0; i < NE; i++) {
                         if (normal) {
-                            if (h_rC == 0) { am[0].v[i] /= er.v[i]; ab[0].v[i] /= er.v[i]; e[0].v[i] /= er.v[i]; }
-                            else { am[1].v[i] /= er.v[i]; ab[1].v[i] /= er.v[i]; e[1].v[i] /= er.v[i]; }
+                            if (h_rC == 0) { a[0].v[i] /= er.v[i]; ab[0].v[i] /= er.v[i]; e[0].v[i] /= er.v[i]; }
+                            else { a[1].v[i] /= er.v[i]; ab[1].v[i] /= er.v[i]; e[1].v[i] /= er.v[i]; }
                         }
-                        if (h_rN == 0) { am[0].v[i] *= er.v[i]; ab[0].v[i] *= er.v[i]; e[0].v[i] *= er.v[i]; }
-                        else { am[1].v[i] *= er.v[i]; ab[1].v[i] *= er.v[i]; e[1].v[i] *= er.v[i]; }
+                        if (h_rN == 0) { a[0].v[i] *= er.v[i]; ab[0].v[i] *= er.v[i]; e[0].v[i] *= er.v[i]; }
+                        else { a[1].v[i] *= er.v[i]; ab[1].v[i] *= er.v[i]; e[1].v[i] *= er.v[i]; }
                     }
-                    if (normal) {
-                        for (int i = 0; i < 3; i++) pC[i] = (h_rN == h_rA1) ? pA1[i] : pA2[i];
-                    } else if (ginit) {
-                        if (h_rN == 1) for (int i = 0; i < 3; i++) pC[i] = pA1[i];
-                    }
+                    if (normal || h_rN == 1) { pC[0] = pA1[0]; pC[1] = pA1[1]; }
                 }
-                // record_read_set (:1142-1165)
-                {
-                    double x[3];
-                    x[h_rC] = norm_pC;
-                    x[h_rA1] = norm_pA1;
-                    x[h_rA2] = norm_pA2;
-                    const double rlc[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {rlc3_0, rlc3_1, 0},
+                if (last_sweep) {
+                    // record_read_set (:1142-1165) with the ff = 0 prototypes (:2707-2729)
+                    const double x[3] = {p0, p1, 0.0};
+                    const double rlc[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0.5 / (0.5 + 0.5), 0.5 / (0.5 + 0.5), 0},
                                               {0.5 / (0.5 + 0.0), 0, 0.0 / (0.5 + 0.0)},
                                               {0, 0.5 / (0.5 + 0.0), 0.0 / (0.5 + 0.0)}, {0.5, 0.5, 0.0}};
                     double local_min = 2;
@@ -545,34 +750,38 @@ __global__ __launch_bounds__(64) void k_gibbs(GibbsParams p) {
                         const double y = fabs(rlc[i][0] - x[0]) + fabs(rlc[i][1] - x[1]) + fabs(rlc[i][2] - x[2]);
                         if (y < local_min) { local_min = y; which = i; }
                     }
-                    if (lane == 0) ch.Hc[r] = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
+                    if (lane == jr) rs.Hc = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
                 }
             }
             if (changed) {
                 // re-inject the moved columns and renormalise (:1262-1292)
+                double sm[2];
+                ch.sum_col2(a[0], a[1], sm[0], sm[1]);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const double alphaConst = 1 / sum_col(am[h]);
+                    const double alphaConst = 1 / sm[h];
                     cg[h] *= alphaConst;
 #pragma unroll
-                    for (int i = 0; i < NE; i++) a[h].v[i] = am[h].v[i] * alphaConst;
-                    store_col(e[h], ch.eg[h] + (size_t)g * Ksp, lane);
+                    for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
+                    ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
                 }
             }
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                store_col(a[h], ch.alpha[h] + (size_t)g * Ksp, lane);
-                if (lane == 0) ch.cv[h][g] = cg[h];
-            }
+            for (int h = 0; h < 2; h++) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+            gs.set_c(lane, jg, cg[0], cg[1]);
+            e[0] = en[0]; e[1] = en[1];
+            bt[0] = bn[0]; bt[1] = bn[1];
         }
-            ch.backward_faster(0);
-        ch.backward_faster(1);
+        gs.store_c(ch);
+        if (rs.base >= 0) rs.store(ch);
+        chain_sync<NW>();
+        backward_both<NE, NW, true>(ch);
         // ---- underflow check (:2959-2969)
-        for (int h = 0; h < 2; h++) {
-            double s = 0;
-            for (int g = lane; g < G; g += 64) s += ch.cv[h][g];
-            s = wsum(s);
-            if (!isfinite(s)) status = 1;
+        {
+            double s[2] = {0, 0};
+            for (int g = t; g < G; g += NT) { s[0] += ch.cv[0][g]; s[1] += ch.cv[1][g]; }
+            ch.template bsum<2>(s);
+            if (!isfinite(s[0]) || !isfinite(s[1])) status = 1;
         }
         if (status) break;
         bool to_block = false;
@@ -583,99 +792,129 @@ __global__ __launch_bounds__(64) void k_gibbs(GibbsParams p) {
             // to the right swaps haplotypes ============
             const double *ru = p.runif_shard + ((size_t)c * p.n_block + shard_it) * (G - 1);
             shard_it++;
-            double mloc1 = 0, mloc2 = 0, mlc1 = 0, mlc2 = 0;
+            double mloc1, mloc2, mlc1 = 0, mlc2 = 0;
             {
-                double s1 = 0, s2 = 0;
-                // sequential order matters little here; keep the reference's running form per lane 0
-                for (int g = 0; g < G; g++) { s1 -= log(ch.cv[0][g]); s2 -= log(ch.cv[1][g]); }
-                mloc1 = s1; mloc2 = s2;
+                double s[2] = {0, 0};
+                for (int g = t; g < G; g += NT) { s[0] -= log(ch.cv[0][g]); s[1] -= log(ch.cv[1][g]); }
+                ch.template bsum<2>(s);
+                mloc1 = s[0]; mloc2 = s[1];
             }
             bool flip = false;
             int ir = 0;
             Col<NE> s_a[2];
+            GridStreams<CH> ss;
+            ReadStreams<CH> rr;
+            rr.base = -1;
+            bool rr_dirty = false;
             for (int g = 0; g < G; g++) {
-                const double oc1 = ch.cv[0][g], oc2 = ch.cv[1][g];
-                Col<NE> e[2];
-                load_col(e[0], ch.eg[0] + (size_t)g * Ksp, lane);
-                load_col(e[1], ch.eg[1] + (size_t)g * Ksp, lane);
+                if ((g & 63) == 0) {
+                    if (g) ss.store_c(ch);
+                    ss.load_fwd(ch, g);
+                }
+                const int jg = g & 63;
+                const double oc1 = rl_f64(ss.c0, jg), oc2 = rl_f64(ss.c1, jg);
+                Col<NE> e2[2];
+                ch.ld(e2[0], ch.eg[0] + (size_t)g * Ksp);
+                ch.ld(e2[1], ch.eg[1] + (size_t)g * Ksp);
+                Col<NE> b1, b2;
+                if (g < G - 1) {
+                    ch.ld(b1, ch.beta[0] + (size_t)g * Ksp);
+                    ch.ld(b2, ch.beta[1] + (size_t)g * Ksp);
+                }
                 double cn[2];
                 if (g == 0) {
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
 #pragma unroll
-                        for (int i = 0; i < NE; i++) s_a[h].v[i] = valid[i] ? prior * e[h].v[i] : 0.0;
-                        cn[h] = 1 / sum_col(s_a[h]);
+                        for (int i = 0; i < NE; i++) s_a[h].v[i] = valid[i] ? prior * e2[h].v[i] : 0.0;
+                    }
+                    double sm[2];
+                    ch.sum_col2(s_a[0], s_a[1], sm[0], sm[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        cn[h] = 1 / sm[h];
 #pragma unroll
                         for (int i = 0; i < NE; i++) s_a[h].v[i] *= cn[h];
                     }
                 } else {
                     if (flip) {
-                        Col<NE> t = e[0]; e[0] = e[1]; e[1] = t;
-                        store_col(e[0], ch.eg[0] + (size_t)g * Ksp, lane);
-                        store_col(e[1], ch.eg[1] + (size_t)g * Ksp, lane);
+                        Col<NE> tmp = e2[0]; e2[0] = e2[1]; e2[1] = tmp;
+                        ch.st(e2[0], ch.eg[0] + (size_t)g * Ksp);
+                        ch.st(e2[1], ch.eg[1] + (size_t)g * Ksp);
                     }
                     // rcpp_alpha_forward_one (gibbs-nipt.cpp:627-657), alphaMat = 1/Ks, normalize
-                    const double x = ch.tm0(g - 1), t1 = ch.tm1(g - 1);
+                    const double x = rl_f64(ss.t0, jg), t1 = rl_f64(ss.t1, jg);
+                    double sp[2];
+                    ch.sum_col2(s_a[0], s_a[1], sp[0], sp[1]);
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        const double alphaConst = t1 * sum_col(s_a[h]);
+                        const double alphaConst = t1 * sp[h];
                         const double c2 = (h == 0) ? oc1 : oc2;
 #pragma unroll
                         for (int i = 0; i < NE; i++)
-                            s_a[h].v[i] = valid[i] ? c2 * e[h].v[i] * (x * s_a[h].v[i] + alphaConst * prior) : 0.0;
-                        const double aa = 1 / sum_col(s_a[h]);
+                            s_a[h].v[i] = valid[i] ? c2 * e2[h].v[i] * (x * s_a[h].v[i] + alphaConst * prior) : 0.0;
+                    }
+                    double sm[2];
+                    ch.sum_col2(s_a[0], s_a[1], sm[0], sm[1]);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const double c2 = (h == 0) ? oc1 : oc2;
+                        const double aa = 1 / sm[h];
                         cn[h] = c2 * aa;
 #pragma unroll
                         for (int i = 0; i < NE; i++) s_a[h].v[i] *= aa;
                     }
                 }
-                store_col(s_a[0], ch.alpha[0] + (size_t)g * Ksp, lane);
-                store_col(s_a[1], ch.alpha[1] + (size_t)g * Ksp, lane);
-                if (lane == 0) { ch.cv[0][g] = cn[0]; ch.cv[1][g] = cn[1]; }
+                ch.st(s_a[0], ch.alpha[0] + (size_t)g * Ksp);
+                ch.st(s_a[1], ch.alpha[1] + (size_t)g * Ksp);
+                ss.set_c(lane, jg, cn[0], cn[1]);
                 mlc1 -= log(cn[0]);
                 mlc2 -= log(cn[1]);
-                while (ir < R && ch.wif[ir] == g) {
-                    if (flip && lane == 0) ch.H[ir] = 3 - ch.H[ir];
+                while (ir < R) {
+                    if ((ir & 63) == 0 && rr.base != ir) {
+                        if (rr.base >= 0 && rr_dirty) rr.store(ch);
+                        rr.load(ch, ir, nullptr, 0);
+                        rr_dirty = false;
+                    }
+                    if (rl_i32(rr.wif, ir & 63) != g) break;
+                    if (flip) {
+                        if (lane == (ir & 63)) rr.H = 3 - rr.H;
+                        rr_dirty = true;
+                    }
                     ir++;
                 }
                 if (g < G - 1) {
-                    Col<NE> b1, b2;
-                    load_col(b1, ch.beta[0] + (size_t)g * Ksp, lane);
-                    load_col(b2, ch.beta[1] + (size_t)g * Ksp, lane);
-                    double s11 = 0, s22 = 0, s21 = 0, s12 = 0;
+                    double s[4] = {0, 0, 0, 0};
 #pragma unroll
                     for (int i = 0; i < NE; i++) {
-                        s11 += s_a[0].v[i] * b1.v[i];
-                        s22 += s_a[1].v[i] * b2.v[i];
-                        s21 += s_a[1].v[i] * b1.v[i];
-                        s12 += s_a[0].v[i] * b2.v[i];
+                        s[0] += s_a[0].v[i] * b1.v[i];
+                        s[1] += s_a[1].v[i] * b2.v[i];
+                        s[2] += s_a[1].v[i] * b1.v[i];
+                        s[3] += s_a[0].v[i] * b2.v[i];
                     }
-                    s11 = wsum(s11); s22 = wsum(s22); s21 = wsum(s21); s12 = wsum(s12);
-                    const double pA1 = mlc1 + mloc1 + log(s11);
-                    const double pA2 = mlc2 + mloc2 + log(s22);
-                    const double pB1 = mlc2 + mloc1 + log(s21);
-                    const double pB2 = mlc1 + mloc2 + log(s12);
+                    ch.template bsum<4>(s);
+                    const double pA1 = mlc1 + mloc1 + log(s[0]);
+                    const double pA2 = mlc2 + mloc2 + log(s[1]);
+                    const double pB1 = mlc2 + mloc1 + log(s[2]);
+                    const double pB2 = mlc1 + mloc2 + log(s[3]);
                     const double diff = pB1 + pB2 - pA1 - pA2;
                     double probs1 = 1;
                     const double probs2 = exp(diff);
                     const double ps = probs1 + probs2;
                     probs1 /= ps;
-                    flip = ru[g] > probs1;
+                    const double ug = seed_shard ? stream_uniform(seed_shard, (uint64_t)(shard_it - 1) * (G - 1) + g) : ru[g];
+                    flip = ug > probs1;
                 }
                 mloc1 += log(oc1);
                 mloc2 += log(oc2);
             }
-                    for (int h = 0; h < 2; h++) {
-                Col<NE> b;
-                const double cl = ch.cv[h][G - 1];
-#pragma unroll
-                for (int i = 0; i < NE; i++) b.v[i] = valid[i] ? cl : 0.0;
-                store_col(b, ch.beta[h] + (size_t)(G - 1) * Ksp, lane);
-                ch.backward_generic(h);
-            }
+            ss.store_c(ch);
+            if (rr.base >= 0 && rr_dirty) rr.store(ch);
+            chain_sync<NW>();
+            backward_both<NE, NW, false>(ch);
         }
     }
-    if (lane == 0) p.status[c] = status;
+    if (t == 0) p.status[c] = status;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -797,6 +1036,7 @@ struct GibbsScratch {
     DBuf<uint8_t> ghr, is_cat1;
     DBuf<double> tabs, runif_reads, runif_shard, eMatRead, alpha, beta, eg, cvec, hap, gm, gf, tm;
     DBuf<size_t> eread_off;
+    DBuf<uint64_t> seeds;
 };
 
 }  // namespace qa
@@ -844,17 +1084,71 @@ std::vector<double> base_quality_tables() {
     return tabs;
 }
 
-template <int NE>
-void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev) {
+template <int NE_READ>
+void launch_ematread(const GibbsParams &prm, int maxR, hipStream_t st) {
+    hipLaunchKernelGGL(k_ematread<NE_READ>, dim3(maxR, prm.C), dim3(64), 0, st, prm);
+    QA_HIP(hipGetLastError());
+}
+
+template <int NE, int NW>
+void launch_gibbs_kernel(const GibbsParams &prm, hipStream_t st) {
+    hipLaunchKernelGGL((k_gibbs<NE, NW>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
+    QA_HIP(hipGetLastError());
+}
+
+// Geometry of one chain: NW waves x NE rows per thread with 64 * NW * NE == Ksp.  More waves shorten the
+// serial chain (latency) at the price of repeating the per-read scalar logic in every wave (throughput):
+// use as many waves as keep the chip at about one wave per SIMD.
+void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs) {
+    const int NE1 = prm.Ksp / 64;   // rows per lane with one wave
     QA_HIP(hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(k_ematread<NE>, dim3(maxR, prm.C), dim3(64), 0, st, prm);
-    QA_HIP(hipGetLastError());
+    switch (NE1) {
+        case 1: launch_ematread<1>(prm, maxR, st); break;
+        case 2: launch_ematread<2>(prm, maxR, st); break;
+        case 3: launch_ematread<3>(prm, maxR, st); break;
+        case 4: launch_ematread<4>(prm, maxR, st); break;
+        case 5: launch_ematread<5>(prm, maxR, st); break;
+        case 6: launch_ematread<6>(prm, maxR, st); break;
+        case 7: launch_ematread<7>(prm, maxR, st); break;
+        case 8: launch_ematread<8>(prm, maxR, st); break;
+        case 9: launch_ematread<9>(prm, maxR, st); break;
+        case 10: launch_ematread<10>(prm, maxR, st); break;
+        case 12: launch_ematread<12>(prm, maxR, st); break;
+        case 16: launch_ematread<16>(prm, maxR, st); break;
+        default: throw std::runtime_error("Ksubset geometry not built (Ksubset / 64 rounded up must be 1..10, 12 or 16)");
+    }
     QA_HIP(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(k_gibbs<NE>, dim3(prm.C), dim3(64), 0, st, prm);
-    QA_HIP(hipGetLastError());
+    const int budget = 1280;  // waves that fit at ~1 per SIMD on 256 CUs, with some slack
+    int nw = 1;
+    for (int cand : {10, 5, 2}) {
+        if (NE1 % cand == 0 && (long)prm.C * cand <= budget) { nw = cand; break; }
+    }
+    if (const char *forced = getenv("QA_GIBBS_NW")) nw = atoi(forced);   // test hook: exercise every geometry
+    if (NE1 == 10) {
+        if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
+        else if (nw == 5) launch_gibbs_kernel<2, 5>(prm, st);
+        else if (nw == 2) launch_gibbs_kernel<5, 2>(prm, st);
+        else launch_gibbs_kernel<10, 1>(prm, st);
+    } else {
+        switch (NE1) {
+            case 1: launch_gibbs_kernel<1, 1>(prm, st); break;
+            case 2: launch_gibbs_kernel<2, 1>(prm, st); break;
+            case 3: launch_gibbs_kernel<3, 1>(prm, st); break;
+            case 4: launch_gibbs_kernel<4, 1>(prm, st); break;
+            case 5: launch_gibbs_kernel<5, 1>(prm, st); break;
+            case 6: launch_gibbs_kernel<6, 1>(prm, st); break;
+            case 7: launch_gibbs_kernel<7, 1>(prm, st); break;
+            case 8: launch_gibbs_kernel<8, 1>(prm, st); break;
+            case 9: launch_gibbs_kernel<9, 1>(prm, st); break;
+            case 12: launch_gibbs_kernel<12, 1>(prm, st); break;
+            default: launch_gibbs_kernel<16, 1>(prm, st); break;
+        }
+    }
     QA_HIP(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(k_happrobs, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
-    QA_HIP(hipGetLastError());
+    if (want_probs) {   // return_hapProbs / return_genProbs (functions.R:2566-2599): skipped when nobody asks
+        hipLaunchKernelGGL(k_happrobs, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
+        QA_HIP(hipGetLastError());
+    }
     QA_HIP(hipEventRecord(ev[3], st));
 }
 
@@ -866,10 +1160,11 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
-                   double *genProbsM_t, double *genProbsF_t, int32_t *underflow_problem, double *state_out) {
+                   double *genProbsM_t, double *genProbsF_t, int32_t *underflow_problem, double *state_out,
+                   const uint64_t *seed_reads, const uint64_t *seed_shard) {
     if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
     if (!pn || !o || n_chain <= 0 || !which_haps_to_use_1based || !read_off || !read_ptr || !u || !bq || !wif ||
-        !runif_reads || !first_read || !H) {
+        (!runif_reads && !seed_reads) || !first_read || !H) {
         qa::set_error("qa_gibbs_batch: null argument");
         return QA_ERR_INVALID;
     }
@@ -935,11 +1230,19 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         S.block_its.ensure(std::max(o->n_block_gibbs_iterations, 1));
         S.block_its.upload(o->block_gibbs_iterations, o->n_block_gibbs_iterations, st);
         S.first_read.ensure(C); S.first_read.upload(first_read, C, st);
-        S.runif_reads.ensure(std::max<size_t>((size_t)totR * n_its, 1));
-        S.runif_reads.upload(runif_reads, (size_t)totR * n_its, st);
+        if (!seed_reads) {
+            S.runif_reads.ensure(std::max<size_t>((size_t)totR * n_its, 1));
+            S.runif_reads.upload(runif_reads, (size_t)totR * n_its, st);
+        } else {
+            S.runif_reads.ensure(1);
+            S.seeds.ensure((size_t)2 * C);
+            S.seeds.upload(seed_reads, C, st);
+            QA_HIP(hipMemcpyAsync(S.seeds.p + C, seed_shard ? seed_shard : seed_reads, sizeof(uint64_t) * C,
+                                  hipMemcpyHostToDevice, st));
+        }
         const size_t nshard = (size_t)C * std::max(o->n_block_gibbs_iterations, 1) * std::max(G - 1, 1);
         S.runif_shard.ensure(nshard);
-        if (runif_shard && o->n_block_gibbs_iterations > 0)
+        if (runif_shard && !seed_shard && o->n_block_gibbs_iterations > 0)
             S.runif_shard.upload(runif_shard, (size_t)C * o->n_block_gibbs_iterations * (G - 1), st);
         S.eread_off.ensure(C); S.eread_off.upload(eoff.data(), C, st);
         S.eMatRead.ensure(std::max<size_t>(etot, 1));
@@ -950,7 +1253,9 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         S.H.ensure(std::max(totR, 1)); S.H.upload(H, totR, st);
         S.H_class.ensure(std::max(totR, 1));
         S.status.ensure(C);
-        S.hap.ensure((size_t)C * T * 3); S.gm.ensure((size_t)C * T * 3); S.gf.ensure((size_t)C * T * 3);
+        if (hapProbs_t || genProbsM_t || genProbsF_t) {
+            S.hap.ensure((size_t)C * T * 3); S.gm.ensure((size_t)C * T * 3); S.gf.ensure((size_t)C * T * 3);
+        }
 
         GibbsParams prm{};
         prm.hm = pn->hm.p; prm.B = pn->B.p; prm.sp_off = pn->sp_off.p; prm.sp_k = pn->sp_k.p;
@@ -967,27 +1272,16 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         prm.disable_read_category_usage = o->disable_read_category_usage;
         prm.class_sum_cutoff = o->class_sum_cutoff;
         prm.runif_reads = S.runif_reads.p; prm.first_read = S.first_read.p; prm.runif_shard = S.runif_shard.p;
+        prm.seed_reads = seed_reads ? S.seeds.p : nullptr;
+        prm.seed_shard = (seed_reads && seed_shard) ? S.seeds.p + C : nullptr;
         prm.eMatRead = S.eMatRead.p; prm.eread_off = S.eread_off.p; prm.is_cat1 = S.is_cat1.p;
         prm.alpha = S.alpha.p; prm.beta = S.beta.p; prm.eg = S.eg.p; prm.cvec = S.cvec.p;
         prm.H = S.H.p; prm.H_class = S.H_class.p; prm.status = S.status.p;
         prm.hapProbs = S.hap.p; prm.genProbsM = S.gm.p; prm.genProbsF = S.gf.p;
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
-        switch (NE) {
-            case 1: launch_gibbs<1>(prm, maxR, st, g_gibbs->ev); break;
-            case 2: launch_gibbs<2>(prm, maxR, st, g_gibbs->ev); break;
-            case 3: launch_gibbs<3>(prm, maxR, st, g_gibbs->ev); break;
-            case 4: launch_gibbs<4>(prm, maxR, st, g_gibbs->ev); break;
-            case 5: launch_gibbs<5>(prm, maxR, st, g_gibbs->ev); break;
-            case 6: launch_gibbs<6>(prm, maxR, st, g_gibbs->ev); break;
-            case 7: launch_gibbs<7>(prm, maxR, st, g_gibbs->ev); break;
-            case 8: launch_gibbs<8>(prm, maxR, st, g_gibbs->ev); break;
-            case 9: launch_gibbs<9>(prm, maxR, st, g_gibbs->ev); break;
-            case 10: launch_gibbs<10>(prm, maxR, st, g_gibbs->ev); break;
-            case 12: launch_gibbs<12>(prm, maxR, st, g_gibbs->ev); break;
-            case 16: launch_gibbs<16>(prm, maxR, st, g_gibbs->ev); break;
-            default: throw std::runtime_error("Ksubset geometry not built (NE must be 1..10, 12 or 16)");
-        }
+        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
+        launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs);
         S.H.download(H, totR, st);
         if (H_class) S.H_class.download(H_class, totR, st);
         std::vector<int32_t> status(C);

@@ -119,18 +119,33 @@ def everything_select_good_haps(Knew: int, K_top_matches: int, new_haps: List[Li
                                 previously_selected_haplotypes: np.ndarray, K: int,
                                 rng: np.random.Generator) -> np.ndarray:
     """functions.R:2262-2310.  ``new_haps[label][thinned grid]`` = 1-based haplotypes, best first."""
+    width = max((len(y) for x in new_haps for y in x), default=0)
+    dense = np.zeros((len(new_haps), max((len(x) for x in new_haps), default=0), max(width, 1)), dtype=np.int64)
+    for a, x in enumerate(new_haps):
+        for b, y in enumerate(x):
+            dense[a, b, : len(y)] = y
+    return everything_select_good_haps_dense(Knew, K_top_matches, dense, previously_selected_haplotypes, K, rng)
+
+
+def everything_select_good_haps_dense(Knew: int, K_top_matches: int, top: np.ndarray,
+                                      previously_selected_haplotypes: np.ndarray, K: int,
+                                      rng: np.random.Generator) -> np.ndarray:
+    """functions.R:2262-2310 on a dense table ``top[label, thinned grid, rank]`` of 1-based haplotypes (0 = no
+    entry), each list ordered best first (functions.R:2161-2170).  Rank by rank, the distinct candidates (label-
+    major, grid order: R's ``unlist(sapply(new_haps, ...))``) are added until ``Knew`` are found; the last rank
+    is subsampled at random."""
     i = 1
     to_keep = np.zeros(0, dtype=np.int64)
     prev = np.asarray(previously_selected_haplotypes, dtype=np.int64)
     done = False
     while not done:
-        if i <= K_top_matches:
-            vals = [y[i - 1] for x in new_haps for y in x if len(y) >= i]
-            new = _unique_in_order(np.asarray(vals, dtype=np.int64)) if vals else np.zeros(0, dtype=np.int64)
+        if i <= K_top_matches and i <= top.shape[2]:
+            vals = top[:, :, i - 1].ravel()
         else:
-            allv = [y for x in new_haps for y in x]
-            new = _unique_in_order(np.concatenate(allv).astype(np.int64)) if allv else np.zeros(0, dtype=np.int64)
+            vals = top.reshape(-1)
             done = True
+        vals = vals[vals > 0]
+        new = _unique_in_order(vals.astype(np.int64)) if len(vals) else np.zeros(0, dtype=np.int64)
         new = new[~np.isin(new, prev)]
         new = new[~np.isin(new, to_keep)]
         if len(new) < Knew - len(to_keep):
@@ -265,6 +280,7 @@ class Driver:
         self.params = (params or DriverParams()).resolved(panel.K)
         self.cols = thinned_grid_columns(panel.nGrids, self.params.heuristic_match_thin)
         self.n_thin = int((self.cols >= 0).sum())
+        self.top_width = max(8, self.params.K_top_matches)   # entries kept per (label, thinned grid) list
         self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0}
 
     # -- one [Gibbs -> full pass -> select] round over a set of chains
@@ -276,7 +292,7 @@ class Driver:
         nb = len(P.small_ref_panel_block_gibbs_iterations)
         t0 = time.perf_counter()
         first = (i_it == 1) and not phasing
-        starts, runif_reads, first_reads, runif_shards = [], [], [], []
+        starts, seed_reads, first_reads, seed_shards = [], [], [], []
         for ch in chains:
             R = samples[ch.i_sample].nReads
             if first:
@@ -286,9 +302,10 @@ class Driver:
             else:
                 H0 = ch.read_labels
             starts.append(H0)
-            runif_reads.append(ch.rng.random(R * n_its))
+            # seeds of the counter-based streams that stand in for Rcpp::runif (quilt_amd/rng.py)
+            seed_reads.append(int(ch.rng.integers(0, 2 ** 63)))
             first_reads.append(int(ch.rng.integers(0, R)))
-            runif_shards.append(ch.rng.random(nb * (G - 1)))
+            seed_shards.append(int(ch.rng.integers(0, 2 ** 63)))
         t1 = time.perf_counter()
         self.timing["host"] += t1 - t0
         # ---- small-panel Gibbs (impute_one_sample, functions.R:2313-2774), with the underflow retry
@@ -304,8 +321,8 @@ class Driver:
             for md, idx in groups.items():
                 out = self.backend.gibbs_batch(
                     [samples[chains[i].i_sample] for i in idx], [chains[i].which_haps_to_use for i in idx],
-                    [starts[i] for i in idx], [runif_reads[i] for i in idx], [first_reads[i] for i in idx],
-                    [runif_shards[i] for i in idx], n_gibbs_burn_in_its=P.small_ref_panel_gibbs_iterations,
+                    [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],
+                    [seed_shards[i] for i in idx], n_gibbs_burn_in_its=P.small_ref_panel_gibbs_iterations,
                     n_gibbs_sample_its=P.n_gibbs_sample_its,
                     block_gibbs_iterations=P.small_ref_panel_block_gibbs_iterations,
                     gibbs_initialize_iteratively=first, maxDifferenceBetweenReads=md, Jmax_local=P.Jmax)
@@ -323,33 +340,25 @@ class Driver:
         self.timing["gibbs"] += t2 - t1
         # ---- full-panel pass per read label (impute_using_everything, functions.R:1922-2157)
         return_dosage = i_it > P.n_burn_in_seek_its
-        gls, want = [], []
         for ch, res in zip(chains, results):
             ch.read_labels = res["double_list_of_ending_read_labels"][0][0].astype(np.int32)
-            s = samples[ch.i_sample]
-            per_base = np.repeat(ch.read_labels, np.diff(s.read_ptr))
-            for i_hap in (1, 2):
-                sel = (per_base == i_hap) & (s.bq != 0)
-                gls.append(make_gl_from_u_bq(s.u[sel], s.bq[sel], T, P.minGLValue, self.backend.make_gl_bound))
-                want.append(return_dosage)
         t3 = time.perf_counter()
         self.timing["host"] += t3 - t2
-        dosages, best = self.backend.fullpass_batch(gls, want, self.cols, P.K_top_matches)
+        dosages, top, top_cnt = self.backend.fullpass_reads_batch(
+            samples, [ch.i_sample for ch in chains], [ch.read_labels for ch in chains],
+            [return_dosage] * len(chains), self.cols, P.K_top_matches, P.minGLValue, self.top_width)
         t4 = time.perf_counter()
         self.timing["fullpass"] += t4 - t3
         for ci, ch in enumerate(chains):
-            new_haps = []
-            ch.hap = []
-            for i_hap in (0, 1):
-                pi = 2 * ci + i_hap
-                d = dosages[pi]
-                if return_dosage:
-                    if d.min() < -1e-5 or d.max() > 1 + 1e-5:   # functions.R:2072-2075
-                        raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
-                ch.hap.append(d)
-                new_haps.append(everything_per_hap_rejig_haps(best[pi]))
+            if return_dosage:
+                d = dosages[ci]
+                if d.min() < -1e-5 or d.max() > 1 + 1e-5:   # functions.R:2072-2075
+                    raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
+                ch.hap = [d[0], d[1]]
+            else:
+                ch.hap = [np.zeros(T), np.zeros(T)]
             prev_sel = ch.which_haps_to_use[ch.rng.permutation(len(ch.which_haps_to_use))[: P.Ksubset - P.Knew]]
-            sel = everything_select_good_haps(P.Knew, P.K_top_matches, new_haps, prev_sel, K, ch.rng)
+            sel = everything_select_good_haps_dense(P.Knew, P.K_top_matches, top[ci].astype(np.int64) + 1, prev_sel, K, ch.rng)
             ch.which_haps_to_use = np.concatenate([prev_sel, sel]).astype(np.int32)
         self.timing["host"] += time.perf_counter() - t4
         return return_dosage
@@ -408,10 +417,11 @@ class HipBackend:
         from .reference_single import Rcpp_make_gl_bound
         Rcpp_make_gl_bound(gl, minGLValue, to_fix)
 
-    def gibbs_batch(self, samples, which, starts, runif_reads, first_reads, runif_shards, **kw):
+    def gibbs_batch(self, samples, which, starts, seed_reads, first_reads, seed_shards, **kw):
         from .gibbs_nipt import forwardBackwardGibbsNIPT_batch
-        return forwardBackwardGibbsNIPT_batch(self.dev, samples, which, starts, runif_reads, first_reads,
-                                              runif_shards, **kw)
+        return forwardBackwardGibbsNIPT_batch(self.dev, samples, which, starts, None, first_reads, None,
+                                              seed_reads=seed_reads, seed_shard=seed_shards,
+                                              return_hapProbs=False, return_genProbs=False, **kw)   # use_mspbwt = FALSE
 
     def fullpass_batch(self, gls, want_dosage, cols, K_top_matches):
         import ctypes as C
@@ -442,6 +452,36 @@ class HipBackend:
                               top_matches_values=bval[bptr[p * n_thin + j]:bptr[p * n_thin + j + 1]])
                          for j in range(n_thin)])
         return list(dosage), best
+
+    def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, cols, K_top_matches, minGLValue, top_width):
+        """impute_using_everything for every chain: returns dosage [n_chain, 2, T], the ordered top matches
+        [n_chain, 2, n_thin, top_width] (0-based, -1 padded) and the full list lengths."""
+        import ctypes as C
+        from .native import check, lib, ptr
+        lib().qa_fullpass_reads_batch.restype = C.c_int
+        P = self.dev.panel
+        T = P.nSNPs
+        n_chain, n_sample = len(chain_sample), len(samples)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        n_thin = int((cols >= 0).sum())
+        read_off = np.zeros(n_sample + 1, dtype=np.int32)
+        for i, s in enumerate(samples):
+            read_off[i + 1] = read_off[i] + s.nReads
+        read_ptr = np.concatenate([np.asarray(s.read_ptr, dtype=np.int32) for s in samples])
+        u = np.concatenate([np.asarray(s.u, dtype=np.int32) for s in samples])
+        bq = np.concatenate([np.asarray(s.bq, dtype=np.int32) for s in samples])
+        H = np.concatenate([np.asarray(h, dtype=np.int32) for h in labels])
+        cs = np.ascontiguousarray(chain_sample, dtype=np.int32)
+        wd = np.ascontiguousarray(want_dosage, dtype=np.int32)
+        dosage = np.zeros((n_chain, 2, T)) if wd.any() else None
+        top = np.full((n_chain, 2, n_thin, top_width), -1, dtype=np.int32)
+        val = np.zeros((n_chain, 2, n_thin, top_width), dtype=np.float32)
+        cnt = np.zeros((n_chain, 2, n_thin), dtype=np.int32)
+        check(lib().qa_fullpass_reads_batch(self.dev.handle, C.c_int32(n_chain), C.c_int32(2), C.c_int32(n_sample), ptr(cs),
+                                            ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(cols),
+                                            C.c_int32(K_top_matches), C.c_double(minGLValue), ptr(dosage),
+                                            C.c_int32(top_width), ptr(top), ptr(val), ptr(cnt)))
+        return dosage, top, cnt
 
     def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):
         from .gibbs_nipt import calculate_eMatRead_t_vs_haplotypes_batch

@@ -39,7 +39,9 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                                    gibbs_initialize_iteratively: bool = False,
                                    disable_read_category_usage: bool = False,
                                    maxDifferenceBetweenReads: float = 1e10, Jmax_local: int = 10000,
-                                   class_sum_cutoff: float = 0.06, return_state: bool = False):
+                                   class_sum_cutoff: float = 0.06, return_state: bool = False,
+                                   seed_reads=None, seed_shard=None, return_hapProbs: bool = True,
+                                   return_genProbs: bool = True):
     """``n_chain`` independent calls of ``rcpp_forwardBackwardGibbsNIPT`` in one launch set.
 
     ``samples[c]`` is a :class:`quilt_amd.synth.SampleReads`-like object (``read_ptr``, ``u``, ``bq``,
@@ -62,18 +64,25 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     u = np.concatenate([np.asarray(s.u, dtype=np.int32) for s in samples])
     bq = np.concatenate([np.asarray(s.bq, dtype=np.int32) for s in samples])
     wif = np.concatenate([np.asarray(s.wif, dtype=np.int32) for s in samples])
-    ru = np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: samples[c].nReads * n_its]
-                         for c, r in enumerate(runif_reads)])
+    use_seeds = seed_reads is not None
+    if use_seeds:
+        ru = None
+        sr = np.ascontiguousarray(seed_reads, dtype=np.uint64)
+        ss = np.ascontiguousarray(seed_shard, dtype=np.uint64)
+    else:
+        sr = ss = None
+        ru = np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: samples[c].nReads * n_its]
+                             for c, r in enumerate(runif_reads)])
     fr = np.ascontiguousarray(first_read, dtype=np.int32)
     rs = (np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: nb * (G - 1)] for r in runif_shard])
-          if nb > 0 else np.zeros(1))
+          if (nb > 0 and not use_seeds) else np.zeros(1))
     H = np.concatenate([np.asarray(h, dtype=np.int32) for h in starting_read_labels]).copy()
     if ff == 0 and H.size and (H.min() < 1 or H.max() > 2):
         raise ValueError("diploid read labels must be 1 or 2")
     Hc = np.zeros_like(H)
-    hap = np.zeros((Cn, T, 3))
-    gm = np.zeros((Cn, T, 3))
-    gf = np.zeros((Cn, T, 3))
+    hap = np.zeros((Cn, T, 3)) if return_hapProbs else None
+    gm = np.zeros((Cn, T, 3)) if return_genProbs else None
+    gf = np.zeros((Cn, T, 3)) if return_genProbs else None
     uf = np.zeros(Cn, dtype=np.int32)
     state = np.zeros(6 * Ks * G + 3 * G) if (return_state and Cn == 1) else None
     opts = GibbsOpts(Ks, float(ff), int(ff == 0), int(Jmax_local), float(maxDifferenceBetweenReads), 1,
@@ -82,15 +91,18 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                      int(disable_read_category_usage), float(class_sum_cutoff))
     st = lib().qa_gibbs_batch(panel.handle, C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr),
                               ptr(u), ptr(bq), ptr(wif), ptr(ru), ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap),
-                              ptr(gm), ptr(gf), ptr(uf), ptr(state))
+                              ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
     check(st)
     out = []
     for c in range(Cn):
         s, e = read_off[c], read_off[c + 1]
-        d = dict(underflow_problem=bool(uf[c]),
-                 hapProbs_t=np.asfortranarray(hap[c].T), genProbsM_t=np.asfortranarray(gm[c].T),
-                 genProbsF_t=np.asfortranarray(gf[c].T), H=H[s:e].copy(),
+        d = dict(underflow_problem=bool(uf[c]), H=H[s:e].copy(),
                  double_list_of_ending_read_labels=[[H[s:e].copy()]], H_class=Hc[s:e].copy())
+        if hap is not None:
+            d["hapProbs_t"] = np.asfortranarray(hap[c].T)
+        if gm is not None:
+            d["genProbsM_t"] = np.asfortranarray(gm[c].T)
+            d["genProbsF_t"] = np.asfortranarray(gf[c].T)
         if state is not None:
             m = state[: 6 * Ks * G].reshape(6, G, Ks)
             names = ("alphaHat_t1", "alphaHat_t2", "betaHat_t1", "betaHat_t2", "eMatGrid_t1", "eMatGrid_t2")

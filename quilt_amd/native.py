@@ -52,7 +52,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         L.qa_last_error.restype = C.c_char_p
         for name in ("qa_abi_version", "qa_device_count", "qa_set_device", "qa_panel_create", "qa_gibbs_batch",
-                 "qa_rcpp_make_eMatRead_t", "qa_profile_reset", "qa_profile_get",
+                 "qa_rcpp_make_eMatRead_t", "qa_profile_reset", "qa_profile_get", "qa_fullpass_reads_batch",
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
                      "qa_last_fullpass_timing_ms"):
             getattr(L, name).restype = C.c_int

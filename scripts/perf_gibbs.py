@@ -1,0 +1,39 @@
+"""Developer aid: time the Gibbs kernels at production scale on the GPU."""
+import argparse, ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quilt_amd import native
+from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+from quilt_amd.native import DevicePanel
+from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--K", type=int, default=50000); ap.add_argument("--T", type=int, default=64000)
+ap.add_argument("--chains", type=int, default=224); ap.add_argument("--reads", type=int, default=20000)
+ap.add_argument("--Ks", type=int, default=600); ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--init-iter", action="store_true")
+a = ap.parse_args()
+panel = make_synthetic_panel(K=a.K, nSNPs=a.T, seed=4916)
+dev = DevicePanel(panel)
+ns = max(1, a.chains // 7)
+samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=a.reads) for i in range(ns)]
+rng = np.random.default_rng(0)
+S = [samples[c % ns] for c in range(a.chains)]
+which = [np.sort(rng.choice(panel.K, a.Ks, replace=False)).astype(np.int32) + 1 for _ in range(a.chains)]
+H0 = [rng.integers(1, 3, size=s.nReads).astype(np.int32) for s in S]
+fr = [int(rng.integers(0, s.nReads)) for s in S]
+sr = rng.integers(0, 2**63, size=a.chains).astype(np.uint64); ss = rng.integers(0, 2**63, size=a.chains).astype(np.uint64)
+for r in range(a.reps):
+    native.lib().qa_profile_reset()
+    t0 = time.time()
+    out = forwardBackwardGibbsNIPT_batch(dev, S, which, H0, None, fr, None, seed_reads=sr, seed_shard=ss,
+                                         gibbs_initialize_iteratively=a.init_iter)
+    wall = time.time() - t0
+    res = []
+    for k, name in ((4, "ematread"), (5, "gibbs"), (6, "happrobs")):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        native.lib().qa_profile_get(k, C.byref(ms), C.byref(n), C.byref(b))
+        res.append(f"{name} {ms.value:.1f} ms ({b.value / 1e9 / max(ms.value, 1e-9) * 1e3:.0f} GB/s)")
+    steps = 21 * (a.reads + panel.nGrids)
+    print(f"rep {r}: wall {wall:.2f}s  " + "  ".join(res) + f"  -> {float(res[1].split()[1]) * 1e3 / steps:.3f} us/step/chain", flush=True)
+print("labels changed in chain 0:", int((out[0]['H'] != H0[0]).sum()), "of", len(H0[0]))

@@ -12,11 +12,16 @@ class OracleBackend:
     def make_gl_bound(self, gl, minGLValue, to_fix):
         O.make_gl_bound(gl, minGLValue, to_fix)
 
-    def gibbs_batch(self, samples, which, starts, runif_reads, first_reads, runif_shards, *,
+    def gibbs_batch(self, samples, which, starts, seed_reads, first_reads, seed_shards, *,
                     n_gibbs_burn_in_its, n_gibbs_sample_its, block_gibbs_iterations, gibbs_initialize_iteratively,
                     maxDifferenceBetweenReads, Jmax_local):
+        from quilt_amd.rng import stream_uniform
         out = []
-        for s, w, h, ru, fr, rs in zip(samples, which, starts, runif_reads, first_reads, runif_shards):
+        n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
+        nb = len(block_gibbs_iterations)
+        for s, w, h, sr, fr, ss in zip(samples, which, starts, seed_reads, first_reads, seed_shards):
+            ru = stream_uniform(sr, s.nReads * n_its)
+            rs = stream_uniform(ss, nb * (self.panel.nGrids - 1))
             r = O.forwardBackwardGibbsNIPT(self.panel, s, w, h, ru, fr, rs,
                                            n_gibbs_burn_in_its=n_gibbs_burn_in_its,
                                            n_gibbs_sample_its=n_gibbs_sample_its,
@@ -38,3 +43,27 @@ class OracleBackend:
 
     def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):
         return [O.calculate_eMatRead_t_vs_haplotypes(s, h, maxDifferenceBetweenReads) for s, h in zip(samples, haps)]
+
+    def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, cols, K_top_matches, minGLValue, top_width):
+        from quilt_amd.driver import make_gl_from_u_bq
+        T = self.panel.nSNPs
+        n_chain = len(chain_sample)
+        n_thin = int((np.asarray(cols) >= 0).sum())
+        dosage = np.zeros((n_chain, 2, T))
+        top = np.full((n_chain, 2, n_thin, top_width), -1, dtype=np.int32)
+        cnt = np.zeros((n_chain, 2, n_thin), dtype=np.int32)
+        for c in range(n_chain):
+            s = samples[chain_sample[c]]
+            per_base = np.repeat(labels[c], np.diff(s.read_ptr))
+            for l in (1, 2):
+                sel = (per_base == l) & (s.bq != 0)
+                gl = make_gl_from_u_bq(s.u[sel], s.bq[sel], T, minGLValue, self.make_gl_bound)
+                r = O.haploid_dosage_versus_refs(self.panel, gl, cols, K_top_matches=K_top_matches,
+                                                 return_dosage=bool(want_dosage[c]), get_best_haps_from_thinned_sites=True)
+                dosage[c, l - 1] = r["dosage"]
+                for j, (idx, v) in enumerate(r["best_haps"]):
+                    order = np.argsort(-v, kind="stable")      # everything_per_hap_rejig_haps (functions.R:2161-2170)
+                    k = idx[order][:top_width]
+                    top[c, l - 1, j, : len(k)] = k
+                    cnt[c, l - 1, j] = len(idx)
+        return dosage, top, cnt

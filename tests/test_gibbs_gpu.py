@@ -103,3 +103,36 @@ def test_gibbs_no_block_no_burn(small_panel, oracle):
     for h in range(2):
         np.testing.assert_allclose(got[f"alphaHat_t{h + 1}"], ref["alphaHat_t"][h], rtol=RTOL, atol=1e-300)
         np.testing.assert_allclose(got[f"betaHat_t{h + 1}"], ref["betaHat_t"][h], rtol=RTOL, atol=1e-300)
+
+
+def test_gibbs_seeded_streams_match_explicit_uniforms(small_panel, oracle):
+    """The device counter-based stream == quilt_amd.rng.stream_uniform fed to the oracle as arrays."""
+    from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.rng import stream_uniform
+    panel = small_panel
+    dev = DevicePanel(panel)
+    s, which, H0, _, _, fr = _setup(panel, 21, 64, 120)
+    sr, ss = 0x1234567890ABCDEF, 0x0FEDCBA987654321
+    got = forwardBackwardGibbsNIPT_batch(dev, [s], [which], [H0], None, [fr], None, seed_reads=[sr], seed_shard=[ss])[0]
+    ru = stream_uniform(sr, s.nReads * 21)
+    rs = stream_uniform(ss, 3 * (panel.nGrids - 1))
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs)
+    assert np.array_equal(got["H"], ref["H"])
+    np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+
+
+@pytest.mark.parametrize("nw", ["1", "2", "5", "10"])
+def test_gibbs_every_chain_geometry(medium_panel, oracle, nw, monkeypatch):
+    """Ksubset = 600 can run as 1, 2, 5 or 10 wavefronts per chain; all must give the oracle's labels."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    monkeypatch.setenv("QA_GIBBS_NW", nw)
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    s, which, H0, ru, rs, fr = _setup(panel, 31, 600, 900)
+    for init_iter in (False, True):
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter)
+        got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter,
+                                            return_state=True)
+        _compare(got, ref, 600)
