@@ -74,6 +74,57 @@ struct DBuf {
     }
 };
 
+// One device arena per panel handle, shared by every launch set (the Gibbs sampler and the full-panel pass never
+// run concurrently): bump-allocated per call, grown only when a call needs more.  Avoids both hipMalloc churn
+// (a 100 GB hipMalloc costs seconds) and double-counting of differently shaped scratch buffers.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    Arena() = default;
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    ~Arena() { if (base) (void)hipFree(base); }
+    void reset() { off = 0; }
+    // bytes this arena may grow to: what is free now plus what it already holds, with headroom
+    size_t budget() const {
+        size_t free_b = 0, total_b = 0;
+        QA_HIP(hipMemGetInfo(&free_b, &total_b));
+        return (size_t)((free_b + cap) * 0.88);
+    }
+    void require(size_t bytes) {
+        if (bytes <= cap) return;
+        if (base) { QA_HIP(hipFree(base)); base = nullptr; cap = 0; }
+        const size_t want = (bytes + (size_t(1) << 28) - 1) >> 28 << 28;   // 256 MiB granules
+        QA_HIP(hipMalloc((void **)&base, want));
+        cap = want;
+        off = 0;
+    }
+    void *take(size_t bytes) {
+        const size_t a = (off + 255) & ~size_t(255);
+        if (a + bytes > cap) throw std::runtime_error("device arena exhausted (internal sizing error)");
+        off = a + bytes;
+        return base + a;
+    }
+};
+
+// typed view carved from an arena; same surface as DBuf for the call sites
+template <typename T>
+struct ABuf {
+    Arena *arena = nullptr;
+    T *p = nullptr;
+    size_t n = 0;
+    void ensure(size_t n_) {   // a fresh carve per call (the arena is reset by the entry point)
+        n = n_;
+        p = n ? static_cast<T *>(arena->take(n * sizeof(T))) : nullptr;
+    }
+    void upload(const T *h, size_t cnt, hipStream_t s = nullptr) {
+        if (cnt) QA_HIP(hipMemcpyAsync(p, h, cnt * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T *h, size_t cnt, hipStream_t s = nullptr) const {
+        if (cnt) QA_HIP(hipMemcpyAsync(h, p, cnt * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+};
+
 // translate exceptions at the C boundary
 template <typename F>
 int guarded(F &&f) {

@@ -70,6 +70,7 @@ struct PassParams {
     double *dosage;          // [P][T]
     int K_top;
     int top_cap;             // capacity per (pass, thinned column)
+    int truncate_lists;      // keep only the head (first top_cap in rejig order) of over-long lists
     int32_t *top_cnt;        // [P][n_thin]
     int32_t *top_idx;        // [P][n_thin][top_cap]
     float *top_val;          // [P][n_thin][top_cap]
@@ -628,12 +629,61 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
         }
     }
     __syncthreads();
+    const int n_all = s_cnt;
+    if (n_all > prm.top_cap && prm.truncate_lists) {
+        // More matches than the list holds (exact ties at the threshold: common in fp32 once haplotypes share a
+        // long identical stretch).  Keep what the host logic can ever look at first: every gamma above the
+        // threshold, then the tied ones by ascending haplotype -- i.e. the head of the ordered list.
+        __shared__ int s_n;
+        auto block_count = [&](int kb) {   // #matches with gamma > thr, or gamma == thr and k <= kb
+            __syncthreads();
+            if (t == 0) s_n = 0;
+            __syncthreads();
+            int mine = 0;
+            for (int v = t; v < nvec; v += 256) {
+                if (k_of(v, 0) >= prm.K) continue;
+                const float4 a4 = av[v], b4 = bv[v];
+                const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kk = k_of(v, r);
+                    if (kk < prm.K && (gq[r] > thr || (gq[r] == thr && kk <= kb))) mine++;
+                }
+            }
+            atomicAdd(&s_n, mine);
+            __syncthreads();
+            return s_n;
+        };
+        int lo = -1, hi = prm.K - 1;   // smallest kb with count(kb) >= top_cap (count(-1) < top_cap: fewer than K_top above thr)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (block_count(mid) >= prm.top_cap) hi = mid; else lo = mid;
+        }
+        const int kb = (block_count(lo) >= prm.top_cap) ? lo : hi;
+        __syncthreads();
+        if (t == 0) s_cnt = 0;
+        __syncthreads();
+        for (int v = t; v < nvec; v += 256) {
+            if (k_of(v, 0) >= prm.K) continue;
+            const float4 a4 = av[v], b4 = bv[v];
+            const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kk = k_of(v, r);
+                if (kk < prm.K && (gq[r] > thr || (gq[r] == thr && kk <= kb))) {
+                    const int at = atomicAdd(&s_cnt, 1);
+                    if (at < prm.top_cap) { oi[at] = kk; ov[at] = gq[r] * fs; }
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (t == 0) {
-        const int n = s_cnt;
-        prm.top_cnt[(size_t)p * prm.n_thin + tcol] = n;
+        prm.top_cnt[(size_t)p * prm.n_thin + tcol] = n_all;
+        const int n = min(min(s_cnt, prm.top_cap), n_all);
         // order as everything_per_hap_rejig_haps does (functions.R:2161-2170): value descending, ties by
         // ascending haplotype (R's stable order() on the k-ascending list).  Lists are ~K_top long.
-        if (n <= prm.top_cap && n <= 64) {
+        if (n <= 64 && (n_all <= prm.top_cap || prm.truncate_lists)) {
             for (int i = 1; i < n; i++) {
                 const int ki = oi[i];
                 const float vi = ov[i];
@@ -749,22 +799,19 @@ __global__ void k_unpermute(const float *src, double *dst, int K, int Kq, int NT
 // host side
 // ---------------------------------------------------------------------------------------------
 struct qa_panel::Scratch {
-    qa::DBuf<double> gl, c, dosage, escale0;
-    qa::DBuf<float> emat, esp, alpha, mg, gsp, gamma, beta, beta_thin, top_val;
-    qa::DBuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
-    qa::DBuf<double> unperm;
+    qa::ABuf<double> gl, c, dosage, escale0, unperm;
+    qa::ABuf<float> emat, esp, alpha, mg, gsp, gamma, beta, beta_thin, top_val;
+    qa::ABuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t bytes() const {
-        return (gl.n + c.n + dosage.n + escale0.n + unperm.n) * 8 +
-               (emat.n + esp.n + alpha.n + mg.n + gsp.n + gamma.n + beta.n + beta_thin.n + top_val.n) * 4 +
-               (thin_col.n + flags.n + alpha_slot.n + top_cnt.n + top_idx.n) * 4;
+    explicit Scratch(qa::Arena *a) {
+        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = a;
+        emat.arena = esp.arena = alpha.arena = mg.arena = gsp.arena = gamma.arena = beta.arena = beta_thin.arena = top_val.arena = a;
+        thin_col.arena = flags.arena = alpha_slot.arena = top_cnt.arena = top_idx.arena = a;
     }
     ~Scratch() {
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
-
-size_t qa_panel::scratch_bytes() const { return scratch ? scratch->bytes() : 0; }
 
 qa_panel::~qa_panel() {
     delete scratch;
@@ -793,6 +840,31 @@ Geometry pick_geometry(int K) {
     return {0, 0};
 }
 
+
+// device bytes one pass needs in run_passes (mirrors its carves, with alignment slack)
+size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stores_all, bool gamma, bool beta,
+                  bool device_gl) {
+    const size_t Kq = (size_t)geo.NT * geo.NCH * 16, G = pn->G, T = pn->T;
+    const size_t cols = stores_all ? G : (size_t)std::max(n_thin, 1);
+    size_t b = (device_gl ? 0 : 0) + T * 16 + G * 4 + G * kMaxRow * 4 * 2 + 8 + (size_t)pn->n_special * 8 + cols * Kq * 4 +
+               G * 8 + T * 8;
+    if (gamma) b += G * Kq * 4;
+    if (beta) b += G * Kq * 4;
+    if (n_thin > 0) b += (size_t)n_thin * Kq * 4 + (size_t)n_thin * (4 + 64 * 8);
+    return b + 256 * 24;
+}
+
+// how many homogeneous passes fit, and make the arena big enough for them
+int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
+    const size_t fixed = (size_t)pn->G * 8 + ((size_t)1 << 20);
+    const size_t budget = pn->arena.budget();
+    long n = budget > fixed ? (long)((budget - fixed) / per_pass) : 0;
+    n = std::max<long>(1, std::min<long>(n, remaining));
+    pn->arena.require(fixed + (size_t)n * per_pass);
+    pn->arena.reset();
+    return (int)n;
+}
+
 template <int NCH, int MAXT>
 void launch_fb(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
     const size_t lds_f = 2 * kMaxRow * 4 + 2 * 16 * 8;
@@ -816,7 +888,9 @@ struct BatchOut {
     bool gamma_small_unscaled = false;  // gammaSmall_t without return_gamma_t: no sigma factor (:2170-2176)
     // best_haps_stuff_list of every (pass, thinned column), appended in pass-major order
     std::vector<std::vector<std::pair<int32_t, float>>> *lists = nullptr;
-    bool order_by_value = false;  // lists ordered as everything_per_hap_rejig_haps wants (else ascending k)
+    bool truncate_lists = false;   // batched drivers: lists capped at 64 entries (head of the ordered list)
+    bool order_by_value = false;
+    std::vector<int32_t> *true_counts = nullptr;   // untruncated list lengths  // lists ordered as everything_per_hap_rejig_haps wants (else ascending k)
 };
 
 // runs P passes; flags per pass as in PassParams
@@ -832,7 +906,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         return QA_ERR_UNSUPPORTED;
     }
     QA_HIP(hipSetDevice(pn->device));
-    if (!pn->scratch) pn->scratch = new qa_panel::Scratch();
+    if (!pn->scratch) pn->scratch = new qa_panel::Scratch(&pn->arena);
     auto &S = *pn->scratch;
     hipStream_t st = pn->stream;
     for (auto &e : S.ev) if (!e) QA_HIP(hipEventCreate(&e));
@@ -925,6 +999,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     std::vector<int32_t> cnt;
     for (int attempt = 0; any_top && attempt < 2; attempt++) {
         prm.top_cap = top_cap;
+        prm.truncate_lists = out.truncate_lists ? 1 : 0;
         S.top_idx.ensure((size_t)P * n_thin * top_cap);
         S.top_val.ensure((size_t)P * n_thin * top_cap);
         prm.top_cnt = S.top_cnt.p; prm.top_idx = S.top_idx.p; prm.top_val = S.top_val.p;
@@ -935,7 +1010,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         QA_HIP(hipStreamSynchronize(st));
         int mx = 0;
         for (int32_t v : cnt) mx = std::max(mx, v);
-        if (mx <= top_cap) break;
+        if (mx <= top_cap || out.truncate_lists) break;
         top_cap = mx;  // pathological ties (e.g. a label without reads): redo with room for all
     }
     QA_HIP(hipEventRecord(S.ev[4], st));
@@ -1007,6 +1082,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         }
     }
     int status = QA_OK;
+    if (any_top && out.true_counts) *out.true_counts = cnt;
     if (any_top && out.lists) {
         const size_t n = (size_t)P * n_thin;
         std::vector<int32_t> idx(n * top_cap);
@@ -1016,11 +1092,12 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         QA_HIP(hipStreamSynchronize(st));
         for (size_t i = 0; i < n; i++) {
             std::vector<std::pair<int32_t, float>> tmp;
-            tmp.reserve(cnt[i]);
-            for (int q = 0; q < cnt[i]; q++) tmp.emplace_back(idx[i * top_cap + q], val[i * top_cap + q]);
+            const int nq = std::min<int>(cnt[i], top_cap);
+            tmp.reserve(nq);
+            for (int q = 0; q < nq; q++) tmp.emplace_back(idx[i * top_cap + q], val[i * top_cap + q]);
             if (!out.order_by_value) {
                 std::sort(tmp.begin(), tmp.end());  // ascending k, the reference's emission order
-            } else if (cnt[i] > 64) {               // (k_topk orders lists of up to 64 entries itself)
+            } else if (nq > 64) {                    // (k_topk orders lists of up to 64 entries itself)
                 std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) {
                     return a.second > b.second || (a.second == b.second && a.first < b.first);
                 });
@@ -1096,6 +1173,16 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         out.gamma_small_unscaled = !o->return_gamma_t;
         std::vector<std::vector<std::pair<int32_t, float>>> lists;
         if (o->get_best_haps_from_thinned_sites) out.lists = &lists;
+        {
+            QA_HIP(hipSetDevice(panel->device));
+            const Geometry geo1 = pick_geometry(panel->K);
+            if (geo1.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
+            int nt = 0;
+            for (int g = 0; g < G; g++) nt = std::max(nt, thin[g] + 1);
+            const size_t need = pass_bytes(panel, geo1, nt, (f & 15) != 0, (f & 4) != 0, (f & 8) != 0, false) +
+                                (size_t)panel->K * G * 8 /* un-permute staging */;
+            plan_chunk(panel, need, 1);
+        }
         int st = run_passes(panel, 1, gl, &f, thin.data(),
                             o->get_best_haps_from_thinned_sites ? o->K_top_matches : 0, o->normalize_emissions, out);
         if (st != QA_OK || !o->get_best_haps_from_thinned_sites) return st;
@@ -1114,32 +1201,22 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
     return qa::guarded([&] {
         std::vector<int32_t> f(n_pass);
         for (int i = 0; i < n_pass; i++) f[i] = want_dosage[i] ? 1 : 0;
-        // chunk the passes so that the alpha checkpoints fit in free HBM (K = 50 000, G = 2 000: 0.4 GB
-        // per dosage pass, 0.04 GB per thin pass)
+        // chunk the passes so that the alpha checkpoints fit in HBM (K = 50 000, G = 2 000: 0.4 GB per dosage
+        // pass, 0.08 GB per thin pass); chunks are homogeneous so that every pass of a chunk has the same footprint
+        QA_HIP(hipSetDevice(panel->device));
         const Geometry geo = pick_geometry(panel->K);
+        if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
         const int G = panel->G, T = panel->T;
         int n_thin = 0;
         for (int g = 0; g < G; g++) n_thin = std::max(n_thin, gammaSmall_cols_to_get[g] + 1);
-        size_t free_b = 0, total_b = 0;
-        QA_HIP(hipSetDevice(panel->device));
-        QA_HIP(hipMemGetInfo(&free_b, &total_b));
-        size_t have = free_b + (panel->scratch ? panel->scratch_bytes() : 0);
-        const size_t Kq = (size_t)geo.NT * geo.NCH * 16;
-        const size_t per_dosage = Kq * 4 * ((size_t)G + n_thin) + (size_t)G * 256 * 8 + (size_t)T * 32;
-        const size_t per_thin = Kq * 4 * (2 * (size_t)std::max(n_thin, 1)) + (size_t)G * 256 * 8 + (size_t)T * 32;
         std::vector<std::vector<std::pair<int32_t, float>>> lists;
         int done = 0;
         int status = QA_OK;
         while (done < n_pass && status == QA_OK) {
-            size_t used = 0;
-            int n = 0;
-            const bool dos = f[done] != 0;  // homogeneous chunks: a mixed chunk would size every pass as a dosage pass
-            while (done + n < n_pass && (f[done + n] != 0) == dos) {
-                const size_t need = dos ? per_dosage : per_thin;
-                if (n > 0 && used + need > have * 8 / 10) break;
-                used += need;
-                n++;
-            }
+            const bool dos = f[done] != 0;
+            int run = 0;
+            while (done + run < n_pass && (f[done + run] != 0) == dos) run++;
+            const int n = plan_chunk(panel, pass_bytes(panel, geo, n_thin, dos, false, false, false), run);
             BatchOut out;
             out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
             out.lists = &lists;
@@ -1166,7 +1243,7 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
     }
     return qa::guarded([&] {
         QA_HIP(hipSetDevice(panel->device));
-        if (!panel->scratch) panel->scratch = new qa_panel::Scratch();
+        if (!panel->scratch) panel->scratch = new qa_panel::Scratch(&panel->arena);
         auto &S = *panel->scratch;
         hipStream_t st = panel->stream;
         const int G = panel->G, T = panel->T;
@@ -1232,24 +1309,13 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
 
         const Geometry geo = pick_geometry(panel->K);
         if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
-        size_t free_b = 0, total_b = 0;
-        QA_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t have = free_b + panel->scratch_bytes();
-        const size_t Kq = (size_t)geo.NT * geo.NCH * 16;
-        const size_t per_dosage = Kq * 4 * ((size_t)G + n_thin) + (size_t)G * 256 * 8 + (size_t)T * 32;
-        const size_t per_thin = Kq * 4 * (2 * (size_t)std::max(n_thin, 1)) + (size_t)G * 256 * 8 + (size_t)T * 32;
         int done = 0, status = QA_OK;
         std::vector<std::vector<std::pair<int32_t, float>>> lists;
         while (done < P && status == QA_OK) {
-            size_t used = 0;
-            int n = 0;
             const bool dos = flags[done] != 0;
-            while (done + n < P && (flags[done + n] != 0) == dos) {
-                const size_t need = dos ? per_dosage : per_thin;
-                if (n > 0 && used + need > have * 8 / 10) break;
-                used += need;
-                n++;
-            }
+            int run = 0;
+            while (done + run < P && (flags[done + run] != 0) == dos) run++;
+            const int n = plan_chunk(panel, pass_bytes(panel, geo, n_thin, dos, false, false, true), run);
             S.gl.ensure((size_t)n * T * 2);
             GlParams gp{};
             gp.P = n; gp.T = T; gp.pass_sample = d_ps.p + done; gp.pass_label = d_pl.p + done; gp.pass_hoff = d_ph.p + done;
@@ -1262,13 +1328,16 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
             lists.clear();
             out.lists = &lists;
             out.order_by_value = true;
+            out.truncate_lists = true;
+            std::vector<int32_t> true_cnt;
+            out.true_counts = &true_cnt;
             status = run_passes(panel, n, nullptr, flags.data() + done, gammaSmall_cols_to_get, K_top_matches, 1, out);
             if (status != QA_OK) break;
             // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
             for (int i = 0; i < n * n_thin; i++) {
                 const auto &l = lists[i];
                 const size_t o = ((size_t)done * n_thin + i);
-                if (top_cnt) top_cnt[o] = (int32_t)l.size();
+                if (top_cnt) top_cnt[o] = true_cnt[i];
                 for (int q = 0; q < top_width; q++) {
                     if (top_idx) top_idx[o * top_width + q] = q < (int)l.size() ? l[q].first : -1;
                     if (top_val) top_val[o * top_width + q] = q < (int)l.size() ? l[q].second : 0.f;

@@ -1034,7 +1034,8 @@ namespace qa {
 struct GibbsScratch {
     DBuf<int32_t> which, read_off, read_ptr, base_off, u, bq, wif, block_its, first_read, H, H_class, status;
     DBuf<uint8_t> ghr, is_cat1;
-    DBuf<double> tabs, runif_reads, runif_shard, eMatRead, alpha, beta, eg, cvec, hap, gm, gf, tm;
+    DBuf<double> tabs, runif_reads, runif_shard, tm;
+    ABuf<double> eMatRead, alpha, beta, eg, cvec, hap, gm, gf;   // carved from the panel's arena per call
     DBuf<size_t> eread_off;
     DBuf<uint64_t> seeds;
 };
@@ -1154,32 +1155,17 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
 
 }  // namespace
 
-extern "C" {
-
-int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
                    double *genProbsM_t, double *genProbsF_t, int32_t *underflow_problem, double *state_out,
                    const uint64_t *seed_reads, const uint64_t *seed_shard) {
-    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
-    if (!pn || !o || n_chain <= 0 || !which_haps_to_use_1based || !read_off || !read_ptr || !u || !bq || !wif ||
-        (!runif_reads && !seed_reads) || !first_read || !H) {
-        qa::set_error("qa_gibbs_batch: null argument");
-        return QA_ERR_INVALID;
-    }
-    if (o->ff != 0.0 || !o->sample_is_diploid) {
-        qa::set_error("qa_gibbs_batch: only the diploid sampler (ff = 0, sample_is_diploid) is implemented on the device");
-        return QA_ERR_UNSUPPORTED;
-    }
-    if (o->Ks <= 0 || o->Ks > 1024) {
-        qa::set_error("qa_gibbs_batch: Ksubset = %d outside 1..1024", o->Ks);
-        return QA_ERR_UNSUPPORTED;
-    }
-    return qa::guarded([&] {
-        QA_HIP(hipSetDevice(pn->device));
+    {
         if (!g_gibbs) g_gibbs.reset(new GibbsHolder());
         auto &S = g_gibbs->s;
+        S.eMatRead.arena = S.alpha.arena = S.beta.arena = S.eg.arena = S.cvec.arena = S.hap.arena = S.gm.arena = S.gf.arena = &pn->arena;
+        pn->arena.reset();
         hipStream_t st = pn->stream;
         const int C = n_chain, G = pn->G, T = pn->T, Ks = o->Ks;
         const int Ksp = (Ks + 63) / 64 * 64, NE = Ksp / 64;
@@ -1310,7 +1296,7 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         if (state_out && C == 1) {
             // debugging / test aid: alpha, beta, eMatGrid of both labels ([6][G][Ks]) then c ([3][G])
             std::vector<double> tmp((size_t)G * Ksp);
-            const qa::DBuf<double> *src[3] = {&S.alpha, &S.beta, &S.eg};
+            const qa::ABuf<double> *src[3] = {&S.alpha, &S.beta, &S.eg};
             size_t o2 = 0;
             for (int m = 0; m < 3; m++)
                 for (int h = 0; h < 2; h++) {
@@ -1323,9 +1309,76 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
             QA_HIP(hipMemcpy(state_out + o2, S.cvec.p, sizeof(double) * 3 * G, hipMemcpyDeviceToHost));
         }
         return rc;
-    });
+    }
 }
 
+
+
+extern "C" {
+
+int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+                   const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                   const int32_t *wif, const double *runif_reads, const int32_t *first_read,
+                   const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
+                   double *genProbsM_t, double *genProbsF_t, int32_t *underflow_problem, double *state_out,
+                   const uint64_t *seed_reads, const uint64_t *seed_shard) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!pn || !o || n_chain <= 0 || !which_haps_to_use_1based || !read_off || !read_ptr || !u || !bq || !wif ||
+        (!runif_reads && !seed_reads) || !first_read || !H) {
+        qa::set_error("qa_gibbs_batch: null argument");
+        return QA_ERR_INVALID;
+    }
+    if (o->ff != 0.0 || !o->sample_is_diploid) {
+        qa::set_error("qa_gibbs_batch: only the diploid sampler (ff = 0, sample_is_diploid) is implemented on the device");
+        return QA_ERR_UNSUPPORTED;
+    }
+    if (o->Ks <= 0 || o->Ks > 1024) {
+        qa::set_error("qa_gibbs_batch: Ksubset = %d outside 1..1024", o->Ks);
+        return QA_ERR_UNSUPPORTED;
+    }
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(pn->device));
+        const int G = pn->G, T = pn->T, Ks = o->Ks, Ksp = (Ks + 63) / 64 * 64;
+        const int n_its = o->n_gibbs_burn_in_its + o->n_gibbs_sample_its;
+        const int nb = o->n_block_gibbs_iterations;
+        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
+        // chains are processed in chunks that fit the device arena (Ks x R fp64 emissions + 6 Ks x G state matrices each)
+        std::vector<size_t> base_of(n_chain + 1, 0);
+        for (int c = 0; c < n_chain; c++) {
+            const int R = read_off[c + 1] - read_off[c];
+            base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
+        }
+        const size_t budget = pn->arena.budget();
+        int c0 = 0, rc = QA_OK;
+        while (c0 < n_chain) {
+            size_t need = (size_t)1 << 20;
+            int c1 = c0;
+            while (c1 < n_chain) {
+                const size_t R = read_off[c1 + 1] - read_off[c1];
+                const size_t add = R * Ksp * 8 + (size_t)6 * G * Ksp * 8 + (size_t)3 * G * 8 + (want_probs ? (size_t)9 * T * 8 : 0) + 4096;
+                if (c1 > c0 && need + add > budget) break;
+                need += add;
+                c1++;
+            }
+            pn->arena.require(need);
+            std::vector<int32_t> ro(c1 - c0 + 1);
+            for (int i = 0; i <= c1 - c0; i++) ro[i] = read_off[c0 + i] - read_off[c0];
+            const int st = gibbs_chunk(
+                pn, o, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
+                u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
+                runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
+                runif_shard ? runif_shard + (size_t)c0 * nb * (G - 1) : nullptr, H + read_off[c0],
+                H_class ? H_class + read_off[c0] : nullptr, hapProbs_t ? hapProbs_t + (size_t)c0 * T * 3 : nullptr,
+                genProbsM_t ? genProbsM_t + (size_t)c0 * T * 3 : nullptr, genProbsF_t ? genProbsF_t + (size_t)c0 * T * 3 : nullptr,
+                underflow_problem ? underflow_problem + c0 : nullptr, state_out, seed_reads ? seed_reads + c0 : nullptr,
+                seed_shard ? seed_shard + c0 : nullptr);
+            if (st < 0) return st;
+            if (st == QA_UNDERFLOW) rc = QA_UNDERFLOW;
+            c0 = c1;
+        }
+        return rc;
+    });
+}
 
 int qa_rcpp_make_eMatRead_t(qa_panel_t *pn, int32_t n_chain, int32_t K, const double *eHaps, const int32_t *read_off,
                             const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
