@@ -128,14 +128,14 @@ def main():
         torch.cuda.synchronize()
 
     for st in range(a.warmup):
-        drv.run(samples[st])
+        drv.run(samples[st], sample_offset=(rank * n_steps + st) * a.batch)
     native.lib().qa_profile_reset()
     drv.timing = {k: 0.0 for k in drv.timing}
     barrier()
     t0 = time.perf_counter()
     last = None
     for st in range(a.warmup, n_steps):
-        last = drv.run(samples[st])
+        last = drv.run(samples[st], sample_offset=(rank * n_steps + st) * a.batch)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -363,11 +363,14 @@ class Driver:
         self.timing["host"] += time.perf_counter() - t4
         return return_dosage
 
-    def run(self, samples) -> List[SampleResult]:
+    def run(self, samples, sample_offset: int = 0) -> List[SampleResult]:
+        """``sample_offset``: global index of ``samples[0]`` (keys the random streams, so that a sample gets the
+        same draws whichever rank / batch it lands in)."""
         P = self.params
         T = self.panel.nSNPs
         N = len(samples)
-        chains = [ChainState(i, c, chain_rng(P.seed, i, c)) for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
+        self._offset = sample_offset
+        chains = [ChainState(i, c, chain_rng(P.seed, sample_offset + i, c)) for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
         dosage = np.zeros((N, T))
         gp_t = np.zeros((N, 3, T))
         nDosage = np.zeros(N, dtype=np.int64)
@@ -390,7 +393,7 @@ class Driver:
             rl_conf = np.stack([assess_ability_of_reads_to_be_confident(conf[k]) for k in mine], axis=1)
             labels = determine_best_read_label_so_far(rl_all, rl_conf, R, P.nGibbsSamples, can_hap=P.nGibbsSamples)
             last = chains[mine[-1]]
-            ph = ChainState(i, P.nGibbsSamples + 1, chain_rng(P.seed, i, P.nGibbsSamples + 1),
+            ph = ChainState(i, P.nGibbsSamples + 1, chain_rng(P.seed, sample_offset + i, P.nGibbsSamples + 1),
                             which_haps_to_use=last.which_haps_to_use.copy(), read_labels=labels)
             phasing.append(ph)
         consensus = [ph.read_labels.copy() for ph in phasing]

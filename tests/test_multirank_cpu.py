@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: two gloo ranks each impute their contiguous sample range (no collective on the data
+path); the concatenation equals the single-process result bit for bit, and the timing reduction is a MAX."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.sharding import get_sample_range
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=600, nSNPs=640, seed=3)
+    N = 5
+    lo, hi = get_sample_range(N, world)[rank]
+    samples = [make_synthetic_sample(panel, seed=100 + i, n_reads=150) for i in range(N)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9)
+    drv = Driver(panel, OracleBackend(panel), prm)
+    res = drv.run(samples[lo:hi], sample_offset=lo)
+    t = torch.tensor([float(rank + 1)])
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [(lo + i, r.dosage) for i, r in enumerate(res)])
+    if rank == 0:
+        q.put((float(t.item()), [x for part in gathered for x in part]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process():
+    sys.path.insert(0, ROOT)
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.sharding import get_sample_range
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    assert get_sample_range(5, 2) == [(0, 2), (2, 5)] and get_sample_range(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert get_sample_range(1024, 8)[3] == (384, 512)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    tmax, parts = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tmax == 2.0
+    panel = make_synthetic_panel(K=600, nSNPs=640, seed=3)
+    samples = [make_synthetic_sample(panel, seed=100 + i, n_reads=150) for i in range(5)]
+    ref = Driver(panel, OracleBackend(panel), DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9)).run(samples)
+    assert [i for i, _ in parts] == [0, 1, 2, 3, 4]
+    for (i, d), r in zip(parts, ref):
+        assert np.array_equal(d, r.dosage)
