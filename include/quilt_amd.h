@@ -82,6 +82,13 @@ typedef struct {
 int qa_panel_create(const qa_panel_desc_t *desc, qa_panel_t **out);
 void qa_panel_destroy(qa_panel_t *panel);
 
+/* Arithmetic of the state behind the best-haplotype lists (get_best_haps_from_thinned_sites).  64 (default): the
+ * lists come from a forward/backward with fp64 state -- the reference computes in double, and which of several
+ * nearly tied haplotypes make a list decides the next small panel, so membership and order must be the reference's.
+ * 32: lists from the fp32-state pass that also produces the dosage (faster, within ~1e-6 of the reference's gamma, but
+ * near-ties may be ordered differently).  Dosages always come from fp32 state (|error| ~1e-6). */
+int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits);
+
 /* ---- full-panel haploid forward/backward -------------------------------- */
 
 /* Flags of Rcpp_haploid_dosage_versus_refs (QUILT/src/reference-single.cpp:2214-2227). */
@@ -154,6 +161,9 @@ int qa_fullpass_batch(
  *   chain_sample      n_chain: sample of each chain (several chains share one sample's reads)
  *   read_off, read_ptr, u, bq   reads of the n_sample samples, laid out as in qa_gibbs_batch (per sample)
  *   H                 read labels (1-based) of the chains back to back, chain c holding R_{chain_sample[c]} labels
+ *   want_top          n_chain: whether the chain's best-haplotype lists are wanted (NULL: all chains); the
+ *                     driver skips them where the reference computes but never reads them (chains 1..nGibbsSamples
+ *                     at the last seek iteration)
  *   dosage            n_chain x n_label x nSNPs (rows of thin passes untouched); may be NULL
  *   top_idx/top_val   n_chain x n_label x n_thin x top_width: 0-based haplotypes / values, best first, -1 padded
  *   top_cnt           n_chain x n_label x n_thin: full length of each list (> top_width means truncated)
@@ -161,7 +171,8 @@ int qa_fullpass_batch(
 int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
                             const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
                             const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
-                            const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double minGLValue,
+                            const int32_t *want_top, const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches,
+                            double minGLValue,
                             double *dosage, int32_t top_width, int32_t *top_idx, float *top_val,
                             int32_t *top_cnt);
 

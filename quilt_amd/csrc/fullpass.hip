@@ -54,26 +54,26 @@ struct PassParams {
     const int32_t *flags;    // [P] bit0: dosage pass; bit1: store all alpha; bit2: store gamma; bit3: store beta
     int normalize_emissions;
     // scratch / outputs
-    float *emat;             // [P][G][kMaxRow]
-    float *esp;              // [P][n_special]
+    void *emat;             // [P][G][kMaxRow]
+    void *esp;              // [P][n_special]
     double *escale0;         // [P] factor applied to the grid-0 emissions (folded back into c[0])
-    float *alpha;            // [P][n_alpha_cols][Kq]   (lane-interleaved order)
+    void *alpha;            // [P][n_alpha_cols][Kq]   (lane-interleaved order)
     const int32_t *alpha_slot; // [P][G] -> column slot in alpha, or -1
-    size_t alpha_pass_stride; // floats
+    size_t alpha_pass_stride; // elements
     int Kq;                  // NT * NCH * 16 (padded K of the launch geometry)
     double *c;               // [P][G]
     float *mg;               // [P][G][kMaxRow]  raw gamma histogram (dosage passes)
     float *gsp;              // [P][n_special]   gamma of special haplotypes
-    float *gamma_out;        // [P][G][Kq] or null
-    float *beta_out;         // [P][G][Kq] or null
-    float *beta_thin;        // [P][n_thin][Kq] unscaled beta at the thinned grids, or null
+    void *gamma_out;        // [P][G][Kq] or null
+    void *beta_out;         // [P][G][Kq] or null
+    void *beta_thin;        // [P][n_thin][Kq] unscaled beta at the thinned grids, or null
     double *dosage;          // [P][T]
     int K_top;
     int top_cap;             // capacity per (pass, thinned column)
     int truncate_lists;      // keep only the head (first top_cap in rejig order) of over-long lists
     int32_t *top_cnt;        // [P][n_thin]
     int32_t *top_idx;        // [P][n_thin][top_cap]
-    float *top_val;          // [P][n_thin][top_cap]
+    void *top_val;          // [P][n_thin][top_cap]
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -92,6 +92,7 @@ __device__ __forceinline__ double word_emission(uint32_t w, const double2 *gl, i
     return prob;
 }
 
+template <typename TS>
 __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     const int g = blockIdx.x, p = blockIdx.y, t = threadIdx.x;
     __shared__ double2 s_gl[32];
@@ -109,12 +110,13 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     }
     __syncthreads();
     const bool has_variant = s_var != 0 || g == 1 || g == 0;
-    float *out = prm.emat + ((size_t)p * prm.G + g) * kMaxRow;
+    TS *out = static_cast<TS *>(prm.emat) + ((size_t)p * prm.G + g) * kMaxRow;
+    TS *esp_out = static_cast<TS *>(prm.esp) + (size_t)p * prm.n_special;
     const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
     if (!has_variant) {
         // reference shortcut (:1078-1088): emission is 1 for every haplotype
-        if (t < prm.nrow) out[t] = (t == 0) ? (sn > 0 ? 1.f : 0.f) : 1.f;
-        for (int i = t; i < sn; i += 256) prm.esp[(size_t)p * prm.n_special + so + i] = 1.f;
+        out[t] = t >= prm.nrow ? TS(0) : (t == 0) ? (sn > 0 ? TS(1) : TS(0)) : TS(1);
+        for (int i = t; i < sn; i += 256) esp_out[so + i] = TS(1);
         return;  // (never taken for g == 0)
     }
     double e = 0;
@@ -151,10 +153,10 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     }
     // row 0 (code 0): 0 normally, so the zero padding K..Kq and any stray code drop out; 1 on grids
     // that hold specials, whose own emission `esp` is applied by the kernels' rare path
-    if (t < prm.nrow) out[t] = (t == 0) ? (sn > 0 ? 1.f : 0.f) : (float)(e * scale);
+    out[t] = t >= prm.nrow ? TS(0) : (t == 0) ? (sn > 0 ? TS(1) : TS(0)) : (TS)(e * scale);   // kMaxRow == blockDim
     for (int i = t; i < sn; i += 256) {
         double es = word_emission(prm.sp_word[so + i], s_gl, nLocal, prm.ref_error) * sp_scale;
-        prm.esp[(size_t)p * prm.n_special + so + i] = (float)es;
+        esp_out[so + i] = (TS)es;
     }
 }
 
@@ -166,9 +168,13 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 32; o > 0; o >>= 1) {
+        const T w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
     return v;
 }
 
@@ -186,10 +192,28 @@ __device__ __forceinline__ bool any_zero_code(const uint4 &d) {
     return has_zero_byte(d.x) || has_zero_byte(d.y) || has_zero_byte(d.z) || has_zero_byte(d.w);
 }
 
-// float4 index of (chunk j, vector q) of this thread in the lane-interleaved alpha checkpoint:
-// each (wave, j, q) owns 64 consecutive float4 (1 KiB) => every dwordx4 store/load is coalesced.
+// The recursions run with fp32 state (dosage passes: 16-byte vectors of 4) or fp64 state (ranking passes: 16-byte
+// vectors of 2).  Checkpoints are written in 16-byte vectors either way.
+template <typename TS> struct Vec;
+template <> struct Vec<float> { using V = float4; static constexpr int EPV = 4; };
+template <> struct Vec<double> { using V = double2; static constexpr int EPV = 2; };
+__device__ __forceinline__ float vget(const float4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; }
+__device__ __forceinline__ double vget(const double2 &v, int r) { return r == 0 ? v.x : v.y; }
+__device__ __forceinline__ float4 vmake(const float *x) { return make_float4(x[0], x[1], x[2], x[3]); }
+__device__ __forceinline__ double2 vmake(const double *x) { return make_double2(x[0], x[1]); }
+
+// vector index of (chunk j, vector q) of this thread in the lane-interleaved checkpoint layout: each
+// (wave, j, q) owns 64 consecutive 16-byte vectors (1 KiB) => every dwordx4 store / load is coalesced.
+template <int NV>
 __device__ __forceinline__ size_t alpha_vec_index(int j, int q, int NT, int t) {
-    return (size_t)j * NT * 4 + (size_t)((t >> 6) * 4 + q) * 64 + (t & 63);
+    return (size_t)j * NT * NV + (size_t)((t >> 6) * NV + q) * 64 + (t & 63);
+}
+
+template <typename TS>
+__device__ __forceinline__ void store_chunk(typename Vec<TS>::V *dst, const TS (&x)[16], int j, int NT, int t) {
+    constexpr int EPV = Vec<TS>::EPV, NV = 16 / EPV;
+#pragma unroll
+    for (int q = 0; q < NV; q++) dst[alpha_vec_index<NV>(j, q, NT, t)] = vmake(&x[EPV * q]);
 }
 
 // block-wide sum of one double per thread: wave shuffle, then LDS across waves.  `buf` is one of two
@@ -207,9 +231,9 @@ __device__ __forceinline__ double block_sum(double v, double *buf, int t, int nw
 // words) by their own emission (reference-single.cpp:1002-1042 / :1902-1964).  Row 0 of the LDS table
 // is 1 on such grids, so x holds the un-emitted value.  A chunk's specials are consecutive entries of
 // the grid's ascending list: one lower_bound per chunk that holds a zero code, then in order.
-template <int NCH>
-__device__ __forceinline__ void apply_special_emissions(float (&x)[NCH][16], const uint4 (&dh)[NCH], const PassParams &prm,
-                                                        const float *esp, int g, int NT, int t) {
+template <typename TS, int NCH>
+__device__ __forceinline__ void apply_special_emissions(TS (&x)[NCH][16], const uint4 (&dh)[NCH], const PassParams &prm,
+                                                        const TS *esp, int g, int NT, int t) {
     const int lo = prm.sp_off[g], hi = prm.sp_off[g + 1];
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
@@ -233,38 +257,39 @@ __device__ __forceinline__ void apply_special_emissions(float (&x)[NCH][16], con
 // k_fwd: forward recursion.  alpha_k <- (alpha_k + psi/sigma) * e_k, renormalised every grid
 // (reference-single.cpp:935-1107 with always_normalize).  One block per pass.
 // ---------------------------------------------------------------------------------------------
-template <int NCH, int MAXT>
+template <typename TS, int NCH, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
+    using V = typename Vec<TS>::V;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *etab = reinterpret_cast<float *>(smem);                     // [2][256]
-    double *red = reinterpret_cast<double *>(smem + 2 * kMaxRow * 4);  // [2][16]
+    TS *etab = reinterpret_cast<TS *>(smem);                                     // [2][256]
+    double *red = reinterpret_cast<double *>(smem + 2 * kMaxRow * sizeof(TS));   // [2][16]
     const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
     const int K = prm.K, G = prm.G;
     const int flags = prm.flags[p];
     const bool store_all = (flags & 15) != 0;
-    const float *emat = prm.emat + (size_t)p * G * kMaxRow;
-    const float *esp = prm.esp + (size_t)p * prm.n_special;
-    float4 *aout = reinterpret_cast<float4 *>(prm.alpha + (size_t)p * prm.alpha_pass_stride);
+    const TS *emat = static_cast<const TS *>(prm.emat) + (size_t)p * G * kMaxRow;
+    const TS *esp = static_cast<const TS *>(prm.esp) + (size_t)p * prm.n_special;
+    V *aout = reinterpret_cast<V *>(static_cast<TS *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
     const int32_t *slot = prm.alpha_slot + (size_t)p * G;
-    const size_t col_vecs = (size_t)prm.Kq / 4;
+    const size_t col_vecs = (size_t)prm.Kq / Vec<TS>::EPV;
 
-    float a[NCH][16];
+    TS a[NCH][16];
     uint4 dh[NCH];
-    const float invK = 1.0f / (float)K;
+    const TS invK = TS(1) / (TS)K;
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const int k0 = (j * NT + t) * 16;
 #pragma unroll
-        for (int i = 0; i < 16; i++) a[j][i] = (k0 + i < K) ? invK : 0.f;
+        for (int i = 0; i < 16; i++) a[j][i] = (k0 + i < K) ? invK : TS(0);
         dh[j] = make_uint4(0, 0, 0, 0);
         if (k0 < K) dh[j] = *reinterpret_cast<const uint4 *>(prm.hm + k0);
     }
-    for (int i = t; i < kMaxRow; i += NT) etab[i] = (i < prm.nrow) ? emat[i] : 0.f;
+    for (int i = t; i < kMaxRow; i += NT) etab[i] = (i < prm.nrow) ? emat[i] : TS(0);
     __syncthreads();
 
     for (int g = 0; g < G; g++) {
-        const float *et = etab + (g & 1) * kMaxRow;
-        float etn[4] = {0.f, 0.f, 0.f, 0.f};  // next grid's table: rows t, t+NT, .. (NT >= 64, nrow <= 256)
+        const TS *et = etab + (g & 1) * kMaxRow;
+        TS etn[4] = {0, 0, 0, 0};  // next grid's table: rows t, t+NT, .. (NT >= 64, nrow <= 256)
         if (g + 1 < G) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
             sig = prm.sigma[g - 1];
             sg = (1.0 - sig) / (double)K / sig;  // psi / sigma with A_prev = 1
         }
-        const float s = (float)sg;
+        const TS s = (TS)sg;
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
             const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
@@ -285,14 +310,14 @@ __global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
                 a[j][i] = (a[j][i] + s) * et[code];
             }
         }
-        if (prm.sp_off[g + 1] > prm.sp_off[g]) apply_special_emissions<NCH>(a, dh, prm, esp, g, NT, t);
-        float psum = 0.f;
+        if (prm.sp_off[g + 1] > prm.sp_off[g]) apply_special_emissions<TS, NCH>(a, dh, prm, esp, g, NT, t);
+        TS psum = 0;
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
             const int k0 = (j * NT + t) * 16;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                if (k0 + 16 > K && k0 + i >= K) a[j][i] = 0.f;  // padding K..Kq (only the tail chunk pays)
+                if (k0 + 16 > K && k0 + i >= K) a[j][i] = 0;  // padding K..Kq (only the tail chunk pays)
                 psum += a[j][i];
             }
         }
@@ -311,74 +336,70 @@ __global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
             }
         }
         const double invA = 1.0 / A;
-        const float inv = (float)invA;
+        const TS inv = (TS)invA;
         if (t == 0) prm.c[(size_t)p * G + g] = (g == 0) ? invA * prm.escale0[p] : invA / sig;
         const int sl = store_all ? g : slot[g];
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
 #pragma unroll
             for (int i = 0; i < 16; i++) a[j][i] *= inv;
-            if (sl >= 0 && (j * NT + t) * 16 < K) {
-                float4 *dst = aout + (size_t)sl * col_vecs;
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    dst[alpha_vec_index(j, q, NT, t)] =
-                        make_float4(a[j][4 * q], a[j][4 * q + 1], a[j][4 * q + 2], a[j][4 * q + 3]);
-            }
+            if (sl >= 0 && (j * NT + t) * 16 < K) store_chunk<TS>(aout + (size_t)sl * col_vecs, a[j], j, NT, t);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_bwd: backward recursion + gamma + histogram (dosage passes) + top-K (thinned grids).
-// reference-single.cpp:1854-2177.
+// k_bwd: backward recursion; FULL adds gamma + the code histogram of the dosage passes; beta at the
+// thinned grids goes to k_topk.  reference-single.cpp:1854-2177.
 // ---------------------------------------------------------------------------------------------
-template <int NCH, int MAXT>
+template <typename TS, int NCH, int MAXT, bool FULL>
 __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
+    using V = typename Vec<TS>::V;
+    constexpr int EPV = Vec<TS>::EPV, NV = 16 / EPV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *etab = reinterpret_cast<float *>(smem);                          // [2][256]
-    double *red = reinterpret_cast<double *>(smem + 2 * kMaxRow * 4);       // [2][16]
-    float *hist = reinterpret_cast<float *>(smem + 2 * kMaxRow * 4 + 2 * 16 * 8);  // [2][kMaxRow][32]
+    TS *etab = reinterpret_cast<TS *>(smem);                                     // [2][256]
+    double *red = reinterpret_cast<double *>(smem + 2 * kMaxRow * sizeof(TS));   // [2][16]
+    float *hist = reinterpret_cast<float *>(smem + 2 * kMaxRow * sizeof(TS) + 2 * 16 * 8);  // [2][kMaxRow][32] (FULL)
     const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
     const int lane = t & 63;
     const int K = prm.K, G = prm.G;
     const int flags = prm.flags[p];
-    const bool want_dosage = (flags & 1) != 0;
+    const bool want_dosage = FULL && (flags & 1) != 0;
     const bool store_all = (flags & 15) != 0;
-    const bool want_gamma = (flags & 4) != 0, want_beta = (flags & 8) != 0;
-    const float *emat = prm.emat + (size_t)p * G * kMaxRow;
-    const float *esp = prm.esp + (size_t)p * prm.n_special;
-    const float4 *ain = reinterpret_cast<const float4 *>(prm.alpha + (size_t)p * prm.alpha_pass_stride);
+    const bool want_gamma = FULL && (flags & 4) != 0, want_beta = FULL && (flags & 8) != 0;
+    const TS *emat = static_cast<const TS *>(prm.emat) + (size_t)p * G * kMaxRow;
+    const TS *esp = static_cast<const TS *>(prm.esp) + (size_t)p * prm.n_special;
+    const V *ain = reinterpret_cast<const V *>(static_cast<const TS *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
     const int32_t *slot = prm.alpha_slot + (size_t)p * G;
-    const size_t col_vecs = (size_t)prm.Kq / 4;
+    const size_t col_vecs = (size_t)prm.Kq / EPV;
     const double *cvec = prm.c + (size_t)p * G;
 
-    float b[NCH][16];
+    TS b[NCH][16];
     uint4 dh[NCH];  // codes of grid g+1 during the emission phase, then reloaded with grid g's
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const int k0 = (j * NT + t) * 16;
 #pragma unroll
-        for (int i = 0; i < 16; i++) b[j][i] = (k0 + i < K) ? 1.f : 0.f;
+        for (int i = 0; i < 16; i++) b[j][i] = (k0 + i < K) ? TS(1) : TS(0);
         dh[j] = make_uint4(0, 0, 0, 0);
     }
     if (want_dosage)
         for (int i = t; i < 2 * kMaxRow * kHistCopies; i += NT) hist[i] = 0.f;
     for (int i = t; i < kMaxRow; i += NT)
-        etab[((G - 1) & 1) * kMaxRow + i] = (i < prm.nrow) ? emat[(size_t)(G - 1) * kMaxRow + i] : 0.f;
+        etab[((G - 1) & 1) * kMaxRow + i] = (i < prm.nrow) ? emat[(size_t)(G - 1) * kMaxRow + i] : TS(0);
     __syncthreads();
 
     for (int g = G - 1; g >= 0; --g) {
         double sig = 1.0;  // "not_jump_prob" of the reference: sigma_g, or 1 at the last grid
         if (g < G - 1) {
-            float etn[4] = {0.f, 0.f, 0.f, 0.f};  // table of grid g (the emission side of iteration g-1)
+            TS etn[4] = {0, 0, 0, 0};  // table of grid g (the emission side of iteration g-1)
             if (g > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     if (t + r * NT < prm.nrow) etn[r] = emat[(size_t)g * kMaxRow + t + r * NT];
             }
             sig = prm.sigma[g];
-            const float *et = etab + ((g + 1) & 1) * kMaxRow;
+            const TS *et = etab + ((g + 1) & 1) * kMaxRow;
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
                 const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
@@ -388,8 +409,8 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
                     b[j][i] *= et[code];
                 }
             }
-            if (prm.sp_off[g + 2] > prm.sp_off[g + 1]) apply_special_emissions<NCH>(b, dh, prm, esp, g + 1, NT, t);
-            float psum = 0.f;
+            if (prm.sp_off[g + 2] > prm.sp_off[g + 1]) apply_special_emissions<TS, NCH>(b, dh, prm, esp, g + 1, NT, t);
+            TS psum = 0;
 #pragma unroll
             for (int j = 0; j < NCH; j++)
 #pragma unroll
@@ -408,14 +429,14 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
                     if (t + r * NT < kMaxRow) etab[(g & 1) * kMaxRow + t + r * NT] = etn[r];
             }
             const double S = block_sum((double)psum, red + (g & 1) * 16, t, nwaves);
-            const float add = (float)((1.0 - sig) / (double)K / sig * S);
+            const TS add = (TS)((1.0 - sig) / (double)K / sig * S);
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
                 const int k0 = (j * NT + t) * 16;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     b[j][i] += add;
-                    if (k0 + 16 > K && k0 + i >= K) b[j][i] = 0.f;
+                    if (k0 + 16 > K && k0 + i >= K) b[j][i] = 0;
                 }
             }
         }
@@ -428,119 +449,440 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
             }
         }
         const int tcol = prm.thin_col[g];
-        const int sl = store_all ? g : slot[g];
-        const bool need_gamma = (want_dosage || want_gamma) && sl >= 0;
-        if (need_gamma) {
-            const float4 *src = ain + (size_t)sl * col_vecs;
-            const bool has_sp = prm.sp_off[g + 1] > prm.sp_off[g];
-            float *h = hist + (g & 1) * kMaxRow * kHistCopies;
-            const float fs = (float)sig;
-            // alpha is streamed through a 2-chunk register pipeline: chunk j+1 is in flight while chunk
-            // j is consumed (holding all 16 * NCH values would double the register footprint)
-            float4 av[2][4];
-            if (t * 16 < K) {
+        if constexpr (FULL) {
+            const int sl = store_all ? g : slot[g];
+            const bool need_gamma = (want_dosage || want_gamma) && sl >= 0;
+            if (need_gamma) {
+                const V *src = ain + (size_t)sl * col_vecs;
+                const bool has_sp = prm.sp_off[g + 1] > prm.sp_off[g];
+                float *h = hist + (g & 1) * kMaxRow * kHistCopies;
+                const TS fs = (TS)sig;
+                // alpha is streamed through a 2-chunk register pipeline: chunk j+1 is in flight while chunk
+                // j is consumed (holding all 16 * NCH values would double the register footprint)
+                V av[2][NV];
+                if (t * 16 < K) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) av[0][q] = src[alpha_vec_index(0, q, NT, t)];
-            }
-#pragma unroll
-            for (int j = 0; j < NCH; j++) {
-                const int k0 = (j * NT + t) * 16;
-                if (j + 1 < NCH && ((j + 1) * NT + t) * 16 < K) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) av[(j + 1) & 1][q] = src[alpha_vec_index(j + 1, q, NT, t)];
+                    for (int q = 0; q < NV; q++) av[0][q] = src[alpha_vec_index<NV>(0, q, NT, t)];
                 }
-                if (k0 < K) {
-                    const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
-                    int sp_at = 0;
-                    if (want_dosage && has_sp && any_zero_code(dh[j]))
-                        sp_at = special_lower_bound(prm.sp_k, prm.sp_off[g], prm.sp_off[g + 1], k0);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 a4 = av[j & 1][q];
-                        const float al[4] = {a4.x, a4.y, a4.z, a4.w};
-                        float gq[4];
+                for (int j = 0; j < NCH; j++) {
+                    const int k0 = (j * NT + t) * 16;
+                    if (j + 1 < NCH && ((j + 1) * NT + t) * 16 < K) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int i = 4 * q + r;
-                            const float gk = al[r] * b[j][i];  // 0 beyond K: b is 0 there
-                            gq[r] = gk;
-                            if (want_dosage) {
-                                const uint32_t code = (w[q] >> (r * 8)) & 0xffu;
-                                atomicAdd(&h[code * kHistCopies + (lane & 31)], gk);
-                                if (has_sp && code == 0 && k0 + i < K) {
-                                    // gamma of a special haplotype goes to its own list (:2096-2128)
-                                    prm.gsp[(size_t)p * prm.n_special + sp_at] = gk;
-                                    sp_at++;
+                        for (int q = 0; q < NV; q++) av[(j + 1) & 1][q] = src[alpha_vec_index<NV>(j + 1, q, NT, t)];
+                    }
+                    if (k0 < K) {
+                        const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+                        int sp_at = 0;
+                        if (want_dosage && has_sp && any_zero_code(dh[j]))
+                            sp_at = special_lower_bound(prm.sp_k, prm.sp_off[g], prm.sp_off[g + 1], k0);
+#pragma unroll
+                        for (int q = 0; q < NV; q++) {
+                            TS gq[EPV];
+#pragma unroll
+                            for (int r = 0; r < EPV; r++) {
+                                const int i = EPV * q + r;
+                                const TS gk = vget(av[j & 1][q], r) * b[j][i];  // 0 beyond K: b is 0 there
+                                gq[r] = gk * fs;
+                                if (want_dosage) {
+                                    const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+                                    atomicAdd(&h[code * kHistCopies + (lane & 31)], (float)gk);
+                                    if (has_sp && code == 0 && k0 + i < K) {
+                                        // gamma of a special haplotype goes to its own list (:2096-2128)
+                                        prm.gsp[(size_t)p * prm.n_special + sp_at] = (float)gk;
+                                        sp_at++;
+                                    }
                                 }
                             }
-                        }
-                        if (want_gamma) {
-                            float4 *dst = reinterpret_cast<float4 *>(prm.gamma_out) + ((size_t)p * G + g) * col_vecs;
-                            dst[alpha_vec_index(j, q, NT, t)] = make_float4(gq[0] * fs, gq[1] * fs, gq[2] * fs, gq[3] * fs);
+                            if (want_gamma) {
+                                V *dst = reinterpret_cast<V *>(prm.gamma_out) + ((size_t)p * G + g) * col_vecs;
+                                dst[alpha_vec_index<NV>(j, q, NT, t)] = vmake(gq);
+                            }
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (want_dosage) {
-                __syncthreads();
-                // fold the 32 bank-private copies (one half-wave per code), re-zeroing as we go
-                float *mgo = prm.mg + ((size_t)p * G + g) * kMaxRow;
-                for (int base = 0; base < prm.nrow; base += 2 * nwaves) {
-                    const int code = base + 2 * (t >> 6) + (lane >> 5);
-                    float v = 0.f;
-                    if (code < prm.nrow) {
-                        v = h[code * kHistCopies + (lane & 31)];
-                        h[code * kHistCopies + (lane & 31)] = 0.f;
-                    }
+                if (want_dosage) {
+                    __syncthreads();
+                    // fold the 32 bank-private copies (one half-wave per code), re-zeroing as we go
+                    float *mgo = prm.mg + ((size_t)p * G + g) * kMaxRow;
+                    for (int base = 0; base < prm.nrow; base += 2 * nwaves) {
+                        const int code = base + 2 * (t >> 6) + (lane >> 5);
+                        float v = 0.f;
+                        if (code < prm.nrow) {
+                            v = h[code * kHistCopies + (lane & 31)];
+                            h[code * kHistCopies + (lane & 31)] = 0.f;
+                        }
 #pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    if (code < prm.nrow && (lane & 31) == 0) mgo[code] = v;
+                        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                        if (code < prm.nrow && (lane & 31) == 0) mgo[code] = v;
+                    }
                 }
             }
         }
         if (tcol >= 0 && prm.beta_thin) {
             // thinned grid: hand the (unscaled) beta column to k_topk, which forms gamma = alpha * beta
             // and picks the top matches off the serial path (:2020-2031)
-            float4 *dst = reinterpret_cast<float4 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
+            V *dst = reinterpret_cast<V *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
                 if ((j * NT + t) * 16 >= K) continue;
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    dst[alpha_vec_index(j, q, NT, t)] =
-                        make_float4(b[j][4 * q], b[j][4 * q + 1], b[j][4 * q + 2], b[j][4 * q + 3]);
+                store_chunk<TS>(dst, b[j], j, NT, t);
             }
         }
         // beta *= c_g * sigma_g   (:2165-2166)
-        const float x = (float)(cvec[g] * sig);
+        const TS x = (TS)(cvec[g] * sig);
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
 #pragma unroll
             for (int i = 0; i < 16; i++) b[j][i] *= x;
         }
         if (want_beta) {
-            float4 *dst = reinterpret_cast<float4 *>(prm.beta_out) + ((size_t)p * G + g) * col_vecs;
+            V *dst = reinterpret_cast<V *>(prm.beta_out) + ((size_t)p * G + g) * col_vecs;
 #pragma unroll
-            for (int j = 0; j < NCH; j++)
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    dst[alpha_vec_index(j, q, NT, t)] =
-                        make_float4(b[j][4 * q], b[j][4 * q + 1], b[j][4 * q + 2], b[j][4 * q + 3]);
+            for (int j = 0; j < NCH; j++) store_chunk<TS>(dst, b[j], j, NT, t);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp64-state kernels of the ranking passes (best-haplotype lists).  One wave per SIMD (256 threads) owns the whole
+// 512-entry VGPR + AGPR file, and 16 doubles x NCH chunks per lane still do not fit next to the temporaries, so
+//   * NR chunks of state live in registers and NL chunks in LDS ([chunk][vector][lane] double2: conflict-free b128),
+//     with the per-grid scaling of the LDS chunks deferred into the next grid's update (one LDS read + write per grid;
+//     the arithmetic sequence per element is exactly that of the register chunks);
+//   * a grid's codes are not held in registers: they sit in an LDS slot per chunk, refilled global -> LDS by DMA
+//     (global_load_lds_dwordx4, no staging registers) as soon as the chunk has consumed them; a wave reads only
+//     codes it fetched itself, so its own vmcnt(0) orders them;
+//   * the 2 KiB emission table of the next grid is DMA'd by wave 0 into the other half of a double buffer and
+//     published by the per-grid barrier of the block-wide sum.
+// ---------------------------------------------------------------------------------------------
+// compile-time loop: the chunk loops are too large for `#pragma unroll` to be honoured, and the register-resident
+// state needs constant indices
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+struct Lds64 {
+    double *etab;    // [2][256]
+    double *red;     // [2][16]
+    char *codes;     // [Kq]
+    double2 *state;  // [NL][8][NT]
+    __device__ __forceinline__ explicit Lds64(char *smem, int Kq) {
+        etab = reinterpret_cast<double *>(smem);
+        red = etab + 2 * kMaxRow;
+        codes = smem + 2 * kMaxRow * 8 + 2 * 16 * 8;
+        state = reinterpret_cast<double2 *>(codes + Kq);
+    }
+};
+inline size_t lds64_bytes(int Kq, int NT, int NL) { return 2 * kMaxRow * 8 + 2 * 16 * 8 + (size_t)Kq + (size_t)NL * NT * 128; }
+
+// wave 0: DMA grid g's emission table into half `buf`
+__device__ __forceinline__ void dma_table(const double *emat, int g, double *etab, int buf, int t) {
+    if (t < 64) {   // 256 doubles = 2 x (64 lanes x 16 B)
+        dma16(emat + (size_t)g * kMaxRow + 2 * t, etab + buf * kMaxRow);
+        dma16(emat + (size_t)g * kMaxRow + 128 + 2 * t, etab + buf * kMaxRow + 128);
+    }
+}
+// refill chunk j's code slot with grid g's codes (this lane's 16 haplotypes)
+__device__ __forceinline__ void dma_codes(const PassParams &prm, int g, char *codes, int j, int NT, int t) {
+    const int k0 = (j * NT + t) * 16;
+    if (k0 < prm.K) dma16(prm.hm + (size_t)g * prm.Kp + k0, codes + (j * NT + (t & ~63)) * 16);
+}
+
+// One chunk of 16 emissions: x_i <- (x_i + addend) * table[code_i]; haplotypes with code 0 on a grid that has specials
+// are then multiplied by their own emission (table row 0 is 1 there; reference-single.cpp:1002-1042 / :1902-1964);
+// elements >= tail of the chunk straddling K are forced back to 0.  Returns the chunk's sum.
+template <bool ADD>
+__device__ __forceinline__ double emit_chunk(double (&x)[16], const uint4 &d, const double *et, double addend, bool has_sp,
+                                             const PassParams &prm, const double *esp, int g, int k0, int tail) {
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+        x[i] = ADD ? (x[i] + addend) * et[code] : x[i] * et[code];
+    }
+    if (has_sp && k0 < prm.K && any_zero_code(d)) {   // rare
+        int lo = prm.sp_off[g], hi = prm.sp_off[g + 1];
+        const int first = lo;
+        while (lo < hi) {   // lower bound of k0 in the grid's ascending special list
+            const int mid = (lo + hi) >> 1;
+            if (prm.sp_k[mid] < k0) lo = mid + 1; else hi = mid;
+        }
+        int at = lo;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+            const bool sp = code == 0 && k0 + i < prm.K;
+            const double e_sp = esp[sp ? at : first];
+            at += sp ? 1 : 0;
+            x[i] *= sp ? e_sp : 1.0;
+        }
+    }
+    if (tail < 16) {   // at most one lane of the block
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = i < tail ? x[i] : 0.0;
+    }
+    double sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += x[i];
+    return sum;
+}
+
+template <int NR, int NL>
+__global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
+    constexpr int NCH = NR + NL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Lds64 L(smem, prm.Kq);
+    const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
+    const int K = prm.K, G = prm.G;
+    const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
+    const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.n_special;
+    double2 *aout = reinterpret_cast<double2 *>(static_cast<double *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
+    const int32_t *slot = prm.alpha_slot + (size_t)p * G;
+    const size_t col_vecs = (size_t)prm.Kq / 2;
+    // chunks past K carry 0 and must stay 0: the additive term is switched off per chunk; `tail` < 16 marks the
+    // lane's chunk that straddles K (row jstar)
+    uint32_t valid = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) valid |= ((j * NT + t) * 16 < K ? 1u : 0u) << j;
+    const int jstar = (K / 16) / NT;
+    const int tail_star = ((K / 16) % NT == t && (K & 15)) ? (K & 15) : 16;
+
+    double a[NR][16];
+    const double invK = 1.0 / (double)K;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int k0 = (j * NT + t) * 16;
+        if (j < NR) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[j][i] = (k0 + i < K) ? invK : 0.0;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                L.state[((j - NR) * 8 + q) * NT + t] = make_double2(k0 + 2 * q < K ? invK : 0.0, k0 + 2 * q + 1 < K ? invK : 0.0);
+        }
+        reinterpret_cast<uint4 *>(L.codes)[j * NT + t] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCH; j++) dma_codes(prm, 0, L.codes, j, NT, t);
+    dma_table(emat, 0, L.etab, 0, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    double inv_prev = 1.0;   // scaling of the previous grid, still owed by the LDS chunks
+    for (int g = 0; g < G; g++) {
+        const int buf = g & 1;
+        if (g + 1 < G) dma_table(emat, g + 1, L.etab, buf ^ 1, t);   // that half was last read in iteration g-1
+        const double *et = L.etab + buf * kMaxRow;
+        const bool has_sp = prm.sp_off[g + 1] > prm.sp_off[g];
+        double sg = 0.0, sig = 1.0;
+        if (g > 0) {
+            sig = prm.sigma[g - 1];
+            sg = (1.0 - sig) / (double)K / sig;  // psi / sigma with A_prev = 1
+        }
+        double psum = 0;
+        static_for<NCH>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const uint4 d = reinterpret_cast<const uint4 *>(L.codes)[j * NT + t];
+            const double sj = ((valid >> j) & 1u) ? sg : 0.0;
+            const int tail = (j == jstar) ? tail_star : 16;
+            const int k0 = (j * NT + t) * 16;
+            if constexpr (j < NR) {
+                psum += emit_chunk<true>(a[j], d, et, sj, has_sp, prm, esp, g, k0, tail);
+            } else {
+                double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
+                double x[16];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double2 v = st[q * NT];
+                    x[2 * q] = v.x * inv_prev;
+                    x[2 * q + 1] = v.y * inv_prev;
+                }
+                psum += emit_chunk<true>(x, d, et, sj, has_sp, prm, esp, g, k0, tail);
+#pragma unroll
+                for (int q = 0; q < 8; q++) st[q * NT] = make_double2(x[2 * q], x[2 * q + 1]);
+            }
+            if (g + 1 < G) dma_codes(prm, g + 1, L.codes, j, NT, t);   // the slot's codes are in registers / used
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs for grid g+1 have landed
+        const double A = block_sum(psum, L.red + buf * 16, t, nwaves);
+        const double invA = 1.0 / A;
+        if (t == 0) prm.c[(size_t)p * G + g] = (g == 0) ? invA * prm.escale0[p] : invA / sig;
+        const int sl = slot[g];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[j][i] *= invA;
+            if (sl >= 0 && (j * NT + t) * 16 < K) store_chunk<double>(aout + (size_t)sl * col_vecs, a[j], j, NT, t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        inv_prev = invA;
+        if (sl >= 0) {
+#pragma unroll
+            for (int j = NR; j < NCH; j++) {
+                if ((j * NT + t) * 16 >= K) continue;
+                const double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
+                double x[16];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const double2 v = st[q * NT];
+                    x[2 * q] = v.x * invA;
+                    x[2 * q + 1] = v.y * invA;
+                }
+                store_chunk<double>(aout + (size_t)sl * col_vecs, x, j, NT, t);
+            }
+        }
+    }
+}
+
+template <int NR, int NL>
+__global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
+    constexpr int NCH = NR + NL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Lds64 L(smem, prm.Kq);
+    const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
+    const int K = prm.K, G = prm.G;
+    const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
+    const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.n_special;
+    const size_t col_vecs = (size_t)prm.Kq / 2;
+    const double *cvec = prm.c + (size_t)p * G;
+    uint32_t valid = 0;   // see k_fwd64
+#pragma unroll
+    for (int j = 0; j < NCH; j++) valid |= ((j * NT + t) * 16 < K ? 1u : 0u) << j;
+    const int jstar = (K / 16) / NT;
+    const int tail_star = ((K / 16) % NT == t && (K & 15)) ? (K & 15) : 16;
+
+    double b[NR][16];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int k0 = (j * NT + t) * 16;
+        if (j < NR) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) b[j][i] = (k0 + i < K) ? 1.0 : 0.0;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                L.state[((j - NR) * 8 + q) * NT + t] = make_double2(k0 + 2 * q < K ? 1.0 : 0.0, k0 + 2 * q + 1 < K ? 1.0 : 0.0);
+        }
+        reinterpret_cast<uint4 *>(L.codes)[j * NT + t] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCH; j++) dma_codes(prm, G - 1, L.codes, j, NT, t);
+    dma_table(emat, G - 1, L.etab, (G - 1) & 1, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // the LDS chunks hold beta after the emission step; "+ add" and "* x" of that grid are applied when next read
+    double add_prev = 0.0, x_prev = 1.0;
+    for (int g = G - 1; g >= 0; --g) {
+        double sig = 1.0;  // "not_jump_prob" of the reference: sigma_g, or 1 at the last grid
+        double add = 0.0;
+        if (g < G - 1) {
+            const int buf = (g + 1) & 1;             // grid g+1's table: the emission side
+            if (g > 0) dma_table(emat, g, L.etab, buf ^ 1, t);   // for iteration g-1; that half was last read in g+1
+            sig = prm.sigma[g];
+            const double *et = L.etab + buf * kMaxRow;
+            const bool has_sp = prm.sp_off[g + 2] > prm.sp_off[g + 1];
+            double psum = 0;
+            static_for<NCH>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const uint4 d = reinterpret_cast<const uint4 *>(L.codes)[j * NT + t];   // grid g+1
+                const int tail = (j == jstar) ? tail_star : 16;
+                const int k0 = (j * NT + t) * 16;
+                if constexpr (j < NR) {
+                    psum += emit_chunk<false>(b[j], d, et, 0.0, has_sp, prm, esp, g + 1, k0, tail);
+                } else {
+                    double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
+                    const double aj = ((valid >> j) & 1u) ? add_prev : 0.0;
+                    double x[16];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double2 v = st[q * NT];
+                        x[2 * q] = (v.x + aj) * x_prev;
+                        x[2 * q + 1] = (v.y + aj) * x_prev;
+                    }
+                    psum += emit_chunk<false>(x, d, et, 0.0, has_sp, prm, esp, g + 1, k0, tail);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) st[q * NT] = make_double2(x[2 * q], x[2 * q + 1]);
+                }
+                if (g > 0) dma_codes(prm, g, L.codes, j, NT, t);   // codes of grid g, for iteration g-1
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const double S = block_sum(psum, L.red + (g & 1) * 16, t, nwaves);
+            add = (1.0 - sig) / (double)K / sig * S;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const double aj = ((valid >> j) & 1u) ? add : 0.0;
+                const int tail = (j == jstar) ? tail_star : 16;
+#pragma unroll
+                for (int i = 0; i < 16; i++) b[j][i] += aj;
+                if (tail < 16) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) b[j][i] = i < tail ? b[j][i] : 0.0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int tcol = prm.thin_col[g];
+        if (tcol >= 0 && prm.beta_thin) {
+            // thinned grid: hand the (unscaled) beta column to k_topk (:2020-2031)
+            double2 *dst = reinterpret_cast<double2 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
+            static_for<NCH>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if ((j * NT + t) * 16 >= K) return;
+                if constexpr (j < NR) {
+                    store_chunk<double>(dst, b[j], j, NT, t);
+                } else {
+                    const double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
+                    const int tail = (j == jstar) ? tail_star : 16;
+                    double x[16];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double2 v = st[q * NT];
+                        x[2 * q] = 2 * q < tail ? v.x + add : 0.0;
+                        x[2 * q + 1] = 2 * q + 1 < tail ? v.y + add : 0.0;
+                    }
+                    store_chunk<double>(dst, x, j, NT, t);
+                }
+            });
+        }
+        const double x = cvec[g] * sig;   // beta *= c_g * sigma_g   (:2165-2166)
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) b[j][i] *= x;
+        }
+        add_prev = add;
+        x_prev = x;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_topk: best haplotypes at one thinned grid of one pass (reference-single.cpp:129-194, :2020-2031).
 // threshold = K_top-th largest gamma counted with multiplicity; every k with gamma >= threshold is
 // reported with gamma * not_jump_prob.  One block per (thinned column, pass); alpha and beta columns
 // are in the same lane-interleaved order, so gamma is an elementwise product of two coalesced streams.
 // ---------------------------------------------------------------------------------------------
+template <typename TS>
 __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
+    using V = typename Vec<TS>::V;
+    constexpr int EPV = Vec<TS>::EPV, NV = 16 / EPV;
     const int tcol = blockIdx.x, p = blockIdx.y, t = threadIdx.x, lane = t & 63;
-    __shared__ float s_top[4][kMaxTop];
+    __shared__ TS s_top[4][kMaxTop];
     __shared__ int s_cnt;
     __shared__ int s_g;
     if (t == 0) {
@@ -553,31 +895,36 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
     const int g = s_g;
     const int flags = prm.flags[p];
     const int sl = (flags & 15) ? g : prm.alpha_slot[(size_t)p * prm.G + g];
-    const size_t col_vecs = (size_t)prm.Kq / 4;
-    const float4 *av = reinterpret_cast<const float4 *>(prm.alpha + (size_t)p * prm.alpha_pass_stride) + (size_t)sl * col_vecs;
-    const float4 *bv = reinterpret_cast<const float4 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
+    const size_t col_vecs = (size_t)prm.Kq / EPV;
+    const V *av = reinterpret_cast<const V *>(static_cast<const TS *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride) + (size_t)sl * col_vecs;
+    const V *bv = reinterpret_cast<const V *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
     const int Ktop = prm.K_top;
-    const int nvec = prm.Kq / 4;
-    float ltop[kMaxTop];
+    const int nvec = prm.Kq / EPV;
+    TS ltop[kMaxTop];
 #pragma unroll
-    for (int q = 0; q < kMaxTop; q++) ltop[q] = 0.f;
+    for (int q = 0; q < kMaxTop; q++) ltop[q] = 0;
     auto k_of = [&](int v, int r) {
-        const int j = v / (NT * 4), rem = v % (NT * 4);
-        const int tt = (rem >> 8) * 64 + (rem & 63), q = (rem >> 6) & 3;
-        return (j * NT + tt) * 16 + 4 * q + r;
+        const int j = v / (NT * NV), rem = v % (NT * NV);
+        const int tt = (rem / (64 * NV)) * 64 + (rem & 63), q = (rem >> 6) % NV;
+        return (j * NT + tt) * 16 + EPV * q + r;
+    };
+    auto gamma_of = [&](int v, TS (&gq)[EPV]) {
+        const V a4 = av[v], b4 = bv[v];
+#pragma unroll
+        for (int r = 0; r < EPV; r++) gq[r] = vget(a4, r) * vget(b4, r);
     };
     for (int v = t; v < nvec; v += 256) {
         if (k_of(v, 0) >= prm.K) continue;
-        const float4 a4 = av[v], b4 = bv[v];
-        const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+        TS gq[EPV];
+        gamma_of(v, gq);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float x = (k_of(v, r) < prm.K) ? gq[r] : 0.f;
+        for (int r = 0; r < EPV; r++) {
+            TS x = (k_of(v, r) < prm.K) ? gq[r] : TS(0);
 #pragma unroll
             for (int z = 0; z < kMaxTop; z++) {
                 if (z < Ktop) {
-                    const float hi = fmaxf(ltop[z], x);
-                    x = fminf(ltop[z], x);
+                    const TS hi = ltop[z] > x ? ltop[z] : x;
+                    x = ltop[z] > x ? x : ltop[z];
                     ltop[z] = hi;
                 }
             }
@@ -585,42 +932,42 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
     }
     // wave merge: pop the maximum Ktop times
     for (int r = 0; r < Ktop; r++) {
-        const float m = wave_max(ltop[0]);
+        const TS m = wave_max(ltop[0]);
         const unsigned long long owners = __ballot(ltop[0] == m);
         const int first = __ffsll((long long)owners) - 1;
         if (lane == first) {
 #pragma unroll
             for (int q = 0; q < kMaxTop - 1; q++) ltop[q] = ltop[q + 1];
-            ltop[kMaxTop - 1] = 0.f;
+            ltop[kMaxTop - 1] = 0;
         }
         if (lane == 0) s_top[t >> 6][r] = m;
     }
     __syncthreads();
-    float thr = 0.f;
+    TS thr = 0;
     {
-        float head = 0.f;
+        TS head = 0;
         int pos = 0;
         if (lane < 4) head = s_top[lane][0];
         for (int r = 0; r < Ktop; r++) {
-            const float m = wave_max(head);
+            const TS m = wave_max(head);
             thr = m;
             const unsigned long long owners = __ballot(lane < 4 && head == m);
             const int first = __ffsll((long long)owners) - 1;
             if (lane == first) {
                 pos++;
-                head = (pos < Ktop) ? s_top[lane][pos] : 0.f;
+                head = (pos < Ktop) ? s_top[lane][pos] : TS(0);
             }
         }
     }
-    const float fs = (g < prm.G - 1) ? (float)prm.sigma[g] : 1.f;
+    const TS fs = (g < prm.G - 1) ? (TS)prm.sigma[g] : TS(1);
     int32_t *oi = prm.top_idx + ((size_t)p * prm.n_thin + tcol) * prm.top_cap;
-    float *ov = prm.top_val + ((size_t)p * prm.n_thin + tcol) * prm.top_cap;
+    TS *ov = static_cast<TS *>(prm.top_val) + ((size_t)p * prm.n_thin + tcol) * prm.top_cap;
     for (int v = t; v < nvec; v += 256) {
         if (k_of(v, 0) >= prm.K) continue;
-        const float4 a4 = av[v], b4 = bv[v];
-        const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+        TS gq[EPV];
+        gamma_of(v, gq);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < EPV; r++) {
             const int kk = k_of(v, r);
             if (kk < prm.K && gq[r] >= thr) {
                 const int at = atomicAdd(&s_cnt, 1);
@@ -631,8 +978,8 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
     __syncthreads();
     const int n_all = s_cnt;
     if (n_all > prm.top_cap && prm.truncate_lists) {
-        // More matches than the list holds (exact ties at the threshold: common in fp32 once haplotypes share a
-        // long identical stretch).  Keep what the host logic can ever look at first: every gamma above the
+        // More matches than the list holds (exact ties at the threshold, e.g. haplotypes identical over the
+        // whole region).  Keep what the host logic can ever look at first: every gamma above the
         // threshold, then the tied ones by ascending haplotype -- i.e. the head of the ordered list.
         __shared__ int s_n;
         auto block_count = [&](int kb) {   // #matches with gamma > thr, or gamma == thr and k <= kb
@@ -642,10 +989,10 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
             int mine = 0;
             for (int v = t; v < nvec; v += 256) {
                 if (k_of(v, 0) >= prm.K) continue;
-                const float4 a4 = av[v], b4 = bv[v];
-                const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+                TS gq[EPV];
+                gamma_of(v, gq);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < EPV; r++) {
                     const int kk = k_of(v, r);
                     if (kk < prm.K && (gq[r] > thr || (gq[r] == thr && kk <= kb))) mine++;
                 }
@@ -665,10 +1012,10 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
         __syncthreads();
         for (int v = t; v < nvec; v += 256) {
             if (k_of(v, 0) >= prm.K) continue;
-            const float4 a4 = av[v], b4 = bv[v];
-            const float gq[4] = {a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
+            TS gq[EPV];
+            gamma_of(v, gq);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < EPV; r++) {
                 const int kk = k_of(v, r);
                 if (kk < prm.K && (gq[r] > thr || (gq[r] == thr && kk <= kb))) {
                     const int at = atomicAdd(&s_cnt, 1);
@@ -686,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
         if (n <= 64 && (n_all <= prm.top_cap || prm.truncate_lists)) {
             for (int i = 1; i < n; i++) {
                 const int ki = oi[i];
-                const float vi = ov[i];
+                const TS vi = ov[i];
                 int j = i - 1;
                 while (j >= 0 && (ov[j] < vi || (ov[j] == vi && oi[j] > ki))) { oi[j + 1] = oi[j]; ov[j + 1] = ov[j]; j--; }
                 oi[j + 1] = ki;
@@ -782,15 +1129,17 @@ __global__ __launch_bounds__(256) void k_make_gl(GlParams p) {
     *out = make_double2(a, b);
 }
 
-// un-permute a lane-interleaved [cols][Kq] float matrix into a K x cols double matrix (column-major)
-__global__ void k_unpermute(const float *src, double *dst, int K, int Kq, int NT, int cols, size_t dst_ld) {
+// un-permute a lane-interleaved [cols][Kq] matrix into a K x cols double matrix (column-major)
+template <typename TS>
+__global__ void k_unpermute(const TS *src, double *dst, int K, int Kq, int NT, int cols, size_t dst_ld) {
+    constexpr int EPV = Vec<TS>::EPV, NV = 16 / EPV;
     const int col = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K || col >= cols) return;
     const int chunk = k >> 4, e = k & 15;
     const int j = chunk / NT, t = chunk % NT;
-    const size_t vec = (size_t)j * NT * 4 + (size_t)((t >> 6) * 4 + (e >> 2)) * 64 + (t & 63);
-    dst[(size_t)col * dst_ld + k] = (double)src[(size_t)col * Kq + vec * 4 + (e & 3)];
+    const size_t vec = alpha_vec_index<NV>(j, e / EPV, NT, t);
+    dst[(size_t)col * dst_ld + k] = (double)src[(size_t)col * Kq + vec * EPV + (e % EPV)];
 }
 
 }  // namespace
@@ -800,7 +1149,8 @@ __global__ void k_unpermute(const float *src, double *dst, int K, int Kq, int NT
 // ---------------------------------------------------------------------------------------------
 struct qa_panel::Scratch {
     qa::ABuf<double> gl, c, dosage, escale0, unperm;
-    qa::ABuf<float> emat, esp, alpha, mg, gsp, gamma, beta, beta_thin, top_val;
+    qa::ABuf<float> mg, gsp;
+    qa::ABuf<char> emat, esp, alpha, gamma, beta, beta_thin, top_val;   // fp32 or fp64 elements (the launch decides)
     qa::ABuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     explicit Scratch(qa::Arena *a) {
@@ -822,35 +1172,40 @@ namespace {
 
 thread_local double g_timing[5] = {0, 0, 0, 0, 0};
 
-struct Geometry { int NT, NCH; };
+struct Geometry { int NT, NCH; bool f64; };
 
-// Register-resident geometry: NT threads (multiple of 64, <= 512 so that each wave may use 256
-// VGPRs) x NCH chunks of 16 haplotypes per lane.  The smallest NCH that covers K gives the most
-// waves; tiny panels still get >= 2 chunks per lane for ILP.
-constexpr int kNchList[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
-Geometry pick_geometry(int K) {
+// Register-resident geometry: NT threads (multiple of 64) x NCH chunks of 16 haplotypes per lane.  fp32 state:
+// NT <= 512 so that each wave may use 256 VGPRs; fp64 state (ranking passes): NT <= 256, one wave per SIMD with
+// the whole 512-entry VGPR + AGPR file.  The smallest NCH that covers K gives the most waves; tiny panels still
+// get >= 2 chunks per lane for ILP.
+constexpr int kNchList32[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
+constexpr int kNchList64[] = {1, 2, 4, 6, 8, 10, 12, 13, 14};
+Geometry pick_geometry(int K, bool f64 = false) {
     const int chunks = (K + 15) / 16;
-    for (int nch : kNchList) {
+    const int max_nt = f64 ? 256 : 512;
+    auto fit = [&](int nch) -> int {
         int nt = (chunks + nch - 1) / nch;
         nt = std::max((nt + 63) / 64 * 64, 64);
-        if (nt > 512) continue;
-        if (nch == 1 && chunks > 128) continue;
-        return {nt, nch};
-    }
-    return {0, 0};
+        if (nt > max_nt) return 0;
+        if (nch == 1 && chunks > 128) return 0;
+        return nt;
+    };
+    if (f64) { for (int nch : kNchList64) if (int nt = fit(nch)) return {nt, nch, true}; }
+    else     { for (int nch : kNchList32) if (int nt = fit(nch)) return {nt, nch, false}; }
+    return {0, 0, f64};
 }
 
 
 // device bytes one pass needs in run_passes (mirrors its carves, with alignment slack)
 size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stores_all, bool gamma, bool beta,
                   bool device_gl) {
-    const size_t Kq = (size_t)geo.NT * geo.NCH * 16, G = pn->G, T = pn->T;
+    const size_t Kq = (size_t)geo.NT * geo.NCH * 16, G = pn->G, T = pn->T, es = geo.f64 ? 8 : 4;
     const size_t cols = stores_all ? G : (size_t)std::max(n_thin, 1);
-    size_t b = (device_gl ? 0 : 0) + T * 16 + G * 4 + G * kMaxRow * 4 * 2 + 8 + (size_t)pn->n_special * 8 + cols * Kq * 4 +
-               G * 8 + T * 8;
-    if (gamma) b += G * Kq * 4;
-    if (beta) b += G * Kq * 4;
-    if (n_thin > 0) b += (size_t)n_thin * Kq * 4 + (size_t)n_thin * (4 + 64 * 8);
+    (void)device_gl;
+    size_t b = T * 16 + G * 4 + G * kMaxRow * (es + 4) + 8 + (size_t)pn->n_special * (es + 4) + cols * Kq * es + G * 8 + T * 8;
+    if (gamma) b += G * Kq * es;
+    if (beta) b += G * Kq * es;
+    if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 64 * 12);
     return b + 256 * 24;
 }
 
@@ -865,21 +1220,70 @@ int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
     return (int)n;
 }
 
-template <int NCH, int MAXT>
+template <typename TS, int NCH, int MAXT, bool FULL>
 void launch_fb(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
-    const size_t lds_f = 2 * kMaxRow * 4 + 2 * 16 * 8;
-    const size_t lds_b = lds_f + (size_t)2 * kMaxRow * kHistCopies * 4;
-    hipLaunchKernelGGL((k_fwd<NCH, MAXT>), dim3(prm.P), dim3(NT), lds_f, s, prm);
+    const size_t lds_f = 2 * kMaxRow * sizeof(TS) + 2 * 16 * 8;
+    const size_t lds_b = lds_f + (FULL ? (size_t)2 * kMaxRow * kHistCopies * 4 : 0);
+    hipLaunchKernelGGL((k_fwd<TS, NCH, MAXT>), dim3(prm.P), dim3(NT), lds_f, s, prm);
     QA_HIP(hipGetLastError());
     QA_HIP(hipEventRecord(e_mid, s));
-    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd<NCH, MAXT>),
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd<TS, NCH, MAXT, FULL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-    hipLaunchKernelGGL((k_bwd<NCH, MAXT>), dim3(prm.P), dim3(NT), lds_b, s, prm);
+    hipLaunchKernelGGL((k_bwd<TS, NCH, MAXT, FULL>), dim3(prm.P), dim3(NT), lds_b, s, prm);
     QA_HIP(hipGetLastError());
 }
 
+template <int NR, int NL>
+void launch_fb64(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
+    const size_t lds = lds64_bytes(prm.Kq, NT, NL);
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_fwd64<NR, NL>), dim3(prm.P), dim3(NT), lds, s, prm);
+    QA_HIP(hipGetLastError());
+    QA_HIP(hipEventRecord(e_mid, s));
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_bwd64<NR, NL>), dim3(prm.P), dim3(NT), lds, s, prm);
+    QA_HIP(hipGetLastError());
+}
+
+void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, hipEvent_t e_mid) {
+    if (geo.f64) {
+        // NCH = NR register chunks + NL LDS chunks (every geometry but the smallest exercises the LDS path)
+        switch (geo.NCH) {
+#ifndef QA_FAST_BUILD
+            case 1: launch_fb64<1, 0>(prm, geo.NT, st, e_mid); break;
+            case 4: launch_fb64<3, 1>(prm, geo.NT, st, e_mid); break;
+            case 6: launch_fb64<5, 1>(prm, geo.NT, st, e_mid); break;
+            case 8: launch_fb64<7, 1>(prm, geo.NT, st, e_mid); break;
+            case 10: launch_fb64<8, 2>(prm, geo.NT, st, e_mid); break;
+            case 12: launch_fb64<9, 3>(prm, geo.NT, st, e_mid); break;
+            case 14: launch_fb64<11, 3>(prm, geo.NT, st, e_mid); break;
+#endif
+            case 2: launch_fb64<1, 1>(prm, geo.NT, st, e_mid); break;
+            case 13: launch_fb64<10, 3>(prm, geo.NT, st, e_mid); break;
+            default: throw std::runtime_error("geometry not built");
+        }
+        return;
+    }
+    switch (geo.NCH) {
+#ifndef QA_FAST_BUILD
+        case 1: launch_fb<float, 1, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 3: launch_fb<float, 3, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 4: launch_fb<float, 4, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 5: launch_fb<float, 5, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 6: launch_fb<float, 6, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 8: launch_fb<float, 8, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 10: launch_fb<float, 10, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 12: launch_fb<float, 12, 512, true>(prm, geo.NT, st, e_mid); break;
+#endif
+        case 2: launch_fb<float, 2, 512, true>(prm, geo.NT, st, e_mid); break;
+        case 7: launch_fb<float, 7, 512, true>(prm, geo.NT, st, e_mid); break;
+        default: throw std::runtime_error("geometry not built");
+    }
+}
+
 struct BatchOut {
-    double *dosage = nullptr;        // [P][T]
+    double *dosage = nullptr;        // [P][T] (row p, or dosage_rows[p] when given)
+    const int32_t *dosage_rows = nullptr;
     double *c = nullptr;             // [P][G]
     double *alphaHat_t = nullptr;    // single-pass API only
     double *betaHat_t = nullptr;
@@ -887,7 +1291,7 @@ struct BatchOut {
     double *gammaSmall_t = nullptr;
     bool gamma_small_unscaled = false;  // gammaSmall_t without return_gamma_t: no sigma factor (:2170-2176)
     // best_haps_stuff_list of every (pass, thinned column), appended in pass-major order
-    std::vector<std::vector<std::pair<int32_t, float>>> *lists = nullptr;
+    std::vector<std::vector<std::pair<int32_t, double>>> *lists = nullptr;
     bool truncate_lists = false;   // batched drivers: lists capped at 64 entries (head of the ordered list)
     bool order_by_value = false;
     std::vector<int32_t> *true_counts = nullptr;   // untruncated list lengths  // lists ordered as everything_per_hap_rejig_haps wants (else ascending k)
@@ -895,16 +1299,21 @@ struct BatchOut {
 
 // runs P passes; flags per pass as in PassParams
 int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, const int32_t *thin_col_h,
-               int K_top, int normalize_emissions, const BatchOut &out) {
+               int K_top, int normalize_emissions, const BatchOut &out, bool f64 = false) {
     if (K_top > kMaxTop) {
         qa::set_error("K_top_matches = %d > %d not supported", K_top, kMaxTop);
         return QA_ERR_UNSUPPORTED;
     }
-    const Geometry geo = pick_geometry(pn->K);
+    const Geometry geo = pick_geometry(pn->K, f64);
     if (geo.NT == 0) {
-        qa::set_error("K = %d exceeds the register-resident capacity (98304 haplotypes) of the full-pass kernels", pn->K);
+        qa::set_error("K = %d exceeds the register-resident capacity (%d haplotypes) of the %s full-pass kernels", pn->K,
+                      f64 ? 57344 : 98304, f64 ? "fp64 ranking" : "fp32");
         return QA_ERR_UNSUPPORTED;
     }
+    const size_t es = f64 ? 8 : 4;
+    if (f64)
+        for (int p = 0; p < P; p++)
+            if (h_flags[p] & 15) throw std::runtime_error("fp64 ranking passes carry no dosage / gamma / beta outputs");
     QA_HIP(hipSetDevice(pn->device));
     if (!pn->scratch) pn->scratch = new qa_panel::Scratch(&pn->arena);
     auto &S = *pn->scratch;
@@ -947,17 +1356,17 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     S.flags.upload(h_flags, P, st);
     S.alpha_slot.ensure((size_t)P * G);
     S.alpha_slot.upload(slot.data(), (size_t)P * G, st);
-    S.emat.ensure((size_t)P * G * kMaxRow);
+    S.emat.ensure((size_t)P * G * kMaxRow * es);
     S.escale0.ensure(P);
-    S.esp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1));
+    S.esp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1) * es);
     S.gsp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1));
-    S.alpha.ensure((size_t)P * alpha_stride);
+    S.alpha.ensure((size_t)P * alpha_stride * es);
     S.c.ensure((size_t)P * G);
     S.mg.ensure((size_t)P * G * kMaxRow);
     S.dosage.ensure((size_t)P * T);
-    if (any_gamma) S.gamma.ensure((size_t)P * G * Kq);
-    if (any_beta) S.beta.ensure((size_t)P * G * Kq);
-    if (any_top) S.beta_thin.ensure((size_t)P * n_thin * Kq);
+    if (any_gamma) S.gamma.ensure((size_t)P * G * Kq * es);
+    if (any_beta) S.beta.ensure((size_t)P * G * Kq * es);
+    if (any_top) S.beta_thin.ensure((size_t)P * n_thin * Kq * es);
     int top_cap = 64;
     S.top_cnt.ensure(std::max<size_t>((size_t)P * std::max(n_thin, 1), 1));
 
@@ -975,24 +1384,11 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.beta_thin = any_top ? S.beta_thin.p : nullptr;
 
     QA_HIP(hipEventRecord(S.ev[0], st));
-    hipLaunchKernelGGL(k_emat, dim3(G, P), dim3(256), 0, st, prm);
+    if (f64) hipLaunchKernelGGL(k_emat<double>, dim3(G, P), dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL(k_emat<float>, dim3(G, P), dim3(256), 0, st, prm);
     QA_HIP(hipGetLastError());
     QA_HIP(hipEventRecord(S.ev[1], st));
-    switch (geo.NCH) {
-#ifndef QA_FAST_BUILD
-        case 1: launch_fb<1, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 3: launch_fb<3, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 4: launch_fb<4, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 5: launch_fb<5, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 6: launch_fb<6, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 8: launch_fb<8, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 10: launch_fb<10, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 12: launch_fb<12, 512>(prm, geo.NT, st, S.ev[2]); break;
-#endif
-        case 2: launch_fb<2, 512>(prm, geo.NT, st, S.ev[2]); break;
-        case 7: launch_fb<7, 512>(prm, geo.NT, st, S.ev[2]); break;
-        default: throw std::runtime_error("geometry not built");
-    }
+    launch_fb_any(geo, prm, st, S.ev[2]);
     QA_HIP(hipEventRecord(S.ev[3], st));
     hipLaunchKernelGGL(k_dosage, dim3(G, P), dim3(256), 0, st, prm);
     QA_HIP(hipGetLastError());
@@ -1001,9 +1397,10 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         prm.top_cap = top_cap;
         prm.truncate_lists = out.truncate_lists ? 1 : 0;
         S.top_idx.ensure((size_t)P * n_thin * top_cap);
-        S.top_val.ensure((size_t)P * n_thin * top_cap);
+        S.top_val.ensure((size_t)P * n_thin * top_cap * es);
         prm.top_cnt = S.top_cnt.p; prm.top_idx = S.top_idx.p; prm.top_val = S.top_val.p;
-        hipLaunchKernelGGL(k_topk, dim3(n_thin, P), dim3(256), 0, st, prm, geo.NT);
+        if (f64) hipLaunchKernelGGL(k_topk<double>, dim3(n_thin, P), dim3(256), 0, st, prm, geo.NT);
+        else hipLaunchKernelGGL(k_topk<float>, dim3(n_thin, P), dim3(256), 0, st, prm, geo.NT);
         QA_HIP(hipGetLastError());
         cnt.resize((size_t)P * n_thin);
         S.top_cnt.download(cnt.data(), cnt.size(), st);
@@ -1023,14 +1420,15 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     QA_HIP(hipEventElapsedTime(&ms, S.ev[0], S.ev[4]));
     g_timing[4] = ms;
     {
-        // algorithmic HBM bytes of this launch set: per cell 1 B code + 4 B alpha on
-        // every stored column, forward (store) and backward (load) alike
+        // algorithmic HBM bytes of this launch set: per cell 1 B code + one state element
+        // (4 B, or 8 B in the fp64 ranking passes) on every stored column, forward (alpha) and backward
+        // (alpha re-read in dosage passes, beta store at thinned grids) alike
         double cells_all = 0, cells_thin = 0;
         for (int p = 0; p < P; p++) {
             if (h_flags[p] & 15) cells_all += (double)K * G; else cells_thin += (double)K * G;
         }
         const double frac = G > 0 ? (double)n_thin / G : 0;
-        const double per_dir = cells_all * 5.0 + cells_thin * (1.0 + 4.0 * frac);
+        const double per_dir = cells_all * (1.0 + es) + cells_thin * (1.0 + es * frac);
         qa::profile_add(qa::PK_EMAT, g_timing[0], 0);
         qa::profile_add(qa::PK_FWD, g_timing[1], per_dir);
         qa::profile_add(qa::PK_BWD, g_timing[2], per_dir);
@@ -1042,13 +1440,18 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     if (out.dosage) {
         for (int p = 0; p < P; p++)
             if (h_flags[p] & 1)
-                QA_HIP(hipMemcpyAsync(out.dosage + (size_t)p * T, S.dosage.p + (size_t)p * T, sizeof(double) * T,
+                QA_HIP(hipMemcpyAsync(out.dosage + (size_t)(out.dosage_rows ? out.dosage_rows[p] : p) * T,
+                                      S.dosage.p + (size_t)p * T, sizeof(double) * T,
                                       hipMemcpyDeviceToHost, st));
     }
-    auto unpermute_to_host = [&](const float *src, int cols, double *dst) {
+    auto unpermute_to_host = [&](const char *base, size_t elem_off, int cols, double *dst) {
         S.unperm.ensure((size_t)K * cols);
-        hipLaunchKernelGGL(k_unpermute, dim3((K + 255) / 256, cols), dim3(256), 0, st, src, S.unperm.p, K, Kq,
-                           geo.NT, cols, (size_t)K);
+        if (f64)
+            hipLaunchKernelGGL(k_unpermute<double>, dim3((K + 255) / 256, cols), dim3(256), 0, st,
+                               reinterpret_cast<const double *>(base) + elem_off, S.unperm.p, K, Kq, geo.NT, cols, (size_t)K);
+        else
+            hipLaunchKernelGGL(k_unpermute<float>, dim3((K + 255) / 256, cols), dim3(256), 0, st,
+                               reinterpret_cast<const float *>(base) + elem_off, S.unperm.p, K, Kq, geo.NT, cols, (size_t)K);
         QA_HIP(hipGetLastError());
         S.unperm.download(dst, (size_t)K * cols, st);
         QA_HIP(hipStreamSynchronize(st));
@@ -1056,25 +1459,25 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     if (P == 1) {
         if (out.alphaHat_t) {
             if (h_flags[0] & 15) {
-                unpermute_to_host(S.alpha.p, G, out.alphaHat_t);
+                unpermute_to_host(S.alpha.p, 0, G, out.alphaHat_t);
             } else {
                 // only column 0 and the thinned columns exist (reference-single.cpp:2264-2268)
                 std::vector<double> col(K);
                 for (int g = 0; g < G; g++) {
                     const int sl = slot[g];
                     if (sl < 0) continue;
-                    unpermute_to_host(S.alpha.p + (size_t)sl * Kq, 1, col.data());
+                    unpermute_to_host(S.alpha.p, (size_t)sl * Kq, 1, col.data());
                     memcpy(out.alphaHat_t + (size_t)g * K, col.data(), sizeof(double) * K);
                 }
             }
         }
-        if (out.gamma_t && any_gamma) unpermute_to_host(S.gamma.p, G, out.gamma_t);
-        if (out.betaHat_t && any_beta) unpermute_to_host(S.beta.p, G, out.betaHat_t);
+        if (out.gamma_t && any_gamma) unpermute_to_host(S.gamma.p, 0, G, out.gamma_t);
+        if (out.betaHat_t && any_beta) unpermute_to_host(S.beta.p, 0, G, out.betaHat_t);
         if (out.gammaSmall_t && any_gamma) {
             std::vector<double> col(K);
             for (int g = 0; g < G; g++) {
                 if (thin_col_h[g] < 0) continue;
-                unpermute_to_host(S.gamma.p + (size_t)g * Kq, 1, col.data());
+                unpermute_to_host(S.gamma.p, (size_t)g * Kq, 1, col.data());
                 if (out.gamma_small_unscaled && g < G - 1)
                     for (int k = 0; k < K; k++) col[k] /= pn->h_sigma[g];
                 memcpy(out.gammaSmall_t + (size_t)thin_col_h[g] * K, col.data(), sizeof(double) * K);
@@ -1086,19 +1489,26 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     if (any_top && out.lists) {
         const size_t n = (size_t)P * n_thin;
         std::vector<int32_t> idx(n * top_cap);
-        std::vector<float> val(n * top_cap);
+        std::vector<double> val(n * top_cap);
         S.top_idx.download(idx.data(), idx.size(), st);
-        S.top_val.download(val.data(), val.size(), st);
-        QA_HIP(hipStreamSynchronize(st));
+        if (f64) {
+            QA_HIP(hipMemcpyAsync(val.data(), S.top_val.p, val.size() * 8, hipMemcpyDeviceToHost, st));
+            QA_HIP(hipStreamSynchronize(st));
+        } else {
+            std::vector<float> v32(val.size());
+            QA_HIP(hipMemcpyAsync(v32.data(), S.top_val.p, v32.size() * 4, hipMemcpyDeviceToHost, st));
+            QA_HIP(hipStreamSynchronize(st));
+            for (size_t i = 0; i < val.size(); i++) val[i] = v32[i];
+        }
         for (size_t i = 0; i < n; i++) {
-            std::vector<std::pair<int32_t, float>> tmp;
+            std::vector<std::pair<int32_t, double>> tmp;
             const int nq = std::min<int>(cnt[i], top_cap);
             tmp.reserve(nq);
             for (int q = 0; q < nq; q++) tmp.emplace_back(idx[i * top_cap + q], val[i * top_cap + q]);
             if (!out.order_by_value) {
                 std::sort(tmp.begin(), tmp.end());  // ascending k, the reference's emission order
             } else if (nq > 64) {                    // (k_topk orders lists of up to 64 entries itself)
-                std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) {
+                std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) {
                     return a.second > b.second || (a.second == b.second && a.first < b.first);
                 });
             }
@@ -1120,7 +1530,7 @@ int qa_last_fullpass_timing_ms(double out[5]) {
 }
 
 // pack best-haps lists into the caller's CSR arrays
-static int pack_lists(const std::vector<std::vector<std::pair<int32_t, float>>> &lists, int32_t *best_ptr,
+static int pack_lists(const std::vector<std::vector<std::pair<int32_t, double>>> &lists, int32_t *best_ptr,
                       int32_t *best_idx, double *best_val, int64_t best_cap) {
     if (!best_ptr) return QA_OK;
     int64_t total = 0;
@@ -1171,21 +1581,43 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         out.gamma_t = o->return_gamma_t ? gamma_t : nullptr;
         out.gammaSmall_t = o->return_gammaSmall_t ? gammaSmall_t : nullptr;
         out.gamma_small_unscaled = !o->return_gamma_t;
-        std::vector<std::vector<std::pair<int32_t, float>>> lists;
-        if (o->get_best_haps_from_thinned_sites) out.lists = &lists;
-        {
-            QA_HIP(hipSetDevice(panel->device));
-            const Geometry geo1 = pick_geometry(panel->K);
+        std::vector<std::vector<std::pair<int32_t, double>>> lists;
+        QA_HIP(hipSetDevice(panel->device));
+        int nt = 0;
+        for (int g = 0; g < G; g++) nt = std::max(nt, thin[g] + 1);
+        const bool want_lists = o->get_best_haps_from_thinned_sites != 0;
+        const int K_top = want_lists ? o->K_top_matches : 0;
+        auto plan = [&](bool f64, int32_t flags) {
+            const Geometry geo1 = pick_geometry(panel->K, f64);
             if (geo1.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
-            int nt = 0;
-            for (int g = 0; g < G; g++) nt = std::max(nt, thin[g] + 1);
-            const size_t need = pass_bytes(panel, geo1, nt, (f & 15) != 0, (f & 4) != 0, (f & 8) != 0, false) +
+            const size_t need = pass_bytes(panel, geo1, nt, (flags & 15) != 0, (flags & 4) != 0, (flags & 8) != 0, false) +
                                 (size_t)panel->K * G * 8 /* un-permute staging */;
             plan_chunk(panel, need, 1);
+        };
+        int st;
+        if (want_lists && panel->rank_fp64) {
+            // the best-haplotype lists come from a pass with fp64 state, so that their membership and order are
+            // the reference's; every other output comes from the fp32 pass
+            if (only_thin) {
+                out.lists = &lists;
+                plan(true, 0);
+                st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, true);
+            } else {
+                plan(false, f);
+                st = run_passes(panel, 1, gl, &f, thin.data(), 0, o->normalize_emissions, out, false);
+                if (st != QA_OK) return st;
+                BatchOut out2;
+                out2.lists = &lists;
+                const int32_t f0 = 0;
+                plan(true, 0);
+                st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, true);
+            }
+        } else {
+            if (want_lists) out.lists = &lists;
+            plan(false, f);
+            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, false);
         }
-        int st = run_passes(panel, 1, gl, &f, thin.data(),
-                            o->get_best_haps_from_thinned_sites ? o->K_top_matches : 0, o->normalize_emissions, out);
-        if (st != QA_OK || !o->get_best_haps_from_thinned_sites) return st;
+        if (st != QA_OK || !want_lists) return st;
         return pack_lists(lists, best_ptr, best_idx, best_val, best_cap);
     });
 }
@@ -1204,24 +1636,46 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
         // chunk the passes so that the alpha checkpoints fit in HBM (K = 50 000, G = 2 000: 0.4 GB per dosage
         // pass, 0.08 GB per thin pass); chunks are homogeneous so that every pass of a chunk has the same footprint
         QA_HIP(hipSetDevice(panel->device));
-        const Geometry geo = pick_geometry(panel->K);
-        if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
+        const bool exact = panel->rank_fp64 && K_top_matches > 0;
+        const Geometry geo = pick_geometry(panel->K, false), geo64 = pick_geometry(panel->K, true);
+        if (geo.NT == 0 || (exact && geo64.NT == 0))
+            throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
         const int G = panel->G, T = panel->T;
         int n_thin = 0;
         for (int g = 0; g < G; g++) n_thin = std::max(n_thin, gammaSmall_cols_to_get[g] + 1);
-        std::vector<std::vector<std::pair<int32_t, float>>> lists;
+        std::vector<std::vector<std::pair<int32_t, double>>> lists;
+        std::vector<int32_t> zeros(n_pass, 0);
         int done = 0;
         int status = QA_OK;
         while (done < n_pass && status == QA_OK) {
             const bool dos = f[done] != 0;
             int run = 0;
             while (done + run < n_pass && (f[done + run] != 0) == dos) run++;
-            const int n = plan_chunk(panel, pass_bytes(panel, geo, n_thin, dos, false, false, false), run);
-            BatchOut out;
-            out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
-            out.lists = &lists;
-            status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, gammaSmall_cols_to_get,
-                                K_top_matches, 1, out);
+            if (!exact) {
+                const int n = plan_chunk(panel, pass_bytes(panel, geo, n_thin, dos, false, false, false), run);
+                BatchOut out;
+                out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
+                out.lists = &lists;
+                status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, gammaSmall_cols_to_get,
+                                    K_top_matches, 1, out);
+                done += n;
+                continue;
+            }
+            // fp64-state ranking passes for the lists; dosage passes (fp32 state) separately
+            int n = plan_chunk(panel, pass_bytes(panel, geo64, n_thin, false, false, false, false), run);
+            if (dos) n = std::min(n, plan_chunk(panel, pass_bytes(panel, geo, 0, true, false, false, false), run));
+            if (dos) {
+                BatchOut out;
+                out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
+                std::vector<int32_t> no_thin(G, -1);
+                status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, no_thin.data(), 0, 1, out, false);
+                if (status != QA_OK) break;
+                plan_chunk(panel, pass_bytes(panel, geo64, n_thin, false, false, false, false), n);
+            }
+            BatchOut out2;
+            out2.lists = &lists;
+            status = run_passes(panel, n, gl + (size_t)done * T * 2, zeros.data(), gammaSmall_cols_to_get, K_top_matches, 1,
+                                out2, true);
             done += n;
         }
         if (status != QA_OK) return status;
@@ -1233,7 +1687,8 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
 int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
                             const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
                             const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
-                            const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double minGLValue,
+                            const int32_t *want_top, const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches,
+                            double minGLValue,
                             double *dosage, int32_t top_width, int32_t *top_idx, float *top_val, int32_t *top_cnt) {
     if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
     if (!panel || n_chain <= 0 || n_label < 1 || n_label > 3 || n_sample <= 0 || !chain_sample || !read_off || !read_ptr ||
@@ -1285,14 +1740,29 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
             hoff[c + 1] = hoff[c] + (read_off[s + 1] - read_off[s]);
         }
         const int P = n_chain * n_label;
-        std::vector<int32_t> ps(P), pl(P), ph(P), flags(P);
-        for (int c = 0; c < n_chain; c++)
-            for (int l = 0; l < n_label; l++) {
-                ps[c * n_label + l] = chain_sample[c];
-                pl[c * n_label + l] = l + 1;
-                ph[c * n_label + l] = hoff[c];
-                flags[c * n_label + l] = want_dosage[c] ? 1 : 0;
+        // Work groups of passes (pass = chain x label).  With fp64 ranking (the default) the dosage comes from a pass
+        // with fp32 state and the best-haplotype lists from a pass with fp64 state; a chain that wants both runs both.
+        struct Group { std::vector<int32_t> ids; int32_t flag; int K_top; bool f64; };
+        std::vector<Group> groups;
+        {
+            const bool exact = panel->rank_fp64;
+            Group gd{{}, 1, 0, false}, gdt{{}, 1, K_top_matches, false}, gt{{}, 0, K_top_matches, exact};
+            for (int c = 0; c < n_chain; c++) {
+                const bool dos = want_dosage[c] != 0, top = K_top_matches > 0 && (!want_top || want_top[c] != 0);
+                for (int l = 0; l < n_label; l++) {
+                    const int id = c * n_label + l;
+                    if (exact) {
+                        if (dos) gd.ids.push_back(id);
+                        if (top) gt.ids.push_back(id);
+                    } else {
+                        if (dos && top) gdt.ids.push_back(id);
+                        else if (dos) gd.ids.push_back(id);
+                        else if (top) gt.ids.push_back(id);
+                    }
+                }
             }
+            for (Group *g : {&gd, &gdt, &gt}) if (!g->ids.empty()) groups.push_back(std::move(*g));
+        }
         // eps tables from the host libm (convertScaledBQtoProbs, as copied-from-stitch.cpp:166-175)
         std::vector<double> tabs(4 * 256);
         for (int q = 0; q < 256; q++) {
@@ -1302,48 +1772,67 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
         qa::DBuf<int32_t> d_ps(P), d_pl(P), d_ph(P), d_sp(snp_ptr.size()), d_eo(n_sample), d_er(ent_read.size()),
             d_eb(ent_bq.size()), d_H(std::max(hoff[n_chain], 1));
         qa::DBuf<double> d_tabs(tabs.size());
-        d_ps.upload(ps.data(), P, st); d_pl.upload(pl.data(), P, st); d_ph.upload(ph.data(), P, st);
         d_sp.upload(snp_ptr.data(), snp_ptr.size(), st); d_eo.upload(ent_off.data(), n_sample, st);
         d_er.upload(ent_read.data(), ent_read.size(), st); d_eb.upload(ent_bq.data(), ent_bq.size(), st);
         d_H.upload(H, hoff[n_chain], st); d_tabs.upload(tabs.data(), tabs.size(), st);
 
-        const Geometry geo = pick_geometry(panel->K);
-        if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
-        int done = 0, status = QA_OK;
-        std::vector<std::vector<std::pair<int32_t, float>>> lists;
-        while (done < P && status == QA_OK) {
-            const bool dos = flags[done] != 0;
-            int run = 0;
-            while (done + run < P && (flags[done + run] != 0) == dos) run++;
-            const int n = plan_chunk(panel, pass_bytes(panel, geo, n_thin, dos, false, false, true), run);
-            S.gl.ensure((size_t)n * T * 2);
-            GlParams gp{};
-            gp.P = n; gp.T = T; gp.pass_sample = d_ps.p + done; gp.pass_label = d_pl.p + done; gp.pass_hoff = d_ph.p + done;
-            gp.snp_ptr = d_sp.p; gp.ent_off = d_eo.p; gp.ent_read = d_er.p; gp.ent_bq = d_eb.p; gp.H = d_H.p;
-            gp.pR_tab = d_tabs.p; gp.pA_tab = d_tabs.p + 512; gp.minGLValue = minGLValue; gp.gl = S.gl.p;
-            hipLaunchKernelGGL(k_make_gl, dim3((T + 255) / 256, n), dim3(256), 0, st, gp);
-            QA_HIP(hipGetLastError());
-            BatchOut out;
-            out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
-            lists.clear();
-            out.lists = &lists;
-            out.order_by_value = true;
-            out.truncate_lists = true;
-            std::vector<int32_t> true_cnt;
-            out.true_counts = &true_cnt;
-            status = run_passes(panel, n, nullptr, flags.data() + done, gammaSmall_cols_to_get, K_top_matches, 1, out);
-            if (status != QA_OK) break;
-            // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
-            for (int i = 0; i < n * n_thin; i++) {
-                const auto &l = lists[i];
-                const size_t o = ((size_t)done * n_thin + i);
-                if (top_cnt) top_cnt[o] = true_cnt[i];
-                for (int q = 0; q < top_width; q++) {
-                    if (top_idx) top_idx[o * top_width + q] = q < (int)l.size() ? l[q].first : -1;
-                    if (top_val) top_val[o * top_width + q] = q < (int)l.size() ? l[q].second : 0.f;
-                }
+        const size_t n_out = (size_t)P * n_thin;
+        if (top_cnt) std::fill(top_cnt, top_cnt + n_out, 0);
+        if (top_idx) std::fill(top_idx, top_idx + n_out * top_width, -1);
+        if (top_val) std::fill(top_val, top_val + n_out * top_width, 0.f);
+
+        int status = QA_OK;
+        std::vector<std::vector<std::pair<int32_t, double>>> lists;
+        std::vector<int32_t> no_thin(G, -1);
+        for (const Group &grp : groups) {
+            const Geometry geo = pick_geometry(panel->K, grp.f64);
+            if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
+            const int n_grp = (int)grp.ids.size();
+            std::vector<int32_t> ps(n_grp), pl(n_grp), ph(n_grp), flags(n_grp, grp.flag);
+            for (int i = 0; i < n_grp; i++) {
+                const int c = grp.ids[i] / n_label, l = grp.ids[i] % n_label;
+                ps[i] = chain_sample[c]; pl[i] = l + 1; ph[i] = hoff[c];
             }
-            done += n;
+            QA_HIP(hipStreamSynchronize(st));   // the previous group's launches read d_ps / d_pl / d_ph
+            d_ps.upload(ps.data(), n_grp, st); d_pl.upload(pl.data(), n_grp, st); d_ph.upload(ph.data(), n_grp, st);
+            const int nt_grp = grp.K_top > 0 ? n_thin : 0;
+            int done = 0;
+            while (done < n_grp && status == QA_OK) {
+                const int n = plan_chunk(panel, pass_bytes(panel, geo, nt_grp, grp.flag != 0, false, false, true), n_grp - done);
+                S.gl.ensure((size_t)n * T * 2);
+                GlParams gp{};
+                gp.P = n; gp.T = T; gp.pass_sample = d_ps.p + done; gp.pass_label = d_pl.p + done; gp.pass_hoff = d_ph.p + done;
+                gp.snp_ptr = d_sp.p; gp.ent_off = d_eo.p; gp.ent_read = d_er.p; gp.ent_bq = d_eb.p; gp.H = d_H.p;
+                gp.pR_tab = d_tabs.p; gp.pA_tab = d_tabs.p + 512; gp.minGLValue = minGLValue; gp.gl = S.gl.p;
+                hipLaunchKernelGGL(k_make_gl, dim3((T + 255) / 256, n), dim3(256), 0, st, gp);
+                QA_HIP(hipGetLastError());
+                BatchOut out;
+                out.dosage = grp.flag ? dosage : nullptr;
+                out.dosage_rows = grp.ids.data() + done;
+                lists.clear();
+                out.lists = &lists;
+                out.order_by_value = true;
+                out.truncate_lists = true;
+                std::vector<int32_t> true_cnt;
+                out.true_counts = &true_cnt;
+                status = run_passes(panel, n, nullptr, flags.data() + done, grp.K_top > 0 ? gammaSmall_cols_to_get : no_thin.data(),
+                                    grp.K_top, 1, out, grp.f64);
+                if (status != QA_OK) break;
+                // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
+                if (grp.K_top > 0) {
+                    for (int i = 0; i < n * n_thin; i++) {
+                        const auto &l = lists[i];
+                        const size_t o = (size_t)grp.ids[done + i / n_thin] * n_thin + (i % n_thin);
+                        if (top_cnt) top_cnt[o] = true_cnt[i];
+                        for (int q = 0; q < top_width && q < (int)l.size(); q++) {
+                            if (top_idx) top_idx[o * top_width + q] = l[q].first;
+                            if (top_val) top_val[o * top_width + q] = (float)l[q].second;
+                        }
+                    }
+                }
+                done += n;
+            }
+            if (status != QA_OK) break;
         }
         return status;
     });

@@ -208,6 +208,15 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
 
 void qa_panel_destroy(qa_panel_t *panel) { delete panel; }
 
+int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits) {
+    if (!panel || (bits != 32 && bits != 64)) {
+        qa::set_error("qa_panel_set_ranking_precision: bits must be 32 or 64");
+        return QA_ERR_INVALID;
+    }
+    panel->rank_fp64 = bits == 64;
+    return QA_OK;
+}
+
 int qa_Rcpp_make_gl_bound(double *gl, double minGLValue, const int32_t *to_fix, int32_t n_to_fix) {
     // reference-single.cpp:68-94; O(n_to_fix) host arithmetic, not worth a launch
     if (!gl || (n_to_fix > 0 && !to_fix)) return QA_ERR_INVALID;

@@ -24,6 +24,7 @@ struct qa_panel {
     qa::DBuf<double> sigma;     // G - 1
     qa::DBuf<double> IE;        // only when the caller's distinctHapsIE is not the (B, eps) expansion
     bool ie_derived = true;
+    bool rank_fp64 = true;      // best-haplotype lists from fp64-state passes (qa_panel_set_ranking_precision)
     int n_special = 0;
     std::vector<double> h_sigma, h_tm1;  // transMatRate_t rows 0 and 1 as passed
     std::vector<int32_t> h_sp_off;

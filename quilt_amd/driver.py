@@ -344,9 +344,13 @@ class Driver:
             ch.read_labels = res["double_list_of_ending_read_labels"][0][0].astype(np.int32)
         t3 = time.perf_counter()
         self.timing["host"] += t3 - t2
+        # The reference asks for the best haplotypes on every call (functions.R:738-743), but the selection made from
+        # them is read again only by a later round of the same chain or -- the last chain's final selection -- by the
+        # phasing rounds (which_haps_to_use carried over): skip the lists nobody reads.
+        want_top = [i_it < P.n_seek_its or (not phasing and ch.i_chain == P.nGibbsSamples) for ch in chains]
         dosages, top, top_cnt = self.backend.fullpass_reads_batch(
             samples, [ch.i_sample for ch in chains], [ch.read_labels for ch in chains],
-            [return_dosage] * len(chains), self.cols, P.K_top_matches, P.minGLValue, self.top_width)
+            [return_dosage] * len(chains), want_top, self.cols, P.K_top_matches, P.minGLValue, self.top_width)
         t4 = time.perf_counter()
         self.timing["fullpass"] += t4 - t3
         for ci, ch in enumerate(chains):
@@ -357,6 +361,8 @@ class Driver:
                 ch.hap = [d[0], d[1]]
             else:
                 ch.hap = [np.zeros(T), np.zeros(T)]
+            if not want_top[ci]:
+                continue
             prev_sel = ch.which_haps_to_use[ch.rng.permutation(len(ch.which_haps_to_use))[: P.Ksubset - P.Knew]]
             sel = everything_select_good_haps_dense(P.Knew, P.K_top_matches, top[ci].astype(np.int64) + 1, prev_sel, K, ch.rng)
             ch.which_haps_to_use = np.concatenate([prev_sel, sel]).astype(np.int32)
@@ -456,9 +462,10 @@ class HipBackend:
                          for j in range(n_thin)])
         return list(dosage), best
 
-    def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, cols, K_top_matches, minGLValue, top_width):
+    def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, want_top, cols, K_top_matches, minGLValue,
+                             top_width):
         """impute_using_everything for every chain: returns dosage [n_chain, 2, T], the ordered top matches
-        [n_chain, 2, n_thin, top_width] (0-based, -1 padded) and the full list lengths."""
+        [n_chain, 2, n_thin, top_width] (0-based, -1 padded; only for chains with want_top) and the full list lengths."""
         import ctypes as C
         from .native import check, lib, ptr
         lib().qa_fullpass_reads_batch.restype = C.c_int
@@ -476,12 +483,13 @@ class HipBackend:
         H = np.concatenate([np.asarray(h, dtype=np.int32) for h in labels])
         cs = np.ascontiguousarray(chain_sample, dtype=np.int32)
         wd = np.ascontiguousarray(want_dosage, dtype=np.int32)
+        wt = np.ascontiguousarray(want_top, dtype=np.int32)
         dosage = np.zeros((n_chain, 2, T)) if wd.any() else None
         top = np.full((n_chain, 2, n_thin, top_width), -1, dtype=np.int32)
         val = np.zeros((n_chain, 2, n_thin, top_width), dtype=np.float32)
         cnt = np.zeros((n_chain, 2, n_thin), dtype=np.int32)
         check(lib().qa_fullpass_reads_batch(self.dev.handle, C.c_int32(n_chain), C.c_int32(2), C.c_int32(n_sample), ptr(cs),
-                                            ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(cols),
+                                            ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(wt), ptr(cols),
                                             C.c_int32(K_top_matches), C.c_double(minGLValue), ptr(dosage),
                                             C.c_int32(top_width), ptr(top), ptr(val), ptr(cnt)))
         return dosage, top, cnt

@@ -44,7 +44,8 @@ class OracleBackend:
     def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):
         return [O.calculate_eMatRead_t_vs_haplotypes(s, h, maxDifferenceBetweenReads) for s, h in zip(samples, haps)]
 
-    def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, cols, K_top_matches, minGLValue, top_width):
+    def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, want_top, cols, K_top_matches, minGLValue,
+                             top_width):
         from quilt_amd.driver import make_gl_from_u_bq
         T = self.panel.nSNPs
         n_chain = len(chain_sample)
@@ -59,9 +60,10 @@ class OracleBackend:
                 sel = (per_base == l) & (s.bq != 0)
                 gl = make_gl_from_u_bq(s.u[sel], s.bq[sel], T, minGLValue, self.make_gl_bound)
                 r = O.haploid_dosage_versus_refs(self.panel, gl, cols, K_top_matches=K_top_matches,
-                                                 return_dosage=bool(want_dosage[c]), get_best_haps_from_thinned_sites=True)
+                                                 return_dosage=bool(want_dosage[c]),
+                                                 get_best_haps_from_thinned_sites=bool(want_top[c]))
                 dosage[c, l - 1] = r["dosage"]
-                for j, (idx, v) in enumerate(r["best_haps"]):
+                for j, (idx, v) in enumerate(r["best_haps"] if want_top[c] else []):
                     order = np.argsort(-v, kind="stable")      # everything_per_hap_rejig_haps (functions.R:2161-2170)
                     k = idx[order][:top_width]
                     top[c, l - 1, j, : len(k)] = k

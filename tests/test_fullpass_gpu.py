@@ -1,7 +1,9 @@
 """GPU parity: HIP full-panel forward/backward (through the C ABI) vs the fp64 CPU oracle.
 
-Tolerances (stated, fp32 device state vs fp64 oracle): dosage |diff| <= 2e-4 and r2 >= 0.99999;
-colSums(gamma) = 1 +- 1e-4; sum(log c) relative 1e-5; top-match values relative 2e-4.
+Tolerances (stated).  Dosage / gamma / alpha / beta / c come from fp32 device state: dosage |diff| <= 2e-4 and
+r2 >= 0.99999; colSums(gamma) = 1 +- 1e-4; sum(log c) relative 1e-5.  The best-haplotype lists come from the fp64-state
+ranking passes and must be identical to the oracle's (same haplotypes, values to 1e-9); in the optional fp32 ranking
+mode they agree up to rounding at the threshold (values relative 2e-4).
 """
 import numpy as np
 import pytest
@@ -133,3 +135,41 @@ def test_batch_matches_single(medium_panel, oracle):
         got = [dict(top_matches=bidx[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]],
                     top_matches_values=bval[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]]) for j in range(n_thin)]
         check_best_haps(got, ref["best_haps"])
+
+
+def test_fp32_ranking_mode(medium_panel, oracle):
+    """qa_panel_set_ranking_precision(32): lists from the fp32-state pass, equal up to rounding at the threshold."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    dev.set_ranking_precision(32)
+    sample = make_synthetic_sample(panel, seed=77, n_reads=800)
+    cols = thin_cols(panel.nGrids, every=10)
+    gl = label_gl(panel, sample, 1, oracle)
+    ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, get_best_haps_from_thinned_sites=True)
+    got = _run_gpu(dev, gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True)
+    assert np.abs(got["dosage"] - ref["dosage"]).max() <= DOSAGE_ATOL
+    check_best_haps(got["best_haps_stuff_list"], ref["best_haps"], exact=False)
+    dev.close()
+
+
+@pytest.mark.parametrize("K", [50000, 30011])
+def test_production_k_geometry(oracle, K):
+    """K = 50 000 (BASELINE.json configs[1]) on a short region: the launch geometries of the real workload
+    (fp32: 448 threads x 7 chunks; fp64 ranking: 256 threads x 10 register + 3 LDS chunks) against the oracle;
+    K = 30 011 adds a chunk that straddles K."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=K, nSNPs=640, seed=4242, nMaxDH=255)
+    dev = DevicePanel(panel)
+    sample = make_synthetic_sample(panel, seed=9, n_reads=200)
+    cols = thin_cols(panel.nGrids, every=4)
+    for label in (1, 2):
+        gl = label_gl(panel, sample, label, oracle)
+        ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, get_best_haps_from_thinned_sites=True, always_normalize=True)
+        got = _run_gpu(dev, gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True)
+        assert np.abs(got["dosage"] - ref["dosage"]).max() <= DOSAGE_ATOL
+        np.testing.assert_allclose(got["c"], ref["c"], rtol=1e-4)
+        check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
+    dev.close()

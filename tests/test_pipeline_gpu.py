@@ -2,8 +2,9 @@
 phasing) on the HIP backend vs the same driver on the fp64 CPU oracle, same seeds.
 
 Bar (BASELINE.json): dosage r2 >= 0.999 against the CPU path; genotype probabilities sum to 1.
-Read labels are compared too: they are identical as long as the fp32 full-panel pass ranks the top
-haplotypes like the fp64 oracle does (near-ties can reorder them; the r2 bar is what must hold).
+The chains themselves must coincide: the Gibbs sampler is fp64 with the same uniforms, and the best-haplotype lists that
+choose every next small panel come from fp64-state ranking passes, so the consensus read labels are identical and the
+dosages differ only by the fp32 rounding of the dosage passes (|diff| <= 1e-4 asserted, ~2e-6 observed).
 """
 import numpy as np
 import pytest
@@ -37,9 +38,6 @@ def _medium_run(panel):
     return _CACHE["run"]
 
 
-@pytest.mark.xfail(strict=False, reason="fp32 state in the full-panel pass ranks near-tied haplotypes differently from the "
-                   "fp64 CPU path, so the re-selected haplotype subsets and then the Gibbs chains drift apart "
-                   "(DESIGN.md 4.4); needs fp64 state in k_fwd / k_bwd")
 def test_pipeline_r2_bar_vs_cpu_path(medium_panel):
     """BASELINE.json: dosage r2 vs the CPU path >= 0.999 for every sample."""
     samples, got, ref = _medium_run(medium_panel)
@@ -53,7 +51,9 @@ def test_pipeline_matches_oracle(medium_panel):
     for i, (g, r) in enumerate(zip(got, ref)):
         assert g.nDosage == r.nDosage == 3
         np.testing.assert_allclose(g.gp_t.sum(axis=0), 1.0, atol=2e-3)   # check_quilt_output (test-drivers.R:38-61)
-        assert r2(g.dosage, r.dosage) >= 0.97, (i, r2(g.dosage, r.dosage))   # same MCMC target, possibly diverged chains
+        assert np.array_equal(g.read_labels, r.read_labels)
+        assert np.abs(g.dosage - r.dosage).max() <= 1e-4
+        assert np.abs(g.phasing_haps - r.phasing_haps).max() <= 1e-4
         truth = samples[i].truth_haps.sum(axis=0)
         assert r2(g.dosage, truth) >= 0.9 and abs(r2(g.dosage, truth) - r2(r.dosage, truth)) < 0.02
         same = np.array_equal(g.read_labels, r.read_labels)

@@ -22,16 +22,21 @@ def r2(a, b):
     return float(np.corrcoef(a, b)[0, 1] ** 2)
 
 
-def check_best_haps(gpu_list, oracle_list, rtol=2e-4):
-    """Top-match lists agree up to fp32 rounding of gamma around the threshold.
+def check_best_haps(gpu_list, oracle_list, rtol=2e-4, exact=True):
+    """Top-match lists of the HIP path vs the oracle's.
 
-    Every haplotype the oracle reports clearly above its threshold must be reported by the GPU path
-    and vice versa; values agree to ``rtol``.
+    exact (the default fp64 ranking passes): the same haplotypes in the same (ascending) order, values to 1e-9.
+    Otherwise (fp32 ranking mode): lists agree up to fp32 rounding of gamma around the threshold -- every haplotype the
+    oracle reports clearly above its threshold must be reported by the GPU path and vice versa; values agree to rtol.
     """
     assert len(gpu_list) == len(oracle_list)
     for got, (oi, ov) in zip(gpu_list, oracle_list):
         gi, gv = got["top_matches"], got["top_matches_values"]
         assert np.all(np.diff(gi) > 0), "top_matches must be ascending in k"
+        if exact:
+            assert np.array_equal(gi, oi)
+            np.testing.assert_allclose(gv, ov, rtol=1e-9, atol=1e-300)
+            continue
         thr = ov.min()
         sure = oi[ov > thr * (1 + 10 * rtol)]
         assert set(sure.tolist()) <= set(gi.tolist())
