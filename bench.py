@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 _CPU_PANEL = None
-KERNEL_NAMES = ["k_emat", "k_fwd", "k_bwd", "k_dosage+k_topk", "k_ematread", "k_gibbs", "k_happrobs"]
+KERNEL_NAMES = ["k_emat", "k_fwd", "k_bwd", "k_dosage+k_topk", "k_ematread", "k_gibbs", "k_happrobs", "k_fwd64", "k_bwd64"]
 
 
 def _cpu_worker(args):

@@ -51,7 +51,8 @@ int qa_set_device(int device);
 /* Per-kernel accumulators since the last reset, measured with HIP events on the launch stream
  * (replaces print_times(), copied-from-stitch.cpp:31-45).  kernel: 0 emission tables, 1 full-panel
  * forward, 2 full-panel backward, 3 dosage mat-vec + top-K, 4 read emissions, 5 Gibbs sweeps,
- * 6 hapProbs.  alg_bytes = algorithmic HBM bytes of those launches. */
+ * 6 hapProbs, 7 / 8 forward / backward of the fp64-state ranking passes.  alg_bytes = algorithmic HBM bytes of
+ * those launches. */
 int qa_profile_reset(void);
 int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_bytes);
 

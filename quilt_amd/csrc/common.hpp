@@ -19,7 +19,7 @@ void set_error(const char *fmt, ...);
 bool device_ready();
 
 // per-kernel accumulators (HIP-event time on the launch stream, launches, algorithmic HBM bytes)
-enum ProfileKernel { PK_EMAT = 0, PK_FWD, PK_BWD, PK_POST, PK_EMATREAD, PK_GIBBS, PK_HAPPROBS, PK_COUNT };
+enum ProfileKernel { PK_EMAT = 0, PK_FWD, PK_BWD, PK_POST, PK_EMATREAD, PK_GIBBS, PK_HAPPROBS, PK_FWD64, PK_BWD64, PK_COUNT };
 void profile_add(int kernel, double ms, double alg_bytes);
 
 struct HipError : std::runtime_error {

@@ -567,41 +567,82 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+// One wave-instruction: 64 lanes x 16 B, global (per-lane address) -> LDS (wave base in M0 + lane * 16).  Emitted as
+// inline asm on purpose: with the builtin the compiler treats every later LDS read as possibly aliasing the DMA in
+// flight and puts `s_waitcnt vmcnt(0)` in front of each, which serialises the grid on HBM latency.  The waits are
+// placed by hand instead (vm_wait): in-order vmcnt makes the compiler's own counts at worst stricter.  `after` is a
+// value the DMA must not overtake (the codes just read from the slot being refilled).
+// Source = wave-uniform base (SGPR pair) + per-lane byte offset (one VGPR shared by all chunks).
+// Both bases must be computed from wave-uniform values only (kernel arguments, blockIdx, the readfirstlane'd wave
+// index), so that they live in SGPRs.
+__device__ __forceinline__ void dma16(const void *gbase_uniform, uint32_t lane_off, uint32_t lds_wave_base, uint32_t after = 0) {
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    const uint64_t src = (uint64_t)(uintptr_t)gbase_uniform;
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(src >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)src);   // (the builtin returns int)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(dst), "v"(after), "s"(base)
+                 : "memory");
 }
+template <int N>
+__device__ __forceinline__ void vm_wait() {   // at most N vector-memory operations of this wave still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int kNT64 = 256;   // threads of the fp64 kernels: compile-time, so that chunk offsets are immediates
 
 struct Lds64 {
     double *etab;    // [2][256]
     double *red;     // [2][16]
     char *codes;     // [Kq]
     double2 *state;  // [NL][8][NT]
+    uint32_t base;   // LDS byte address of smem (uniform)
+    static constexpr uint32_t kCodesOff = 2 * kMaxRow * 8 + 2 * 16 * 8;
     __device__ __forceinline__ explicit Lds64(char *smem, int Kq) {
         etab = reinterpret_cast<double *>(smem);
         red = etab + 2 * kMaxRow;
-        codes = smem + 2 * kMaxRow * 8 + 2 * 16 * 8;
+        codes = smem + kCodesOff;
         state = reinterpret_cast<double2 *>(codes + Kq);
+        base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
     }
 };
 inline size_t lds64_bytes(int Kq, int NT, int NL) { return 2 * kMaxRow * 8 + 2 * 16 * 8 + (size_t)Kq + (size_t)NL * NT * 128; }
 
 // wave 0: DMA grid g's emission table into half `buf`
-__device__ __forceinline__ void dma_table(const double *emat, int g, double *etab, int buf, int t) {
-    if (t < 64) {   // 256 doubles = 2 x (64 lanes x 16 B)
-        dma16(emat + (size_t)g * kMaxRow + 2 * t, etab + buf * kMaxRow);
-        dma16(emat + (size_t)g * kMaxRow + 128 + 2 * t, etab + buf * kMaxRow + 128);
+__device__ __forceinline__ void dma_table(const double *emat, int g, const Lds64 &L, int buf, int wave, int lane) {
+    if (wave == 0) {   // 256 doubles = 2 x (64 lanes x 16 B)
+        dma16(emat + (size_t)g * kMaxRow, 16 * lane, L.base + buf * kMaxRow * 8);
+        dma16(emat + (size_t)g * kMaxRow + 128, 16 * lane, L.base + buf * kMaxRow * 8 + 1024);
     }
 }
-// refill chunk j's code slot with grid g's codes (this lane's 16 haplotypes)
-__device__ __forceinline__ void dma_codes(const PassParams &prm, int g, char *codes, int j, int NT, int t) {
-    const int k0 = (j * NT + t) * 16;
-    if (k0 < prm.K) dma16(prm.hm + (size_t)g * prm.Kp + k0, codes + (j * NT + (t & ~63)) * 16);
+// refill chunk j's code slot with grid g's codes (this lane's 16 haplotypes).  Unconditional (the row pitch Kp covers
+// whole chunk rows; padding codes are 0 and the padding state stays 0 whatever the code), so that every wave issues
+// exactly one DMA per chunk per grid and the hand-placed vmcnt waits can count them.
+__device__ __forceinline__ void dma_codes(const PassParams &prm, int g, const Lds64 &L, int j, int wave, int lane, uint32_t after) {
+    const uint32_t off = (uint32_t)(j * kNT64 + wave * 64) * 16;
+    dma16(prm.hm + (size_t)g * prm.Kp + off, lane * 16, L.base + Lds64::kCodesOff + off, after);
 }
 
 // One chunk of 16 emissions: x_i <- (x_i + addend) * table[code_i]; haplotypes with code 0 on a grid that has specials
 // are then multiplied by their own emission (table row 0 is 1 there; reference-single.cpp:1002-1042 / :1902-1964);
 // elements >= tail of the chunk straddling K are forced back to 0.  Returns the chunk's sum.
+// block_sum with a bare barrier (no fence: the only LDS traffic to publish is `buf` and wave 0's table DMA, both
+// waited for explicitly), so that the code DMAs in flight are not drained at every grid
+template <int TABLE_WAIT>
+__device__ __forceinline__ double block_sum64(double v, double *buf, int t, int nwaves) {
+    v = wave_sum(v);
+    if ((t & 63) == 0) buf[t >> 6] = v;
+    vm_wait<TABLE_WAIT>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    double s = 0;
+    for (int w = 0; w < nwaves; w++) s += buf[w];
+    return s;
+}
+
 template <bool ADD>
 __device__ __forceinline__ double emit_chunk(double (&x)[16], const uint4 &d, const double *et, double addend, bool has_sp,
                                              const PassParams &prm, const double *esp, int g, int k0, int tail) {
@@ -643,7 +684,9 @@ __global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
     constexpr int NCH = NR + NL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Lds64 L(smem, prm.Kq);
-    const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
+    const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int NT = kNT64, nwaves = NT >> 6;
     const int K = prm.K, G = prm.G;
     const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
     const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.n_special;
@@ -675,15 +718,15 @@ __global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NCH; j++) dma_codes(prm, 0, L.codes, j, NT, t);
-    dma_table(emat, 0, L.etab, 0, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < NCH; j++) dma_codes(prm, 0, L, j, wave, lane, 0);
+    dma_table(emat, 0, L, 0, wave, lane);
+    vm_wait<0>();
     __syncthreads();
 
     double inv_prev = 1.0;   // scaling of the previous grid, still owed by the LDS chunks
     for (int g = 0; g < G; g++) {
         const int buf = g & 1;
-        if (g + 1 < G) dma_table(emat, g + 1, L.etab, buf ^ 1, t);   // that half was last read in iteration g-1
+        if (g + 1 < G) dma_table(emat, g + 1, L, buf ^ 1, wave, lane);   // that half was last read in iteration g-1
         const double *et = L.etab + buf * kMaxRow;
         const bool has_sp = prm.sp_off[g + 1] > prm.sp_off[g];
         double sg = 0.0, sig = 1.0;
@@ -694,6 +737,8 @@ __global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
         double psum = 0;
         static_for<NCH>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
+            // this chunk's DMA of the previous iteration: NCH - 1 code DMAs (+ wave 0's table) were issued after it
+            vm_wait<NCH - 1>();
             const uint4 d = reinterpret_cast<const uint4 *>(L.codes)[j * NT + t];
             const double sj = ((valid >> j) & 1u) ? sg : 0.0;
             const int tail = (j == jstar) ? tail_star : 16;
@@ -713,11 +758,10 @@ __global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
 #pragma unroll
                 for (int q = 0; q < 8; q++) st[q * NT] = make_double2(x[2 * q], x[2 * q + 1]);
             }
-            if (g + 1 < G) dma_codes(prm, g + 1, L.codes, j, NT, t);   // the slot's codes are in registers / used
+            if (g + 1 < G) dma_codes(prm, g + 1, L, j, wave, lane, d.x);   // the slot's codes have been consumed
             __builtin_amdgcn_sched_barrier(0);
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs for grid g+1 have landed
-        const double A = block_sum(psum, L.red + buf * 16, t, nwaves);
+        const double A = block_sum64<NCH>(psum, L.red + buf * 16, t, nwaves);   // wave 0's table DMA precedes NCH code DMAs
         const double invA = 1.0 / A;
         if (t == 0) prm.c[(size_t)p * G + g] = (g == 0) ? invA * prm.escale0[p] : invA / sig;
         const int sl = slot[g];
@@ -752,7 +796,9 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
     constexpr int NCH = NR + NL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Lds64 L(smem, prm.Kq);
-    const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
+    const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int NT = kNT64, nwaves = NT >> 6;
     const int K = prm.K, G = prm.G;
     const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
     const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.n_special;
@@ -780,9 +826,9 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NCH; j++) dma_codes(prm, G - 1, L.codes, j, NT, t);
-    dma_table(emat, G - 1, L.etab, (G - 1) & 1, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int j = 0; j < NCH; j++) dma_codes(prm, G - 1, L, j, wave, lane, 0);
+    dma_table(emat, G - 1, L, (G - 1) & 1, wave, lane);
+    vm_wait<0>();
     __syncthreads();
 
     // the LDS chunks hold beta after the emission step; "+ add" and "* x" of that grid are applied when next read
@@ -792,13 +838,14 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
         double add = 0.0;
         if (g < G - 1) {
             const int buf = (g + 1) & 1;             // grid g+1's table: the emission side
-            if (g > 0) dma_table(emat, g, L.etab, buf ^ 1, t);   // for iteration g-1; that half was last read in g+1
+            if (g > 0) dma_table(emat, g, L, buf ^ 1, wave, lane);   // for iteration g-1; that half was last read in g+1
             sig = prm.sigma[g];
             const double *et = L.etab + buf * kMaxRow;
             const bool has_sp = prm.sp_off[g + 2] > prm.sp_off[g + 1];
             double psum = 0;
             static_for<NCH>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
+                vm_wait<NCH - 1>();   // see k_fwd64
                 const uint4 d = reinterpret_cast<const uint4 *>(L.codes)[j * NT + t];   // grid g+1
                 const int tail = (j == jstar) ? tail_star : 16;
                 const int k0 = (j * NT + t) * 16;
@@ -818,11 +865,10 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
 #pragma unroll
                     for (int q = 0; q < 8; q++) st[q * NT] = make_double2(x[2 * q], x[2 * q + 1]);
                 }
-                if (g > 0) dma_codes(prm, g, L.codes, j, NT, t);   // codes of grid g, for iteration g-1
+                if (g > 0) dma_codes(prm, g, L, j, wave, lane, d.x);   // codes of grid g, for iteration g-1
                 __builtin_amdgcn_sched_barrier(0);
             });
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const double S = block_sum(psum, L.red + (g & 1) * 16, t, nwaves);
+            const double S = block_sum64<NCH>(psum, L.red + (g & 1) * 16, t, nwaves);
             add = (1.0 - sig) / (double)K / sig * S;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
@@ -1179,7 +1225,7 @@ struct Geometry { int NT, NCH; bool f64; };
 // the whole 512-entry VGPR + AGPR file.  The smallest NCH that covers K gives the most waves; tiny panels still
 // get >= 2 chunks per lane for ILP.
 constexpr int kNchList32[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
-constexpr int kNchList64[] = {1, 2, 4, 6, 8, 10, 12, 13, 14};
+constexpr int kMaxNch64 = 14;   // fp64: NT = 256 fixed, NCH = ceil(K / 4096) (== Kp / 4096)
 Geometry pick_geometry(int K, bool f64 = false) {
     const int chunks = (K + 15) / 16;
     const int max_nt = f64 ? 256 : 512;
@@ -1190,8 +1236,12 @@ Geometry pick_geometry(int K, bool f64 = false) {
         if (nch == 1 && chunks > 128) return 0;
         return nt;
     };
-    if (f64) { for (int nch : kNchList64) if (int nt = fit(nch)) return {nt, nch, true}; }
-    else     { for (int nch : kNchList32) if (int nt = fit(nch)) return {nt, nch, false}; }
+    if (f64) {
+        const int nch = (K + 4095) / 4096;
+        if (nch <= kMaxNch64) return {256, nch, true};
+    } else {
+        for (int nch : kNchList32) if (int nt = fit(nch)) return {nt, nch, false};
+    }
     return {0, 0, f64};
 }
 
@@ -1251,10 +1301,15 @@ void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, h
         switch (geo.NCH) {
 #ifndef QA_FAST_BUILD
             case 1: launch_fb64<1, 0>(prm, geo.NT, st, e_mid); break;
+            case 3: launch_fb64<2, 1>(prm, geo.NT, st, e_mid); break;
             case 4: launch_fb64<3, 1>(prm, geo.NT, st, e_mid); break;
+            case 5: launch_fb64<4, 1>(prm, geo.NT, st, e_mid); break;
             case 6: launch_fb64<5, 1>(prm, geo.NT, st, e_mid); break;
+            case 7: launch_fb64<6, 1>(prm, geo.NT, st, e_mid); break;
             case 8: launch_fb64<7, 1>(prm, geo.NT, st, e_mid); break;
+            case 9: launch_fb64<8, 1>(prm, geo.NT, st, e_mid); break;
             case 10: launch_fb64<8, 2>(prm, geo.NT, st, e_mid); break;
+            case 11: launch_fb64<8, 3>(prm, geo.NT, st, e_mid); break;
             case 12: launch_fb64<9, 3>(prm, geo.NT, st, e_mid); break;
             case 14: launch_fb64<11, 3>(prm, geo.NT, st, e_mid); break;
 #endif
@@ -1430,8 +1485,8 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         const double frac = G > 0 ? (double)n_thin / G : 0;
         const double per_dir = cells_all * (1.0 + es) + cells_thin * (1.0 + es * frac);
         qa::profile_add(qa::PK_EMAT, g_timing[0], 0);
-        qa::profile_add(qa::PK_FWD, g_timing[1], per_dir);
-        qa::profile_add(qa::PK_BWD, g_timing[2], per_dir);
+        qa::profile_add(f64 ? qa::PK_FWD64 : qa::PK_FWD, g_timing[1], per_dir);
+        qa::profile_add(f64 ? qa::PK_BWD64 : qa::PK_BWD, g_timing[2], per_dir);
         qa::profile_add(qa::PK_POST, g_timing[3], 0);
     }
 

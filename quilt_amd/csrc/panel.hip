@@ -118,7 +118,7 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
         QA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         const int K = d->K, G = d->nGrids;
         p->K = K; p->G = G; p->T = d->nSNPs; p->nMaxDH = d->nMaxDH; p->nrow = d->nMaxDH + 1;
-        p->Kp = (K + 63) / 64 * 64;
+        p->Kp = (K + 4095) / 4096 * 4096;   // whole 256-lane x 16-haplotype chunk rows (zero padded): see panel.hpp
         p->ref_error = d->ref_error;
         // hapMatcher -> uint8 [G][Kp]
         p->hm.alloc((size_t)G * p->Kp);

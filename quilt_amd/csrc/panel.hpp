@@ -5,8 +5,9 @@
 
 // HBM layout (all resident for the life of the handle):
 //   hm     uint8  [nGrids][Kp]      hapMatcherR, grid-major, haplotypes contiguous, row pitch Kp =
-//                                   K rounded up to 64 B so that every 16-haplotype chunk is one
-//                                   aligned 16-byte load (K=50 000, G=2 000: 100 MB)
+//                                   K rounded up to 4096 (zero padded): every 16-haplotype chunk is one
+//                                   aligned 16-byte load and the fp64 ranking kernels can fetch whole
+//                                   256-lane chunk rows without bounds checks (K=50 000, G=2 000: 106 MB)
 //   B      int32  [nGrids][nMaxDH]  distinctHapsB (same bytes as R's nMaxDH x nGrids matrix)
 //   sp_*   CSR over grids of the "special" haplotypes (hapMatcher == 0): ascending k and the 32-bit
 //          word the reference would decode for it
