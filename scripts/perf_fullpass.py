@@ -17,6 +17,7 @@ ap.add_argument("--T", type=int, default=64000)
 ap.add_argument("--P", type=int, default=256)
 ap.add_argument("--thin-frac", type=float, default=0.0, help="fraction of thin passes")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--ktop", type=int, default=5)
 a = ap.parse_args()
 
 t0 = time.time()
@@ -43,13 +44,21 @@ bptr = np.zeros(a.P * n_thin + 1, dtype=np.int32)
 cap = a.P * n_thin * 64
 bidx = np.zeros(cap, dtype=np.int32)
 bval = np.zeros(cap)
+NAMES = ["k_emat", "k_fwd", "k_bwd", "k_dosage+k_topk", "k_ematread", "k_gibbs", "k_happrobs", "k_fwd64", "k_bwd64"]
 for r in range(a.reps):
     t0 = time.time()
-    check(lib().qa_fullpass_batch(dev.handle, C.c_int32(a.P), ptr(gl), ptr(want), ptr(cols), C.c_int32(5),
+    lib().qa_profile_reset()
+    check(lib().qa_fullpass_batch(dev.handle, C.c_int32(a.P), ptr(gl), ptr(want), ptr(cols), C.c_int32(a.ktop),
                                   ptr(dosage), ptr(bptr), ptr(bidx), ptr(bval), C.c_int64(cap)))
     wall = time.time() - t0
     tm = last_fullpass_timing_ms()
     nd = int(want.sum()); nt = a.P - nd
     alg = (nd * 10.0 + nt * 2.8) * panel.K * G
-    print(f"rep {r}: wall {wall:.3f}s device {tm}  alg GB {alg/1e9:.1f}  fwd+bwd GB/s {alg/1e9/((tm['forward']+tm['backward'])/1e3):.0f}", flush=True)
+    line = []
+    for k, nm in enumerate(NAMES):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        lib().qa_profile_get(C.c_int32(k), C.byref(ms), C.byref(n), C.byref(b))
+        if n.value:
+            line.append(f"{nm} {ms.value:.1f} ms ({b.value / 1e6 / max(ms.value, 1e-9):.0f} GB/s)")
+    print(f"rep {r}: wall {wall:.3f}s  " + "  ".join(line), flush=True)
 print("dosage range", dosage[want == 1].min() if want.any() else None, dosage.max())
