@@ -280,9 +280,16 @@ __global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
     TS a[NCH][16];
     uint4 dh[NCH];
     const TS invK = TS(1) / (TS)K;
+    // Chunks past K carry 0 and must stay 0: their codes are 0 (never loaded), so they see a finite table entry, and the
+    // additive term is switched off per chunk (one select per chunk instead of a compare per element).  `tail_star` < 16
+    // marks the one lane whose chunk (row jstar) straddles K.
+    uint32_t valid = 0;
+    const int jstar = (K / 16) / NT;
+    const int tail_star = ((K / 16) % NT == t && (K & 15)) ? (K & 15) : 16;
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const int k0 = (j * NT + t) * 16;
+        valid |= (k0 < K ? 1u : 0u) << j;
 #pragma unroll
         for (int i = 0; i < 16; i++) a[j][i] = (k0 + i < K) ? invK : TS(0);
         dh[j] = make_uint4(0, 0, 0, 0);
@@ -308,22 +315,23 @@ __global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
             const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+            const TS sj = ((valid >> j) & 1u) ? s : TS(0);
+            TS e[16];   // the 16 table look-ups first, back to back, then the arithmetic
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-                a[j][i] = (a[j][i] + s) * et[code];
-            }
+            for (int i = 0; i < 16; i++) e[i] = et[(w[i >> 2] >> ((i & 3) * 8)) & 0xffu];
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[j][i] = (a[j][i] + sj) * e[i];
         }
         if (prm.sp_off[g + 1] > prm.sp_off[g]) apply_special_emissions<TS, NCH>(a, dh, prm, esp, g, NT, t);
         TS psum = 0;
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
-            const int k0 = (j * NT + t) * 16;
+            if (j == jstar && tail_star < 16) {   // one lane of the block
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (k0 + 16 > K && k0 + i >= K) a[j][i] = 0;  // padding K..Kq (only the tail chunk pays)
-                psum += a[j][i];
+                for (int i = 0; i < 16; i++) a[j][i] = i < tail_star ? a[j][i] : TS(0);
             }
+#pragma unroll
+            for (int i = 0; i < 16; i++) psum += a[j][i];
         }
         if (g + 1 < G) {
 #pragma unroll
@@ -380,13 +388,33 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
 
     TS b[NCH][16];
     uint4 dh[NCH];  // codes of grid g+1 during the emission phase, then reloaded with grid g's
+    uint32_t valid = 0;   // see k_fwd
+    const int jstar = (K / 16) / NT;
+    const int tail_star = ((K / 16) % NT == t && (K & 15)) ? (K & 15) : 16;
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const int k0 = (j * NT + t) * 16;
+        valid |= (k0 < K ? 1u : 0u) << j;
 #pragma unroll
         for (int i = 0; i < 16; i++) b[j][i] = (k0 + i < K) ? TS(1) : TS(0);
         dh[j] = make_uint4(0, 0, 0, 0);
     }
+    // fold one grid's 32 bank-private histogram copies into prm.mg (thread = code; copies visited in a rotated order
+    // so that a wave's reads spread over the banks), re-zeroing them
+    auto fold_histogram = [&](int g_of) {
+        uint32_t *h = hist + (g_of & 1) * kMaxRow * kHistCopies;
+        uint32_t *mgo = prm.mg + ((size_t)p * G + g_of) * kMaxRow;
+        for (int code = t; code < prm.nrow; code += NT) {
+            uint32_t v = 0;
+#pragma unroll 8
+            for (int c = 0; c < kHistCopies; c++) {
+                const int at = code * kHistCopies + ((c + lane) & (kHistCopies - 1));
+                v += h[at];
+                h[at] = 0u;
+            }
+            mgo[code] = v;
+        }
+    };
     if (want_dosage)
         for (int i = t; i < 2 * kMaxRow * kHistCopies; i += NT) hist[i] = 0u;
     for (int i = t; i < kMaxRow; i += NT)
@@ -407,11 +435,11 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
                 const uint32_t w[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+                TS e[16];   // look-ups first, back to back
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-                    b[j][i] *= et[code];
-                }
+                for (int i = 0; i < 16; i++) e[i] = et[(w[i >> 2] >> ((i & 3) * 8)) & 0xffu];
+#pragma unroll
+                for (int i = 0; i < 16; i++) b[j][i] *= e[i];
             }
             if (prm.sp_off[g + 2] > prm.sp_off[g + 1]) apply_special_emissions<TS, NCH>(b, dh, prm, esp, g + 1, NT, t);
             TS psum = 0;
@@ -433,14 +461,20 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
                     if (t + r * NT < kMaxRow) etab[(g & 1) * kMaxRow + t + r * NT] = etn[r];
             }
             const double S = block_sum((double)psum, red + (g & 1) * 16, t, nwaves);
+            // every wave is past its atomics of grid g+1 (they precede this barrier), and none reaches the atomics of
+            // grid g-1 (same buffer) before the next barrier: fold grid g+1 here, without a barrier of its own
+            if constexpr (FULL) {
+                if (want_dosage && (store_all || slot[g + 1] >= 0)) fold_histogram(g + 1);
+            }
             const TS add = (TS)((1.0 - sig) / (double)K / sig * S);
 #pragma unroll
             for (int j = 0; j < NCH; j++) {
-                const int k0 = (j * NT + t) * 16;
+                const TS aj = ((valid >> j) & 1u) ? add : TS(0);
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    b[j][i] += add;
-                    if (k0 + 16 > K && k0 + i >= K) b[j][i] = 0;
+                for (int i = 0; i < 16; i++) b[j][i] += aj;
+                if (j == jstar && tail_star < 16) {   // one lane of the block
+#pragma unroll
+                    for (int i = 0; i < 16; i++) b[j][i] = i < tail_star ? b[j][i] : TS(0);
                 }
             }
         }
@@ -506,22 +540,6 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (want_dosage) {
-                    __syncthreads();
-                    // fold the 32 bank-private copies (one half-wave per code), re-zeroing as we go
-                    uint32_t *mgo = prm.mg + ((size_t)p * G + g) * kMaxRow;
-                    for (int base = 0; base < prm.nrow; base += 2 * nwaves) {
-                        const int code = base + 2 * (t >> 6) + (lane >> 5);
-                        uint32_t v = 0;
-                        if (code < prm.nrow) {
-                            v = h[code * kHistCopies + (lane & 31)];
-                            h[code * kHistCopies + (lane & 31)] = 0u;
-                        }
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                        if (code < prm.nrow && (lane & 31) == 0) mgo[code] = v;
-                    }
-                }
             }
         }
         if (tcol >= 0 && prm.beta_thin) {
@@ -545,6 +563,12 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
             V *dst = reinterpret_cast<V *>(prm.beta_out) + ((size_t)p * G + g) * col_vecs;
 #pragma unroll
             for (int j = 0; j < NCH; j++) store_chunk<TS>(dst, b[j], j, NT, t);
+        }
+    }
+    if constexpr (FULL) {
+        if (want_dosage && (store_all || slot[0] >= 0)) {
+            __syncthreads();
+            fold_histogram(0);
         }
     }
 }
