@@ -237,6 +237,9 @@ typedef struct {
  *   state_out                 NULL, or (n_chain == 1 only) 6 * Ks * nGrids + 3 * nGrids doubles:
  *                             alphaHat_t1, alphaHat_t2, betaHat_t1, betaHat_t2, eMatGrid_t1, eMatGrid_t2,
  *                             c1, c2, c3 -- the matrices the reference mutates in place
+ *   first_read                per chain, 0-based (`sample(nReads, 1) - 1`); a negative entry makes that chain start
+ *                             from its starting labels even when gibbs_initialize_iteratively is set (lets one
+ *                             launch mix first-round chains with later-round chains)
  */
 int qa_gibbs_batch(qa_panel_t *panel, const qa_gibbs_opts_t *opts, int32_t n_chain,
                    const int32_t *which_haps_to_use_1based, const int32_t *read_off,

@@ -501,6 +501,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
     const double *runif = p.seed_reads ? nullptr : p.runif_reads + (size_t)p.read_off[c] * p.n_its;
     const uint64_t seed_reads = p.seed_reads ? p.seed_reads[c] : 0, seed_shard = p.seed_shard ? p.seed_shard[c] : 0;
     const int first_read = p.first_read[c];
+    // first_read < 0: this chain starts from its starting labels even in a launch that initialises iteratively
+    const bool init_iteratively = p.init_iteratively && first_read >= 0;
 
     // ---- c = 0 (arma::zeros, gibbs-nipt.cpp:2676-2678), H_class = 0
     for (int h = 0; h < 3; h++)
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
             for (int g = 0; g < G; g++) ch.st(one, ch.eg[h] + (size_t)g * Ksp);
     }
     chain_sync<NW>();
-    if (!p.init_iteratively) {
+    if (!init_iteratively) {
         // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281): reads are sorted by grid, so the
         // products of one grid are formed in registers in read order
         ReadStreams<CH> rs;
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 // unconditional (clamped) so that no control-flow join forces the in-order vmcnt to drain
                 ch.ld(pre_er, ch.eMatRead + (size_t)min(iRead, R - 1) * Ksp);
                 if (rl_i32(rs.cat1, jr) != 0) continue;  // reads that cannot discriminate are skipped (:815)
-                if (!p.init_iteratively) normal = true;
+                if (!init_iteratively) normal = true;
                 else if (r < first_read && it == 0) pass = true;
                 else if (first_read <= r && it == 0) { pass = false; ginit = true; }
                 else if (r < first_read && it == 1) { pass = false; ginit = true; }
@@ -1119,11 +1121,12 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
         default: throw std::runtime_error("Ksubset geometry not built (Ksubset / 64 rounded up must be 1..10, 12 or 16)");
     }
     QA_HIP(hipEventRecord(ev[1], st));
-    const int budget = 1280;  // waves that fit at ~1 per SIMD on 256 CUs, with some slack
+    // Waves per chain.  The kernel holds 512 registers per lane (one wave per SIMD, 1024 per device), and a chain's
+    // time is its serial per-read latency: measured at Ksubset = 600 with 128 chains NW = 2 is fastest (0.64 s vs 0.77
+    // NW = 1, 0.70 NW = 5, 0.86 NW = 10: more waves = costlier exchange per read), with 896 chains NW = 1 (0.94 s vs
+    // 1.36 NW = 2, which no longer fits in one wave of workgroups).
     int nw = 1;
-    for (int cand : {10, 5, 2}) {
-        if (NE1 % cand == 0 && (long)prm.C * cand <= budget) { nw = cand; break; }
-    }
+    if (NE1 % 2 == 0 && (long)prm.C * 2 <= 1024) nw = 2;
     if (const char *forced = getenv("QA_GIBBS_NW")) nw = atoi(forced);   // test hook: exercise every geometry
     if (NE1 == 10) {
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);

@@ -253,12 +253,19 @@ def recast_haps(hd1: np.ndarray, hd2: np.ndarray, gp: np.ndarray):
 
 @dataclass
 class ChainState:
-    i_sample: int
+    sample: object                    # the chain's SampleReads
+    i_sample: int                     # index of the sample within its batch
     i_chain: int                      # 1..nGibbsSamples, nGibbsSamples + 1 = phasing
     rng: np.random.Generator
     which_haps_to_use: Optional[np.ndarray] = None   # 1-based
     read_labels: Optional[np.ndarray] = None
     hap: Optional[List[np.ndarray]] = None           # dosage1, dosage2 of the latest full pass
+
+    _phasing: bool = False
+
+    @property
+    def phasing(self) -> bool:
+        return self._phasing
 
 
 @dataclass
@@ -271,8 +278,28 @@ class SampleResult:
     n_underflow_retries: int = 0
 
 
+@dataclass
+class _Batch:
+    """One batch of samples in flight: its Gibbs chains and the accumulators of get_and_impute_one_sample."""
+    samples: list
+    offset: int                       # global index of samples[0] (keys the random streams)
+    chains: List[ChainState]
+    dosage: np.ndarray
+    gp_t: np.ndarray
+    nDosage: np.ndarray
+    phasing: Optional[List[ChainState]] = None
+    consensus: Optional[List[np.ndarray]] = None
+
+
 class Driver:
-    """Runs ``get_and_impute_one_sample`` for a batch of samples, chains in lock-step."""
+    """Runs ``get_and_impute_one_sample`` (quilt.R:688-996, functions.R:420-1259) for batches of samples, all chains of
+    a batch in lock-step.
+
+    Batches are software-pipelined: the phasing rounds of batch i (one chain per sample) share their launches with the
+    main rounds of batch i + 1 (nGibbsSamples chains per sample).  A Gibbs chain is a serial walk over the reads, so a
+    launch costs the same whether it carries 128 or 1024 chains (one per SIMD); fusing the two halves the number of
+    latency-bound launches.  Results do not depend on the batching: every chain owns its random stream.
+    """
 
     def __init__(self, panel, backend, params: Optional[DriverParams] = None):
         self.panel = panel
@@ -283,18 +310,18 @@ class Driver:
         self.top_width = max(8, self.params.K_top_matches)   # entries kept per (label, thinned grid) list
         self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0}
 
-    # -- one [Gibbs -> full pass -> select] round over a set of chains
-    def _round(self, chains: List[ChainState], samples, i_it: int, phasing: bool):
+    # -- one [Gibbs -> full pass -> select] round over a set of chains (main and / or phasing chains, same i_it)
+    def _round(self, chains: List[ChainState], i_it: int):
         import time
         P = self.params
         K, G, T = self.panel.K, self.panel.nGrids, self.panel.nSNPs
-        n_its = P.small_ref_panel_gibbs_iterations + P.n_gibbs_sample_its
-        nb = len(P.small_ref_panel_block_gibbs_iterations)
         t0 = time.perf_counter()
-        first = (i_it == 1) and not phasing
+        any_first = False
         starts, seed_reads, first_reads, seed_shards = [], [], [], []
         for ch in chains:
-            R = samples[ch.i_sample].nReads
+            R = ch.sample.nReads
+            first = (i_it == 1) and not ch.phasing
+            any_first |= first
             if first:
                 # functions.R:579-585
                 ch.which_haps_to_use = np.sort(ch.rng.permutation(K)[: P.Ksubset] + 1).astype(np.int32)
@@ -304,8 +331,13 @@ class Driver:
             starts.append(H0)
             # seeds of the counter-based streams that stand in for Rcpp::runif (quilt_amd/rng.py)
             seed_reads.append(int(ch.rng.integers(0, 2 ** 63)))
-            first_reads.append(int(ch.rng.integers(0, R)))
+            fr = int(ch.rng.integers(0, R))
+            # only first-round chains initialise iteratively (functions.R:2369); in a launch that also carries
+            # later-round (phasing) chains a negative first_read marks those (include/quilt_amd.h)
+            first_reads.append(fr if first else -1)
             seed_shards.append(int(ch.rng.integers(0, 2 ** 63)))
+        if not any_first:
+            first_reads = [0] * len(chains)   # unused without gibbs_initialize_iteratively
         t1 = time.perf_counter()
         self.timing["host"] += t1 - t0
         # ---- small-panel Gibbs (impute_one_sample, functions.R:2313-2774), with the underflow retry
@@ -320,12 +352,12 @@ class Driver:
             nxt = []
             for md, idx in groups.items():
                 out = self.backend.gibbs_batch(
-                    [samples[chains[i].i_sample] for i in idx], [chains[i].which_haps_to_use for i in idx],
+                    [chains[i].sample for i in idx], [chains[i].which_haps_to_use for i in idx],
                     [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],
                     [seed_shards[i] for i in idx], n_gibbs_burn_in_its=P.small_ref_panel_gibbs_iterations,
                     n_gibbs_sample_its=P.n_gibbs_sample_its,
                     block_gibbs_iterations=P.small_ref_panel_block_gibbs_iterations,
-                    gibbs_initialize_iteratively=first, maxDifferenceBetweenReads=md, Jmax_local=P.Jmax)
+                    gibbs_initialize_iteratively=any_first, maxDifferenceBetweenReads=md, Jmax_local=P.Jmax)
                 for i, o in zip(idx, out):
                     if o["underflow_problem"]:
                         maxdiff[i] = max(1.0, maxdiff[i] / 10)   # functions.R:2704-2715
@@ -342,14 +374,19 @@ class Driver:
         return_dosage = i_it > P.n_burn_in_seek_its
         for ch, res in zip(chains, results):
             ch.read_labels = res["double_list_of_ending_read_labels"][0][0].astype(np.int32)
+        uniq, sample_list = {}, []
+        for ch in chains:
+            if id(ch.sample) not in uniq:
+                uniq[id(ch.sample)] = len(sample_list)
+                sample_list.append(ch.sample)
         t3 = time.perf_counter()
         self.timing["host"] += t3 - t2
         # The reference asks for the best haplotypes on every call (functions.R:738-743), but the selection made from
         # them is read again only by a later round of the same chain or -- the last chain's final selection -- by the
         # phasing rounds (which_haps_to_use carried over): skip the lists nobody reads.
-        want_top = [i_it < P.n_seek_its or (not phasing and ch.i_chain == P.nGibbsSamples) for ch in chains]
+        want_top = [i_it < P.n_seek_its or (not ch.phasing and ch.i_chain == P.nGibbsSamples) for ch in chains]
         dosages, top, top_cnt = self.backend.fullpass_reads_batch(
-            samples, [ch.i_sample for ch in chains], [ch.read_labels for ch in chains],
+            sample_list, [uniq[id(ch.sample)] for ch in chains], [ch.read_labels for ch in chains],
             [return_dosage] * len(chains), want_top, self.cols, P.K_top_matches, P.minGLValue, self.top_width)
         t4 = time.perf_counter()
         self.timing["fullpass"] += t4 - t3
@@ -369,49 +406,70 @@ class Driver:
         self.timing["host"] += time.perf_counter() - t4
         return return_dosage
 
-    def run(self, samples, sample_offset: int = 0) -> List[SampleResult]:
-        """``sample_offset``: global index of ``samples[0]`` (keys the random streams, so that a sample gets the
-        same draws whichever rank / batch it lands in)."""
+    def _new_batch(self, samples, offset: int) -> _Batch:
         P = self.params
         T = self.panel.nSNPs
         N = len(samples)
-        self._offset = sample_offset
-        chains = [ChainState(i, c, chain_rng(P.seed, sample_offset + i, c)) for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
-        dosage = np.zeros((N, T))
-        gp_t = np.zeros((N, 3, T))
-        nDosage = np.zeros(N, dtype=np.int64)
-        for i_it in range(1, P.n_seek_its + 1):
-            stored = self._round(chains, samples, i_it, phasing=False)
-            if stored:   # functions.R:999-1020
-                for ch in chains:
-                    h1, h2 = ch.hap
-                    dosage[ch.i_sample] += h1 + h2
-                    gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
-                    nDosage[ch.i_sample] += 1
-        # ---- read confidence per chain and consensus labels (functions.R:1144-1205)
-        conf = self.backend.read_confidence_batch([samples[ch.i_sample] for ch in chains], [ch.hap for ch in chains],
+        chains = [ChainState(samples[i], i, c, chain_rng(P.seed, offset + i, c))
+                  for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
+        return _Batch(list(samples), offset, chains, np.zeros((N, T)), np.zeros((N, 3, T)), np.zeros(N, dtype=np.int64))
+
+    def _start_phasing(self, b: _Batch):
+        """Read confidence per chain and consensus labels (functions.R:1144-1205); one phasing chain per sample."""
+        P = self.params
+        conf = self.backend.read_confidence_batch([ch.sample for ch in b.chains], [ch.hap for ch in b.chains],
                                                   P.maxDifferenceBetweenReads)
-        phasing = []
-        for i in range(N):
-            R = samples[i].nReads
-            mine = [k for k, ch in enumerate(chains) if ch.i_sample == i]
-            rl_all = np.stack([chains[k].read_labels for k in mine], axis=1)
+        b.phasing = []
+        for i, smp in enumerate(b.samples):
+            mine = [k for k, ch in enumerate(b.chains) if ch.i_sample == i]
+            rl_all = np.stack([b.chains[k].read_labels for k in mine], axis=1)
             rl_conf = np.stack([assess_ability_of_reads_to_be_confident(conf[k]) for k in mine], axis=1)
-            labels = determine_best_read_label_so_far(rl_all, rl_conf, R, P.nGibbsSamples, can_hap=P.nGibbsSamples)
-            last = chains[mine[-1]]
-            ph = ChainState(i, P.nGibbsSamples + 1, chain_rng(P.seed, sample_offset + i, P.nGibbsSamples + 1),
-                            which_haps_to_use=last.which_haps_to_use.copy(), read_labels=labels)
-            phasing.append(ph)
-        consensus = [ph.read_labels.copy() for ph in phasing]
-        for i_it in range(1, P.n_seek_its + 1):
-            self._round(phasing, samples, i_it, phasing=True)
+            labels = determine_best_read_label_so_far(rl_all, rl_conf, smp.nReads, P.nGibbsSamples, can_hap=P.nGibbsSamples)
+            last = b.chains[mine[-1]]
+            b.phasing.append(ChainState(smp, i, P.nGibbsSamples + 1, chain_rng(P.seed, b.offset + i, P.nGibbsSamples + 1),
+                                        which_haps_to_use=last.which_haps_to_use.copy(), read_labels=labels, _phasing=True))
+        b.consensus = [ph.read_labels.copy() for ph in b.phasing]
+        b.chains = []   # the main chains are done
+
+    def _finish(self, b: _Batch) -> List[SampleResult]:
         out = []
-        for i in range(N):
-            d = dosage[i] / nDosage[i]
-            g = gp_t[i] / nDosage[i]
-            h1, h2 = recast_haps(phasing[i].hap[0], phasing[i].hap[1], g.T)   # functions.R:1207-1217
-            out.append(SampleResult(d, g, np.stack([h1, h2], axis=1), consensus[i], int(nDosage[i])))
+        for i in range(len(b.samples)):
+            d = b.dosage[i] / b.nDosage[i]
+            g = b.gp_t[i] / b.nDosage[i]
+            h1, h2 = recast_haps(b.phasing[i].hap[0], b.phasing[i].hap[1], g.T)   # functions.R:1207-1217
+            out.append(SampleResult(d, g, np.stack([h1, h2], axis=1), b.consensus[i], int(b.nDosage[i])))
         return out
+
+    def run_stream(self, batches):
+        """``batches``: iterable of ``(samples, sample_offset)``; yields one list of SampleResult per batch, in order.
+        The phasing rounds of a batch run fused with the main rounds of the next one (the last batch's run alone)."""
+        P = self.params
+        prev: Optional[_Batch] = None
+        it = iter(batches)
+        while True:
+            nxt = next(it, None)
+            cur = self._new_batch(*nxt) if nxt is not None else None
+            if cur is None and prev is None:
+                return
+            for i_it in range(1, P.n_seek_its + 1):
+                chains = (cur.chains if cur else []) + (prev.phasing if prev else [])
+                stored = self._round(chains, i_it)
+                if stored and cur:   # functions.R:999-1020
+                    for ch in cur.chains:
+                        h1, h2 = ch.hap
+                        cur.dosage[ch.i_sample] += h1 + h2
+                        cur.gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
+                        cur.nDosage[ch.i_sample] += 1
+            if prev:
+                yield self._finish(prev)
+            if cur:
+                self._start_phasing(cur)
+            prev = cur
+
+    def run(self, samples, sample_offset: int = 0) -> List[SampleResult]:
+        """One batch.  ``sample_offset``: global index of ``samples[0]`` (keys the random streams, so that a sample
+        gets the same draws whichever rank / batch it lands in)."""
+        return next(self.run_stream([(samples, sample_offset)]))
 
 
 # ---------------------------------------------------------------------------------------------

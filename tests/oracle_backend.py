@@ -22,11 +22,12 @@ class OracleBackend:
         for s, w, h, sr, fr, ss in zip(samples, which, starts, seed_reads, first_reads, seed_shards):
             ru = stream_uniform(sr, s.nReads * n_its)
             rs = stream_uniform(ss, nb * (self.panel.nGrids - 1))
-            r = O.forwardBackwardGibbsNIPT(self.panel, s, w, h, ru, fr, rs,
+            init = bool(gibbs_initialize_iteratively) and fr >= 0   # per chain (include/quilt_amd.h: first_read < 0)
+            r = O.forwardBackwardGibbsNIPT(self.panel, s, w, h, ru, max(fr, 0), rs,
                                            n_gibbs_burn_in_its=n_gibbs_burn_in_its,
                                            n_gibbs_sample_its=n_gibbs_sample_its,
                                            block_gibbs_iterations=block_gibbs_iterations,
-                                           gibbs_initialize_iteratively=gibbs_initialize_iteratively,
+                                           gibbs_initialize_iteratively=init,
                                            maxDifferenceBetweenReads=maxDifferenceBetweenReads, Jmax=Jmax_local)
             r["double_list_of_ending_read_labels"] = [[r["H"]]]
             out.append(r)

@@ -59,3 +59,21 @@ def test_params_small_panel_reset():
     p = D.DriverParams().resolved(K=100)
     assert (p.n_seek_its, p.n_burn_in_seek_its, p.Ksubset, p.Knew) == (1, 0, 100, 100)
     assert D.DriverParams().resolved(K=5000).n_burn_in_seek_its == 2
+
+
+def test_pipelined_batches_equal_separate_runs():
+    """run_stream fuses the phasing rounds of a batch with the main rounds of the next one (mixed launches, first-round
+    chains next to later-round chains): per-sample results must not depend on it."""
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=400, nSNPs=320, seed=21)
+    samples = [make_synthetic_sample(panel, seed=50 + i, n_reads=60) for i in range(5)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9)
+    batches = [(samples[0:2], 0), (samples[2:3], 2), (samples[3:5], 3)]
+    streamed = list(D.Driver(panel, OracleBackend(panel), prm).run_stream(batches))
+    assert [len(b) for b in streamed] == [2, 1, 2]
+    for (smp, off), got in zip(batches, streamed):
+        ref = D.Driver(panel, OracleBackend(panel), prm).run(smp, sample_offset=off)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g.read_labels, r.read_labels)
+            assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)

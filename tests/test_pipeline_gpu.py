@@ -72,3 +72,23 @@ def test_pipeline_default_parameters_small(small_panel):
     prm = DriverParams(nGibbsSamples=2, Ksubset=2000, Knew=2000, seed=3)
     got, ref = _run_both(panel, samples, prm)
     assert r2(got[0].dosage, ref[0].dosage) >= 0.999
+
+
+def test_pipelined_batches_gpu(medium_panel):
+    """Driver.run_stream on the HIP backend: launches that mix first-round main chains with phasing chains of the
+    previous batch (first_read < 0 marks the latter) give each sample the result of a run of its own."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=2000 + i, n_reads=600) for i in range(4)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=200, Knew=200, seed=11)
+    dev = DevicePanel(panel)
+    batches = [(samples[0:2], 0), (samples[2:4], 2)]
+    streamed = list(Driver(panel, HipBackend(dev), prm).run_stream(batches))
+    for (smp, off), got in zip(batches, streamed):
+        ref = Driver(panel, HipBackend(dev), prm).run(smp, sample_offset=off)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g.read_labels, r.read_labels)
+            assert np.abs(g.dosage - r.dosage).max() <= 1e-6
+    dev.close()
