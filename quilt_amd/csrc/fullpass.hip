@@ -1284,7 +1284,7 @@ size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stor
     size_t b = T * 16 + G * 4 + G * kMaxRow * (es + 4) + 8 + (size_t)pn->n_special * (es + 4) + cols * Kq * es + G * 8 + T * 8;
     if (gamma) b += G * Kq * es;
     if (beta) b += G * Kq * es;
-    if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 64 * 12);
+    if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 64 * 12);   // (lists of up to 64 entries)
     return b + 256 * 24;
 }
 
@@ -1376,7 +1376,11 @@ struct BatchOut {
     bool gamma_small_unscaled = false;  // gammaSmall_t without return_gamma_t: no sigma factor (:2170-2176)
     // best_haps_stuff_list of every (pass, thinned column), appended in pass-major order
     std::vector<std::vector<std::pair<int32_t, double>>> *lists = nullptr;
-    bool truncate_lists = false;   // batched drivers: lists capped at 64 entries (head of the ordered list)
+    bool truncate_lists = false;   // batched drivers: lists capped at top_cap entries (head of the ordered list)
+    int top_cap = 64;              // initial (or, truncating, final) capacity per list
+    // truncating drivers: the device arrays as they are, [P][n_thin][top_cap], instead of `lists`
+    std::vector<int32_t> *flat_idx = nullptr;
+    std::vector<double> *flat_val = nullptr;
     bool order_by_value = false;
     std::vector<int32_t> *true_counts = nullptr;   // untruncated list lengths  // lists ordered as everything_per_hap_rejig_haps wants (else ascending k)
 };
@@ -1451,7 +1455,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     if (any_gamma) S.gamma.ensure((size_t)P * G * Kq * es);
     if (any_beta) S.beta.ensure((size_t)P * G * Kq * es);
     if (any_top) S.beta_thin.ensure((size_t)P * n_thin * Kq * es);
-    int top_cap = 64;
+    int top_cap = out.top_cap;
     S.top_cnt.ensure(std::max<size_t>((size_t)P * std::max(n_thin, 1), 1));
 
     PassParams prm{};
@@ -1571,10 +1575,14 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     }
     int status = QA_OK;
     if (any_top && out.true_counts) *out.true_counts = cnt;
-    if (any_top && out.lists) {
+    if (any_top && (out.lists || out.flat_idx)) {
         const size_t n = (size_t)P * n_thin;
-        std::vector<int32_t> idx(n * top_cap);
-        std::vector<double> val(n * top_cap);
+        std::vector<int32_t> idx_local;
+        std::vector<double> val_local;
+        std::vector<int32_t> &idx = out.flat_idx ? *out.flat_idx : idx_local;
+        std::vector<double> &val = out.flat_val ? *out.flat_val : val_local;
+        idx.resize(n * top_cap);
+        val.resize(n * top_cap);
         S.top_idx.download(idx.data(), idx.size(), st);
         if (f64) {
             QA_HIP(hipMemcpyAsync(val.data(), S.top_val.p, val.size() * 8, hipMemcpyDeviceToHost, st));
@@ -1585,7 +1593,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
             QA_HIP(hipStreamSynchronize(st));
             for (size_t i = 0; i < val.size(); i++) val[i] = v32[i];
         }
-        for (size_t i = 0; i < n; i++) {
+        for (size_t i = 0; out.lists && i < n; i++) {
             std::vector<std::pair<int32_t, double>> tmp;
             const int nq = std::min<int>(cnt[i], top_cap);
             tmp.reserve(nq);
@@ -1777,7 +1785,7 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                             double *dosage, int32_t top_width, int32_t *top_idx, float *top_val, int32_t *top_cnt) {
     if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
     if (!panel || n_chain <= 0 || n_label < 1 || n_label > 3 || n_sample <= 0 || !chain_sample || !read_off || !read_ptr ||
-        !u || !bq || !H || !want_dosage || !gammaSmall_cols_to_get || top_width < K_top_matches) {
+        !u || !bq || !H || !want_dosage || !gammaSmall_cols_to_get || top_width < K_top_matches || top_width > 64) {
         qa::set_error("qa_fullpass_reads_batch: bad argument");
         return QA_ERR_INVALID;
     }
@@ -1867,7 +1875,6 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
         if (top_val) std::fill(top_val, top_val + n_out * top_width, 0.f);
 
         int status = QA_OK;
-        std::vector<std::vector<std::pair<int32_t, double>>> lists;
         std::vector<int32_t> no_thin(G, -1);
         for (const Group &grp : groups) {
             const Geometry geo = pick_geometry(panel->K, grp.f64);
@@ -1894,8 +1901,11 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                 BatchOut out;
                 out.dosage = grp.flag ? dosage : nullptr;
                 out.dosage_rows = grp.ids.data() + done;
-                lists.clear();
-                out.lists = &lists;
+                std::vector<int32_t> fidx;
+                std::vector<double> fval;
+                out.flat_idx = &fidx;
+                out.flat_val = &fval;
+                out.top_cap = top_width;      // k_topk keeps the ordered head of each list: all the driver reads
                 out.order_by_value = true;
                 out.truncate_lists = true;
                 std::vector<int32_t> true_cnt;
@@ -1906,12 +1916,12 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                 // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
                 if (grp.K_top > 0) {
                     for (int i = 0; i < n * n_thin; i++) {
-                        const auto &l = lists[i];
                         const size_t o = (size_t)grp.ids[done + i / n_thin] * n_thin + (i % n_thin);
+                        const int len = std::min<int>(true_cnt[i], top_width);
                         if (top_cnt) top_cnt[o] = true_cnt[i];
-                        for (int q = 0; q < top_width && q < (int)l.size(); q++) {
-                            if (top_idx) top_idx[o * top_width + q] = l[q].first;
-                            if (top_val) top_val[o * top_width + q] = (float)l[q].second;
+                        for (int q = 0; q < len; q++) {
+                            if (top_idx) top_idx[o * top_width + q] = fidx[(size_t)i * top_width + q];
+                            if (top_val) top_val[o * top_width + q] = (float)fval[(size_t)i * top_width + q];
                         }
                     }
                 }

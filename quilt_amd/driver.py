@@ -177,6 +177,50 @@ def assess_ability_of_reads_to_be_confident(p: np.ndarray, minrp: float = 0.95) 
 
 def determine_best_read_label_so_far(read_label_matrix_all: np.ndarray, read_label_matrix_conf: np.ndarray,
                                      nReads: int, nGibbsSamples: int, can_hap: int) -> np.ndarray:
+    """functions.R:1680-1784 (including that the final flips start at the LAST change point, counted in the filtered
+    row space: ``w <- s1[i]:nReads`` with the leftover loop variable).
+
+    The reference rewrites the suffix ``w`` of its working matrix at every change point; rows are only ever read at
+    later change points, so the rewrites are kept here as flip parities per column (and one for the canonical
+    haplotype) and applied when a row is looked at: O(change points x columns) instead of O(change points x reads).
+    ``_determine_best_read_label_so_far_literal`` is the line-by-line form the tests compare against.
+    """
+    rl = read_label_matrix_all.astype(np.int64)
+    default = rl[:, can_hap - 1].astype(np.int32)
+    keep = read_label_matrix_conf.all(axis=1)
+    L0 = rl[keep]
+    if L0.shape[0] < 10:
+        return default
+    can0 = L0[:, can_hap - 1]
+    a0 = L0 - can0[:, None]
+    s = np.nonzero(np.diff(np.abs(a0).sum(axis=1)) != 0)[0] + 1  # R's which(), 1-based
+    if len(s) == 0:
+        return default
+    s1 = np.concatenate([[1], s + 1])
+    fc = np.zeros(nGibbsSamples, dtype=bool)   # label-flip parity of each column over the current suffix
+    fcan = False                               # flip parity of the canonical labels
+    flipped = np.zeros(nGibbsSamples, dtype=bool)
+    half = nGibbsSamples / 2
+    for r in (s1[1:] - 1).tolist():            # R: for(i in 2:length(s1))
+        lab = np.where(fc, 3 - L0[r], L0[r])
+        cur = lab - ((3 - can0[r]) if fcan else can0[r])
+        changed = np.nonzero(cur != 0)[0]
+        if len(changed) > 0:
+            if len(changed) > half:
+                changed = np.nonzero(cur == 0)[0]
+                fcan = not fcan
+            fc[changed] ^= True
+        flipped[changed] = True
+    out = default.copy()
+    if flipped[can_hap - 1]:
+        w0 = int(s1[-1]) - 1                   # s1[i] with the loop's last i; an index into the UNFILTERED reads
+        if w0 < nReads:
+            out[w0:nReads] = 3 - out[w0:nReads]
+    return out
+
+
+def _determine_best_read_label_so_far_literal(read_label_matrix_all: np.ndarray, read_label_matrix_conf: np.ndarray,
+                                     nReads: int, nGibbsSamples: int, can_hap: int) -> np.ndarray:
     """functions.R:1680-1784, line by line (including that the final flips start at the LAST change point,
     counted in the filtered row space: ``w <- s1[i]:nReads`` with the leftover loop variable)."""
     rl = read_label_matrix_all.astype(np.int64).copy()
@@ -308,7 +352,7 @@ class Driver:
         self.cols = thinned_grid_columns(panel.nGrids, self.params.heuristic_match_thin)
         self.n_thin = int((self.cols >= 0).sum())
         self.top_width = max(8, self.params.K_top_matches)   # entries kept per (label, thinned grid) list
-        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0}
+        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0}
 
     # -- one [Gibbs -> full pass -> select] round over a set of chains (main and / or phasing chains, same i_it)
     def _round(self, chains: List[ChainState], i_it: int):
@@ -324,7 +368,7 @@ class Driver:
             any_first |= first
             if first:
                 # functions.R:579-585
-                ch.which_haps_to_use = np.sort(ch.rng.permutation(K)[: P.Ksubset] + 1).astype(np.int32)
+                ch.which_haps_to_use = np.sort(ch.rng.choice(K, size=P.Ksubset, replace=False) + 1).astype(np.int32)
                 H0 = ch.rng.integers(1, 3, size=R).astype(np.int32)
             else:
                 H0 = ch.read_labels
@@ -460,11 +504,17 @@ class Driver:
                         cur.dosage[ch.i_sample] += h1 + h2
                         cur.gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
                         cur.nDosage[ch.i_sample] += 1
-            if prev:
-                yield self._finish(prev)
+            import time
+            t0 = time.perf_counter()
+            done = self._finish(prev) if prev else None
+            t1 = time.perf_counter()
             if cur:
                 self._start_phasing(cur)
+            self.timing["finish"] += t1 - t0
+            self.timing["consensus"] += time.perf_counter() - t1
             prev = cur
+            if done is not None:
+                yield done
 
     def run(self, samples, sample_offset: int = 0) -> List[SampleResult]:
         """One batch.  ``sample_offset``: global index of ``samples[0]`` (keys the random streams, so that a sample

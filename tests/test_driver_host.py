@@ -77,3 +77,22 @@ def test_pipelined_batches_equal_separate_runs():
         for g, r in zip(got, ref):
             assert np.array_equal(g.read_labels, r.read_labels)
             assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
+
+
+def test_best_read_labels_lazy_form_equals_literal_form():
+    """determine_best_read_label_so_far keeps the reference's suffix rewrites as flip parities; the line-by-line
+    restatement of functions.R:1680-1784 is the check."""
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        R = int(rng.integers(5, 300))
+        n = int(rng.choice([1, 2, 3, 7]))
+        m = np.tile(rng.integers(1, 3, size=R)[:, None], (1, n))
+        for c in range(n):
+            for pos in rng.integers(0, R, size=rng.integers(0, 4)):
+                m[pos:, c] = 3 - m[pos:, c]
+            noise = rng.random(R) < rng.choice([0, 0.02, 0.2])
+            m[noise, c] = 3 - m[noise, c]
+        conf = rng.random((R, n)) < rng.choice([0.3, 0.8, 1.0])
+        can = int(rng.integers(1, n + 1))
+        assert np.array_equal(D.determine_best_read_label_so_far(m, conf, R, n, can_hap=can),
+                              D._determine_best_read_label_so_far_literal(m, conf, R, n, can_hap=can))
