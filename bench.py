@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--nsnps", type=int, default=64000)
     ap.add_argument("--batch", type=int, default=128, help="samples per step per GPU")
     ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--workers", type=int, default=2, help="host threads per GPU (each with its own stream and arena)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -111,15 +112,15 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from quilt_amd import native
-    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.driver import DriverParams
     from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from quilt_amd.workers import DeviceWorkers
     native.check(native.lib().qa_set_device(local_rank))
     panel = make_synthetic_panel(K=a.K, nSNPs=a.nsnps, seed=4916)
-    dev = native.DevicePanel(panel)
     n_steps = a.warmup + a.steps
     samples = [[make_synthetic_sample(panel, seed=1000 + (rank * n_steps + st) * a.batch + i, n_reads=a.reads)
                 for i in range(a.batch)] for st in range(n_steps)]
-    drv = Driver(panel, HipBackend(dev), DriverParams(**params))
+    drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers)
 
     def barrier():
         torch.cuda.synchronize()
@@ -133,7 +134,7 @@ def main():
     for _ in drv.run_stream(stream(0, a.warmup)):
         pass
     native.lib().qa_profile_reset()
-    drv.timing = {k: 0.0 for k in drv.timing}
+    drv.reset_timing()
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -170,7 +171,8 @@ def main():
                                    f"({panel.nGrids} grids, 2 Mb + buffers), K={a.K} haplotypes, {a.reads} reads/sample, "
                                    "QUILT defaults (nGibbsSamples=7, n_seek_its=3, Ksubset=600), use_mspbwt=FALSE",
                        "K": a.K, "nSNPs": a.nsnps, "samples_per_step_per_gpu": a.batch,
-                       "parallelism": f"samples sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
+                                      "GPU, consecutive batches pipelined"},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],

@@ -90,6 +90,12 @@ void qa_panel_destroy(qa_panel_t *panel);
  * near-ties may be ordered differently).  Dosages always come from fp32 state (|error| ~1e-6). */
 int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits);
 
+/* Tell the library that n_sharers panel handles (normally one per host thread, each with its own stream and arena)
+ * work on this device at the same time: each then sizes its scratch for 1 / n_sharers of the free memory and its Gibbs
+ * launches for 1 / n_sharers of the SIMDs.  Two host threads hide each other's host-side phases (marshalling, the R-level
+ * logic between native calls) behind the other's kernels. */
+int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers);
+
 /* ---- full-panel haploid forward/backward -------------------------------- */
 
 /* Flags of Rcpp_haploid_dosage_versus_refs (QUILT/src/reference-single.cpp:2214-2227). */

@@ -1102,7 +1102,7 @@ void launch_gibbs_kernel(const GibbsParams &prm, hipStream_t st) {
 // Geometry of one chain: NW waves x NE rows per thread with 64 * NW * NE == Ksp.  More waves shorten the
 // serial chain (latency) at the price of repeating the per-read scalar logic in every wave (throughput):
 // use as many waves as keep the chip at about one wave per SIMD.
-void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs) {
+void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs, int share) {
     const int NE1 = prm.Ksp / 64;   // rows per lane with one wave
     QA_HIP(hipEventRecord(ev[0], st));
     switch (NE1) {
@@ -1126,7 +1126,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
     // NW = 1, 0.70 NW = 5, 0.86 NW = 10: more waves = costlier exchange per read), with 896 chains NW = 1 (0.94 s vs
     // 1.36 NW = 2, which no longer fits in one wave of workgroups).
     int nw = 1;
-    if (NE1 % 2 == 0 && (long)prm.C * 2 <= 1024) nw = 2;
+    if (NE1 % 2 == 0 && (long)prm.C * 2 <= 1024 / share) nw = 2;   // share: host threads sharing the device
     if (const char *forced = getenv("QA_GIBBS_NW")) nw = atoi(forced);   // test hook: exercise every geometry
     if (NE1 == 10) {
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
@@ -1270,7 +1270,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
         const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
-        launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs);
+        launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs, pn->share);
         S.H.download(H, totR, st);
         if (H_class) S.H_class.download(H_class, totR, st);
         std::vector<int32_t> status(C);
@@ -1351,7 +1351,7 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
             const int R = read_off[c + 1] - read_off[c];
             base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
         }
-        const size_t budget = pn->arena.budget();
+        const size_t budget = pn->arena.budget() / pn->share;
         int c0 = 0, rc = QA_OK;
         while (c0 < n_chain) {
             size_t need = (size_t)1 << 20;

@@ -1,6 +1,8 @@
 // panel.hip -- library state, error reporting and panel upload.
 #include "panel.hpp"
 
+#include <mutex>
+
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -55,9 +57,11 @@ static int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, in
 
 struct ProfileSlot { double ms = 0, bytes = 0; long long launches = 0; };
 static ProfileSlot g_profile[PK_COUNT];
+static std::mutex g_profile_mutex;   // several host threads (one panel handle each) may share the device
 
 void profile_add(int kernel, double ms, double alg_bytes) {
     if (kernel < 0 || kernel >= PK_COUNT) return;
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
     g_profile[kernel].ms += ms;
     g_profile[kernel].bytes += alg_bytes;
     g_profile[kernel].launches += 1;
@@ -68,12 +72,14 @@ void profile_add(int kernel, double ms, double alg_bytes) {
 extern "C" {
 
 int qa_profile_reset(void) {
+    std::lock_guard<std::mutex> lock(qa::g_profile_mutex);
     for (auto &s : qa::g_profile) s = qa::ProfileSlot();
     return QA_OK;
 }
 
 int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_bytes) {
     if (kernel < 0 || kernel >= qa::PK_COUNT) return QA_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(qa::g_profile_mutex);
     if (ms) *ms = qa::g_profile[kernel].ms;
     if (launches) *launches = qa::g_profile[kernel].launches;
     if (alg_bytes) *alg_bytes = qa::g_profile[kernel].bytes;
@@ -207,6 +213,15 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
 }
 
 void qa_panel_destroy(qa_panel_t *panel) { delete panel; }
+
+int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers) {
+    if (!panel || n_sharers < 1 || n_sharers > 16) {
+        qa::set_error("qa_panel_set_device_share: n_sharers must be 1..16");
+        return QA_ERR_INVALID;
+    }
+    panel->share = n_sharers;
+    return QA_OK;
+}
 
 int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits) {
     if (!panel || (bits != 32 && bits != 64)) {

@@ -25,6 +25,7 @@ struct qa_panel {
     qa::DBuf<double> sigma;     // G - 1
     qa::DBuf<double> IE;        // only when the caller's distinctHapsIE is not the (B, eps) expansion
     bool ie_derived = true;
+    int share = 1;              // host threads / panel handles sharing this device (qa_panel_set_device_share)
     bool rank_fp64 = true;      // best-haplotype lists from fp64-state passes (qa_panel_set_ranking_precision)
     int n_special = 0;
     std::vector<double> h_sigma, h_tm1;  // transMatRate_t rows 0 and 1 as passed

@@ -54,7 +54,7 @@ def lib() -> C.CDLL:
         for name in ("qa_abi_version", "qa_device_count", "qa_set_device", "qa_panel_create", "qa_gibbs_batch",
                  "qa_rcpp_make_eMatRead_t", "qa_profile_reset", "qa_profile_get", "qa_fullpass_reads_batch",
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
-                     "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision"):
+                     "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share"):
             getattr(L, name).restype = C.c_int
         L.qa_panel_destroy.restype = None
         _lib = L
@@ -115,6 +115,10 @@ class DevicePanel:
         """64 (default): best-haplotype lists from fp64-state passes (the reference's arithmetic); 32: from the
         fp32-state pass (faster; near-ties may be ordered differently)."""
         check(lib().qa_panel_set_ranking_precision(self.handle, C.c_int32(bits)))
+
+    def set_device_share(self, n_sharers: int):
+        """This handle is one of ``n_sharers`` working on the device concurrently (one per host thread)."""
+        check(lib().qa_panel_set_device_share(self.handle, C.c_int32(n_sharers)))
 
     def close(self):
         if self.handle:

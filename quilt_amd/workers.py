@@ -1,0 +1,74 @@
+"""Several host threads per GPU, each with its own device panel handle, stream, arena and Driver.
+
+The per-sample driver alternates device phases (Gibbs launches, full-panel passes) with host phases (marshalling, the
+R-level logic between the native calls: haplotype re-selection, consensus labels).  One thread leaves the GPU idle
+during its host phases; with two, one thread's kernels run while the other is on the host (the ctypes calls release the
+GIL), and their Gibbs launches -- serial chains, one wave per SIMD -- fill the device together.  Samples are independent
+and every chain owns its random stream, so the results do not depend on the split (reference: mclapply over
+sampleRanges, quilt.R:691-692).
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Iterable, List, Optional, Tuple
+
+from .driver import Driver, DriverParams, HipBackend
+from .native import DevicePanel
+from .sharding import get_sample_range
+
+
+class DeviceWorkers:
+    def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2):
+        self.n = n_workers
+        self.devs = [DevicePanel(panel) for _ in range(n_workers)]
+        for d in self.devs:
+            d.set_device_share(n_workers)
+        self.drivers = [Driver(panel, HipBackend(d), params) for d in self.devs]
+
+    @property
+    def timing(self):
+        keys = self.drivers[0].timing.keys()
+        return {k: sum(d.timing[k] for d in self.drivers) for k in keys}
+
+    def reset_timing(self):
+        for d in self.drivers:
+            d.timing = {k: 0.0 for k in d.timing}
+
+    def close(self):
+        for d in self.devs:
+            d.close()
+
+    def run_stream(self, batches: Iterable[Tuple[list, int]]):
+        """Like Driver.run_stream: yields one list of SampleResult per batch, in order.  Each batch is cut into
+        contiguous parts, one per worker thread; every worker pipelines its own parts."""
+        batches = list(batches)
+        outs = [queue.Queue() for _ in range(self.n)]
+
+        def work(w: int):
+            def parts():
+                for samples, offset in batches:
+                    lo, hi = get_sample_range(len(samples), self.n)[w]
+                    yield samples[lo:hi], offset + lo
+            try:
+                for res in self.drivers[w].run_stream(p for p in parts() if len(p[0]) > 0):
+                    outs[w].put(res)
+            except BaseException as e:   # surfaced by the consumer
+                outs[w].put(e)
+
+        threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(self.n)]
+        for t in threads:
+            t.start()
+        for samples, _ in batches:
+            merged: List = []
+            for w in range(self.n):
+                lo, hi = get_sample_range(len(samples), self.n)[w]
+                if hi <= lo:
+                    continue
+                res = outs[w].get()
+                if isinstance(res, BaseException):
+                    raise res
+                merged.extend(res)
+            yield merged
+        for t in threads:
+            t.join()
