@@ -231,6 +231,16 @@ __device__ __forceinline__ void store_col(const Col<NE> &c, double *dst, int t, 
     for (int i = 0; i < NE; i++) dst[t + NT * i] = c.v[i];
 }
 
+// 1 / e to within 1 ulp: v_rcp_f64 and two Newton steps (5 instructions; an IEEE division expands to ~15).  The
+// sampler takes a read's emission out of a label with it -- x * (1 / e) where the reference writes x / e: the two can
+// differ in the last bit, 1e-16 relative, against sampling thresholds compared with a 53-bit uniform.
+__device__ __forceinline__ double fast_rcp(double e) {
+    double r = __builtin_amdgcn_rcp(e);
+    r = __builtin_fma(__builtin_fma(-e, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-e, r, 1.0), r, r);
+    return r;
+}
+
 __device__ __forceinline__ double rl_f64(double v, int j) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
@@ -689,6 +699,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     grid_started = true;
                 }
                 double pA1[2] = {pC[0], pC[1]};
+                Col<NE> ri;   // 1 / er (normal reads)
                 if (normal) {
                     h_rC = rl_i32(rs.H, jr) - 1;
                     h_rA1 = 1 - h_rC;
@@ -696,11 +707,13 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     // algebraically the same sums: test-unit-gibbs-diploid.R:114-124)
                     double s[2] = {0, 0};
 #pragma unroll
-                    for (int i = 0; i < NE; i++) {
-                        const double xc = (h_rC == 0) ? ab[0].v[i] : ab[1].v[i];
-                        const double xa = (h_rC == 0) ? ab[1].v[i] : ab[0].v[i];
-                        s[0] += xc / er.v[i];
-                        s[1] += xa * er.v[i];
+                    for (int i = 0; i < NE; i++) ri.v[i] = fast_rcp(er.v[i]);
+                    if (h_rC == 0) {   // wave-uniform: two straight-line versions instead of per-element selects
+#pragma unroll
+                        for (int i = 0; i < NE; i++) { s[0] += ab[0].v[i] * ri.v[i]; s[1] += ab[1].v[i] * er.v[i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) { s[0] += ab[1].v[i] * ri.v[i]; s[1] += ab[0].v[i] * er.v[i]; }
                     }
                     ch.template bsum<2>(s);
                     pA1[h_rC] = s[0];     // the current label loses the read
@@ -729,14 +742,21 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 if (((h_rN != h_rC) || ginit) && !pass) {
                     changed = true;
                     if (lane == jr) rs.H = h_rN + 1;
+                    if (normal) {
+                        if (h_rC == 0) {
 #pragma unroll
-                    for (int i = 0; i < NE; i++) {
-                        if (normal) {
-                            if (h_rC == 0) { a[0].v[i] /= er.v[i]; ab[0].v[i] /= er.v[i]; e[0].v[i] /= er.v[i]; }
-                            else { a[1].v[i] /= er.v[i]; ab[1].v[i] /= er.v[i]; e[1].v[i] /= er.v[i]; }
+                            for (int i = 0; i < NE; i++) { a[0].v[i] *= ri.v[i]; ab[0].v[i] *= ri.v[i]; e[0].v[i] *= ri.v[i]; }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NE; i++) { a[1].v[i] *= ri.v[i]; ab[1].v[i] *= ri.v[i]; e[1].v[i] *= ri.v[i]; }
                         }
-                        if (h_rN == 0) { a[0].v[i] *= er.v[i]; ab[0].v[i] *= er.v[i]; e[0].v[i] *= er.v[i]; }
-                        else { a[1].v[i] *= er.v[i]; ab[1].v[i] *= er.v[i]; e[1].v[i] *= er.v[i]; }
+                    }
+                    if (h_rN == 0) {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) { a[0].v[i] *= er.v[i]; ab[0].v[i] *= er.v[i]; e[0].v[i] *= er.v[i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) { a[1].v[i] *= er.v[i]; ab[1].v[i] *= er.v[i]; e[1].v[i] *= er.v[i]; }
                     }
                     if (normal || h_rN == 1) { pC[0] = pA1[0]; pC[1] = pA1[1]; }
                 }
