@@ -158,6 +158,15 @@ def main():
             prof.append(dict(kernel=KERNEL_NAMES[k], ms=ms.value, launches=n.value, alg_bytes=b.value))
         dom = max(prof, key=lambda p: p["ms"])
         ach = dom["alg_bytes"] / 1e9 / (dom["ms"] / 1e3) if dom["ms"] > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same workload
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, scripts/pmc_summary.py), else null
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if f"--batch {a.batch} " in pmc["command"] + " " and f"--workers {a.workers} " in pmc["command"] + " ":
+                traffic = pmc["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         truth = samples[-1][0].truth_haps.sum(axis=0)
         r2_truth = float(np.corrcoef(last[0].dosage, truth)[0, 1] ** 2)
         value = a.batch * world * a.steps / elapsed
@@ -174,7 +183,7 @@ def main():
                        "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
                                       "GPU, consecutive batches pipelined"},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
                          "alg_bytes_per_launch": dom["alg_bytes"] / max(dom["launches"], 1)},
             "kernels": [{"kernel": p["kernel"], "ms": round(p["ms"], 2), "launches": p["launches"],
