@@ -136,79 +136,86 @@ __device__ __forceinline__ uint32_t panel_word(const GibbsParams &p, int g, int 
 
 // ---------------------------------------------------------------------------------------------
 // k_ematread: P(read r | small-panel haplotype k) (gibbs-small.cpp:148-263).  One wave per
-// (read, chain); lane l owns rows l, l+64, ...  Products run over the read's bases in order, so each
-// entry is bit-identical to the reference's; then divide by the column max and floor (:235-262).
+// (block of kReadsPerWave consecutive reads, chain); lane l owns rows l, l+64, ...  The chain's haplotype
+// list and the panel words of the current grid stay in registers across the block's reads (reads are sorted
+// by grid).  Products run over the read's bases in order, so each entry is bit-identical to the
+// reference's; then divide by the column max and floor (:235-262).
 // ---------------------------------------------------------------------------------------------
+constexpr int kReadsPerWave = 32;
+
 template <int NE>
 __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
     const int c = blockIdx.y, lane = threadIdx.x;
     const int R = p.read_off[c + 1] - p.read_off[c];
-    const int r = blockIdx.x;
-    if (r >= R) return;
+    const int r0 = blockIdx.x * kReadsPerWave;
+    if (r0 >= R) return;
     const int32_t *rp = p.read_ptr + p.read_off[c] + c;
     const int32_t *u = p.u + p.base_off[c], *bq = p.bq + p.base_off[c];
     const int32_t *which = p.which + (size_t)c * p.Ks;
     int kk[NE];
-    double v[NE];
 #pragma unroll
     for (int i = 0; i < NE; i++) {
         const int k = lane + 64 * i;
         kk[i] = (k < p.Ks) ? which[k] : -1;
-        v[i] = 1.0;
     }
-    const int s = rp[r];
-    int J = rp[r + 1] - s - 1;
-    if (J >= p.Jmax) J = p.Jmax;
     int g_prev = -1;
     uint32_t w[NE];
-    for (int j = 0; j <= J; j++) {
-        const int b = bq[s + j];
-        const int snp = u[s + j];
-        const int g = snp >> 5;
-        if (g != g_prev) {
+    for (int r = r0; r < min(r0 + kReadsPerWave, R); r++) {
+        double v[NE];
+#pragma unroll
+        for (int i = 0; i < NE; i++) v[i] = 1.0;
+        const int s = rp[r];
+        int J = rp[r + 1] - s - 1;
+        if (J >= p.Jmax) J = p.Jmax;
+        for (int j = 0; j <= J; j++) {
+            const int b = bq[s + j];
+            const int snp = u[s + j];
+            const int g = snp >> 5;
+            if (g != g_prev) {
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    w[i] = 0;
+                    if (kk[i] >= 0) w[i] = panel_word(p, g, kk[i], p.hm[(size_t)g * p.Kp + kk[i]]);
+                }
+                g_prev = g;
+            }
+            if (b == 0) continue;  // no base quality seen yet: factor 1 (host folded the carry-over rule)
+            const int ab = b < 0 ? -b : b;
+            const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
 #pragma unroll
             for (int i = 0; i < NE; i++) {
-                w[i] = 0;
-                if (kk[i] >= 0) w[i] = panel_word(p, g, kk[i], p.hm[(size_t)g * p.Kp + kk[i]]);
-            }
-            g_prev = g;
-        }
-        if (b == 0) continue;  // no base quality seen yet: factor 1 (host folded the carry-over rule)
-        const int ab = b < 0 ? -b : b;
-        const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
-#pragma unroll
-        for (int i = 0; i < NE; i++) {
-            const double e = ((w[i] >> (snp & 31)) & 1u) ? 1 - p.ref_error : p.ref_error;
-            v[i] *= (e * pA + (1 - e) * pR);
-        }
-    }
-    if (p.rescale) {
-        double x = 0;
-#pragma unroll
-        for (int i = 0; i < NE; i++) if (kk[i] >= 0 && v[i] > x) x = v[i];
-        x = wmax(x);
-        const double d1 = 1 / x;
-        if (isinf(x) || x == 0 || isinf(d1)) {
-#pragma unroll
-            for (int i = 0; i < NE; i++) v[i] = 1;
-        } else {
-#pragma unroll
-            for (int i = 0; i < NE; i++) {
-                v[i] *= d1;
-                if (v[i] < p.inv_maxdiff) v[i] = p.inv_maxdiff;
+                const double e = ((w[i] >> (snp & 31)) & 1u) ? 1 - p.ref_error : p.ref_error;
+                v[i] *= (e * pA + (1 - e) * pR);
             }
         }
+        if (p.rescale) {
+            double x = 0;
+#pragma unroll
+            for (int i = 0; i < NE; i++) if (kk[i] >= 0 && v[i] > x) x = v[i];
+            x = wmax(x);
+            const double d1 = 1 / x;
+            if (isinf(x) || x == 0 || isinf(d1)) {
+#pragma unroll
+                for (int i = 0; i < NE; i++) v[i] = 1;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    v[i] *= d1;
+                    if (v[i] < p.inv_maxdiff) v[i] = p.inv_maxdiff;
+                }
+            }
+        }
+        // category 1 (gibbs-nipt.cpp:350-372): no entry below 1 - 1e-12
+        const double thresh = 1 - 1e-12;
+        bool below = false;
+#pragma unroll
+        for (int i = 0; i < NE; i++) if (kk[i] >= 0 && v[i] < thresh) below = true;
+        const bool any_below = __any(below);
+        double *out = p.eMatRead + p.eread_off[c] + (size_t)r * p.Ksp;
+#pragma unroll
+        for (int i = 0; i < NE; i++) out[lane + 64 * i] = (kk[i] >= 0) ? v[i] : 1.0;
+        if (lane == 0) p.is_cat1[p.read_off[c] + r] = (any_below || p.disable_read_category_usage) ? 0 : 1;
     }
-    // category 1 (gibbs-nipt.cpp:350-372): no entry below 1 - 1e-12
-    const double thresh = 1 - 1e-12;
-    bool below = false;
-#pragma unroll
-    for (int i = 0; i < NE; i++) if (kk[i] >= 0 && v[i] < thresh) below = true;
-    const bool any_below = __any(below);
-    double *out = p.eMatRead + p.eread_off[c] + (size_t)r * p.Ksp;
-#pragma unroll
-    for (int i = 0; i < NE; i++) out[lane + 64 * i] = (kk[i] >= 0) ? v[i] : 1.0;
-    if (lane == 0) p.is_cat1[p.read_off[c] + r] = (any_below || p.disable_read_category_usage) ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1109,7 +1116,7 @@ std::vector<double> base_quality_tables() {
 
 template <int NE_READ>
 void launch_ematread(const GibbsParams &prm, int maxR, hipStream_t st) {
-    hipLaunchKernelGGL(k_ematread<NE_READ>, dim3(maxR, prm.C), dim3(64), 0, st, prm);
+    hipLaunchKernelGGL(k_ematread<NE_READ>, dim3((maxR + kReadsPerWave - 1) / kReadsPerWave, prm.C), dim3(64), 0, st, prm);
     QA_HIP(hipGetLastError());
 }
 
