@@ -675,11 +675,11 @@ template <bool ADD>
 __device__ __forceinline__ double emit_chunk(double (&x)[16], const uint4 &d, const double *et, double addend, bool has_sp,
                                              const PassParams &prm, const double *esp, int g, int k0, int tail) {
     const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+    double e[16];   // the 16 table look-ups first, back to back, then the arithmetic
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-        x[i] = ADD ? (x[i] + addend) * et[code] : x[i] * et[code];
-    }
+    for (int i = 0; i < 16; i++) e[i] = et[(w[i >> 2] >> ((i & 3) * 8)) & 0xffu];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = ADD ? (x[i] + addend) * e[i] : x[i] * e[i];
     if (has_sp && k0 < prm.K && any_zero_code(d)) {   // rare
         int lo = prm.sp_off[g], hi = prm.sp_off[g + 1];
         const int first = lo;
@@ -701,10 +701,10 @@ __device__ __forceinline__ double emit_chunk(double (&x)[16], const uint4 &d, co
 #pragma unroll
         for (int i = 0; i < 16; i++) x[i] = i < tail ? x[i] : 0.0;
     }
-    double sum = 0;
+    double s4[4] = {0, 0, 0, 0};   // four independent partial sums: a 16-long dependent chain of fp64 adds would stall
 #pragma unroll
-    for (int i = 0; i < 16; i++) sum += x[i];
-    return sum;
+    for (int i = 0; i < 16; i++) s4[i & 3] += x[i];
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
 template <int NR, int NL>
