@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -37,6 +38,88 @@ struct HipError : std::runtime_error {
         }                                                                                    \
     } while (0)
 
+// Host <-> device transfers go through a pinned, device-visible staging buffer (one per host thread) and are carried
+// out by k_stage_copy below, a copy kernel with one-wave workgroups.  The runtime's own copies (pageable or pinned
+// alike in this environment) are blit kernels with 512-thread workgroups, and those cannot be placed on a CU while Gibbs
+// waves hold the register files of two of its SIMDs: a 100 MB upload then waits for the other host thread's whole
+// Gibbs launch (0.6 s, seen in the rocprofv3 trace of round 1).  One-wave workgroups fit on the SIMDs left free.
+template <typename V>
+static __global__ __launch_bounds__(64) void k_stage_copy(V *dst, const V *src, size_t n, const unsigned char *src_tail,
+                                                          unsigned char *dst_tail, int n_tail) {
+    const size_t stride = (size_t)gridDim.x * 64;
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+template <typename V>
+inline void stage_copy_as(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    const size_t n = bytes / sizeof(V);
+    const int n_tail = (int)(bytes - n * sizeof(V));
+    const int blocks = (int)std::min<size_t>(std::max<size_t>((n + 63) / 64, 1), 2048);
+    hipLaunchKernelGGL(k_stage_copy<V>, dim3(blocks), dim3(64), 0, s, static_cast<V *>(dst), static_cast<const V *>(src), n,
+                       static_cast<const unsigned char *>(src) + n * sizeof(V), static_cast<unsigned char *>(dst) + n * sizeof(V),
+                       n_tail);
+}
+inline void stage_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src);
+    if ((a & 15) == 0) stage_copy_as<uint4>(dst, src, bytes, s);
+    else if ((a & 7) == 0) stage_copy_as<uint2>(dst, src, bytes, s);
+    else if ((a & 3) == 0) stage_copy_as<uint32_t>(dst, src, bytes, s);
+    else stage_copy_as<unsigned char>(dst, src, bytes, s);
+}
+struct PinnedStage {
+    char *p = nullptr;
+    size_t cap = 0;
+    ~PinnedStage() { if (p) (void)hipHostFree(p); }
+    char *get(size_t bytes) {
+        if (bytes > cap) {
+            if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+            const size_t want = std::max<size_t>(bytes, size_t(64) << 20);
+            if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return nullptr; }
+            cap = want;
+        }
+        return p;
+    }
+};
+inline PinnedStage &pinned_stage() {
+    thread_local PinnedStage s;
+    return s;
+}
+constexpr size_t kStagePiece = size_t(64) << 20;
+
+// host -> device; complete (stream-synchronised) on return
+inline void staged_upload(void *dev, const void *host, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    char *stage = pinned_stage().get(std::min(bytes, kStagePiece));
+    if (!stage) {   // no pinned memory: fall back to the runtime's own path
+        QA_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    for (size_t off = 0; off < bytes; off += kStagePiece) {
+        const size_t n = std::min(kStagePiece, bytes - off);
+        memcpy(stage, static_cast<const char *>(host) + off, n);
+        stage_copy(static_cast<char *>(dev) + off, stage, n, s);
+        QA_HIP(hipGetLastError());
+        QA_HIP(hipStreamSynchronize(s));
+    }
+}
+// device -> host, after everything queued on the stream; complete on return
+inline void staged_download(void *host, const void *dev, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    char *stage = pinned_stage().get(std::min(bytes, kStagePiece));
+    if (!stage) {
+        QA_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+        QA_HIP(hipStreamSynchronize(s));
+        return;
+    }
+    for (size_t off = 0; off < bytes; off += kStagePiece) {
+        const size_t n = std::min(kStagePiece, bytes - off);
+        stage_copy(stage, static_cast<const char *>(dev) + off, n, s);
+        QA_HIP(hipGetLastError());
+        QA_HIP(hipStreamSynchronize(s));
+        memcpy(static_cast<char *>(host) + off, stage, n);
+    }
+}
+
 // RAII device buffer
 template <typename T>
 struct DBuf {
@@ -63,12 +146,8 @@ struct DBuf {
         p = nullptr;
         n = 0;
     }
-    void upload(const T *h, size_t cnt, hipStream_t s = nullptr) {
-        if (cnt) QA_HIP(hipMemcpyAsync(p, h, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-    }
-    void download(T *h, size_t cnt, hipStream_t s = nullptr) const {
-        if (cnt) QA_HIP(hipMemcpyAsync(h, p, cnt * sizeof(T), hipMemcpyDeviceToHost, s));
-    }
+    void upload(const T *h, size_t cnt, hipStream_t s = nullptr) { staged_upload(p, h, cnt * sizeof(T), s); }
+    void download(T *h, size_t cnt, hipStream_t s = nullptr) const { staged_download(h, p, cnt * sizeof(T), s); }
     void zero(hipStream_t s = nullptr) {
         if (n) QA_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
     }
@@ -117,12 +196,8 @@ struct ABuf {
         n = n_;
         p = n ? static_cast<T *>(arena->take(n * sizeof(T))) : nullptr;
     }
-    void upload(const T *h, size_t cnt, hipStream_t s = nullptr) {
-        if (cnt) QA_HIP(hipMemcpyAsync(p, h, cnt * sizeof(T), hipMemcpyHostToDevice, s));
-    }
-    void download(T *h, size_t cnt, hipStream_t s = nullptr) const {
-        if (cnt) QA_HIP(hipMemcpyAsync(h, p, cnt * sizeof(T), hipMemcpyDeviceToHost, s));
-    }
+    void upload(const T *h, size_t cnt, hipStream_t s = nullptr) { staged_upload(p, h, cnt * sizeof(T), s); }
+    void download(T *h, size_t cnt, hipStream_t s = nullptr) const { staged_download(h, p, cnt * sizeof(T), s); }
 };
 
 // translate exceptions at the C boundary

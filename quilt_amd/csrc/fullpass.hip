@@ -1527,11 +1527,20 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     // ---- copy results back
     if (out.c) S.c.download(out.c, (size_t)P * G, st);
     if (out.dosage) {
-        for (int p = 0; p < P; p++)
-            if (h_flags[p] & 1)
-                QA_HIP(hipMemcpyAsync(out.dosage + (size_t)(out.dosage_rows ? out.dosage_rows[p] : p) * T,
-                                      S.dosage.p + (size_t)p * T, sizeof(double) * T,
-                                      hipMemcpyDeviceToHost, st));
+        // runs of consecutive dosage passes come back in one staged transfer each, then scatter to their rows
+        const int max_rows = std::max<int>(1, (int)(qa::kStagePiece / (sizeof(double) * T)));
+        std::vector<double> tmp;
+        for (int p = 0; p < P;) {
+            if (!(h_flags[p] & 1)) { p++; continue; }
+            int n = 1;
+            while (p + n < P && n < max_rows && (h_flags[p + n] & 1)) n++;
+            tmp.resize((size_t)n * T);
+            qa::staged_download(tmp.data(), S.dosage.p + (size_t)p * T, sizeof(double) * T * n, st);
+            for (int i = 0; i < n; i++)
+                memcpy(out.dosage + (size_t)(out.dosage_rows ? out.dosage_rows[p + i] : p + i) * T, tmp.data() + (size_t)i * T,
+                       sizeof(double) * T);
+            p += n;
+        }
     }
     auto unpermute_to_host = [&](const char *base, size_t elem_off, int cols, double *dst) {
         S.unperm.ensure((size_t)K * cols);
@@ -1585,12 +1594,10 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         val.resize(n * top_cap);
         S.top_idx.download(idx.data(), idx.size(), st);
         if (f64) {
-            QA_HIP(hipMemcpyAsync(val.data(), S.top_val.p, val.size() * 8, hipMemcpyDeviceToHost, st));
-            QA_HIP(hipStreamSynchronize(st));
+            qa::staged_download(val.data(), S.top_val.p, val.size() * 8, st);
         } else {
             std::vector<float> v32(val.size());
-            QA_HIP(hipMemcpyAsync(v32.data(), S.top_val.p, v32.size() * 4, hipMemcpyDeviceToHost, st));
-            QA_HIP(hipStreamSynchronize(st));
+            qa::staged_download(v32.data(), S.top_val.p, v32.size() * 4, st);
             for (size_t i = 0; i < val.size(); i++) val[i] = v32[i];
         }
         for (size_t i = 0; out.lists && i < n; i++) {

@@ -1253,8 +1253,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
             S.runif_reads.ensure(1);
             S.seeds.ensure((size_t)2 * C);
             S.seeds.upload(seed_reads, C, st);
-            QA_HIP(hipMemcpyAsync(S.seeds.p + C, seed_shard ? seed_shard : seed_reads, sizeof(uint64_t) * C,
-                                  hipMemcpyHostToDevice, st));
+            qa::staged_upload(S.seeds.p + C, seed_shard ? seed_shard : seed_reads, sizeof(uint64_t) * C, st);
         }
         const size_t nshard = (size_t)C * std::max(o->n_block_gibbs_iterations, 1) * std::max(G - 1, 1);
         S.runif_shard.ensure(nshard);
