@@ -55,6 +55,10 @@ int qa_set_device(int device);
  * those launches. */
 int qa_profile_reset(void);
 int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_bytes);
+/* Device time during which at least one launch of the kernel was running (ms, union of the launch intervals over all
+ * streams): with several host threads the per-launch times of concurrent launches overlap, and the aggregate rate of a
+ * kernel is alg_bytes / busy time. */
+int qa_profile_get_busy(int32_t kernel, double *busy_ms);
 
 /* ---- prepared reference panel (upload once per process) ------------------ */
 

@@ -21,7 +21,8 @@ bool device_ready();
 
 // per-kernel accumulators (HIP-event time on the launch stream, launches, algorithmic HBM bytes)
 enum ProfileKernel { PK_EMAT = 0, PK_FWD, PK_BWD, PK_POST, PK_EMATREAD, PK_GIBBS, PK_HAPPROBS, PK_FWD64, PK_BWD64, PK_COUNT };
-void profile_add(int kernel, double ms, double alg_bytes);
+void profile_add(int kernel, double ms, double alg_bytes, double start_ms = -1);
+double profile_clock_ms(hipEvent_t completed_event);
 
 struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;

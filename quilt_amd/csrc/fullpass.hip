@@ -1518,10 +1518,11 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         }
         const double frac = G > 0 ? (double)n_thin / G : 0;
         const double per_dir = cells_all * (1.0 + es) + cells_thin * (1.0 + es * frac);
-        qa::profile_add(qa::PK_EMAT, g_timing[0], 0);
-        qa::profile_add(f64 ? qa::PK_FWD64 : qa::PK_FWD, g_timing[1], per_dir);
-        qa::profile_add(f64 ? qa::PK_BWD64 : qa::PK_BWD, g_timing[2], per_dir);
-        qa::profile_add(qa::PK_POST, g_timing[3], 0);
+        const double t_e = qa::profile_clock_ms(S.ev[0]);
+        qa::profile_add(qa::PK_EMAT, g_timing[0], 0, t_e);
+        qa::profile_add(f64 ? qa::PK_FWD64 : qa::PK_FWD, g_timing[1], per_dir, t_e + g_timing[0]);
+        qa::profile_add(f64 ? qa::PK_BWD64 : qa::PK_BWD, g_timing[2], per_dir, t_e + g_timing[0] + g_timing[1]);
+        qa::profile_add(qa::PK_POST, g_timing[3], 0, t_e + g_timing[0] + g_timing[1] + g_timing[2]);
     }
 
     // ---- copy results back

@@ -1313,9 +1313,10 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
             const double col = 2.0 * Ks * (double)G * 48.0;
             const double sweeps = (double)n_its * (C * col + (double)totR * Ks * 8.0) +
                                   (1.0 + 2.0 * prm.n_block) * C * col;
-            qa::profile_add(qa::PK_EMATREAD, ms[0], (double)totR * Ks * 8.0);
-            qa::profile_add(qa::PK_GIBBS, ms[1], sweeps);
-            qa::profile_add(qa::PK_HAPPROBS, ms[2], C * 2.0 * Ks * (double)G * 16.0);
+            const double t_e = qa::profile_clock_ms(g_gibbs->ev[0]);
+            qa::profile_add(qa::PK_EMATREAD, ms[0], (double)totR * Ks * 8.0, t_e);
+            qa::profile_add(qa::PK_GIBBS, ms[1], sweeps, t_e + ms[0]);
+            qa::profile_add(qa::PK_HAPPROBS, ms[2], C * 2.0 * Ks * (double)G * 16.0, t_e + ms[0] + ms[1]);
         }
         int rc = QA_OK;
         for (int c = 0; c < C; c++) {

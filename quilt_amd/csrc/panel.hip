@@ -55,16 +55,36 @@ static int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, in
     return mat[(size_t)nrow + s1];
 }
 
-struct ProfileSlot { double ms = 0, bytes = 0; long long launches = 0; };
+struct ProfileSlot {
+    double ms = 0, bytes = 0;
+    long long launches = 0;
+    std::vector<std::pair<double, double>> busy;   // [start, end) of every launch, ms since the process's reference event
+};
 static ProfileSlot g_profile[PK_COUNT];
 static std::mutex g_profile_mutex;   // several host threads (one panel handle each) may share the device
 
-void profile_add(int kernel, double ms, double alg_bytes) {
+static hipEvent_t g_ref_event = nullptr;
+
+// ms between the process-wide reference event and a completed event (any stream)
+double profile_clock_ms(hipEvent_t ev) {
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    if (!g_ref_event) {
+        if (hipEventCreate(&g_ref_event) != hipSuccess) return 0;
+        (void)hipEventRecord(g_ref_event, nullptr);
+        (void)hipEventSynchronize(g_ref_event);
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g_ref_event, ev) != hipSuccess) return 0;
+    return ms;
+}
+
+void profile_add(int kernel, double ms, double alg_bytes, double start_ms) {
     if (kernel < 0 || kernel >= PK_COUNT) return;
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     g_profile[kernel].ms += ms;
     g_profile[kernel].bytes += alg_bytes;
     g_profile[kernel].launches += 1;
+    if (start_ms >= 0) g_profile[kernel].busy.emplace_back(start_ms, start_ms + ms);
 }
 
 }  // namespace qa
@@ -83,6 +103,21 @@ int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_by
     if (ms) *ms = qa::g_profile[kernel].ms;
     if (launches) *launches = qa::g_profile[kernel].launches;
     if (alg_bytes) *alg_bytes = qa::g_profile[kernel].bytes;
+    return QA_OK;
+}
+
+int qa_profile_get_busy(int32_t kernel, double *busy_ms) {
+    if (kernel < 0 || kernel >= qa::PK_COUNT || !busy_ms) return QA_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(qa::g_profile_mutex);
+    auto iv = qa::g_profile[kernel].busy;
+    std::sort(iv.begin(), iv.end());
+    double tot = 0, cs = 0, ce = -1;
+    for (auto &x : iv) {
+        if (x.first > ce) { if (ce > cs) tot += ce - cs; cs = x.first; ce = x.second; }
+        else ce = std::max(ce, x.second);
+    }
+    if (ce > cs) tot += ce - cs;
+    *busy_ms = tot;
     return QA_OK;
 }
 

@@ -54,7 +54,7 @@ def lib() -> C.CDLL:
         for name in ("qa_abi_version", "qa_device_count", "qa_set_device", "qa_panel_create", "qa_gibbs_batch",
                  "qa_rcpp_make_eMatRead_t", "qa_profile_reset", "qa_profile_get", "qa_fullpass_reads_batch",
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
-                     "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share"):
+                     "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy"):
             getattr(L, name).restype = C.c_int
         L.qa_panel_destroy.restype = None
         _lib = L

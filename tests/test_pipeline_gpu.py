@@ -116,3 +116,18 @@ def test_two_host_threads_share_the_device(medium_panel):
             assert np.array_equal(g.read_labels, r.read_labels)
             assert np.abs(g.dosage - r.dosage).max() <= 1e-6
     dev.close()
+
+
+def test_pipeline_ont_reads(medium_panel):
+    """BASELINE configs[3] in small: long noisy reads (hundreds of SNPs each, Jmax path, reads spanning many grids)
+    through the whole driver, GPU vs the same driver on the oracle."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=4000 + i, mode="ont", n_reads=40) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=200, Knew=200, seed=17)
+    got, ref = _run_both(panel, samples, prm)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.read_labels, r.read_labels)
+        assert np.abs(g.dosage - r.dosage).max() <= 1e-4
+        assert r2(g.dosage, r.dosage) >= 0.999
