@@ -504,8 +504,8 @@ __device__ void backward_both(Chain<NE, NW> &ch) {
     }
 }
 
-template <int NE, int NW>
-__global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
+template <int NE, int NW, bool kLean>
+__device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
     __shared__ double s_red[2 * NW * 4];
     const int c = blockIdx.x, t = threadIdx.x;
     using CH = Chain<NE, NW>;
@@ -619,9 +619,11 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
             }
             const int jg = g & 63;
             const bool has = rl_i32(gs.has, jg) != 0;
-            // next grid's eMatGrid and beta columns: issued now, used after this grid's reads
-            Col<NE> en[2], bn[2];
-            {
+            // next grid's eMatGrid and beta columns: issued now, used after this grid's reads -- unless the chain is
+            // to stay within 256 registers so that two chains share a SIMD (kLean): then they are loaded at the grid
+            // boundary and the other chain's wave covers the round trip
+            Col<kLean ? 1 : NE> en[2], bn[2];
+            if constexpr (!kLean) {
                 const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: loads stay unconditional
                 ch.ld(en[0], ch.eg[0] + gn);
                 ch.ld(en[1], ch.eg[1] + gn);
@@ -674,7 +676,6 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
             }
             // ---- sample_reads_in_grid (:733-1295), diploid: labels 0 / 1, the third label has prior 0, pC(2) = 1
             bool grid_started = false, changed = false;
-            Col<NE> ab[2];
             double pC[2] = {1, 1};
             int h_rC = 0, h_rA1 = 1;
             bool normal = false, ginit = false, pass = false;
@@ -696,13 +697,14 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 else if (first_read <= r && it == 0) { pass = false; ginit = true; }
                 else if (r < first_read && it == 1) { pass = false; ginit = true; }
                 else { ginit = false; normal = true; }
+                // alpha * beta of the current grid is formed where it is summed (holding it in registers, as the
+                // reference's ab_m does, costs 4 * NE registers per lane)
                 if (!grid_started) {
+                    double s[2] = {0, 0};
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-#pragma unroll
-                        for (int i = 0; i < NE; i++) ab[h].v[i] = a[h].v[i] * bt[h].v[i];
-                    }
-                    ch.sum_col2(ab[0], ab[1], pC[0], pC[1]);
+                    for (int i = 0; i < NE; i++) { s[0] += a[0].v[i] * bt[0].v[i]; s[1] += a[1].v[i] * bt[1].v[i]; }
+                    ch.template bsum<2>(s);
+                    pC[0] = s[0]; pC[1] = s[1];
                     grid_started = true;
                 }
                 double pA1[2] = {pC[0], pC[1]};
@@ -717,10 +719,16 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     for (int i = 0; i < NE; i++) ri.v[i] = fast_rcp(er.v[i]);
                     if (h_rC == 0) {   // wave-uniform: two straight-line versions instead of per-element selects
 #pragma unroll
-                        for (int i = 0; i < NE; i++) { s[0] += ab[0].v[i] * ri.v[i]; s[1] += ab[1].v[i] * er.v[i]; }
+                        for (int i = 0; i < NE; i++) {
+                            s[0] += (a[0].v[i] * bt[0].v[i]) * ri.v[i];
+                            s[1] += (a[1].v[i] * bt[1].v[i]) * er.v[i];
+                        }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < NE; i++) { s[0] += ab[1].v[i] * ri.v[i]; s[1] += ab[0].v[i] * er.v[i]; }
+                        for (int i = 0; i < NE; i++) {
+                            s[0] += (a[1].v[i] * bt[1].v[i]) * ri.v[i];
+                            s[1] += (a[0].v[i] * bt[0].v[i]) * er.v[i];
+                        }
                     }
                     ch.template bsum<2>(s);
                     pA1[h_rC] = s[0];     // the current label loses the read
@@ -730,8 +738,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     double s[2] = {0, 0};
 #pragma unroll
                     for (int i = 0; i < NE; i++) {
-                        s[0] += ab[0].v[i] * er.v[i];
-                        s[1] += ab[1].v[i] * er.v[i];
+                        s[0] += (a[0].v[i] * bt[0].v[i]) * er.v[i];
+                        s[1] += (a[1].v[i] * bt[1].v[i]) * er.v[i];
                     }
                     ch.template bsum<2>(s);
                     pC[0] = s[0];
@@ -752,18 +760,18 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     if (normal) {
                         if (h_rC == 0) {
 #pragma unroll
-                            for (int i = 0; i < NE; i++) { a[0].v[i] *= ri.v[i]; ab[0].v[i] *= ri.v[i]; e[0].v[i] *= ri.v[i]; }
+                            for (int i = 0; i < NE; i++) { a[0].v[i] *= ri.v[i]; e[0].v[i] *= ri.v[i]; }
                         } else {
 #pragma unroll
-                            for (int i = 0; i < NE; i++) { a[1].v[i] *= ri.v[i]; ab[1].v[i] *= ri.v[i]; e[1].v[i] *= ri.v[i]; }
+                            for (int i = 0; i < NE; i++) { a[1].v[i] *= ri.v[i]; e[1].v[i] *= ri.v[i]; }
                         }
                     }
                     if (h_rN == 0) {
 #pragma unroll
-                        for (int i = 0; i < NE; i++) { a[0].v[i] *= er.v[i]; ab[0].v[i] *= er.v[i]; e[0].v[i] *= er.v[i]; }
+                        for (int i = 0; i < NE; i++) { a[0].v[i] *= er.v[i]; e[0].v[i] *= er.v[i]; }
                     } else {
 #pragma unroll
-                        for (int i = 0; i < NE; i++) { a[1].v[i] *= er.v[i]; ab[1].v[i] *= er.v[i]; e[1].v[i] *= er.v[i]; }
+                        for (int i = 0; i < NE; i++) { a[1].v[i] *= er.v[i]; e[1].v[i] *= er.v[i]; }
                     }
                     if (normal || h_rN == 1) { pC[0] = pA1[0]; pC[1] = pA1[1]; }
                 }
@@ -795,11 +803,23 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
                 }
             }
+            // alphaHat_t is not read again inside the call (the shard pass runs its own forward): only the state left
+            // by the last sweep is observable (hapProbs, state_out), so only that sweep writes it
+            if (last_sweep) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+                for (int h = 0; h < 2; h++) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+            }
             gs.set_c(lane, jg, cg[0], cg[1]);
-            e[0] = en[0]; e[1] = en[1];
-            bt[0] = bn[0]; bt[1] = bn[1];
+            if constexpr (kLean) {
+                const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
+                ch.ld(e[0], ch.eg[0] + gn);
+                ch.ld(e[1], ch.eg[1] + gn);
+                ch.ld(bt[0], ch.beta[0] + gn);
+                ch.ld(bt[1], ch.beta[1] + gn);
+            } else {
+                e[0] = en[0]; e[1] = en[1];
+                bt[0] = bn[0]; bt[1] = bn[1];
+            }
         }
         gs.store_c(ch);
         if (rs.base >= 0) rs.store(ch);
@@ -894,8 +914,10 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                         for (int i = 0; i < NE; i++) s_a[h].v[i] *= aa;
                     }
                 }
-                ch.st(s_a[0], ch.alpha[0] + (size_t)g * Ksp);
-                ch.st(s_a[1], ch.alpha[1] + (size_t)g * Ksp);
+                if (last_sweep) {
+                    ch.st(s_a[0], ch.alpha[0] + (size_t)g * Ksp);
+                    ch.st(s_a[1], ch.alpha[1] + (size_t)g * Ksp);
+                }
                 ss.set_c(lane, jg, cn[0], cn[1]);
                 mlc1 -= log(cn[0]);
                 mlc2 -= log(cn[1]);
@@ -944,6 +966,17 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
         }
     }
     if (t == 0) p.status[c] = status;
+}
+
+template <int NE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
+    gibbs_chain<NE, NW, false>(p);
+}
+// single-wave chains with many columns per lane, held to 256 registers so that two chains share a SIMD (2048 chains per
+// device instead of 1024)
+template <int NE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gibbs_lean(GibbsParams p) {
+    gibbs_chain<NE, 1, true>(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1159,7 +1192,10 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
         else if (nw == 5) launch_gibbs_kernel<2, 5>(prm, st);
         else if (nw == 2) launch_gibbs_kernel<5, 2>(prm, st);
-        else launch_gibbs_kernel<10, 1>(prm, st);
+        else if (getenv("QA_GIBBS_LEAN")) {
+            hipLaunchKernelGGL((k_gibbs_lean<10>), dim3(prm.C), dim3(64), 0, st, prm);
+            QA_HIP(hipGetLastError());
+        } else launch_gibbs_kernel<10, 1>(prm, st);
     } else {
         switch (NE1) {
             case 1: launch_gibbs_kernel<1, 1>(prm, st); break;
