@@ -75,8 +75,19 @@ struct GibbsParams {
     const double *runif_shard; // [C][n_block][G-1]
     const uint64_t *seed_reads, *seed_shard;  // [C] or null: uniforms from the counter-based stream instead
     // state (per chain)
-    double *eMatRead;        // at eread_off[c] doubles: [R_c][Ksp]
+    // Read emissions, compact form.  A read that covers n <= kMaxPatternBits informative SNPs takes at most 2^n distinct
+    // values over the haplotypes -- one per allele pattern at those SNPs: per read a 64-entry table (er_tab; entry 63 is
+    // 1, the padding rows' value) and per (read, row) a pattern byte (er_idx, laid out [read][thread][PADB] for the
+    // geometry of the Gibbs launch, so that a thread fetches its rows' bytes with one load).  1.5 KB per read instead
+    // of the 5 KB of a dense Ks-column of doubles, re-read by every sweep.  Reads with more SNPs keep a dense column in
+    // eMatRead (dense_of[r] = its row, else -1).
+    double *eMatRead;        // at eread_off[c] doubles: [n_dense_c][Ksp]
     const size_t *eread_off; // [C]
+    uint8_t *er_idx;         // at eridx_off[c] bytes: [R_c][er_nt][er_padb]
+    const size_t *eridx_off; // [C]
+    double *er_tab;          // [totR][64]
+    const int32_t *dense_of; // [totR]
+    int er_nt, er_padb;
     uint8_t *is_cat1;        // [sum R]
     double *alpha, *beta, *eg;  // [C][2][G][Ksp]
     double *cvec;            // [C][3][G]
@@ -142,9 +153,12 @@ __device__ __forceinline__ uint32_t panel_word(const GibbsParams &p, int g, int 
 // reference's; then divide by the column max and floor (:235-262).
 // ---------------------------------------------------------------------------------------------
 constexpr int kReadsPerWave = 32;
+constexpr int kMaxPatternBits = 5;
+constexpr int padb_of(int ne) { return ne <= 4 ? 4 : ne <= 8 ? 8 : 16; }
 
-template <int NE>
+template <int NEALL, int NW>
 __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
+    constexpr int NE = NEALL / NW, PADB = padb_of(NE), NT = 64 * NW;
     const int c = blockIdx.y, lane = threadIdx.x;
     const int R = p.read_off[c + 1] - p.read_off[c];
     const int r0 = blockIdx.x * kReadsPerWave;
@@ -152,28 +166,33 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
     const int32_t *rp = p.read_ptr + p.read_off[c] + c;
     const int32_t *u = p.u + p.base_off[c], *bq = p.bq + p.base_off[c];
     const int32_t *which = p.which + (size_t)c * p.Ks;
-    int kk[NE];
+    int kk[NEALL];
 #pragma unroll
-    for (int i = 0; i < NE; i++) {
+    for (int i = 0; i < NEALL; i++) {
         const int k = lane + 64 * i;
         kk[i] = (k < p.Ks) ? which[k] : -1;
     }
     int g_prev = -1;
-    uint32_t w[NE];
+    uint32_t w[NEALL];
+    const double e1 = 1 - p.ref_error, e0 = p.ref_error;
     for (int r = r0; r < min(r0 + kReadsPerWave, R); r++) {
-        double v[NE];
+        double v[NEALL];
+        uint32_t pat[NEALL];
 #pragma unroll
-        for (int i = 0; i < NE; i++) v[i] = 1.0;
+        for (int i = 0; i < NEALL; i++) { v[i] = 1.0; pat[i] = 0; }
         const int s = rp[r];
         int J = rp[r + 1] - s - 1;
         if (J >= p.Jmax) J = p.Jmax;
+        const int dense = p.dense_of[p.read_off[c] + r];
+        int n_inf = 0;
+        double tv = 1.0;   // lane l: the product for allele pattern l (bit j = allele at the read's j-th informative SNP)
         for (int j = 0; j <= J; j++) {
             const int b = bq[s + j];
             const int snp = u[s + j];
             const int g = snp >> 5;
             if (g != g_prev) {
 #pragma unroll
-                for (int i = 0; i < NE; i++) {
+                for (int i = 0; i < NEALL; i++) {
                     w[i] = 0;
                     if (kk[i] >= 0) w[i] = panel_word(p, g, kk[i], p.hm[(size_t)g * p.Kp + kk[i]]);
                 }
@@ -183,38 +202,72 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
             const int ab = b < 0 ? -b : b;
             const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
 #pragma unroll
-            for (int i = 0; i < NE; i++) {
-                const double e = ((w[i] >> (snp & 31)) & 1u) ? 1 - p.ref_error : p.ref_error;
+            for (int i = 0; i < NEALL; i++) {
+                const uint32_t bit = (w[i] >> (snp & 31)) & 1u;
+                const double e = bit ? e1 : e0;
                 v[i] *= (e * pA + (1 - e) * pR);
+                pat[i] |= bit << min(n_inf, 7);
             }
+            {   // the same factor, in the same order, for this lane's pattern
+                const double e = ((lane >> min(n_inf, 31)) & 1) ? e1 : e0;
+                tv *= (e * pA + (1 - e) * pR);
+            }
+            n_inf++;
         }
+        bool degenerate = false;
+        double d1 = 1.0;
         if (p.rescale) {
             double x = 0;
 #pragma unroll
-            for (int i = 0; i < NE; i++) if (kk[i] >= 0 && v[i] > x) x = v[i];
+            for (int i = 0; i < NEALL; i++) if (kk[i] >= 0 && v[i] > x) x = v[i];
             x = wmax(x);
-            const double d1 = 1 / x;
-            if (isinf(x) || x == 0 || isinf(d1)) {
+            d1 = 1 / x;
+            degenerate = isinf(x) || x == 0 || isinf(d1);
+            if (degenerate) {
 #pragma unroll
-                for (int i = 0; i < NE; i++) v[i] = 1;
+                for (int i = 0; i < NEALL; i++) v[i] = 1;
+                tv = 1;
             } else {
 #pragma unroll
-                for (int i = 0; i < NE; i++) {
+                for (int i = 0; i < NEALL; i++) {
                     v[i] *= d1;
                     if (v[i] < p.inv_maxdiff) v[i] = p.inv_maxdiff;
                 }
+                tv *= d1;
+                if (tv < p.inv_maxdiff) tv = p.inv_maxdiff;
             }
         }
         // category 1 (gibbs-nipt.cpp:350-372): no entry below 1 - 1e-12
         const double thresh = 1 - 1e-12;
         bool below = false;
 #pragma unroll
-        for (int i = 0; i < NE; i++) if (kk[i] >= 0 && v[i] < thresh) below = true;
+        for (int i = 0; i < NEALL; i++) if (kk[i] >= 0 && v[i] < thresh) below = true;
         const bool any_below = __any(below);
-        double *out = p.eMatRead + p.eread_off[c] + (size_t)r * p.Ksp;
-#pragma unroll
-        for (int i = 0; i < NE; i++) out[lane + 64 * i] = (kk[i] >= 0) ? v[i] : 1.0;
         if (lane == 0) p.is_cat1[p.read_off[c] + r] = (any_below || p.disable_read_category_usage) ? 0 : 1;
+        if (dense >= 0) {
+            double *out = p.eMatRead + p.eread_off[c] + (size_t)dense * p.Ksp;
+#pragma unroll
+            for (int i = 0; i < NEALL; i++) out[lane + 64 * i] = (kk[i] >= 0) ? v[i] : 1.0;
+        } else {
+            // (a degenerate read has every entry 1: pattern 63 for every row)
+            p.er_tab[(size_t)(p.read_off[c] + r) * 64 + lane] = (lane < (1 << n_inf) && lane != 63) ? tv : 1.0;
+            uint8_t *ix = p.er_idx + p.eridx_off[c] + (size_t)r * NT * PADB;
+#pragma unroll
+            for (int wv = 0; wv < NW; wv++) {
+                uint32_t pk[PADB / 4];
+#pragma unroll
+                for (int q = 0; q < PADB / 4; q++) pk[q] = 0;
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    const int j = wv + NW * i;   // thread lane + 64 wv of the chain owns rows lane + 64 (wv + NW i)
+                    const uint32_t code = (kk[j] >= 0 && !degenerate) ? pat[j] : 63u;
+                    pk[i >> 2] |= code << ((i & 3) * 8);
+                }
+                uint32_t *dst = reinterpret_cast<uint32_t *>(ix + (size_t)(lane + 64 * wv) * PADB);
+#pragma unroll
+                for (int q = 0; q < PADB / 4; q++) dst[q] = pk[q];
+            }
+        }
     }
 }
 
@@ -261,7 +314,10 @@ struct Chain {
     const GibbsParams &p;
     int c, t, lane, wave, R, G, Ks, Ksp;
     double *alpha[2], *beta[2], *eg[2], *cv[3];
-    const double *eMatRead;
+    const double *eMatRead;   // dense columns of the reads that have one
+    const uint8_t *eridx;     // compact read emissions (GibbsParams)
+    const double *ertab;
+    const int32_t *dense_of;
     const int32_t *wif;
     const uint8_t *ghr, *cat1;
     int32_t *H, *Hc;
@@ -282,6 +338,9 @@ struct Chain {
         }
         for (int h = 0; h < 3; h++) cv[h] = p.cvec + ((size_t)c * 3 + h) * G;
         eMatRead = p.eMatRead + p.eread_off[c];
+        eridx = p.er_idx + p.eridx_off[c];
+        ertab = p.er_tab + (size_t)p.read_off[c] * 64;
+        dense_of = p.dense_of + p.read_off[c];
         wif = p.wif + p.read_off[c];
         cat1 = p.is_cat1 + p.read_off[c];
         ghr = p.grid_has_read + (size_t)c * G;
@@ -291,6 +350,40 @@ struct Chain {
 #pragma unroll
         for (int i = 0; i < NE; i++) valid[i] = (t + NT * i) < Ks;
     }
+    // A read's emission column, compact form: this thread's pattern bytes and the lane's table entry (one load each,
+    // issued a read ahead), expanded by a cross-lane gather (ds_bpermute: no memory traffic).
+    static constexpr int PADB = padb_of(NE);
+    struct ErPre {
+        uint32_t w[PADB / 4];
+        double tv;
+    };
+    __device__ __forceinline__ void ld_pre(ErPre &x, int r) const {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(eridx + ((size_t)r * NT + t) * PADB);
+        if constexpr (PADB == 16) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(src);
+            x.w[0] = q.x; x.w[1] = q.y; x.w[2] = q.z; x.w[3] = q.w;
+        } else if constexpr (PADB == 8) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(src);
+            x.w[0] = q.x; x.w[1] = q.y;
+        } else {
+            x.w[0] = *src;
+        }
+        x.tv = ertab[(size_t)r * 64 + lane];
+    }
+    __device__ __forceinline__ void expand(Col<NE> &er, const ErPre &x) const {
+        const int lo = __double2loint(x.tv), hi = __double2hiint(x.tv);
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int src = (int)((x.w[i >> 2] >> ((i & 3) * 8)) & 0xffu) << 2;
+            er.v[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, hi), __builtin_amdgcn_ds_bpermute(src, lo));
+        }
+    }
+    // emission column of read r with its (wave-uniform) dense row dn
+    __device__ __forceinline__ void read_emission(Col<NE> &er, const ErPre &x, int dn) const {
+        if (dn >= 0) ld(er, eMatRead + (size_t)dn * Ksp);
+        else expand(er, x);
+    }
+
     __device__ __forceinline__ double tm0(int g) const { return p.sigma[g]; }
     // transMatRate_t row 1 as the caller passed it (the reference never recomputes 1 - sigma)
     __device__ __forceinline__ double tm1(int g) const { return p.sigma[p.G - 1 + g]; }
@@ -386,13 +479,14 @@ struct GridStreams {   // lane j <-> grid base + j
 
 template <class CH>
 struct ReadStreams {   // lane j <-> read base + j
-    int wif, cat1, H, Hc, base;
+    int wif, cat1, H, Hc, base, dn;
     double u;
     __device__ void load(const CH &ch, int b, const double *runif, int it) {
         base = b;
         const int r = b + ch.lane;
         const bool ok = r < ch.R;
         wif = ok ? ch.wif[r] : -1;
+        dn = ok ? ch.dense_of[r] : -1;
         cat1 = ok ? ch.cat1[r] : 1;
         H = ok ? ch.H[r] : 1;
         Hc = ok ? ch.Hc[r] : 0;
@@ -551,7 +645,11 @@ __device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
                 if ((r & 63) == 0 && rs.base != r) rs.load(ch, r, nullptr, 0);
                 if (rl_i32(rs.wif, r & 63) != g) break;
                 Col<NE> er;
-                ch.ld(er, ch.eMatRead + (size_t)r * Ksp);
+                {
+                    typename CH::ErPre x;
+                    ch.ld_pre(x, r);
+                    ch.read_emission(er, x, rl_i32(rs.dn, r & 63));
+                }
                 const int h = rl_i32(rs.H, r & 63) - 1;
 #pragma unroll
                 for (int i = 0; i < NE; i++) {
@@ -602,8 +700,8 @@ __device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
         int iRead = 0;  // next unprocessed read
         // software pipeline over reads: the emission column of read iRead is always in flight one read
         // ahead of its use; all per-read scalars come from the lane-held streams
-        Col<NE> pre_er;
-        if (R > 0) ch.ld(pre_er, ch.eMatRead);
+        typename CH::ErPre pre_er;
+        if (R > 0) ch.ld_pre(pre_er, 0);
         ReadStreams<CH> rs;
         rs.base = -1;
         GridStreams<CH> gs;
@@ -687,11 +785,13 @@ __device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
                 const int jr = iRead & 63;
                 if (rl_i32(rs.wif, jr) != g) break;
                 const int r = iRead;
-                const Col<NE> er = pre_er;
+                const typename CH::ErPre cur_er = pre_er;
                 iRead++;
                 // unconditional (clamped) so that no control-flow join forces the in-order vmcnt to drain
-                ch.ld(pre_er, ch.eMatRead + (size_t)min(iRead, R - 1) * Ksp);
+                ch.ld_pre(pre_er, min(iRead, R - 1));
                 if (rl_i32(rs.cat1, jr) != 0) continue;  // reads that cannot discriminate are skipped (:815)
+                Col<NE> er;
+                ch.read_emission(er, cur_er, rl_i32(rs.dn, jr));
                 if (!init_iteratively) normal = true;
                 else if (r < first_read && it == 0) pass = true;
                 else if (first_read <= r && it == 0) { pass = false; ginit = true; }
@@ -1096,6 +1196,10 @@ namespace qa {
 struct GibbsScratch {
     DBuf<int32_t> which, read_off, read_ptr, base_off, u, bq, wif, block_its, first_read, H, H_class, status;
     DBuf<uint8_t> ghr, is_cat1;
+    DBuf<int32_t> dense_of;
+    DBuf<size_t> eridx_off;
+    ABuf<uint8_t> er_idx;
+    ABuf<double> er_tab;
     DBuf<double> tabs, runif_reads, runif_shard, tm;
     ABuf<double> eMatRead, alpha, beta, eg, cvec, hap, gm, gf;   // carved from the panel's arena per call
     DBuf<size_t> eread_off;
@@ -1147,9 +1251,9 @@ std::vector<double> base_quality_tables() {
     return tabs;
 }
 
-template <int NE_READ>
+template <int NEALL, int NW>
 void launch_ematread(const GibbsParams &prm, int maxR, hipStream_t st) {
-    hipLaunchKernelGGL(k_ematread<NE_READ>, dim3((maxR + kReadsPerWave - 1) / kReadsPerWave, prm.C), dim3(64), 0, st, prm);
+    hipLaunchKernelGGL((k_ematread<NEALL, NW>), dim3((maxR + kReadsPerWave - 1) / kReadsPerWave, prm.C), dim3(64), 0, st, prm);
     QA_HIP(hipGetLastError());
 }
 
@@ -1159,35 +1263,46 @@ void launch_gibbs_kernel(const GibbsParams &prm, hipStream_t st) {
     QA_HIP(hipGetLastError());
 }
 
-// Geometry of one chain: NW waves x NE rows per thread with 64 * NW * NE == Ksp.  More waves shorten the
-// serial chain (latency) at the price of repeating the per-read scalar logic in every wave (throughput):
-// use as many waves as keep the chip at about one wave per SIMD.
-void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs, int share) {
+// Geometry of one chain: NW waves x NE rows per thread with 64 * NW * NE == Ksp.
+// The single-wave kernel (10 columns per lane) holds 512 registers, i.e. one chain per SIMD, 1024 per device, and a
+// chain's time is its serial per-read latency: measured at Ksubset = 600 with 128 chains NW = 2 is fastest (0.64 s vs
+// 0.77 NW = 1, 0.70 NW = 5, 0.86 NW = 10: more waves = costlier exchange per read), with 896 chains NW = 1 (0.94 s vs
+// 1.36 NW = 2, which no longer fits in one wave of workgroups).  Geometries with several waves exist for Ksp = 640.
+int choose_gibbs_waves(int Ksp, int C, int share) {
+    if (Ksp != 640) return 1;
+    int nw = 1;
+    if ((long)C * 2 <= 1024 / share) nw = 2;   // share: host threads sharing the device
+    if (const char *forced = getenv("QA_GIBBS_NW")) {   // test hook: exercise every geometry
+        const int f = atoi(forced);
+        if (f == 1 || f == 2 || f == 5 || f == 10) nw = f;
+    }
+    return nw;
+}
+
+void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs, int nw) {
     const int NE1 = prm.Ksp / 64;   // rows per lane with one wave
     QA_HIP(hipEventRecord(ev[0], st));
     switch (NE1) {
-        case 1: launch_ematread<1>(prm, maxR, st); break;
-        case 2: launch_ematread<2>(prm, maxR, st); break;
-        case 3: launch_ematread<3>(prm, maxR, st); break;
-        case 4: launch_ematread<4>(prm, maxR, st); break;
-        case 5: launch_ematread<5>(prm, maxR, st); break;
-        case 6: launch_ematread<6>(prm, maxR, st); break;
-        case 7: launch_ematread<7>(prm, maxR, st); break;
-        case 8: launch_ematread<8>(prm, maxR, st); break;
-        case 9: launch_ematread<9>(prm, maxR, st); break;
-        case 10: launch_ematread<10>(prm, maxR, st); break;
-        case 12: launch_ematread<12>(prm, maxR, st); break;
-        case 16: launch_ematread<16>(prm, maxR, st); break;
+        case 1: launch_ematread<1, 1>(prm, maxR, st); break;
+        case 2: launch_ematread<2, 1>(prm, maxR, st); break;
+        case 3: launch_ematread<3, 1>(prm, maxR, st); break;
+        case 4: launch_ematread<4, 1>(prm, maxR, st); break;
+        case 5: launch_ematread<5, 1>(prm, maxR, st); break;
+        case 6: launch_ematread<6, 1>(prm, maxR, st); break;
+        case 7: launch_ematread<7, 1>(prm, maxR, st); break;
+        case 8: launch_ematread<8, 1>(prm, maxR, st); break;
+        case 9: launch_ematread<9, 1>(prm, maxR, st); break;
+        case 10:
+            if (nw == 10) launch_ematread<10, 10>(prm, maxR, st);
+            else if (nw == 5) launch_ematread<10, 5>(prm, maxR, st);
+            else if (nw == 2) launch_ematread<10, 2>(prm, maxR, st);
+            else launch_ematread<10, 1>(prm, maxR, st);
+            break;
+        case 12: launch_ematread<12, 1>(prm, maxR, st); break;
+        case 16: launch_ematread<16, 1>(prm, maxR, st); break;
         default: throw std::runtime_error("Ksubset geometry not built (Ksubset / 64 rounded up must be 1..10, 12 or 16)");
     }
     QA_HIP(hipEventRecord(ev[1], st));
-    // Waves per chain.  The kernel holds 512 registers per lane (one wave per SIMD, 1024 per device), and a chain's
-    // time is its serial per-read latency: measured at Ksubset = 600 with 128 chains NW = 2 is fastest (0.64 s vs 0.77
-    // NW = 1, 0.70 NW = 5, 0.86 NW = 10: more waves = costlier exchange per read), with 896 chains NW = 1 (0.94 s vs
-    // 1.36 NW = 2, which no longer fits in one wave of workgroups).
-    int nw = 1;
-    if (NE1 % 2 == 0 && (long)prm.C * 2 <= 1024 / share) nw = 2;   // share: host threads sharing the device
-    if (const char *forced = getenv("QA_GIBBS_NW")) nw = atoi(forced);   // test hook: exercise every geometry
     if (NE1 == 10) {
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
         else if (nw == 5) launch_gibbs_kernel<2, 5>(prm, st);
@@ -1230,6 +1345,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
     {
         if (!g_gibbs) g_gibbs.reset(new GibbsHolder());
         auto &S = g_gibbs->s;
+        S.er_idx.arena = S.er_tab.arena = &pn->arena;
         S.eMatRead.arena = S.alpha.arena = S.beta.arena = S.eg.arena = S.cvec.arena = S.hap.arena = S.gm.arena = S.gf.arena = &pn->arena;
         pn->arena.reset();
         hipStream_t st = pn->stream;
@@ -1239,17 +1355,20 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         const int totR = read_off[C];
         // bases: per chain the CSR block read_ptr[read_off[c] + c .. read_off[c+1] + c] is local (starts at 0)
         std::vector<int32_t> base_off(C + 1, 0), which0((size_t)C * Ks), bq_eff;
-        std::vector<size_t> eoff(C);
+        std::vector<size_t> eoff(C), ixoff(C);
         std::vector<uint8_t> ghr((size_t)C * G, 0);
+        std::vector<int32_t> dense_of(std::max(totR, 1), -1);
+        const int nw = choose_gibbs_waves(Ksp, C, pn->share);
+        const int er_nt = 64 * nw, er_padb = padb_of(NE / nw);
         int maxR = 0;
-        size_t etot = 0;
+        size_t etot = 0, ixtot = 0;
         for (int c = 0; c < C; c++) {
             const int R = read_off[c + 1] - read_off[c];
             maxR = std::max(maxR, R);
             const int32_t *rp = read_ptr + read_off[c] + c;
             base_off[c + 1] = base_off[c] + rp[R];
-            eoff[c] = etot;
-            etot += (size_t)R * Ksp;
+            ixoff[c] = ixtot;
+            ixtot += (size_t)R * er_nt * er_padb;
             for (int r = 0; r < R; r++) {
                 const int g = wif[read_off[c] + r];
                 if (g < 0 || g >= G) throw std::runtime_error("read grid index out of range");
@@ -1265,6 +1384,21 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         const int totB = base_off[C];
         bq_eff.assign(bq, bq + totB);
         fold_zero_base_qualities(bq_eff, C, read_off, read_ptr, base_off, o->Jmax);
+        // reads whose informative bases (k_ematread skips bq == 0) exceed the pattern width keep a dense column
+        for (int c = 0; c < C; c++) {
+            const int R = read_off[c + 1] - read_off[c];
+            const int32_t *rp = read_ptr + read_off[c] + c;
+            eoff[c] = etot;
+            int n_dense = 0;
+            for (int r = 0; r < R; r++) {
+                int J = rp[r + 1] - rp[r] - 1;
+                if (J >= o->Jmax) J = o->Jmax;
+                int n_inf = 0;
+                for (int j = 0; j <= J; j++) n_inf += bq_eff[(size_t)base_off[c] + rp[r] + j] != 0;
+                if (n_inf > kMaxPatternBits) dense_of[read_off[c] + r] = n_dense++;
+            }
+            etot += (size_t)n_dense * Ksp;
+        }
         const std::vector<double> tabs = base_quality_tables();
         std::vector<double> tm((size_t)2 * std::max(G - 1, 1));
         for (int g = 0; g < G - 1; g++) { tm[g] = pn->h_sigma[g]; tm[(size_t)G - 1 + g] = pn->h_tm1[g]; }
@@ -1297,6 +1431,10 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
             S.runif_shard.upload(runif_shard, (size_t)C * o->n_block_gibbs_iterations * (G - 1), st);
         S.eread_off.ensure(C); S.eread_off.upload(eoff.data(), C, st);
         S.eMatRead.ensure(std::max<size_t>(etot, 1));
+        S.eridx_off.ensure(C); S.eridx_off.upload(ixoff.data(), C, st);
+        S.dense_of.ensure(dense_of.size()); S.dense_of.upload(dense_of.data(), dense_of.size(), st);
+        S.er_idx.ensure(std::max<size_t>(ixtot, 1));
+        S.er_tab.ensure(std::max<size_t>((size_t)totR * 64, 1));
         S.is_cat1.ensure(std::max(totR, 1));
         const size_t mat = (size_t)C * 2 * G * Ksp;
         S.alpha.ensure(mat); S.beta.ensure(mat); S.eg.ensure(mat);
@@ -1326,13 +1464,15 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         prm.seed_reads = seed_reads ? S.seeds.p : nullptr;
         prm.seed_shard = (seed_reads && seed_shard) ? S.seeds.p + C : nullptr;
         prm.eMatRead = S.eMatRead.p; prm.eread_off = S.eread_off.p; prm.is_cat1 = S.is_cat1.p;
+        prm.er_idx = S.er_idx.p; prm.eridx_off = S.eridx_off.p; prm.er_tab = S.er_tab.p; prm.dense_of = S.dense_of.p;
+        prm.er_nt = er_nt; prm.er_padb = er_padb;
         prm.alpha = S.alpha.p; prm.beta = S.beta.p; prm.eg = S.eg.p; prm.cvec = S.cvec.p;
         prm.H = S.H.p; prm.H_class = S.H_class.p; prm.status = S.status.p;
         prm.hapProbs = S.hap.p; prm.genProbsM = S.gm.p; prm.genProbsF = S.gf.p;
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
         const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
-        launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs, pn->share);
+        launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs, nw);
         S.H.download(H, totR, st);
         if (H_class) S.H_class.download(H_class, totR, st);
         std::vector<int32_t> status(C);
@@ -1408,7 +1548,7 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         const int n_its = o->n_gibbs_burn_in_its + o->n_gibbs_sample_its;
         const int nb = o->n_block_gibbs_iterations;
         const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
-        // chains are processed in chunks that fit the device arena (Ks x R fp64 emissions + 6 Ks x G state matrices each)
+        // chains are processed in chunks that fit the device arena (read emissions + 6 Ks x G state matrices each)
         std::vector<size_t> base_of(n_chain + 1, 0);
         for (int c = 0; c < n_chain; c++) {
             const int R = read_off[c + 1] - read_off[c];
@@ -1421,7 +1561,13 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
             int c1 = c0;
             while (c1 < n_chain) {
                 const size_t R = read_off[c1 + 1] - read_off[c1];
-                const size_t add = R * Ksp * 8 + (size_t)6 * G * Ksp * 8 + (size_t)3 * G * 8 + (want_probs ? (size_t)9 * T * 8 : 0) + 4096;
+                // read emissions: pattern bytes (<= 2560 B) + table (512 B) per read, a dense Ks-column for the reads with
+                // more bases than the pattern width (an upper bound of those that end up dense)
+                const int32_t *rp = read_ptr + read_off[c1] + c1;
+                size_t n_long = 0;
+                for (size_t r = 0; r < R; r++) n_long += std::min(rp[r + 1] - rp[r], o->Jmax + 1) > kMaxPatternBits;
+                const size_t add = R * (2560 + 512) + n_long * Ksp * 8 + (size_t)6 * G * Ksp * 8 + (size_t)3 * G * 8 +
+                                   (want_probs ? (size_t)9 * T * 8 : 0) + 8192;
                 if (c1 > c0 && need + add > budget) break;
                 need += add;
                 c1++;
