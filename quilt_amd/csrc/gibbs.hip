@@ -29,6 +29,9 @@
 // NIPT (ff > 0) block Gibbs is not implemented yet (QA_ERR_UNSUPPORTED).
 #include "panel.hpp"
 
+#include <chrono>
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1345,6 +1348,9 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
     {
         if (!g_gibbs) g_gibbs.reset(new GibbsHolder());
         auto &S = g_gibbs->s;
+        const bool tmg = getenv("QA_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double T0 = now();
         S.er_idx.arena = S.er_tab.arena = &pn->arena;
         S.eMatRead.arena = S.alpha.arena = S.beta.arena = S.eg.arena = S.cvec.arena = S.hap.arena = S.gm.arena = S.gf.arena = &pn->arena;
         pn->arena.reset();
@@ -1362,43 +1368,69 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         const int er_nt = 64 * nw, er_padb = padb_of(NE / nw);
         int maxR = 0;
         size_t etot = 0, ixtot = 0;
-        for (int c = 0; c < C; c++) {
+        for (int c = 0; c < C; c++) {   // offsets first (cheap), then the per-chain passes over the reads in parallel
             const int R = read_off[c + 1] - read_off[c];
             maxR = std::max(maxR, R);
             const int32_t *rp = read_ptr + read_off[c] + c;
             base_off[c + 1] = base_off[c] + rp[R];
             ixoff[c] = ixtot;
             ixtot += (size_t)R * er_nt * er_padb;
-            for (int r = 0; r < R; r++) {
-                const int g = wif[read_off[c] + r];
-                if (g < 0 || g >= G) throw std::runtime_error("read grid index out of range");
-                if (r > 0 && g < wif[read_off[c] + r - 1]) throw std::runtime_error("reads must be sorted by grid");
-                ghr[(size_t)c * G + g] = 1;
-            }
-            for (int k = 0; k < Ks; k++) {
-                const int v = which_haps_to_use_1based[(size_t)c * Ks + k] - 1;
-                if (v < 0 || v >= pn->K) throw std::runtime_error("which_haps_to_use out of range");
-                which0[(size_t)c * Ks + k] = v;
-            }
         }
         const int totB = base_off[C];
         bq_eff.assign(bq, bq + totB);
-        fold_zero_base_qualities(bq_eff, C, read_off, read_ptr, base_off, o->Jmax);
-        // reads whose informative bases (k_ematread skips bq == 0) exceed the pattern width keep a dense column
-        for (int c = 0; c < C; c++) {
-            const int R = read_off[c + 1] - read_off[c];
-            const int32_t *rp = read_ptr + read_off[c] + c;
-            eoff[c] = etot;
-            int n_dense = 0;
-            for (int r = 0; r < R; r++) {
-                int J = rp[r + 1] - rp[r] - 1;
-                if (J >= o->Jmax) J = o->Jmax;
-                int n_inf = 0;
-                for (int j = 0; j <= J; j++) n_inf += bq_eff[(size_t)base_off[c] + rp[r] + j] != 0;
-                if (n_inf > kMaxPatternBits) dense_of[read_off[c] + r] = n_dense++;
-            }
-            etot += (size_t)n_dense * Ksp;
+        std::vector<int32_t> n_dense(C, 0);
+        {
+            // validation, grid_has_read, 0-based haplotypes, the bq == 0 carry-over (fold_zero_base_qualities) and the
+            // choice of the reads that keep a dense column (more informative bases -- k_ematread skips bq == 0 -- than the
+            // pattern width): independent per chain, spread over host threads
+            const int n_thr = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), C}));
+            std::vector<std::string> errs(n_thr);
+            auto work = [&](int tid) {
+                try {
+                    for (int c = tid; c < C; c += n_thr) {
+                        const int R = read_off[c + 1] - read_off[c];
+                        const int32_t *rp = read_ptr + read_off[c] + c;
+                        for (int r = 0; r < R; r++) {
+                            const int g = wif[read_off[c] + r];
+                            if (g < 0 || g >= G) throw std::runtime_error("read grid index out of range");
+                            if (r > 0 && g < wif[read_off[c] + r - 1]) throw std::runtime_error("reads must be sorted by grid");
+                            ghr[(size_t)c * G + g] = 1;
+                        }
+                        for (int k = 0; k < Ks; k++) {
+                            const int v = which_haps_to_use_1based[(size_t)c * Ks + k] - 1;
+                            if (v < 0 || v >= pn->K) throw std::runtime_error("which_haps_to_use out of range");
+                            which0[(size_t)c * Ks + k] = v;
+                        }
+                        int last = 0, nd = 0;
+                        for (int r = 0; r < R; r++) {
+                            int J = rp[r + 1] - rp[r] - 1;
+                            if (J >= o->Jmax) J = o->Jmax;
+                            int n_inf = 0;
+                            for (int j = 0; j <= J; j++) {
+                                int32_t &b = bq_eff[(size_t)base_off[c] + rp[r] + j];
+                                if (b == 0) b = last; else last = b;
+                                if (b > 255 || b < -255) throw std::runtime_error("|base quality| > 255");
+                                n_inf += b != 0;
+                            }
+                            if (n_inf > kMaxPatternBits) dense_of[read_off[c] + r] = nd++;
+                        }
+                        n_dense[c] = nd;
+                    }
+                } catch (const std::exception &e) {
+                    errs[tid] = e.what();
+                }
+            };
+            std::vector<std::thread> th;
+            for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
+            work(0);
+            for (auto &t : th) t.join();
+            for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
         }
+        for (int c = 0; c < C; c++) {
+            eoff[c] = etot;
+            etot += (size_t)n_dense[c] * Ksp;
+        }
+        const double T1 = now();
         const std::vector<double> tabs = base_quality_tables();
         std::vector<double> tm((size_t)2 * std::max(G - 1, 1));
         for (int g = 0; g < G - 1; g++) { tm[g] = pn->h_sigma[g]; tm[(size_t)G - 1 + g] = pn->h_tm1[g]; }
@@ -1472,11 +1504,15 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
         const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
+        QA_HIP(hipStreamSynchronize(st));
+        const double T2 = now();
         launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs, nw);
         S.H.download(H, totR, st);
         if (H_class) S.H_class.download(H_class, totR, st);
         std::vector<int32_t> status(C);
         S.status.download(status.data(), C, st);
+        QA_HIP(hipStreamSynchronize(st));
+        const double T3 = now();
         if (hapProbs_t) S.hap.download(hapProbs_t, (size_t)C * T * 3, st);
         if (genProbsM_t) S.gm.download(genProbsM_t, (size_t)C * T * 3, st);
         if (genProbsF_t) S.gf.download(genProbsF_t, (size_t)C * T * 3, st);
@@ -1493,6 +1529,9 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
             qa::profile_add(qa::PK_EMATREAD, ms[0], (double)totR * Ks * 8.0, t_e);
             qa::profile_add(qa::PK_GIBBS, ms[1], sweeps, t_e + ms[0]);
             qa::profile_add(qa::PK_HAPPROBS, ms[2], C * 2.0 * Ks * (double)G * 16.0, t_e + ms[0] + ms[1]);
+            if (tmg)
+                fprintf(stderr, "[qa_gibbs C=%d] host prep %.3f s, tables+uploads %.3f s, kernels %.3f s (events %.3f), downloads %.3f s\n", C,
+                        T1 - T0, T2 - T1, T3 - T2, (ms[0] + ms[1] + ms[2]) / 1e3, now() - T3);
         }
         int rc = QA_OK;
         for (int c = 0; c < C; c++) {

@@ -48,6 +48,8 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     ``wif``); the other sequences hold one entry per chain.  Returns a list of dicts.
     """
     lib().qa_gibbs_batch.restype = C.c_int
+    import os, time
+    _t0 = time.perf_counter()
     P = panel.panel
     G, T = P.nGrids, P.nSNPs
     Cn = len(samples)
@@ -89,10 +91,13 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                      int(n_gibbs_burn_in_its), int(n_gibbs_sample_its), ptr(blocks), int(len(blocks)),
                      int(perform_block_gibbs), int(ff == 0), int(gibbs_initialize_iteratively),
                      int(disable_read_category_usage), float(class_sum_cutoff))
+    _t1 = time.perf_counter()
     st = lib().qa_gibbs_batch(panel.handle, C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr),
                               ptr(u), ptr(bq), ptr(wif), ptr(ru), ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap),
                               ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
     check(st)
+    if os.environ.get("QA_TIMING"):
+        print(f"[gibbs_batch py C={Cn}] marshal {_t1 - _t0:.3f} s, native call {time.perf_counter() - _t1:.3f} s", flush=True)
     out = []
     for c in range(Cn):
         s, e = read_off[c], read_off[c + 1]
