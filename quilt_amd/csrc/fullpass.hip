@@ -25,6 +25,7 @@
 #include "panel.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <memory>
 #include <utility>
@@ -1805,6 +1806,10 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
         const int G = panel->G, T = panel->T;
         int n_thin = 0;
         for (int g = 0; g < G; g++) n_thin = std::max(n_thin, gammaSmall_cols_to_get[g] + 1);
+        const bool tmg = getenv("QA_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double T0 = now();
+        double t_kern = 0, t_run = 0;
         // ---- per-sample SNP-major index of the bases (input marshalling, O(bases))
         std::vector<int32_t> base_off(n_sample + 1, 0), snp_ptr((size_t)n_sample * (T + 1), 0), ent_off(n_sample, 0);
         for (int s = 0; s < n_sample; s++) {
@@ -1884,6 +1889,7 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
 
         int status = QA_OK;
         std::vector<int32_t> no_thin(G, -1);
+        const double T1 = now();
         for (const Group &grp : groups) {
             const Geometry geo = pick_geometry(panel->K, grp.f64);
             if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
@@ -1918,8 +1924,11 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                 out.truncate_lists = true;
                 std::vector<int32_t> true_cnt;
                 out.true_counts = &true_cnt;
+                const double tr = now();
                 status = run_passes(panel, n, nullptr, flags.data() + done, grp.K_top > 0 ? gammaSmall_cols_to_get : no_thin.data(),
                                     grp.K_top, 1, out, grp.f64);
+                t_run += now() - tr;
+                t_kern += g_timing[4] / 1e3;
                 if (status != QA_OK) break;
                 // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
                 if (grp.K_top > 0) {
@@ -1937,6 +1946,9 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
             }
             if (status != QA_OK) break;
         }
+        if (tmg)
+            fprintf(stderr, "[qa_fullpass_reads P=%d] index+uploads %.3f s, run_passes %.3f s (device %.3f s), scatter etc %.3f s\n", P,
+                    T1 - T0, t_run, t_kern, now() - T1 - t_run);
         return status;
     });
 }
