@@ -87,6 +87,22 @@ typedef struct {
 int qa_panel_create(const qa_panel_desc_t *desc, qa_panel_t **out);
 void qa_panel_destroy(qa_panel_t *panel);
 
+/* The panel handle straight from the packed panel: per-grid dictionary compression on the device.  Replaces
+ * STITCH::make_rhb_t_equality (STITCH 1.8.4; call sites QUILT/R/quilt-prepare-reference.R:416-428, QUILT/R/quilt.R:551-563)
+ * followed by qa_panel_create: per grid the distinct 32-bit words of rhb_t are ranked by descending frequency (ties:
+ * ascending signed value), the first nMaxDH (<= 255) get the 1-based codes of hapMatcherR / rows of distinctHapsB, every
+ * other haplotype code 0 and an entry in the special tables.
+ *   rhb_t   K x nGrids int32, column-major (the R matrix), bit b of word g = allele at SNP 32 g + b
+ *   use_eMatDH_special_symbols   as in qa_panel_desc_t: decode special words the way the reference does without rhb_t
+ * qa_panel_export_tables copies the tables back in the reference's layouts (hapMatcherR K x nGrids raw, distinctHapsB
+ * nMaxDH x nGrids int32; specials as CSR over grids: special_off[nGrids + 1], ascending 0-based k and the word of each);
+ * any output may be NULL. */
+int qa_panel_create_from_rhb(const int32_t *rhb_t, int32_t K, int32_t nGrids, int32_t nSNPs, int32_t nMaxDH,
+                             const double *transMatRate_t, double ref_error, int32_t use_eMatDH_special_symbols,
+                             qa_panel_t **out);
+int qa_panel_export_tables(qa_panel_t *panel, uint8_t *hapMatcherR, int32_t *distinctHapsB, int32_t *special_off,
+                           int32_t *special_k, int32_t *special_word, int64_t special_cap);
+
 /* Arithmetic of the state behind the best-haplotype lists (get_best_haps_from_thinned_sites).  64 (default): the
  * lists come from a forward/backward with fp64 state -- the reference computes in double, and which of several
  * nearly tied haplotypes make a list decides the next small panel, so membership and order must be the reference's.

@@ -40,7 +40,7 @@ bool device_ready() {
 // the reference's clamped halving search over rows s1..e1 (1-based) of the special matrix
 // (QUILT/src/gibbs-small.cpp:69-105), quirks included: this is how the device tables inherit
 // exactly the word the reference would decode.
-static int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, int s1, int e1) {
+int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, int s1, int e1) {
     int nori = e1 - s1 + 1;
     if (nori == 1) return 0;
     int n = nori, i = n / 2;

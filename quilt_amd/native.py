@@ -54,7 +54,8 @@ def lib() -> C.CDLL:
         for name in ("qa_abi_version", "qa_device_count", "qa_set_device", "qa_panel_create", "qa_gibbs_batch",
                  "qa_rcpp_make_eMatRead_t", "qa_profile_reset", "qa_profile_get", "qa_fullpass_reads_batch",
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
-                     "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy"):
+                     "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy", "qa_panel_create_from_rhb",
+                     "qa_panel_export_tables"):
             getattr(L, name).restype = C.c_int
         L.qa_panel_destroy.restype = None
         _lib = L
@@ -110,6 +111,36 @@ class DevicePanel:
         h = C.c_void_p()
         check(lib().qa_panel_create(C.byref(d), C.byref(h)))
         self.handle = h
+
+    @classmethod
+    def from_rhb(cls, panel, nMaxDH=None, use_eMatDH_special_symbols=False):
+        """Build the device panel straight from ``panel.rhb_t`` (K x nGrids int32): the per-grid dictionary compression
+        (STITCH::make_rhb_t_equality) runs on the GPU.  ``panel`` supplies rhb_t, nSNPs, transMatRate_t, ref_error."""
+        self = cls.__new__(cls)
+        self.panel = panel
+        rhb = np.asfortranarray(panel.rhb_t, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().qa_panel_create_from_rhb(ptr(rhb), C.c_int32(rhb.shape[0]), C.c_int32(rhb.shape[1]), C.c_int32(panel.nSNPs),
+                                             C.c_int32(nMaxDH if nMaxDH is not None else panel.nMaxDH), ptr(panel.transMatRate_t),
+                                             C.c_double(panel.ref_error), C.c_int32(int(bool(use_eMatDH_special_symbols))),
+                                             C.byref(h)))
+        self.handle = h
+        self._nMaxDH = int(nMaxDH if nMaxDH is not None else panel.nMaxDH)
+        return self
+
+    def export_tables(self):
+        """(hapMatcherR K x G uint8 F, distinctHapsB nMaxDH x G int32 F, special_off, special_k, special_word)."""
+        K, G = self.panel.K, self.panel.nGrids
+        nMaxDH = getattr(self, "_nMaxDH", self.panel.nMaxDH)
+        hm = np.zeros((K, G), dtype=np.uint8, order="F")
+        B = np.zeros((nMaxDH, G), dtype=np.int32, order="F")
+        off = np.zeros(G + 1, dtype=np.int32)
+        check(lib().qa_panel_export_tables(self.handle, ptr(hm), ptr(B), ptr(off), None, None, C.c_int64(0)))
+        n = int(off[-1])
+        sk = np.zeros(max(n, 1), dtype=np.int32)
+        sw = np.zeros(max(n, 1), dtype=np.int32)
+        check(lib().qa_panel_export_tables(self.handle, None, None, None, ptr(sk), ptr(sw), C.c_int64(max(n, 1))))
+        return hm, B, off, sk[:n], sw[:n]
 
     def set_ranking_precision(self, bits: int):
         """64 (default): best-haplotype lists from fp64-state passes (the reference's arithmetic); 32: from the
