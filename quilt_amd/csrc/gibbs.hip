@@ -601,8 +601,8 @@ __device__ void backward_both(Chain<NE, NW> &ch) {
     }
 }
 
-template <int NE, int NW, bool kLean>
-__device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
+template <int NE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
     __shared__ double s_red[2 * NW * 4];
     const int c = blockIdx.x, t = threadIdx.x;
     using CH = Chain<NE, NW>;
@@ -720,11 +720,9 @@ __device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
             }
             const int jg = g & 63;
             const bool has = rl_i32(gs.has, jg) != 0;
-            // next grid's eMatGrid and beta columns: issued now, used after this grid's reads -- unless the chain is
-            // to stay within 256 registers so that two chains share a SIMD (kLean): then they are loaded at the grid
-            // boundary and the other chain's wave covers the round trip
-            Col<kLean ? 1 : NE> en[2], bn[2];
-            if constexpr (!kLean) {
+            // next grid's eMatGrid and beta columns: issued now, used after this grid's reads
+            Col<NE> en[2], bn[2];
+            {
                 const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: loads stay unconditional
                 ch.ld(en[0], ch.eg[0] + gn);
                 ch.ld(en[1], ch.eg[1] + gn);
@@ -913,16 +911,8 @@ __device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
                 for (int h = 0; h < 2; h++) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
             }
             gs.set_c(lane, jg, cg[0], cg[1]);
-            if constexpr (kLean) {
-                const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
-                ch.ld(e[0], ch.eg[0] + gn);
-                ch.ld(e[1], ch.eg[1] + gn);
-                ch.ld(bt[0], ch.beta[0] + gn);
-                ch.ld(bt[1], ch.beta[1] + gn);
-            } else {
-                e[0] = en[0]; e[1] = en[1];
-                bt[0] = bn[0]; bt[1] = bn[1];
-            }
+            e[0] = en[0]; e[1] = en[1];
+            bt[0] = bn[0]; bt[1] = bn[1];
         }
         gs.store_c(ch);
         if (rs.base >= 0) rs.store(ch);
@@ -1069,17 +1059,6 @@ __device__ __forceinline__ void gibbs_chain(const GibbsParams &p) {
         }
     }
     if (t == 0) p.status[c] = status;
-}
-
-template <int NE, int NW>
-__global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
-    gibbs_chain<NE, NW, false>(p);
-}
-// single-wave chains with many columns per lane, held to 256 registers so that two chains share a SIMD (2048 chains per
-// device instead of 1024)
-template <int NE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gibbs_lean(GibbsParams p) {
-    gibbs_chain<NE, 1, true>(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1310,10 +1289,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
         else if (nw == 5) launch_gibbs_kernel<2, 5>(prm, st);
         else if (nw == 2) launch_gibbs_kernel<5, 2>(prm, st);
-        else if (getenv("QA_GIBBS_LEAN")) {
-            hipLaunchKernelGGL((k_gibbs_lean<10>), dim3(prm.C), dim3(64), 0, st, prm);
-            QA_HIP(hipGetLastError());
-        } else launch_gibbs_kernel<10, 1>(prm, st);
+        else launch_gibbs_kernel<10, 1>(prm, st);
     } else {
         switch (NE1) {
             case 1: launch_gibbs_kernel<1, 1>(prm, st); break;

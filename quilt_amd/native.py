@@ -33,7 +33,7 @@ class QuiltAmdError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", CSRC, "-s"]
+    args = ["make", "-C", CSRC, "-s", "-j8"]
     if force:
         args.append("-B")
     subprocess.check_call(args)
