@@ -136,3 +136,61 @@ def test_gibbs_every_chain_geometry(medium_panel, oracle, nw, monkeypatch):
         got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter,
                                             return_state=True)
         _compare(got, ref, 600)
+
+
+def test_gibbs_edge_inputs(small_panel, oracle):
+    """Ragged and degenerate chains in one launch: a single read; all reads in one grid; reads of 6-8 SNPs (dense
+    emission columns next to the compact table form); a read whose bases all have zero quality."""
+    import copy
+    from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+    from quilt_amd.native import DevicePanel
+    panel = small_panel
+    dev = DevicePanel(panel)
+    setups = []
+    # (a) one read
+    setups.append(_setup(panel, 301, 64, 1))
+    # (b) every read in the same grid
+    s, which, H0, ru, rs, fr = _setup(panel, 302, 64, 30)
+    s = copy.deepcopy(s)
+    g0 = int(s.wif[0])
+    s.wif[:] = g0
+    s.u[:] = 32 * g0 + (s.u % 32)
+    setups.append((s, which, H0, ru, rs, fr))
+    # (c) many long-ish reads: more than 5 informative SNPs -> dense columns
+    s, which, H0, ru, rs, fr = _setup(panel, 303, 64, 120)
+    assert (np.diff(s.read_ptr) > 5).any() and (np.diff(s.read_ptr) <= 5).any()
+    setups.append((s, which, H0, ru, rs, fr))
+    # (d) first read without any base quality (factor 1 everywhere: gibbs-small.cpp:139-181 carry-over from nothing)
+    s, which, H0, ru, rs, fr = _setup(panel, 304, 64, 40)
+    s = copy.deepcopy(s)
+    s.bq[s.read_ptr[0]:s.read_ptr[1]] = 0
+    setups.append((s, which, H0, ru, rs, fr))
+    got = forwardBackwardGibbsNIPT_batch(dev, [x[0] for x in setups], [x[1] for x in setups], [x[2] for x in setups],
+                                         [x[3] for x in setups], [x[5] for x in setups], [x[4] for x in setups])
+    for g, (s, which, H0, ru, rs, fr) in zip(got, setups):
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs)
+        assert np.array_equal(g["H"], ref["H"])
+        assert bool(g["underflow_problem"]) == bool(ref["status"] == 1)
+        np.testing.assert_allclose(g["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    dev.close()
+
+
+def test_gibbs_underflow_is_reported(small_panel, oracle):
+    """Thousands of reads piled on one grid: the grid's emission product underflows for every haplotype, the forward
+    sum is 0 and c infinite -- status QA_UNDERFLOW / underflow_problem on both sides (the driver then retries with a
+    smaller maxDifferenceBetweenReads, functions.R:2704-2715)."""
+    import copy
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    panel = small_panel
+    dev = DevicePanel(panel)
+    s, which, H0, ru, rs, fr = _setup(panel, 78, 64, 4000)
+    s = copy.deepcopy(s)
+    g0 = int(s.wif[len(s.wif) // 2])
+    s.wif[:] = g0
+    s.u[:] = 32 * g0 + (s.u % 32)
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs)
+    assert ref["status"] == 1, "the test input is meant to underflow"
+    assert got["underflow_problem"]
+    dev.close()
