@@ -818,13 +818,17 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     double s[2] = {0, 0};
 #pragma unroll
                     for (int i = 0; i < NE; i++) ri.v[i] = fast_rcp(er.v[i]);
-                    if (h_rC == 0) {   // wave-uniform: two straight-line versions instead of per-element selects
+                    // wave-uniform branch: two straight-line versions instead of per-element selects (the empty asm keeps
+                    // the compiler from converting the branch back into 4 * NE v_cndmask)
+                    if (h_rC == 0) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < NE; i++) {
                             s[0] += (a[0].v[i] * bt[0].v[i]) * ri.v[i];
                             s[1] += (a[1].v[i] * bt[1].v[i]) * er.v[i];
                         }
                     } else {
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < NE; i++) {
                             s[0] += (a[1].v[i] * bt[1].v[i]) * ri.v[i];
@@ -850,7 +854,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 // so the normalised probabilities are P / (P + Q) and Q / (P + Q) bit for bit; label 3 has weight 0
                 const double P = pC[0] * pC[1], Q = pA1[0] * pA1[1];
                 const double denom = P + Q;
-                const double norm_pC = P / denom, norm_pA1 = Q / denom;
+                const double rden = fast_rcp(denom);
+                const double norm_pC = P * rden, norm_pA1 = Q * rden;
                 const double chance = runif ? rl_f64(rs.u, jr) : stream_uniform(seed_reads, (uint64_t)R * it + r);
                 const double p0 = (h_rC == 0) ? norm_pC : norm_pA1, p1 = (h_rC == 0) ? norm_pA1 : norm_pC;
                 const double cs0 = p0, cs1 = p1 + p0;
