@@ -14,14 +14,19 @@
 //     from a <=256-entry fp32 table staged in LDS, and (dosage passes) checkpoints alpha to HBM in
 //     a lane-interleaved order that makes every store a fully coalesced 1 KiB dwordx4 store.
 //   * the backward pass re-reads that checkpoint, forms gamma = alpha * beta in registers, and
-//     histograms gamma by haplotype code with conflict-free LDS float atomics (32 bank-private
-//     copies); the 32 x nMaxDH dosage mat-vec is taken off the serial path (k_dosage).
+//     histograms gamma * sigma by haplotype code with fixed-point integer LDS atomics (32 bank-private
+//     copies; ds_add_f32 is ~30x slower on gfx950); the histogram of grid g+1 is folded after the
+//     block-sum barrier of grid g; the 32 x nMaxDH dosage mat-vec is off the serial path (k_dosage).
+//   * the best-haplotype lists come from a second family of kernels with fp64 state (k_fwd64 / k_bwd64 /
+//     k_topk<double>: register + LDS resident state, haplotype codes DMA'd global -> LDS): which of several
+//     nearly tied haplotypes the reference (double arithmetic) reports decides the next small panel, and
+//     fp32 state ranks them differently.  See the comment above those kernels.
 //   * alpha/beta are renormalised every grid (the reference's always_normalize = TRUE semantics,
 //     equivalent for dosage / gamma / sum(log c): test-unit-reference-single.R:588-642), which is
 //     what makes fp32 state safe; emissions are built in fp64 and rounded once.
 //
 // Algorithmic HBM bytes: dosage pass 10 * K * G (1 B code + 4 B alpha store
-// forward; 1 B code + 4 B alpha load backward), thin pass 2.8 * K * G.
+// forward; 1 B code + 4 B alpha load backward), ranking pass (1 + 0.1 * 8) * 2 * K * G.
 #include "panel.hpp"
 
 #include <algorithm>

@@ -9,16 +9,19 @@
 //
 // How (MI355X-first):
 //   * a sweep is a chain of ~G + R dependent Ks-wide steps (every accepted move changes what the next
-//     read sees), so the unit of parallelism is the chain: ONE 64-lane wavefront owns one (sample,
-//     Gibbs chain) and keeps the current grid's alpha / beta / eMatGrid columns of both labels in
-//     VGPRs (Ks = 600 -> 10 fp64 per lane per column).  All Ks-wide sums are DPP/shuffle butterflies
-//     -- no LDS, no barrier anywhere on the serial path.  Hundreds of chains fill the chip.
-//   * columns live in HBM as [grid][Ks padded to 64] fp64, lane-strided, so every column load/store is
-//     10 coalesced 512-byte wave accesses; the next read's emission column is prefetched while the
-//     current one is resolved.
-//   * fp64 throughout and no FMA contraction (-ffp-contract=off): per-element arithmetic is bit-for-
-//     bit the reference's; only the order of the Ks-wide sums differs (1e-16 relative), which is what
-//     lets the sampled read labels match the CPU path under the same uniforms.
+//     read sees), so the unit of parallelism is the chain: ONE workgroup of NW wavefronts (1 when the
+//     device is full: one chain per SIMD, 1024 per device; 2 when it is not) owns one (sample, Gibbs
+//     chain) and keeps the current grid's alpha / beta / eMatGrid columns of both labels in registers
+//     (Ks = 600 -> 10 fp64 per lane per column at NW = 1).  All Ks-wide sums are DPP butterflies, plus one
+//     LDS exchange with a bare s_barrier when NW > 1.
+//   * columns live in HBM as [grid][Ks padded to 64] fp64, lane-strided, so every column access is
+//     coalesced; read emissions are kept in a compact form (per-read table + pattern byte per row, expanded
+//     with ds_bpermute; see GibbsParams) and fetched one read ahead.
+//   * fp64 throughout and no FMA contraction (-ffp-contract=off).  Deviations from the reference's
+//     per-element arithmetic, each <= 1 ulp: the order of the Ks-wide sums; x * (1 / e) with a refined
+//     v_rcp_f64 where the reference divides by a read's emission (and by P + Q); alpha * beta formed where
+//     it is summed.  Sampling thresholds are compared with 53-bit uniforms, so the sampled labels equal the
+//     CPU path's under the same uniforms in every test.
 //   * the uniforms the reference draws from R's RNG are inputs.
 //
 // Block Gibbs: for diploid samples `Rcpp_block_gibbs_resampler` (gibbs-nipt-block.cpp:1636-1967) is the
