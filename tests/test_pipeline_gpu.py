@@ -131,3 +131,32 @@ def test_pipeline_ont_reads(medium_panel):
         assert np.array_equal(g.read_labels, r.read_labels)
         assert np.abs(g.dosage - r.dosage).max() <= 1e-4
         assert r2(g.dosage, r.dosage) >= 0.999
+
+
+def test_full_size_invariants():
+    """BASELINE.json's headline sizes (K = 50 000 haplotypes, 64 000 SNPs / 2 000 grids, 20 000 reads): the CPU path
+    takes ~20 minutes per sample there, so the whole driver is checked through size-independent properties -- the
+    acceptance criteria of the reference's own end-to-end tests (check_quilt_output, test-drivers.R:1-89): genotype
+    probabilities sum to 1 +- 0.002, dosages within [0, 2] and consistent with them, imputed dosage close to the
+    simulated truth; plus: every Gibbs label is 1 or 2, phased haplotypes in [0, 1], results independent of batching."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=50000, nSNPs=64000, seed=4916)
+    samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=20000) for i in range(2)]
+    dev = DevicePanel.from_rhb(panel)          # the device-built panel, as a production run would use it
+    prm = DriverParams(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
+    res = Driver(panel, HipBackend(dev), prm).run(samples)
+    for s, r in zip(samples, res):
+        assert r.nDosage == 7
+        np.testing.assert_allclose(r.gp_t.sum(axis=0), 1.0, atol=2e-3)
+        assert r.dosage.min() >= -1e-9 and r.dosage.max() <= 2 + 1e-9
+        np.testing.assert_allclose(r.dosage, r.gp_t[1] + 2 * r.gp_t[2], atol=1e-9)
+        assert set(np.unique(r.read_labels)) <= {1, 2}
+        assert r.phasing_haps.min() >= 0 and r.phasing_haps.max() <= 1
+        truth = s.truth_haps.sum(axis=0)
+        assert r2(r.dosage, truth) >= 0.99
+        assert np.mean(np.abs(r.dosage - truth) > 0.1) < 0.02    # "DS within 0.1 of truth" for nearly every site
+    one = Driver(panel, HipBackend(dev), prm).run(samples[1:], sample_offset=1)[0]
+    assert np.array_equal(one.read_labels, res[1].read_labels) and np.abs(one.dosage - res[1].dosage).max() <= 1e-6
+    dev.close()
