@@ -40,476 +40,14 @@
 #include <cstdlib>
 #include <memory>
 
+#include "gibbs_dev.hpp"
+
+namespace qa {
+int gibbs3_waves(int Ksp);
+void launch_gibbs3(const void *gibbs_params, hipStream_t st);
+}
+
 namespace {
-
-struct GibbsParams {
-    // panel
-    const uint8_t *hm;       // [G][Kp]
-    const int32_t *B;        // [G][nMaxDH]
-    const int32_t *sp_off;
-    const int32_t *sp_k;
-    const uint32_t *sp_word;
-    const double *sigma;     // [G-1]
-    int Kp, G, T, nMaxDH;
-    double ref_error;
-    // chain batch
-    int C;                   // chains
-    int Ks, Ksp, NE;         // Ksp = Ks rounded up to 64, NE = Ksp / 64
-    const int32_t *which;    // [C][Ks] 0-based panel haplotype of each small-panel row
-    // reads (per chain: offsets into the flattened arrays)
-    const int32_t *read_off; // [C+1] read index offsets
-    const int32_t *read_ptr; // [sum R + C] CSR over bases, per chain block starting at read_off[c] + c
-    const int32_t *base_off; // [C+1] base index offsets
-    const int32_t *u;        // SNP index per base
-    const int32_t *bq;       // effective signed base quality per base (0 = factor 1)
-    const int32_t *wif;      // [sum R] grid of each read
-    const uint8_t *grid_has_read;  // [C][G]
-    const double *pR_tab, *pA_tab;  // [2][256]: by |bq|, for bq < 0 (index 0) and bq > 0 (index 1)
-    int Jmax;
-    double inv_maxdiff;      // 1 / maxDifferenceBetweenReads
-    int rescale;
-    // sampler
-    int n_its, n_burn_in;
-    const int32_t *block_its;  // [n_block]
-    int n_block;
-    int do_shard;
-    int init_iteratively;
-    int disable_read_category_usage;
-    double class_sum_cutoff;
-    const double *runif_reads; // [C][R_c * n_its] at offset read_off[c] * n_its
-    const int32_t *first_read; // [C]
-    const double *runif_shard; // [C][n_block][G-1]
-    const uint64_t *seed_reads, *seed_shard;  // [C] or null: uniforms from the counter-based stream instead
-    // state (per chain)
-    // Read emissions, compact form.  A read that covers n <= kMaxPatternBits informative SNPs takes at most 2^n distinct
-    // values over the haplotypes -- one per allele pattern at those SNPs: per read a 64-entry table (er_tab; entry 63 is
-    // 1, the padding rows' value) and per (read, row) a pattern byte (er_idx, laid out [read][thread][PADB] for the
-    // geometry of the Gibbs launch, so that a thread fetches its rows' bytes with one load).  1.5 KB per read instead
-    // of the 5 KB of a dense Ks-column of doubles, re-read by every sweep.  Reads with more SNPs keep a dense column in
-    // eMatRead (dense_of[r] = its row, else -1).
-    double *eMatRead;        // at eread_off[c] doubles: [n_dense_c][Ksp]
-    const size_t *eread_off; // [C]
-    uint8_t *er_idx;         // at eridx_off[c] bytes: [R_c][er_nt][er_padb]
-    const size_t *eridx_off; // [C]
-    double *er_tab;          // [totR][64]
-    const int32_t *dense_of; // [totR]
-    int er_nt, er_padb;
-    uint8_t *is_cat1;        // [sum R]
-    double *alpha, *beta, *eg;  // [C][2][G][Ksp]
-    double *cvec;            // [C][3][G]
-    int32_t *H;              // [sum R] labels 1-based (in/out)
-    int32_t *H_class;        // [sum R]
-    int32_t *status;         // [C] 0 ok, 1 underflow
-    // outputs
-    double *hapProbs, *genProbsM, *genProbsF;  // [C][T][3]
-};
-
-// 64-lane sum of doubles by DPP row shifts / row broadcasts (no LDS traffic), result broadcast to every
-// lane through a scalar register.  Deterministic order: within 16-lane rows, then rows 0+1, 2+3, then all.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_get(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wsum(double v) {
-    v += dpp_get<0x111, 0xf>(v);  // row_shr:1
-    v += dpp_get<0x112, 0xf>(v);  // row_shr:2
-    v += dpp_get<0x114, 0xf>(v);  // row_shr:4
-    v += dpp_get<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row total
-    v += dpp_get<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-    v += dpp_get<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// Counter-based uniform stream (splitmix64 finaliser of seed + (i + 1) * golden ratio), 53-bit mantissa in
-// [0, 1): element i of stream `seed`.  The host restates it exactly (quilt_amd/rng.py).
-__device__ __forceinline__ double stream_uniform(uint64_t seed, uint64_t i) {
-    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
-}
-
-// word of haplotype k (panel index) at grid g with code `code`
-__device__ __forceinline__ uint32_t panel_word(const GibbsParams &p, int g, int k, int code) {
-    if (code > 0) return (uint32_t)p.B[(size_t)g * p.nMaxDH + (code - 1)];
-    int lo = p.sp_off[g], hi = p.sp_off[g + 1] - 1;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (p.sp_k[mid] < k) lo = mid + 1; else hi = mid;
-    }
-    return p.sp_word[lo];
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_ematread: P(read r | small-panel haplotype k) (gibbs-small.cpp:148-263).  One wave per
-// (block of kReadsPerWave consecutive reads, chain); lane l owns rows l, l+64, ...  The chain's haplotype
-// list and the panel words of the current grid stay in registers across the block's reads (reads are sorted
-// by grid).  Products run over the read's bases in order, so each entry is bit-identical to the
-// reference's; then divide by the column max and floor (:235-262).
-// ---------------------------------------------------------------------------------------------
-constexpr int kReadsPerWave = 32;
-constexpr int kMaxPatternBits = 5;
-constexpr int padb_of(int ne) { return ne <= 4 ? 4 : ne <= 8 ? 8 : 16; }
-
-template <int NEALL, int NW>
-__global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
-    constexpr int NE = NEALL / NW, PADB = padb_of(NE), NT = 64 * NW;
-    const int c = blockIdx.y, lane = threadIdx.x;
-    const int R = p.read_off[c + 1] - p.read_off[c];
-    const int r0 = blockIdx.x * kReadsPerWave;
-    if (r0 >= R) return;
-    const int32_t *rp = p.read_ptr + p.read_off[c] + c;
-    const int32_t *u = p.u + p.base_off[c], *bq = p.bq + p.base_off[c];
-    const int32_t *which = p.which + (size_t)c * p.Ks;
-    int kk[NEALL];
-#pragma unroll
-    for (int i = 0; i < NEALL; i++) {
-        const int k = lane + 64 * i;
-        kk[i] = (k < p.Ks) ? which[k] : -1;
-    }
-    int g_prev = -1;
-    uint32_t w[NEALL];
-    const double e1 = 1 - p.ref_error, e0 = p.ref_error;
-    for (int r = r0; r < min(r0 + kReadsPerWave, R); r++) {
-        double v[NEALL];
-        uint32_t pat[NEALL];
-#pragma unroll
-        for (int i = 0; i < NEALL; i++) { v[i] = 1.0; pat[i] = 0; }
-        const int s = rp[r];
-        int J = rp[r + 1] - s - 1;
-        if (J >= p.Jmax) J = p.Jmax;
-        const int dense = p.dense_of[p.read_off[c] + r];
-        int n_inf = 0;
-        double tv = 1.0;   // lane l: the product for allele pattern l (bit j = allele at the read's j-th informative SNP)
-        for (int j = 0; j <= J; j++) {
-            const int b = bq[s + j];
-            const int snp = u[s + j];
-            const int g = snp >> 5;
-            if (g != g_prev) {
-#pragma unroll
-                for (int i = 0; i < NEALL; i++) {
-                    w[i] = 0;
-                    if (kk[i] >= 0) w[i] = panel_word(p, g, kk[i], p.hm[(size_t)g * p.Kp + kk[i]]);
-                }
-                g_prev = g;
-            }
-            if (b == 0) continue;  // no base quality seen yet: factor 1 (host folded the carry-over rule)
-            const int ab = b < 0 ? -b : b;
-            const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
-#pragma unroll
-            for (int i = 0; i < NEALL; i++) {
-                const uint32_t bit = (w[i] >> (snp & 31)) & 1u;
-                const double e = bit ? e1 : e0;
-                v[i] *= (e * pA + (1 - e) * pR);
-                pat[i] |= bit << min(n_inf, 7);
-            }
-            {   // the same factor, in the same order, for this lane's pattern
-                const double e = ((lane >> min(n_inf, 31)) & 1) ? e1 : e0;
-                tv *= (e * pA + (1 - e) * pR);
-            }
-            n_inf++;
-        }
-        bool degenerate = false;
-        double d1 = 1.0;
-        if (p.rescale) {
-            double x = 0;
-#pragma unroll
-            for (int i = 0; i < NEALL; i++) if (kk[i] >= 0 && v[i] > x) x = v[i];
-            x = wmax(x);
-            d1 = 1 / x;
-            degenerate = isinf(x) || x == 0 || isinf(d1);
-            if (degenerate) {
-#pragma unroll
-                for (int i = 0; i < NEALL; i++) v[i] = 1;
-                tv = 1;
-            } else {
-#pragma unroll
-                for (int i = 0; i < NEALL; i++) {
-                    v[i] *= d1;
-                    if (v[i] < p.inv_maxdiff) v[i] = p.inv_maxdiff;
-                }
-                tv *= d1;
-                if (tv < p.inv_maxdiff) tv = p.inv_maxdiff;
-            }
-        }
-        // category 1 (gibbs-nipt.cpp:350-372): no entry below 1 - 1e-12
-        const double thresh = 1 - 1e-12;
-        bool below = false;
-#pragma unroll
-        for (int i = 0; i < NEALL; i++) if (kk[i] >= 0 && v[i] < thresh) below = true;
-        const bool any_below = __any(below);
-        if (lane == 0) p.is_cat1[p.read_off[c] + r] = (any_below || p.disable_read_category_usage) ? 0 : 1;
-        if (dense >= 0) {
-            double *out = p.eMatRead + p.eread_off[c] + (size_t)dense * p.Ksp;
-#pragma unroll
-            for (int i = 0; i < NEALL; i++) out[lane + 64 * i] = (kk[i] >= 0) ? v[i] : 1.0;
-        } else {
-            // (a degenerate read has every entry 1: pattern 63 for every row)
-            p.er_tab[(size_t)(p.read_off[c] + r) * 64 + lane] = (lane < (1 << n_inf) && lane != 63) ? tv : 1.0;
-            uint8_t *ix = p.er_idx + p.eridx_off[c] + (size_t)r * NT * PADB;
-#pragma unroll
-            for (int wv = 0; wv < NW; wv++) {
-                uint32_t pk[PADB / 4];
-#pragma unroll
-                for (int q = 0; q < PADB / 4; q++) pk[q] = 0;
-#pragma unroll
-                for (int i = 0; i < NE; i++) {
-                    const int j = wv + NW * i;   // thread lane + 64 wv of the chain owns rows lane + 64 (wv + NW i)
-                    const uint32_t code = (kk[j] >= 0 && !degenerate) ? pat[j] : 63u;
-                    pk[i >> 2] |= code << ((i & 3) * 8);
-                }
-                uint32_t *dst = reinterpret_cast<uint32_t *>(ix + (size_t)(lane + 64 * wv) * PADB);
-#pragma unroll
-                for (int q = 0; q < PADB / 4; q++) dst[q] = pk[q];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_gibbs: NW wavefronts (one workgroup) per chain; initialisation, all sweeps, shard passes.
-// Thread t of the NT = 64 * NW threads owns small-panel rows t, t + NT, ... (NE of them).
-// ---------------------------------------------------------------------------------------------
-template <int NE>
-struct Col {
-    double v[NE];
-};
-
-template <int NE>
-__device__ __forceinline__ void load_col(Col<NE> &c, const double *src, int t, int NT) {
-#pragma unroll
-    for (int i = 0; i < NE; i++) c.v[i] = src[t + NT * i];
-}
-template <int NE>
-__device__ __forceinline__ void store_col(const Col<NE> &c, double *dst, int t, int NT) {
-#pragma unroll
-    for (int i = 0; i < NE; i++) dst[t + NT * i] = c.v[i];
-}
-
-// 1 / e to within 1 ulp: v_rcp_f64 and two Newton steps (5 instructions; an IEEE division expands to ~15).  The
-// sampler takes a read's emission out of a label with it -- x * (1 / e) where the reference writes x / e: the two can
-// differ in the last bit, 1e-16 relative, against sampling thresholds compared with a 53-bit uniform.
-__device__ __forceinline__ double fast_rcp(double e) {
-    double r = __builtin_amdgcn_rcp(e);
-    r = __builtin_fma(__builtin_fma(-e, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-e, r, 1.0), r, r);
-    return r;
-}
-
-__device__ __forceinline__ double rl_f64(double v, int j) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ int rl_i32(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
-
-template <int NE, int NW>
-struct Chain {
-    static constexpr int NT = 64 * NW;
-    const GibbsParams &p;
-    int c, t, lane, wave, R, G, Ks, Ksp;
-    double *alpha[2], *beta[2], *eg[2], *cv[3];
-    const double *eMatRead;   // dense columns of the reads that have one
-    const uint8_t *eridx;     // compact read emissions (GibbsParams)
-    const double *ertab;
-    const int32_t *dense_of;
-    const int32_t *wif;
-    const uint8_t *ghr, *cat1;
-    int32_t *H, *Hc;
-    double prior;  // 1 / Ks
-    bool valid[NE];
-    double *red;   // LDS [2][NW][4]
-    int par;
-
-    __device__ Chain(const GibbsParams &p_, int c_, int t_, double *red_)
-        : p(p_), c(c_), t(t_), lane(t_ & 63), wave(t_ >> 6), red(red_), par(0) {
-        G = p.G; Ks = p.Ks; Ksp = p.Ksp;
-        R = p.read_off[c + 1] - p.read_off[c];
-        const size_t mat = (size_t)G * Ksp;
-        for (int h = 0; h < 2; h++) {
-            alpha[h] = p.alpha + ((size_t)c * 2 + h) * mat;
-            beta[h] = p.beta + ((size_t)c * 2 + h) * mat;
-            eg[h] = p.eg + ((size_t)c * 2 + h) * mat;
-        }
-        for (int h = 0; h < 3; h++) cv[h] = p.cvec + ((size_t)c * 3 + h) * G;
-        eMatRead = p.eMatRead + p.eread_off[c];
-        eridx = p.er_idx + p.eridx_off[c];
-        ertab = p.er_tab + (size_t)p.read_off[c] * 64;
-        dense_of = p.dense_of + p.read_off[c];
-        wif = p.wif + p.read_off[c];
-        cat1 = p.is_cat1 + p.read_off[c];
-        ghr = p.grid_has_read + (size_t)c * G;
-        H = p.H + p.read_off[c];
-        Hc = p.H_class + p.read_off[c];
-        prior = 1.0 / Ks;
-#pragma unroll
-        for (int i = 0; i < NE; i++) valid[i] = (t + NT * i) < Ks;
-    }
-    // A read's emission column, compact form: this thread's pattern bytes and the lane's table entry (one load each,
-    // issued a read ahead), expanded by a cross-lane gather (ds_bpermute: no memory traffic).
-    static constexpr int PADB = padb_of(NE);
-    struct ErPre {
-        uint32_t w[PADB / 4];
-        double tv;
-    };
-    __device__ __forceinline__ void ld_pre(ErPre &x, int r) const {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(eridx + ((size_t)r * NT + t) * PADB);
-        if constexpr (PADB == 16) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(src);
-            x.w[0] = q.x; x.w[1] = q.y; x.w[2] = q.z; x.w[3] = q.w;
-        } else if constexpr (PADB == 8) {
-            const uint2 q = *reinterpret_cast<const uint2 *>(src);
-            x.w[0] = q.x; x.w[1] = q.y;
-        } else {
-            x.w[0] = *src;
-        }
-        x.tv = ertab[(size_t)r * 64 + lane];
-    }
-    __device__ __forceinline__ void expand(Col<NE> &er, const ErPre &x) const {
-        const int lo = __double2loint(x.tv), hi = __double2hiint(x.tv);
-#pragma unroll
-        for (int i = 0; i < NE; i++) {
-            const int src = (int)((x.w[i >> 2] >> ((i & 3) * 8)) & 0xffu) << 2;
-            er.v[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, hi), __builtin_amdgcn_ds_bpermute(src, lo));
-        }
-    }
-    // emission column of read r with its (wave-uniform) dense row dn
-    __device__ __forceinline__ void read_emission(Col<NE> &er, const ErPre &x, int dn) const {
-        if (dn >= 0) ld(er, eMatRead + (size_t)dn * Ksp);
-        else expand(er, x);
-    }
-
-    __device__ __forceinline__ double tm0(int g) const { return p.sigma[g]; }
-    // transMatRate_t row 1 as the caller passed it (the reference never recomputes 1 - sigma)
-    __device__ __forceinline__ double tm1(int g) const { return p.sigma[p.G - 1 + g]; }
-
-    // workgroup-wide sums of N values per thread; every thread gets the totals.  Waves reduce by DPP, then
-    // exchange through a parity-alternating LDS buffer with a bare s_barrier (lgkmcnt only: the column
-    // prefetches in flight on vmcnt must not be drained here, which __syncthreads() would do).
-    template <int N>
-    __device__ __forceinline__ void bsum(double (&x)[N]) {
-#pragma unroll
-        for (int q = 0; q < N; q++) x[q] = wsum(x[q]);
-        if (NW == 1) return;
-        double *buf = red + (size_t)par * NW * 4;
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < N; q++) buf[wave * 4 + q] = x[q];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < N; q++) {
-            double s = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) s += buf[w * 4 + q];
-            x[q] = s;
-        }
-        par ^= 1;
-    }
-    __device__ __forceinline__ double bsum1(double v) {
-        double x[1] = {v};
-        bsum<1>(x);
-        return x[0];
-    }
-    __device__ __forceinline__ double sum_col(const Col<NE> &c) {
-        double s = 0;
-#pragma unroll
-        for (int i = 0; i < NE; i++) s += c.v[i];
-        return bsum1(s);
-    }
-    __device__ __forceinline__ void sum_col2(const Col<NE> &c0, const Col<NE> &c1, double &s0, double &s1) {
-        double x[2] = {0, 0};
-#pragma unroll
-        for (int i = 0; i < NE; i++) { x[0] += c0.v[i]; x[1] += c1.v[i]; }
-        bsum<2>(x);
-        s0 = x[0]; s1 = x[1];
-    }
-    __device__ __forceinline__ void ld(Col<NE> &c, const double *src) const { load_col(c, src, t, NT); }
-    __device__ __forceinline__ void st(const Col<NE> &c, double *dst) const { store_col(c, dst, t, NT); }
-};
-
-// ---- lane-held scalar streams --------------------------------------------------------------
-// The per-grid / per-read scalars of a chain (c, sigma, grid_has_read; wif, category, label) are uniform,
-// and a uniform value loaded through the vector memory path has to be waited for before it can steer
-// control flow -- which would expose one memory round trip per grid and per read and also drain the
-// column prefetches (in-order vmcnt).  Instead lane j of every wave holds element base + j of each
-// stream: ONE vector load per 64 elements, then v_readlane (no memory) per element, and one store per 64
-// elements (by wave 0) for the streams the sampler updates.
-template <class CH>
-struct GridStreams {   // lane j <-> grid base + j
-    double t0, t1;     // transition INTO the grid (forward) or OUT of it (backward)
-    double c0, c1;
-    int has;           // grid_has_read of the grid (forward) or of grid + 1 (backward)
-    int base;
-    __device__ void load_fwd(const CH &ch, int b) {
-        base = b;
-        const int g = b + ch.lane;
-        const bool ok = g < ch.G;
-        t0 = (ok && g > 0) ? ch.tm0(g - 1) : 1.0;
-        t1 = (ok && g > 0) ? ch.tm1(g - 1) : 0.0;
-        c0 = ok ? ch.cv[0][g] : 1.0;
-        c1 = ok ? ch.cv[1][g] : 1.0;
-        has = ok ? ch.ghr[g] : 0;
-    }
-    __device__ void load_bwd(const CH &ch, int b) {
-        base = b;
-        const int g = b + ch.lane;
-        const bool ok = g < ch.G - 1;
-        t0 = ok ? ch.tm0(g) : 1.0;
-        t1 = ok ? ch.tm1(g) : 0.0;
-        c0 = (g < ch.G) ? ch.cv[0][g] : 1.0;
-        c1 = (g < ch.G) ? ch.cv[1][g] : 1.0;
-        has = ok ? ch.ghr[g + 1] : 0;
-    }
-    __device__ void store_c(const CH &ch) const {
-        const int g = base + ch.lane;
-        if (ch.wave == 0 && g < ch.G) { ch.cv[0][g] = c0; ch.cv[1][g] = c1; }
-    }
-    __device__ __forceinline__ void set_c(int lane, int j, double a, double b) {
-        if (lane == j) { c0 = a; c1 = b; }
-    }
-};
-
-template <class CH>
-struct ReadStreams {   // lane j <-> read base + j
-    int wif, cat1, H, Hc, base, dn;
-    double u;
-    __device__ void load(const CH &ch, int b, const double *runif, int it) {
-        base = b;
-        const int r = b + ch.lane;
-        const bool ok = r < ch.R;
-        wif = ok ? ch.wif[r] : -1;
-        dn = ok ? ch.dense_of[r] : -1;
-        cat1 = ok ? ch.cat1[r] : 1;
-        H = ok ? ch.H[r] : 1;
-        Hc = ok ? ch.Hc[r] : 0;
-        u = (ok && runif) ? runif[(size_t)ch.R * it + r] : 0.0;
-    }
-    __device__ void store(const CH &ch) const {
-        const int r = base + ch.lane;
-        if (ch.wave == 0 && r < ch.R) { ch.H[r] = H; ch.Hc[r] = Hc; }
-    }
-};
-
-// all waves of the chain must see the global-memory stores of the other waves (columns are private to their
-// owning thread, but cv / H / Hc written by wave 0 are re-read by every wave at the next block refill)
-template <int NW>
-__device__ __forceinline__ void chain_sync() {
-    if (NW > 1) __syncthreads();
-}
 
 // Rcpp_run_forward_haploid (copied-from-stitch.cpp:340-387) for both labels, prior = alphaMat = 1/Ks
 template <int NE, int NW>
@@ -1077,7 +615,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
 __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
     const int g = blockIdx.x, c = blockIdx.y;
     const int b = threadIdx.x & 31, part = threadIdx.x >> 5;
-    __shared__ double s_g[2][8][32], s_t[2][8];
+    __shared__ double s_g[3][8][32], s_t[3][8];
     __shared__ uint32_t s_w[1024];
     const int Ks = p.Ks, Ksp = p.Ksp, G = p.G;
     const int32_t *which = p.which + (size_t)c * Ks;
@@ -1088,10 +626,10 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
     __syncthreads();
     const int s = 32 * g, nLocal = min(32, p.T - s);
     const size_t mat = (size_t)G * Ksp;
-    double acc[2] = {0, 0}, tot[2] = {0, 0};
-    for (int h = 0; h < 2; h++) {
-        const double *a = p.alpha + ((size_t)c * 2 + h) * mat + (size_t)g * Ksp;
-        const double *be = p.beta + ((size_t)c * 2 + h) * mat + (size_t)g * Ksp;
+    double acc[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
+    for (int h = 0; h < p.nH; h++) {
+        const double *a = p.alpha + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
+        const double *be = p.beta + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
         const double x = 1 / p.cvec[((size_t)c * 3 + h) * G + g];
         for (int k = part; k < Ks; k += 8) {
             const double gk = (a[k] * be[k]) * x;
@@ -1103,14 +641,14 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
     }
     __syncthreads();
     if (part == 0 && b < nLocal) {
-        double g1[2];
-        for (int h = 0; h < 2; h++) {
+        double g1[3] = {0, 0, 0.0 * (1 - p.ref_error) + 0.0 * p.ref_error};
+        for (int h = 0; h < p.nH; h++) {
             double on = 0, all = 0;
             for (int q = 0; q < 8; q++) { on += s_g[h][q][b]; all += s_t[h][q]; }
             const double off = all - on;  // sum over haplotypes whose bit is 0
             g1[h] = on * (1 - p.ref_error) + off * p.ref_error;
         }
-        const double g0 = g1[0], gB = g1[1], g2 = 0.0 * (1 - p.ref_error) + 0.0 * p.ref_error;
+        const double g0 = g1[0], gB = g1[1], g2 = g1[2];
         double *hp = p.hapProbs + ((size_t)c * p.T + s + b) * 3;
         double *gm = p.genProbsM + ((size_t)c * p.T + s + b) * 3;
         double *gf = p.genProbsF + ((size_t)c * p.T + s + b) * 3;
@@ -1293,7 +831,9 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
         default: throw std::runtime_error("Ksubset geometry not built (Ksubset / 64 rounded up must be 1..10, 12 or 16)");
     }
     QA_HIP(hipEventRecord(ev[1], st));
-    if (NE1 == 10) {
+    if (prm.nH == 3) {
+        qa::launch_gibbs3(&prm, st);   // three-label sampler (NIPT), gibbs3.hip
+    } else if (NE1 == 10) {
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
         else if (nw == 5) launch_gibbs_kernel<2, 5>(prm, st);
         else if (nw == 2) launch_gibbs_kernel<5, 2>(prm, st);
@@ -1348,7 +888,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         std::vector<size_t> eoff(C), ixoff(C);
         std::vector<uint8_t> ghr((size_t)C * G, 0);
         std::vector<int32_t> dense_of(std::max(totR, 1), -1);
-        const int nw = choose_gibbs_waves(Ksp, C, pn->share);
+        const int nw = o->ff != 0.0 ? qa::gibbs3_waves(Ksp) : choose_gibbs_waves(Ksp, C, pn->share);
         const int er_nt = 64 * nw, er_padb = padb_of(NE / nw);
         int maxR = 0;
         size_t etot = 0, ixtot = 0;
@@ -1452,7 +992,8 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         S.er_idx.ensure(std::max<size_t>(ixtot, 1));
         S.er_tab.ensure(std::max<size_t>((size_t)totR * 64, 1));
         S.is_cat1.ensure(std::max(totR, 1));
-        const size_t mat = (size_t)C * 2 * G * Ksp;
+        const int nH = o->ff != 0.0 ? 3 : 2;
+        const size_t mat = (size_t)C * nH * G * Ksp;
         S.alpha.ensure(mat); S.beta.ensure(mat); S.eg.ensure(mat);
         S.cvec.ensure((size_t)C * 3 * G);
         S.H.ensure(std::max(totR, 1)); S.H.upload(H, totR, st);
@@ -1476,6 +1017,17 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         prm.do_shard = o->do_shard_block_gibbs; prm.init_iteratively = o->gibbs_initialize_iteratively;
         prm.disable_read_category_usage = o->disable_read_category_usage;
         prm.class_sum_cutoff = o->class_sum_cutoff;
+        prm.nH = nH;
+        {   // prior over labels and the read-label class prototypes (gibbs-nipt.cpp:2707-2729)
+            const double ff = o->ff, pp[3] = {0.5, (1 - ff) * 0.5, ff * 0.5};
+            const double r[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1},
+                                    {pp[0] / (pp[0] + pp[1]), pp[1] / (pp[0] + pp[1]), 0},
+                                    {pp[0] / (pp[0] + pp[2]), 0, pp[2] / (pp[0] + pp[2])},
+                                    {0, pp[1] / (pp[1] + pp[2]), pp[2] / (pp[1] + pp[2])},
+                                    {pp[0], pp[1], pp[2]}};
+            for (int i = 0; i < 3; i++) prm.prior_probs[i] = pp[i];
+            for (int i = 0; i < 7; i++) for (int j = 0; j < 3; j++) prm.rlc[i][j] = r[i][j];
+        }
         prm.runif_reads = S.runif_reads.p; prm.first_read = S.first_read.p; prm.runif_shard = S.runif_shard.p;
         prm.seed_reads = seed_reads ? S.seeds.p : nullptr;
         prm.seed_shard = (seed_reads && seed_shard) ? S.seeds.p + C : nullptr;
@@ -1557,8 +1109,13 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
         qa::set_error("qa_gibbs_batch: null argument");
         return QA_ERR_INVALID;
     }
-    if (o->ff != 0.0 || !o->sample_is_diploid) {
-        qa::set_error("qa_gibbs_batch: only the diploid sampler (ff = 0, sample_is_diploid) is implemented on the device");
+    if ((o->ff != 0.0) != (o->sample_is_diploid == 0) || o->ff < 0 || o->ff >= 1) {
+        qa::set_error("qa_gibbs_batch: ff > 0 goes with sample_is_diploid = 0 (NIPT), ff = 0 with sample_is_diploid = 1");
+        return QA_ERR_INVALID;
+    }
+    if (o->ff != 0.0 && o->perform_block_gibbs && o->n_block_gibbs_iterations > 0) {
+        qa::set_error("qa_gibbs_batch: the NIPT block Gibbs resampler (gibbs-nipt-block.cpp:1636-1967) is not built yet; "
+                      "call with perform_block_gibbs = 0 for ff > 0");
         return QA_ERR_UNSUPPORTED;
     }
     if (o->Ks <= 0 || o->Ks > 1024) {
@@ -1589,7 +1146,7 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
                 const int32_t *rp = read_ptr + read_off[c1] + c1;
                 size_t n_long = 0;
                 for (size_t r = 0; r < R; r++) n_long += std::min(rp[r + 1] - rp[r], o->Jmax + 1) > kMaxPatternBits;
-                const size_t add = R * (2560 + 512) + n_long * Ksp * 8 + (size_t)6 * G * Ksp * 8 + (size_t)3 * G * 8 +
+                const size_t add = R * (2560 + 512) + n_long * Ksp * 8 + (size_t)(o->ff != 0.0 ? 9 : 6) * G * Ksp * 8 + (size_t)3 * G * 8 +
                                    (want_probs ? (size_t)9 * T * 8 : 0) + 8192;
                 if (c1 > c0 && need + add > budget) break;
                 need += add;

@@ -1,0 +1,406 @@
+// gibbs3.hip -- the read-label sampler with three labels: NIPT mode (fetal fraction ff > 0: maternal transmitted,
+// maternal untransmitted, paternal transmitted) of `rcpp_forwardBackwardGibbsNIPT` (QUILT/src/gibbs-nipt.cpp:2395-3307).
+//
+// Same decomposition as the diploid kernel of gibbs.hip -- one workgroup of NW wavefronts per chain, the current grid's
+// columns of every label in registers, DPP reductions, fp64, no FMA contraction -- written for the general label logic
+// of `sample_reads_in_grid` (:733-1295): three candidate moves per read (stay, the lower of the two other labels, the
+// higher), move probabilities prod_h p(h) * prior(label) with prior = (0.5, (1 - ff) / 2, ff / 2), the 7-prototype read
+// class (record_read_set, :1142-1165).  It is the straightforward form (no software pipelining of the column loads yet).
+//
+// Not built: the NIPT block Gibbs (`Rcpp_block_gibbs_resampler` with its six relabellings and
+// `rcpp_sample_H_using_H_class`, gibbs-nipt-block.cpp:1636-1967): the host rejects ff > 0 together with
+// perform_block_gibbs.  Category 1 reads are not skipped in this mode (:815) but leave every probability unchanged.
+#include "gibbs_dev.hpp"
+
+namespace {
+
+template <int NE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
+    __shared__ double s_red[2 * NW * 4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    using CH = Chain<NE, NW>;
+    CH ch(p, c, t, s_red);
+    constexpr int NT = CH::NT;
+    constexpr int NH = 3;
+    const int G = ch.G, Ksp = ch.Ksp, R = ch.R, Ks = ch.Ks;
+    const double prior = ch.prior;
+    bool (&valid)[NE] = ch.valid;
+    const double *runif = p.seed_reads ? nullptr : p.runif_reads + (size_t)p.read_off[c] * p.n_its;
+    const uint64_t seed_reads = p.seed_reads ? p.seed_reads[c] : 0;
+    const int first_read = p.first_read[c];
+    const bool init_iteratively = p.init_iteratively && first_read >= 0;
+    const double one_over_K = 1 / (double)Ks;
+
+    auto sum3 = [&](const Col<NE> (&x)[NH], double (&s)[NH]) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            s[h] = 0;
+#pragma unroll
+            for (int i = 0; i < NE; i++) s[h] += x[h].v[i];
+        }
+        ch.template bsum<NH>(s);
+    };
+    // wave-uniform scalars straight from memory (this kernel does not use the lane-held streams)
+    auto uni_d = [](const double *q) { return rl_f64(*q, 0); };
+    auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+
+    // ---- c = 0 (arma::zeros, :2676-2678), H_class = 0, eMatGrid = 1
+    for (int h = 0; h < 3; h++)
+        for (int g = t; g < G; g += NT) ch.cv[h][g] = 0.0;
+    for (int r = t; r < R; r += NT) ch.Hc[r] = 0;
+    {
+        Col<NE> one;
+#pragma unroll
+        for (int i = 0; i < NE; i++) one.v[i] = 1.0;
+        for (int h = 0; h < NH; h++)
+            for (int g = 0; g < G; g++) ch.st(one, ch.eg[h] + (size_t)g * Ksp);
+    }
+    chain_sync<NW>();
+
+    // forward over all grids for every label (Rcpp_run_forward_haploid, copied-from-stitch.cpp:340-387)
+    auto forward_full = [&]() {
+        Col<NE> a[NH], e[NH];
+        for (int g = 0; g < G; g++) {
+            const double s0 = g > 0 ? ch.tm0(g - 1) : 1.0, s1 = g > 0 ? ch.tm1(g - 1) : 0.0;
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    if (g == 0) a[h].v[i] = valid[i] ? prior * e[h].v[i] : 0.0;
+                    else a[h].v[i] = valid[i] ? e[h].v[i] * (s0 * a[h].v[i] + s1 * prior) : 0.0;
+                }
+            }
+            double sm[NH];
+            sum3(a, sm);
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                const double cc = 1 / sm[h];
+#pragma unroll
+                for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * cc;
+                ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+                if (t == 0) ch.cv[h][g] = cc;
+            }
+        }
+        chain_sync<NW>();
+    };
+    // Rcpp_run_backward_haploid (copied-from-stitch.cpp:392-409) or its QUILT_faster form (:417-440); beta(G-1) = c(G-1)
+    auto backward_full = [&](bool faster) {
+        Col<NE> b[NH], e[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const double cl = uni_d(&ch.cv[h][G - 1]);
+#pragma unroll
+            for (int i = 0; i < NE; i++) b[h].v[i] = valid[i] ? cl : 0.0;
+            ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
+        }
+        for (int g = G - 2; g >= 0; --g) {
+            const double s0 = ch.tm0(g), s1 = ch.tm1(g);
+            const bool has = !faster || uni_i(ch.ghr[g + 1]) != 0;
+            double x[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                ch.ld(e[h], ch.eg[h] + (size_t)(g + 1) * Ksp);
+                x[h] = 0;
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    if (has) b[h].v[i] = e[h].v[i] * b[h].v[i];
+                    if (faster) x[h] += b[h].v[i];
+                    else x[h] += valid[i] ? prior * b[h].v[i] : 0.0;
+                }
+            }
+            ch.template bsum<NH>(x);
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                const double cg = uni_d(&ch.cv[h][g]);
+                const double xx = faster ? s1 * x[h] * one_over_K : s1 * x[h];
+#pragma unroll
+                for (int i = 0; i < NE; i++) b[h].v[i] = valid[i] ? cg * (xx + s0 * b[h].v[i]) : 0.0;
+                ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
+            }
+        }
+        chain_sync<NW>();
+    };
+    auto emission_of = [&](Col<NE> &er, int r) {
+        typename CH::ErPre x;
+        ch.ld_pre(x, r);
+        ch.read_emission(er, x, uni_i(ch.dense_of[r]));
+    };
+
+    // ---- rcpp_gibbs_nipt_initialize (:1629-1750)
+    if (!init_iteratively) {
+        int r = 0;
+        while (r < R) {   // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281): reads are sorted by grid
+            const int g = uni_i(ch.wif[r]);
+            Col<NE> e[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int i = 0; i < NE; i++) e[h].v[i] = 1.0;
+            while (r < R && uni_i(ch.wif[r]) == g) {
+                Col<NE> er;
+                emission_of(er, r);
+                const int hh = uni_i(ch.H[r]) - 1;
+#pragma unroll
+                for (int h = 0; h < NH; h++)
+                    if (hh == h) {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) e[h].v[i] *= er.v[i];
+                    }
+                r++;
+            }
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+        }
+        chain_sync<NW>();
+        forward_full();
+        backward_full(false);   // rcpp_initialize_gibbs_forward_backward (:453-487)
+    } else {
+        // alpha = beta = 1, c = 1, then only column 0 of alpha is initialised (:1725-1740)
+        Col<NE> one;
+#pragma unroll
+        for (int i = 0; i < NE; i++) one.v[i] = valid[i] ? 1.0 : 0.0;
+        for (int h = 0; h < NH; h++) {
+            for (int g = 0; g < G; g++) {
+                ch.st(one, ch.alpha[h] + (size_t)g * Ksp);
+                ch.st(one, ch.beta[h] + (size_t)g * Ksp);
+            }
+            for (int g = t; g < G; g += NT) ch.cv[h][g] = 1.0;
+        }
+        chain_sync<NW>();
+        for (int h = 0; h < NH; h++) {
+            Col<NE> a;
+#pragma unroll
+            for (int i = 0; i < NE; i++) a.v[i] = valid[i] ? prior * 1.0 : 0.0;
+            const double cc = 1 / ch.sum_col(a);
+#pragma unroll
+            for (int i = 0; i < NE; i++) a.v[i] = a.v[i] * cc;
+            ch.st(a, ch.alpha[h]);
+            if (t == 0) ch.cv[h][0] = cc;
+        }
+    }
+    chain_sync<NW>();
+
+    int status = 0;
+    for (int it = 0; it < p.n_its && status == 0; it++) {
+        // ================= rcpp_gibbs_nipt_iterate (:1756-1956) =================
+        Col<NE> a[NH];
+        int iRead = 0;
+        for (int g = 0; g < G; g++) {
+            Col<NE> e[NH], bt[NH];
+            double cg[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
+                ch.ld(bt[h], ch.beta[h] + (size_t)g * Ksp);
+            }
+            if (g > 0) {
+                // rcpp_alpha_forward_one_QUILT_faster (:671-707), normalize = true
+                const double x = ch.tm0(g - 1), t1 = ch.tm1(g - 1);
+                const bool has = uni_i(ch.ghr[g]) != 0;
+                double sp[NH];
+                sum3(a, sp);
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    const double alphaConst = t1 * sp[h];
+#pragma unroll
+                    for (int i = 0; i < NE; i++) {
+                        const double inner = (x * a[h].v[i] + alphaConst * one_over_K);
+                        a[h].v[i] = valid[i] ? (has ? e[h].v[i] * inner : inner) : 0.0;
+                    }
+                }
+                double sn[NH];
+                sum3(a, sn);
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    const double c2 = uni_d(&ch.cv[h][g]);
+                    double aa = 1 / (c2 * sn[h]);
+                    cg[h] = c2 * aa;
+                    aa *= c2;
+#pragma unroll
+                    for (int i = 0; i < NE; i++) a[h].v[i] *= aa;
+                }
+            } else {
+                // rcpp_reinitialize_in_iterations (:712-727)
+#pragma unroll
+                for (int h = 0; h < NH; h++)
+#pragma unroll
+                    for (int i = 0; i < NE; i++) a[h].v[i] = valid[i] ? prior * e[h].v[i] : 0.0;
+                double sn[NH];
+                sum3(a, sn);
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    cg[h] = 1 / sn[h];
+#pragma unroll
+                    for (int i = 0; i < NE; i++) a[h].v[i] *= cg[h];
+                }
+            }
+            // ---- sample_reads_in_grid (:733-1295), three labels
+            bool grid_started = false, changed = false;
+            Col<NE> ab[NH];
+            double pC[3] = {1, 1, 1};
+            bool normal = false, ginit = false, pass = false;
+            while (iRead < R && uni_i(ch.wif[iRead]) == g) {
+                const int r = iRead;
+                iRead++;
+                // (not diploid: reads of every category are visited, :815)
+                if (!init_iteratively) normal = true;
+                else if (r < first_read && it == 0) pass = true;
+                else if (first_read <= r && it == 0) { pass = false; ginit = true; }
+                else if (r < first_read && it == 1) { pass = false; ginit = true; }
+                else { ginit = false; normal = true; }
+                if (!grid_started) {
+#pragma unroll
+                    for (int h = 0; h < NH; h++)
+#pragma unroll
+                        for (int i = 0; i < NE; i++) ab[h].v[i] = a[h].v[i] * bt[h].v[i];
+                    sum3(ab, pC);
+                    grid_started = true;
+                }
+                Col<NE> er;
+                emission_of(er, r);
+                int h_rC = 0, h_rA1 = 1, h_rA2 = 2;
+                double pA1[3] = {pC[0], pC[1], pC[2]}, pA2[3] = {pC[0], pC[1], pC[2]};
+                if (normal) {
+                    h_rC = uni_i(ch.H[r]) - 1;
+                    if (h_rC == 0) { h_rA1 = 1; h_rA2 = 2; }
+                    else if (h_rC == 1) { h_rA1 = 0; h_rA2 = 2; }
+                    else { h_rA1 = 0; h_rA2 = 1; }
+                    if (uni_i(ch.cat1[r]) == 0) {
+                        // dense form for categories 0, 2 and 3 (the sparse updates of 2 / 3 are the same sums)
+                        double s[3] = {0, 0, 0};
+#pragma unroll
+                        for (int h = 0; h < NH; h++) {
+                            double acc = 0;
+#pragma unroll
+                            for (int i = 0; i < NE; i++) acc += (h == h_rC) ? ab[h].v[i] / er.v[i] : ab[h].v[i] * er.v[i];
+                            s[h] = acc;
+                        }
+                        ch.template bsum<3>(s);
+                        pA1[h_rC] = s[h_rC];
+                        pA1[h_rA1] = s[h_rA1];
+                        pA2[h_rA2] = s[h_rA2];
+                    }
+                    pA2[h_rA1] = pC[h_rA1];
+                    pA2[h_rC] = pA1[h_rC];
+                } else if (ginit) {
+                    double s[3] = {0, 0, 0};
+#pragma unroll
+                    for (int h = 0; h < NH; h++)
+#pragma unroll
+                        for (int i = 0; i < NE; i++) s[h] += ab[h].v[i] * er.v[i];
+                    ch.template bsum<3>(s);
+                    pC[0] = s[0];
+                    pA1[1] = s[1];
+                    pA2[2] = s[2];
+                }
+                const double prod_pC = (pC[0] * pC[1] * pC[2]) * p.prior_probs[h_rC];
+                const double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * p.prior_probs[h_rA1];
+                const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * p.prior_probs[h_rA2];
+                const double denom = prod_pC + prod_pA1 + prod_pA2;
+                const double norm_pC = prod_pC / denom, norm_pA1 = prod_pA1 / denom, norm_pA2 = prod_pA2 / denom;
+                const double chance = runif ? uni_d(&runif[(size_t)R * it + r]) : stream_uniform(seed_reads, (uint64_t)R * it + r);
+                double x3[3];
+                x3[h_rC] = norm_pC; x3[h_rA1] = norm_pA1; x3[h_rA2] = norm_pA2;
+                const double cs0 = x3[0], cs1 = x3[1] + cs0, cs2 = x3[2] + cs1;
+                int h_rN = 0;
+                if (chance < cs2) h_rN = 2;
+                if (chance < cs1) h_rN = 1;
+                if (chance < cs0) h_rN = 0;
+                if (((h_rN != h_rC) || ginit) && !pass) {
+                    changed = true;
+                    if (t == 0) ch.H[r] = h_rN + 1;
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        if (normal && h == h_rC) {
+#pragma unroll
+                            for (int i = 0; i < NE; i++) { a[h].v[i] /= er.v[i]; ab[h].v[i] /= er.v[i]; e[h].v[i] /= er.v[i]; }
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        if (h == h_rN) {
+#pragma unroll
+                            for (int i = 0; i < NE; i++) { a[h].v[i] *= er.v[i]; ab[h].v[i] *= er.v[i]; e[h].v[i] *= er.v[i]; }
+                        }
+                    }
+                    if (normal) {
+                        // the A1 move goes to the lower of the two other labels, A2 to the higher (:1103-1117)
+                        const bool to_a1 = h_rN == h_rA1;
+                        for (int i = 0; i < 3; i++) pC[i] = to_a1 ? pA1[i] : pA2[i];
+                    } else if (ginit) {
+                        if (h_rN == 1) for (int i = 0; i < 3; i++) pC[i] = pA1[i];
+                        if (h_rN == 2) for (int i = 0; i < 3; i++) pC[i] = pA2[i];
+                    }
+                }
+                {   // record_read_set (:1142-1165)
+                    double local_min = 2;
+                    int which = 8;
+                    for (int i = 0; i < 7; i++) {
+                        const double y = fabs(p.rlc[i][0] - x3[0]) + fabs(p.rlc[i][1] - x3[1]) + fabs(p.rlc[i][2] - x3[2]);
+                        if (y < local_min) { local_min = y; which = i; }
+                    }
+                    if (t == 0) ch.Hc[r] = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
+                }
+            }
+            if (changed) {
+                // re-inject the moved columns and renormalise (:1262-1292)
+                double sm[NH];
+                sum3(a, sm);
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    const double alphaConst = 1 / sm[h];
+                    cg[h] *= alphaConst;
+#pragma unroll
+                    for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
+                    ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+                if (t == 0) ch.cv[h][g] = cg[h];
+            }
+        }
+        chain_sync<NW>();
+        backward_full(true);
+        // ---- underflow check (:2959-2969): with ff != 0 the third label's c is not looked at
+        {
+            double s[2] = {0, 0};
+            for (int g = t; g < G; g += NT) { s[0] += ch.cv[0][g]; s[1] += ch.cv[1][g]; }
+            ch.template bsum<2>(s);
+            if (!isfinite(s[0]) || !isfinite(s[1])) status = 1;
+        }
+    }
+    if (t == 0) p.status[c] = status;
+}
+
+template <int NE, int NW>
+void launch_one(const GibbsParams &prm, hipStream_t st) {
+    hipLaunchKernelGGL((k_gibbs3<NE, NW>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
+    QA_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+namespace qa {
+
+// geometry: two waves per chain for Ksp = 640 (5 columns per lane and label), one otherwise
+int gibbs3_waves(int Ksp) { return Ksp == 640 ? 2 : 1; }
+
+void launch_gibbs3(const void *params, hipStream_t st) {
+    const GibbsParams &prm = *static_cast<const GibbsParams *>(params);
+    switch (prm.Ksp / 64) {
+        case 1: launch_one<1, 1>(prm, st); break;
+        case 2: launch_one<2, 1>(prm, st); break;
+        case 3: launch_one<3, 1>(prm, st); break;
+        case 4: launch_one<4, 1>(prm, st); break;
+        case 5: launch_one<5, 1>(prm, st); break;
+        case 6: launch_one<6, 1>(prm, st); break;
+        case 8: launch_one<8, 1>(prm, st); break;
+        case 10: launch_one<5, 2>(prm, st); break;
+        default: throw std::runtime_error("NIPT sampler: Ksubset geometry not built (Ksubset / 64 rounded up must be 1..6, 8 or 10)");
+    }
+}
+
+}  // namespace qa

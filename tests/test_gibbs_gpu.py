@@ -194,3 +194,38 @@ def test_gibbs_underflow_is_reported(small_panel, oracle):
     assert ref["status"] == 1, "the test input is meant to underflow"
     assert got["underflow_problem"]
     dev.close()
+
+
+@pytest.mark.parametrize("init_iter", [False, True])
+@pytest.mark.parametrize("panel_name,Ks,n_reads", [("small_panel", 100, 150), ("medium_panel", 600, 900)])
+def test_nipt_three_label_sampler(request, oracle, panel_name, Ks, n_reads, init_iter):
+    """NIPT mode (BASELINE configs[4] in small): ff > 0, three read labels, the sampler without the block resampler
+    (the NIPT block Gibbs is not built: perform_block_gibbs must be off).  Labels and classes identical, hapProbs /
+    genProbs (all three haplotypes) to 1e-9."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel, QuiltAmdError
+    from quilt_amd.synth import make_synthetic_sample
+    panel = request.getfixturevalue(panel_name)
+    dev = DevicePanel(panel)
+    ff = 0.2
+    s = make_synthetic_sample(panel, seed=21, n_reads=n_reads, ff=ff)
+    rng = np.random.default_rng(5)
+    which = np.sort(rng.choice(panel.K, Ks, replace=False)).astype(np.int32) + 1
+    H0 = rng.integers(1, 4, size=s.nReads).astype(np.int32)
+    ru = rng.random(s.nReads * 21)
+    rs = rng.random(3 * (panel.nGrids - 1))
+    fr = int(rng.integers(0, s.nReads))
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs, ff=ff, perform_block_gibbs=False,
+                                          gibbs_initialize_iteratively=init_iter)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, ff=ff, perform_block_gibbs=False,
+                                        gibbs_initialize_iteratively=init_iter)
+    assert ref["status"] == 0 and not got["underflow_problem"]
+    assert set(np.unique(ref["H"])) <= {1, 2, 3} and (ref["H"] == 3).any()
+    assert np.array_equal(got["H"], ref["H"]), f"{(got['H'] != ref['H']).sum()} labels differ"
+    assert np.array_equal(got["H_class"], ref["H_class"])
+    np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(got["genProbsM_t"], ref["genProbsM_t"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(got["genProbsF_t"], ref["genProbsF_t"], rtol=RTOL, atol=1e-14)
+    with pytest.raises(QuiltAmdError):   # the NIPT block resampler is not built: refused, not silently skipped
+        rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, ff=ff)
+    dev.close()
