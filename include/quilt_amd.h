@@ -289,6 +289,50 @@ int qa_rcpp_make_eMatRead_t(qa_panel_t *panel, int32_t n_chain, int32_t K, const
                             const int32_t *bq, double maxDifferenceBetweenReads, int32_t Jmax,
                             int32_t rescale_eMatRead_t, double *eMatRead_t);
 
+/* As qa_rcpp_make_eMatRead_t with eHapsCurrent_tc of nSNPs columns rather than the panel's: the all-SNP read
+ * likelihoods of get_initial_read_labels (QUILT/R/rare_common.R:61-107). */
+int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *panel, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                                  const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
+                                  const int32_t *bq, double maxDifferenceBetweenReads, int32_t Jmax,
+                                  int32_t rescale_eMatRead_t, double *eMatRead_t);
+
+/* ---- rare + common SNPs: the final all-SNP Gibbs of QUILT2 ------------------ */
+
+/*
+ * The all-SNP side of a panel prepared with impute_rare_common = TRUE: `special_rare_common_objects`
+ * (QUILT/R/prepare_reference_functions.R:172-247) as far as the native call uses it.  The panel tables cover the
+ * common SNPs; rare SNPs are held per haplotype.
+ *   snp_is_common        nSNPs_all flags; sum = the panel's nSNPs (common_snp_index of QUILT/R/rare_common.R:222-223
+ *                        is derived from it)
+ *   rare_ptr, rare_snp   rare_per_hap_info as CSR over the K panel haplotypes: 1-based all-SNP indices of the rare
+ *                        SNPs haplotype k carries the alt of, ascending
+ *   transMatRate_t_all   2 x (nGrids_all - 1), column-major, of the all-SNP grid (32 SNPs per grid):
+ *                        small_transMatRate_tc_H of special_rare_common_objects
+ */
+typedef struct qa_rare_common qa_rare_common_t;
+int qa_rare_common_create(qa_panel_t *panel, int32_t nSNPs_all, const uint8_t *snp_is_common,
+                          const int64_t *rare_ptr, const int32_t *rare_snp_1based,
+                          const double *transMatRate_t_all, qa_rare_common_t **out);
+void qa_rare_common_destroy(qa_rare_common_t *rc);
+
+/*
+ * `_QUILT_rcpp_forwardBackwardGibbsNIPT` called with make_eMatRead_t_rare_common = TRUE
+ * (QUILT/R/rare_common.R:325-398 via impute_one_sample; QUILT/src/gibbs-nipt.cpp:2805-2806 and :2305-2318):
+ * read emissions by Rcpp_make_eMatRead_t_for_final_rare_common_gibbs_using_objects
+ * (QUILT/src/gibbs-small.cpp:270-460), hapProbs / genProbs by
+ * rcpp_calculate_genProbs_and_hapProbs_final_rare_common (:711-867).  Arguments as qa_gibbs_batch, except that
+ * u indexes ALL SNPs, wif is the read's grid among the nGrids_all all-SNP grids, runif_shard holds
+ * (nGrids_all - 1) uniforms per pass, and hapProbs_t / genProbs*_t are per chain 3 x nSNPs_all.
+ * rare_per_snp_info (QUILT/R/rare_common.R:313-322) is derived here from rare_per_hap_info and which_haps_to_use.
+ */
+int qa_gibbs_batch_rare_common(qa_panel_t *panel, const qa_rare_common_t *rc, const qa_gibbs_opts_t *opts,
+                               int32_t n_chain, const int32_t *which_haps_to_use_1based, const int32_t *read_off,
+                               const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif,
+                               const double *runif_reads, const int32_t *first_read, const double *runif_shard,
+                               int32_t *H, int32_t *H_class, double *hapProbs_t, double *genProbsM_t,
+                               double *genProbsF_t, int32_t *underflow_problem, double *state_out,
+                               const uint64_t *seed_reads, const uint64_t *seed_shard);
+
 #ifdef __cplusplus
 }
 #endif

@@ -582,6 +582,177 @@ static void calc_hapProbs(const qo_panel_t *p, const int32_t *which_1based, swee
     free(gam);
 }
 
+/* ---- rare + common SNPs: the final all-SNP Gibbs of QUILT2 (rare_common.R:109-420) ------------- */
+
+/* rare_per_snp_info (rare_common.R:313-322) for one which_haps_to_use: per all-SNP index the small-panel rows
+ * (0-based here, in increasing order, as the R loop appends them) whose haplotype carries the alt.  An empty list
+ * here is R's lone -1 ("k_with_alt.length() == 1"). */
+typedef struct {
+    int64_t *ptr;
+    int32_t *k;
+} rare_snp_lists_t;
+
+static rare_snp_lists_t build_rare_per_snp(const qo_rare_common_t *rc, const int32_t *which_1based, int Ks)
+{
+    rare_snp_lists_t L;
+    const int T = rc->nSNPs_all;
+    L.ptr = (int64_t *)calloc((size_t)T + 1, sizeof(int64_t));
+    for (int k = 0; k < Ks; k++) {
+        const int hap = which_1based[k] - 1;
+        for (int64_t i = rc->rare_ptr[hap]; i < rc->rare_ptr[hap + 1]; i++) L.ptr[rc->rare_snp_1based[i]]++;
+    }
+    for (int t = 0; t < T; t++) L.ptr[t + 1] += L.ptr[t];
+    L.k = (int32_t *)malloc(sizeof(int32_t) * (size_t)(L.ptr[T] > 0 ? L.ptr[T] : 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(T > 0 ? T : 1));
+    for (int t = 0; t < T; t++) cur[t] = L.ptr[t];
+    for (int k = 0; k < Ks; k++) {
+        const int hap = which_1based[k] - 1;
+        for (int64_t i = rc->rare_ptr[hap]; i < rc->rare_ptr[hap + 1]; i++) L.k[cur[rc->rare_snp_1based[i] - 1]++] = k;
+    }
+    free(cur);
+    return L;
+}
+
+/* Rcpp_make_eMatRead_t_for_final_rare_common_gibbs_using_objects (gibbs-small.cpp:270-460) */
+void qo_make_eMatRead_t_rare_common(
+    const qo_panel_t *p, const qo_rare_common_t *rc, const int32_t *which_haps_to_use_1based, int Ks, int nReads,
+    const int32_t *read_ptr, const int32_t *u, const int32_t *bq, int rescale_eMatRead_t, int Jmax,
+    double maxDifferenceBetweenReads, double *eMatRead_t /* Ks x nReads, pre-filled with 1 */)
+{
+    double pR = 1, pA = 1; /* carried over between reads when bq == 0 (:293-294) */
+    const double d2 = 1 / maxDifferenceBetweenReads;
+    const double ref_error = p->ref_error, one_minus_ref_error = 1 - ref_error;
+    rare_snp_lists_t L = build_rare_per_snp(rc, which_haps_to_use_1based, Ks);
+    int *codes = (int *)malloc(sizeof(int) * (size_t)Ks);
+    for (int r = 0; r < nReads; r++) {
+        const int32_t *ru = u + read_ptr[r], *rbq = bq + read_ptr[r];
+        int J = read_ptr[r + 1] - read_ptr[r] - 1;
+        double *col = eMatRead_t + (size_t)Ks * r;
+        int g_prev = -1;
+        if (J >= Jmax) J = Jmax;
+        for (int j = 0; j <= J; j++) {
+            if (rbq[j] < 0) {
+                double eps = pow(10, (double)rbq[j] / 10);
+                pR = 1 - eps;
+                pA = eps / 3;
+            }
+            if (rbq[j] > 0) {
+                double eps = pow(10, -(double)rbq[j] / 10);
+                pR = eps / 3;
+                pA = 1 - eps;
+            }
+            const int snp = ru[j];
+            if (rc->snp_is_common[snp]) {
+                const int uc = rc->common_snp_index[snp] - 1; /* index among the common SNPs (:347) */
+                const int g = uc / 32;
+                if (g != g_prev)
+                    for (int k = 0; k < Ks; k++) codes[k] = panel_code(p, which_haps_to_use_1based[k] - 1, g);
+                g_prev = g;
+                for (int k = 0; k < Ks; k++) {
+                    double e;
+                    if (codes[k] > 0) {
+                        e = p->distinctHapsIE[(size_t)p->nMaxDH * uc + (codes[k] - 1)];
+                    } else {
+                        uint32_t w = panel_special_word(p, which_haps_to_use_1based[k] - 1, g);
+                        e = ((w >> (uc % 32)) & 1u) ? 1 - ref_error : ref_error;
+                    }
+                    col[k] *= (e * pA + (1 - e) * pR);
+                }
+            } else {
+                const int64_t a0 = L.ptr[snp], a1 = L.ptr[snp + 1];
+                if (a0 == a1) { /* no selected haplotype carries the alt (:385-389) */
+                    if (!rescale_eMatRead_t) {
+                        double xe1 = ref_error * pA + one_minus_ref_error * pR;
+                        for (int k = 0; k < Ks; k++) col[k] *= xe1;
+                    }
+                } else { /* everyone as ref, then the carriers re-done (:390-400) */
+                    double xe1 = ref_error * pA + one_minus_ref_error * pR;
+                    double xe2 = one_minus_ref_error * pA + ref_error * pR;
+                    for (int k = 0; k < Ks; k++) col[k] *= xe1;
+                    for (int64_t i = a0; i < a1; i++) col[L.k[i]] *= xe2 / xe1;
+                }
+            }
+        }
+        if (rescale_eMatRead_t) {
+            double x = 0;
+            for (int k = 0; k < Ks; k++) if (col[k] > x) x = col[k];
+            double d1 = 1 / x;
+            if (isinf(x) || x == 0 || isinf(d1)) {
+                for (int k = 0; k < Ks; k++) col[k] = 1;
+            } else {
+                for (int k = 0; k < Ks; k++) {
+                    col[k] *= d1;
+                    if (col[k] < d2) col[k] = d2;
+                }
+            }
+        }
+    }
+    free(codes); free(L.ptr); free(L.k);
+}
+
+/* rcpp_calculate_genProbs_and_hapProbs_final_rare_common (gibbs-small.cpp:711-867); the outputs start at 0 */
+static void calc_hapProbs_rare_common(const qo_panel_t *p, const qo_rare_common_t *rc, const int32_t *which_1based,
+                                      sweep_t *S, double *genProbsM, double *genProbsF, double *hapProbs)
+{
+    const int Ks = S->Ks, T = rc->nSNPs_all, nH = S->nH;
+    const double ref_error = p->ref_error, one_minus_2_times_ref_error = 1 - 2 * ref_error;
+    rare_snp_lists_t L = build_rare_per_snp(rc, which_1based, Ks);
+    double *gam = (double *)calloc((size_t)3 * Ks, sizeof(double));
+    for (size_t i = 0; i < (size_t)3 * T; i++) hapProbs[i] = genProbsM[i] = genProbsF[i] = 0;
+    int g_prev = -1;
+    for (int snp = 0; snp < T; snp++) {
+        const int g = snp / 32;
+        double *hp = hapProbs + 3 * (size_t)snp;
+        if (g != g_prev) {
+            for (int h = 0; h < nH; h++) {
+                double x = 1 / S->c[h][g];
+                const double *a = S->alpha[h] + (size_t)Ks * g, *b = S->beta[h] + (size_t)Ks * g;
+                for (int k = 0; k < Ks; k++) gam[(size_t)Ks * h + k] = (a[k] * b[k]) * x;
+            }
+            g_prev = g;
+        }
+        if (rc->snp_is_common[snp]) {
+            const int cs = rc->common_snp_index[snp] - 1, cg = cs / 32;
+            for (int k = 0; k < Ks; k++) {
+                const int kk = panel_code(p, which_1based[k] - 1, cg);
+                double d;
+                if (kk > 0) {
+                    d = p->distinctHapsIE[(size_t)p->nMaxDH * cs + (kk - 1)];
+                } else {
+                    uint32_t w = panel_special_word(p, which_1based[k] - 1, cg);
+                    d = ((w >> (cs % 32)) & 1u) ? 1 - ref_error : ref_error;
+                }
+                for (int h = 0; h < nH; h++) hp[h] += gam[(size_t)Ks * h + k] * d;
+            }
+        } else {
+            const int64_t a0 = L.ptr[snp], a1 = L.ptr[snp + 1];
+            if (a0 == a1) {
+                for (int h = 0; h < nH; h++) hp[h] = ref_error;
+            } else {
+                for (int k = 0; k < Ks; k++)
+                    for (int h = 0; h < nH; h++) hp[h] += gam[(size_t)Ks * h + k] * ref_error;
+                for (int64_t i = a0; i < a1; i++)
+                    for (int h = 0; h < nH; h++) hp[h] += gam[(size_t)Ks * h + L.k[i]] * one_minus_2_times_ref_error;
+            }
+        }
+        {
+            double h1 = hp[0], h2 = hp[1];
+            double *gm = genProbsM + 3 * (size_t)snp;
+            gm[0] = (1 - h1) * (1 - h2);
+            gm[1] = h1 * (1 - h2) + h2 * (1 - h1);
+            gm[2] = h1 * h2;
+        }
+        if (nH == 3) {
+            double h1 = hp[0], h2 = hp[2];
+            double *gf = genProbsF + 3 * (size_t)snp;
+            gf[0] = (1 - h1) * (1 - h2);
+            gf[1] = h1 * (1 - h2) + h2 * (1 - h1);
+            gf[2] = h1 * h2;
+        }
+    }
+    free(gam); free(L.ptr); free(L.k);
+}
+
 /*
  * rcpp_forwardBackwardGibbsNIPT (gibbs-nipt.cpp:2395-3307), production path.
  * Returns 0 ok, 1 underflow_problem (:2959-2969), -2 unsupported (NIPT block Gibbs).
@@ -591,13 +762,15 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
              double *eMatRead_t, int32_t *read_category_out, double *hapProbs_t, double *genProbsM_t,
              double *genProbsF_t)
 {
-    const int Ks = a->Ks, G = p->nGrids, R = a->nReads, T = p->nSNPs;
+    const qo_rare_common_t *rc = a->rc;
+    const int Ks = a->Ks, G = rc ? rc->nGrids_all : p->nGrids, R = a->nReads, T = rc ? rc->nSNPs_all : p->nSNPs;
     const int nH = a->sample_is_diploid ? 2 : 3;
     const int n_its = a->n_gibbs_burn_in_its + a->n_gibbs_sample_its;
     sweep_t S;
     memset(&S, 0, sizeof S);
     S.Ks = Ks; S.G = G; S.R = R; S.nH = nH;
-    S.eMatRead = eMatRead_t; S.wif = a->wif; S.grid_has_read = a->grid_has_read; S.tm = p->transMatRate_t;
+    S.eMatRead = eMatRead_t; S.wif = a->wif; S.grid_has_read = a->grid_has_read;
+    S.tm = rc ? rc->transMatRate_t_all : p->transMatRate_t;
     S.H = H; S.H_class = H_class; S.sample_is_diploid = a->sample_is_diploid;
     S.class_sum_cutoff = a->class_sum_cutoff;
     const double ff = a->ff;
@@ -620,9 +793,13 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
 
     /* emissions (pass_in_eMatRead_t = FALSE: ones, then multiply) */
     for (size_t i = 0; i < (size_t)Ks * R; i++) eMatRead_t[i] = 1;
-    qo_make_eMatRead_t_for_gibbs_using_objects(p, a->which_haps_to_use_1based, Ks, R, a->read_ptr, a->u, a->bq,
-                                               a->rescale_eMatRead_t, a->Jmax, a->maxDifferenceBetweenReads,
-                                               eMatRead_t);
+    if (rc) /* make_eMatRead_t_rare_common (gibbs-nipt.cpp:2805-2806) */
+        qo_make_eMatRead_t_rare_common(p, rc, a->which_haps_to_use_1based, Ks, R, a->read_ptr, a->u, a->bq,
+                                       a->rescale_eMatRead_t, a->Jmax, a->maxDifferenceBetweenReads, eMatRead_t);
+    else
+        qo_make_eMatRead_t_for_gibbs_using_objects(p, a->which_haps_to_use_1based, Ks, R, a->read_ptr, a->u, a->bq,
+                                                   a->rescale_eMatRead_t, a->Jmax, a->maxDifferenceBetweenReads,
+                                                   eMatRead_t);
     int32_t *n_non1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
     int32_t *idx_non1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)Ks * (R > 0 ? R : 1));
     int32_t *cat = (int32_t *)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
@@ -680,7 +857,10 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
             }
         }
         if (it + 1 > a->n_gibbs_burn_in_its) {
-            calc_hapProbs(p, a->which_haps_to_use_1based, &S, genProbsM_t, genProbsF_t, hapProbs_t);
+            if (rc) /* gibbs-nipt.cpp:2305-2318 */
+                calc_hapProbs_rare_common(p, rc, a->which_haps_to_use_1based, &S, genProbsM_t, genProbsF_t, hapProbs_t);
+            else
+                calc_hapProbs(p, a->which_haps_to_use_1based, &S, genProbsM_t, genProbsF_t, hapProbs_t);
         }
     }
     (void)T; (void)c3_local;

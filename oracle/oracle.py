@@ -180,7 +180,41 @@ class _GibbsArgs(C.Structure):
         ("sample_is_diploid", C.c_int), ("disable_read_category_usage", C.c_int),
         ("rescale_eMatRead_t", C.c_int), ("class_sum_cutoff", C.c_double),
         ("runif_reads", C.c_void_p), ("first_read", C.c_int), ("runif_shard", C.c_void_p),
+        ("rc", C.c_void_p),
     ]
+
+
+class _RareCommon(C.Structure):
+    _fields_ = [
+        ("nSNPs_all", C.c_int), ("nGrids_all", C.c_int), ("snp_is_common", C.c_void_p),
+        ("common_snp_index", C.c_void_p), ("rare_ptr", C.c_void_p), ("rare_snp_1based", C.c_void_p),
+        ("transMatRate_t_all", C.c_void_p),
+    ]
+
+
+def rare_common_struct(rc):
+    keep = dict(a=np.ascontiguousarray(rc.snp_is_common, dtype=np.uint8),
+                b=np.ascontiguousarray(rc.common_snp_index, dtype=np.int32),
+                c=np.ascontiguousarray(rc.rare_ptr, dtype=np.int64),
+                d=np.ascontiguousarray(rc.rare_snp, dtype=np.int32),
+                e=np.asfortranarray(rc.transMatRate_t_all, dtype=np.float64))
+    st = _RareCommon(int(rc.nSNPs_all), int(rc.nGrids_all), _p(keep["a"]), _p(keep["b"]), _p(keep["c"]), _p(keep["d"]),
+                     _p(keep["e"]))
+    return st, keep
+
+
+def make_eMatRead_t_rare_common(panel, rc, sample_all, which_haps_to_use, maxDifferenceBetweenReads=1e10, Jmax=10000,
+                                rescale_eMatRead_t=True, use_eMatDH_special_symbols=None):
+    """``Rcpp_make_eMatRead_t_for_final_rare_common_gibbs_using_objects`` (gibbs-small.cpp:270-460)."""
+    which = np.ascontiguousarray(which_haps_to_use, dtype=np.int32)
+    Ks, R = len(which), sample_all.nReads
+    ps, keep = panel_struct(panel, use_eMatDH_special_symbols)
+    rs, keep2 = rare_common_struct(rc)
+    e = np.ones((Ks, R), dtype=np.float64, order="F")
+    lib().qo_make_eMatRead_t_rare_common(
+        C.byref(ps), C.byref(rs), _p(which), C.c_int(Ks), C.c_int(R), _p(sample_all.read_ptr), _p(sample_all.u),
+        _p(sample_all.bq), C.c_int(int(rescale_eMatRead_t)), C.c_int(Jmax), C.c_double(maxDifferenceBetweenReads), _p(e))
+    return e
 
 
 def grid_has_read_of(sample, nGrids):
@@ -215,15 +249,20 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
                              block_gibbs_iterations=(3, 6, 9), perform_block_gibbs=True,
                              gibbs_initialize_iteratively=False, sample_is_diploid=None,
                              disable_read_category_usage=False, maxDifferenceBetweenReads=1e10, Jmax=10000,
-                             class_sum_cutoff=0.06, use_eMatDH_special_symbols=None):
+                             class_sum_cutoff=0.06, use_eMatDH_special_symbols=None, rare_common=None):
     """Oracle twin of ``rcpp_forwardBackwardGibbsNIPT`` (gibbs-nipt.cpp:2395-3307), production path.
 
     ``H``: starting labels (1-based); returns a dict holding the ending labels and every state
-    matrix the reference mutates in place.
+    matrix the reference mutates in place.  ``rare_common``: the all-SNP side of the panel for the final
+    rare + common Gibbs (``make_eMatRead_t_rare_common = TRUE``); ``sample`` then holds the all-SNP reads.
     """
     lib().qo_gibbs.restype = C.c_int
     which = np.ascontiguousarray(which_haps_to_use, dtype=np.int32)
     Ks, R, G, T = len(which), sample.nReads, panel.nGrids, panel.nSNPs
+    rs = keep_rc = None
+    if rare_common is not None:
+        G, T = rare_common.nGrids_all, rare_common.nSNPs_all
+        rs, keep_rc = rare_common_struct(rare_common)
     if sample_is_diploid is None:
         sample_is_diploid = ff == 0
     blocks = np.ascontiguousarray(block_gibbs_iterations, dtype=np.int32)
@@ -238,7 +277,7 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
                       int(n_gibbs_sample_its), _p(blocks), len(blocks), int(perform_block_gibbs),
                       int(ff == 0), int(gibbs_initialize_iteratively), int(sample_is_diploid),
                       int(disable_read_category_usage), 1, float(class_sum_cutoff), _p(runif_reads),
-                      int(first_read), _p(runif_shard))
+                      int(first_read), _p(runif_shard), C.cast(C.pointer(rs), C.c_void_p) if rs is not None else None)
     ps, keep = panel_struct(panel, use_eMatDH_special_symbols)
     Hout = np.array(H, dtype=np.int32).copy()
     Hc = np.zeros(R, dtype=np.int32)

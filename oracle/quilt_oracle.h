@@ -120,6 +120,24 @@ void qo_evaluate_read_variability(const double *eMatRead_t, int Ks, int nReads,
                                   int32_t *number_of_non_1_reads, int32_t *indices_of_non_1_reads,
                                   int32_t *read_category);
 
+/* The "special_rare_common_objects" a rare/common call needs (prepare_reference_functions.R:172-247,
+ * rare_common.R:222-223): SNPs of the panel tables are the common ones; rare SNPs are held per haplotype. */
+typedef struct qo_rare_common {
+    int nSNPs_all, nGrids_all;
+    const uint8_t *snp_is_common;       /* nSNPs_all */
+    const int32_t *common_snp_index;    /* nSNPs_all: 1-based index among the common SNPs, 0 for a rare SNP */
+    const int64_t *rare_ptr;            /* K + 1: CSR over rare_per_hap_info */
+    const int32_t *rare_snp_1based;     /* all-SNP 1-based indices of the rare SNPs each haplotype carries the alt of */
+    const double *transMatRate_t_all;   /* 2 x (nGrids_all - 1) */
+} qo_rare_common_t;
+
+/* gibbs-small.cpp:270-460 (Rcpp_make_eMatRead_t_for_final_rare_common_gibbs_using_objects); rare_per_snp_info is
+ * built from rare_per_hap_info and which_haps_to_use as rare_common.R:313-322 does. */
+void qo_make_eMatRead_t_rare_common(
+    const qo_panel_t *p, const qo_rare_common_t *rc, const int32_t *which_haps_to_use_1based, int Ks, int nReads,
+    const int32_t *read_ptr, const int32_t *u, const int32_t *bq, int rescale_eMatRead_t, int Jmax,
+    double maxDifferenceBetweenReads, double *eMatRead_t);
+
 typedef struct {
     int Ks, nReads;
     const int32_t *which_haps_to_use_1based; /* Ks */
@@ -138,6 +156,10 @@ typedef struct {
     const double *runif_reads;   /* nReads * n_its   (gibbs-nipt.cpp:2845) */
     int first_read;              /* 0-based          (gibbs-nipt.cpp:2846-2848) */
     const double *runif_shard;   /* n_block_its * (nGrids - 1)  (gibbs-nipt-block.cpp:2054) */
+    /* NULL, or the final all-SNP ("rare + common") Gibbs of QUILT2 (make_eMatRead_t_rare_common = TRUE,
+     * rare_common.R:109-420): the sampler then runs on rc->nGrids_all grids of rc->nSNPs_all SNPs, reads index
+     * all SNPs, and hapProbs_t / genProbs*_t are 3 x rc->nSNPs_all. */
+    const struct qo_rare_common *rc;
 } qo_gibbs_args_t;
 
 /* rcpp_forwardBackwardGibbsNIPT (gibbs-nipt.cpp:2395-3307), production argument values.

@@ -664,6 +664,92 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
 
 
 // ---------------------------------------------------------------------------------------------
+// k_happrobs_rc: hapProbs / genProbs over ALL SNPs for the rare + common call
+// (rcpp_calculate_genProbs_and_hapProbs_final_rare_common, gibbs-small.cpp:711-867).  One 256-thread block per
+// (all-SNP grid, chain): gamma of the grid's column goes to LDS once; thread = (SNP b of the grid, slice of 8 over k).
+// A common SNP reads its allele from the panel word of its common grid (the block's 32 SNPs span at most two of them);
+// a rare SNP from the haplotype's rare list, or is ref_error outright when no selected haplotype carries it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
+    const int g = blockIdx.x, c = blockIdx.y;
+    const int b = threadIdx.x & 31, part = threadIdx.x >> 5;
+    __shared__ double s_gam[3][1024], s_on[3][8][32], s_all[3][8];
+    __shared__ uint32_t s_w[2][1024];
+    __shared__ int s_cg;
+    const int Ks = p.Ks, Ksp = p.Ksp, G = p.G;
+    const int32_t *which = p.which + (size_t)c * Ks;
+    const int s = 32 * g, nLocal = min(32, p.T - s);
+    if (threadIdx.x == 0) {
+        int cg = -1;
+        for (int i = 0; i < nLocal && cg < 0; i++) {
+            const int cs = p.rc_common[s + i];
+            if (cs >= 0) cg = cs >> 5;
+        }
+        s_cg = cg;
+    }
+    __syncthreads();
+    const int cg = s_cg;
+    const size_t mat = (size_t)G * Ksp;
+    for (int k = threadIdx.x; k < Ks; k += 256) {
+        const int kk = which[k];
+        for (int q = 0; q < 2; q++) {
+            const int gq = cg + q;
+            s_w[q][k] = (cg >= 0 && gq < p.rc_Gc) ? panel_word(p, gq, kk, p.hm[(size_t)gq * p.Kp + kk]) : 0u;
+        }
+        for (int h = 0; h < p.nH; h++) {
+            const double *a = p.alpha + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
+            const double *be = p.beta + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
+            const double x = 1 / p.cvec[((size_t)c * 3 + h) * G + g];
+            s_gam[h][k] = (a[k] * be[k]) * x;
+        }
+    }
+    __syncthreads();
+    const int snp = s + b;
+    const int cs = b < nLocal ? p.rc_common[snp] : -1;
+    const bool rare = b < nLocal && cs < 0;
+    const bool any = rare && ((p.rc_any[(size_t)c * p.rc_words + (snp >> 5)] >> (snp & 31)) & 1u);
+    double on[3] = {0, 0, 0};
+    if (b < nLocal && (!rare || any)) {
+        const int q = rare ? 0 : (cs >> 5) - cg, bit = cs & 31;
+        for (int k = part; k < Ks; k += 8) {
+            const bool alt = rare ? rare_has_alt(p, which[k], snp) : ((s_w[q][k] >> bit) & 1u);
+            for (int h = 0; h < p.nH; h++) {
+                if (alt) on[h] += s_gam[h][k];
+            }
+        }
+    }
+    for (int h = 0; h < 3; h++) s_on[h][part][b] = on[h];
+    if (b == 0) {   // the column total does not depend on the SNP
+        double t[3] = {0, 0, 0};
+        for (int k = part; k < Ks; k += 8) for (int h = 0; h < p.nH; h++) t[h] += s_gam[h][k];
+        for (int h = 0; h < 3; h++) s_all[h][part] = t[h];
+    }
+    __syncthreads();
+    if (part == 0 && b < nLocal) {
+        double g1[3] = {0, 0, 0};
+        for (int h = 0; h < p.nH; h++) {
+            double o = 0, t = 0;
+            for (int q = 0; q < 8; q++) { o += s_on[h][q][b]; t += s_all[h][q]; }
+            if (!rare) g1[h] = o * (1 - p.ref_error) + (t - o) * p.ref_error;
+            else if (!any) g1[h] = p.ref_error;
+            else g1[h] = t * p.ref_error + o * (1 - 2 * p.ref_error);
+        }
+        const double g0 = g1[0], gB = g1[1], g2 = g1[2];
+        double *hp = p.hapProbs + ((size_t)c * p.T + snp) * 3;
+        double *gm = p.genProbsM + ((size_t)c * p.T + snp) * 3;
+        double *gf = p.genProbsF + ((size_t)c * p.T + snp) * 3;
+        hp[0] = g0; hp[1] = gB; hp[2] = g2;
+        gm[0] = (1 - g0) * (1 - gB);
+        gm[1] = (g0 * (1 - gB) + (1 - g0) * gB);
+        gm[2] = g0 * gB;
+        gf[0] = (1 - g0) * (1 - g2);
+        gf[1] = (g0 * (1 - g2) + (1 - g0) * g2);
+        gf[2] = g0 * g2;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // k_ematread_dense: `rcpp_make_eMatRead_t` (copied-from-stitch.cpp:115-229) for dense per-SNP
 // haplotype dosages (the 2-3 "haplotypes" of calculate_eMatRead_t_vs_haplotypes, functions.R:2975-3020).
 // One thread per (read, chain): K is 2 or 3, the products run over the read's bases in order.
@@ -732,6 +818,7 @@ struct GibbsScratch {
     ABuf<double> eMatRead, alpha, beta, eg, cvec, hap, gm, gf;   // carved from the panel's arena per call
     DBuf<size_t> eread_off;
     DBuf<uint64_t> seeds;
+    DBuf<uint32_t> rc_any;
 };
 
 }  // namespace qa
@@ -855,7 +942,8 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
     }
     QA_HIP(hipEventRecord(ev[2], st));
     if (want_probs) {   // return_hapProbs / return_genProbs (functions.R:2566-2599): skipped when nobody asks
-        hipLaunchKernelGGL(k_happrobs, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
+        if (prm.rc_common) hipLaunchKernelGGL(k_happrobs_rc, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
+        else hipLaunchKernelGGL(k_happrobs, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
         QA_HIP(hipGetLastError());
     }
     QA_HIP(hipEventRecord(ev[3], st));
@@ -863,7 +951,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
 
 }  // namespace
 
-static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
@@ -879,8 +967,10 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         S.eMatRead.arena = S.alpha.arena = S.beta.arena = S.eg.arena = S.cvec.arena = S.hap.arena = S.gm.arena = S.gf.arena = &pn->arena;
         pn->arena.reset();
         hipStream_t st = pn->stream;
-        const int C = n_chain, G = pn->G, T = pn->T, Ks = o->Ks;
+        const int C = n_chain, G = rc ? rc->G_all : pn->G, T = rc ? rc->T_all : pn->T, Ks = o->Ks;
         const int Ksp = (Ks + 63) / 64 * 64, NE = Ksp / 64;
+        const int rc_words = rc ? (T + 31) / 32 : 0;
+        std::vector<uint32_t> rc_any((size_t)C * rc_words, 0u);
         const int n_its = o->n_gibbs_burn_in_its + o->n_gibbs_sample_its;
         const int totR = read_off[C];
         // bases: per chain the CSR block read_ptr[read_off[c] + c .. read_off[c+1] + c] is local (starts at 0)
@@ -924,7 +1014,13 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
                             const int v = which_haps_to_use_1based[(size_t)c * Ks + k] - 1;
                             if (v < 0 || v >= pn->K) throw std::runtime_error("which_haps_to_use out of range");
                             which0[(size_t)c * Ks + k] = v;
+                            if (rc)   // rare SNPs some selected haplotype carries the alt of (rare_per_snp_info, rare_common.R:313-322)
+                                for (int64_t i = rc->h_rare_ptr[v]; i < rc->h_rare_ptr[v + 1]; i++) {
+                                    const int t = rc->h_rare_snp[i];
+                                    rc_any[(size_t)c * rc_words + (t >> 5)] |= 1u << (t & 31);
+                                }
                         }
+                        const int32_t *cu = u + base_off[c];
                         int last = 0, nd = 0;
                         for (int r = 0; r < R; r++) {
                             int J = rp[r + 1] - rp[r] - 1;
@@ -934,7 +1030,12 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
                                 int32_t &b = bq_eff[(size_t)base_off[c] + rp[r] + j];
                                 if (b == 0) b = last; else last = b;
                                 if (b > 255 || b < -255) throw std::runtime_error("|base quality| > 255");
-                                n_inf += b != 0;
+                                const int t = cu[rp[r] + j];
+                                if (t < 0 || t >= T) throw std::runtime_error("read SNP index out of range");
+                                // a rare SNP nobody selected carries is a common factor: no pattern bit (k_ematread)
+                                const bool informative = !rc || rc->h_common_index[t] >= 0 ||
+                                                         ((rc_any[(size_t)c * rc_words + (t >> 5)] >> (t & 31)) & 1u);
+                                n_inf += (b != 0) && informative;
                             }
                             if (n_inf > kMaxPatternBits) dense_of[read_off[c] + r] = nd++;
                         }
@@ -957,7 +1058,10 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         const double T1 = now();
         const std::vector<double> tabs = base_quality_tables();
         std::vector<double> tm((size_t)2 * std::max(G - 1, 1));
-        for (int g = 0; g < G - 1; g++) { tm[g] = pn->h_sigma[g]; tm[(size_t)G - 1 + g] = pn->h_tm1[g]; }
+        for (int g = 0; g < G - 1; g++) {
+            tm[g] = rc ? rc->h_sigma[g] : pn->h_sigma[g];
+            tm[(size_t)G - 1 + g] = rc ? rc->h_tm1[g] : pn->h_tm1[g];
+        }
 
         S.which.ensure(which0.size()); S.which.upload(which0.data(), which0.size(), st);
         S.read_off.ensure(C + 1); S.read_off.upload(read_off, C + 1, st);
@@ -1037,6 +1141,11 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
         prm.alpha = S.alpha.p; prm.beta = S.beta.p; prm.eg = S.eg.p; prm.cvec = S.cvec.p;
         prm.H = S.H.p; prm.H_class = S.H_class.p; prm.status = S.status.p;
         prm.hapProbs = S.hap.p; prm.genProbsM = S.gm.p; prm.genProbsF = S.gf.p;
+        if (rc) {
+            S.rc_any.ensure(std::max<size_t>(rc_any.size(), 1)); S.rc_any.upload(rc_any.data(), rc_any.size(), st);
+            prm.rc_common = rc->common_index.p; prm.rc_rare_ptr = rc->rare_ptr.p; prm.rc_rare_snp = rc->rare_snp.p;
+            prm.rc_any = S.rc_any.p; prm.rc_words = rc_words; prm.rc_Gc = pn->G;
+        }
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
         const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
@@ -1069,10 +1178,10 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
                 fprintf(stderr, "[qa_gibbs C=%d] host prep %.3f s, tables+uploads %.3f s, kernels %.3f s (events %.3f), downloads %.3f s\n", C,
                         T1 - T0, T2 - T1, T3 - T2, (ms[0] + ms[1] + ms[2]) / 1e3, now() - T3);
         }
-        int rc = QA_OK;
+        int ret = QA_OK;
         for (int c = 0; c < C; c++) {
             if (underflow_problem) underflow_problem[c] = status[c];
-            if (status[c]) rc = QA_UNDERFLOW;
+            if (status[c]) ret = QA_UNDERFLOW;
         }
         if (state_out && C == 1) {
             // debugging / test aid: alpha, beta, eMatGrid of both labels ([6][G][Ks]) then c ([3][G])
@@ -1089,7 +1198,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
                 }
             QA_HIP(hipMemcpy(state_out + o2, S.cvec.p, sizeof(double) * 3 * G, hipMemcpyDeviceToHost));
         }
-        return rc;
+        return ret;
     }
 }
 
@@ -1097,7 +1206,8 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain
 
 extern "C" {
 
-int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_opts_t *o, int32_t n_chain,
+                   const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
@@ -1124,7 +1234,7 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
     }
     return qa::guarded([&] {
         QA_HIP(hipSetDevice(pn->device));
-        const int G = pn->G, T = pn->T, Ks = o->Ks, Ksp = (Ks + 63) / 64 * 64;
+        const int G = rc ? rc->G_all : pn->G, T = rc ? rc->T_all : pn->T, Ks = o->Ks, Ksp = (Ks + 63) / 64 * 64;
         const int n_its = o->n_gibbs_burn_in_its + o->n_gibbs_sample_its;
         const int nb = o->n_block_gibbs_iterations;
         const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
@@ -1135,7 +1245,7 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
             base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
         }
         const size_t budget = pn->arena.budget() / pn->share;
-        int c0 = 0, rc = QA_OK;
+        int c0 = 0, ret = QA_OK;
         while (c0 < n_chain) {
             size_t need = (size_t)1 << 20;
             int c1 = c0;
@@ -1156,7 +1266,7 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
             std::vector<int32_t> ro(c1 - c0 + 1);
             for (int i = 0; i <= c1 - c0; i++) ro[i] = read_off[c0 + i] - read_off[c0];
             const int st = gibbs_chunk(
-                pn, o, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
+                pn, rc, o, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
                 u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
                 runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
                 runif_shard ? runif_shard + (size_t)c0 * nb * (G - 1) : nullptr, H + read_off[c0],
@@ -1165,26 +1275,99 @@ int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, co
                 underflow_problem ? underflow_problem + c0 : nullptr, state_out, seed_reads ? seed_reads + c0 : nullptr,
                 seed_shard ? seed_shard + c0 : nullptr);
             if (st < 0) return st;
-            if (st == QA_UNDERFLOW) rc = QA_UNDERFLOW;
+            if (st == QA_UNDERFLOW) ret = QA_UNDERFLOW;
             c0 = c1;
         }
-        return rc;
+        return ret;
     });
 }
 
-int qa_rcpp_make_eMatRead_t(qa_panel_t *pn, int32_t n_chain, int32_t K, const double *eHaps, const int32_t *read_off,
-                            const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
-                            double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
-                            double *eMatRead_t) {
+int qa_gibbs_batch(qa_panel_t *pn, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+                   const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                   const int32_t *wif, const double *runif_reads, const int32_t *first_read,
+                   const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
+                   double *genProbsM_t, double *genProbsF_t, int32_t *underflow_problem, double *state_out,
+                   const uint64_t *seed_reads, const uint64_t *seed_shard) {
+    return gibbs_batch_impl(pn, nullptr, o, n_chain, which_haps_to_use_1based, read_off, read_ptr, u, bq, wif, runif_reads,
+                            first_read, runif_shard, H, H_class, hapProbs_t, genProbsM_t, genProbsF_t, underflow_problem,
+                            state_out, seed_reads, seed_shard);
+}
+
+int qa_gibbs_batch_rare_common(qa_panel_t *pn, const qa_rare_common_t *rc, const qa_gibbs_opts_t *o, int32_t n_chain,
+                               const int32_t *which_haps_to_use_1based, const int32_t *read_off, const int32_t *read_ptr,
+                               const int32_t *u, const int32_t *bq, const int32_t *wif, const double *runif_reads,
+                               const int32_t *first_read, const double *runif_shard, int32_t *H, int32_t *H_class,
+                               double *hapProbs_t, double *genProbsM_t, double *genProbsF_t,
+                               int32_t *underflow_problem, double *state_out, const uint64_t *seed_reads,
+                               const uint64_t *seed_shard) {
+    if (!rc || !pn) {
+        qa::set_error("qa_gibbs_batch_rare_common: null argument");
+        return QA_ERR_INVALID;
+    }
+    if (rc->K != pn->K || rc->device != pn->device) {
+        qa::set_error("qa_gibbs_batch_rare_common: the rare/common handle belongs to another panel or device");
+        return QA_ERR_INVALID;
+    }
+    return gibbs_batch_impl(pn, rc, o, n_chain, which_haps_to_use_1based, read_off, read_ptr, u, bq, wif, runif_reads,
+                            first_read, runif_shard, H, H_class, hapProbs_t, genProbsM_t, genProbsF_t, underflow_problem,
+                            state_out, seed_reads, seed_shard);
+}
+
+int qa_rare_common_create(qa_panel_t *pn, int32_t nSNPs_all, const uint8_t *snp_is_common, const int64_t *rare_ptr,
+                          const int32_t *rare_snp_1based, const double *transMatRate_t_all, qa_rare_common_t **out) {
     if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
-    if (!pn || n_chain <= 0 || K < 1 || K > 3 || !eHaps || !read_off || !read_ptr || !u || !bq || !eMatRead_t) {
+    if (!pn || !snp_is_common || !rare_ptr || !transMatRate_t_all || !out || nSNPs_all < pn->T) {
+        qa::set_error("qa_rare_common_create: null argument or fewer SNPs than the panel has");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(pn->device));
+        std::unique_ptr<qa_rare_common> rc(new qa_rare_common());
+        rc->device = pn->device; rc->K = pn->K; rc->T_all = nSNPs_all; rc->G_all = (nSNPs_all + 31) / 32;
+        rc->h_common_index.assign(nSNPs_all, -1);
+        int n_common = 0;
+        for (int t = 0; t < nSNPs_all; t++) if (snp_is_common[t]) rc->h_common_index[t] = n_common++;
+        if (n_common != pn->T) throw std::runtime_error("sum(snp_is_common) differs from the panel's number of SNPs");
+        const int64_t n_rare = rare_ptr[pn->K];
+        if (rare_ptr[0] != 0 || n_rare < 0 || (n_rare > 0 && !rare_snp_1based)) throw std::runtime_error("bad rare_per_hap_info CSR");
+        rc->h_rare_ptr.assign(rare_ptr, rare_ptr + pn->K + 1);
+        rc->h_rare_snp.resize(n_rare);
+        for (int k = 0; k < pn->K; k++) {
+            if (rare_ptr[k + 1] < rare_ptr[k]) throw std::runtime_error("bad rare_per_hap_info CSR");
+            for (int64_t i = rare_ptr[k]; i < rare_ptr[k + 1]; i++) {
+                const int t = rare_snp_1based[i] - 1;
+                if (t < 0 || t >= nSNPs_all || snp_is_common[t]) throw std::runtime_error("rare_per_hap_info names a SNP that is not rare");
+                if (i > rare_ptr[k] && t <= rc->h_rare_snp[i - 1]) throw std::runtime_error("rare_per_hap_info must ascend within a haplotype");
+                rc->h_rare_snp[i] = t;
+            }
+        }
+        const int G = rc->G_all;
+        rc->h_sigma.resize(std::max(G - 1, 0)); rc->h_tm1.resize(std::max(G - 1, 0));
+        for (int g = 0; g < G - 1; g++) { rc->h_sigma[g] = transMatRate_t_all[2 * (size_t)g]; rc->h_tm1[g] = transMatRate_t_all[2 * (size_t)g + 1]; }
+        rc->common_index.alloc(nSNPs_all); rc->common_index.upload(rc->h_common_index.data(), nSNPs_all, pn->stream);
+        rc->rare_ptr.alloc(pn->K + 1); rc->rare_ptr.upload(rc->h_rare_ptr.data(), pn->K + 1, pn->stream);
+        rc->rare_snp.alloc(std::max<int64_t>(n_rare, 1)); rc->rare_snp.upload(rc->h_rare_snp.data(), n_rare, pn->stream);
+        QA_HIP(hipStreamSynchronize(pn->stream));
+        *out = rc.release();
+        return (int)QA_OK;
+    });
+}
+
+void qa_rare_common_destroy(qa_rare_common_t *rc) { delete rc; }
+
+int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                                  const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                                  double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                                  double *eMatRead_t) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!pn || nSNPs <= 0 || n_chain <= 0 || K < 1 || K > 3 || !eHaps || !read_off || !read_ptr || !u || !bq || !eMatRead_t) {
         qa::set_error("qa_rcpp_make_eMatRead_t: bad argument");
         return QA_ERR_INVALID;
     }
     return qa::guarded([&] {
         QA_HIP(hipSetDevice(pn->device));
         hipStream_t st = pn->stream;
-        const int C = n_chain, T = pn->T;
+        const int C = n_chain, T = nSNPs;
         std::vector<int32_t> base_off(C + 1, 0);
         int maxR = 0;
         for (int c = 0; c < C; c++) {
@@ -1193,6 +1376,7 @@ int qa_rcpp_make_eMatRead_t(qa_panel_t *pn, int32_t n_chain, int32_t K, const do
             base_off[c + 1] = base_off[c] + (read_ptr + read_off[c] + c)[R];
         }
         const int totR = read_off[C], totB = base_off[C];
+        for (int i = 0; i < totB; i++) if (u[i] < 0 || u[i] >= T) throw std::runtime_error("read SNP index out of range");
         std::vector<int32_t> bq_eff(bq, bq + totB);
         fold_zero_base_qualities(bq_eff, C, read_off, read_ptr, base_off, Jmax);
         const std::vector<double> tabs = base_quality_tables();
@@ -1212,6 +1396,18 @@ int qa_rcpp_make_eMatRead_t(qa_panel_t *pn, int32_t n_chain, int32_t K, const do
         QA_HIP(hipStreamSynchronize(st));
         return QA_OK;
     });
+}
+
+int qa_rcpp_make_eMatRead_t(qa_panel_t *pn, int32_t n_chain, int32_t K, const double *eHaps, const int32_t *read_off,
+                            const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                            double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                            double *eMatRead_t) {
+    if (!pn) {
+        qa::set_error("qa_rcpp_make_eMatRead_t: bad argument");
+        return QA_ERR_INVALID;
+    }
+    return qa_rcpp_make_eMatRead_t_nsnps(pn, pn->T, n_chain, K, eHaps, read_off, read_ptr, u, bq, maxDifferenceBetweenReads,
+                                         Jmax, rescale_eMatRead_t, eMatRead_t);
 }
 
 }  // extern "C"

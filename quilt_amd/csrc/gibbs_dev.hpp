@@ -74,7 +74,26 @@ struct GibbsParams {
     int32_t *status;         // [C] 0 ok, 1 underflow
     // outputs
     double *hapProbs, *genProbsM, *genProbsF;  // [C][T][3]
+    // rare + common SNPs (the final all-SNP Gibbs of QUILT2, rare_common.R:109-420): rc_common == null for an ordinary
+    // call.  With it, T / G / sigma / wif / u refer to ALL SNPs, the panel tables to the common ones (rc_Gc grids).
+    const int32_t *rc_common;    // [T] 0-based index among the common SNPs, -1 for a rare SNP
+    const int64_t *rc_rare_ptr;  // [K + 1] CSR: rare SNPs each panel haplotype carries the alt of
+    const int32_t *rc_rare_snp;  // 0-based all-SNP indices, ascending within a haplotype
+    const uint32_t *rc_any;      // [C][rc_words] bit t: some selected haplotype of the chain carries the alt of SNP t
+    int rc_words, rc_Gc;
 };
+
+// does panel haplotype `hap` carry the alt allele of rare SNP `snp` (rare_per_hap_info)
+__device__ __forceinline__ bool rare_has_alt(const GibbsParams &p, int hap, int snp) {
+    int64_t lo = p.rc_rare_ptr[hap], hi = p.rc_rare_ptr[hap + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int v = p.rc_rare_snp[mid];
+        if (v == snp) return true;
+        if (v < snp) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
 
 // 64-lane sum of doubles by DPP row shifts / row broadcasts (no LDS traffic), result broadcast to every
 // lane through a scalar register.  Deterministic order: within 16-lane rows, then rows 0+1, 2+3, then all.
@@ -166,7 +185,39 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
         double tv = 1.0;   // lane l: the product for allele pattern l (bit j = allele at the read's j-th informative SNP)
         for (int j = 0; j <= J; j++) {
             const int b = bq[s + j];
-            const int snp = u[s + j];
+            int snp = u[s + j];
+            if (p.rc_common) {   // all-SNP read: a common SNP maps to its panel column, a rare one has no column
+                const int all_snp = snp;
+                snp = p.rc_common[all_snp];
+                if (snp < 0) {
+                    // rare SNP (gibbs-small.cpp:382-401): everyone as ref, then the carriers re-done -- in that order
+                    if (b == 0) continue;
+                    const int ab = b < 0 ? -b : b;
+                    const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
+                    const double xe1 = e0 * pA + e1 * pR;
+                    const bool any = (p.rc_any[(size_t)c * p.rc_words + (all_snp >> 5)] >> (all_snp & 31)) & 1u;
+                    if (!any) {   // no selected haplotype carries it: a common factor, dropped under rescaling
+                        if (!p.rescale) {
+#pragma unroll
+                            for (int i = 0; i < NEALL; i++) v[i] *= xe1;
+                            tv *= xe1;
+                        }
+                        continue;
+                    }
+                    const double ratio = (e1 * pA + e0 * pR) / xe1;
+#pragma unroll
+                    for (int i = 0; i < NEALL; i++) {
+                        const uint32_t bit = (kk[i] >= 0 && rare_has_alt(p, kk[i], all_snp)) ? 1u : 0u;
+                        v[i] *= xe1;
+                        if (bit) v[i] *= ratio;
+                        pat[i] |= bit << min(n_inf, 7);
+                    }
+                    tv *= xe1;
+                    if ((lane >> min(n_inf, 31)) & 1) tv *= ratio;
+                    n_inf++;
+                    continue;
+                }
+            }
             const int g = snp >> 5;
             if (g != g_prev) {
 #pragma unroll

@@ -37,3 +37,16 @@ struct qa_panel {
     Scratch *scratch = nullptr;
     ~qa_panel();
 };
+
+// The all-SNP side of a QUILT2 panel (rare + common SNPs): what the final all-SNP Gibbs call needs on top of the
+// common-SNP panel tables.  rare_snp holds 0-based all-SNP indices, ascending within a haplotype.
+struct qa_rare_common {
+    int device = 0, K = 0, T_all = 0, G_all = 0;
+    qa::DBuf<int32_t> common_index;   // [T_all] 0-based index among the common SNPs, -1 for a rare SNP
+    qa::DBuf<int64_t> rare_ptr;       // [K + 1]
+    qa::DBuf<int32_t> rare_snp;
+    std::vector<int64_t> h_rare_ptr;
+    std::vector<int32_t> h_rare_snp;
+    std::vector<int32_t> h_common_index;
+    std::vector<double> h_sigma, h_tm1;   // transMatRate_t of the all-SNP grid, rows 0 and 1
+};

@@ -41,17 +41,24 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                                    maxDifferenceBetweenReads: float = 1e10, Jmax_local: int = 10000,
                                    class_sum_cutoff: float = 0.06, return_state: bool = False,
                                    seed_reads=None, seed_shard=None, return_hapProbs: bool = True,
-                                   return_genProbs: bool = True):
+                                   return_genProbs: bool = True, rare_common=None):
     """``n_chain`` independent calls of ``rcpp_forwardBackwardGibbsNIPT`` in one launch set.
 
     ``samples[c]`` is a :class:`quilt_amd.synth.SampleReads`-like object (``read_ptr``, ``u``, ``bq``,
     ``wif``); the other sequences hold one entry per chain.  Returns a list of dicts.
+
+    ``rare_common`` (a :class:`quilt_amd.native.DeviceRareCommon`): the call the reference makes with
+    ``make_eMatRead_t_rare_common = TRUE`` (QUILT/R/rare_common.R:325-398) -- ``samples`` then hold the all-SNP reads
+    (``allSNP_sampleReads``) and the outputs cover all SNPs.
     """
     lib().qa_gibbs_batch.restype = C.c_int
+    lib().qa_gibbs_batch_rare_common.restype = C.c_int
     import os, time
     _t0 = time.perf_counter()
     P = panel.panel
     G, T = P.nGrids, P.nSNPs
+    if rare_common is not None:
+        G, T = rare_common.rc.nGrids_all, rare_common.rc.nSNPs_all
     Cn = len(samples)
     Ks = len(which_haps_to_use[0])
     n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
@@ -92,9 +99,12 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                      int(perform_block_gibbs), int(ff == 0), int(gibbs_initialize_iteratively),
                      int(disable_read_category_usage), float(class_sum_cutoff))
     _t1 = time.perf_counter()
-    st = lib().qa_gibbs_batch(panel.handle, C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr),
-                              ptr(u), ptr(bq), ptr(wif), ptr(ru), ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap),
-                              ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
+    tail = (C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(ru),
+            ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap), ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
+    if rare_common is not None:
+        st = lib().qa_gibbs_batch_rare_common(panel.handle, rare_common.handle, *tail)
+    else:
+        st = lib().qa_gibbs_batch(panel.handle, *tail)
     check(st)
     if os.environ.get("QA_TIMING"):
         print(f"[gibbs_batch py C={Cn}] marshal {_t1 - _t0:.3f} s, native call {time.perf_counter() - _t1:.3f} s", flush=True)
@@ -129,13 +139,14 @@ def rcpp_forwardBackwardGibbsNIPT(panel: DevicePanel, sampleReads, which_haps_to
 
 def calculate_eMatRead_t_vs_haplotypes_batch(panel: DevicePanel, samples: Sequence, haps: Sequence,
                                              maxDifferenceBetweenReads: float, rescale_eMatRead_t: bool = False,
-                                             Jmax: int = 1000):
+                                             Jmax: int = 1000, nSNPs: Optional[int] = None):
     """``calculate_eMatRead_t_vs_haplotypes`` (QUILT/R/functions.R:2975-3020) for a batch: ``haps[c]`` is the
-    list of K dense haplotype dosages of chain ``c``.  Returns one K x nReads matrix per chain."""
-    lib().qa_rcpp_make_eMatRead_t.restype = C.c_int
+    list of K dense haplotype dosages of chain ``c``.  Returns one K x nReads matrix per chain.  ``nSNPs``: the
+    length of the dosages when it is not the panel's (all-SNP reads, QUILT/R/rare_common.R:61-107)."""
+    lib().qa_rcpp_make_eMatRead_t_nsnps.restype = C.c_int
     Cn = len(samples)
     K = len(haps[0])
-    T = panel.panel.nSNPs
+    T = panel.panel.nSNPs if nSNPs is None else int(nSNPs)
     e = np.ascontiguousarray(np.stack([np.stack([np.asarray(h, dtype=np.float64) for h in hs], axis=1) for hs in haps]))
     assert e.shape == (Cn, T, K)
     read_off = np.zeros(Cn + 1, dtype=np.int32)
@@ -145,7 +156,7 @@ def calculate_eMatRead_t_vs_haplotypes_batch(panel: DevicePanel, samples: Sequen
     u = np.concatenate([np.asarray(s.u, dtype=np.int32) for s in samples])
     bq = np.concatenate([np.asarray(s.bq, dtype=np.int32) for s in samples])
     out = np.zeros((int(read_off[-1]), K))
-    check(lib().qa_rcpp_make_eMatRead_t(panel.handle, C.c_int32(Cn), C.c_int32(K), ptr(e), ptr(read_off), ptr(read_ptr),
-                                        ptr(u), ptr(bq), C.c_double(maxDifferenceBetweenReads), C.c_int32(Jmax),
-                                        C.c_int32(int(rescale_eMatRead_t)), ptr(out)))
+    check(lib().qa_rcpp_make_eMatRead_t_nsnps(panel.handle, C.c_int32(T), C.c_int32(Cn), C.c_int32(K), ptr(e), ptr(read_off),
+                                              ptr(read_ptr), ptr(u), ptr(bq), C.c_double(maxDifferenceBetweenReads),
+                                              C.c_int32(Jmax), C.c_int32(int(rescale_eMatRead_t)), ptr(out)))
     return [np.asfortranarray(out[read_off[c]:read_off[c + 1]].T) for c in range(Cn)]

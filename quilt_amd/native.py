@@ -55,9 +55,11 @@ def lib() -> C.CDLL:
                  "qa_rcpp_make_eMatRead_t", "qa_profile_reset", "qa_profile_get", "qa_fullpass_reads_batch",
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
                      "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy", "qa_panel_create_from_rhb",
-                     "qa_panel_export_tables"):
+                     "qa_panel_export_tables", "qa_rcpp_make_eMatRead_t_nsnps", "qa_rare_common_create",
+                     "qa_gibbs_batch_rare_common"):
             getattr(L, name).restype = C.c_int
         L.qa_panel_destroy.restype = None
+        L.qa_rare_common_destroy.restype = None
         _lib = L
     return _lib
 
@@ -154,6 +156,37 @@ class DevicePanel:
     def close(self):
         if self.handle:
             lib().qa_panel_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceRareCommon:
+    """Device-resident all-SNP side of a QUILT2 panel (:class:`quilt_amd.panel.RareCommon`) for the final rare + common
+    Gibbs call; belongs to one :class:`DevicePanel`."""
+
+    def __init__(self, device_panel: DevicePanel, rc):
+        self.rc = rc
+        self.device_panel = device_panel
+        is_common = np.ascontiguousarray(rc.snp_is_common, dtype=np.uint8)
+        rare_ptr = np.ascontiguousarray(rc.rare_ptr, dtype=np.int64)
+        rare_snp = np.ascontiguousarray(rc.rare_snp, dtype=np.int32)
+        tm = np.asfortranarray(rc.transMatRate_t_all, dtype=np.float64)
+        h = C.c_void_p()
+        lib().qa_rare_common_create.restype = C.c_int
+        check(lib().qa_rare_common_create(device_panel.handle, C.c_int32(rc.nSNPs_all), ptr(is_common), ptr(rare_ptr),
+                                          ptr(rare_snp if rare_snp.size else np.zeros(1, dtype=np.int32)), ptr(tm),
+                                          C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib().qa_rare_common_destroy.restype = None
+            lib().qa_rare_common_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

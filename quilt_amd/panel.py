@@ -79,6 +79,23 @@ class Panel:
         return ptr, vals
 
 
+@dataclass
+class RareCommon:
+    """The all-SNP side of a QUILT2 panel (``special_rare_common_objects``, prepare_reference_functions.R:172-247):
+    the panel tables cover the common SNPs; every haplotype lists the rare SNPs it carries the alt of
+    (``rare_per_hap_info``); the all-SNP grid is 32 SNPs wide like the common one."""
+
+    nSNPs_all: int
+    nGrids_all: int
+    snp_is_common: np.ndarray        # uint8 T_all
+    common_snp_index: np.ndarray     # int32 T_all: 1-based index among the common SNPs, 0 for rare (rare_common.R:222-223)
+    rare_ptr: np.ndarray             # int64 K + 1: CSR over rare_per_hap_info
+    rare_snp: np.ndarray             # int32: 1-based all-SNP indices, ascending within a haplotype
+    transMatRate_t_all: np.ndarray   # float64 2 x (G_all - 1) (F)
+    L_all: Optional[np.ndarray] = None
+    L_grid_all: Optional[np.ndarray] = None
+
+
 def make_rhb_t_equality(rhb_t: np.ndarray, nMaxDH: Optional[int], nSNPs: int, ref_error: float,
                         use_hapMatcherR: bool = True) -> dict:
     """Per-grid dictionary compression of the packed panel.

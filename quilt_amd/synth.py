@@ -21,7 +21,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 
-from .panel import Panel, int_expand, make_rhb_t_equality
+from .panel import Panel, RareCommon, int_expand, make_rhb_t_equality
 
 
 def _sigma_from_positions(L_grid, nGen, expRate, minRate=0.1, maxRate=100.0):
@@ -176,3 +176,107 @@ def make_synthetic_sample(panel: Panel, seed: int, mode: str = "short", n_reads:
     wif = (central // 32).astype(np.int32)
     return SampleReads(read_ptr=read_ptr, u=u, bq=bq, wif=wif, truth_label=label.astype(np.int32),
                        truth_haps=truth, ff=ff)
+
+
+def make_rare_common(panel: Panel, seed: int, n_rare: Optional[int] = None, carriers=(0, 4)) -> RareCommon:
+    """Rare SNPs scattered between the panel's (common) SNPs, as ``QUILT_prepare_reference(impute_rare_common=TRUE)``
+    leaves them (quilt-prepare-reference.R: ``rare_per_hap_info``, ``snp_is_common``): each rare SNP gets
+    ``carriers[0]..carriers[1]`` panel haplotypes that carry its alt allele."""
+    rng = np.random.default_rng(seed)
+    T = panel.nSNPs
+    if n_rare is None:
+        n_rare = 2 * T
+    lo, hi = int(panel.L[0]), int(panel.L[-1])
+    free = np.setdiff1d(np.arange(lo, hi + 1), panel.L)
+    rare_pos = np.sort(rng.choice(free, size=min(n_rare, len(free)), replace=False))
+    L_all = np.sort(np.concatenate([panel.L, rare_pos])).astype(np.int64)
+    T_all = len(L_all)
+    snp_is_common = np.isin(L_all, panel.L).astype(np.uint8)
+    common_snp_index = np.zeros(T_all, dtype=np.int32)
+    common_snp_index[snp_is_common == 1] = np.arange(1, T + 1, dtype=np.int32)
+    G_all = (T_all + 31) // 32
+    starts = np.arange(0, T_all, 32)
+    L_grid_all = (np.add.reduceat(L_all, starts) // np.diff(np.r_[starts, T_all])).astype(np.int64)
+    ex = panel.extra
+    sigma = _sigma_from_positions(L_grid_all, ex.get("nGen", 100.0), ex.get("expRate", 1.0))
+    tm = np.asfortranarray(np.stack([sigma, 1.0 - sigma], axis=0))
+    rare_idx = np.flatnonzero(snp_is_common == 0)
+    per_hap = [[] for _ in range(panel.K)]
+    for t in rare_idx:
+        n = int(rng.integers(carriers[0], carriers[1] + 1))
+        for k in rng.choice(panel.K, size=min(n, panel.K), replace=False):
+            per_hap[int(k)].append(int(t) + 1)
+    rare_ptr = np.zeros(panel.K + 1, dtype=np.int64)
+    rare_ptr[1:] = np.cumsum([len(x) for x in per_hap])
+    rare_snp = (np.concatenate([np.asarray(x, dtype=np.int32) for x in per_hap])
+                if rare_ptr[-1] else np.zeros(0, dtype=np.int32)).astype(np.int32)
+    return RareCommon(nSNPs_all=T_all, nGrids_all=G_all, snp_is_common=snp_is_common,
+                      common_snp_index=common_snp_index, rare_ptr=rare_ptr, rare_snp=rare_snp,
+                      transMatRate_t_all=tm, L_all=L_all, L_grid_all=L_grid_all)
+
+
+def rare_common_hap_bits(panel: Panel, rc: RareCommon, k: int) -> np.ndarray:
+    """0/1 alleles of panel haplotype ``k`` over all (common + rare) SNPs."""
+    out = np.zeros(rc.nSNPs_all, dtype=np.int8)
+    out[rc.snp_is_common == 1] = panel_hap_bits(panel, k)
+    out[rc.rare_snp[rc.rare_ptr[k]:rc.rare_ptr[k + 1]] - 1] = 1
+    return out
+
+
+def make_synthetic_sample_rare_common(panel: Panel, rc: RareCommon, seed: int, n_reads: Optional[int] = None):
+    """One diploid sample read twice, as get_and_impute_one_sample does with ``impute_rare_common``
+    (functions.R:130-175): over all SNPs (``allSNP_sampleReads``) and over the common SNPs only.  Returns
+    ``(sample_common, sample_all)``; reads without a common SNP are absent from the first."""
+    rng = np.random.default_rng(seed)
+    T_all = rc.nSNPs_all
+    truth = []
+    for _ in range(2):
+        nseg = int(rng.integers(3, 7))
+        cuts = np.sort(rng.choice(np.arange(1, T_all), size=nseg - 1, replace=False))
+        bounds = np.r_[0, cuts, T_all]
+        hap = np.zeros(T_all, dtype=np.int8)
+        for i in range(nseg):
+            k = int(rng.integers(0, panel.K))
+            hap[bounds[i]:bounds[i + 1]] = rare_common_hap_bits(panel, rc, k)[bounds[i]:bounds[i + 1]]
+        truth.append(hap)
+    truth = np.stack(truth, axis=0)
+    if n_reads is None:
+        n_reads = max(2, int(round(panel.nSNPs * 20000 / 64000)))
+    nsnp = np.minimum(1 + rng.poisson(2 * T_all / panel.nSNPs, size=n_reads), 24)
+    nsnp = np.minimum(nsnp, T_all)
+    start = np.array([rng.integers(0, T_all - n + 1) for n in nsnp], dtype=np.int64)
+    central = start + (nsnp - 1) // 2
+    order = np.argsort(central, kind="stable")
+    start, nsnp, central = start[order], nsnp[order], central[order]
+    label = rng.integers(1, 3, size=n_reads)
+    us, bqs = [], []
+    for r in range(n_reads):
+        idx = np.arange(start[r], start[r] + nsnp[r])
+        phred = rng.integers(20, 41, size=nsnp[r])
+        allele = truth[label[r] - 1, idx].astype(np.int32)
+        err = rng.random(nsnp[r]) < 10.0 ** (-phred / 10.0)
+        allele = np.where(err, 1 - allele, allele)
+        us.append(idx.astype(np.int32))
+        bqs.append(np.where(allele == 1, phred, -phred).astype(np.int32))
+
+    def pack(us, bqs, labels, T):
+        keep = [i for i, x in enumerate(us) if len(x)]
+        us, bqs = [us[i] for i in keep], [bqs[i] for i in keep]
+        cen = np.array([x[(len(x) - 1) // 2] for x in us], dtype=np.int64)
+        o = np.argsort(cen, kind="stable")
+        us, bqs, cen = [us[i] for i in o], [bqs[i] for i in o], cen[o]
+        ptr = np.zeros(len(us) + 1, dtype=np.int32)
+        ptr[1:] = np.cumsum([len(x) for x in us])
+        return SampleReads(read_ptr=ptr, u=np.concatenate(us).astype(np.int32), bq=np.concatenate(bqs).astype(np.int32),
+                           wif=(cen // 32).astype(np.int32), truth_label=np.asarray(labels)[keep][o].astype(np.int32))
+
+    s_all = pack(us, bqs, label, T_all)
+    s_all.truth_haps = truth
+    com_u, com_bq = [], []
+    for x, b in zip(us, bqs):
+        m = rc.snp_is_common[x] == 1
+        com_u.append(rc.common_snp_index[x[m]] - 1)
+        com_bq.append(b[m])
+    s_com = pack(com_u, com_bq, label, panel.nSNPs)
+    s_com.truth_haps = truth[:, rc.snp_is_common == 1]
+    return s_com, s_all

@@ -121,3 +121,32 @@ def test_gibbs_invariants(medium_panel):
     eh = np.where(bits == 1, 1 - p.ref_error, p.ref_error)
     dense = O.calculate_eMatRead_t_vs_haplotypes(s, list(eh), 1e10, rescale_eMatRead_t=False, Jmax=10000)
     np.testing.assert_allclose(e[:20], dense, rtol=1e-12)
+
+
+def test_rare_common_restatement_matches_dense_expansion(small_panel):
+    """Rare + common emissions and hapProbs (gibbs-small.cpp:270-460, :711-867) == the dense computation on the
+    haplotypes expanded over all SNPs -- the all-SNP analogue of invariants (6) and (7)."""
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common, rare_common_hap_bits
+    p = small_panel
+    rc = make_rare_common(p, 5)
+    s_com, s_all = make_synthetic_sample_rare_common(p, rc, 77, n_reads=200)
+    assert rc.nSNPs_all == p.nSNPs + (rc.snp_is_common == 0).sum() and s_com.u.max() < p.nSNPs
+    rng = np.random.default_rng(1)
+    which = np.sort(rng.choice(p.K, 120, replace=False)).astype(np.int32) + 1
+    bits = np.stack([rare_common_hap_bits(p, rc, int(k) - 1) for k in which]).astype(np.float64)
+    eh = np.where(bits == 1, 1 - p.ref_error, p.ref_error)
+    for rescale in (True, False):
+        e = O.make_eMatRead_t_rare_common(p, rc, s_all, which, rescale_eMatRead_t=rescale)
+        dense = O.calculate_eMatRead_t_vs_haplotypes(s_all, list(eh), 1e10, rescale_eMatRead_t=rescale, Jmax=10000)
+        np.testing.assert_allclose(e, dense, rtol=1e-12)
+    R, G = s_all.nReads, rc.nGrids_all
+    H0 = rng.integers(1, 3, size=R)
+    out = O.forwardBackwardGibbsNIPT(p, s_all, which, H0, rng.random(R * 21), 0, rng.random(3 * (G - 1)),
+                                     disable_read_category_usage=True, rare_common=rc)
+    assert out["status"] == 0
+    for h in range(2):
+        gam = out["alphaHat_t"][h] * out["betaHat_t"][h] / out["c"][h][None, :]
+        np.testing.assert_allclose(gam.sum(axis=0), 1.0, atol=1e-12)
+        d = (gam[:, np.arange(rc.nSNPs_all) // 32] * eh).sum(axis=0)
+        np.testing.assert_allclose(out["hapProbs_t"][h], d, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(out["genProbsM_t"].sum(axis=0), 1.0, atol=1e-12)

@@ -1,0 +1,109 @@
+"""GPU parity of the final all-SNP ("rare + common") Gibbs call of QUILT2 through the C ABI vs the fp64 CPU oracle
+(make_eMatRead_t_rare_common = TRUE: QUILT/R/rare_common.R:325-398; gibbs-small.cpp:270-460 and :711-867).
+
+Bar as for the ordinary call: read labels and H_class IDENTICAL under the same uniforms; fp64 state and
+hapProbs / genProbs over all SNPs within 1e-9 relative.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _setup(panel, seed, Ks, n_reads, carriers=(0, 4)):
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    rc = make_rare_common(panel, seed, carriers=carriers)
+    _, s_all = make_synthetic_sample_rare_common(panel, rc, seed + 1, n_reads=n_reads)
+    rng = np.random.default_rng(seed + 17)
+    which = np.sort(rng.choice(panel.K, Ks, replace=False)).astype(np.int32) + 1
+    H0 = rng.integers(1, 3, size=s_all.nReads).astype(np.int32)
+    ru = rng.random(s_all.nReads * 21)
+    rs = rng.random(3 * (rc.nGrids_all - 1))
+    return rc, s_all, which, H0, ru, rs
+
+
+def _compare(got, ref):
+    assert not got["underflow_problem"] and ref["status"] == 0
+    assert np.array_equal(got["H"], ref["H"]), f"{(got['H'] != ref['H']).sum()} labels differ"
+    assert np.array_equal(got["H_class"], ref["H_class"])
+    for h in range(2):
+        np.testing.assert_allclose(got[f"eMatGrid_t{h + 1}"], ref["eMatGrid_t"][h], rtol=RTOL)
+        np.testing.assert_allclose(got[f"alphaHat_t{h + 1}"], ref["alphaHat_t"][h], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(got[f"betaHat_t{h + 1}"], ref["betaHat_t"][h], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(got[f"c{h + 1}"], ref["c"][h], rtol=RTOL)
+    for n in ("hapProbs_t", "genProbsM_t"):
+        np.testing.assert_allclose(got[n][:2] if n == "hapProbs_t" else got[n], ref[n][:2] if n == "hapProbs_t" else ref[n],
+                                   rtol=RTOL, atol=1e-14)
+
+
+@pytest.mark.parametrize("panel_name,Ks,n_reads,carriers", [("small_panel", 100, 120, (0, 4)),
+                                                            ("ragged_panel", 77, 250, (0, 40)),
+                                                            ("medium_panel", 600, 1200, (0, 6))])
+def test_rare_common_gibbs_matches_oracle(request, oracle, panel_name, Ks, n_reads, carriers):
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    panel = request.getfixturevalue(panel_name)
+    dev = DevicePanel(panel)
+    rc, s_all, which, H0, ru, rs = _setup(panel, 23, Ks, n_reads, carriers)
+    drc = DeviceRareCommon(dev, rc)
+    # the reference's arguments for this call: starting labels given, read categories off (impute_one_sample defaults)
+    for dis in (True, False):
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s_all, which, H0, ru, 0, rs, disable_read_category_usage=dis,
+                                              rare_common=rc)
+        got = rcpp_forwardBackwardGibbsNIPT(dev, s_all, which, H0, ru, 0, rs, disable_read_category_usage=dis,
+                                            return_state=True, rare_common=drc)
+        _compare(got, ref)
+    drc.close()
+    dev.close()
+
+
+def test_rare_common_batch_and_wave_geometries(medium_panel, oracle, monkeypatch):
+    """Several chains in one launch (different samples and haplotype subsets) under every chain geometry."""
+    from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    panel = medium_panel
+    rc = make_rare_common(panel, 5)
+    dev = DevicePanel(panel)
+    drc = DeviceRareCommon(dev, rc)
+    rng = np.random.default_rng(3)
+    G = rc.nGrids_all
+    samples, whichs, H0s, rus, rss, refs = [], [], [], [], [], []
+    for c in range(3):
+        _, s_all = make_synthetic_sample_rare_common(panel, rc, 100 + c, n_reads=400 + 50 * c)
+        which = np.sort(rng.choice(panel.K, 600, replace=False)).astype(np.int32) + 1
+        H0 = rng.integers(1, 3, size=s_all.nReads).astype(np.int32)
+        ru, rs = rng.random(s_all.nReads * 21), rng.random(3 * (G - 1))
+        samples.append(s_all); whichs.append(which); H0s.append(H0); rus.append(ru); rss.append(rs)
+        refs.append(oracle.forwardBackwardGibbsNIPT(panel, s_all, which, H0, ru, 0, rs, disable_read_category_usage=True,
+                                                    rare_common=rc))
+    for nw in ("1", "2", "5"):
+        monkeypatch.setenv("QA_GIBBS_NW", nw)
+        got = forwardBackwardGibbsNIPT_batch(dev, samples, whichs, H0s, rus, [0, 0, 0], rss,
+                                             disable_read_category_usage=True, rare_common=drc)
+        for g, r in zip(got, refs):
+            assert np.array_equal(g["H"], r["H"])
+            np.testing.assert_allclose(g["hapProbs_t"][:2], r["hapProbs_t"][:2], rtol=RTOL, atol=1e-14)
+            np.testing.assert_allclose(g["genProbsM_t"], r["genProbsM_t"], rtol=RTOL, atol=1e-14)
+    drc.close()
+    dev.close()
+
+
+def test_rare_common_rejects_bad_tables(small_panel):
+    from quilt_amd.native import DevicePanel, DeviceRareCommon, QuiltAmdError
+    from quilt_amd.synth import make_rare_common
+    import dataclasses
+    dev = DevicePanel(small_panel)
+    rc = make_rare_common(small_panel, 9)
+    bad = dataclasses.replace(rc, snp_is_common=np.ones_like(rc.snp_is_common))
+    with pytest.raises(QuiltAmdError):
+        DeviceRareCommon(dev, bad)
+    dev.close()
