@@ -44,6 +44,7 @@ class DriverParams:
     minGLValue: float = 1e-10
     Jmax: int = 10000
     seed: int = 1
+    impute_rare_common: bool = False   # quilt.R:180: finish every Gibbs sample with a Gibbs call over ALL SNPs
 
     def resolved(self, K: int) -> "DriverParams":
         p = DriverParams(**self.__dict__)
@@ -304,6 +305,7 @@ class ChainState:
     which_haps_to_use: Optional[np.ndarray] = None   # 1-based
     read_labels: Optional[np.ndarray] = None
     hap: Optional[List[np.ndarray]] = None           # dosage1, dosage2 of the latest full pass
+    hap_all: Optional[List[np.ndarray]] = None       # hap1_all, hap2_all of the rare + common call (all SNPs)
 
     _phasing: bool = False
 
@@ -333,6 +335,15 @@ class _Batch:
     nDosage: np.ndarray
     phasing: Optional[List[ChainState]] = None
     consensus: Optional[List[np.ndarray]] = None
+    dosage_all: Optional[np.ndarray] = None     # impute_rare_common: the same accumulators over ALL SNPs
+    gp_t_all: Optional[np.ndarray] = None
+    nDosage_all: Optional[np.ndarray] = None
+
+
+def get_initial_read_labels(e: np.ndarray, runif: np.ndarray) -> np.ndarray:
+    """rare_common.R:61-107 (diploid): ``e`` = 2 x nReads likelihoods of the all-SNP reads against (hap1, hap2) spread
+    over all SNPs (0.5 at the rare ones); ``H <- as.integer(runif(nReads) < e[1, ] / colSums(e)) + 1``."""
+    return (runif < (e[0] / (e[0] + e[1]))).astype(np.int32) + 1
 
 
 class Driver:
@@ -345,10 +356,15 @@ class Driver:
     latency-bound launches.  Results do not depend on the batching: every chain owns its random stream.
     """
 
-    def __init__(self, panel, backend, params: Optional[DriverParams] = None):
+    def __init__(self, panel, backend, params: Optional[DriverParams] = None, rare_common=None):
+        """``rare_common`` (:class:`quilt_amd.panel.RareCommon`), with ``params.impute_rare_common``: every sample then
+        carries its all-SNP reads as ``sample.all_snp`` and the results cover all SNPs (functions.R:1306-1307)."""
         self.panel = panel
         self.backend = backend
         self.params = (params or DriverParams()).resolved(panel.K)
+        self.rare_common = rare_common
+        if self.params.impute_rare_common and rare_common is None:
+            raise ValueError("impute_rare_common needs the panel's rare/common tables")
         self.cols = thinned_grid_columns(panel.nGrids, self.params.heuristic_match_thin)
         self.n_thin = int((self.cols >= 0).sum())
         self.top_width = max(8, self.params.K_top_matches)   # entries kept per (label, thinned grid) list
@@ -385,33 +401,8 @@ class Driver:
         t1 = time.perf_counter()
         self.timing["host"] += t1 - t0
         # ---- small-panel Gibbs (impute_one_sample, functions.R:2313-2774), with the underflow retry
-        pending = list(range(len(chains)))
-        maxdiff = [P.maxDifferenceBetweenReads] * len(chains)
-        results = [None] * len(chains)
-        n_try = 0
-        while pending:
-            groups = {}
-            for i in pending:
-                groups.setdefault(maxdiff[i], []).append(i)
-            nxt = []
-            for md, idx in groups.items():
-                out = self.backend.gibbs_batch(
-                    [chains[i].sample for i in idx], [chains[i].which_haps_to_use for i in idx],
-                    [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],
-                    [seed_shards[i] for i in idx], n_gibbs_burn_in_its=P.small_ref_panel_gibbs_iterations,
-                    n_gibbs_sample_its=P.n_gibbs_sample_its,
-                    block_gibbs_iterations=P.small_ref_panel_block_gibbs_iterations,
-                    gibbs_initialize_iteratively=any_first, maxDifferenceBetweenReads=md, Jmax_local=P.Jmax)
-                for i, o in zip(idx, out):
-                    if o["underflow_problem"]:
-                        maxdiff[i] = max(1.0, maxdiff[i] / 10)   # functions.R:2704-2715
-                        nxt.append(i)
-                    else:
-                        results[i] = o
-            pending = nxt
-            n_try += 1
-            if n_try > 10 and pending:
-                raise RuntimeError("There were consecutive underflow problems (functions.R:2710)")
+        results = self._gibbs_with_retry(chains, [ch.sample for ch in chains], starts, seed_reads, first_reads, seed_shards,
+                                         gibbs_initialize_iteratively=any_first)
         t2 = time.perf_counter()
         self.timing["gibbs"] += t2 - t1
         # ---- full-panel pass per read label (impute_using_everything, functions.R:1922-2157)
@@ -428,7 +419,9 @@ class Driver:
         # The reference asks for the best haplotypes on every call (functions.R:738-743), but the selection made from
         # them is read again only by a later round of the same chain or -- the last chain's final selection -- by the
         # phasing rounds (which_haps_to_use carried over): skip the lists nobody reads.
-        want_top = [i_it < P.n_seek_its or (not ch.phasing and ch.i_chain == P.nGibbsSamples) for ch in chains]
+        # (with impute_rare_common every chain's final selection feeds its all-SNP Gibbs call)
+        want_top = [i_it < P.n_seek_its or P.impute_rare_common or (not ch.phasing and ch.i_chain == P.nGibbsSamples)
+                    for ch in chains]
         dosages, top, top_cnt = self.backend.fullpass_reads_batch(
             sample_list, [uniq[id(ch.sample)] for ch in chains], [ch.read_labels for ch in chains],
             [return_dosage] * len(chains), want_top, self.cols, P.K_top_matches, P.minGLValue, self.top_width)
@@ -450,13 +443,80 @@ class Driver:
         self.timing["host"] += time.perf_counter() - t4
         return return_dosage
 
+    def _gibbs_with_retry(self, chains, samples, starts, seed_reads, first_reads, seed_shards, **kw):
+        """impute_one_sample's loop (functions.R:2612-2716): a chain whose call reports underflow is re-run with
+        maxDifferenceBetweenReads / 10."""
+        P = self.params
+        pending = list(range(len(chains)))
+        maxdiff = [P.maxDifferenceBetweenReads] * len(chains)
+        results = [None] * len(chains)
+        n_try = 0
+        while pending:
+            groups = {}
+            for i in pending:
+                groups.setdefault(maxdiff[i], []).append(i)
+            nxt = []
+            for md, idx in groups.items():
+                out = self.backend.gibbs_batch(
+                    [samples[i] for i in idx], [chains[i].which_haps_to_use for i in idx],
+                    [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],
+                    [seed_shards[i] for i in idx], n_gibbs_burn_in_its=P.small_ref_panel_gibbs_iterations,
+                    n_gibbs_sample_its=P.n_gibbs_sample_its,
+                    block_gibbs_iterations=P.small_ref_panel_block_gibbs_iterations,
+                    maxDifferenceBetweenReads=md, Jmax_local=P.Jmax, **kw)
+                for i, o in zip(idx, out):
+                    if o["underflow_problem"]:
+                        maxdiff[i] = max(1.0, maxdiff[i] / 10)   # functions.R:2704-2715
+                        nxt.append(i)
+                    else:
+                        results[i] = o
+            pending = nxt
+            n_try += 1
+            if n_try > 10 and pending:
+                raise RuntimeError("There were consecutive underflow problems (functions.R:2710)")
+        return results
+
+    def _rare_common_round(self, chains: List[ChainState]):
+        """impute_final_gibbs_with_rare_common (rare_common.R:109-420), once per Gibbs sample after its seek
+        iterations (functions.R:1042-1098): starting labels from the all-SNP reads against the latest (hap1, hap2)
+        (get_initial_read_labels), then one Gibbs call over ALL SNPs with the haplotypes selected last."""
+        import time
+        P, rc = self.params, self.rare_common
+        t0 = time.perf_counter()
+        common = rc.snp_is_common == 1
+        reads = [ch.sample.all_snp for ch in chains]
+        haps = []
+        for ch in chains:
+            e = np.full((2, rc.nSNPs_all), 0.5)
+            e[0, common] = ch.hap[0]
+            e[1, common] = ch.hap[1]
+            haps.append([e[0], e[1]])
+        lik = self.backend.read_likelihood_all_snps_batch(reads, haps, P.maxDifferenceBetweenReads)
+        starts, seed_reads, seed_shards = [], [], []
+        for ch, e in zip(chains, lik):
+            starts.append(get_initial_read_labels(e, ch.rng.random(e.shape[1])))
+            seed_reads.append(int(ch.rng.integers(0, 2 ** 63)))
+            seed_shards.append(int(ch.rng.integers(0, 2 ** 63)))
+        t1 = time.perf_counter()
+        self.timing["host"] += t1 - t0
+        # impute_one_sample's defaults for this call (functions.R:2385-2409): labels given, read categories off
+        results = self._gibbs_with_retry(chains, reads, starts, seed_reads, [0] * len(chains), seed_shards,
+                                         gibbs_initialize_iteratively=False, rare_common=True)
+        for ch, res in zip(chains, results):
+            ch.hap_all = [res["hapProbs_t"][0], res["hapProbs_t"][1]]
+        self.timing["gibbs"] += time.perf_counter() - t1
+
     def _new_batch(self, samples, offset: int) -> _Batch:
         P = self.params
         T = self.panel.nSNPs
         N = len(samples)
         chains = [ChainState(samples[i], i, c, chain_rng(P.seed, offset + i, c))
                   for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
-        return _Batch(list(samples), offset, chains, np.zeros((N, T)), np.zeros((N, 3, T)), np.zeros(N, dtype=np.int64))
+        b = _Batch(list(samples), offset, chains, np.zeros((N, T)), np.zeros((N, 3, T)), np.zeros(N, dtype=np.int64))
+        if P.impute_rare_common:
+            Ta = self.rare_common.nSNPs_all
+            b.dosage_all, b.gp_t_all, b.nDosage_all = np.zeros((N, Ta)), np.zeros((N, 3, Ta)), np.zeros(N, dtype=np.int64)
+        return b
 
     def _start_phasing(self, b: _Batch):
         """Read confidence per chain and consensus labels (functions.R:1144-1205); one phasing chain per sample."""
@@ -477,7 +537,14 @@ class Driver:
 
     def _finish(self, b: _Batch) -> List[SampleResult]:
         out = []
+        rc = self.params.impute_rare_common
         for i in range(len(b.samples)):
+            if rc:   # the switch-over to all SNPs (functions.R:1232-1240, 1305-1307)
+                d = b.dosage_all[i] / b.nDosage_all[i]
+                g = b.gp_t_all[i] / b.nDosage_all[i]
+                h1, h2 = recast_haps(b.phasing[i].hap_all[0], b.phasing[i].hap_all[1], g.T)
+                out.append(SampleResult(d, g, np.stack([h1, h2], axis=1), b.consensus[i], int(b.nDosage_all[i])))
+                continue
             d = b.dosage[i] / b.nDosage[i]
             g = b.gp_t[i] / b.nDosage[i]
             h1, h2 = recast_haps(b.phasing[i].hap[0], b.phasing[i].hap[1], g.T)   # functions.R:1207-1217
@@ -504,6 +571,13 @@ class Driver:
                         cur.dosage[ch.i_sample] += h1 + h2
                         cur.gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
                         cur.nDosage[ch.i_sample] += 1
+            if P.impute_rare_common:   # functions.R:1042-1123
+                self._rare_common_round((cur.chains if cur else []) + (prev.phasing if prev else []))
+                for ch in (cur.chains if cur else []):
+                    h1, h2 = ch.hap_all
+                    cur.dosage_all[ch.i_sample] += h1 + h2
+                    cur.gp_t_all[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
+                    cur.nDosage_all[ch.i_sample] += 1
             import time
             t0 = time.perf_counter()
             done = self._finish(prev) if prev else None
@@ -527,18 +601,32 @@ class Driver:
 # ---------------------------------------------------------------------------------------------
 
 class HipBackend:
-    def __init__(self, device_panel):
+    def __init__(self, device_panel, device_rare_common=None):
         self.dev = device_panel
+        self.drc = device_rare_common   # quilt_amd.native.DeviceRareCommon, for impute_rare_common
 
     def make_gl_bound(self, gl, minGLValue, to_fix):
         from .reference_single import Rcpp_make_gl_bound
         Rcpp_make_gl_bound(gl, minGLValue, to_fix)
 
-    def gibbs_batch(self, samples, which, starts, seed_reads, first_reads, seed_shards, **kw):
+    def gibbs_batch(self, samples, which, starts, seed_reads, first_reads, seed_shards, rare_common=False, **kw):
         from .gibbs_nipt import forwardBackwardGibbsNIPT_batch
+        if rare_common:   # the all-SNP call: hapProbs_t is its result (rare_common.R:401-407)
+            if self.drc is None:
+                raise ValueError("this backend was created without the rare/common tables")
+            return forwardBackwardGibbsNIPT_batch(self.dev, samples, which, starts, None, first_reads, None,
+                                                  seed_reads=seed_reads, seed_shard=seed_shards, return_hapProbs=True,
+                                                  return_genProbs=False, disable_read_category_usage=True,
+                                                  rare_common=self.drc, **kw)
         return forwardBackwardGibbsNIPT_batch(self.dev, samples, which, starts, None, first_reads, None,
                                               seed_reads=seed_reads, seed_shard=seed_shards,
                                               return_hapProbs=False, return_genProbs=False, **kw)   # use_mspbwt = FALSE
+
+    def read_likelihood_all_snps_batch(self, samples_all, haps, maxDifferenceBetweenReads):
+        """rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100."""
+        from .gibbs_nipt import calculate_eMatRead_t_vs_haplotypes_batch
+        return calculate_eMatRead_t_vs_haplotypes_batch(self.dev, samples_all, haps, maxDifferenceBetweenReads,
+                                                        rescale_eMatRead_t=True, Jmax=100, nSNPs=self.drc.rc.nSNPs_all)
 
     def fullpass_batch(self, gls, want_dosage, cols, K_top_matches):
         import ctypes as C

@@ -99,6 +99,7 @@ class SampleReads:
     truth_label: Optional[np.ndarray] = None  # int32 R: 1-based generating haplotype
     truth_haps: Optional[np.ndarray] = None   # int8 H x T
     ff: float = 0.0
+    all_snp: Optional["SampleReads"] = None   # the same sample read over ALL SNPs (impute_rare_common)
 
     @property
     def nReads(self) -> int:
@@ -279,4 +280,5 @@ def make_synthetic_sample_rare_common(panel: Panel, rc: RareCommon, seed: int, n
         com_bq.append(b[m])
     s_com = pack(com_u, com_bq, label, panel.nSNPs)
     s_com.truth_haps = truth[:, rc.snp_is_common == 1]
+    s_com.all_snp = s_all
     return s_com, s_all

@@ -6,29 +6,32 @@ from oracle import oracle as O
 
 
 class OracleBackend:
-    def __init__(self, panel):
+    def __init__(self, panel, rare_common=None):
         self.panel = panel
+        self.rare_common = rare_common
 
     def make_gl_bound(self, gl, minGLValue, to_fix):
         O.make_gl_bound(gl, minGLValue, to_fix)
 
     def gibbs_batch(self, samples, which, starts, seed_reads, first_reads, seed_shards, *,
                     n_gibbs_burn_in_its, n_gibbs_sample_its, block_gibbs_iterations, gibbs_initialize_iteratively,
-                    maxDifferenceBetweenReads, Jmax_local):
+                    maxDifferenceBetweenReads, Jmax_local, rare_common=False):
         from quilt_amd.rng import stream_uniform
         out = []
         n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
         nb = len(block_gibbs_iterations)
+        G = self.rare_common.nGrids_all if rare_common else self.panel.nGrids
+        extra = dict(rare_common=self.rare_common, disable_read_category_usage=True) if rare_common else {}
         for s, w, h, sr, fr, ss in zip(samples, which, starts, seed_reads, first_reads, seed_shards):
             ru = stream_uniform(sr, s.nReads * n_its)
-            rs = stream_uniform(ss, nb * (self.panel.nGrids - 1))
+            rs = stream_uniform(ss, nb * (G - 1))
             init = bool(gibbs_initialize_iteratively) and fr >= 0   # per chain (include/quilt_amd.h: first_read < 0)
             r = O.forwardBackwardGibbsNIPT(self.panel, s, w, h, ru, max(fr, 0), rs,
                                            n_gibbs_burn_in_its=n_gibbs_burn_in_its,
                                            n_gibbs_sample_its=n_gibbs_sample_its,
                                            block_gibbs_iterations=block_gibbs_iterations,
                                            gibbs_initialize_iteratively=init,
-                                           maxDifferenceBetweenReads=maxDifferenceBetweenReads, Jmax=Jmax_local)
+                                           maxDifferenceBetweenReads=maxDifferenceBetweenReads, Jmax=Jmax_local, **extra)
             r["double_list_of_ending_read_labels"] = [[r["H"]]]
             out.append(r)
         return out
@@ -44,6 +47,10 @@ class OracleBackend:
 
     def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):
         return [O.calculate_eMatRead_t_vs_haplotypes(s, h, maxDifferenceBetweenReads) for s, h in zip(samples, haps)]
+
+    def read_likelihood_all_snps_batch(self, samples_all, haps, maxDifferenceBetweenReads):
+        return [O.calculate_eMatRead_t_vs_haplotypes(s, h, maxDifferenceBetweenReads, rescale_eMatRead_t=True, Jmax=100)
+                for s, h in zip(samples_all, haps)]
 
     def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, want_top, cols, K_top_matches, minGLValue,
                              top_width):

@@ -1,5 +1,6 @@
 """CPU tests of the host-side driver logic restated from QUILT/R/functions.R."""
 import numpy as np
+import pytest
 
 from quilt_amd import driver as D
 
@@ -96,3 +97,33 @@ def test_best_read_labels_lazy_form_equals_literal_form():
         can = int(rng.integers(1, n + 1))
         assert np.array_equal(D.determine_best_read_label_so_far(m, conf, R, n, can_hap=can),
                               D._determine_best_read_label_so_far_literal(m, conf, R, n, can_hap=can))
+
+
+def test_rare_common_pipeline_on_the_oracle():
+    """impute_rare_common (functions.R:1042-1123, rare_common.R:109-420): every Gibbs sample ends with a Gibbs call over
+    ALL SNPs; results switch over to all SNPs (functions.R:1305-1307) and stay independent of the batching."""
+    from quilt_amd.synth import make_rare_common, make_synthetic_panel, make_synthetic_sample_rare_common
+    from tests.oracle_backend import OracleBackend
+    from tests.util import r2
+    panel = make_synthetic_panel(K=400, nSNPs=320, seed=21)
+    rc = make_rare_common(panel, 3)
+    samples = [make_synthetic_sample_rare_common(panel, rc, 50 + i, n_reads=150)[0] for i in range(3)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, impute_rare_common=True)
+    one = D.Driver(panel, OracleBackend(panel, rc), prm, rare_common=rc).run(samples)
+    for smp, r in zip(samples, one):
+        assert r.dosage.shape == (rc.nSNPs_all,) and r.gp_t.shape == (3, rc.nSNPs_all) and r.nDosage == 2
+        assert r.phasing_haps.shape == (rc.nSNPs_all, 2)
+        np.testing.assert_allclose(r.gp_t.sum(axis=0), 1.0, atol=1e-9)
+        truth = smp.all_snp.truth_haps.sum(axis=0)
+        assert r2(r.dosage, truth) > 0.5
+        assert r.dosage[rc.snp_is_common == 0].min() >= 2 * panel.ref_error - 1e-12   # rare SNPs: ref_error per haplotype at least
+    streamed = list(D.Driver(panel, OracleBackend(panel, rc), prm, rare_common=rc).run_stream([(samples[:2], 0), (samples[2:], 2)]))
+    for g, r in zip(streamed[0] + streamed[1], one):
+        assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
+    with pytest.raises(ValueError):
+        D.Driver(panel, OracleBackend(panel), prm)
+
+
+def test_get_initial_read_labels():
+    e = np.array([[0.9, 0.1, 0.5], [0.1, 0.9, 0.5]])
+    assert D.get_initial_read_labels(e, np.array([0.5, 0.5, 0.7])).tolist() == [2, 1, 1]

@@ -107,3 +107,31 @@ def test_rare_common_rejects_bad_tables(small_panel):
     with pytest.raises(QuiltAmdError):
         DeviceRareCommon(dev, bad)
     dev.close()
+
+
+def test_rare_common_pipeline_matches_oracle(medium_panel):
+    """The whole driver with impute_rare_common on the HIP backend vs on the oracle: consensus labels identical, all-SNP
+    dosages within the fp32 rounding of the dosage passes that seed the all-SNP starting labels."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    from tests.oracle_backend import OracleBackend
+    from tests.util import r2
+    panel = medium_panel
+    rc = make_rare_common(panel, 4)
+    samples = [make_synthetic_sample_rare_common(panel, rc, 2000 + i, n_reads=1000)[0] for i in range(3)]
+    prm = DriverParams(nGibbsSamples=3, Ksubset=200, Knew=200, seed=5, impute_rare_common=True)
+    dev = DevicePanel(panel)
+    drc = DeviceRareCommon(dev, rc)
+    got = Driver(panel, HipBackend(dev, drc), prm, rare_common=rc).run(samples)
+    ref = Driver(panel, OracleBackend(panel, rc), prm, rare_common=rc).run(samples)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g.nDosage == r.nDosage == 3 and g.dosage.shape == (rc.nSNPs_all,)
+        assert np.array_equal(g.read_labels, r.read_labels)
+        np.testing.assert_allclose(g.gp_t.sum(axis=0), 1.0, atol=2e-3)
+        print(f"sample {i}: all-SNP r2(gpu, oracle) = {r2(g.dosage, r.dosage):.6f}, max|d| = {np.abs(g.dosage - r.dosage).max():.2e}")
+        assert r2(g.dosage, r.dosage) >= 0.999
+        truth = samples[i].all_snp.truth_haps.sum(axis=0)
+        assert abs(r2(g.dosage, truth) - r2(r.dosage, truth)) < 0.02
+    drc.close()
+    dev.close()
