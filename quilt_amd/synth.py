@@ -202,15 +202,14 @@ def make_rare_common(panel: Panel, seed: int, n_rare: Optional[int] = None, carr
     sigma = _sigma_from_positions(L_grid_all, ex.get("nGen", 100.0), ex.get("expRate", 1.0))
     tm = np.asfortranarray(np.stack([sigma, 1.0 - sigma], axis=0))
     rare_idx = np.flatnonzero(snp_is_common == 0)
-    per_hap = [[] for _ in range(panel.K)]
-    for t in rare_idx:
-        n = int(rng.integers(carriers[0], carriers[1] + 1))
-        for k in rng.choice(panel.K, size=min(n, panel.K), replace=False):
-            per_hap[int(k)].append(int(t) + 1)
+    n_car = rng.integers(carriers[0], carriers[1] + 1, size=len(rare_idx))
+    snp = np.repeat(rare_idx, n_car).astype(np.int64)
+    hap = rng.integers(0, panel.K, size=len(snp)).astype(np.int64)
+    pairs = np.unique(hap * T_all + snp)            # distinct (haplotype, SNP), sorted by haplotype then SNP
+    hap, snp = pairs // T_all, pairs % T_all
     rare_ptr = np.zeros(panel.K + 1, dtype=np.int64)
-    rare_ptr[1:] = np.cumsum([len(x) for x in per_hap])
-    rare_snp = (np.concatenate([np.asarray(x, dtype=np.int32) for x in per_hap])
-                if rare_ptr[-1] else np.zeros(0, dtype=np.int32)).astype(np.int32)
+    rare_ptr[1:] = np.cumsum(np.bincount(hap, minlength=panel.K))
+    rare_snp = (snp + 1).astype(np.int32)
     return RareCommon(nSNPs_all=T_all, nGrids_all=G_all, snp_is_common=snp_is_common,
                       common_snp_index=common_snp_index, rare_ptr=rare_ptr, rare_snp=rare_snp,
                       transMatRate_t_all=tm, L_all=L_all, L_grid_all=L_grid_all)

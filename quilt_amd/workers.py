@@ -14,17 +14,18 @@ import threading
 from typing import Iterable, List, Optional, Tuple
 
 from .driver import Driver, DriverParams, HipBackend
-from .native import DevicePanel
+from .native import DevicePanel, DeviceRareCommon
 from .sharding import get_sample_range
 
 
 class DeviceWorkers:
-    def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2):
+    def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None):
         self.n = n_workers
         self.devs = [DevicePanel(panel) for _ in range(n_workers)]
         for d in self.devs:
             d.set_device_share(n_workers)
-        self.drivers = [Driver(panel, HipBackend(d), params) for d in self.devs]
+        self.drcs = [DeviceRareCommon(d, rare_common) if rare_common is not None else None for d in self.devs]
+        self.drivers = [Driver(panel, HipBackend(d, r), params, rare_common=rare_common) for d, r in zip(self.devs, self.drcs)]
 
     @property
     def timing(self):
@@ -36,6 +37,9 @@ class DeviceWorkers:
             d.timing = {k: 0.0 for k in d.timing}
 
     def close(self):
+        for r in self.drcs:
+            if r is not None:
+                r.close()
         for d in self.devs:
             d.close()
 
