@@ -23,8 +23,10 @@
  * final backward re-run (:1947-1954), which reproduces the beta the sweep already
  * holds bit for bit.  The oracle therefore treats the diploid block resampler as
  * the identity and runs the shard resampler (:1975-2355), which is active.
- * Block Gibbs for ff > 0 (NIPT) is not restated yet: qo_gibbs returns -2 if asked.
+ * Block Gibbs for ff > 0 (NIPT): block definition (:311-523), make_gibbs_considers (:1307-1553) and the block
+ * resampler proper (:590-949, :1122-1292, :1636-1967) for block_approach = 6, restated below.
  */
+#define _GNU_SOURCE /* qsort_r */
 #include "quilt_oracle.h"
 
 #include <math.h>
@@ -582,6 +584,457 @@ static void calc_hapProbs(const qo_panel_t *p, const int32_t *which_1based, swee
     free(gam);
 }
 
+/* ---- NIPT block Gibbs (gibbs-nipt-block.cpp), ff > 0, block_approach = 6 ---------------------- */
+
+/* rcpp_simple_quantile (gibbs-nipt-block.cpp:81-85): x[order(x)][int(n * q)] */
+static int cmp_idx_asc(const void *a, const void *b, void *x)
+{
+    const double *v = (const double *)x;
+    int i = *(const int *)a, j = *(const int *)b;
+    if (v[i] < v[j]) return -1;
+    if (v[i] > v[j]) return 1;
+    return i - j;
+}
+static void sort_index(const double *x, int n, int *idx, int descending)
+{
+    for (int i = 0; i < n; i++) idx[i] = i;
+    qsort_r(idx, (size_t)n, sizeof(int), cmp_idx_asc, (void *)x);
+    if (descending) { /* ties keep increasing index (arma::sort_index is not stable; ties are measure zero here) */
+        int *tmp = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+        int o = 0;
+        for (int hi = n; hi > 0;) {
+            int lo = hi - 1;
+            while (lo > 0 && x[idx[lo - 1]] == x[idx[hi - 1]]) lo--;
+            for (int i = lo; i < hi; i++) tmp[o++] = idx[i];
+            hi = lo;
+        }
+        memcpy(idx, tmp, sizeof(int) * (size_t)n);
+        free(tmp);
+    }
+}
+double qo_simple_quantile(const double *x, int n, double q)
+{
+    int *idx = (int *)malloc(sizeof(int) * (size_t)n);
+    sort_index(x, n, idx, 0);
+    double v = x[idx[(int)(n * q)]];
+    free(idx);
+    return v;
+}
+
+/* rcpp_make_smoothed_rate (copied-from-stitch.cpp:446-518) */
+void qo_make_smoothed_rate(const double *sigma_rate, const int32_t *L_grid, int nGrids, int shuffle_bin_radius,
+                           double *smoothed_rate /* nGrids - 1 */)
+{
+    for (int g = 0; g < nGrids - 1; g++) {
+        int focal_point = (L_grid[g] + L_grid[g + 1]) / 2;
+        int left = g, bp_remaining = shuffle_bin_radius, bp_prev = focal_point, bp_to_add;
+        double total = 0, acc = 0;
+        while ((0 < bp_remaining) & (0 <= left)) {
+            bp_to_add = bp_prev - L_grid[left];
+            if ((bp_remaining - bp_to_add) < 0) { bp_to_add = bp_remaining; bp_remaining = 0; }
+            else bp_remaining = bp_remaining - bp_to_add;
+            acc = acc + bp_to_add * sigma_rate[left];
+            total += bp_to_add;
+            bp_prev = L_grid[left];
+            left = left - 1;
+        }
+        int right = g + 1;
+        bp_remaining = shuffle_bin_radius;
+        bp_prev = focal_point;
+        while ((0 < bp_remaining) & (right < nGrids)) {
+            bp_to_add = L_grid[right] - bp_prev;
+            if ((bp_remaining - bp_to_add) < 0) { bp_to_add = bp_remaining; bp_remaining = 0; }
+            else bp_remaining = bp_remaining - bp_to_add;
+            acc = acc + bp_to_add * sigma_rate[right - 1];
+            total += bp_to_add;
+            bp_prev = L_grid[right];
+            right = right + 1;
+        }
+        smoothed_rate[g] = acc / total;
+    }
+}
+
+/* rcpp_determine_where_to_stop (copied-from-stitch.cpp:522-567) */
+static int determine_where_to_stop(const double *smoothed_rate, const uint8_t *available, int snp_best, double thresh,
+                                   int nGrids, int is_left)
+{
+    const int mult = is_left ? 1 : -1;
+    int snp_consider = snp_best;
+    double val_cur, val_prev = smoothed_rate[snp_best];
+    int snp_min = snp_consider;
+    double val_min = smoothed_rate[snp_min];
+    int c = 1, are_done = 0;
+    while (!are_done) {
+        snp_consider = snp_consider + (-1) * mult;
+        val_cur = smoothed_rate[snp_consider];
+        if (5 <= c) val_prev = smoothed_rate[snp_consider + 5 * mult];
+        c += 1;
+        if (val_cur < val_min) { snp_min = snp_consider; val_min = val_cur; }
+        if ((snp_consider <= 2) | ((nGrids - 3) <= snp_consider)) are_done = 1;
+        else if (!available[snp_consider + (-1) * mult]) are_done = 1;
+        else if ((3 * val_min) < val_cur) are_done = 1;
+        else if ((val_cur < thresh) & (val_prev < val_cur)) are_done = 1;
+    }
+    return snp_min;
+}
+
+/* Rcpp_define_blocked_snps_using_gamma_on_the_fly (gibbs-nipt-block.cpp:311-523) from rate2 on, at the level of grids:
+ * blocked_snps[i] = blocked_grid[grid[i]] and every 32-SNP grid holds a SNP, so nothing is lost.  (The reference
+ * multiplies rate2 by smooth_cm AFTER smoothed_rate was computed from it, :373-381: no effect.) */
+void qo_define_blocked_grids(const double *rate2 /* nGrids - 1 */, const int32_t *L_grid, int nGrids,
+                             int shuffle_bin_radius, double block_gibbs_quantile_prob, int32_t *blocked_grid /* nGrids */)
+{
+    const int n = nGrids - 1;
+    double *sm = (double *)malloc(sizeof(double) * (size_t)n);
+    uint8_t *available = (uint8_t *)calloc((size_t)n, 1);
+    int *best = (int *)malloc(sizeof(int) * (size_t)n);
+    int *to_keep = (int *)malloc(sizeof(int) * (size_t)(n + 3));
+    int n_keep = 0;
+    for (int g = 0; g < nGrids; g++) blocked_grid[g] = 0;
+    qo_make_smoothed_rate(rate2, L_grid, nGrids, shuffle_bin_radius, sm);
+    double break_thresh = 1;
+    double d = qo_simple_quantile(sm, n, block_gibbs_quantile_prob);
+    if (d < break_thresh) break_thresh = d;
+    int nAvailable = 0;
+    for (int i = 0; i < n; i++) {
+        available[i] = 0; /* (< 0.01 and NA leave it FALSE) */
+        if (break_thresh < sm[i]) available[i] = 1;
+        nAvailable += available[i];
+    }
+    if (nAvailable == 0) goto done;
+    sort_index(sm, n, best, 1);
+    for (int iBest = 0; iBest < nAvailable; iBest++) {
+        if (!available[best[iBest]]) continue;
+        const int snp_best = best[iBest];
+        const int a = snp_best - 1 > 0 ? snp_best - 1 : 0;
+        const int b = snp_best + 1 < nGrids - 2 ? snp_best + 1 : nGrids - 2;
+        int cnt = 0;
+        for (int j = a; j <= b; j++) cnt += available[j];
+        if (cnt == 3) {
+            int left = determine_where_to_stop(sm, available, snp_best, break_thresh, nGrids, 1);
+            int right = determine_where_to_stop(sm, available, snp_best, break_thresh, nGrids, 0);
+            for (int j = left; j <= right; j++) available[j] = 0;
+        } else {
+            for (int j = a; j <= b; j++) available[j] = 0;
+        }
+        to_keep[n_keep++] = snp_best + 1;
+    }
+    {
+        int mn = to_keep[0], mx = to_keep[0];
+        for (int i = 1; i < n_keep; i++) { if (to_keep[i] < mn) mn = to_keep[i]; if (to_keep[i] > mx) mx = to_keep[i]; }
+        if (mn != 0) to_keep[n_keep++] = 0;
+        if (mx != nGrids - 1) to_keep[n_keep++] = nGrids - 1;
+        for (int i = 1; i < n_keep; i++) { /* sort ascending */
+            int v = to_keep[i], j = i - 1;
+            while (j >= 0 && to_keep[j] > v) { to_keep[j + 1] = to_keep[j]; j--; }
+            to_keep[j + 1] = v;
+        }
+        for (int i = 0; i < n_keep - 1; i++)
+            for (int j = to_keep[i]; j <= to_keep[i + 1]; j++) blocked_grid[j] = i;
+    }
+done:
+    free(sm); free(available); free(best); free(to_keep);
+}
+
+static double ceiling_point5(double x) { return ((double)(int)x < x) ? x + 0.5 : x; }
+
+/* Rcpp_make_gibbs_considers (gibbs-nipt-block.cpp:1307-1553), do_removal = TRUE, at the level of grids (see above).
+ * Arrays need capacity nGrids; returns n_blocks. */
+int qo_make_gibbs_considers(const int32_t *blocked_grid_in, int nGrids, const int32_t *wif0, int nReads,
+                            int32_t *grid_start, int32_t *grid_end, int32_t *reads_start, int32_t *reads_end,
+                            int32_t *grid_where /* nGrids */)
+{
+    int n_blocks = blocked_grid_in[nGrids - 1] + 1;
+    int iBlock = 0, start = 0;
+    for (int g = 0; g < nGrids; g++) {
+        int record = (g == nGrids - 1) || (blocked_grid_in[g] < blocked_grid_in[g + 1]);
+        if (record) { grid_start[iBlock] = start; grid_end[iBlock] = g; start = g + 1; iBlock++; }
+    }
+    int32_t *blocked_grid = (int32_t *)calloc((size_t)nGrids, sizeof(int32_t));
+    for (int b = 0; b < n_blocks; b++)
+        for (int i = grid_start[b]; i <= grid_end[b]; i++) blocked_grid[i] = b;
+    for (int b = 0; b < n_blocks; b++) reads_start[b] = reads_end[b] = -1;
+    if (nReads > 0) {
+        int previous_block_first_iRead = 0;
+        int previous_block = blocked_grid[wif0[0]];
+        for (int this_iRead = 1; this_iRead < nReads; this_iRead++) {
+            int this_block = blocked_grid[wif0[this_iRead]];
+            if (this_iRead == nReads - 1) {
+                reads_start[this_block] = previous_block_first_iRead;
+                reads_end[this_block] = this_iRead;
+            } else if (previous_block < this_block) {
+                reads_start[previous_block] = previous_block_first_iRead;
+                reads_end[previous_block] = this_iRead - 1;
+                previous_block_first_iRead = this_iRead;
+                previous_block = blocked_grid[wif0[this_iRead]];
+            }
+        }
+    }
+    int n_to_remove = 0;
+    int *w = (int *)malloc(sizeof(int) * (size_t)(n_blocks > 0 ? n_blocks : 1));
+    for (int b = 0; b < n_blocks; b++) if (reads_start[b] == -1) w[n_to_remove++] = b;
+    if (n_to_remove > 0 && n_to_remove < n_blocks) {
+        int jBefore = 0;
+        for (int jNow = 0; jNow < n_to_remove; jNow++) {
+            int todo;
+            if (jNow == n_to_remove - 1) todo = 1;
+            else if ((w[jNow + 1] - w[jNow]) == 1) { todo = 0; jBefore -= 1; }
+            else todo = 1;
+            if (todo) {
+                int s1 = w[jBefore], e1 = w[jNow];
+                double x = ceiling_point5(0.5 * (double)(grid_start[s1] + grid_end[e1]));
+                if (s1 == 0) { s1 = 1; x = 0; }
+                if (e1 == n_blocks - 1) { e1 = e1 - 1; x = grid_end[n_blocks - 1]; }
+                grid_start[e1 + 1] = (int32_t)x;
+                grid_end[s1 - 1] = (int32_t)(x - 1);
+                jBefore = jNow;
+            }
+            jBefore += 1;
+        }
+        int o = 0;
+        for (int b = 0; b < n_blocks; b++) {
+            if (reads_start[b] == -1) continue;
+            reads_start[o] = reads_start[b]; reads_end[o] = reads_end[b];
+            grid_start[o] = grid_start[b]; grid_end[o] = grid_end[b];
+            o++;
+        }
+        n_blocks = o;
+    }
+    for (int g = 0; g < nGrids; g++) grid_where[g] = -1;
+    for (int b = 0; b < n_blocks; b++) grid_where[grid_end[b]] = b;
+    free(w); free(blocked_grid);
+    return n_blocks;
+}
+
+/* rcpp_get_log_p_H_class2 (gibbs-nipt-block.cpp:170-207) */
+double qo_get_log_p_H_class2(int n1, int n2, int n3, int n4, int n5, int n6, double ff)
+{
+    if (ff == 0)
+        return 0 + n1 * log(0.5) + n2 * log(0.5 - ff * 0.5) + n3 * log(0.001) + n4 * log(1 - ff * 0.5) +
+               n5 * log(1 * 0.5 + ff * 0.5) + n6 * log(1 * 0.5);
+    if (ff == 1)
+        return 0 + n1 * log(0.5) + n2 * log(0.001) + n3 * log(ff * 0.5) + n4 * log(1 - ff * 0.5) +
+               n5 * log(1 * 0.5 + ff * 0.5) + n6 * log(1 * 0.5);
+    return 0 + n1 * log(0.5) + n2 * log(0.5 - ff * 0.5) + n3 * log(ff * 0.5) + n4 * log(1 - ff * 0.5) +
+           n5 * log(1 * 0.5 + ff * 0.5) + n6 * log(1 * 0.5);
+}
+
+static const int kRR[6][3] = {{1, 2, 3}, {1, 3, 2}, {2, 1, 3}, {2, 3, 1}, {3, 1, 2}, {3, 2, 1}};   /* :1755-1761 */
+static const int kRX[6][3] = {{1, 2, 3}, {1, 3, 2}, {2, 1, 3}, {3, 1, 2}, {2, 3, 1}, {3, 2, 1}};   /* :752-758 */
+
+/* the label / class relabelling of choice ir (0-based), :760-769 */
+void qo_zero_based_swap(int ir_chosen, int swap[8])
+{
+    swap[0] = 0;
+    swap[1] = kRX[ir_chosen][0]; swap[2] = kRX[ir_chosen][1]; swap[3] = kRX[ir_chosen][2];
+    swap[4] = 7 - kRX[ir_chosen][2]; swap[5] = 7 - kRX[ir_chosen][1]; swap[6] = 7 - kRX[ir_chosen][0];
+    swap[7] = 7;
+}
+
+/* Rcpp::sample(1:3, 1, FALSE, probs) given its one uniform: probabilities normalised, sorted in decreasing order
+ * (Rf_revsort), first j with u <= cumulative mass (Rcpp sugar sample.h, SampleReplace for size 1). */
+int qo_sample3(const double probs[3], double u)
+{
+    double p[3] = {probs[0], probs[1], probs[2]};
+    int perm[3] = {1, 2, 3};
+    double sum = p[0] + p[1] + p[2];
+    for (int i = 0; i < 3; i++) p[i] /= sum;
+    for (int i = 1; i < 3; i++) { /* stable insertion sort, descending */
+        double v = p[i]; int q = perm[i], j = i - 1;
+        while (j >= 0 && p[j] < v) { p[j + 1] = p[j]; perm[j + 1] = perm[j]; j--; }
+        p[j + 1] = v; perm[j + 1] = q;
+    }
+    p[1] += p[0]; p[2] += p[1];
+    int j;
+    for (j = 0; j < 2; j++) if (u <= p[j]) break;
+    return perm[j];
+}
+
+/*
+ * Rcpp_block_gibbs_resampler (gibbs-nipt-block.cpp:1636-1967) with Rcpp_gibbs_block_forward_one (:1122-1253),
+ * Rcpp_consider_block_relabelling (:590-949), Rcpp_reset_local_variables (:1257-1292) and
+ * rcpp_sample_H_using_H_class (:213-246), for the production arguments: ff > 0, block_approach = 6,
+ * consider_total_relabelling = FALSE, resample_H_using_H_class = TRUE.
+ *   runif_block     one uniform per block (the reference draws nReads of them and uses the first n_blocks, :3016)
+ *   runif_resample  one uniform per read, used by the reads whose class leaves a choice (:226-243)
+ */
+static void block_gibbs_resampler_nipt(sweep_t *S, double ff, const int32_t *blocked_grid, const double *runif_block,
+                                       const double *runif_resample)
+{
+    const int Ks = S->Ks, G = S->G, R = S->R;
+    const double one_over_K = 1 / (double)Ks, prior = 1.0 / Ks;
+    int32_t *gs = (int32_t *)malloc(sizeof(int32_t) * (size_t)G * 5);
+    int32_t *ge = gs + G, *rs = ge + G, *re = rs + G, *where = re + G;
+    const int n_blocks = qo_make_gibbs_considers(blocked_grid, G, S->wif, R, gs, ge, rs, re, where);
+    double *alphaStore = (double *)calloc((size_t)18 * Ks, sizeof(double));   /* [ir][h][k] */
+    double *log_cStore = (double *)calloc((size_t)18 * G, sizeof(double));    /* [ir][h][g] */
+    double *eLocal = (double *)malloc(sizeof(double) * (size_t)3 * Ks);
+    double logC_before[3] = {0, 0, 0}, logC_after[3] = {0, 0, 0};
+    for (int h = 0; h < 3; h++) for (int g = 0; g < G; g++) logC_after[h] += log(S->c[h][g]);
+    double sum_H[3] = {0, 0, 0};
+    for (int r = 0; r < R; r++) sum_H[S->H[r] - 1] += 1;
+    int ever_changed = 0;
+#define AS(ir, h) (alphaStore + ((size_t)(ir) * 3 + (h)) * Ks)
+#define LC(ir, h, g) log_cStore[((size_t)(ir) * 3 + (h)) * G + (g)]
+    for (int g = 0; g < G; g++) {
+        for (int i = 0; i < 3; i++) memcpy(eLocal + (size_t)i * Ks, S->eg[i] + (size_t)Ks * g, sizeof(double) * Ks);
+        /* Rcpp_gibbs_block_forward_one, block_approach = 6 */
+        for (int ir = 0; ir < 6; ir++)
+            for (int i = 0; i < 3; i++) {
+                const int h = kRR[ir][i] - 1;
+                double *a = AS(ir, h);
+                const double *e = eLocal + (size_t)i * Ks;
+                if (g == 0) {
+                    for (int k = 0; k < Ks; k++) a[k] = prior * e[k];
+                } else {
+                    const double t0 = S->tm[2 * (size_t)(g - 1)], t1 = S->tm[2 * (size_t)(g - 1) + 1];
+                    for (int k = 0; k < Ks; k++) a[k] = e[k] * (t0 * a[k] + t1 * one_over_K);
+                }
+                double d = 1 / col_sum(a, Ks);
+                LC(ir, h, g) = log(d);
+                for (int k = 0; k < Ks; k++) a[k] = d * a[k];
+            }
+        if (where[g] > -1) {
+            const int iBlock = where[g];
+            const int grid_start = gs[iBlock], grid_end = ge[iBlock], read_start = rs[iBlock], read_end = re[iBlock];
+            /* ---- Rcpp_consider_block_relabelling ---- */
+            double Pm[6][3], P[6] = {0, 0, 0, 0, 0, 0};
+            for (int ir = 0; ir < 6; ir++)
+                for (int i = 0; i < 3; i++) {
+                    double logC_inside = 0;
+                    for (int g2 = grid_start; g2 <= grid_end; g2++) logC_inside += LC(ir, i, g2);
+                    const double *a = AS(ir, i), *b = S->beta[i] + (size_t)Ks * g;
+                    double dot = 0;
+                    for (int k = 0; k < Ks; k++) dot += a[k] * b[k];
+                    Pm[ir][i] = log(dot) + -logC_before[i] + -logC_inside + -logC_after[i];
+                    P[ir] += Pm[ir][i];
+                }
+            int ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = read_start; r <= read_end; r++) ns[S->H_class[r]]++;
+            double clp[6], cp[6];
+            for (int ir = 0; ir < 6; ir++) {
+                const int *q = kRR[ir];
+                clp[ir] = qo_get_log_p_H_class2(ns[q[0]], ns[q[1]], ns[q[2]], ns[7 - q[2]], ns[7 - q[1]], ns[7 - q[0]], ff) + P[ir];
+            }
+            double mx = clp[0];
+            for (int ir = 1; ir < 6; ir++) if (clp[ir] > mx) mx = clp[ir];
+            double a = -mx, tot = 0;
+            for (int ir = 0; ir < 6; ir++) {
+                clp[ir] += a;
+                if (clp[ir] < -100) clp[ir] = -100;
+                cp[ir] = exp(clp[ir]);
+                tot += cp[ir];
+            }
+            double d = 1 / tot;
+            for (int ir = 0; ir < 6; ir++) cp[ir] *= d;
+            const double chance = runif_block[iBlock];
+            double cum[6];
+            cum[0] = cp[0];
+            for (int ir = 1; ir < 6; ir++) cum[ir] = cp[ir] + cum[ir - 1];
+            int ir_chosen = 0;
+            for (int ir = 5; ir >= 0; ir--) if (chance < cum[ir]) ir_chosen = ir;
+            int swap[8];
+            qo_zero_based_swap(ir_chosen, swap);
+            if ((ever_changed == 1) | (ir_chosen != 0)) {
+                ever_changed = 1;
+                int iRead = read_start;
+                int wif_read = S->wif[iRead];
+                for (int g2 = grid_start; g2 <= grid_end; g2++) {
+                    for (size_t i = 0; i < (size_t)3 * Ks; i++) eLocal[i] = 1;
+                    while ((iRead <= (R - 1)) & (wif_read < g2)) {
+                        iRead += 1;
+                        if (iRead < (R - 1)) wif_read = S->wif[iRead];
+                    }
+                    while ((iRead <= (R - 1)) & (wif_read == g2)) {
+                        const int h = swap[S->H[iRead]] - 1;
+                        const double *er = S->eMatRead + (size_t)Ks * iRead;
+                        double *e = eLocal + (size_t)h * Ks;
+                        for (int k = 0; k < Ks; k++) e[k] *= er[k];
+                        iRead += 1;
+                        if (iRead <= (R - 1)) wif_read = S->wif[iRead];
+                    }
+                    for (int h = 0; h < 3; h++) {
+                        double *e = S->eg[h] + (size_t)Ks * g2, *al = S->alpha[h] + (size_t)Ks * g2;
+                        memcpy(e, eLocal + (size_t)h * Ks, sizeof(double) * Ks);
+                        if (g2 == 0) {
+                            for (int k = 0; k < Ks; k++) al[k] = prior * e[k];
+                        } else {
+                            const double t0 = S->tm[2 * (size_t)(g2 - 1)], t1 = S->tm[2 * (size_t)(g2 - 1) + 1];
+                            const double *ap = S->alpha[h] + (size_t)Ks * (g2 - 1);
+                            for (int k = 0; k < Ks; k++) al[k] = e[k] * (t0 * ap[k] + t1 * prior);
+                        }
+                        S->c[h][g2] = 1 / col_sum(al, Ks);
+                        for (int k = 0; k < Ks; k++) al[k] *= S->c[h][g2];
+                    }
+                }
+                for (int r = read_start; r <= read_end; r++) {
+                    const int lost = S->H[r] - 1, gained = swap[S->H[r]] - 1;
+                    S->H_class[r] = swap[S->H_class[r]];
+                    S->H[r] = gained + 1;
+                    sum_H[gained] += 1.0;
+                    sum_H[lost] -= 1.0;
+                }
+            }
+            /* Rcpp_reset_local_variables */
+            if ((iBlock + 1) < n_blocks)
+                for (int ir = 0; ir < 6; ir++)
+                    for (int h = 0; h < 3; h++) {
+                        memcpy(AS(ir, h), S->alpha[h] + (size_t)Ks * g, sizeof(double) * Ks);
+                        LC(ir, h, g) = log(S->c[h][g]);
+                    }
+            for (int g2 = grid_start; g2 <= grid_end; g2++)
+                for (int h = 0; h < 3; h++) logC_before[h] += log(S->c[h][g2]);
+        }
+        for (int h = 0; h < 3; h++) logC_after[h] -= log(S->c[h][g]);
+    }
+#undef AS
+#undef LC
+    /* resample H given its class, rebuild everything (:1898-1934) */
+    {
+        const double probs07[3] = {0.5, 0.5 - ff * 0.5, ff * 0.5}, probs4[3] = {0.5, 0.5 - 0.5 * ff, 0};
+        const double probs5[3] = {0.5, 0, 0.5 * ff}, probs6[3] = {0, 0.5 - ff * 0.5, ff * 0.5};
+        for (int r = 0; r < R; r++) {
+            const int hc = S->H_class[r];
+            if (hc == 0 || hc == 7) S->H[r] = qo_sample3(probs07, runif_resample[r]);
+            else if (hc <= 3) S->H[r] = hc;
+            else if (hc == 4) S->H[r] = qo_sample3(probs4, runif_resample[r]);
+            else if (hc == 5) S->H[r] = qo_sample3(probs5, runif_resample[r]);
+            else S->H[r] = qo_sample3(probs6, runif_resample[r]);
+        }
+        for (int h = 0; h < 3; h++) for (size_t i = 0; i < (size_t)Ks * G; i++) S->eg[h][i] = 1;
+        for (int r = 0; r < R; r++) {
+            double *e = S->eg[S->H[r] - 1] + (size_t)Ks * S->wif[r];
+            const double *er = S->eMatRead + (size_t)Ks * r;
+            for (int k = 0; k < Ks; k++) e[k] *= er[k];
+        }
+        for (int h = 0; h < 3; h++) run_forward_haploid(S->alpha[h], S->c[h], S->eg[h], S->tm, Ks, G, 0);
+    }
+    /* re-run backward (:1939-1954): the QUILT_faster form overwrites the generic one's result */
+    for (int h = 0; h < 3; h++) {
+        double *b = S->beta[h] + (size_t)Ks * (G - 1);
+        for (int k = 0; k < Ks; k++) b[k] = S->c[h][G - 1];
+        run_backward_haploid_faster(S->beta[h], S->c[h], S->eg[h], S->tm, S->grid_has_read, Ks, G, eLocal);
+    }
+    (void)sum_H;
+    free(gs); free(alphaStore); free(log_cStore); free(eLocal);
+}
+
+/* rate2 of Rcpp_define_blocked_snps_using_gamma_on_the_fly (:347-363) */
+static void block_rate2(const sweep_t *S, double ff, double *rate2 /* G - 1 */)
+{
+    const int Ks = S->Ks, G = S->G;
+    for (int g = 0; g < G - 1; g++) rate2[g] = 0;
+    for (int h = 0; h < (ff > 0 ? 3 : 2); h++)
+        for (int g = 0; g < G - 2; g++) {
+            const double d = S->tm[2 * (size_t)g];
+            const double *a = S->alpha[h] + (size_t)Ks * g, *b = S->beta[h] + (size_t)Ks * (g + 1);
+            const double *e = S->eg[h] + (size_t)Ks * (g + 1);
+            double s = 0;
+            for (int k = 0; k < Ks; k++) s += a[k] * b[k] * e[k];
+            rate2[g] += 1 - d * s;
+        }
+}
+
 /* ---- rare + common SNPs: the final all-SNP Gibbs of QUILT2 (rare_common.R:109-420) ------------- */
 
 /* rare_per_snp_info (rare_common.R:313-322) for one which_haps_to_use: per all-SNP index the small-panel rows
@@ -848,8 +1301,19 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
         int to_block = 0;
         if (a->perform_block_gibbs)
             for (int i = 0; i < a->n_block_gibbs_iterations; i++) if (a->block_gibbs_iterations[i] == it) to_block = 1;
-        if (to_block) {
-            if (!(a->sample_is_diploid && ff == 0)) { status = -2; break; }
+        if (to_block && !(a->sample_is_diploid && ff == 0)) {
+            /* NIPT (gibbs-nipt.cpp:3003-3021): define the blocks from the current state, then the block resampler;
+             * do_shard_block_gibbs is FALSE for ff > 0 (functions.R:2552-2556) */
+            if (!a->L_grid || !a->runif_block || !a->runif_resample) { status = -2; break; }
+            double *rate2 = (double *)malloc(sizeof(double) * (size_t)(G > 1 ? G - 1 : 1));
+            int32_t *blocked = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
+            block_rate2(&S, ff, rate2);
+            qo_define_blocked_grids(rate2, a->L_grid, G, a->shuffle_bin_radius, a->block_gibbs_quantile_prob, blocked);
+            block_gibbs_resampler_nipt(&S, ff, blocked, a->runif_block + (size_t)shard_it * R,
+                                       a->runif_resample + (size_t)shard_it * R);
+            shard_it++;
+            free(rate2); free(blocked);
+        } else if (to_block) {
             /* diploid: Rcpp_block_gibbs_resampler is the identity (see header) */
             if (a->do_shard_block_gibbs) {
                 shard_block_gibbs_diploid(&S, a->runif_shard + (size_t)shard_it * (G - 1), work);

@@ -181,6 +181,8 @@ class _GibbsArgs(C.Structure):
         ("rescale_eMatRead_t", C.c_int), ("class_sum_cutoff", C.c_double),
         ("runif_reads", C.c_void_p), ("first_read", C.c_int), ("runif_shard", C.c_void_p),
         ("rc", C.c_void_p),
+        ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int), ("block_gibbs_quantile_prob", C.c_double),
+        ("runif_block", C.c_void_p), ("runif_resample", C.c_void_p),
     ]
 
 
@@ -249,12 +251,16 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
                              block_gibbs_iterations=(3, 6, 9), perform_block_gibbs=True,
                              gibbs_initialize_iteratively=False, sample_is_diploid=None,
                              disable_read_category_usage=False, maxDifferenceBetweenReads=1e10, Jmax=10000,
-                             class_sum_cutoff=0.06, use_eMatDH_special_symbols=None, rare_common=None):
+                             class_sum_cutoff=0.06, use_eMatDH_special_symbols=None, rare_common=None,
+                             runif_block=None, runif_resample=None, shuffle_bin_radius=5000,
+                             block_gibbs_quantile_prob=0.95, L_grid=None):
     """Oracle twin of ``rcpp_forwardBackwardGibbsNIPT`` (gibbs-nipt.cpp:2395-3307), production path.
 
     ``H``: starting labels (1-based); returns a dict holding the ending labels and every state
     matrix the reference mutates in place.  ``rare_common``: the all-SNP side of the panel for the final
     rare + common Gibbs (``make_eMatRead_t_rare_common = TRUE``); ``sample`` then holds the all-SNP reads.
+    NIPT (``ff`` > 0) with block Gibbs: ``runif_block`` / ``runif_resample`` hold ``len(block_gibbs_iterations) x
+    nReads`` uniforms (gibbs-nipt.cpp:3016; gibbs-nipt-block.cpp:226-243).
     """
     lib().qo_gibbs.restype = C.c_int
     which = np.ascontiguousarray(which_haps_to_use, dtype=np.int32)
@@ -277,7 +283,16 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
                       int(n_gibbs_sample_its), _p(blocks), len(blocks), int(perform_block_gibbs),
                       int(ff == 0), int(gibbs_initialize_iteratively), int(sample_is_diploid),
                       int(disable_read_category_usage), 1, float(class_sum_cutoff), _p(runif_reads),
-                      int(first_read), _p(runif_shard), C.cast(C.pointer(rs), C.c_void_p) if rs is not None else None)
+                      int(first_read), _p(runif_shard), C.cast(C.pointer(rs), C.c_void_p) if rs is not None else None,
+                      None, int(shuffle_bin_radius), float(block_gibbs_quantile_prob), None, None)
+    keep_nipt = None
+    if ff != 0 and perform_block_gibbs and len(blocks) and runif_block is not None:
+        Lg = np.ascontiguousarray(panel.L_grid if L_grid is None else L_grid, dtype=np.int32)
+        rb = np.ascontiguousarray(runif_block, dtype=np.float64)
+        rr_ = np.ascontiguousarray(runif_resample, dtype=np.float64)
+        assert rb.size >= len(blocks) * R and rr_.size >= len(blocks) * R and len(Lg) == G
+        keep_nipt = (Lg, rb, rr_)
+        args.L_grid, args.runif_block, args.runif_resample = Lg.ctypes.data, rb.ctypes.data, rr_.ctypes.data
     ps, keep = panel_struct(panel, use_eMatDH_special_symbols)
     Hout = np.array(H, dtype=np.int32).copy()
     Hc = np.zeros(R, dtype=np.int32)
@@ -307,4 +322,60 @@ def calculate_eMatRead_t_vs_haplotypes(sample, haps, maxDifferenceBetweenReads, 
     lib().qo_make_eMatRead_t_dense(_p(e), C.c_int(K), C.c_int(sample.nReads), _p(sample.read_ptr), _p(sample.u),
                                    _p(sample.bq), C.c_double(maxDifferenceBetweenReads), C.c_int(Jmax),
                                    C.c_int(int(rescale_eMatRead_t)), _p(out))
+    return out
+
+
+# ---- pieces of the NIPT block Gibbs (gibbs-nipt-block.cpp) with known answers / defining properties ----
+
+def simple_quantile(x, q):
+    lib().qo_simple_quantile.restype = C.c_double
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return float(lib().qo_simple_quantile(_p(x), C.c_int(len(x)), C.c_double(q)))
+
+
+def get_log_p_H_class2(n1, n2, n3, n4, n5, n6, ff):
+    lib().qo_get_log_p_H_class2.restype = C.c_double
+    return float(lib().qo_get_log_p_H_class2(*(C.c_int(int(v)) for v in (n1, n2, n3, n4, n5, n6)), C.c_double(ff)))
+
+
+def zero_based_swap(ir_chosen_0based):
+    out = (C.c_int * 8)()
+    lib().qo_zero_based_swap(C.c_int(ir_chosen_0based), out)
+    return np.array(list(out), dtype=np.int64)
+
+
+def sample3(probs, u):
+    lib().qo_sample3.restype = C.c_int
+    return int(lib().qo_sample3((C.c_double * 3)(*probs), C.c_double(u)))
+
+
+def make_smoothed_rate(sigma_rate, L_grid, shuffle_bin_radius):
+    L = np.ascontiguousarray(L_grid, dtype=np.int32)
+    r = np.ascontiguousarray(sigma_rate, dtype=np.float64)
+    out = np.zeros(len(L) - 1)
+    lib().qo_make_smoothed_rate(_p(r), _p(L), C.c_int(len(L)), C.c_int(shuffle_bin_radius), _p(out))
+    return out
+
+
+def define_blocked_grids(rate2, L_grid, shuffle_bin_radius=5000, block_gibbs_quantile_prob=0.95):
+    L = np.ascontiguousarray(L_grid, dtype=np.int32)
+    r = np.ascontiguousarray(rate2, dtype=np.float64)
+    out = np.zeros(len(L), dtype=np.int32)
+    lib().qo_define_blocked_grids(_p(r), _p(L), C.c_int(len(L)), C.c_int(shuffle_bin_radius),
+                                  C.c_double(block_gibbs_quantile_prob), _p(out))
+    return out
+
+
+def make_gibbs_considers(blocked_grid, wif0):
+    b = np.ascontiguousarray(blocked_grid, dtype=np.int32)
+    w = np.ascontiguousarray(wif0, dtype=np.int32)
+    G = len(b)
+    arrs = [np.zeros(G, dtype=np.int32) for _ in range(5)]
+    lib().qo_make_gibbs_considers.restype = C.c_int
+    n = lib().qo_make_gibbs_considers(_p(b), C.c_int(G), _p(w), C.c_int(len(w)), *[_p(a) for a in arrs])
+    names = ("consider_grid_start_0_based", "consider_grid_end_0_based", "consider_reads_start_0_based",
+             "consider_reads_end_0_based")
+    out = {k: a[:n].copy() for k, a in zip(names, arrs)}
+    out["consider_grid_where_0_based"] = arrs[4]
+    out["n_blocks"] = n
     return out

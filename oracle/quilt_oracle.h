@@ -160,7 +160,27 @@ typedef struct {
      * rare_common.R:109-420): the sampler then runs on rc->nGrids_all grids of rc->nSNPs_all SNPs, reads index
      * all SNPs, and hapProbs_t / genProbs*_t are 3 x rc->nSNPs_all. */
     const struct qo_rare_common *rc;
+    /* NIPT block Gibbs (ff > 0 with perform_block_gibbs): what Rcpp_define_blocked_snps_using_gamma_on_the_fly needs
+     * beyond the state (gibbs-nipt.cpp:3008), and the uniforms of every block pass (gibbs-nipt.cpp:3016,
+     * gibbs-nipt-block.cpp:226-243), n_block_gibbs_iterations x nReads each */
+    const int32_t *L_grid;
+    int shuffle_bin_radius;
+    double block_gibbs_quantile_prob;
+    const double *runif_block, *runif_resample;
 } qo_gibbs_args_t;
+
+/* pieces of the NIPT block Gibbs with known answers in the reference's tests (test-unit-gibbs-block-nipt.R) */
+double qo_simple_quantile(const double *x, int n, double q);
+void qo_make_smoothed_rate(const double *sigma_rate, const int32_t *L_grid, int nGrids, int shuffle_bin_radius,
+                           double *smoothed_rate);
+void qo_define_blocked_grids(const double *rate2, const int32_t *L_grid, int nGrids, int shuffle_bin_radius,
+                             double block_gibbs_quantile_prob, int32_t *blocked_grid);
+int qo_make_gibbs_considers(const int32_t *blocked_grid, int nGrids, const int32_t *wif0, int nReads,
+                            int32_t *grid_start, int32_t *grid_end, int32_t *reads_start, int32_t *reads_end,
+                            int32_t *grid_where);
+double qo_get_log_p_H_class2(int n1, int n2, int n3, int n4, int n5, int n6, double ff);
+void qo_zero_based_swap(int ir_chosen, int swap[8]);
+int qo_sample3(const double probs[3], double u);
 
 /* rcpp_forwardBackwardGibbsNIPT (gibbs-nipt.cpp:2395-3307), production argument values.
  * H (1-based labels) is updated in place; alphaHat_t/betaHat_t/eMatGrid_t are Ks x nGrids each,

@@ -150,3 +150,79 @@ def test_rare_common_restatement_matches_dense_expansion(small_panel):
         d = (gam[:, np.arange(rc.nSNPs_all) // 32] * eh).sum(axis=0)
         np.testing.assert_allclose(out["hapProbs_t"][h], d, rtol=1e-10, atol=1e-14)
     np.testing.assert_allclose(out["genProbsM_t"].sum(axis=0), 1.0, atol=1e-12)
+
+
+def test_nipt_block_pieces_known_answers():
+    """test-unit-gibbs-block-nipt.R:35-42 (H_class log-probability), :92-130 (label / class swap table), :132-138
+    (quantile), :238-304 (make_gibbs_considers: brute-force definition, no gaps, non-overlapping and spanning)."""
+    ln = np.log
+    assert O.get_log_p_H_class2(5, 10, 15, 20, 25, 30, 0.2) == pytest.approx(
+        5 * ln(.5) + 10 * ln(.4) + 15 * ln(.1) + 20 * ln(.9) + 25 * ln(.6) + 30 * ln(.5), rel=1e-14)
+    rx = np.array([[1, 2, 3], [1, 3, 2], [2, 1, 3], [3, 1, 2], [2, 3, 1], [3, 2, 1]])
+    for ir in range(6):
+        one_based_swap = np.r_[1, 1 + rx[ir], 8 - rx[ir][::-1], 8]
+        assert np.array_equal(O.zero_based_swap(ir), one_based_swap - 1)
+    rng = np.random.default_rng(7)
+    x = rng.random(1000)
+    assert O.simple_quantile(x, 0.90) == np.sort(x)[int(0.90 * 1000)]
+    # sample(1:3, 1, prob): mass in decreasing order, first cumulative mass >= u
+    assert [O.sample3((0.5, 0.4, 0.1), u) for u in (0.3, 0.5, 0.7, 0.95)] == [1, 1, 2, 3]
+    assert [O.sample3((0, 0.4, 0.1), u) for u in (0.3, 0.85)] == [2, 3]
+    for trial in range(30):
+        G = int(rng.integers(20, 80))
+        n_cut = int(rng.integers(1, 8))
+        cuts = np.sort(rng.choice(np.arange(1, G), size=n_cut, replace=False))
+        blocked = np.searchsorted(cuts, np.arange(G), side="right").astype(np.int32)
+        R = int(rng.integers(10, 200))
+        wif = np.sort(rng.integers(0, G, size=R)).astype(np.int32)
+        out = O.make_gibbs_considers(blocked, wif)
+        n = out["n_blocks"]
+        gs, ge = out["consider_grid_start_0_based"], out["consider_grid_end_0_based"]
+        rs, re_ = out["consider_reads_start_0_based"], out["consider_reads_end_0_based"]
+        n_blocks0 = blocked[-1] + 1
+        has = [np.isin(wif, np.arange(np.nonzero(blocked == b)[0][0], np.nonzero(blocked == b)[0][-1] + 1)) for b in range(n_blocks0)]
+        # grids: no gaps, span -- except that removing a read-less LAST block leaves the final grid out (:1476-1483:
+        # `x <- grid_end[last]; grid_end[s1 - 1] <- x - 1`), which the restatement keeps
+        last_removed = out["consider_reads_start_0_based"] is not None and not has[-1].any() and n < n_blocks0
+        assert gs[0] == 0 and np.all(gs[1:] - 1 == ge[:-1]) and ge[-1] == (G - 2 if last_removed else G - 1)
+        assert np.array_equal(np.nonzero(out["consider_grid_where_0_based"] >= 0)[0], ge)
+        if all(h.any() for h in has) and blocked[wif[-1]] == blocked[wif[-2]]:
+            # nothing removed: the brute-force definition (:238-262)
+            assert n == n_blocks0
+            for b in range(n):
+                w = np.nonzero(has[b])[0]
+                assert (rs[b], re_[b]) == (w[0], w[-1])
+            assert rs[0] == 0 and re_[-1] == R - 1 and np.all(rs[1:] - 1 == re_[:-1])   # reads: non-overlapping, span
+
+
+def test_nipt_block_gibbs_invariants(medium_panel):
+    """ff > 0 with the block resampler: the state left behind equals a from-scratch forward-backward given the labels
+    (Appendix B (12)), the smoothing is a weighted mean, block definitions cover the grids."""
+    from quilt_amd.synth import make_synthetic_sample
+    p = medium_panel
+    s = make_synthetic_sample(p, seed=3, n_reads=800, ff=0.2)
+    rng = np.random.default_rng(5)
+    which = np.sort(rng.choice(p.K, 100, replace=False)).astype(np.int32) + 1
+    R, G = s.nReads, p.nGrids
+    H0 = rng.choice([1, 2, 3], p=[0.5, 0.4, 0.1], size=R)
+    ru, rs = rng.random(R * 21), rng.random(3 * (G - 1))
+    rb, rr = rng.random(3 * R), rng.random(3 * R)
+    # stop right after the last block pass (sweeps 0..9, block passes after sweeps 3, 6 and 9)
+    out = O.forwardBackwardGibbsNIPT(p, s, which, H0, ru, 3, rs, ff=0.2, gibbs_initialize_iteratively=True,
+                                     n_gibbs_burn_in_its=9, runif_block=rb, runif_resample=rr)
+    assert out["status"] == 0 and set(np.unique(out["H"])) <= {1, 2, 3}
+    fresh = O.forwardBackwardGibbsNIPT(p, s, which, out["H"], ru, 0, rs, ff=0.2, n_gibbs_burn_in_its=0,
+                                       n_gibbs_sample_its=0, perform_block_gibbs=False)
+    for h in range(3):
+        np.testing.assert_allclose(out["eMatGrid_t"][h], fresh["eMatGrid_t"][h], rtol=1e-12)
+        np.testing.assert_allclose(out["alphaHat_t"][h], fresh["alphaHat_t"][h], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(out["betaHat_t"][h], fresh["betaHat_t"][h], rtol=1e-9, atol=1e-300)
+    without = O.forwardBackwardGibbsNIPT(p, s, which, H0, ru, 3, rs, ff=0.2, gibbs_initialize_iteratively=True,
+                                         n_gibbs_burn_in_its=9, perform_block_gibbs=False)
+    assert (without["H"] != out["H"]).any()          # the block passes do something
+    sm = O.make_smoothed_rate(np.full(G - 1, 0.3), p.L_grid, 5000)
+    np.testing.assert_allclose(sm, 0.3, rtol=1e-12)
+    rate = rng.random(G - 1) * 0.02
+    rate[[20, 21, 22, 60]] = 0.9
+    blocked = O.define_blocked_grids(rate, p.L_grid)
+    assert blocked[0] == 0 and np.all(np.diff(blocked) >= 0) and np.all(np.diff(blocked) <= 1) and blocked[-1] >= 1
