@@ -232,6 +232,12 @@ typedef struct {
     int32_t gibbs_initialize_iteratively;
     int32_t disable_read_category_usage;
     double class_sum_cutoff;
+    /* NIPT block Gibbs only (ff > 0 with perform_block_gibbs): what Rcpp_define_blocked_snps_using_gamma_on_the_fly
+     * takes beyond the state (QUILT/src/gibbs-nipt.cpp:3008): L_grid (nGrids grid positions, bp),
+     * shuffle_bin_radius (quilt.R:134, 5000), block_gibbs_quantile_prob (functions.R:2393, 0.95) */
+    const int32_t *L_grid;
+    int32_t shuffle_bin_radius;
+    double block_gibbs_quantile_prob;
 } qa_gibbs_opts_t;
 
 /*
@@ -249,7 +255,12 @@ typedef struct {
  *                             what `Rcpp::runif(nReads * n_gibbs_full_its)` returns (gibbs-nipt.cpp:2845)
  *   first_read                per chain `Rcpp::sample(nReads, 1) - 1` (gibbs-nipt.cpp:2846-2848)
  *   runif_shard               n_chain x n_block_gibbs_iterations x (nGrids - 1): the
- *                             `Rcpp::runif(n_blocks - 1)` of each shard pass (gibbs-nipt-block.cpp:2054)
+ *                             `Rcpp::runif(n_blocks - 1)` of each shard pass (gibbs-nipt-block.cpp:2054).
+ *                             NIPT (ff > 0; no shard pass there): the uniforms of the block passes instead -- per
+ *                             chain n_block_gibbs_iterations x 2 x R_c at offset read_off[c] * n_block_gibbs_iterations
+ *                             * 2: per pass R_c `runif_block` values (gibbs-nipt.cpp:3016; entry b decides block b),
+ *                             then one uniform per read for the reads whose class leaves a choice in
+ *                             rcpp_sample_H_using_H_class (gibbs-nipt-block.cpp:226-243)
  *   H                         in: starting read labels (double_list_of_starting_read_labels), 1-based;
  *                             out: ending labels (double_list_of_ending_read_labels)
  *   H_class                   out (may be NULL)
@@ -288,6 +299,16 @@ int qa_rcpp_make_eMatRead_t(qa_panel_t *panel, int32_t n_chain, int32_t K, const
                             const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
                             const int32_t *bq, double maxDifferenceBetweenReads, int32_t Jmax,
                             int32_t rescale_eMatRead_t, double *eMatRead_t);
+
+/*
+ * Host-side part of the NIPT block definition, exported for testing without a device: from rate2 (nGrids - 1 values,
+ * QUILT/src/gibbs-nipt-block.cpp:347-363) to blocked_grid (:366-523) and the block table of Rcpp_make_gibbs_considers
+ * (:1307-1553).  Output arrays need nGrids entries; *n_blocks receives the number of blocks.
+ */
+int qa_nipt_block_table(const double *rate2, const int32_t *L_grid, int32_t nGrids, int32_t shuffle_bin_radius,
+                        double block_gibbs_quantile_prob, const int32_t *wif0, int32_t nReads, int32_t *blocked_grid,
+                        int32_t *grid_start, int32_t *grid_end, int32_t *reads_start, int32_t *reads_end,
+                        int32_t *grid_where, int32_t *n_blocks);
 
 /* As qa_rcpp_make_eMatRead_t with eHapsCurrent_tc of nSNPs columns rather than the panel's: the all-SNP read
  * likelihoods of get_initial_read_labels (QUILT/R/rare_common.R:61-107). */

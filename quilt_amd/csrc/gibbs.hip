@@ -33,6 +33,7 @@
 #include "panel.hpp"
 
 #include <chrono>
+#include <functional>
 #include <thread>
 
 #include <algorithm>
@@ -41,10 +42,13 @@
 #include <memory>
 
 #include "gibbs_dev.hpp"
+#include "gibbs_blocks.hpp"
 
 namespace qa {
 int gibbs3_waves(int Ksp);
 void launch_gibbs3(const void *gibbs_params, hipStream_t st);
+void launch_block_rate3(const void *gibbs_params, hipStream_t st);
+void launch_block3(const void *gibbs_params, hipStream_t st);
 }
 
 namespace {
@@ -819,6 +823,8 @@ struct GibbsScratch {
     DBuf<size_t> eread_off;
     DBuf<uint64_t> seeds;
     DBuf<uint32_t> rc_any;
+    DBuf<double> blk_rate2;
+    DBuf<int32_t> blk_where, blk_tab, blk_n;
 };
 
 }  // namespace qa
@@ -894,7 +900,8 @@ int choose_gibbs_waves(int Ksp, int C, int share) {
     return nw;
 }
 
-void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs, int nw) {
+void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs, int nw,
+                  const std::function<void()> &nipt_sweeps) {
     const int NE1 = prm.Ksp / 64;   // rows per lane with one wave
     QA_HIP(hipEventRecord(ev[0], st));
     switch (NE1) {
@@ -919,7 +926,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
     }
     QA_HIP(hipEventRecord(ev[1], st));
     if (prm.nH == 3) {
-        qa::launch_gibbs3(&prm, st);   // three-label sampler (NIPT), gibbs3.hip
+        nipt_sweeps();   // three-label sampler (NIPT) with its block passes: gibbs3.hip, driven from gibbs_chunk
     } else if (NE1 == 10) {
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
         else if (nw == 5) launch_gibbs_kernel<2, 5>(prm, st);
@@ -1085,10 +1092,13 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
             S.seeds.upload(seed_reads, C, st);
             qa::staged_upload(S.seeds.p + C, seed_shard ? seed_shard : seed_reads, sizeof(uint64_t) * C, st);
         }
-        const size_t nshard = (size_t)C * std::max(o->n_block_gibbs_iterations, 1) * std::max(G - 1, 1);
-        S.runif_shard.ensure(nshard);
-        if (runif_shard && !seed_shard && o->n_block_gibbs_iterations > 0)
-            S.runif_shard.upload(runif_shard, (size_t)C * o->n_block_gibbs_iterations * (G - 1), st);
+        // diploid: the shard passes' uniforms; NIPT: the block passes' (include/quilt_amd.h)
+        const bool nipt = o->ff != 0.0;
+        const size_t nshard_used = nipt ? (size_t)totR * o->n_block_gibbs_iterations * 2
+                                        : (size_t)C * o->n_block_gibbs_iterations * (G - 1);
+        S.runif_shard.ensure(std::max<size_t>(nshard_used, 1));
+        if (runif_shard && !seed_shard && o->n_block_gibbs_iterations > 0 && (!nipt || o->perform_block_gibbs))
+            S.runif_shard.upload(runif_shard, nshard_used, st);
         S.eread_off.ensure(C); S.eread_off.upload(eoff.data(), C, st);
         S.eMatRead.ensure(std::max<size_t>(etot, 1));
         S.eridx_off.ensure(C); S.eridx_off.upload(ixoff.data(), C, st);
@@ -1122,6 +1132,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         prm.disable_read_category_usage = o->disable_read_category_usage;
         prm.class_sum_cutoff = o->class_sum_cutoff;
         prm.nH = nH;
+        prm.it_begin = 0; prm.it_end = n_its;
         {   // prior over labels and the read-label class prototypes (gibbs-nipt.cpp:2707-2729)
             const double ff = o->ff, pp[3] = {0.5, (1 - ff) * 0.5, ff * 0.5};
             const double r[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1},
@@ -1151,7 +1162,68 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
         QA_HIP(hipStreamSynchronize(st));
         const double T2 = now();
-        launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs, nw);
+        // NIPT: the sweeps are cut at the block-Gibbs iterations; between two segments the switch rate per grid boundary
+        // comes back to the host, which defines the blocks (scalar logic per chain, gibbs_blocks.hpp) for the block kernel
+        auto nipt_sweeps = [&]() {
+            GibbsParams q = prm;
+            q.ff = o->ff;
+            q.blk_n_pass = std::max(o->n_block_gibbs_iterations, 1);
+            std::vector<int> passes;
+            if (o->perform_block_gibbs)
+                for (int i = 0; i < o->n_block_gibbs_iterations; i++) {
+                    const int b = o->block_gibbs_iterations[i];
+                    if (b >= 0 && b < n_its && std::find(passes.begin(), passes.end(), b) == passes.end()) passes.push_back(b);
+                }
+            std::sort(passes.begin(), passes.end());
+            if (!passes.empty()) {
+                S.blk_rate2.ensure((size_t)C * G); S.blk_where.ensure((size_t)C * G);
+                S.blk_tab.ensure((size_t)C * 4 * G); S.blk_n.ensure(C);
+                q.blk_rate2 = S.blk_rate2.p; q.blk_where = S.blk_where.p; q.blk_tab = S.blk_tab.p; q.blk_n = S.blk_n.p;
+            }
+            std::vector<double> rate2;
+            std::vector<int32_t> h_where, h_tab, h_n;
+            int it0 = 0;
+            for (size_t j = 0; j < passes.size(); j++) {
+                q.it_begin = it0; q.it_end = passes[j] + 1;
+                qa::launch_gibbs3(&q, st);
+                qa::launch_block_rate3(&q, st);
+                rate2.resize((size_t)C * G);
+                S.blk_rate2.download(rate2.data(), rate2.size(), st);
+                QA_HIP(hipStreamSynchronize(st));
+                h_where.assign((size_t)C * G, -1); h_tab.assign((size_t)C * 4 * G, 0); h_n.assign(C, 0);
+                const int n_thr = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), C}));
+                auto work = [&](int tid) {
+                    for (int c = tid; c < C; c += n_thr) {
+                        const int R = read_off[c + 1] - read_off[c];
+                        const std::vector<int32_t> blocked = qa::define_blocked_grids(
+                            rate2.data() + (size_t)c * G, o->L_grid, G, o->shuffle_bin_radius, o->block_gibbs_quantile_prob);
+                        const qa::BlockTable T = qa::make_gibbs_considers(blocked, wif + read_off[c], R);
+                        h_n[c] = T.n_blocks;
+                        std::copy(T.grid_where.begin(), T.grid_where.end(), h_where.begin() + (size_t)c * G);
+                        int32_t *tb = h_tab.data() + (size_t)c * 4 * G;
+                        for (int b = 0; b < T.n_blocks; b++) {
+                            tb[b] = T.grid_start[b]; tb[G + b] = T.grid_end[b];
+                            tb[2 * G + b] = T.reads_start[b]; tb[3 * G + b] = T.reads_end[b];
+                        }
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
+                work(0);
+                for (auto &t : th) t.join();
+                S.blk_where.upload(h_where.data(), h_where.size(), st);
+                S.blk_tab.upload(h_tab.data(), h_tab.size(), st);
+                S.blk_n.upload(h_n.data(), h_n.size(), st);
+                q.blk_pass = (int)j;
+                qa::launch_block3(&q, st);
+                it0 = passes[j] + 1;
+            }
+            if (passes.empty() || it0 < n_its) {
+                q.it_begin = it0; q.it_end = n_its;
+                qa::launch_gibbs3(&q, st);
+            }
+        };
+        launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs, nw, nipt_sweeps);
         S.H.download(H, totR, st);
         if (H_class) S.H_class.download(H_class, totR, st);
         std::vector<int32_t> status(C);
@@ -1223,10 +1295,12 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
         qa::set_error("qa_gibbs_batch: ff > 0 goes with sample_is_diploid = 0 (NIPT), ff = 0 with sample_is_diploid = 1");
         return QA_ERR_INVALID;
     }
-    if (o->ff != 0.0 && o->perform_block_gibbs && o->n_block_gibbs_iterations > 0) {
-        qa::set_error("qa_gibbs_batch: the NIPT block Gibbs resampler (gibbs-nipt-block.cpp:1636-1967) is not built yet; "
-                      "call with perform_block_gibbs = 0 for ff > 0");
-        return QA_ERR_UNSUPPORTED;
+    if (o->ff != 0.0 && o->perform_block_gibbs && o->n_block_gibbs_iterations > 0 &&
+        (!o->L_grid || o->shuffle_bin_radius <= 0 || !(o->block_gibbs_quantile_prob > 0 && o->block_gibbs_quantile_prob < 1) ||
+         (!runif_shard && !seed_shard && !seed_reads))) {
+        qa::set_error("qa_gibbs_batch: the NIPT block Gibbs needs opts->L_grid, shuffle_bin_radius, block_gibbs_quantile_prob "
+                      "and the block passes' uniforms (runif_shard or seeds)");
+        return QA_ERR_INVALID;
     }
     if (o->Ks <= 0 || o->Ks > 1024) {
         qa::set_error("qa_gibbs_batch: Ksubset = %d outside 1..1024", o->Ks);
@@ -1269,7 +1343,8 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
                 pn, rc, o, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
                 u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
                 runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
-                runif_shard ? runif_shard + (size_t)c0 * nb * (G - 1) : nullptr, H + read_off[c0],
+                runif_shard ? runif_shard + (o->ff != 0.0 ? (size_t)read_off[c0] * nb * 2 : (size_t)c0 * nb * (G - 1)) : nullptr,
+                H + read_off[c0],
                 H_class ? H_class + read_off[c0] : nullptr, hapProbs_t ? hapProbs_t + (size_t)c0 * T * 3 : nullptr,
                 genProbsM_t ? genProbsM_t + (size_t)c0 * T * 3 : nullptr, genProbsF_t ? genProbsF_t + (size_t)c0 * T * 3 : nullptr,
                 underflow_problem ? underflow_problem + c0 : nullptr, state_out, seed_reads ? seed_reads + c0 : nullptr,
@@ -1354,6 +1429,29 @@ int qa_rare_common_create(qa_panel_t *pn, int32_t nSNPs_all, const uint8_t *snp_
 }
 
 void qa_rare_common_destroy(qa_rare_common_t *rc) { delete rc; }
+
+int qa_nipt_block_table(const double *rate2, const int32_t *L_grid, int32_t nGrids, int32_t shuffle_bin_radius,
+                        double block_gibbs_quantile_prob, const int32_t *wif0, int32_t nReads, int32_t *blocked_grid,
+                        int32_t *grid_start, int32_t *grid_end, int32_t *reads_start, int32_t *reads_end,
+                        int32_t *grid_where, int32_t *n_blocks) {
+    if (!rate2 || !L_grid || nGrids < 2 || !wif0 || nReads < 1 || !blocked_grid || !grid_start || !grid_end || !reads_start ||
+        !reads_end || !grid_where || !n_blocks) {
+        qa::set_error("qa_nipt_block_table: bad argument");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        const std::vector<int32_t> blocked = qa::define_blocked_grids(rate2, L_grid, nGrids, shuffle_bin_radius, block_gibbs_quantile_prob);
+        const qa::BlockTable T = qa::make_gibbs_considers(blocked, wif0, nReads);
+        std::copy(blocked.begin(), blocked.end(), blocked_grid);
+        std::copy(T.grid_where.begin(), T.grid_where.end(), grid_where);
+        for (int b = 0; b < T.n_blocks; b++) {
+            grid_start[b] = T.grid_start[b]; grid_end[b] = T.grid_end[b];
+            reads_start[b] = T.reads_start[b]; reads_end[b] = T.reads_end[b];
+        }
+        *n_blocks = T.n_blocks;
+        return (int)QA_OK;
+    });
+}
 
 int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
                                   const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
     auto uni_d = [](const double *q) { return rl_f64(*q, 0); };
     auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
+    int status = 0;
+    if (p.it_begin > 0) {   // a later segment of the call: the state is in HBM, a chain that underflowed stays stopped
+        status = uni_i(p.status[c]);
+    } else {
     // ---- c = 0 (arma::zeros, :2676-2678), H_class = 0, eMatGrid = 1
     for (int h = 0; h < 3; h++)
         for (int g = t; g < G; g += NT) ch.cv[h][g] = 0.0;
@@ -55,6 +59,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
         for (int h = 0; h < NH; h++)
             for (int g = 0; g < G; g++) ch.st(one, ch.eg[h] + (size_t)g * Ksp);
     }
+    }   // first segment
     chain_sync<NW>();
 
     // forward over all grids for every label (Rcpp_run_forward_haploid, copied-from-stitch.cpp:340-387)
@@ -128,7 +133,9 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
     };
 
     // ---- rcpp_gibbs_nipt_initialize (:1629-1750)
-    if (!init_iteratively) {
+    if (p.it_begin > 0) {
+        // (nothing to initialise)
+    } else if (!init_iteratively) {
         int r = 0;
         while (r < R) {   // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281): reads are sorted by grid
             const int g = uni_i(ch.wif[r]);
@@ -181,8 +188,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
     }
     chain_sync<NW>();
 
-    int status = 0;
-    for (int it = 0; it < p.n_its && status == 0; it++) {
+    for (int it = p.it_begin; it < p.it_end && status == 0; it++) {
         // ================= rcpp_gibbs_nipt_iterate (:1756-1956) =================
         Col<NE> a[NH];
         int iRead = 0;
@@ -375,6 +381,429 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
     if (t == 0) p.status[c] = status;
 }
 
+// ---------------------------------------------------------------------------------------------
+// NIPT block Gibbs (gibbs-nipt-block.cpp), between two segments of sweeps.
+//   k_block_rate3   rate2 of Rcpp_define_blocked_snps_using_gamma_on_the_fly (:347-363): per grid boundary
+//                   sum over labels of 1 - sigma * sum_k alpha(k, g) beta(k, g + 1) eMatGrid(k, g + 1).
+//                   The smoothing / quantile / peak picking that turns it into blocks, and make_gibbs_considers, are
+//                   scalar integer logic per chain and run on the host (gibbs.hip), as they run in R-facing C++.
+//   k_block3        Rcpp_block_gibbs_resampler (:1636-1967), block_approach = 6: the forward recursion of all six
+//                   relabellings (18 columns in registers), at every block end the choice among them
+//                   (Rcpp_consider_block_relabelling, :590-949), the rebuild of the block under the chosen relabelling,
+//                   then labels re-drawn from their classes (rcpp_sample_H_using_H_class, :213-246), eMatGrid, forward
+//                   and backward redone.  One workgroup per chain, like the sampler.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_block_rate3(GibbsParams p) {
+    const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    const int G = p.G, Ksp = p.Ksp, Ks = p.Ks;
+    if (g >= G - 1) return;
+    double out = 0;
+    if (g < G - 2) {
+        const size_t mat = (size_t)G * Ksp;
+        const double d = p.sigma[g];
+        for (int h = 0; h < p.nH; h++) {
+            const double *a = p.alpha + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
+            const double *b = p.beta + ((size_t)c * p.nH + h) * mat + (size_t)(g + 1) * Ksp;
+            const double *e = p.eg + ((size_t)c * p.nH + h) * mat + (size_t)(g + 1) * Ksp;
+            double s = 0;
+            for (int k = lane; k < Ks; k += 64) s += a[k] * b[k] * e[k];
+            s = wsum(s);
+            out += 1 - d * s;
+        }
+    }
+    if (lane == 0) p.blk_rate2[(size_t)c * G + g] = out;
+}
+
+__device__ __forceinline__ void block_sync() {
+    __threadfence_block();
+    __syncthreads();
+}
+
+// Rcpp::sample(1:3, 1, FALSE, probs) from its one uniform (Rcpp sugar: mass normalised, decreasing order, first
+// cumulative mass >= u)
+__device__ inline int sample3(double p0, double p1, double p2, double u) {
+    double p[3] = {p0, p1, p2};
+    int perm[3] = {1, 2, 3};
+    const double sum = p[0] + p[1] + p[2];
+    for (int i = 0; i < 3; i++) p[i] /= sum;
+    for (int i = 1; i < 3; i++) {
+        const double v = p[i];
+        const int q = perm[i];
+        int j = i - 1;
+        while (j >= 0 && p[j] < v) { p[j + 1] = p[j]; perm[j + 1] = perm[j]; j--; }
+        p[j + 1] = v; perm[j + 1] = q;
+    }
+    p[1] += p[0];
+    if (u <= p[0]) return perm[0];
+    if (u <= p[1]) return perm[1];
+    return perm[2];
+}
+
+__device__ inline double log_p_H_class2(const int (&n)[6], double ff) {   // rcpp_get_log_p_H_class2 (:170-207), 0 < ff < 1
+    return 0 + n[0] * log(0.5) + n[1] * log(0.5 - ff * 0.5) + n[2] * log(ff * 0.5) + n[3] * log(1 - ff * 0.5) +
+           n[4] * log(1 * 0.5 + ff * 0.5) + n[5] * log(1 * 0.5);
+}
+
+template <int NE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
+    __shared__ double s_red[2 * NW * 4];
+    const int c = blockIdx.x, t = threadIdx.x;
+    using CH = Chain<NE, NW>;
+    CH ch(p, c, t, s_red);
+    constexpr int NT = CH::NT;
+    constexpr int NH = 3;
+    constexpr int RR[6][3] = {{1, 2, 3}, {1, 3, 2}, {2, 1, 3}, {2, 3, 1}, {3, 1, 2}, {3, 2, 1}};   // :1755-1761
+    constexpr int RX[6][3] = {{1, 2, 3}, {1, 3, 2}, {2, 1, 3}, {3, 1, 2}, {2, 3, 1}, {3, 2, 1}};   // :752-758
+    const int G = ch.G, Ksp = ch.Ksp, R = ch.R, Ks = ch.Ks;
+    const double prior = ch.prior, one_over_K = 1 / (double)Ks, ff = p.ff;
+    bool (&valid)[NE] = ch.valid;
+    if (__builtin_amdgcn_readfirstlane(p.status[c]) != 0) return;   // the chain underflowed: the caller retries it
+    auto uni_d = [](const double *q) { return rl_f64(*q, 0); };
+    auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int32_t *where = p.blk_where + (size_t)c * G;
+    const int32_t *tab = p.blk_tab + (size_t)c * 4 * G;
+    const int n_blocks = uni_i(p.blk_n[c]);
+    // the pass's uniforms: explicit (runif_shard doubles as [n_pass][2][R]: block choice, then label re-draw) or streams
+    const double *ru = p.seed_shard ? nullptr : p.runif_shard + ((size_t)p.read_off[c] * p.blk_n_pass + (size_t)p.blk_pass * R) * 2;
+    const uint64_t seed = p.seed_shard ? p.seed_shard[c] : 0;
+    auto u_block = [&](int i) { return ru ? ru[i] : stream_uniform(seed, (uint64_t)p.blk_pass * 2 * R + i); };
+    auto u_draw = [&](int r) { return ru ? ru[R + r] : stream_uniform(seed, (uint64_t)p.blk_pass * 2 * R + R + r); };
+    auto emission_of = [&](Col<NE> &er, int r) {
+        typename CH::ErPre x;
+        ch.ld_pre(x, r);
+        ch.read_emission(er, x, uni_i(ch.dense_of[r]));
+    };
+    auto sum3 = [&](const Col<NE> (&x)[NH], double (&s)[NH]) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            s[h] = 0;
+#pragma unroll
+            for (int i = 0; i < NE; i++) s[h] += x[h].v[i];
+        }
+        ch.template bsum<NH>(s);
+    };
+
+    Col<NE> aS[6][3];          // alphaStore
+    double inside[6][3];       // sum of log_cStore over the current block, in grid order
+    double logC_before[3] = {0, 0, 0}, logC_after[3];
+    {
+        double s[3] = {0, 0, 0};
+        for (int g = t; g < G; g += NT)
+#pragma unroll
+            for (int h = 0; h < 3; h++) s[h] += log(ch.cv[h][g]);
+        ch.template bsum<3>(s);
+#pragma unroll
+        for (int h = 0; h < 3; h++) logC_after[h] = s[h];
+    }
+#pragma unroll
+    for (int ir = 0; ir < 6; ir++)
+#pragma unroll
+        for (int h = 0; h < 3; h++) inside[ir][h] = 0;
+    bool ever_changed = false;
+
+    for (int g = 0; g < G; g++) {
+        Col<NE> e[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
+        const double t0 = g > 0 ? ch.tm0(g - 1) : 1.0, t1 = g > 0 ? ch.tm1(g - 1) : 0.0;
+        // ---- Rcpp_gibbs_block_forward_one (:1122-1253)
+#pragma unroll
+        for (int ir = 0; ir < 6; ir++) {
+            Col<NE> nx[NH];   // indexed by the slot h = rr0(ir, i)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int h = RR[ir][i] - 1;
+#pragma unroll
+                for (int q = 0; q < NE; q++) {
+                    if (g == 0) nx[h].v[q] = valid[q] ? prior * e[i].v[q] : 0.0;
+                    else nx[h].v[q] = valid[q] ? e[i].v[q] * (t0 * aS[ir][h].v[q] + t1 * one_over_K) : 0.0;
+                }
+            }
+            double sm[NH];
+            sum3(nx, sm);
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+                const double d = 1 / sm[h];
+                inside[ir][h] += log(d);
+#pragma unroll
+                for (int q = 0; q < NE; q++) aS[ir][h].v[q] = d * nx[h].v[q];
+            }
+        }
+        const int iBlock = uni_i(where[g]);
+        if (iBlock > -1) {
+            const int grid_start = uni_i(tab[iBlock]), grid_end = uni_i(tab[G + iBlock]);
+            const int read_start = uni_i(tab[2 * G + iBlock]), read_end = uni_i(tab[3 * G + iBlock]);
+            // ---- Rcpp_consider_block_relabelling: probability of the panel side of each relabelling
+            Col<NE> bt[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + (size_t)g * Ksp);
+            double P[6];
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++) {
+                double dot[3] = {0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int q = 0; q < NE; q++) dot[i] += aS[ir][i].v[q] * bt[i].v[q];
+                ch.template bsum<3>(dot);
+                P[ir] = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    P[ir] += log(dot[i]) + -logC_before[i] + -inside[ir][i] + -logC_after[i];
+            }
+            // ... and of the read classes under it (rcpp_calculate_block_read_label_probabilities_using_H_class)
+            int ns[8];
+            {
+                double cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int r = read_start + t; r <= read_end; r += NT) {
+                    const int hc = ch.Hc[r];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) cnt[q] += (hc == q) ? 1.0 : 0.0;
+                }
+                double a4[4] = {cnt[0], cnt[1], cnt[2], cnt[3]}, b4[4] = {cnt[4], cnt[5], cnt[6], cnt[7]};
+                ch.template bsum<4>(a4);
+                ch.template bsum<4>(b4);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { ns[q] = (int)a4[q]; ns[4 + q] = (int)b4[q]; }
+            }
+            double clp[6], cp[6];
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++) {
+                const int n6[6] = {ns[RR[ir][0]], ns[RR[ir][1]], ns[RR[ir][2]], ns[7 - RR[ir][2]], ns[7 - RR[ir][1]], ns[7 - RR[ir][0]]};
+                clp[ir] = log_p_H_class2(n6, ff) + P[ir];
+            }
+            double mx = clp[0];
+#pragma unroll
+            for (int ir = 1; ir < 6; ir++) mx = clp[ir] > mx ? clp[ir] : mx;
+            double tot = 0;
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++) {
+                clp[ir] += -mx;
+                if (clp[ir] < -100) clp[ir] = -100;
+                cp[ir] = exp(clp[ir]);
+                tot += cp[ir];
+            }
+            const double dn = 1 / tot;
+            const double chance = rl_f64(u_block(iBlock), 0);
+            int ir_chosen = 0;
+            {
+                double cum[6];
+                cum[0] = cp[0] * dn;
+#pragma unroll
+                for (int ir = 1; ir < 6; ir++) cum[ir] = cp[ir] * dn + cum[ir - 1];
+#pragma unroll
+                for (int ir = 5; ir >= 0; ir--) if (chance < cum[ir]) ir_chosen = ir;
+            }
+            ir_chosen = uni_i(ir_chosen);
+            int swp[8];
+            swp[0] = 0; swp[7] = 7;
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                if (q == ir_chosen) {
+                    swp[1] = RX[q][0]; swp[2] = RX[q][1]; swp[3] = RX[q][2];
+                    swp[4] = 7 - RX[q][2]; swp[5] = 7 - RX[q][1]; swp[6] = 7 - RX[q][0];
+                }
+            auto swap_of = [&](int v) {   // swp[v] without dynamic register indexing
+                int o = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) o = (v == q) ? swp[q] : o;
+                return o;
+            };
+            Col<NE> al[NH];   // alpha at g after the block (for the reset)
+            bool have_al = false;
+            if (ever_changed || ir_chosen != 0) {
+                ever_changed = true;
+                // rebuild eMatGrid, alpha, c of the block's grids under the relabelling (:846-912), reads walked by grid
+                int iRead = read_start;
+                int wif_read = uni_i(ch.wif[iRead]);
+                if (grid_start > 0) {
+#pragma unroll
+                    for (int h = 0; h < NH; h++) ch.ld(al[h], ch.alpha[h] + (size_t)(grid_start - 1) * Ksp);
+                }
+                for (int g2 = grid_start; g2 <= grid_end; g2++) {
+                    Col<NE> el[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; h++)
+#pragma unroll
+                        for (int q = 0; q < NE; q++) el[h].v[q] = 1.0;
+                    while ((iRead <= (R - 1)) & (wif_read < g2)) {
+                        iRead += 1;
+                        if (iRead < (R - 1)) wif_read = uni_i(ch.wif[iRead]);
+                    }
+                    while ((iRead <= (R - 1)) & (wif_read == g2)) {
+                        const int hh = swap_of(uni_i(ch.H[iRead])) - 1;
+                        Col<NE> er;
+                        emission_of(er, iRead);
+#pragma unroll
+                        for (int h = 0; h < NH; h++)
+                            if (hh == h) {
+#pragma unroll
+                                for (int q = 0; q < NE; q++) el[h].v[q] *= er.v[q];
+                            }
+                        iRead += 1;
+                        if (iRead <= (R - 1)) wif_read = uni_i(ch.wif[iRead]);
+                    }
+                    const double s0 = g2 > 0 ? ch.tm0(g2 - 1) : 1.0, s1 = g2 > 0 ? ch.tm1(g2 - 1) : 0.0;
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        ch.st(el[h], ch.eg[h] + (size_t)g2 * Ksp);
+#pragma unroll
+                        for (int q = 0; q < NE; q++) {
+                            if (g2 == 0) al[h].v[q] = valid[q] ? prior * el[h].v[q] : 0.0;
+                            else al[h].v[q] = valid[q] ? el[h].v[q] * (s0 * al[h].v[q] + s1 * prior) : 0.0;
+                        }
+                    }
+                    double sm[NH];
+                    sum3(al, sm);
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        const double cc = 1 / sm[h];
+#pragma unroll
+                        for (int q = 0; q < NE; q++) al[h].v[q] *= cc;
+                        ch.st(al[h], ch.alpha[h] + (size_t)g2 * Ksp);
+                        if (t == 0) ch.cv[h][g2] = cc;
+                    }
+                }
+                have_al = grid_end == g;
+                block_sync();   // every wave is done reading the old labels
+                for (int r = read_start + t; r <= read_end; r += NT) {
+                    ch.H[r] = swap_of(ch.H[r]);
+                    ch.Hc[r] = swap_of(ch.Hc[r]);
+                }
+                block_sync();
+            }
+            // Rcpp_reset_local_variables (:1257-1292)
+            if ((iBlock + 1) < n_blocks) {
+                if (!have_al) {
+#pragma unroll
+                    for (int h = 0; h < NH; h++) ch.ld(al[h], ch.alpha[h] + (size_t)g * Ksp);
+                }
+#pragma unroll
+                for (int ir = 0; ir < 6; ir++)
+#pragma unroll
+                    for (int h = 0; h < 3; h++) aS[ir][h] = al[h];
+            }
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++)
+#pragma unroll
+                for (int h = 0; h < 3; h++) inside[ir][h] = 0;
+            for (int g2 = grid_start; g2 <= grid_end; g2++)
+#pragma unroll
+                for (int h = 0; h < 3; h++) logC_before[h] += log(uni_d(&ch.cv[h][g2]));
+        }
+#pragma unroll
+        for (int h = 0; h < 3; h++) logC_after[h] -= log(uni_d(&ch.cv[h][g]));
+    }
+    block_sync();
+    // ---- rcpp_sample_H_using_H_class (:213-246), then eMatGrid, forward and backward from scratch (:1898-1954)
+    for (int r = t; r < R; r += NT) {
+        const int hc = ch.Hc[r];
+        int hn;
+        if (hc >= 1 && hc <= 3) hn = hc;
+        else {
+            const double u = u_draw(r);
+            if (hc == 0 || hc == 7) hn = sample3(0.5, 0.5 - ff * 0.5, ff * 0.5, u);
+            else if (hc == 4) hn = sample3(0.5, 0.5 - 0.5 * ff, 0, u);
+            else if (hc == 5) hn = sample3(0.5, 0, 0.5 * ff, u);
+            else hn = sample3(0, 0.5 - ff * 0.5, ff * 0.5, u);
+        }
+        ch.H[r] = hn;
+    }
+    block_sync();
+    {
+        int r = 0;
+        for (int g = 0; g < G; g++) {   // rcpp_make_eMatGrid_t: reads are sorted by grid
+            Col<NE> el[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++)
+#pragma unroll
+                for (int q = 0; q < NE; q++) el[h].v[q] = 1.0;
+            while (r < R && uni_i(ch.wif[r]) == g) {
+                Col<NE> er;
+                emission_of(er, r);
+                const int hh = uni_i(ch.H[r]) - 1;
+#pragma unroll
+                for (int h = 0; h < NH; h++)
+                    if (hh == h) {
+#pragma unroll
+                        for (int q = 0; q < NE; q++) el[h].v[q] *= er.v[q];
+                    }
+                r++;
+            }
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.st(el[h], ch.eg[h] + (size_t)g * Ksp);
+        }
+    }
+    {   // Rcpp_run_forward_haploid
+        Col<NE> a[NH], e[NH];
+        for (int g = 0; g < G; g++) {
+            const double s0 = g > 0 ? ch.tm0(g - 1) : 1.0, s1 = g > 0 ? ch.tm1(g - 1) : 0.0;
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
+#pragma unroll
+                for (int q = 0; q < NE; q++) {
+                    if (g == 0) a[h].v[q] = valid[q] ? prior * e[h].v[q] : 0.0;
+                    else a[h].v[q] = valid[q] ? e[h].v[q] * (s0 * a[h].v[q] + s1 * prior) : 0.0;
+                }
+            }
+            double sm[NH];
+            sum3(a, sm);
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                const double cc = 1 / sm[h];
+#pragma unroll
+                for (int q = 0; q < NE; q++) a[h].v[q] = a[h].v[q] * cc;
+                ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+                if (t == 0) ch.cv[h][g] = cc;
+            }
+        }
+    }
+    block_sync();
+    {   // the backward pass that stays: Rcpp_run_backward_haploid_QUILT_faster from beta(G - 1) = c(G - 1) (:1939-1954)
+        Col<NE> b[NH], e[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const double cl = uni_d(&ch.cv[h][G - 1]);
+#pragma unroll
+            for (int q = 0; q < NE; q++) b[h].v[q] = valid[q] ? cl : 0.0;
+            ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
+        }
+        for (int g = G - 2; g >= 0; --g) {
+            const double s0 = ch.tm0(g), s1 = ch.tm1(g);
+            const bool has = uni_i(ch.ghr[g + 1]) != 0;
+            double x[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                ch.ld(e[h], ch.eg[h] + (size_t)(g + 1) * Ksp);
+                x[h] = 0;
+#pragma unroll
+                for (int q = 0; q < NE; q++) {
+                    if (has) b[h].v[q] = e[h].v[q] * b[h].v[q];
+                    x[h] += b[h].v[q];
+                }
+            }
+            ch.template bsum<NH>(x);
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                const double cg = uni_d(&ch.cv[h][g]);
+                const double xx = s1 * x[h] * one_over_K;
+#pragma unroll
+                for (int q = 0; q < NE; q++) b[h].v[q] = valid[q] ? cg * (xx + s0 * b[h].v[q]) : 0.0;
+                ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
+            }
+        }
+    }
+}
+
+template <int NE, int NW>
+void launch_block(const GibbsParams &prm, hipStream_t st) {
+    hipLaunchKernelGGL((k_block3<NE, NW>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
+    QA_HIP(hipGetLastError());
+}
+
 template <int NE, int NW>
 void launch_one(const GibbsParams &prm, hipStream_t st) {
     hipLaunchKernelGGL((k_gibbs3<NE, NW>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
@@ -400,6 +829,27 @@ void launch_gibbs3(const void *params, hipStream_t st) {
         case 8: launch_one<8, 1>(prm, st); break;
         case 10: launch_one<5, 2>(prm, st); break;
         default: throw std::runtime_error("NIPT sampler: Ksubset geometry not built (Ksubset / 64 rounded up must be 1..6, 8 or 10)");
+    }
+}
+
+void launch_block_rate3(const void *params, hipStream_t st) {
+    const GibbsParams &prm = *static_cast<const GibbsParams *>(params);
+    hipLaunchKernelGGL(k_block_rate3, dim3((prm.G - 1 + 3) / 4, prm.C), dim3(256), 0, st, prm);
+    QA_HIP(hipGetLastError());
+}
+
+void launch_block3(const void *params, hipStream_t st) {
+    const GibbsParams &prm = *static_cast<const GibbsParams *>(params);
+    switch (prm.Ksp / 64) {
+        case 1: launch_block<1, 1>(prm, st); break;
+        case 2: launch_block<2, 1>(prm, st); break;
+        case 3: launch_block<3, 1>(prm, st); break;
+        case 4: launch_block<4, 1>(prm, st); break;
+        case 5: launch_block<5, 1>(prm, st); break;
+        case 6: launch_block<6, 1>(prm, st); break;
+        case 8: launch_block<8, 1>(prm, st); break;
+        case 10: launch_block<5, 2>(prm, st); break;
+        default: throw std::runtime_error("NIPT block Gibbs: Ksubset geometry not built");
     }
 }
 

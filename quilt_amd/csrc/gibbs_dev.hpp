@@ -81,6 +81,15 @@ struct GibbsParams {
     const int32_t *rc_rare_snp;  // 0-based all-SNP indices, ascending within a haplotype
     const uint32_t *rc_any;      // [C][rc_words] bit t: some selected haplotype of the chain carries the alt of SNP t
     int rc_words, rc_Gc;
+    // NIPT (three labels): a call is cut into segments of sweeps [it_begin, it_end) with a block-Gibbs pass between
+    // them (gibbs3.hip); the state lives in HBM across the launches.  blk_*: the pass's block table per chain.
+    int it_begin, it_end;
+    const int32_t *blk_where;   // [C][G] consider_grid_where_0_based
+    const int32_t *blk_tab;     // [C][4][G] per block: grid_start, grid_end, reads_start, reads_end
+    const int32_t *blk_n;       // [C] n_blocks
+    double *blk_rate2;          // [C][G] rate2 of the block definition (k_block_rate3)
+    int blk_pass, blk_n_pass;   // this pass / passes per call (indexes the pass's uniforms)
+    double ff;
 };
 
 // does panel haplotype `hap` carry the alt allele of rare SNP `snp` (rare_per_hap_info)

@@ -28,6 +28,7 @@ class GibbsOpts(C.Structure):
         ("perform_block_gibbs", C.c_int32), ("do_shard_block_gibbs", C.c_int32),
         ("gibbs_initialize_iteratively", C.c_int32), ("disable_read_category_usage", C.c_int32),
         ("class_sum_cutoff", C.c_double),
+        ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int32), ("block_gibbs_quantile_prob", C.c_double),
     ]
 
 
@@ -41,7 +42,9 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                                    maxDifferenceBetweenReads: float = 1e10, Jmax_local: int = 10000,
                                    class_sum_cutoff: float = 0.06, return_state: bool = False,
                                    seed_reads=None, seed_shard=None, return_hapProbs: bool = True,
-                                   return_genProbs: bool = True, rare_common=None):
+                                   return_genProbs: bool = True, rare_common=None, runif_block=None,
+                                   runif_resample=None, L_grid=None, shuffle_bin_radius: int = 5000,
+                                   block_gibbs_quantile_prob: float = 0.95):
     """``n_chain`` independent calls of ``rcpp_forwardBackwardGibbsNIPT`` in one launch set.
 
     ``samples[c]`` is a :class:`quilt_amd.synth.SampleReads`-like object (``read_ptr``, ``u``, ``bq``,
@@ -50,6 +53,10 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     ``rare_common`` (a :class:`quilt_amd.native.DeviceRareCommon`): the call the reference makes with
     ``make_eMatRead_t_rare_common = TRUE`` (QUILT/R/rare_common.R:325-398) -- ``samples`` then hold the all-SNP reads
     (``allSNP_sampleReads``) and the outputs cover all SNPs.
+
+    NIPT (``ff`` > 0) with ``perform_block_gibbs``: ``runif_block[c]`` / ``runif_resample[c]`` hold
+    ``len(block_gibbs_iterations) x nReads`` uniforms each (QUILT/src/gibbs-nipt.cpp:3016; gibbs-nipt-block.cpp:226-243)
+    unless seeds are used; ``L_grid`` defaults to the panel's (the all-SNP grid's with ``rare_common``).
     """
     lib().qa_gibbs_batch.restype = C.c_int
     lib().qa_gibbs_batch_rare_common.restype = C.c_int
@@ -83,8 +90,26 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
         ru = np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: samples[c].nReads * n_its]
                              for c, r in enumerate(runif_reads)])
     fr = np.ascontiguousarray(first_read, dtype=np.int32)
-    rs = (np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: nb * (G - 1)] for r in runif_shard])
-          if (nb > 0 and not use_seeds) else np.zeros(1))
+    if ff != 0:
+        # the block passes' uniforms, per chain [pass][block choice | label re-draw][read] (include/quilt_amd.h)
+        if nb > 0 and not use_seeds:
+            if runif_block is None or runif_resample is None:
+                raise ValueError("NIPT block Gibbs: pass runif_block and runif_resample (or seeds)")
+            parts = []
+            for c, smp in enumerate(samples):
+                R = smp.nReads
+                rb = np.ascontiguousarray(runif_block[c], dtype=np.float64).ravel()[: len(blocks) * R].reshape(len(blocks), R)
+                rr = np.ascontiguousarray(runif_resample[c], dtype=np.float64).ravel()[: len(blocks) * R].reshape(len(blocks), R)
+                parts.append(np.stack([rb, rr], axis=1).ravel())
+            rs = np.concatenate(parts)
+        else:
+            rs = np.zeros(1)
+    else:
+        rs = (np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: nb * (G - 1)] for r in runif_shard])
+              if (nb > 0 and not use_seeds) else np.zeros(1))
+    if L_grid is None:
+        L_grid = rare_common.rc.L_grid_all if rare_common is not None else P.L_grid
+    Lg = np.ascontiguousarray(L_grid, dtype=np.int32) if L_grid is not None else None
     H = np.concatenate([np.asarray(h, dtype=np.int32) for h in starting_read_labels]).copy()
     if ff == 0 and H.size and (H.min() < 1 or H.max() > 2):
         raise ValueError("diploid read labels must be 1 or 2")
@@ -97,7 +122,8 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     opts = GibbsOpts(Ks, float(ff), int(ff == 0), int(Jmax_local), float(maxDifferenceBetweenReads), 1,
                      int(n_gibbs_burn_in_its), int(n_gibbs_sample_its), ptr(blocks), int(len(blocks)),
                      int(perform_block_gibbs), int(ff == 0), int(gibbs_initialize_iteratively),
-                     int(disable_read_category_usage), float(class_sum_cutoff))
+                     int(disable_read_category_usage), float(class_sum_cutoff), ptr(Lg), int(shuffle_bin_radius),
+                     float(block_gibbs_quantile_prob))
     _t1 = time.perf_counter()
     tail = (C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(ru),
             ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap), ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
@@ -132,6 +158,9 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
 def rcpp_forwardBackwardGibbsNIPT(panel: DevicePanel, sampleReads, which_haps_to_use, starting_read_labels,
                                   runif_reads, first_read_for_gibbs_initialization, runif_shard, **kw):
     """Single-chain form with the reference's name; see :func:`forwardBackwardGibbsNIPT_batch`."""
+    for k in ("runif_block", "runif_resample"):
+        if kw.get(k) is not None:
+            kw[k] = [kw[k]]
     return forwardBackwardGibbsNIPT_batch(panel, [sampleReads], [which_haps_to_use], [starting_read_labels],
                                           [runif_reads], [first_read_for_gibbs_initialization], [runif_shard],
                                           **kw)[0]

@@ -56,7 +56,7 @@ def lib() -> C.CDLL:
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
                      "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy", "qa_panel_create_from_rhb",
                      "qa_panel_export_tables", "qa_rcpp_make_eMatRead_t_nsnps", "qa_rare_common_create",
-                     "qa_gibbs_batch_rare_common"):
+                     "qa_gibbs_batch_rare_common", "qa_nipt_block_table"):
             getattr(L, name).restype = C.c_int
         L.qa_panel_destroy.restype = None
         L.qa_rare_common_destroy.restype = None

@@ -199,9 +199,8 @@ def test_gibbs_underflow_is_reported(small_panel, oracle):
 @pytest.mark.parametrize("init_iter", [False, True])
 @pytest.mark.parametrize("panel_name,Ks,n_reads", [("small_panel", 100, 150), ("medium_panel", 600, 900)])
 def test_nipt_three_label_sampler(request, oracle, panel_name, Ks, n_reads, init_iter):
-    """NIPT mode (BASELINE configs[4] in small): ff > 0, three read labels, the sampler without the block resampler
-    (the NIPT block Gibbs is not built: perform_block_gibbs must be off).  Labels and classes identical, hapProbs /
-    genProbs (all three haplotypes) to 1e-9."""
+    """NIPT mode (BASELINE configs[4] in small): ff > 0, three read labels, the sampler without the block resampler.
+    Labels and classes identical, hapProbs / genProbs (all three haplotypes) to 1e-9."""
     from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
     from quilt_amd.native import DevicePanel, QuiltAmdError
     from quilt_amd.synth import make_synthetic_sample
@@ -226,6 +225,77 @@ def test_nipt_three_label_sampler(request, oracle, panel_name, Ks, n_reads, init
     np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
     np.testing.assert_allclose(got["genProbsM_t"], ref["genProbsM_t"], rtol=RTOL, atol=1e-14)
     np.testing.assert_allclose(got["genProbsF_t"], ref["genProbsF_t"], rtol=RTOL, atol=1e-14)
-    with pytest.raises(QuiltAmdError):   # the NIPT block resampler is not built: refused, not silently skipped
-        rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, ff=ff)
+    with pytest.raises((QuiltAmdError, ValueError)):   # block passes without their uniforms: refused, not silently skipped
+        rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, None, ff=ff)
+    dev.close()
+
+
+@pytest.mark.parametrize("init_iter", [False, True])
+@pytest.mark.parametrize("panel_name,Ks,n_reads", [("small_panel", 100, 150), ("ragged_panel", 77, 400),
+                                                   ("medium_panel", 600, 900)])
+def test_nipt_block_gibbs(request, oracle, panel_name, Ks, n_reads, init_iter):
+    """NIPT with the block resampler (gibbs-nipt-block.cpp: block definition from the switch rate, six relabellings per
+    block, labels re-drawn from their classes), as the reference runs it by default (block passes after sweeps 3, 6, 9):
+    labels and classes identical to the oracle under the same uniforms, hapProbs / genProbs to 1e-9."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = request.getfixturevalue(panel_name)
+    dev = DevicePanel(panel)
+    ff = 0.2
+    s = make_synthetic_sample(panel, seed=21, n_reads=n_reads, ff=ff)
+    rng = np.random.default_rng(5)
+    which = np.sort(rng.choice(panel.K, Ks, replace=False)).astype(np.int32) + 1
+    R = s.nReads
+    H0 = rng.choice([1, 2, 3], p=[0.5, 0.4, 0.1], size=R).astype(np.int32)
+    ru = rng.random(R * 21)
+    rb, rr = rng.random(3 * R), rng.random(3 * R)
+    fr = int(rng.integers(0, R))
+    for n_burn in (20, 9):   # 9: the call ends right after the last block pass
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, np.zeros(3 * panel.nGrids), ff=ff,
+                                              gibbs_initialize_iteratively=init_iter, n_gibbs_burn_in_its=n_burn,
+                                              runif_block=rb, runif_resample=rr)
+        got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, None, ff=ff, gibbs_initialize_iteratively=init_iter,
+                                            n_gibbs_burn_in_its=n_burn, runif_block=rb, runif_resample=rr)
+        assert ref["status"] == 0 and not got["underflow_problem"]
+        assert np.array_equal(got["H"], ref["H"]), f"{(got['H'] != ref['H']).sum()} labels differ (n_burn = {n_burn})"
+        assert np.array_equal(got["H_class"], ref["H_class"])
+        np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+        np.testing.assert_allclose(got["genProbsM_t"], ref["genProbsM_t"], rtol=RTOL, atol=1e-14)
+        np.testing.assert_allclose(got["genProbsF_t"], ref["genProbsF_t"], rtol=RTOL, atol=1e-14)
+    # the block passes do something: without them the labels differ
+    plain = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, None, ff=ff, perform_block_gibbs=False,
+                                          gibbs_initialize_iteratively=init_iter)
+    assert (plain["H"] != got["H"]).any()
+    dev.close()
+
+
+def test_nipt_block_gibbs_seeded_batch(medium_panel, oracle):
+    """Several NIPT chains in one launch set with the counter-based uniform streams."""
+    from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.rng import stream_uniform
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    rng = np.random.default_rng(9)
+    samples, whichs, H0s, srs, sss, refs = [], [], [], [], [], []
+    for c in range(3):
+        ff = 0.15
+        s = make_synthetic_sample(panel, seed=40 + c, n_reads=500 + 100 * c, ff=ff)
+        which = np.sort(rng.choice(panel.K, 600, replace=False)).astype(np.int32) + 1
+        H0 = rng.choice([1, 2, 3], p=[0.5, 0.4, 0.1], size=s.nReads).astype(np.int32)
+        sr, ss = int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 62))
+        R = s.nReads
+        ru = stream_uniform(sr, R * 21)
+        blk = stream_uniform(ss, 3 * 2 * R).reshape(3, 2, R)
+        refs.append(oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, 0, np.zeros(3 * panel.nGrids), ff=ff,
+                                                    runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy()))
+        samples.append(s); whichs.append(which); H0s.append(H0); srs.append(sr); sss.append(ss)
+    got = forwardBackwardGibbsNIPT_batch(dev, samples, whichs, H0s, None, [0, 0, 0], None, ff=0.15, seed_reads=srs,
+                                         seed_shard=sss)
+    for g, r in zip(got, refs):
+        assert np.array_equal(g["H"], r["H"]) and np.array_equal(g["H_class"], r["H_class"])
+        np.testing.assert_allclose(g["hapProbs_t"], r["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    dev.close()
     dev.close()
