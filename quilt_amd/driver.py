@@ -45,6 +45,8 @@ class DriverParams:
     Jmax: int = 10000
     seed: int = 1
     impute_rare_common: bool = False   # quilt.R:180: finish every Gibbs sample with a Gibbs call over ALL SNPs
+    method: str = "diploid"            # or "nipt": mother + fetus, three read labels, fetal fraction per sample (sample.ff)
+    shuffle_bin_radius: int = 5000     # quilt.R:134 (block definition of the NIPT block Gibbs)
 
     def resolved(self, K: int) -> "DriverParams":
         p = DriverParams(**self.__dict__)
@@ -167,7 +169,17 @@ def everything_select_good_haps_dense(Knew: int, K_top_matches: int, top: np.nda
 
 
 def assess_ability_of_reads_to_be_confident(p: np.ndarray, minrp: float = 0.95) -> np.ndarray:
-    """functions.R:1615-1660 (diploid): ``p`` = 2 x nReads read likelihoods against (hap1, hap2)."""
+    """functions.R:1615-1660: ``p`` = 2 x nReads read likelihoods against (hap1, hap2), or 3 x nReads (NIPT)."""
+    if p.shape[0] == 3:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            q = p / p.sum(axis=0)
+        mp = q[0].copy()
+        w = q[1] > q[0]
+        mp[w] = q[1][w]
+        w = q[2] > mp
+        mp[w] = q[2][w]
+        mp[np.isnan(mp)] = 1 / 3
+        return mp > minrp
     p1, p2 = p[0], p[1]
     with np.errstate(invalid="ignore", divide="ignore"):
         mp = p1 / (p1 + p2)
@@ -292,6 +304,52 @@ def recast_haps(hd1: np.ndarray, hd2: np.ndarray, gp: np.ndarray):
     return hd1, hd2
 
 
+def determine_best_read_label_so_far_nipt(read_label_matrix_all: np.ndarray, read_label_matrix_conf: np.ndarray,
+                                          nReads: int, nGibbsSamples: int, can_hap: int) -> np.ndarray:
+    """functions.R:1788-1829: label 3 folded into 2 (and called not confident) for the consensus, then put back."""
+    rl = read_label_matrix_all.copy()
+    conf = read_label_matrix_conf.copy()
+    three = rl == 3
+    conf[three] = False
+    rl[three] = 2
+    out = determine_best_read_label_so_far(rl, conf, nReads, nGibbsSamples, can_hap)
+    out = out.copy()
+    out[three[:, can_hap - 1]] = 3
+    return out
+
+
+def recast_nipt_haps(hap1, hap2, hap3, mat_gp_t, fet_gp_t):
+    """functions.R:3214-3287: phased haplotypes of mother and fetus made to agree with the argmax genotypes
+    (``*_gp_t`` are 3 x nSNPs)."""
+    hap1, hap2, hap3 = hap1.copy(), hap2.copy(), hap3.copy()
+    gtMT = np.zeros(mat_gp_t.shape[1])
+    gtFT = np.zeros(mat_gp_t.shape[1])
+    mxA, mxB = mat_gp_t[0].copy(), fet_gp_t[0].copy()
+    for i in (1, 2):
+        w = mat_gp_t[i] > mxA
+        gtMT[w] = i
+        mxA[w] = mat_gp_t[i][w]
+        w = fet_gp_t[i] > mxB
+        gtFT[w] = i
+        mxB[w] = fet_gp_t[i][w]
+    conv = [(0, 0, 0, 0, 0), (0, 1, 0, 0, 1), (0, 2, 0, 0, 1), (1, 0, 0, 1, 0), (1, 2, 1, 0, 1), (2, 0, 1, 1, 0),
+            (2, 1, 1, 1, 0), (2, 2, 1, 1, 1)]
+    for m, f, a, b, c in conv:
+        w = (gtMT == m) & (gtFT == f)
+        hap1[w], hap2[w], hap3[w] = a, b, c
+    w1 = np.nonzero((gtMT == 1) & (gtFT == 1))[0]
+    r1, r2, r3 = np.round(hap1[w1]), np.round(hap2[w1]), np.round(hap3[w1])
+    w2 = (r1 == 1) & (r2 == 0) & (r3 == 0)
+    w3 = (r1 == 0) & (r2 == 1) & (r3 == 1)
+    w4 = ~w2 & ~w3
+    hap1[w1[w2]], hap2[w1[w2]], hap3[w1[w2]] = 1, 0, 0
+    hap1[w1[w3]], hap2[w1[w3]], hap3[w1[w3]] = 0, 1, 1
+    hap1[w1[w4]] = np.round(hap1[w1[w4]])
+    hap2[w1[w4]] = np.round(hap2[w1[w4]])
+    hap3[w1[w4]] = 1 - hap1[w1[w4]]
+    return np.round(hap1), np.round(hap2), np.round(hap3)
+
+
 # ---------------------------------------------------------------------------------------------
 # the lock-step driver
 # ---------------------------------------------------------------------------------------------
@@ -322,6 +380,9 @@ class SampleResult:
     read_labels: np.ndarray           # consensus labels used by the phasing pass
     nDosage: int
     n_underflow_retries: int = 0
+    # method = "nipt": dosage / gp_t are the mother's; the fetus':
+    fet_dosage: Optional[np.ndarray] = None
+    fet_gp_t: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -335,6 +396,8 @@ class _Batch:
     nDosage: np.ndarray
     phasing: Optional[List[ChainState]] = None
     consensus: Optional[List[np.ndarray]] = None
+    fet_dosage: Optional[np.ndarray] = None     # method = "nipt": dosage / gp_t hold the mother's
+    fet_gp_t: Optional[np.ndarray] = None
     dosage_all: Optional[np.ndarray] = None     # impute_rare_common: the same accumulators over ALL SNPs
     gp_t_all: Optional[np.ndarray] = None
     nDosage_all: Optional[np.ndarray] = None
@@ -365,6 +428,11 @@ class Driver:
         self.rare_common = rare_common
         if self.params.impute_rare_common and rare_common is None:
             raise ValueError("impute_rare_common needs the panel's rare/common tables")
+        if self.params.method not in ("diploid", "nipt"):
+            raise ValueError("method is 'diploid' or 'nipt'")
+        if self.params.method == "nipt" and self.params.impute_rare_common:
+            raise NotImplementedError("impute_rare_common with method = 'nipt' (rare_common.R:195-205) is not built")
+        self.n_label = 3 if self.params.method == "nipt" else 2
         self.cols = thinned_grid_columns(panel.nGrids, self.params.heuristic_match_thin)
         self.n_thin = int((self.cols >= 0).sum())
         self.top_width = max(8, self.params.K_top_matches)   # entries kept per (label, thinned grid) list
@@ -385,7 +453,11 @@ class Driver:
             if first:
                 # functions.R:579-585
                 ch.which_haps_to_use = np.sort(ch.rng.choice(K, size=P.Ksubset, replace=False) + 1).astype(np.int32)
-                H0 = ch.rng.integers(1, 3, size=R).astype(np.int32)
+                if P.method == "nipt":   # functions.R:586
+                    ff = ch.sample.ff
+                    H0 = (ch.rng.choice(3, size=R, p=[0.5, 0.5 - ff / 2, ff / 2]) + 1).astype(np.int32)
+                else:
+                    H0 = ch.rng.integers(1, 3, size=R).astype(np.int32)
             else:
                 H0 = ch.read_labels
             starts.append(H0)
@@ -424,7 +496,8 @@ class Driver:
                     for ch in chains]
         dosages, top, top_cnt = self.backend.fullpass_reads_batch(
             sample_list, [uniq[id(ch.sample)] for ch in chains], [ch.read_labels for ch in chains],
-            [return_dosage] * len(chains), want_top, self.cols, P.K_top_matches, P.minGLValue, self.top_width)
+            [return_dosage] * len(chains), want_top, self.cols, P.K_top_matches, P.minGLValue, self.top_width,
+            n_label=self.n_label)
         t4 = time.perf_counter()
         self.timing["fullpass"] += t4 - t3
         for ci, ch in enumerate(chains):
@@ -432,9 +505,9 @@ class Driver:
                 d = dosages[ci]
                 if d.min() < -1e-5 or d.max() > 1 + 1e-5:   # functions.R:2072-2075
                     raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
-                ch.hap = [d[0], d[1]]
+                ch.hap = [d[l] for l in range(self.n_label)]
             else:
-                ch.hap = [np.zeros(T), np.zeros(T)]
+                ch.hap = [np.zeros(T) for _ in range(self.n_label)]
             if not want_top[ci]:
                 continue
             prev_sel = ch.which_haps_to_use[ch.rng.permutation(len(ch.which_haps_to_use))[: P.Ksubset - P.Knew]]
@@ -453,10 +526,12 @@ class Driver:
         n_try = 0
         while pending:
             groups = {}
-            for i in pending:
-                groups.setdefault(maxdiff[i], []).append(i)
+            for i in pending:   # one launch set per (maxDifferenceBetweenReads, fetal fraction)
+                groups.setdefault((maxdiff[i], float(samples[i].ff) if P.method == "nipt" else 0.0), []).append(i)
             nxt = []
-            for md, idx in groups.items():
+            for (md, ff), idx in groups.items():
+                if P.method == "nipt":
+                    kw = dict(kw, ff=ff, shuffle_bin_radius=P.shuffle_bin_radius)
                 out = self.backend.gibbs_batch(
                     [samples[i] for i in idx], [chains[i].which_haps_to_use for i in idx],
                     [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],
@@ -513,6 +588,8 @@ class Driver:
         chains = [ChainState(samples[i], i, c, chain_rng(P.seed, offset + i, c))
                   for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
         b = _Batch(list(samples), offset, chains, np.zeros((N, T)), np.zeros((N, 3, T)), np.zeros(N, dtype=np.int64))
+        if P.method == "nipt":
+            b.fet_dosage, b.fet_gp_t = np.zeros((N, T)), np.zeros((N, 3, T))
         if P.impute_rare_common:
             Ta = self.rare_common.nSNPs_all
             b.dosage_all, b.gp_t_all, b.nDosage_all = np.zeros((N, Ta)), np.zeros((N, 3, Ta)), np.zeros(N, dtype=np.int64)
@@ -528,7 +605,8 @@ class Driver:
             mine = [k for k, ch in enumerate(b.chains) if ch.i_sample == i]
             rl_all = np.stack([b.chains[k].read_labels for k in mine], axis=1)
             rl_conf = np.stack([assess_ability_of_reads_to_be_confident(conf[k]) for k in mine], axis=1)
-            labels = determine_best_read_label_so_far(rl_all, rl_conf, smp.nReads, P.nGibbsSamples, can_hap=P.nGibbsSamples)
+            consensus = determine_best_read_label_so_far_nipt if P.method == "nipt" else determine_best_read_label_so_far
+            labels = consensus(rl_all, rl_conf, smp.nReads, P.nGibbsSamples, can_hap=P.nGibbsSamples)
             last = b.chains[mine[-1]]
             b.phasing.append(ChainState(smp, i, P.nGibbsSamples + 1, chain_rng(P.seed, b.offset + i, P.nGibbsSamples + 1),
                                         which_haps_to_use=last.which_haps_to_use.copy(), read_labels=labels, _phasing=True))
@@ -547,6 +625,13 @@ class Driver:
                 continue
             d = b.dosage[i] / b.nDosage[i]
             g = b.gp_t[i] / b.nDosage[i]
+            if self.params.method == "nipt":   # functions.R:1218-1231, 1313-1317
+                fd, fg = b.fet_dosage[i] / b.nDosage[i], b.fet_gp_t[i] / b.nDosage[i]
+                ph = b.phasing[i].hap
+                h1, h2, h3 = recast_nipt_haps(ph[0], ph[1], ph[2], g, fg)
+                out.append(SampleResult(d, g, np.stack([h1, h2, h3], axis=1), b.consensus[i], int(b.nDosage[i]),
+                                        fet_dosage=fd, fet_gp_t=fg))
+                continue
             h1, h2 = recast_haps(b.phasing[i].hap[0], b.phasing[i].hap[1], g.T)   # functions.R:1207-1217
             out.append(SampleResult(d, g, np.stack([h1, h2], axis=1), b.consensus[i], int(b.nDosage[i])))
         return out
@@ -567,9 +652,13 @@ class Driver:
                 stored = self._round(chains, i_it)
                 if stored and cur:   # functions.R:999-1020
                     for ch in cur.chains:
-                        h1, h2 = ch.hap
+                        h1, h2 = ch.hap[0], ch.hap[1]
                         cur.dosage[ch.i_sample] += h1 + h2
                         cur.gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
+                        if P.method == "nipt":   # functions.R:1009-1016: fetus = maternal transmitted + paternal transmitted
+                            h3 = ch.hap[2]
+                            cur.fet_dosage[ch.i_sample] += h1 + h3
+                            cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
                         cur.nDosage[ch.i_sample] += 1
             if P.impute_rare_common:   # functions.R:1042-1123
                 self._rare_common_round((cur.chains if cur else []) + (prev.phasing if prev else []))
@@ -659,9 +748,9 @@ class HipBackend:
         return list(dosage), best
 
     def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, want_top, cols, K_top_matches, minGLValue,
-                             top_width):
-        """impute_using_everything for every chain: returns dosage [n_chain, 2, T], the ordered top matches
-        [n_chain, 2, n_thin, top_width] (0-based, -1 padded; only for chains with want_top) and the full list lengths."""
+                             top_width, n_label=2):
+        """impute_using_everything for every chain: returns dosage [n_chain, n_label, T], the ordered top matches
+        [n_chain, n_label, n_thin, top_width] (0-based, -1 padded; only for chains with want_top) and the full list lengths."""
         import ctypes as C
         from .native import check, lib, ptr
         lib().qa_fullpass_reads_batch.restype = C.c_int
@@ -680,11 +769,11 @@ class HipBackend:
         cs = np.ascontiguousarray(chain_sample, dtype=np.int32)
         wd = np.ascontiguousarray(want_dosage, dtype=np.int32)
         wt = np.ascontiguousarray(want_top, dtype=np.int32)
-        dosage = np.zeros((n_chain, 2, T)) if wd.any() else None
-        top = np.full((n_chain, 2, n_thin, top_width), -1, dtype=np.int32)
-        val = np.zeros((n_chain, 2, n_thin, top_width), dtype=np.float32)
-        cnt = np.zeros((n_chain, 2, n_thin), dtype=np.int32)
-        check(lib().qa_fullpass_reads_batch(self.dev.handle, C.c_int32(n_chain), C.c_int32(2), C.c_int32(n_sample), ptr(cs),
+        dosage = np.zeros((n_chain, n_label, T)) if wd.any() else None
+        top = np.full((n_chain, n_label, n_thin, top_width), -1, dtype=np.int32)
+        val = np.zeros((n_chain, n_label, n_thin, top_width), dtype=np.float32)
+        cnt = np.zeros((n_chain, n_label, n_thin), dtype=np.int32)
+        check(lib().qa_fullpass_reads_batch(self.dev.handle, C.c_int32(n_chain), C.c_int32(n_label), C.c_int32(n_sample), ptr(cs),
                                             ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(wt), ptr(cols),
                                             C.c_int32(K_top_matches), C.c_double(minGLValue), ptr(dosage),
                                             C.c_int32(top_width), ptr(top), ptr(val), ptr(cnt)))

@@ -15,7 +15,7 @@ class OracleBackend:
 
     def gibbs_batch(self, samples, which, starts, seed_reads, first_reads, seed_shards, *,
                     n_gibbs_burn_in_its, n_gibbs_sample_its, block_gibbs_iterations, gibbs_initialize_iteratively,
-                    maxDifferenceBetweenReads, Jmax_local, rare_common=False):
+                    maxDifferenceBetweenReads, Jmax_local, rare_common=False, ff=0.0, shuffle_bin_radius=5000):
         from quilt_amd.rng import stream_uniform
         out = []
         n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
@@ -24,7 +24,13 @@ class OracleBackend:
         extra = dict(rare_common=self.rare_common, disable_read_category_usage=True) if rare_common else {}
         for s, w, h, sr, fr, ss in zip(samples, which, starts, seed_reads, first_reads, seed_shards):
             ru = stream_uniform(sr, s.nReads * n_its)
-            rs = stream_uniform(ss, nb * (G - 1))
+            if ff != 0:   # NIPT: the block passes' uniforms, [pass][block choice | label re-draw][read] of the same stream
+                blk = stream_uniform(ss, nb * 2 * s.nReads).reshape(nb, 2, s.nReads)
+                extra = dict(extra, ff=ff, runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy(),
+                             shuffle_bin_radius=shuffle_bin_radius)
+                rs = np.zeros(nb * G)
+            else:
+                rs = stream_uniform(ss, nb * (G - 1))
             init = bool(gibbs_initialize_iteratively) and fr >= 0   # per chain (include/quilt_amd.h: first_read < 0)
             r = O.forwardBackwardGibbsNIPT(self.panel, s, w, h, ru, max(fr, 0), rs,
                                            n_gibbs_burn_in_its=n_gibbs_burn_in_its,
@@ -53,18 +59,18 @@ class OracleBackend:
                 for s, h in zip(samples_all, haps)]
 
     def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, want_top, cols, K_top_matches, minGLValue,
-                             top_width):
+                             top_width, n_label=2):
         from quilt_amd.driver import make_gl_from_u_bq
         T = self.panel.nSNPs
         n_chain = len(chain_sample)
         n_thin = int((np.asarray(cols) >= 0).sum())
-        dosage = np.zeros((n_chain, 2, T))
-        top = np.full((n_chain, 2, n_thin, top_width), -1, dtype=np.int32)
-        cnt = np.zeros((n_chain, 2, n_thin), dtype=np.int32)
+        dosage = np.zeros((n_chain, n_label, T))
+        top = np.full((n_chain, n_label, n_thin, top_width), -1, dtype=np.int32)
+        cnt = np.zeros((n_chain, n_label, n_thin), dtype=np.int32)
         for c in range(n_chain):
             s = samples[chain_sample[c]]
             per_base = np.repeat(labels[c], np.diff(s.read_ptr))
-            for l in (1, 2):
+            for l in range(1, n_label + 1):
                 sel = (per_base == l) & (s.bq != 0)
                 gl = make_gl_from_u_bq(s.u[sel], s.bq[sel], T, minGLValue, self.make_gl_bound)
                 r = O.haploid_dosage_versus_refs(self.panel, gl, cols, K_top_matches=K_top_matches,

@@ -127,3 +127,40 @@ def test_rare_common_pipeline_on_the_oracle():
 def test_get_initial_read_labels():
     e = np.array([[0.9, 0.1, 0.5], [0.1, 0.9, 0.5]])
     assert D.get_initial_read_labels(e, np.array([0.5, 0.5, 0.7])).tolist() == [2, 1, 1]
+
+
+def test_nipt_pipeline_on_the_oracle():
+    """method = "nipt" (functions.R:586, 1009-1016, 1188-1199, 1218-1231): three read labels, mother and fetus
+    accumulators, the NIPT consensus and recast; batching does not change results."""
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    from tests.util import r2
+    panel = make_synthetic_panel(K=400, nSNPs=640, seed=21)
+    samples = [make_synthetic_sample(panel, seed=70 + i, n_reads=300, ff=0.2) for i in range(3)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method="nipt")
+    one = D.Driver(panel, OracleBackend(panel), prm).run(samples)
+    for smp, r in zip(samples, one):
+        assert r.phasing_haps.shape == (panel.nSNPs, 3) and set(np.unique(r.phasing_haps)) <= {0.0, 1.0}
+        assert set(np.unique(r.read_labels)) <= {1, 2, 3}
+        np.testing.assert_allclose(r.gp_t.sum(axis=0), 1.0, atol=1e-9)
+        np.testing.assert_allclose(r.fet_gp_t.sum(axis=0), 1.0, atol=1e-9)
+        mat = smp.truth_haps[0] + smp.truth_haps[1]
+        fet = smp.truth_haps[0] + smp.truth_haps[2]
+        assert r2(r.dosage, mat) > 0.3 and r2(r.fet_dosage, fet) > 0.2
+    streamed = list(D.Driver(panel, OracleBackend(panel), prm).run_stream([(samples[:2], 0), (samples[2:], 2)]))
+    for g, r in zip(streamed[0] + streamed[1], one):
+        assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.fet_dosage, r.fet_dosage)
+        assert np.array_equal(g.read_labels, r.read_labels)
+
+
+def test_nipt_consensus_and_recast():
+    rl = np.array([[1, 1], [3, 2], [2, 2], [1, 3]] * 3)
+    conf = np.ones_like(rl, dtype=bool)
+    out = D.determine_best_read_label_so_far_nipt(rl, conf, len(rl), 2, can_hap=2)
+    assert np.array_equal(out, rl[:, 1])        # too few confident rows to flip anything; the 3s survive
+    h1, h2, h3 = np.array([0.9, 0.2, 0.6, 0.4]), np.array([0.1, 0.7, 0.6, 0.4]), np.array([0.2, 0.9, 0.1, 0.6])
+    mat = np.array([[0.1, 0.1, 0.0, 0.8], [0.8, 0.8, 0.1, 0.1], [0.1, 0.1, 0.9, 0.1]])
+    fet = np.array([[0.1, 0.7, 0.1, 0.1], [0.8, 0.2, 0.1, 0.8], [0.1, 0.1, 0.8, 0.1]])
+    a, b, c = D.recast_nipt_haps(h1, h2, h3, mat, fet)
+    # site 0: (1, 1) with rounded haps (1, 0, 0) kept; site 1: (1, 0) -> (0, 1, 0); site 2: (2, 2) -> all 1; site 3: (0, 1) -> (0, 0, 1)
+    assert (a.tolist(), b.tolist(), c.tolist()) == ([1, 0, 1, 0], [0, 1, 1, 0], [0, 0, 1, 1])

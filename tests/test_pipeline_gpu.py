@@ -160,3 +160,30 @@ def test_full_size_invariants():
     one = Driver(panel, HipBackend(dev), prm).run(samples[1:], sample_offset=1)[0]
     assert np.array_equal(one.read_labels, res[1].read_labels) and np.abs(one.dosage - res[1].dosage).max() <= 1e-6
     dev.close()
+
+
+def test_pipeline_nipt(medium_panel):
+    """BASELINE configs[4] in small: method = "nipt" end to end (three-label sampler with its block Gibbs, three
+    full-panel passes per chain, NIPT consensus and recast) on the HIP backend vs the oracle backend."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=3000 + i, n_reads=1000, ff=0.2) for i in range(3)]
+    prm = DriverParams(nGibbsSamples=3, Ksubset=200, Knew=200, seed=5, method="nipt")
+    dev = DevicePanel(panel)
+    got = Driver(panel, HipBackend(dev), prm).run(samples)
+    ref = Driver(panel, OracleBackend(panel), prm).run(samples)
+    dev.close()
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g.nDosage == r.nDosage == 3
+        assert np.array_equal(g.read_labels, r.read_labels) and (g.read_labels == 3).any()
+        np.testing.assert_allclose(g.gp_t.sum(axis=0), 1.0, atol=2e-3)
+        np.testing.assert_allclose(g.fet_gp_t.sum(axis=0), 1.0, atol=2e-3)
+        assert np.abs(g.dosage - r.dosage).max() <= 1e-4 and np.abs(g.fet_dosage - r.fet_dosage).max() <= 1e-4
+        assert r2(g.dosage, r.dosage) >= 0.999 and r2(g.fet_dosage, r.fet_dosage) >= 0.999
+        assert np.mean(np.abs(g.phasing_haps - r.phasing_haps) > 1e-4) <= 2e-3
+        mat = samples[i].truth_haps[0] + samples[i].truth_haps[1]
+        print(f"sample {i}: r2(gpu, oracle) mother {r2(g.dosage, r.dosage):.6f} fetus {r2(g.fet_dosage, r.fet_dosage):.6f}; "
+              f"mother vs truth {r2(g.dosage, mat):.3f}")
