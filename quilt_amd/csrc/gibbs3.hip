@@ -7,9 +7,9 @@
 // higher), move probabilities prod_h p(h) * prior(label) with prior = (0.5, (1 - ff) / 2, ff / 2), the 7-prototype read
 // class (record_read_set, :1142-1165).  It is the straightforward form (no software pipelining of the column loads yet).
 //
-// Not built: the NIPT block Gibbs (`Rcpp_block_gibbs_resampler` with its six relabellings and
-// `rcpp_sample_H_using_H_class`, gibbs-nipt-block.cpp:1636-1967): the host rejects ff > 0 together with
-// perform_block_gibbs.  Category 1 reads are not skipped in this mode (:815) but leave every probability unchanged.
+// A call is run as segments of sweeps [it_begin, it_end) with a block-Gibbs pass between them (k_block_rate3, host block
+// definition in gibbs_blocks.hpp, k_block3 -- below); the state lives in HBM across the launches.  Category 1 reads are
+// not skipped in this mode (:815) but leave every probability unchanged.
 #include "gibbs_dev.hpp"
 
 namespace {
