@@ -238,6 +238,9 @@ typedef struct {
     const int32_t *L_grid;
     int32_t shuffle_bin_radius;
     double block_gibbs_quantile_prob;
+    /* NULL, or (NIPT only, ff > 0) n_chain fetal fractions in (0, 1), one per chain, overriding ff: lets one launch set
+     * carry samples with different fetal fractions (ff_values[iSample], functions.R:128) */
+    const double *ff_chain;
 } qa_gibbs_opts_t;
 
 /*

@@ -823,7 +823,7 @@ struct GibbsScratch {
     DBuf<size_t> eread_off;
     DBuf<uint64_t> seeds;
     DBuf<uint32_t> rc_any;
-    DBuf<double> blk_rate2;
+    DBuf<double> blk_rate2, ff_chain;
     DBuf<int32_t> blk_where, blk_tab, blk_n;
 };
 
@@ -958,7 +958,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
 
 }  // namespace
 
-static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_opts_t *o, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, int32_t n_chain, const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
@@ -1133,6 +1133,11 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         prm.class_sum_cutoff = o->class_sum_cutoff;
         prm.nH = nH;
         prm.it_begin = 0; prm.it_end = n_its;
+        prm.ff = o->ff;
+        if (ff_chain) {
+            S.ff_chain.ensure(C); S.ff_chain.upload(ff_chain, C, st);
+            prm.ff_chain = S.ff_chain.p;
+        }
         {   // prior over labels and the read-label class prototypes (gibbs-nipt.cpp:2707-2729)
             const double ff = o->ff, pp[3] = {0.5, (1 - ff) * 0.5, ff * 0.5};
             const double r[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1},
@@ -1302,6 +1307,14 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
                       "and the block passes' uniforms (runif_shard or seeds)");
         return QA_ERR_INVALID;
     }
+    if (o->ff_chain) {
+        bool ok = o->ff != 0.0;
+        for (int c = 0; c < n_chain && ok; c++) ok = o->ff_chain[c] > 0 && o->ff_chain[c] < 1;
+        if (!ok) {
+            qa::set_error("qa_gibbs_batch: ff_chain goes with ff > 0 (NIPT) and holds fetal fractions in (0, 1)");
+            return QA_ERR_INVALID;
+        }
+    }
     if (o->Ks <= 0 || o->Ks > 1024) {
         qa::set_error("qa_gibbs_batch: Ksubset = %d outside 1..1024", o->Ks);
         return QA_ERR_UNSUPPORTED;
@@ -1340,7 +1353,7 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             std::vector<int32_t> ro(c1 - c0 + 1);
             for (int i = 0; i <= c1 - c0; i++) ro[i] = read_off[c0 + i] - read_off[c0];
             const int st = gibbs_chunk(
-                pn, rc, o, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
+                pn, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
                 u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
                 runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
                 runif_shard ? runif_shard + (o->ff != 0.0 ? (size_t)read_off[c0] * nb * 2 : (size_t)c0 * nb * (G - 1)) : nullptr,

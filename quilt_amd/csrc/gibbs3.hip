@@ -44,6 +44,14 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
     auto uni_d = [](const double *q) { return rl_f64(*q, 0); };
     auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
+    // prior over labels and the read-label class prototypes (gibbs-nipt.cpp:2707-2729) of this chain's fetal fraction
+    const double ffc = p.ff_chain ? uni_d(&p.ff_chain[c]) : p.ff;
+    const double pp[3] = {0.5, (1 - ffc) * 0.5, ffc * 0.5};
+    const double rlc[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1},
+                              {pp[0] / (pp[0] + pp[1]), pp[1] / (pp[0] + pp[1]), 0},
+                              {pp[0] / (pp[0] + pp[2]), 0, pp[2] / (pp[0] + pp[2])},
+                              {0, pp[1] / (pp[1] + pp[2]), pp[2] / (pp[1] + pp[2])},
+                              {pp[0], pp[1], pp[2]}};
     int status = 0;
     if (p.it_begin > 0) {   // a later segment of the call: the state is in HBM, a chain that underflowed stays stopped
         status = uni_i(p.status[c]);
@@ -300,9 +308,9 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
                     pA1[1] = s[1];
                     pA2[2] = s[2];
                 }
-                const double prod_pC = (pC[0] * pC[1] * pC[2]) * p.prior_probs[h_rC];
-                const double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * p.prior_probs[h_rA1];
-                const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * p.prior_probs[h_rA2];
+                const double prod_pC = (pC[0] * pC[1] * pC[2]) * (h_rC == 0 ? pp[0] : h_rC == 1 ? pp[1] : pp[2]);
+                const double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * (h_rA1 == 0 ? pp[0] : h_rA1 == 1 ? pp[1] : pp[2]);
+                const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * (h_rA2 == 0 ? pp[0] : h_rA2 == 1 ? pp[1] : pp[2]);
                 const double denom = prod_pC + prod_pA1 + prod_pA2;
                 const double norm_pC = prod_pC / denom, norm_pA1 = prod_pA1 / denom, norm_pA2 = prod_pA2 / denom;
                 const double chance = runif ? uni_d(&runif[(size_t)R * it + r]) : stream_uniform(seed_reads, (uint64_t)R * it + r);
@@ -342,8 +350,9 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
                 {   // record_read_set (:1142-1165)
                     double local_min = 2;
                     int which = 8;
+#pragma unroll
                     for (int i = 0; i < 7; i++) {
-                        const double y = fabs(p.rlc[i][0] - x3[0]) + fabs(p.rlc[i][1] - x3[1]) + fabs(p.rlc[i][2] - x3[2]);
+                        const double y = fabs(rlc[i][0] - x3[0]) + fabs(rlc[i][1] - x3[1]) + fabs(rlc[i][2] - x3[2]);
                         if (y < local_min) { local_min = y; which = i; }
                     }
                     if (t == 0) ch.Hc[r] = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
@@ -456,7 +465,8 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
     constexpr int RR[6][3] = {{1, 2, 3}, {1, 3, 2}, {2, 1, 3}, {2, 3, 1}, {3, 1, 2}, {3, 2, 1}};   // :1755-1761
     constexpr int RX[6][3] = {{1, 2, 3}, {1, 3, 2}, {2, 1, 3}, {3, 1, 2}, {2, 3, 1}, {3, 2, 1}};   // :752-758
     const int G = ch.G, Ksp = ch.Ksp, R = ch.R, Ks = ch.Ks;
-    const double prior = ch.prior, one_over_K = 1 / (double)Ks, ff = p.ff;
+    const double prior = ch.prior, one_over_K = 1 / (double)Ks;
+    const double ff = p.ff_chain ? rl_f64(p.ff_chain[c], 0) : p.ff;
     bool (&valid)[NE] = ch.valid;
     if (__builtin_amdgcn_readfirstlane(p.status[c]) != 0) return;   // the chain underflowed: the caller retries it
     auto uni_d = [](const double *q) { return rl_f64(*q, 0); };

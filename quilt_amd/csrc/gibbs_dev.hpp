@@ -90,6 +90,7 @@ struct GibbsParams {
     double *blk_rate2;          // [C][G] rate2 of the block definition (k_block_rate3)
     int blk_pass, blk_n_pass;   // this pass / passes per call (indexes the pass's uniforms)
     double ff;
+    const double *ff_chain;     // [C] or null: per-chain fetal fraction overriding ff
 };
 
 // does panel haplotype `hap` carry the alt allele of rare SNP `snp` (rare_per_hap_info)

@@ -409,6 +409,48 @@ def get_initial_read_labels(e: np.ndarray, runif: np.ndarray) -> np.ndarray:
     return (runif < (e[0] / (e[0] + e[1]))).astype(np.int32) + 1
 
 
+def preserve_round(x: np.ndarray) -> np.ndarray:
+    """gibbs-nipt.R:1779-1789: round to integers keeping the sum (the largest fractional parts go up)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.floor(x)
+    n_up = int(np.round(x.sum()) - y.sum())
+    if n_up > 0:
+        idx = np.argsort(x - y, kind="stable")[-n_up:]
+        y[idx] += 1
+    if abs(x.sum() - y.sum()) > 0.1:
+        raise RuntimeError("preserve round has not worked")
+    return y.astype(np.int64)
+
+
+def get_initial_read_labels_nipt(e: np.ndarray, ff: float, rng: np.random.Generator) -> np.ndarray:
+    """rare_common.R:104-105 with get_read_groupings_given_fetal_fraction_and_cov and sample_H_for_NIPT_given_groupings
+    (gibbs-nipt.R:1655-1777, :1796-1849): ``e`` = 3 x nReads rescaled likelihoods of the all-SNP reads against
+    (hap1, hap2, hap3).  A read is grouped by which haplotypes it fits (> 0.5); reads that fit exactly one take its label,
+    reads shared by two are split between them in the ratio of the label priors (rounded, sum preserved) and drawn with
+    those proportions, the rest follow the prior.  (The reference also draws a down-sampled read set here whose result
+    is not used; it is not drawn.)"""
+    frp = np.array([0.5, 0.5 - ff / 2, ff / 2])
+    with np.errstate(invalid="ignore"):
+        m = [np.where(np.isnan(e[i]), False, e[i] > 0.5) for i in range(3)]
+    n_fit = m[0].astype(int) + m[1].astype(int) + m[2].astype(int)
+    R = e.shape[1]
+    H = np.zeros(R, dtype=np.int32)
+    every = (n_fit == 3) | (n_fit == 0)
+    H[every] = rng.choice(3, size=int(every.sum()), p=frp) + 1
+    for i in range(3):
+        H[(n_fit == 1) & m[i]] = i + 1
+    for i in range(2):
+        for j in range(i + 1, 3):
+            both = (n_fit == 2) & m[i] & m[j]
+            n = int(both.sum())
+            if n == 0:
+                continue
+            f1 = frp[i] / (frp[i] + frp[j])
+            a, b = preserve_round(n * np.array([f1, 1 - f1]))
+            H[both] = np.where(rng.random(n) < a / (a + b), i + 1, j + 1)
+    return H
+
+
 class Driver:
     """Runs ``get_and_impute_one_sample`` (quilt.R:688-996, functions.R:420-1259) for batches of samples, all chains of
     a batch in lock-step.
@@ -430,8 +472,6 @@ class Driver:
             raise ValueError("impute_rare_common needs the panel's rare/common tables")
         if self.params.method not in ("diploid", "nipt"):
             raise ValueError("method is 'diploid' or 'nipt'")
-        if self.params.method == "nipt" and self.params.impute_rare_common:
-            raise NotImplementedError("impute_rare_common with method = 'nipt' (rare_common.R:195-205) is not built")
         self.n_label = 3 if self.params.method == "nipt" else 2
         self.cols = thinned_grid_columns(panel.nGrids, self.params.heuristic_match_thin)
         self.n_thin = int((self.cols >= 0).sum())
@@ -526,12 +566,12 @@ class Driver:
         n_try = 0
         while pending:
             groups = {}
-            for i in pending:   # one launch set per (maxDifferenceBetweenReads, fetal fraction)
-                groups.setdefault((maxdiff[i], float(samples[i].ff) if P.method == "nipt" else 0.0), []).append(i)
+            for i in pending:
+                groups.setdefault(maxdiff[i], []).append(i)
             nxt = []
-            for (md, ff), idx in groups.items():
-                if P.method == "nipt":
-                    kw = dict(kw, ff=ff, shuffle_bin_radius=P.shuffle_bin_radius)
+            for md, idx in groups.items():
+                if P.method == "nipt":   # every chain carries its sample's fetal fraction (functions.R:128)
+                    kw = dict(kw, ff=[float(chains[i].sample.ff) for i in idx], shuffle_bin_radius=P.shuffle_bin_radius)
                 out = self.backend.gibbs_batch(
                     [samples[i] for i in idx], [chains[i].which_haps_to_use for i in idx],
                     [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],
@@ -560,16 +600,20 @@ class Driver:
         t0 = time.perf_counter()
         common = rc.snp_is_common == 1
         reads = [ch.sample.all_snp for ch in chains]
+        nL = self.n_label
         haps = []
         for ch in chains:
-            e = np.full((2, rc.nSNPs_all), 0.5)
-            e[0, common] = ch.hap[0]
-            e[1, common] = ch.hap[1]
-            haps.append([e[0], e[1]])
+            e = np.full((nL, rc.nSNPs_all), 0.5)
+            for l in range(nL):
+                e[l, common] = ch.hap[l]
+            haps.append([e[l] for l in range(nL)])
         lik = self.backend.read_likelihood_all_snps_batch(reads, haps, P.maxDifferenceBetweenReads)
         starts, seed_reads, seed_shards = [], [], []
         for ch, e in zip(chains, lik):
-            starts.append(get_initial_read_labels(e, ch.rng.random(e.shape[1])))
+            if P.method == "nipt":
+                starts.append(get_initial_read_labels_nipt(e, ch.sample.ff, ch.rng))
+            else:
+                starts.append(get_initial_read_labels(e, ch.rng.random(e.shape[1])))
             seed_reads.append(int(ch.rng.integers(0, 2 ** 63)))
             seed_shards.append(int(ch.rng.integers(0, 2 ** 63)))
         t1 = time.perf_counter()
@@ -578,7 +622,7 @@ class Driver:
         results = self._gibbs_with_retry(chains, reads, starts, seed_reads, [0] * len(chains), seed_shards,
                                          gibbs_initialize_iteratively=False, rare_common=True)
         for ch, res in zip(chains, results):
-            ch.hap_all = [res["hapProbs_t"][0], res["hapProbs_t"][1]]
+            ch.hap_all = [res["hapProbs_t"][l] for l in range(nL)]
         self.timing["gibbs"] += time.perf_counter() - t1
 
     def _new_batch(self, samples, offset: int) -> _Batch:
@@ -588,11 +632,13 @@ class Driver:
         chains = [ChainState(samples[i], i, c, chain_rng(P.seed, offset + i, c))
                   for i in range(N) for c in range(1, P.nGibbsSamples + 1)]
         b = _Batch(list(samples), offset, chains, np.zeros((N, T)), np.zeros((N, 3, T)), np.zeros(N, dtype=np.int64))
-        if P.method == "nipt":
+        if P.method == "nipt" and not P.impute_rare_common:
             b.fet_dosage, b.fet_gp_t = np.zeros((N, T)), np.zeros((N, 3, T))
         if P.impute_rare_common:
             Ta = self.rare_common.nSNPs_all
             b.dosage_all, b.gp_t_all, b.nDosage_all = np.zeros((N, Ta)), np.zeros((N, 3, Ta)), np.zeros(N, dtype=np.int64)
+            if P.method == "nipt":
+                b.fet_dosage, b.fet_gp_t = np.zeros((N, Ta)), np.zeros((N, 3, Ta))
         return b
 
     def _start_phasing(self, b: _Batch):
@@ -617,9 +663,16 @@ class Driver:
         out = []
         rc = self.params.impute_rare_common
         for i in range(len(b.samples)):
-            if rc:   # the switch-over to all SNPs (functions.R:1232-1240, 1305-1307)
+            if rc:   # the switch-over to all SNPs (functions.R:1232-1252, 1305-1317)
                 d = b.dosage_all[i] / b.nDosage_all[i]
                 g = b.gp_t_all[i] / b.nDosage_all[i]
+                if self.params.method == "nipt":
+                    fd, fg = b.fet_dosage[i] / b.nDosage_all[i], b.fet_gp_t[i] / b.nDosage_all[i]
+                    ph = b.phasing[i].hap_all
+                    h1, h2, h3 = recast_nipt_haps(ph[0], ph[1], ph[2], g, fg)
+                    out.append(SampleResult(d, g, np.stack([h1, h2, h3], axis=1), b.consensus[i], int(b.nDosage_all[i]),
+                                            fet_dosage=fd, fet_gp_t=fg))
+                    continue
                 h1, h2 = recast_haps(b.phasing[i].hap_all[0], b.phasing[i].hap_all[1], g.T)
                 out.append(SampleResult(d, g, np.stack([h1, h2], axis=1), b.consensus[i], int(b.nDosage_all[i])))
                 continue
@@ -655,7 +708,7 @@ class Driver:
                         h1, h2 = ch.hap[0], ch.hap[1]
                         cur.dosage[ch.i_sample] += h1 + h2
                         cur.gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
-                        if P.method == "nipt":   # functions.R:1009-1016: fetus = maternal transmitted + paternal transmitted
+                        if P.method == "nipt" and not P.impute_rare_common:   # functions.R:1009-1016: fetus = maternal transmitted + paternal transmitted
                             h3 = ch.hap[2]
                             cur.fet_dosage[ch.i_sample] += h1 + h3
                             cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
@@ -663,9 +716,13 @@ class Driver:
             if P.impute_rare_common:   # functions.R:1042-1123
                 self._rare_common_round((cur.chains if cur else []) + (prev.phasing if prev else []))
                 for ch in (cur.chains if cur else []):
-                    h1, h2 = ch.hap_all
+                    h1, h2 = ch.hap_all[0], ch.hap_all[1]
                     cur.dosage_all[ch.i_sample] += h1 + h2
                     cur.gp_t_all[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
+                    if P.method == "nipt":   # functions.R:1113-1120
+                        h3 = ch.hap_all[2]
+                        cur.fet_dosage[ch.i_sample] += h1 + h3
+                        cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
                     cur.nDosage_all[ch.i_sample] += 1
             import time
             t0 = time.perf_counter()

@@ -29,6 +29,7 @@ class GibbsOpts(C.Structure):
         ("gibbs_initialize_iteratively", C.c_int32), ("disable_read_category_usage", C.c_int32),
         ("class_sum_cutoff", C.c_double),
         ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int32), ("block_gibbs_quantile_prob", C.c_double),
+        ("ff_chain", C.c_void_p),
     ]
 
 
@@ -61,6 +62,10 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     lib().qa_gibbs_batch.restype = C.c_int
     lib().qa_gibbs_batch_rare_common.restype = C.c_int
     import os, time
+    ffc = None
+    if np.ndim(ff) > 0:   # one fetal fraction per chain (NIPT)
+        ffc = np.ascontiguousarray(ff, dtype=np.float64)
+        ff = float(ffc[0])
     _t0 = time.perf_counter()
     P = panel.panel
     G, T = P.nGrids, P.nSNPs
@@ -123,7 +128,7 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                      int(n_gibbs_burn_in_its), int(n_gibbs_sample_its), ptr(blocks), int(len(blocks)),
                      int(perform_block_gibbs), int(ff == 0), int(gibbs_initialize_iteratively),
                      int(disable_read_category_usage), float(class_sum_cutoff), ptr(Lg), int(shuffle_bin_radius),
-                     float(block_gibbs_quantile_prob))
+                     float(block_gibbs_quantile_prob), ptr(ffc))
     _t1 = time.perf_counter()
     tail = (C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(ru),
             ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap), ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))

@@ -223,14 +223,15 @@ def rare_common_hap_bits(panel: Panel, rc: RareCommon, k: int) -> np.ndarray:
     return out
 
 
-def make_synthetic_sample_rare_common(panel: Panel, rc: RareCommon, seed: int, n_reads: Optional[int] = None):
+def make_synthetic_sample_rare_common(panel: Panel, rc: RareCommon, seed: int, n_reads: Optional[int] = None,
+                                      ff: float = 0.0):
     """One diploid sample read twice, as get_and_impute_one_sample does with ``impute_rare_common``
     (functions.R:130-175): over all SNPs (``allSNP_sampleReads``) and over the common SNPs only.  Returns
     ``(sample_common, sample_all)``; reads without a common SNP are absent from the first."""
     rng = np.random.default_rng(seed)
     T_all = rc.nSNPs_all
     truth = []
-    for _ in range(2):
+    for _ in range(3 if ff > 0 else 2):
         nseg = int(rng.integers(3, 7))
         cuts = np.sort(rng.choice(np.arange(1, T_all), size=nseg - 1, replace=False))
         bounds = np.r_[0, cuts, T_all]
@@ -248,7 +249,7 @@ def make_synthetic_sample_rare_common(panel: Panel, rc: RareCommon, seed: int, n
     central = start + (nsnp - 1) // 2
     order = np.argsort(central, kind="stable")
     start, nsnp, central = start[order], nsnp[order], central[order]
-    label = rng.integers(1, 3, size=n_reads)
+    label = (rng.choice(3, size=n_reads, p=[0.5, 0.5 - ff / 2, ff / 2]) + 1) if ff > 0 else rng.integers(1, 3, size=n_reads)
     us, bqs = [], []
     for r in range(n_reads):
         idx = np.arange(start[r], start[r] + nsnp[r])
@@ -279,5 +280,6 @@ def make_synthetic_sample_rare_common(panel: Panel, rc: RareCommon, seed: int, n
         com_bq.append(b[m])
     s_com = pack(com_u, com_bq, label, panel.nSNPs)
     s_com.truth_haps = truth[:, rc.snp_is_common == 1]
+    s_com.ff = s_all.ff = ff
     s_com.all_snp = s_all
     return s_com, s_all

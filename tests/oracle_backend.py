@@ -22,12 +22,14 @@ class OracleBackend:
         nb = len(block_gibbs_iterations)
         G = self.rare_common.nGrids_all if rare_common else self.panel.nGrids
         extra = dict(rare_common=self.rare_common, disable_read_category_usage=True) if rare_common else {}
-        for s, w, h, sr, fr, ss in zip(samples, which, starts, seed_reads, first_reads, seed_shards):
+        ffs = list(ff) if np.ndim(ff) > 0 else [ff] * len(samples)
+        for s, w, h, sr, fr, ss, ff in zip(samples, which, starts, seed_reads, first_reads, seed_shards, ffs):
             ru = stream_uniform(sr, s.nReads * n_its)
             if ff != 0:   # NIPT: the block passes' uniforms, [pass][block choice | label re-draw][read] of the same stream
                 blk = stream_uniform(ss, nb * 2 * s.nReads).reshape(nb, 2, s.nReads)
                 extra = dict(extra, ff=ff, runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy(),
-                             shuffle_bin_radius=shuffle_bin_radius)
+                             shuffle_bin_radius=shuffle_bin_radius,
+                             L_grid=self.rare_common.L_grid_all if rare_common else None)
                 rs = np.zeros(nb * G)
             else:
                 rs = stream_uniform(ss, nb * (G - 1))

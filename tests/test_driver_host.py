@@ -136,7 +136,7 @@ def test_nipt_pipeline_on_the_oracle():
     from tests.oracle_backend import OracleBackend
     from tests.util import r2
     panel = make_synthetic_panel(K=400, nSNPs=640, seed=21)
-    samples = [make_synthetic_sample(panel, seed=70 + i, n_reads=300, ff=0.2) for i in range(3)]
+    samples = [make_synthetic_sample(panel, seed=70 + i, n_reads=300, ff=0.15 + 0.05 * i) for i in range(3)]
     prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method="nipt")
     one = D.Driver(panel, OracleBackend(panel), prm).run(samples)
     for smp, r in zip(samples, one):
@@ -164,3 +164,27 @@ def test_nipt_consensus_and_recast():
     a, b, c = D.recast_nipt_haps(h1, h2, h3, mat, fet)
     # site 0: (1, 1) with rounded haps (1, 0, 0) kept; site 1: (1, 0) -> (0, 1, 0); site 2: (2, 2) -> all 1; site 3: (0, 1) -> (0, 0, 1)
     assert (a.tolist(), b.tolist(), c.tolist()) == ([1, 0, 1, 0], [0, 1, 1, 0], [0, 0, 1, 1])
+
+
+def test_nipt_rare_common_pipeline_on_the_oracle():
+    """impute_rare_common with method = "nipt": all-SNP starting labels by read grouping (gibbs-nipt.R:1655-1849), the
+    all-SNP Gibbs call with three labels and its block Gibbs on the all-SNP grid, mother / fetus outputs over all SNPs."""
+    from quilt_amd.synth import make_rare_common, make_synthetic_panel, make_synthetic_sample_rare_common
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=400, nSNPs=640, seed=21)
+    rc = make_rare_common(panel, 3)
+    samples = [make_synthetic_sample_rare_common(panel, rc, 90 + i, n_reads=300, ff=0.2)[0] for i in range(2)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method="nipt", impute_rare_common=True)
+    res = D.Driver(panel, OracleBackend(panel, rc), prm, rare_common=rc).run(samples)
+    for r in res:
+        assert r.dosage.shape == r.fet_dosage.shape == (rc.nSNPs_all,) and r.phasing_haps.shape == (rc.nSNPs_all, 3)
+        np.testing.assert_allclose(r.gp_t.sum(axis=0), 1.0, atol=1e-9)
+        np.testing.assert_allclose(r.fet_gp_t.sum(axis=0), 1.0, atol=1e-9)
+
+
+def test_nipt_initial_labels_by_grouping():
+    assert D.preserve_round(np.array([1.5, 2.5, 3.0])).tolist() == [1, 3, 3] and D.preserve_round(np.array([0.2, 0.8])).tolist() == [0, 1]
+    rng = np.random.default_rng(1)
+    e = np.array([[1.0, 0.1, 1.0, 0.2, 1.0], [0.1, 1.0, 1.0, 0.1, 0.9], [0.2, 0.2, 0.1, 1.0, 0.8]])
+    H = D.get_initial_read_labels_nipt(e, 0.2, rng)
+    assert H[0] == 1 and H[1] == 2 and H[3] == 3 and H[2] in (1, 2) and H[4] in (1, 2, 3)

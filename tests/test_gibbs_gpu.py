@@ -280,8 +280,9 @@ def test_nipt_block_gibbs_seeded_batch(medium_panel, oracle):
     dev = DevicePanel(panel)
     rng = np.random.default_rng(9)
     samples, whichs, H0s, srs, sss, refs = [], [], [], [], [], []
+    ffs = [0.1, 0.15, 0.25]   # one launch set, a fetal fraction per chain
     for c in range(3):
-        ff = 0.15
+        ff = ffs[c]
         s = make_synthetic_sample(panel, seed=40 + c, n_reads=500 + 100 * c, ff=ff)
         which = np.sort(rng.choice(panel.K, 600, replace=False)).astype(np.int32) + 1
         H0 = rng.choice([1, 2, 3], p=[0.5, 0.4, 0.1], size=s.nReads).astype(np.int32)
@@ -292,7 +293,7 @@ def test_nipt_block_gibbs_seeded_batch(medium_panel, oracle):
         refs.append(oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, 0, np.zeros(3 * panel.nGrids), ff=ff,
                                                     runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy()))
         samples.append(s); whichs.append(which); H0s.append(H0); srs.append(sr); sss.append(ss)
-    got = forwardBackwardGibbsNIPT_batch(dev, samples, whichs, H0s, None, [0, 0, 0], None, ff=0.15, seed_reads=srs,
+    got = forwardBackwardGibbsNIPT_batch(dev, samples, whichs, H0s, None, [0, 0, 0], None, ff=ffs, seed_reads=srs,
                                          seed_shard=sss)
     for g, r in zip(got, refs):
         assert np.array_equal(g["H"], r["H"]) and np.array_equal(g["H_class"], r["H_class"])

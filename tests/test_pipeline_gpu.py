@@ -170,7 +170,7 @@ def test_pipeline_nipt(medium_panel):
     from quilt_amd.synth import make_synthetic_sample
     from tests.oracle_backend import OracleBackend
     panel = medium_panel
-    samples = [make_synthetic_sample(panel, seed=3000 + i, n_reads=1000, ff=0.2) for i in range(3)]
+    samples = [make_synthetic_sample(panel, seed=3000 + i, n_reads=1000, ff=0.15 + 0.05 * i) for i in range(3)]   # one launch, three fetal fractions
     prm = DriverParams(nGibbsSamples=3, Ksubset=200, Knew=200, seed=5, method="nipt")
     dev = DevicePanel(panel)
     got = Driver(panel, HipBackend(dev), prm).run(samples)

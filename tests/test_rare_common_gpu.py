@@ -135,3 +135,28 @@ def test_rare_common_pipeline_matches_oracle(medium_panel):
         assert abs(r2(g.dosage, truth) - r2(r.dosage, truth)) < 0.02
     drc.close()
     dev.close()
+
+
+def test_rare_common_nipt_pipeline_matches_oracle(medium_panel):
+    """impute_rare_common with method = "nipt": the all-SNP call with three labels and its block Gibbs on the all-SNP
+    grid, fetal fractions differing between samples; HIP backend vs oracle backend."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    from tests.oracle_backend import OracleBackend
+    from tests.util import r2
+    panel = medium_panel
+    rc = make_rare_common(panel, 4)
+    samples = [make_synthetic_sample_rare_common(panel, rc, 2500 + i, n_reads=800, ff=0.15 + 0.1 * i)[0] for i in range(2)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=5, impute_rare_common=True, method="nipt")
+    dev = DevicePanel(panel)
+    drc = DeviceRareCommon(dev, rc)
+    got = Driver(panel, HipBackend(dev, drc), prm, rare_common=rc).run(samples)
+    ref = Driver(panel, OracleBackend(panel, rc), prm, rare_common=rc).run(samples)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.read_labels, r.read_labels)
+        assert g.dosage.shape == (rc.nSNPs_all,) and g.phasing_haps.shape == (rc.nSNPs_all, 3)
+        assert r2(g.dosage, r.dosage) >= 0.999 and r2(g.fet_dosage, r.fet_dosage) >= 0.999
+        assert np.abs(g.dosage - r.dosage).max() <= 1e-4 and np.abs(g.fet_dosage - r.fet_dosage).max() <= 1e-4
+    drc.close()
+    dev.close()
