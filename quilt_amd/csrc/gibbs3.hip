@@ -14,8 +14,10 @@
 
 namespace {
 
+// (two waves per chain must also mean two waves per SIMD -- 256 registers each -- or 1024 chains would not be resident
+// together: amdgpu_waves_per_eu)
 template <int NE, int NW>
-__global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) void k_gibbs3(GibbsParams p) {
     __shared__ double s_red[2 * NW * 4];
     const int c = blockIdx.x, t = threadIdx.x;
     using CH = Chain<NE, NW>;
@@ -200,6 +202,19 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
         // ================= rcpp_gibbs_nipt_iterate (:1756-1956) =================
         Col<NE> a[NH];
         int iRead = 0;
+        // the reads' scalars (grid, label, class, category, uniform) as lane-held streams: one vector load per 64 reads
+        // instead of a dependent uniform load per read and field (gibbs_dev.hpp)
+        ReadStreams<CH> rs;
+        bool rs_dirty = false;
+        auto rs_load = [&](int base) {
+            rs.load(ch, base, runif, it);
+            if (!runif) rs.u = stream_uniform(seed_reads, (uint64_t)R * it + base + ch.lane);
+        };
+        rs_load(0);
+        // the next read's compact emission (pattern bytes + table entry) is fetched one read ahead, unconditionally
+        // (clamped index): its latency hides behind the current read's arithmetic
+        typename CH::ErPre pre{};
+        if (R > 0) ch.ld_pre(pre, 0);
         for (int g = 0; g < G; g++) {
             Col<NE> e[NH], bt[NH];
             double cg[NH];
@@ -254,7 +269,13 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
             Col<NE> ab[NH];
             double pC[3] = {1, 1, 1};
             bool normal = false, ginit = false, pass = false;
-            while (iRead < R && uni_i(ch.wif[iRead]) == g) {
+            while (iRead < R) {
+                if (iRead >= rs.base + 64) {
+                    if (rs_dirty) { rs.store(ch); rs_dirty = false; }
+                    rs_load(iRead);
+                }
+                const int j = iRead - rs.base;
+                if (rl_i32(rs.wif, j) != g) break;
                 const int r = iRead;
                 iRead++;
                 // (not diploid: reads of every category are visited, :815)
@@ -271,23 +292,29 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
                     sum3(ab, pC);
                     grid_started = true;
                 }
-                Col<NE> er;
-                emission_of(er, r);
+                Col<NE> er, rer;   // the read's emission column and its reciprocal (x * (1 / e) for the reference's x / e,
+                {                  // as in the two-label kernel: <= 1 ulp apart)
+                    const typename CH::ErPre x = pre;
+                    ch.ld_pre(pre, min(r + 1, R - 1));
+                    ch.read_emission(er, x, rl_i32(rs.dn, j));
+                }
                 int h_rC = 0, h_rA1 = 1, h_rA2 = 2;
                 double pA1[3] = {pC[0], pC[1], pC[2]}, pA2[3] = {pC[0], pC[1], pC[2]};
                 if (normal) {
-                    h_rC = uni_i(ch.H[r]) - 1;
+#pragma unroll
+                    for (int i = 0; i < NE; i++) rer.v[i] = fast_rcp(er.v[i]);
+                    h_rC = rl_i32(rs.H, j) - 1;
                     if (h_rC == 0) { h_rA1 = 1; h_rA2 = 2; }
                     else if (h_rC == 1) { h_rA1 = 0; h_rA2 = 2; }
                     else { h_rA1 = 0; h_rA2 = 1; }
-                    if (uni_i(ch.cat1[r]) == 0) {
+                    if (rl_i32(rs.cat1, j) == 0) {
                         // dense form for categories 0, 2 and 3 (the sparse updates of 2 / 3 are the same sums)
                         double s[3] = {0, 0, 0};
 #pragma unroll
                         for (int h = 0; h < NH; h++) {
                             double acc = 0;
 #pragma unroll
-                            for (int i = 0; i < NE; i++) acc += (h == h_rC) ? ab[h].v[i] / er.v[i] : ab[h].v[i] * er.v[i];
+                            for (int i = 0; i < NE; i++) acc += ab[h].v[i] * ((h == h_rC) ? rer.v[i] : er.v[i]);
                             s[h] = acc;
                         }
                         ch.template bsum<3>(s);
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
                 const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * (h_rA2 == 0 ? pp[0] : h_rA2 == 1 ? pp[1] : pp[2]);
                 const double denom = prod_pC + prod_pA1 + prod_pA2;
                 const double norm_pC = prod_pC / denom, norm_pA1 = prod_pA1 / denom, norm_pA2 = prod_pA2 / denom;
-                const double chance = runif ? uni_d(&runif[(size_t)R * it + r]) : stream_uniform(seed_reads, (uint64_t)R * it + r);
+                const double chance = rl_f64(rs.u, j);
                 double x3[3];
                 x3[h_rC] = norm_pC; x3[h_rA1] = norm_pA1; x3[h_rA2] = norm_pA2;
                 const double cs0 = x3[0], cs1 = x3[1] + cs0, cs2 = x3[2] + cs1;
@@ -323,12 +350,13 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
                 if (chance < cs0) h_rN = 0;
                 if (((h_rN != h_rC) || ginit) && !pass) {
                     changed = true;
-                    if (t == 0) ch.H[r] = h_rN + 1;
+                    if (ch.lane == j) rs.H = h_rN + 1;
+                    rs_dirty = true;
 #pragma unroll
                     for (int h = 0; h < NH; h++) {
                         if (normal && h == h_rC) {
 #pragma unroll
-                            for (int i = 0; i < NE; i++) { a[h].v[i] /= er.v[i]; ab[h].v[i] /= er.v[i]; e[h].v[i] /= er.v[i]; }
+                            for (int i = 0; i < NE; i++) { a[h].v[i] *= rer.v[i]; ab[h].v[i] *= rer.v[i]; e[h].v[i] *= rer.v[i]; }
                         }
                     }
 #pragma unroll
@@ -355,7 +383,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
                         const double y = fabs(rlc[i][0] - x3[0]) + fabs(rlc[i][1] - x3[1]) + fabs(rlc[i][2] - x3[2]);
                         if (y < local_min) { local_min = y; which = i; }
                     }
-                    if (t == 0) ch.Hc[r] = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
+                    if (ch.lane == j) rs.Hc = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
+                    rs_dirty = true;
                 }
             }
             if (changed) {
@@ -377,6 +406,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs3(GibbsParams p) {
                 if (t == 0) ch.cv[h][g] = cg[h];
             }
         }
+        if (rs_dirty) rs.store(ch);
         chain_sync<NW>();
         backward_full(true);
         // ---- underflow check (:2959-2969): with ff != 0 the third label's c is not looked at
