@@ -45,7 +45,7 @@
 #include "gibbs_blocks.hpp"
 
 namespace qa {
-int gibbs3_waves(int Ksp);
+int gibbs3_waves(int Ksp, int C, int share);
 void launch_gibbs3(const void *gibbs_params, hipStream_t st);
 void launch_block_rate3(const void *gibbs_params, hipStream_t st);
 void launch_block3(const void *gibbs_params, hipStream_t st);
@@ -985,7 +985,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         std::vector<size_t> eoff(C), ixoff(C);
         std::vector<uint8_t> ghr((size_t)C * G, 0);
         std::vector<int32_t> dense_of(std::max(totR, 1), -1);
-        const int nw = o->ff != 0.0 ? qa::gibbs3_waves(Ksp) : choose_gibbs_waves(Ksp, C, pn->share);
+        const int nw = o->ff != 0.0 ? qa::gibbs3_waves(Ksp, C, pn->share) : choose_gibbs_waves(Ksp, C, pn->share);
         const int er_nt = 64 * nw, er_padb = padb_of(NE / nw);
         int maxR = 0;
         size_t etot = 0, ixtot = 0;

@@ -509,10 +509,32 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
     const uint64_t seed = p.seed_shard ? p.seed_shard[c] : 0;
     auto u_block = [&](int i) { return ru ? ru[i] : stream_uniform(seed, (uint64_t)p.blk_pass * 2 * R + i); };
     auto u_draw = [&](int r) { return ru ? ru[R + r] : stream_uniform(seed, (uint64_t)p.blk_pass * 2 * R + R + r); };
+    // The block kernel runs two waves per chain at Ksp = 640 (its 18 columns need it) even when the sampler, and with it
+    // the compact read emissions, were laid out for one wave of 10 rows per lane: then row l + 64 (w + 2 i) of this thread
+    // (lane l, wave w) is byte w + 2 i of lane l's 16-byte pack.
+    const bool foreign = NW == 2 && p.er_nt == 64;
     auto emission_of = [&](Col<NE> &er, int r) {
-        typename CH::ErPre x;
-        ch.ld_pre(x, r);
-        ch.read_emission(er, x, uni_i(ch.dense_of[r]));
+        const int dn = uni_i(ch.dense_of[r]);
+        if (dn >= 0) { ch.ld(er, ch.eMatRead + (size_t)dn * Ksp); return; }
+        if (!foreign) {
+            typename CH::ErPre x;
+            ch.ld_pre(x, r);
+            ch.expand(er, x);
+            return;
+        }
+        const uint4 q = *reinterpret_cast<const uint4 *>(ch.eridx + ((size_t)r * 64 + ch.lane) * 16);
+        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+        const double tv = ch.ertab[(size_t)r * 64 + ch.lane];
+        const int lo = __double2loint(tv), hi = __double2hiint(tv);
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            uint32_t code = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++)   // byte ch.wave + 2 i, without dynamic register indexing
+                if (b == ch.wave + 2 * i) code = (w4[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+            const int src = (int)code << 2;
+            er.v[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, hi), __builtin_amdgcn_ds_bpermute(src, lo));
+        }
     };
     auto sum3 = [&](const Col<NE> (&x)[NH], double (&s)[NH]) {
 #pragma unroll
@@ -854,8 +876,17 @@ void launch_one(const GibbsParams &prm, hipStream_t st) {
 
 namespace qa {
 
-// geometry: two waves per chain for Ksp = 640 (5 columns per lane and label), one otherwise
-int gibbs3_waves(int Ksp) { return Ksp == 640 ? 2 : 1; }
+// geometry at Ksp = 640: one wave per chain (10 columns per lane and label, a SIMD's whole register file) when the launch
+// fills the device's 1024 SIMDs anyway, two waves (5 columns, 256 registers) for few chains; one wave otherwise
+int gibbs3_waves(int Ksp, int C, int share) {
+    if (Ksp != 640) return 1;
+    int nw = ((long)C * 2 <= 1024 / share) ? 2 : 1;
+    if (const char *forced = getenv("QA_GIBBS_NW")) {   // test hook
+        const int f = atoi(forced);
+        if (f == 1 || f == 2) nw = f;
+    }
+    return nw;
+}
 
 void launch_gibbs3(const void *params, hipStream_t st) {
     const GibbsParams &prm = *static_cast<const GibbsParams *>(params);
@@ -867,7 +898,10 @@ void launch_gibbs3(const void *params, hipStream_t st) {
         case 5: launch_one<5, 1>(prm, st); break;
         case 6: launch_one<6, 1>(prm, st); break;
         case 8: launch_one<8, 1>(prm, st); break;
-        case 10: launch_one<5, 2>(prm, st); break;
+        case 10:
+            if (prm.er_nt == 64) launch_one<10, 1>(prm, st);
+            else launch_one<5, 2>(prm, st);
+            break;
         default: throw std::runtime_error("NIPT sampler: Ksubset geometry not built (Ksubset / 64 rounded up must be 1..6, 8 or 10)");
     }
 }

@@ -300,3 +300,30 @@ def test_nipt_block_gibbs_seeded_batch(medium_panel, oracle):
         np.testing.assert_allclose(g["hapProbs_t"], r["hapProbs_t"], rtol=RTOL, atol=1e-14)
     dev.close()
     dev.close()
+
+
+
+@pytest.mark.parametrize("nw", ["1", "2"])
+def test_nipt_every_chain_geometry(medium_panel, oracle, nw, monkeypatch):
+    """Ksubset = 600 in NIPT mode: the sampler with one wave per chain (10 rows per lane) or two; the block kernel always
+    runs two waves and reads the compact emissions in whichever layout the sampler's geometry produced."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    monkeypatch.setenv("QA_GIBBS_NW", nw)
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    ff = 0.2
+    s = make_synthetic_sample(panel, seed=33, n_reads=700, ff=ff)
+    rng = np.random.default_rng(8)
+    which = np.sort(rng.choice(panel.K, 600, replace=False)).astype(np.int32) + 1
+    R = s.nReads
+    H0 = rng.choice([1, 2, 3], p=[0.5, 0.4, 0.1], size=R).astype(np.int32)
+    ru, rb, rr = rng.random(R * 21), rng.random(3 * R), rng.random(3 * R)
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, 5, np.zeros(3 * panel.nGrids), ff=ff,
+                                          gibbs_initialize_iteratively=True, runif_block=rb, runif_resample=rr)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, 5, None, ff=ff, gibbs_initialize_iteratively=True,
+                                        runif_block=rb, runif_resample=rr)
+    assert np.array_equal(got["H"], ref["H"]) and np.array_equal(got["H_class"], ref["H_class"])
+    np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    dev.close()
