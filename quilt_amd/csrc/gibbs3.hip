@@ -375,7 +375,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                         if (h_rN == 2) for (int i = 0; i < 3; i++) pC[i] = pA2[i];
                     }
                 }
-                {   // record_read_set (:1142-1165)
+                if (it == p.it_end - 1) {
+                    // record_read_set (:1142-1165): H_class is overwritten for every read in every sweep and read only by
+                    // the block pass after a segment or by the caller, so only a segment's last sweep computes it
                     double local_min = 2;
                     int which = 8;
 #pragma unroll
