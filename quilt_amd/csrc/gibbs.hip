@@ -29,7 +29,9 @@
 // :1896-1898), every choice_log_probs entry is NaN (:661-675), ir_chosen stays 0 (:741-752), the
 // "No change warranted" branch is taken (:830) and the final backward (:1947-1954) reproduces the beta
 // the sweep already holds.  The shard resampler is the active step and is implemented here.
-// NIPT (ff > 0) block Gibbs is not implemented yet (QA_ERR_UNSUPPORTED).
+// NIPT (ff > 0): the three-label sampler and its block Gibbs are in gibbs3.hip / gibbs_blocks.hpp; this file drives
+// them (segments of sweeps with a block pass between them, gibbs_chunk) and holds the panel-facing kernels both modes
+// share, including the rare + common forms (k_ematread's rare branch in gibbs_dev.hpp, k_happrobs_rc).
 #include "panel.hpp"
 
 #include <chrono>
