@@ -329,6 +329,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 if ((iRead & 63) == 0 && rs.base != iRead) {
                     if (rs.base >= 0) rs.store(ch);
                     rs.load(ch, iRead, runif, it);
+                    // counter-based uniforms: 64 at a time, one per lane, instead of one on the scalar unit per read
+                    if (!runif) rs.u = stream_uniform(seed_reads, (uint64_t)R * it + iRead + lane);
                 }
                 const int jr = iRead & 63;
                 if (rl_i32(rs.wif, jr) != g) break;
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 const double denom = P + Q;
                 const double rden = fast_rcp(denom);
                 const double norm_pC = P * rden, norm_pA1 = Q * rden;
-                const double chance = runif ? rl_f64(rs.u, jr) : stream_uniform(seed_reads, (uint64_t)R * it + r);
+                const double chance = rl_f64(rs.u, jr);
                 const double p0 = (h_rC == 0) ? norm_pC : norm_pA1, p1 = (h_rC == 0) ? norm_pA1 : norm_pC;
                 const double cs0 = p0, cs1 = p1 + p0;
                 const int h_rN = (chance < cs0) ? 0 : ((chance < cs1) ? 1 : 0);
