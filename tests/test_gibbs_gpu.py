@@ -327,3 +327,36 @@ def test_nipt_every_chain_geometry(medium_panel, oracle, nw, monkeypatch):
     assert np.array_equal(got["H"], ref["H"]) and np.array_equal(got["H_class"], ref["H_class"])
     np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
     dev.close()
+
+
+
+def test_nipt_edge_inputs(small_panel, oracle):
+    """NIPT block Gibbs on awkward inputs: a handful of reads (blocks without reads are merged away, possibly all but
+    one), reads piled on the first / last grid, a single block."""
+    import copy
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = small_panel
+    dev = DevicePanel(panel)
+    ff = 0.3
+    rng = np.random.default_rng(12)
+    which = np.sort(rng.choice(panel.K, 70, replace=False)).astype(np.int32) + 1
+    G = panel.nGrids
+    cases = []
+    for n_reads in (2, 3, 7):
+        cases.append(make_synthetic_sample(panel, seed=60 + n_reads, n_reads=n_reads, ff=ff))
+    s = copy.deepcopy(make_synthetic_sample(panel, seed=70, n_reads=40, ff=ff))
+    s.wif[:20] = 0; s.u[: s.read_ptr[20]] %= 32
+    s.wif[20:] = G - 1; s.u[s.read_ptr[20]:] = 32 * (G - 1) + s.u[s.read_ptr[20]:] % (panel.nSNPs - 32 * (G - 1))
+    cases.append(s)
+    for s in cases:
+        R = s.nReads
+        H0 = rng.choice([1, 2, 3], p=[0.5, 0.35, 0.15], size=R).astype(np.int32)
+        ru, rb, rr = rng.random(R * 21), rng.random(3 * R), rng.random(3 * R)
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, 0, np.zeros(3 * G), ff=ff, runif_block=rb, runif_resample=rr)
+        got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, 0, None, ff=ff, runif_block=rb, runif_resample=rr)
+        assert ref["status"] == 0 and not got["underflow_problem"]
+        assert np.array_equal(got["H"], ref["H"]) and np.array_equal(got["H_class"], ref["H_class"]), R
+        np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    dev.close()

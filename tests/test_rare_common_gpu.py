@@ -167,3 +167,41 @@ def test_rare_common_nipt_pipeline_matches_oracle(medium_panel):
         assert np.abs(g.dosage - r.dosage).max() <= 1e-4 and np.abs(g.fet_dosage - r.fet_dosage).max() <= 1e-4
     drc.close()
     dev.close()
+
+
+def test_rare_common_degenerate_tables(small_panel, oracle):
+    """No rare SNP at all (every SNP common: the call must equal the ordinary one), and rare SNPs nobody carries."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample, make_synthetic_sample_rare_common
+    panel = small_panel
+    dev = DevicePanel(panel)
+    rng = np.random.default_rng(4)
+    which = np.sort(rng.choice(panel.K, 90, replace=False)).astype(np.int32) + 1
+    # (a) all SNPs common
+    rc0 = make_rare_common(panel, 1, n_rare=0)
+    assert rc0.nSNPs_all == panel.nSNPs
+    s = make_synthetic_sample(panel, seed=8, n_reads=150)
+    R = s.nReads
+    H0 = rng.integers(1, 3, size=R).astype(np.int32)
+    ru, rs = rng.random(R * 21), rng.random(3 * (panel.nGrids - 1))
+    d0 = DeviceRareCommon(dev, rc0)
+    a = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, 0, rs, rare_common=d0)
+    b = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, 0, rs)
+    assert np.array_equal(a["H"], b["H"])
+    np.testing.assert_allclose(a["hapProbs_t"], b["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    d0.close()
+    # (b) rare SNPs without carriers: common factors that rescaling removes; hapProbs = ref_error there
+    rc1 = make_rare_common(panel, 2, carriers=(0, 0))
+    _, s_all = make_synthetic_sample_rare_common(panel, rc1, 9, n_reads=150)
+    R = s_all.nReads
+    H0 = rng.integers(1, 3, size=R).astype(np.int32)
+    ru, rs = rng.random(R * 21), rng.random(3 * (rc1.nGrids_all - 1))
+    d1 = DeviceRareCommon(dev, rc1)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s_all, which, H0, ru, 0, rs, rare_common=d1, disable_read_category_usage=True)
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s_all, which, H0, ru, 0, rs, rare_common=rc1, disable_read_category_usage=True)
+    assert np.array_equal(got["H"], ref["H"])
+    np.testing.assert_allclose(got["hapProbs_t"][:2], ref["hapProbs_t"][:2], rtol=RTOL, atol=1e-14)
+    assert np.allclose(got["hapProbs_t"][:2][:, rc1.snp_is_common == 0], panel.ref_error)
+    d1.close()
+    dev.close()
