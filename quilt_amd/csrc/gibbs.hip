@@ -1142,16 +1142,6 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
             S.ff_chain.ensure(C); S.ff_chain.upload(ff_chain, C, st);
             prm.ff_chain = S.ff_chain.p;
         }
-        {   // prior over labels and the read-label class prototypes (gibbs-nipt.cpp:2707-2729)
-            const double ff = o->ff, pp[3] = {0.5, (1 - ff) * 0.5, ff * 0.5};
-            const double r[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1},
-                                    {pp[0] / (pp[0] + pp[1]), pp[1] / (pp[0] + pp[1]), 0},
-                                    {pp[0] / (pp[0] + pp[2]), 0, pp[2] / (pp[0] + pp[2])},
-                                    {0, pp[1] / (pp[1] + pp[2]), pp[2] / (pp[1] + pp[2])},
-                                    {pp[0], pp[1], pp[2]}};
-            for (int i = 0; i < 3; i++) prm.prior_probs[i] = pp[i];
-            for (int i = 0; i < 7; i++) for (int j = 0; j < 3; j++) prm.rlc[i][j] = r[i][j];
-        }
         prm.runif_reads = S.runif_reads.p; prm.first_read = S.first_read.p; prm.runif_shard = S.runif_shard.p;
         prm.seed_reads = seed_reads ? S.seeds.p : nullptr;
         prm.seed_shard = (seed_reads && seed_shard) ? S.seeds.p + C : nullptr;

@@ -44,8 +44,8 @@ struct GibbsParams {
     int init_iteratively;
     // labels: 2 (diploid) or 3 (NIPT: maternal transmitted, maternal untransmitted, paternal transmitted)
     int nH;
-    double prior_probs[3];   // (0.5, (1 - ff) / 2, ff / 2)  (gibbs-nipt.cpp:2707-2729)
-    double rlc[7][3];        // read-label class prototypes of record_read_set (:1142-1165)
+    // (the label priors (0.5, (1 - ff) / 2, ff / 2) and the read-label class prototypes, gibbs-nipt.cpp:2707-2729, are
+    // derived in the kernels from the chain's fetal fraction: ff / ff_chain below)
     int disable_read_category_usage;
     double class_sum_cutoff;
     const double *runif_reads; // [C][R_c * n_its] at offset read_off[c] * n_its
