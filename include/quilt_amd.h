@@ -116,6 +116,15 @@ int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits);
  * logic between native calls) behind the other's kernels. */
 int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers);
 
+/* With several handles sharing a device: confine this handle's Gibbs launches to CUs [index, index + 1) * n_CU / count
+ * (a CU-masked HIP stream).  A Gibbs chain holds a SIMD's whole register file for ~0.7 s; spread over every CU, one
+ * handle's chains leave no CU on which the other handle's full-panel workgroups (one wave per SIMD, most of the LDS) can
+ * start.  The full-panel passes stay on the unmasked stream and use whatever is free.  count = 1 removes the mask.
+ * (Measured on the headline workload with two host threads: 17.5 samples/s with the partition against 19.3 without --
+ * the other thread's passes then run beside the chains at half rate instead of after them at full rate -- so the
+ * driver leaves it off.) */
+int qa_panel_set_cu_partition(qa_panel_t *panel, int32_t index, int32_t count);
+
 /* ---- full-panel haploid forward/backward -------------------------------- */
 
 /* Flags of Rcpp_haploid_dosage_versus_refs (QUILT/src/reference-single.cpp:2214-2227). */

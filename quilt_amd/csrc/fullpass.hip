@@ -1246,6 +1246,7 @@ struct qa_panel::Scratch {
 
 qa_panel::~qa_panel() {
     delete scratch;
+    if (gibbs_stream) (void)hipStreamDestroy(gibbs_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -977,7 +977,10 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         S.er_idx.arena = S.er_tab.arena = &pn->arena;
         S.eMatRead.arena = S.alpha.arena = S.beta.arena = S.eg.arena = S.cvec.arena = S.hap.arena = S.gm.arena = S.gf.arena = &pn->arena;
         pn->arena.reset();
-        hipStream_t st = pn->stream;
+        // the Gibbs launches of a handle that shares the device go to its own CU partition (qa_panel_set_cu_partition): the
+        // chains hold whole register files for the launch's lifetime, and spread over every CU they would leave no CU free
+        // for the other handle's full-panel workgroups
+        hipStream_t st = pn->gibbs_stream ? pn->gibbs_stream : pn->stream;
         const int C = n_chain, G = rc ? rc->G_all : pn->G, T = rc ? rc->T_all : pn->T, Ks = o->Ks;
         const int Ksp = (Ks + 63) / 64 * 64, NE = Ksp / 64;
         const int rc_words = rc ? (T + 31) / 32 : 0;

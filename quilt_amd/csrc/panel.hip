@@ -258,6 +258,26 @@ int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers) {
     return QA_OK;
 }
 
+int qa_panel_set_cu_partition(qa_panel_t *panel, int32_t index, int32_t count) {
+    if (!panel || count < 1 || count > 8 || index < 0 || index >= count) {
+        qa::set_error("qa_panel_set_cu_partition: need 0 <= index < count <= 8");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(panel->device));
+        if (panel->gibbs_stream) { QA_HIP(hipStreamDestroy(panel->gibbs_stream)); panel->gibbs_stream = nullptr; }
+        if (count == 1) return (int)QA_OK;
+        hipDeviceProp_t prop;
+        QA_HIP(hipGetDeviceProperties(&prop, panel->device));
+        const int n_cu = prop.multiProcessorCount;
+        const int lo = (int)((long)n_cu * index / count), hi = (int)((long)n_cu * (index + 1) / count);
+        std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+        for (int cu = lo; cu < hi; cu++) mask[cu >> 5] |= 1u << (cu & 31);
+        QA_HIP(hipExtStreamCreateWithCUMask(&panel->gibbs_stream, (uint32_t)mask.size(), mask.data()));
+        return (int)QA_OK;
+    });
+}
+
 int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits) {
     if (!panel || (bits != 32 && bits != 64)) {
         qa::set_error("qa_panel_set_ranking_precision: bits must be 32 or 64");

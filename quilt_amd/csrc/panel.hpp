@@ -31,6 +31,7 @@ struct qa_panel {
     std::vector<double> h_sigma, h_tm1;  // transMatRate_t rows 0 and 1 as passed
     std::vector<int32_t> h_sp_off;
     hipStream_t stream = nullptr;
+    hipStream_t gibbs_stream = nullptr;   // CU-masked stream of the Gibbs launches (qa_panel_set_cu_partition), else null
     qa::Arena arena;            // scratch of every launch set on this panel (see common.hpp)
     // scratch owned by the panel handle, grown on demand (see fullpass.hip)
     struct Scratch;

@@ -56,7 +56,7 @@ def lib() -> C.CDLL:
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
                      "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy", "qa_panel_create_from_rhb",
                      "qa_panel_export_tables", "qa_rcpp_make_eMatRead_t_nsnps", "qa_rare_common_create",
-                     "qa_gibbs_batch_rare_common", "qa_nipt_block_table"):
+                     "qa_gibbs_batch_rare_common", "qa_nipt_block_table", "qa_panel_set_cu_partition"):
             getattr(L, name).restype = C.c_int
         L.qa_panel_destroy.restype = None
         L.qa_rare_common_destroy.restype = None
@@ -152,6 +152,10 @@ class DevicePanel:
     def set_device_share(self, n_sharers: int):
         """This handle is one of ``n_sharers`` working on the device concurrently (one per host thread)."""
         check(lib().qa_panel_set_device_share(self.handle, C.c_int32(n_sharers)))
+
+    def set_cu_partition(self, index: int, count: int):
+        """Confine this handle's Gibbs launches to the index-th of ``count`` equal CU partitions (count = 1: no mask)."""
+        check(lib().qa_panel_set_cu_partition(self.handle, C.c_int32(index), C.c_int32(count)))
 
     def close(self):
         if self.handle:

@@ -19,11 +19,14 @@ from .sharding import get_sample_range
 
 
 class DeviceWorkers:
-    def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None):
+    def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
+                 cu_partition: bool = False):
         self.n = n_workers
         self.devs = [DevicePanel(panel) for _ in range(n_workers)]
-        for d in self.devs:
+        for w, d in enumerate(self.devs):
             d.set_device_share(n_workers)
+            if cu_partition and n_workers > 1:   # each thread's Gibbs chains on its own share of the CUs (measured slower: DESIGN.md 5)
+                d.set_cu_partition(w, n_workers)
         self.drcs = [DeviceRareCommon(d, rare_common) if rare_common is not None else None for d in self.devs]
         self.drivers = [Driver(panel, HipBackend(d, r), params, rare_common=rare_common) for d, r in zip(self.devs, self.drcs)]
 

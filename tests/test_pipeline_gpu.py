@@ -187,3 +187,22 @@ def test_pipeline_nipt(medium_panel):
         mat = samples[i].truth_haps[0] + samples[i].truth_haps[1]
         print(f"sample {i}: r2(gpu, oracle) mother {r2(g.dosage, r.dosage):.6f} fetus {r2(g.fet_dosage, r.fet_dosage):.6f}; "
               f"mother vs truth {r2(g.dosage, mat):.3f}")
+
+
+def test_cu_partition_does_not_change_results(medium_panel):
+    """qa_panel_set_cu_partition only moves the Gibbs launches to a CU-masked stream."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=600) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=5)
+    outs = []
+    for part in (None, (1, 2)):
+        dev = DevicePanel(panel)
+        if part:
+            dev.set_cu_partition(*part)
+        outs.append(Driver(panel, HipBackend(dev), prm).run(samples))
+        dev.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a.read_labels, b.read_labels) and np.array_equal(a.dosage, b.dosage)
