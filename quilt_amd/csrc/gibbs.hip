@@ -1191,12 +1191,15 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
                 qa::launch_block_rate3(&q, st);
                 rate2.resize((size_t)C * G);
                 S.blk_rate2.download(rate2.data(), rate2.size(), st);
+                std::vector<int32_t> seg_status(C);
+                S.status.download(seg_status.data(), C, st);
                 QA_HIP(hipStreamSynchronize(st));
                 h_where.assign((size_t)C * G, -1); h_tab.assign((size_t)C * 4 * G, 0); h_n.assign(C, 0);
                 const int n_thr = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), C}));
                 auto work = [&](int tid) {
                     for (int c = tid; c < C; c += n_thr) {
                         const int R = read_off[c + 1] - read_off[c];
+                        if (seg_status[c] != 0 || R < 1) continue;   // underflowed chain: stopped, the caller retries it
                         const std::vector<int32_t> blocked = qa::define_blocked_grids(
                             rate2.data() + (size_t)c * G, o->L_grid, G, o->shuffle_bin_radius, o->block_gibbs_quantile_prob);
                         const qa::BlockTable T = qa::make_gibbs_considers(blocked, wif + read_off[c], R);
