@@ -360,3 +360,30 @@ def test_nipt_edge_inputs(small_panel, oracle):
         assert np.array_equal(got["H"], ref["H"]) and np.array_equal(got["H_class"], ref["H_class"]), R
         np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
     dev.close()
+
+
+
+def test_nipt_underflow_is_reported(small_panel, oracle):
+    """NIPT with block passes when the sweeps underflow: the chain stops, the block definition is skipped for it, the call
+    reports underflow_problem (the driver then retries with a smaller maxDifferenceBetweenReads)."""
+    import copy
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = small_panel
+    dev = DevicePanel(panel)
+    s = copy.deepcopy(make_synthetic_sample(panel, seed=78, n_reads=4000, ff=0.2))
+    g0 = int(s.wif[len(s.wif) // 2])
+    s.wif[:] = g0
+    s.u[:] = 32 * g0 + (s.u % 32)
+    rng = np.random.default_rng(2)
+    which = np.sort(rng.choice(panel.K, 64, replace=False)).astype(np.int32) + 1
+    R = s.nReads
+    H0 = rng.choice([1, 2, 3], p=[0.5, 0.4, 0.1], size=R).astype(np.int32)
+    ru, rb, rr = rng.random(R * 21), rng.random(3 * R), rng.random(3 * R)
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, 0, np.zeros(3 * panel.nGrids), ff=0.2, runif_block=rb,
+                                          runif_resample=rr)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, 0, None, ff=0.2, runif_block=rb, runif_resample=rr)
+    assert ref["status"] == 1, "the test input is meant to underflow"
+    assert got["underflow_problem"]
+    dev.close()
