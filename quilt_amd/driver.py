@@ -601,12 +601,12 @@ class Driver:
         common = rc.snp_is_common == 1
         reads = [ch.sample.all_snp for ch in chains]
         nL = self.n_label
-        haps = []
-        for ch in chains:
-            e = np.full((nL, rc.nSNPs_all), 0.5)
-            for l in range(nL):
-                e[l, common] = ch.hap[l]
-            haps.append([e[l] for l in range(nL)])
+        # eHapsCurrent_tc of get_initial_read_labels (rare_common.R:76-81) for every chain at once: [chain, SNP, haplotype],
+        # 0.5 at the rare SNPs, the latest full-pass dosages at the common ones
+        haps = np.full((len(chains), rc.nSNPs_all, nL), 0.5)
+        cidx = np.flatnonzero(common)
+        for l in range(nL):
+            haps[:, cidx, l] = np.stack([ch.hap[l] for ch in chains])
         lik = self.backend.read_likelihood_all_snps_batch(reads, haps, P.maxDifferenceBetweenReads)
         starts, seed_reads, seed_shards = [], [], []
         for ch, e in zip(chains, lik):
@@ -769,7 +769,8 @@ class HipBackend:
                                               return_hapProbs=False, return_genProbs=False, **kw)   # use_mspbwt = FALSE
 
     def read_likelihood_all_snps_batch(self, samples_all, haps, maxDifferenceBetweenReads):
-        """rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100."""
+        """rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100.
+        ``haps``: [chain, SNP, haplotype] array over all SNPs."""
         from .gibbs_nipt import calculate_eMatRead_t_vs_haplotypes_batch
         return calculate_eMatRead_t_vs_haplotypes_batch(self.dev, samples_all, haps, maxDifferenceBetweenReads,
                                                         rescale_eMatRead_t=True, Jmax=100, nSNPs=self.drc.rc.nSNPs_all)

@@ -179,9 +179,13 @@ def calculate_eMatRead_t_vs_haplotypes_batch(panel: DevicePanel, samples: Sequen
     length of the dosages when it is not the panel's (all-SNP reads, QUILT/R/rare_common.R:61-107)."""
     lib().qa_rcpp_make_eMatRead_t_nsnps.restype = C.c_int
     Cn = len(samples)
-    K = len(haps[0])
     T = panel.panel.nSNPs if nSNPs is None else int(nSNPs)
-    e = np.ascontiguousarray(np.stack([np.stack([np.asarray(h, dtype=np.float64) for h in hs], axis=1) for hs in haps]))
+    if isinstance(haps, np.ndarray):   # already [chain, SNP, haplotype]
+        e = np.ascontiguousarray(haps, dtype=np.float64)
+        K = e.shape[2]
+    else:
+        K = len(haps[0])
+        e = np.ascontiguousarray(np.stack([np.stack([np.asarray(h, dtype=np.float64) for h in hs], axis=1) for hs in haps]))
     assert e.shape == (Cn, T, K)
     read_off = np.zeros(Cn + 1, dtype=np.int32)
     for c, s in enumerate(samples):

@@ -57,7 +57,7 @@ class OracleBackend:
         return [O.calculate_eMatRead_t_vs_haplotypes(s, h, maxDifferenceBetweenReads) for s, h in zip(samples, haps)]
 
     def read_likelihood_all_snps_batch(self, samples_all, haps, maxDifferenceBetweenReads):
-        return [O.calculate_eMatRead_t_vs_haplotypes(s, h, maxDifferenceBetweenReads, rescale_eMatRead_t=True, Jmax=100)
+        return [O.calculate_eMatRead_t_vs_haplotypes(s, list(h.T), maxDifferenceBetweenReads, rescale_eMatRead_t=True, Jmax=100)
                 for s, h in zip(samples_all, haps)]
 
     def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, want_top, cols, K_top_matches, minGLValue,
