@@ -11,9 +11,12 @@
  * cannot be built or run in this image and stores no golden vectors.  The
  * oracle is pinned against (i) the RNG-independent known-answer tests the
  * reference's testthat suite holds (binary searches, quantile, H_class
- * log-probabilities, label-permutation table, gl bounding rule, top-K picker
- * definition) and (ii) the structural invariants those tests assert
- * (SURVEY.md 8(c) (1)-(14)).  For the bulk forward/backward and Gibbs
+ * log-probabilities, label / class swap table, make_gibbs_considers' defining
+ * properties, gl bounding rule, top-K picker definition; not the rlcM table of
+ * block_approach 4, which production does not use) and (ii) the structural
+ * invariants those tests assert, plus, for the
+ * rare + common forms, equality with the dense computation on haplotypes
+ * expanded over all SNPs.  For the bulk forward/backward and Gibbs
  * arithmetic that is all that exists: "parity unpinned" beyond those.
  *
  * All matrices are column-major (R layout).  Indices are 0-based unless a
