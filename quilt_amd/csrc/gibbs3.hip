@@ -515,8 +515,24 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
     // the compact read emissions, were laid out for one wave of 10 rows per lane: then row l + 64 (w + 2 i) of this thread
     // (lane l, wave w) is byte w + 2 i of lane l's 16-byte pack.
     const bool foreign = NW == 2 && p.er_nt == 64;
+    // grid, label and dense row of the reads being walked, 64 at a time in lanes (one vector load per field and block
+    // instead of a dependent uniform load per read and field); dropped whenever labels have been rewritten
+    int rb_base = -1, rb_wif = 0, rb_H = 0, rb_dn = 0;
+    auto rb_get = [&](int r) {   // makes the block holding read r current; returns its lane
+        if (rb_base < 0 || r < rb_base || r >= rb_base + 64) {
+            rb_base = r & ~63;
+            const int q = rb_base + ch.lane;
+            const bool ok = q < R;
+            rb_wif = ok ? ch.wif[q] : -1;
+            rb_H = ok ? ch.H[q] : 1;
+            rb_dn = ok ? ch.dense_of[q] : -1;
+        }
+        return r - rb_base;
+    };
+    auto wif_of = [&](int r) { const int j = rb_get(r); return rl_i32(rb_wif, j); };
+    auto H_of = [&](int r) { const int j = rb_get(r); return rl_i32(rb_H, j); };
     auto emission_of = [&](Col<NE> &er, int r) {
-        const int dn = uni_i(ch.dense_of[r]);
+        const int dn = rl_i32(rb_dn, rb_get(r));
         if (dn >= 0) { ch.ld(er, ch.eMatRead + (size_t)dn * Ksp); return; }
         if (!foreign) {
             typename CH::ErPre x;
@@ -681,7 +697,7 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
                 ever_changed = true;
                 // rebuild eMatGrid, alpha, c of the block's grids under the relabelling (:846-912), reads walked by grid
                 int iRead = read_start;
-                int wif_read = uni_i(ch.wif[iRead]);
+                int wif_read = wif_of(iRead);
                 if (grid_start > 0) {
 #pragma unroll
                     for (int h = 0; h < NH; h++) ch.ld(al[h], ch.alpha[h] + (size_t)(grid_start - 1) * Ksp);
@@ -694,10 +710,10 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
                         for (int q = 0; q < NE; q++) el[h].v[q] = 1.0;
                     while ((iRead <= (R - 1)) & (wif_read < g2)) {
                         iRead += 1;
-                        if (iRead < (R - 1)) wif_read = uni_i(ch.wif[iRead]);
+                        if (iRead < (R - 1)) wif_read = wif_of(iRead);
                     }
                     while ((iRead <= (R - 1)) & (wif_read == g2)) {
-                        const int hh = swap_of(uni_i(ch.H[iRead])) - 1;
+                        const int hh = swap_of(H_of(iRead)) - 1;
                         Col<NE> er;
                         emission_of(er, iRead);
 #pragma unroll
@@ -707,7 +723,7 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
                                 for (int q = 0; q < NE; q++) el[h].v[q] *= er.v[q];
                             }
                         iRead += 1;
-                        if (iRead <= (R - 1)) wif_read = uni_i(ch.wif[iRead]);
+                        if (iRead <= (R - 1)) wif_read = wif_of(iRead);
                     }
                     const double s0 = g2 > 0 ? ch.tm0(g2 - 1) : 1.0, s1 = g2 > 0 ? ch.tm1(g2 - 1) : 0.0;
 #pragma unroll
@@ -737,6 +753,7 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
                     ch.Hc[r] = swap_of(ch.Hc[r]);
                 }
                 block_sync();
+                rb_base = -1;
             }
             // Rcpp_reset_local_variables (:1257-1292)
             if ((iBlock + 1) < n_blocks) {
@@ -776,6 +793,7 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
         ch.H[r] = hn;
     }
     block_sync();
+    rb_base = -1;
     {
         int r = 0;
         for (int g = 0; g < G; g++) {   // rcpp_make_eMatGrid_t: reads are sorted by grid
@@ -784,10 +802,10 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
             for (int h = 0; h < NH; h++)
 #pragma unroll
                 for (int q = 0; q < NE; q++) el[h].v[q] = 1.0;
-            while (r < R && uni_i(ch.wif[r]) == g) {
+            while (r < R && wif_of(r) == g) {
                 Col<NE> er;
                 emission_of(er, r);
-                const int hh = uni_i(ch.H[r]) - 1;
+                const int hh = H_of(r) - 1;
 #pragma unroll
                 for (int h = 0; h < NH; h++)
                     if (hh == h) {
