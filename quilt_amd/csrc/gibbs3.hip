@@ -339,7 +339,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 const double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * (h_rA1 == 0 ? pp[0] : h_rA1 == 1 ? pp[1] : pp[2]);
                 const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * (h_rA2 == 0 ? pp[0] : h_rA2 == 1 ? pp[1] : pp[2]);
                 const double denom = prod_pC + prod_pA1 + prod_pA2;
-                const double norm_pC = prod_pC / denom, norm_pA1 = prod_pA1 / denom, norm_pA2 = prod_pA2 / denom;
+                const double rden = fast_rcp(denom);   // (x * (1 / d) for the reference's x / d, as in the two-label kernel)
+                const double norm_pC = prod_pC * rden, norm_pA1 = prod_pA1 * rden, norm_pA2 = prod_pA2 * rden;
                 const double chance = rl_f64(rs.u, j);
                 double x3[3];
                 x3[h_rC] = norm_pC; x3[h_rA1] = norm_pA1; x3[h_rA2] = norm_pA2;
