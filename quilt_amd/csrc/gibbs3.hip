@@ -318,12 +318,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                             s[h] = acc;
                         }
                         ch.template bsum<3>(s);
-                        pA1[h_rC] = s[h_rC];
-                        pA1[h_rA1] = s[h_rA1];
-                        pA2[h_rA2] = s[h_rA2];
+                        // pA1: the read leaves h_rC for h_rA1; pA2: for h_rA2 (:905-960).  Written label by label with
+                        // selects: a dynamically indexed local array would live in scratch memory
+#pragma unroll
+                        for (int h = 0; h < 3; h++) {
+                            pA1[h] = (h == h_rC || h == h_rA1) ? s[h] : pC[h];
+                            pA2[h] = (h == h_rC || h == h_rA2) ? s[h] : pC[h];
+                        }
                     }
-                    pA2[h_rA1] = pC[h_rA1];
-                    pA2[h_rC] = pA1[h_rC];
                 } else if (ginit) {
                     double s[3] = {0, 0, 0};
 #pragma unroll
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 const double norm_pC = prod_pC * rden, norm_pA1 = prod_pA1 * rden, norm_pA2 = prod_pA2 * rden;
                 const double chance = rl_f64(rs.u, j);
                 double x3[3];
-                x3[h_rC] = norm_pC; x3[h_rA1] = norm_pA1; x3[h_rA2] = norm_pA2;
+#pragma unroll
+                for (int h = 0; h < 3; h++) x3[h] = (h == h_rC) ? norm_pC : ((h == h_rA1) ? norm_pA1 : norm_pA2);
                 const double cs0 = x3[0], cs1 = x3[1] + cs0, cs2 = x3[2] + cs1;
                 int h_rN = 0;
                 if (chance < cs2) h_rN = 2;
