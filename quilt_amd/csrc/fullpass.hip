@@ -778,6 +778,10 @@ __global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
             const int tail = (j == jstar) ? tail_star : 16;
             const int k0 = (j * NT + t) * 16;
             if constexpr (j < NR) {
+                // the previous grid's scaling is applied here, when the chunk is touched anyway (one pass over the
+                // register state per grid instead of two; the same operations on every element, in the same order)
+#pragma unroll
+                for (int i = 0; i < 16; i++) a[j][i] *= inv_prev;
                 psum += emit_chunk<true>(a[j], d, et, sj, has_sp, prm, esp, g, k0, tail);
             } else {
                 double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
@@ -799,12 +803,17 @@ __global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
         const double invA = 1.0 / A;
         if (t == 0) prm.c[(size_t)p * G + g] = (g == 0) ? invA * prm.escale0[p] : invA / sig;
         const int sl = slot[g];
+        if (sl >= 0) {   // a thinned grid: the scaled column goes out (the state itself is scaled at the next grid)
 #pragma unroll
-        for (int j = 0; j < NR; j++) {
+            for (int j = 0; j < NR; j++) {
+                if ((j * NT + t) * 16 < K) {
+                    double x[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) a[j][i] *= invA;
-            if (sl >= 0 && (j * NT + t) * 16 < K) store_chunk<double>(aout + (size_t)sl * col_vecs, a[j], j, NT, t);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 16; i++) x[i] = a[j][i] * invA;
+                    store_chunk<double>(aout + (size_t)sl * col_vecs, x, j, NT, t);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         inv_prev = invA;
         if (sl >= 0) {
@@ -884,6 +893,11 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
                 const int tail = (j == jstar) ? tail_star : 16;
                 const int k0 = (j * NT + t) * 16;
                 if constexpr (j < NR) {
+                    // "+ add" and "* x" of grid g+1 are applied here, when the chunk is touched anyway (one pass over the
+                    // register state per grid instead of three; the same operations on every element, in the same order)
+                    const double aj = ((valid >> j) & 1u) ? add_prev : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) b[j][i] = (i < tail ? b[j][i] + aj : 0.0) * x_prev;
                     psum += emit_chunk<false>(b[j], d, et, 0.0, has_sp, prm, esp, g + 1, k0, tail);
                 } else {
                     double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
@@ -904,18 +918,6 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
             });
             const double S = block_sum64<NCH>(psum, L.red + (g & 1) * 16, t, nwaves);
             add = (1.0 - sig) / (double)K / sig * S;
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const double aj = ((valid >> j) & 1u) ? add : 0.0;
-                const int tail = (j == jstar) ? tail_star : 16;
-#pragma unroll
-                for (int i = 0; i < 16; i++) b[j][i] += aj;
-                if (tail < 16) {
-#pragma unroll
-                    for (int i = 0; i < 16; i++) b[j][i] = i < tail ? b[j][i] : 0.0;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
         const int tcol = prm.thin_col[g];
         if (tcol >= 0 && prm.beta_thin) {
@@ -925,7 +927,11 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
                 constexpr int j = decltype(jc)::value;
                 if ((j * NT + t) * 16 >= K) return;
                 if constexpr (j < NR) {
-                    store_chunk<double>(dst, b[j], j, NT, t);
+                    const int tail = (j == jstar) ? tail_star : 16;
+                    double x[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) x[i] = i < tail ? b[j][i] + add : 0.0;
+                    store_chunk<double>(dst, x, j, NT, t);
                 } else {
                     const double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
                     const int tail = (j == jstar) ? tail_star : 16;
@@ -940,12 +946,7 @@ __global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
                 }
             });
         }
-        const double x = cvec[g] * sig;   // beta *= c_g * sigma_g   (:2165-2166)
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) b[j][i] *= x;
-        }
+        const double x = cvec[g] * sig;   // beta *= c_g * sigma_g   (:2165-2166), applied when the state is next touched
         add_prev = add;
         x_prev = x;
     }
