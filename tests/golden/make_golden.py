@@ -4,7 +4,9 @@ The reference (R + Rcpp) cannot be built or run in this environment and stores n
 (SURVEY.md 8(c)); what can be pinned is:
   * known_answers.json -- the RNG-independent known answers asserted by the reference's own tests, transcribed by hand
     (inputs and expected outputs only; the file:line of each is in the entry);
-  * fullpass_small.npz / gibbs_small.npz -- outputs of this repo's fp64 oracle (oracle/) on small seeded problems, so
+  * fullpass_small.npz / gibbs_small.npz / nipt_small.npz / rare_common_small.npz -- outputs of this repo's fp64 oracle
+    (oracle/) on small seeded problems (diploid full pass and Gibbs; NIPT Gibbs with its block passes; the rare + common
+    all-SNP Gibbs call), so
     that a change of the oracle or of the HIP path shows up as a diff against committed data.  They are NOT outputs of
     the reference ("parity unpinned", see oracle/quilt_oracle.h).
 """
@@ -19,11 +21,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import oracle as O                                   # noqa: E402
 from quilt_amd.rng import stream_uniform                          # noqa: E402
-from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample   # noqa: E402
+from quilt_amd.synth import (make_rare_common, make_synthetic_panel, make_synthetic_sample,   # noqa: E402
+                             make_synthetic_sample_rare_common)
 from tests.util import label_gl, thin_cols                        # noqa: E402
 
 PANEL = dict(K=300, nSNPs=160, seed=77, nMaxDH=20)
 SAMPLE = dict(seed=78, n_reads=40)
+RC_SEED = 79
 
 
 def known_answers():
@@ -84,6 +88,30 @@ def main():
     g = O.forwardBackwardGibbsNIPT(panel, sample, which, H0, ru, first_read, rs, gibbs_initialize_iteratively=True)
     np.savez_compressed(os.path.join(HERE, "gibbs_small.npz"), which=which, H0=H0, seed_reads=np.uint64(seed_reads),
                         seed_shard=np.uint64(seed_shard), first_read=np.int32(first_read), H=g["H"],
+                        hapProbs_t=g["hapProbs_t"], underflow=np.int32(g["underflow_problem"]))
+    # NIPT: three labels, block passes after sweeps 3, 6, 9; uniforms from the two counter-based streams
+    ff = 0.2
+    s3 = make_synthetic_sample(panel, seed=SAMPLE["seed"] + 1, n_reads=60, ff=ff)
+    R = s3.nReads
+    H0 = (rng.choice(3, size=R, p=[0.5, 0.4, 0.1]) + 1).astype(np.int32)
+    blk = stream_uniform(seed_shard, nb * 2 * R).reshape(nb, 2, R)
+    g = O.forwardBackwardGibbsNIPT(panel, s3, which, H0, stream_uniform(seed_reads, R * n_its), first_read,
+                                   np.zeros(nb * panel.nGrids), ff=ff, gibbs_initialize_iteratively=True,
+                                   runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy())
+    np.savez_compressed(os.path.join(HERE, "nipt_small.npz"), which=which, H0=H0, ff=np.float64(ff),
+                        seed_reads=np.uint64(seed_reads), seed_shard=np.uint64(seed_shard), first_read=np.int32(first_read),
+                        H=g["H"], H_class=g["H_class"], hapProbs_t=g["hapProbs_t"], genProbsF_t=g["genProbsF_t"],
+                        underflow=np.int32(g["underflow_problem"]))
+    # rare + common: the all-SNP Gibbs call (diploid), starting labels given, read categories off
+    rc = make_rare_common(panel, RC_SEED)
+    _, s_all = make_synthetic_sample_rare_common(panel, rc, SAMPLE["seed"] + 2, n_reads=60)
+    R = s_all.nReads
+    H0 = rng.integers(1, 3, size=R).astype(np.int32)
+    g = O.forwardBackwardGibbsNIPT(panel, s_all, which, H0, stream_uniform(seed_reads, R * n_its), 0,
+                                   stream_uniform(seed_shard, nb * (rc.nGrids_all - 1)), disable_read_category_usage=True,
+                                   rare_common=rc)
+    np.savez_compressed(os.path.join(HERE, "rare_common_small.npz"), which=which, H0=H0,
+                        seed_reads=np.uint64(seed_reads), seed_shard=np.uint64(seed_shard), H=g["H"],
                         hapProbs_t=g["hapProbs_t"], underflow=np.int32(g["underflow_problem"]))
     print("written:", sorted(os.listdir(HERE)))
 

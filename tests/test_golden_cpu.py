@@ -56,3 +56,29 @@ def test_oracle_reproduces_gibbs_fixture():
                                    gibbs_initialize_iteratively=True)
     assert np.array_equal(g["H"], z["H"]) and int(g["underflow_problem"]) == int(z["underflow"])
     np.testing.assert_allclose(g["hapProbs_t"], z["hapProbs_t"], rtol=0, atol=1e-13)
+
+
+def test_oracle_reproduces_nipt_and_rare_common_fixtures():
+    from quilt_amd.rng import stream_uniform
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample, make_synthetic_sample_rare_common
+    from tests.golden.make_golden import RC_SEED, SAMPLE
+    panel, _ = _problem()
+    z = np.load(os.path.join(GOLD, "nipt_small.npz"))
+    ff = float(z["ff"])
+    s3 = make_synthetic_sample(panel, seed=SAMPLE["seed"] + 1, n_reads=60, ff=ff)
+    R = s3.nReads
+    blk = stream_uniform(int(z["seed_shard"]), 3 * 2 * R).reshape(3, 2, R)
+    g = O.forwardBackwardGibbsNIPT(panel, s3, z["which"], z["H0"], stream_uniform(int(z["seed_reads"]), R * 21),
+                                   int(z["first_read"]), np.zeros(3 * panel.nGrids), ff=ff, gibbs_initialize_iteratively=True,
+                                   runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy())
+    assert np.array_equal(g["H"], z["H"]) and np.array_equal(g["H_class"], z["H_class"])
+    np.testing.assert_allclose(g["hapProbs_t"], z["hapProbs_t"], rtol=0, atol=1e-13)
+    z = np.load(os.path.join(GOLD, "rare_common_small.npz"))
+    rc = make_rare_common(panel, RC_SEED)
+    _, s_all = make_synthetic_sample_rare_common(panel, rc, SAMPLE["seed"] + 2, n_reads=60)
+    R = s_all.nReads
+    g = O.forwardBackwardGibbsNIPT(panel, s_all, z["which"], z["H0"], stream_uniform(int(z["seed_reads"]), R * 21), 0,
+                                   stream_uniform(int(z["seed_shard"]), 3 * (rc.nGrids_all - 1)),
+                                   disable_read_category_usage=True, rare_common=rc)
+    assert np.array_equal(g["H"], z["H"])
+    np.testing.assert_allclose(g["hapProbs_t"], z["hapProbs_t"], rtol=0, atol=1e-13)
