@@ -340,8 +340,15 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 // unconditional (clamped) so that no control-flow join forces the in-order vmcnt to drain
                 ch.ld_pre(pre_er, min(iRead, R - 1));
                 if (rl_i32(rs.cat1, jr) != 0) continue;  // reads that cannot discriminate are skipped (:815)
-                Col<NE> er;
-                ch.read_emission(er, cur_er, rl_i32(rs.dn, jr));
+                Col<NE> er, ri;   // the read's emission column and 1 / it (used by normal reads)
+                const int dn_r = rl_i32(rs.dn, jr);
+                if (dn_r >= 0) {
+                    ch.ld(er, ch.eMatRead + (size_t)dn_r * Ksp);
+#pragma unroll
+                    for (int i = 0; i < NE; i++) ri.v[i] = fast_rcp(er.v[i]);
+                } else {
+                    ch.expand_with_rcp(er, ri, cur_er);
+                }
                 if (!init_iteratively) normal = true;
                 else if (r < first_read && it == 0) pass = true;
                 else if (first_read <= r && it == 0) { pass = false; ginit = true; }
@@ -358,15 +365,12 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     grid_started = true;
                 }
                 double pA1[2] = {pC[0], pC[1]};
-                Col<NE> ri;   // 1 / er (normal reads)
                 if (normal) {
                     h_rC = rl_i32(rs.H, jr) - 1;
                     h_rA1 = 1 - h_rC;
                     // dense form for every category (the reference's sparse category-2/3 updates are
                     // algebraically the same sums: test-unit-gibbs-diploid.R:114-124)
                     double s[2] = {0, 0};
-#pragma unroll
-                    for (int i = 0; i < NE; i++) ri.v[i] = fast_rcp(er.v[i]);
                     // wave-uniform branch: two straight-line versions instead of per-element selects (the empty asm keeps
                     // the compiler from converting the branch back into 4 * NE v_cndmask)
                     if (h_rC == 0) {

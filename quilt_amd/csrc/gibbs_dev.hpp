@@ -418,6 +418,20 @@ struct Chain {
             er.v[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, hi), __builtin_amdgcn_ds_bpermute(src, lo));
         }
     }
+    // compact form, emission and its reciprocal together: the reciprocal is taken once per table entry (this lane's) and
+    // gathered like the emission itself -- 1 v_rcp + 2 Newton steps per read instead of per row, for 2 more ds_bpermute per
+    // row; the values are those of fast_rcp applied row by row
+    __device__ __forceinline__ void expand_with_rcp(Col<NE> &er, Col<NE> &ri, const ErPre &x) const {
+        const double tvi = fast_rcp(x.tv);
+        const int lo = __double2loint(x.tv), hi = __double2hiint(x.tv);
+        const int ilo = __double2loint(tvi), ihi = __double2hiint(tvi);
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const int src = (int)((x.w[i >> 2] >> ((i & 3) * 8)) & 0xffu) << 2;
+            er.v[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, hi), __builtin_amdgcn_ds_bpermute(src, lo));
+            ri.v[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, ihi), __builtin_amdgcn_ds_bpermute(src, ilo));
+        }
+    }
     // emission column of read r with its (wave-uniform) dense row dn
     __device__ __forceinline__ void read_emission(Col<NE> &er, const ErPre &x, int dn) const {
         if (dn >= 0) ld(er, eMatRead + (size_t)dn * Ksp);
