@@ -296,13 +296,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 {                  // as in the two-label kernel: <= 1 ulp apart)
                     const typename CH::ErPre x = pre;
                     ch.ld_pre(pre, min(r + 1, R - 1));
-                    ch.read_emission(er, x, rl_i32(rs.dn, j));
+                    const int dn_r = rl_i32(rs.dn, j);
+                    if (dn_r >= 0) {
+                        ch.ld(er, ch.eMatRead + (size_t)dn_r * Ksp);
+#pragma unroll
+                        for (int i = 0; i < NE; i++) rer.v[i] = fast_rcp(er.v[i]);
+                    } else {
+                        ch.expand_with_rcp(er, rer, x);   // reciprocal once per table entry, gathered like the emission
+                    }
                 }
                 int h_rC = 0, h_rA1 = 1, h_rA2 = 2;
                 double pA1[3] = {pC[0], pC[1], pC[2]}, pA2[3] = {pC[0], pC[1], pC[2]};
                 if (normal) {
-#pragma unroll
-                    for (int i = 0; i < NE; i++) rer.v[i] = fast_rcp(er.v[i]);
                     h_rC = rl_i32(rs.H, j) - 1;
                     if (h_rC == 0) { h_rA1 = 1; h_rA2 = 2; }
                     else if (h_rC == 1) { h_rA1 = 0; h_rA2 = 2; }
