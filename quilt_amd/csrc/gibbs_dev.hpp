@@ -125,6 +125,22 @@ __device__ __forceinline__ double wsum(double v) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
+// Two 64-lane sums for the price of little more than one: v_permlane32_swap puts a's upper half beside its lower half in
+// lanes 0..31 and b's halves in lanes 32..63 (one add folds both), then one 32-lane butterfly serves both values
+// (22 instructions instead of 40; checked by scripts/micro/permlane_sum2.hip).  Order: (l, l + 32) pairs, then 16-lane
+// rows, then the two rows of each half.
+__device__ __forceinline__ void wsum2(double &a, double &b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    double v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    v += dpp_get<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_get<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_get<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_get<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_get<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 -> lane 31 holds sum(a), lane 63 sum(b)
+    a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 31), __builtin_amdgcn_readlane(__double2loint(v), 31));
+    b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 __device__ __forceinline__ double wmax(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -447,8 +463,11 @@ struct Chain {
     // prefetches in flight on vmcnt must not be drained here, which __syncthreads() would do).
     template <int N>
     __device__ __forceinline__ void bsum(double (&x)[N]) {
-#pragma unroll
-        for (int q = 0; q < N; q++) x[q] = wsum(x[q]);
+        if constexpr (N >= 2) wsum2(x[0], x[1]);
+        if constexpr (N == 4) wsum2(x[2], x[3]);
+        if constexpr (N == 1) x[0] = wsum(x[0]);
+        if constexpr (N == 3) x[2] = wsum(x[2]);
+        static_assert(N >= 1 && N <= 4, "bsum handles 1..4 values");
         if (NW == 1) return;
         double *buf = red + (size_t)par * NW * 4;
         if (lane == 0) {
