@@ -373,21 +373,26 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     double s[2] = {0, 0};
                     // wave-uniform branch: two straight-line versions instead of per-element selects (the empty asm keeps
                     // the compiler from converting the branch back into 4 * NE v_cndmask)
+                    // (two partial sums per value: the dependent chain of NE fp64 adds is on the read's critical path)
+                    double s2[2] = {0, 0};
                     if (h_rC == 0) {
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < NE; i++) {
-                            s[0] += (a[0].v[i] * bt[0].v[i]) * ri.v[i];
-                            s[1] += (a[1].v[i] * bt[1].v[i]) * er.v[i];
+                            double &u0 = (i & 1) ? s2[0] : s[0], &u1 = (i & 1) ? s2[1] : s[1];
+                            u0 += (a[0].v[i] * bt[0].v[i]) * ri.v[i];
+                            u1 += (a[1].v[i] * bt[1].v[i]) * er.v[i];
                         }
                     } else {
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < NE; i++) {
-                            s[0] += (a[1].v[i] * bt[1].v[i]) * ri.v[i];
-                            s[1] += (a[0].v[i] * bt[0].v[i]) * er.v[i];
+                            double &u0 = (i & 1) ? s2[0] : s[0], &u1 = (i & 1) ? s2[1] : s[1];
+                            u0 += (a[1].v[i] * bt[1].v[i]) * ri.v[i];
+                            u1 += (a[0].v[i] * bt[0].v[i]) * er.v[i];
                         }
                     }
+                    s[0] += s2[0]; s[1] += s2[1];
                     ch.template bsum<2>(s);
                     pA1[h_rC] = s[0];     // the current label loses the read
                     pA1[h_rA1] = s[1];    // the other label gains it
