@@ -49,12 +49,16 @@ int qa_device_count(void);
 int qa_set_device(int device);
 
 /* Per-kernel accumulators since the last reset, measured with HIP events on the launch stream
- * (replaces print_times(), copied-from-stitch.cpp:31-45).  kernel: 0 emission tables, 1 full-panel
- * forward, 2 full-panel backward, 3 dosage mat-vec + top-K, 4 read emissions, 5 Gibbs sweeps,
- * 6 hapProbs, 7 / 8 forward / backward of the fp64-state ranking passes.  alg_bytes = algorithmic HBM bytes of
- * those launches. */
+ * (replaces print_times(), copied-from-stitch.cpp:31-45).  Kernels are numbered 0 .. qa_profile_count() - 1 and named by
+ * qa_profile_name (k_emat, k_fwd, k_bwd, k_dosage, k_ematread, k_gibbs, k_happrobs, k_fwd64, k_bwd64, k_topk, ...).
+ * alg_bytes = algorithmic HBM bytes of those launches.  qa_profile_get_work: units = work units (Gibbs:
+ * read visits + grid steps over all chains), serial = summed length of the launches' serial chains (Gibbs: read visits +
+ * grid steps of the longest chain of each launch) -- for rates such as microseconds per grid step. */
 int qa_profile_reset(void);
+int qa_profile_count(void);
+const char *qa_profile_name(int32_t kernel);
 int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_bytes);
+int qa_profile_get_work(int32_t kernel, double *units, double *serial);
 /* Device time during which at least one launch of the kernel was running (ms, union of the launch intervals over all
  * streams): with several host threads the per-launch times of concurrent launches overlap, and the aggregate rate of a
  * kernel is alg_bytes / busy time. */
@@ -109,6 +113,13 @@ int qa_panel_export_tables(qa_panel_t *panel, uint8_t *hapMatcherR, int32_t *dis
  * 32: lists from the fp32-state pass that also produces the dosage (faster, within ~1e-6 of the reference's gamma, but
  * near-ties may be ordered differently).  Dosages always come from fp32 state (|error| ~1e-6). */
 int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits);
+
+/* Arithmetic of the state behind every other output of the full-panel pass (dosage, alphaHat_t, betaHat_t, gamma_t, c):
+ * 32 (default): fp32 state with fp64 emissions and normalisers (|dosage error| ~1e-6 against the reference's doubles);
+ * 64: fp64 state throughout, as the reference (reference-single.cpp:2189-2413) -- a verification mode, several times
+ * slower (18 instead of 10 algorithmic bytes per cell and untuned kernels); a pass that wants dosage and lists then yields
+ * both from the one fp64 state. */
+int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits);
 
 /* Tell the library that n_sharers panel handles (normally one per host thread, each with its own stream and arena)
  * work on this device at the same time: each then sizes its scratch for 1 / n_sharers of the free memory and its Gibbs

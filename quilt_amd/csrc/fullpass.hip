@@ -27,7 +27,7 @@
 //
 // Algorithmic HBM bytes: dosage pass 10 * K * G (1 B code + 4 B alpha store
 // forward; 1 B code + 4 B alpha load backward), ranking pass (1 + 0.1 * 8) * 2 * K * G.
-#include "panel.hpp"
+#include "fullpass_dev.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -37,71 +37,12 @@
 
 namespace {
 
-constexpr int kMaxRow = 256;      // nMaxDH + 1 <= 256
-constexpr int kHistCopies = 32;   // bank-private copies of the gamma histogram
-// The histogram accumulates gamma * sigma_g (in [0, 1], summing to 1 over a grid) as 32-bit fixed point with LDS
-// integer atomics: on gfx950 ds_add_u32 runs ~30x faster than ds_add_f32 (scripts/micro/lds_atomic_rate.hip: 0.10 vs
-// 3.0 clk per lane-op), and round-to-nearest at 2^-31 keeps the per-grid error near 3e-8 (random walk over K adds).
-constexpr float kHistScale = 2147483648.f;   // 2^31
-constexpr int kMaxTop = 8;        // K_top_matches supported in registers
-
-struct PassParams {
-    // panel
-    const uint8_t *hm;       // [G][Kp]
-    const int32_t *B;        // [G][nMaxDH]
-    const int32_t *sp_off;   // [G+1]
-    const int32_t *sp_k;
-    const uint32_t *sp_word;
-    const double *sigma;     // [G-1]
-    const double *IE;        // [T][nMaxDH] or null
-    int K, Kp, G, T, nMaxDH, nrow, n_special;
-    double ref_error;
-    // per launch
-    int P;                   // passes
-    const double *gl;        // [P][T][2]
-    const int32_t *thin_col; // [G]  -1 or thinned column
-    int n_thin;
-    const int32_t *flags;    // [P] bit0: dosage pass; bit1: store all alpha; bit2: store gamma; bit3: store beta
-    int normalize_emissions;
-    // scratch / outputs
-    void *emat;             // [P][G][kMaxRow]
-    void *esp;              // [P][n_special]
-    double *escale0;         // [P] factor applied to the grid-0 emissions (folded back into c[0])
-    void *alpha;            // [P][n_alpha_cols][Kq]   (lane-interleaved order)
-    const int32_t *alpha_slot; // [P][G] -> column slot in alpha, or -1
-    size_t alpha_pass_stride; // elements
-    int Kq;                  // NT * NCH * 16 (padded K of the launch geometry)
-    double *c;               // [P][G]
-    uint32_t *mg;            // [P][G][kMaxRow]  histogram of gamma * sigma_g by code, fixed point 2^-31 (dosage passes)
-    float *gsp;              // [P][n_special]   gamma of special haplotypes
-    void *gamma_out;        // [P][G][Kq] or null
-    void *beta_out;         // [P][G][Kq] or null
-    void *beta_thin;        // [P][n_thin][Kq] unscaled beta at the thinned grids, or null
-    double *dosage;          // [P][T]
-    int K_top;
-    int top_cap;             // capacity per (pass, thinned column)
-    int truncate_lists;      // keep only the head (first top_cap in rejig order) of over-long lists
-    int32_t *top_cnt;        // [P][n_thin]
-    int32_t *top_idx;        // [P][n_thin][top_cap]
-    void *top_val;          // [P][n_thin][top_cap]
-};
-
 // ---------------------------------------------------------------------------------------------
 // k_emat: emission tables.  One block per (grid, pass); thread d computes the fp64 emission of
 // distinct word d-1 (reference-single.cpp:294-327), the block finds min / max, applies
 // normalize_emissions (:985-990) and writes fp32.  Row 0 is written as 0: haplotypes with code 0
 // ("specials") get their own emission from `esp` (:1002-1042).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double word_emission(uint32_t w, const double2 *gl, int nLocal, double eps) {
-    double prob = 1.0;
-    const double ome = 1.0 - eps;
-    for (int b = 0; b < nLocal; b++) {
-        double2 v = gl[b];  // x = P(reads | ref), y = P(reads | alt)
-        prob *= ((w >> b) & 1u) ? (v.x * eps + v.y * ome) : (v.x * ome + v.y * eps);
-    }
-    return prob;
-}
-
 template <typename TS>
 __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     const int g = blockIdx.x, p = blockIdx.y, t = threadIdx.x;
@@ -121,12 +62,16 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     __syncthreads();
     const bool has_variant = s_var != 0 || g == 1 || g == 0;
     TS *out = static_cast<TS *>(prm.emat) + ((size_t)p * prm.G + g) * kMaxRow;
-    TS *esp_out = static_cast<TS *>(prm.esp) + (size_t)p * prm.n_special;
     const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
+    // special emissions: the grid's list as it is, or (lazy: the fp64 ranking kernels) followed by 16 zero entries that
+    // keep the zero-coded padding beyond K at 0 (fullpass64.hip)
+    TS *esp_out = static_cast<TS *>(prm.esp) + (size_t)p * prm.esp_stride + so + (prm.lazy && sn > 0 ? 16 * prm.sp_gidx[g] : 0);
+    if (prm.lazy && sn > 0 && t < 16) esp_out[sn + t] = TS(0);
     if (!has_variant) {
         // reference shortcut (:1078-1088): emission is 1 for every haplotype
         out[t] = t >= prm.nrow ? TS(0) : (t == 0) ? (sn > 0 ? TS(1) : TS(0)) : TS(1);
-        for (int i = t; i < sn; i += 256) esp_out[so + i] = TS(1);
+        for (int i = t; i < sn; i += 256) esp_out[i] = TS(1);
+        if (prm.lazy && t == 0) prm.emin[(size_t)p * prm.G + g] = -1.0;   // "no variant": the forward takes the shortcut
         return;  // (never taken for g == 0)
     }
     double e = 0;
@@ -150,91 +95,41 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
         __syncthreads();
     }
     const double emax = s_red[0];
+    __syncthreads();
     double scale = 1.0, sp_scale = 1.0;
     if (prm.normalize_emissions) {
         if (emax < 1.0) scale = 1.0 / emax;
         sp_scale = 1.0 / emax;  // specials are always divided by emission_max (:1034)
     }
     if (g == 0) {
-        // the reference initialises alpha(0) from the raw emissions (:2314-2347); fp32 state cannot,
-        // so scale by 1 / max here and fold the factor back into c[0] in k_fwd
-        scale = sp_scale = 1.0 / emax;
+        if (prm.lazy) {
+            scale = sp_scale = 1.0;   // the reference initialises alpha(0) from the raw emissions (:2314-2347)
+        } else {
+            // state that cannot hold the raw emissions: scale by 1 / max here and fold the factor back into c[0] in k_fwd
+            scale = sp_scale = 1.0 / emax;
+        }
         if (t == 0) prm.escale0[p] = scale;
     }
     // row 0 (code 0): 0 normally, so the zero padding K..Kq and any stray code drop out; 1 on grids
     // that hold specials, whose own emission `esp` is applied by the kernels' rare path
     out[t] = t >= prm.nrow ? TS(0) : (t == 0) ? (sn > 0 ? TS(1) : TS(0)) : (TS)(e * scale);   // kMaxRow == blockDim
+    double sp_min = 2.0;
     for (int i = t; i < sn; i += 256) {
         double es = word_emission(prm.sp_word[so + i], s_gl, nLocal, prm.ref_error) * sp_scale;
-        esp_out[so + i] = (TS)es;
+        esp_out[i] = (TS)es;
+        sp_min = fmin(sp_min, es);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// shared device helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <typename T>
-__device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const T w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
+    if (prm.lazy) {
+        // min_emission_prob of the grid (:1044-1057): the smallest table row after normalisation (row 0 holds the column
+        // minimum, the initial 1 included), then the specials
+        s_red[t] = sp_min;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) s_red[t] = fmin(s_red[t], s_red[t + o]);
+            __syncthreads();
+        }
+        if (t == 0) prm.emin[(size_t)p * prm.G + g] = fmin(row0 * scale, s_red[0]);
     }
-    return v;
-}
-
-// first position in grid g's ascending special list whose haplotype index is >= k (rare path)
-__device__ __noinline__ int special_lower_bound(const int32_t *sp_k, int lo, int hi, int k) {
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (sp_k[mid] < k) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-__device__ __forceinline__ bool has_zero_byte(uint32_t v) { return ((v - 0x01010101u) & ~v & 0x80808080u) != 0; }
-__device__ __forceinline__ bool any_zero_code(const uint4 &d) {
-    return has_zero_byte(d.x) || has_zero_byte(d.y) || has_zero_byte(d.z) || has_zero_byte(d.w);
-}
-
-// The recursions run with fp32 state (dosage passes: 16-byte vectors of 4) or fp64 state (ranking passes: 16-byte
-// vectors of 2).  Checkpoints are written in 16-byte vectors either way.
-template <typename TS> struct Vec;
-template <> struct Vec<float> { using V = float4; static constexpr int EPV = 4; };
-template <> struct Vec<double> { using V = double2; static constexpr int EPV = 2; };
-__device__ __forceinline__ float vget(const float4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; }
-__device__ __forceinline__ double vget(const double2 &v, int r) { return r == 0 ? v.x : v.y; }
-__device__ __forceinline__ float4 vmake(const float *x) { return make_float4(x[0], x[1], x[2], x[3]); }
-__device__ __forceinline__ double2 vmake(const double *x) { return make_double2(x[0], x[1]); }
-
-// vector index of (chunk j, vector q) of this thread in the lane-interleaved checkpoint layout: each
-// (wave, j, q) owns 64 consecutive 16-byte vectors (1 KiB) => every dwordx4 store / load is coalesced.
-template <int NV>
-__device__ __forceinline__ size_t alpha_vec_index(int j, int q, int NT, int t) {
-    return (size_t)j * NT * NV + (size_t)((t >> 6) * NV + q) * 64 + (t & 63);
-}
-
-template <typename TS>
-__device__ __forceinline__ void store_chunk(typename Vec<TS>::V *dst, const TS (&x)[16], int j, int NT, int t) {
-    constexpr int EPV = Vec<TS>::EPV, NV = 16 / EPV;
-#pragma unroll
-    for (int q = 0; q < NV; q++) dst[alpha_vec_index<NV>(j, q, NT, t)] = vmake(&x[EPV * q]);
-}
-
-// block-wide sum of one double per thread: wave shuffle, then LDS across waves.  `buf` is one of two
-// alternating 16-entry buffers so that one barrier per call suffices.
-__device__ __forceinline__ double block_sum(double v, double *buf, int t, int nwaves) {
-    v = wave_sum(v);
-    if ((t & 63) == 0) buf[t >> 6] = v;
-    __syncthreads();
-    double s = 0;
-    for (int w = 0; w < nwaves; w++) s += buf[w];
-    return s;
 }
 
 // Multiply the state of the haplotypes with code 0 ("specials": grids with more than nMaxDH distinct
@@ -278,7 +173,7 @@ __global__ __launch_bounds__(MAXT) void k_fwd(PassParams prm) {
     const int flags = prm.flags[p];
     const bool store_all = (flags & 15) != 0;
     const TS *emat = static_cast<const TS *>(prm.emat) + (size_t)p * G * kMaxRow;
-    const TS *esp = static_cast<const TS *>(prm.esp) + (size_t)p * prm.n_special;
+    const TS *esp = static_cast<const TS *>(prm.esp) + (size_t)p * prm.esp_stride;
     V *aout = reinterpret_cast<V *>(static_cast<TS *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
     const int32_t *slot = prm.alpha_slot + (size_t)p * G;
     const size_t col_vecs = (size_t)prm.Kq / Vec<TS>::EPV;
@@ -377,7 +272,8 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TS *etab = reinterpret_cast<TS *>(smem);                                     // [2][256]
     double *red = reinterpret_cast<double *>(smem + 2 * kMaxRow * sizeof(TS));   // [2][16]
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + 2 * kMaxRow * sizeof(TS) + 2 * 16 * 8);  // [2][kMaxRow][32] (FULL)
+    using Hist = typename Vec<TS>::Hist;   // uint32 at 2^-31 (fp32 state) / uint64 at 2^-62 (fp64 state)
+    Hist *hist = reinterpret_cast<Hist *>(smem + 2 * kMaxRow * sizeof(TS) + 2 * 16 * 8);  // [2][kMaxRow][32] (FULL)
     const int p = blockIdx.x, t = threadIdx.x, NT = blockDim.x, nwaves = NT >> 6;
     const int lane = t & 63;
     const int K = prm.K, G = prm.G;
@@ -386,7 +282,7 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
     const bool store_all = (flags & 15) != 0;
     const bool want_gamma = FULL && (flags & 4) != 0, want_beta = FULL && (flags & 8) != 0;
     const TS *emat = static_cast<const TS *>(prm.emat) + (size_t)p * G * kMaxRow;
-    const TS *esp = static_cast<const TS *>(prm.esp) + (size_t)p * prm.n_special;
+    const TS *esp = static_cast<const TS *>(prm.esp) + (size_t)p * prm.esp_stride;
     const V *ain = reinterpret_cast<const V *>(static_cast<const TS *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
     const int32_t *slot = prm.alpha_slot + (size_t)p * G;
     const size_t col_vecs = (size_t)prm.Kq / EPV;
@@ -408,21 +304,21 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
     // fold one grid's 32 bank-private histogram copies into prm.mg (thread = code; copies visited in a rotated order
     // so that a wave's reads spread over the banks), re-zeroing them
     auto fold_histogram = [&](int g_of) {
-        uint32_t *h = hist + (g_of & 1) * kMaxRow * kHistCopies;
-        uint32_t *mgo = prm.mg + ((size_t)p * G + g_of) * kMaxRow;
+        Hist *h = hist + (g_of & 1) * kMaxRow * kHistCopies;
+        Hist *mgo = static_cast<Hist *>(prm.mg) + ((size_t)p * G + g_of) * kMaxRow;
         for (int code = t; code < prm.nrow; code += NT) {
-            uint32_t v = 0;
+            Hist v = 0;
 #pragma unroll 8
             for (int c = 0; c < kHistCopies; c++) {
                 const int at = code * kHistCopies + ((c + lane) & (kHistCopies - 1));
                 v += h[at];
-                h[at] = 0u;
+                h[at] = 0;
             }
             mgo[code] = v;
         }
     };
     if (want_dosage)
-        for (int i = t; i < 2 * kMaxRow * kHistCopies; i += NT) hist[i] = 0u;
+        for (int i = t; i < 2 * kMaxRow * kHistCopies; i += NT) hist[i] = 0;
     for (int i = t; i < kMaxRow; i += NT)
         etab[((G - 1) & 1) * kMaxRow + i] = (i < prm.nrow) ? emat[(size_t)(G - 1) * kMaxRow + i] : TS(0);
     __syncthreads();
@@ -499,7 +395,7 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
             if (need_gamma) {
                 const V *src = ain + (size_t)sl * col_vecs;
                 const bool has_sp = prm.sp_off[g + 1] > prm.sp_off[g];
-                uint32_t *h = hist + (g & 1) * kMaxRow * kHistCopies;
+                Hist *h = hist + (g & 1) * kMaxRow * kHistCopies;
                 const TS fs = (TS)sig;
                 // alpha is streamed through a 2-chunk register pipeline: chunk j+1 is in flight while chunk
                 // j is consumed (holding all 16 * NCH values would double the register footprint)
@@ -530,10 +426,13 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
                                 gq[r] = gk * fs;
                                 if (want_dosage) {
                                     const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-                                    atomicAdd(&h[code * kHistCopies + (lane & 31)], (uint32_t)((float)gq[r] * kHistScale + 0.5f));
+                                    if constexpr (sizeof(TS) == 8)
+                                        atomicAdd(&h[code * kHistCopies + (lane & 31)], (Hist)((double)gq[r] * kHistScale64 + 0.5));
+                                    else
+                                        atomicAdd(&h[code * kHistCopies + (lane & 31)], (Hist)((float)gq[r] * kHistScale + 0.5f));
                                     if (has_sp && code == 0 && k0 + i < K) {
                                         // gamma of a special haplotype goes to its own list (:2096-2128)
-                                        prm.gsp[(size_t)p * prm.n_special + sp_at] = (float)gk;
+                                        static_cast<TS *>(prm.gsp)[(size_t)p * prm.n_special + sp_at] = gk;
                                         sp_at++;
                                     }
                                 }
@@ -580,379 +479,6 @@ __global__ __launch_bounds__(MAXT) void k_bwd(PassParams prm) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// fp64-state kernels of the ranking passes (best-haplotype lists).  One wave per SIMD (256 threads) owns the whole
-// 512-entry VGPR + AGPR file, and 16 doubles x NCH chunks per lane still do not fit next to the temporaries, so
-//   * NR chunks of state live in registers and NL chunks in LDS ([chunk][vector][lane] double2: conflict-free b128),
-//     with the per-grid scaling of the LDS chunks deferred into the next grid's update (one LDS read + write per grid;
-//     the arithmetic sequence per element is exactly that of the register chunks);
-//   * a grid's codes are not held in registers: they sit in an LDS slot per chunk, refilled global -> LDS by DMA
-//     (global_load_lds_dwordx4, no staging registers) as soon as the chunk has consumed them; a wave reads only
-//     codes it fetched itself, so its own vmcnt(0) orders them;
-//   * the 2 KiB emission table of the next grid is DMA'd by wave 0 into the other half of a double buffer and
-//     published by the per-grid barrier of the block-wide sum.
-// ---------------------------------------------------------------------------------------------
-// compile-time loop: the chunk loops are too large for `#pragma unroll` to be honoured, and the register-resident
-// state needs constant indices
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-
-// One wave-instruction: 64 lanes x 16 B, global (per-lane address) -> LDS (wave base in M0 + lane * 16).  Emitted as
-// inline asm on purpose: with the builtin the compiler treats every later LDS read as possibly aliasing the DMA in
-// flight and puts `s_waitcnt vmcnt(0)` in front of each, which serialises the grid on HBM latency.  The waits are
-// placed by hand instead (vm_wait): in-order vmcnt makes the compiler's own counts at worst stricter.  `after` is a
-// value the DMA must not overtake (the codes just read from the slot being refilled).
-// Source = wave-uniform base (SGPR pair) + per-lane byte offset (one VGPR shared by all chunks).
-// Both bases must be computed from wave-uniform values only (kernel arguments, blockIdx, the readfirstlane'd wave
-// index), so that they live in SGPRs.
-__device__ __forceinline__ void dma16(const void *gbase_uniform, uint32_t lane_off, uint32_t lds_wave_base, uint32_t after = 0) {
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_wave_base);
-    const uint64_t src = (uint64_t)(uintptr_t)gbase_uniform;
-    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(src >> 32)) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)src);   // (the builtin returns int)
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_off), "s"(dst), "v"(after), "s"(base)
-                 : "memory");
-}
-template <int N>
-__device__ __forceinline__ void vm_wait() {   // at most N vector-memory operations of this wave still in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-constexpr int kNT64 = 256;   // threads of the fp64 kernels: compile-time, so that chunk offsets are immediates
-
-struct Lds64 {
-    double *etab;    // [2][256]
-    double *red;     // [2][16]
-    char *codes;     // [Kq]
-    double2 *state;  // [NL][8][NT]
-    uint32_t base;   // LDS byte address of smem (uniform)
-    static constexpr uint32_t kCodesOff = 2 * kMaxRow * 8 + 2 * 16 * 8;
-    __device__ __forceinline__ explicit Lds64(char *smem, int Kq) {
-        etab = reinterpret_cast<double *>(smem);
-        red = etab + 2 * kMaxRow;
-        codes = smem + kCodesOff;
-        state = reinterpret_cast<double2 *>(codes + Kq);
-        base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
-    }
-};
-inline size_t lds64_bytes(int Kq, int NT, int NL) { return 2 * kMaxRow * 8 + 2 * 16 * 8 + (size_t)Kq + (size_t)NL * NT * 128; }
-
-// wave 0: DMA grid g's emission table into half `buf`
-__device__ __forceinline__ void dma_table(const double *emat, int g, const Lds64 &L, int buf, int wave, int lane) {
-    if (wave == 0) {   // 256 doubles = 2 x (64 lanes x 16 B)
-        dma16(emat + (size_t)g * kMaxRow, 16 * lane, L.base + buf * kMaxRow * 8);
-        dma16(emat + (size_t)g * kMaxRow + 128, 16 * lane, L.base + buf * kMaxRow * 8 + 1024);
-    }
-}
-// refill chunk j's code slot with grid g's codes (this lane's 16 haplotypes).  Unconditional (the row pitch Kp covers
-// whole chunk rows; padding codes are 0 and the padding state stays 0 whatever the code), so that every wave issues
-// exactly one DMA per chunk per grid and the hand-placed vmcnt waits can count them.
-__device__ __forceinline__ void dma_codes(const PassParams &prm, int g, const Lds64 &L, int j, int wave, int lane, uint32_t after) {
-    const uint32_t off = (uint32_t)(j * kNT64 + wave * 64) * 16;
-    dma16(prm.hm + (size_t)g * prm.Kp + off, lane * 16, L.base + Lds64::kCodesOff + off, after);
-}
-
-// One chunk of 16 emissions: x_i <- (x_i + addend) * table[code_i]; haplotypes with code 0 on a grid that has specials
-// are then multiplied by their own emission (table row 0 is 1 there; reference-single.cpp:1002-1042 / :1902-1964);
-// elements >= tail of the chunk straddling K are forced back to 0.  Returns the chunk's sum.
-// block_sum with a bare barrier (no fence: the only LDS traffic to publish is `buf` and wave 0's table DMA, both
-// waited for explicitly), so that the code DMAs in flight are not drained at every grid
-template <int TABLE_WAIT>
-__device__ __forceinline__ double block_sum64(double v, double *buf, int t, int nwaves) {
-    v = wave_sum(v);
-    if ((t & 63) == 0) buf[t >> 6] = v;
-    vm_wait<TABLE_WAIT>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    double s = 0;
-    for (int w = 0; w < nwaves; w++) s += buf[w];
-    return s;
-}
-
-template <bool ADD>
-__device__ __forceinline__ double emit_chunk(double (&x)[16], const uint4 &d, const double *et, double addend, bool has_sp,
-                                             const PassParams &prm, const double *esp, int g, int k0, int tail) {
-    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
-    double e[16];   // the 16 table look-ups first, back to back, then the arithmetic
-#pragma unroll
-    for (int i = 0; i < 16; i++) e[i] = et[(w[i >> 2] >> ((i & 3) * 8)) & 0xffu];
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = ADD ? (x[i] + addend) * e[i] : x[i] * e[i];
-    if (has_sp && k0 < prm.K && any_zero_code(d)) {   // rare
-        int lo = prm.sp_off[g], hi = prm.sp_off[g + 1];
-        const int first = lo;
-        while (lo < hi) {   // lower bound of k0 in the grid's ascending special list
-            const int mid = (lo + hi) >> 1;
-            if (prm.sp_k[mid] < k0) lo = mid + 1; else hi = mid;
-        }
-        int at = lo;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-            const bool sp = code == 0 && k0 + i < prm.K;
-            const double e_sp = esp[sp ? at : first];
-            at += sp ? 1 : 0;
-            x[i] *= sp ? e_sp : 1.0;
-        }
-    }
-    if (tail < 16) {   // at most one lane of the block
-#pragma unroll
-        for (int i = 0; i < 16; i++) x[i] = i < tail ? x[i] : 0.0;
-    }
-    double s4[4] = {0, 0, 0, 0};   // four independent partial sums: a 16-long dependent chain of fp64 adds would stall
-#pragma unroll
-    for (int i = 0; i < 16; i++) s4[i & 3] += x[i];
-    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
-}
-
-template <int NR, int NL>
-__global__ __launch_bounds__(256) void k_fwd64(PassParams prm) {
-    constexpr int NCH = NR + NL;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds64 L(smem, prm.Kq);
-    const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr int NT = kNT64, nwaves = NT >> 6;
-    const int K = prm.K, G = prm.G;
-    const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
-    const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.n_special;
-    double2 *aout = reinterpret_cast<double2 *>(static_cast<double *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
-    const int32_t *slot = prm.alpha_slot + (size_t)p * G;
-    const size_t col_vecs = (size_t)prm.Kq / 2;
-    // chunks past K carry 0 and must stay 0: the additive term is switched off per chunk; `tail` < 16 marks the
-    // lane's chunk that straddles K (row jstar)
-    uint32_t valid = 0;
-#pragma unroll
-    for (int j = 0; j < NCH; j++) valid |= ((j * NT + t) * 16 < K ? 1u : 0u) << j;
-    const int jstar = (K / 16) / NT;
-    const int tail_star = ((K / 16) % NT == t && (K & 15)) ? (K & 15) : 16;
-
-    double a[NR][16];
-    const double invK = 1.0 / (double)K;
-#pragma unroll
-    for (int j = 0; j < NCH; j++) {
-        const int k0 = (j * NT + t) * 16;
-        if (j < NR) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) a[j][i] = (k0 + i < K) ? invK : 0.0;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-                L.state[((j - NR) * 8 + q) * NT + t] = make_double2(k0 + 2 * q < K ? invK : 0.0, k0 + 2 * q + 1 < K ? invK : 0.0);
-        }
-        reinterpret_cast<uint4 *>(L.codes)[j * NT + t] = make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NCH; j++) dma_codes(prm, 0, L, j, wave, lane, 0);
-    dma_table(emat, 0, L, 0, wave, lane);
-    vm_wait<0>();
-    __syncthreads();
-
-    double inv_prev = 1.0;   // scaling of the previous grid, still owed by the LDS chunks
-    for (int g = 0; g < G; g++) {
-        const int buf = g & 1;
-        if (g + 1 < G) dma_table(emat, g + 1, L, buf ^ 1, wave, lane);   // that half was last read in iteration g-1
-        const double *et = L.etab + buf * kMaxRow;
-        const bool has_sp = prm.sp_off[g + 1] > prm.sp_off[g];
-        double sg = 0.0, sig = 1.0;
-        if (g > 0) {
-            sig = prm.sigma[g - 1];
-            sg = (1.0 - sig) / (double)K / sig;  // psi / sigma with A_prev = 1
-        }
-        double psum = 0;
-        static_for<NCH>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            // this chunk's DMA of the previous iteration: NCH - 1 code DMAs (+ wave 0's table) were issued after it
-            vm_wait<NCH - 1>();
-            const uint4 d = reinterpret_cast<const uint4 *>(L.codes)[j * NT + t];
-            const double sj = ((valid >> j) & 1u) ? sg : 0.0;
-            const int tail = (j == jstar) ? tail_star : 16;
-            const int k0 = (j * NT + t) * 16;
-            if constexpr (j < NR) {
-                // the previous grid's scaling is applied here, when the chunk is touched anyway (one pass over the
-                // register state per grid instead of two; the same operations on every element, in the same order)
-#pragma unroll
-                for (int i = 0; i < 16; i++) a[j][i] *= inv_prev;
-                psum += emit_chunk<true>(a[j], d, et, sj, has_sp, prm, esp, g, k0, tail);
-            } else {
-                double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
-                double x[16];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const double2 v = st[q * NT];
-                    x[2 * q] = v.x * inv_prev;
-                    x[2 * q + 1] = v.y * inv_prev;
-                }
-                psum += emit_chunk<true>(x, d, et, sj, has_sp, prm, esp, g, k0, tail);
-#pragma unroll
-                for (int q = 0; q < 8; q++) st[q * NT] = make_double2(x[2 * q], x[2 * q + 1]);
-            }
-            if (g + 1 < G) dma_codes(prm, g + 1, L, j, wave, lane, d.x);   // the slot's codes have been consumed
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        const double A = block_sum64<NCH>(psum, L.red + buf * 16, t, nwaves);   // wave 0's table DMA precedes NCH code DMAs
-        const double invA = 1.0 / A;
-        if (t == 0) prm.c[(size_t)p * G + g] = (g == 0) ? invA * prm.escale0[p] : invA / sig;
-        const int sl = slot[g];
-        if (sl >= 0) {   // a thinned grid: the scaled column goes out (the state itself is scaled at the next grid)
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                if ((j * NT + t) * 16 < K) {
-                    double x[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) x[i] = a[j][i] * invA;
-                    store_chunk<double>(aout + (size_t)sl * col_vecs, x, j, NT, t);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        inv_prev = invA;
-        if (sl >= 0) {
-#pragma unroll
-            for (int j = NR; j < NCH; j++) {
-                if ((j * NT + t) * 16 >= K) continue;
-                const double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
-                double x[16];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const double2 v = st[q * NT];
-                    x[2 * q] = v.x * invA;
-                    x[2 * q + 1] = v.y * invA;
-                }
-                store_chunk<double>(aout + (size_t)sl * col_vecs, x, j, NT, t);
-            }
-        }
-    }
-}
-
-template <int NR, int NL>
-__global__ __launch_bounds__(256) void k_bwd64(PassParams prm) {
-    constexpr int NCH = NR + NL;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds64 L(smem, prm.Kq);
-    const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr int NT = kNT64, nwaves = NT >> 6;
-    const int K = prm.K, G = prm.G;
-    const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
-    const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.n_special;
-    const size_t col_vecs = (size_t)prm.Kq / 2;
-    const double *cvec = prm.c + (size_t)p * G;
-    uint32_t valid = 0;   // see k_fwd64
-#pragma unroll
-    for (int j = 0; j < NCH; j++) valid |= ((j * NT + t) * 16 < K ? 1u : 0u) << j;
-    const int jstar = (K / 16) / NT;
-    const int tail_star = ((K / 16) % NT == t && (K & 15)) ? (K & 15) : 16;
-
-    double b[NR][16];
-#pragma unroll
-    for (int j = 0; j < NCH; j++) {
-        const int k0 = (j * NT + t) * 16;
-        if (j < NR) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) b[j][i] = (k0 + i < K) ? 1.0 : 0.0;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-                L.state[((j - NR) * 8 + q) * NT + t] = make_double2(k0 + 2 * q < K ? 1.0 : 0.0, k0 + 2 * q + 1 < K ? 1.0 : 0.0);
-        }
-        reinterpret_cast<uint4 *>(L.codes)[j * NT + t] = make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NCH; j++) dma_codes(prm, G - 1, L, j, wave, lane, 0);
-    dma_table(emat, G - 1, L, (G - 1) & 1, wave, lane);
-    vm_wait<0>();
-    __syncthreads();
-
-    // the LDS chunks hold beta after the emission step; "+ add" and "* x" of that grid are applied when next read
-    double add_prev = 0.0, x_prev = 1.0;
-    for (int g = G - 1; g >= 0; --g) {
-        double sig = 1.0;  // "not_jump_prob" of the reference: sigma_g, or 1 at the last grid
-        double add = 0.0;
-        if (g < G - 1) {
-            const int buf = (g + 1) & 1;             // grid g+1's table: the emission side
-            if (g > 0) dma_table(emat, g, L, buf ^ 1, wave, lane);   // for iteration g-1; that half was last read in g+1
-            sig = prm.sigma[g];
-            const double *et = L.etab + buf * kMaxRow;
-            const bool has_sp = prm.sp_off[g + 2] > prm.sp_off[g + 1];
-            double psum = 0;
-            static_for<NCH>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                vm_wait<NCH - 1>();   // see k_fwd64
-                const uint4 d = reinterpret_cast<const uint4 *>(L.codes)[j * NT + t];   // grid g+1
-                const int tail = (j == jstar) ? tail_star : 16;
-                const int k0 = (j * NT + t) * 16;
-                if constexpr (j < NR) {
-                    // "+ add" and "* x" of grid g+1 are applied here, when the chunk is touched anyway (one pass over the
-                    // register state per grid instead of three; the same operations on every element, in the same order)
-                    const double aj = ((valid >> j) & 1u) ? add_prev : 0.0;
-#pragma unroll
-                    for (int i = 0; i < 16; i++) b[j][i] = (i < tail ? b[j][i] + aj : 0.0) * x_prev;
-                    psum += emit_chunk<false>(b[j], d, et, 0.0, has_sp, prm, esp, g + 1, k0, tail);
-                } else {
-                    double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
-                    const double aj = ((valid >> j) & 1u) ? add_prev : 0.0;
-                    double x[16];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const double2 v = st[q * NT];
-                        x[2 * q] = (v.x + aj) * x_prev;
-                        x[2 * q + 1] = (v.y + aj) * x_prev;
-                    }
-                    psum += emit_chunk<false>(x, d, et, 0.0, has_sp, prm, esp, g + 1, k0, tail);
-#pragma unroll
-                    for (int q = 0; q < 8; q++) st[q * NT] = make_double2(x[2 * q], x[2 * q + 1]);
-                }
-                if (g > 0) dma_codes(prm, g, L, j, wave, lane, d.x);   // codes of grid g, for iteration g-1
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            const double S = block_sum64<NCH>(psum, L.red + (g & 1) * 16, t, nwaves);
-            add = (1.0 - sig) / (double)K / sig * S;
-        }
-        const int tcol = prm.thin_col[g];
-        if (tcol >= 0 && prm.beta_thin) {
-            // thinned grid: hand the (unscaled) beta column to k_topk (:2020-2031)
-            double2 *dst = reinterpret_cast<double2 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
-            static_for<NCH>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if ((j * NT + t) * 16 >= K) return;
-                if constexpr (j < NR) {
-                    const int tail = (j == jstar) ? tail_star : 16;
-                    double x[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) x[i] = i < tail ? b[j][i] + add : 0.0;
-                    store_chunk<double>(dst, x, j, NT, t);
-                } else {
-                    const double2 *st = L.state + (size_t)(j - NR) * 8 * NT + t;
-                    const int tail = (j == jstar) ? tail_star : 16;
-                    double x[16];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const double2 v = st[q * NT];
-                        x[2 * q] = 2 * q < tail ? v.x + add : 0.0;
-                        x[2 * q + 1] = 2 * q + 1 < tail ? v.y + add : 0.0;
-                    }
-                    store_chunk<double>(dst, x, j, NT, t);
-                }
-            });
-        }
-        const double x = cvec[g] * sig;   // beta *= c_g * sigma_g   (:2165-2166), applied when the state is next touched
-        add_prev = add;
-        x_prev = x;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_topk: best haplotypes at one thinned grid of one pass (reference-single.cpp:129-194, :2020-2031).
 // threshold = K_top-th largest gamma counted with multiplicity; every k with gamma >= threshold is
 // reported with gamma * not_jump_prob.  One block per (thinned column, pass); alpha and beta columns
@@ -962,7 +488,11 @@ template <typename TS>
 __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
     using V = typename Vec<TS>::V;
     constexpr int EPV = Vec<TS>::EPV, NV = 16 / EPV;
-    const int tcol = blockIdx.x, p = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    // one block per (thinned column, pass), or per entry of the to-do list (the grids the fused picker of the fp64
+    // ranking kernels handed over)
+    const int tcol = prm.topk_todo ? prm.topk_todo[2 * blockIdx.x + 1] : blockIdx.x;
+    const int p = prm.topk_todo ? prm.topk_todo[2 * blockIdx.x] : blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63;
     __shared__ TS s_top[4][kMaxTop];
     __shared__ int s_cnt;
     __shared__ int s_g;
@@ -1128,14 +658,16 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
 // k_dosage: dosage[32g + b] = sigma_g * ( sum_d IE[d, 32g+b] * mg[d] + sum_specials gamma * (bit ? 1-eps : eps) )
 // (reference-single.cpp:2092-2139).  One block of 32 x 8 threads per (grid, pass).
 // ---------------------------------------------------------------------------------------------
+template <typename TS>
 __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
+    using Hist = typename Vec<TS>::Hist;
     const int g = blockIdx.x, p = blockIdx.y;
     if (!(prm.flags[p] & 1)) return;
     const int b = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts
     __shared__ double s_acc[8][32];
     const int s = 32 * g;
     const int nLocal = min(32, prm.T - s);
-    const uint32_t *mg = prm.mg + ((size_t)p * prm.G + g) * kMaxRow;
+    const Hist *mg = static_cast<const Hist *>(prm.mg) + ((size_t)p * prm.G + g) * kMaxRow;
     const double eps = prm.ref_error, ome = 1.0 - eps;
     double acc = 0, acc_sp = 0;   // histogram part (already times sigma_g) and specials (raw gamma)
     if (b < nLocal) {
@@ -1147,11 +679,11 @@ __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
                 const uint32_t w = (uint32_t)prm.B[(size_t)g * prm.nMaxDH + (d - 1)];
                 ie = ((w >> b) & 1u) ? ome : eps;
             }
-            acc += ie * ((double)mg[d] * (1.0 / (double)kHistScale));
+            acc += ie * ((double)mg[d] * (sizeof(TS) == 8 ? 1.0 / kHistScale64 : 1.0 / (double)kHistScale));
         }
         const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
         for (int i = part; i < sn; i += 8) {
-            const double gk = (double)prm.gsp[(size_t)p * prm.n_special + so + i];
+            const double gk = (double)static_cast<const TS *>(prm.gsp)[(size_t)p * prm.n_special + so + i];
             acc_sp += gk * (((prm.sp_word[so + i] >> b) & 1u) ? ome : eps);
         }
     }
@@ -1229,14 +761,12 @@ __global__ void k_unpermute(const TS *src, double *dst, int K, int Kq, int NT, i
 // host side
 // ---------------------------------------------------------------------------------------------
 struct qa_panel::Scratch {
-    qa::ABuf<double> gl, c, dosage, escale0, unperm;
-    qa::ABuf<float> gsp;
-    qa::ABuf<uint32_t> mg;
-    qa::ABuf<char> emat, esp, alpha, gamma, beta, beta_thin, top_val;   // fp32 or fp64 elements (the launch decides)
+    qa::ABuf<double> gl, c, dosage, escale0, unperm, emin;
+    qa::ABuf<char> emat, esp, alpha, gamma, beta, beta_thin, top_val, mg, gsp;   // fp32 or fp64 elements (the launch decides)
     qa::ABuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     explicit Scratch(qa::Arena *a) {
-        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = a;
+        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = a;
         emat.arena = esp.arena = alpha.arena = mg.arena = gsp.arena = gamma.arena = beta.arena = beta_thin.arena = top_val.arena = a;
         thin_col.arena = flags.arena = alpha_slot.arena = top_cnt.arena = top_idx.arena = a;
     }
@@ -1253,46 +783,56 @@ qa_panel::~qa_panel() {
 
 namespace {
 
-thread_local double g_timing[5] = {0, 0, 0, 0, 0};
+thread_local double g_timing[6] = {0, 0, 0, 0, 0, 0};   // emat, forward, backward, dosage, separate top-K, total
 
-struct Geometry { int NT, NCH; bool f64; };
+// Three families of kernels run a pass:
+//   KIND_F32       fp32 state (k_fwd / k_bwd<float>): the dosage passes, any output
+//   KIND_F64_RANK  fp64 state, the reference's lazy normalisation, fused top-K (fullpass64.hip): best-haplotype lists only
+//   KIND_F64_FULL  fp64 state through the generic kernels (k_fwd / k_bwd<double>, one wave per SIMD): any output in
+//                  double -- the verification mode behind qa_panel_set_dosage_precision(64); not tuned (it spills)
+enum PassKind { KIND_F32 = 0, KIND_F64_RANK = 1, KIND_F64_FULL = 2 };
+struct Geometry { int NT, NCH; PassKind kind; bool f64() const { return kind != KIND_F32; } };
 
 // Register-resident geometry: NT threads (multiple of 64) x NCH chunks of 16 haplotypes per lane.  fp32 state:
-// NT <= 512 so that each wave may use 256 VGPRs; fp64 state (ranking passes): NT <= 256, one wave per SIMD with
-// the whole 512-entry VGPR + AGPR file.  The smallest NCH that covers K gives the most waves; tiny panels still
-// get >= 2 chunks per lane for ILP.
+// NT <= 512 so that each wave may use 256 VGPRs.  The smallest NCH that covers K gives the most waves; tiny panels
+// still get >= 2 chunks per lane for ILP.  KIND_F64_RANK: 512 threads, chunk rows of 8192 haplotypes (fullpass64.hip).
+// KIND_F64_FULL: 256 threads, NCH = ceil(K / 4096) rounded up to a built variant.
 constexpr int kNchList32[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
-constexpr int kMaxNch64 = 14;   // fp64: NT = 256 fixed, NCH = ceil(K / 4096) (== Kp / 4096)
-Geometry pick_geometry(int K, bool f64 = false) {
+constexpr int kNchList64[] = {1, 2, 4, 6, 8, 10, 12, 13, 14};
+Geometry pick_geometry(int K, PassKind kind = KIND_F32) {
     const int chunks = (K + 15) / 16;
-    const int max_nt = f64 ? 256 : 512;
+    if (kind == KIND_F64_RANK) {
+        const int nch = qa::fb64_chunks(K);
+        return {nch ? 512 : 0, nch, kind};
+    }
+    if (kind == KIND_F64_FULL) {
+        const int need = (K + 4095) / 4096;
+        for (int nch : kNchList64) if (nch >= need) return {256, nch, kind};
+        return {0, 0, kind};
+    }
     auto fit = [&](int nch) -> int {
         int nt = (chunks + nch - 1) / nch;
         nt = std::max((nt + 63) / 64 * 64, 64);
-        if (nt > max_nt) return 0;
+        if (nt > 512) return 0;
         if (nch == 1 && chunks > 128) return 0;
         return nt;
     };
-    if (f64) {
-        const int nch = (K + 4095) / 4096;
-        if (nch <= kMaxNch64) return {256, nch, true};
-    } else {
-        for (int nch : kNchList32) if (int nt = fit(nch)) return {nt, nch, false};
-    }
-    return {0, 0, f64};
+    for (int nch : kNchList32) if (int nt = fit(nch)) return {nt, nch, kind};
+    return {0, 0, kind};
 }
 
 
 // device bytes one pass needs in run_passes (mirrors its carves, with alignment slack)
 size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stores_all, bool gamma, bool beta,
                   bool device_gl) {
-    const size_t Kq = (size_t)geo.NT * geo.NCH * 16, G = pn->G, T = pn->T, es = geo.f64 ? 8 : 4;
+    const size_t Kq = (size_t)geo.NT * geo.NCH * 16, G = pn->G, T = pn->T, es = geo.f64() ? 8 : 4;
     const size_t cols = stores_all ? G : (size_t)std::max(n_thin, 1);
     (void)device_gl;
-    size_t b = T * 16 + G * 4 + G * kMaxRow * (es + 4) + 8 + (size_t)pn->n_special * (es + 4) + cols * Kq * es + G * 8 + T * 8;
+    const size_t nsp = (size_t)pn->n_special + 16 * (size_t)pn->n_sp_grids + 16;
+    size_t b = T * 16 + G * 4 + G * kMaxRow * (es + 8) + 8 + nsp * (es + 8) + cols * Kq * es + G * 16 + T * 8;
     if (gamma) b += G * Kq * es;
     if (beta) b += G * Kq * es;
-    if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 64 * 12);   // (lists of up to 64 entries)
+    if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 8 + 64 * 12);   // (lists of up to 64 entries)
     return b + 256 * 24;
 }
 
@@ -1310,7 +850,7 @@ int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
 template <typename TS, int NCH, int MAXT, bool FULL>
 void launch_fb(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
     const size_t lds_f = 2 * kMaxRow * sizeof(TS) + 2 * 16 * 8;
-    const size_t lds_b = lds_f + (FULL ? (size_t)2 * kMaxRow * kHistCopies * 4 : 0);
+    const size_t lds_b = lds_f + (FULL ? (size_t)2 * kMaxRow * kHistCopies * sizeof(typename Vec<TS>::Hist) : 0);
     hipLaunchKernelGGL((k_fwd<TS, NCH, MAXT>), dim3(prm.P), dim3(NT), lds_f, s, prm);
     QA_HIP(hipGetLastError());
     QA_HIP(hipEventRecord(e_mid, s));
@@ -1320,38 +860,24 @@ void launch_fb(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
     QA_HIP(hipGetLastError());
 }
 
-template <int NR, int NL>
-void launch_fb64(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
-    const size_t lds = lds64_bytes(prm.Kq, NT, NL);
-    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_fwd64<NR, NL>), dim3(prm.P), dim3(NT), lds, s, prm);
-    QA_HIP(hipGetLastError());
-    QA_HIP(hipEventRecord(e_mid, s));
-    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_bwd64<NR, NL>), dim3(prm.P), dim3(NT), lds, s, prm);
-    QA_HIP(hipGetLastError());
-}
-
 void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, hipEvent_t e_mid) {
-    if (geo.f64) {
-        // NCH = NR register chunks + NL LDS chunks (every geometry but the smallest exercises the LDS path)
+    if (geo.kind == KIND_F64_RANK) {
+        qa::launch_fb64(&prm, st, e_mid);
+        return;
+    }
+    if (geo.kind == KIND_F64_FULL) {
         switch (geo.NCH) {
 #ifndef QA_FAST_BUILD
-            case 1: launch_fb64<1, 0>(prm, geo.NT, st, e_mid); break;
-            case 3: launch_fb64<2, 1>(prm, geo.NT, st, e_mid); break;
-            case 4: launch_fb64<3, 1>(prm, geo.NT, st, e_mid); break;
-            case 5: launch_fb64<4, 1>(prm, geo.NT, st, e_mid); break;
-            case 6: launch_fb64<5, 1>(prm, geo.NT, st, e_mid); break;
-            case 7: launch_fb64<6, 1>(prm, geo.NT, st, e_mid); break;
-            case 8: launch_fb64<7, 1>(prm, geo.NT, st, e_mid); break;
-            case 9: launch_fb64<8, 1>(prm, geo.NT, st, e_mid); break;
-            case 10: launch_fb64<8, 2>(prm, geo.NT, st, e_mid); break;
-            case 11: launch_fb64<8, 3>(prm, geo.NT, st, e_mid); break;
-            case 12: launch_fb64<9, 3>(prm, geo.NT, st, e_mid); break;
-            case 14: launch_fb64<11, 3>(prm, geo.NT, st, e_mid); break;
+            case 1: launch_fb<double, 1, 256, true>(prm, geo.NT, st, e_mid); break;
+            case 4: launch_fb<double, 4, 256, true>(prm, geo.NT, st, e_mid); break;
+            case 6: launch_fb<double, 6, 256, true>(prm, geo.NT, st, e_mid); break;
+            case 8: launch_fb<double, 8, 256, true>(prm, geo.NT, st, e_mid); break;
+            case 10: launch_fb<double, 10, 256, true>(prm, geo.NT, st, e_mid); break;
+            case 12: launch_fb<double, 12, 256, true>(prm, geo.NT, st, e_mid); break;
+            case 14: launch_fb<double, 14, 256, true>(prm, geo.NT, st, e_mid); break;
 #endif
-            case 2: launch_fb64<1, 1>(prm, geo.NT, st, e_mid); break;
-            case 13: launch_fb64<10, 3>(prm, geo.NT, st, e_mid); break;
+            case 2: launch_fb<double, 2, 256, true>(prm, geo.NT, st, e_mid); break;
+            case 13: launch_fb<double, 13, 256, true>(prm, geo.NT, st, e_mid); break;
             default: throw std::runtime_error("geometry not built");
         }
         return;
@@ -1395,19 +921,21 @@ struct BatchOut {
 
 // runs P passes; flags per pass as in PassParams
 int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, const int32_t *thin_col_h,
-               int K_top, int normalize_emissions, const BatchOut &out, bool f64 = false) {
+               int K_top, int normalize_emissions, const BatchOut &out, PassKind kind = KIND_F32,
+               int always_normalize = 0, double norm_threshold = 1e-100) {
     if (K_top > kMaxTop) {
         qa::set_error("K_top_matches = %d > %d not supported", K_top, kMaxTop);
         return QA_ERR_UNSUPPORTED;
     }
-    const Geometry geo = pick_geometry(pn->K, f64);
+    const Geometry geo = pick_geometry(pn->K, kind);
     if (geo.NT == 0) {
-        qa::set_error("K = %d exceeds the register-resident capacity (%d haplotypes) of the %s full-pass kernels", pn->K,
-                      f64 ? 57344 : 98304, f64 ? "fp64 ranking" : "fp32");
+        qa::set_error("K = %d exceeds the on-chip capacity of the %s full-pass kernels", pn->K,
+                      kind == KIND_F32 ? "fp32" : kind == KIND_F64_RANK ? "fp64 ranking" : "generic fp64");
         return QA_ERR_UNSUPPORTED;
     }
+    const bool f64 = geo.f64();
     const size_t es = f64 ? 8 : 4;
-    if (f64)
+    if (kind == KIND_F64_RANK)
         for (int p = 0; p < P; p++)
             if (h_flags[p] & 15) throw std::runtime_error("fp64 ranking passes carry no dosage / gamma / beta outputs");
     QA_HIP(hipSetDevice(pn->device));
@@ -1440,7 +968,11 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         any_beta |= (f & 8) != 0;
     }
     const bool any_top = n_thin > 0 && K_top > 0;
+    // the fp64 ranking kernels pick the lists themselves when only the ordered head of each list is wanted (the driver)
+    const bool fused = any_top && kind == KIND_F64_RANK && out.truncate_lists && out.top_cap <= 64;
     const size_t alpha_stride = max_cols * (size_t)Kq;
+    const bool lazy = kind == KIND_F64_RANK;
+    const size_t esp_stride = (size_t)pn->n_special + (lazy ? 16 * (size_t)pn->n_sp_grids : 0) + 16;
 
     if (gl) {   // host gl; otherwise the caller has filled S.gl on the device already (k_make_gl)
         S.gl.ensure((size_t)P * T * 2);
@@ -1454,11 +986,12 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     S.alpha_slot.upload(slot.data(), (size_t)P * G, st);
     S.emat.ensure((size_t)P * G * kMaxRow * es);
     S.escale0.ensure(P);
-    S.esp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1) * es);
-    S.gsp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1));
+    S.emin.ensure((size_t)P * G);
+    S.esp.ensure((size_t)P * esp_stride * es);
+    S.gsp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1) * es);
     S.alpha.ensure((size_t)P * alpha_stride * es);
     S.c.ensure((size_t)P * G);
-    S.mg.ensure((size_t)P * G * kMaxRow);
+    S.mg.ensure((size_t)P * G * kMaxRow * (f64 ? 8 : 4));
     S.dosage.ensure((size_t)P * T);
     if (any_gamma) S.gamma.ensure((size_t)P * G * Kq * es);
     if (any_beta) S.beta.ensure((size_t)P * G * Kq * es);
@@ -1468,17 +1001,28 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
 
     PassParams prm{};
     prm.hm = pn->hm.p; prm.B = pn->B.p; prm.sp_off = pn->sp_off.p; prm.sp_k = pn->sp_k.p;
-    prm.sp_word = pn->sp_word.p; prm.sigma = pn->sigma.p; prm.IE = pn->ie_derived ? nullptr : pn->IE.p;
+    prm.sp_word = pn->sp_word.p; prm.sp_gidx = pn->sp_gidx.p; prm.sp_chunk_at = pn->sp_chunk_at.p;
+    prm.sigma = pn->sigma.p; prm.tm1 = pn->tm1.p; prm.IE = pn->ie_derived ? nullptr : pn->IE.p;
     prm.K = K; prm.Kp = pn->Kp; prm.G = G; prm.T = T; prm.nMaxDH = pn->nMaxDH; prm.nrow = pn->nrow;
     prm.n_special = pn->n_special; prm.ref_error = pn->ref_error;
     prm.P = P; prm.gl = S.gl.p; prm.thin_col = S.thin_col.p; prm.n_thin = n_thin; prm.flags = S.flags.p;
     prm.normalize_emissions = normalize_emissions;
+    prm.lazy = lazy ? 1 : 0; prm.always_normalize = always_normalize; prm.norm_threshold = norm_threshold;
+    prm.emin = S.emin.p; prm.esp_stride = (int)esp_stride;
 
     prm.emat = S.emat.p; prm.esp = S.esp.p; prm.escale0 = S.escale0.p; prm.alpha = S.alpha.p; prm.alpha_slot = S.alpha_slot.p;
     prm.alpha_pass_stride = alpha_stride; prm.Kq = Kq; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;
     prm.gamma_out = any_gamma ? S.gamma.p : nullptr; prm.beta_out = any_beta ? S.beta.p : nullptr;
     prm.dosage = S.dosage.p; prm.K_top = any_top ? K_top : 0;
     prm.beta_thin = any_top ? S.beta_thin.p : nullptr;
+    prm.fused_topk = fused ? 1 : 0;
+    prm.top_cap = top_cap;
+    prm.truncate_lists = out.truncate_lists ? 1 : 0;
+    if (any_top) {
+        S.top_idx.ensure((size_t)P * n_thin * top_cap);
+        S.top_val.ensure((size_t)P * n_thin * top_cap * es);
+        prm.top_cnt = S.top_cnt.p; prm.top_idx = S.top_idx.p; prm.top_val = S.top_val.p;
+    }
 
     QA_HIP(hipEventRecord(S.ev[0], st));
     if (f64) hipLaunchKernelGGL(k_emat<double>, dim3(G, P), dim3(256), 0, st, prm);
@@ -1487,12 +1031,34 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     QA_HIP(hipEventRecord(S.ev[1], st));
     launch_fb_any(geo, prm, st, S.ev[2]);
     QA_HIP(hipEventRecord(S.ev[3], st));
-    hipLaunchKernelGGL(k_dosage, dim3(G, P), dim3(256), 0, st, prm);
+    if (f64) hipLaunchKernelGGL(k_dosage<double>, dim3(G, P), dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL(k_dosage<float>, dim3(G, P), dim3(256), 0, st, prm);
     QA_HIP(hipGetLastError());
+    QA_HIP(hipEventRecord(S.ev[4], st));
     std::vector<int32_t> cnt;
-    for (int attempt = 0; any_top && attempt < 2; attempt++) {
+    int n_handed_over = 0;
+    if (fused) {
+        // the backward kernel wrote the lists; the grids whose candidates overflowed its LDS list (top_cnt = -1: ties)
+        // left their beta column for k_topk
+        cnt.resize((size_t)P * n_thin);
+        S.top_cnt.download(cnt.data(), cnt.size(), st);
+        std::vector<int32_t> todo;
+        for (size_t i = 0; i < cnt.size(); i++)
+            if (cnt[i] < 0) { todo.push_back((int32_t)(i / n_thin)); todo.push_back((int32_t)(i % n_thin)); }
+        n_handed_over = (int)todo.size() / 2;
+        if (n_handed_over) {
+            qa::DBuf<int32_t> d_todo(todo.size());
+            d_todo.upload(todo.data(), todo.size(), st);
+            prm.topk_todo = d_todo.p;
+            hipLaunchKernelGGL(k_topk<double>, dim3(n_handed_over), dim3(256), 0, st, prm, geo.NT);
+            QA_HIP(hipGetLastError());
+            S.top_cnt.download(cnt.data(), cnt.size(), st);
+            QA_HIP(hipStreamSynchronize(st));
+            prm.topk_todo = nullptr;
+        }
+    }
+    for (int attempt = 0; any_top && !fused && attempt < 2; attempt++) {
         prm.top_cap = top_cap;
-        prm.truncate_lists = out.truncate_lists ? 1 : 0;
         S.top_idx.ensure((size_t)P * n_thin * top_cap);
         S.top_val.ensure((size_t)P * n_thin * top_cap * es);
         prm.top_cnt = S.top_cnt.p; prm.top_idx = S.top_idx.p; prm.top_val = S.top_val.p;
@@ -1507,30 +1073,39 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         if (mx <= top_cap || out.truncate_lists) break;
         top_cap = mx;  // pathological ties (e.g. a label without reads): redo with room for all
     }
-    QA_HIP(hipEventRecord(S.ev[4], st));
+    QA_HIP(hipEventRecord(S.ev[5], st));
     QA_HIP(hipStreamSynchronize(st));
     float ms;
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 5; i++) {
         QA_HIP(hipEventElapsedTime(&ms, S.ev[i], S.ev[i + 1]));
         g_timing[i] = ms;
     }
-    QA_HIP(hipEventElapsedTime(&ms, S.ev[0], S.ev[4]));
-    g_timing[4] = ms;
+    QA_HIP(hipEventElapsedTime(&ms, S.ev[0], S.ev[5]));
+    g_timing[5] = ms;
     {
         // algorithmic HBM bytes of this launch set: per cell 1 B code + one state element
-        // (4 B, or 8 B in the fp64 ranking passes) on every stored column, forward (alpha) and backward
-        // (alpha re-read in dosage passes, beta store at thinned grids) alike
-        double cells_all = 0, cells_thin = 0;
+        // (4 B, or 8 B with fp64 state) on every stored column, forward (alpha) and backward (alpha re-read) alike;
+        // the separate top-K picker re-reads alpha and beta at the thinned grids twice (outside the SURVEY contract:
+        // it is what the fused picker of the fp64 ranking kernels removes); k_dosage reads the code histograms
+        double cells_all = 0, cells_thin = 0, n_dos = 0;
         for (int p = 0; p < P; p++) {
             if (h_flags[p] & 15) cells_all += (double)K * G; else cells_thin += (double)K * G;
+            if (h_flags[p] & 1) n_dos += 1;
         }
         const double frac = G > 0 ? (double)n_thin / G : 0;
         const double per_dir = cells_all * (1.0 + es) + cells_thin * (1.0 + es * frac);
+        const double topk_bytes = (any_top && !fused) ? (double)P * n_thin * K * es * 4.0
+                                                      : (double)n_handed_over * K * es * 4.0;
         const double t_e = qa::profile_clock_ms(S.ev[0]);
-        qa::profile_add(qa::PK_EMAT, g_timing[0], 0, t_e);
-        qa::profile_add(f64 ? qa::PK_FWD64 : qa::PK_FWD, g_timing[1], per_dir, t_e + g_timing[0]);
-        qa::profile_add(f64 ? qa::PK_BWD64 : qa::PK_BWD, g_timing[2], per_dir, t_e + g_timing[0] + g_timing[1]);
-        qa::profile_add(qa::PK_POST, g_timing[3], 0, t_e + g_timing[0] + g_timing[1] + g_timing[2]);
+        double at = t_e;
+        qa::profile_add(qa::PK_EMAT, g_timing[0], (double)P * T * 16.0 + (double)P * G * kMaxRow * es, at); at += g_timing[0];
+        const int pk_f = kind == KIND_F32 ? qa::PK_FWD : kind == KIND_F64_RANK ? qa::PK_FWD64 : qa::PK_FWD64G;
+        const int pk_b = kind == KIND_F32 ? qa::PK_BWD : kind == KIND_F64_RANK ? qa::PK_BWD64 : qa::PK_BWD64G;
+        qa::profile_add(pk_f, g_timing[1], per_dir, at); at += g_timing[1];
+        qa::profile_add(pk_b, g_timing[2], per_dir, at); at += g_timing[2];
+        if (n_dos > 0) qa::profile_add(qa::PK_DOSAGE, g_timing[3], n_dos * G * kMaxRow * (f64 ? 8.0 : 4.0) + n_dos * T * 8.0, at);
+        at += g_timing[3];
+        if (topk_bytes > 0) qa::profile_add(qa::PK_TOPK, g_timing[4], topk_bytes, at);
     }
 
     // ---- copy results back
@@ -1634,7 +1209,9 @@ extern "C" {
 
 int qa_last_fullpass_timing_ms(double out[5]) {
     if (!out) return QA_ERR_INVALID;
-    for (int i = 0; i < 5; i++) out[i] = g_timing[i];
+    for (int i = 0; i < 3; i++) out[i] = g_timing[i];
+    out[3] = g_timing[3] + g_timing[4];
+    out[4] = g_timing[5];
     return QA_OK;
 }
 
@@ -1696,35 +1273,39 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         for (int g = 0; g < G; g++) nt = std::max(nt, thin[g] + 1);
         const bool want_lists = o->get_best_haps_from_thinned_sites != 0;
         const int K_top = want_lists ? o->K_top_matches : 0;
-        auto plan = [&](bool f64, int32_t flags) {
-            const Geometry geo1 = pick_geometry(panel->K, f64);
-            if (geo1.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
+        auto plan = [&](PassKind kind, int32_t flags) {
+            const Geometry geo1 = pick_geometry(panel->K, kind);
+            if (geo1.NT == 0) throw std::runtime_error("K exceeds the on-chip capacity of the full-pass kernels");
             const size_t need = pass_bytes(panel, geo1, nt, (flags & 15) != 0, (flags & 4) != 0, (flags & 8) != 0, false) +
                                 (size_t)panel->K * G * 8 /* un-permute staging */;
             plan_chunk(panel, need, 1);
         };
+        const PassKind main_kind = panel->dosage_fp64 ? KIND_F64_FULL : KIND_F32;
         int st;
-        if (want_lists && panel->rank_fp64) {
+        if (want_lists && panel->rank_fp64 && only_thin) {
+            // only the lists (and alpha at the thinned grids, c): the fp64 ranking pass, which follows the reference's
+            // normalisation schedule (always_normalize / min_emission_prob_normalization_threshold honoured)
+            out.lists = &lists;
+            plan(KIND_F64_RANK, 0);
+            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, KIND_F64_RANK,
+                            o->always_normalize, o->min_emission_prob_normalization_threshold);
+        } else if (want_lists && panel->rank_fp64 && main_kind == KIND_F32) {
             // the best-haplotype lists come from a pass with fp64 state, so that their membership and order are
             // the reference's; every other output comes from the fp32 pass
-            if (only_thin) {
-                out.lists = &lists;
-                plan(true, 0);
-                st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, true);
-            } else {
-                plan(false, f);
-                st = run_passes(panel, 1, gl, &f, thin.data(), 0, o->normalize_emissions, out, false);
-                if (st != QA_OK) return st;
-                BatchOut out2;
-                out2.lists = &lists;
-                const int32_t f0 = 0;
-                plan(true, 0);
-                st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, true);
-            }
+            plan(KIND_F32, f);
+            st = run_passes(panel, 1, gl, &f, thin.data(), 0, o->normalize_emissions, out, KIND_F32);
+            if (st != QA_OK) return st;
+            BatchOut out2;
+            out2.lists = &lists;
+            const int32_t f0 = 0;
+            plan(KIND_F64_RANK, 0);
+            st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, KIND_F64_RANK,
+                            o->always_normalize, o->min_emission_prob_normalization_threshold);
         } else {
+            // one pass yields everything: fp32 state with fp32 ranking, or fp64 state (qa_panel_set_dosage_precision(64))
             if (want_lists) out.lists = &lists;
-            plan(false, f);
-            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, false);
+            plan(main_kind, f);
+            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, main_kind);
         }
         if (st != QA_OK || !want_lists) return st;
         return pack_lists(lists, best_ptr, best_idx, best_val, best_cap);
@@ -1745,10 +1326,12 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
         // chunk the passes so that the alpha checkpoints fit in HBM (K = 50 000, G = 2 000: 0.4 GB per dosage
         // pass, 0.08 GB per thin pass); chunks are homogeneous so that every pass of a chunk has the same footprint
         QA_HIP(hipSetDevice(panel->device));
-        const bool exact = panel->rank_fp64 && K_top_matches > 0;
-        const Geometry geo = pick_geometry(panel->K, false), geo64 = pick_geometry(panel->K, true);
+        const PassKind main_kind = panel->dosage_fp64 ? KIND_F64_FULL : KIND_F32;
+        // fp64 ranking passes beside fp32 dosage passes; with fp64 dosage passes, or fp32 ranking, one pass yields both
+        const bool exact = panel->rank_fp64 && K_top_matches > 0 && main_kind == KIND_F32;
+        const Geometry geo = pick_geometry(panel->K, main_kind), geo64 = pick_geometry(panel->K, KIND_F64_RANK);
         if (geo.NT == 0 || (exact && geo64.NT == 0))
-            throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
+            throw std::runtime_error("K exceeds the on-chip capacity of the full-pass kernels");
         const int G = panel->G, T = panel->T;
         int n_thin = 0;
         for (int g = 0; g < G; g++) n_thin = std::max(n_thin, gammaSmall_cols_to_get[g] + 1);
@@ -1761,12 +1344,14 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
             int run = 0;
             while (done + run < n_pass && (f[done + run] != 0) == dos) run++;
             if (!exact) {
-                const int n = plan_chunk(panel, pass_bytes(panel, geo, n_thin, dos, false, false, false), run);
+                // (thin passes of the fp64-dosage mode still take the faster ranking kernels)
+                const bool rank = !dos && panel->rank_fp64 && K_top_matches > 0 && geo64.NT != 0;
+                const int n = plan_chunk(panel, pass_bytes(panel, rank ? geo64 : geo, n_thin, dos, false, false, false), run);
                 BatchOut out;
                 out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
                 out.lists = &lists;
                 status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, gammaSmall_cols_to_get,
-                                    K_top_matches, 1, out);
+                                    K_top_matches, 1, out, rank ? KIND_F64_RANK : main_kind);
                 done += n;
                 continue;
             }
@@ -1777,14 +1362,14 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
                 BatchOut out;
                 out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
                 std::vector<int32_t> no_thin(G, -1);
-                status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, no_thin.data(), 0, 1, out, false);
+                status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, no_thin.data(), 0, 1, out, KIND_F32);
                 if (status != QA_OK) break;
                 plan_chunk(panel, pass_bytes(panel, geo64, n_thin, false, false, false, false), n);
             }
             BatchOut out2;
             out2.lists = &lists;
             status = run_passes(panel, n, gl + (size_t)done * T * 2, zeros.data(), gammaSmall_cols_to_get, K_top_matches, 1,
-                                out2, true);
+                                out2, KIND_F64_RANK);
             done += n;
         }
         if (status != QA_OK) return status;
@@ -1855,11 +1440,13 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
         const int P = n_chain * n_label;
         // Work groups of passes (pass = chain x label).  With fp64 ranking (the default) the dosage comes from a pass
         // with fp32 state and the best-haplotype lists from a pass with fp64 state; a chain that wants both runs both.
-        struct Group { std::vector<int32_t> ids; int32_t flag; int K_top; bool f64; };
+        struct Group { std::vector<int32_t> ids; int32_t flag; int K_top; PassKind kind; };
         std::vector<Group> groups;
         {
-            const bool exact = panel->rank_fp64;
-            Group gd{{}, 1, 0, false}, gdt{{}, 1, K_top_matches, false}, gt{{}, 0, K_top_matches, exact};
+            const PassKind main_kind = panel->dosage_fp64 ? KIND_F64_FULL : KIND_F32;
+            const bool exact = panel->rank_fp64 && main_kind == KIND_F32;   // else one pass yields dosage and lists
+            Group gd{{}, 1, 0, main_kind}, gdt{{}, 1, K_top_matches, main_kind},
+                gt{{}, 0, K_top_matches, panel->rank_fp64 ? KIND_F64_RANK : KIND_F32};
             for (int c = 0; c < n_chain; c++) {
                 const bool dos = want_dosage[c] != 0, top = K_top_matches > 0 && (!want_top || want_top[c] != 0);
                 for (int l = 0; l < n_label; l++) {
@@ -1898,8 +1485,8 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
         std::vector<int32_t> no_thin(G, -1);
         const double T1 = now();
         for (const Group &grp : groups) {
-            const Geometry geo = pick_geometry(panel->K, grp.f64);
-            if (geo.NT == 0) throw std::runtime_error("K exceeds the register-resident capacity of the full-pass kernels");
+            const Geometry geo = pick_geometry(panel->K, grp.kind);
+            if (geo.NT == 0) throw std::runtime_error("K exceeds the on-chip capacity of the full-pass kernels");
             const int n_grp = (int)grp.ids.size();
             std::vector<int32_t> ps(n_grp), pl(n_grp), ph(n_grp), flags(n_grp, grp.flag);
             for (int i = 0; i < n_grp; i++) {
@@ -1933,9 +1520,9 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                 out.true_counts = &true_cnt;
                 const double tr = now();
                 status = run_passes(panel, n, nullptr, flags.data() + done, grp.K_top > 0 ? gammaSmall_cols_to_get : no_thin.data(),
-                                    grp.K_top, 1, out, grp.f64);
+                                    grp.K_top, 1, out, grp.kind);
                 t_run += now() - tr;
-                t_kern += g_timing[4] / 1e3;
+                t_kern += g_timing[5] / 1e3;
                 if (status != QA_OK) break;
                 // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
                 if (grp.K_top > 0) {

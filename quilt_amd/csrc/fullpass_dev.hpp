@@ -1,0 +1,170 @@
+// fullpass_dev.hpp -- launch parameters and device helpers shared by the full-panel pass kernels: fullpass.hip (emission
+// tables, the fp32-state dosage passes, the generic fp64 passes, dosage mat-vec, top-K picker, host side) and
+// fullpass64.hip (the fp64-state ranking passes).  Everything lives in an unnamed namespace: each translation unit gets its
+// own copy.
+#pragma once
+
+#include "panel.hpp"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+constexpr int kMaxRow = 256;      // nMaxDH + 1 <= 256
+constexpr int kHistCopies = 32;   // bank-private copies of the gamma histogram
+// The histogram accumulates gamma * sigma_g (in [0, 1], summing to 1 over a grid) as fixed point with LDS integer
+// atomics: on gfx950 ds_add_u32 runs ~30x faster than ds_add_f32 (scripts/micro/lds_atomic_rate.hip: 0.10 vs 3.0 clk per
+// lane-op).  fp32-state passes: 32 bits, round-to-nearest at 2^-31 keeps the per-grid error near 3e-8 (random walk over K
+// adds).  fp64-state passes: 64 bits at 2^-62 (2e-19 per add: below fp64 rounding of the sum).
+constexpr float kHistScale = 2147483648.f;              // 2^31
+constexpr double kHistScale64 = 4611686018427387904.0;  // 2^62
+constexpr int kMaxTop = 8;        // K_top_matches supported in registers
+constexpr int kCandCap = 1024;    // candidates of the fused top-K picker kept in LDS (fp64 ranking passes)
+
+struct PassParams {
+    // panel
+    const uint8_t *hm;       // [G][Kp]
+    const int32_t *B;        // [G][nMaxDH]
+    const int32_t *sp_off;   // [G+1]
+    const int32_t *sp_k;
+    const uint32_t *sp_word;
+    const int32_t *sp_gidx;      // [G] index of the grid among those holding specials, or -1
+    const int32_t *sp_chunk_at;  // [n_sp_grids][Kp / 16] first entry (absolute) of the grid's special list at or after each 16-haplotype chunk
+    const double *sigma;     // [G-1]  transMatRate_t row 0
+    const double *tm1;       // [G-1]  transMatRate_t row 1 (1 - sigma as the caller passed it)
+    const double *IE;        // [T][nMaxDH] or null
+    int K, Kp, G, T, nMaxDH, nrow, n_special;
+    double ref_error;
+    // per launch
+    int P;                   // passes
+    const double *gl;        // [P][T][2]
+    const int32_t *thin_col; // [G]  -1 or thinned column
+    int n_thin;
+    const int32_t *flags;    // [P] bit0: dosage pass; bit1: store all alpha; bit2: store gamma; bit3: store beta
+    int normalize_emissions;
+    // fp64 ranking passes (fullpass64.hip): the reference's own normalisation schedule (reference-single.cpp:1096-1107)
+    int lazy;                // k_emat: raw grid-0 emissions and emin (the lazily normalised forward needs both)
+    int always_normalize;
+    double norm_threshold;   // min_emission_prob_normalization_threshold
+    double *emin;            // [P][G] min emission of the grid after normalisation (:1044-1057), -1: grid without variant
+    // scratch / outputs
+    void *emat;             // [P][G][kMaxRow]
+    void *esp;              // [P][esp_stride]
+    int esp_stride;          // n_special, or (lazy) n_special + 16 * (grids with specials): see k_emat
+    double *escale0;         // [P] factor applied to the grid-0 emissions (folded back into c[0])
+    void *alpha;            // [P][n_alpha_cols][Kq]   (lane-interleaved order)
+    const int32_t *alpha_slot; // [P][G] -> column slot in alpha, or -1
+    size_t alpha_pass_stride; // elements
+    int Kq;                  // NT * NCH * 16 (padded K of the launch geometry)
+    double *c;               // [P][G]
+    void *mg;                // [P][G][kMaxRow]  histogram of gamma * sigma_g by code, fixed point (dosage passes): uint32 at
+                             // 2^-31 (fp32 state) or uint64 at 2^-62 (fp64 state)
+    void *gsp;               // [P][n_special]   gamma of special haplotypes (float / double)
+    void *gamma_out;        // [P][G][Kq] or null
+    void *beta_out;         // [P][G][Kq] or null
+    void *beta_thin;        // [P][n_thin][Kq] unscaled beta at the thinned grids, or null
+    double *dosage;          // [P][T]
+    int K_top;
+    int top_cap;             // capacity per (pass, thinned column)
+    int truncate_lists;      // keep only the head (first top_cap in rejig order) of over-long lists
+    int fused_topk;          // fp64 ranking passes: the backward kernel picks the lists itself (top_cnt = -1: left to k_topk)
+    int32_t *top_cnt;        // [P][n_thin]
+    int32_t *top_idx;        // [P][n_thin][top_cap]
+    void *top_val;          // [P][n_thin][top_cap]
+    const int32_t *topk_todo;  // k_topk: null (every (thinned column, pass)), or [n][2] = (pass, column) pairs to do
+};
+
+__device__ __forceinline__ double word_emission(uint32_t w, const double2 *gl, int nLocal, double eps) {
+    double prob = 1.0;
+    const double ome = 1.0 - eps;
+    for (int b = 0; b < nLocal; b++) {
+        double2 v = gl[b];  // x = P(reads | ref), y = P(reads | alt)
+        prob *= ((w >> b) & 1u) ? (v.x * eps + v.y * ome) : (v.x * ome + v.y * eps);
+    }
+    return prob;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// first position in grid g's ascending special list whose haplotype index is >= k (rare path)
+__device__ __noinline__ int special_lower_bound(const int32_t *sp_k, int lo, int hi, int k) {
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (sp_k[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ bool has_zero_byte(uint32_t v) { return ((v - 0x01010101u) & ~v & 0x80808080u) != 0; }
+__device__ __forceinline__ bool any_zero_code(const uint4 &d) {
+    return has_zero_byte(d.x) || has_zero_byte(d.y) || has_zero_byte(d.z) || has_zero_byte(d.w);
+}
+
+// The recursions run with fp32 state (dosage passes: 16-byte vectors of 4) or fp64 state (16-byte vectors of 2).
+// Checkpoints are written in 16-byte vectors either way.
+template <typename TS> struct Vec;
+template <> struct Vec<float> { using V = float4; static constexpr int EPV = 4; using Hist = uint32_t; };
+template <> struct Vec<double> { using V = double2; static constexpr int EPV = 2; using Hist = unsigned long long; };
+__device__ __forceinline__ float vget(const float4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; }
+__device__ __forceinline__ double vget(const double2 &v, int r) { return r == 0 ? v.x : v.y; }
+__device__ __forceinline__ float4 vmake(const float *x) { return make_float4(x[0], x[1], x[2], x[3]); }
+__device__ __forceinline__ double2 vmake(const double *x) { return make_double2(x[0], x[1]); }
+
+// vector index of (chunk j, vector q) of this thread in the lane-interleaved checkpoint layout: each
+// (wave, j, q) owns 64 consecutive 16-byte vectors (1 KiB) => every dwordx4 store / load is coalesced.
+template <int NV>
+__device__ __forceinline__ size_t alpha_vec_index(int j, int q, int NT, int t) {
+    return (size_t)j * NT * NV + (size_t)((t >> 6) * NV + q) * 64 + (t & 63);
+}
+
+template <typename TS>
+__device__ __forceinline__ void store_chunk(typename Vec<TS>::V *dst, const TS (&x)[16], int j, int NT, int t) {
+    constexpr int EPV = Vec<TS>::EPV, NV = 16 / EPV;
+#pragma unroll
+    for (int q = 0; q < NV; q++) dst[alpha_vec_index<NV>(j, q, NT, t)] = vmake(&x[EPV * q]);
+}
+
+// block-wide sum of one double per thread: wave shuffle, then LDS across waves.  `buf` is one of two
+// alternating 16-entry buffers so that one barrier per call suffices.
+__device__ __forceinline__ double block_sum(double v, double *buf, int t, int nwaves) {
+    v = wave_sum(v);
+    if ((t & 63) == 0) buf[t >> 6] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < nwaves; w++) s += buf[w];
+    return s;
+}
+
+// compile-time loop: the chunk loops are too large for `#pragma unroll` to be honoured, and register-resident
+// state needs constant indices
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+}  // namespace
+
+namespace qa {
+// fullpass64.hip: the fp64-state ranking passes.  fb64_chunks: chunk rows (of 512 x 16 haplotypes) the geometry needs for K
+// haplotypes, 0 when K exceeds its on-chip capacity.
+int fb64_chunks(int K);
+size_t fb64_lds_bytes(int K);
+void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
+}  // namespace qa

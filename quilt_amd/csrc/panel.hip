@@ -56,7 +56,7 @@ int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, int s1, i
 }
 
 struct ProfileSlot {
-    double ms = 0, bytes = 0;
+    double ms = 0, bytes = 0, units = 0, serial = 0;
     long long launches = 0;
     std::vector<std::pair<double, double>> busy;   // [start, end) of every launch, ms since the process's reference event
 };
@@ -78,18 +78,78 @@ double profile_clock_ms(hipEvent_t ev) {
     return ms;
 }
 
-void profile_add(int kernel, double ms, double alg_bytes, double start_ms) {
+void profile_add(int kernel, double ms, double alg_bytes, double start_ms, double units, double serial) {
     if (kernel < 0 || kernel >= PK_COUNT) return;
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     g_profile[kernel].ms += ms;
     g_profile[kernel].bytes += alg_bytes;
+    g_profile[kernel].units += units;
+    g_profile[kernel].serial += serial;
     g_profile[kernel].launches += 1;
     if (start_ms >= 0) g_profile[kernel].busy.emplace_back(start_ms, start_ms + ms);
+}
+
+static const char *const kProfileNames[PK_COUNT] = {
+    "k_emat", "k_fwd", "k_bwd", "k_dosage", "k_ematread", "k_gibbs", "k_happrobs", "k_fwd64", "k_bwd64", "k_topk",
+    "k_fwd<double>", "k_bwd<double>", "k_gibbs3", "k_block3", "k_select"};
+
+// sp_gidx / sp_chunk_at (see panel.hpp): one thread per (grid with specials, 16-haplotype chunk), lower bound of the
+// chunk's first haplotype in the grid's ascending special list, shifted into the padded per-pass layout
+__global__ void k_special_chunk_index(const int32_t *sp_off, const int32_t *sp_k, const int32_t *sp_grids, int n_chunks,
+                                      int32_t *chunk_at) {
+    const int i = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int g = sp_grids[i];
+    int lo = sp_off[g], hi = sp_off[g + 1];
+    const int k0 = c * 16;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sp_k[mid] < k0) lo = mid + 1; else hi = mid;
+    }
+    chunk_at[(size_t)i * n_chunks + c] = lo + 16 * i;
+}
+
+void finish_panel_tables(qa_panel *p) {
+    const int G = p->G;
+    std::vector<int32_t> gidx(G, -1), grids;
+    for (int g = 0; g < G; g++)
+        if (p->h_sp_off[g + 1] > p->h_sp_off[g]) { gidx[g] = (int32_t)grids.size(); grids.push_back(g); }
+    p->n_sp_grids = (int)grids.size();
+    p->sp_gidx.alloc(G);
+    p->sp_gidx.upload(gidx.data(), G, p->stream);
+    // chunks up to the largest padded K any kernel geometry uses (rows of 8192 haplotypes: fullpass64.hip)
+    const int n_chunks = (p->K + 8191) / 8192 * 512;
+    p->sp_chunk_at.alloc(std::max<size_t>((size_t)p->n_sp_grids * n_chunks, 1));
+    if (p->n_sp_grids > 0) {
+        DBuf<int32_t> d_grids(grids.size());
+        d_grids.upload(grids.data(), grids.size(), p->stream);
+        hipLaunchKernelGGL(k_special_chunk_index, dim3((n_chunks + 255) / 256, p->n_sp_grids), dim3(256), 0, p->stream,
+                           p->sp_off.p, p->sp_k.p, d_grids.p, n_chunks, p->sp_chunk_at.p);
+        QA_HIP(hipGetLastError());
+        QA_HIP(hipStreamSynchronize(p->stream));
+    }
+    p->tm1.alloc(std::max(G - 1, 1));
+    p->tm1.upload(p->h_tm1.data(), std::max(G - 1, 0), p->stream);
+    QA_HIP(hipStreamSynchronize(p->stream));
 }
 
 }  // namespace qa
 
 extern "C" {
+
+int qa_profile_count(void) { return qa::PK_COUNT; }
+
+const char *qa_profile_name(int32_t kernel) {
+    return (kernel >= 0 && kernel < qa::PK_COUNT) ? qa::kProfileNames[kernel] : "";
+}
+
+int qa_profile_get_work(int32_t kernel, double *units, double *serial) {
+    if (kernel < 0 || kernel >= qa::PK_COUNT) return QA_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(qa::g_profile_mutex);
+    if (units) *units = qa::g_profile[kernel].units;
+    if (serial) *serial = qa::g_profile[kernel].serial;
+    return QA_OK;
+}
 
 int qa_profile_reset(void) {
     std::lock_guard<std::mutex> lock(qa::g_profile_mutex);
@@ -159,7 +219,7 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
         QA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         const int K = d->K, G = d->nGrids;
         p->K = K; p->G = G; p->T = d->nSNPs; p->nMaxDH = d->nMaxDH; p->nrow = d->nMaxDH + 1;
-        p->Kp = (K + 4095) / 4096 * 4096;   // whole 256-lane x 16-haplotype chunk rows (zero padded): see panel.hpp
+        p->Kp = (K + 8191) / 8192 * 8192;   // whole 512-lane x 16-haplotype chunk rows (zero padded): see panel.hpp
         p->ref_error = d->ref_error;
         // hapMatcher -> uint8 [G][Kp]
         p->hm.alloc((size_t)G * p->Kp);
@@ -242,6 +302,7 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
             }
         }
         QA_HIP(hipStreamSynchronize(p->stream));
+        qa::finish_panel_tables(p);
         *out = guard.release();
         return QA_OK;
     });
@@ -284,6 +345,15 @@ int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits) {
         return QA_ERR_INVALID;
     }
     panel->rank_fp64 = bits == 64;
+    return QA_OK;
+}
+
+int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits) {
+    if (!panel || (bits != 32 && bits != 64)) {
+        qa::set_error("qa_panel_set_dosage_precision: bits must be 32 or 64");
+        return QA_ERR_INVALID;
+    }
+    panel->dosage_fp64 = bits == 64;
     return QA_OK;
 }
 

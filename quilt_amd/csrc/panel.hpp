@@ -23,10 +23,17 @@ struct qa_panel {
     qa::DBuf<int32_t> sp_k;     // n_special
     qa::DBuf<uint32_t> sp_word; // n_special
     qa::DBuf<double> sigma;     // G - 1
+    qa::DBuf<double> tm1;       // G - 1: transMatRate_t row 1 as the caller passed it
+    // grids that hold specials: sp_gidx[g] = index among them (or -1), sp_chunk_at[index][Kq / 16] = position of the first
+    // special at or after each 16-haplotype chunk in the per-pass special-emission array of the fp64 ranking kernels (each
+    // such grid's list followed by 16 zero entries: k_emat), so that those kernels need no search
+    qa::DBuf<int32_t> sp_gidx, sp_chunk_at;
+    int n_sp_grids = 0;
     qa::DBuf<double> IE;        // only when the caller's distinctHapsIE is not the (B, eps) expansion
     bool ie_derived = true;
     int share = 1;              // host threads / panel handles sharing this device (qa_panel_set_device_share)
     bool rank_fp64 = true;      // best-haplotype lists from fp64-state passes (qa_panel_set_ranking_precision)
+    bool dosage_fp64 = false;   // dosage / alpha / beta / gamma outputs from fp64-state passes (qa_panel_set_dosage_precision)
     int n_special = 0;
     std::vector<double> h_sigma, h_tm1;  // transMatRate_t rows 0 and 1 as passed
     std::vector<int32_t> h_sp_off;
@@ -38,6 +45,11 @@ struct qa_panel {
     Scratch *scratch = nullptr;
     ~qa_panel();
 };
+
+namespace qa {
+// after sp_off / sp_k are on the device and h_sp_off on the host: sp_gidx, sp_chunk_at, tm1
+void finish_panel_tables(qa_panel *p);
+}
 
 // The all-SNP side of a QUILT2 panel (rare + common SNPs): what the final all-SNP Gibbs call needs on top of the
 // common-SNP panel tables.  rare_snp holds 0-based all-SNP indices, ascending within a haplotype.

@@ -221,7 +221,7 @@ int qa_panel_create_from_rhb(const int32_t *rhb_t, int32_t K, int32_t nGrids, in
         hipStream_t st = p->stream;
         const int G = nGrids;
         p->K = K; p->G = G; p->T = nSNPs; p->nMaxDH = nMaxDH; p->nrow = nMaxDH + 1;
-        p->Kp = (K + 4095) / 4096 * 4096;
+        p->Kp = (K + 8191) / 8192 * 8192;
         p->ref_error = ref_error;
         p->ie_derived = true;
         p->hm.alloc((size_t)G * p->Kp);
@@ -284,6 +284,7 @@ int qa_panel_create_from_rhb(const int32_t *rhb_t, int32_t K, int32_t nGrids, in
         p->sigma.alloc(std::max(G - 1, 1));
         p->sigma.upload(p->h_sigma.data(), std::max(G - 1, 0), st);
         QA_HIP(hipStreamSynchronize(st));
+        qa::finish_panel_tables(p);
         *out = guard.release();
         return QA_OK;
     });

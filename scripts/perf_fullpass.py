@@ -18,6 +18,7 @@ ap.add_argument("--P", type=int, default=256)
 ap.add_argument("--thin-frac", type=float, default=0.0, help="fraction of thin passes")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--ktop", type=int, default=5)
+ap.add_argument("--driver", action="store_true", help="time the driver path (qa_fullpass_reads_batch: fused top-K)")
 a = ap.parse_args()
 
 t0 = time.time()
@@ -44,7 +45,8 @@ bptr = np.zeros(a.P * n_thin + 1, dtype=np.int32)
 cap = a.P * n_thin * 64
 bidx = np.zeros(cap, dtype=np.int32)
 bval = np.zeros(cap)
-NAMES = ["k_emat", "k_fwd", "k_bwd", "k_dosage+k_topk", "k_ematread", "k_gibbs", "k_happrobs", "k_fwd64", "k_bwd64"]
+lib().qa_profile_name.restype = C.c_char_p
+NAMES = [lib().qa_profile_name(C.c_int32(k)).decode() for k in range(lib().qa_profile_count())]
 for r in range(a.reps):
     t0 = time.time()
     lib().qa_profile_reset()

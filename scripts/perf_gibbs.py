@@ -11,11 +11,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--K", type=int, default=50000); ap.add_argument("--T", type=int, default=64000)
 ap.add_argument("--chains", type=int, default=224); ap.add_argument("--reads", type=int, default=20000)
 ap.add_argument("--Ks", type=int, default=600); ap.add_argument("--reps", type=int, default=2)
-ap.add_argument("--init-iter", action="store_true")
+ap.add_argument("--init-iter", action="store_true"); ap.add_argument("--samples", type=int, default=0)
 a = ap.parse_args()
 panel = make_synthetic_panel(K=a.K, nSNPs=a.T, seed=4916)
 dev = DevicePanel(panel)
-ns = max(1, a.chains // 7)
+ns = a.samples or max(1, a.chains // 7)
 samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=a.reads) for i in range(ns)]
 rng = np.random.default_rng(0)
 S = [samples[c % ns] for c in range(a.chains)]
