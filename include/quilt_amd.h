@@ -261,6 +261,13 @@ typedef struct {
     /* NULL, or (NIPT only, ff > 0) n_chain fetal fractions in (0, 1), one per chain, overriding ff: lets one launch set
      * carry samples with different fetal fractions (ff_values[iSample], functions.R:128) */
     const double *ff_chain;
+    /* NULL, or an OUTPUT of n_chain x (n_gibbs_burn_in_its + n_gibbs_sample_its) x 8 doubles: what add_to_per_it_likelihoods
+     * (QUILT/src/gibbs-nipt.cpp:1583-1621, calculate_likelihoods_values :1483-1519) needs after every sweep, per chain and
+     * sweep: -sum(log c1), -sum(log c2), -sum(log c3) (0 for a label the mode does not have), the number of reads holding
+     * label 1, 2, 3, and two reserved zeros.  The R shim turns a row into the 13 columns of per_it_likelihoods
+     * (p_O_given_H_L, p_H_given_L, p_set_H_given_L ...); p_H_class_given_L needs H_class, which only the last sweep
+     * records (it is overwritten by every sweep: gibbs-nipt.cpp:1142-1165). */
+    double *per_it_out;
 } qa_gibbs_opts_t;
 
 /*

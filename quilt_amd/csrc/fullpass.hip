@@ -664,11 +664,12 @@ __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
     const int g = blockIdx.x, p = blockIdx.y;
     if (!(prm.flags[p] & 1)) return;
     const int b = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts
-    __shared__ double s_acc[8][32];
+    __shared__ double s_acc[8][32], s_tot[8];
     const int s = 32 * g;
     const int nLocal = min(32, prm.T - s);
     const Hist *mg = static_cast<const Hist *>(prm.mg) + ((size_t)p * prm.G + g) * kMaxRow;
     const double eps = prm.ref_error, ome = 1.0 - eps;
+    const double unit = sizeof(TS) == 8 ? 1.0 / kHistScale64 : 1.0 / (double)kHistScale;
     double acc = 0, acc_sp = 0;   // histogram part (already times sigma_g) and specials (raw gamma)
     if (b < nLocal) {
         for (int d = 1 + part; d < prm.nrow; d += 8) {
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
                 const uint32_t w = (uint32_t)prm.B[(size_t)g * prm.nMaxDH + (d - 1)];
                 ie = ((w >> b) & 1u) ? ome : eps;
             }
-            acc += ie * ((double)mg[d] * (sizeof(TS) == 8 ? 1.0 / kHistScale64 : 1.0 / (double)kHistScale));
+            acc += ie * ((double)mg[d] * unit);
         }
         const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
         for (int i = part; i < sn; i += 8) {
@@ -687,12 +688,22 @@ __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
             acc_sp += gk * (((prm.sp_word[so + i] >> b) & 1u) ? ome : eps);
         }
     }
+    if (b == 0) {   // this part's share of the grid's total gamma * sigma (bin 0 holds the specials')
+        double tot = 0;
+        for (int d = part; d < prm.nrow; d += 8) tot += (double)mg[d] * unit;
+        s_tot[part] = tot;
+    }
     const double sig = (g < prm.G - 1) ? prm.sigma[g] : 1.0;
     s_acc[part][b] = acc + acc_sp * sig;
     __syncthreads();
     if (part == 0 && b < nLocal) {
-        double tot = 0;
-        for (int q = 0; q < 8; q++) tot += s_acc[q][b];
+        double tot = 0, mass = 0;
+        for (int q = 0; q < 8; q++) { tot += s_acc[q][b]; mass += s_tot[q]; }
+        // gamma * sigma_g of a grid (what the histogram accumulates) sums to 1 (reference-single.cpp:2048-2091, :2170-2176;
+        // the reference's test suite checks colSums(gamma_t) == 1).  Dividing by the mass actually accumulated removes the
+        // common-mode drift of the state's scale (with fp32 state ~3e-8 per grid, 6e-5 over 2 000 grids), which is all
+        // the dosage of a long region would otherwise inherit from 2 000 renormalisations in single precision.
+        if (mass > 0) tot /= mass;
         prm.dosage[(size_t)p * prm.T + s + b] = tot;
     }
 }

@@ -488,6 +488,17 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
             ch.template bsum<2>(s);
             if (!isfinite(s[0]) || !isfinite(s[1])) status = 1;
         }
+        if (p.per_it) {
+            // add_to_per_it_likelihoods (:1583-1621): -sum(log c_h) and the number of reads per label after this sweep
+            double s[4] = {0, 0, 0, 0};
+            for (int g = t; g < G; g += NT) { s[0] -= log(ch.cv[0][g]); s[1] -= log(ch.cv[1][g]); }
+            for (int r = t; r < R; r += NT) { const int h = ch.H[r]; s[2] += h == 1 ? 1.0 : 0.0; s[3] += h == 2 ? 1.0 : 0.0; }
+            ch.template bsum<4>(s);
+            if (t == 0) {
+                double *o = p.per_it + ((size_t)c * p.n_its + it) * 8;
+                o[0] = s[0]; o[1] = s[1]; o[2] = 0; o[3] = s[2]; o[4] = s[3]; o[5] = 0; o[6] = 0; o[7] = 0;
+            }
+        }
         if (status) break;
         bool to_block = false;
         for (int i = 0; i < p.n_block; i++) if (p.block_its[i] == it) to_block = true;
@@ -836,7 +847,7 @@ struct GibbsScratch {
     DBuf<size_t> eread_off;
     DBuf<uint64_t> seeds;
     DBuf<uint32_t> rc_any;
-    DBuf<double> blk_rate2, ff_chain;
+    DBuf<double> blk_rate2, ff_chain, per_it;
     DBuf<int32_t> blk_where, blk_tab, blk_n;
 };
 
@@ -971,7 +982,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
 
 }  // namespace
 
-static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, int per_it_off, int32_t n_chain, const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
@@ -1150,6 +1161,11 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         prm.nH = nH;
         prm.it_begin = 0; prm.it_end = n_its;
         prm.ff = o->ff;
+        if (o->per_it_out) {
+            S.per_it.ensure((size_t)C * n_its * 8);
+            QA_HIP(hipMemsetAsync(S.per_it.p, 0, sizeof(double) * C * n_its * 8, st));
+            prm.per_it = S.per_it.p;
+        }
         if (ff_chain) {
             S.ff_chain.ensure(C); S.ff_chain.upload(ff_chain, C, st);
             prm.ff_chain = S.ff_chain.p;
@@ -1240,6 +1256,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         launch_gibbs(prm, maxR, st, g_gibbs->ev, want_probs, nw, nipt_sweeps);
         S.H.download(H, totR, st);
         if (H_class) S.H_class.download(H_class, totR, st);
+        if (o->per_it_out) S.per_it.download(o->per_it_out + (size_t)per_it_off * n_its * 8, (size_t)C * n_its * 8, st);
         std::vector<int32_t> status(C);
         S.status.download(status.data(), C, st);
         QA_HIP(hipStreamSynchronize(st));
@@ -1257,9 +1274,14 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
             const double sweeps = (double)n_its * (C * col + (double)totR * Ks * 8.0) +
                                   (1.0 + 2.0 * prm.n_block) * C * col;
             const double t_e = qa::profile_clock_ms(g_gibbs->ev[0]);
+            // work units: read visits + grid steps over all chains; serial: those of the longest chain (the launch's
+            // critical path: sweeps, initial forward / backward, shard or block passes)
+            const double passes = (double)n_its + 1.0 + 2.0 * prm.n_block;
+            const double units = (double)n_its * totR + passes * (double)C * G;
+            const double serial = (double)n_its * maxR + passes * (double)G;
             qa::profile_add(qa::PK_EMATREAD, ms[0], (double)totR * Ks * 8.0, t_e);
-            qa::profile_add(qa::PK_GIBBS, ms[1], sweeps, t_e + ms[0]);
-            qa::profile_add(qa::PK_HAPPROBS, ms[2], C * 2.0 * Ks * (double)G * 16.0, t_e + ms[0] + ms[1]);
+            qa::profile_add(nH == 3 ? qa::PK_GIBBS3 : qa::PK_GIBBS, ms[1], sweeps * (nH / 2.0), t_e + ms[0], units, serial);
+            if (want_probs) qa::profile_add(qa::PK_HAPPROBS, ms[2], C * (double)nH * Ks * (double)G * 16.0, t_e + ms[0] + ms[1]);
             if (tmg)
                 fprintf(stderr, "[qa_gibbs C=%d] host prep %.3f s, tables+uploads %.3f s, kernels %.3f s (events %.3f), downloads %.3f s\n", C,
                         T1 - T0, T2 - T1, T3 - T2, (ms[0] + ms[1] + ms[2]) / 1e3, now() - T3);
@@ -1316,6 +1338,20 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
                       "and the block passes' uniforms (runif_shard or seeds)");
         return QA_ERR_INVALID;
     }
+    // the uniforms of the shard passes (diploid) / block passes (NIPT): explicit, or the per-chain seed of the counter-based
+    // stream -- never uninitialised device memory
+    if (seed_shard && !seed_reads) {
+        qa::set_error("qa_gibbs_batch: seed_shard goes with seed_reads (the two counter-based streams of a chain)");
+        return QA_ERR_INVALID;
+    }
+    {
+        const bool passes = o->perform_block_gibbs && o->n_block_gibbs_iterations > 0 && (o->ff != 0.0 || o->do_shard_block_gibbs);
+        if (passes && !runif_shard && !(seed_reads && seed_shard)) {
+            qa::set_error("qa_gibbs_batch: block / shard passes requested without their uniforms (runif_shard, or seed_reads and "
+                          "seed_shard)");
+            return QA_ERR_INVALID;
+        }
+    }
     if (o->ff_chain) {
         bool ok = o->ff != 0.0;
         for (int c = 0; c < n_chain && ok; c++) ok = o->ff_chain[c] > 0 && o->ff_chain[c] < 1;
@@ -1362,7 +1398,7 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             std::vector<int32_t> ro(c1 - c0 + 1);
             for (int i = 0; i <= c1 - c0; i++) ro[i] = read_off[c0 + i] - read_off[c0];
             const int st = gibbs_chunk(
-                pn, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
+                pn, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, c0, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
                 u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
                 runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
                 runif_shard ? runif_shard + (o->ff != 0.0 ? (size_t)read_off[c0] * nb * 2 : (size_t)c0 * nb * (G - 1)) : nullptr,

@@ -427,6 +427,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
             ch.template bsum<2>(s);
             if (!isfinite(s[0]) || !isfinite(s[1])) status = 1;
         }
+        if (p.per_it) {
+            // add_to_per_it_likelihoods (:1583-1621): -sum(log c_h) and the number of reads per label after this sweep
+            double s[6] = {0, 0, 0, 0, 0, 0};
+            for (int g = t; g < G; g += NT) { s[0] -= log(ch.cv[0][g]); s[1] -= log(ch.cv[1][g]); s[2] -= log(ch.cv[2][g]); }
+            for (int r = t; r < R; r += NT) { const int h = ch.H[r]; s[3] += h == 1 ? 1.0 : 0.0; s[4] += h == 2 ? 1.0 : 0.0; s[5] += h == 3 ? 1.0 : 0.0; }
+            double s2[2];
+            s2[0] = s[0]; s2[1] = s[1]; ch.template bsum<2>(s2); s[0] = s2[0]; s[1] = s2[1];
+            s2[0] = s[2]; s2[1] = s[3]; ch.template bsum<2>(s2); s[2] = s2[0]; s[3] = s2[1];
+            s2[0] = s[4]; s2[1] = s[5]; ch.template bsum<2>(s2); s[4] = s2[0]; s[5] = s2[1];
+            if (t == 0) {
+                double *o = p.per_it + ((size_t)c * p.n_its + it) * 8;
+                for (int i = 0; i < 6; i++) o[i] = s[i];
+                o[6] = o[7] = 0;
+            }
+        }
     }
     if (t == 0) p.status[c] = status;
 }

@@ -91,6 +91,7 @@ struct GibbsParams {
     int blk_pass, blk_n_pass;   // this pass / passes per call (indexes the pass's uniforms)
     double ff;
     const double *ff_chain;     // [C] or null: per-chain fetal fraction overriding ff
+    double *per_it;             // [C][n_its][8] or null: per sweep -sum(log c_h) and the label counts (qa_gibbs_opts_t.per_it_out)
 };
 
 // does panel haplotype `hap` carry the alt allele of rare SNP `snp` (rare_per_hap_info)

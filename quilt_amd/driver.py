@@ -56,6 +56,16 @@ class DriverParams:
             p.n_seek_its, p.n_burn_in_seek_its, p.Ksubset, p.Knew = 1, 0, K, K
         if p.Knew > p.Ksubset:                      # quilt.R:467-471
             p.Knew = p.Ksubset
+        # validate_n_seek_its_and_n_burn_in_seek_its (quilt.R; STITCH-style argument checks)
+        if p.n_seek_its < 1 or int(p.n_seek_its) != p.n_seek_its:
+            raise ValueError("n_seek_its must be an integer >= 1")
+        if p.n_burn_in_seek_its < 0 or p.n_burn_in_seek_its >= p.n_seek_its:
+            raise ValueError("n_burn_in_seek_its must be in 0 .. n_seek_its - 1 (at least one seek iteration must count towards "
+                             "the dosages)")
+        if p.nGibbsSamples < 1 or p.Ksubset < 1 or p.Knew < 1:
+            raise ValueError("nGibbsSamples, Ksubset and Knew must be >= 1")
+        if p.K_top_matches < 1:
+            raise ValueError("K_top_matches must be >= 1")
         return p
 
 
@@ -88,6 +98,10 @@ def make_gl_from_u_bq(u: np.ndarray, bq: np.ndarray, nSNPs: int, minGLValue: flo
     """reference-single.R:19-42: per-label genotype likelihoods from the reads' bases (host code in the
     reference too); ``make_gl_bound`` is the native ``Rcpp_make_gl_bound``."""
     gl = np.ones((2, nSNPs), dtype=np.float64, order="F")
+    # a base with bq == 0 carries no allele (neither ref nor alt in the signed-quality convention): the caller filters
+    # such bases (functions.R:2018-2020) and the device kernel skips them (k_make_gl); here too they contribute nothing
+    keep = np.asarray(bq) != 0
+    u, bq = np.asarray(u)[keep], np.asarray(bq)[keep]
     if len(u) == 0:
         return gl
     eps = 10.0 ** (-np.abs(bq) / 10.0)
@@ -113,6 +127,11 @@ def everything_per_hap_rejig_haps(best_haps_stuff_list) -> List[np.ndarray]:
     return out
 
 
+class ListsTruncated(Exception):
+    """everything_select_good_haps reached its exhausted branch (all entries of all lists, functions.R:2278-2281) while at
+    least one best-haplotype list had been cut to the batched call's ``top_width``: the full lists are needed."""
+
+
 def _unique_in_order(a: np.ndarray) -> np.ndarray:
     _, idx = np.unique(a, return_index=True)
     return a[np.sort(idx)]
@@ -132,11 +151,12 @@ def everything_select_good_haps(Knew: int, K_top_matches: int, new_haps: List[Li
 
 def everything_select_good_haps_dense(Knew: int, K_top_matches: int, top: np.ndarray,
                                       previously_selected_haplotypes: np.ndarray, K: int,
-                                      rng: np.random.Generator) -> np.ndarray:
+                                      rng: np.random.Generator, truncated: bool = False) -> np.ndarray:
     """functions.R:2262-2310 on a dense table ``top[label, thinned grid, rank]`` of 1-based haplotypes (0 = no
     entry), each list ordered best first (functions.R:2161-2170).  Rank by rank, the distinct candidates (label-
     major, grid order: R's ``unlist(sapply(new_haps, ...))``) are added until ``Knew`` are found; the last rank
-    is subsampled at random."""
+    is subsampled at random.  ``truncated``: some list is longer than the table is wide (ties at its threshold); the ranks
+    up to ``K_top_matches`` are still exact, the exhausted branch is not (see :class:`ListsTruncated`)."""
     i = 1
     to_keep = np.zeros(0, dtype=np.int64)
     prev = np.asarray(previously_selected_haplotypes, dtype=np.int64)
@@ -145,6 +165,8 @@ def everything_select_good_haps_dense(Knew: int, K_top_matches: int, top: np.nda
         if i <= K_top_matches and i <= top.shape[2]:
             vals = top[:, :, i - 1].ravel()
         else:
+            if truncated:   # raised before any random draw: the caller re-runs the selection on the full lists
+                raise ListsTruncated()
             vals = top.reshape(-1)
             done = True
         vals = vals[vals > 0]
@@ -477,6 +499,8 @@ class Driver:
         self.n_thin = int((self.cols >= 0).sum())
         self.top_width = max(8, self.params.K_top_matches)   # entries kept per (label, thinned grid) list
         self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0}
+        self.n_full_list_refetches = 0   # chains whose selection needed the untruncated best-haplotype lists
+        self.n_underflow_retries = 0     # Gibbs calls repeated with a smaller maxDifferenceBetweenReads
 
     # -- one [Gibbs -> full pass -> select] round over a set of chains (main and / or phasing chains, same i_it)
     def _round(self, chains: List[ChainState], i_it: int):
@@ -488,6 +512,8 @@ class Driver:
         starts, seed_reads, first_reads, seed_shards = [], [], [], []
         for ch in chains:
             R = ch.sample.nReads
+            if R < 1:   # the reference drops such samples before imputing (functions.R:300-310: "sample has no reads")
+                raise ValueError("a sample without reads cannot be imputed (no read intersects a SNP of the region)")
             first = (i_it == 1) and not ch.phasing
             any_first |= first
             if first:
@@ -551,10 +577,33 @@ class Driver:
             if not want_top[ci]:
                 continue
             prev_sel = ch.which_haps_to_use[ch.rng.permutation(len(ch.which_haps_to_use))[: P.Ksubset - P.Knew]]
-            sel = everything_select_good_haps_dense(P.Knew, P.K_top_matches, top[ci].astype(np.int64) + 1, prev_sel, K, ch.rng)
+            try:
+                sel = everything_select_good_haps_dense(P.Knew, P.K_top_matches, top[ci].astype(np.int64) + 1, prev_sel, K,
+                                                        ch.rng, truncated=bool((top_cnt[ci] > self.top_width).any()))
+            except ListsTruncated:
+                # the reference's lists hold every haplotype at or above the threshold (reference-single.cpp:129-194); the
+                # batched call returns their first top_width entries.  Ties made a list longer and the selection ran out
+                # of ranked candidates: fetch this chain's full lists and select from them (functions.R:2278-2281)
+                self.n_full_list_refetches += 1
+                new_haps = self._full_lists(ch)
+                sel = everything_select_good_haps(P.Knew, P.K_top_matches, new_haps, prev_sel, K, ch.rng)
             ch.which_haps_to_use = np.concatenate([prev_sel, sel]).astype(np.int32)
         self.timing["host"] += time.perf_counter() - t4
         return return_dosage
+
+    def _full_lists(self, ch: ChainState) -> List[List[np.ndarray]]:
+        """``new_haps`` of one chain from complete best-haplotype lists: per read label its gl (make_gl_from_u_bq,
+        reference-single.R:19-42), a thin full-panel pass returning the whole lists, ordered per thinned grid as
+        everything_per_hap_rejig_haps does."""
+        P = self.params
+        s = ch.sample
+        per_base = np.repeat(ch.read_labels, np.diff(s.read_ptr))
+        gls = []
+        for l in range(1, self.n_label + 1):
+            sel = (per_base == l) & (s.bq != 0)
+            gls.append(make_gl_from_u_bq(s.u[sel], s.bq[sel], self.panel.nSNPs, P.minGLValue, self.backend.make_gl_bound))
+        _, best = self.backend.fullpass_batch(gls, [0] * len(gls), self.cols, P.K_top_matches)
+        return [everything_per_hap_rejig_haps(b) for b in best]
 
     def _gibbs_with_retry(self, chains, samples, starts, seed_reads, first_reads, seed_shards, **kw):
         """impute_one_sample's loop (functions.R:2612-2716): a chain whose call reports underflow is re-run with
@@ -583,6 +632,7 @@ class Driver:
                     if o["underflow_problem"]:
                         maxdiff[i] = max(1.0, maxdiff[i] / 10)   # functions.R:2704-2715
                         nxt.append(i)
+                        self.n_underflow_retries += 1
                     else:
                         results[i] = o
             pending = nxt

@@ -55,9 +55,11 @@ def lib() -> C.CDLL:
                  "qa_rcpp_make_eMatRead_t", "qa_profile_reset", "qa_profile_get", "qa_fullpass_reads_batch",
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
                      "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy", "qa_panel_create_from_rhb",
-                     "qa_panel_export_tables", "qa_rcpp_make_eMatRead_t_nsnps", "qa_rare_common_create",
+                     "qa_panel_export_tables", "qa_rcpp_make_eMatRead_t_nsnps", "qa_rare_common_create", "qa_profile_count",
+                     "qa_profile_get_work", "qa_panel_set_dosage_precision",
                      "qa_gibbs_batch_rare_common", "qa_nipt_block_table", "qa_panel_set_cu_partition"):
             getattr(L, name).restype = C.c_int
+        L.qa_profile_name.restype = C.c_char_p
         L.qa_panel_destroy.restype = None
         L.qa_rare_common_destroy.restype = None
         _lib = L
@@ -148,6 +150,11 @@ class DevicePanel:
         """64 (default): best-haplotype lists from fp64-state passes (the reference's arithmetic); 32: from the
         fp32-state pass (faster; near-ties may be ordered differently)."""
         check(lib().qa_panel_set_ranking_precision(self.handle, C.c_int32(bits)))
+
+    def set_dosage_precision(self, bits: int):
+        """32 (default): dosage / alpha / beta / gamma outputs from fp32 state (fp64 emissions and sums); 64: fp64 state
+        throughout, as the reference (a verification mode, several times slower)."""
+        check(lib().qa_panel_set_dosage_precision(self.handle, C.c_int32(bits)))
 
     def set_device_share(self, n_sharers: int):
         """This handle is one of ``n_sharers`` working on the device concurrently (one per host thread)."""

@@ -20,11 +20,13 @@ from .sharding import get_sample_range
 
 class DeviceWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
-                 cu_partition: bool = False):
+                 cu_partition: bool = False, fp64_dosage: bool = False):
         self.n = n_workers
         self.devs = [DevicePanel(panel) for _ in range(n_workers)]
         for w, d in enumerate(self.devs):
             d.set_device_share(n_workers)
+            if fp64_dosage:   # dosage passes with fp64 state, as the reference (verification mode)
+                d.set_dosage_precision(64)
             if cu_partition and n_workers > 1:   # each thread's Gibbs chains on its own share of the CUs (measured slower: DESIGN.md 5)
                 d.set_cu_partition(w, n_workers)
         self.drcs = [DeviceRareCommon(d, rare_common) if rare_common is not None else None for d in self.devs]
@@ -79,3 +81,28 @@ class DeviceWorkers:
             yield merged
         for t in threads:
             t.join()
+
+
+class StubWorkers:
+    """Test hook of ``bench.py --stub``: the DeviceWorkers surface without any device (or oracle) work -- every sample comes
+    back with zero dosages.  Lets the multi-rank launch / rendezvous / timing / reporting path of the bench be exercised
+    on a machine without GPUs; it measures nothing."""
+
+    def __init__(self, panel, params: Optional[DriverParams] = None):
+        self.panel = panel
+        self.devs = []
+        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0}
+
+    def reset_timing(self):
+        self.timing = {k: 0.0 for k in self.timing}
+
+    def close(self):
+        pass
+
+    def run_stream(self, batches):
+        import numpy as np
+        from .driver import SampleResult
+        T = self.panel.nSNPs
+        for samples, _ in batches:
+            yield [SampleResult(np.zeros(T), np.zeros((3, T)), np.zeros((T, 2)), np.zeros(s.nReads, dtype=np.int32), 0)
+                   for s in samples]

@@ -1,0 +1,442 @@
+/*
+ * quilt_amd_shim.c -- the R side of the drop-in boundary: a shared object whose registered `.Call` routines have the
+ * reference's own names and arities and forward to libquilt_amd.so (include/quilt_amd.h).
+ *
+ * What it replaces.  QUILT's R code reaches its native hot path through `.Call('_QUILT_<fn>', PACKAGE = 'QUILT', ...)`
+ * (QUILT/R/RcppExports.R); the routines are registered in QUILT/src/RcppExports.cpp:1703-1782 (`CallEntries[]`,
+ * `R_init_QUILT`).  This file registers, under the same symbol names and with the same number of arguments:
+ *
+ *   _QUILT_Rcpp_haploid_dosage_versus_refs   38 arguments   RcppExports.cpp:1580-1625   -> qa_Rcpp_haploid_dosage_versus_refs
+ *   _QUILT_rcpp_forwardBackwardGibbsNIPT     63 arguments   RcppExports.cpp:966-1038    -> qa_gibbs_batch(_rare_common)
+ *   _QUILT_Rcpp_make_gl_bound                 3 arguments   RcppExports.cpp:1263-1273   -> qa_Rcpp_make_gl_bound
+ *
+ * Built as QUILT.so's replacement for these three entries (link order / `useDynLib` of a patched package), or loaded
+ * beside an unmodified QUILT and swapped in with `assignInNamespace` (INTEGRATION.md shows both); no R function changes its
+ * signature.  The prepared panel is uploaded on first use and cached in this file (keyed by the identity of the R
+ * objects: data pointer and dimensions of distinctHapsB / hapMatcherR), so the 38- and 63-argument entries keep their
+ * arity; `qa_shim_release()` (0 arguments) drops the cache.  R owns every buffer it passes: results are copied back into
+ * them before returning (SURVEY.md 8(b) "Ownership").
+ *
+ * Random numbers.  The reference draws inside the native call from R's generator (`Rcpp::runif`, `Rcpp::sample`:
+ * gibbs-nipt.cpp:2845-2848, 3013-3018; gibbs-nipt-block.cpp:2054) under `Rcpp::RNGScope` (RcppExports.cpp:971).  The
+ * shim draws the same uniforms, in the same order, with unif_rand() between GetRNGstate() / PutRNGstate() and passes them
+ * down; the device never generates R-incompatible numbers on this path.  Where the reference's draw count depends on
+ * intermediate results (`Rcpp::sample(1:3, 1, prob)` per read in rcpp_sample_H_using_H_class, NIPT only) the stream
+ * cannot be pre-drawn in R's order: one uniform per read is drawn instead (documented deviation).
+ *
+ * Type-checked without R by `make -C shim check` against shim/qa_r_api.h (declarations only).
+ */
+#ifdef QA_HAVE_R
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Random.h>
+#include <R_ext/Rdynload.h>
+#else
+#include "qa_r_api.h"
+#endif
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/quilt_amd.h"
+
+/* ---- small helpers ---------------------------------------------------------------------------------------------- */
+
+static SEXP list_get(SEXP list, const char *name) {
+    SEXP names = Rf_getAttrib(list, R_NamesSymbol);
+    for (R_xlen_t i = 0; i < Rf_xlength(list); i++)
+        if (names != R_NilValue && strcmp(CHAR(STRING_ELT(names, i)), name) == 0) return VECTOR_ELT(list, i);
+    return R_NilValue;
+}
+static int flag(SEXP param_list, const char *name, int dflt) {
+    SEXP v = list_get(param_list, name);
+    return v == R_NilValue ? dflt : Rf_asLogical(v);
+}
+static void check_status(int st, const char *what) {
+    if (st < 0) Rf_error("%s: libquilt_amd status %d: %s", what, st, qa_last_error());
+}
+static SEXP named_list(int n, const char **names) {
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, n));
+    SEXP nm = PROTECT(Rf_allocVector(STRSXP, n));
+    for (int i = 0; i < n; i++) SET_STRING_ELT(nm, i, Rf_mkChar(names[i]));
+    Rf_setAttrib(out, R_NamesSymbol, nm);
+    UNPROTECT(2);
+    return out;
+}
+
+/* ---- the prepared panel, uploaded once per process ---------------------------------------------------------------- */
+
+static struct {
+    qa_panel_t *panel;
+    qa_rare_common_t *rc;
+    const void *key_B, *key_hm, *key_rare;
+    int K, G, T, nMaxDH;
+} g_cache;
+
+static void cache_drop(void) {
+    if (g_cache.rc) qa_rare_common_destroy(g_cache.rc);
+    if (g_cache.panel) qa_panel_destroy(g_cache.panel);
+    memset(&g_cache, 0, sizeof g_cache);
+}
+
+/* transMatRate: 2 x (G - 1) doubles (column-major), the first slice of transMatRate_tc_H or transMatRate_t itself */
+static qa_panel_t *panel_for(SEXP hapMatcher, SEXP hapMatcherR, int use_hapMatcherR, SEXP distinctHapsB, SEXP distinctHapsIE,
+                             SEXP special_helper, SEXP special_matrix, SEXP special_grid_which, SEXP rhb_t, double ref_error,
+                             int use_eMatDH_special_symbols, const double *transMatRate) {
+    const int nMaxDH = Rf_nrows(distinctHapsB), G = Rf_ncols(distinctHapsB), T = Rf_ncols(distinctHapsIE);
+    SEXP hm = use_hapMatcherR ? hapMatcherR : hapMatcher;
+    const int K = Rf_nrows(hm);
+    const void *kB = INTEGER(distinctHapsB), *kh = use_hapMatcherR ? (const void *)RAW(hapMatcherR) : (const void *)INTEGER(hapMatcher);
+    if (g_cache.panel && g_cache.key_B == kB && g_cache.key_hm == kh && g_cache.K == K && g_cache.G == G && g_cache.T == T &&
+        g_cache.nMaxDH == nMaxDH)
+        return g_cache.panel;
+    cache_drop();
+    qa_panel_desc_t d;
+    memset(&d, 0, sizeof d);
+    d.K = K; d.nGrids = G; d.nSNPs = T; d.nMaxDH = nMaxDH;
+    d.hapMatcherR = use_hapMatcherR ? RAW(hapMatcherR) : NULL;
+    d.hapMatcher = use_hapMatcherR ? NULL : INTEGER(hapMatcher);
+    const int have_rhb = Rf_nrows(rhb_t) == K && Rf_ncols(rhb_t) == G;   /* 1 x 1 in msPBWT mode (quilt.R:551-563) */
+    d.rhb_t = have_rhb ? INTEGER(rhb_t) : NULL;
+    d.distinctHapsB = INTEGER(distinctHapsB);
+    d.distinctHapsIE = REAL(distinctHapsIE);
+    int *which = NULL;
+    if (special_grid_which != R_NilValue) {
+        d.eMatDH_special_grid_which = INTEGER(special_grid_which);
+    } else {   /* the Gibbs entry does not receive it: a grid holds specials iff its helper row is set (first row > 0) */
+        which = (int *)calloc((size_t)G, sizeof(int));
+        int n = 0;
+        for (int g = 0; g < G; g++)
+            if (Rf_nrows(special_helper) == G && INTEGER(special_helper)[g] > 0) which[g] = ++n;
+        d.eMatDH_special_grid_which = which;
+    }
+    d.eMatDH_special_matrix_helper = Rf_nrows(special_helper) == G ? INTEGER(special_helper) : NULL;
+    d.eMatDH_special_matrix = INTEGER(special_matrix);
+    d.eMatDH_special_matrix_nrow = Rf_nrows(special_matrix);
+    d.use_eMatDH_special_symbols = use_eMatDH_special_symbols || !have_rhb;
+    d.transMatRate_t = transMatRate;
+    d.ref_error = ref_error;
+    qa_panel_t *p = NULL;
+    const int st = qa_panel_create(&d, &p);
+    free(which);
+    check_status(st, "qa_panel_create");
+    g_cache.panel = p; g_cache.key_B = kB; g_cache.key_hm = kh;
+    g_cache.K = K; g_cache.G = G; g_cache.T = T; g_cache.nMaxDH = nMaxDH;
+    return p;
+}
+
+SEXP qa_shim_release(void) {
+    cache_drop();
+    return R_NilValue;
+}
+
+/* ---- _QUILT_Rcpp_make_gl_bound(gl, minGLValue, to_fix)  (reference-single.cpp:68-94; to_fix 0-based) --------------- */
+
+SEXP _QUILT_Rcpp_make_gl_bound(SEXP glSEXP, SEXP minGLValueSEXP, SEXP to_fixSEXP) {
+    check_status(qa_Rcpp_make_gl_bound(REAL(glSEXP), Rf_asReal(minGLValueSEXP), INTEGER(to_fixSEXP), Rf_length(to_fixSEXP)),
+                 "qa_Rcpp_make_gl_bound");
+    return R_NilValue;
+}
+
+/* ---- _QUILT_Rcpp_haploid_dosage_versus_refs: the 38 arguments of RcppExports.cpp:1582, in order ------------------------- */
+
+SEXP _QUILT_Rcpp_haploid_dosage_versus_refs(
+    SEXP glSEXP, SEXP arma_alphaHat_tSEXP, SEXP eigen_alphaHat_tSEXP, SEXP betaHat_tSEXP, SEXP cSEXP, SEXP gamma_tSEXP,
+    SEXP gammaSmall_tSEXP, SEXP best_haps_stuff_listSEXP, SEXP dosageSEXP, SEXP transMatRate_tSEXP, SEXP rhb_tSEXP,
+    SEXP ref_errorSEXP, SEXP use_eMatDHSEXP, SEXP distinctHapsBSEXP, SEXP distinctHapsIESEXP,
+    SEXP eMatDH_special_matrix_helperSEXP, SEXP eMatDH_special_matrixSEXP, SEXP use_eMatDH_special_symbolsSEXP,
+    SEXP hapMatcherSEXP, SEXP hapMatcherRSEXP, SEXP use_hapMatcherRSEXP, SEXP gammaSmall_cols_to_getSEXP,
+    SEXP eMatDH_special_grid_whichSEXP, SEXP eMatDH_special_values_listSEXP, SEXP K_top_matchesSEXP, SEXP suppressOutputSEXP,
+    SEXP min_emission_prob_normalization_thresholdSEXP, SEXP return_betaHat_tSEXP, SEXP return_dosageSEXP,
+    SEXP return_gamma_tSEXP, SEXP return_gammaSmall_tSEXP, SEXP get_best_haps_from_thinned_sitesSEXP, SEXP is_version_2SEXP,
+    SEXP is_version_3SEXP, SEXP return_extraSEXP, SEXP always_normalizeSEXP, SEXP use_eigenSEXP, SEXP normalize_emissionsSEXP) {
+    (void)eMatDH_special_values_listSEXP; (void)is_version_2SEXP; (void)return_extraSEXP; (void)use_eigenSEXP;
+    if (!Rf_asLogical(use_eMatDHSEXP)) Rf_error("quilt_amd: use_eMatDH = FALSE is not supported (the production path uses TRUE)");
+    qa_panel_t *panel = panel_for(hapMatcherSEXP, hapMatcherRSEXP, Rf_asLogical(use_hapMatcherRSEXP), distinctHapsBSEXP,
+                                  distinctHapsIESEXP, eMatDH_special_matrix_helperSEXP, eMatDH_special_matrixSEXP,
+                                  eMatDH_special_grid_whichSEXP, rhb_tSEXP, Rf_asReal(ref_errorSEXP),
+                                  Rf_asLogical(use_eMatDH_special_symbolsSEXP), REAL(transMatRate_tSEXP));
+    qa_fullpass_opts_t o;
+    memset(&o, 0, sizeof o);
+    o.K_top_matches = Rf_asInteger(K_top_matchesSEXP);
+    o.return_betaHat_t = Rf_asLogical(return_betaHat_tSEXP);
+    o.return_dosage = Rf_asLogical(return_dosageSEXP);
+    o.return_gamma_t = Rf_asLogical(return_gamma_tSEXP);
+    o.return_gammaSmall_t = Rf_asLogical(return_gammaSmall_tSEXP);
+    o.get_best_haps_from_thinned_sites = Rf_asLogical(get_best_haps_from_thinned_sitesSEXP);
+    o.always_normalize = Rf_asLogical(always_normalizeSEXP);
+    o.normalize_emissions = Rf_asLogical(normalize_emissionsSEXP);
+    o.min_emission_prob_normalization_threshold = Rf_asReal(min_emission_prob_normalization_thresholdSEXP);
+    o.suppressOutput = Rf_asInteger(suppressOutputSEXP);
+    /* version 3 writes alpha through the Eigen map, versions 1 / 2 through the arma matrix: both alias R's matrix */
+    SEXP alphaSEXP = Rf_asLogical(is_version_3SEXP) ? eigen_alphaHat_tSEXP : arma_alphaHat_tSEXP;
+    const int G = g_cache.G, K = g_cache.K;
+    double *alpha = (Rf_nrows(alphaSEXP) == K && Rf_ncols(alphaSEXP) == G) ? REAL(alphaSEXP) : NULL;
+    const int *cols = INTEGER(gammaSmall_cols_to_getSEXP);
+    int n_thin = 0;
+    for (int g = 0; g < G; g++) if (cols[g] + 1 > n_thin) n_thin = cols[g] + 1;
+    int32_t *bptr = (int32_t *)calloc((size_t)n_thin + 1, sizeof(int32_t));
+    int64_t cap = 64 * (int64_t)(n_thin > 0 ? n_thin : 1);
+    int32_t *bidx = NULL;
+    double *bval = NULL;
+    int st = QA_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        bidx = (int32_t *)realloc(bidx, sizeof(int32_t) * (size_t)cap);
+        bval = (double *)realloc(bval, sizeof(double) * (size_t)cap);
+        st = qa_Rcpp_haploid_dosage_versus_refs(panel, REAL(glSEXP), cols, &o, alpha,
+                                                o.return_betaHat_t ? REAL(betaHat_tSEXP) : NULL, REAL(cSEXP),
+                                                o.return_gamma_t ? REAL(gamma_tSEXP) : NULL,
+                                                o.return_gammaSmall_t ? REAL(gammaSmall_tSEXP) : NULL,
+                                                o.return_dosage ? REAL(dosageSEXP) : NULL, bptr, bidx, bval, cap);
+        if (st != QA_ERR_CAPACITY) break;
+        cap = bptr[n_thin];   /* needed sizes are in bptr */
+    }
+    if (st >= 0 && o.get_best_haps_from_thinned_sites) {
+        /* best_haps_stuff_list[[i]] <- list(top_matches = <0-based k>, top_matches_values = <gamma>) (reference-single.cpp:2024-2030) */
+        static const char *nm[2] = {"top_matches", "top_matches_values"};
+        for (int i = 0; i < n_thin && i < Rf_length(best_haps_stuff_listSEXP); i++) {
+            const int n = bptr[i + 1] - bptr[i];
+            SEXP e = PROTECT(named_list(2, nm));
+            SEXP tm = PROTECT(Rf_allocVector(INTSXP, n)), tv = PROTECT(Rf_allocVector(REALSXP, n));
+            memcpy(INTEGER(tm), bidx + bptr[i], sizeof(int) * (size_t)n);
+            memcpy(REAL(tv), bval + bptr[i], sizeof(double) * (size_t)n);
+            SET_VECTOR_ELT(e, 0, tm);
+            SET_VECTOR_ELT(e, 1, tv);
+            SET_VECTOR_ELT(best_haps_stuff_listSEXP, i, e);
+            UNPROTECT(3);
+        }
+    }
+    free(bptr); free(bidx); free(bval);
+    check_status(st, "qa_Rcpp_haploid_dosage_versus_refs");
+    return R_NilValue;
+}
+
+/* ---- _QUILT_rcpp_forwardBackwardGibbsNIPT: the 63 arguments of RcppExports.cpp:968, in order -------------------------- */
+
+/* calculate_likelihoods_values + add_to_per_it_likelihoods (gibbs-nipt.cpp:1463-1621) from the per-sweep record */
+static double lgamma1(double x) { return lgamma(x + 1.0); }
+static void fill_per_it_row(double *m, int nrow, int row, const double *rec, double ff, int it, double p_H_class) {
+    const double prior[3] = {0.5, (1 - ff) / 2, ff / 2};
+    const double d1 = rec[0], d2 = rec[1], d3 = rec[2], rc[3] = {rec[3], rec[4], rec[5]};
+    double dH = 0, set = lgamma1(rc[0] + rc[1] + rc[2]);
+    for (int h = 0; h < 3; h++) {
+        if (rc[h] > 0) dH += rc[h] * log(prior[h]);
+        if (prior[h] > 0) set += rc[h] * log(prior[h]) - lgamma1(rc[h]);
+    }
+    const double v[13] = {1, 1, it + 1, 1, d1, d2, d3, d1 + d2 + d3, dH, d1 + d2 + d3 + dH, set, 0, p_H_class};
+    for (int j = 0; j < 13; j++) m[(size_t)j * nrow + row] = v[j];
+}
+static double log_p_H_class(const int *H_class, int n, double ff) {   /* rcpp_get_log_p_H_class, gibbs-nipt-block.cpp:146-164 */
+    const double vals[8] = {0, log(0.5), log(0.5 - ff * 0.5), log(ff * 0.5), log(1.0 - ff * 0.5), log(0.5 + ff * 0.5), log(0.5), 0};
+    double out = 0;
+    for (int i = 0; i < n; i++) out += vals[H_class[i] & 7];
+    return out;
+}
+
+SEXP _QUILT_rcpp_forwardBackwardGibbsNIPT(
+    SEXP sampleReadsSEXP, SEXP eMatRead_tSEXP, SEXP priorCurrent_mSEXP, SEXP alphaMatCurrent_tcSEXP, SEXP eHapsCurrent_tcSEXP,
+    SEXP transMatRate_tc_HSEXP, SEXP ffSEXP, SEXP blocks_for_outputSEXP, SEXP alphaHat_t1SEXP, SEXP betaHat_t1SEXP,
+    SEXP alphaHat_t2SEXP, SEXP betaHat_t2SEXP, SEXP alphaHat_t3SEXP, SEXP betaHat_t3SEXP, SEXP eMatGrid_t1SEXP,
+    SEXP eMatGrid_t2SEXP, SEXP eMatGrid_t3SEXP, SEXP gammaMT_t_localSEXP, SEXP gammaMU_t_localSEXP, SEXP gammaP_t_localSEXP,
+    SEXP hapSum_tcSEXP, SEXP hapMatcherSEXP, SEXP hapMatcherRSEXP, SEXP use_hapMatcherRSEXP, SEXP distinctHapsBSEXP,
+    SEXP distinctHapsIESEXP, SEXP eMatDH_special_matrix_helperSEXP, SEXP eMatDH_special_matrixSEXP, SEXP rhb_tSEXP,
+    SEXP ref_errorSEXP, SEXP which_haps_to_useSEXP, SEXP wif0SEXP, SEXP grid_has_readSEXP, SEXP L_gridSEXP, SEXP smooth_cmSEXP,
+    SEXP param_listSEXP, SEXP skip_read_iterationSEXP, SEXP Jmax_localSEXP, SEXP maxDifferenceBetweenReadsSEXP,
+    SEXP maxEmissionMatrixDifferenceSEXP, SEXP run_fb_grid_offsetSEXP, SEXP gridSEXP, SEXP snp_start_1_basedSEXP,
+    SEXP snp_end_1_basedSEXP, SEXP generate_fb_snp_offsetsSEXP, SEXP suppressOutputSEXP, SEXP n_gibbs_startsSEXP,
+    SEXP n_gibbs_sample_itsSEXP, SEXP n_gibbs_burn_in_itsSEXP, SEXP double_list_of_starting_read_labelsSEXP,
+    SEXP seed_vectorSEXP, SEXP prev_list_of_alphaBetaBlocksSEXP, SEXP i_snp_block_for_alpha_betaSEXP,
+    SEXP do_block_resamplingSEXP, SEXP artificial_relabelSEXP, SEXP class_sum_cutoffSEXP, SEXP shuffle_bin_radiusSEXP,
+    SEXP block_gibbs_iterationsSEXP, SEXP block_gibbs_quantile_probSEXP, SEXP rare_per_hap_infoSEXP,
+    SEXP common_snp_indexSEXP, SEXP snp_is_commonSEXP, SEXP rare_per_snp_infoSEXP) {
+    /* arguments the production caller holds constant or that only the unused code paths read */
+    (void)eMatRead_tSEXP; (void)priorCurrent_mSEXP; (void)alphaMatCurrent_tcSEXP; (void)eHapsCurrent_tcSEXP;
+    (void)blocks_for_outputSEXP; (void)alphaHat_t3SEXP; (void)betaHat_t3SEXP; (void)eMatGrid_t3SEXP; (void)gammaMT_t_localSEXP;
+    (void)gammaMU_t_localSEXP; (void)gammaP_t_localSEXP; (void)hapSum_tcSEXP; (void)grid_has_readSEXP; (void)smooth_cmSEXP;
+    (void)skip_read_iterationSEXP; (void)maxEmissionMatrixDifferenceSEXP; (void)run_fb_grid_offsetSEXP; (void)gridSEXP;
+    (void)snp_start_1_basedSEXP; (void)snp_end_1_basedSEXP; (void)suppressOutputSEXP; (void)seed_vectorSEXP;
+    (void)prev_list_of_alphaBetaBlocksSEXP; (void)i_snp_block_for_alpha_betaSEXP; (void)do_block_resamplingSEXP;
+    (void)artificial_relabelSEXP; (void)common_snp_indexSEXP; (void)rare_per_snp_infoSEXP;
+    SEXP pl = param_listSEXP;
+    if (Rf_asInteger(n_gibbs_startsSEXP) != 1 || flag(pl, "run_fb_subset", 0) || Rf_asLogical(generate_fb_snp_offsetsSEXP) ||
+        !flag(pl, "use_starting_read_labels", 1) || flag(pl, "pass_in_eMatRead_t", 0) || flag(pl, "use_small_eHapsCurrent_tc", 0))
+        Rf_error("quilt_amd: only the production form of rcpp_forwardBackwardGibbsNIPT is supported (n_gibbs_starts = 1, "
+                 "run_fb_subset = FALSE, use_starting_read_labels = TRUE, pass_in_eMatRead_t = FALSE, packed panel)");
+    const double ff = Rf_asReal(ffSEXP);
+    const int rare_common = flag(pl, "make_eMatRead_t_rare_common", 0);
+    const int G_panel = Rf_ncols(distinctHapsBSEXP);
+    /* transMatRate_tc_H: 2 x (G - 1) x S; with rare + common it is the all-SNP grid's and the panel's own is not passed:
+     * the panel handle must then exist already (created by a full-panel call or an earlier common-SNP Gibbs call) */
+    const int G = Rf_nrows(transMatRate_tc_HSEXP) == 2 ? (int)(Rf_xlength(transMatRate_tc_HSEXP) / 2) + 1 : G_panel;
+    if (rare_common && !g_cache.panel) Rf_error("quilt_amd: the rare + common call needs the panel of an earlier common-SNP call");
+    qa_panel_t *panel = rare_common ? g_cache.panel :
+        panel_for(hapMatcherSEXP, hapMatcherRSEXP, Rf_asLogical(use_hapMatcherRSEXP), distinctHapsBSEXP, distinctHapsIESEXP,
+                  eMatDH_special_matrix_helperSEXP, eMatDH_special_matrixSEXP, R_NilValue, rhb_tSEXP, Rf_asReal(ref_errorSEXP),
+                  flag(pl, "use_eMatDH_special_symbols", 0), REAL(transMatRate_tc_HSEXP));
+    const int T = rare_common ? Rf_length(snp_is_commonSEXP) : g_cache.T;
+    if (rare_common && (!g_cache.rc || g_cache.key_rare != (const void *)LOGICAL(snp_is_commonSEXP))) {
+        /* rare_per_hap_info: list over the K haplotypes of 1-based all-SNP indices (rare_common.R:222-247) */
+        if (g_cache.rc) { qa_rare_common_destroy(g_cache.rc); g_cache.rc = NULL; }
+        const int K = g_cache.K;
+        int64_t *rptr = (int64_t *)calloc((size_t)K + 1, sizeof(int64_t));
+        for (int k = 0; k < K; k++) rptr[k + 1] = rptr[k] + Rf_length(VECTOR_ELT(rare_per_hap_infoSEXP, k));
+        int32_t *rsnp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rptr[K] > 0 ? rptr[K] : 1));
+        for (int k = 0; k < K; k++)
+            memcpy(rsnp + rptr[k], INTEGER(VECTOR_ELT(rare_per_hap_infoSEXP, k)), sizeof(int) * (size_t)(rptr[k + 1] - rptr[k]));
+        uint8_t *isc = (uint8_t *)malloc((size_t)T);
+        for (int t = 0; t < T; t++) isc[t] = LOGICAL(snp_is_commonSEXP)[t] != 0;
+        const int st = qa_rare_common_create(panel, T, isc, rptr, rsnp, REAL(transMatRate_tc_HSEXP), &g_cache.rc);
+        free(rptr); free(rsnp); free(isc);
+        check_status(st, "qa_rare_common_create");
+        g_cache.key_rare = LOGICAL(snp_is_commonSEXP);
+    }
+
+    /* ---- sampleReads -> CSR (sampleReads[[r]] = list(J, wif, bq matrix, u matrix): copied-from-stitch.cpp:153-160) */
+    const int R = Rf_length(sampleReadsSEXP), Ks = Rf_length(which_haps_to_useSEXP);
+    int32_t *read_ptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)R + 1));
+    read_ptr[0] = 0;
+    for (int r = 0; r < R; r++) read_ptr[r + 1] = read_ptr[r] + Rf_length(VECTOR_ELT(VECTOR_ELT(sampleReadsSEXP, r), 3));
+    const int nB = read_ptr[R];
+    int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nB > 0 ? nB : 1)), *bq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nB > 0 ? nB : 1));
+    for (int r = 0; r < R; r++) {
+        SEXP rd = VECTOR_ELT(sampleReadsSEXP, r);
+        const int n = read_ptr[r + 1] - read_ptr[r];
+        memcpy(bq + read_ptr[r], INTEGER(VECTOR_ELT(rd, 2)), sizeof(int) * (size_t)n);
+        memcpy(u + read_ptr[r], INTEGER(VECTOR_ELT(rd, 3)), sizeof(int) * (size_t)n);
+    }
+    int32_t read_off[2] = {0, R};
+
+    /* ---- options */
+    const int n_burn = Rf_asInteger(n_gibbs_burn_in_itsSEXP), n_samp = Rf_asInteger(n_gibbs_sample_itsSEXP), n_its = n_burn + n_samp;
+    const int nb = Rf_length(block_gibbs_iterationsSEXP);
+    qa_gibbs_opts_t o;
+    memset(&o, 0, sizeof o);
+    o.Ks = Ks; o.ff = ff; o.sample_is_diploid = flag(pl, "sample_is_diploid", ff == 0);
+    o.Jmax = Rf_asInteger(Jmax_localSEXP);
+    o.maxDifferenceBetweenReads = Rf_asReal(maxDifferenceBetweenReadsSEXP);
+    o.rescale_eMatRead_t = flag(pl, "rescale_eMatRead_t", 1);
+    o.n_gibbs_burn_in_its = n_burn; o.n_gibbs_sample_its = n_samp;
+    o.block_gibbs_iterations = INTEGER(block_gibbs_iterationsSEXP); o.n_block_gibbs_iterations = nb;
+    o.perform_block_gibbs = flag(pl, "perform_block_gibbs", 0);
+    o.do_shard_block_gibbs = flag(pl, "do_shard_block_gibbs", 1);
+    o.gibbs_initialize_iteratively = flag(pl, "gibbs_initialize_iteratively", 0);
+    o.disable_read_category_usage = flag(pl, "disable_read_category_usage", 0);
+    o.class_sum_cutoff = Rf_asReal(class_sum_cutoffSEXP);
+    o.L_grid = INTEGER(L_gridSEXP); o.shuffle_bin_radius = Rf_asInteger(shuffle_bin_radiusSEXP);
+    o.block_gibbs_quantile_prob = Rf_asReal(block_gibbs_quantile_probSEXP);
+    double *per_it = (double *)calloc((size_t)(n_its > 0 ? n_its : 1) * 8, sizeof(double));
+    o.per_it_out = per_it;
+
+    /* ---- the reference's draws, in its order (RcppExports.cpp:971 RNGScope) */
+    const size_t n_pass_unif = ff != 0 ? (size_t)nb * 2 * (size_t)R : (size_t)nb * (size_t)(G - 1);
+    double *runif_reads = (double *)malloc(sizeof(double) * ((size_t)R * (size_t)n_its + 1));
+    double *runif_pass = (double *)malloc(sizeof(double) * (n_pass_unif + 1));
+    int32_t first_read = 0;
+    GetRNGstate();
+    for (size_t i = 0; i < (size_t)R * (size_t)n_its; i++) runif_reads[i] = unif_rand();         /* gibbs-nipt.cpp:2845 */
+    if (!flag(pl, "gibbs_initialize_at_first_read", 0) && R > 0) {
+        first_read = (int32_t)(unif_rand() * R);                                                 /* :2846-2848 sample(nReads, 1) - 1 */
+        if (first_read >= R) first_read = R - 1;
+    }
+    if (o.perform_block_gibbs) {
+        for (int ib = 0; ib < nb; ib++) {
+            for (size_t i = 0; i < 6 * (size_t)R; i++) (void)unif_rand();                        /* :3013-3015 runif_proposed (unused by approach 6) */
+            if (ff != 0) {
+                for (int r = 0; r < R; r++) runif_pass[((size_t)ib * 2 + 0) * R + r] = unif_rand();   /* :3016 runif_block */
+                for (int r = 0; r < R; r++) runif_pass[((size_t)ib * 2 + 1) * R + r] = unif_rand();   /* :3017 runif_total: here the per-read re-draws */
+            } else {
+                for (size_t i = 0; i < 2 * (size_t)R; i++) (void)unif_rand();                    /* :3016-3017, no effect for diploid samples */
+                if (o.do_shard_block_gibbs)
+                    for (int g = 0; g < G - 1; g++) runif_pass[(size_t)ib * (G - 1) + g] = unif_rand();   /* gibbs-nipt-block.cpp:2054 */
+            }
+        }
+    }
+    PutRNGstate();
+
+    /* ---- starting labels in, ending labels out */
+    SEXP start = VECTOR_ELT(VECTOR_ELT(double_list_of_starting_read_labelsSEXP, 0), 0);
+    int32_t *H = (int32_t *)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1)), *H_class = (int32_t *)calloc((size_t)(R > 0 ? R : 1), sizeof(int32_t));
+    memcpy(H, INTEGER(start), sizeof(int) * (size_t)R);
+    const int want_hap = flag(pl, "return_hapProbs", 0), want_gen = flag(pl, "return_genProbs", 0);
+    SEXP hap = PROTECT(Rf_allocMatrix(REALSXP, 3, T)), gm = PROTECT(Rf_allocMatrix(REALSXP, 3, T)), gf = PROTECT(Rf_allocMatrix(REALSXP, 3, T));
+    double *state = (double *)malloc(sizeof(double) * ((size_t)6 * Ks * G + (size_t)3 * G));
+    int32_t underflow = 0;
+    const int st = rare_common
+        ? qa_gibbs_batch_rare_common(panel, g_cache.rc, &o, 1, INTEGER(which_haps_to_useSEXP), read_off, read_ptr, u, bq,
+                                     INTEGER(wif0SEXP), runif_reads, &first_read, runif_pass, H, H_class,
+                                     (want_hap || want_gen) ? REAL(hap) : NULL, want_gen ? REAL(gm) : NULL,
+                                     want_gen ? REAL(gf) : NULL, &underflow, state, NULL, NULL)
+        : qa_gibbs_batch(panel, &o, 1, INTEGER(which_haps_to_useSEXP), read_off, read_ptr, u, bq, INTEGER(wif0SEXP), runif_reads,
+                         &first_read, runif_pass, H, H_class, (want_hap || want_gen) ? REAL(hap) : NULL,
+                         want_gen ? REAL(gm) : NULL, want_gen ? REAL(gf) : NULL, &underflow, state, NULL, NULL);
+    SEXP out = R_NilValue;
+    if (st >= 0 && !underflow) {
+        /* the matrices the reference mutates in place (pass_in_alphaBeta = TRUE: R's buffers, quilt.R:731-745) */
+        const size_t m = (size_t)Ks * G;
+        SEXP dst[6] = {alphaHat_t1SEXP, alphaHat_t2SEXP, betaHat_t1SEXP, betaHat_t2SEXP, eMatGrid_t1SEXP, eMatGrid_t2SEXP};
+        for (int i = 0; i < 6; i++)
+            if (Rf_nrows(dst[i]) == Ks && Rf_ncols(dst[i]) == G) memcpy(REAL(dst[i]), state + (size_t)i * m, sizeof(double) * m);
+        /* the result list, names as gibbs-nipt.cpp:3217-3306 */
+        const char *nm[8];
+        int n = 0;
+        nm[n++] = "underflow_problem";
+        if (want_gen) { nm[n++] = "genProbsM_t"; nm[n++] = "genProbsF_t"; }
+        if (want_hap) nm[n++] = "hapProbs_t";
+        nm[n++] = "H"; nm[n++] = "double_list_of_ending_read_labels"; nm[n++] = "per_it_likelihoods"; nm[n++] = "H_class";
+        out = PROTECT(named_list(n, nm));
+        int at = 0;
+        SET_VECTOR_ELT(out, at++, Rf_ScalarLogical(0));
+        if (want_gen) { SET_VECTOR_ELT(out, at++, gm); SET_VECTOR_ELT(out, at++, gf); }
+        if (want_hap) SET_VECTOR_ELT(out, at++, hap);
+        SEXP Hs = PROTECT(Rf_allocVector(INTSXP, R)), Hc = PROTECT(Rf_allocVector(INTSXP, R));
+        memcpy(INTEGER(Hs), H, sizeof(int) * (size_t)R);
+        memcpy(INTEGER(Hc), H_class, sizeof(int) * (size_t)R);
+        SET_VECTOR_ELT(out, at++, Hs);
+        SEXP l1 = PROTECT(Rf_allocVector(VECSXP, 1)), l2 = PROTECT(Rf_allocVector(VECSXP, 1));   /* [[s]][[i_gibbs_sampling]] */
+        SET_VECTOR_ELT(l2, 0, Hs);
+        SET_VECTOR_ELT(l1, 0, l2);
+        SET_VECTOR_ELT(out, at++, l1);
+        /* per_it_likelihoods: one row per sweep, the 13 columns of gibbs-nipt.cpp:2767-2768 */
+        static const char *cn[13] = {"s", "i_samp", "i_it", "i_result_it", "p_O1_given_H1_L", "p_O2_given_H2_L", "p_O3_given_H3_L",
+                                     "p_O_given_H_L", "p_H_given_L", "p_O_H_given_L_up_to_C", "p_set_H_given_L", "relabel",
+                                     "p_H_class_given_L"};
+        SEXP pit = PROTECT(Rf_allocMatrix(REALSXP, n_its, 13));
+        for (int it = 0; it < n_its; it++)   /* H_class is recorded by the last sweep only: NA before */
+            fill_per_it_row(REAL(pit), n_its, it, per_it + (size_t)it * 8, ff, it,
+                            it == n_its - 1 ? log_p_H_class(H_class, R, ff) : NA_REAL);
+        SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2)), cns = PROTECT(Rf_allocVector(STRSXP, 13));
+        for (int j = 0; j < 13; j++) SET_STRING_ELT(cns, j, Rf_mkChar(cn[j]));
+        SET_VECTOR_ELT(dn, 0, R_NilValue);
+        SET_VECTOR_ELT(dn, 1, cns);
+        Rf_setAttrib(pit, R_DimNamesSymbol, dn);
+        SET_VECTOR_ELT(out, at++, pit);
+        SET_VECTOR_ELT(out, at++, Hc);
+        UNPROTECT(8);
+    } else if (st >= 0) {
+        /* gibbs-nipt.cpp:2959-2969: only `underflow_problem = TRUE`; impute_one_sample retries (functions.R:2704-2715) */
+        static const char *nm[1] = {"underflow_problem"};
+        out = PROTECT(named_list(1, nm));
+        SET_VECTOR_ELT(out, 0, Rf_ScalarLogical(1));
+        UNPROTECT(1);
+    }
+    free(read_ptr); free(u); free(bq); free(per_it); free(runif_reads); free(runif_pass); free(H); free(H_class); free(state);
+    UNPROTECT(3);
+    check_status(st, "qa_gibbs_batch");
+    return out;
+}
+
+/* ---- registration (RcppExports.cpp:1703-1782) ---------------------------------------------------------------------- */
+
+static const R_CallMethodDef CallEntries[] = {
+    {"_QUILT_rcpp_forwardBackwardGibbsNIPT", (DL_FUNC)&_QUILT_rcpp_forwardBackwardGibbsNIPT, 63},
+    {"_QUILT_Rcpp_haploid_dosage_versus_refs", (DL_FUNC)&_QUILT_Rcpp_haploid_dosage_versus_refs, 38},
+    {"_QUILT_Rcpp_make_gl_bound", (DL_FUNC)&_QUILT_Rcpp_make_gl_bound, 3},
+    {"qa_shim_release", (DL_FUNC)&qa_shim_release, 0},
+    {NULL, NULL, 0}};
+
+void R_init_quilt_amd_shim(DllInfo *dll) {
+    R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}

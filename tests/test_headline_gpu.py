@@ -1,0 +1,173 @@
+"""GPU parity at the HEADLINE dimensions (BASELINE.json configs[2..4]): single native calls against the fp64 CPU oracle.
+
+The pipeline at K = 50 000 costs the oracle ~20 core-minutes per sample, so whole-pipeline parity at full size is checked by
+properties only (tests/test_pipeline_gpu.py); but ONE call is seconds to a minute of CPU, and effects that only show over
+2 000 grids / 20 000 reads (renormalisations, read streams crossing hundreds of 64-entry reloads, reciprocal refinement)
+cannot be seen in small tests.  Each test here is one call of the production geometry:
+
+  * one small-panel Gibbs call, Ks = 600, 2 000 grids, 20 000 short reads, shard passes: labels and H_class bit-identical,
+    alpha / beta / eMatGrid / c to 1e-9 relative                               (gibbs-nipt.cpp:2395-3307)
+  * one ONT-length read set (300 reads x 200-800 SNPs, every emission a dense column), Ks = 600: the same bar
+  * one NIPT call (three labels, block Gibbs, ff = 0.2), Ks = 600, 20 000 reads: labels / classes identical, hapProbs 1e-9
+  * one thin pass and one dosage pass at K = 50 000 x 2 000 grids: best-haplotype lists identical (values 1e-9), alpha at the
+    thinned grids and c to 1e-9 (the fp64 ranking kernels follow the reference's lazy normalisation operation by operation),
+    |dosage diff| <= 2e-6 (fp32 state) resp. <= 1e-9 (qa_panel_set_dosage_precision(64)), sum(log c) to 1e-7
+                                                                                (reference-single.cpp:2189-2413)
+"""
+import numpy as np
+import pytest
+
+from tests.util import check_best_haps, r2
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+K_HEAD, T_HEAD, KS, R_HEAD = 50000, 64000, 600, 20000
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+@pytest.fixture(scope="module")
+def head_panel():
+    from quilt_amd.synth import make_synthetic_panel
+    return make_synthetic_panel(K=K_HEAD, nSNPs=T_HEAD, seed=4916)
+
+
+@pytest.fixture(scope="module")
+def head_dev(head_panel):
+    from quilt_amd.native import DevicePanel
+    dev = DevicePanel(head_panel)
+    yield dev
+    dev.close()
+
+
+def _gibbs_inputs(panel, seed, n_reads, mode="short", ff=0.0):
+    from quilt_amd.synth import make_synthetic_sample
+    s = make_synthetic_sample(panel, seed=seed, n_reads=n_reads, mode=mode, ff=ff)
+    rng = np.random.default_rng(seed + 17)
+    which = np.sort(rng.choice(panel.K, KS, replace=False)).astype(np.int32) + 1
+    R = s.nReads
+    if ff > 0:
+        H0 = (rng.choice(3, size=R, p=[0.5, 0.5 - ff / 2, ff / 2]) + 1).astype(np.int32)
+    else:
+        H0 = rng.integers(1, 3, size=R).astype(np.int32)
+    return s, which, H0, rng.random(R * 21), rng.random(3 * (panel.nGrids - 1)), int(rng.integers(0, R)), rng
+
+
+def _compare_state(got, ref):
+    assert not got["underflow_problem"] and ref["status"] == 0
+    assert np.array_equal(got["H"], ref["H"]), f"{(got['H'] != ref['H']).sum()} labels differ"
+    assert np.array_equal(got["H_class"], ref["H_class"])
+    for h in range(2):
+        np.testing.assert_allclose(got[f"eMatGrid_t{h + 1}"], ref["eMatGrid_t"][h], rtol=RTOL)
+        np.testing.assert_allclose(got[f"alphaHat_t{h + 1}"], ref["alphaHat_t"][h], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(got[f"betaHat_t{h + 1}"], ref["betaHat_t"][h], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(got[f"c{h + 1}"], ref["c"][h], rtol=RTOL)
+    np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+
+
+@pytest.mark.parametrize("init_iter", [True, False])
+def test_gibbs_call_headline_size(head_panel, head_dev, oracle, init_iter):
+    """configs[2]: Ks = 600, G = 2 000, R = 20 000, 21 sweeps, shard passes after sweeps 3, 6, 9; first-round
+    (iterative initialisation) and later-round form."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    s, which, H0, ru, rs, fr, _ = _gibbs_inputs(head_panel, 1001, R_HEAD)
+    assert s.nReads == R_HEAD and head_panel.nGrids == 2000
+    ref = oracle.forwardBackwardGibbsNIPT(head_panel, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter)
+    got = rcpp_forwardBackwardGibbsNIPT(head_dev, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter,
+                                        return_state=True)
+    _compare_state(got, ref)
+    assert (got["H"] != H0).sum() > 1000   # the sampler did move labels
+
+
+def test_gibbs_call_ont_headline_size(head_panel, head_dev, oracle):
+    """configs[3]: 300 reads of 200-800 SNPs, phred 5-15: every read emission is a dense Ks-column."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    s, which, H0, ru, rs, fr, _ = _gibbs_inputs(head_panel, 1003, 300, mode="ont")
+    n = np.diff(s.read_ptr)
+    assert s.nReads == 300 and n.min() >= 200 and n.max() <= 800
+    ref = oracle.forwardBackwardGibbsNIPT(head_panel, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=True)
+    got = rcpp_forwardBackwardGibbsNIPT(head_dev, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=True,
+                                        return_state=True)
+    _compare_state(got, ref)
+
+
+def test_nipt_call_headline_size(head_panel, head_dev, oracle):
+    """configs[4]: three labels, block Gibbs (blocks from the switch rate over 2 000 grids), ff = 0.2, 20 000 reads."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    ff = 0.2
+    s, which, H0, ru, _, fr, rng = _gibbs_inputs(head_panel, 1005, R_HEAD, ff=ff)
+    R = s.nReads
+    rb, rr = rng.random(3 * R), rng.random(3 * R)
+    ref = oracle.forwardBackwardGibbsNIPT(head_panel, s, which, H0, ru, fr, np.zeros(3 * head_panel.nGrids), ff=ff,
+                                          gibbs_initialize_iteratively=True, runif_block=rb, runif_resample=rr)
+    got = rcpp_forwardBackwardGibbsNIPT(head_dev, s, which, H0, ru, fr, None, ff=ff, gibbs_initialize_iteratively=True,
+                                        runif_block=rb, runif_resample=rr)
+    assert ref["status"] == 0 and not got["underflow_problem"]
+    assert np.array_equal(got["H"], ref["H"]), f"{(got['H'] != ref['H']).sum()} labels differ"
+    assert np.array_equal(got["H_class"], ref["H_class"])
+    np.testing.assert_allclose(got["hapProbs_t"], ref["hapProbs_t"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(got["genProbsM_t"], ref["genProbsM_t"], rtol=RTOL, atol=1e-14)
+    np.testing.assert_allclose(got["genProbsF_t"], ref["genProbsF_t"], rtol=RTOL, atol=1e-14)
+
+
+@pytest.fixture(scope="module")
+def head_gl(head_panel, oracle):
+    """gl of one read label of a 20 000-read sample (the labels a converged Gibbs chain would hold: the truth)."""
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.util import label_gl
+    s = make_synthetic_sample(head_panel, seed=1007, n_reads=R_HEAD)
+    return label_gl(head_panel, s, 1, oracle)
+
+
+def _run_gpu(dev, gl, cols, **kw):
+    from quilt_amd.reference_single import Rcpp_haploid_dosage_versus_refs
+    P = dev.panel
+    n_thin = int((cols >= 0).sum())
+    out = dict(alphaHat_t=np.zeros((P.K, P.nGrids), order="F"), c=np.ones(P.nGrids), dosage=np.zeros(P.nSNPs),
+               best_haps_stuff_list=[None] * n_thin)
+    Rcpp_haploid_dosage_versus_refs(dev, gl, gammaSmall_cols_to_get=cols, return_gamma_t=False, return_betaHat_t=False,
+                                    **out, **kw)
+    return out
+
+
+def test_thin_pass_headline_size(head_panel, head_dev, head_gl, oracle):
+    """One thin pass (return_dosage = FALSE: best-haplotype lists at the 200 thinned grids) at K = 50 000 x 2 000 grids: the
+    fp64 ranking kernels (lazy normalisation over 2 000 grids, fused / separate top-K)."""
+    from quilt_amd.driver import thinned_grid_columns
+    cols = thinned_grid_columns(head_panel.nGrids, 0.1)
+    assert int((cols >= 0).sum()) == 200
+    ref = oracle.haploid_dosage_versus_refs(head_panel, head_gl, cols, return_dosage=False, get_best_haps_from_thinned_sites=True)
+    got = _run_gpu(head_dev, head_gl, cols, return_dosage=False, get_best_haps_from_thinned_sites=True, always_normalize=False)
+    check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
+    # the reference's own (lazily normalised) alpha columns and c: same operations, only the order of the K-wide sums differs
+    np.testing.assert_allclose(got["c"], ref["c"], rtol=RTOL)
+    np.testing.assert_allclose(np.log(got["c"]).sum(), np.log(ref["c"]).sum(), rtol=1e-12)
+    n_renorm = int((np.abs(ref["c"][1:] * head_panel.transMatRate_t[0] - 1) > 1e-9).sum())
+    assert 5 < n_renorm < 1000, "the lazy schedule renormalises now and then, not every grid"
+    for g in np.nonzero(cols >= 0)[0][::20]:
+        np.testing.assert_allclose(got["alphaHat_t"][:, g], ref["alphaHat_t"][:, g], rtol=RTOL, atol=1e-300)
+
+
+def test_dosage_pass_headline_size(head_panel, head_dev, head_gl, oracle):
+    """One dosage pass at K = 50 000 x 2 000 grids: fp32 state (default) and fp64 state (qa_panel_set_dosage_precision)."""
+    from quilt_amd.driver import thinned_grid_columns
+    cols = thinned_grid_columns(head_panel.nGrids, 0.1)
+    ref = oracle.haploid_dosage_versus_refs(head_panel, head_gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True)
+    got = _run_gpu(head_dev, head_gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True)
+    assert np.abs(got["dosage"] - ref["dosage"]).max() <= 2e-6
+    assert r2(got["dosage"], ref["dosage"]) >= 0.999999
+    np.testing.assert_allclose(np.log(got["c"]).sum(), np.log(ref["c"]).sum(), rtol=1e-7)
+    check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
+    head_dev.set_dosage_precision(64)
+    try:
+        got64 = _run_gpu(head_dev, head_gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True)
+    finally:
+        head_dev.set_dosage_precision(32)
+    assert np.abs(got64["dosage"] - ref["dosage"]).max() <= 1e-9
+    np.testing.assert_allclose(np.log(got64["c"]).sum(), np.log(ref["c"]).sum(), rtol=1e-12)
+    check_best_haps(got64["best_haps_stuff_list"], ref["best_haps"])

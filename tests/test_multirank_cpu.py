@@ -61,3 +61,28 @@ def test_two_ranks_equal_one_process():
     assert [i for i, _ in parts] == [0, 1, 2, 3, 4]
     for (i, d), r in zip(parts, ref):
         assert np.array_equal(d, r.dosage)
+
+
+def test_bench_gpus_flag_creates_the_ranks():
+    """`bench.py --gpus 2` launched plainly re-executes itself under torch.distributed.run with two ranks (the driver's
+    own launch line sets WORLD_SIZE and is taken as it is); with the stub driver (no device work, gloo) the line
+    reports n_gpus = 2.  Reference analogue: mclapply(mc.cores = nCores), quilt.R:691-692."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "2", "--K", "300", "--nsnps", "640",
+                          "--batch", "2", "--reads", "40", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["stub"] is True and rec["value"] == 0.0 and rec["scaling"] == "weak"
+    # and the launcher's own form: WORLD_SIZE already set, no re-exec
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "1", "--K", "300", "--nsnps", "640",
+                          "--batch", "2", "--reads", "40", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env1, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
