@@ -188,3 +188,116 @@ def test_nipt_initial_labels_by_grouping():
     e = np.array([[1.0, 0.1, 1.0, 0.2, 1.0], [0.1, 1.0, 1.0, 0.1, 0.9], [0.2, 0.2, 0.1, 1.0, 0.8]])
     H = D.get_initial_read_labels_nipt(e, 0.2, rng)
     assert H[0] == 1 and H[1] == 2 and H[3] == 3 and H[2] in (1, 2) and H[4] in (1, 2, 3)
+
+
+def test_parameter_validation():
+    """validate_n_seek_its_and_n_burn_in_seek_its (quilt.R): the burn-in must leave at least one counting iteration."""
+    import pytest
+    from quilt_amd.driver import DriverParams
+    with pytest.raises(ValueError):
+        DriverParams(n_seek_its=3, n_burn_in_seek_its=3).resolved(5000)
+    with pytest.raises(ValueError):
+        DriverParams(n_seek_its=0).resolved(5000)
+    assert DriverParams(n_seek_its=1).resolved(5000).n_burn_in_seek_its == 0
+
+
+def test_sample_without_reads_is_rejected():
+    import pytest
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import SampleReads, make_synthetic_panel
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=300, nSNPs=320, seed=3)
+    empty = SampleReads(read_ptr=np.zeros(1, dtype=np.int32), u=np.zeros(0, dtype=np.int32), bq=np.zeros(0, dtype=np.int32),
+                        wif=np.zeros(0, dtype=np.int32))
+    with pytest.raises(ValueError, match="without reads"):
+        Driver(panel, OracleBackend(panel), DriverParams(nGibbsSamples=1, Ksubset=32, Knew=32)).run([empty])
+
+
+def test_bq_zero_bases_carry_nothing():
+    """A base with bq == 0 is neither ref nor alt: host mirror, oracle and device kernel all skip it (functions.R:2018-2020)."""
+    from oracle import oracle as O
+    from quilt_amd.driver import make_gl_from_u_bq
+    u = np.array([3, 3, 7, 9], dtype=np.int32)
+    bq = np.array([30, 0, -25, 0], dtype=np.int32)
+    gl = make_gl_from_u_bq(u, bq, 12, 1e-10, O.make_gl_bound)
+    ref = O.make_gl_from_u_bq(u, bq, 12)
+    assert np.array_equal(gl, ref)
+    assert gl[0, 9] == 1 and gl[1, 9] == 1
+    only = make_gl_from_u_bq(u[[0, 2]], bq[[0, 2]], 12, 1e-10, O.make_gl_bound)
+    assert np.array_equal(gl, only)
+
+
+def test_underflow_retry_reruns_only_the_failed_chains():
+    """impute_one_sample's loop (functions.R:2612-2716): a chain whose Gibbs call reports underflow is re-run with
+    maxDifferenceBetweenReads / 10, the others keep their result; more than ten consecutive failures is an error."""
+    import pytest
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=400, nSNPs=320, seed=3)
+    samples = [make_synthetic_sample(panel, seed=50 + i, n_reads=60) for i in range(2)]
+
+    class Flaky(OracleBackend):
+        def __init__(self, panel, fail_above):
+            super().__init__(panel)
+            self.fail_above, self.calls = fail_above, []
+
+        def gibbs_batch(self, samples, which, *a, maxDifferenceBetweenReads, **kw):
+            self.calls.append((len(samples), maxDifferenceBetweenReads))
+            out = super().gibbs_batch(samples, which, *a, maxDifferenceBetweenReads=maxDifferenceBetweenReads, **kw)
+            if maxDifferenceBetweenReads > self.fail_above:
+                out[0] = dict(out[0], underflow_problem=True)   # the first chain of every launch "underflows"
+            return out
+
+    prm = DriverParams(nGibbsSamples=2, Ksubset=48, Knew=48, seed=2)
+    be = Flaky(panel, fail_above=1e8)
+    drv = Driver(panel, be, prm)
+    res = drv.run(samples)
+    assert drv.n_underflow_retries > 0 and len(res) == 2
+    first = be.calls[:3]
+    assert first[0] == (4, 1e10) and first[1] == (1, 1e9) and first[2] == (1, 1e8)   # 2 samples x 2 chains, then the failed one alone
+    assert all(np.isfinite(r.dosage).all() for r in res)
+    with pytest.raises(RuntimeError, match="underflow"):
+        Driver(panel, Flaky(panel, fail_above=0.5), prm).run(samples)
+
+
+def test_truncated_lists_are_refetched():
+    """A panel with duplicated haplotypes: gamma ties make best-haplotype lists longer than the batched call returns; when the
+    selection runs out of ranked candidates it must draw from the FULL lists (functions.R:2278-2281), as the reference does."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    from tests.util import panel_from_rhb
+    base = make_synthetic_panel(K=40, nSNPs=320, seed=8)
+    rhb = np.asfortranarray(np.tile(base.rhb_t, (12, 1)))          # every haplotype 12 times: 480 haplotypes
+    panel = panel_from_rhb(rhb, base.transMatRate_t, 320, 255, base.ref_error)
+    panel.L_grid = base.L_grid
+    samples = [make_synthetic_sample(panel, seed=70, n_reads=80)]
+    prm = DriverParams(nGibbsSamples=1, Ksubset=64, Knew=64, seed=4)
+
+    class Narrow(OracleBackend):
+        pass
+
+    drv = Driver(panel, Narrow(panel), prm)
+    res = drv.run(samples)
+    assert drv.n_full_list_refetches > 0, "the test panel is meant to produce truncated lists and an exhausted selection"
+    # the same run with lists wide enough never to truncate gives the same result
+    wide = Driver(panel, OracleBackend(panel), prm)
+    wide.top_width = 600
+    res_wide = wide.run(samples)
+    assert wide.n_full_list_refetches == 0
+    assert np.array_equal(res[0].read_labels, res_wide[0].read_labels)
+    assert np.array_equal(res[0].dosage, res_wide[0].dosage)
+
+
+def test_underflowing_input_is_retried_by_the_cpu_path(small_panel):
+    """The input tests/test_pipeline_gpu.py::test_underflow_retry_on_the_device runs on the device does underflow in the
+    oracle at 1e10, and the retry loop (functions.R:2704-2715) brings it through."""
+    from quilt_amd.driver import Driver, DriverParams
+    from tests.oracle_backend import OracleBackend
+    from tests.util import underflowing_sample
+    s = underflowing_sample(small_panel)
+    drv = Driver(small_panel, OracleBackend(small_panel), DriverParams(nGibbsSamples=1, Ksubset=64, Knew=64, seed=6))
+    res = drv.run([s])
+    assert drv.n_underflow_retries > 0
+    assert np.isfinite(res[0].dosage).all()

@@ -206,3 +206,51 @@ def test_cu_partition_does_not_change_results(medium_panel):
         dev.close()
     for a, b in zip(*outs):
         assert np.array_equal(a.read_labels, b.read_labels) and np.array_equal(a.dosage, b.dosage)
+
+
+def test_truncated_lists_refetched_on_the_device():
+    """Duplicated panel haplotypes: exact gamma ties overflow the fused picker's candidate list (the grid is handed to k_topk)
+    and the lists the driver receives are truncated; the selection that runs out of ranked candidates re-fetches the full
+    lists (qa_fullpass_batch) -- result identical to the CPU path's, which always holds full lists."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    from tests.util import panel_from_rhb
+    base = make_synthetic_panel(K=40, nSNPs=320, seed=8)
+    rhb = np.asfortranarray(np.tile(base.rhb_t, (12, 1)))
+    panel = panel_from_rhb(rhb, base.transMatRate_t, 320, 255, base.ref_error)
+    panel.L_grid = base.L_grid
+    samples = [make_synthetic_sample(panel, seed=70, n_reads=80)]
+    prm = DriverParams(nGibbsSamples=1, Ksubset=64, Knew=64, seed=4)
+    dev = DevicePanel(panel)
+    drv = Driver(panel, HipBackend(dev), prm)
+    got = drv.run(samples)
+    ref = Driver(panel, OracleBackend(panel), prm).run(samples)
+    assert drv.n_full_list_refetches > 0
+    assert np.array_equal(got[0].read_labels, ref[0].read_labels)
+    assert np.abs(got[0].dosage - ref[0].dosage).max() <= 1e-4
+    dev.close()
+
+
+def test_underflow_retry_on_the_device(small_panel):
+    """Contradictory reads piled on one grid underflow the small-panel forward at maxDifferenceBetweenReads = 1e10; the driver repeats
+    the call with a tenth of it until the call succeeds (functions.R:2704-2715) -- the same number of retries and the same
+    labels as the CPU path."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from tests.oracle_backend import OracleBackend
+    from tests.util import underflowing_sample
+    panel = small_panel
+    s = underflowing_sample(panel)
+    prm = DriverParams(nGibbsSamples=1, Ksubset=64, Knew=64, seed=6)
+    dev = DevicePanel(panel)
+    d_gpu = Driver(panel, HipBackend(dev), prm)
+    got = d_gpu.run([s])
+    d_cpu = Driver(panel, OracleBackend(panel), prm)
+    ref = d_cpu.run([s])
+    assert d_cpu.n_underflow_retries > 0, "the test input is meant to underflow at the default maxDifferenceBetweenReads"
+    assert d_gpu.n_underflow_retries == d_cpu.n_underflow_retries
+    assert np.array_equal(got[0].read_labels, ref[0].read_labels)
+    assert np.isfinite(got[0].dosage).all()
+    dev.close()
