@@ -1,0 +1,132 @@
+/* quilt_amd_io.h -- host-side data formats either side of the hot path.
+ *
+ * Plain C ABI, no device work: these run on the host thread that feeds / drains the device workers of quilt_amd.h.
+ *
+ *   f3  BAM -> sampleReads       replaces STITCH::loadBamAndConvert + snap_sampleReads_to_grid as called from
+ *                                QUILT/R/functions.R:243-298 (per-sample RData temp files and R lists of 4-element lists
+ *                                become one flattened CSR, the layout qa_gibbs_batch / qa_fullpass_reads_batch take)
+ *   f4  per-sample VCF column    replaces STITCH::rcpp_make_column_of_vcf and the paste0 assembly of
+ *                                QUILT/R/functions.R:1408-1463, and the body writer QUILT/R/writers.R:80-128
+ *                                (data.table::fwrite + bgzip become one BGZF stream written here)
+ *
+ * STITCH (1.8.4) is not vendored in the reference tree, so the parts that live in STITCH are restated from its documented
+ * behaviour and from QUILT's call sites / parameter documentation (QUILT/R/quilt.R:30-56); where a choice is not visible
+ * from QUILT (tie rules, the central SNP of an even-length read, which reads a coverage cap removes) the rule used here is
+ * stated next to the function and is UNPINNED against STITCH.  The NIPT column and the header/INFO assembly are QUILT's
+ * own R code and follow it exactly.
+ */
+#ifndef QUILT_AMD_IO_H
+#define QUILT_AMD_IO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * f3: BAM -> sampleReads
+ * ---------------------------------------------------------------------------------------------------------------------- */
+
+typedef struct qa_sample_reads qa_sample_reads_t;   /* opaque; owned by the library */
+
+typedef struct {
+    int32_t bqFilter;              /* 17   minimum base quality of a SNP in a read; base quality is capped at the read's
+                                    *      mapping quality, and a read whose mapping quality is below it is not used
+                                    *      (QUILT/R/quilt.R:30) */
+    int32_t iSizeUpperLimit;       /* 1e6  reads with |template length| above this are not used (quilt.R:42) */
+    int32_t useSoftClippedBases;   /* 0    whether bases in soft-clipped parts count (quilt.R:31) */
+    int32_t downsampleToCov;       /* 30   per-SNP coverage cap (quilt.R:54); <= 0: no cap */
+    int32_t chrStart, chrEnd;      /* 1-based inclusive window alignments must overlap; 0, 0 = the whole chromosome
+                                    *      (functions.R:262-263: regionStart - buffer .. regionEnd + buffer) */
+    int32_t merge_mates;           /* 1    two alignments with the same query name become ONE read (they come from one
+                                    *      molecule, hence one haplotype), bases in SNP order */
+    uint64_t seed;                 /* key of the counter stream used where the loader has to choose (coverage cap) */
+} qa_bam_opts_t;
+
+void qa_bam_opts_default(qa_bam_opts_t *opts);
+
+/* Scan a (BGZF-compressed) BAM for alignments on `chr`, pile their bases onto the nSNPs sites and return the reads that
+ * cover at least one site.
+ *   L            nSNPs ascending 1-based positions (pos[, 2]); ref / alt: nSNPs bytes each, the two alleles of every site
+ *                (pos[, 3:4]; sites are biallelic SNPs -- a base that is neither allele is skipped)
+ *   grid         nSNPs 0-based grid index of every site (STITCH::assign_positions_to_grid; 32 SNPs per grid: site / 32)
+ * A base enters with bq = +q when it shows the alternate allele and -q for the reference allele (the sign convention of
+ * sampleReads[[r]][[3]], consumed at QUILT/src/gibbs-nipt.cpp:125-141), q = min(base quality, mapping quality), and is
+ * dropped when q < bqFilter.  Unmapped, secondary, supplementary, duplicate and QC-fail alignments are skipped.
+ * Unpinned-vs-STITCH rules: the read's central SNP is its (n - 1) / 2-th site (lower median); the coverage cap visits sites
+ * in ascending order and, at a site above the cap, drops the covering reads with the smallest counter-stream keys
+ * (key = stream(seed, read index)) until the site is at the cap.
+ * Reads come back ordered by the grid of their central SNP (stable), as snap_sampleReads_to_grid leaves them
+ * (functions.R:295-298).  QA_ERR_INVALID for unreadable / malformed files and unknown chromosome names. */
+int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNPs, const int32_t *L, const char *ref,
+                             const char *alt, const int32_t *grid, const qa_bam_opts_t *opts, qa_sample_reads_t **out);
+
+int32_t qa_sample_reads_n_reads(const qa_sample_reads_t *s);
+int64_t qa_sample_reads_n_bases(const qa_sample_reads_t *s);
+/* counts for the log lines of functions.R:289-290 and the loader's filters: [0] alignments seen on chr, [1] used,
+ * [2] dropped by mapping quality, [3] by insert size, [4] by flags, [5] reads removed by the coverage cap,
+ * [6] mate pairs merged, [7] alignments without a site */
+void qa_sample_reads_stats(const qa_sample_reads_t *s, int64_t stats[8]);
+/* read_ptr[n_reads + 1], u / bq [n_bases] (0-based site, signed quality), wif [n_reads] (0-based grid of the central SNP),
+ * central [n_reads] (0-based central site); any pointer may be NULL */
+int qa_sample_reads_export(const qa_sample_reads_t *s, int32_t *read_ptr, int32_t *u, int32_t *bq, int32_t *wif,
+                           int32_t *central);
+void qa_sample_reads_destroy(qa_sample_reads_t *s);
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * f4: per-sample VCF column and the VCF body
+ * ---------------------------------------------------------------------------------------------------------------------- */
+
+/* One sample's column of the VCF body, method = "diploid" (functions.R:1420-1441), FORMAT GT:GP:DS:HD.
+ *   gp_t           3 x nSNPs column-major genotype posteriors; phasing_haps nSNPs x 2 column-major haploid dosages
+ *   phased_gt      output_gt_phased_genotypes: GT becomes round(hd1)|round(hd2) (R's round: half to even)
+ * Entry t is "GT:gp0,gp1,gp2:ds:hd1,hd2" with three decimals (%.3f); unphased GT is the genotype whose posterior is >= 0.9,
+ * "./." when none is (the threshold rule lives in STITCH: unpinned).  Entries are written back to back into buf, each
+ * terminated by '\0'; off[t] is entry t's start, off[nSNPs] the bytes used.  QA_ERR_CAPACITY when cap is too small: *needed
+ * is set and nothing else written (a second call with that capacity succeeds). */
+int qa_vcf_column_diploid(int32_t nSNPs, const double *gp_t, const double *phasing_haps, int32_t phased_gt, char *buf,
+                          int64_t cap, int64_t *off, int64_t *needed);
+
+/* method = "nipt" (functions.R:1443-1459), FORMAT GT:MGP:MDS:FGP:FDS:
+ *   "h1|h2|h3:m0,m1,m2:mds:f0,f1,f2:fds" where every number is R's paste0(round(x, 3)): three decimals, trailing zeros and a
+ *   trailing point removed ("0.5", "1", "0").  phasing_haps nSNPs x 3 column-major. */
+int qa_vcf_column_nipt(int32_t nSNPs, const double *mat_gp_t, const double *fet_gp_t, const double *phasing_haps,
+                       const double *mat_dosage, const double *fet_dosage, char *buf, int64_t cap, int64_t *off,
+                       int64_t *needed);
+
+/* The column of a sample that was not imputed (fewer than minimum_number_of_sample_reads reads; functions.R:274-287):
+ * every entry "./.:.,.,.:.:.,." */
+const char *qa_vcf_missing_entry(void);
+
+/* INFO strings from the cross-sample sums (writers.R:38-58, 73-80): per site
+ *   "EAF=..;INFO_SCORE=..;HWE=..;ERC=..;EAC=..;PAF=.." with R's round(x, 5) / formatC(hwe, format = "e", digits = 2)
+ *   eaf, info, hwe: nSNPs each; alleleCount nSNPs x 3 column-major (ref-count, total-count, frequency as in writers.R:76-78:
+ *   ERC = alleleCount[, 1], EAC = alleleCount[, 2] - alleleCount[, 1], PAF = alleleCount[, 3]) */
+int qa_vcf_info_column(int32_t nSNPs, const double *eaf, const double *info, const double *hwe, const double *alleleCount,
+                       char *buf, int64_t cap, int64_t *off, int64_t *needed);
+
+/* Exact Hardy-Weinberg p-value per site from the counts of most-likely genotypes (writers.R:58; replaces
+ * STITCH::generate_hwe_on_counts -- the exact test of Wigginton et al. 2005; that STITCH uses this test is its documented
+ * behaviour, unpinned).  counts nSNPs x 3 column-major (hom-ref, het, hom-alt), rounded to integers. */
+int qa_hwe_exact(int32_t nSNPs, const double *counts, double *p_out);
+
+/* Write the VCF body (writers.R:81-117): one line per site with keep[t] != 0 (inRegion2),
+ *   chr \t pos \t . \t ref \t alt \t . \t PASS \t INFO \t FORMAT \t col_1 ... col_N \n
+ * appended to `path`.  bgzf != 0: the bytes are written as BGZF blocks (what `bgzip` produces from the text, including the
+ * end-of-file marker when finish != 0), so header and body can be appended in turn and `tabix` can index the result.
+ *   chr            chromosome name; pos_bp nSNPs 1-based positions; ref / alt nSNPs bytes
+ *   info / format  INFO entries (buf + off as produced by qa_vcf_info_column) and the FORMAT string
+ *   cols / offs    N pointers to column buffers and their offset arrays (as produced by qa_vcf_column_*); a NULL column is
+ *                  an unimputed sample
+ */
+int qa_vcf_write_body(const char *path, int32_t bgzf, int32_t finish, const char *chr, int32_t nSNPs, const int32_t *pos_bp,
+                      const char *ref, const char *alt, const uint8_t *keep, const char *info, const int64_t *info_off,
+                      const char *format, int32_t N, const char *const *cols, const int64_t *const *offs);
+/* Append raw text (the VCF header of writers.R:1-36) through the same BGZF framing. */
+int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const char *text, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

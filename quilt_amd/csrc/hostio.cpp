@@ -1,0 +1,564 @@
+// hostio.cpp -- host-side data formats either side of the hot path (include/quilt_amd_io.h):
+// BGZF/BAM -> flattened sampleReads, and sampleReads' way out: per-sample VCF columns, INFO strings, BGZF-framed body.
+// Plain C++ on the feeding thread; nothing here touches the device.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/quilt_amd.h"
+#include "../../include/quilt_amd_io.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BGZF: a series of gzip members, each <= 64 KiB, with the compressed size in a 'BC' extra field (SAM spec 4.1)
+// ---------------------------------------------------------------------------------------------------------------------
+struct BgzfReader {
+    FILE *f = nullptr;
+    std::vector<uint8_t> in, out;
+    size_t pos = 0;      // read cursor in out
+    bool eof = false, bad = false;
+
+    explicit BgzfReader(const char *path) : f(fopen(path, "rb")) { if (!f) bad = true; }
+    ~BgzfReader() { if (f) fclose(f); }
+
+    bool next_block() {
+        uint8_t h[18];
+        size_t n = fread(h, 1, 12, f);
+        if (n == 0) { eof = true; return false; }
+        if (n != 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { bad = true; return false; }
+        int xlen = h[10] | (h[11] << 8);
+        std::vector<uint8_t> extra(xlen);
+        if (fread(extra.data(), 1, xlen, f) != (size_t)xlen) { bad = true; return false; }
+        int bsize = -1;
+        for (int i = 0; i + 4 <= xlen;) {
+            int slen = extra[i + 2] | (extra[i + 3] << 8);
+            if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = extra[i + 4] | (extra[i + 5] << 8);
+            i += 4 + slen;
+        }
+        if (bsize < 0) { bad = true; return false; }
+        int clen = bsize - xlen - 19;   // deflate bytes; then CRC32 and ISIZE
+        if (clen < 0) { bad = true; return false; }
+        in.resize((size_t)clen + 8);
+        if (fread(in.data(), 1, in.size(), f) != in.size()) { bad = true; return false; }
+        uint32_t crc, isize;
+        memcpy(&crc, in.data() + clen, 4);
+        memcpy(&isize, in.data() + clen + 4, 4);
+        if (isize > (1u << 16)) { bad = true; return false; }
+        out.resize(isize);
+        pos = 0;
+        if (isize == 0) return true;   // the end-of-file marker (or an empty block): keep going
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return false; }
+        zs.next_in = in.data();
+        zs.avail_in = (uInt)clen;
+        zs.next_out = out.data();
+        zs.avail_out = isize;
+        int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.total_out != isize || crc32(crc32(0L, Z_NULL, 0), out.data(), isize) != crc) {
+            bad = true;
+            return false;
+        }
+        return true;
+    }
+    // exactly n bytes, or false at a clean end of file before the first byte (eof) / on a truncated stream (bad)
+    bool read(void *dst, size_t n) {
+        uint8_t *d = static_cast<uint8_t *>(dst);
+        size_t got = 0;
+        while (got < n) {
+            if (pos == out.size()) {
+                if (!next_block()) { if (got > 0) bad = true; return false; }
+                continue;
+            }
+            size_t m = std::min(n - got, out.size() - pos);
+            memcpy(d + got, out.data() + pos, m);
+            pos += m;
+            got += m;
+        }
+        return true;
+    }
+};
+
+struct BgzfWriter {
+    FILE *f = nullptr;
+    bool framed;
+    std::vector<uint8_t> buf;
+    static constexpr size_t kBlock = 0xff00;   // bgzip's uncompressed block size
+    BgzfWriter(const char *path, bool framed_, bool truncate) : f(fopen(path, truncate ? "wb" : "ab")), framed(framed_) {}
+    ~BgzfWriter() { if (f) fclose(f); }
+    bool ok() const { return f != nullptr; }
+    bool flush_block(const uint8_t *p, size_t n) {
+        uint8_t comp[1 << 16];
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        zs.next_in = const_cast<uint8_t *>(p);
+        zs.avail_in = (uInt)n;
+        zs.next_out = comp;
+        zs.avail_out = sizeof comp;
+        int rc = deflate(&zs, Z_FINISH);
+        size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) return false;
+        uint32_t bsize = (uint32_t)(clen + 25);   // header 18 + data + 8, stored minus one
+        uint8_t h[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0,
+                         (uint8_t)(bsize & 0xff), (uint8_t)(bsize >> 8)};
+        uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n), isize = (uint32_t)n;
+        return fwrite(h, 1, 18, f) == 18 && fwrite(comp, 1, clen, f) == clen && fwrite(&crc, 4, 1, f) == 1 &&
+               fwrite(&isize, 4, 1, f) == 1;
+    }
+    bool write(const char *p, size_t n) {
+        if (!framed) return fwrite(p, 1, n, f) == n;
+        buf.insert(buf.end(), p, p + n);
+        size_t done = 0;
+        while (buf.size() - done >= kBlock) {
+            if (!flush_block(buf.data() + done, kBlock)) return false;
+            done += kBlock;
+        }
+        buf.erase(buf.begin(), buf.begin() + done);
+        return true;
+    }
+    bool finish(bool eof_marker) {
+        if (!framed) return fflush(f) == 0;
+        if (!buf.empty() && !flush_block(buf.data(), buf.size())) return false;
+        buf.clear();
+        if (eof_marker && !flush_block(nullptr, 0)) return false;
+        return fflush(f) == 0;
+    }
+};
+
+inline uint64_t stream_key(uint64_t seed, uint64_t i) {   // the library's counter stream (gibbs_dev.hpp stream_uniform)
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct Base { int32_t u, bq; };
+struct Read { std::vector<Base> b; bool alive = true; };
+
+}  // namespace
+
+struct qa_sample_reads {
+    std::vector<int32_t> read_ptr, u, bq, wif, central;
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+extern "C" {
+
+void qa_bam_opts_default(qa_bam_opts_t *o) {
+    if (!o) return;
+    o->bqFilter = 17;
+    o->iSizeUpperLimit = 1000000;
+    o->useSoftClippedBases = 0;
+    o->downsampleToCov = 30;
+    o->chrStart = o->chrEnd = 0;
+    o->merge_mates = 1;
+    o->seed = 1;
+}
+
+int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNPs, const int32_t *L, const char *ref,
+                             const char *alt, const int32_t *grid, const qa_bam_opts_t *opts, qa_sample_reads_t **out) {
+    if (!bam_path || !chr || nSNPs < 1 || !L || !ref || !alt || !grid || !out) return QA_ERR_INVALID;
+    for (int32_t t = 1; t < nSNPs; t++) if (L[t] <= L[t - 1]) return QA_ERR_INVALID;
+    qa_bam_opts_t o;
+    if (opts) o = *opts; else qa_bam_opts_default(&o);
+    BgzfReader bz(bam_path);
+    if (bz.bad) return QA_ERR_INVALID;
+    char magic[4];
+    int32_t l_text, n_ref;
+    if (!bz.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !bz.read(&l_text, 4) || l_text < 0) return QA_ERR_INVALID;
+    std::string text((size_t)l_text, '\0');
+    if (l_text && !bz.read(&text[0], (size_t)l_text)) return QA_ERR_INVALID;
+    const bool sorted = text.find("SO:coordinate") != std::string::npos;
+    if (!bz.read(&n_ref, 4) || n_ref < 0) return QA_ERR_INVALID;
+    int32_t target = -1;
+    for (int32_t i = 0; i < n_ref; i++) {
+        int32_t l_name, l_ref;
+        if (!bz.read(&l_name, 4) || l_name < 1 || l_name > 65536) return QA_ERR_INVALID;
+        std::string name((size_t)l_name, '\0');
+        if (!bz.read(&name[0], (size_t)l_name) || !bz.read(&l_ref, 4)) return QA_ERR_INVALID;
+        if (strcmp(name.c_str(), chr) == 0) target = i;
+    }
+    if (target < 0) return QA_ERR_INVALID;
+
+    auto *S = new qa_sample_reads;
+    std::vector<Read> reads;
+    std::unordered_map<std::string, size_t> by_name;
+    const int32_t lo_bp = o.chrStart > 0 ? o.chrStart : 1, hi_bp = o.chrEnd > 0 ? o.chrEnd : INT32_MAX;
+    std::vector<uint8_t> rec;
+    static const char kNt16[] = "=ACMGRSVTWYHKDBN";
+    for (;;) {
+        int32_t block_size;
+        if (!bz.read(&block_size, 4)) break;
+        if (block_size < 32) { bz.bad = true; break; }
+        rec.resize((size_t)block_size);
+        if (!bz.read(rec.data(), rec.size())) { bz.bad = true; break; }
+        int32_t refID, pos0, next_ref, next_pos, tlen, l_seq;
+        memcpy(&refID, &rec[0], 4);
+        memcpy(&pos0, &rec[4], 4);
+        const int l_read_name = rec[8], mapq = rec[9];
+        uint16_t n_cigar, flag;
+        memcpy(&n_cigar, &rec[12], 2);
+        memcpy(&flag, &rec[14], 2);
+        memcpy(&l_seq, &rec[16], 4);
+        memcpy(&next_ref, &rec[20], 4);
+        memcpy(&next_pos, &rec[24], 4);
+        memcpy(&tlen, &rec[28], 4);
+        (void)next_ref; (void)next_pos;
+        if (refID != target) {
+            if (sorted && refID > target) break;
+            continue;
+        }
+        size_t need = 32 + (size_t)l_read_name + 4 * (size_t)n_cigar + (size_t)((l_seq + 1) / 2) + (size_t)l_seq;
+        if (l_seq < 0 || need > rec.size()) { bz.bad = true; break; }
+        if (sorted && pos0 + 1 > hi_bp) break;
+        S->stats[0]++;
+        if (flag & (0x4 | 0x100 | 0x200 | 0x400 | 0x800)) { S->stats[4]++; continue; }
+        if (mapq < o.bqFilter) { S->stats[2]++; continue; }
+        if (std::abs((int64_t)tlen) > (int64_t)o.iSizeUpperLimit) { S->stats[3]++; continue; }
+        const uint8_t *cig = &rec[32 + l_read_name], *seq = cig + 4 * (size_t)n_cigar, *qual = seq + (l_seq + 1) / 2;
+        // walk the CIGAR; a soft clip is laid out left of / right of the aligned part when its bases are to be used
+        int64_t rpos = (int64_t)pos0 + 1;   // 1-based reference coordinate of the next reference-consuming base
+        if (o.useSoftClippedBases && n_cigar > 0) {
+            uint32_t c0;
+            memcpy(&c0, cig, 4);
+            if ((c0 & 15) == 4) rpos -= (c0 >> 4);
+        }
+        const int64_t aln_start = rpos;
+        int32_t q = 0;
+        std::vector<Base> bases;
+        // first site at or after the alignment start
+        int32_t t = (int32_t)(std::lower_bound(L, L + nSNPs, (int32_t)std::max<int64_t>(rpos, INT32_MIN)) - L);
+        for (int ci = 0; ci < n_cigar; ci++) {
+            uint32_t c;
+            memcpy(&c, cig + 4 * (size_t)ci, 4);
+            const int op = c & 15;
+            const int32_t len = (int32_t)(c >> 4);
+            const bool clip_used = op == 4 && o.useSoftClippedBases;
+            if (op == 0 || op == 7 || op == 8 || clip_used) {   // M, =, X (and S when used): query and reference advance
+                while (t < nSNPs && L[t] < rpos) t++;
+                while (t < nSNPs && L[t] < rpos + len) {
+                    const int32_t qi = q + (int32_t)(L[t] - rpos);
+                    if (qi < l_seq) {
+                        const char base = kNt16[(seq[qi >> 1] >> ((qi & 1) ? 0 : 4)) & 15];
+                        int32_t bqv = qual[qi] == 0xff ? 0 : qual[qi];
+                        if (bqv > mapq) bqv = mapq;
+                        if (bqv >= o.bqFilter) {
+                            if (base == ref[t]) bases.push_back({t, -bqv});
+                            else if (base == alt[t]) bases.push_back({t, bqv});
+                        }
+                    }
+                    t++;
+                }
+                q += len;
+                rpos += len;
+            } else if (op == 1 || op == 4) {   // I, S (unused): query only
+                q += len;
+            } else if (op == 2 || op == 3) {   // D, N: reference only
+                rpos += len;
+            }                                  // H, P: neither
+        }
+        if (rpos - 1 < lo_bp || aln_start > hi_bp) continue;   // outside the window
+        S->stats[1]++;
+        if (bases.empty()) { S->stats[7]++; continue; }
+        if (o.merge_mates && (flag & 0x1)) {
+            std::string name(reinterpret_cast<const char *>(&rec[32]), (size_t)std::max(0, l_read_name - 1));
+            auto it = by_name.find(name);
+            if (it != by_name.end()) {
+                auto &dst = reads[it->second].b;
+                dst.insert(dst.end(), bases.begin(), bases.end());
+                std::stable_sort(dst.begin(), dst.end(), [](const Base &a, const Base &b) { return a.u < b.u; });
+                by_name.erase(it);
+                S->stats[6]++;
+                continue;
+            }
+            by_name.emplace(std::move(name), reads.size());
+        }
+        reads.emplace_back();
+        reads.back().b = std::move(bases);
+    }
+    if (bz.bad) { delete S; return QA_ERR_INVALID; }
+
+    // coverage cap (quilt.R:54): sites in ascending order; at a site above the cap the covering reads with the smallest
+    // stream keys go, until the site is at the cap
+    if (o.downsampleToCov > 0) {
+        std::vector<int32_t> depth((size_t)nSNPs, 0);
+        for (auto &r : reads) for (auto &b : r.b) depth[b.u]++;
+        bool any = false;
+        for (int32_t t = 0; t < nSNPs; t++) any |= depth[t] > o.downsampleToCov;
+        if (any) {
+            std::vector<std::vector<uint32_t>> cover((size_t)nSNPs);
+            for (size_t r = 0; r < reads.size(); r++)
+                for (auto &b : reads[r].b) if (depth[b.u] > o.downsampleToCov) cover[b.u].push_back((uint32_t)r);
+            for (int32_t t = 0; t < nSNPs; t++) {
+                if (depth[t] <= o.downsampleToCov) continue;
+                std::vector<std::pair<uint64_t, uint32_t>> cand;
+                for (uint32_t r : cover[t]) if (reads[r].alive) cand.push_back({stream_key(o.seed, r), r});
+                std::sort(cand.begin(), cand.end());
+                for (size_t i = 0; i < cand.size() && depth[t] > o.downsampleToCov; i++) {
+                    Read &rd = reads[cand[i].second];
+                    if (!rd.alive) continue;
+                    rd.alive = false;
+                    S->stats[5]++;
+                    for (auto &b : rd.b) depth[b.u]--;
+                }
+            }
+        }
+    }
+
+    // order by the grid of the central site (stable), flatten
+    std::vector<uint32_t> order;
+    std::vector<int32_t> cen(reads.size());
+    for (size_t r = 0; r < reads.size(); r++) {
+        if (!reads[r].alive) continue;
+        cen[r] = reads[r].b[(reads[r].b.size() - 1) / 2].u;
+        order.push_back((uint32_t)r);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return grid[cen[a]] < grid[cen[b]]; });
+    S->read_ptr.push_back(0);
+    for (uint32_t r : order) {
+        for (auto &b : reads[r].b) { S->u.push_back(b.u); S->bq.push_back(b.bq); }
+        S->read_ptr.push_back((int32_t)S->u.size());
+        S->wif.push_back(grid[cen[r]]);
+        S->central.push_back(cen[r]);
+    }
+    *out = S;
+    return QA_OK;
+}
+
+int32_t qa_sample_reads_n_reads(const qa_sample_reads_t *s) { return s ? (int32_t)s->wif.size() : 0; }
+int64_t qa_sample_reads_n_bases(const qa_sample_reads_t *s) { return s ? (int64_t)s->u.size() : 0; }
+void qa_sample_reads_stats(const qa_sample_reads_t *s, int64_t stats[8]) {
+    if (s && stats) memcpy(stats, s->stats, sizeof s->stats);
+}
+int qa_sample_reads_export(const qa_sample_reads_t *s, int32_t *read_ptr, int32_t *u, int32_t *bq, int32_t *wif,
+                           int32_t *central) {
+    if (!s) return QA_ERR_INVALID;
+    auto cp = [](int32_t *d, const std::vector<int32_t> &v) { if (d && !v.empty()) memcpy(d, v.data(), 4 * v.size()); };
+    cp(read_ptr, s->read_ptr);
+    cp(u, s->u);
+    cp(bq, s->bq);
+    cp(wif, s->wif);
+    cp(central, s->central);
+    return QA_OK;
+}
+void qa_sample_reads_destroy(qa_sample_reads_t *s) { delete s; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// f4
+// ---------------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// R's paste0(round(x, 3)) for the magnitudes a posterior / dosage takes: three decimals, then the shortest form
+int fmt_round3(char *p, double x) {
+    if (std::isnan(x)) { memcpy(p, "NA", 2); return 2; }
+    int n = snprintf(p, 32, "%.3f", x);
+    if (strcmp(p, "-0.000") == 0) { memcpy(p, "0", 2); return 1; }
+    while (n > 0 && p[n - 1] == '0') n--;
+    if (n > 0 && p[n - 1] == '.') n--;
+    p[n] = 0;
+    return n;
+}
+// R's as.character(round(x, 5))
+int fmt_round5(char *p, double x) {
+    if (std::isnan(x)) { memcpy(p, "NaN", 3); return 3; }
+    if (std::isinf(x)) { int n = snprintf(p, 32, x > 0 ? "Inf" : "-Inf"); return n; }
+    int n = snprintf(p, 32, "%.5f", x);
+    while (n > 0 && p[n - 1] == '0') n--;
+    if (n > 0 && p[n - 1] == '.') n--;
+    p[n] = 0;
+    if (strcmp(p, "-0") == 0) { memcpy(p, "0", 2); return 1; }
+    // R switches to scientific notation when that is no wider: below 1e-4 after rounding to 5 decimals only 1e-05 .. 9e-05
+    if (x != 0 && std::fabs(x) < 1e-4 && n > 1) {
+        double r = std::round(std::fabs(x) * 1e5);
+        if (r >= 1 && r <= 9) n = snprintf(p, 32, "%s%de-05", x < 0 ? "-" : "", (int)r);
+    }
+    return n;
+}
+inline int r_round_int(double x) { return (int)std::nearbyint(x); }   // half to even, as R's round(x)
+
+struct Sink {
+    char *buf;
+    int64_t cap, used = 0;
+    int64_t *off;
+    void put(int32_t t, const char *s, int n) {
+        if (used + n + 1 <= cap) {
+            if (off) off[t] = used;
+            memcpy(buf + used, s, (size_t)n);
+            buf[used + n] = 0;
+        }
+        used += n + 1;
+    }
+    int done(int32_t T, int64_t *needed) {
+        if (needed) *needed = used;
+        if (used > cap) return QA_ERR_CAPACITY;
+        if (off) off[T] = used;
+        return QA_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *qa_vcf_missing_entry(void) { return "./.:.,.,.:.:.,."; }
+
+int qa_vcf_column_diploid(int32_t T, const double *gp_t, const double *hd, int32_t phased_gt, char *buf, int64_t cap,
+                          int64_t *off, int64_t *needed) {
+    if (T < 0 || !gp_t || !hd || (!buf && cap > 0)) return QA_ERR_INVALID;
+    Sink s{buf, cap, 0, off};
+    char e[160];
+    for (int32_t t = 0; t < T; t++) {
+        const double g0 = gp_t[3 * (size_t)t], g1 = gp_t[3 * (size_t)t + 1], g2 = gp_t[3 * (size_t)t + 2];
+        const double h1 = hd[t], h2 = hd[(size_t)T + t];
+        int n;
+        if (phased_gt) {
+            n = snprintf(e, sizeof e, "%d|%d", r_round_int(h1), r_round_int(h2));
+        } else {
+            const char *gt = g0 >= 0.9 ? "0/0" : g1 >= 0.9 ? "0/1" : g2 >= 0.9 ? "1/1" : "./.";
+            memcpy(e, gt, 3);
+            n = 3;
+        }
+        n += snprintf(e + n, sizeof e - n, ":%.3f,%.3f,%.3f:%.3f:%.3f,%.3f", g0, g1, g2, g1 + 2 * g2, h1, h2);
+        s.put(t, e, n);
+    }
+    return s.done(T, needed);
+}
+
+int qa_vcf_column_nipt(int32_t T, const double *m, const double *f, const double *hd, const double *mds, const double *fds,
+                       char *buf, int64_t cap, int64_t *off, int64_t *needed) {
+    if (T < 0 || !m || !f || !hd || !mds || !fds || (!buf && cap > 0)) return QA_ERR_INVALID;
+    Sink s{buf, cap, 0, off};
+    char e[320];
+    for (int32_t t = 0; t < T; t++) {
+        int n = snprintf(e, sizeof e, "%d|%d|%d:", r_round_int(hd[t]), r_round_int(hd[(size_t)T + t]),
+                         r_round_int(hd[2 * (size_t)T + t]));
+        const double v[8] = {m[3 * (size_t)t], m[3 * (size_t)t + 1], m[3 * (size_t)t + 2], mds[t],
+                             f[3 * (size_t)t], f[3 * (size_t)t + 1], f[3 * (size_t)t + 2], fds[t]};
+        static const char sep[8] = {',', ',', ':', ':', ',', ',', ':', 0};
+        for (int i = 0; i < 8; i++) {
+            n += fmt_round3(e + n, v[i]);
+            if (sep[i]) e[n++] = sep[i];
+        }
+        e[n] = 0;
+        s.put(t, e, n);
+    }
+    return s.done(T, needed);
+}
+
+int qa_vcf_info_column(int32_t T, const double *eaf, const double *info, const double *hwe, const double *ac, char *buf,
+                       int64_t cap, int64_t *off, int64_t *needed) {
+    if (T < 0 || !eaf || !info || !hwe || !ac || (!buf && cap > 0)) return QA_ERR_INVALID;
+    Sink s{buf, cap, 0, off};
+    char e[320];
+    for (int32_t t = 0; t < T; t++) {
+        int n = 0;
+        memcpy(e + n, "EAF=", 4); n += 4; n += fmt_round5(e + n, eaf[t]);
+        memcpy(e + n, ";INFO_SCORE=", 12); n += 12; n += fmt_round5(e + n, info[t]);
+        // formatC(hwe, format = "e", digits = 2): C's %.2e (two-digit exponent at least)
+        n += snprintf(e + n, sizeof e - n, ";HWE=%.2e", hwe[t]);
+        memcpy(e + n, ";ERC=", 5); n += 5; n += fmt_round5(e + n, ac[t]);
+        memcpy(e + n, ";EAC=", 5); n += 5; n += fmt_round5(e + n, ac[(size_t)T + t] - ac[t]);
+        memcpy(e + n, ";PAF=", 5); n += 5; n += fmt_round5(e + n, ac[2 * (size_t)T + t]);
+        e[n] = 0;
+        s.put(t, e, n);
+    }
+    return s.done(T, needed);
+}
+
+// Exact Hardy-Weinberg test on genotype counts (Wigginton, Cutler & Abecasis 2005: sum of the probabilities of all
+// heterozygote counts no more likely than the observed one, given the allele counts); replaces
+// STITCH::generate_hwe_on_counts as called at writers.R:58.  counts nSNPs x 3 column-major (hom-ref, het, hom-alt).
+int qa_hwe_exact(int32_t T, const double *counts, double *p_out) {
+    if (T < 0 || !counts || !p_out) return QA_ERR_INVALID;
+    std::vector<double> pr;
+    for (int32_t t = 0; t < T; t++) {
+        const long n_aa = std::lround(counts[t]), n_ab = std::lround(counts[(size_t)T + t]),
+                   n_bb = std::lround(counts[2 * (size_t)T + t]);
+        if (n_aa < 0 || n_ab < 0 || n_bb < 0) return QA_ERR_INVALID;
+        const long n = n_aa + n_ab + n_bb;
+        if (n == 0) { p_out[t] = 1; continue; }
+        const long rare = 2 * std::min(n_aa, n_bb) + n_ab;
+        pr.assign((size_t)rare + 1, 0.0);
+        long mid = (long)((double)rare * (double)(2 * n - rare) / (double)(2 * n));
+        if ((mid & 1) != (rare & 1)) mid++;
+        long het = mid, hr = (rare - mid) / 2, hc = n - het - hr;
+        pr[mid] = 1;
+        double sum = 1;
+        for (het = mid; het > 1; het -= 2) {
+            pr[het - 2] = pr[het] * (double)het * (double)(het - 1) / (4.0 * (double)(hr + 1) * (double)(hc + 1));
+            sum += pr[het - 2];
+            hr++;
+            hc++;
+        }
+        hr = (rare - mid) / 2;
+        hc = n - mid - hr;
+        for (het = mid; het <= rare - 2; het += 2) {
+            pr[het + 2] = pr[het] * 4.0 * (double)hr * (double)hc / ((double)(het + 2) * (double)(het + 1));
+            sum += pr[het + 2];
+            hr--;
+            hc--;
+        }
+        double p = 0;
+        const double obs = pr[n_ab] / sum;
+        for (long i = 0; i <= rare; i++) if (pr[i] / sum <= obs) p += pr[i] / sum;
+        p_out[t] = p > 1 ? 1 : p;
+    }
+    return QA_OK;
+}
+
+int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const char *text, int64_t n) {
+    if (!path || (!text && n > 0) || n < 0) return QA_ERR_INVALID;
+    BgzfWriter w(path, bgzf != 0, truncate != 0);
+    if (!w.ok()) return QA_ERR_INVALID;
+    if (n && !w.write(text, (size_t)n)) return QA_ERR_INVALID;
+    return w.finish(false) ? QA_OK : QA_ERR_INVALID;
+}
+
+int qa_vcf_write_body(const char *path, int32_t bgzf, int32_t finish, const char *chr, int32_t T, const int32_t *pos_bp,
+                      const char *ref, const char *alt, const uint8_t *keep, const char *info, const int64_t *info_off,
+                      const char *format, int32_t N, const char *const *cols, const int64_t *const *offs) {
+    if (!path || !chr || T < 0 || !pos_bp || !ref || !alt || !info || !info_off || !format || N < 0 || (N && (!cols || !offs)))
+        return QA_ERR_INVALID;
+    BgzfWriter w(path, bgzf != 0, false);
+    if (!w.ok()) return QA_ERR_INVALID;
+    std::string line;
+    const char *miss = qa_vcf_missing_entry();
+    char num[16];
+    for (int32_t t = 0; t < T; t++) {
+        if (keep && !keep[t]) continue;
+        line.clear();
+        line += chr;
+        line += '\t';
+        snprintf(num, sizeof num, "%d", pos_bp[t]);
+        line += num;
+        line += "\t.\t";
+        line += ref[t];
+        line += '\t';
+        line += alt[t];
+        line += "\t.\tPASS\t";
+        line += info + info_off[t];
+        line += '\t';
+        line += format;
+        for (int32_t i = 0; i < N; i++) {
+            line += '\t';
+            line += cols[i] ? cols[i] + offs[i][t] : miss;
+        }
+        line += '\n';
+        if (!w.write(line.data(), line.size())) return QA_ERR_INVALID;
+    }
+    return w.finish(finish != 0) ? QA_OK : QA_ERR_INVALID;
+}
+
+}  // extern "C"

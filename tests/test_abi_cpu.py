@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/quilt_amd.h declares; without a GPU every
+"""The C-ABI library loads and exports every symbol include/*.h declares; without a GPU every
 compute entry point fails loudly (no CPU fallback)."""
 import ctypes as C
 import os
@@ -11,9 +11,12 @@ from quilt_amd import native
 
 
 def _declared_functions():
-    text = open(native.HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(qa_[a-zA-Z0-9_]+)\s*\(", text)))
+    import glob
+    names = set()
+    for header in glob.glob(os.path.join(os.path.dirname(native.HEADER), "*.h")):   # quilt_amd.h, quilt_amd_io.h
+        text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+        names |= set(re.findall(r"\b(qa_[a-zA-Z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 @pytest.fixture(scope="module")
@@ -27,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
     names = _declared_functions()
     assert len(names) >= 10
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/quilt_amd.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     assert lib.qa_abi_version() == 2
 
 
