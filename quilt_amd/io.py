@@ -286,3 +286,39 @@ def make_and_write_output_file(output_filename: str, sampleNames: Sequence[str],
                                 "".join(ref).encode(), "".join(alt).encode(), ptr(keep), ptr(info.buf), ptr(info.off), fmt,
                                 C.c_int32(N), col_ptrs, off_ptrs), "body")
     return fin
+
+
+def impute_bams_to_vcf(panel, backend, bam_files: Sequence[str], sampleNames: Sequence[str], chr: str, ref: Sequence[str],
+                       alt: Sequence[str], output_filename: str, params=None, inRegion2: Optional[np.ndarray] = None,
+                       minimum_number_of_sample_reads: int = 2, ff: Optional[Sequence[float]] = None,
+                       output_gt_phased_genotypes: bool = True, **bam_opts):
+    """The per-sample path end to end for one region: BAM -> sampleReads (f3) -> the driver loop on `backend` -> VCF
+    columns and file (f4).  What get_and_impute_one_sample does between its ``loadBamAndConvert`` call and its return
+    value, plus the writer (functions.R:243-298, 1408-1477; writers.R).  Samples with fewer than
+    ``minimum_number_of_sample_reads`` reads are written as missing and left out of the counts (functions.R:274-287)."""
+    from .driver import Driver, DriverParams
+    params = params or DriverParams()
+    if panel.L is None:
+        raise ValueError("the panel carries no SNP positions (Panel.L)")
+    grid = panel.grid if panel.grid is not None else np.arange(panel.nSNPs, dtype=np.int32) // 32
+    samples, imputed = [], []
+    for i, path in enumerate(bam_files):
+        s = loadBamAndConvert(path, chr, panel.L, ref, alt, grid, **bam_opts)
+        if ff is not None:
+            s.ff = float(ff[i])
+        if s.nReads < minimum_number_of_sample_reads:
+            continue
+        samples.append(s)
+        imputed.append(i)
+    results = Driver(panel, backend, params).run(samples) if samples else []
+    counts = SummaryCounts(panel.nSNPs)
+    cols: List[Optional[VcfColumn]] = [None] * len(bam_files)
+    for i, s, r in zip(imputed, samples, results):
+        counts.add_sample(*per_sample_counts(r.gp_t, s, panel.nSNPs))
+        if params.method == "nipt":
+            cols[i] = make_per_sample_vcf_col_nipt(r.gp_t, r.fet_gp_t, r.phasing_haps, r.dosage, r.fet_dosage)
+        else:
+            cols[i] = make_per_sample_vcf_col(r.gp_t, r.phasing_haps, output_gt_phased_genotypes)
+    make_and_write_output_file(output_filename, sampleNames, chr, panel.L, ref, alt, cols, counts, inRegion2=inRegion2,
+                               method=params.method, output_gt_phased_genotypes=output_gt_phased_genotypes)
+    return dict(results=dict(zip(imputed, results)), columns=cols, counts=counts)

@@ -301,3 +301,54 @@ def test_underflowing_input_is_retried_by_the_cpu_path(small_panel):
     res = drv.run([s])
     assert drv.n_underflow_retries > 0
     assert np.isfinite(res[0].dosage).all()
+
+
+def _bam_to_vcf(tmp_path, panel, backend, method="diploid", n_samples=3, n_reads=300, ff=None):
+    """Synthetic samples -> BAM files -> loader -> driver -> VCF; returns (parsed VCF rows, run record, truth dosages)."""
+    import gzip
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.io import impute_bams_to_vcf
+    from quilt_amd.synth import make_synthetic_sample
+    from tests import bamutil
+    rng = np.random.default_rng(21)
+    T = panel.nSNPs
+    alleles = [tuple(rng.choice(list("ACGT"), size=2, replace=False)) for _ in range(T)]
+    ref, alt = [a for a, _ in alleles], [b for _, b in alleles]
+    bams, truth = [], []
+    for i in range(n_samples):
+        s = make_synthetic_sample(panel, seed=300 + i, n_reads=n_reads, ff=(ff or 0.0))
+        path = str(tmp_path / f"s{i}.bam")
+        bamutil.write_bam(path, [("chr20", int(panel.L[-1]) + 1000)], bamutil.sample_to_alignments(s, panel.L, ref, alt, rng))
+        bams.append(path)
+        truth.append(s.truth_haps[:2].sum(axis=0).astype(float))
+    empty = str(tmp_path / "empty.bam")                     # a sample without reads in the region: written as missing
+    bamutil.write_bam(empty, [("chr20", int(panel.L[-1]) + 1000)], [])
+    bams.insert(1, empty)
+    names = [f"NA{i}" for i in range(len(bams))]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method=method)
+    out = str(tmp_path / "quilt.vcf.gz")
+    rec = impute_bams_to_vcf(panel, backend, bams, names, "chr20", ref, alt, out, params=prm,
+                             ff=None if ff is None else [ff] * len(bams))
+    lines = [l for l in gzip.open(out, "rt").read().split("\n") if l and not l.startswith("##")]
+    assert lines[0].split("\t")[9:] == names
+    rows = [l.split("\t") for l in lines[1:]]
+    assert len(rows) == T
+    return rows, rec, truth
+
+
+def test_bam_to_vcf_end_to_end_on_the_cpu_path(tmp_path, small_panel):
+    """f3 -> the driver (on the oracle backend) -> f4: dosages in the file are the driver's, rounded to three decimals; the
+    sample without reads is '.'; imputed dosages track the truth."""
+    from tests.oracle_backend import OracleBackend
+    from tests.util import r2
+    rows, rec, truth = _bam_to_vcf(tmp_path, small_panel, OracleBackend(small_panel))
+    assert set(rec["results"]) == {0, 2, 3} and rec["columns"][1] is None
+    for col, i_truth in ((0, 0), (2, 1), (3, 2)):
+        ds = np.array([float(r[9 + col].split(":")[2]) for r in rows])
+        res = rec["results"][col]
+        assert np.abs(ds - (res.gp_t[1] + 2 * res.gp_t[2])).max() <= 5.1e-4
+        assert r2(ds, truth[i_truth]) > 0.8
+        gt = rows[0][9 + col].split(":")[0]
+        assert len(gt) == 3 and gt[1] == "|"
+    assert all(r[9 + 1] == "./.:.,.,.:.:.,." for r in rows)
+    assert rows[5][8] == "GT:GP:DS:HD" and rows[5][7].startswith("EAF=")

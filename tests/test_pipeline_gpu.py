@@ -254,3 +254,34 @@ def test_underflow_retry_on_the_device(small_panel):
     assert np.array_equal(got[0].read_labels, ref[0].read_labels)
     assert np.isfinite(got[0].dosage).all()
     dev.close()
+
+
+@pytest.mark.parametrize("method", ["diploid", "nipt"])
+def test_bam_to_vcf_end_to_end_on_the_device(tmp_path, small_panel, method):
+    """The formats either side of the path with the device in the middle: BAM files -> loader ->
+    driver on the HIP backend -> VCF.  Same file as the CPU path writes from the same BAMs (the labels are bit-identical, the
+    posteriors agree to ~1e-6, so three-decimal strings may differ in the last digit at a rounding boundary only)."""
+    from quilt_amd.driver import HipBackend
+    from quilt_amd.native import DevicePanel
+    from tests.oracle_backend import OracleBackend
+    from tests.test_driver_host import _bam_to_vcf
+    ff = 0.2 if method == "nipt" else None
+    dev = DevicePanel(small_panel)
+    (tmp_path / "gpu").mkdir()
+    (tmp_path / "cpu").mkdir()
+    rows_g, rec_g, truth = _bam_to_vcf(tmp_path / "gpu", small_panel, HipBackend(dev), method=method, ff=ff)
+    rows_c, rec_c, _ = _bam_to_vcf(tmp_path / "cpu", small_panel, OracleBackend(small_panel), method=method, ff=ff)
+    dev.close()
+    assert len(rows_g) == len(rows_c)
+    n_diff = 0
+    for a, b in zip(rows_g, rows_c):
+        assert a[:7] == b[:7] and a[8] == b[8]
+        for x, y in zip(a[9:], b[9:]):
+            if x != y:
+                n_diff += 1
+                fx = [float(v) for part in x.split(":")[1:] for v in part.split(",")]
+                fy = [float(v) for part in y.split(":")[1:] for v in part.split(",")]
+                assert np.abs(np.array(fx) - np.array(fy)).max() <= 1.001e-3
+    assert n_diff <= 0.01 * len(rows_g) * 4
+    for i in rec_g["results"]:
+        assert np.array_equal(rec_g["results"][i].read_labels, rec_c["results"][i].read_labels)
