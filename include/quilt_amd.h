@@ -223,6 +223,34 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                             double *dosage, int32_t top_width, int32_t *top_idx, float *top_val,
                             int32_t *top_cnt);
 
+/*
+ * qa_fullpass_reads_batch followed, on the device, by the re-selection of every chain's small panel:
+ * `everything_per_hap_rejig_haps` + `everything_select_good_haps` (QUILT/R/functions.R:2161-2170, 2262-2310; SURVEY.md
+ * 8(f) rank 2(a)).  The best-haplotype lists stay on the device (top_idx / top_val may be NULL: then they are not copied
+ * back at all; top_cnt is always cheap); only the next which_haps_to_use crosses PCIe.
+ *
+ *   Ksubset, Knew         size of the small panel and how many of it are replaced per round (functions.R:2286-2295)
+ *   which_haps_to_use     n_chain x Ksubset, 1-based: the chains' current small panels
+ *   seed_select           n_chain keys of the library's counter stream (splitmix64, see qa_gibbs_batch seed_reads).  The
+ *                         reference draws with R's sample(); here each draw is "the n smallest keys, in key order":
+ *                         previously_selected_haplotypes = the Ksubset - Knew entries of which_haps_to_use with the
+ *                         smallest keys [0, Ksubset); the rank that overshoots Knew keeps the candidates with the
+ *                         smallest keys [2^20, 2^20 + n_candidates) -- restated on the host in quilt_amd/driver.py
+ *   which_next            n_chain x Ksubset, 1-based: previously selected, then the Knew new haplotypes (rows of chains
+ *                         without want_top are left untouched)
+ *   select_status         n_chain: 0 selected; 1 the ranks up to K_top_matches did not yield Knew new haplotypes -- the
+ *                         reference then uses every entry of the complete lists and finally a random draw from the panel
+ *                         (functions.R:2278-2300), which the caller does on the host from untruncated lists (rare);
+ *                         -1 chain without want_top
+ */
+int qa_fullpass_reads_select_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
+                                   const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
+                                   const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
+                                   const int32_t *want_top, const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches,
+                                   double minGLValue, double *dosage, int32_t top_width, int32_t *top_idx, float *top_val,
+                                   int32_t *top_cnt, int32_t Ksubset, int32_t Knew, const int32_t *which_haps_to_use,
+                                   const uint64_t *seed_select, int32_t *which_next, int32_t *select_status);
+
 /* Timing of the most recent full-pass launch set on this thread, measured with HIP
  * events on the launch stream (ms): [0] emission build, [1] forward, [2] backward,
  * [3] dosage mat-vec, [4] total device.  Replaces print_times()

@@ -1389,18 +1389,37 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
 }
 
 
-int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
-                            const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
-                            const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
-                            const int32_t *want_top, const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches,
-                            double minGLValue,
-                            double *dosage, int32_t top_width, int32_t *top_idx, float *top_val, int32_t *top_cnt) {
+// selection arguments of qa_fullpass_reads_select_batch (nullptr: plain qa_fullpass_reads_batch)
+struct SelectArgs {
+    int32_t Ksubset, Knew;
+    const int32_t *which;
+    const uint64_t *seed;
+    int32_t *which_next, *status;
+};
+
+static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
+                               const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
+                               const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
+                               const int32_t *want_top, const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches,
+                               double minGLValue, double *dosage, int32_t top_width, int32_t *top_idx, float *top_val,
+                               int32_t *top_cnt, const SelectArgs *sel) {
     if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
     if (!panel || n_chain <= 0 || n_label < 1 || n_label > 3 || n_sample <= 0 || !chain_sample || !read_off || !read_ptr ||
         !u || !bq || !H || !want_dosage || !gammaSmall_cols_to_get || top_width < K_top_matches || top_width > 64) {
         qa::set_error("qa_fullpass_reads_batch: bad argument");
         return QA_ERR_INVALID;
     }
+    if (sel && (sel->Ksubset < 1 || sel->Ksubset > panel->K || sel->Knew < 0 || sel->Knew > sel->Ksubset || !sel->which ||
+                !sel->seed || !sel->which_next || !sel->status || K_top_matches < 1)) {
+        qa::set_error("qa_fullpass_reads_select_batch: bad selection argument");
+        return QA_ERR_INVALID;
+    }
+    if (sel)
+        for (size_t i = 0; i < (size_t)n_chain * sel->Ksubset; i++)
+            if (sel->which[i] < 1 || sel->which[i] > panel->K) {
+                qa::set_error("qa_fullpass_reads_select_batch: which_haps_to_use out of range");
+                return QA_ERR_INVALID;
+            }
     return qa::guarded([&] {
         QA_HIP(hipSetDevice(panel->device));
         if (!panel->scratch) panel->scratch = new qa_panel::Scratch(&panel->arena);
@@ -1494,6 +1513,14 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
 
         int status = QA_OK;
         std::vector<int32_t> no_thin(G, -1);
+        // call-wide list table for the device-side selection: [chain * n_label + label][thinned grid][top_width]
+        qa::DBuf<int32_t> d_top_all(sel ? std::max<size_t>(n_out * top_width, 1) : 1), d_cnt_all(sel ? std::max<size_t>(n_out, 1) : 1),
+            d_rows(sel ? P : 1);
+        if (sel) {
+            QA_HIP(hipMemsetAsync(d_top_all.p, 0xff, sizeof(int32_t) * std::max<size_t>(n_out * top_width, 1), st));
+            QA_HIP(hipMemsetAsync(d_cnt_all.p, 0, sizeof(int32_t) * std::max<size_t>(n_out, 1), st));
+        }
+        const bool lists_to_host = top_idx || top_val;
         const double T1 = now();
         for (const Group &grp : groups) {
             const Geometry geo = pick_geometry(panel->K, grp.kind);
@@ -1522,8 +1549,10 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                 out.dosage_rows = grp.ids.data() + done;
                 std::vector<int32_t> fidx;
                 std::vector<double> fval;
-                out.flat_idx = &fidx;
-                out.flat_val = &fval;
+                if (lists_to_host) {   // with the selection on the device the lists need not cross PCIe
+                    out.flat_idx = &fidx;
+                    out.flat_val = &fval;
+                }
                 out.top_cap = top_width;      // k_topk keeps the ordered head of each list: all the driver reads
                 out.order_by_value = true;
                 out.truncate_lists = true;
@@ -1536,10 +1565,15 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
                 t_kern += g_timing[5] / 1e3;
                 if (status != QA_OK) break;
                 // compact, already ordered lists: the first top_width entries of every (pass, thinned grid)
+                if (grp.K_top > 0 && sel) {   // this launch set's lists to their rows of the call-wide device table
+                    d_rows.upload(grp.ids.data() + done, n, st);
+                    qa::launch_scatter_lists(S.top_idx.p, S.top_cnt.p, d_rows.p, n, n_thin, top_width, d_top_all.p, d_cnt_all.p, st);
+                    QA_HIP(hipStreamSynchronize(st));   // d_rows is re-used by the next launch set
+                }
                 if (grp.K_top > 0) {
                     for (int i = 0; i < n * n_thin; i++) {
                         const size_t o = (size_t)grp.ids[done + i / n_thin] * n_thin + (i % n_thin);
-                        const int len = std::min<int>(true_cnt[i], top_width);
+                        const int len = lists_to_host ? std::min<int>(true_cnt[i], top_width) : 0;
                         if (top_cnt) top_cnt[o] = true_cnt[i];
                         for (int q = 0; q < len; q++) {
                             if (top_idx) top_idx[o * top_width + q] = fidx[(size_t)i * top_width + q];
@@ -1551,11 +1585,64 @@ int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label,
             }
             if (status != QA_OK) break;
         }
+        if (sel && status == QA_OK) {
+            // everything_select_good_haps for every chain that asked for lists (select.hip), on the lists still on the device
+            qa::DBuf<int32_t> d_which((size_t)n_chain * sel->Ksubset), d_next((size_t)n_chain * sel->Ksubset), d_stat(n_chain),
+                d_want(n_chain);
+            qa::DBuf<uint64_t> d_seed(n_chain);
+            std::vector<int32_t> want(n_chain);
+            for (int c = 0; c < n_chain; c++) want[c] = K_top_matches > 0 && (!want_top || want_top[c] != 0);
+            d_which.upload(sel->which, (size_t)n_chain * sel->Ksubset, st);
+            d_seed.upload(sel->seed, n_chain, st);
+            d_want.upload(want.data(), n_chain, st);
+            qa::SelectParams sp{};
+            sp.n_label = n_label; sp.n_thin = n_thin; sp.top_width = top_width; sp.K_top_matches = K_top_matches; sp.K = panel->K;
+            sp.Ksubset = sel->Ksubset; sp.Knew = sel->Knew; sp.top = d_top_all.p; sp.which = d_which.p; sp.seed = d_seed.p;
+            sp.want = d_want.p; sp.out = d_next.p; sp.status = d_stat.p;
+            hipEvent_t e0, e1;
+            QA_HIP(hipEventCreate(&e0)); QA_HIP(hipEventCreate(&e1));
+            QA_HIP(hipEventRecord(e0, st));
+            qa::launch_select(sp, n_chain, st);
+            QA_HIP(hipEventRecord(e1, st));
+            d_next.download(sel->which_next, (size_t)n_chain * sel->Ksubset, st);
+            d_stat.download(sel->status, n_chain, st);
+            QA_HIP(hipStreamSynchronize(st));
+            float ms = 0;
+            QA_HIP(hipEventElapsedTime(&ms, e0, e1));
+            qa::profile_add(qa::PK_SELECT, ms, (double)n_out * top_width * 4.0 + (double)n_chain * sel->Ksubset * 8.0,
+                            qa::profile_clock_ms(e0), n_chain);
+            QA_HIP(hipEventDestroy(e0)); QA_HIP(hipEventDestroy(e1));
+            // a truncated list only matters to the exhausted branch, which the device leaves to the host (status 1)
+        }
         if (tmg)
             fprintf(stderr, "[qa_fullpass_reads P=%d] index+uploads %.3f s, run_passes %.3f s (device %.3f s), scatter etc %.3f s\n", P,
                     T1 - T0, t_run, t_kern, now() - T1 - t_run);
         return status;
     });
+}
+
+int qa_fullpass_reads_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
+                            const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
+                            const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
+                            const int32_t *want_top, const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches,
+                            double minGLValue,
+                            double *dosage, int32_t top_width, int32_t *top_idx, float *top_val, int32_t *top_cnt) {
+    return fullpass_reads_impl(panel, n_chain, n_label, n_sample, chain_sample, read_off, read_ptr, u, bq, H, want_dosage,
+                               want_top, gammaSmall_cols_to_get, K_top_matches, minGLValue, dosage, top_width, top_idx,
+                               top_val, top_cnt, nullptr);
+}
+
+int qa_fullpass_reads_select_batch(qa_panel_t *panel, int32_t n_chain, int32_t n_label, int32_t n_sample,
+                                   const int32_t *chain_sample, const int32_t *read_off, const int32_t *read_ptr,
+                                   const int32_t *u, const int32_t *bq, const int32_t *H, const int32_t *want_dosage,
+                                   const int32_t *want_top, const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches,
+                                   double minGLValue, double *dosage, int32_t top_width, int32_t *top_idx, float *top_val,
+                                   int32_t *top_cnt, int32_t Ksubset, int32_t Knew, const int32_t *which_haps_to_use,
+                                   const uint64_t *seed_select, int32_t *which_next, int32_t *select_status) {
+    const SelectArgs sel{Ksubset, Knew, which_haps_to_use, seed_select, which_next, select_status};
+    return fullpass_reads_impl(panel, n_chain, n_label, n_sample, chain_sample, read_off, read_ptr, u, bq, H, want_dosage,
+                               want_top, gammaSmall_cols_to_get, K_top_matches, minGLValue, dosage, top_width, top_idx,
+                               top_val, top_cnt, &sel);
 }
 
 }  // extern "C"

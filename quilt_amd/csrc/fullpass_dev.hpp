@@ -167,4 +167,19 @@ namespace qa {
 int fb64_chunks(int K);
 size_t fb64_lds_bytes(int K);
 void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
+
+// select.hip: everything_select_good_haps on the device (one wave per chain)
+struct SelectParams {
+    int n_label, n_thin, top_width, K_top_matches, K, Ksubset, Knew;
+    const int32_t *top;      // [chain][label][thinned grid][top_width]: 0-based haplotypes, best first, -1 padded
+    const int32_t *which;    // [chain][Ksubset]: the chain's current small panel, 1-based
+    const uint64_t *seed;    // [chain]: key of the chain's selection stream
+    const int32_t *want;     // [chain] or nullptr: chains without a selection get status -1
+    int32_t *out;            // [chain][Ksubset]: previously selected (Ksubset - Knew), then the Knew new ones, 1-based
+    int32_t *status;         // [chain]: 0 selected; 1 ranks exhausted before Knew were found (host path); -1 not wanted
+};
+size_t select_lds_bytes(const SelectParams &p);
+void launch_select(const SelectParams &p, int n_chain, hipStream_t st);
+void launch_scatter_lists(const int32_t *src_idx, const int32_t *src_cnt, const int32_t *rows, int n, int n_thin, int top_cap,
+                          int32_t *dst_idx, int32_t *dst_cnt, hipStream_t st);
 }  // namespace qa

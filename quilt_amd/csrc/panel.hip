@@ -181,7 +181,7 @@ int qa_profile_get_busy(int32_t kernel, double *busy_ms) {
     return QA_OK;
 }
 
-int qa_abi_version(void) { return 2; }
+int qa_abi_version(void) { return 3; }
 
 const char *qa_last_error(void) { return qa::g_err; }
 

@@ -138,25 +138,33 @@ def _unique_in_order(a: np.ndarray) -> np.ndarray:
 
 
 def everything_select_good_haps(Knew: int, K_top_matches: int, new_haps: List[List[np.ndarray]],
-                                previously_selected_haplotypes: np.ndarray, K: int,
-                                rng: np.random.Generator) -> np.ndarray:
+                                previously_selected_haplotypes: np.ndarray, K: int, seed_select: int) -> np.ndarray:
     """functions.R:2262-2310.  ``new_haps[label][thinned grid]`` = 1-based haplotypes, best first."""
     width = max((len(y) for x in new_haps for y in x), default=0)
     dense = np.zeros((len(new_haps), max((len(x) for x in new_haps), default=0), max(width, 1)), dtype=np.int64)
     for a, x in enumerate(new_haps):
         for b, y in enumerate(x):
             dense[a, b, : len(y)] = y
-    return everything_select_good_haps_dense(Knew, K_top_matches, dense, previously_selected_haplotypes, K, rng)
+    return everything_select_good_haps_dense(Knew, K_top_matches, dense, previously_selected_haplotypes, K, seed_select)
+
+
+def previously_selected(which_haps_to_use: np.ndarray, n_keep: int, seed_select: int) -> np.ndarray:
+    """functions.R:2286: ``sample(which_haps_to_use, Ksubset - Knew)``, drawn as the device draws it (csrc/select.hip)."""
+    from .rng import SELECT_OFFSET_PREV, keyed_subset
+    return which_haps_to_use[keyed_subset(seed_select, len(which_haps_to_use), n_keep, SELECT_OFFSET_PREV)]
 
 
 def everything_select_good_haps_dense(Knew: int, K_top_matches: int, top: np.ndarray,
                                       previously_selected_haplotypes: np.ndarray, K: int,
-                                      rng: np.random.Generator, truncated: bool = False) -> np.ndarray:
+                                      seed_select: int, truncated: bool = False) -> np.ndarray:
     """functions.R:2262-2310 on a dense table ``top[label, thinned grid, rank]`` of 1-based haplotypes (0 = no
     entry), each list ordered best first (functions.R:2161-2170).  Rank by rank, the distinct candidates (label-
     major, grid order: R's ``unlist(sapply(new_haps, ...))``) are added until ``Knew`` are found; the last rank
-    is subsampled at random.  ``truncated``: some list is longer than the table is wide (ties at its threshold); the ranks
-    up to ``K_top_matches`` are still exact, the exhausted branch is not (see :class:`ListsTruncated`)."""
+    is subsampled at random.  The reference draws with R's ``sample``; here every draw is "the smallest keys of the
+    counter stream ``seed_select``" (quilt_amd/rng.py), the rule the device kernel csrc/select.hip implements, so the host
+    and the device selection are the same function.  ``truncated``: some list is longer than the table is wide (ties at its
+    threshold); the ranks up to ``K_top_matches`` are still exact, the exhausted branch is not (see :class:`ListsTruncated`)."""
+    from .rng import SELECT_OFFSET_POOL, SELECT_OFFSET_RANK, keyed_subset
     i = 1
     to_keep = np.zeros(0, dtype=np.int64)
     prev = np.asarray(previously_selected_haplotypes, dtype=np.int64)
@@ -178,12 +186,12 @@ def everything_select_good_haps_dense(Knew: int, K_top_matches: int, top: np.nda
             i += 1
         else:
             toadd = Knew - len(to_keep)
-            pick = rng.permutation(len(new))[:toadd]
+            pick = keyed_subset(seed_select, len(new), toadd, SELECT_OFFSET_RANK)
             to_keep = np.concatenate([to_keep, new[pick]])
             done = True
     if len(to_keep) < Knew:
         pool = np.setdiff1d(np.arange(1, K + 1), np.concatenate([to_keep, prev]))
-        extra = pool[rng.permutation(len(pool))[: Knew - len(to_keep)]]
+        extra = pool[keyed_subset(seed_select, len(pool), Knew - len(to_keep), SELECT_OFFSET_POOL)]
         to_keep = np.concatenate([to_keep, extra])
     if len(to_keep) != Knew:
         raise RuntimeError("Have returned too many haps")
@@ -501,6 +509,7 @@ class Driver:
         self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0}
         self.n_full_list_refetches = 0   # chains whose selection needed the untruncated best-haplotype lists
         self.n_underflow_retries = 0     # Gibbs calls repeated with a smaller maxDifferenceBetweenReads
+        self.n_device_selections = 0     # chains whose next small panel was chosen by csrc/select.hip
 
     # -- one [Gibbs -> full pass -> select] round over a set of chains (main and / or phasing chains, same i_it)
     def _round(self, chains: List[ChainState], i_it: int):
@@ -560,10 +569,19 @@ class Driver:
         # (with impute_rare_common every chain's final selection feeds its all-SNP Gibbs call)
         want_top = [i_it < P.n_seek_its or P.impute_rare_common or (not ch.phasing and ch.i_chain == P.nGibbsSamples)
                     for ch in chains]
-        dosages, top, top_cnt = self.backend.fullpass_reads_batch(
+        # everything_select_good_haps: one selection stream per chain and round; its draws are keyed (quilt_amd/rng.py), so
+        # the device (csrc/select.hip, behind the full-panel call) and the host make the same choice
+        seed_sel = [int(ch.rng.integers(0, 2 ** 63)) for ch in chains]
+        on_device = bool(getattr(self.backend, "select_on_device", False)) and any(want_top)
+        select = None
+        if on_device:
+            select = dict(Ksubset=P.Ksubset, Knew=P.Knew, which=[ch.which_haps_to_use for ch in chains], seeds=seed_sel)
+        out = self.backend.fullpass_reads_batch(
             sample_list, [uniq[id(ch.sample)] for ch in chains], [ch.read_labels for ch in chains],
             [return_dosage] * len(chains), want_top, self.cols, P.K_top_matches, P.minGLValue, self.top_width,
-            n_label=self.n_label)
+            n_label=self.n_label, **({"select": select} if on_device else {}))
+        dosages, top, top_cnt = out[:3]
+        which_next, sel_status = out[3:5] if on_device else (None, None)
         t4 = time.perf_counter()
         self.timing["fullpass"] += t4 - t3
         for ci, ch in enumerate(chains):
@@ -576,17 +594,23 @@ class Driver:
                 ch.hap = [np.zeros(T) for _ in range(self.n_label)]
             if not want_top[ci]:
                 continue
-            prev_sel = ch.which_haps_to_use[ch.rng.permutation(len(ch.which_haps_to_use))[: P.Ksubset - P.Knew]]
+            if on_device and sel_status[ci] == 0:
+                ch.which_haps_to_use = which_next[ci].astype(np.int32)
+                self.n_device_selections += 1
+                continue
+            prev_sel = previously_selected(ch.which_haps_to_use, P.Ksubset - P.Knew, seed_sel[ci])
             try:
+                if on_device:   # the device ran out of ranked candidates (status 1): the lists did not come back
+                    raise ListsTruncated()
                 sel = everything_select_good_haps_dense(P.Knew, P.K_top_matches, top[ci].astype(np.int64) + 1, prev_sel, K,
-                                                        ch.rng, truncated=bool((top_cnt[ci] > self.top_width).any()))
+                                                        seed_sel[ci], truncated=bool((top_cnt[ci] > self.top_width).any()))
             except ListsTruncated:
                 # the reference's lists hold every haplotype at or above the threshold (reference-single.cpp:129-194); the
                 # batched call returns their first top_width entries.  Ties made a list longer and the selection ran out
                 # of ranked candidates: fetch this chain's full lists and select from them (functions.R:2278-2281)
                 self.n_full_list_refetches += 1
                 new_haps = self._full_lists(ch)
-                sel = everything_select_good_haps(P.Knew, P.K_top_matches, new_haps, prev_sel, K, ch.rng)
+                sel = everything_select_good_haps(P.Knew, P.K_top_matches, new_haps, prev_sel, K, seed_sel[ci])
             ch.which_haps_to_use = np.concatenate([prev_sel, sel]).astype(np.int32)
         self.timing["host"] += time.perf_counter() - t4
         return return_dosage
@@ -797,6 +821,8 @@ class Driver:
 # ---------------------------------------------------------------------------------------------
 
 class HipBackend:
+    select_on_device = True   # everything_select_good_haps behind the full-panel call (csrc/select.hip)
+
     def __init__(self, device_panel, device_rare_common=None):
         self.dev = device_panel
         self.drc = device_rare_common   # quilt_amd.native.DeviceRareCommon, for impute_rare_common
@@ -856,12 +882,16 @@ class HipBackend:
         return list(dosage), best
 
     def fullpass_reads_batch(self, samples, chain_sample, labels, want_dosage, want_top, cols, K_top_matches, minGLValue,
-                             top_width, n_label=2):
+                             top_width, n_label=2, select=None):
         """impute_using_everything for every chain: returns dosage [n_chain, n_label, T], the ordered top matches
-        [n_chain, n_label, n_thin, top_width] (0-based, -1 padded; only for chains with want_top) and the full list lengths."""
+        [n_chain, n_label, n_thin, top_width] (0-based, -1 padded; only for chains with want_top) and the full list lengths.
+        With ``select`` (Ksubset, Knew, which, seeds) the re-selection of the small panels runs on the device behind the
+        passes (qa_fullpass_reads_select_batch): the lists stay there (``top`` is None) and the call also returns
+        which_next [n_chain, Ksubset] and the per-chain selection status."""
         import ctypes as C
         from .native import check, lib, ptr
         lib().qa_fullpass_reads_batch.restype = C.c_int
+        lib().qa_fullpass_reads_select_batch.restype = C.c_int
         P = self.dev.panel
         T = P.nSNPs
         n_chain, n_sample = len(chain_sample), len(samples)
@@ -878,13 +908,22 @@ class HipBackend:
         wd = np.ascontiguousarray(want_dosage, dtype=np.int32)
         wt = np.ascontiguousarray(want_top, dtype=np.int32)
         dosage = np.zeros((n_chain, n_label, T)) if wd.any() else None
+        cnt = np.zeros((n_chain, n_label, n_thin), dtype=np.int32)
+        head = (self.dev.handle, C.c_int32(n_chain), C.c_int32(n_label), C.c_int32(n_sample), ptr(cs), ptr(read_off),
+                ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(wt), ptr(cols), C.c_int32(K_top_matches),
+                C.c_double(minGLValue), ptr(dosage), C.c_int32(top_width))
+        if select is not None:
+            Ks = int(select["Ksubset"])
+            which = np.ascontiguousarray(np.stack([np.asarray(w, dtype=np.int32) for w in select["which"]]))
+            seeds = np.ascontiguousarray(select["seeds"], dtype=np.uint64)
+            nxt = np.zeros((n_chain, Ks), dtype=np.int32)
+            status = np.full(n_chain, -1, dtype=np.int32)
+            check(lib().qa_fullpass_reads_select_batch(*head, None, None, ptr(cnt), C.c_int32(Ks), C.c_int32(int(select["Knew"])),
+                                                       ptr(which), ptr(seeds), ptr(nxt), ptr(status)))
+            return dosage, None, cnt, nxt, status
         top = np.full((n_chain, n_label, n_thin, top_width), -1, dtype=np.int32)
         val = np.zeros((n_chain, n_label, n_thin, top_width), dtype=np.float32)
-        cnt = np.zeros((n_chain, n_label, n_thin), dtype=np.int32)
-        check(lib().qa_fullpass_reads_batch(self.dev.handle, C.c_int32(n_chain), C.c_int32(n_label), C.c_int32(n_sample), ptr(cs),
-                                            ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(wt), ptr(cols),
-                                            C.c_int32(K_top_matches), C.c_double(minGLValue), ptr(dosage),
-                                            C.c_int32(top_width), ptr(top), ptr(val), ptr(cnt)))
+        check(lib().qa_fullpass_reads_batch(*head, ptr(top), ptr(val), ptr(cnt)))
         return dosage, top, cnt
 
     def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):

@@ -18,13 +18,22 @@ def test_select_good_haps_takes_rank_by_rank():
     # two labels, three grids; rank-1 haplotypes first, then rank-2, ...
     new_haps = [[np.array([5, 9, 1, 2, 3]), np.array([7, 5, 4, 6, 8]), np.array([5, 7, 10, 11, 12])],
                 [np.array([20, 21, 22, 23, 24]), np.array([20, 5, 25, 26, 27]), np.array([30, 31, 32, 33, 34])]]
-    out = D.everything_select_good_haps(4, 5, new_haps, np.zeros(0, dtype=np.int64), 100, rng)
+    out = D.everything_select_good_haps(4, 5, new_haps, np.zeros(0, dtype=np.int64), 100, 11)
     assert set(out.tolist()) == {5, 7, 20, 30}           # exactly the distinct rank-1 entries
-    out = D.everything_select_good_haps(6, 5, new_haps, np.array([7]), 100, rng)
+    out = D.everything_select_good_haps(6, 5, new_haps, np.array([7]), 100, 12)
     assert {5, 20, 30} <= set(out.tolist()) and 7 not in out and len(set(out.tolist())) == 6
+    # the subsample of the overshooting rank depends on the seed only (the device draws the same keys)
+    a = D.everything_select_good_haps(5, 5, new_haps, np.zeros(0, dtype=np.int64), 100, 13)
+    b = D.everything_select_good_haps(5, 5, new_haps, np.zeros(0, dtype=np.int64), 100, 13)
+    c = [D.everything_select_good_haps(5, 5, new_haps, np.zeros(0, dtype=np.int64), 100, sd) for sd in range(20, 40)]
+    assert np.array_equal(a, b) and len({tuple(x.tolist()) for x in c}) == 3   # rank 2 offers 9, 21, 31
     # not enough candidates: filled at random from the rest of the panel
-    out = D.everything_select_good_haps(40, 5, new_haps, np.zeros(0, dtype=np.int64), 100, rng)
+    out = D.everything_select_good_haps(40, 5, new_haps, np.zeros(0, dtype=np.int64), 100, 14)
     assert len(set(out.tolist())) == 40 and out.min() >= 1 and out.max() <= 100
+    # previously selected haplotypes: a keyed subset of the current small panel, no repeats
+    w = np.arange(1, 601, dtype=np.int32)[::-1].copy()
+    p1, p2 = D.previously_selected(w, 100, 5), D.previously_selected(w, 100, 6)
+    assert len(set(p1.tolist())) == 100 and set(p1.tolist()) <= set(w.tolist()) and not np.array_equal(p1, p2)
 
 
 def test_recast_haps():
