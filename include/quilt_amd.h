@@ -94,7 +94,9 @@ void qa_panel_destroy(qa_panel_t *panel);
 /* The panel handle straight from the packed panel: per-grid dictionary compression on the device.  Replaces
  * STITCH::make_rhb_t_equality (STITCH 1.8.4; call sites QUILT/R/quilt-prepare-reference.R:416-428, QUILT/R/quilt.R:551-563)
  * followed by qa_panel_create: per grid the distinct 32-bit words of rhb_t are ranked by descending frequency (ties:
- * ascending signed value), the first nMaxDH (<= 255) get the 1-based codes of hapMatcherR / rows of distinctHapsB, every
+ * ascending signed value -- the builder's choice: STITCH is not in the reference tree, so its tie rule is UNPINNED; any
+ * rule gives tables the path accepts and the same imputation, pinned by the round-trip property of
+ * test-unit-reference-single.R:210-309 only), the first nMaxDH (<= 255) get the 1-based codes of hapMatcherR / rows of distinctHapsB, every
  * other haplotype code 0 and an entry in the special tables.
  *   rhb_t   K x nGrids int32, column-major (the R matrix), bit b of word g = allele at SNP 32 g + b
  *   use_eMatDH_special_symbols   as in qa_panel_desc_t: decode special words the way the reference does without rhb_t
@@ -104,6 +106,12 @@ void qa_panel_destroy(qa_panel_t *panel);
 int qa_panel_create_from_rhb(const int32_t *rhb_t, int32_t K, int32_t nGrids, int32_t nSNPs, int32_t nMaxDH,
                              const double *transMatRate_t, double ref_error, int32_t use_eMatDH_special_symbols,
                              qa_panel_t **out);
+/* The packed panel from the integer allele matrix: replaces STITCH::make_rhb_t_from_rhi_t (STITCH 1.8.4, un-vendored; call
+ * site QUILT/R/test-drivers.R:394, the panel builder of the reference's own tests).  rhi_t K x nSNPs int32 column-major, entries 0 / 1 (non-zero counts as
+ * 1); rhb_t out K x ceil(nSNPs / 32) int32 column-major, bit b of word g = allele at SNP 32 g + b, unused high bits of the
+ * last grid 0.  Packed on the device in slabs of whole grids. */
+int qa_make_rhb_t_from_rhi_t(const int32_t *rhi_t, int32_t K, int32_t nSNPs, int32_t *rhb_t);
+
 int qa_panel_export_tables(qa_panel_t *panel, uint8_t *hapMatcherR, int32_t *distinctHapsB, int32_t *special_off,
                            int32_t *special_k, int32_t *special_word, int64_t special_cap);
 

@@ -126,6 +126,17 @@ int qa_vcf_write_body(const char *path, int32_t bgzf, int32_t finish, const char
 /* Append raw text (the VCF header of writers.R:1-36) through the same BGZF framing. */
 int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const char *text, int64_t n);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * driver-side accumulation (QUILT/R/functions.R:999-1020): all chains of a round in one pass
+ *   hap            n_chain x n_label x nSNPs haploid dosages of the round's full-panel passes (as qa_fullpass_reads_batch
+ *                  returns them); chain_sample: the sample of each chain
+ *   dosage, gp_t   n_sample x nSNPs and n_sample x 3 x nSNPs running sums: dosage += h1 + h2,
+ *                  gp_t += rbind((1-h1)(1-h2), (1-h1) h2 + h1 (1-h2), h1 h2), chain by chain in order
+ *   fet_*          NIPT (n_label = 3; both or neither): the same with (h1, h3) (functions.R:1009-1016)
+ * ---------------------------------------------------------------------------------------------------------------------- */
+int qa_accumulate_dosage(int32_t n_chain, int32_t n_label, int32_t nSNPs, const double *hap, const int32_t *chain_sample,
+                         int32_t n_sample, double *dosage, double *gp_t, double *fet_dosage, double *fet_gp_t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -480,7 +480,9 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
         gs.store_c(ch);
         if (rs.base >= 0) rs.store(ch);
         chain_sync<NW>();
+#ifndef QA_DBG_SKIP_BWD   // (developer timing builds: scripts/perf_gibbs.py with QUILT_AMD_LIB)
         backward_both<NE, NW, true>(ch);
+#endif
         // ---- underflow check (:2959-2969)
         {
             double s[2] = {0, 0};
@@ -502,6 +504,9 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
         if (status) break;
         bool to_block = false;
         for (int i = 0; i < p.n_block; i++) if (p.block_its[i] == it) to_block = true;
+#ifdef QA_DBG_SKIP_SHARD
+        to_block = false;
+#endif
         if (to_block && p.do_shard) {
             // ============ Rcpp_shard_block_gibbs_resampler (gibbs-nipt-block.cpp:1975-2355), ff = 0,
             // shard_check_every_pair: one left-to-right pass deciding at every grid whether everything

@@ -518,6 +518,40 @@ int qa_hwe_exact(int32_t T, const double *counts, double *p_out) {
     return QA_OK;
 }
 
+// functions.R:999-1020 for a whole round: every chain's haploid dosages h1, h2 (h3: NIPT) added to its sample's dosage and
+// genotype-posterior sums -- dosage += h1 + h2; gp_t += rbind((1-h1)(1-h2), (1-h1)h2 + h1(1-h2), h1 h2); fetal:
+// the same with (h1, h3) -- chain by chain in order, each expression rounded as R / numpy round it (built without
+// contraction), one pass over the chain's rows instead of a dozen temporaries.
+int qa_accumulate_dosage(int32_t n_chain, int32_t n_label, int32_t T, const double *hap, const int32_t *chain_sample,
+                         int32_t n_sample, double *dosage, double *gp_t, double *fet_dosage, double *fet_gp_t) {
+    if (n_chain < 0 || n_label < 2 || n_label > 3 || T < 0 || !hap || !chain_sample || !dosage || !gp_t) return QA_ERR_INVALID;
+    if ((fet_dosage || fet_gp_t) && (n_label != 3 || !fet_dosage || !fet_gp_t)) return QA_ERR_INVALID;
+    for (int32_t c = 0; c < n_chain; c++) {
+        const int32_t s = chain_sample[c];
+        if (s < 0 || s >= n_sample) return QA_ERR_INVALID;
+        const double *h1 = hap + ((size_t)c * n_label) * T, *h2 = h1 + T, *h3 = h1 + 2 * (size_t)T;
+        double *d = dosage + (size_t)s * T, *g0 = gp_t + (size_t)s * 3 * T, *g1 = g0 + T, *g2 = g1 + T;
+        for (int32_t t = 0; t < T; t++) {
+            const double a = h1[t], b = h2[t], na = 1 - a, nb = 1 - b;
+            d[t] += a + b;
+            g0[t] += na * nb;
+            g1[t] += na * b + a * nb;
+            g2[t] += a * b;
+        }
+        if (fet_dosage) {
+            double *fd = fet_dosage + (size_t)s * T, *f0 = fet_gp_t + (size_t)s * 3 * T, *f1 = f0 + T, *f2 = f1 + T;
+            for (int32_t t = 0; t < T; t++) {
+                const double a = h1[t], b = h3[t], na = 1 - a, nb = 1 - b;
+                fd[t] += a + b;
+                f0[t] += na * nb;
+                f1[t] += na * b + a * nb;
+                f2[t] += a * b;
+            }
+        }
+    }
+    return QA_OK;
+}
+
 int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const char *text, int64_t n) {
     if (!path || (!text && n > 0) || n < 0) return QA_ERR_INVALID;
     BgzfWriter w(path, bgzf != 0, truncate != 0);

@@ -195,9 +195,51 @@ void rank_grid_on_host(const int32_t *col, int K, int nMaxDH, uint8_t *codes, in
     }
 }
 
+// rhi: [T][K] 0 / 1 alleles (the R matrix K x nSNPs, column-major), SNPs t0 .. t0 + 32 n_grid - 1 of it resident at `rhi`;
+// rhb: [G][K].  One thread per (haplotype, grid): bit b of the word = allele at SNP 32 g + b; loads coalesce over k.
+__global__ __launch_bounds__(256) void k_pack_rhi(const int32_t *rhi, int K, int T, int t0, int n_grid, int32_t *rhb, int g0) {
+    const int k = blockIdx.x * 256 + threadIdx.x, gl = blockIdx.y;
+    if (k >= K || gl >= n_grid) return;
+    uint32_t w = 0;
+#pragma unroll 8
+    for (int b = 0; b < 32; b++) {
+        const int t = t0 + 32 * gl + b;
+        if (t < T && rhi[(size_t)(32 * gl + b) * K + k] != 0) w |= 1u << b;
+    }
+    rhb[(size_t)(g0 + gl) * K + k] = (int32_t)w;
+}
+
 }  // namespace
 
 extern "C" {
+
+int qa_make_rhb_t_from_rhi_t(const int32_t *rhi_t, int32_t K, int32_t nSNPs, int32_t *rhb_t) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!rhi_t || !rhb_t || K <= 0 || nSNPs <= 0) {
+        qa::set_error("qa_make_rhb_t_from_rhi_t: bad argument");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        const int G = (nSNPs + 31) / 32;
+        // slabs of whole grids, about 256 MB of alleles each: upload, pack, next
+        const int grids_per_slab = std::max<int>(1, (int)std::min<int64_t>(G, ((int64_t)64 << 20) / ((int64_t)32 * K)));
+        qa::DBuf<int32_t> d_rhi((size_t)grids_per_slab * 32 * K), d_rhb((size_t)G * K);
+        hipStream_t st;
+        QA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int g0 = 0; g0 < G; g0 += grids_per_slab) {
+            const int ng = std::min(grids_per_slab, G - g0);
+            const int t0 = 32 * g0, nt = std::min(32 * ng, nSNPs - t0);
+            qa::staged_upload(d_rhi.p, rhi_t + (size_t)t0 * K, sizeof(int32_t) * (size_t)nt * K, st);
+            hipLaunchKernelGGL(k_pack_rhi, dim3((K + 255) / 256, ng), dim3(256), 0, st, d_rhi.p, K, nSNPs, t0, ng, d_rhb.p, g0);
+            QA_HIP(hipGetLastError());
+            QA_HIP(hipStreamSynchronize(st));
+        }
+        qa::staged_download(rhb_t, d_rhb.p, sizeof(int32_t) * (size_t)G * K, st);
+        QA_HIP(hipStreamSynchronize(st));
+        QA_HIP(hipStreamDestroy(st));
+        return QA_OK;
+    });
+}
 
 int qa_panel_create_from_rhb(const int32_t *rhb_t, int32_t K, int32_t nGrids, int32_t nSNPs, int32_t nMaxDH,
                              const double *transMatRate_t, double ref_error, int32_t use_eMatDH_special_symbols,

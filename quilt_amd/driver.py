@@ -510,6 +510,8 @@ class Driver:
         self.n_full_list_refetches = 0   # chains whose selection needed the untruncated best-haplotype lists
         self.n_underflow_retries = 0     # Gibbs calls repeated with a smaller maxDifferenceBetweenReads
         self.n_device_selections = 0     # chains whose next small panel was chosen by csrc/select.hip
+        self._zero_hap = None
+        self._round_dosages = None
 
     # -- one [Gibbs -> full pass -> select] round over a set of chains (main and / or phasing chains, same i_it)
     def _round(self, chains: List[ChainState], i_it: int):
@@ -584,14 +586,17 @@ class Driver:
         which_next, sel_status = out[3:5] if on_device else (None, None)
         t4 = time.perf_counter()
         self.timing["fullpass"] += t4 - t3
+        if return_dosage and (dosages.min() < -1e-5 or dosages.max() > 1 + 1e-5):   # functions.R:2072-2075
+            raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
+        self._round_dosages = dosages if return_dosage else None   # [chain, label, T]: run_stream accumulates from it
+        if self._zero_hap is None or len(self._zero_hap) != T:
+            self._zero_hap = np.zeros(T)
+            self._zero_hap.flags.writeable = False
         for ci, ch in enumerate(chains):
             if return_dosage:
-                d = dosages[ci]
-                if d.min() < -1e-5 or d.max() > 1 + 1e-5:   # functions.R:2072-2075
-                    raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
-                ch.hap = [d[l] for l in range(self.n_label)]
+                ch.hap = [dosages[ci][l] for l in range(self.n_label)]
             else:
-                ch.hap = [np.zeros(T) for _ in range(self.n_label)]
+                ch.hap = [self._zero_hap] * self.n_label
             if not want_top[ci]:
                 continue
             if on_device and sel_status[ci] == 0:
@@ -777,15 +782,14 @@ class Driver:
             for i_it in range(1, P.n_seek_its + 1):
                 chains = (cur.chains if cur else []) + (prev.phasing if prev else [])
                 stored = self._round(chains, i_it)
-                if stored and cur:   # functions.R:999-1020
+                if stored and cur:   # functions.R:999-1020 (1009-1016: fetus = maternal transmitted + paternal transmitted)
+                    from .io import accumulate_dosage
+                    n_cur = len(cur.chains)           # the round's chains: cur's first, then prev's phasing chains
+                    fetal = P.method == "nipt" and not P.impute_rare_common
+                    accumulate_dosage(np.ascontiguousarray(self._round_dosages[:n_cur], dtype=np.float64),
+                                      [ch.i_sample for ch in cur.chains], cur.dosage, cur.gp_t,
+                                      cur.fet_dosage if fetal else None, cur.fet_gp_t if fetal else None)
                     for ch in cur.chains:
-                        h1, h2 = ch.hap[0], ch.hap[1]
-                        cur.dosage[ch.i_sample] += h1 + h2
-                        cur.gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
-                        if P.method == "nipt" and not P.impute_rare_common:   # functions.R:1009-1016: fetus = maternal transmitted + paternal transmitted
-                            h3 = ch.hap[2]
-                            cur.fet_dosage[ch.i_sample] += h1 + h3
-                            cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
                         cur.nDosage[ch.i_sample] += 1
             if P.impute_rare_common:   # functions.R:1042-1123
                 self._rare_common_round((cur.chains if cur else []) + (prev.phasing if prev else []))

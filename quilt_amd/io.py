@@ -31,7 +31,8 @@ def _io_lib():
     L = lib()
     if not getattr(L, "_io_ready", False):
         for name in ("qa_bam_load_sample_reads", "qa_sample_reads_n_reads", "qa_sample_reads_export", "qa_vcf_column_diploid",
-                     "qa_vcf_column_nipt", "qa_vcf_info_column", "qa_vcf_write_body", "qa_vcf_write_text", "qa_hwe_exact"):
+                     "qa_vcf_column_nipt", "qa_vcf_info_column", "qa_vcf_write_body", "qa_vcf_write_text", "qa_hwe_exact",
+                     "qa_accumulate_dosage"):
             getattr(L, name).restype = C.c_int
         L.qa_sample_reads_n_bases.restype = C.c_int64
         L.qa_vcf_missing_entry.restype = C.c_char_p
@@ -45,6 +46,20 @@ def _io_lib():
 def _check(st: int, what: str):
     if st < 0:
         raise QuiltAmdError(st, what)
+
+
+def accumulate_dosage(hap: np.ndarray, chain_sample: np.ndarray, dosage: np.ndarray, gp_t: np.ndarray,
+                      fet_dosage: Optional[np.ndarray] = None, fet_gp_t: Optional[np.ndarray] = None) -> None:
+    """functions.R:999-1020 for all chains of a round (native, one pass): ``hap`` [n_chain, n_label, T] haploid dosages,
+    ``dosage`` [n_sample, T] and ``gp_t`` [n_sample, 3, T] running sums, updated in place."""
+    n_chain, n_label, T = hap.shape
+    for a in (hap, dosage, gp_t, fet_dosage, fet_gp_t):
+        if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous):
+            raise ValueError("accumulate_dosage takes C-contiguous float64 arrays")
+    cs = np.ascontiguousarray(chain_sample, dtype=np.int32)
+    _check(_io_lib().qa_accumulate_dosage(C.c_int32(n_chain), C.c_int32(n_label), C.c_int32(T), ptr(hap), ptr(cs),
+                                          C.c_int32(dosage.shape[0]), ptr(dosage), ptr(gp_t), ptr(fet_dosage), ptr(fet_gp_t)),
+           "qa_accumulate_dosage")
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libquilt_amd.so")
+LIB_PATH = os.environ.get("QUILT_AMD_LIB") or os.path.join(CSRC, "libquilt_amd.so")   # (developer A/B builds)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "quilt_amd.h")
 
 QA_OK = 0

@@ -78,3 +78,23 @@ def test_special_symbols_mode_matches_host_created_panel(ragged_panel):
         assert np.array_equal(x, y)
     a.close()
     b.close()
+
+
+def test_make_rhb_t_from_rhi_t():
+    """STITCH::make_rhb_t_from_rhi_t on the device (test-drivers.R:393-394): K x nSNPs alleles -> K x ceil(nSNPs / 32) words,
+    bit b of word g = allele at SNP 32 g + b; ragged last grid; non-zero counts as 1."""
+    import ctypes as C
+    from quilt_amd.native import check, lib, ptr
+    rng = np.random.default_rng(8)
+    for K, T in ((1000, 500), (37, 1), (513, 64), (2000, 3333)):
+        rhi = np.asfortranarray(rng.integers(0, 2, size=(K, T)).astype(np.int32))
+        if T > 3:
+            rhi[:, 3] *= 7                     # any non-zero entry is an alternate allele
+        G = (T + 31) // 32
+        out = np.zeros((K, G), dtype=np.int32, order="F")
+        lib().qa_make_rhb_t_from_rhi_t.restype = C.c_int
+        check(lib().qa_make_rhb_t_from_rhi_t(ptr(rhi), C.c_int32(K), C.c_int32(T), ptr(out)))
+        pad = np.zeros((K, 32 * G), dtype=np.uint64)
+        pad[:, :T] = rhi != 0
+        exp = (pad.reshape(K, G, 32) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32).view(np.int32)
+        assert np.array_equal(out, exp)
