@@ -382,6 +382,12 @@ int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *panel, int32_t nSNPs, int32_t n_ch
                                   const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
                                   const int32_t *bq, double maxDifferenceBetweenReads, int32_t Jmax,
                                   int32_t rescale_eMatRead_t, double *eMatRead_t);
+/* The same with eHaps laid out chain x haplotype x SNP (the layout qa_fullpass_reads_batch returns haploid dosages in): the
+ * driver's read-confidence step (QUILT/R/functions.R:2975-3020) then needs no transposed copy. */
+int qa_rcpp_make_eMatRead_t_hap_major(qa_panel_t *panel, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                                  const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
+                                  const int32_t *bq, double maxDifferenceBetweenReads, int32_t Jmax,
+                                  int32_t rescale_eMatRead_t, double *eMatRead_t);
 
 /* ---- rare + common SNPs: the final all-SNP Gibbs of QUILT2 ------------------ */
 

@@ -144,7 +144,9 @@ struct DBuf {
         n = n_;
         if (n) QA_HIP(hipMalloc((void **)&p, n * sizeof(T)));
     }
-    void ensure(size_t n_) { if (n_ > n) alloc(n_); }
+    // grow-only with slack: hipFree / hipMalloc synchronise the whole device (every stream, the other host threads' launches
+    // included), so a buffer whose size wanders from call to call must not be reallocated for every new maximum
+    void ensure(size_t n_) { if (n_ > n) alloc(n_ + n_ / 4 + 64); }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;

@@ -775,6 +775,7 @@ struct qa_panel::Scratch {
     qa::ABuf<double> gl, c, dosage, escale0, unperm, emin;
     qa::ABuf<char> emat, esp, alpha, gamma, beta, beta_thin, top_val, mg, gsp;   // fp32 or fp64 elements (the launch decides)
     qa::ABuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
+    qa::DBuf<int32_t> todo;   // (grid, pass) pairs handed to k_topk: persistent, grow-only
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     explicit Scratch(qa::Arena *a) {
         gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = a;
@@ -853,6 +854,15 @@ int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
     const size_t budget = pn->arena.budget() / pn->share;
     long n = budget > fixed ? (long)((budget - fixed) / per_pass) : 0;
     n = std::max<long>(1, std::min<long>(n, remaining));
+    // One pass is one workgroup and a compute unit holds one such workgroup: a launch runs in rounds of n_cu passes.  When
+    // the passes have to be split anyway, split at whole rounds (292 passes cost two rounds, 256 + 36, like 512 would).
+    static const int n_cu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return std::max(prop.multiProcessorCount, 1);
+    }();
+    if (n < remaining && n > n_cu) n = n / n_cu * n_cu;
     pn->arena.require(fixed + (size_t)n * per_pass);
     pn->arena.reset();
     return (int)n;
@@ -1058,9 +1068,9 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
             if (cnt[i] < 0) { todo.push_back((int32_t)(i / n_thin)); todo.push_back((int32_t)(i % n_thin)); }
         n_handed_over = (int)todo.size() / 2;
         if (n_handed_over) {
-            qa::DBuf<int32_t> d_todo(todo.size());
-            d_todo.upload(todo.data(), todo.size(), st);
-            prm.topk_todo = d_todo.p;
+            S.todo.ensure(todo.size());
+            S.todo.upload(todo.data(), todo.size(), st);
+            prm.topk_todo = S.todo.p;
             hipLaunchKernelGGL(k_topk<double>, dim3(n_handed_over), dim3(256), 0, st, prm, geo.NT);
             QA_HIP(hipGetLastError());
             S.top_cnt.download(cnt.data(), cnt.size(), st);
@@ -1499,9 +1509,29 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
             const double e = std::pow(10, -(double)q / 10);
             tabs[q] = 1 - e; tabs[256 + q] = e / 3; tabs[512 + q] = e / 3; tabs[768 + q] = 1 - e;
         }
-        qa::DBuf<int32_t> d_ps(P), d_pl(P), d_ph(P), d_sp(snp_ptr.size()), d_eo(n_sample), d_er(ent_read.size()),
-            d_eb(ent_bq.size()), d_H(std::max(hoff[n_chain], 1));
-        qa::DBuf<double> d_tabs(tabs.size());
+        // per-call device buffers, carved from the handle's grow-only side arena (no hipMalloc / hipFree per call)
+        const size_t n_out_all = (size_t)P * n_thin;
+        {
+            auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+            size_t need = 0;
+            for (size_t b : {(size_t)P * 4, (size_t)P * 4, (size_t)P * 4, snp_ptr.size() * 4, (size_t)n_sample * 4, ent_read.size() * 4,
+                             ent_bq.size() * 4, (size_t)std::max(hoff[n_chain], 1) * 4, tabs.size() * 8})
+                need += pad(b);
+            if (sel)
+                for (size_t b : {std::max<size_t>(n_out_all * top_width, 1) * 4, std::max<size_t>(n_out_all, 1) * 4, (size_t)P * 4,
+                                 (size_t)n_chain * sel->Ksubset * 4, (size_t)n_chain * sel->Ksubset * 4, (size_t)n_chain * 4,
+                                 (size_t)n_chain * 4, (size_t)n_chain * 8})
+                    need += pad(b);
+            if (need > panel->aux.cap) panel->aux.require(need + need / 4);
+            panel->aux.reset();
+        }
+        auto carve_i32 = [&](size_t n) { qa::ABuf<int32_t> b; b.arena = &panel->aux; b.ensure(std::max<size_t>(n, 1)); return b; };
+        qa::ABuf<int32_t> d_ps = carve_i32(P), d_pl = carve_i32(P), d_ph = carve_i32(P), d_sp = carve_i32(snp_ptr.size()),
+                          d_eo = carve_i32(n_sample), d_er = carve_i32(ent_read.size()), d_eb = carve_i32(ent_bq.size()),
+                          d_H = carve_i32(std::max(hoff[n_chain], 1));
+        qa::ABuf<double> d_tabs;
+        d_tabs.arena = &panel->aux;
+        d_tabs.ensure(tabs.size());
         d_sp.upload(snp_ptr.data(), snp_ptr.size(), st); d_eo.upload(ent_off.data(), n_sample, st);
         d_er.upload(ent_read.data(), ent_read.size(), st); d_eb.upload(ent_bq.data(), ent_bq.size(), st);
         d_H.upload(H, hoff[n_chain], st); d_tabs.upload(tabs.data(), tabs.size(), st);
@@ -1514,12 +1544,15 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
         int status = QA_OK;
         std::vector<int32_t> no_thin(G, -1);
         // call-wide list table for the device-side selection: [chain * n_label + label][thinned grid][top_width]
-        qa::DBuf<int32_t> d_top_all(sel ? std::max<size_t>(n_out * top_width, 1) : 1), d_cnt_all(sel ? std::max<size_t>(n_out, 1) : 1),
-            d_rows(sel ? P : 1);
+        qa::ABuf<int32_t> d_top_all, d_cnt_all, d_rows;
         if (sel) {
-            QA_HIP(hipMemsetAsync(d_top_all.p, 0xff, sizeof(int32_t) * std::max<size_t>(n_out * top_width, 1), st));
-            QA_HIP(hipMemsetAsync(d_cnt_all.p, 0, sizeof(int32_t) * std::max<size_t>(n_out, 1), st));
+            d_top_all = carve_i32(n_out * top_width);
+            d_cnt_all = carve_i32(n_out);
+            d_rows = carve_i32(P);
         }
+        // (no memset: the scatter kernel writes every entry of every row of a chain that wants lists, -1 past the list's
+        // end, and the selection reads no other rows; the runtime's fill is a blit with 512-thread workgroups, which waits
+        // for a compute unit free of the other host thread's Gibbs waves -- half a second per occurrence in the r02 trace)
         const bool lists_to_host = top_idx || top_val;
         const double T1 = now();
         for (const Group &grp : groups) {
@@ -1587,9 +1620,11 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
         }
         if (sel && status == QA_OK) {
             // everything_select_good_haps for every chain that asked for lists (select.hip), on the lists still on the device
-            qa::DBuf<int32_t> d_which((size_t)n_chain * sel->Ksubset), d_next((size_t)n_chain * sel->Ksubset), d_stat(n_chain),
-                d_want(n_chain);
-            qa::DBuf<uint64_t> d_seed(n_chain);
+            qa::ABuf<int32_t> d_which = carve_i32((size_t)n_chain * sel->Ksubset), d_next = carve_i32((size_t)n_chain * sel->Ksubset),
+                              d_stat = carve_i32(n_chain), d_want = carve_i32(n_chain);
+            qa::ABuf<uint64_t> d_seed;
+            d_seed.arena = &panel->aux;
+            d_seed.ensure(n_chain);
             std::vector<int32_t> want(n_chain);
             for (int c = 0; c < n_chain; c++) want[c] = K_top_matches > 0 && (!want_top || want_top[c] != 0);
             d_which.upload(sel->which, (size_t)n_chain * sel->Ksubset, st);

@@ -788,9 +788,9 @@ __global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
 // One thread per (read, chain): K is 2 or 3, the products run over the read's bases in order.
 // ---------------------------------------------------------------------------------------------
 struct DenseParams {
-    int C, K, T, Jmax, rescale;
+    int C, K, T, Jmax, rescale, hap_major;
     double inv_maxdiff;
-    const double *eHaps;      // [C][T][K]
+    const double *eHaps;      // [C][T][K], or [C][K][T] with hap_major
     const int32_t *read_off, *read_ptr, *base_off, *u, *bq;
     const double *pR_tab, *pA_tab;
     double *out;              // [sum R][K]
@@ -813,8 +813,13 @@ __global__ __launch_bounds__(64) void k_ematread_dense(DenseParams p) {
         if (b == 0) continue;
         const int ab = b < 0 ? -b : b;
         const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
-        const double *e = eh + (size_t)u[s + j] * p.K;
-        for (int k = 0; k < p.K; k++) v[k] *= (e[k] * pA + (1 - e[k]) * pR);
+        if (p.hap_major) {
+            const double *e = eh + u[s + j];
+            for (int k = 0; k < p.K; k++) { const double ek = e[(size_t)k * p.T]; v[k] *= (ek * pA + (1 - ek) * pR); }
+        } else {
+            const double *e = eh + (size_t)u[s + j] * p.K;
+            for (int k = 0; k < p.K; k++) v[k] *= (e[k] * pA + (1 - e[k]) * pR);
+        }
     }
     if (p.rescale) {
         double x = 0;
@@ -1516,10 +1521,10 @@ int qa_nipt_block_table(const double *rate2, const int32_t *L_grid, int32_t nGri
     });
 }
 
-int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
-                                  const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
-                                  double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
-                                  double *eMatRead_t) {
+static int make_eMatRead_t_impl(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                                const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                                double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                                double *eMatRead_t, int hap_major) {
     if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
     if (!pn || nSNPs <= 0 || n_chain <= 0 || K < 1 || K > 3 || !eHaps || !read_off || !read_ptr || !u || !bq || !eMatRead_t) {
         qa::set_error("qa_rcpp_make_eMatRead_t: bad argument");
@@ -1541,13 +1546,27 @@ int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain
         std::vector<int32_t> bq_eff(bq, bq + totB);
         fold_zero_base_qualities(bq_eff, C, read_off, read_ptr, base_off, Jmax);
         const std::vector<double> tabs = base_quality_tables();
-        qa::DBuf<double> d_e((size_t)C * T * K), d_tabs(tabs.size()), d_out(std::max<size_t>((size_t)totR * K, 1));
-        qa::DBuf<int32_t> d_ro(C + 1), d_rp(totR + C), d_bo(C + 1), d_u(std::max(totB, 1)), d_bq(std::max(totB, 1));
+        // carved from the handle's arena (no launch set of this handle is in flight during this call): a call-local
+        // hipMalloc / hipFree pair would synchronise the device with the other host threads' launches
+        qa::ABuf<double> d_e, d_tabs, d_out;
+        qa::ABuf<int32_t> d_ro, d_rp, d_bo, d_u, d_bq;
+        {
+            auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+            const size_t n_e = (size_t)C * T * K, n_out = std::max<size_t>((size_t)totR * K, 1), n_b = std::max(totB, 1);
+            const size_t need = pad(n_e * 8) + pad(tabs.size() * 8) + pad(n_out * 8) + 2 * pad((size_t)(C + 1) * 4) +
+                                pad((size_t)(totR + C) * 4) + 2 * pad(n_b * 4) + 4096;
+            pn->arena.require(need);
+            pn->arena.reset();
+            for (auto *b : {&d_e, &d_tabs, &d_out}) b->arena = &pn->arena;
+            for (auto *b : {&d_ro, &d_rp, &d_bo, &d_u, &d_bq}) b->arena = &pn->arena;
+            d_e.ensure(n_e); d_tabs.ensure(tabs.size()); d_out.ensure(n_out);
+            d_ro.ensure(C + 1); d_rp.ensure(totR + C); d_bo.ensure(C + 1); d_u.ensure(n_b); d_bq.ensure(n_b);
+        }
         d_e.upload(eHaps, (size_t)C * T * K, st); d_tabs.upload(tabs.data(), tabs.size(), st);
         d_ro.upload(read_off, C + 1, st); d_rp.upload(read_ptr, totR + C, st); d_bo.upload(base_off.data(), C + 1, st);
         d_u.upload(u, totB, st); d_bq.upload(bq_eff.data(), totB, st);
         DenseParams prm{};
-        prm.C = C; prm.K = K; prm.T = T; prm.Jmax = Jmax; prm.rescale = rescale_eMatRead_t;
+        prm.C = C; prm.K = K; prm.T = T; prm.Jmax = Jmax; prm.rescale = rescale_eMatRead_t; prm.hap_major = hap_major;
         prm.inv_maxdiff = 1 / maxDifferenceBetweenReads; prm.eHaps = d_e.p; prm.read_off = d_ro.p;
         prm.read_ptr = d_rp.p; prm.base_off = d_bo.p; prm.u = d_u.p; prm.bq = d_bq.p;
         prm.pR_tab = d_tabs.p; prm.pA_tab = d_tabs.p + 512; prm.out = d_out.p;
@@ -1557,6 +1576,22 @@ int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain
         QA_HIP(hipStreamSynchronize(st));
         return QA_OK;
     });
+}
+
+int qa_rcpp_make_eMatRead_t_nsnps(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                                  const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                                  double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                                  double *eMatRead_t) {
+    return make_eMatRead_t_impl(pn, nSNPs, n_chain, K, eHaps, read_off, read_ptr, u, bq, maxDifferenceBetweenReads, Jmax,
+                                rescale_eMatRead_t, eMatRead_t, 0);
+}
+
+int qa_rcpp_make_eMatRead_t_hap_major(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                                      const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                                      double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                                      double *eMatRead_t) {
+    return make_eMatRead_t_impl(pn, nSNPs, n_chain, K, eHaps, read_off, read_ptr, u, bq, maxDifferenceBetweenReads, Jmax,
+                                rescale_eMatRead_t, eMatRead_t, 1);
 }
 
 int qa_rcpp_make_eMatRead_t(qa_panel_t *pn, int32_t n_chain, int32_t K, const double *eHaps, const int32_t *read_off,

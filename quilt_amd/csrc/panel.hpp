@@ -40,6 +40,8 @@ struct qa_panel {
     hipStream_t stream = nullptr;
     hipStream_t gibbs_stream = nullptr;   // CU-masked stream of the Gibbs launches (qa_panel_set_cu_partition), else null
     qa::Arena arena;            // scratch of every launch set on this panel (see common.hpp)
+    qa::Arena aux;              // per-call index / list buffers of the driver-level entry points (grow-only: a call-local
+                                // hipMalloc / hipFree pair would synchronise the device with the other host threads' launches)
     // scratch owned by the panel handle, grown on demand (see fullpass.hip)
     struct Scratch;
     Scratch *scratch = nullptr;

@@ -506,12 +506,14 @@ class Driver:
         self.cols = thinned_grid_columns(panel.nGrids, self.params.heuristic_match_thin)
         self.n_thin = int((self.cols >= 0).sum())
         self.top_width = max(8, self.params.K_top_matches)   # entries kept per (label, thinned grid) list
-        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0}
+        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0, "accumulate": 0.0,
+                       "new_batch": 0.0}
         self.n_full_list_refetches = 0   # chains whose selection needed the untruncated best-haplotype lists
         self.n_underflow_retries = 0     # Gibbs calls repeated with a smaller maxDifferenceBetweenReads
         self.n_device_selections = 0     # chains whose next small panel was chosen by csrc/select.hip
         self._zero_hap = None
         self._round_dosages = None
+        self._round_dosage_chains = []
 
     # -- one [Gibbs -> full pass -> select] round over a set of chains (main and / or phasing chains, same i_it)
     def _round(self, chains: List[ChainState], i_it: int):
@@ -589,6 +591,7 @@ class Driver:
         if return_dosage and (dosages.min() < -1e-5 or dosages.max() > 1 + 1e-5):   # functions.R:2072-2075
             raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
         self._round_dosages = dosages if return_dosage else None   # [chain, label, T]: run_stream accumulates from it
+        self._round_dosage_chains = list(chains) if return_dosage else []
         if self._zero_hap is None or len(self._zero_hap) != T:
             self._zero_hap = np.zeros(T)
             self._zero_hap.flags.writeable = False
@@ -723,8 +726,14 @@ class Driver:
     def _start_phasing(self, b: _Batch):
         """Read confidence per chain and consensus labels (functions.R:1144-1205); one phasing chain per sample."""
         P = self.params
-        conf = self.backend.read_confidence_batch([ch.sample for ch in b.chains], [ch.hap for ch in b.chains],
-                                                  P.maxDifferenceBetweenReads)
+        # the chains' haploid dosages: rows of the last round's [chain, label, SNP] array (b's chains come first in a round)
+        rd, rc = self._round_dosages, self._round_dosage_chains
+        n = len(b.chains)
+        if isinstance(rd, np.ndarray) and len(rc) >= n and all(x is y for x, y in zip(b.chains, rc)):
+            haps = rd[:n]
+        else:
+            haps = [ch.hap for ch in b.chains]
+        conf = self.backend.read_confidence_batch([ch.sample for ch in b.chains], haps, P.maxDifferenceBetweenReads)
         b.phasing = []
         for i, smp in enumerate(b.samples):
             mine = [k for k, ch in enumerate(b.chains) if ch.i_sample == i]
@@ -775,8 +784,11 @@ class Driver:
         prev: Optional[_Batch] = None
         it = iter(batches)
         while True:
+            import time
             nxt = next(it, None)
+            t_nb = time.perf_counter()
             cur = self._new_batch(*nxt) if nxt is not None else None
+            self.timing["new_batch"] += time.perf_counter() - t_nb
             if cur is None and prev is None:
                 return
             for i_it in range(1, P.n_seek_its + 1):
@@ -784,6 +796,7 @@ class Driver:
                 stored = self._round(chains, i_it)
                 if stored and cur:   # functions.R:999-1020 (1009-1016: fetus = maternal transmitted + paternal transmitted)
                     from .io import accumulate_dosage
+                    t_acc = time.perf_counter()
                     n_cur = len(cur.chains)           # the round's chains: cur's first, then prev's phasing chains
                     fetal = P.method == "nipt" and not P.impute_rare_common
                     accumulate_dosage(np.ascontiguousarray(self._round_dosages[:n_cur], dtype=np.float64),
@@ -791,6 +804,7 @@ class Driver:
                                       cur.fet_dosage if fetal else None, cur.fet_gp_t if fetal else None)
                     for ch in cur.chains:
                         cur.nDosage[ch.i_sample] += 1
+                    self.timing["accumulate"] += time.perf_counter() - t_acc
             if P.impute_rare_common:   # functions.R:1042-1123
                 self._rare_common_round((cur.chains if cur else []) + (prev.phasing if prev else []))
                 for ch in (cur.chains if cur else []):
@@ -802,7 +816,6 @@ class Driver:
                         cur.fet_dosage[ch.i_sample] += h1 + h3
                         cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
                     cur.nDosage_all[ch.i_sample] += 1
-            import time
             t0 = time.perf_counter()
             done = self._finish(prev) if prev else None
             t1 = time.perf_counter()
@@ -931,5 +944,7 @@ class HipBackend:
         return dosage, top, cnt
 
     def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):
+        """``haps``: per chain the list of its haploid dosages, or one [chain, label, SNP] array."""
         from .gibbs_nipt import calculate_eMatRead_t_vs_haplotypes_batch
-        return calculate_eMatRead_t_vs_haplotypes_batch(self.dev, samples, haps, maxDifferenceBetweenReads)
+        return calculate_eMatRead_t_vs_haplotypes_batch(self.dev, samples, haps, maxDifferenceBetweenReads,
+                                                        hap_major=isinstance(haps, np.ndarray))

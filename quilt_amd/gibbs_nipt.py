@@ -176,20 +176,28 @@ def rcpp_forwardBackwardGibbsNIPT(panel: DevicePanel, sampleReads, which_haps_to
 
 def calculate_eMatRead_t_vs_haplotypes_batch(panel: DevicePanel, samples: Sequence, haps: Sequence,
                                              maxDifferenceBetweenReads: float, rescale_eMatRead_t: bool = False,
-                                             Jmax: int = 1000, nSNPs: Optional[int] = None):
+                                             Jmax: int = 1000, nSNPs: Optional[int] = None, hap_major: bool = False):
     """``calculate_eMatRead_t_vs_haplotypes`` (QUILT/R/functions.R:2975-3020) for a batch: ``haps[c]`` is the
     list of K dense haplotype dosages of chain ``c``.  Returns one K x nReads matrix per chain.  ``nSNPs``: the
     length of the dosages when it is not the panel's (all-SNP reads, QUILT/R/rare_common.R:61-107)."""
     lib().qa_rcpp_make_eMatRead_t_nsnps.restype = C.c_int
+    lib().qa_rcpp_make_eMatRead_t_hap_major.restype = C.c_int
     Cn = len(samples)
     T = panel.panel.nSNPs if nSNPs is None else int(nSNPs)
-    if isinstance(haps, np.ndarray):   # already [chain, SNP, haplotype]
+    fn = lib().qa_rcpp_make_eMatRead_t_nsnps
+    if isinstance(haps, np.ndarray) and hap_major:   # [chain, haplotype, SNP], as the full-panel call returns dosages: no copy
+        e = np.ascontiguousarray(haps, dtype=np.float64)
+        K = e.shape[1]
+        assert e.shape == (Cn, K, T)
+        fn = lib().qa_rcpp_make_eMatRead_t_hap_major
+    elif isinstance(haps, np.ndarray):   # already [chain, SNP, haplotype]
         e = np.ascontiguousarray(haps, dtype=np.float64)
         K = e.shape[2]
+        assert e.shape == (Cn, T, K)
     else:
         K = len(haps[0])
         e = np.ascontiguousarray(np.stack([np.stack([np.asarray(h, dtype=np.float64) for h in hs], axis=1) for hs in haps]))
-    assert e.shape == (Cn, T, K)
+        assert e.shape == (Cn, T, K)
     read_off = np.zeros(Cn + 1, dtype=np.int32)
     for c, s in enumerate(samples):
         read_off[c + 1] = read_off[c] + s.nReads
@@ -197,7 +205,7 @@ def calculate_eMatRead_t_vs_haplotypes_batch(panel: DevicePanel, samples: Sequen
     u = np.concatenate([np.asarray(s.u, dtype=np.int32) for s in samples])
     bq = np.concatenate([np.asarray(s.bq, dtype=np.int32) for s in samples])
     out = np.zeros((int(read_off[-1]), K))
-    check(lib().qa_rcpp_make_eMatRead_t_nsnps(panel.handle, C.c_int32(T), C.c_int32(Cn), C.c_int32(K), ptr(e), ptr(read_off),
-                                              ptr(read_ptr), ptr(u), ptr(bq), C.c_double(maxDifferenceBetweenReads),
-                                              C.c_int32(Jmax), C.c_int32(int(rescale_eMatRead_t)), ptr(out)))
+    check(fn(panel.handle, C.c_int32(T), C.c_int32(Cn), C.c_int32(K), ptr(e), ptr(read_off),
+             ptr(read_ptr), ptr(u), ptr(bq), C.c_double(maxDifferenceBetweenReads), C.c_int32(Jmax),
+             C.c_int32(int(rescale_eMatRead_t)), ptr(out)))
     return [np.asfortranarray(out[read_off[c]:read_off[c + 1]].T) for c in range(Cn)]

@@ -91,7 +91,8 @@ class StubWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None):
         self.panel = panel
         self.devs = []
-        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0}
+        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0, "accumulate": 0.0,
+                       "new_batch": 0.0}
 
     def reset_timing(self):
         self.timing = {k: 0.0 for k in self.timing}
