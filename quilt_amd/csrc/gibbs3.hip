@@ -101,21 +101,33 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
     };
     // Rcpp_run_backward_haploid (copied-from-stitch.cpp:392-409) or its QUILT_faster form (:417-440); beta(G-1) = c(G-1)
     auto backward_full = [&](bool faster) {
+        // per-grid scalars from lane-held streams, the next grid's eMatGrid columns fetched while this one computes
+        // (as backward_both of the two-label kernel, gibbs.hip)
         Col<NE> b[NH], e[NH];
+        GridStreams3<CH> gs;
+        gs.load_bwd(ch, (G - 1) & ~63);
 #pragma unroll
         for (int h = 0; h < NH; h++) {
-            const double cl = uni_d(&ch.cv[h][G - 1]);
+            const double cl = gs.c_of(h, (G - 1) & 63);
 #pragma unroll
             for (int i = 0; i < NE; i++) b[h].v[i] = valid[i] ? cl : 0.0;
             ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
         }
+        if (G >= 2) {
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h] + (size_t)(G - 1) * Ksp);
+        }
         for (int g = G - 2; g >= 0; --g) {
-            const double s0 = ch.tm0(g), s1 = ch.tm1(g);
-            const bool has = !faster || uni_i(ch.ghr[g + 1]) != 0;
+            if ((g & 63) == 63) gs.load_bwd(ch, g & ~63);
+            const int j = g & 63;
+            Col<NE> en[NH];   // the next iteration's emission columns (grid g)
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + (size_t)g * Ksp);
+            const double s0 = rl_f64(gs.t0, j), s1 = rl_f64(gs.t1, j);
+            const bool has = !faster || rl_i32(gs.has, j) != 0;
             double x[NH];
 #pragma unroll
             for (int h = 0; h < NH; h++) {
-                ch.ld(e[h], ch.eg[h] + (size_t)(g + 1) * Ksp);
                 x[h] = 0;
 #pragma unroll
                 for (int i = 0; i < NE; i++) {
@@ -127,12 +139,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
             ch.template bsum<NH>(x);
 #pragma unroll
             for (int h = 0; h < NH; h++) {
-                const double cg = uni_d(&ch.cv[h][g]);
+                const double cg = gs.c_of(h, j);
                 const double xx = faster ? s1 * x[h] * one_over_K : s1 * x[h];
 #pragma unroll
                 for (int i = 0; i < NE; i++) b[h].v[i] = valid[i] ? cg * (xx + s0 * b[h].v[i]) : 0.0;
                 ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
             }
+#pragma unroll
+            for (int h = 0; h < NH; h++) e[h] = en[h];
         }
         chain_sync<NW>();
     };
@@ -215,18 +229,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
         // (clamped index): its latency hides behind the current read's arithmetic
         typename CH::ErPre pre{};
         if (R > 0) ch.ld_pre(pre, 0);
-        for (int g = 0; g < G; g++) {
-            Col<NE> e[NH], bt[NH];
-            double cg[NH];
+        // per-grid scalars (transition, c, grid_has_read) as lane-held streams and the next grid's eMatGrid / beta columns
+        // fetched a grid ahead, as in the two-label kernel: a uniform scalar loaded through the vector path would have to
+        // be waited for before use, which (in-order vmcnt) would also drain the column prefetches
+        GridStreams3<CH> gs;
+        Col<NE> e[NH], bt[NH];
 #pragma unroll
-            for (int h = 0; h < NH; h++) {
-                ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
-                ch.ld(bt[h], ch.beta[h] + (size_t)g * Ksp);
+        for (int h = 0; h < NH; h++) {
+            ch.ld(e[h], ch.eg[h]);
+            ch.ld(bt[h], ch.beta[h]);
+        }
+        for (int g = 0; g < G; g++) {
+            if ((g & 63) == 0) {
+                if (g) gs.store_c(ch);
+                gs.load_fwd(ch, g);
             }
+            const int jg = g & 63;
+            double cg[NH];
+            Col<NE> en[NH];
+            const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: the loads stay unconditional
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
             if (g > 0) {
                 // rcpp_alpha_forward_one_QUILT_faster (:671-707), normalize = true
-                const double x = ch.tm0(g - 1), t1 = ch.tm1(g - 1);
-                const bool has = uni_i(ch.ghr[g]) != 0;
+                const double x = rl_f64(gs.t0, jg), t1 = rl_f64(gs.t1, jg);
+                const bool has = rl_i32(gs.has, jg) != 0;
                 double sp[NH];
                 sum3(a, sp);
 #pragma unroll
@@ -242,7 +269,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 sum3(a, sn);
 #pragma unroll
                 for (int h = 0; h < NH; h++) {
-                    const double c2 = uni_d(&ch.cv[h][g]);
+                    const double c2 = gs.c_of(h, jg);
                     double aa = 1 / (c2 * sn[h]);
                     cg[h] = c2 * aa;
                     aa *= c2;
@@ -264,9 +291,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                     for (int i = 0; i < NE; i++) a[h].v[i] *= cg[h];
                 }
             }
+            // alpha * beta of the grid (the reference's ab_m), formed once the forward step is done; beta's registers then
+            // take the next grid's columns
+            Col<NE> ab[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+#pragma unroll
+                for (int i = 0; i < NE; i++) ab[h].v[i] = a[h].v[i] * bt[h].v[i];
+            }
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + gn);
             // ---- sample_reads_in_grid (:733-1295), three labels
             bool grid_started = false, changed = false;
-            Col<NE> ab[NH];
             double pC[3] = {1, 1, 1};
             bool normal = false, ginit = false, pass = false;
             while (iRead < R) {
@@ -285,10 +321,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 else if (r < first_read && it == 1) { pass = false; ginit = true; }
                 else { ginit = false; normal = true; }
                 if (!grid_started) {
-#pragma unroll
-                    for (int h = 0; h < NH; h++)
-#pragma unroll
-                        for (int i = 0; i < NE; i++) ab[h].v[i] = a[h].v[i] * bt[h].v[i];
                     sum3(ab, pC);
                     grid_started = true;
                 }
@@ -414,9 +446,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
 #pragma unroll
             for (int h = 0; h < NH; h++) {
                 ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
-                if (t == 0) ch.cv[h][g] = cg[h];
+                e[h] = en[h];
             }
+            gs.set_c(ch.lane, jg, cg[0], cg[1], cg[2]);
         }
+        gs.store_c(ch);
         if (rs_dirty) rs.store(ch);
         chain_sync<NW>();
         backward_full(true);

@@ -555,6 +555,43 @@ struct GridStreams {   // lane j <-> grid base + j
     }
 };
 
+// the same for the three-label (NIPT) kernels
+template <class CH>
+struct GridStreams3 {
+    double t0, t1, c0, c1, c2;
+    int has, base;
+    __device__ void load_fwd(const CH &ch, int b) {
+        base = b;
+        const int g = b + ch.lane;
+        const bool ok = g < ch.G;
+        t0 = (ok && g > 0) ? ch.tm0(g - 1) : 1.0;
+        t1 = (ok && g > 0) ? ch.tm1(g - 1) : 0.0;
+        c0 = ok ? ch.cv[0][g] : 1.0;
+        c1 = ok ? ch.cv[1][g] : 1.0;
+        c2 = ok ? ch.cv[2][g] : 1.0;
+        has = ok ? ch.ghr[g] : 0;
+    }
+    __device__ void load_bwd(const CH &ch, int b) {
+        base = b;
+        const int g = b + ch.lane;
+        const bool ok = g < ch.G - 1;
+        t0 = ok ? ch.tm0(g) : 1.0;
+        t1 = ok ? ch.tm1(g) : 0.0;
+        c0 = (g < ch.G) ? ch.cv[0][g] : 1.0;
+        c1 = (g < ch.G) ? ch.cv[1][g] : 1.0;
+        c2 = (g < ch.G) ? ch.cv[2][g] : 1.0;
+        has = ok ? ch.ghr[g + 1] : 0;
+    }
+    __device__ void store_c(const CH &ch) const {
+        const int g = base + ch.lane;
+        if (ch.wave == 0 && g < ch.G) { ch.cv[0][g] = c0; ch.cv[1][g] = c1; ch.cv[2][g] = c2; }
+    }
+    __device__ __forceinline__ void set_c(int lane, int j, double a, double b, double c) {
+        if (lane == j) { c0 = a; c1 = b; c2 = c; }
+    }
+    __device__ __forceinline__ double c_of(int h, int j) const { return rl_f64(h == 0 ? c0 : (h == 1 ? c1 : c2), j); }
+};
+
 template <class CH>
 struct ReadStreams {   // lane j <-> read base + j
     int wif, cat1, H, Hc, base, dn;

@@ -75,7 +75,7 @@ def test_driver_uses_the_device_selection(medium_panel):
     from tests.oracle_backend import OracleBackend
     panel = medium_panel
     samples = [make_synthetic_sample(panel, seed=40 + i, n_reads=600) for i in range(2)]
-    prm = DriverParams(nGibbsSamples=2, n_seek_its=3, Ksubset=200, Knew=120, seed=5)
+    prm = DriverParams(nGibbsSamples=2, n_seek_its=3, Ksubset=200, Knew=40, seed=5)   # 2 labels x 10 thinned grids x 5 ranks >= Knew
     dev = DevicePanel(panel)
     d_on = Driver(panel, HipBackend(dev), prm)
     got = d_on.run(samples)
