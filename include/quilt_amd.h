@@ -259,6 +259,24 @@ int qa_fullpass_reads_select_batch(qa_panel_t *panel, int32_t n_chain, int32_t n
                                    int32_t *top_cnt, int32_t Ksubset, int32_t Knew, const int32_t *which_haps_to_use,
                                    const uint64_t *seed_select, int32_t *which_next, int32_t *select_status);
 
+/*
+ * The haplotype search of the msPBWT mode (use_mspbwt = TRUE): stands in for mspbwt::Rcpp_find_good_matches_without_a as
+ * `select_new_haps_mspbwt_v3` calls it (QUILT/R/mspbwt.R:265-301).  The mspbwt package (a
+ * positional-BWT index over the panel's per-grid symbols) is not in the reference tree; here the query is compared with
+ * EVERY haplotype -- the symbol table streams at HBM rate, no index to build or hold.  The definition of what is
+ * reported is this library's (UNPINNED against mspbwt; see csrc/match.hip):
+ *   Zs            n_query x nGrids int32: the queries' packed words (rcpp_int_contract of the rounded haploid dosage)
+ *   nindices      interleaved indices (mspbwt_nindices): index i covers grids i, i + nindices, ... (positions 0, 1, ...)
+ *   min_len       minimum number of consecutive matching positions (mspbwtM)
+ *   max_matches   how many matches per (query, index) come back at most
+ *   match         n_query x nindices x max_matches x 3: (index0 = 0-based haplotype, start0 = 0-based first position,
+ *                 len1 = positions) -- per haplotype its longest run of matching positions, the max_matches longest of
+ *                 those, ties at the cut to the lower haplotype; written in haplotype order
+ *   n_match       n_query x nindices: entries written
+ */
+int qa_find_good_matches(qa_panel_t *panel, int32_t n_query, const int32_t *Zs, int32_t nindices, int32_t min_len,
+                         int32_t max_matches, int32_t *match, int32_t *n_match);
+
 /* Timing of the most recent full-pass launch set on this thread, measured with HIP
  * events on the launch stream (ms): [0] emission build, [1] forward, [2] backward,
  * [3] dosage mat-vec, [4] total device.  Replaces print_times()
@@ -304,6 +322,11 @@ typedef struct {
      * (p_O_given_H_L, p_H_given_L, p_set_H_given_L ...); p_H_class_given_L needs H_class, which only the last sweep
      * records (it is overwritten by every sweep: gibbs-nipt.cpp:1142-1165). */
     double *per_it_out;
+    /* use_mspbwt = TRUE: the call's haploid dosages rounded and packed on the device, n_chain x 3 x nGrids int32 --
+     * rcpp_int_contract(round(hapProbs_t[h, ])) (QUILT/R/mspbwt.R:271-272: bit b of word g = (hapProbs_t[h, 32 g + b] > 0.5)),
+     * the queries qa_find_good_matches takes.  With it hapProbs_t itself need not cross PCIe on the rounds whose dosages are
+     * not accumulated.  NULL: not produced. */
+    int32_t *hap_words_out;
 } qa_gibbs_opts_t;
 
 /*

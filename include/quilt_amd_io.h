@@ -137,6 +137,18 @@ int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const ch
 int qa_accumulate_dosage(int32_t n_chain, int32_t n_label, int32_t nSNPs, const double *hap, const int32_t *chain_sample,
                          int32_t n_sample, double *dosage, double *gp_t, double *fet_dosage, double *fet_gp_t);
 
+/* The sequential match weighting of select_new_haps_mspbwt_v3 (QUILT/R/mspbwt.R:418-427; msPBWT mode): matches in the given
+ * order, weight[i] = (end1 - start1 + 1) / sum(cur_sum[start1..end1]) with cur_sum (all ones at first) incremented over each
+ * match's span after it is weighted.  1-based inclusive coordinates. */
+int qa_mspbwt_weights(int32_t n, const int64_t *start1, const int64_t *end1, double *weight);
+
+/* select_new_haps_mspbwt_v3 (QUILT/R/mspbwt.R:303-474) for a batch of chains, from the match tables of qa_find_good_matches
+ * (include/quilt_amd.h): match n_chain x n_label x nindices x max_matches x 3, n_match n_chain x n_label x nindices; seed: one
+ * selection-stream key per chain (R's sample() = the smallest keys at offset 2^21, in key order); out n_chain x Knew, 1-based. */
+int qa_select_new_haps_mspbwt(int32_t n_chain, int32_t n_label, int32_t nindices, int32_t max_matches, const int32_t *match,
+                              const int32_t *n_match, int32_t Knew, int32_t Kfull, int32_t nGrids, const uint64_t *seed,
+                              int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

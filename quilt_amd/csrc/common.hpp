@@ -21,7 +21,7 @@ bool device_ready();
 
 // per-kernel accumulators (HIP-event time on the launch stream, launches, algorithmic HBM bytes)
 enum ProfileKernel { PK_EMAT = 0, PK_FWD, PK_BWD, PK_DOSAGE, PK_EMATREAD, PK_GIBBS, PK_HAPPROBS, PK_FWD64, PK_BWD64, PK_TOPK,
-                     PK_FWD64G, PK_BWD64G, PK_GIBBS3, PK_BLOCK3, PK_SELECT, PK_COUNT };
+                     PK_FWD64G, PK_BWD64G, PK_GIBBS3, PK_BLOCK3, PK_SELECT, PK_MATCH, PK_COUNT };
 // units / serial: work units of the launch (Gibbs: read visits + grid steps over all chains) and the length of its serial
 // chain (Gibbs: read visits + grid steps of the longest chain), for rates other than bytes per second
 void profile_add(int kernel, double ms, double alg_bytes, double start_ms = -1, double units = 0, double serial = 0);
@@ -175,6 +175,15 @@ struct Arena {
         size_t free_b = 0, total_b = 0;
         QA_HIP(hipMemGetInfo(&free_b, &total_b));
         return (size_t)((free_b + cap) * 0.88);
+    }
+    // the same for a handle that shares the device with `share` - 1 others: an equal part of the device at most, but not a
+    // fraction of what is free NOW (the others' arenas are already out of `free`: dividing that again by `share` counted
+    // them twice and kept launch sets a fifth smaller than the memory allows)
+    size_t budget_shared(int share) const {
+        size_t free_b = 0, total_b = 0;
+        QA_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t mine = (size_t)((free_b + cap) * 0.88), part = (size_t)(total_b * 0.88 / (share > 0 ? share : 1));
+        return mine < part ? mine : part;
     }
     void require(size_t bytes) {
         if (bytes <= cap) return;

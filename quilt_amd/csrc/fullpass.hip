@@ -851,7 +851,7 @@ size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stor
 // how many homogeneous passes fit, and make the arena big enough for them
 int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
     const size_t fixed = (size_t)pn->G * 8 + ((size_t)1 << 20);
-    const size_t budget = pn->arena.budget() / pn->share;
+    const size_t budget = pn->arena.budget_shared(pn->share);
     long n = budget > fixed ? (long)((budget - fixed) / per_pass) : 0;
     n = std::max<long>(1, std::min<long>(n, remaining));
     // One pass is one workgroup and a compute unit holds one such workgroup: a launch runs in rounds of n_cu passes.  When

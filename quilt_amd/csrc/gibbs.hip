@@ -838,6 +838,18 @@ __global__ __launch_bounds__(64) void k_ematread_dense(DenseParams p) {
     for (int k = 0; k < p.K; k++) o[k] = v[k];
 }
 
+// rcpp_int_contract(round(hapProbs)) per chain and label: hap [C][T][3] -> words [C][3][G]
+__global__ __launch_bounds__(256) void k_pack_hap_words(const double *hap, int T, int G, int32_t *words) {
+    const int g = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, c = blockIdx.z;
+    if (g >= G) return;
+    uint32_t w = 0;
+    for (int b = 0; b < 32; b++) {
+        const int t = 32 * g + b;
+        if (t < T && hap[((size_t)c * T + t) * 3 + h] > 0.5) w |= 1u << b;
+    }
+    words[((size_t)c * 3 + h) * G + g] = (int32_t)w;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1150,7 +1162,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         S.H.ensure(std::max(totR, 1)); S.H.upload(H, totR, st);
         S.H_class.ensure(std::max(totR, 1));
         S.status.ensure(C);
-        if (hapProbs_t || genProbsM_t || genProbsF_t) {
+        if (hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out) {
             S.hap.ensure((size_t)C * T * 3); S.gm.ensure((size_t)C * T * 3); S.gf.ensure((size_t)C * T * 3);
         }
 
@@ -1196,7 +1208,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         }
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
-        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
+        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out;
         QA_HIP(hipStreamSynchronize(st));
         const double T2 = now();
         // NIPT: the sweeps are cut at the block-Gibbs iterations; between two segments the switch rate per grid boundary
@@ -1272,6 +1284,13 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         QA_HIP(hipStreamSynchronize(st));
         const double T3 = now();
         if (hapProbs_t) S.hap.download(hapProbs_t, (size_t)C * T * 3, st);
+        if (o->hap_words_out) {   // (the genotype-probability buffers are free by now: the words are staged in S.gm)
+            int32_t *d_words = reinterpret_cast<int32_t *>(S.gm.p);
+            hipLaunchKernelGGL(k_pack_hap_words, dim3((G + 255) / 256, 3, C), dim3(256), 0, st, S.hap.p, T, G, d_words);
+            QA_HIP(hipGetLastError());
+            if (genProbsM_t) throw std::runtime_error("hap_words_out cannot be combined with genProbs outputs");
+            qa::staged_download(o->hap_words_out + (size_t)per_it_off * 3 * G, d_words, sizeof(int32_t) * (size_t)C * 3 * G, st);
+        }
         if (genProbsM_t) S.gm.download(genProbsM_t, (size_t)C * T * 3, st);
         if (genProbsF_t) S.gf.download(genProbsF_t, (size_t)C * T * 3, st);
         QA_HIP(hipStreamSynchronize(st));
@@ -1379,14 +1398,14 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
         const int G = rc ? rc->G_all : pn->G, T = rc ? rc->T_all : pn->T, Ks = o->Ks, Ksp = (Ks + 63) / 64 * 64;
         const int n_its = o->n_gibbs_burn_in_its + o->n_gibbs_sample_its;
         const int nb = o->n_block_gibbs_iterations;
-        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t;
+        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out;
         // chains are processed in chunks that fit the device arena (read emissions + 6 Ks x G state matrices each)
         std::vector<size_t> base_of(n_chain + 1, 0);
         for (int c = 0; c < n_chain; c++) {
             const int R = read_off[c + 1] - read_off[c];
             base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
         }
-        const size_t budget = pn->arena.budget() / pn->share;
+        const size_t budget = pn->arena.budget_shared(pn->share);
         int c0 = 0, ret = QA_OK;
         while (c0 < n_chain) {
             size_t need = (size_t)1 << 20;

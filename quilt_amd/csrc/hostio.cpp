@@ -552,6 +552,133 @@ int qa_accumulate_dosage(int32_t n_chain, int32_t n_label, int32_t T, const doub
     return QA_OK;
 }
 
+// The match weights of select_new_haps_mspbwt_v3 (QUILT/R/mspbwt.R:418-427): matches in the given order, each weighted
+// by its length over the coverage accumulated by the matches before it: weight = (e - s + 1) / sum(cur_sum[s:e]), then
+// cur_sum[s:e] += 1 (cur_sum starts at 1).  start1 / end1 are 1-based inclusive.
+int qa_mspbwt_weights(int32_t n, const int64_t *start1, const int64_t *end1, double *weight) {
+    if (n < 0 || (n > 0 && (!start1 || !end1 || !weight))) return QA_ERR_INVALID;
+    int64_t top = 0;
+    for (int32_t i = 0; i < n; i++) {
+        if (start1[i] < 1 || end1[i] < start1[i]) return QA_ERR_INVALID;
+        top = std::max(top, end1[i]);
+    }
+    std::vector<double> cur((size_t)top + 1, 1.0);
+    for (int32_t i = 0; i < n; i++) {
+        double sum = 0;
+        for (int64_t p = start1[i]; p <= end1[i]; p++) sum += cur[p];
+        weight[i] = (double)(end1[i] - start1[i] + 1) * 1 / sum;
+        for (int64_t p = start1[i]; p <= end1[i]; p++) cur[p] += 1;
+    }
+    return QA_OK;
+}
+
+// select_new_haps_mspbwt_v3 (QUILT/R/mspbwt.R:303-474, heuristic_approach "A") for a batch of chains, from the match tables
+// qa_find_good_matches returns.  Restated line by line (quilt_amd/mspbwt.py is the same text in numpy, and the test of this
+// function); R's sample() draws are keyed draws of the chain's selection stream (smallest keys at offset 2^21, in key order).
+//   match      n_chain x n_label x nindices x max_matches x 3 (index0, start0, len1), n_match the rows in use
+//   out        n_chain x Knew 1-based haplotypes
+int qa_select_new_haps_mspbwt(int32_t n_chain, int32_t n_label, int32_t nindices, int32_t max_matches, const int32_t *match,
+                              const int32_t *n_match, int32_t Knew, int32_t Kfull, int32_t nGrids, const uint64_t *seed,
+                              int32_t *out) {
+    if (n_chain < 0 || n_label < 1 || n_label > 3 || nindices < 1 || max_matches < 1 || !match || !n_match || Knew < 1 ||
+        Knew > Kfull || !seed || !out)
+        return QA_ERR_INVALID;
+    struct Row { int64_t index1, start1, end1, len1; };
+    constexpr uint64_t kPoolOffset = 1ull << 21;
+    auto keyed_subset = [](uint64_t sd, int64_t n, int64_t m, uint64_t off, std::vector<int64_t> &pick) {
+        std::vector<std::pair<uint64_t, int64_t>> k((size_t)n);
+        for (int64_t i = 0; i < n; i++) k[(size_t)i] = {stream_key(sd, off + (uint64_t)i), i};
+        m = std::min(m, n);
+        std::partial_sort(k.begin(), k.begin() + m, k.end());
+        pick.resize((size_t)m);
+        for (int64_t i = 0; i < m; i++) pick[(size_t)i] = k[(size_t)i].second;
+    };
+    std::vector<uint8_t> seen((size_t)Kfull + 1);
+    for (int32_t c = 0; c < n_chain; c++) {
+        std::vector<std::vector<Row>> outm((size_t)n_label);
+        for (int32_t h = 0; h < n_label; h++) {
+            std::vector<Row> &all = outm[(size_t)h];
+            for (int32_t i = 0; i < nindices; i++) {
+                const size_t q = ((size_t)c * n_label + h) * nindices + i;
+                const int32_t n = n_match[q];
+                if (n < 0 || n > max_matches) return QA_ERR_INVALID;
+                const int32_t *m = match + q * (size_t)max_matches * 3;
+                std::vector<Row> rows((size_t)n);
+                for (int32_t r = 0; r < n; r++) {
+                    if (m[3 * r] < 0 || m[3 * r] >= Kfull || m[3 * r + 2] < 1) return QA_ERR_INVALID;
+                    rows[(size_t)r] = {(int64_t)m[3 * r] + 1, (int64_t)m[3 * r + 1] + 1, (int64_t)m[3 * r + 1] + m[3 * r + 2],
+                                       (int64_t)m[3 * r + 2]};
+                }
+                if (n > 1) {   // same haplotype and start: the longest first, the others dropped (mspbwt.R:349-358)
+                    std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) {
+                        if (a.index1 != b.index1) return a.index1 < b.index1;
+                        if (a.end1 != b.end1) return a.end1 > b.end1;
+                        return a.start1 > b.start1;
+                    });
+                    std::vector<Row> keep;
+                    for (size_t r = 0; r < rows.size(); r++)
+                        if (r == 0 || !(rows[r].index1 == rows[r - 1].index1 && rows[r].start1 == rows[r - 1].start1))
+                            keep.push_back(rows[r]);
+                    rows.swap(keep);
+                }
+                all.insert(all.end(), rows.begin(), rows.end());
+            }
+            std::stable_sort(all.begin(), all.end(), [](const Row &a, const Row &b) { return a.len1 > b.len1; });
+        }
+        std::fill(seen.begin(), seen.end(), 0);
+        std::vector<int64_t> unique_haps;
+        for (auto &all : outm)
+            for (auto &r : all)
+                if (!seen[(size_t)r.index1]) { seen[(size_t)r.index1] = 1; unique_haps.push_back(r.index1); }
+        int32_t *o = out + (size_t)c * Knew;
+        std::vector<int64_t> pick;
+        if (unique_haps.empty()) {                              // sample(1:Kfull, Knew)
+            keyed_subset(seed[c], Kfull, Knew, kPoolOffset, pick);
+            for (int32_t i = 0; i < Knew; i++) o[i] = (int32_t)pick[(size_t)i] + 1;
+            continue;
+        }
+        if ((int64_t)unique_haps.size() <= Knew) {              // the identified ones, topped up from the rest of the panel
+            std::vector<int64_t> pool;
+            for (int64_t k = 1; k <= Kfull; k++) if (!seen[(size_t)k]) pool.push_back(k);
+            const int64_t n_u = (int64_t)unique_haps.size();
+            keyed_subset(seed[c], (int64_t)pool.size(), Knew - n_u, kPoolOffset, pick);
+            for (int64_t i = 0; i < n_u; i++) o[i] = (int32_t)unique_haps[(size_t)i];
+            for (int64_t i = 0; i < Knew - n_u; i++) o[n_u + i] = (int32_t)pool[(size_t)pick[(size_t)i]];
+            continue;
+        }
+        // prioritise by length and new-ness per haplotype, then interleave (mspbwt.R:416-466)
+        std::vector<std::vector<int64_t>> results((size_t)n_label);
+        size_t a = 0;
+        for (int32_t h = 0; h < n_label; h++) {
+            const std::vector<Row> &all = outm[(size_t)h];
+            const int32_t n = (int32_t)all.size();
+            std::vector<int64_t> s1((size_t)n), e1((size_t)n);
+            std::vector<double> w((size_t)n);
+            for (int32_t r = 0; r < n; r++) { s1[(size_t)r] = all[(size_t)r].start1; e1[(size_t)r] = all[(size_t)r].end1; }
+            if (qa_mspbwt_weights(n, s1.data(), e1.data(), w.data()) != QA_OK) return QA_ERR_INVALID;
+            std::vector<int32_t> ord((size_t)n);
+            for (int32_t r = 0; r < n; r++) ord[(size_t)r] = r;
+            std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return w[(size_t)x] > w[(size_t)y]; });
+            for (int32_t r : ord) results[(size_t)h].push_back(all[(size_t)r].index1);
+            a = std::max(a, results[(size_t)h].size());
+        }
+        std::fill(seen.begin(), seen.end(), 0);
+        std::vector<int64_t> ordered;
+        for (size_t r = 0; r < a; r++)
+            for (int32_t h = 0; h < n_label; h++)
+                if (r < results[(size_t)h].size()) {
+                    const int64_t k = results[(size_t)h][r];
+                    if (!seen[(size_t)k]) { seen[(size_t)k] = 1; ordered.push_back(k); }
+                }
+        if ((int64_t)ordered.size() >= Knew) {
+            for (int32_t i = 0; i < Knew; i++) o[i] = (int32_t)ordered[(size_t)i];
+        } else {   // c(setdiff(unique_ordered_haps, unique_haps), unique_haps)[1:Knew] (the setdiff is empty by construction)
+            for (int32_t i = 0; i < Knew; i++) o[i] = (int32_t)unique_haps[(size_t)i];
+        }
+    }
+    return QA_OK;
+}
+
 int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const char *text, int64_t n) {
     if (!path || (!text && n > 0) || n < 0) return QA_ERR_INVALID;
     BgzfWriter w(path, bgzf != 0, truncate != 0);

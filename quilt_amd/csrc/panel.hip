@@ -91,7 +91,7 @@ void profile_add(int kernel, double ms, double alg_bytes, double start_ms, doubl
 
 static const char *const kProfileNames[PK_COUNT] = {
     "k_emat", "k_fwd", "k_bwd", "k_dosage", "k_ematread", "k_gibbs", "k_happrobs", "k_fwd64", "k_bwd64", "k_topk",
-    "k_fwd<double>", "k_bwd<double>", "k_gibbs3", "k_block3", "k_select"};
+    "k_fwd<double>", "k_bwd<double>", "k_gibbs3", "k_block3", "k_select", "k_best_run"};
 
 // sp_gidx / sp_chunk_at (see panel.hpp): one thread per (grid with specials, 16-haplotype chunk), lower bound of the
 // chunk's first haplotype in the grid's ascending special list, shifted into the padded per-pass layout

@@ -47,6 +47,13 @@ class DriverParams:
     impute_rare_common: bool = False   # quilt.R:180: finish every Gibbs sample with a Gibbs call over ALL SNPs
     method: str = "diploid"            # or "nipt": mother + fetus, three read labels, fetal fraction per sample (sample.ff)
     shuffle_bin_radius: int = 5000     # quilt.R:134 (block definition of the NIPT block Gibbs)
+    # use_mspbwt = TRUE (quilt.R:170-174): no full-panel pass; the next small panel comes from long matches of the Gibbs call's
+    # rounded haploid dosages against the panel (mspbwt.R:225-474), the dosages from the Gibbs call itself (functions.R:784-893)
+    use_mspbwt: bool = False
+    mspbwtL: int = 3                   # neighbours scanned up and down per grid in the reference's index; here it scales how
+    mspbwtM: int = 1                   # many matches a search returns (mspbwt_max_matches); mspbwtM: minimum match length
+    mspbwt_nindices: int = 4
+    mspbwt_max_matches: Optional[int] = None   # matches per (haplotype, index) from the device search; None: 50 * mspbwtL
 
     def resolved(self, K: int) -> "DriverParams":
         p = DriverParams(**self.__dict__)
@@ -66,6 +73,11 @@ class DriverParams:
             raise ValueError("nGibbsSamples, Ksubset and Knew must be >= 1")
         if p.K_top_matches < 1:
             raise ValueError("K_top_matches must be >= 1")
+        if p.use_mspbwt and p.Knew != p.Ksubset:
+            raise ValueError("use_mspbwt: select_new_haps_mspbwt_v3 returns the whole next small panel, so Knew must equal "
+                             "Ksubset (the reference's defaults: 600 / 600)")
+        if p.use_mspbwt and (p.mspbwt_nindices < 1 or p.mspbwtM < 1 or p.mspbwtL < 1):
+            raise ValueError("mspbwt_nindices, mspbwtM and mspbwtL must be >= 1")
         return p
 
 
@@ -552,14 +564,21 @@ class Driver:
         t1 = time.perf_counter()
         self.timing["host"] += t1 - t0
         # ---- small-panel Gibbs (impute_one_sample, functions.R:2313-2774), with the underflow retry
+        # use_mspbwt: the haplotype search wants the call's rounded, packed haploid dosages (formed on the device); the
+        # dosages themselves only on the rounds that accumulate them (the last round's also feed the read-confidence step)
+        extra = {"return_hap_words": True, "return_hapProbs": i_it > P.n_burn_in_seek_its} if P.use_mspbwt else {}
         results = self._gibbs_with_retry(chains, [ch.sample for ch in chains], starts, seed_reads, first_reads, seed_shards,
-                                         gibbs_initialize_iteratively=any_first)
+                                         gibbs_initialize_iteratively=any_first, **extra)
         t2 = time.perf_counter()
         self.timing["gibbs"] += t2 - t1
         # ---- full-panel pass per read label (impute_using_everything, functions.R:1922-2157)
         return_dosage = i_it > P.n_burn_in_seek_its
         for ch, res in zip(chains, results):
             ch.read_labels = res["double_list_of_ending_read_labels"][0][0].astype(np.int32)
+        if P.use_mspbwt:
+            self._round_mspbwt(chains, results, i_it, return_dosage)
+            self.timing["fullpass"] += time.perf_counter() - t2
+            return return_dosage
         uniq, sample_list = {}, []
         for ch in chains:
             if id(ch.sample) not in uniq:
@@ -622,6 +641,46 @@ class Driver:
             ch.which_haps_to_use = np.concatenate([prev_sel, sel]).astype(np.int32)
         self.timing["host"] += time.perf_counter() - t4
         return return_dosage
+
+    def _round_mspbwt(self, chains: List[ChainState], results, i_it: int, return_dosage: bool):
+        """use_mspbwt = TRUE (functions.R:784-893): the haploid dosages are the Gibbs call's hapProbs_t; the next small panel
+        comes from the long matches of their rounded form against the whole panel (select_new_haps_mspbwt_v3,
+        mspbwt.R:225-474) -- searched on the device for all chains and labels at once."""
+        from .mspbwt import int_contract_rows, select_new_haps_mspbwt_batch
+        P = self.params
+        T, nL = self.panel.nSNPs, self.n_label
+        if return_dosage:
+            dosages = np.empty((len(chains), nL, T))
+            for ci, res in enumerate(results):
+                dosages[ci] = np.asarray(res["hapProbs_t"])[:nL]
+            for ci, ch in enumerate(chains):
+                ch.hap = [dosages[ci][l] for l in range(nL)]
+        else:
+            dosages = None
+            if self._zero_hap is None or len(self._zero_hap) != T:
+                self._zero_hap = np.zeros(T)
+                self._zero_hap.flags.writeable = False
+            for ch in chains:
+                ch.hap = [self._zero_hap] * nL
+        self._round_dosages = dosages
+        self._round_dosage_chains = list(chains) if return_dosage else []
+        want = [i_it < P.n_seek_its or P.impute_rare_common or (not ch.phasing and ch.i_chain == P.nGibbsSamples)
+                for ch in chains]
+        idx = [ci for ci, w in enumerate(want) if w]
+        if not idx:
+            return
+        seed_sel = {ci: int(chains[ci].rng.integers(0, 2 ** 63)) for ci in idx}
+        # per chain its nL haplotypes, rounded and packed (mspbwt.R:271-272)
+        if "hap_words" in results[idx[0]]:
+            Zs = np.concatenate([np.asarray(results[ci]["hap_words"])[:nL] for ci in idx])
+        else:
+            Zs = int_contract_rows(np.concatenate([np.asarray(results[ci]["hapProbs_t"])[:nL] for ci in idx]))
+        n_max = P.mspbwt_max_matches or 50 * P.mspbwtL
+        match, n_match = self.backend.find_good_matches(Zs, P.mspbwt_nindices, P.mspbwtM, n_max)
+        new = select_new_haps_mspbwt_batch(match, n_match, nL, P.Knew, self.panel.K, self.panel.nGrids,
+                                           [seed_sel[ci] for ci in idx])
+        for a, ci in enumerate(idx):
+            chains[ci].which_haps_to_use = new[a].copy()
 
     def _full_lists(self, ch: ChainState) -> List[List[np.ndarray]]:
         """``new_haps`` of one chain from complete best-haplotype lists: per read label its gl (make_gl_from_u_bq,
@@ -859,7 +918,13 @@ class HipBackend:
                                                   rare_common=self.drc, **kw)
         return forwardBackwardGibbsNIPT_batch(self.dev, samples, which, starts, None, first_reads, None,
                                               seed_reads=seed_reads, seed_shard=seed_shards,
-                                              return_hapProbs=False, return_genProbs=False, **kw)   # use_mspbwt = FALSE
+                                              return_hapProbs=bool(kw.pop("return_hapProbs", False)),   # use_mspbwt = TRUE
+                                              return_hap_words=bool(kw.pop("return_hap_words", False)),
+                                              return_genProbs=False, **kw)
+
+    def find_good_matches(self, Zs, nindices, min_len, max_matches):
+        from .mspbwt import find_good_matches
+        return find_good_matches(self.dev, Zs, nindices, min_len, max_matches)
 
     def read_likelihood_all_snps_batch(self, samples_all, haps, maxDifferenceBetweenReads):
         """rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100.

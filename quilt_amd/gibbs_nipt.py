@@ -29,7 +29,7 @@ class GibbsOpts(C.Structure):
         ("gibbs_initialize_iteratively", C.c_int32), ("disable_read_category_usage", C.c_int32),
         ("class_sum_cutoff", C.c_double),
         ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int32), ("block_gibbs_quantile_prob", C.c_double),
-        ("ff_chain", C.c_void_p), ("per_it_out", C.c_void_p),
+        ("ff_chain", C.c_void_p), ("per_it_out", C.c_void_p), ("hap_words_out", C.c_void_p),
     ]
 
 
@@ -45,7 +45,8 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                                    seed_reads=None, seed_shard=None, return_hapProbs: bool = True,
                                    return_genProbs: bool = True, rare_common=None, runif_block=None,
                                    runif_resample=None, L_grid=None, shuffle_bin_radius: int = 5000,
-                                   block_gibbs_quantile_prob: float = 0.95, return_per_it: bool = False):
+                                   block_gibbs_quantile_prob: float = 0.95, return_per_it: bool = False,
+                                   return_hap_words: bool = False):
     """``n_chain`` independent calls of ``rcpp_forwardBackwardGibbsNIPT`` in one launch set.
 
     ``samples[c]`` is a :class:`quilt_amd.synth.SampleReads`-like object (``read_ptr``, ``u``, ``bq``,
@@ -119,17 +120,19 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     if ff == 0 and H.size and (H.min() < 1 or H.max() > 2):
         raise ValueError("diploid read labels must be 1 or 2")
     Hc = np.zeros_like(H)
-    hap = np.zeros((Cn, T, 3)) if return_hapProbs else None
-    gm = np.zeros((Cn, T, 3)) if return_genProbs else None
-    gf = np.zeros((Cn, T, 3)) if return_genProbs else None
+    # (np.empty: the library writes every entry of the rows it is asked for; zero-filling ~1 GB per call costs more than the copy)
+    hap = np.empty((Cn, T, 3)) if return_hapProbs else None
+    gm = np.empty((Cn, T, 3)) if return_genProbs else None
+    gf = np.empty((Cn, T, 3)) if return_genProbs else None
     uf = np.zeros(Cn, dtype=np.int32)
     state = np.zeros(6 * Ks * G + 3 * G) if (return_state and Cn == 1) else None
     per_it = np.zeros((Cn, n_its, 8)) if return_per_it else None
+    words = np.zeros((Cn, 3, G), dtype=np.int32) if return_hap_words else None   # use_mspbwt: rounded, packed hapProbs
     opts = GibbsOpts(Ks, float(ff), int(ff == 0), int(Jmax_local), float(maxDifferenceBetweenReads), 1,
                      int(n_gibbs_burn_in_its), int(n_gibbs_sample_its), ptr(blocks), int(len(blocks)),
                      int(perform_block_gibbs), int(ff == 0), int(gibbs_initialize_iteratively),
                      int(disable_read_category_usage), float(class_sum_cutoff), ptr(Lg), int(shuffle_bin_radius),
-                     float(block_gibbs_quantile_prob), ptr(ffc), ptr(per_it))
+                     float(block_gibbs_quantile_prob), ptr(ffc), ptr(per_it), ptr(words))
     _t1 = time.perf_counter()
     tail = (C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(ru),
             ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap), ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
@@ -147,6 +150,8 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                  double_list_of_ending_read_labels=[[H[s:e].copy()]], H_class=Hc[s:e].copy())
         if per_it is not None:
             d["per_it"] = per_it[c].copy()
+        if words is not None:
+            d["hap_words"] = words[c]
         if hap is not None:
             d["hapProbs_t"] = np.asfortranarray(hap[c].T)
         if gm is not None:

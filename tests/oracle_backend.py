@@ -15,7 +15,8 @@ class OracleBackend:
 
     def gibbs_batch(self, samples, which, starts, seed_reads, first_reads, seed_shards, *,
                     n_gibbs_burn_in_its, n_gibbs_sample_its, block_gibbs_iterations, gibbs_initialize_iteratively,
-                    maxDifferenceBetweenReads, Jmax_local, rare_common=False, ff=0.0, shuffle_bin_radius=5000):
+                    maxDifferenceBetweenReads, Jmax_local, rare_common=False, ff=0.0, shuffle_bin_radius=5000,
+                    return_hapProbs=False, return_hap_words=False):   # (the oracle always returns hapProbs_t; the driver packs)
         from quilt_amd.rng import stream_uniform
         out = []
         n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
@@ -85,3 +86,42 @@ class OracleBackend:
                     top[c, l - 1, j, : len(k)] = k
                     cnt[c, l - 1, j] = len(idx)
         return dosage, top, cnt
+
+    def find_good_matches(self, Zs, nindices, min_len, max_matches):
+        from quilt_amd.mspbwt import match_lists_as_tables
+        return match_lists_as_tables(find_good_matches_bruteforce(self.panel, Zs, nindices, min_len, max_matches), max_matches)
+
+
+def find_good_matches_bruteforce(panel, Zs, nindices, min_len, max_matches):
+    """The definition in csrc/match.hip / include/quilt_amd.h (qa_find_good_matches), written out with numpy: per haplotype its
+    longest (earliest) run of matching positions within each interleaved index; the max_matches longest of those with at least
+    min_len positions, ties at the cut to the lower haplotype; reported in haplotype order."""
+    hm = np.asarray(panel.hapMatcherR if panel.hapMatcherR is not None else panel.hapMatcher).astype(np.int64)   # K x G
+    B = np.asarray(panel.distinctHapsB)                                                                           # nMaxDH x G
+    K, G = hm.shape
+    out = []
+    for Z in np.asarray(Zs):
+        qc = np.zeros(G, dtype=np.int64)
+        for g in range(G):
+            w = np.nonzero(B[:, g] == Z[g])[0]
+            qc[g] = w[0] + 1 if len(w) else 0
+        per_index = []
+        for i in range(nindices):
+            grids = np.arange(i, G, nindices)
+            m = (hm[:, grids] == qc[grids][None, :]) & (hm[:, grids] != 0)            # K x positions
+            best_len = np.zeros(K, dtype=np.int64)
+            best_start = np.zeros(K, dtype=np.int64)
+            run = np.zeros(K, dtype=np.int64)
+            start = np.zeros(K, dtype=np.int64)
+            for j in range(len(grids)):
+                start = np.where(m[:, j] & (run == 0), j, start)
+                run = np.where(m[:, j], run + 1, 0)
+                better = run > best_len
+                best_len = np.where(better, run, best_len)
+                best_start = np.where(better, start, best_start)
+            ok = np.nonzero(best_len >= min_len)[0]
+            order = ok[np.lexsort((ok, -best_len[ok]))][:max_matches]     # length descending, haplotype ascending
+            order = np.sort(order)                                         # reported in haplotype order
+            per_index.append(np.column_stack([order, best_start[order], best_len[order]]).astype(np.int32))
+        out.append(per_index)
+    return out

@@ -1,0 +1,104 @@
+"""use_mspbwt = TRUE: the selection logic of QUILT/R/mspbwt.R:225-474 restated in
+quilt_amd/mspbwt.py, on hand-made match tables, and the mode end to end on the CPU path (oracle Gibbs + the numpy statement
+of the device search)."""
+import numpy as np
+
+
+def test_int_contract_and_mtm_table():
+    from quilt_amd.mspbwt import matches_to_mtm, rcpp_int_contract
+    hap = np.zeros(70, dtype=int)
+    hap[[0, 3, 31, 32, 69]] = 1
+    assert rcpp_int_contract(hap).tolist() == [np.int32(1 | 8 | (1 << 31) - (1 << 32)).item(), 1, 1 << 5]
+    # index 1: haplotype 4 twice from the same start (the longer one stays), haplotype 2 once; index 2: haplotype 7
+    idx1 = np.array([[4, 2, 5], [4, 2, 3], [2, 0, 9]])       # (index0, start0, len1)
+    idx2 = np.array([[7, 1, 9]])
+    mtm = matches_to_mtm([idx1, idx2], nGrids=40)
+    # columns index1, start1, end1, len1, key, n; ordered by length (stable: index 1's rows before index 2's at a tie)
+    assert mtm[:, :4].tolist() == [[3, 1, 9, 9], [8, 2, 10, 9], [5, 3, 7, 5]]
+    assert mtm[:, 4].tolist() == [40 * 1 + 9, 40 * 2 + 10, 40 * 3 + 7] and mtm[:, 5].tolist() == [1, 2, 1]
+    assert matches_to_mtm([np.zeros((0, 3), dtype=int), None], 40).shape == (0, 6)
+
+
+def test_select_new_haps_branches():
+    from quilt_amd.mspbwt import select_new_haps_mspbwt_v3
+    none = [[np.zeros((0, 3), dtype=int)], [np.zeros((0, 3), dtype=int)]]
+    out = select_new_haps_mspbwt_v3(none, Knew=10, Kfull=100, nGrids=50, seed_select=3)
+    assert len(set(out.tolist())) == 10 and out.min() >= 1 and out.max() <= 100            # sample(1:Kfull, Knew)
+    few = [[np.array([[4, 0, 9], [9, 3, 4]])], [np.array([[4, 5, 2], [11, 0, 7]])]]
+    out = select_new_haps_mspbwt_v3(few, Knew=6, Kfull=100, nGrids=50, seed_select=3)
+    assert out[:3].tolist() == [5, 10, 12] and len(set(out.tolist())) == 6                 # found ones first, then a top-up
+    # more candidates than Knew: weights = length / coverage so far, interleaved between the two haplotypes
+    h1 = np.array([[0, 0, 10], [1, 0, 10], [2, 20, 5], [3, 30, 4]])     # 1 and 2 cover the same stretch: the second weighs half
+    h2 = np.array([[10, 0, 8], [11, 10, 8], [12, 20, 8]])
+    out = select_new_haps_mspbwt_v3([[h1], [h2]], Knew=4, Kfull=100, nGrids=50, seed_select=3)
+    # h1 by length: 1 (w 1), 2 (w 0.5), 3 (w 1), 4 (w 1) -> order by weight, stable: 1, 3, 4, 2; h2: 11, 12, 13 (all 1)
+    assert out.tolist() == [1, 11, 3, 12]
+    out = select_new_haps_mspbwt_v3([[h1], [h2]], Knew=6, Kfull=100, nGrids=50, seed_select=3)
+    assert out.tolist() == [1, 11, 3, 12, 4, 13]
+    # exactly as many as wanted: the identified haplotypes as they come (haplotype 1's by length, then haplotype 2's)
+    out = select_new_haps_mspbwt_v3([[h1], [h2]], Knew=7, Kfull=100, nGrids=50, seed_select=3)
+    assert out.tolist() == [1, 2, 3, 4, 11, 12, 13]
+
+
+def test_bruteforce_search_definition(small_panel):
+    """The numpy statement of the search on a query copied from a panel haplotype: that haplotype matches end to end."""
+    from quilt_amd.mspbwt import rcpp_int_contract
+    from quilt_amd.synth import panel_hap_bits
+    from tests.oracle_backend import find_good_matches_bruteforce
+    panel = small_panel
+    k = 17
+    Z = rcpp_int_contract(panel_hap_bits(panel, k))
+    found = find_good_matches_bruteforce(panel, Z[None, :], 2, 1, 20)[0]
+    for i, m in enumerate(found):
+        n_pos = len(range(i, panel.nGrids, 2))
+        row = m[m[:, 0] == k]
+        special = np.asarray(panel.hapMatcherR)[k, i::2] == 0
+        if not special.any():
+            assert len(row) == 1 and row[0, 1] == 0 and row[0, 2] == n_pos
+        assert (np.diff(m[:, 0]) > 0).all() and (m[:, 2] >= 1).all() and len(m) <= 20
+
+
+def test_pipeline_mspbwt_on_the_cpu_path(medium_panel):
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    from tests.util import r2
+    import pytest
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=900 + i, n_reads=600) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=100, Knew=100, seed=3, use_mspbwt=True, mspbwt_nindices=2)
+    res = Driver(panel, OracleBackend(panel), prm).run(samples)
+    for s, r in zip(samples, res):
+        assert r.nDosage == 2 and np.isfinite(r.dosage).all() and r.dosage.min() >= 0 and r.dosage.max() <= 2 + 1e-9
+        np.testing.assert_allclose(r.gp_t.sum(axis=0), 1.0, atol=1e-9)
+        assert r2(r.dosage, s.truth_haps[:2].sum(axis=0)) > 0.8
+    with pytest.raises(ValueError, match="Knew must equal"):
+        Driver(panel, OracleBackend(panel), DriverParams(Ksubset=100, Knew=50, use_mspbwt=True)).run(samples)
+
+
+def test_native_batch_selection_equals_the_numpy_text():
+    """csrc/hostio.cpp qa_select_new_haps_mspbwt against quilt_amd/mspbwt.py select_new_haps_mspbwt_v3 on random match tables
+    that reach all three branches (no match, fewer than Knew, more than Knew), two and three haplotypes per chain."""
+    from quilt_amd.mspbwt import match_tables_as_lists, select_new_haps_mspbwt_batch, select_new_haps_mspbwt_v3
+    rng = np.random.default_rng(12)
+    Kfull, nGrids = 300, 200
+    for n_label in (2, 3):
+        for Knew, n_avail in ((20, 0), (40, 12), (15, 60), (50, 200), (7, 7)):
+            n_chain, ni, mm = 6, 3, 25
+            match = np.zeros((n_chain * n_label, ni, mm, 3), dtype=np.int32)
+            n = np.zeros((n_chain * n_label, ni), dtype=np.int32)
+            haps_pool = rng.choice(Kfull, size=max(n_avail, 1), replace=False)
+            for q in range(n_chain * n_label):
+                for i in range(ni):
+                    cnt = 0 if n_avail == 0 else int(rng.integers(0, mm + 1))
+                    hp = np.sort(rng.choice(haps_pool, size=min(cnt, len(haps_pool)), replace=False))
+                    n[q, i] = len(hp)
+                    match[q, i, :len(hp), 0] = hp
+                    match[q, i, :len(hp), 1] = rng.integers(0, 30, size=len(hp))
+                    match[q, i, :len(hp), 2] = rng.integers(1, 20, size=len(hp))
+            seeds = [int(x) for x in rng.integers(0, 2 ** 63, size=n_chain)]
+            got = select_new_haps_mspbwt_batch(match, n, n_label, Knew, Kfull, nGrids, seeds)
+            lists = match_tables_as_lists(match, n)
+            for c in range(n_chain):
+                ref = select_new_haps_mspbwt_v3(lists[c * n_label:(c + 1) * n_label], Knew, Kfull, nGrids, seeds[c])
+                assert np.array_equal(got[c], ref), (n_label, Knew, n_avail, c)

@@ -1,0 +1,51 @@
+"""use_mspbwt = TRUE on the device: the haplotype search (csrc/match.hip) against its numpy
+statement -- integer work, identical -- and the mode end to end against the CPU path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("which", ["small", "ragged", "medium"])
+def test_device_search_equals_its_definition(small_panel, ragged_panel, medium_panel, which):
+    from quilt_amd.mspbwt import find_good_matches, match_tables_as_lists, rcpp_int_contract
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_truth_haplotype, panel_hap_bits
+    from tests.oracle_backend import find_good_matches_bruteforce
+    panel = dict(small=small_panel, ragged=ragged_panel, medium=medium_panel)[which]
+    rng = np.random.default_rng(5)
+    queries = [panel_hap_bits(panel, 3)]                               # a panel haplotype: matches itself end to end
+    queries += [make_truth_haplotype(panel, rng) for _ in range(3)]    # mosaics of panel haplotypes
+    noisy = queries[1].copy()
+    flip = rng.random(len(noisy)) < 0.02
+    noisy[flip] = 1 - noisy[flip]
+    queries.append(noisy)                                              # words that are in no dictionary
+    queries.append(np.zeros(panel.nSNPs, dtype=np.int8))
+    Zs = np.stack([rcpp_int_contract(q) for q in queries])
+    dev = DevicePanel(panel)
+    for nind, min_len, n_max in ((1, 1, 7), (2, 1, 40), (4, 2, 150), (3, 1, 1), (4, 1, 2000)):
+        got = match_tables_as_lists(*find_good_matches(dev, Zs, nind, min_len, n_max))
+        ref = find_good_matches_bruteforce(panel, Zs, nind, min_len, n_max)
+        for q in range(len(Zs)):
+            for i in range(nind):
+                assert np.array_equal(got[q][i], ref[q][i]), (which, nind, min_len, n_max, q, i)
+    dev.close()
+
+
+def test_pipeline_mspbwt_matches_the_cpu_path(medium_panel):
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    from tests.util import r2
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=900 + i, n_reads=600) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=100, Knew=100, seed=3, use_mspbwt=True, mspbwt_nindices=2)
+    dev = DevicePanel(panel)
+    got = Driver(panel, HipBackend(dev), prm).run(samples)
+    dev.close()
+    ref = Driver(panel, OracleBackend(panel), prm).run(samples)
+    for s, g, r in zip(samples, got, ref):
+        assert np.array_equal(g.read_labels, r.read_labels)
+        assert np.abs(g.dosage - r.dosage).max() <= 1e-6      # the dosages are the Gibbs call's fp64 hapProbs
+        assert r2(g.dosage, s.truth_haps[:2].sum(axis=0)) > 0.8
