@@ -4,6 +4,14 @@
  * fp64 restatement of the full-panel haploid Li-Stephens forward/backward of
  * QUILT/src/reference-single.cpp, in the reference's arithmetic order
  * (version 3 == version 2 arithmetic), use_eMatDH = TRUE.
+ *
+ * PIN: the reference cannot be built or run in this container (no R, Rcpp, Armadillo, Eigen) and its tests hold no golden
+ * vectors, so this file is pinned by (1) oracle/rtwin.py -- an independent NumPy restatement of the reference's R twin of
+ * this code (QUILT/R/reference-single.R:94-372), cross-checked by tests/golden/make_golden_rtwin.py and on every CPU run by
+ * tests/test_rtwin_cpu.py against fixtures generated from the R-twin side (dosage 1e-12, gamma 1e-9, best-haplotype lists
+ * identical); (2) the RNG-independent known answers of the reference's testthat suite (tests/golden/known_answers.json);
+ * (3) the invariants that suite asserts (tests/test_oracle_cpu.py).  Not an execution of the reference: parity claims
+ * resting on this oracle are "unpinned against a reference run" (DESIGN.md section 3).
  */
 #include "quilt_oracle.h"
 

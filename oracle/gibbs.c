@@ -25,6 +25,15 @@
  * the identity and runs the shard resampler (:1975-2355), which is active.
  * Block Gibbs for ff > 0 (NIPT): block definition (:311-523), make_gibbs_considers (:1307-1553) and the block
  * resampler proper (:590-949, :1122-1292, :1636-1967) for block_approach = 6, restated below.
+ *
+ * PIN: the reference cannot be built or run in this container and its tests hold no golden vectors.  This file is pinned by
+ * (1) oracle/rtwin.py, an independent NumPy restatement of the reference's R sampler (QUILT/R/gibbs-nipt.R:508-997 with
+ * make_eMatRead_t / evaluate_read_variability / make_rlc): same uniforms in, read labels and H_class identical, alpha / beta
+ * / eMatGrid to 1e-8 (tests/golden/make_golden_rtwin.py; tests/test_rtwin_cpu.py on every CPU run, fixtures generated from
+ * the R-twin side) -- the R twin has no block / shard pass, so those rest on (2) the known answers and (3) the invariants
+ * of the reference's tests (tests/golden/known_answers.json, tests/test_oracle_cpu.py: state after a pass == from-scratch
+ * forward-backward given the labels, the label / class swap table, get_log_p_H_class2, make_gibbs_considers' definition).
+ * Not an execution of the reference: "unpinned against a reference run" (DESIGN.md section 3).
  */
 #define _GNU_SOURCE /* qsort_r */
 #include "quilt_oracle.h"
