@@ -3,7 +3,7 @@
 #   gpurun --timeout 3000 -- 'bash scripts/profile_round.sh r02'
 # 1. the -m gpu tests; 2. the bench line of the driver's own command (--steps 20 --warmup 5); 3. rocprofv3 --kernel-trace
 # --stats of the same command (CPU baseline leg off: it forks 128 host processes the profiler would follow); 4. PMC passes
-# (each alone with --kernel-trace: FETCH_SIZE, WRITE_SIZE, instruction counters); 5. the ONT / NIPT / fp64-dosage lines.
+# (each alone with --kernel-trace: FETCH_SIZE, WRITE_SIZE, instruction counters); 5. the ONT / NIPT / fp64-dosage / msPBWT-mode lines.
 TAG=${1:-r02}
 WHAT=${2:-all}
 OUT=$PWD/gpurun_out/$TAG
@@ -43,4 +43,5 @@ if [[ $WHAT == all || $WHAT == lines ]]; then
 python bench.py --mode ont --steps 4 --warmup 1 > $OUT/bench_line_ont.json 2> $OUT/bench_ont.err; tail -c 300 $OUT/bench_line_ont.json
 python bench.py --mode nipt --steps 4 --warmup 1 > $OUT/bench_line_nipt.json 2> $OUT/bench_nipt.err; tail -c 300 $OUT/bench_line_nipt.json
 python bench.py --fp64-dosage --steps 4 --warmup 1 --r2-vs-cpu 1 > $OUT/bench_line_fp64_dosage.json 2> $OUT/bench_fp64.err; tail -c 300 $OUT/bench_line_fp64_dosage.json
+python bench.py --mspbwt --steps 4 --warmup 1 > $OUT/bench_line_mspbwt.json 2> $OUT/bench_mspbwt.err; tail -c 300 $OUT/bench_line_mspbwt.json
 fi

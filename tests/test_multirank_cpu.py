@@ -31,8 +31,15 @@ def _worker(rank, world, port, q):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     gathered = [None] * world
     dist.all_gather_object(gathered, [(lo + i, r.dosage) for i, r in enumerate(res)])
+    # the run's only cross-shard reduction: the per-SNP count arrays behind the VCF's INFO column (writers.R:38-47)
+    from quilt_amd.io import SummaryCounts, per_sample_counts
+    from quilt_amd.sharding import reduce_counts
+    counts = SummaryCounts(panel.nSNPs)
+    for s, r in zip(samples[lo:hi], res):
+        counts.add_sample(*per_sample_counts(r.gp_t, s, panel.nSNPs))
+    reduce_counts(counts)
     if rank == 0:
-        q.put((float(t.item()), [x for part in gathered for x in part]))
+        q.put((float(t.item()), [x for part in gathered for x in part], counts.as_vector()))
     dist.destroy_process_group()
 
 
@@ -50,7 +57,7 @@ def test_two_ranks_equal_one_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    tmax, parts = q.get(timeout=300)
+    tmax, parts, count_vec = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -61,6 +68,12 @@ def test_two_ranks_equal_one_process():
     assert [i for i, _ in parts] == [0, 1, 2, 3, 4]
     for (i, d), r in zip(parts, ref):
         assert np.array_equal(d, r.dosage)
+    # the summed count arrays equal the single-process sums
+    from quilt_amd.io import SummaryCounts, per_sample_counts
+    one = SummaryCounts(panel.nSNPs)
+    for s, r in zip(samples, ref):
+        one.add_sample(*per_sample_counts(r.gp_t, s, panel.nSNPs))
+    np.testing.assert_allclose(count_vec, one.as_vector(), rtol=1e-12, atol=1e-12)
 
 
 def test_bench_gpus_flag_creates_the_ranks():
