@@ -30,8 +30,8 @@ __global__ __launch_bounds__(64) void k_query_codes(const int32_t *Z, const int3
     const int32_t w = Z[(size_t)q * G + g];
     int code = 0;
     for (int d = lane; d < nMaxDH; d += 64)
-        if (B[(size_t)g * nMaxDH + d] == w) code = d + 1;   // distinct words: at most one lane finds it
-    // unused rows of distinctHapsB hold 0 = a legal word: take the first matching row
+        if (!code && B[(size_t)g * nMaxDH + d] == w) code = d + 1;   // the lane's first matching row
+    // unused rows of distinctHapsB hold 0, which is also a legal word: the FIRST matching row is the symbol
     int best = code ? code : 0x7fffffff;
     for (int off = 32; off; off >>= 1) best = min(best, __shfl_xor(best, off));
     if (lane == 0) qc[(size_t)q * G + g] = best == 0x7fffffff ? 0 : (uint8_t)best;

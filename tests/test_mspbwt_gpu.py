@@ -6,13 +6,27 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("which", ["small", "ragged", "medium"])
-def test_device_search_equals_its_definition(small_panel, ragged_panel, medium_panel, which):
+@pytest.fixture(scope="module")
+def sparse_panel():
+    """Mostly reference alleles: the all-zero word is a real symbol (usually the first) of every grid's dictionary, next to the
+    zero padding of distinctHapsB's unused rows."""
+    from quilt_amd.synth import make_synthetic_panel
+    from tests.util import panel_from_rhb
+    base = make_synthetic_panel(K=600, nSNPs=640, seed=3)
+    rng = np.random.default_rng(4)
+    rhb = np.asfortranarray(np.where(rng.random(base.rhb_t.shape) < 0.7, 0, base.rhb_t).astype(np.int32))
+    p = panel_from_rhb(rhb, base.transMatRate_t, 640, 255, base.ref_error)
+    p.L_grid = base.L_grid
+    return p
+
+
+@pytest.mark.parametrize("which", ["small", "ragged", "medium", "sparse"])
+def test_device_search_equals_its_definition(small_panel, ragged_panel, medium_panel, sparse_panel, which):
     from quilt_amd.mspbwt import find_good_matches, match_tables_as_lists, rcpp_int_contract
     from quilt_amd.native import DevicePanel
     from quilt_amd.synth import make_truth_haplotype, panel_hap_bits
     from tests.oracle_backend import find_good_matches_bruteforce
-    panel = dict(small=small_panel, ragged=ragged_panel, medium=medium_panel)[which]
+    panel = dict(small=small_panel, ragged=ragged_panel, medium=medium_panel, sparse=sparse_panel)[which]
     rng = np.random.default_rng(5)
     queries = [panel_hap_bits(panel, 3)]                               # a panel haplotype: matches itself end to end
     queries += [make_truth_haplotype(panel, rng) for _ in range(3)]    # mosaics of panel haplotypes
@@ -49,3 +63,27 @@ def test_pipeline_mspbwt_matches_the_cpu_path(medium_panel):
         assert np.array_equal(g.read_labels, r.read_labels)
         assert np.abs(g.dosage - r.dosage).max() <= 1e-6      # the dosages are the Gibbs call's fp64 hapProbs
         assert r2(g.dosage, s.truth_haps[:2].sum(axis=0)) > 0.8
+
+
+def test_hap_words_formed_on_the_device(medium_panel):
+    """qa_gibbs_opts_t.hap_words_out: rcpp_int_contract(round(hapProbs_t)) per chain and haplotype (mspbwt.R:271-272), formed on
+    the device from the hapProbs the same call returns."""
+    from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+    from quilt_amd.mspbwt import int_contract_rows
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    rng = np.random.default_rng(2)
+    samples = [make_synthetic_sample(panel, seed=700 + i, n_reads=400) for i in range(3)]
+    which = [np.sort(rng.choice(panel.K, 100, replace=False)).astype(np.int32) + 1 for _ in samples]
+    H0 = [rng.integers(1, 3, size=s.nReads).astype(np.int32) for s in samples]
+    seeds = rng.integers(0, 2 ** 63, size=3).astype(np.uint64)
+    dev = DevicePanel(panel)
+    out = forwardBackwardGibbsNIPT_batch(dev, samples, which, H0, None, [0, 5, 9], None, seed_reads=seeds, seed_shard=seeds + 1,
+                                         return_hapProbs=True, return_genProbs=False, return_hap_words=True)
+    only = forwardBackwardGibbsNIPT_batch(dev, samples, which, H0, None, [0, 5, 9], None, seed_reads=seeds, seed_shard=seeds + 1,
+                                          return_hapProbs=False, return_genProbs=False, return_hap_words=True)
+    dev.close()
+    for o, w in zip(out, only):
+        assert np.array_equal(o["hap_words"], int_contract_rows(np.asarray(o["hapProbs_t"])))
+        assert np.array_equal(o["hap_words"], w["hap_words"]) and "hapProbs_t" not in w
