@@ -1406,21 +1406,36 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
         }
         const size_t budget = pn->arena.budget_shared(pn->share);
+        // device bytes per chain: read emissions -- pattern bytes (<= 2560 B) + table (512 B) per read, a dense Ks-column for
+        // the reads with more bases than the pattern width (an upper bound of those that end up dense) -- and the state matrices
+        std::vector<size_t> adds(n_chain);
+        for (int c = 0; c < n_chain; c++) {
+            const size_t R = read_off[c + 1] - read_off[c];
+            const int32_t *rp = read_ptr + read_off[c] + c;
+            size_t n_long = 0;
+            for (size_t r = 0; r < R; r++) n_long += std::min(rp[r + 1] - rp[r], o->Jmax + 1) > kMaxPatternBits;
+            adds[c] = R * (2560 + 512) + n_long * Ksp * 8 + (size_t)(o->ff != 0.0 ? 9 : 6) * G * Ksp * 8 + (size_t)3 * G * 8 +
+                      (want_probs ? (size_t)9 * T * 8 : 0) + 8192;
+        }
+        // A launch costs a chain's serial latency whatever it carries, so when the chains do not fit one launch they are cut
+        // into EQUAL launches (1 000 + 24 would cost two full launches for 1 024 chains; 512 + 512 costs the same two but
+        // leaves both at one chain per SIMD)
+        int n_launch = 1;
+        {
+            size_t need = (size_t)1 << 20;
+            for (int c = 0, first = 1; c < n_chain; c++, first = 0) {
+                if (!first && need + adds[c] > budget) { n_launch++; need = (size_t)1 << 20; }
+                need += adds[c];
+            }
+        }
+        const int target = (n_chain + n_launch - 1) / n_launch;
         int c0 = 0, ret = QA_OK;
         while (c0 < n_chain) {
             size_t need = (size_t)1 << 20;
             int c1 = c0;
-            while (c1 < n_chain) {
-                const size_t R = read_off[c1 + 1] - read_off[c1];
-                // read emissions: pattern bytes (<= 2560 B) + table (512 B) per read, a dense Ks-column for the reads with
-                // more bases than the pattern width (an upper bound of those that end up dense)
-                const int32_t *rp = read_ptr + read_off[c1] + c1;
-                size_t n_long = 0;
-                for (size_t r = 0; r < R; r++) n_long += std::min(rp[r + 1] - rp[r], o->Jmax + 1) > kMaxPatternBits;
-                const size_t add = R * (2560 + 512) + n_long * Ksp * 8 + (size_t)(o->ff != 0.0 ? 9 : 6) * G * Ksp * 8 + (size_t)3 * G * 8 +
-                                   (want_probs ? (size_t)9 * T * 8 : 0) + 8192;
-                if (c1 > c0 && need + add > budget) break;
-                need += add;
+            while (c1 < n_chain && c1 - c0 < target) {
+                if (c1 > c0 && need + adds[c1] > budget) break;
+                need += adds[c1];
                 c1++;
             }
             pn->arena.require(need);

@@ -20,8 +20,13 @@ from .sharding import get_sample_range
 
 class DeviceWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
-                 cu_partition: bool = False, fp64_dosage: bool = False):
+                 cu_partition: bool = False, fp64_dosage: bool = False, split: str = "halves"):
         self.n = n_workers
+        # "halves": every batch is cut into one contiguous part per thread; "alternate": whole batches go to the threads in turn
+        # (a thread's Gibbs launch then carries a whole batch's chains -- 1 024 at the defaults, one per SIMD -- instead of half)
+        if split not in ("halves", "alternate"):
+            raise ValueError("split must be 'halves' or 'alternate'")
+        self.split = split
         self.devs = [DevicePanel(panel) for _ in range(n_workers)]
         for w, d in enumerate(self.devs):
             d.set_device_share(n_workers)
@@ -53,6 +58,24 @@ class DeviceWorkers:
         contiguous parts, one per worker thread; every worker pipelines its own parts."""
         batches = list(batches)
         outs = [queue.Queue() for _ in range(self.n)]
+        if self.split == "alternate":
+            def work_alt(w: int):
+                try:
+                    for res in self.drivers[w].run_stream(batches[w::self.n]):
+                        outs[w].put(res)
+                except BaseException as e:   # surfaced by the consumer
+                    outs[w].put(e)
+            threads = [threading.Thread(target=work_alt, args=(w,), daemon=True) for w in range(self.n)]
+            for t in threads:
+                t.start()
+            for i in range(len(batches)):
+                res = outs[i % self.n].get()
+                if isinstance(res, BaseException):
+                    raise res
+                yield res
+            for t in threads:
+                t.join()
+            return
 
         def work(w: int):
             def parts():
