@@ -640,11 +640,30 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
         for (int h = 0; h < 3; h++) inside[ir][h] = 0;
     bool ever_changed = false;
 
-    for (int g = 0; g < G; g++) {
-        Col<NE> e[NH];
+    // the forward recursion's inputs are fetched a grid ahead (columns) or 64 grids at a time into lanes (block index,
+    // transition): a uniform value loaded through the vector path would have to be waited for, draining the column prefetch
+    Col<NE> e[NH];
 #pragma unroll
-        for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
-        const double t0 = g > 0 ? ch.tm0(g - 1) : 1.0, t1 = g > 0 ? ch.tm1(g - 1) : 0.0;
+    for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h]);
+    int where_l = -1;
+    double t0_l = 1.0, t1_l = 0.0;
+    for (int g = 0; g < G; g++) {
+        if ((g & 63) == 0) {
+            const int gg = g + ch.lane;
+            where_l = gg < G ? where[gg] : -1;
+            t0_l = (gg < G && gg > 0) ? ch.tm0(gg - 1) : 1.0;
+            t1_l = (gg < G && gg > 0) ? ch.tm1(gg - 1) : 0.0;
+        }
+        Col<NE> en[NH];
+        {
+            const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
+        }
+        const double t0 = rl_f64(t0_l, g & 63), t1 = rl_f64(t1_l, g & 63);
+        // the 18 normalisers of this grid (uniform values): lane 3 ir + h keeps d(ir, h), so that ONE logarithm per lane
+        // replaces 18 per lane (the same function on the same inputs)
+        double d_of_lane = 1.0;
         // ---- Rcpp_gibbs_block_forward_one (:1122-1253)
 #pragma unroll
         for (int ir = 0; ir < 6; ir++) {
@@ -664,12 +683,19 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
 #pragma unroll
             for (int h = 0; h < 3; h++) {
                 const double d = 1 / sm[h];
-                inside[ir][h] += log(d);
+                if (ch.lane == 3 * ir + h) d_of_lane = d;
 #pragma unroll
                 for (int q = 0; q < NE; q++) aS[ir][h].v[q] = d * nx[h].v[q];
             }
         }
-        const int iBlock = uni_i(where[g]);
+        {
+            const double lg = log(d_of_lane);
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++)
+#pragma unroll
+                for (int h = 0; h < 3; h++) inside[ir][h] += rl_f64(lg, 3 * ir + h);
+        }
+        const int iBlock = rl_i32(where_l, g & 63);
         if (iBlock > -1) {
             const int grid_start = uni_i(tab[iBlock]), grid_end = uni_i(tab[G + iBlock]);
             const int read_start = uni_i(tab[2 * G + iBlock]), read_end = uni_i(tab[3 * G + iBlock]);
@@ -832,8 +858,19 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
 #pragma unroll
                 for (int h = 0; h < 3; h++) logC_before[h] += log(uni_d(&ch.cv[h][g2]));
         }
+        {   // logC_after(h) -= log(c_h(g)): the three values in three lanes, one logarithm
+            double cv_of_lane = 1.0;
 #pragma unroll
-        for (int h = 0; h < 3; h++) logC_after[h] -= log(uni_d(&ch.cv[h][g]));
+            for (int h = 0; h < 3; h++) {
+                const double cvh = uni_d(&ch.cv[h][g]);
+                if (ch.lane == h) cv_of_lane = cvh;
+            }
+            const double lg = log(cv_of_lane);
+#pragma unroll
+            for (int h = 0; h < 3; h++) logC_after[h] -= rl_f64(lg, h);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; h++) e[h] = en[h];
     }
     block_sync();
     // ---- rcpp_sample_H_using_H_class (:213-246), then eMatGrid, forward and backward from scratch (:1898-1954)
