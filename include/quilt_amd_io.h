@@ -57,6 +57,9 @@ void qa_bam_opts_default(qa_bam_opts_t *opts);
  * Unpinned-vs-STITCH rules: the read's central SNP is its (n - 1) / 2-th site (lower median); the coverage cap visits sites
  * in ascending order and, at a site above the cap, drops the covering reads with the smallest counter-stream keys
  * (key = stream(seed, read index)) until the site is at the cap.
+ * A coordinate-sorted file with a BAI index beside it (<file>.bai or <file without .bam>.bai) is entered at the linear index's
+ * offset for the window's first 16 kb interval (SAM spec 5.1.3, 5.2) instead of being scanned from the top; without a usable
+ * index the file is scanned sequentially (and the scan stops once a sorted file has passed the window).
  * Reads come back ordered by the grid of their central SNP (stable), as snap_sampleReads_to_grid leaves them
  * (functions.R:295-298).  QA_ERR_INVALID for unreadable / malformed files and unknown chromosome names. */
 int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNPs, const int32_t *L, const char *ref,

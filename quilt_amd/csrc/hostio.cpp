@@ -69,6 +69,18 @@ struct BgzfReader {
         }
         return true;
     }
+    // position at a BGZF virtual file offset (compressed block start << 16 | offset inside the inflated block)
+    bool seek_virtual(uint64_t voff) {
+        if (fseeko(f, (off_t)(voff >> 16), SEEK_SET) != 0) { bad = true; return false; }
+        out.clear();
+        pos = 0;
+        eof = false;
+        if (!next_block()) return false;
+        const size_t u = (size_t)(voff & 0xffff);
+        if (u > out.size()) { bad = true; return false; }
+        pos = u;
+        return true;
+    }
     // exactly n bytes, or false at a clean end of file before the first byte (eof) / on a truncated stream (bad)
     bool read(void *dst, size_t n) {
         uint8_t *d = static_cast<uint8_t *>(dst);
@@ -142,6 +154,44 @@ inline uint64_t stream_key(uint64_t seed, uint64_t i) {   // the library's count
     return z ^ (z >> 31);
 }
 
+// linear-index offset of the 16 kb interval holding 0-based position pos0 of reference `ref` (0: no usable index)
+uint64_t bai_linear_offset(const char *bam_path, int32_t ref, int32_t pos0) {
+    std::string p1 = std::string(bam_path) + ".bai", p2 = bam_path;
+    if (p2.size() > 4 && p2.compare(p2.size() - 4, 4, ".bam") == 0) p2 = p2.substr(0, p2.size() - 4) + ".bai"; else p2.clear();
+    FILE *f = fopen(p1.c_str(), "rb");
+    if (!f && !p2.empty()) f = fopen(p2.c_str(), "rb");
+    if (!f) return 0;
+    uint64_t result = 0;
+    auto rd = [&](void *d, size_t n) { return fread(d, 1, n, f) == n; };
+    char magic[4];
+    int32_t n_ref = 0;
+    if (rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && ref < n_ref) {
+        bool ok = true;
+        for (int32_t r = 0; ok && r <= ref; r++) {
+            int32_t n_bin = 0, n_intv = 0;
+            ok = rd(&n_bin, 4) && n_bin >= 0;
+            for (int32_t b = 0; ok && b < n_bin; b++) {
+                uint32_t bin;
+                int32_t n_chunk = 0;
+                ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && fseeko(f, (off_t)n_chunk * 16, SEEK_CUR) == 0;
+            }
+            ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+            if (!ok) break;
+            if (r < ref) { ok = fseeko(f, (off_t)n_intv * 8, SEEK_CUR) == 0; continue; }
+            // the interval's own offset, or the next non-empty one (an interval no alignment overlaps holds 0 in some writers)
+            const int32_t first = std::min<int32_t>(pos0 >> 14, n_intv);
+            if (fseeko(f, (off_t)first * 8, SEEK_CUR) != 0) break;
+            for (int32_t i = first; i < n_intv; i++) {
+                uint64_t v = 0;
+                if (!rd(&v, 8)) break;
+                if (v != 0) { result = v; break; }
+            }
+        }
+    }
+    fclose(f);
+    return result;
+}
+
 struct Base { int32_t u, bq; };
 struct Read { std::vector<Base> b; bool alive = true; };
 
@@ -189,6 +239,13 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
         if (strcmp(name.c_str(), chr) == 0) target = i;
     }
     if (target < 0) return QA_ERR_INVALID;
+    // A coordinate-sorted file with a BAI index next to it (<file>.bai or <file without .bam>.bai): start at the linear
+    // index's offset for the window's first 16 kb interval -- the first alignment overlapping it (SAM spec 5.1.3) -- instead
+    // of scanning from the top of a whole-genome file.  Any problem with the index just means the sequential scan.
+    if (sorted) {
+        const uint64_t voff = bai_linear_offset(bam_path, target, o.chrStart > 0 ? o.chrStart - 1 : 0);
+        if (voff != 0 && !bz.seek_virtual(voff)) return QA_ERR_INVALID;
+    }
 
     auto *S = new qa_sample_reads;
     std::vector<Read> reads;

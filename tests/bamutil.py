@@ -52,9 +52,10 @@ def _record(ref_id, pos0, name, mapq, flag, cigar, seq, qual, next_ref=-1, next_
     return struct.pack("<i", len(body)) + body
 
 
-def write_bam(path, refs, alignments, sorted_header=True):
+def write_bam(path, refs, alignments, sorted_header=True, index=False, block=0xff00):
     """refs: [(name, length)]; alignments: dicts with ref_id, pos (1-based), name, mapq, flag, cigar [(n, op)], seq, qual
-    (list of ints) and optionally tlen."""
+    (list of ints) and optionally tlen.  index: also write <path>.bai holding the linear index (SAM spec 5.2; no bins -- the
+    loader only uses the linear index)."""
     text = ("@HD\tVN:1.6\tSO:%s\n" % ("coordinate" if sorted_header else "unsorted") +
             "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)).encode()
     data = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
@@ -63,8 +64,26 @@ def write_bam(path, refs, alignments, sorted_header=True):
         data += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
     recs = [_record(a["ref_id"], a["pos"] - 1, a["name"], a["mapq"], a["flag"], a["cigar"], a["seq"], a["qual"],
                     tlen=a.get("tlen", 0)) for a in alignments]
+    starts = np.cumsum([len(data)] + [len(r) for r in recs])[:-1]   # uncompressed offset of every record
+    raw = data + b"".join(recs)
+    blocks = [bgzf_block(raw[i:i + block]) for i in range(0, len(raw), block)]
     with open(path, "wb") as f:
-        f.write(bgzf_bytes(data + b"".join(recs)))
+        f.write(b"".join(blocks) + bgzf_block(b""))
+    if index:
+        coff = np.cumsum([0] + [len(b) for b in blocks])
+        lin = [dict() for _ in refs]
+        for a, p in zip(alignments, starts):
+            voff = (int(coff[p // block]) << 16) | int(p % block)
+            ref_len = sum(n for n, op in a["cigar"] if op in "MDN=X")
+            for w in range((a["pos"] - 1) >> 14, ((a["pos"] - 1 + max(ref_len, 1) - 1) >> 14) + 1):
+                if w not in lin[a["ref_id"]] or voff < lin[a["ref_id"]][w]:
+                    lin[a["ref_id"]][w] = voff
+        out = b"BAI\1" + struct.pack("<i", len(refs))
+        for d in lin:
+            n_intv = (max(d) + 1) if d else 0
+            out += struct.pack("<i", 0) + struct.pack("<i", n_intv) + b"".join(struct.pack("<Q", d.get(w, 0)) for w in range(n_intv))
+        with open(path + ".bai", "wb") as f:
+            f.write(out)
 
 
 def sample_to_alignments(sample, L, ref, alt, rng, read_len_pad=5, mapq=60, chrom_id=0, genome=None):

@@ -360,3 +360,37 @@ def test_accumulate_dosage_equals_the_r_expressions():
         assert np.array_equal(d, exp[0]) and np.array_equal(g, exp[1])
         if n_label == 3:
             assert np.array_equal(fd, exp[2]) and np.array_equal(fg, exp[3])
+
+
+def test_bai_linear_index_is_used(tmp_path):
+    """A coordinate-sorted BAM with a .bai next to it: the loader starts at the linear index's offset for the window (SAM spec
+    5.1.3) instead of scanning from the top -- the same reads, fewer alignments looked at -- including an alignment that
+    starts before the window and reaches into it."""
+    from quilt_amd.io import loadBamAndConvert
+    rng = np.random.default_rng(13)
+    L = (np.arange(400) * 500 + 1000).astype(np.int32)          # sites every 500 bp up to 200 kb
+    ref, alt = ["A"] * 400, ["C"] * 400
+    alns = [dict(ref_id=0, pos=int(p), name=f"o{i}", mapq=60, flag=0, cigar=[(50, "M")], seq="T" * 50, qual=[30] * 50)
+            for i, p in enumerate(np.sort(rng.integers(1, 150000, size=300)))]          # another chromosome first
+    pos = np.sort(rng.integers(1, 199000, size=800))
+    for i, p in enumerate(pos):
+        n = 700 if i % 97 == 0 else 120                            # a few long alignments spanning a 16 kb boundary region
+        seq = "".join(rng.choice(list("AC"), size=n))
+        alns.append(dict(ref_id=1, pos=int(p), name=f"r{i}", mapq=60, flag=0, cigar=[(n, "M")], seq=seq, qual=[30] * n))
+    long_one = dict(ref_id=1, pos=98000, name="span", mapq=60, flag=0, cigar=[(3000, "M")], seq="C" * 3000, qual=[30] * 3000)
+    alns.append(long_one)
+    alns.sort(key=lambda a: (a["ref_id"], a["pos"]))
+    plain, indexed = str(tmp_path / "plain.bam"), str(tmp_path / "indexed.bam")
+    bamutil.write_bam(plain, [("chr19", 10 ** 6), ("chr20", 10 ** 6)], alns, block=4096)
+    bamutil.write_bam(indexed, [("chr19", 10 ** 6), ("chr20", 10 ** 6)], alns, index=True, block=4096)
+    assert os.path.exists(indexed + ".bai")
+    for start, end in ((100000, 140000), (1, 30000), (163841, 200000), (0, 0)):
+        a, sa = loadBamAndConvert(plain, "chr20", L, ref, alt, chrStart=start, chrEnd=end, downsampleToCov=0, return_stats=True)
+        b, sb = loadBamAndConvert(indexed, "chr20", L, ref, alt, chrStart=start, chrEnd=end, downsampleToCov=0, return_stats=True)
+        _same(a, b)
+        assert a.nReads > 0
+        if start > 40000:
+            assert sb["alignments_on_chr"] < sa["alignments_on_chr"]        # the index skipped the alignments before the window
+    # the alignment that starts at 98 000 and reaches 101 000 is found for a window starting at 100 000
+    a, _ = loadBamAndConvert(indexed, "chr20", L, ref, alt, chrStart=100000, chrEnd=100600, downsampleToCov=0, return_stats=True)
+    assert any((a.bq[a.read_ptr[r]:a.read_ptr[r + 1]] > 0).all() and a.read_ptr[r + 1] - a.read_ptr[r] >= 5 for r in range(a.nReads))
