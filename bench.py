@@ -88,24 +88,52 @@ def _cpu_worker(args):
 _CPU_RC = None
 
 
+_BAM_DIR = None
+
+
 def _sample_worker(args):
     from quilt_amd.synth import make_synthetic_sample, make_synthetic_sample_rare_common
     seed, n_reads, mode = args
     if mode == "nipt":   # BASELINE configs[4]: mother + fetus, one fetal fraction for the batch
-        return make_synthetic_sample(_CPU_PANEL, seed=seed, n_reads=n_reads, ff=0.2)
-    if _CPU_RC is not None:   # the sample read over the common SNPs, with its all-SNP reads attached
-        return make_synthetic_sample_rare_common(_CPU_PANEL, _CPU_RC, seed, n_reads=n_reads)[0]
-    return make_synthetic_sample(_CPU_PANEL, seed=seed, n_reads=n_reads, mode=mode)
+        s = make_synthetic_sample(_CPU_PANEL, seed=seed, n_reads=n_reads, ff=0.2)
+    elif _CPU_RC is not None:   # the sample read over the common SNPs, with its all-SNP reads attached
+        s = make_synthetic_sample_rare_common(_CPU_PANEL, _CPU_RC, seed, n_reads=n_reads)[0]
+    else:
+        s = make_synthetic_sample(_CPU_PANEL, seed=seed, n_reads=n_reads, mode=mode)
+    if _BAM_DIR is not None:   # --bam: the sample also as a BAM file, which the run then reads back through the loader
+        from quilt_amd.synth import synthetic_alleles, write_synthetic_bam
+        ref, alt = synthetic_alleles(_CPU_PANEL.nSNPs, 1)
+        write_synthetic_bam(os.path.join(_BAM_DIR, f"s{seed}.bam"), s, _CPU_PANEL.L, ref, alt, seed=seed)
+    return s
 
 
-def make_samples(panel, seeds, n_reads, n_proc, mode="short", rare_common=None):
+def make_samples(panel, seeds, n_reads, n_proc, mode="short", rare_common=None, bam_dir=None):
     """Synthetic samples, generated by forked workers (before any HIP context exists in this process)."""
     import multiprocessing as mp
-    global _CPU_PANEL, _CPU_RC
+    global _CPU_PANEL, _CPU_RC, _BAM_DIR
     _CPU_PANEL = panel
     _CPU_RC = rare_common
+    _BAM_DIR = bam_dir
     with mp.get_context("fork").Pool(max(1, n_proc)) as pool:
         return pool.map(_sample_worker, [(sd, n_reads, mode) for sd in seeds], chunksize=4)
+
+
+def reload_from_bams(panel, flat, seeds, bam_dir):
+    """--bam: every sample is read back from its BAM file by the native loader (qa_bam_load_sample_reads)
+    and THAT is what the timed run imputes.  Returns the loaded samples and the loader's time per sample."""
+    from quilt_amd.io import loadBamAndConvert
+    from quilt_amd.synth import synthetic_alleles
+    ref, alt = synthetic_alleles(panel.nSNPs, 1)
+    out, t0 = [], time.perf_counter()
+    for s, sd in zip(flat, seeds):
+        # (bqFilter = 1, no coverage cap: the synthetic base qualities -- 5-15 in ONT mode -- and depths are the workload itself)
+        g = loadBamAndConvert(os.path.join(bam_dir, f"s{sd}.bam"), "chr20", panel.L, ref, alt, panel.grid, downsampleToCov=0,
+                              bqFilter=1)
+        if g.nReads != s.nReads or len(g.u) != len(s.u):
+            raise RuntimeError("the BAM loader did not give back the sample's reads")
+        g.truth_haps, g.ff, g.all_snp = s.truth_haps, s.ff, s.all_snp
+        out.append(g)
+    return out, (time.perf_counter() - t0) / max(len(flat), 1)
 
 
 def cpu_baseline(panel, n_reads, params, full_chains, ff=0.0):
@@ -207,6 +235,9 @@ def main():
                          "(QUILT2; not the headline workload, no CPU baseline)")
     ap.add_argument("--fp64-dosage", action="store_true",
                     help="dosage passes with fp64 state as the reference (qa_panel_set_dosage_precision(64)): the all-fp64 line")
+    ap.add_argument("--bam", action="store_true",
+                    help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
+                         "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
     ap.add_argument("--split", choices=["halves", "alternate"], default="halves",
                     help="how the host threads share the work: every batch cut in halves (default), or whole batches in turn")
     ap.add_argument("--mspbwt", action="store_true",
@@ -250,7 +281,18 @@ def main():
         cpu, keep = cpu_baseline(panel, a.reads, params, full_chains, ff=ff)
     n_steps = a.warmup + a.steps
     seeds = [1000 + (rank * n_steps + st) * a.batch + i for st in range(n_steps) for i in range(a.batch)]
-    flat = make_samples(panel, seeds, a.reads, min(32, max(1, physical_cores() // max(world, 1))), a.mode, rc)
+    bam_dir, bam_load_s = None, None
+    if a.bam:
+        import tempfile
+        if rc is not None:
+            raise SystemExit("--bam is not combined with --rare-common")
+        bam_dir = tempfile.mkdtemp(prefix="quilt_amd_bams_")
+    flat = make_samples(panel, seeds, a.reads, min(32, max(1, physical_cores() // max(world, 1))), a.mode, rc, bam_dir)
+    if a.bam:
+        flat, bam_load_s = reload_from_bams(panel, flat, seeds, bam_dir)
+        a.bam_load_s = bam_load_s
+        import shutil
+        shutil.rmtree(bam_dir, ignore_errors=True)
     samples = [flat[st * a.batch:(st + 1) * a.batch] for st in range(n_steps)]
 
     import torch
@@ -323,7 +365,8 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
         "vs_baseline": None,
         "dtype": "f64 throughout (Gibbs sampler, ranking passes, dosage passes)" if fp64 else
                  "f64 (Gibbs sampler, ranking passes) / f32 state with f64 emissions and sums (dosage passes)",
-        "data": "stub (no device work)" if a.stub else "synthetic",
+        "data": "stub (no device work)" if a.stub else
+                ("synthetic, through BAM files read by the native loader before the timed region" if a.bam else "synthetic"),
         "config": {"workload": f"{WORKLOADS[a.mode]}: {a.batch} synthetic 1x {a.mode}-read samples per GPU per step, "
                                f"{a.nsnps} SNPs ({panel.nGrids} grids, 2 Mb + buffers), K={a.K} haplotypes, {a.reads} reads/sample, "
                                "QUILT defaults (nGibbsSamples=7, n_seek_its=3, Ksubset=600), "
@@ -336,6 +379,8 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
                    "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
                                   "GPU, consecutive batches pipelined"},
     }
+    if getattr(a, "bam_load_s", None) is not None:
+        out["bam_load_ms_per_sample"] = 1e3 * a.bam_load_s
     if a.stub:
         out["stub"] = True
         out["roofline"] = None

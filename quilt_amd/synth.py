@@ -283,3 +283,71 @@ def make_synthetic_sample_rare_common(panel: Panel, rc: RareCommon, seed: int, n
     s_com.ff = s_all.ff = ff
     s_com.all_snp = s_all
     return s_com, s_all
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# synthetic BAM files (input-side data generator for `bench.py --bam`): one plain-M alignment per read
+# ---------------------------------------------------------------------------------------------------------------------------
+def synthetic_alleles(nSNPs: int, seed: int = 0):
+    """A reference / alternate base per SNP (two different letters of ACGT)."""
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 4, size=nSNPs)
+    alt = (ref + rng.integers(1, 4, size=nSNPs)) % 4
+    letters = np.array(list("ACGT"))
+    return "".join(letters[ref]), "".join(letters[alt])
+
+
+def write_synthetic_bam(path: str, sample: SampleReads, L: np.ndarray, ref: str, alt: str, chrom: str = "chr20",
+                        seed: int = 0, mapq: int = 60) -> None:
+    """The reads of ``sample`` as a coordinate-sorted BAM (BGZF, SAM spec 4.1-4.2): read r becomes one alignment spanning its
+    first to last SNP, showing the ref / alt allele with quality |bq| at its SNPs and a third base at every other SNP it
+    crosses, so that a pile-up over ``L`` gives back exactly the sample's (u, bq) lists."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(seed)
+    L = np.asarray(L, dtype=np.int64)
+    code = {"=": 0, "A": 1, "C": 2, "G": 4, "T": 8}
+    lut = np.zeros(256, dtype=np.uint8)
+    for k, v in code.items():
+        lut[ord(k)] = v
+    refb, altb = np.frombuffer(ref.encode(), dtype=np.uint8), np.frombuffer(alt.encode(), dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    # a base that is neither allele, per SNP
+    other = np.array([next(c for c in acgt if c != a and c != b) for a, b in zip(refb, altb)], dtype=np.uint8)
+    recs = []
+    for r in range(sample.nReads):
+        a, b = sample.read_ptr[r], sample.read_ptr[r + 1]
+        us, bqs = sample.u[a:b], sample.bq[a:b]
+        start, end = int(L[us[0]]), int(L[us[-1]])
+        n = end - start + 1
+        seq = acgt[rng.integers(0, 4, size=n)].copy()
+        qual = rng.integers(20, 41, size=n).astype(np.uint8)
+        lo, hi = np.searchsorted(L, start), np.searchsorted(L, end, side="right")
+        at = (L[lo:hi] - start).astype(np.int64)
+        seq[at] = other[lo:hi]
+        at_u = (L[us] - start).astype(np.int64)
+        seq[at_u] = np.where(bqs > 0, altb[us], refb[us])
+        qual[at_u] = np.abs(bqs).astype(np.uint8)
+        nib = lut[seq]
+        if n & 1:
+            nib = np.append(nib, 0)
+        packed = ((nib[0::2] << 4) | nib[1::2]).astype(np.uint8)
+        name = b"r%d\0" % r
+        body = (struct.pack("<iiBBHHHIiii", 0, start - 1, len(name), mapq, 4680, 1, 0, n, -1, -1, 0) + name +
+                struct.pack("<I", (n << 4) | 0) + packed.tobytes() + qual.tobytes())
+        recs.append((start, struct.pack("<i", len(body)) + body))
+    recs.sort(key=lambda t: t[0])
+    text = f"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:{chrom}\tLN:{int(L[-1]) + 1000}\n".encode()
+    nm = chrom.encode() + b"\0"
+    raw = (b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", len(nm)) + nm +
+           struct.pack("<i", int(L[-1]) + 1000) + b"".join(x for _, x in recs))
+
+    def block(data: bytes) -> bytes:
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = co.compress(data) + co.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+    with open(path, "wb") as f:
+        for i in range(0, len(raw), 0xff00):
+            f.write(block(raw[i:i + 0xff00]))
+        f.write(block(b""))

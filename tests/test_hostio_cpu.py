@@ -394,3 +394,24 @@ def test_bai_linear_index_is_used(tmp_path):
     # the alignment that starts at 98 000 and reaches 101 000 is found for a window starting at 100 000
     a, _ = loadBamAndConvert(indexed, "chr20", L, ref, alt, chrStart=100000, chrEnd=100600, downsampleToCov=0, return_stats=True)
     assert any((a.bq[a.read_ptr[r]:a.read_ptr[r + 1]] > 0).all() and a.read_ptr[r + 1] - a.read_ptr[r] >= 5 for r in range(a.nReads))
+
+
+def test_synthetic_bam_generator_round_trip(tmp_path):
+    """quilt_amd/synth.py::write_synthetic_bam (the input-side generator behind `bench.py --bam`) against the native loader:
+    the pile-up gives back the sample's reads (as a multiset: the file is coordinate-sorted), and the file is well-formed BGZF."""
+    from quilt_amd.io import loadBamAndConvert
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample, synthetic_alleles, write_synthetic_bam
+    panel = make_synthetic_panel(K=300, nSNPs=3200, seed=3)
+    ref, alt = synthetic_alleles(panel.nSNPs, 1)
+    assert all(a != b for a, b in zip(ref, alt))
+    for mode, n in (("short", 1500), ("ont", 40)):
+        s = make_synthetic_sample(panel, seed=5, n_reads=n, mode=mode)
+        path = str(tmp_path / f"{mode}.bam")
+        write_synthetic_bam(path, s, panel.L, ref, alt, seed=2)
+        assert bamutil.bgzf_decompress(open(path, "rb").read())[:4] == b"BAM\x01"
+        # (the ONT-style synthetic reads carry base qualities 5-15: below the default bqFilter = 17 the loader drops them all)
+        assert mode != "ont" or loadBamAndConvert(path, "chr20", panel.L, ref, alt, panel.grid).nReads == 0
+        g = loadBamAndConvert(path, "chr20", panel.L, ref, alt, panel.grid, downsampleToCov=0, bqFilter=1)
+        key = lambda x: sorted((tuple(x.u[x.read_ptr[r]:x.read_ptr[r + 1]]), tuple(x.bq[x.read_ptr[r]:x.read_ptr[r + 1]]))
+                               for r in range(x.nReads))
+        assert g.nReads == s.nReads and key(g) == key(s) and np.array_equal(g.wif, np.sort(s.wif))
