@@ -289,6 +289,7 @@ def main():
         bam_dir = tempfile.mkdtemp(prefix="quilt_amd_bams_")
     flat = make_samples(panel, seeds, a.reads, min(32, max(1, physical_cores() // max(world, 1))), a.mode, rc, bam_dir)
     if a.bam:
+        import torch  # noqa: F401  (before libquilt_amd.so is loaded: both must resolve the HIP runtime torch ships, see main())
         flat, bam_load_s = reload_from_bams(panel, flat, seeds, bam_dir)
         a.bam_load_s = bam_load_s
         import shutil
