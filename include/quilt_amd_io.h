@@ -152,6 +152,12 @@ int qa_select_new_haps_mspbwt(int32_t n_chain, int32_t n_label, int32_t nindices
                               const int32_t *n_match, int32_t Knew, int32_t Kfull, int32_t nGrids, const uint64_t *seed,
                               int32_t *out);
 
+/* Read confidence and consensus read labels of one sample before its phasing pass (QUILT/R/functions.R:1615-1660, :1680-1784,
+ * NIPT :1788-1829).  labels n x nReads (Gibbs-sample-major); p n x K x nReads: the reads' likelihoods against each Gibbs sample's
+ * K haplotypes (K = 2, or 3 for NIPT: label 3 is folded into 2 for the consensus and put back); minrp 0.95; can_hap 1-based. */
+int qa_consensus_read_labels(int32_t nReads, int32_t n, const int32_t *labels, const double *p, int32_t K, double minrp,
+                             int32_t can_hap, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

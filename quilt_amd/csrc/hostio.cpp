@@ -736,6 +736,99 @@ int qa_select_new_haps_mspbwt(int32_t n_chain, int32_t n_label, int32_t nindices
     return QA_OK;
 }
 
+// Read confidence and consensus labels of one sample (QUILT/R/functions.R:1615-1660 assess_ability_of_reads_to_be_confident,
+// :1680-1784 determine_best_read_label_so_far, :1788-1829 its NIPT wrapper): from the Gibbs samples' read labels and the
+// reads' likelihoods against each sample's haplotypes, the labels the phasing pass starts from.  The suffix rewrites of
+// the reference's working matrix are kept as flip parities (quilt_amd/driver.py has the numpy text and the line-by-line
+// form this is tested against), including that the final flip starts at the LAST change point counted in the filtered rows.
+//   labels  n x nReads (chain-major) read labels of the n Gibbs samples; p  n x K x nReads likelihoods (K = 2, or 3: NIPT)
+int qa_consensus_read_labels(int32_t nReads, int32_t n, const int32_t *labels, const double *p, int32_t K, double minrp,
+                             int32_t can_hap, int32_t *out) {
+    if (nReads < 0 || n < 1 || !labels || !p || (K != 2 && K != 3) || can_hap < 1 || can_hap > n || !out) return QA_ERR_INVALID;
+    const bool nipt = K == 3;
+    const size_t R = (size_t)nReads;
+    std::vector<int32_t> rl((size_t)n * R);
+    std::vector<uint8_t> conf((size_t)n * R);
+    for (int32_t c = 0; c < n; c++) {
+        const double *pc = p + (size_t)c * K * R;
+        for (size_t r = 0; r < R; r++) {
+            double mp;
+            if (!nipt) {
+                mp = pc[r] / (pc[r] + pc[R + r]);
+                if (std::isnan(mp)) mp = 0.5;
+                if (mp < 0.5) mp = 1 - mp;
+            } else {
+                const double sum = pc[r] + pc[R + r] + pc[2 * R + r];
+                const double q0 = pc[r] / sum, q1 = pc[R + r] / sum, q2 = pc[2 * R + r] / sum;
+                mp = q0;
+                if (q1 > q0) mp = q1;
+                if (q2 > mp) mp = q2;
+                if (std::isnan(mp)) mp = 1.0 / 3;
+            }
+            int32_t l = labels[(size_t)c * R + r];
+            bool cf = mp > minrp;
+            if (nipt && l == 3) { cf = false; l = 2; }   // label 3 folded into 2 and called not confident (:1800-1806)
+            rl[(size_t)c * R + r] = l;
+            conf[(size_t)c * R + r] = cf;
+        }
+    }
+    const int32_t can = can_hap - 1;
+    for (size_t r = 0; r < R; r++) out[r] = rl[(size_t)can * R + r];
+    auto finish = [&]() {
+        if (nipt) for (size_t r = 0; r < R; r++) if (labels[(size_t)can * R + r] == 3) out[r] = 3;
+        return (int)QA_OK;
+    };
+    std::vector<size_t> keep;
+    for (size_t r = 0; r < R; r++) {
+        bool all = true;
+        for (int32_t c = 0; c < n && all; c++) all = conf[(size_t)c * R + r] != 0;
+        if (all) keep.push_back(r);
+    }
+    if (keep.size() < 10) return finish();
+    auto L0 = [&](size_t i, int32_t c) { return (int64_t)rl[(size_t)c * R + keep[i]]; };
+    auto rowsum = [&](size_t i) { int64_t s = 0; for (int32_t c = 0; c < n; c++) s += std::llabs(L0(i, c) - L0(i, can)); return s; };
+    std::vector<size_t> change;   // filtered rows at which the pattern of disagreements changes (0-based)
+    {
+        int64_t prev = rowsum(0);
+        for (size_t i = 1; i < keep.size(); i++) {
+            const int64_t cur = rowsum(i);
+            if (cur != prev) change.push_back(i);
+            prev = cur;
+        }
+    }
+    if (change.empty()) return finish();
+    std::vector<uint8_t> fc((size_t)n, 0), flipped((size_t)n, 0);
+    bool fcan = false;
+    const double half = n / 2.0;
+    std::vector<int32_t> changed;
+    for (size_t i : change) {
+        const int64_t canv = fcan ? 3 - L0(i, can) : L0(i, can);
+        changed.clear();
+        for (int32_t c = 0; c < n; c++) {
+            const int64_t lab = fc[(size_t)c] ? 3 - L0(i, c) : L0(i, c);
+            if (lab - canv != 0) changed.push_back(c);
+        }
+        if (!changed.empty()) {
+            if ((double)changed.size() > half) {   // the majority moved: it is the canonical haplotype that flips
+                std::vector<int32_t> others;
+                for (int32_t c = 0; c < n; c++) {
+                    const int64_t lab = fc[(size_t)c] ? 3 - L0(i, c) : L0(i, c);
+                    if (lab - canv == 0) others.push_back(c);
+                }
+                changed.swap(others);
+                fcan = !fcan;
+            }
+            for (int32_t c : changed) fc[(size_t)c] ^= 1;
+        }
+        for (int32_t c : changed) flipped[(size_t)c] = 1;
+    }
+    if (flipped[(size_t)can]) {
+        const size_t w0 = change.back();   // s1[i] - 1 with the loop's last i: an index into the UNFILTERED reads
+        for (size_t r = w0; r < R; r++) out[r] = 3 - out[r];
+    }
+    return finish();
+}
+
 int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const char *text, int64_t n) {
     if (!path || (!text && n > 0) || n < 0) return QA_ERR_INVALID;
     BgzfWriter w(path, bgzf != 0, truncate != 0);

@@ -794,12 +794,17 @@ class Driver:
             haps = [ch.hap for ch in b.chains]
         conf = self.backend.read_confidence_batch([ch.sample for ch in b.chains], haps, P.maxDifferenceBetweenReads)
         b.phasing = []
+        from .io import consensus_read_labels
+        by_sample: dict = {}
+        for k, ch in enumerate(b.chains):
+            by_sample.setdefault(ch.i_sample, []).append(k)
         for i, smp in enumerate(b.samples):
-            mine = [k for k, ch in enumerate(b.chains) if ch.i_sample == i]
-            rl_all = np.stack([b.chains[k].read_labels for k in mine], axis=1)
-            rl_conf = np.stack([assess_ability_of_reads_to_be_confident(conf[k]) for k in mine], axis=1)
-            consensus = determine_best_read_label_so_far_nipt if P.method == "nipt" else determine_best_read_label_so_far
-            labels = consensus(rl_all, rl_conf, smp.nReads, P.nGibbsSamples, can_hap=P.nGibbsSamples)
+            mine = by_sample.get(i, [])
+            # assess_ability_of_reads_to_be_confident + determine_best_read_label_so_far(_nipt) (functions.R:1615-1660, :1680-1829),
+            # native; the numpy text of both stays in this module as the tested statement of what it does
+            labels = consensus_read_labels(np.stack([b.chains[k].read_labels for k in mine]),
+                                           np.stack([np.asarray(conf[k], dtype=np.float64) for k in mine]),
+                                           can_hap=P.nGibbsSamples)
             last = b.chains[mine[-1]]
             b.phasing.append(ChainState(smp, i, P.nGibbsSamples + 1, chain_rng(P.seed, b.offset + i, P.nGibbsSamples + 1),
                                         which_haps_to_use=last.which_haps_to_use.copy(), read_labels=labels, _phasing=True))

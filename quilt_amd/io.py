@@ -32,7 +32,7 @@ def _io_lib():
     if not getattr(L, "_io_ready", False):
         for name in ("qa_bam_load_sample_reads", "qa_sample_reads_n_reads", "qa_sample_reads_export", "qa_vcf_column_diploid",
                      "qa_vcf_column_nipt", "qa_vcf_info_column", "qa_vcf_write_body", "qa_vcf_write_text", "qa_hwe_exact",
-                     "qa_accumulate_dosage"):
+                     "qa_accumulate_dosage", "qa_consensus_read_labels"):
             getattr(L, name).restype = C.c_int
         L.qa_sample_reads_n_bases.restype = C.c_int64
         L.qa_vcf_missing_entry.restype = C.c_char_p
@@ -60,6 +60,21 @@ def accumulate_dosage(hap: np.ndarray, chain_sample: np.ndarray, dosage: np.ndar
     _check(_io_lib().qa_accumulate_dosage(C.c_int32(n_chain), C.c_int32(n_label), C.c_int32(T), ptr(hap), ptr(cs),
                                           C.c_int32(dosage.shape[0]), ptr(dosage), ptr(gp_t), ptr(fet_dosage), ptr(fet_gp_t)),
            "qa_accumulate_dosage")
+
+
+def consensus_read_labels(labels: np.ndarray, p: np.ndarray, can_hap: int, minrp: float = 0.95) -> np.ndarray:
+    """Read confidence + consensus labels of one sample before its phasing pass (functions.R:1615-1660, :1680-1784, NIPT
+    :1788-1829), native: ``labels`` [n Gibbs samples, nReads], ``p`` [n, K, nReads] read likelihoods against each Gibbs sample's
+    K haplotypes (K = 3: NIPT).  The numpy text of the same functions is in quilt_amd/driver.py (tested equal)."""
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    n, R = labels.shape
+    if p.shape[0] != n or p.shape[2] != R or p.shape[1] not in (2, 3):
+        raise ValueError("p must be [n, 2 or 3, nReads]")
+    out = np.zeros(R, dtype=np.int32)
+    _check(_io_lib().qa_consensus_read_labels(C.c_int32(R), C.c_int32(n), ptr(labels), ptr(p), C.c_int32(p.shape[1]),
+                                              C.c_double(minrp), C.c_int32(can_hap), ptr(out)), "qa_consensus_read_labels")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -361,3 +361,36 @@ def test_bam_to_vcf_end_to_end_on_the_cpu_path(tmp_path, small_panel):
         assert len(gt) == 3 and gt[1] == "|"
     assert all(r[9 + 1] == "./.:.,.,.:.:.,." for r in rows)
     assert rows[5][8] == "GT:GP:DS:HD" and rows[5][7].startswith("EAF=")
+
+
+def test_native_consensus_equals_the_numpy_text():
+    """csrc/hostio.cpp qa_consensus_read_labels against assess_ability_of_reads_to_be_confident + determine_best_read_label_so_far
+    (and its NIPT wrapper) of quilt_amd/driver.py, themselves tested against the line-by-line form: random label matrices with
+    switch points, flipped runs, unconfident reads, NaN likelihoods, fewer than 10 confident rows."""
+    from quilt_amd.io import consensus_read_labels
+    rng = np.random.default_rng(17)
+    for trial in range(60):
+        n = int(rng.choice([1, 2, 3, 7]))
+        R = int(rng.choice([5, 40, 600]))
+        K = int(rng.choice([2, 3]))
+        base = rng.integers(1, 3, size=R)
+        lab = np.empty((n, R), dtype=np.int32)
+        for c in range(n):
+            x = base.copy()
+            for cut in rng.integers(0, R, size=int(rng.integers(0, 4))):      # runs with flipped labels
+                x[cut:] = 3 - x[cut:]
+            noise = rng.random(R) < 0.03
+            x[noise] = 3 - x[noise]
+            lab[c] = x
+        if K == 3:
+            lab[rng.random((n, R)) < 0.1] = 3
+        p = rng.random((n, K, R)) ** 8
+        p[:, :, rng.random(R) < 0.02] = 0.0                                     # 0 / 0 -> NaN -> 0.5 (1 / 3)
+        if trial % 7 == 0:
+            p[:] = 0.5                                                           # nothing confident
+        can = int(rng.integers(1, n + 1))
+        got = consensus_read_labels(lab, p, can_hap=can)
+        conf = np.stack([D.assess_ability_of_reads_to_be_confident(p[c]) for c in range(n)], axis=1)
+        fn = D.determine_best_read_label_so_far_nipt if K == 3 else D.determine_best_read_label_so_far
+        ref = fn(lab.T.copy(), conf, R, n, can_hap=can)
+        assert np.array_equal(got, ref), (trial, n, R, K, can)
