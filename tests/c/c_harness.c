@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "../../include/quilt_amd.h"
+#include "../../include/quilt_amd_io.h"
 
 #define NK 512
 #define NT 256
@@ -40,6 +41,30 @@ int main(void) {
     d.eMatDH_special_matrix_helper = helper; d.eMatDH_special_matrix = spmat; d.eMatDH_special_matrix_nrow = 0;
     d.use_eMatDH_special_symbols = 1; d.transMatRate_t = tm; d.ref_error = 1e-3;
     printf("abi %d, devices %d\n", qa_abi_version(), qa_device_count());
+    {   /* the host-side formats (include/quilt_amd_io.h) need no device: one VCF column, INFO strings, the consensus labels */
+        const double gp[3 * 2] = {1.0, 0.0, 0.0, 0.05, 0.9, 0.05}, hd[2 * 2] = {0.0, 0.6, 0.0, 0.4};   /* 3 x 2; 2 x 2 col-major */
+        char buf[256];
+        int64_t off[3], need = 0;
+        CHECK(qa_vcf_column_diploid(2, gp, hd, 0, buf, sizeof buf, off, &need) == QA_OK, "qa_vcf_column_diploid");
+        CHECK(strcmp(buf + off[0], "0/0:1.000,0.000,0.000:0.000:0.000,0.000") == 0, "VCF entry 0");
+        CHECK(strcmp(buf + off[1], "0/1:0.050,0.900,0.050:1.000:0.600,0.400") == 0, "VCF entry 1");
+        CHECK(qa_vcf_column_diploid(2, gp, hd, 1, buf, 8, off, &need) == QA_ERR_CAPACITY && need > 8, "capacity protocol");
+        CHECK(strcmp(qa_vcf_missing_entry(), "./.:.,.,.:.:.,.") == 0, "missing entry");
+        const double counts[3] = {25, 50, 25};
+        double pv = 0;
+        CHECK(qa_hwe_exact(1, counts, &pv) == QA_OK && pv > 0.9 && pv <= 1.0, "qa_hwe_exact");
+        int32_t lab[2 * 12], cons[12];
+        double pr[2 * 2 * 12];
+        for (int c = 0; c < 2; c++)
+            for (int r = 0; r < 12; r++) {
+                lab[c * 12 + r] = 1 + (r & 1);
+                pr[(c * 2 + 0) * 12 + r] = (r & 1) ? 0.01 : 0.99;
+                pr[(c * 2 + 1) * 12 + r] = (r & 1) ? 0.99 : 0.01;
+            }
+        CHECK(qa_consensus_read_labels(12, 2, lab, pr, 2, 0.95, 2, cons) == QA_OK, "qa_consensus_read_labels");
+        for (int r = 0; r < 12; r++) CHECK(cons[r] == 1 + (r & 1), "agreeing Gibbs samples keep their labels");
+        printf("HOST_FORMATS_OK\n");
+    }
     qa_panel_t *panel = NULL;
     int st = qa_panel_create(&d, &panel);
     if (st == QA_ERR_NO_DEVICE) { printf("NO_DEVICE\n"); return 0; }

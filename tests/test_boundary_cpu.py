@@ -35,3 +35,4 @@ def test_c_harness_builds_and_reports_no_device_here():
     run = subprocess.run([os.path.join(ROOT, "tests", "c", "c_harness")], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "HARNESS_OK" in run.stdout or "NO_DEVICE" in run.stdout
+    assert "HOST_FORMATS_OK" in run.stdout   # include/quilt_amd_io.h from plain C: needs no device
