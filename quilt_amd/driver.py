@@ -994,7 +994,8 @@ class HipBackend:
         cs = np.ascontiguousarray(chain_sample, dtype=np.int32)
         wd = np.ascontiguousarray(want_dosage, dtype=np.int32)
         wt = np.ascontiguousarray(want_top, dtype=np.int32)
-        dosage = np.zeros((n_chain, n_label, T)) if wd.any() else None
+        # (np.empty when every chain's rows are written: zero-filling ~1 GB per dosage round costs more than the copy back)
+        dosage = (np.empty((n_chain, n_label, T)) if wd.all() else np.zeros((n_chain, n_label, T))) if wd.any() else None
         cnt = np.zeros((n_chain, n_label, n_thin), dtype=np.int32)
         head = (self.dev.handle, C.c_int32(n_chain), C.c_int32(n_label), C.c_int32(n_sample), ptr(cs), ptr(read_off),
                 ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(wt), ptr(cols), C.c_int32(K_top_matches),
