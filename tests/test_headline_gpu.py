@@ -171,3 +171,24 @@ def test_dosage_pass_headline_size(head_panel, head_dev, head_gl, oracle):
     assert np.abs(got64["dosage"] - ref["dosage"]).max() <= 1e-9
     np.testing.assert_allclose(np.log(got64["c"]).sum(), np.log(ref["c"]).sum(), rtol=1e-12)
     check_best_haps(got64["best_haps_stuff_list"], ref["best_haps"])
+
+
+def test_haplotype_search_headline_size(head_panel, head_dev):
+    """msPBWT mode's search at K = 50 000 x 2 000 grids (four interleaved indices, QUILT's defaults): the device's tables equal
+    the numpy statement of the definition -- integer work, identical."""
+    from quilt_amd.mspbwt import find_good_matches, match_tables_as_lists, rcpp_int_contract
+    from quilt_amd.synth import make_truth_haplotype, panel_hap_bits
+    from tests.oracle_backend import find_good_matches_bruteforce
+    rng = np.random.default_rng(3)
+    queries = [panel_hap_bits(head_panel, 12345), make_truth_haplotype(head_panel, rng)]
+    noisy = queries[1].copy()
+    flip = rng.random(len(noisy)) < 0.002
+    noisy[flip] = 1 - noisy[flip]
+    queries.append(noisy)
+    Zs = np.stack([rcpp_int_contract(q) for q in queries])
+    got = match_tables_as_lists(*find_good_matches(head_dev, Zs, 4, 1, 150))
+    ref = find_good_matches_bruteforce(head_panel, Zs, 4, 1, 150)
+    for q in range(len(Zs)):
+        for i in range(4):
+            assert np.array_equal(got[q][i], ref[q][i]), (q, i)
+    assert got[0][0][:, 2].max() == len(range(0, head_panel.nGrids, 4)) or (np.asarray(head_panel.hapMatcherR)[12345, 0::4] == 0).any()
