@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
+    ap.add_argument("--gibbs-gate", type=float, default=0.0, metavar="SEC",
+                    help="host threads wait up to SEC for each other before a Gibbs launch, so that the two launches overlap fully")
     ap.add_argument("--split", choices=["halves", "alternate"], default="halves",
                     help="how the host threads share the work: every batch cut in halves (default), or whole batches in turn")
     ap.add_argument("--mspbwt", action="store_true",
@@ -316,7 +318,7 @@ def main():
         from quilt_amd.workers import DeviceWorkers
         native.check(native.lib().qa_set_device(local_rank))
         drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
-                            cu_partition=a.cu_partition, fp64_dosage=a.fp64_dosage, split=a.split)
+                            cu_partition=a.cu_partition, fp64_dosage=a.fp64_dosage, split=a.split, gibbs_gate=a.gibbs_gate)
 
     def barrier():
         if not a.stub:

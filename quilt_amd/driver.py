@@ -524,6 +524,7 @@ class Driver:
         self.n_underflow_retries = 0     # Gibbs calls repeated with a smaller maxDifferenceBetweenReads
         self.n_device_selections = 0     # chains whose next small panel was chosen by csrc/select.hip
         self._zero_hap = None
+        self.gibbs_gate = None           # workers.PairGate shared by the host threads of a device, or None
         self._round_dosages = None
         self._round_dosage_chains = []
 
@@ -712,6 +713,8 @@ class Driver:
             for md, idx in groups.items():
                 if P.method == "nipt":   # every chain carries its sample's fetal fraction (functions.R:128)
                     kw = dict(kw, ff=[float(chains[i].sample.ff) for i in idx], shuffle_bin_radius=P.shuffle_bin_radius)
+                if self.gibbs_gate is not None and n_try == 0:
+                    self.gibbs_gate.wait()   # start together with the other host thread's launch (workers.PairGate)
                 out = self.backend.gibbs_batch(
                     [samples[i] for i in idx], [chains[i].which_haps_to_use for i in idx],
                     [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],

@@ -18,9 +18,34 @@ from .native import DevicePanel, DeviceRareCommon
 from .sharding import get_sample_range
 
 
+class PairGate:
+    """Optional meeting point of the host threads right before their Gibbs launches: a launch of 512 chains fills half the
+    SIMDs and takes the chain's serial latency whatever runs beside it, so two launches that start together cost one launch
+    time, two that start 0.3 s apart cost 1.3.  A thread waits at most ``timeout`` seconds for the others, then goes alone."""
+
+    def __init__(self, n: int, timeout: float):
+        self.n, self.timeout = n, timeout
+        self.cv = threading.Condition()
+        self.count, self.gen = 0, 0
+
+    def wait(self) -> bool:
+        with self.cv:
+            gen = self.gen
+            self.count += 1
+            if self.count >= self.n:
+                self.gen += 1
+                self.count = 0
+                self.cv.notify_all()
+                return True
+            ok = self.cv.wait_for(lambda: self.gen != gen, self.timeout)
+            if not ok:
+                self.count -= 1
+            return ok
+
+
 class DeviceWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
-                 cu_partition: bool = False, fp64_dosage: bool = False, split: str = "halves"):
+                 cu_partition: bool = False, fp64_dosage: bool = False, split: str = "halves", gibbs_gate: float = 0.0):
         self.n = n_workers
         # "halves": every batch is cut into one contiguous part per thread; "alternate": whole batches go to the threads in turn
         # (a thread's Gibbs launch then carries a whole batch's chains -- 1 024 at the defaults, one per SIMD -- instead of half)
@@ -36,6 +61,10 @@ class DeviceWorkers:
                 d.set_cu_partition(w, n_workers)
         self.drcs = [DeviceRareCommon(d, rare_common) if rare_common is not None else None for d in self.devs]
         self.drivers = [Driver(panel, HipBackend(d, r), params, rare_common=rare_common) for d, r in zip(self.devs, self.drcs)]
+        if gibbs_gate > 0 and n_workers > 1:
+            gate = PairGate(n_workers, gibbs_gate)
+            for d in self.drivers:
+                d.gibbs_gate = gate
 
     @property
     def timing(self):
