@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per sample (default 20000; 300 with --mode ont)")
     ap.add_argument("--mode", choices=["short", "ont", "nipt"], default="short",
                     help="read model (ont: BASELINE configs[3]; nipt: configs[4], method = nipt with ff = 0.2)")
-    ap.add_argument("--workers", type=int, default=2, help="host threads per GPU (each with its own stream and arena)")
+    ap.add_argument("--workers", type=int, default=4, help="host threads per GPU (each with its own stream and arena)")
     ap.add_argument("--rare-common", type=float, default=0.0, metavar="F",
                     help="impute_rare_common with F x nsnps rare SNPs: every Gibbs sample ends with a Gibbs call over all SNPs "
                          "(QUILT2; not the headline workload, no CPU baseline)")
@@ -238,10 +238,13 @@ def main():
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
+    ap.add_argument("--pass-priority", type=int, default=0, choices=(0, 1),
+                    help="full-panel calls on a highest-priority stream (qa_panel_set_pass_priority)")
     ap.add_argument("--gibbs-gate", type=float, default=0.0, metavar="SEC",
                     help="host threads wait up to SEC for each other before a Gibbs launch, so that the two launches overlap fully")
-    ap.add_argument("--split", choices=["halves", "alternate"], default="halves",
-                    help="how the host threads share the work: every batch cut in halves (default), or whole batches in turn")
+    ap.add_argument("--split", choices=["halves", "alternate"], default="alternate",
+                    help="how the host threads share the work: whole batches in turn (default: a thread's Gibbs launch then carries "
+                         "a whole batch's chains, one per SIMD at the defaults), or every batch cut into one part per thread")
     ap.add_argument("--mspbwt", action="store_true",
                     help="use_mspbwt = TRUE (mode M2): no full-panel pass; the small panel is re-selected from long matches of the "
                          "Gibbs call's haploid dosages against the panel (device search, csrc/match.hip); no CPU baseline")
@@ -318,7 +321,8 @@ def main():
         from quilt_amd.workers import DeviceWorkers
         native.check(native.lib().qa_set_device(local_rank))
         drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
-                            cu_partition=a.cu_partition, fp64_dosage=a.fp64_dosage, split=a.split, gibbs_gate=a.gibbs_gate)
+                            cu_partition=a.cu_partition, fp64_dosage=a.fp64_dosage, split=a.split, gibbs_gate=a.gibbs_gate,
+                            pass_priority=bool(a.pass_priority))
 
     def barrier():
         if not a.stub:
@@ -350,6 +354,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    from quilt_amd import trace
+    trace.dump()   # host span trace, only with QUILT_AMD_TRACE=<file>
     if rank == 0:
         out = report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu, keep, ff, full_chains)
         print(json.dumps(out))
@@ -380,7 +386,8 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
                    "inputs": "host buffers cross PCIe inside the timed region (reads per call, labels, seeds; dosages and top "
                              "lists back): value is the PCIe-inclusive rate",
                    "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
-                                  "GPU, consecutive batches pipelined"},
+                                  "GPU (" + ("whole batches in turn" if a.split == "alternate" else "every batch cut into one part per thread") +
+                                  "), consecutive batches pipelined"},
     }
     if getattr(a, "bam_load_s", None) is not None:
         out["bam_load_ms_per_sample"] = 1e3 * a.bam_load_s
@@ -414,7 +421,8 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
         def _flag(name, default):   # the value a flag had in the profiled command (absent = bench.py's default)
             m = re.search(rf"--{name}[ =](\S+)", pmc["command"])
             return m.group(1) if m else str(default)
-        same_workload = (_flag("batch", 128) == str(a.batch) and _flag("workers", 2) == str(a.workers) and
+        same_workload = (_flag("batch", 128) == str(a.batch) and _flag("workers", 4) == str(a.workers) and
+                         _flag("split", "alternate") == a.split and
                          _flag("mode", "short") == a.mode and _flag("K", 50000) == str(a.K) and
                          "--mspbwt" not in pmc["command"] and "--fp64-dosage" not in pmc["command"])
         if same_workload and rc is None and not fp64 and not a.mspbwt:

@@ -22,6 +22,7 @@
 #ifndef QUILT_AMD_H
 #define QUILT_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -47,6 +48,20 @@ int qa_device_count(void);
 /* Bind the calling thread (and the objects it creates) to a device.  Must be called
  * in the worker process itself: HIP contexts do not survive fork (quilt.R:692). */
 int qa_set_device(int device);
+
+/* Host buffers the device reads and writes directly (pinned, device-visible).  Every entry point accepts any host pointer;
+ * a buffer that lies inside a qa_host_alloc region skips the library's pinned staging copy -- worth it for the large,
+ * reused ones (a dosage round returns n_chain x n_label x nSNPs doubles: 1 GB at 1 024 passes x 64 000 SNPs, whose staged
+ * copy into fresh pageable memory costs ten times the transfer).  R's own vectors (the reference's caller,
+ * functions.R:2043-2068) cannot live there: the shim keeps the staged path.  qa_host_alloc returns NULL on failure
+ * (qa_last_error); qa_host_free returns QA_ERR_INVALID for a pointer it did not hand out. */
+void *qa_host_alloc(size_t bytes);
+int qa_host_free(void *p);
+
+/* Diagnostic: milliseconds (best of three) of one transfer of `bytes` between device memory and a host buffer.  mode 0: the
+ * library's copy kernel on a pinned buffer (what a qa_host_alloc buffer gets), 1: hipMemcpyAsync on a pinned buffer,
+ * 2: the staged path into pageable memory (what any other host pointer gets). */
+int qa_selftest_copy_rate(int32_t to_device, size_t bytes, int32_t mode, double *ms);
 
 /* Per-kernel accumulators since the last reset, measured with HIP events on the launch stream
  * (replaces print_times(), copied-from-stitch.cpp:31-45).  Kernels are numbered 0 .. qa_profile_count() - 1 and named by
@@ -143,6 +158,15 @@ int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers);
  * the other thread's passes then run beside the chains at half rate instead of after them at full rate -- so the
  * driver leaves it off.) */
 int qa_panel_set_cu_partition(qa_panel_t *panel, int32_t index, int32_t count);
+
+/* With several handles sharing a device: run this handle's full-panel calls on a stream of the highest priority (its
+ * Gibbs launches stay on the default one).  A Gibbs launch is one long wave per chain, a full-panel launch many short
+ * workgroups that each need most of a compute unit; at equal priority the next Gibbs launch's waves take the SIMDs the
+ * last one frees one by one and the full-panel workgroups of the other handles wait for a whole free CU.  With the
+ * priority the dispatcher places pending full-panel workgroups first, so those calls run at their stand-alone rate between
+ * Gibbs launches instead of beside them.  on = 0 restores the default stream.  (Calls are host-synchronous, so the two
+ * streams of a handle never overlap.) */
+int qa_panel_set_pass_priority(qa_panel_t *panel, int32_t on);
 
 /* ---- full-panel haploid forward/backward -------------------------------- */
 

@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -99,6 +101,29 @@ inline PinnedStage &pinned_stage() {
 }
 constexpr size_t kStagePiece = size_t(64) << 20;
 
+// Host buffers handed out by qa_host_alloc (include/quilt_amd.h): pinned and device-visible, so a transfer from / to one
+// needs no staging -- the copy kernel reads / writes it directly.  (Callers with buffers of their own, e.g. R vectors, get
+// the staged path.)
+struct PinnedRegistry {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> regions;   // base -> bytes
+    void add(void *p, size_t n) { std::lock_guard<std::mutex> g(mu); regions[reinterpret_cast<uintptr_t>(p)] = n; }
+    bool remove(void *p) { std::lock_guard<std::mutex> g(mu); return regions.erase(reinterpret_cast<uintptr_t>(p)) > 0; }
+    bool covers(const void *p, size_t n) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        std::lock_guard<std::mutex> g(mu);
+        if (regions.empty()) return false;
+        auto it = regions.upper_bound(a);
+        if (it == regions.begin()) return false;
+        --it;
+        return a >= it->first && a + n <= it->first + it->second;
+    }
+};
+inline PinnedRegistry &pinned_registry() {
+    static PinnedRegistry r;
+    return r;
+}
+
 // pageable <-> pinned copies of tens of MB run at one core's memcpy rate (~8 GB/s), a sixth of what PCIe moves: split them
 inline void par_memcpy(void *dst, const void *src, size_t n) {
     constexpr size_t kMin = size_t(4) << 20;
@@ -118,6 +143,12 @@ inline void par_memcpy(void *dst, const void *src, size_t n) {
 // one while the device drains the other.
 inline void staged_upload(void *dev, const void *host, size_t bytes, hipStream_t s) {
     if (!bytes) return;
+    if (pinned_registry().covers(host, bytes)) {   // a qa_host_alloc buffer: no staging
+        stage_copy(dev, host, bytes, s);
+        QA_HIP(hipGetLastError());
+        QA_HIP(hipStreamSynchronize(s));
+        return;
+    }
     PinnedStage &ps = pinned_stage();
     if (!ps.get(std::min(bytes, kStagePiece))) {   // no pinned memory: fall back to the runtime's own path
         QA_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
@@ -138,6 +169,12 @@ inline void staged_upload(void *dev, const void *host, size_t bytes, hipStream_t
 // device -> host, after everything queued on the stream; complete on return
 inline void staged_download(void *host, const void *dev, size_t bytes, hipStream_t s) {
     if (!bytes) return;
+    if (pinned_registry().covers(host, bytes)) {   // a qa_host_alloc buffer: no staging
+        stage_copy(host, dev, bytes, s);
+        QA_HIP(hipGetLastError());
+        QA_HIP(hipStreamSynchronize(s));
+        return;
+    }
     PinnedStage &ps = pinned_stage();
     if (!ps.get(std::min(bytes, kStagePiece))) {
         QA_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));

@@ -790,6 +790,7 @@ struct qa_panel::Scratch {
 qa_panel::~qa_panel() {
     delete scratch;
     if (gibbs_stream) (void)hipStreamDestroy(gibbs_stream);
+    if (pass_stream) (void)hipStreamDestroy(pass_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -962,7 +963,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     QA_HIP(hipSetDevice(pn->device));
     if (!pn->scratch) pn->scratch = new qa_panel::Scratch(&pn->arena);
     auto &S = *pn->scratch;
-    hipStream_t st = pn->stream;
+    hipStream_t st = pn->pass_stream ? pn->pass_stream : pn->stream;
     for (auto &e : S.ev) if (!e) QA_HIP(hipEventCreate(&e));
     const int G = pn->G, T = pn->T, K = pn->K;
     const int Kq = geo.NT * geo.NCH * 16;
@@ -1034,7 +1035,19 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.emat = S.emat.p; prm.esp = S.esp.p; prm.escale0 = S.escale0.p; prm.alpha = S.alpha.p; prm.alpha_slot = S.alpha_slot.p;
     prm.alpha_pass_stride = alpha_stride; prm.Kq = Kq; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;
     prm.gamma_out = any_gamma ? S.gamma.p : nullptr; prm.beta_out = any_beta ? S.beta.p : nullptr;
-    prm.dosage = S.dosage.p; prm.K_top = any_top ? K_top : 0;
+    // Dosage rows that go to consecutive rows of a qa_host_alloc buffer are written there by k_dosage itself (every element
+    // once, 256 contiguous bytes per workgroup): the transfer rides under the kernel instead of following it.
+    bool dosage_direct = false;
+    if (out.dosage && P > 0) {
+        const size_t r0 = out.dosage_rows ? (size_t)out.dosage_rows[0] : 0;
+        dosage_direct = true;
+        for (int p = 0; p < P && dosage_direct; p++)
+            dosage_direct = (h_flags[p] & 1) && (out.dosage_rows ? (size_t)out.dosage_rows[p] : (size_t)p) == r0 + (size_t)p;
+        dosage_direct = dosage_direct && qa::pinned_registry().covers(out.dosage + r0 * T, sizeof(double) * (size_t)P * T);
+        if (dosage_direct) prm.dosage = out.dosage + r0 * T;
+    }
+    if (!dosage_direct) prm.dosage = S.dosage.p;
+    prm.K_top = any_top ? K_top : 0;
     prm.beta_thin = any_top ? S.beta_thin.p : nullptr;
     prm.fused_topk = fused ? 1 : 0;
     prm.top_cap = top_cap;
@@ -1131,19 +1144,27 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
 
     // ---- copy results back
     if (out.c) S.c.download(out.c, (size_t)P * G, st);
-    if (out.dosage) {
+    if (out.dosage && !dosage_direct) {
         // runs of consecutive dosage passes come back in one staged transfer each, then scatter to their rows
+        // (a run whose destination rows are consecutive too -- the batch calls' layout -- lands in the caller's buffer
+        // directly: one transfer, staged piecewise or, for a qa_host_alloc buffer, written by the copy kernel itself)
         const int max_rows = std::max<int>(1, (int)(qa::kStagePiece / (sizeof(double) * T)));
+        auto row_of = [&](int p) { return (size_t)(out.dosage_rows ? out.dosage_rows[p] : p); };
         std::vector<double> tmp;
         for (int p = 0; p < P;) {
             if (!(h_flags[p] & 1)) { p++; continue; }
             int n = 1;
+            while (p + n < P && (h_flags[p + n] & 1) && row_of(p + n) == row_of(p) + (size_t)n) n++;
+            if (n > 1 || max_rows == 1) {
+                qa::staged_download(out.dosage + row_of(p) * T, S.dosage.p + (size_t)p * T, sizeof(double) * T * n, st);
+                p += n;
+                continue;
+            }
             while (p + n < P && n < max_rows && (h_flags[p + n] & 1)) n++;
             tmp.resize((size_t)n * T);
             qa::staged_download(tmp.data(), S.dosage.p + (size_t)p * T, sizeof(double) * T * n, st);
             for (int i = 0; i < n; i++)
-                memcpy(out.dosage + (size_t)(out.dosage_rows ? out.dosage_rows[p + i] : p + i) * T, tmp.data() + (size_t)i * T,
-                       sizeof(double) * T);
+                memcpy(out.dosage + row_of(p + i) * T, tmp.data() + (size_t)i * T, sizeof(double) * T);
             p += n;
         }
     }
@@ -1434,7 +1455,7 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
         QA_HIP(hipSetDevice(panel->device));
         if (!panel->scratch) panel->scratch = new qa_panel::Scratch(&panel->arena);
         auto &S = *panel->scratch;
-        hipStream_t st = panel->stream;
+        hipStream_t st = panel->pass_stream ? panel->pass_stream : panel->stream;
         const int G = panel->G, T = panel->T;
         int n_thin = 0;
         for (int g = 0; g < G; g++) n_thin = std::max(n_thin, gammaSmall_cols_to_get[g] + 1);

@@ -1,4 +1,5 @@
 // panel.hip -- library state, error reporting and panel upload.
+#include <chrono>
 #include "panel.hpp"
 
 #include <mutex>
@@ -149,6 +150,65 @@ int qa_profile_get_work(int32_t kernel, double *units, double *serial) {
     if (units) *units = qa::g_profile[kernel].units;
     if (serial) *serial = qa::g_profile[kernel].serial;
     return QA_OK;
+}
+
+void *qa_host_alloc(size_t bytes) {
+    if (!qa::device_ready()) return nullptr;
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+        qa::set_error("qa_host_alloc: cannot pin %zu bytes of host memory", bytes);
+        return nullptr;
+    }
+    qa::pinned_registry().add(p, bytes);
+    return p;
+}
+
+int qa_host_free(void *p) {
+    if (!p || !qa::pinned_registry().remove(p)) {
+        qa::set_error("qa_host_free: not a qa_host_alloc buffer");
+        return QA_ERR_INVALID;
+    }
+    (void)hipHostFree(p);
+    return QA_OK;
+}
+
+int qa_selftest_copy_rate(int32_t to_device, size_t bytes, int32_t mode, double *ms) {
+    // diagnostic: one transfer of `bytes` between a device buffer and a pinned host buffer; mode 0 = the library's copy
+    // kernel writing / reading the host buffer directly, 1 = hipMemcpyAsync, 2 = the staged path into pageable memory
+    if (!qa::device_ready() || !ms || bytes == 0) return QA_ERR_INVALID;
+    try {
+        void *d = nullptr, *h = nullptr;
+        QA_HIP(hipMalloc(&d, bytes));
+        std::vector<char> pageable;
+        if (mode == 2) { pageable.resize(bytes); h = pageable.data(); }
+        else QA_HIP(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+        memset(h, 1, bytes);
+        hipStream_t st;
+        QA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        double best = 1e30;
+        for (int rep = 0; rep < 3; rep++) {
+            QA_HIP(hipStreamSynchronize(st));
+            const auto t0 = std::chrono::steady_clock::now();
+            if (mode == 0) {
+                if (to_device) qa::stage_copy(d, h, bytes, st); else qa::stage_copy(h, d, bytes, st);
+                QA_HIP(hipGetLastError());
+            } else if (mode == 1) {
+                QA_HIP(hipMemcpyAsync(to_device ? d : h, to_device ? h : d, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+            } else {
+                if (to_device) qa::staged_upload(d, h, bytes, st); else qa::staged_download(h, d, bytes, st);
+            }
+            QA_HIP(hipStreamSynchronize(st));
+            best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        *ms = best;
+        (void)hipStreamDestroy(st);
+        (void)hipFree(d);
+        if (mode != 2) (void)hipHostFree(h);
+        return QA_OK;
+    } catch (const std::exception &e) {
+        qa::set_error("%s", e.what());
+        return QA_ERR_HIP;
+    }
 }
 
 int qa_profile_reset(void) {
@@ -335,6 +395,22 @@ int qa_panel_set_cu_partition(qa_panel_t *panel, int32_t index, int32_t count) {
         std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
         for (int cu = lo; cu < hi; cu++) mask[cu >> 5] |= 1u << (cu & 31);
         QA_HIP(hipExtStreamCreateWithCUMask(&panel->gibbs_stream, (uint32_t)mask.size(), mask.data()));
+        return (int)QA_OK;
+    });
+}
+
+int qa_panel_set_pass_priority(qa_panel_t *panel, int32_t on) {
+    if (!panel) {
+        qa::set_error("qa_panel_set_pass_priority: null handle");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(panel->device));
+        if (panel->pass_stream) { QA_HIP(hipStreamDestroy(panel->pass_stream)); panel->pass_stream = nullptr; }
+        if (!on) return (int)QA_OK;
+        int least = 0, greatest = 0;
+        QA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        QA_HIP(hipStreamCreateWithPriority(&panel->pass_stream, hipStreamNonBlocking, greatest));
         return (int)QA_OK;
     });
 }

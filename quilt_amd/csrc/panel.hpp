@@ -38,6 +38,7 @@ struct qa_panel {
     std::vector<double> h_sigma, h_tm1;  // transMatRate_t rows 0 and 1 as passed
     std::vector<int32_t> h_sp_off;
     hipStream_t stream = nullptr;
+    hipStream_t pass_stream = nullptr;    // higher-priority stream of the full-panel calls (qa_panel_set_pass_priority), else null
     hipStream_t gibbs_stream = nullptr;   // CU-masked stream of the Gibbs launches (qa_panel_set_cu_partition), else null
     qa::Arena arena;            // scratch of every launch set on this panel (see common.hpp)
     qa::Arena aux;              // per-call index / list buffers of the driver-level entry points (grow-only: a call-local

@@ -25,6 +25,9 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
+from . import trace
+from .trace import span
+
 
 @dataclass
 class DriverParams:
@@ -564,6 +567,7 @@ class Driver:
             first_reads = [0] * len(chains)   # unused without gibbs_initialize_iteratively
         t1 = time.perf_counter()
         self.timing["host"] += t1 - t0
+        trace.add("round:prepare", t0, t1)
         # ---- small-panel Gibbs (impute_one_sample, functions.R:2313-2774), with the underflow retry
         # use_mspbwt: the haplotype search wants the call's rounded, packed haploid dosages (formed on the device); the
         # dosages themselves only on the rounds that accumulate them (the last round's also feed the read-confidence step)
@@ -572,6 +576,7 @@ class Driver:
                                          gibbs_initialize_iteratively=any_first, **extra)
         t2 = time.perf_counter()
         self.timing["gibbs"] += t2 - t1
+        trace.add("round:gibbs_call", t1, t2)
         # ---- full-panel pass per read label (impute_using_everything, functions.R:1922-2157)
         return_dosage = i_it > P.n_burn_in_seek_its
         for ch, res in zip(chains, results):
@@ -587,6 +592,7 @@ class Driver:
                 sample_list.append(ch.sample)
         t3 = time.perf_counter()
         self.timing["host"] += t3 - t2
+        trace.add("round:labels", t2, t3)
         # The reference asks for the best haplotypes on every call (functions.R:738-743), but the selection made from
         # them is read again only by a later round of the same chain or -- the last chain's final selection -- by the
         # phasing rounds (which_haps_to_use carried over): skip the lists nobody reads.
@@ -608,6 +614,7 @@ class Driver:
         which_next, sel_status = out[3:5] if on_device else (None, None)
         t4 = time.perf_counter()
         self.timing["fullpass"] += t4 - t3
+        trace.add("round:fullpass_call", t3, t4)
         if return_dosage and (dosages.min() < -1e-5 or dosages.max() > 1 + 1e-5):   # functions.R:2072-2075
             raise RuntimeError("Dosage observed outside of range of 0 to 1 on forward-backward full iteration")
         self._round_dosages = dosages if return_dosage else None   # [chain, label, T]: run_stream accumulates from it
@@ -640,7 +647,9 @@ class Driver:
                 new_haps = self._full_lists(ch)
                 sel = everything_select_good_haps(P.Knew, P.K_top_matches, new_haps, prev_sel, K, seed_sel[ci])
             ch.which_haps_to_use = np.concatenate([prev_sel, sel]).astype(np.int32)
-        self.timing["host"] += time.perf_counter() - t4
+        t5 = time.perf_counter()
+        self.timing["host"] += t5 - t4
+        trace.add("round:select", t4, t5)
         return return_dosage
 
     def _round_mspbwt(self, chains: List[ChainState], results, i_it: int, return_dosage: bool):
@@ -860,7 +869,8 @@ class Driver:
                 return
             for i_it in range(1, P.n_seek_its + 1):
                 chains = (cur.chains if cur else []) + (prev.phasing if prev else [])
-                stored = self._round(chains, i_it)
+                with span("round"):
+                    stored = self._round(chains, i_it)
                 if stored and cur:   # functions.R:999-1020 (1009-1016: fetus = maternal transmitted + paternal transmitted)
                     from .io import accumulate_dosage
                     t_acc = time.perf_counter()
@@ -884,10 +894,12 @@ class Driver:
                         cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
                     cur.nDosage_all[ch.i_sample] += 1
             t0 = time.perf_counter()
-            done = self._finish(prev) if prev else None
+            with span("finish"):
+                done = self._finish(prev) if prev else None
             t1 = time.perf_counter()
             if cur:
-                self._start_phasing(cur)
+                with span("start_phasing"):
+                    self._start_phasing(cur)
             self.timing["finish"] += t1 - t0
             self.timing["consensus"] += time.perf_counter() - t1
             prev = cur
@@ -910,6 +922,7 @@ class HipBackend:
     def __init__(self, device_panel, device_rare_common=None):
         self.dev = device_panel
         self.drc = device_rare_common   # quilt_amd.native.DeviceRareCommon, for impute_rare_common
+        self._dosage_buf = None         # pinned host buffer of the dosage rounds (fullpass_reads_batch)
 
     def make_gl_bound(self, gl, minGLValue, to_fix):
         from .reference_single import Rcpp_make_gl_bound
@@ -997,8 +1010,19 @@ class HipBackend:
         cs = np.ascontiguousarray(chain_sample, dtype=np.int32)
         wd = np.ascontiguousarray(want_dosage, dtype=np.int32)
         wt = np.ascontiguousarray(want_top, dtype=np.int32)
-        # (np.empty when every chain's rows are written: zero-filling ~1 GB per dosage round costs more than the copy back)
-        dosage = (np.empty((n_chain, n_label, T)) if wd.all() else np.zeros((n_chain, n_label, T))) if wd.any() else None
+        # The round's dosages land in this backend's pinned buffer (qa_host_alloc: no staging copy, no fresh pages for ~1 GB
+        # per dosage round) -- valid until the next dosage round of this backend; the driver consumes a round's rows
+        # (accumulation, read confidence, the phasing haplotypes) before it starts the next one.
+        dosage = None
+        if wd.any():
+            need = n_chain * n_label * T
+            if self._dosage_buf is None or self._dosage_buf.size < need:
+                from .native import pinned_empty
+                self._dosage_buf = None   # (release the smaller one first)
+                self._dosage_buf = pinned_empty((need + need // 8,))
+            dosage = self._dosage_buf[:need].reshape(n_chain, n_label, T)
+            if not wd.all():
+                dosage[...] = 0.0
         cnt = np.zeros((n_chain, n_label, n_thin), dtype=np.int32)
         head = (self.dev.handle, C.c_int32(n_chain), C.c_int32(n_label), C.c_int32(n_sample), ptr(cs), ptr(read_off),
                 ptr(read_ptr), ptr(u), ptr(bq), ptr(H), ptr(wd), ptr(wt), ptr(cols), C.c_int32(K_top_matches),
@@ -1009,12 +1033,15 @@ class HipBackend:
             seeds = np.ascontiguousarray(select["seeds"], dtype=np.uint64)
             nxt = np.zeros((n_chain, Ks), dtype=np.int32)
             status = np.full(n_chain, -1, dtype=np.int32)
-            check(lib().qa_fullpass_reads_select_batch(*head, None, None, ptr(cnt), C.c_int32(Ks), C.c_int32(int(select["Knew"])),
-                                                       ptr(which), ptr(seeds), ptr(nxt), ptr(status)))
+            with span("device:fullpass"):
+                check(lib().qa_fullpass_reads_select_batch(*head, None, None, ptr(cnt), C.c_int32(Ks),
+                                                           C.c_int32(int(select["Knew"])), ptr(which), ptr(seeds), ptr(nxt),
+                                                           ptr(status)))
             return dosage, None, cnt, nxt, status
         top = np.full((n_chain, n_label, n_thin, top_width), -1, dtype=np.int32)
         val = np.zeros((n_chain, n_label, n_thin, top_width), dtype=np.float32)
-        check(lib().qa_fullpass_reads_batch(*head, ptr(top), ptr(val), ptr(cnt)))
+        with span("device:fullpass"):
+            check(lib().qa_fullpass_reads_batch(*head, ptr(top), ptr(val), ptr(cnt)))
         return dosage, top, cnt
 
     def read_confidence_batch(self, samples, haps, maxDifferenceBetweenReads):

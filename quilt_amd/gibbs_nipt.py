@@ -17,6 +17,7 @@ import numpy as np
 
 from . import native
 from .native import DevicePanel, check, lib, ptr
+from .trace import span
 
 
 class GibbsOpts(C.Structure):
@@ -137,9 +138,11 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     tail = (C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(ru),
             ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap), ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
     if rare_common is not None:
-        st = lib().qa_gibbs_batch_rare_common(panel.handle, rare_common.handle, *tail)
+        with span("device:gibbs_rare_common"):
+            st = lib().qa_gibbs_batch_rare_common(panel.handle, rare_common.handle, *tail)
     else:
-        st = lib().qa_gibbs_batch(panel.handle, *tail)
+        with span("device:gibbs"):
+            st = lib().qa_gibbs_batch(panel.handle, *tail)
     check(st)
     if os.environ.get("QA_TIMING"):
         print(f"[gibbs_batch py C={Cn}] marshal {_t1 - _t0:.3f} s, native call {time.perf_counter() - _t1:.3f} s", flush=True)
@@ -210,7 +213,8 @@ def calculate_eMatRead_t_vs_haplotypes_batch(panel: DevicePanel, samples: Sequen
     u = np.concatenate([np.asarray(s.u, dtype=np.int32) for s in samples])
     bq = np.concatenate([np.asarray(s.bq, dtype=np.int32) for s in samples])
     out = np.zeros((int(read_off[-1]), K))
-    check(fn(panel.handle, C.c_int32(T), C.c_int32(Cn), C.c_int32(K), ptr(e), ptr(read_off),
-             ptr(read_ptr), ptr(u), ptr(bq), C.c_double(maxDifferenceBetweenReads), C.c_int32(Jmax),
-             C.c_int32(int(rescale_eMatRead_t)), ptr(out)))
+    with span("device:read_confidence"):
+        check(fn(panel.handle, C.c_int32(T), C.c_int32(Cn), C.c_int32(K), ptr(e), ptr(read_off),
+                 ptr(read_ptr), ptr(u), ptr(bq), C.c_double(maxDifferenceBetweenReads), C.c_int32(Jmax),
+                 C.c_int32(int(rescale_eMatRead_t)), ptr(out)))
     return [np.asfortranarray(out[read_off[c]:read_off[c + 1]].T) for c in range(Cn)]

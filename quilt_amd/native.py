@@ -76,6 +76,24 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """An uninitialised array in a ``qa_host_alloc`` buffer (pinned, device-visible): transfers from / to it skip the
+    library's staging copy.  The buffer is released when the array and every view of it are gone."""
+    import weakref
+    L = lib()
+    L.qa_host_alloc.restype = C.c_void_p
+    L.qa_host_alloc.argtypes = [C.c_size_t]
+    L.qa_host_free.argtypes = [C.c_void_p]
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    p = L.qa_host_alloc(C.c_size_t(max(n, 1)))
+    if not p:
+        raise QuiltAmdError(QA_ERR_HIP, L.qa_last_error().decode())
+    raw = (C.c_char * max(n, 1)).from_address(p)
+    weakref.finalize(raw, L.qa_host_free, C.c_void_p(p))   # numpy keeps ``raw`` alive as the base of the array and its views
+    return np.frombuffer(raw, dtype=dt, count=n // dt.itemsize).reshape(shape)
+
+
 class PanelDesc(C.Structure):
     _fields_ = [
         ("K", C.c_int32), ("nGrids", C.c_int32), ("nSNPs", C.c_int32), ("nMaxDH", C.c_int32),
@@ -163,6 +181,11 @@ class DevicePanel:
     def set_cu_partition(self, index: int, count: int):
         """Confine this handle's Gibbs launches to the index-th of ``count`` equal CU partitions (count = 1: no mask)."""
         check(lib().qa_panel_set_cu_partition(self.handle, C.c_int32(index), C.c_int32(count)))
+
+    def set_pass_priority(self, on: bool = True):
+        """Full-panel calls of this handle on a highest-priority stream (several handles sharing the device)."""
+        lib().qa_panel_set_pass_priority.restype = C.c_int
+        check(lib().qa_panel_set_pass_priority(self.handle, C.c_int32(int(on))))
 
     def close(self):
         if self.handle:

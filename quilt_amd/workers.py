@@ -45,7 +45,8 @@ class PairGate:
 
 class DeviceWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
-                 cu_partition: bool = False, fp64_dosage: bool = False, split: str = "halves", gibbs_gate: float = 0.0):
+                 cu_partition: bool = False, fp64_dosage: bool = False, split: str = "halves", gibbs_gate: float = 0.0,
+                 pass_priority: bool = False):
         self.n = n_workers
         # "halves": every batch is cut into one contiguous part per thread; "alternate": whole batches go to the threads in turn
         # (a thread's Gibbs launch then carries a whole batch's chains -- 1 024 at the defaults, one per SIMD -- instead of half)
@@ -57,6 +58,8 @@ class DeviceWorkers:
             d.set_device_share(n_workers)
             if fp64_dosage:   # dosage passes with fp64 state, as the reference (verification mode)
                 d.set_dosage_precision(64)
+            if pass_priority and n_workers > 1:   # full-panel calls ahead of the other threads' Gibbs launches
+                d.set_pass_priority(True)
             if cu_partition and n_workers > 1:   # each thread's Gibbs chains on its own share of the CUs (measured slower: DESIGN.md 5)
                 d.set_cu_partition(w, n_workers)
         self.drcs = [DeviceRareCommon(d, rare_common) if rare_common is not None else None for d in self.devs]
