@@ -426,9 +426,18 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
                          _flag("mode", "short") == a.mode and _flag("K", 50000) == str(a.K) and
                          "--mspbwt" not in pmc["command"] and "--fp64-dosage" not in pmc["command"])
         if same_workload and rc is None and not fp64 and not a.mspbwt:
-            traffic = pmc["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
+            pk = pmc["kernels"][dom["kernel"]]
+            chains = getattr(drv, "n_gibbs_chain_calls", 0)
+            if "hbm_bytes_per_workgroup" in pk and chains and dom["kernel"].startswith("k_gibbs"):
+                # launches come in sizes (a whole batch's chains, the phasing chains alone when the stream drains): the
+                # counters' bytes per workgroup (= per chain) times this run's chains per launch
+                traffic = pk["hbm_bytes_per_workgroup"] * chains / max(dom["launches"], 1)
+                how = f"bytes per workgroup (one per chain) x this run's {chains / max(dom['launches'], 1):.0f} chains per launch"
+            else:
+                traffic = pk["hbm_bytes_per_launch"]
+                how = "bytes per launch"
             traffic_source = (f"{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `{pmc['command']}`, "
-                              "not measured in this run")
+                              f"{how}; not measured in this run")
     except (OSError, KeyError, ValueError):
         pass
     ratio = (traffic / per_launch) if traffic else None

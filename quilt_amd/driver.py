@@ -525,6 +525,7 @@ class Driver:
                        "new_batch": 0.0}
         self.n_full_list_refetches = 0   # chains whose selection needed the untruncated best-haplotype lists
         self.n_underflow_retries = 0     # Gibbs calls repeated with a smaller maxDifferenceBetweenReads
+        self.n_gibbs_chain_calls = 0     # chains handed to the Gibbs entry point, retries included
         self.n_device_selections = 0     # chains whose next small panel was chosen by csrc/select.hip
         self._zero_hap = None
         self.gibbs_gate = None           # workers.PairGate shared by the host threads of a device, or None
@@ -724,6 +725,7 @@ class Driver:
                     kw = dict(kw, ff=[float(chains[i].sample.ff) for i in idx], shuffle_bin_radius=P.shuffle_bin_radius)
                 if self.gibbs_gate is not None and n_try == 0:
                     self.gibbs_gate.wait()   # start together with the other host thread's launch (workers.PairGate)
+                self.n_gibbs_chain_calls += len(idx)
                 out = self.backend.gibbs_batch(
                     [samples[i] for i in idx], [chains[i].which_haps_to_use for i in idx],
                     [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],

@@ -74,9 +74,14 @@ class DeviceWorkers:
         keys = self.drivers[0].timing.keys()
         return {k: sum(d.timing[k] for d in self.drivers) for k in keys}
 
+    @property
+    def n_gibbs_chain_calls(self) -> int:
+        return sum(d.n_gibbs_chain_calls for d in self.drivers)
+
     def reset_timing(self):
         for d in self.drivers:
             d.timing = {k: 0.0 for k in d.timing}
+            d.n_gibbs_chain_calls = 0
 
     def close(self):
         for r in self.drcs:

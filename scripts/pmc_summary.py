@@ -17,6 +17,7 @@ def per_kernel(path, counter):
     tot = collections.defaultdict(float)
     n = collections.Counter()
     ms = collections.defaultdict(float)
+    wgs = collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
@@ -27,13 +28,18 @@ def per_kernel(path, counter):
         tot[k] += float(r["Counter_Value"])
         n[k] += 1
         ms[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    return tot, n, ms
+        # workgroups of the launch (a Gibbs launch: one per chain), from whichever geometry columns the csv carries
+        try:
+            wgs[k] += max(1, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+        except (KeyError, ValueError):
+            pass
+    return tot, n, ms, wgs
 
 
 def main():
     fetch_csv, write_csv, out, cmd = sys.argv[1:5]
-    f, nf, msf = per_kernel(fetch_csv, "FETCH_SIZE")
-    w, nw, _ = per_kernel(write_csv, "WRITE_SIZE")
+    f, nf, msf, wg = per_kernel(fetch_csv, "FETCH_SIZE")
+    w, nw, _, _ = per_kernel(write_csv, "WRITE_SIZE")
     res = {"command": cmd, "units": "bytes; FETCH_SIZE (KB) x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE (KB) x 1024",
            "kernels": {}}
     for k in sorted(f):
@@ -41,6 +47,9 @@ def main():
         wb = w.get(k, 0.0) * 1024
         res["kernels"][k] = {"launches": nf[k], "fetch_bytes": fb, "write_bytes": wb,
                              "hbm_bytes_per_launch": (fb + wb) / max(nf[k], 1), "total_ms": msf[k]}
+        if wg.get(k):   # launches of different sizes in one run (a Gibbs launch of a whole batch, of the phasing chains alone)
+            res["kernels"][k]["workgroups"] = wg[k]
+            res["kernels"][k]["hbm_bytes_per_workgroup"] = (fb + wb) / wg[k]
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():
         print(k, v["launches"], f"{v['hbm_bytes_per_launch'] / 1e9:.2f} GB/launch", f"{v['total_ms']:.1f} ms")
