@@ -448,9 +448,17 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
             "avg_launch_ms": avg_ms, "launches": dom["launches"], "alg_bytes_per_launch": per_launch,
             "aggregate": {"achieved": agg, "frac": agg / HBM_PEAK_GBS, "busy_ms": dom["busy_ms"],
                           "note": "all overlapping launches of the kernel together: algorithmic bytes / time with >= 1 launch running"}}
+    if traffic and dom["busy_ms"] > 0:   # what HBM actually carries while >= 1 launch of the kernel runs (counter bytes)
+        hbm = traffic * dom["launches"] / 1e9 / (dom["busy_ms"] / 1e3)
+        roof["aggregate"]["hbm_traffic_GBps"] = hbm
+        roof["aggregate"]["hbm_traffic_frac_of_peak"] = hbm / HBM_PEAK_GBS
     if bound == "latency":
         roof["limited_by"] = ("fp64 VALU issue and dependency latency of one wave per SIMD (a serial chain per Gibbs chain); the "
                               "counters show a fraction of the algorithmic bytes crossing HBM")
+    elif dom["kernel"].startswith("k_gibbs"):
+        roof["limited_by"] = ("both: one launch alone is bound by the fp64 VALU issue of its one wave per SIMD (512 chains: 0.59 s, "
+                              "2.9 TB/s of counter traffic); with every SIMD holding a chain the launches together draw the "
+                              "aggregate.hbm_traffic_GBps above from HBM, and a launch then takes 0.7-0.8 s")
     if dom["serial"] > 0:   # the serial chain's step time and the rate of read visits
         roof["us_per_grid_step"] = 1e3 * dom["ms"] / dom["serial"]
         roof["read_visits_and_grid_steps_per_s"] = dom["units"] / (dom["busy_ms"] / 1e3) if dom["busy_ms"] > 0 else None

@@ -40,9 +40,9 @@ cat $OUT/pmc_insts.json | head -40
 rm -f $OUT/pmc_*_counters.csv
 fi
 if [[ $WHAT == all || $WHAT == lines ]]; then
-python bench.py --mode ont --steps 4 --warmup 1 > $OUT/bench_line_ont.json 2> $OUT/bench_ont.err; tail -c 300 $OUT/bench_line_ont.json
-python bench.py --mode nipt --steps 4 --warmup 1 > $OUT/bench_line_nipt.json 2> $OUT/bench_nipt.err; tail -c 300 $OUT/bench_line_nipt.json
-python bench.py --fp64-dosage --steps 4 --warmup 1 --r2-vs-cpu 1 > $OUT/bench_line_fp64_dosage.json 2> $OUT/bench_fp64.err; tail -c 300 $OUT/bench_line_fp64_dosage.json
-python bench.py --mspbwt --steps 4 --warmup 1 > $OUT/bench_line_mspbwt.json 2> $OUT/bench_mspbwt.err; tail -c 300 $OUT/bench_line_mspbwt.json
-python bench.py --bam --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_line_from_bam.json 2> $OUT/bench_from_bam.err; tail -c 300 $OUT/bench_line_from_bam.json
+python bench.py --mode ont --steps 12 --warmup 4 > $OUT/bench_line_ont.json 2> $OUT/bench_ont.err; tail -c 300 $OUT/bench_line_ont.json
+python bench.py --mode nipt --steps 12 --warmup 4 > $OUT/bench_line_nipt.json 2> $OUT/bench_nipt.err; tail -c 300 $OUT/bench_line_nipt.json
+python bench.py --fp64-dosage --steps 12 --warmup 4 --r2-vs-cpu 1 > $OUT/bench_line_fp64_dosage.json 2> $OUT/bench_fp64.err; tail -c 300 $OUT/bench_line_fp64_dosage.json
+python bench.py --mspbwt --steps 12 --warmup 4 > $OUT/bench_line_mspbwt.json 2> $OUT/bench_mspbwt.err; tail -c 300 $OUT/bench_line_mspbwt.json
+python bench.py --bam --steps 12 --warmup 4 --no-cpu-baseline > $OUT/bench_line_from_bam.json 2> $OUT/bench_from_bam.err; tail -c 300 $OUT/bench_line_from_bam.json
 fi
