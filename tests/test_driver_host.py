@@ -394,3 +394,24 @@ def test_native_consensus_equals_the_numpy_text():
         fn = D.determine_best_read_label_so_far_nipt if K == 3 else D.determine_best_read_label_so_far
         ref = fn(lab.T.copy(), conf, R, n, can_hap=can)
         assert np.array_equal(got, ref), (trial, n, R, K, can)
+
+
+def test_host_span_trace_records_the_phases_of_a_run(tmp_path, monkeypatch):
+    """quilt_amd/trace.py: off by default; with a path set the driver's phases come out as (thread, name, start, end)."""
+    import json
+    from quilt_amd import trace
+    assert not trace.enabled()
+    with trace.span("nothing"):
+        pass
+    assert trace._spans == []
+    out = tmp_path / "trace.json"
+    monkeypatch.setattr(trace, "_PATH", str(out))
+    monkeypatch.setattr(trace, "_spans", [])
+    with trace.span("device:fake"):
+        trace.add("inner", 1.0, 2.0)
+    trace.mark("instant")
+    trace.dump()
+    got = json.load(open(out))
+    names = [x[1] for x in got]
+    assert names == ["inner", "device:fake", "instant"]
+    assert all(x[3] >= x[2] for x in got)
