@@ -155,6 +155,14 @@ int main(void) {
     int found = 0;
     for (int q = 0; q < best_ptr[n_thin]; q++) found |= best_idx[q] == 3 || best_idx[q] == 7;
     CHECK(found, "a truth haplotype is among the best matches");
+    /* the same call with its dosage in a qa_host_alloc buffer (pinned: no staging copy): the same bytes */
+    double *pinned = (double *)qa_host_alloc(sizeof(double) * NT);
+    CHECK(pinned != NULL, "qa_host_alloc");
+    st = qa_Rcpp_haploid_dosage_versus_refs(panel, gl, cols, &fo, NULL, NULL, c, NULL, NULL, pinned, best_ptr, best_idx, best_val, 4096);
+    CHECK(st == QA_OK, "qa_Rcpp_haploid_dosage_versus_refs into a pinned buffer");
+    CHECK(memcmp(pinned, dosage, sizeof(double) * NT) == 0, "pinned and staged dosages are identical");
+    CHECK(qa_host_free(pinned) == QA_OK, "qa_host_free");
+    CHECK(qa_host_free(dosage) == QA_ERR_INVALID, "qa_host_free rejects foreign pointers");
     qa_panel_destroy(panel);
     free(runif_reads); free(runif_shard);
     printf("HARNESS_OK\n");
