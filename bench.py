@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip the stand-alone kernel timings taken before the warm-up (`kernels_alone` in the output)")
     ap.add_argument("--pass-priority", type=int, default=0, choices=(0, 1),
                     help="full-panel calls on a highest-priority stream (qa_panel_set_pass_priority)")
     ap.add_argument("--gibbs-gate", type=float, default=0.0, metavar="SEC",
@@ -335,6 +337,9 @@ def main():
     def stream(lo, hi):
         return ((samples[st], (rank * n_steps + st) * a.batch) for st in range(lo, hi))
 
+    alone = None
+    if native is not None and rank == 0 and not a.no_alone and hasattr(drv, "drivers"):
+        alone = kernels_alone(native, drv, samples)
     for _ in drv.run_stream(stream(0, a.warmup)):
         pass
     if native is not None:
@@ -357,13 +362,60 @@ def main():
     from quilt_amd import trace
     trace.dump()   # host span trace, only with QUILT_AMD_TRACE=<file>
     if rank == 0:
-        out = report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu, keep, ff, full_chains)
+        out = report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu, keep, ff, full_chains, alone)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu, keep, ff, full_chains):
+def read_profile(native):
+    """The library's per-kernel accumulators since the last reset (HIP events on the launch streams)."""
+    import ctypes as C
+    L = native.lib()
+    L.qa_profile_name.restype = C.c_char_p
+    prof = []
+    for k in range(L.qa_profile_count()):
+        ms, n, b, busy, units, serial = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        L.qa_profile_get(k, C.byref(ms), C.byref(n), C.byref(b))
+        L.qa_profile_get_busy(k, C.byref(busy))
+        L.qa_profile_get_work(k, C.byref(units), C.byref(serial))
+        if n.value:
+            prof.append(dict(kernel=L.qa_profile_name(k).decode(), ms=ms.value, launches=n.value, alg_bytes=b.value,
+                             busy_ms=busy.value, units=units.value, serial=serial.value))
+    return prof
+
+
+def kernels_alone(native, drv, samples):
+    """Every kernel of the path with the device to itself: one host thread takes 512 chains through a first and a last round
+    of the driver while the others wait (before the warm-up, outside the timed region).  Per kernel the mean launch time and the algorithmic
+    GB/s of a launch -- the kernels' own rates, next to the in-run ones that include the waiting for compute units other
+    threads' launches hold."""
+    from quilt_amd.driver import ChainState, chain_rng
+    native.lib().qa_profile_reset()
+    d = drv.drivers[0]
+    P = d.params
+    half = samples[0][:max(1, len(samples[0]) // 2)]
+    # 64 samples x (nGibbsSamples + 1) chains = 512: one first round (Gibbs launch + ranking passes, selection) and one last
+    # round (Gibbs launch + dosage passes), the two kinds of round a batch goes through
+    chains = [ChainState(smp, i, c, chain_rng(P.seed, i, c)) for i, smp in enumerate(half) for c in range(1, P.nGibbsSamples + 2)]
+    d._round(chains, 1)
+    d._round(chains, P.n_seek_its)
+    d._round_dosages, d._round_dosage_chains = None, []
+    d.timing = {k: 0.0 for k in d.timing}
+    d.n_gibbs_chain_calls = 0
+    d.n_device_selections = 0
+    out = []
+    for p in read_profile(native):
+        per = p["alg_bytes"] / max(p["launches"], 1)
+        avg = p["ms"] / max(p["launches"], 1)
+        out.append({"kernel": p["kernel"], "launches": p["launches"], "avg_launch_ms": round(avg, 3),
+                    "GBps_per_launch": round(per / 1e6 / avg, 1) if avg > 0 else 0.0,
+                    "frac_of_hbm_peak": round(per / 1e6 / avg / HBM_PEAK_GBS, 3) if avg > 0 else 0.0})
+    native.lib().qa_profile_reset()
+    return out
+
+
+def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu, keep, ff, full_chains, alone=None):
     import ctypes as C
     value = 0.0 if a.stub else a.batch * world * a.steps / elapsed
     fp64 = a.fp64_dosage
@@ -396,17 +448,7 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
         out["roofline"] = None
         out["cpu_baseline"] = None
         return out
-    L = native.lib()
-    L.qa_profile_name.restype = C.c_char_p
-    prof = []
-    for k in range(L.qa_profile_count()):
-        ms, n, b, busy, units, serial = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
-        L.qa_profile_get(k, C.byref(ms), C.byref(n), C.byref(b))
-        L.qa_profile_get_busy(k, C.byref(busy))
-        L.qa_profile_get_work(k, C.byref(units), C.byref(serial))
-        if n.value:
-            prof.append(dict(kernel=L.qa_profile_name(k).decode(), ms=ms.value, launches=n.value, alg_bytes=b.value,
-                             busy_ms=busy.value, units=units.value, serial=serial.value))
+    prof = read_profile(native)
     dom = max(prof, key=lambda p: p["ms"])
     # per-launch figure (the recipe): algorithmic bytes of one launch / its mean duration.  Launches of the host threads
     # overlap on the device, so the aggregate rate (bytes / time during which at least one launch of the kernel ran) is given
@@ -466,6 +508,15 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
     out["kernels"] = [{"kernel": p["kernel"], "ms": round(p["ms"], 2), "busy_ms": round(p["busy_ms"], 2), "launches": p["launches"],
                        "avg_launch_ms": round(p["ms"] / max(p["launches"], 1), 3),
                        "GBps_per_launch": round(p["alg_bytes"] / 1e6 / p["ms"], 1) if p["ms"] > 0 else 0.0} for p in prof]
+    if alone is not None:
+        out["kernels_alone"] = {"what": "one host thread, 512 chains through a first and a last round of the driver with the device "
+                                        "to itself, before the warm-up (outside the timed region): the kernels' own launch times, without the waiting "
+                                        "for compute units that the in-run figures of `kernels` include",
+                                "kernels": alone}
+        da = [k for k in alone if k["kernel"] == dom["kernel"]]
+        if da:
+            roof["alone"] = {"avg_launch_ms": da[0]["avg_launch_ms"], "achieved": da[0]["GBps_per_launch"],
+                             "frac": da[0]["frac_of_hbm_peak"]}
     out["host_seconds"] = {k: round(v, 3) for k, v in drv.timing.items()}
     truth = (samples[-1][0].all_snp if rc is not None else samples[-1][0]).truth_haps[:2].sum(axis=0)
     out["dosage_r2_vs_truth_sample0"] = float(np.corrcoef(last[0].dosage, truth)[0, 1] ** 2)
