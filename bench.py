@@ -266,6 +266,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the native calls' own host threads (per-chain tables, validation): the machine's cores divided between the ranks of this
+    # node and the host threads of each rank, so that 8 ranks x 4 threads do not start 16 helpers each at the same moment
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    os.environ.setdefault("QA_HOST_THREADS", str(max(2, (os.cpu_count() or 16) // max(1, local_world * a.workers))))
     params = dict(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
     full_chains = params["nGibbsSamples"] + 1
     ff = 0.2 if a.mode == "nipt" else 0.0

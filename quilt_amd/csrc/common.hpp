@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -122,6 +123,21 @@ struct PinnedRegistry {
 inline PinnedRegistry &pinned_registry() {
     static PinnedRegistry r;
     return r;
+}
+
+// Host threads one native call may use for its per-chain host work (input validation, tables, block definition): at most
+// 16, the machine's hardware threads, or QA_HOST_THREADS when the caller sets it (a launcher that runs several ranks and
+// several host threads per rank divides the cores between them: bench.py does).
+inline int host_threads_cap() {
+    static const int cap = [] {
+        int c = std::min<int>(16, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = getenv("QA_HOST_THREADS")) {
+            const int v = atoi(e);
+            if (v >= 1) c = std::min(c, v);
+        }
+        return c;
+    }();
+    return cap;
 }
 
 // pageable <-> pinned copies of tens of MB run at one core's memcpy rate (~8 GB/s), a sixth of what PCIe moves: split them

@@ -1053,7 +1053,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
             // validation, grid_has_read, 0-based haplotypes, the bq == 0 carry-over (fold_zero_base_qualities) and the
             // choice of the reads that keep a dense column (more informative bases -- k_ematread skips bq == 0 -- than the
             // pattern width): independent per chain, spread over host threads
-            const int n_thr = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), C}));
+            const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), C));
             std::vector<std::string> errs(n_thr);
             auto work = [&](int tid) {
                 try {
@@ -1242,7 +1242,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
                 S.status.download(seg_status.data(), C, st);
                 QA_HIP(hipStreamSynchronize(st));
                 h_where.assign((size_t)C * G, -1); h_tab.assign((size_t)C * 4 * G, 0); h_n.assign(C, 0);
-                const int n_thr = std::max(1, std::min<int>({16, (int)std::thread::hardware_concurrency(), C}));
+                const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), C));
                 auto work = [&](int tid) {
                     for (int c = tid; c < C; c += n_thr) {
                         const int R = read_off[c + 1] - read_off[c];
