@@ -992,7 +992,10 @@ class HipBackend:
         [n_chain, n_label, n_thin, top_width] (0-based, -1 padded; only for chains with want_top) and the full list lengths.
         With ``select`` (Ksubset, Knew, which, seeds) the re-selection of the small panels runs on the device behind the
         passes (qa_fullpass_reads_select_batch): the lists stay there (``top`` is None) and the call also returns
-        which_next [n_chain, Ksubset] and the per-chain selection status."""
+        which_next [n_chain, Ksubset] and the per-chain selection status.
+
+        The dosage array is a view of this backend's pinned transfer buffer (``qa_host_alloc``): it is valid until the
+        next call that asks for dosages -- copy what must outlive that (the driver consumes a round before the next)."""
         import ctypes as C
         from .native import check, lib, ptr
         lib().qa_fullpass_reads_batch.restype = C.c_int
