@@ -50,6 +50,12 @@ class DriverParams:
     impute_rare_common: bool = False   # quilt.R:180: finish every Gibbs sample with a Gibbs call over ALL SNPs
     method: str = "diploid"            # or "nipt": mother + fetus, three read labels, fetal fraction per sample (sample.ff)
     shuffle_bin_radius: int = 5000     # quilt.R:134 (block definition of the NIPT block Gibbs)
+    # Block Gibbs of DIPLOID samples (Rcpp_block_gibbs_resampler with ff = 0).  "reference_noop": what the reference does in
+    # production -- the third label's c is all zero, the relabelling scores are NaN, no block is ever relabelled, the pass
+    # only re-runs the backward sweep (gibbs-nipt-block.cpp:1819-1821, :661-675, :741-752, :830; derivation in
+    # oracle/gibbs.c).  An "active" two-label block pass -- which the reference never executes -- is not built; the name is
+    # here so that the behaviour is a stated choice rather than an omission (NIPT samples, ff > 0, run the real block pass).
+    diploid_block_gibbs: str = "reference_noop"
     # use_mspbwt = TRUE (quilt.R:170-174): no full-panel pass; the next small panel comes from long matches of the Gibbs call's
     # rounded haploid dosages against the panel (mspbwt.R:225-474), the dosages from the Gibbs call itself (functions.R:784-893)
     use_mspbwt: bool = False
@@ -76,6 +82,9 @@ class DriverParams:
             raise ValueError("nGibbsSamples, Ksubset and Knew must be >= 1")
         if p.K_top_matches < 1:
             raise ValueError("K_top_matches must be >= 1")
+        if p.diploid_block_gibbs != "reference_noop":
+            raise ValueError("diploid_block_gibbs: only 'reference_noop' exists (the reference's diploid block pass never "
+                             "relabels; an 'active' two-label block Gibbs is not built)")
         if p.use_mspbwt and p.Knew != p.Ksubset:
             raise ValueError("use_mspbwt: select_new_haps_mspbwt_v3 returns the whole next small panel, so Knew must equal "
                              "Ksubset (the reference's defaults: 600 / 600)")

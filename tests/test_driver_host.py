@@ -415,3 +415,12 @@ def test_host_span_trace_records_the_phases_of_a_run(tmp_path, monkeypatch):
     names = [x[1] for x in got]
     assert names == ["inner", "device:fake", "instant"]
     assert all(x[3] >= x[2] for x in got)
+
+
+def test_diploid_block_gibbs_is_a_named_choice():
+    """the reference's diploid block pass never relabels; that is the only behaviour on offer and it has
+    a name."""
+    from quilt_amd.driver import DriverParams
+    assert DriverParams().resolved(1000).diploid_block_gibbs == "reference_noop"
+    with pytest.raises(ValueError, match="reference_noop"):
+        DriverParams(diploid_block_gibbs="active").resolved(1000)
