@@ -242,6 +242,9 @@ def main():
                     help="skip the stand-alone kernel timings taken before the warm-up (`kernels_alone` in the output)")
     ap.add_argument("--pass-priority", type=int, default=0, choices=(0, 1),
                     help="full-panel calls on a highest-priority stream (qa_panel_set_pass_priority)")
+    ap.add_argument("--exclusive", type=int, default=0, choices=(0, 1),
+                    help="exclusive device phases (qa_panel_set_exclusive): every Gibbs launch / full-panel launch set gets the whole "
+                         "device and the device-wide arena, the host threads take turns")
     ap.add_argument("--gibbs-gate", type=float, default=0.0, metavar="SEC",
                     help="host threads wait up to SEC for each other before a Gibbs launch, so that the two launches overlap fully")
     ap.add_argument("--split", choices=["halves", "alternate"], default="alternate",
@@ -328,7 +331,7 @@ def main():
         native.check(native.lib().qa_set_device(local_rank))
         drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
                             cu_partition=a.cu_partition, fp64_dosage=a.fp64_dosage, split=a.split, gibbs_gate=a.gibbs_gate,
-                            pass_priority=bool(a.pass_priority))
+                            pass_priority=bool(a.pass_priority), exclusive=bool(a.exclusive))
 
     def barrier():
         if not a.stub:
@@ -349,6 +352,8 @@ def main():
     if native is not None:
         native.lib().qa_profile_reset()
     drv.reset_timing()
+    if native is not None:
+        native.gate_stats(local_rank, reset=True)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -522,6 +527,10 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
             roof["alone"] = {"avg_launch_ms": da[0]["avg_launch_ms"], "achieved": da[0]["GBps_per_launch"],
                              "frac": da[0]["frac_of_hbm_peak"]}
     out["host_seconds"] = {k: round(v, 3) for k, v in drv.timing.items()}
+    if a.exclusive:
+        gs = native.gate_stats(int(os.environ.get("LOCAL_RANK", "0")))
+        out["device_gate"] = {"held_s": round(gs["held_ms"] / 1e3, 3), "queued_s": round(gs["queued_ms"] / 1e3, 3), "holds": gs["holds"],
+                              "held_frac_of_timed_region": round(gs["held_ms"] / 1e3 / elapsed, 3)}
     truth = (samples[-1][0].all_snp if rc is not None else samples[-1][0]).truth_haps[:2].sum(axis=0)
     out["dosage_r2_vs_truth_sample0"] = float(np.corrcoef(last[0].dosage, truth)[0, 1] ** 2)
     out["cpu_baseline"] = cpu

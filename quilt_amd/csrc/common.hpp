@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -25,7 +26,7 @@ bool device_ready();
 
 // per-kernel accumulators (HIP-event time on the launch stream, launches, algorithmic HBM bytes)
 enum ProfileKernel { PK_EMAT = 0, PK_FWD, PK_BWD, PK_DOSAGE, PK_EMATREAD, PK_GIBBS, PK_HAPPROBS, PK_FWD64, PK_BWD64, PK_TOPK,
-                     PK_FWD64G, PK_BWD64G, PK_GIBBS3, PK_BLOCK3, PK_SELECT, PK_MATCH, PK_COUNT };
+                     PK_FWD64G, PK_BWD64G, PK_GIBBS3, PK_BLOCK3, PK_SELECT, PK_MATCH, PK_FWD64D, PK_BWD64D, PK_COUNT };
 // units / serial: work units of the launch (Gibbs: read visits + grid steps over all chains) and the length of its serial
 // chain (Gibbs: read visits + grid steps of the longest chain), for rates other than bytes per second
 void profile_add(int kernel, double ms, double alg_bytes, double start_ms = -1, double units = 0, double serial = 0);
@@ -255,10 +256,11 @@ struct DBuf {
 struct Arena {
     char *base = nullptr;
     size_t cap = 0, off = 0;
+    bool owned = true;        // false: a slice of another arena (GateHold): fixed size, not freed
     Arena() = default;
     Arena(const Arena &) = delete;
     Arena &operator=(const Arena &) = delete;
-    ~Arena() { if (base) (void)hipFree(base); }
+    ~Arena() { if (base && owned) (void)hipFree(base); }
     void reset() { off = 0; }
     // bytes this arena may grow to: what is free now plus what it already holds, with headroom
     size_t budget() const {
@@ -277,6 +279,7 @@ struct Arena {
     }
     void require(size_t bytes) {
         if (bytes <= cap) return;
+        if (!owned) throw std::runtime_error("device arena slice too small (internal sizing error)");
         if (base) { QA_HIP(hipFree(base)); base = nullptr; cap = 0; }
         const size_t want = (bytes + (size_t(1) << 28) - 1) >> 28 << 28;   // 256 MiB granules
         QA_HIP(hipMalloc((void **)&base, want));
@@ -288,6 +291,101 @@ struct Arena {
         if (a + bytes > cap) throw std::runtime_error("device arena exhausted (internal sizing error)");
         off = a + bytes;
         return base + a;
+    }
+};
+
+// Device phases (qa_panel_set_exclusive): the launch sets of the handles that opted in take the device in arrival order.
+//   * a full-panel launch set (one workgroup per compute unit) holds it EXCLUSIVELY;
+//   * Gibbs launches (one wave per chain, a SIMD each) hold as many of the 1 024 SIMD slots as they have waves: launches
+//     that fit together run together (the 128 phasing chains of one batch beside the 896 main chains of another), a launch
+//     that does not fit waits for the phase to end.
+// Admission is strictly first come, first served (no bypassing: a waiting full-panel set is never overtaken by later Gibbs
+// launches).  Why: both kinds of launch sets are bound by the same HBM stream when they fill the chip, so overlapping them
+// gains nothing, while a full-panel workgroup needs a whole compute unit and used to wait for one while another thread's
+// Gibbs waves took the SIMDs one by one (62 against 11 ms per launch); and every thread sized its launches for
+// a fraction of the memory (512 chains / 200 passes instead of 1 024 / 256).  ONE scratch arena serves all holders: an
+// exclusive holder has all of it, Gibbs launches get disjoint slices.  The other host threads do their host-side work
+// (marshalling, the R-level logic between the native calls) meanwhile.
+struct DeviceGate {
+    static constexpr int kSlots = 1024;   // SIMDs of the device (256 CUs x 4)
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t next_ticket = 0, head = 0;
+    int active = 0, used_slots = 0;
+    bool active_exclusive = false;
+    size_t bump = 0;          // bytes of the arena handed to the Gibbs launches of the running phase
+    Arena arena;
+    double held_ms = 0;       // accumulated time with at least one holder (qa_gate_stats)
+    double wait_ms = 0;       // accumulated time callers spent queueing
+    double t_busy_from = 0;
+    uint64_t n_holds = 0;
+};
+DeviceGate &device_gate(int device);
+
+// RAII hold of the device (or of `slots` SIMD slots of it) with the scratch arena that goes with it.  Without a gate (a
+// handle that did not opt in) the hold is a no-op around the handle's own arena.
+struct GateHold {
+    DeviceGate *g = nullptr;
+    Arena *own = nullptr;
+    Arena view;               // slice of the gate's arena (shared holds)
+    int slots = 0;
+    bool exclusive = false;
+    double queued_ms = 0;
+    static double now_ms();
+    GateHold() = default;
+    GateHold(const GateHold &) = delete;
+    GateHold &operator=(const GateHold &) = delete;
+    ~GateHold() { release(); }
+    // slots_ == 0: the whole device and the whole arena (which the holder may grow); else `slots_` SIMD slots and `bytes` of arena
+    void acquire(DeviceGate *gate, Arena *own_arena, int slots_ = 0, size_t bytes = 0) {
+        own = own_arena;
+        if (!gate || g) return;
+        const double t0 = now_ms();
+        slots = std::min(slots_, (int)DeviceGate::kSlots);
+        exclusive = slots == 0;
+        const size_t need = (bytes + 4095) & ~size_t(4095);
+        std::unique_lock<std::mutex> lk(gate->mu);
+        const uint64_t mine = gate->next_ticket++;
+        gate->cv.wait(lk, [&] {
+            if (gate->head != mine) return false;
+            if (exclusive) return gate->active == 0;
+            if (gate->active_exclusive || gate->used_slots + slots > DeviceGate::kSlots) return false;
+            return gate->active == 0 || gate->bump + need <= gate->arena.cap;   // (the first holder of a phase may grow the arena)
+        });
+        gate->head++;
+        if (gate->active == 0) gate->t_busy_from = now_ms();
+        gate->active++;
+        if (exclusive) {
+            gate->active_exclusive = true;
+        } else {
+            if (gate->active == 1) { gate->arena.require(need); gate->bump = 0; }
+            view.base = gate->arena.base + gate->bump;
+            view.cap = need;
+            view.off = 0;
+            view.owned = false;
+            gate->bump += need;
+            gate->used_slots += slots;
+        }
+        g = gate;
+        queued_ms = now_ms() - t0;
+        gate->wait_ms += queued_ms;
+        lk.unlock();
+        gate->cv.notify_all();   // the next in line may fit beside this one
+    }
+    Arena &arena() { return g ? (exclusive ? g->arena : view) : *own; }
+    void release() {
+        if (!g) return;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->active--;
+            if (exclusive) g->active_exclusive = false; else g->used_slots -= slots;
+            if (g->active == 0) { g->bump = 0; g->held_ms += now_ms() - g->t_busy_from; }
+            g->n_holds++;
+        }
+        g->cv.notify_all();
+        g = nullptr;
+        view.base = nullptr;
+        view.cap = 0;
     }
 };
 

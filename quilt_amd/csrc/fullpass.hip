@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
     const int nLocal = min(32, prm.T - s);
     const Hist *mg = static_cast<const Hist *>(prm.mg) + ((size_t)p * prm.G + g) * kMaxRow;
     const double eps = prm.ref_error, ome = 1.0 - eps;
-    const double unit = sizeof(TS) == 8 ? 1.0 / kHistScale64 : 1.0 / (double)kHistScale;
+    const double unit = sizeof(TS) == 8 ? prm.hist_unit : 1.0 / (double)kHistScale;
     double acc = 0, acc_sp = 0;   // histogram part (already times sigma_g) and specials (raw gamma)
     if (b < nLocal) {
         for (int d = 1 + part; d < prm.nrow; d += 8) {
@@ -801,9 +801,11 @@ thread_local double g_timing[6] = {0, 0, 0, 0, 0, 0};   // emat, forward, backwa
 // Three families of kernels run a pass:
 //   KIND_F32       fp32 state (k_fwd / k_bwd<float>): the dosage passes, any output
 //   KIND_F64_RANK  fp64 state, the reference's lazy normalisation, fused top-K (fullpass64.hip): best-haplotype lists only
+//   KIND_F64_DOS   fp64 state, the reference's lazy normalisation, alpha stored at every grid, gamma histogram for the dosage
+//                  (k_fwd64 + k_bwd64d, fullpass64.hip): the DOSAGE passes of qa_panel_set_dosage_precision(64)
 //   KIND_F64_FULL  fp64 state through the generic kernels (k_fwd / k_bwd<double>, one wave per SIMD): any output in
-//                  double -- the verification mode behind qa_panel_set_dosage_precision(64); not tuned (it spills)
-enum PassKind { KIND_F32 = 0, KIND_F64_RANK = 1, KIND_F64_FULL = 2 };
+//                  double (alphaHat_t / betaHat_t / gamma_t of the single-pass entry point in that mode); not tuned (it spills)
+enum PassKind { KIND_F32 = 0, KIND_F64_RANK = 1, KIND_F64_FULL = 2, KIND_F64_DOS = 3 };
 struct Geometry { int NT, NCH; PassKind kind; bool f64() const { return kind != KIND_F32; } };
 
 // Register-resident geometry: NT threads (multiple of 64) x NCH chunks of 16 haplotypes per lane.  fp32 state:
@@ -814,8 +816,9 @@ constexpr int kNchList32[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12};
 constexpr int kNchList64[] = {1, 2, 4, 6, 8, 10, 12, 13, 14};
 Geometry pick_geometry(int K, PassKind kind = KIND_F32) {
     const int chunks = (K + 15) / 16;
-    if (kind == KIND_F64_RANK) {
-        const int nch = qa::fb64_chunks(K);
+    if (kind == KIND_F64_RANK || kind == KIND_F64_DOS) {
+        int nch = qa::fb64_chunks(K);
+        if (kind == KIND_F64_DOS && nch && qa::fb64_dos_lds_bytes(K) > 160 * 1024) nch = 0;
         return {nch ? 512 : 0, nch, kind};
     }
     if (kind == KIND_F64_FULL) {
@@ -842,7 +845,8 @@ size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stor
     const size_t cols = stores_all ? G : (size_t)std::max(n_thin, 1);
     (void)device_gl;
     const size_t nsp = (size_t)pn->n_special + 16 * (size_t)pn->n_sp_grids + 16;
-    size_t b = T * 16 + G * 4 + G * kMaxRow * (es + 8) + 8 + nsp * (es + 8) + cols * Kq * es + G * 16 + T * 8;
+    const size_t col = geo.kind == KIND_F64_DOS ? qa::fb64_alpha_col_elems(pn->K) : Kq;
+    size_t b = T * 16 + G * 4 + G * kMaxRow * (es + 8) + 8 + nsp * (es + 8) + cols * col * es + G * 16 + T * 8;
     if (gamma) b += G * Kq * es;
     if (beta) b += G * Kq * es;
     if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 8 + 64 * 12);   // (lists of up to 64 entries)
@@ -851,8 +855,8 @@ size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stor
 
 // how many homogeneous passes fit, and make the arena big enough for them
 int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
-    const size_t fixed = (size_t)pn->G * 8 + ((size_t)1 << 20);
-    const size_t budget = pn->arena.budget_shared(pn->share);
+    const size_t fixed = (size_t)pn->G * 8 + ((size_t)2 << 20);
+    const size_t budget = pn->A().budget_shared(pn->sharers());
     long n = budget > fixed ? (long)((budget - fixed) / per_pass) : 0;
     n = std::max<long>(1, std::min<long>(n, remaining));
     // One pass is one workgroup and a compute unit holds one such workgroup: a launch runs in rounds of n_cu passes.  When
@@ -864,8 +868,8 @@ int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
         return std::max(prop.multiProcessorCount, 1);
     }();
     if (n < remaining && n > n_cu) n = n / n_cu * n_cu;
-    pn->arena.require(fixed + (size_t)n * per_pass);
-    pn->arena.reset();
+    pn->A().require(fixed + (size_t)n * per_pass);
+    pn->A().reset();
     return (int)n;
 }
 
@@ -883,6 +887,10 @@ void launch_fb(const PassParams &prm, int NT, hipStream_t s, hipEvent_t e_mid) {
 }
 
 void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, hipEvent_t e_mid) {
+    if (geo.kind == KIND_F64_DOS) {
+        qa::launch_fb64_dosage(&prm, st, e_mid);
+        return;
+    }
     if (geo.kind == KIND_F64_RANK) {
         qa::launch_fb64(&prm, st, e_mid);
         return;
@@ -921,6 +929,13 @@ void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, h
     }
 }
 
+// the kernels behind the dosage passes of a handle: fp32 state, or (qa_panel_set_dosage_precision(64)) the fp64 dosage
+// kernels -- the generic fp64 kernels when K exceeds those kernels' on-chip capacity
+PassKind dosage_kind(const qa_panel *pn) {
+    if (!pn->dosage_fp64) return KIND_F32;
+    return pick_geometry(pn->K, KIND_F64_DOS).NT ? KIND_F64_DOS : KIND_F64_FULL;
+}
+
 struct BatchOut {
     double *dosage = nullptr;        // [P][T] (row p, or dosage_rows[p] when given)
     const int32_t *dosage_rows = nullptr;
@@ -952,7 +967,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     const Geometry geo = pick_geometry(pn->K, kind);
     if (geo.NT == 0) {
         qa::set_error("K = %d exceeds the on-chip capacity of the %s full-pass kernels", pn->K,
-                      kind == KIND_F32 ? "fp32" : kind == KIND_F64_RANK ? "fp64 ranking" : "generic fp64");
+                      kind == KIND_F32 ? "fp32" : kind == KIND_F64_RANK ? "fp64 ranking" : kind == KIND_F64_DOS ? "fp64 dosage" : "generic fp64");
         return QA_ERR_UNSUPPORTED;
     }
     const bool f64 = geo.f64();
@@ -960,8 +975,13 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     if (kind == KIND_F64_RANK)
         for (int p = 0; p < P; p++)
             if (h_flags[p] & 15) throw std::runtime_error("fp64 ranking passes carry no dosage / gamma / beta outputs");
+    if (kind == KIND_F64_DOS) {
+        for (int p = 0; p < P; p++)
+            if (!(h_flags[p] & 1) || (h_flags[p] & 12)) throw std::runtime_error("fp64 dosage passes yield the dosage (and c) only");
+        if (K_top > 0) throw std::runtime_error("fp64 dosage passes carry no best-haplotype lists (the ranking passes do)");
+    }
     QA_HIP(hipSetDevice(pn->device));
-    if (!pn->scratch) pn->scratch = new qa_panel::Scratch(&pn->arena);
+    if (!pn->scratch) pn->scratch = new qa_panel::Scratch(&pn->A());
     auto &S = *pn->scratch;
     hipStream_t st = pn->pass_stream ? pn->pass_stream : pn->stream;
     for (auto &e : S.ev) if (!e) QA_HIP(hipEventCreate(&e));
@@ -992,8 +1012,9 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     const bool any_top = n_thin > 0 && K_top > 0;
     // the fp64 ranking kernels pick the lists themselves when only the ordered head of each list is wanted (the driver)
     const bool fused = any_top && kind == KIND_F64_RANK && out.truncate_lists && out.top_cap <= 64;
-    const size_t alpha_stride = max_cols * (size_t)Kq;
-    const bool lazy = kind == KIND_F64_RANK;
+    const size_t alpha_col = kind == KIND_F64_DOS ? qa::fb64_alpha_col_elems(K) : (size_t)Kq;
+    const size_t alpha_stride = max_cols * alpha_col;
+    const bool lazy = kind == KIND_F64_RANK || kind == KIND_F64_DOS;
     const size_t esp_stride = (size_t)pn->n_special + (lazy ? 16 * (size_t)pn->n_sp_grids : 0) + 16;
 
     if (gl) {   // host gl; otherwise the caller has filled S.gl on the device already (k_make_gl)
@@ -1011,7 +1032,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     S.emin.ensure((size_t)P * G);
     S.esp.ensure((size_t)P * esp_stride * es);
     S.gsp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1) * es);
-    S.alpha.ensure((size_t)P * alpha_stride * es);
+    S.alpha.ensure((size_t)P * alpha_stride * es + ((size_t)1 << 20));   // (slack: k_bwd64d's idle lanes fetch a fixed line past a short column)
     S.c.ensure((size_t)P * G);
     S.mg.ensure((size_t)P * G * kMaxRow * (f64 ? 8 : 4));
     S.dosage.ensure((size_t)P * T);
@@ -1033,7 +1054,8 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.emin = S.emin.p; prm.esp_stride = (int)esp_stride;
 
     prm.emat = S.emat.p; prm.esp = S.esp.p; prm.escale0 = S.escale0.p; prm.alpha = S.alpha.p; prm.alpha_slot = S.alpha_slot.p;
-    prm.alpha_pass_stride = alpha_stride; prm.Kq = Kq; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;
+    prm.alpha_pass_stride = alpha_stride; prm.Kq = Kq; prm.alpha_col_elems = alpha_col;
+    prm.hist_unit = kind == KIND_F64_DOS ? 1.0 / 2251799813685248.0 /* 2^-51: k_bwd64d */ : 1.0 / kHistScale64; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;
     prm.gamma_out = any_gamma ? S.gamma.p : nullptr; prm.beta_out = any_beta ? S.beta.p : nullptr;
     // Dosage rows that go to consecutive rows of a qa_host_alloc buffer are written there by k_dosage itself (every element
     // once, 256 contiguous bytes per workgroup): the transfer rides under the kernel instead of following it.
@@ -1133,8 +1155,8 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         const double t_e = qa::profile_clock_ms(S.ev[0]);
         double at = t_e;
         qa::profile_add(qa::PK_EMAT, g_timing[0], (double)P * T * 16.0 + (double)P * G * kMaxRow * es, at); at += g_timing[0];
-        const int pk_f = kind == KIND_F32 ? qa::PK_FWD : kind == KIND_F64_RANK ? qa::PK_FWD64 : qa::PK_FWD64G;
-        const int pk_b = kind == KIND_F32 ? qa::PK_BWD : kind == KIND_F64_RANK ? qa::PK_BWD64 : qa::PK_BWD64G;
+        const int pk_f = kind == KIND_F32 ? qa::PK_FWD : kind == KIND_F64_RANK ? qa::PK_FWD64 : kind == KIND_F64_DOS ? qa::PK_FWD64D : qa::PK_FWD64G;
+        const int pk_b = kind == KIND_F32 ? qa::PK_BWD : kind == KIND_F64_RANK ? qa::PK_BWD64 : kind == KIND_F64_DOS ? qa::PK_BWD64D : qa::PK_BWD64G;
         qa::profile_add(pk_f, g_timing[1], per_dir, at); at += g_timing[1];
         qa::profile_add(pk_b, g_timing[2], per_dir, at); at += g_timing[2];
         if (n_dos > 0) qa::profile_add(qa::PK_DOSAGE, g_timing[3], n_dos * G * kMaxRow * (f64 ? 8.0 : 4.0) + n_dos * T * 8.0, at);
@@ -1290,6 +1312,8 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         return QA_ERR_INVALID;
     }
     return qa::guarded([&] {
+        qa::GateHold hold;
+        hold.acquire(panel->gate(), &panel->arena);
         const int G = panel->G;
         std::vector<int32_t> thin(G, -1);
         const bool use_thin = o->get_best_haps_from_thinned_sites || o->return_gammaSmall_t;
@@ -1322,9 +1346,27 @@ int qa_Rcpp_haploid_dosage_versus_refs(
                                 (size_t)panel->K * G * 8 /* un-permute staging */;
             plan_chunk(panel, need, 1);
         };
-        const PassKind main_kind = panel->dosage_fp64 ? KIND_F64_FULL : KIND_F32;
+        // fp64 dosage: the tuned kernels yield dosage and c; a call that also wants alpha / beta / gamma matrices takes the
+        // generic fp64 kernels
+        const bool matrices = alphaHat_t || o->return_betaHat_t || o->return_gamma_t || o->return_gammaSmall_t;
+        const PassKind main_kind = !panel->dosage_fp64 ? KIND_F32 : (matrices || !o->return_dosage) ? KIND_F64_FULL : dosage_kind(panel);
         int st;
-        if (want_lists && panel->rank_fp64 && only_thin) {
+        if (main_kind == KIND_F64_DOS) {
+            std::vector<int32_t> no_thin(G, -1);
+            const int32_t f1 = 1;
+            plan(KIND_F64_DOS, f1);
+            st = run_passes(panel, 1, gl, &f1, no_thin.data(), 0, o->normalize_emissions, out, KIND_F64_DOS,
+                            o->always_normalize, o->min_emission_prob_normalization_threshold);
+            if (st == QA_OK && want_lists) {
+                BatchOut out2;
+                out2.lists = &lists;
+                const int32_t f0 = 0;
+                const PassKind rk = panel->rank_fp64 ? KIND_F64_RANK : KIND_F32;
+                plan(rk, 0);
+                st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, rk,
+                                o->always_normalize, o->min_emission_prob_normalization_threshold);
+            }
+        } else if (want_lists && panel->rank_fp64 && only_thin) {
             // only the lists (and alpha at the thinned grids, c): the fp64 ranking pass, which follows the reference's
             // normalisation schedule (always_normalize / min_emission_prob_normalization_threshold honoured)
             out.lists = &lists;
@@ -1363,14 +1405,18 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
         return QA_ERR_INVALID;
     }
     return qa::guarded([&] {
+        qa::GateHold hold;
+        hold.acquire(panel->gate(), &panel->arena);
         std::vector<int32_t> f(n_pass);
         for (int i = 0; i < n_pass; i++) f[i] = want_dosage[i] ? 1 : 0;
         // chunk the passes so that the alpha checkpoints fit in HBM (K = 50 000, G = 2 000: 0.4 GB per dosage
         // pass, 0.08 GB per thin pass); chunks are homogeneous so that every pass of a chunk has the same footprint
         QA_HIP(hipSetDevice(panel->device));
-        const PassKind main_kind = panel->dosage_fp64 ? KIND_F64_FULL : KIND_F32;
-        // fp64 ranking passes beside fp32 dosage passes; with fp64 dosage passes, or fp32 ranking, one pass yields both
-        const bool exact = panel->rank_fp64 && K_top_matches > 0 && main_kind == KIND_F32;
+        PassKind main_kind = dosage_kind(panel);
+        if (main_kind == KIND_F64_DOS && !panel->rank_fp64 && K_top_matches > 0) main_kind = KIND_F64_FULL;   // (lists from the dosage pass itself)
+        // fp64 ranking passes beside the dosage passes (fp32 state, or the fp64 dosage kernels); with the generic fp64 kernels,
+        // or fp32 ranking, one pass yields both
+        const bool exact = panel->rank_fp64 && K_top_matches > 0 && main_kind != KIND_F64_FULL;
         const Geometry geo = pick_geometry(panel->K, main_kind), geo64 = pick_geometry(panel->K, KIND_F64_RANK);
         if (geo.NT == 0 || (exact && geo64.NT == 0))
             throw std::runtime_error("K exceeds the on-chip capacity of the full-pass kernels");
@@ -1397,14 +1443,14 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
                 done += n;
                 continue;
             }
-            // fp64-state ranking passes for the lists; dosage passes (fp32 state) separately
+            // fp64-state ranking passes for the lists; dosage passes separately
             int n = plan_chunk(panel, pass_bytes(panel, geo64, n_thin, false, false, false, false), run);
             if (dos) n = std::min(n, plan_chunk(panel, pass_bytes(panel, geo, 0, true, false, false, false), run));
             if (dos) {
                 BatchOut out;
                 out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
                 std::vector<int32_t> no_thin(G, -1);
-                status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, no_thin.data(), 0, 1, out, KIND_F32);
+                status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, no_thin.data(), 0, 1, out, main_kind);
                 if (status != QA_OK) break;
                 plan_chunk(panel, pass_bytes(panel, geo64, n_thin, false, false, false, false), n);
             }
@@ -1453,7 +1499,7 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
             }
     return qa::guarded([&] {
         QA_HIP(hipSetDevice(panel->device));
-        if (!panel->scratch) panel->scratch = new qa_panel::Scratch(&panel->arena);
+        if (!panel->scratch) panel->scratch = new qa_panel::Scratch(&panel->A());
         auto &S = *panel->scratch;
         hipStream_t st = panel->pass_stream ? panel->pass_stream : panel->stream;
         const int G = panel->G, T = panel->T;
@@ -1504,8 +1550,9 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
         struct Group { std::vector<int32_t> ids; int32_t flag; int K_top; PassKind kind; };
         std::vector<Group> groups;
         {
-            const PassKind main_kind = panel->dosage_fp64 ? KIND_F64_FULL : KIND_F32;
-            const bool exact = panel->rank_fp64 && main_kind == KIND_F32;   // else one pass yields dosage and lists
+            PassKind main_kind = dosage_kind(panel);
+            if (main_kind == KIND_F64_DOS && !panel->rank_fp64) main_kind = KIND_F64_FULL;   // (lists from the dosage pass itself)
+            const bool exact = panel->rank_fp64 && main_kind != KIND_F64_FULL;   // else one pass yields dosage and lists
             Group gd{{}, 1, 0, main_kind}, gdt{{}, 1, K_top_matches, main_kind},
                 gt{{}, 0, K_top_matches, panel->rank_fp64 ? KIND_F64_RANK : KIND_F32};
             for (int c = 0; c < n_chain; c++) {
@@ -1575,6 +1622,11 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
         // end, and the selection reads no other rows; the runtime's fill is a blit with 512-thread workgroups, which waits
         // for a compute unit free of the other host thread's Gibbs waves -- half a second per occurrence in the r02 trace)
         const bool lists_to_host = top_idx || top_val;
+        // ---- everything above is host work and uploads into this handle's own buffers; the launch sets below have the
+        // device (exclusive phases: queue behind the other handles' launch sets) and the arena
+        const double T1q = now();
+        qa::GateHold hold;
+        hold.acquire(panel->gate(), &panel->arena);
         const double T1 = now();
         for (const Group &grp : groups) {
             const Geometry geo = pick_geometry(panel->K, grp.kind);
@@ -1670,9 +1722,10 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
             QA_HIP(hipEventDestroy(e0)); QA_HIP(hipEventDestroy(e1));
             // a truncated list only matters to the exhausted branch, which the device leaves to the host (status 1)
         }
+        hold.release();
         if (tmg)
-            fprintf(stderr, "[qa_fullpass_reads P=%d] index+uploads %.3f s, run_passes %.3f s (device %.3f s), scatter etc %.3f s\n", P,
-                    T1 - T0, t_run, t_kern, now() - T1 - t_run);
+            fprintf(stderr, "[qa_fullpass_reads P=%d] index+uploads %.3f s, queued for the device %.3f s, run_passes %.3f s (device %.3f s), scatter etc %.3f s\n", P,
+                    T1q - T0, T1 - T1q, t_run, t_kern, now() - T1 - t_run);
         return status;
     });
 }

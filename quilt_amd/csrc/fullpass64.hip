@@ -79,8 +79,8 @@ struct Lds {
 };
 
 // state vectors of LDS row r for thread t: st[q * stride], q = 0..7 (rows before the last hold 512 lanes, the last n_last)
-template <int NL>
-__device__ __forceinline__ double2 *lds_row(const Lds &L, int r, int t) { return L.state + (size_t)r * 8 * kNT + t; }
+template <int NL, typename LT>
+__device__ __forceinline__ double2 *lds_row(const LT &L, int r, int t) { return L.state + (size_t)r * 8 * kNT + t; }
 template <int NL>
 __device__ __forceinline__ int lds_stride(int r, int n_last) { return r == NL - 1 ? n_last : kNT; }
 
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
     const double *emin = prm.emin + (size_t)p * G;
     double2 *aout = reinterpret_cast<double2 *>(static_cast<double *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
     const int32_t *slot = prm.alpha_slot + (size_t)p * G;
-    const size_t col_vecs = (size_t)prm.Kq / 2;
+    const size_t col_vecs = (size_t)prm.alpha_col_elems / 2;
     const double double_K = uniform((double)K), one_over_K = uniform(1 / (double)K);
 
     double a[NR][16];
@@ -425,7 +425,8 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
     const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
     const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.esp_stride;
     const double *emin = prm.emin + (size_t)p * G;
-    const size_t col_vecs = (size_t)prm.Kq / 2;
+    const size_t col_vecs = (size_t)prm.alpha_col_elems / 2;   // (beta_thin, if asked for, keeps the Kq pitch k_topk reads)
+    const size_t col_vecs_q = (size_t)prm.Kq / 2;
     const double *cvec = prm.c + (size_t)p * G;
     const int32_t *slot = prm.alpha_slot + (size_t)p * G;
     const double2 *ain = reinterpret_cast<const double2 *>(static_cast<const double *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
                 if (tp == 0) L.misc[0] = 0;
             }
             if (to_topk && prm.beta_thin) {
-                double2 *dst = reinterpret_cast<double2 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs;
+                double2 *dst = reinterpret_cast<double2 *>(prm.beta_thin) + ((size_t)p * prm.n_thin + tcol) * col_vecs_q;
                 static_for<NCH>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const int k0 = (j * NT + tp) * 16;
@@ -641,6 +642,289 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
         val_prev = val;
         x_prev = uniform(c_g * not_jump_prob);   // beta *= c_g * sigma_g (:2165-2166), applied when the state is next touched
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// backward of a DOSAGE pass with fp64 state (qa_panel_set_dosage_precision(64)): the reference's arithmetic throughout
+// (reference-single.cpp:1781-2179 with the lazily normalised alpha of k_fwd64, stored at EVERY grid), gamma = alpha * beta
+// histogrammed by haplotype code for k_dosage (:2083-2139).
+//
+// Bytes: 1 B code + 8 B alpha per cell -- with the forward's 1 + 8 the 18 K G of SURVEY.md 8(d) ("fp64 alpha as in the
+// reference").  At 0.8 GB of alpha per pass the kernel is bound by that stream (one pass per compute unit, 256 at a time:
+// 205 GB per launch), not by its arithmetic, so the structure differs from k_bwd64's:
+//   * gamma of grid g is formed when the state is next touched anyway -- in the chunk loop that applies grid g's
+//     emissions (iteration g - 1), where beta_g = state + val is a by-product and the haplotype codes of grid g are already
+//     decoded for the emission look-up: one pass over the state per grid, one decode per cell.  Grid 0 gets an epilogue.
+//   * alpha and the codes are fetched ONE CHUNK AHEAD (9 x 16 B per lane in flight, 36 KB per compute unit: enough for the
+//     stream at this rate) instead of a grid ahead: 72 registers for two chunks of alpha and codes, which is what fits
+//     beside four chunk rows of state.
+//   * the histogram: LDS u64 bins, 8 copies per code (lane & 7) -- all the LDS the three state rows leave (16 KB).  A cell
+//     adds gamma * sigma_g in fixed point at 2^-51: the double (gamma * sigma_g * 2^51 + 2^52) carries that integer in its
+//     mantissa (one multiply, one add, one AND instead of a float -> u64 conversion).  gamma * sigma sums to 1 over a grid
+//     (colSums(gamma_t) == 1), so a bin never exceeds 2^51; rounding is to nearest at 2^-52 of the total: 1e-16 per cell,
+//     ~1e-13 over K = 50 000 cells (the bar against the oracle is 1e-9).  Integer adds commute: the bins do not depend on
+//     the order the waves reach them.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHistCopiesD = 8;
+constexpr int kNStreamD = 6;   // SC_SIG .. SC_C
+constexpr size_t kLdsFixedD = 2 * kMaxRow * 8 + 2 * 16 * 8 + kNStreamD * 64 * 8 + (size_t)kMaxRow * kHistCopiesD * 8;
+inline size_t lds_bytes_d(const Geo64 &g) { return kLdsFixedD + (g.NL > 0 ? ((size_t)(g.NL - 1) * kNT + g.n_last) * 128 : 0); }
+
+struct LdsD {
+    double *etab;                // [2][256]
+    double *red;                 // [2][16]
+    double *sc;                  // [kNStreamD][64]
+    unsigned long long *hist;    // [256][kHistCopiesD]
+    double2 *state;
+    __device__ __forceinline__ explicit LdsD(char *smem) {
+        etab = reinterpret_cast<double *>(smem);
+        red = etab + 2 * kMaxRow;
+        sc = red + 2 * 16;
+        hist = reinterpret_cast<unsigned long long *>(sc + kNStreamD * 64);
+        state = reinterpret_cast<double2 *>(hist + kMaxRow * kHistCopiesD);
+    }
+};
+
+// eight haplotypes of a chunk: t = x + v is beta of the grid whose emissions are about to be applied; gamma = alpha * t goes
+// to the histogram bin of the haplotype's code; then x <- (t * s) * table[code] (k_bwd64's update)
+template <bool EMIT>
+__device__ __forceinline__ void half_step_dos(double (&x)[8], uint32_t w0, uint32_t w1, const double *et, double v, double s,
+                                              const double2 *a, double scale, unsigned long long *hist_lane, bool hist_on) {
+    const uint32_t w[2] = {w0, w1};
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {   // look-ups in batches of four, back to back, then the arithmetic
+        double e[4];
+        uint32_t code[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            code[i] = (w[hh] >> (i * 8)) & 0xffu;
+            if (EMIT) e[i] = et[code[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ii = 4 * hh + i;
+            const double t = x[ii] + v;
+            const double gam = ((ii & 1) ? a[ii >> 1].y : a[ii >> 1].x) * t;
+            const double y = gam * scale + 4503599627370496.0;   // 2^52: the mantissa now holds round(gam * scale)
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(y) & 0x000fffffffffffffull;
+            if (hist_on) atomicAdd(hist_lane + code[i] * kHistCopiesD, bits);
+            if (EMIT) x[ii] = (t * s) * e[i];
+        }
+    }
+}
+
+// gamma of the special haplotypes (code 0) of half a chunk -> their own list (:2096-2128); `at` = index of the half's first
+// special in the pass's gsp array, k0 the haplotype of its first element
+__device__ __forceinline__ void special_gammas(const double (&x_before)[8], uint32_t w0, uint32_t w1, double v, const double2 *a,
+                                               double *gsp, int at, int k0, int K) {
+    const uint32_t w[2] = {w0, w1};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+        if (code == 0 && k0 + i < K) {
+            gsp[at] = ((i & 1) ? a[i >> 1].y : a[i >> 1].x) * (x_before[i] + v);
+            at++;
+        }
+    }
+}
+
+template <int NR, int NL>
+__global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
+    constexpr int NCH = NR + NL, NT = kNT, nwaves = NT >> 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const LdsD L(smem);
+    const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t lds_etab = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const int K = prm.K, G = prm.G;
+    const double *emat = static_cast<const double *>(prm.emat) + (size_t)p * G * kMaxRow;
+    const double *esp = static_cast<const double *>(prm.esp) + (size_t)p * prm.esp_stride;
+    const double *emin = prm.emin + (size_t)p * G;
+    const size_t col_vecs = (size_t)prm.alpha_col_elems / 2;
+    const double *cvec = prm.c + (size_t)p * G;
+    const double2 *ain = reinterpret_cast<const double2 *>(static_cast<const double *>(prm.alpha) + (size_t)p * prm.alpha_pass_stride);
+    double *gsp = static_cast<double *>(prm.gsp) + (size_t)p * prm.n_special;
+    unsigned long long *mg = static_cast<unsigned long long *>(prm.mg) + (size_t)p * G * kMaxRow;
+    const double double_K = uniform((double)K);
+    const bool last_row_wave = wave * 64 < n_last;   // the last chunk row holds n_last lanes only
+
+    double b[NR][16];
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const int k0 = (j * NT + t) * 16;
+        if (j < NR) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) b[j][i] = (k0 + i < K) ? 1.0 : 0.0;   // beta(G-1) = 1 (:1866-1870)
+        } else if (j - NR < NL - 1 || t < n_last) {
+            double2 *st = lds_row<NL>(L, j - NR, t);
+            const int stride = lds_stride<NL>(j - NR, n_last);
+#pragma unroll
+            for (int q = 0; q < 8; q++) st[q * stride] = make_double2(k0 + 2 * q < K ? 1.0 : 0.0, k0 + 2 * q + 1 < K ? 1.0 : 0.0);
+        }
+    }
+    for (int i = t; i < kMaxRow * kHistCopiesD; i += NT) L.hist[i] = 0ull;
+    if (t < kMaxRow) L.etab[((G - 1) & 1) * kMaxRow + t] = emat[(size_t)(G - 1) * kMaxRow + t];
+
+    // half a chunk (8 haplotypes of row j) of grid gq: its alpha (4 vectors) and, with the first half, the chunk's codes --
+    // all unconditional 16-byte loads.  A wave without a chunk in the last row fetches one fixed line instead (no branch around
+    // loads: the compiler could not count them).
+    uint4 d_nx;
+    double2 a_nx[4];
+    auto prefetch = [&](int gq, int j, int h, int tt) {
+        const bool real = j < NCH - 1 || last_row_wave;
+        // (the codes' row pitch covers whole chunk rows: beyond K they are the zero padding, whose emission is 0)
+        if (h == 0) d_nx = reinterpret_cast<const uint4 *>(prm.hm + (size_t)gq * prm.Kp + (size_t)j * kRowHaps)[tt];
+        const double2 *av = ain + (size_t)gq * col_vecs;
+#pragma unroll
+        for (int q = 0; q < 4; q++) a_nx[q] = av[real ? alpha_vec_index<8>(j, 4 * h + q, NT, tt) : (size_t)(q * 64 + (tt & 63))];
+    };
+    prefetch(G - 1, 0, 0, t);
+    __syncthreads();
+
+    // one pass over the state: gamma of grid gp (its alpha, its codes) into the histogram and, unless gp == 0, the update
+    // with grid gp's emissions.  Returns this thread's share of sum(e * beta).
+    auto process = [&](auto emit_c, int gp, const double *et, const int32_t *sp_at, int sp_g, double v, double s, double fs) -> double {
+        constexpr bool EMIT = decltype(emit_c)::value;
+        const double scale = uniform(fs * 2251799813685248.0);   // sigma_gp * 2^51
+        double psum = 0;
+        uint4 d = make_uint4(0, 0, 0, 0);
+        int n_sp = 0;   // specials of the chunk's first half
+        static_for<2 * NCH>([&](auto jc) {
+            constexpr int j = decltype(jc)::value >> 1, h = decltype(jc)::value & 1;
+            const int tt = fresh_tid(wave);
+            if (h == 0) d = d_nx;
+            double2 a[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = a_nx[q];
+            // the next half chunk (of this grid, or the first of the next grid down) is in flight while this one is consumed
+            if constexpr (h == 0) prefetch(gp, j, 1, tt);
+            else if constexpr (j + 1 < NCH) prefetch(gp, j + 1, 0, tt);
+            else prefetch(gp > 0 ? gp - 1 : 0, 0, 0, tt);
+            const int k0 = (j * NT + tt) * 16;
+            unsigned long long *hl = L.hist + (tt & (kHistCopiesD - 1));
+            const bool on = k0 < K;   // (a chunk wholly beyond K was never stored by the forward)
+            const uint32_t w0 = h ? d.z : d.x, w1 = h ? d.w : d.y;
+            const bool sp = sp_at && (has_zero_byte(w0) || has_zero_byte(w1));
+            auto body = [&](double (&x)[8]) {
+                if (h == 0) n_sp = 0;
+                int at = 0;
+                if (sp) {
+                    at = sp_at[k0 >> 4] + n_sp;   // position in the pass's (lazily padded) special-emission array
+                    if (on) special_gammas(x, w0, w1, v, a, gsp, at - 16 * sp_g, k0 + 8 * h, K);
+                }
+                half_step_dos<EMIT>(x, w0, w1, et, v, s, a, scale, hl, on);
+                if (EMIT) {
+                    if (sp) n_sp += special_half(x, w0, w1, esp + at);
+                    psum += sum8(x);
+                }
+            };
+            if constexpr (j < NR) {
+                body(*reinterpret_cast<double (*)[8]>(&b[j][8 * h]));
+            } else {
+                if (j - NR < NL - 1 || last_row_wave) {
+                    double2 *st = lds_row<NL>(L, j - NR, tt) + (size_t)(4 * h) * lds_stride<NL>(j - NR, n_last);
+                    const int stride = lds_stride<NL>(j - NR, n_last);
+                    double x[8];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const double2 u = st[q * stride];
+                        x[2 * q] = u.x;
+                        x[2 * q + 1] = u.y;
+                    }
+                    body(x);
+                    if (EMIT) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) st[q * stride] = make_double2(x[2 * q], x[2 * q + 1]);
+                    }
+                }
+            }
+        });
+        return psum;
+    };
+    // fold the eight copies of every bin into mg[gp] and clear them (after the barrier that ends gp's atomics; a barrier
+    // of its own before the next grid's begin)
+    auto fold = [&](int gp) {
+        if (t < kMaxRow) {
+            unsigned long long *h = L.hist + t * kHistCopiesD;
+            unsigned long long v = 0;
+#pragma unroll
+            for (int c = 0; c < kHistCopiesD; c++) { v += h[c]; h[c] = 0ull; }
+            mg[(size_t)gp * kMaxRow + t] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    double val_prev = 0.0, x_prev = 1.0, sig_prev = 1.0;
+    double B_prev = 1, B_prev_star = uniform(double_K * cvec[G - 1] * 1.0);   // (:1871)
+    for (int g = G - 1; g >= 0; --g) {
+        const int jl = g & 63;
+        if (jl == 63 || g == G - 1) {
+            __syncthreads();
+            if (t < 64) {
+                const int gb = g & ~63;
+                const int gi = clampi(gb + lane, 0, G - 1), g1 = clampi(gb + lane + 1, 0, G - 1), gs = clampi(gb + lane, 0, G > 1 ? G - 2 : 0);
+                L.sc[SC_SIG * 64 + lane] = G > 1 ? prm.sigma[gs] : 1.0;
+                L.sc[SC_TM1 * 64 + lane] = G > 1 ? prm.tm1[gs] : 0.0;
+                L.sc[SC_EMIN * 64 + lane] = emin[g1];                       // of grid + 1
+                L.sc[SC_SPG * 64 + lane] = (double)prm.sp_gidx[g1];        // of grid + 1
+                L.sc[SC_C * 64 + lane] = cvec[gi];
+            }
+            __syncthreads();
+        }
+        const double c_g = uniform(L.sc[SC_C * 64 + jl]);
+        double not_jump_prob = 1.0, val = 0.0;
+        if (g < G - 1) {
+            const int buf = (g + 1) & 1;
+            const int tt = fresh_tid(wave);
+            dma_table(emat, g, lds_etab, buf ^ 1, wave, tt & 63);   // grid g's table, for iteration g - 1
+            const double jump_prob = uniform(L.sc[SC_TM1 * 64 + jl]) / double_K;
+            not_jump_prob = uniform(L.sc[SC_SIG * 64 + jl]);
+            const double *et = L.etab + buf * kMaxRow;
+            const int sp_g = (int)uniform(L.sc[SC_SPG * 64 + jl]);
+            const int32_t *sp_at = sp_g >= 0 ? prm.sp_chunk_at + (size_t)sp_g * (prm.Kq >> 4) : nullptr;
+            const bool has_variant = uniform(L.sc[SC_EMIN * 64 + jl]) >= 0;
+            const double psum = process(std::true_type{}, g + 1, et, sp_at, sp_g, val_prev, x_prev, sig_prev);
+            // (the table DMA is older than the 5 loads of the half chunk fetched ahead: wait for all but those)
+            const double sum_e_times_b = block_sum64<5>(psum, L.red + (g & 1) * 16, wave, lane, nwaves);
+            fold(g + 1);
+            if (has_variant) {   // (:1945-1982)
+                val = uniform(jump_prob / not_jump_prob * sum_e_times_b);
+                B_prev = sum_e_times_b;
+            } else {
+                val = uniform(jump_prob / not_jump_prob * B_prev_star);
+                B_prev = B_prev_star;
+            }
+            B_prev_star = uniform(c_g * B_prev);
+        }
+        val_prev = val;
+        x_prev = uniform(c_g * not_jump_prob);   // beta *= c_g * sigma_g (:2165-2166), applied when the state is next touched
+        sig_prev = not_jump_prob;
+    }
+    // grid 0: gamma only
+    {
+        const int sp_g = prm.sp_gidx[0];
+        const int32_t *sp_at = sp_g >= 0 ? prm.sp_chunk_at + (size_t)sp_g * (prm.Kq >> 4) : nullptr;
+        process(std::false_type{}, 0, L.etab, sp_at, sp_g, val_prev, x_prev, sig_prev);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        fold(0);
+    }
+}
+
+template <int NR, int NL>
+void launch_dos(const PassParams &prm, const Geo64 &geo, hipStream_t s, hipEvent_t e_mid) {
+    const size_t lds = lds_bytes(geo), lds_d = lds_bytes_d(geo);
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_fwd64<NR, NL>), dim3(prm.P), dim3(kNT), lds, s, prm, geo.n_last);
+    QA_HIP(hipGetLastError());
+    if (e_mid) QA_HIP(hipEventRecord(e_mid, s));
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd64d<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+    hipLaunchKernelGGL((k_bwd64d<NR, NL>), dim3(prm.P), dim3(kNT), lds_d, s, prm, geo.n_last);
+    QA_HIP(hipGetLastError());
 }
 
 template <int NR, int NL>
@@ -661,6 +945,34 @@ namespace qa {
 
 int fb64_chunks(int K) { return geo64(K).NCH; }
 size_t fb64_lds_bytes(int K) { return lds_bytes(geo64(K)); }
+
+// elements per stored alpha column of the dosage passes: the lane-interleaved layout of the chunk rows in use, no padding to
+// whole rows (K = 50 000: 50 176 instead of 57 344 doubles -- 0.80 instead of 0.92 GB per pass over 2 000 grids)
+size_t fb64_alpha_col_elems(int K) {
+    const Geo64 g = geo64(K);
+    return g.NCH ? (size_t)(g.NCH - 1) * kRowHaps + (size_t)g.n_last * 16 : 0;
+}
+size_t fb64_dos_lds_bytes(int K) { return lds_bytes_d(geo64(K)); }
+
+void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
+    const PassParams &prm = *static_cast<const PassParams *>(pass_params);
+    const Geo64 geo = geo64(prm.K);
+    if (geo.NCH == 0 || lds_bytes_d(geo) > kLdsMax) throw std::runtime_error("K exceeds the on-chip capacity of the fp64 dosage kernels");
+    if (prm.Kq != geo.NCH * kRowHaps) throw std::runtime_error("internal: Kq does not match the fp64 geometry");
+    switch (geo.NR * 10 + geo.NL) {
+#ifndef QA_FAST_BUILD
+        case 10: launch_dos<1, 0>(prm, geo, st, e_mid); break;
+        case 20: launch_dos<2, 0>(prm, geo, st, e_mid); break;
+        case 30: launch_dos<3, 0>(prm, geo, st, e_mid); break;
+        case 40: launch_dos<4, 0>(prm, geo, st, e_mid); break;
+        case 41: launch_dos<4, 1>(prm, geo, st, e_mid); break;
+        case 42: launch_dos<4, 2>(prm, geo, st, e_mid); break;
+        case 52: launch_dos<5, 2>(prm, geo, st, e_mid); break;
+#endif
+        case 43: launch_dos<4, 3>(prm, geo, st, e_mid); break;
+        default: throw std::runtime_error("fp64 geometry not built");
+    }
+}
 
 void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
     const PassParams &prm = *static_cast<const PassParams *>(pass_params);

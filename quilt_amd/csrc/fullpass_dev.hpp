@@ -57,6 +57,8 @@ struct PassParams {
     const int32_t *alpha_slot; // [P][G] -> column slot in alpha, or -1
     size_t alpha_pass_stride; // elements
     int Kq;                  // NT * NCH * 16 (padded K of the launch geometry)
+    size_t alpha_col_elems;  // elements between two stored alpha columns of a pass (Kq, or the tighter pitch of the fp64 dosage passes)
+    double hist_unit;        // value of one unit of the fp64 histogram (mg as uint64): 2^-62 (generic kernels) or 2^-51 (k_bwd64d)
     double *c;               // [P][G]
     void *mg;                // [P][G][kMaxRow]  histogram of gamma * sigma_g by code, fixed point (dosage passes): uint32 at
                              // 2^-31 (fp32 state) or uint64 at 2^-62 (fp64 state)
@@ -167,6 +169,10 @@ namespace qa {
 int fb64_chunks(int K);
 size_t fb64_lds_bytes(int K);
 void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
+// the fp64-state DOSAGE passes: k_fwd64 storing every column + k_bwd64d (gamma histogram for k_dosage)
+size_t fb64_alpha_col_elems(int K);
+size_t fb64_dos_lds_bytes(int K);
+void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
 
 // select.hip: everything_select_good_haps on the device (one wave per chain)
 struct SelectParams {

@@ -938,7 +938,9 @@ void launch_gibbs_kernel(const GibbsParams &prm, hipStream_t st) {
 int choose_gibbs_waves(int Ksp, int C, int share) {
     if (Ksp != 640) return 1;
     int nw = 1;
-    if ((long)C * 2 <= 1024 / share) nw = 2;   // share: host threads sharing the device
+    // share: host threads sharing the device; 0: device phases (qa_panel_set_exclusive) -- launches that fit run together, one
+    // SIMD slot per wave, and a phase lasts as long as its slowest launch: one wave per chain always
+    if (share > 0 && (long)C * 2 <= 1024 / share) nw = 2;
     if (const char *forced = getenv("QA_GIBBS_NW")) {   // test hook: exercise every geometry
         const int f = atoi(forced);
         if (f == 1 || f == 2 || f == 5 || f == 10) nw = f;
@@ -1004,7 +1006,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
 
 }  // namespace
 
-static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, int per_it_off, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, int per_it_off, int32_t n_chain, const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
@@ -1016,9 +1018,6 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         const bool tmg = getenv("QA_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double T0 = now();
-        S.er_idx.arena = S.er_tab.arena = &pn->arena;
-        S.eMatRead.arena = S.alpha.arena = S.beta.arena = S.eg.arena = S.cvec.arena = S.hap.arena = S.gm.arena = S.gf.arena = &pn->arena;
-        pn->arena.reset();
         // the Gibbs launches of a handle that shares the device go to its own CU partition (qa_panel_set_cu_partition): the
         // chains hold whole register files for the launch's lifetime, and spread over every CU they would leave no CU free
         // for the other handle's full-panel workgroups
@@ -1034,7 +1033,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         std::vector<size_t> eoff(C), ixoff(C);
         std::vector<uint8_t> ghr((size_t)C * G, 0);
         std::vector<int32_t> dense_of(std::max(totR, 1), -1);
-        const int nw = o->ff != 0.0 ? qa::gibbs3_waves(Ksp, C, pn->share) : choose_gibbs_waves(Ksp, C, pn->share);
+        const int nw = o->ff != 0.0 ? qa::gibbs3_waves(Ksp, C, pn->sharers()) : choose_gibbs_waves(Ksp, C, pn->exclusive ? 0 : pn->share);
         const int er_nt = 64 * nw, er_padb = padb_of(NE / nw);
         int maxR = 0;
         size_t etot = 0, ixtot = 0;
@@ -1149,19 +1148,33 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         if (runif_shard && !seed_shard && o->n_block_gibbs_iterations > 0 && (!nipt || o->perform_block_gibbs))
             S.runif_shard.upload(runif_shard, nshard_used, st);
         S.eread_off.ensure(C); S.eread_off.upload(eoff.data(), C, st);
-        S.eMatRead.ensure(std::max<size_t>(etot, 1));
         S.eridx_off.ensure(C); S.eridx_off.upload(ixoff.data(), C, st);
         S.dense_of.ensure(dense_of.size()); S.dense_of.upload(dense_of.data(), dense_of.size(), st);
-        S.er_idx.ensure(std::max<size_t>(ixtot, 1));
-        S.er_tab.ensure(std::max<size_t>((size_t)totR * 64, 1));
         S.is_cat1.ensure(std::max(totR, 1));
         const int nH = o->ff != 0.0 ? 3 : 2;
         const size_t mat = (size_t)C * nH * G * Ksp;
-        S.alpha.ensure(mat); S.beta.ensure(mat); S.eg.ensure(mat);
-        S.cvec.ensure((size_t)C * 3 * G);
         S.H.ensure(std::max(totR, 1)); S.H.upload(H, totR, st);
         S.H_class.ensure(std::max(totR, 1));
         S.status.ensure(C);
+        if (o->per_it_out) S.per_it.ensure((size_t)C * n_its * 8);
+        if (ff_chain) { S.ff_chain.ensure(C); S.ff_chain.upload(ff_chain, C, st); }
+        if (rc) { S.rc_any.ensure(std::max<size_t>(rc_any.size(), 1)); S.rc_any.upload(rc_any.data(), rc_any.size(), st); }
+        // ---- everything above is host work and uploads into this thread's own buffers; from here on the launch set has the
+        // device (exclusive phases: queue behind the other handles' launch sets) and the arena
+        const double hold_t0 = now();
+        qa::GateHold hold;
+        hold.acquire(pn->gate(), &pn->arena, C * nw, arena_need);
+        const double T1g = now();
+        qa::Arena &arena = hold.arena();
+        S.er_idx.arena = S.er_tab.arena = &arena;
+        S.eMatRead.arena = S.alpha.arena = S.beta.arena = S.eg.arena = S.cvec.arena = S.hap.arena = S.gm.arena = S.gf.arena = &arena;
+        arena.require(arena_need);
+        arena.reset();
+        S.eMatRead.ensure(std::max<size_t>(etot, 1));
+        S.er_idx.ensure(std::max<size_t>(ixtot, 1));
+        S.er_tab.ensure(std::max<size_t>((size_t)totR * 64, 1));
+        S.alpha.ensure(mat); S.beta.ensure(mat); S.eg.ensure(mat);
+        S.cvec.ensure((size_t)C * 3 * G);
         if (hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out) {
             S.hap.ensure((size_t)C * T * 3); S.gm.ensure((size_t)C * T * 3); S.gf.ensure((size_t)C * T * 3);
         }
@@ -1184,14 +1197,10 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         prm.it_begin = 0; prm.it_end = n_its;
         prm.ff = o->ff;
         if (o->per_it_out) {
-            S.per_it.ensure((size_t)C * n_its * 8);
             QA_HIP(hipMemsetAsync(S.per_it.p, 0, sizeof(double) * C * n_its * 8, st));
             prm.per_it = S.per_it.p;
         }
-        if (ff_chain) {
-            S.ff_chain.ensure(C); S.ff_chain.upload(ff_chain, C, st);
-            prm.ff_chain = S.ff_chain.p;
-        }
+        if (ff_chain) prm.ff_chain = S.ff_chain.p;
         prm.runif_reads = S.runif_reads.p; prm.first_read = S.first_read.p; prm.runif_shard = S.runif_shard.p;
         prm.seed_reads = seed_reads ? S.seeds.p : nullptr;
         prm.seed_shard = (seed_reads && seed_shard) ? S.seeds.p + C : nullptr;
@@ -1202,7 +1211,6 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         prm.H = S.H.p; prm.H_class = S.H_class.p; prm.status = S.status.p;
         prm.hapProbs = S.hap.p; prm.genProbsM = S.gm.p; prm.genProbsF = S.gf.p;
         if (rc) {
-            S.rc_any.ensure(std::max<size_t>(rc_any.size(), 1)); S.rc_any.upload(rc_any.data(), rc_any.size(), st);
             prm.rc_common = rc->common_index.p; prm.rc_rare_ptr = rc->rare_ptr.p; prm.rc_rare_snp = rc->rare_snp.p;
             prm.rc_any = S.rc_any.p; prm.rc_words = rc_words; prm.rc_Gc = pn->G;
         }
@@ -1294,6 +1302,7 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
         if (genProbsM_t) S.gm.download(genProbsM_t, (size_t)C * T * 3, st);
         if (genProbsF_t) S.gf.download(genProbsF_t, (size_t)C * T * 3, st);
         QA_HIP(hipStreamSynchronize(st));
+        if (!(state_out && C == 1)) hold.release();
         {
             float ms[3];
             for (int i = 0; i < 3; i++) QA_HIP(hipEventElapsedTime(&ms[i], g_gibbs->ev[i], g_gibbs->ev[i + 1]));
@@ -1312,8 +1321,8 @@ static int gibbs_chunk(qa_panel_t *pn, const qa_rare_common *rc, const qa_gibbs_
             qa::profile_add(nH == 3 ? qa::PK_GIBBS3 : qa::PK_GIBBS, ms[1], sweeps * (nH / 2.0), t_e + ms[0], units, serial);
             if (want_probs) qa::profile_add(qa::PK_HAPPROBS, ms[2], C * (double)nH * Ks * (double)G * 16.0, t_e + ms[0] + ms[1]);
             if (tmg)
-                fprintf(stderr, "[qa_gibbs C=%d] host prep %.3f s, tables+uploads %.3f s, kernels %.3f s (events %.3f), downloads %.3f s\n", C,
-                        T1 - T0, T2 - T1, T3 - T2, (ms[0] + ms[1] + ms[2]) / 1e3, now() - T3);
+                fprintf(stderr, "[qa_gibbs C=%d] host prep %.3f s, tables+uploads %.3f s (of which queued for the device %.3f s), kernels %.3f s (events %.3f), downloads %.3f s\n", C,
+                        T1 - T0, T2 - T1, T1g - hold_t0, T3 - T2, (ms[0] + ms[1] + ms[2]) / 1e3, now() - T3);
         }
         int ret = QA_OK;
         for (int c = 0; c < C; c++) {
@@ -1405,7 +1414,7 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             const int R = read_off[c + 1] - read_off[c];
             base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
         }
-        const size_t budget = pn->arena.budget_shared(pn->share);
+        const size_t budget = pn->A().budget_shared(pn->sharers());
         // device bytes per chain: read emissions -- pattern bytes (<= 2560 B) + table (512 B) per read, a dense Ks-column for
         // the reads with more bases than the pattern width (an upper bound of those that end up dense) -- and the state matrices
         std::vector<size_t> adds(n_chain);
@@ -1438,11 +1447,10 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
                 need += adds[c1];
                 c1++;
             }
-            pn->arena.require(need);
             std::vector<int32_t> ro(c1 - c0 + 1);
             for (int i = 0; i <= c1 - c0; i++) ro[i] = read_off[c0 + i] - read_off[c0];
             const int st = gibbs_chunk(
-                pn, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, c0, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
+                pn, need, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, c0, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
                 u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
                 runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
                 runif_shard ? runif_shard + (o->ff != 0.0 ? (size_t)read_off[c0] * nb * 2 : (size_t)c0 * nb * (G - 1)) : nullptr,

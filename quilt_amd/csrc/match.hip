@@ -144,17 +144,20 @@ int qa_find_good_matches(qa_panel_t *panel, int32_t n_query, const int32_t *Zs, 
         const int G = panel->G, K = panel->K;
         // queries in slabs that fit the handle's arena: per query G words + G symbols + 4 B per haplotype and index + results
         const size_t per_q = (size_t)G * 5 + (size_t)nindices * K * 4 + (size_t)nindices * (max_matches * 12 + 4) + 1024;
-        const size_t budget = panel->arena.budget_shared(panel->share);
+        qa::GateHold hold;
+        hold.acquire(panel->gate(), &panel->arena);
+        qa::Arena &arena = hold.arena();
+        const size_t budget = arena.budget_shared(panel->sharers());
         const int slab = (int)std::max<size_t>(1, std::min<size_t>(n_query, budget / per_q));
-        panel->arena.require((size_t)slab * per_q + 4096);
+        arena.require((size_t)slab * per_q + 4096);
         for (int q0 = 0; q0 < n_query; q0 += slab) {
             const int nq = std::min(slab, n_query - q0);
-            panel->arena.reset();
+            arena.reset();
             qa::ABuf<int32_t> d_Z, d_match, d_n;
             qa::ABuf<uint8_t> d_qc;
             qa::ABuf<uint16_t> d_len, d_start;
-            for (auto *b : {&d_Z, &d_match, &d_n}) b->arena = &panel->arena;
-            d_qc.arena = d_len.arena = d_start.arena = &panel->arena;
+            for (auto *b : {&d_Z, &d_match, &d_n}) b->arena = &arena;
+            d_qc.arena = d_len.arena = d_start.arena = &arena;
             d_Z.ensure((size_t)nq * G); d_qc.ensure((size_t)nq * G);
             d_len.ensure((size_t)nq * nindices * K); d_start.ensure((size_t)nq * nindices * K);
             d_match.ensure((size_t)nq * nindices * max_matches * 3); d_n.ensure((size_t)nq * nindices);

@@ -38,6 +38,14 @@ bool device_ready() {
     return cached == 1;
 }
 
+DeviceGate &device_gate(int device) {
+    static DeviceGate gates[16];
+    return gates[device >= 0 && device < 16 ? device : 0];
+}
+double GateHold::now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // the reference's clamped halving search over rows s1..e1 (1-based) of the special matrix
 // (QUILT/src/gibbs-small.cpp:69-105), quirks included: this is how the device tables inherit
 // exactly the word the reference would decode.
@@ -92,7 +100,7 @@ void profile_add(int kernel, double ms, double alg_bytes, double start_ms, doubl
 
 static const char *const kProfileNames[PK_COUNT] = {
     "k_emat", "k_fwd", "k_bwd", "k_dosage", "k_ematread", "k_gibbs", "k_happrobs", "k_fwd64", "k_bwd64", "k_topk",
-    "k_fwd<double>", "k_bwd<double>", "k_gibbs3", "k_block3", "k_select", "k_best_run"};
+    "k_fwd<double>", "k_bwd<double>", "k_gibbs3", "k_block3", "k_select", "k_best_run", "k_fwd64d", "k_bwd64d"};
 
 // sp_gidx / sp_chunk_at (see panel.hpp): one thread per (grid with specials, 16-haplotype chunk), lower bound of the
 // chunk's first haplotype in the grid's ascending special list, shifted into the padded per-pass layout
@@ -376,6 +384,35 @@ int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers) {
         return QA_ERR_INVALID;
     }
     panel->share = n_sharers;
+    return QA_OK;
+}
+
+int qa_panel_set_exclusive(qa_panel_t *panel, int32_t on) {
+    if (!panel) {
+        qa::set_error("qa_panel_set_exclusive: null handle");
+        return QA_ERR_INVALID;
+    }
+    if ((on != 0) != panel->exclusive) {
+        delete panel->scratch;   // its buffers are views of the arena in use
+        panel->scratch = nullptr;
+        panel->exclusive = on != 0;
+    }
+    return QA_OK;
+}
+
+int qa_gate_stats(int32_t device, double out[3]) {
+    if (!out || device < 0 || device >= 16) return QA_ERR_INVALID;
+    qa::DeviceGate &g = qa::device_gate(device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    out[0] = g.held_ms; out[1] = g.wait_ms; out[2] = (double)g.n_holds;
+    return QA_OK;
+}
+
+int qa_gate_stats_reset(int32_t device) {
+    if (device < 0 || device >= 16) return QA_ERR_INVALID;
+    qa::DeviceGate &g = qa::device_gate(device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.held_ms = g.wait_ms = 0; g.n_holds = 0;
     return QA_OK;
 }
 

@@ -40,7 +40,13 @@ struct qa_panel {
     hipStream_t stream = nullptr;
     hipStream_t pass_stream = nullptr;    // higher-priority stream of the full-panel calls (qa_panel_set_pass_priority), else null
     hipStream_t gibbs_stream = nullptr;   // CU-masked stream of the Gibbs launches (qa_panel_set_cu_partition), else null
-    qa::Arena arena;            // scratch of every launch set on this panel (see common.hpp)
+    qa::Arena arena;            // scratch of every launch set on this panel (see common.hpp) -- unless `exclusive`
+    bool exclusive = false;     // launch sets run with the device to themselves, out of the device-wide arena (qa_panel_set_exclusive)
+    // the gate this handle's launch sets hold while they run (null: none; the handle's own arena then), and the arena whose
+    // size plans them (GateHold::arena() is the one they carve from)
+    qa::DeviceGate *gate() { return exclusive ? &qa::device_gate(device) : nullptr; }
+    qa::Arena &A() { return exclusive ? qa::device_gate(device).arena : arena; }
+    int sharers() const { return exclusive ? 1 : share; }   // handles whose launch sets may be on the device at the same time
     qa::Arena aux;              // per-call index / list buffers of the driver-level entry points (grow-only: a call-local
                                 // hipMalloc / hipFree pair would synchronise the device with the other host threads' launches)
     // scratch owned by the panel handle, grown on demand (see fullpass.hip)

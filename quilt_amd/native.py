@@ -182,6 +182,12 @@ class DevicePanel:
         """Confine this handle's Gibbs launches to the index-th of ``count`` equal CU partitions (count = 1: no mask)."""
         check(lib().qa_panel_set_cu_partition(self.handle, C.c_int32(index), C.c_int32(count)))
 
+    def set_exclusive(self, on: bool = True):
+        """Exclusive device phases: this handle's launch sets run with the device to themselves, out of the device-wide arena,
+        queueing in arrival order behind those of the other handles that opted in (include/quilt_amd.h)."""
+        lib().qa_panel_set_exclusive.restype = C.c_int
+        check(lib().qa_panel_set_exclusive(self.handle, C.c_int32(int(on))))
+
     def set_pass_priority(self, on: bool = True):
         """Full-panel calls of this handle on a highest-priority stream (several handles sharing the device)."""
         lib().qa_panel_set_pass_priority.restype = C.c_int
@@ -228,6 +234,16 @@ class DeviceRareCommon:
             self.close()
         except Exception:
             pass
+
+
+def gate_stats(device: int = 0, reset: bool = False) -> dict:
+    """Exclusive device phases (DevicePanel.set_exclusive): ms some handle held the device, ms callers queued, holds."""
+    out = (C.c_double * 3)()
+    lib().qa_gate_stats.restype = C.c_int
+    check(lib().qa_gate_stats(C.c_int32(device), out))
+    if reset:
+        lib().qa_gate_stats_reset(C.c_int32(device))
+    return dict(held_ms=out[0], queued_ms=out[1], holds=int(out[2]))
 
 
 def last_fullpass_timing_ms():

@@ -46,7 +46,7 @@ class PairGate:
 class DeviceWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
                  cu_partition: bool = False, fp64_dosage: bool = False, split: str = "halves", gibbs_gate: float = 0.0,
-                 pass_priority: bool = False):
+                 pass_priority: bool = False, exclusive: bool = False):
         self.n = n_workers
         # "halves": every batch is cut into one contiguous part per thread; "alternate": whole batches go to the threads in turn
         # (a thread's Gibbs launch then carries a whole batch's chains -- 1 024 at the defaults, one per SIMD -- instead of half)
@@ -56,6 +56,8 @@ class DeviceWorkers:
         self.devs = [DevicePanel(panel) for _ in range(n_workers)]
         for w, d in enumerate(self.devs):
             d.set_device_share(n_workers)
+            if exclusive and n_workers > 1:   # launch sets take the device in turn, each with all of it
+                d.set_exclusive(True)
             if fp64_dosage:   # dosage passes with fp64 state, as the reference (verification mode)
                 d.set_dosage_precision(64)
             if pass_priority and n_workers > 1:   # full-panel calls ahead of the other threads' Gibbs launches

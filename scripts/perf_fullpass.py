@@ -18,6 +18,7 @@ ap.add_argument("--P", type=int, default=256)
 ap.add_argument("--thin-frac", type=float, default=0.0, help="fraction of thin passes")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--ktop", type=int, default=5)
+ap.add_argument("--fp64", action="store_true", help="dosage passes with fp64 state (k_fwd64 + k_bwd64d)")
 ap.add_argument("--driver", action="store_true", help="time the driver path (qa_fullpass_reads_batch: fused top-K)")
 a = ap.parse_args()
 
@@ -25,6 +26,8 @@ t0 = time.time()
 panel = make_synthetic_panel(K=a.K, nSNPs=a.T, seed=4916, keep_rhb_t=True)
 print(f"panel built in {time.time() - t0:.1f}s: K={panel.K} G={panel.nGrids}", flush=True)
 dev = DevicePanel(panel)
+if a.fp64:
+    dev.set_dosage_precision(64)
 G, T = panel.nGrids, panel.nSNPs
 rng = np.random.default_rng(1)
 # synthetic gl: ~10 % of SNPs informative per label

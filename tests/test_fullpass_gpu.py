@@ -173,3 +173,98 @@ def test_production_k_geometry(oracle, K):
         np.testing.assert_allclose(got["c"], ref["c"], rtol=1e-4)
         check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
     dev.close()
+
+
+def _dosage_only(dev, gl, cols=None, lists=False):
+    """The call a dosage round makes: dosage and c, no K x G matrices (with fp64 dosage precision: k_fwd64 + k_bwd64d)."""
+    from quilt_amd.reference_single import Rcpp_haploid_dosage_versus_refs
+    P = dev.panel
+    out = dict(c=np.ones(P.nGrids), dosage=np.zeros(P.nSNPs))
+    if lists:
+        out["best_haps_stuff_list"] = [None] * int((cols >= 0).sum())
+    Rcpp_haploid_dosage_versus_refs(dev, gl, gammaSmall_cols_to_get=cols, return_dosage=True, return_gamma_t=False,
+                                    return_betaHat_t=False, get_best_haps_from_thinned_sites=lists, always_normalize=False,
+                                    **out)
+    return out
+
+
+@pytest.mark.parametrize("panel_name,symbols", [("small_panel", False), ("small_panel", True), ("ragged_panel", False),
+                                                ("ragged_panel", True), ("medium_panel", False)])
+def test_fp64_dosage_kernels_match_oracle(request, oracle, panel_name, symbols):
+    """qa_panel_set_dosage_precision(64): the fp64-state dosage kernels follow the reference's arithmetic (lazy
+    normalisation, reference-single.cpp:878-1131, :1781-2179) -- dosage to 1e-10, c elementwise to 1e-12, and the lists of
+    the ranking pass beside them identical; grids with special haplotypes included (small / ragged panels)."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = request.getfixturevalue(panel_name)
+    dev = DevicePanel(panel, use_eMatDH_special_symbols=symbols)
+    dev.set_dosage_precision(64)
+    sample = make_synthetic_sample(panel, seed=1001, n_reads=max(40, panel.nSNPs // 4))
+    cols = thin_cols(panel.nGrids)
+    for label in (1, 2):
+        gl = label_gl(panel, sample, label, oracle)
+        ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, always_normalize=False, get_best_haps_from_thinned_sites=True,
+                                                use_eMatDH_special_symbols=symbols)
+        got = _dosage_only(dev, gl, cols, lists=True)
+        assert np.abs(got["dosage"] - ref["dosage"]).max() <= 1e-10
+        np.testing.assert_allclose(got["c"], ref["c"], rtol=1e-12)
+        check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
+    # a label without reads: gl == 1 everywhere, every grid takes the no-variant shortcut
+    gl = np.ones((2, panel.nSNPs), order="F")
+    ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, always_normalize=False)
+    got = _dosage_only(dev, gl)
+    assert np.abs(got["dosage"] - ref["dosage"]).max() <= 1e-10
+    dev.close()
+
+
+@pytest.mark.parametrize("K", [50000, 30011, 8192, 8193])
+def test_fp64_dosage_kernels_production_geometry(oracle, K):
+    """The fp64 dosage kernels at the launch geometries of the real workload (K = 50 000: four chunk rows in registers, two
+    and a fraction in LDS), a K whose last chunk straddles K, and K at / just past a whole chunk row."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=K, nSNPs=640, seed=4242, nMaxDH=255)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    sample = make_synthetic_sample(panel, seed=9, n_reads=200)
+    for label in (1, 2):
+        gl = label_gl(panel, sample, label, oracle)
+        ref = oracle.haploid_dosage_versus_refs(panel, gl, None, always_normalize=False)
+        got = _dosage_only(dev, gl)
+        assert np.abs(got["dosage"] - ref["dosage"]).max() <= 1e-10
+        np.testing.assert_allclose(got["c"], ref["c"], rtol=1e-12)
+    dev.close()
+
+
+def test_fp64_dosage_batch(medium_panel, oracle):
+    """qa_fullpass_batch with fp64 dosage precision: dosage passes (k_fwd64 + k_bwd64d) and ranking passes in one call."""
+    import ctypes as C
+    from quilt_amd.native import DevicePanel, check, lib, ptr
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    cols = thin_cols(panel.nGrids, every=10)
+    n_thin = int((cols >= 0).sum())
+    gls, want = [], []
+    for i in range(7):
+        s = make_synthetic_sample(panel, seed=200 + i, n_reads=1000)
+        gls.append(label_gl(panel, s, 1 + i % 2, oracle))
+        want.append(i % 3 != 0)
+    gl = np.ascontiguousarray(np.stack([np.ascontiguousarray(g.T) for g in gls]))
+    wd = np.array(want, dtype=np.int32)
+    dosage = np.zeros((len(gls), panel.nSNPs))
+    bptr = np.zeros(len(gls) * n_thin + 1, dtype=np.int32)
+    cap = len(gls) * n_thin * 64
+    bidx = np.zeros(cap, dtype=np.int32)
+    bval = np.zeros(cap)
+    check(lib().qa_fullpass_batch(dev.handle, C.c_int32(len(gls)), ptr(gl), ptr(wd), ptr(cols), C.c_int32(5),
+                                  ptr(dosage), ptr(bptr), ptr(bidx), ptr(bval), C.c_int64(cap)))
+    for i, g in enumerate(gls):
+        ref = oracle.haploid_dosage_versus_refs(panel, g, cols, return_dosage=bool(want[i]), get_best_haps_from_thinned_sites=True)
+        if want[i]:
+            assert np.abs(dosage[i] - ref["dosage"]).max() <= 1e-10
+        got = [dict(top_matches=bidx[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]],
+                    top_matches_values=bval[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]]) for j in range(n_thin)]
+        check_best_haps(got, ref["best_haps"])
+    dev.close()
