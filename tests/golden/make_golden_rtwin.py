@@ -90,7 +90,76 @@ def gibbs_case(seed, K, T, Ks, n_reads, init_iter):
                 alphaHat_t1=tw["alphaHat_t"][0], betaHat_t2=tw["betaHat_t"][1], c1=tw["c"][0], c2=tw["c"][1])
 
 
+def shard_case(seed, K, T, Ks, n_reads):
+    """Diploid Gibbs call WITH its shard passes (after sweeps 3, 6, 9): R_shard_block_gibbs_resampler restated
+    (oracle/rtwin.py) against the C oracle's reading of Rcpp_shard_block_gibbs_resampler."""
+    panel = make_synthetic_panel(K=K, nSNPs=T, seed=seed, nMaxDH=255, ref_error=1e-3, stress_grids=())
+    s = make_synthetic_sample(panel, seed=seed + 1, n_reads=n_reads)
+    rng = np.random.default_rng(seed + 2)
+    which = np.sort(rng.choice(K, Ks, replace=False)).astype(np.int32) + 1
+    H0 = rng.integers(1, 3, size=s.nReads).astype(np.int32)
+    ru = rng.random(s.nReads * 21)
+    rs = rng.random(3 * (panel.nGrids - 1))
+    fr = int(rng.integers(0, s.nReads))
+    tr = []
+    tw = rtwin.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, block_gibbs_iterations=(3, 6, 9), runif_shard=rs, trace=tr)
+    oc = O.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs)
+    assert np.array_equal(oc["H"], tw["H"]) and np.array_equal(oc["H_class"], tw["H_class"]), "shard passes: C oracle vs R twin"
+    flips = np.stack([t["flip_mode"] for t in tr])
+    assert flips.sum() >= 2, "the fixture must contain flips"
+    for h in range(2):
+        for nm in ("alphaHat_t", "betaHat_t", "c", "eMatGrid_t"):
+            np.testing.assert_allclose(oc[nm][h], tw[nm][h], rtol=1e-9, atol=1e-300)
+    return dict(rhb_t=panel.rhb_t, transMatRate_t=panel.transMatRate_t, nSNPs=T, ref_error=panel.ref_error,
+                read_ptr=s.read_ptr, u=s.u, bq=s.bq, wif=s.wif, which=which, H0=H0, runif_reads=ru, runif_shard=rs, first_read=fr,
+                H=tw["H"], H_class=tw["H_class"], flip_mode=flips, p_stay=np.stack([t["p_stay"] for t in tr]),
+                hapProbs_t=tw["hapProbs_t"], alphaHat_t1=tw["alphaHat_t"][0], betaHat_t2=tw["betaHat_t"][1],
+                eMatGrid_t1=tw["eMatGrid_t"][0], c1=tw["c"][0], c2=tw["c"][1])
+
+
+def block_case(seed, ff, K, T, Ks, n_reads, q, radius):
+    """NIPT Gibbs call WITH block definition and block passes (block_approach = 6): R_define_blocked_snps_using_gamma_on_the_fly,
+    R_make_gibbs_considers and R_block_gibbs_resampler restated (oracle/rtwin.py) against the C oracle's reading of the C++."""
+    panel = make_synthetic_panel(K=K, nSNPs=T, seed=seed, nMaxDH=255, ref_error=1e-3, stress_grids=())
+    s = make_synthetic_sample(panel, seed=seed + 1, n_reads=n_reads, ff=ff)
+    rng = np.random.default_rng(seed + 2)
+    which = np.sort(rng.choice(K, Ks, replace=False)).astype(np.int32) + 1
+    R = s.nReads
+    H0 = (rng.choice(3, size=R, p=[0.5, 0.5 - ff / 2, ff / 2]) + 1).astype(np.int32)
+    ru = rng.random(R * 21)
+    rb, rr = rng.random(3 * R), rng.random(3 * R)
+    fr = int(rng.integers(0, R))
+    tr = []
+    kw = dict(ff=ff, runif_block=rb, runif_resample=rr, block_gibbs_quantile_prob=q, shuffle_bin_radius=radius)
+    tw = rtwin.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, block_gibbs_iterations=(3, 6, 9), trace=tr, **kw)
+    oc = O.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, np.zeros(3 * (panel.nGrids - 1)), **kw)
+    assert np.array_equal(oc["H"], tw["H"]) and np.array_equal(oc["H_class"], tw["H_class"]), "block passes: C oracle vs R twin"
+    chosen = np.concatenate([t["ir_chosen"] for t in tr])
+    assert all(t["available_rules_agree"] for t in tr), "pick a case on which the R and the C++ availability rules coincide"
+    assert len(chosen) >= 12 and len(set(chosen.tolist())) >= 3, "the fixture must hold several blocks and several relabellings"
+    for h in range(3):
+        for nm in ("alphaHat_t", "betaHat_t", "c", "eMatGrid_t"):
+            np.testing.assert_allclose(oc[nm][h], tw[nm][h], rtol=1e-9, atol=1e-300)
+    return dict(rhb_t=panel.rhb_t, transMatRate_t=panel.transMatRate_t, nSNPs=T, ref_error=panel.ref_error, L_grid=panel.L_grid,
+                read_ptr=s.read_ptr, u=s.u, bq=s.bq, wif=s.wif, which=which, H0=H0, runif_reads=ru, runif_block=rb,
+                runif_resample=rr, first_read=fr, ff=ff, quantile_prob=q, shuffle_bin_radius=radius,
+                H=tw["H"], H_class=tw["H_class"], ir_chosen=chosen,
+                n_blocks=np.array([len(t["ir_chosen"]) for t in tr], dtype=np.int32),
+                block_grid_end=np.concatenate([t["grid_end"] for t in tr]),
+                hapProbs_t=tw["hapProbs_t"], alphaHat_t1=tw["alphaHat_t"][0], betaHat_t3=tw["betaHat_t"][2],
+                eMatGrid_t2=tw["eMatGrid_t"][1], c1=tw["c"][0], c3=tw["c"][2])
+
+
 if __name__ == "__main__":
+    for i, sd in enumerate((51, 52)):
+        g = shard_case(seed=sd, K=400, T=320, Ks=48, n_reads=120)
+        np.savez_compressed(os.path.join(HERE, f"rtwin_shard_{i}.npz"), **g)
+        print(f"shard passes (case {i}): C oracle == R twin (labels, H_class identical; state 1e-9; {int(g['flip_mode'].sum())} flips)")
+    for i, sd in enumerate((61, 63)):
+        g = block_case(seed=sd, ff=0.2, K=300, T=1920, Ks=32, n_reads=500, q=0.8, radius=2000)
+        np.savez_compressed(os.path.join(HERE, f"rtwin_block_{i}.npz"), **g)
+        print(f"NIPT block passes (case {i}): C oracle == R twin (labels, H_class identical; state 1e-9; relabellings "
+              f"{g['ir_chosen'].tolist()})")
     fp = fullpass_case(seed=31, K=160, T=150, nMaxDH=6, n_reads=60)
     np.savez_compressed(os.path.join(HERE, "rtwin_fullpass.npz"), **fp)
     print("full-panel pass: C oracle == R twin (dosage 1e-12, gamma 1e-9, lists identical)")

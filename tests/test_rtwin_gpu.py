@@ -52,3 +52,43 @@ def test_gibbs_hip_matches_r_twin(name):
     np.testing.assert_allclose(got["c1"], z["c1"], rtol=1e-8)
     np.testing.assert_allclose(got["hapProbs_t"][:2], z["hapProbs_t"][:2], rtol=1e-8, atol=1e-14)
     dev.close()
+
+
+@pytest.mark.parametrize("name", ["rtwin_shard_0.npz", "rtwin_shard_1.npz"])
+def test_shard_passes_hip_match_r_twin(name):
+    """a15 on the device against the R-twin side: labels and classes identical, state to 1e-8."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    z = np.load(os.path.join(GOLD, name))
+    panel = panel_from_rhb(z["rhb_t"], z["transMatRate_t"], z["nSNPs"], 255, z["ref_error"])
+    s = sample_from_arrays(z["read_ptr"], z["u"], z["bq"], z["wif"])
+    dev = DevicePanel(panel)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, z["which"], z["H0"], z["runif_reads"], int(z["first_read"]), z["runif_shard"],
+                                        return_state=True)
+    assert np.array_equal(got["H"], z["H"]) and np.array_equal(got["H_class"], z["H_class"])
+    np.testing.assert_allclose(got["alphaHat_t1"], z["alphaHat_t1"], rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(got["betaHat_t2"], z["betaHat_t2"], rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(got["eMatGrid_t1"], z["eMatGrid_t1"], rtol=1e-8)
+    np.testing.assert_allclose(got["c1"], z["c1"], rtol=1e-8)
+    np.testing.assert_allclose(got["hapProbs_t"][:2], z["hapProbs_t"][:2], rtol=1e-8, atol=1e-14)
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["rtwin_block_0.npz", "rtwin_block_1.npz"])
+def test_block_passes_hip_match_r_twin(name):
+    """a13 / a14 on the device against the R-twin side (NIPT: block definition, six relabellings, label re-draw)."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    z = np.load(os.path.join(GOLD, name))
+    panel = panel_from_rhb(z["rhb_t"], z["transMatRate_t"], z["nSNPs"], 255, z["ref_error"])
+    s = sample_from_arrays(z["read_ptr"], z["u"], z["bq"], z["wif"])
+    dev = DevicePanel(panel)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, z["which"], z["H0"], z["runif_reads"], int(z["first_read"]), None,
+                                        ff=float(z["ff"]), runif_block=z["runif_block"], runif_resample=z["runif_resample"],
+                                        L_grid=z["L_grid"], block_gibbs_quantile_prob=float(z["quantile_prob"]),
+                                        shuffle_bin_radius=int(z["shuffle_bin_radius"]), return_state=True)
+    assert np.array_equal(got["H"], z["H"]) and np.array_equal(got["H_class"], z["H_class"])
+    np.testing.assert_allclose(got["alphaHat_t1"], z["alphaHat_t1"], rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(got["c1"], z["c1"], rtol=1e-8)
+    np.testing.assert_allclose(got["hapProbs_t"], z["hapProbs_t"], rtol=1e-8, atol=1e-14)
+    dev.close()
