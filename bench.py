@@ -233,8 +233,12 @@ def main():
     ap.add_argument("--rare-common", type=float, default=0.0, metavar="F",
                     help="impute_rare_common with F x nsnps rare SNPs: every Gibbs sample ends with a Gibbs call over all SNPs "
                          "(QUILT2; not the headline workload, no CPU baseline)")
-    ap.add_argument("--fp64-dosage", action="store_true",
-                    help="dosage passes with fp64 state as the reference (qa_panel_set_dosage_precision(64)): the all-fp64 line")
+    ap.add_argument("--precision", choices=["both", "fp64", "mixed"], default="both",
+                    help="fp64: every kernel of the path computes in double, as the reference (the headline `value`); mixed: dosage "
+                         "passes with fp32 state, fp64 emissions and sums (SURVEY 8(d)'s fp32 alpha checkpoint); both (default): the "
+                         "K timed steps run at fp64 and are reported as `value`, then the same K steps run again with the mixed "
+                         "dosage passes in a second timed region of their own, reported under `mixed_precision`")
+    ap.add_argument("--fp64-dosage", action="store_true", help="(older spelling of --precision fp64)")
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
@@ -242,7 +246,7 @@ def main():
                     help="skip the stand-alone kernel timings taken before the warm-up (`kernels_alone` in the output)")
     ap.add_argument("--pass-priority", type=int, default=0, choices=(0, 1),
                     help="full-panel calls on a highest-priority stream (qa_panel_set_pass_priority)")
-    ap.add_argument("--exclusive", type=int, default=0, choices=(0, 1),
+    ap.add_argument("--exclusive", type=int, default=1, choices=(0, 1),
                     help="exclusive device phases (qa_panel_set_exclusive): every Gibbs launch / full-panel launch set gets the whole "
                          "device and the device-wide arena, the host threads take turns")
     ap.add_argument("--gibbs-gate", type=float, default=0.0, metavar="SEC",
@@ -256,12 +260,15 @@ def main():
     ap.add_argument("--cu-partition", action="store_true",
                     help="confine each host thread's Gibbs launches to its own half of the CUs (measured slower, DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--r2-vs-cpu", type=int, default=0, metavar="N",
-                    help="also impute the first N samples of the last batch with the whole pipeline on the CPU oracle (about "
-                         "5 minutes of wall time per sample on a many-core host) and report dosage r2 GPU vs CPU")
+    ap.add_argument("--r2-vs-cpu", type=int, default=1, metavar="N",
+                    help="also impute the first N samples of the last batch with the whole pipeline on the CPU oracle (its chains on "
+                         "a thread pool: about a minute per sample on a many-core host; before any HIP context exists, rank 0 at "
+                         "N = 1 only) and report the metric's `dosage r2 vs CPU ref`; 0 switches it off")
     ap.add_argument("--stub", action="store_true",
                     help="test hook: no device work at all (gloo rendezvous, a driver that returns zeros); value is 0")
     a = ap.parse_args()
+    if a.fp64_dosage:
+        a.precision = "fp64"
     maybe_spawn(a, sys.argv[1:])
     if a.reads is None:
         a.reads = 300 if a.mode == "ont" else 20000
@@ -291,8 +298,22 @@ def main():
         params["use_mspbwt"] = True
         a.no_cpu_baseline = True
     cpu, keep = None, None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and rc is None and not a.stub:
+    # The CPU legs run on rank 0 while the host cores are otherwise idle and before any HIP context exists in this process
+    # (they fork / start threads).  With several ranks the others wait for rank 0, so that the baseline is measured "in the
+    # same run" at every N without the ranks' own sample generation competing for the cores (a flag file in /tmp keyed by the
+    # launcher's pid and port: no process group -- and so no HIP context -- is needed yet)
+    cpu_flag = None
+    if world > 1 and not a.stub:
+        cpu_flag = f"/tmp/quilt_amd_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.cpu_done"
+    if rank == 0 and not a.no_cpu_baseline and rc is None and not a.stub:
         cpu, keep = cpu_baseline(panel, a.reads, params, full_chains, ff=ff)
+    if cpu_flag is not None:
+        if rank == 0:
+            open(cpu_flag, "w").close()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(cpu_flag) and time.time() - t_wait < 600:
+                time.sleep(0.2)
     n_steps = a.warmup + a.steps
     seeds = [1000 + (rank * n_steps + st) * a.batch + i for st in range(n_steps) for i in range(a.batch)]
     bam_dir, bam_load_s = None, None
@@ -309,7 +330,9 @@ def main():
         import shutil
         shutil.rmtree(bam_dir, ignore_errors=True)
     samples = [flat[st * a.batch:(st + 1) * a.batch] for st in range(n_steps)]
-
+    cpu_pipeline = None
+    if rank == 0 and world == 1 and a.r2_vs_cpu > 0 and rc is None and not a.stub and not a.mspbwt:
+        cpu_pipeline = cpu_pipeline_reference(a, panel, params, samples)
     import torch
     import torch.distributed as dist
     if world > 1:
@@ -330,7 +353,7 @@ def main():
         from quilt_amd.workers import DeviceWorkers
         native.check(native.lib().qa_set_device(local_rank))
         drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
-                            cu_partition=a.cu_partition, fp64_dosage=a.fp64_dosage, split=a.split, gibbs_gate=a.gibbs_gate,
+                            cu_partition=a.cu_partition, fp64_dosage=a.precision != "mixed", split=a.split, gibbs_gate=a.gibbs_gate,
                             pass_priority=bool(a.pass_priority), exclusive=bool(a.exclusive))
 
     def barrier():
@@ -347,33 +370,64 @@ def main():
     alone = None
     if native is not None and rank == 0 and not a.no_alone and hasattr(drv, "drivers"):
         alone = kernels_alone(native, drv, samples)
-    for _ in drv.run_stream(stream(0, a.warmup)):
-        pass
-    if native is not None:
-        native.lib().qa_profile_reset()
-    drv.reset_timing()
-    if native is not None:
-        native.gate_stats(local_rank, reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    # the K timed steps are K whole batches: the driver pipelines consecutive batches (phasing rounds of one fused
-    # with the main rounds of the next), and the pipeline is filled and drained inside the timed region
-    for res in drv.run_stream(stream(a.warmup, n_steps)):
-        last = res
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if a.stub else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_region(n_warm):
+        """n_warm untimed batches, then the K timed batches bracketed by barriers; returns what report() needs."""
+        for _ in drv.run_stream(stream(0, n_warm)):
+            pass
+        if native is not None:
+            native.lib().qa_profile_reset()
+            native.gate_stats(local_rank, reset=True)
+        drv.reset_timing()
+        barrier()
+        t0 = time.perf_counter()
+        last = None
+        # the K timed steps are K whole batches: the driver pipelines consecutive batches (phasing rounds of one fused
+        # with the main rounds of the next), and the pipeline is filled and drained inside the timed region
+        for res in drv.run_stream(stream(a.warmup, n_steps)):
+            last = res
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device="cpu" if a.stub else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        reg = dict(elapsed=elapsed, last=last, timing=dict(drv.timing), chains=getattr(drv, "n_gibbs_chain_calls", 0))
+        if native is not None:
+            reg["prof"] = read_profile(native)
+            reg["gate"] = native.gate_stats(local_rank)
+        return reg
+
+    main_reg = timed_region(a.warmup)
+    mixed_reg = None
+    if a.precision == "both" and native is not None:
+        for d in drv.devs:   # the same K batches again with the mixed dosage passes, in a timed region of their own
+            d.set_dosage_precision(32)
+        mixed_reg = timed_region(min(a.warmup, 1))
 
     from quilt_amd import trace
     trace.dump()   # host span trace, only with QUILT_AMD_TRACE=<file>
     if rank == 0:
-        out = report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu, keep, ff, full_chains, alone)
+        out = report(a, panel, params, native, drv, samples, main_reg, world, rc, cpu, keep, ff, full_chains, alone,
+                     fp64=a.precision != "mixed")
+        if mixed_reg is not None:
+            mx = report(a, panel, params, native, drv, samples, mixed_reg, world, rc, None, None, ff, full_chains, None, fp64=False)
+            out["mixed_precision"] = {k: mx[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "kernels", "host_seconds",
+                                                          "device_phases", "dosage_r2_vs_truth_sample0") if k in mx}
+            out["mixed_precision"]["what"] = ("the same K batches in a second timed region with the dosage passes at fp32 state (fp64 "
+                                              "emissions and sums): SURVEY 8(d)'s fp32 alpha checkpoint, 10 instead of 18 bytes per cell")
+            a_, b_ = main_reg["last"][0].dosage, mixed_reg["last"][0].dosage
+            out["mixed_precision"]["dosage_vs_fp64_run_sample0"] = {"r2": float(np.corrcoef(a_, b_)[0, 1] ** 2),
+                                                                    "max_abs_diff": float(np.abs(a_ - b_).max())}
+        if cpu_pipeline is not None:
+            out["dosage_r2_vs_cpu_pipeline"] = r2_vs_cpu_pipeline(cpu_pipeline, main_reg["last"])
+            if mixed_reg is not None:
+                out["mixed_precision"]["dosage_r2_vs_cpu_pipeline"] = r2_vs_cpu_pipeline(cpu_pipeline, mixed_reg["last"])
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
+        if rank == 0 and cpu_flag is not None and os.path.exists(cpu_flag):
+            os.remove(cpu_flag)
         dist.destroy_process_group()
 
 
@@ -424,17 +478,16 @@ def kernels_alone(native, drv, samples):
     return out
 
 
-def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu, keep, ff, full_chains, alone=None):
+def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff, full_chains, alone=None, fp64=True):
     import ctypes as C
+    last, elapsed = reg["last"], reg["elapsed"]
     value = 0.0 if a.stub else a.batch * world * a.steps / elapsed
-    fp64 = a.fp64_dosage
     out = {
         "metric": "samples/sec on 2Mb region, K=50k haps, 1x coverage; dosage r2 vs CPU ref",
         "value": value, "unit": "samples/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64 throughout (Gibbs sampler, ranking passes, dosage passes)" if fp64 else
-                 "f64 (Gibbs sampler, ranking passes) / f32 state with f64 emissions and sums (dosage passes)",
+        "dtype": "f64" if fp64 else "f64 (Gibbs sampler, ranking passes) / f32 state with f64 emissions and sums (dosage passes)",
         "data": "stub (no device work)" if a.stub else
                 ("synthetic, through BAM files read by the native loader before the timed region" if a.bam else "synthetic"),
         "config": {"workload": f"{WORKLOADS[a.mode]}: {a.batch} synthetic 1x {a.mode}-read samples per GPU per step, "
@@ -448,7 +501,8 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
                              "lists back): value is the PCIe-inclusive rate",
                    "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
                                   "GPU (" + ("whole batches in turn" if a.split == "alternate" else "every batch cut into one part per thread") +
-                                  "), consecutive batches pipelined"},
+                                  "), consecutive batches pipelined"
+                                  + ("; device phases: full-panel launch sets exclusive, Gibbs launches that fit run together" if a.exclusive else "")},
     }
     if getattr(a, "bam_load_s", None) is not None:
         out["bam_load_ms_per_sample"] = 1e3 * a.bam_load_s
@@ -457,7 +511,7 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
         out["roofline"] = None
         out["cpu_baseline"] = None
         return out
-    prof = read_profile(native)
+    prof = reg["prof"]
     dom = max(prof, key=lambda p: p["ms"])
     # per-launch figure (the recipe): algorithmic bytes of one launch / its mean duration.  Launches of the host threads
     # overlap on the device, so the aggregate rate (bytes / time during which at least one launch of the kernel ran) is given
@@ -472,13 +526,12 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
         def _flag(name, default):   # the value a flag had in the profiled command (absent = bench.py's default)
             m = re.search(rf"--{name}[ =](\S+)", pmc["command"])
             return m.group(1) if m else str(default)
-        same_workload = (_flag("batch", 128) == str(a.batch) and _flag("workers", 4) == str(a.workers) and
-                         _flag("split", "alternate") == a.split and
+        same_workload = (_flag("batch", 128) == str(a.batch) and
                          _flag("mode", "short") == a.mode and _flag("K", 50000) == str(a.K) and
-                         "--mspbwt" not in pmc["command"] and "--fp64-dosage" not in pmc["command"])
-        if same_workload and rc is None and not fp64 and not a.mspbwt:
+                         "--mspbwt" not in pmc["command"])
+        if same_workload and rc is None and not a.mspbwt:
             pk = pmc["kernels"][dom["kernel"]]
-            chains = getattr(drv, "n_gibbs_chain_calls", 0)
+            chains = reg["chains"]
             if "hbm_bytes_per_workgroup" in pk and chains and dom["kernel"].startswith("k_gibbs"):
                 # launches come in sizes (a whole batch's chains, the phasing chains alone when the stream drains): the
                 # counters' bytes per workgroup (= per chain) times this run's chains per launch
@@ -526,34 +579,51 @@ def report(a, panel, params, native, drv, samples, last, elapsed, world, rc, cpu
         if da:
             roof["alone"] = {"avg_launch_ms": da[0]["avg_launch_ms"], "achieved": da[0]["GBps_per_launch"],
                              "frac": da[0]["frac_of_hbm_peak"]}
-    out["host_seconds"] = {k: round(v, 3) for k, v in drv.timing.items()}
-    if a.exclusive:
-        gs = native.gate_stats(int(os.environ.get("LOCAL_RANK", "0")))
-        out["device_gate"] = {"held_s": round(gs["held_ms"] / 1e3, 3), "queued_s": round(gs["queued_ms"] / 1e3, 3), "holds": gs["holds"],
-                              "held_frac_of_timed_region": round(gs["held_ms"] / 1e3 / elapsed, 3)}
+    out["host_seconds"] = {k: round(v, 3) for k, v in reg["timing"].items()}
+    gib = [p for p in prof if p["kernel"] in ("k_gibbs", "k_gibbs3")]
+    if gib and reg["chains"]:
+        out["gibbs_chains_per_launch"] = round(reg["chains"] / max(sum(p["launches"] for p in gib), 1), 1)
+    if a.exclusive and reg.get("gate"):
+        gs = reg["gate"]
+        g_ms = max(gs["held_ms"] - gs["exclusive_ms"], 1e-9)
+        out["device_phases"] = {
+            "what": "qa_gate_stats over the timed region: time with a launch set on the device, split into full-panel phases "
+                    "(exclusive) and Gibbs phases; SIMD slots (of 1 024) the Gibbs launches held, averaged over the Gibbs phases",
+            "busy_frac": round(gs["held_ms"] / 1e3 / elapsed, 3), "fullpass_frac": round(gs["exclusive_ms"] / 1e3 / elapsed, 3),
+            "gibbs_frac": round(g_ms / 1e3 / elapsed, 3), "gibbs_mean_simd_slots": round(gs["gibbs_slot_ms"] / g_ms, 1),
+            "mean_simd_slots_over_the_region": round(gs["gibbs_slot_ms"] / 1e3 / elapsed, 1),
+            "queued_s": round(gs["queued_ms"] / 1e3, 2), "holds": gs["holds"]}
     truth = (samples[-1][0].all_snp if rc is not None else samples[-1][0]).truth_haps[:2].sum(axis=0)
     out["dosage_r2_vs_truth_sample0"] = float(np.corrcoef(last[0].dosage, truth)[0, 1] ** 2)
     out["cpu_baseline"] = cpu
     if keep is not None:
         dev = drv.devs[0]
         out["parity_vs_cpu_path"] = parity_vs_cpu(dev, panel, a.reads, params, ff, keep)
-    if a.r2_vs_cpu > 0 and rc is None:
-        out["dosage_r2_vs_cpu_pipeline"] = r2_vs_cpu_pipeline(a, panel, params, samples, last)
     return out
 
 
-def r2_vs_cpu_pipeline(a, panel, params, samples, last):
-    """The metric's r2: whole-pipeline dosages, GPU vs the same driver on the CPU oracle, same seeds (opt-in: slow)."""
+def cpu_pipeline_reference(a, panel, params, samples):
+    """The metric's "dosage r2 vs CPU ref": the first N samples of the LAST timed batch through the whole per-sample pipeline
+    on the CPU oracle -- the same driver, the same seeds (every chain's stream is keyed by the global sample index), its
+    chains on a thread pool.  Runs before any HIP context exists; compared with the GPU run's results afterwards."""
     from quilt_amd.driver import Driver, DriverParams
     from tests.oracle_backend import OracleBackend
     n_steps = a.warmup + a.steps
     n = min(a.r2_vs_cpu, len(samples[-1]))
     t0 = time.perf_counter()
-    ref = Driver(panel, OracleBackend(panel), DriverParams(**params)).run(samples[-1][:n], sample_offset=(n_steps - 1) * a.batch)
+    n_thr = min(32, physical_cores())
+    ref = Driver(panel, OracleBackend(panel, n_threads=n_thr), DriverParams(**params)).run(samples[-1][:n],
+                                                                                            sample_offset=(n_steps - 1) * a.batch)
+    return dict(ref=ref, n=n, cpu_seconds=round(time.perf_counter() - t0, 1), threads=n_thr)
+
+
+def r2_vs_cpu_pipeline(cpu_pipeline, last):
+    ref, n = cpu_pipeline["ref"], cpu_pipeline["n"]
     r2 = [float(np.corrcoef(last[i].dosage, ref[i].dosage)[0, 1] ** 2) for i in range(n)]
-    return dict(samples=n, r2=r2, max_abs_diff=[float(np.abs(last[i].dosage - ref[i].dosage).max()) for i in range(n)],
+    return dict(what="whole pipeline, GPU vs the same driver on the CPU oracle (fp64), same seeds: the metric's `dosage r2 vs CPU ref`",
+                samples=n, r2=r2, max_abs_diff=[float(np.abs(last[i].dosage - ref[i].dosage).max()) for i in range(n)],
                 labels_identical=[bool(np.array_equal(last[i].read_labels, ref[i].read_labels)) for i in range(n)],
-                cpu_seconds=round(time.perf_counter() - t0, 1))
+                cpu_seconds=cpu_pipeline["cpu_seconds"], cpu_threads=cpu_pipeline["threads"])
 
 
 if __name__ == "__main__":

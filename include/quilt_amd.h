@@ -150,17 +150,20 @@ int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits);
  * logic between native calls) behind the other's kernels. */
 int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers);
 
-/* Exclusive device phases.  on = 1: every launch set of this handle (the kernels of a Gibbs call; the full-panel passes of
- * a call) runs with the device to itself: the call queues, in arrival order, behind the launch sets of the other handles
- * that opted in, and carves its scratch from ONE device-wide arena instead of the handle's 1 / n_sharers part -- so a Gibbs
- * launch carries up to one chain per SIMD (1 024) and a full-panel launch one pass per compute unit (256) whatever the
- * number of host threads.  The host-side parts of the calls (validation, tables, marshalling) stay outside the queue: with
- * 3-4 host threads per device they overlap the other threads' device phases.  Both kinds of launch sets are HBM-bound when
- * they fill the chip, so nothing is lost by not overlapping them; measured gains in DESIGN.md 5.  Default off (a single
- * handle has the device to itself anyway).  qa_gate_stats: [0] ms some handle held the device, [1] ms callers queued,
- * [2] holds since the last reset. */
+/* Device phases.  on = 1: the launch sets of this handle take the device in arrival order together with those of the other
+ * handles that opted in (strictly first come, first served).  The full-panel passes of a call (one workgroup per compute
+ * unit) hold the device EXCLUSIVELY; the kernels of a Gibbs call hold one SIMD slot per wave (of 1 024), so Gibbs launches
+ * that fit together run together -- the 128 phasing chains of one batch beside the 896 main chains of another -- and one
+ * that does not fit waits for the phase to end.  All of them carve their scratch from ONE device-wide arena instead of the
+ * handle's 1 / n_sharers part, so a Gibbs launch carries up to one chain per SIMD and a full-panel launch one pass per
+ * compute unit (256) whatever the number of host threads.  The host-side parts of the calls (validation, tables,
+ * marshalling) stay outside the queue: with 3-4 host threads per device they overlap the other threads' device phases.
+ * Both kinds of launch sets are HBM-bound when they fill the chip, so nothing is lost by not overlapping them; measured
+ * gains in DESIGN.md 5.  Default off (a single handle has the device to itself anyway).  qa_gate_stats since the last
+ * reset: [0] ms with at least one holder, [1] ms callers queued, [2] holds, [3] ms with an exclusive holder (full-panel launch
+ * sets), [4] sum over the Gibbs holds of SIMD slots x ms, [5] Gibbs holds, [6] their SIMD slots in total. */
 int qa_panel_set_exclusive(qa_panel_t *panel, int32_t on);
-int qa_gate_stats(int32_t device, double out[3]);
+int qa_gate_stats(int32_t device, double out[7]);
 int qa_gate_stats_reset(int32_t device);
 
 /* With several handles sharing a device: confine this handle's Gibbs launches to CUs [index, index + 1) * n_CU / count

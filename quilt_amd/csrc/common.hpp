@@ -317,8 +317,10 @@ struct DeviceGate {
     Arena arena;
     double held_ms = 0;       // accumulated time with at least one holder (qa_gate_stats)
     double wait_ms = 0;       // accumulated time callers spent queueing
+    double excl_ms = 0;       // of held_ms: an exclusive holder (full-panel launch sets)
+    double slot_ms = 0;       // sum over Gibbs holds of (SIMD slots x duration): / (held_ms - excl_ms) = mean slots in use
     double t_busy_from = 0;
-    uint64_t n_holds = 0;
+    uint64_t n_holds = 0, n_shared = 0, slots_total = 0;
 };
 DeviceGate &device_gate(int device);
 
@@ -330,7 +332,7 @@ struct GateHold {
     Arena view;               // slice of the gate's arena (shared holds)
     int slots = 0;
     bool exclusive = false;
-    double queued_ms = 0;
+    double queued_ms = 0, t_in = 0;
     static double now_ms();
     GateHold() = default;
     GateHold(const GateHold &) = delete;
@@ -367,7 +369,8 @@ struct GateHold {
             gate->used_slots += slots;
         }
         g = gate;
-        queued_ms = now_ms() - t0;
+        t_in = now_ms();
+        queued_ms = t_in - t0;
         gate->wait_ms += queued_ms;
         lk.unlock();
         gate->cv.notify_all();   // the next in line may fit beside this one
@@ -379,7 +382,10 @@ struct GateHold {
             std::lock_guard<std::mutex> lk(g->mu);
             g->active--;
             if (exclusive) g->active_exclusive = false; else g->used_slots -= slots;
-            if (g->active == 0) { g->bump = 0; g->held_ms += now_ms() - g->t_busy_from; }
+            const double t_out = now_ms();
+            if (g->active == 0) { g->bump = 0; g->held_ms += t_out - g->t_busy_from; }
+            if (exclusive) g->excl_ms += t_out - t_in;
+            else { g->slot_ms += (double)slots * (t_out - t_in); g->n_shared++; g->slots_total += (uint64_t)slots; }
             g->n_holds++;
         }
         g->cv.notify_all();

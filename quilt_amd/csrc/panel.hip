@@ -400,11 +400,12 @@ int qa_panel_set_exclusive(qa_panel_t *panel, int32_t on) {
     return QA_OK;
 }
 
-int qa_gate_stats(int32_t device, double out[3]) {
+int qa_gate_stats(int32_t device, double out[7]) {
     if (!out || device < 0 || device >= 16) return QA_ERR_INVALID;
     qa::DeviceGate &g = qa::device_gate(device);
     std::lock_guard<std::mutex> lk(g.mu);
     out[0] = g.held_ms; out[1] = g.wait_ms; out[2] = (double)g.n_holds;
+    out[3] = g.excl_ms; out[4] = g.slot_ms; out[5] = (double)g.n_shared; out[6] = (double)g.slots_total;
     return QA_OK;
 }
 
@@ -412,7 +413,7 @@ int qa_gate_stats_reset(int32_t device) {
     if (device < 0 || device >= 16) return QA_ERR_INVALID;
     qa::DeviceGate &g = qa::device_gate(device);
     std::lock_guard<std::mutex> lk(g.mu);
-    g.held_ms = g.wait_ms = 0; g.n_holds = 0;
+    g.held_ms = g.wait_ms = g.excl_ms = g.slot_ms = 0; g.n_holds = g.n_shared = g.slots_total = 0;
     return QA_OK;
 }
 

@@ -238,12 +238,13 @@ class DeviceRareCommon:
 
 def gate_stats(device: int = 0, reset: bool = False) -> dict:
     """Exclusive device phases (DevicePanel.set_exclusive): ms some handle held the device, ms callers queued, holds."""
-    out = (C.c_double * 3)()
+    out = (C.c_double * 7)()
     lib().qa_gate_stats.restype = C.c_int
     check(lib().qa_gate_stats(C.c_int32(device), out))
     if reset:
         lib().qa_gate_stats_reset(C.c_int32(device))
-    return dict(held_ms=out[0], queued_ms=out[1], holds=int(out[2]))
+    return dict(held_ms=out[0], queued_ms=out[1], holds=int(out[2]), exclusive_ms=out[3], gibbs_slot_ms=out[4],
+                gibbs_holds=int(out[5]), gibbs_slots=int(out[6]))
 
 
 def last_fullpass_timing_ms():

@@ -6,9 +6,19 @@ from oracle import oracle as O
 
 
 class OracleBackend:
-    def __init__(self, panel, rare_common=None):
+    def __init__(self, panel, rare_common=None, n_threads=1):
+        """``n_threads`` > 1: the chains of a call run on a thread pool (the oracle's C calls release the GIL) -- the chains
+        are independent, so nothing but the wall time changes."""
         self.panel = panel
         self.rare_common = rare_common
+        self.n_threads = n_threads
+
+    def _map(self, f, items):
+        if self.n_threads <= 1 or len(items) <= 1:
+            return [f(x) for x in items]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(self.n_threads) as ex:
+            return list(ex.map(f, items))
 
     def make_gl_bound(self, gl, minGLValue, to_fix):
         O.make_gl_bound(gl, minGLValue, to_fix)
@@ -18,19 +28,20 @@ class OracleBackend:
                     maxDifferenceBetweenReads, Jmax_local, rare_common=False, ff=0.0, shuffle_bin_radius=5000,
                     return_hapProbs=False, return_hap_words=False):   # (the oracle always returns hapProbs_t; the driver packs)
         from quilt_amd.rng import stream_uniform
-        out = []
         n_its = n_gibbs_burn_in_its + n_gibbs_sample_its
         nb = len(block_gibbs_iterations)
         G = self.rare_common.nGrids_all if rare_common else self.panel.nGrids
         extra = dict(rare_common=self.rare_common, disable_read_category_usage=True) if rare_common else {}
         ffs = list(ff) if np.ndim(ff) > 0 else [ff] * len(samples)
-        for s, w, h, sr, fr, ss, ff in zip(samples, which, starts, seed_reads, first_reads, seed_shards, ffs):
+        def one(args):
+            s, w, h, sr, fr, ss, ff = args
+            ex = dict(extra)
             ru = stream_uniform(sr, s.nReads * n_its)
             if ff != 0:   # NIPT: the block passes' uniforms, [pass][block choice | label re-draw][read] of the same stream
                 blk = stream_uniform(ss, nb * 2 * s.nReads).reshape(nb, 2, s.nReads)
-                extra = dict(extra, ff=ff, runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy(),
-                             shuffle_bin_radius=shuffle_bin_radius,
-                             L_grid=self.rare_common.L_grid_all if rare_common else None)
+                ex = dict(ex, ff=ff, runif_block=blk[:, 0, :].copy(), runif_resample=blk[:, 1, :].copy(),
+                          shuffle_bin_radius=shuffle_bin_radius,
+                          L_grid=self.rare_common.L_grid_all if rare_common else None)
                 rs = np.zeros(nb * G)
             else:
                 rs = stream_uniform(ss, nb * (G - 1))
@@ -40,10 +51,10 @@ class OracleBackend:
                                            n_gibbs_sample_its=n_gibbs_sample_its,
                                            block_gibbs_iterations=block_gibbs_iterations,
                                            gibbs_initialize_iteratively=init,
-                                           maxDifferenceBetweenReads=maxDifferenceBetweenReads, Jmax=Jmax_local, **extra)
+                                           maxDifferenceBetweenReads=maxDifferenceBetweenReads, Jmax=Jmax_local, **ex)
             r["double_list_of_ending_read_labels"] = [[r["H"]]]
-            out.append(r)
-        return out
+            return r
+        return self._map(one, list(zip(samples, which, starts, seed_reads, first_reads, seed_shards, ffs)))
 
     def fullpass_batch(self, gls, want_dosage, cols, K_top_matches):
         dosages, best = [], []
@@ -70,7 +81,7 @@ class OracleBackend:
         dosage = np.zeros((n_chain, n_label, T))
         top = np.full((n_chain, n_label, n_thin, top_width), -1, dtype=np.int32)
         cnt = np.zeros((n_chain, n_label, n_thin), dtype=np.int32)
-        for c in range(n_chain):
+        def one(c):
             s = samples[chain_sample[c]]
             per_base = np.repeat(labels[c], np.diff(s.read_ptr))
             for l in range(1, n_label + 1):
@@ -85,6 +96,7 @@ class OracleBackend:
                     k = idx[order][:top_width]
                     top[c, l - 1, j, : len(k)] = k
                     cnt[c, l - 1, j] = len(idx)
+        self._map(one, list(range(n_chain)))
         return dosage, top, cnt
 
     def find_good_matches(self, Zs, nindices, min_len, max_matches):
