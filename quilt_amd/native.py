@@ -43,12 +43,39 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  libquilt_amd.so needs libamdhip64; PyTorch-ROCm ships its own copy (same soname) and
+    loads it when torch is imported.  Whichever copy is mapped first serves both -- but if THIS library came first with the
+    system's copy, torch's later import ended up with a second runtime that saw no device (the load-order trap of round 2).
+    So when a torch installation exists and has not been imported yet, its copy is mapped here first: this library binds to
+    it, and a later ``import torch`` finds it already there.  Hosts without torch (R) are not affected."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamd_comgr.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise QuiltAmdError(QA_ERR_NO_DEVICE, f"{LIB_PATH} is missing: run quilt_amd.native.build() "
                                 "(or __graft_entry__.build()); there is no CPU fallback")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.qa_last_error.restype = C.c_char_p
         for name in ("qa_abi_version", "qa_device_count", "qa_set_device", "qa_panel_create", "qa_gibbs_batch",
