@@ -40,7 +40,8 @@ typedef struct {
     int32_t chrStart, chrEnd;      /* 1-based inclusive window alignments must overlap; 0, 0 = the whole chromosome
                                     *      (functions.R:262-263: regionStart - buffer .. regionEnd + buffer) */
     int32_t merge_mates;           /* 1    two alignments with the same query name become ONE read (they come from one
-                                    *      molecule, hence one haplotype), bases in SNP order */
+                                    *      molecule, hence one haplotype), bases in SNP order; a site both mates cover counts
+                                    *      once: calls that agree keep the higher quality, calls that disagree drop the site */
     uint64_t seed;                 /* key of the counter stream used where the loader has to choose (coverage cap) */
 } qa_bam_opts_t;
 
@@ -54,7 +55,7 @@ void qa_bam_opts_default(qa_bam_opts_t *opts);
  * A base enters with bq = +q when it shows the alternate allele and -q for the reference allele (the sign convention of
  * sampleReads[[r]][[3]], consumed at QUILT/src/gibbs-nipt.cpp:125-141), q = min(base quality, mapping quality), and is
  * dropped when q < bqFilter.  Unmapped, secondary, supplementary, duplicate and QC-fail alignments are skipped.
- * Unpinned-vs-STITCH rules: the read's central SNP is its (n - 1) / 2-th site (lower median); the coverage cap visits sites
+ * Unpinned-vs-STITCH rules: overlapping mates (above); the read's central SNP is its (n - 1) / 2-th site (lower median); the coverage cap visits sites
  * in ascending order and, at a site above the cap, drops the covering reads with the smallest counter-stream keys
  * (key = stream(seed, read index)) until the site is at the cap.
  * A coordinate-sorted file with a BAI index beside it (<file>.bai or <file without .bam>.bai) is entered at the linear index's

@@ -787,6 +787,11 @@ struct qa_panel::Scratch {
     }
 };
 
+void qa::drop_pass_scratch(qa_panel *p) {
+    delete p->scratch;
+    p->scratch = nullptr;
+}
+
 qa_panel::~qa_panel() {
     delete scratch;
     if (gibbs_stream) (void)hipStreamDestroy(gibbs_stream);

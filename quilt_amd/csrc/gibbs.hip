@@ -109,19 +109,19 @@ __device__ void backward_both(Chain<NE, NW> &ch) {
         for (int h = 0; h < 2; h++) {
 #pragma unroll
             for (int i = 0; i < NE; i++) b[h].v[i] = ch.valid[i] ? cl[h] : 0.0;
-            ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
+            ch.stm(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
         }
     }
     if (G >= 2) {
-        ch.ld(e[0], ch.eg[0] + (size_t)(G - 1) * Ksp);
-        ch.ld(e[1], ch.eg[1] + (size_t)(G - 1) * Ksp);
+        ch.ldm(e[0], ch.eg[0] + (size_t)(G - 1) * Ksp);
+        ch.ldm(e[1], ch.eg[1] + (size_t)(G - 1) * Ksp);
     }
     for (int g = G - 2; g >= 0; --g) {
         if ((g & 63) == 63) gs.load_bwd(ch, g & ~63);
         const int j = g & 63;
         Col<NE> en[2];   // next iteration's emission columns (grid g) while this one computes
-        ch.ld(en[0], ch.eg[0] + (size_t)g * Ksp);
-        ch.ld(en[1], ch.eg[1] + (size_t)g * Ksp);
+        ch.ldm(en[0], ch.eg[0] + (size_t)g * Ksp);
+        ch.ldm(en[1], ch.eg[1] + (size_t)g * Ksp);
         const double s0 = rl_f64(gs.t0, j), s1 = rl_f64(gs.t1, j);
         const double cg[2] = {rl_f64(gs.c0, j), rl_f64(gs.c1, j)};
         const bool has = !FASTER || rl_i32(gs.has, j) != 0;
@@ -141,7 +141,7 @@ __device__ void backward_both(Chain<NE, NW> &ch) {
             const double xx = FASTER ? s1 * x[h] * one_over_K : s1 * x[h];
 #pragma unroll
             for (int i = 0; i < NE; i++) b[h].v[i] = ch.valid[i] ? cg[h] * (xx + s0 * b[h].v[i]) : 0.0;
-            ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
+            ch.stm(b[h], ch.beta[h] + (size_t)g * Ksp);
         }
         e[0] = en[0];
         e[1] = en[1];
@@ -256,10 +256,10 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
         rs.base = -1;
         GridStreams<CH> gs;
         Col<NE> e[2], bt[2];
-        ch.ld(e[0], ch.eg[0]);
-        ch.ld(e[1], ch.eg[1]);
-        ch.ld(bt[0], ch.beta[0]);
-        ch.ld(bt[1], ch.beta[1]);
+        ch.ldm(e[0], ch.eg[0]);
+        ch.ldm(e[1], ch.eg[1]);
+        ch.ldm(bt[0], ch.beta[0]);
+        ch.ldm(bt[1], ch.beta[1]);
         for (int g = 0; g < G; g++) {
             if ((g & 63) == 0) {
                 if (g) gs.store_c(ch);
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
             Col<NE> en[2], bn[2];
             {
                 const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: loads stay unconditional
-                ch.ld(en[0], ch.eg[0] + gn);
-                ch.ld(en[1], ch.eg[1] + gn);
-                ch.ld(bn[0], ch.beta[0] + gn);
-                ch.ld(bn[1], ch.beta[1] + gn);
+                ch.ldm(en[0], ch.eg[0] + gn);
+                ch.ldm(en[1], ch.eg[1] + gn);
+                ch.ldm(bn[0], ch.beta[0] + gn);
+                ch.ldm(bn[1], ch.beta[1] + gn);
             }
             double cg[2];
             if (g > 0) {
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 const typename CH::ErPre cur_er = pre_er;
                 iRead++;
                 // unconditional (clamped) so that no control-flow join forces the in-order vmcnt to drain
-                ch.ld_pre(pre_er, min(iRead, R - 1));
+                // (the next read's table size comes from the lane-held stream; across a stream boundary: the whole table)
+                ch.ld_pre(pre_er, min(iRead, R - 1), (iRead & 63) ? rl_i32(rs.nent, iRead & 63) : 64);
                 if (rl_i32(rs.cat1, jr) != 0) continue;  // reads that cannot discriminate are skipped (:815)
                 Col<NE> er, ri;   // the read's emission column and 1 / it (used by normal reads)
                 const int dn_r = rl_i32(rs.dn, jr);
@@ -464,14 +465,14 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     cg[h] *= alphaConst;
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
-                    ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+                    ch.stm(e[h], ch.eg[h] + (size_t)g * Ksp);
                 }
             }
             // alphaHat_t is not read again inside the call (the shard pass runs its own forward): only the state left
             // by the last sweep is observable (hapProbs, state_out), so only that sweep writes it
             if (last_sweep) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+                for (int h = 0; h < 2; h++) ch.stm(a[h], ch.alpha[h] + (size_t)g * Ksp);
             }
             gs.set_c(lane, jg, cg[0], cg[1]);
             e[0] = en[0]; e[1] = en[1];
@@ -535,12 +536,12 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 const int jg = g & 63;
                 const double oc1 = rl_f64(ss.c0, jg), oc2 = rl_f64(ss.c1, jg);
                 Col<NE> e2[2];
-                ch.ld(e2[0], ch.eg[0] + (size_t)g * Ksp);
-                ch.ld(e2[1], ch.eg[1] + (size_t)g * Ksp);
+                ch.ldm(e2[0], ch.eg[0] + (size_t)g * Ksp);
+                ch.ldm(e2[1], ch.eg[1] + (size_t)g * Ksp);
                 Col<NE> b1, b2;
                 if (g < G - 1) {
-                    ch.ld(b1, ch.beta[0] + (size_t)g * Ksp);
-                    ch.ld(b2, ch.beta[1] + (size_t)g * Ksp);
+                    ch.ldm(b1, ch.beta[0] + (size_t)g * Ksp);
+                    ch.ldm(b2, ch.beta[1] + (size_t)g * Ksp);
                 }
                 double cn[2];
                 if (g == 0) {
@@ -560,8 +561,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 } else {
                     if (flip) {
                         Col<NE> tmp = e2[0]; e2[0] = e2[1]; e2[1] = tmp;
-                        ch.st(e2[0], ch.eg[0] + (size_t)g * Ksp);
-                        ch.st(e2[1], ch.eg[1] + (size_t)g * Ksp);
+                        ch.stm(e2[0], ch.eg[0] + (size_t)g * Ksp);
+                        ch.stm(e2[1], ch.eg[1] + (size_t)g * Ksp);
                     }
                     // rcpp_alpha_forward_one (gibbs-nipt.cpp:627-657), alphaMat = 1/Ks, normalize
                     const double x = rl_f64(ss.t0, jg), t1 = rl_f64(ss.t1, jg);
@@ -587,8 +588,8 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                     }
                 }
                 if (last_sweep) {
-                    ch.st(s_a[0], ch.alpha[0] + (size_t)g * Ksp);
-                    ch.st(s_a[1], ch.alpha[1] + (size_t)g * Ksp);
+                    ch.stm(s_a[0], ch.alpha[0] + (size_t)g * Ksp);
+                    ch.stm(s_a[1], ch.alpha[1] + (size_t)g * Ksp);
                 }
                 ss.set_c(lane, jg, cn[0], cn[1]);
                 mlc1 -= log(cn[0]);
@@ -859,7 +860,7 @@ namespace qa {
 
 struct GibbsScratch {
     DBuf<int32_t> which, read_off, read_ptr, base_off, u, bq, wif, block_its, first_read, H, H_class, status;
-    DBuf<uint8_t> ghr, is_cat1;
+    DBuf<uint8_t> ghr, is_cat1, er_nent;
     DBuf<int32_t> dense_of;
     DBuf<size_t> eridx_off;
     ABuf<uint8_t> er_idx;
@@ -1151,6 +1152,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         S.eridx_off.ensure(C); S.eridx_off.upload(ixoff.data(), C, st);
         S.dense_of.ensure(dense_of.size()); S.dense_of.upload(dense_of.data(), dense_of.size(), st);
         S.is_cat1.ensure(std::max(totR, 1));
+        S.er_nent.ensure(std::max(totR, 1));
         const int nH = o->ff != 0.0 ? 3 : 2;
         const size_t mat = (size_t)C * nH * G * Ksp;
         S.H.ensure(std::max(totR, 1)); S.H.upload(H, totR, st);
@@ -1204,7 +1206,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         prm.runif_reads = S.runif_reads.p; prm.first_read = S.first_read.p; prm.runif_shard = S.runif_shard.p;
         prm.seed_reads = seed_reads ? S.seeds.p : nullptr;
         prm.seed_shard = (seed_reads && seed_shard) ? S.seeds.p + C : nullptr;
-        prm.eMatRead = S.eMatRead.p; prm.eread_off = S.eread_off.p; prm.is_cat1 = S.is_cat1.p;
+        prm.eMatRead = S.eMatRead.p; prm.eread_off = S.eread_off.p; prm.is_cat1 = S.is_cat1.p; prm.er_nent = S.er_nent.p;
         prm.er_idx = S.er_idx.p; prm.eridx_off = S.eridx_off.p; prm.er_tab = S.er_tab.p; prm.dense_of = S.dense_of.p;
         prm.er_nt = er_nt; prm.er_padb = er_padb;
         prm.alpha = S.alpha.p; prm.beta = S.beta.p; prm.eg = S.eg.p; prm.cvec = S.cvec.p;

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
     auto u_draw = [&](int r) { return ru ? ru[R + r] : stream_uniform(seed, (uint64_t)p.blk_pass * 2 * R + R + r); };
     // The block kernel runs two waves per chain at Ksp = 640 (its 18 columns need it) even when the sampler, and with it
     // the compact read emissions, were laid out for one wave of 10 rows per lane: then row l + 64 (w + 2 i) of this thread
-    // (lane l, wave w) is byte w + 2 i of lane l's 16-byte pack.
+    // (lane l, wave w) is byte w + 2 i of lane l's 12-byte pack.
     const bool foreign = NW == 2 && p.er_nt == 64;
     // grid, label and dense row of the reads being walked, 64 at a time in lanes (one vector load per field and block
     // instead of a dependent uniform load per read and field); dropped whenever labels have been rewritten
@@ -598,15 +598,16 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
             ch.expand(er, x);
             return;
         }
-        const uint4 q = *reinterpret_cast<const uint4 *>(ch.eridx + ((size_t)r * 64 + ch.lane) * 16);
-        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+        struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };   // (padb_of(10) = 12 bytes per lane)
+        const U3 q = *reinterpret_cast<const U3 *>(ch.eridx + ((size_t)r * 64 + ch.lane) * 12);
+        const uint32_t w4[4] = {q.a, q.b, q.c, 0u};
         const double tv = ch.ertab[(size_t)r * 64 + ch.lane];
         const int lo = __double2loint(tv), hi = __double2hiint(tv);
 #pragma unroll
         for (int i = 0; i < NE; i++) {
             uint32_t code = 0;
 #pragma unroll
-            for (int b = 0; b < 16; b++)   // byte ch.wave + 2 i, without dynamic register indexing
+            for (int b = 0; b < 12; b++)   // byte ch.wave + 2 i, without dynamic register indexing
                 if (b == ch.wave + 2 * i) code = (w4[b >> 2] >> ((b & 3) * 8)) & 0xffu;
             const int src = (int)code << 2;
             er.v[i] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, hi), __builtin_amdgcn_ds_bpermute(src, lo));

@@ -67,6 +67,7 @@ struct GibbsParams {
     const int32_t *dense_of; // [totR]
     int er_nt, er_padb;
     uint8_t *is_cat1;        // [sum R]
+    uint8_t *er_nent;        // [sum R] table entries a compact read refers to (2^informative SNPs; 64: unknown / all)
     double *alpha, *beta, *eg;  // [C][2][G][Ksp]
     double *cvec;            // [C][3][G]
     int32_t *H;              // [sum R] labels 1-based (in/out)
@@ -178,7 +179,7 @@ __device__ __forceinline__ uint32_t panel_word(const GibbsParams &p, int g, int 
 // ---------------------------------------------------------------------------------------------
 constexpr int kReadsPerWave = 32;
 constexpr int kMaxPatternBits = 5;
-constexpr int padb_of(int ne) { return ne <= 4 ? 4 : ne <= 8 ? 8 : 16; }
+constexpr int padb_of(int ne) { return ne <= 4 ? 4 : ne <= 8 ? 8 : ne <= 12 ? 12 : 16; }
 
 template <int NEALL, int NW>
 __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
@@ -299,7 +300,10 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
 #pragma unroll
         for (int i = 0; i < NEALL; i++) if (kk[i] >= 0 && v[i] < thresh) below = true;
         const bool any_below = __any(below);
-        if (lane == 0) p.is_cat1[p.read_off[c] + r] = (any_below || p.disable_read_category_usage) ? 0 : 1;
+        if (lane == 0) {
+            p.is_cat1[p.read_off[c] + r] = (any_below || p.disable_read_category_usage) ? 0 : 1;
+            p.er_nent[p.read_off[c] + r] = (uint8_t)(n_inf <= kMaxPatternBits ? (1 << n_inf) : 64);
+        }
         if (dense >= 0) {
             double *out = p.eMatRead + p.eread_off[c] + (size_t)dense * p.Ksp;
 #pragma unroll
@@ -335,6 +339,21 @@ template <int NE>
 struct Col {
     double v[NE];
 };
+
+// Raw buffer access (a wave-uniform base in scalar registers + a byte count): lanes whose offset lies beyond the count read 0
+// and write nothing WITHOUT a memory request -- bounds that cost no branch and no traffic.  Used for the tail of the last
+// small-panel row (Ks = 600: lanes 24..63 of row 9, 320 of a column's 5 120 bytes) and for the unused part of a compact
+// read's 64-entry table.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_st_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, v), r,
+                                          (int)byte_off, 0, 0);
+}
 
 template <int NE>
 __device__ __forceinline__ void load_col(Col<NE> &c, const double *src, int t, int NT) {
@@ -375,7 +394,7 @@ struct Chain {
     const double *ertab;
     const int32_t *dense_of;
     const int32_t *wif;
-    const uint8_t *ghr, *cat1;
+    const uint8_t *ghr, *cat1, *nent;
     int32_t *H, *Hc;
     double prior;  // 1 / Ks
     bool valid[NE];
@@ -400,6 +419,7 @@ struct Chain {
         dense_of = p.dense_of + p.read_off[c];
         wif = p.wif + p.read_off[c];
         cat1 = p.is_cat1 + p.read_off[c];
+        nent = p.er_nent + p.read_off[c];
         ghr = p.grid_has_read + (size_t)c * G;
         H = p.H + p.read_off[c];
         Hc = p.H_class + p.read_off[c];
@@ -414,18 +434,25 @@ struct Chain {
         uint32_t w[PADB / 4];
         double tv;
     };
-    __device__ __forceinline__ void ld_pre(ErPre &x, int r) const {
+    // `nent`: the table entries the read refers to (wave-uniform; 64 = all).  Entry 63 -- the value of padding rows and of
+    // degenerate reads -- is 1 by construction and is not fetched.
+    __device__ __forceinline__ void ld_pre(ErPre &x, int r, int nent = 64) const {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(eridx + ((size_t)r * NT + t) * PADB);
         if constexpr (PADB == 16) {
             const uint4 q = *reinterpret_cast<const uint4 *>(src);
             x.w[0] = q.x; x.w[1] = q.y; x.w[2] = q.z; x.w[3] = q.w;
+        } else if constexpr (PADB == 12) {
+            struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+            const U3 q = *reinterpret_cast<const U3 *>(src);
+            x.w[0] = q.a; x.w[1] = q.b; x.w[2] = q.c;
         } else if constexpr (PADB == 8) {
             const uint2 q = *reinterpret_cast<const uint2 *>(src);
             x.w[0] = q.x; x.w[1] = q.y;
         } else {
             x.w[0] = *src;
         }
-        x.tv = ertab[(size_t)r * 64 + lane];
+        const double tv = buf_ld_f64(buf_rsrc(ertab + (size_t)r * 64, (uint32_t)nent * 8), (uint32_t)lane * 8);
+        x.tv = lane == 63 ? 1.0 : tv;
     }
     __device__ __forceinline__ void expand(Col<NE> &er, const ErPre &x) const {
         const int lo = __double2loint(x.tv), hi = __double2hiint(x.tv);
@@ -511,6 +538,19 @@ struct Chain {
     }
     __device__ __forceinline__ void ld(Col<NE> &c, const double *src) const { load_col(c, src, t, NT); }
     __device__ __forceinline__ void st(const Col<NE> &c, double *dst) const { store_col(c, dst, t, NT); }
+    // the same for STATE columns (alpha / beta / eMatGrid) in the sweeps: only the Ks real rows move; the padding rows of a
+    // column keep what the initialisation stored (0 for alpha and beta, 1 for eMatGrid) and read as 0 here -- every use of
+    // a padding row is either masked by `valid` or a product with an alpha / beta that is 0
+    __device__ __forceinline__ void ldm(Col<NE> &c, const double *src) const {
+        const __amdgpu_buffer_rsrc_t r = buf_rsrc(src, (uint32_t)Ks * 8);
+#pragma unroll
+        for (int i = 0; i < NE; i++) c.v[i] = buf_ld_f64(r, (uint32_t)(t + NT * i) * 8);
+    }
+    __device__ __forceinline__ void stm(const Col<NE> &c, double *dst) const {
+        const __amdgpu_buffer_rsrc_t r = buf_rsrc(dst, (uint32_t)Ks * 8);
+#pragma unroll
+        for (int i = 0; i < NE; i++) buf_st_f64(r, (uint32_t)(t + NT * i) * 8, c.v[i]);
+    }
 };
 
 // ---- lane-held scalar streams --------------------------------------------------------------
@@ -594,13 +634,14 @@ struct GridStreams3 {
 
 template <class CH>
 struct ReadStreams {   // lane j <-> read base + j
-    int wif, cat1, H, Hc, base, dn;
+    int wif, cat1, H, Hc, base, dn, nent;
     double u;
     __device__ void load(const CH &ch, int b, const double *runif, int it) {
         base = b;
         const int r = b + ch.lane;
         const bool ok = r < ch.R;
         wif = ok ? ch.wif[r] : -1;
+        nent = ok ? ch.nent[r] : 64;
         dn = ok ? ch.dense_of[r] : -1;
         cat1 = ok ? ch.cat1[r] : 1;
         H = ok ? ch.H[r] : 1;

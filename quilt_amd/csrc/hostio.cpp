@@ -285,10 +285,14 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
         const uint8_t *cig = &rec[32 + l_read_name], *seq = cig + 4 * (size_t)n_cigar, *qual = seq + (l_seq + 1) / 2;
         // walk the CIGAR; a soft clip is laid out left of / right of the aligned part when its bases are to be used
         int64_t rpos = (int64_t)pos0 + 1;   // 1-based reference coordinate of the next reference-consuming base
-        if (o.useSoftClippedBases && n_cigar > 0) {
-            uint32_t c0;
-            memcpy(&c0, cig, 4);
-            if ((c0 & 15) == 4) rpos -= (c0 >> 4);
+        if (o.useSoftClippedBases) {   // the leading soft clip: the first operation that is not a hard clip (2H3S4M)
+            for (int ci = 0; ci < n_cigar; ci++) {
+                uint32_t c0;
+                memcpy(&c0, cig + 4 * (size_t)ci, 4);
+                if ((c0 & 15) == 5) continue;
+                if ((c0 & 15) == 4) rpos -= (c0 >> 4);
+                break;
+            }
         }
         const int64_t aln_start = rpos;
         int32_t q = 0;
@@ -334,6 +338,22 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
                 auto &dst = reads[it->second].b;
                 dst.insert(dst.end(), bases.begin(), bases.end());
                 std::stable_sort(dst.begin(), dst.end(), [](const Base &a, const Base &b) { return a.u < b.u; });
+                // A site both mates cover is ONE observation of the molecule, not two: mates that agree keep the call with the
+                // higher quality, mates that disagree drop the site (rule stated in include/quilt_amd_io.h; unpinned vs STITCH)
+                size_t w = 0;
+                for (size_t i = 0; i < dst.size();) {
+                    size_t j = i + 1;
+                    Base keep = dst[i];
+                    bool conflict = false;
+                    for (; j < dst.size() && dst[j].u == dst[i].u; j++) {
+                        if ((dst[j].bq < 0) != (keep.bq < 0)) conflict = true;
+                        else if (std::abs(dst[j].bq) > std::abs(keep.bq)) keep = dst[j];
+                    }
+                    if (!conflict) dst[w++] = keep;
+                    i = j;
+                }
+                dst.resize(w);
+                if (dst.empty()) { reads[it->second].alive = false; S->stats[7]++; }
                 by_name.erase(it);
                 S->stats[6]++;
                 continue;

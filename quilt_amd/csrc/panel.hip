@@ -393,8 +393,7 @@ int qa_panel_set_exclusive(qa_panel_t *panel, int32_t on) {
         return QA_ERR_INVALID;
     }
     if ((on != 0) != panel->exclusive) {
-        delete panel->scratch;   // its buffers are views of the arena in use
-        panel->scratch = nullptr;
+        qa::drop_pass_scratch(panel);   // its buffers are views of the arena in use
         panel->exclusive = on != 0;
     }
     return QA_OK;

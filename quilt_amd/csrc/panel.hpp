@@ -58,6 +58,8 @@ struct qa_panel {
 namespace qa {
 // after sp_off / sp_k are on the device and h_sp_off on the host: sp_gidx, sp_chunk_at, tm1
 void finish_panel_tables(qa_panel *p);
+// fullpass.hip: delete the handle's full-pass scratch views (re-created on the next call, over the arena then in use)
+void drop_pass_scratch(qa_panel *p);
 }
 
 // The all-SNP side of a QUILT2 panel (rare + common SNPs): what the final all-SNP Gibbs call needs on top of the

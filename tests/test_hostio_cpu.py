@@ -154,6 +154,25 @@ def test_loader_filters_and_cigar(tmp_path):
     assert s.nReads == 1 and s.u.tolist() == [0, 4] and s.bq.tolist() == [30, -25]
     s, st = load([m1, m2], merge_mates=False, return_stats=True)
     assert s.nReads == 2 and st["mates_merged"] == 0
+    # OVERLAPPING mates (short inserts: cfDNA): a site both mates cover is one observation -- agreeing calls keep the better
+    # quality, disagreeing calls drop the site; a pair left without any site is no read
+    o1 = _aln(98, "TTCTTTTATTTTC", [30] * 13, name="ov", flag=0x1 | 0x40, tlen=20)      # 100 alt q30, 105 ref q30, 110 alt q30
+    sq, q = list("TTTTTTTATTTTA"), [25] * 13                                              # 105 ref q25, 110 REF q25 (conflict)
+    o2 = _aln(98, "".join(sq), q, name="ov", flag=0x1 | 0x80, tlen=-20)
+    s, st = load([o1, o2], return_stats=True)
+    assert s.nReads == 1 and s.u.tolist() == [0, 1] and s.bq.tolist() == [30, -30] and st["mates_merged"] == 1
+    o3 = _aln(98, "TTATT", 40, name="cf", flag=0x1 | 0x40, tlen=5)
+    o4 = _aln(98, "TTCTT", 20, name="cf", flag=0x1 | 0x80, tlen=-5)
+    assert load([o3, o4]).nReads == 0
+    s = load([_aln(98, "TTCTT", 20, name="hq", flag=0x1 | 0x40, tlen=5), _aln(98, "TTCTT", 35, name="hq", flag=0x1 | 0x80, tlen=-5)])
+    assert s.nReads == 1 and s.u.tolist() == [0] and s.bq.tolist() == [35]
+    # a hard clip in front of the leading soft clip (2H3S10M)
+    cig = [(2, "H"), (3, "S"), (10, "M")]
+    sq = list("T" * 13)
+    sq[0] = "C"
+    sq[3 + 2] = "A"
+    s = load([_aln(103, "".join(sq), 30, cigar=cig)], useSoftClippedBases=True)
+    assert s.u.tolist() == [0, 1] and s.bq.tolist() == [30, -30]
     # window: alignments must overlap chrStart..chrEnd
     assert load([m1, m2], merge_mates=False, chrStart=150, chrEnd=400).u.tolist() == [4]
     assert load([m1, m2], merge_mates=False, chrStart=1, chrEnd=99).u.tolist() == [0]
