@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per sample (default 20000; 300 with --mode ont)")
     ap.add_argument("--mode", choices=["short", "ont", "nipt"], default="short",
                     help="read model (ont: BASELINE configs[3]; nipt: configs[4], method = nipt with ff = 0.2)")
-    ap.add_argument("--workers", type=int, default=4, help="host threads per GPU (each with its own stream and arena)")
+    ap.add_argument("--workers", type=int, default=3, help="host threads per GPU (each with its own stream and arena)")
     ap.add_argument("--rare-common", type=float, default=0.0, metavar="F",
                     help="impute_rare_common with F x nsnps rare SNPs: every Gibbs sample ends with a Gibbs call over all SNPs "
                          "(QUILT2; not the headline workload, no CPU baseline)")
