@@ -1,10 +1,10 @@
 #!/bin/bash
 # Produces the files profiles/<tag>_* are copied from.  Run on the GPU box:
-#   gpurun --timeout 3000 -- 'bash scripts/profile_round.sh r02'
+#   gpurun --timeout 3000 -- 'bash scripts/profile_round.sh r03'
 # 1. the -m gpu tests; 2. the bench line of the driver's own command (--steps 20 --warmup 5); 3. rocprofv3 --kernel-trace
 # --stats of the same command (CPU baseline leg off: it forks 128 host processes the profiler would follow); 4. PMC passes
 # (each alone with --kernel-trace: FETCH_SIZE, WRITE_SIZE, instruction counters); 5. the ONT / NIPT / fp64-dosage / msPBWT-mode lines.
-TAG=${1:-r02}
+TAG=${1:-r03}
 WHAT=${2:-all}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
@@ -18,7 +18,7 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_line_steps20.json 2> $OUT/ben
 fi
 if [[ $WHAT == all || $WHAT == stats ]]; then
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_under_rocprof.json 2> $OUT/rocprof_stats.err)
+    python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_under_rocprof.json 2> $OUT/rocprof_stats.err)
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/stats -name '*agent_info.csv' -exec cp {} $OUT/agent_info.csv \;
 head -12 $OUT/kernel_stats.csv
@@ -28,21 +28,22 @@ if [[ $WHAT == all || $WHAT == pmc ]]; then
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     N=$(echo $C | cut -d' ' -f1)
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o pmc -- \
-        python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err)
+        python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --r2-vs-cpu 0 --no-alone > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err)
     find $OUT/pmc_$N -name '*counter_collection.csv' -exec cp {} $OUT/pmc_${N}_counters.csv \;
     rm -rf $OUT/pmc_$N
 done
 python scripts/pmc_summary.py $OUT/pmc_FETCH_SIZE_counters.csv $OUT/pmc_WRITE_SIZE_counters.csv $OUT/pmc_traffic.json \
-    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --r2-vs-cpu 0 --no-alone"
 python scripts/pmc_insts.py $OUT/pmc_SQ_INSTS_VALU_counters.csv $OUT/pmc_SQ_INSTS_VMEM_counters.csv > $OUT/pmc_insts.json
 cat $OUT/pmc_insts.json | head -40
 # the raw per-dispatch counter files are large; keep the summaries only
 rm -f $OUT/pmc_*_counters.csv
 fi
 if [[ $WHAT == all || $WHAT == lines ]]; then
-python bench.py --mode ont --steps 12 --warmup 4 > $OUT/bench_line_ont.json 2> $OUT/bench_ont.err; tail -c 300 $OUT/bench_line_ont.json
-python bench.py --mode nipt --steps 12 --warmup 4 > $OUT/bench_line_nipt.json 2> $OUT/bench_nipt.err; tail -c 300 $OUT/bench_line_nipt.json
-python bench.py --fp64-dosage --steps 12 --warmup 4 --r2-vs-cpu 1 > $OUT/bench_line_fp64_dosage.json 2> $OUT/bench_fp64.err; tail -c 300 $OUT/bench_line_fp64_dosage.json
+python bench.py --mode ont --steps 12 --warmup 4 --r2-vs-cpu 0 > $OUT/bench_line_ont.json 2> $OUT/bench_ont.err; tail -c 300 $OUT/bench_line_ont.json
+python bench.py --mode nipt --steps 12 --warmup 4 --r2-vs-cpu 0 > $OUT/bench_line_nipt.json 2> $OUT/bench_nipt.err; tail -c 300 $OUT/bench_line_nipt.json
 python bench.py --mspbwt --steps 12 --warmup 4 > $OUT/bench_line_mspbwt.json 2> $OUT/bench_mspbwt.err; tail -c 300 $OUT/bench_line_mspbwt.json
-python bench.py --bam --steps 12 --warmup 4 --no-cpu-baseline > $OUT/bench_line_from_bam.json 2> $OUT/bench_from_bam.err; tail -c 300 $OUT/bench_line_from_bam.json
+python bench.py --bam --steps 12 --warmup 4 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_from_bam.json 2> $OUT/bench_from_bam.err; tail -c 300 $OUT/bench_line_from_bam.json
+python bench.py --K 5000 --batch 32 --steps 12 --warmup 4 > $OUT/bench_line_configs1_K5000_b32.json 2> $OUT/bench_configs1.err; tail -c 300 $OUT/bench_line_configs1_K5000_b32.json
+python bench.py --exclusive 0 --workers 4 --steps 20 --warmup 5 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_no_device_phases.json 2> $OUT/bench_nophases.err; tail -c 300 $OUT/bench_line_no_device_phases.json
 fi

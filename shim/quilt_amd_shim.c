@@ -9,18 +9,25 @@
  *   _QUILT_Rcpp_haploid_dosage_versus_refs   38 arguments   RcppExports.cpp:1580-1625   -> qa_Rcpp_haploid_dosage_versus_refs
  *   _QUILT_rcpp_forwardBackwardGibbsNIPT     63 arguments   RcppExports.cpp:966-1038    -> qa_gibbs_batch(_rare_common)
  *   _QUILT_Rcpp_make_gl_bound                 3 arguments   RcppExports.cpp:1263-1273   -> qa_Rcpp_make_gl_bound
+ *   _QUILT_rcpp_make_eMatRead_t              15 arguments   RcppExports.cpp:15-38       -> qa_rcpp_make_eMatRead_t
  *
- * Built as QUILT.so's replacement for these three entries (link order / `useDynLib` of a patched package), or loaded
- * beside an unmodified QUILT and swapped in with `assignInNamespace` (INTEGRATION.md shows both); no R function changes its
- * signature.  The prepared panel is uploaded on first use and cached in this file (keyed by the identity of the R
- * objects: data pointer and dimensions of distinctHapsB / hapMatcherR), so the 38- and 63-argument entries keep their
- * arity; `qa_shim_release()` (0 arguments) drops the cache.  R owns every buffer it passes: results are copied back into
+ * The C functions are called qa_QUILT_<fn> -- NOT _QUILT_<fn>: RcppExports.cpp defines those symbols itself, and this
+ * file is compiled INTO QUILT.so (shim/QUILT-src.patch adds it to QUILT/src and points the four rows of RcppExports.cpp's
+ * CallEntries[] at the functions here; R_init_QUILT then registers them under the reference's names, so every
+ * `.Call('_QUILT_<fn>', PACKAGE = 'QUILT', ...)` of the unmodified R code lands here).  It can also be built as a DLL of its
+ * own (R_init_quilt_amd_shim below) and swapped in with `assignInNamespace` (INTEGRATION.md shows both); no R function
+ * changes its signature.  The prepared panel is uploaded on first use and cached in this file (keyed by the identity of the R
+ * objects -- data pointer and dimensions of distinctHapsB / hapMatcherR -- plus ref_error and a checksum over transMatRate and
+ * samples of both tables, so that a different panel that lands on a recycled address is not mistaken for the cached one), so
+ * the 38- and 63-argument entries keep their arity; `qa_shim_release()` (0 arguments) drops the cache.  R owns every buffer it passes: results are copied back into
  * them before returning (SURVEY.md 8(b) "Ownership").
  *
  * Random numbers.  The reference draws inside the native call from R's generator (`Rcpp::runif`, `Rcpp::sample`:
  * gibbs-nipt.cpp:2845-2848, 3013-3018; gibbs-nipt-block.cpp:2054) under `Rcpp::RNGScope` (RcppExports.cpp:971).  The
- * shim draws the same uniforms, in the same order, with unif_rand() between GetRNGstate() / PutRNGstate() and passes them
- * down; the device never generates R-incompatible numbers on this path.  Where the reference's draw count depends on
+ * shim draws the same uniforms, in the same order, with unif_rand() (R_unif_index() for `sample(nReads, 1)`, as Rcpp's sugar
+ * does) between GetRNGstate() / PutRNGstate() and passes them down; the device never generates R-incompatible numbers on this
+ * path.  The shard pass draws nGrids - 1 uniforms per block iteration: what gibbs-nipt-block.cpp:2054 draws with
+ * shard_check_every_pair = TRUE, the production value (quilt.R:178); FALSE is rejected.  Where the reference's draw count depends on
  * intermediate results (`Rcpp::sample(1:3, 1, prob)` per read in rcpp_sample_H_using_H_class, NIPT only) the stream
  * cannot be pre-drawn in R's order: one uniform per read is drawn instead (documented deviation).
  *
@@ -73,7 +80,24 @@ static struct {
     qa_rare_common_t *rc;
     const void *key_B, *key_hm, *key_rare;
     int K, G, T, nMaxDH;
+    double ref_error;
+    uint64_t checksum;
 } g_cache;
+
+/* FNV-1a over the transition rates and evenly spaced samples of the two panel tables: cheap next to any call it guards */
+static uint64_t fnv(uint64_t h, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+static uint64_t panel_checksum(const void *hm, size_t hm_bytes, const int *B, size_t nB, const double *tm, size_t n_tm) {
+    uint64_t h = 1469598103934665603ull;
+    h = fnv(h, tm, n_tm * sizeof(double));
+    const size_t step_h = hm_bytes / 4096 + 1, step_B = nB / 4096 + 1;
+    for (size_t i = 0; i < hm_bytes; i += step_h) h = fnv(h, (const unsigned char *)hm + i, 1);
+    for (size_t i = 0; i < nB; i += step_B) h = fnv(h, B + i, sizeof(int));
+    return h;
+}
 
 static void cache_drop(void) {
     if (g_cache.rc) qa_rare_common_destroy(g_cache.rc);
@@ -89,8 +113,10 @@ static qa_panel_t *panel_for(SEXP hapMatcher, SEXP hapMatcherR, int use_hapMatch
     SEXP hm = use_hapMatcherR ? hapMatcherR : hapMatcher;
     const int K = Rf_nrows(hm);
     const void *kB = INTEGER(distinctHapsB), *kh = use_hapMatcherR ? (const void *)RAW(hapMatcherR) : (const void *)INTEGER(hapMatcher);
+    const uint64_t sum = panel_checksum(kh, (size_t)K * G * (use_hapMatcherR ? 1 : sizeof(int)), INTEGER(distinctHapsB),
+                                        (size_t)nMaxDH * G, transMatRate, 2 * (size_t)(G > 1 ? G - 1 : 0));
     if (g_cache.panel && g_cache.key_B == kB && g_cache.key_hm == kh && g_cache.K == K && g_cache.G == G && g_cache.T == T &&
-        g_cache.nMaxDH == nMaxDH)
+        g_cache.nMaxDH == nMaxDH && g_cache.ref_error == ref_error && g_cache.checksum == sum)
         return g_cache.panel;
     cache_drop();
     qa_panel_desc_t d;
@@ -124,6 +150,7 @@ static qa_panel_t *panel_for(SEXP hapMatcher, SEXP hapMatcherR, int use_hapMatch
     check_status(st, "qa_panel_create");
     g_cache.panel = p; g_cache.key_B = kB; g_cache.key_hm = kh;
     g_cache.K = K; g_cache.G = G; g_cache.T = T; g_cache.nMaxDH = nMaxDH;
+    g_cache.ref_error = ref_error; g_cache.checksum = sum;
     return p;
 }
 
@@ -134,7 +161,7 @@ SEXP qa_shim_release(void) {
 
 /* ---- _QUILT_Rcpp_make_gl_bound(gl, minGLValue, to_fix)  (reference-single.cpp:68-94; to_fix 0-based) --------------- */
 
-SEXP _QUILT_Rcpp_make_gl_bound(SEXP glSEXP, SEXP minGLValueSEXP, SEXP to_fixSEXP) {
+SEXP qa_QUILT_Rcpp_make_gl_bound(SEXP glSEXP, SEXP minGLValueSEXP, SEXP to_fixSEXP) {
     check_status(qa_Rcpp_make_gl_bound(REAL(glSEXP), Rf_asReal(minGLValueSEXP), INTEGER(to_fixSEXP), Rf_length(to_fixSEXP)),
                  "qa_Rcpp_make_gl_bound");
     return R_NilValue;
@@ -142,7 +169,7 @@ SEXP _QUILT_Rcpp_make_gl_bound(SEXP glSEXP, SEXP minGLValueSEXP, SEXP to_fixSEXP
 
 /* ---- _QUILT_Rcpp_haploid_dosage_versus_refs: the 38 arguments of RcppExports.cpp:1582, in order ------------------------- */
 
-SEXP _QUILT_Rcpp_haploid_dosage_versus_refs(
+SEXP qa_QUILT_Rcpp_haploid_dosage_versus_refs(
     SEXP glSEXP, SEXP arma_alphaHat_tSEXP, SEXP eigen_alphaHat_tSEXP, SEXP betaHat_tSEXP, SEXP cSEXP, SEXP gamma_tSEXP,
     SEXP gammaSmall_tSEXP, SEXP best_haps_stuff_listSEXP, SEXP dosageSEXP, SEXP transMatRate_tSEXP, SEXP rhb_tSEXP,
     SEXP ref_errorSEXP, SEXP use_eMatDHSEXP, SEXP distinctHapsBSEXP, SEXP distinctHapsIESEXP,
@@ -235,7 +262,7 @@ static double log_p_H_class(const int *H_class, int n, double ff) {   /* rcpp_ge
     return out;
 }
 
-SEXP _QUILT_rcpp_forwardBackwardGibbsNIPT(
+SEXP qa_QUILT_rcpp_forwardBackwardGibbsNIPT(
     SEXP sampleReadsSEXP, SEXP eMatRead_tSEXP, SEXP priorCurrent_mSEXP, SEXP alphaMatCurrent_tcSEXP, SEXP eHapsCurrent_tcSEXP,
     SEXP transMatRate_tc_HSEXP, SEXP ffSEXP, SEXP blocks_for_outputSEXP, SEXP alphaHat_t1SEXP, SEXP betaHat_t1SEXP,
     SEXP alphaHat_t2SEXP, SEXP betaHat_t2SEXP, SEXP alphaHat_t3SEXP, SEXP betaHat_t3SEXP, SEXP eMatGrid_t1SEXP,
@@ -264,6 +291,8 @@ SEXP _QUILT_rcpp_forwardBackwardGibbsNIPT(
         !flag(pl, "use_starting_read_labels", 1) || flag(pl, "pass_in_eMatRead_t", 0) || flag(pl, "use_small_eHapsCurrent_tc", 0))
         Rf_error("quilt_amd: only the production form of rcpp_forwardBackwardGibbsNIPT is supported (n_gibbs_starts = 1, "
                  "run_fb_subset = FALSE, use_starting_read_labels = TRUE, pass_in_eMatRead_t = FALSE, packed panel)");
+    if (!flag(pl, "shard_check_every_pair", 1))
+        Rf_error("quilt_amd: shard_check_every_pair = FALSE is not supported (QUILT() passes TRUE, quilt.R:178)");
     const double ff = Rf_asReal(ffSEXP);
     const int rare_common = flag(pl, "make_eMatRead_t_rare_common", 0);
     const int G_panel = Rf_ncols(distinctHapsBSEXP);
@@ -337,7 +366,7 @@ SEXP _QUILT_rcpp_forwardBackwardGibbsNIPT(
     GetRNGstate();
     for (size_t i = 0; i < (size_t)R * (size_t)n_its; i++) runif_reads[i] = unif_rand();         /* gibbs-nipt.cpp:2845 */
     if (!flag(pl, "gibbs_initialize_at_first_read", 0) && R > 0) {
-        first_read = (int32_t)(unif_rand() * R);                                                 /* :2846-2848 sample(nReads, 1) - 1 */
+        first_read = (int32_t)R_unif_index((double)R);   /* :2846-2848 sample(nReads, 1) - 1: Rcpp's sugar draws R_unif_index(n) */
         if (first_read >= R) first_read = R - 1;
     }
     if (o.perform_block_gibbs) {
@@ -427,12 +456,52 @@ SEXP _QUILT_rcpp_forwardBackwardGibbsNIPT(
     return out;
 }
 
-/* ---- registration (RcppExports.cpp:1703-1782) ---------------------------------------------------------------------- */
+/* ---- _QUILT_rcpp_make_eMatRead_t: the 15 arguments of RcppExports.cpp:17, in order ----------------------------------
+ * Read likelihoods against the K rows of eHapsCurrent_tc[, , s + 1] (copied-from-stitch.cpp:115-229), written into the
+ * caller's K x nReads eMatRead_t; production caller: calculate_eMatRead_t_vs_haplotypes (functions.R:2975-3020, K = 2 or 3).
+ * Needs the device context of a panel handle: the calls that precede it in the driver loop have created one. */
+SEXP qa_QUILT_rcpp_make_eMatRead_t(SEXP eMatRead_tSEXP, SEXP sampleReadsSEXP, SEXP eHapsCurrent_tcSEXP, SEXP sSEXP,
+                                   SEXP maxDifferenceBetweenReadsSEXP, SEXP JmaxSEXP, SEXP eMatHapOri_tSEXP, SEXP pRgivenH1SEXP,
+                                   SEXP pRgivenH2SEXP, SEXP prevSEXP, SEXP suppressOutputSEXP, SEXP prev_sectionSEXP,
+                                   SEXP next_sectionSEXP, SEXP run_pseudo_haploidSEXP, SEXP rescale_eMatRead_tSEXP) {
+    (void)eMatHapOri_tSEXP; (void)pRgivenH1SEXP; (void)pRgivenH2SEXP; (void)prevSEXP; (void)suppressOutputSEXP;
+    (void)prev_sectionSEXP; (void)next_sectionSEXP;
+    if (Rf_asLogical(run_pseudo_haploidSEXP)) Rf_error("quilt_amd: rcpp_make_eMatRead_t with run_pseudo_haploid = TRUE is not supported");
+    if (!g_cache.panel) Rf_error("quilt_amd: rcpp_make_eMatRead_t needs the panel of an earlier full-panel or Gibbs call");
+    const int K = Rf_nrows(eMatRead_tSEXP), R = Rf_length(sampleReadsSEXP), s = Rf_asInteger(sSEXP);
+    SEXP dim = Rf_getAttrib(eHapsCurrent_tcSEXP, R_DimSymbol);
+    if (Rf_length(dim) != 3 || INTEGER(dim)[0] != K || s < 0 || s >= INTEGER(dim)[2] || Rf_ncols(eMatRead_tSEXP) != R)
+        Rf_error("quilt_amd: rcpp_make_eMatRead_t: eHapsCurrent_tc must be K x nSNPs x S with K = nrow(eMatRead_t), 0 <= s < S");
+    const int T = INTEGER(dim)[1];
+    int32_t *read_ptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)R + 1));
+    read_ptr[0] = 0;
+    for (int r = 0; r < R; r++) read_ptr[r + 1] = read_ptr[r] + Rf_length(VECTOR_ELT(VECTOR_ELT(sampleReadsSEXP, r), 3));
+    const int nB = read_ptr[R];
+    int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nB > 0 ? nB : 1)), *bq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nB > 0 ? nB : 1));
+    for (int r = 0; r < R; r++) {
+        SEXP rd = VECTOR_ELT(sampleReadsSEXP, r);
+        const int n = read_ptr[r + 1] - read_ptr[r];
+        memcpy(bq + read_ptr[r], INTEGER(VECTOR_ELT(rd, 2)), sizeof(int) * (size_t)n);
+        memcpy(u + read_ptr[r], INTEGER(VECTOR_ELT(rd, 3)), sizeof(int) * (size_t)n);
+    }
+    const int32_t read_off[2] = {0, R};
+    const int st = qa_rcpp_make_eMatRead_t_nsnps(g_cache.panel, T, 1, K, REAL(eHapsCurrent_tcSEXP) + (size_t)s * K * T, read_off,
+                                                 read_ptr, u, bq, Rf_asReal(maxDifferenceBetweenReadsSEXP), Rf_asInteger(JmaxSEXP),
+                                                 Rf_asLogical(rescale_eMatRead_tSEXP), REAL(eMatRead_tSEXP));
+    free(read_ptr); free(u); free(bq);
+    check_status(st, "qa_rcpp_make_eMatRead_t");
+    return R_NilValue;
+}
+
+/* ---- registration (RcppExports.cpp:1703-1782) ----------------------------------------------------------------------
+ * Inside QUILT.so (shim/QUILT-src.patch): RcppExports.cpp's own CallEntries[] names these functions in the four rows, and
+ * R_init_QUILT registers them.  As a DLL of its own: R_init_quilt_amd_shim. */
 
 static const R_CallMethodDef CallEntries[] = {
-    {"_QUILT_rcpp_forwardBackwardGibbsNIPT", (DL_FUNC)&_QUILT_rcpp_forwardBackwardGibbsNIPT, 63},
-    {"_QUILT_Rcpp_haploid_dosage_versus_refs", (DL_FUNC)&_QUILT_Rcpp_haploid_dosage_versus_refs, 38},
-    {"_QUILT_Rcpp_make_gl_bound", (DL_FUNC)&_QUILT_Rcpp_make_gl_bound, 3},
+    {"_QUILT_rcpp_forwardBackwardGibbsNIPT", (DL_FUNC)&qa_QUILT_rcpp_forwardBackwardGibbsNIPT, 63},
+    {"_QUILT_Rcpp_haploid_dosage_versus_refs", (DL_FUNC)&qa_QUILT_Rcpp_haploid_dosage_versus_refs, 38},
+    {"_QUILT_Rcpp_make_gl_bound", (DL_FUNC)&qa_QUILT_Rcpp_make_gl_bound, 3},
+    {"_QUILT_rcpp_make_eMatRead_t", (DL_FUNC)&qa_QUILT_rcpp_make_eMatRead_t, 15},
     {"qa_shim_release", (DL_FUNC)&qa_shim_release, 0},
     {NULL, NULL, 0}};
 
