@@ -59,8 +59,11 @@ void qa_bam_opts_default(qa_bam_opts_t *opts);
  * in ascending order and, at a site above the cap, drops the covering reads with the smallest counter-stream keys
  * (key = stream(seed, read index)) until the site is at the cap.
  * A coordinate-sorted file with a BAI index beside it (<file>.bai or <file without .bam>.bai) is entered at the linear index's
- * offset for the window's first 16 kb interval (SAM spec 5.1.3, 5.2) instead of being scanned from the top; without a usable
- * index the file is scanned sequentially (and the scan stops once a sorted file has passed the window).
+ * offset for the window's first 16 kb interval, tightened by the chunks of the bins that can hold an overlapping alignment
+ * (SAM spec 5.1.3, 5.2, 5.3), instead of being scanned from the top; without a usable index the file is scanned
+ * sequentially (and the scan stops once a sorted file has passed the window).
+ * CRAM (`cramlist` + `reference`, QUILT/R/quilt.R:106-108) is not decoded: QA_ERR_UNSUPPORTED, and qa_last_error() holds the
+ * `samtools view -b -T <reference.fa>` command that converts the file.
  * Reads come back ordered by the grid of their central SNP (stable), as snap_sampleReads_to_grid leaves them
  * (functions.R:295-298).  QA_ERR_INVALID for unreadable / malformed files and unknown chromosome names. */
 int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNPs, const int32_t *L, const char *ref,

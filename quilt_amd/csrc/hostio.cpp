@@ -14,6 +14,8 @@
 #include "../../include/quilt_amd.h"
 #include "../../include/quilt_amd_io.h"
 
+namespace qa { void set_error(const char *fmt, ...); }   // panel.hip: the library's last-error text (qa_last_error)
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -154,42 +156,77 @@ inline uint64_t stream_key(uint64_t seed, uint64_t i) {   // the library's count
     return z ^ (z >> 31);
 }
 
-// linear-index offset of the 16 kb interval holding 0-based position pos0 of reference `ref` (0: no usable index)
-uint64_t bai_linear_offset(const char *bam_path, int32_t ref, int32_t pos0) {
+// Where to start reading for alignments that overlap [beg0, end0) (0-based, half open) of reference `ref`, from the BAI
+// index beside the file (SAM spec 5.2): 0 when there is no usable index (scan from the top).
+//   * linear index: ioffset[beg0 >> 14] = the smallest offset of an alignment overlapping that 16 kb interval -- a lower
+//     bound of everything the window needs (an interval no alignment overlaps holds 0 in some writers: the next one that
+//     does is taken);
+//   * bin index: the chunks of the bins that can hold an overlapping alignment (reg2bins, spec 5.3).  Every alignment the
+//     window needs lies in one of those chunks, so nothing before the first such chunk that ends after the linear bound is
+//     needed: in a whole-genome file whose window starts in the tail of a 16 kb interval this skips the alignments of
+//     larger bins' unrelated chunks the linear bound would start in.
+// The scan is sequential from the returned offset and filters by position itself, so any valid lower bound is correct.
+uint64_t bai_start_offset(const char *bam_path, int32_t ref, int32_t beg0, int32_t end0) {
     std::string p1 = std::string(bam_path) + ".bai", p2 = bam_path;
     if (p2.size() > 4 && p2.compare(p2.size() - 4, 4, ".bam") == 0) p2 = p2.substr(0, p2.size() - 4) + ".bai"; else p2.clear();
     FILE *f = fopen(p1.c_str(), "rb");
     if (!f && !p2.empty()) f = fopen(p2.c_str(), "rb");
     if (!f) return 0;
-    uint64_t result = 0;
+    uint64_t linear = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> chunks;   // (begin, end) of the chunks of overlapping bins
     auto rd = [&](void *d, size_t n) { return fread(d, 1, n, f) == n; };
+    auto overlaps = [&](uint32_t bin) {   // does bin cover part of [beg0, end0)?  (bins 0; 1-8; 9-72; 73-584; 585-4680; 4681-37448)
+        static const uint32_t first[6] = {0, 1, 9, 73, 585, 4681};
+        static const int shift[6] = {29, 26, 23, 20, 17, 14};
+        for (int l = 5; l >= 0; l--) {
+            if (bin < first[l]) continue;
+            const int64_t lo = (int64_t)(bin - first[l]) << shift[l], hi = lo + ((int64_t)1 << shift[l]);
+            return lo < (int64_t)end0 && hi > (int64_t)beg0;
+        }
+        return false;
+    };
     char magic[4];
     int32_t n_ref = 0;
-    if (rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && ref < n_ref) {
-        bool ok = true;
-        for (int32_t r = 0; ok && r <= ref; r++) {
-            int32_t n_bin = 0, n_intv = 0;
-            ok = rd(&n_bin, 4) && n_bin >= 0;
-            for (int32_t b = 0; ok && b < n_bin; b++) {
-                uint32_t bin;
-                int32_t n_chunk = 0;
-                ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0 && fseeko(f, (off_t)n_chunk * 16, SEEK_CUR) == 0;
-            }
-            ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+    bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && ref < n_ref;
+    for (int32_t r = 0; ok && r <= ref; r++) {
+        int32_t n_bin = 0, n_intv = 0;
+        ok = rd(&n_bin, 4) && n_bin >= 0;
+        for (int32_t b = 0; ok && b < n_bin; b++) {
+            uint32_t bin;
+            int32_t n_chunk = 0;
+            ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0;
             if (!ok) break;
-            if (r < ref) { ok = fseeko(f, (off_t)n_intv * 8, SEEK_CUR) == 0; continue; }
-            // the interval's own offset, or the next non-empty one (an interval no alignment overlaps holds 0 in some writers)
-            const int32_t first = std::min<int32_t>(pos0 >> 14, n_intv);
-            if (fseeko(f, (off_t)first * 8, SEEK_CUR) != 0) break;
-            for (int32_t i = first; i < n_intv; i++) {
-                uint64_t v = 0;
-                if (!rd(&v, 8)) break;
-                if (v != 0) { result = v; break; }
+            if (r == ref && bin < 37449 && overlaps(bin)) {   // (bin 37450 is samtools' pseudo-bin of counts)
+                for (int32_t c = 0; ok && c < n_chunk; c++) {
+                    uint64_t v[2];
+                    ok = rd(v, 16);
+                    if (ok) chunks.emplace_back(v[0], v[1]);
+                }
+            } else {
+                ok = fseeko(f, (off_t)n_chunk * 16, SEEK_CUR) == 0;
             }
+        }
+        ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+        if (!ok) break;
+        if (r < ref) { ok = fseeko(f, (off_t)n_intv * 8, SEEK_CUR) == 0; continue; }
+        const int32_t first = std::min<int32_t>(beg0 >> 14, n_intv);
+        if (fseeko(f, (off_t)first * 8, SEEK_CUR) != 0) { ok = false; break; }
+        for (int32_t i = first; i < n_intv; i++) {
+            uint64_t v = 0;
+            if (!rd(&v, 8)) break;
+            if (v != 0) { linear = v; break; }
         }
     }
     fclose(f);
-    return result;
+    if (!ok) return 0;
+    uint64_t best = 0;
+    bool have = false;
+    for (auto &c : chunks) {
+        if (c.second <= linear) continue;            // ends before anything the window can need
+        const uint64_t at = std::max(c.first, linear);
+        if (!have || at < best) { best = at; have = true; }
+    }
+    return have ? best : linear;
 }
 
 struct Base { int32_t u, bq; };
@@ -221,6 +258,19 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
     for (int32_t t = 1; t < nSNPs; t++) if (L[t] <= L[t - 1]) return QA_ERR_INVALID;
     qa_bam_opts_t o;
     if (opts) o = *opts; else qa_bam_opts_default(&o);
+    {   // CRAM (cramlist + reference, quilt.R:106-108): not decoded here -- say so, with the way round it
+        FILE *fc = fopen(bam_path, "rb");
+        char m4[4] = {0, 0, 0, 0};
+        const bool cram = fc && fread(m4, 1, 4, fc) == 4 && memcmp(m4, "CRAM", 4) == 0;
+        if (fc) fclose(fc);
+        if (cram) {
+            qa::set_error("%s is a CRAM file: qa_bam_load_sample_reads reads BAM only.  Convert it first -- "
+                          "`samtools view -b -T <reference.fa> -o sample.bam sample.cram && samtools index sample.bam` -- "
+                          "(the reference reads CRAM through STITCH / htslib given `reference`; test-acceptance-cram.R makes its "
+                          "CRAMs with the inverse command)", bam_path);
+            return QA_ERR_UNSUPPORTED;
+        }
+    }
     BgzfReader bz(bam_path);
     if (bz.bad) return QA_ERR_INVALID;
     char magic[4];
@@ -240,10 +290,11 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
     }
     if (target < 0) return QA_ERR_INVALID;
     // A coordinate-sorted file with a BAI index next to it (<file>.bai or <file without .bam>.bai): start at the linear
-    // index's offset for the window's first 16 kb interval -- the first alignment overlapping it (SAM spec 5.1.3) -- instead
-    // of scanning from the top of a whole-genome file.  Any problem with the index just means the sequential scan.
+    // index's offset for the window's first 16 kb interval -- the first alignment overlapping it (SAM spec 5.1.3) --, tightened
+    // by the bin index's chunks (bai_start_offset), instead of scanning from the top of a whole-genome file.  Any problem with the index just means the sequential scan.
     if (sorted) {
-        const uint64_t voff = bai_linear_offset(bam_path, target, o.chrStart > 0 ? o.chrStart - 1 : 0);
+        const uint64_t voff = bai_start_offset(bam_path, target, o.chrStart > 0 ? o.chrStart - 1 : 0,
+                                               o.chrEnd > 0 ? o.chrEnd : INT32_MAX);
         if (voff != 0 && !bz.seek_virtual(voff)) return QA_ERR_INVALID;
     }
 

@@ -45,7 +45,15 @@ def _io_lib():
 
 def _check(st: int, what: str):
     if st < 0:
-        raise QuiltAmdError(st, what)
+        detail = ""
+        if st == -3:   # QA_ERR_UNSUPPORTED carries the library's explanation (e.g. CRAM input and how to convert it)
+            try:
+                lb = _io_lib()
+                lb.qa_last_error.restype = C.c_char_p
+                detail = ": " + lb.qa_last_error().decode()
+            except Exception:
+                pass
+        raise QuiltAmdError(st, what + detail)
 
 
 def accumulate_dosage(hap: np.ndarray, chain_sample: np.ndarray, dosage: np.ndarray, gp_t: np.ndarray,

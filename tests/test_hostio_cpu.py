@@ -434,3 +434,49 @@ def test_synthetic_bam_generator_round_trip(tmp_path):
         key = lambda x: sorted((tuple(x.u[x.read_ptr[r]:x.read_ptr[r + 1]]), tuple(x.bq[x.read_ptr[r]:x.read_ptr[r + 1]]))
                                for r in range(x.nReads))
         assert g.nReads == s.nReads and key(g) == key(s) and np.array_equal(g.wif, np.sort(s.wif))
+
+
+def _reads_of(s):
+    return [dict(u=s.u[s.read_ptr[r]:s.read_ptr[r + 1]].tolist(), bq=s.bq[s.read_ptr[r]:s.read_ptr[r + 1]].tolist())
+            for r in range(s.nReads)]
+
+
+def test_sam_spec_example_bam_from_an_independent_encoder():
+    """tests/golden/sam_spec_example.bam: the example alignment of the SAM specification (section 1.1), encoded byte by byte
+    from the spec's tables by tests/golden/make_sam_spec_bam.py -- not by tests/bamutil.py -- with records straddling 96-byte
+    BGZF blocks, I / D / N / P / S / H operations, a supplementary line, auxiliary fields and a multi-bin BAI.  The expected
+    pile-up was worked out by hand from the spec's picture (comments in the generator)."""
+    import gzip
+    import json
+    from quilt_amd.io import loadBamAndConvert
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    bam = os.path.join(gold, "sam_spec_example.bam")
+    z = json.load(open(os.path.join(gold, "sam_spec_example.json")))
+    raw = gzip.open(bam, "rb").read()        # python's gzip reads the BGZF members as one multi-member stream
+    assert raw[:4] == b"BAM\x01" and len(raw) == z["stream_bytes"] and z["n_bgzf_blocks"] > 6
+    L, ref, alt = np.array(z["sites"]["L"], dtype=np.int32), list(z["sites"]["ref"]), list(z["sites"]["alt"])
+    want = lambda key: [dict(u=e["u"], bq=e["bq"]) for e in z["expect"][key]]
+    s, st = loadBamAndConvert(bam, "ref", L, ref, alt, downsampleToCov=0, return_stats=True)
+    assert _reads_of(s) == want("default")
+    e = z["expect"]["stats_default"]
+    assert (st["alignments_on_chr"], st["used"], st["flagged"], st["mates_merged"]) == (e["seen"], e["used"], e["by_flags"], e["mates_merged"])
+    assert _reads_of(loadBamAndConvert(bam, "ref", L, ref, alt, downsampleToCov=0, useSoftClippedBases=True)) == want("soft_clips")
+    assert _reads_of(loadBamAndConvert(bam, "ref", L, ref, alt, downsampleToCov=0, chrStart=30, chrEnd=45)) == want("window_30_45")
+    # the long reference: whole, and windows entered through the index (bins + linear index) -- the same reads as a scan
+    b = z["expect"]["big"]
+    Lb = np.array(b["L"], dtype=np.int32)
+    assert _reads_of(loadBamAndConvert(bam, "big", Lb, list(b["ref"]), list(b["alt"]), downsampleToCov=0)) == b["whole"]
+    for lo, hi, key in ((39000, 41000, "window_39000_41000"), (16384, 17000, "window_16384_17000")):
+        got = loadBamAndConvert(bam, "big", Lb, list(b["ref"]), list(b["alt"]), downsampleToCov=0, chrStart=lo, chrEnd=hi)
+        assert _reads_of(got) == b[key], key
+
+
+def test_cram_is_refused_with_a_recipe(tmp_path):
+    """cramlist (quilt.R:106-108): CRAM is not decoded; the loader says so and how to convert (no silent empty sample)."""
+    from quilt_amd.io import loadBamAndConvert
+    from quilt_amd.native import QuiltAmdError
+    p = str(tmp_path / "x.cram")
+    open(p, "wb").write(b"CRAM\x03\x00" + b"\0" * 64)
+    with pytest.raises(QuiltAmdError) as ei:
+        loadBamAndConvert(p, "chr20", np.array([10, 20], dtype=np.int32), list("AA"), list("CC"))
+    assert "samtools view -b" in str(ei.value) and "status -3" in str(ei.value)
