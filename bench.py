@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; 6.3 TB/s is what a streaming copy achieves)
 _CPU_PANEL = None
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 WORKLOADS = {
     "short": "BASELINE.json configs[2] (the K=50k configuration the metric is quoted on), per-GPU share",
