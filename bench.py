@@ -136,7 +136,7 @@ def reload_from_bams(panel, flat, seeds, bam_dir):
     return out, (time.perf_counter() - t0) / max(len(flat), 1)
 
 
-def cpu_baseline(panel, n_reads, params, full_chains, ff=0.0):
+def cpu_baseline(panel, n_reads, params, full_chains, ff=0.0, mspbwt=False):
     """CPU baseline on a BOUNDED SAMPLE (no whole sample is imputed on the CPU: one costs ~20 core-minutes): every
     physical host core (one synthetic sample each, mirroring the reference's mclapply sharding, quilt.R:691-692) runs ONE
     small-panel Gibbs call, ONE thin full-panel pass and ONE dosage full-panel pass on the fp64 oracle; a sample costs
@@ -161,6 +161,8 @@ def cpu_baseline(panel, n_reads, params, full_chains, ff=0.0):
     n_lab = 3 if ff > 0 else 2   # one full-panel pass per read label and Gibbs call (impute_using_everything)
     def per_sample(t):
         tg, tt, td = t
+        if mspbwt:   # use_mspbwt = TRUE: no full-panel pass; the indexed query of the reference costs milliseconds: priced at 0
+            return n_calls * tg
         return n_calls * tg + n_lab * (n_calls - full_chains) * tt + n_lab * full_chains * td
     ps_mean, ps_max = per_sample(times.mean(axis=0)), per_sample(times.max(axis=0))
     tg, tt, td = times.mean(axis=0)
@@ -171,6 +173,12 @@ def cpu_baseline(panel, n_reads, params, full_chains, ff=0.0):
                       f"concurrently; per-sample cost = {n_calls} Gibbs calls + {n_lab * (n_calls - full_chains)} thin + "
                       f"{n_lab * full_chains} dosage passes = {ps_mean:.1f} s/core mean ({ps_max:.1f} s slowest core); "
                       f"{wall:.0f} s of wall time")
+    if mspbwt:
+        out["sample"] = (f"bounded sample, composed (not a whole-sample run): per physical core 1 Gibbs call ({tg:.2f} s mean) of one "
+                         f"synthetic sample, all {cores} cores concurrently; use_mspbwt = TRUE: per-sample cost = {n_calls} Gibbs calls "
+                         f"= {ps_mean:.1f} s/core mean ({ps_max:.1f} s slowest core); the msPBWT queries between them (milliseconds "
+                         f"each with the reference's index) are priced at 0, so this baseline is faster than the reference; "
+                         f"{wall:.0f} s of wall time")
     return out, keep
 
 
@@ -229,7 +237,8 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per sample (default 20000; 300 with --mode ont)")
     ap.add_argument("--mode", choices=["short", "ont", "nipt"], default="short",
                     help="read model (ont: BASELINE configs[3]; nipt: configs[4], method = nipt with ff = 0.2)")
-    ap.add_argument("--workers", type=int, default=3, help="host threads per GPU (each with its own stream and arena)")
+    ap.add_argument("--workers", type=int, default=None,
+                    help="host threads per GPU (each with its own stream); default 3, 4 with --mspbwt (measured: DESIGN.md 5)")
     ap.add_argument("--rare-common", type=float, default=0.0, metavar="F",
                     help="impute_rare_common with F x nsnps rare SNPs: every Gibbs sample ends with a Gibbs call over all SNPs "
                          "(QUILT2; not the headline workload, no CPU baseline)")
@@ -259,7 +268,12 @@ def main():
                          "Gibbs call's haploid dosages against the panel (device search, csrc/match.hip); no CPU baseline")
     ap.add_argument("--cu-partition", action="store_true",
                     help="confine each host thread's Gibbs launches to its own half of the CUs (measured slower, DESIGN.md 5)")
+    ap.add_argument("--gate-trace", default=None, metavar="NPY",
+                    help="write the device gate's hold trace of the (first) timed region (request, admit, kernels done, release, "
+                         "SIMD slots, thread) to this .npy file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scan-check", action="store_true",
+                    help="--mspbwt: skip the comparison of the device search with the msPBWT neighbour scan (CPU, ~20 s)")
     ap.add_argument("--r2-vs-cpu", type=int, default=1, metavar="N",
                     help="also impute the first N samples of the last batch with the whole pipeline on the CPU oracle (its chains on "
                          "a thread pool: about a minute per sample on a many-core host; before any HIP context exists, rank 0 at "
@@ -279,6 +293,8 @@ def main():
     # the native calls' own host threads (per-chain tables, validation): the machine's cores divided between the ranks of this
     # node and the host threads of each rank, so that 8 ranks x 4 threads do not start 16 helpers each at the same moment
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if a.workers is None:
+        a.workers = 4 if a.mspbwt else 3
     os.environ.setdefault("QA_HOST_THREADS", str(max(2, (os.cpu_count() or 16) // max(1, local_world * a.workers))))
     params = dict(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
     full_chains = params["nGibbsSamples"] + 1
@@ -296,7 +312,6 @@ def main():
         params["impute_rare_common"] = True
     if a.mspbwt:
         params["use_mspbwt"] = True
-        a.no_cpu_baseline = True
     cpu, keep = None, None
     # The CPU legs run on rank 0 while the host cores are otherwise idle and before any HIP context exists in this process
     # (they fork / start threads).  With several ranks the others wait for rank 0, so that the baseline is measured "in the
@@ -306,7 +321,7 @@ def main():
     if world > 1 and not a.stub:
         cpu_flag = f"/tmp/quilt_amd_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.cpu_done"
     if rank == 0 and not a.no_cpu_baseline and rc is None and not a.stub:
-        cpu, keep = cpu_baseline(panel, a.reads, params, full_chains, ff=ff)
+        cpu, keep = cpu_baseline(panel, a.reads, params, full_chains, ff=ff, mspbwt=a.mspbwt)
     if cpu_flag is not None:
         if rank == 0:
             open(cpu_flag, "w").close()
@@ -378,9 +393,12 @@ def main():
         if native is not None:
             native.lib().qa_profile_reset()
             native.gate_stats(local_rank, reset=True)
+            if a.gate_trace:
+                native.gate_trace(local_rank, on=True)
         drv.reset_timing()
         barrier()
         t0 = time.perf_counter()
+        t0_gate = time.monotonic() * 1e3   # (std::chrono::steady_clock on Linux: the gate trace's clock)
         last = None
         # the K timed steps are K whole batches: the driver pipelines consecutive batches (phasing rounds of one fused
         # with the main rounds of the next), and the pipeline is filled and drained inside the timed region
@@ -396,6 +414,11 @@ def main():
         if native is not None:
             reg["prof"] = read_profile(native)
             reg["gate"] = native.gate_stats(local_rank)
+            if a.gate_trace and rank == 0:
+                tr = native.gate_trace(local_rank, on=False)
+                if len(tr):
+                    np.save(a.gate_trace, np.column_stack([tr[:, :4] - t0_gate, tr[:, 4:]]))
+                a.gate_trace = None
         return reg
 
     main_reg = timed_region(a.warmup)
@@ -596,10 +619,37 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
     truth = (samples[-1][0].all_snp if rc is not None else samples[-1][0]).truth_haps[:2].sum(axis=0)
     out["dosage_r2_vs_truth_sample0"] = float(np.corrcoef(last[0].dosage, truth)[0, 1] ** 2)
     out["cpu_baseline"] = cpu
+    if a.mspbwt and fp64 and native is not None and not getattr(a, "no_scan_check", False):
+        out["mspbwt_search_vs_neighbour_scan"] = search_vs_scan(drv.devs[0], panel, params, last[0])
     if keep is not None:
         dev = drv.devs[0]
         out["parity_vs_cpu_path"] = parity_vs_cpu(dev, panel, a.reads, params, ff, keep)
     return out
+
+
+def search_vs_scan(dev, panel, params, res):
+    """use_mspbwt = TRUE: the device search's definition of a good match (csrc/match.hip: every haplotype's longest run, the
+    longest first) against the restated msPBWT neighbour scan (tests/mspbwt_scan.py; the mspbwt package is not in the reference
+    tree, so parity with it is unpinned), on the two phased haplotypes of one result of the last batch."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.mspbwt import find_good_matches, int_contract_rows, match_tables_as_lists
+    from tests.mspbwt_scan import find_good_matches_scan, selection_agreement
+    P = DriverParams(**params)
+    Zs = int_contract_rows(np.ascontiguousarray(res.phasing_haps.T[:2], dtype=np.float64))
+    n_max = P.mspbwt_max_matches or 50 * P.mspbwtL
+    t0 = time.perf_counter()
+    got = match_tables_as_lists(*find_good_matches(dev, Zs, P.mspbwt_nindices, P.mspbwtM, n_max))
+    t1 = time.perf_counter()
+    scan = find_good_matches_scan(panel, Zs, P.mspbwt_nindices, P.mspbwtL, P.mspbwtM)
+    t2 = time.perf_counter()
+    agree = selection_agreement(scan, got, P.Knew, panel.K, panel.nGrids)
+    return dict(what="the next small panel (select_new_haps_mspbwt_v3, Knew haplotypes) chosen from the device search and from the "
+                     "restated msPBWT neighbour scan (mspbwtL up and down per grid, tests/mspbwt_scan.py) for the two phased "
+                     "haplotypes of sample 0 of the last batch: `selected` = share chosen by both; `longest` = share of the scan's "
+                     "Knew longest-matching haplotypes the device search reports at all; `length` = the same weighted by match "
+                     "length.  Parity with the mspbwt package itself is unpinned (not in the reference tree)",
+                **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in agree.items()},
+                device_search_ms=round((t1 - t0) * 1e3, 1), scan_cpu_s=round(t2 - t1, 1))
 
 
 def cpu_pipeline_reference(a, panel, params, samples):

@@ -151,11 +151,13 @@ int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits);
 int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers);
 
 /* Device phases.  on = 1: the launch sets of this handle take the device in arrival order together with those of the other
- * handles that opted in (strictly first come, first served).  The full-panel passes of a call (one workgroup per compute
+ * handles that opted in (first come, first served; only the short haplotype searches of qa_find_good_matches go before the
+ * queued launch sets).  The full-panel passes of a call (one workgroup per compute
  * unit) hold the device EXCLUSIVELY; the kernels of a Gibbs call hold one SIMD slot per wave (of 1 024), so Gibbs launches
  * that fit together run together -- the 128 phasing chains of one batch beside the 896 main chains of another -- and one
- * that does not fit waits for the phase to end.  All of them carve their scratch from ONE device-wide arena instead of the
- * handle's 1 / n_sharers part, so a Gibbs launch carries up to one chain per SIMD and a full-panel launch one pass per
+ * that does not fit waits for the phase to end.  All of them carve their scratch from ONE device-wide arena (allocated once,
+ * at 88 % of the device's free memory; freed when the last handle that opted in is destroyed) instead of the handle's
+ * 1 / n_sharers part, so a Gibbs launch carries up to one chain per SIMD and a full-panel launch one pass per
  * compute unit (256) whatever the number of host threads.  The host-side parts of the calls (validation, tables,
  * marshalling) stay outside the queue: with 3-4 host threads per device they overlap the other threads' device phases.
  * Both kinds of launch sets are HBM-bound when they fill the chip, so nothing is lost by not overlapping them; measured
@@ -165,6 +167,13 @@ int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers);
 int qa_panel_set_exclusive(qa_panel_t *panel, int32_t on);
 int qa_gate_stats(int32_t device, double out[7]);
 int qa_gate_stats_reset(int32_t device);
+/* Diagnostics: switch the gate's hold trace on / off and read it.  Returns the number of rows recorded so far (>= 0) and copies
+ * up to cap_rows of them -- request, admit, kernels done, release [ms on one clock], SIMD slots (0: exclusive), thread --
+ * then clears the trace (a call with rows == NULL and on != 0 only switches it on). */
+int qa_gate_trace(int32_t device, int32_t on, double *rows, int32_t cap_rows);
+/* Diagnostics: the gate's admission rules (co-running Gibbs launches, first come first served, express holds first) on a gate
+ * of its own; no device is touched.  QA_OK, or QA_ERR_INVALID with the failed rule in qa_last_error(). */
+int qa_gate_selftest(void);
 
 /* With several handles sharing a device: confine this handle's Gibbs launches to CUs [index, index + 1) * n_CU / count
  * (a CU-masked HIP stream).  A Gibbs chain holds a SIMD's whole register file for ~0.7 s; spread over every CU, one
@@ -367,6 +376,13 @@ typedef struct {
      * the queries qa_find_good_matches takes.  With it hapProbs_t itself need not cross PCIe on the rounds whose dosages are
      * not accumulated.  NULL: not produced. */
     int32_t *hap_words_out;
+    /* NULL, or an OUTPUT of n_chain x hap_major_labels x nSNPs doubles: the call's haploid dosages (rows of hapProbs_t) label by
+     * label, the layout qa_fullpass_reads_batch returns dosages in and qa_accumulate_dosage / qa_rcpp_make_eMatRead_t_hap_major
+     * take -- use_mspbwt = TRUE keeps the Gibbs call's dosages (functions.R:839-843), so a round's 1 GB goes from the device
+     * into the caller's buffer in that form (directly when the buffer comes from qa_host_alloc) instead of being transposed
+     * chain by chain on the host.  hap_major_labels: 2 or 3. */
+    double *hap_major_out;
+    int32_t hap_major_labels;
 } qa_gibbs_opts_t;
 
 /*

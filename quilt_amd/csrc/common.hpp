@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <condition_variable>
+#include <deque>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -294,24 +297,35 @@ struct Arena {
     }
 };
 
-// Device phases (qa_panel_set_exclusive): the launch sets of the handles that opted in take the device in arrival order.
+// Device phases (qa_panel_set_exclusive): the launch sets of the handles that opted in take the device in turn.
 //   * a full-panel launch set (one workgroup per compute unit) holds it EXCLUSIVELY;
 //   * Gibbs launches (one wave per chain, a SIMD each) hold as many of the 1 024 SIMD slots as they have waves: launches
 //     that fit together run together (the 128 phasing chains of one batch beside the 896 main chains of another), a launch
 //     that does not fit waits for the phase to end.
-// Admission is strictly first come, first served (no bypassing: a waiting full-panel set is never overtaken by later Gibbs
-// launches).  Why: both kinds of launch sets are bound by the same HBM stream when they fill the chip, so overlapping them
-// gains nothing, while a full-panel workgroup needs a whole compute unit and used to wait for one while another thread's
-// Gibbs waves took the SIMDs one by one (62 against 11 ms per launch); and every thread sized its launches for
-// a fraction of the memory (512 chains / 200 passes instead of 1 024 / 256).  ONE scratch arena serves all holders: an
-// exclusive holder has all of it, Gibbs launches get disjoint slices.  The other host threads do their host-side work
-// (marshalling, the R-level logic between the native calls) meanwhile.
+// Admission is first come, first served, with one exception: EXPRESS holds (short exclusive jobs: the haplotype search of
+// the msPBWT mode, tens of ms) go before the queued launch sets.  Without it a thread's search waited behind every other
+// thread's second-long Gibbs launch, all threads finished their rounds together and did their host work together with the
+// device idle (27 % of the use_mspbwt bench).  Whoever is next blocks everyone behind it (a waiting
+// full-panel set is never overtaken by later Gibbs launches).  Why phases at all: both kinds of launch sets are bound by
+// the same HBM stream when they fill the chip, so overlapping them gains nothing, while a full-panel workgroup needs a
+// whole compute unit and used to wait for one while another thread's Gibbs waves took the SIMDs one by one (62 against
+// 11 ms per launch); and every thread sized its launches for a fraction of the memory (512 chains / 200 passes instead of
+// 1 024 / 256).  ONE scratch arena serves all holders: an exclusive holder has all of it, Gibbs launches get disjoint
+// slices; it is allocated once, at the size the launch sets are planned against (Arena::budget), so that no launch set
+// of a later, larger shape has to re-allocate it (a 7 s stall when that happened inside a timed region).  The other host
+// threads do their host-side work (marshalling, the R-level logic between the native calls) meanwhile.
 struct DeviceGate {
     static constexpr int kSlots = 1024;   // SIMDs of the device (256 CUs x 4)
+    struct Waiter {
+        int slots = 0;
+        size_t need = 0, offset = 0;
+        bool exclusive = false, express = false, admitted = false, failed = false;
+        std::string error;
+    };
     std::mutex mu;
     std::condition_variable cv;
-    uint64_t next_ticket = 0, head = 0;
-    int active = 0, used_slots = 0;
+    std::deque<Waiter *> queue;
+    int active = 0, used_slots = 0, users = 0;
     bool active_exclusive = false;
     size_t bump = 0;          // bytes of the arena handed to the Gibbs launches of the running phase
     Arena arena;
@@ -321,8 +335,55 @@ struct DeviceGate {
     double slot_ms = 0;       // sum over Gibbs holds of (SIMD slots x duration): / (held_ms - excl_ms) = mean slots in use
     double t_busy_from = 0;
     uint64_t n_holds = 0, n_shared = 0, slots_total = 0;
+    // qa_gate_trace: one row per finished hold -- request, admit, mark (the holder's GateHold::mark(), e.g. its last
+    // kernel done), release [ms, one clock], SIMD slots (0: exclusive), holder's thread
+    bool tracing = false;
+    std::vector<std::array<double, 6>> trace;
+
+    // the whole planning budget at once (see above); called with `mu` held, by a thread whose current device is the gate's
+    void grow_arena(size_t need) {
+        if (need <= arena.cap) return;
+        const size_t all = arena.budget();
+        arena.require(std::max(need, all));
+    }
+    // admit whoever can go now (with `mu` held)
+    void pump(double now) {
+        for (;;) {
+            if (queue.empty()) return;
+            auto it = queue.begin();
+            for (auto e = queue.begin(); e != queue.end(); ++e)
+                if ((*e)->express) { it = e; break; }
+            Waiter *w = *it;
+            if (w->exclusive) {
+                if (active != 0) return;
+                active_exclusive = true;
+            } else {
+                if (active_exclusive || used_slots + w->slots > kSlots) return;
+                if (active != 0 && bump + w->need > arena.cap) return;   // (the first holder of a phase may grow the arena)
+                if (active == 0) {
+                    try {
+                        grow_arena(w->need);
+                    } catch (const std::exception &e) {   // its acquire() reports it; the others go on
+                        w->failed = w->admitted = true;
+                        w->error = e.what();
+                        queue.erase(it);
+                        continue;
+                    }
+                    bump = 0;
+                }
+                w->offset = bump;
+                bump += w->need;
+                used_slots += w->slots;
+            }
+            if (active == 0) t_busy_from = now;
+            active++;
+            w->admitted = true;
+            queue.erase(it);
+        }
+    }
 };
 DeviceGate &device_gate(int device);
+void gate_user(int device, int delta);
 
 // RAII hold of the device (or of `slots` SIMD slots of it) with the scratch arena that goes with it.  Without a gate (a
 // handle that did not opt in) the hold is a no-op around the handle's own arena.
@@ -332,50 +393,56 @@ struct GateHold {
     Arena view;               // slice of the gate's arena (shared holds)
     int slots = 0;
     bool exclusive = false;
-    double queued_ms = 0, t_in = 0;
+    double queued_ms = 0, t_in = 0, t_mark = 0;
     static double now_ms();
+    void mark() { if (g && g->tracing) t_mark = now_ms(); }
     GateHold() = default;
     GateHold(const GateHold &) = delete;
     GateHold &operator=(const GateHold &) = delete;
     ~GateHold() { release(); }
-    // slots_ == 0: the whole device and the whole arena (which the holder may grow); else `slots_` SIMD slots and `bytes` of arena
-    void acquire(DeviceGate *gate, Arena *own_arena, int slots_ = 0, size_t bytes = 0) {
+    // slots_ == 0: the whole device and the whole arena (which the holder may grow); else `slots_` SIMD slots and `bytes` of
+    // arena.  express: a short exclusive job that goes before the queued launch sets.
+    void acquire(DeviceGate *gate, Arena *own_arena, int slots_ = 0, size_t bytes = 0, bool express = false) {
         own = own_arena;
         if (!gate || g) return;
         const double t0 = now_ms();
         slots = std::min(slots_, (int)DeviceGate::kSlots);
         exclusive = slots == 0;
-        const size_t need = (bytes + 4095) & ~size_t(4095);
+        DeviceGate::Waiter w;
+        w.slots = slots;
+        w.need = (bytes + 4095) & ~size_t(4095);
+        w.exclusive = exclusive;
+        w.express = express && exclusive;
         std::unique_lock<std::mutex> lk(gate->mu);
-        const uint64_t mine = gate->next_ticket++;
-        gate->cv.wait(lk, [&] {
-            if (gate->head != mine) return false;
-            if (exclusive) return gate->active == 0;
-            if (gate->active_exclusive || gate->used_slots + slots > DeviceGate::kSlots) return false;
-            return gate->active == 0 || gate->bump + need <= gate->arena.cap;   // (the first holder of a phase may grow the arena)
-        });
-        gate->head++;
-        if (gate->active == 0) gate->t_busy_from = now_ms();
-        gate->active++;
-        if (exclusive) {
-            gate->active_exclusive = true;
-        } else {
-            if (gate->active == 1) { gate->arena.require(need); gate->bump = 0; }
-            view.base = gate->arena.base + gate->bump;
-            view.cap = need;
+        gate->queue.push_back(&w);
+        gate->pump(t0);
+        if (!w.admitted) gate->cv.wait(lk, [&] { return w.admitted; });
+        if (w.failed) {
+            lk.unlock();
+            gate->cv.notify_all();
+            throw std::runtime_error("device arena: " + w.error);
+        }
+        if (!exclusive) {
+            view.base = gate->arena.base + w.offset;
+            view.cap = w.need;
             view.off = 0;
             view.owned = false;
-            gate->bump += need;
-            gate->used_slots += slots;
         }
         g = gate;
         t_in = now_ms();
         queued_ms = t_in - t0;
         gate->wait_ms += queued_ms;
-        lk.unlock();
-        gate->cv.notify_all();   // the next in line may fit beside this one
     }
     Arena &arena() { return g ? (exclusive ? g->arena : view) : *own; }
+    // at least `bytes` of arena for this hold (an exclusive holder grows the device-wide arena: to the planning budget)
+    void require(size_t bytes) {
+        if (g && exclusive) {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->grow_arena(bytes);
+        } else {
+            arena().require(bytes);
+        }
+    }
     void release() {
         if (!g) return;
         {
@@ -387,6 +454,10 @@ struct GateHold {
             if (exclusive) g->excl_ms += t_out - t_in;
             else { g->slot_ms += (double)slots * (t_out - t_in); g->n_shared++; g->slots_total += (uint64_t)slots; }
             g->n_holds++;
+            if (g->tracing && g->trace.size() < (1u << 20))
+                g->trace.push_back({t_in - queued_ms, t_in, t_mark ? t_mark : t_out, t_out, (double)slots,
+                                    (double)(std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xffffff)});
+            g->pump(t_out);
         }
         g->cv.notify_all();
         g = nullptr;

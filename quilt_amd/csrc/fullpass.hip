@@ -873,7 +873,7 @@ int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
         return std::max(prop.multiProcessorCount, 1);
     }();
     if (n < remaining && n > n_cu) n = n / n_cu * n_cu;
-    pn->A().require(fixed + (size_t)n * per_pass);
+    pn->require_scratch(fixed + (size_t)n * per_pass);
     pn->A().reset();
     return (int)n;
 }
@@ -1715,10 +1715,14 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
             hipEvent_t e0, e1;
             QA_HIP(hipEventCreate(&e0)); QA_HIP(hipEventCreate(&e1));
             QA_HIP(hipEventRecord(e0, st));
-            qa::launch_select(sp, n_chain, st);
+            const bool launched = qa::launch_select(sp, n_chain, st);
             QA_HIP(hipEventRecord(e1, st));
-            d_next.download(sel->which_next, (size_t)n_chain * sel->Ksubset, st);
-            d_stat.download(sel->status, n_chain, st);
+            if (launched) {
+                d_next.download(sel->which_next, (size_t)n_chain * sel->Ksubset, st);
+                d_stat.download(sel->status, n_chain, st);
+            } else {   // tables beyond the LDS: every chain is left to the caller's host path
+                for (int c = 0; c < n_chain; c++) sel->status[c] = want[c] ? 1 : -1;
+            }
             QA_HIP(hipStreamSynchronize(st));
             float ms = 0;
             QA_HIP(hipEventElapsedTime(&ms, e0, e1));

@@ -185,7 +185,7 @@ struct SelectParams {
     int32_t *status;         // [chain]: 0 selected; 1 ranks exhausted before Knew were found (host path); -1 not wanted
 };
 size_t select_lds_bytes(const SelectParams &p);
-void launch_select(const SelectParams &p, int n_chain, hipStream_t st);
+bool launch_select(const SelectParams &p, int n_chain, hipStream_t st);
 void launch_scatter_lists(const int32_t *src_idx, const int32_t *src_cnt, const int32_t *rows, int n, int n_thin, int top_cap,
                           int32_t *dst_idx, int32_t *dst_cnt, hipStream_t st);
 }  // namespace qa

@@ -651,25 +651,42 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
     const int b = threadIdx.x & 31, part = threadIdx.x >> 5;
     __shared__ double s_g[3][8][32], s_t[3][8];
     __shared__ uint32_t s_w[1024];
+    __shared__ double s_gk[3][1024];
     const int Ks = p.Ks, Ksp = p.Ksp, G = p.G;
     const int32_t *which = p.which + (size_t)c * Ks;
+    const size_t mat = (size_t)G * Ksp;
+    // gamma once per (label, haplotype), read with consecutive lanes on consecutive haplotypes (it used to be re-formed by
+    // each of the 32 bit lanes from broadcast loads: 70 ms per launch, load-issue bound); the sums below keep their order
     for (int k = threadIdx.x; k < Ks; k += 256) {
         const int kk = which[k];
         s_w[k] = panel_word(p, g, kk, p.hm[(size_t)g * p.Kp + kk]);
+        for (int h = 0; h < p.nH; h++) {
+            const size_t o = ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp + k;
+            const double x = 1 / p.cvec[((size_t)c * 3 + h) * G + g];
+            s_gk[h][k] = (p.alpha[o] * p.beta[o]) * x;
+        }
     }
     __syncthreads();
     const int s = 32 * g, nLocal = min(32, p.T - s);
-    const size_t mat = (size_t)G * Ksp;
     double acc[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
-    for (int h = 0; h < p.nH; h++) {
-        const double *a = p.alpha + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
-        const double *be = p.beta + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
-        const double x = 1 / p.cvec[((size_t)c * 3 + h) * G + g];
+    if (p.nH == 2) {
         for (int k = part; k < Ks; k += 8) {
-            const double gk = (a[k] * be[k]) * x;
-            tot[h] += gk;
-            if ((s_w[k] >> b) & 1u) acc[h] += gk;
+            const bool on = (s_w[k] >> b) & 1u;
+            const double g0 = s_gk[0][k], g1 = s_gk[1][k];
+            tot[0] += g0; tot[1] += g1;
+            if (on) { acc[0] += g0; acc[1] += g1; }
         }
+    } else {
+        for (int k = part; k < Ks; k += 8) {
+            const bool on = (s_w[k] >> b) & 1u;
+            for (int h = 0; h < p.nH; h++) {
+                const double gk = s_gk[h][k];
+                tot[h] += gk;
+                if (on) acc[h] += gk;
+            }
+        }
+    }
+    for (int h = 0; h < p.nH; h++) {
         s_g[h][part][b] = acc[h];
         if (b == 0) s_t[h][part] = tot[h];
     }
@@ -849,6 +866,13 @@ __global__ __launch_bounds__(256) void k_pack_hap_words(const double *hap, int T
         if (t < T && hap[((size_t)c * T + t) * 3 + h] > 0.5) w |= 1u << b;
     }
     words[((size_t)c * 3 + h) * G + g] = (int32_t)w;
+}
+
+// hap [C][T][3] -> out [C][nL][T] (haploid dosages label by label: qa_gibbs_opts_t.hap_major_out)
+__global__ __launch_bounds__(256) void k_hap_major(const double *hap, int T, int nL, double *out) {
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (t >= T) return;
+    for (int h = 0; h < nL; h++) out[((size_t)c * nL + h) * T + t] = hap[((size_t)c * T + t) * 3 + h];
 }
 
 }  // namespace
@@ -1177,7 +1201,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         S.er_tab.ensure(std::max<size_t>((size_t)totR * 64, 1));
         S.alpha.ensure(mat); S.beta.ensure(mat); S.eg.ensure(mat);
         S.cvec.ensure((size_t)C * 3 * G);
-        if (hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out) {
+        if (hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out || o->hap_major_out) {
             S.hap.ensure((size_t)C * T * 3); S.gm.ensure((size_t)C * T * 3); S.gf.ensure((size_t)C * T * 3);
         }
 
@@ -1218,7 +1242,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         }
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));
-        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out;
+        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out || o->hap_major_out;
         QA_HIP(hipStreamSynchronize(st));
         const double T2 = now();
         // NIPT: the sweeps are cut at the block-Gibbs iterations; between two segments the switch rate per grid boundary
@@ -1293,6 +1317,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         S.status.download(status.data(), C, st);
         QA_HIP(hipStreamSynchronize(st));
         const double T3 = now();
+        hold.mark();
         if (hapProbs_t) S.hap.download(hapProbs_t, (size_t)C * T * 3, st);
         if (o->hap_words_out) {   // (the genotype-probability buffers are free by now: the words are staged in S.gm)
             int32_t *d_words = reinterpret_cast<int32_t *>(S.gm.p);
@@ -1300,6 +1325,13 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
             QA_HIP(hipGetLastError());
             if (genProbsM_t) throw std::runtime_error("hap_words_out cannot be combined with genProbs outputs");
             qa::staged_download(o->hap_words_out + (size_t)per_it_off * 3 * G, d_words, sizeof(int32_t) * (size_t)C * 3 * G, st);
+        }
+        if (o->hap_major_out) {   // (staged in the free S.gf: label-major rows, then one transfer)
+            const int nL = o->hap_major_labels;
+            if (genProbsF_t || nL < 1 || nL > 3) throw std::runtime_error("hap_major_out: 1..3 labels, not combined with genProbs outputs");
+            hipLaunchKernelGGL(k_hap_major, dim3((T + 255) / 256, C), dim3(256), 0, st, S.hap.p, T, nL, S.gf.p);
+            QA_HIP(hipGetLastError());
+            qa::staged_download(o->hap_major_out + (size_t)per_it_off * nL * T, S.gf.p, sizeof(double) * (size_t)C * nL * T, st);
         }
         if (genProbsM_t) S.gm.download(genProbsM_t, (size_t)C * T * 3, st);
         if (genProbsF_t) S.gf.download(genProbsF_t, (size_t)C * T * 3, st);
@@ -1409,7 +1441,7 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
         const int G = rc ? rc->G_all : pn->G, T = rc ? rc->T_all : pn->T, Ks = o->Ks, Ksp = (Ks + 63) / 64 * 64;
         const int n_its = o->n_gibbs_burn_in_its + o->n_gibbs_sample_its;
         const int nb = o->n_block_gibbs_iterations;
-        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out;
+        const bool want_probs = hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out || o->hap_major_out;
         // chains are processed in chunks that fit the device arena (read emissions + 6 Ks x G state matrices each)
         std::vector<size_t> base_of(n_chain + 1, 0);
         for (int c = 0; c < n_chain; c++) {

@@ -515,6 +515,14 @@ int fmt_round5(char *p, double x) {
     return n;
 }
 inline int r_round_int(double x) { return (int)std::nearbyint(x); }   // half to even, as R's round(x)
+// what the column writers accept: posteriors, dosages and counts -- finite and of a magnitude whose fixed-point text has a known
+// width (so that no entry can outgrow its buffer); anything else is the caller's error, reported with the SNP
+inline bool printable(double x) { return std::isfinite(x) && std::fabs(x) <= 1e9; }
+inline bool bounded(double x) { return !std::isfinite(x) || std::fabs(x) <= 1e9; }   // NaN / Inf have their own short texts
+inline int bad_value(const char *fn, int32_t t, const char *what) {
+    qa::set_error("%s: %s at SNP %d is not finite (or beyond 1e9)", fn, what, (int)t);
+    return QA_ERR_INVALID;
+}
 
 struct Sink {
     char *buf;
@@ -550,6 +558,8 @@ int qa_vcf_column_diploid(int32_t T, const double *gp_t, const double *hd, int32
     for (int32_t t = 0; t < T; t++) {
         const double g0 = gp_t[3 * (size_t)t], g1 = gp_t[3 * (size_t)t + 1], g2 = gp_t[3 * (size_t)t + 2];
         const double h1 = hd[t], h2 = hd[(size_t)T + t];
+        if (!printable(g0) || !printable(g1) || !printable(g2)) return bad_value("qa_vcf_column_diploid", t, "a genotype posterior");
+        if (!printable(h1) || !printable(h2)) return bad_value("qa_vcf_column_diploid", t, "a haploid dosage");
         int n;
         if (phased_gt) {
             n = snprintf(e, sizeof e, "%d|%d", r_round_int(h1), r_round_int(h2));
@@ -558,7 +568,10 @@ int qa_vcf_column_diploid(int32_t T, const double *gp_t, const double *hd, int32
             memcpy(e, gt, 3);
             n = 3;
         }
-        n += snprintf(e + n, sizeof e - n, ":%.3f,%.3f,%.3f:%.3f:%.3f,%.3f", g0, g1, g2, g1 + 2 * g2, h1, h2);
+        // (six numbers of at most 14 characters each: well inside e[160])
+        const int m = snprintf(e + n, sizeof e - n, ":%.3f,%.3f,%.3f:%.3f:%.3f,%.3f", g0, g1, g2, g1 + 2 * g2, h1, h2);
+        if (m < 0 || m >= (int)sizeof e - n) return bad_value("qa_vcf_column_diploid", t, "an entry (too long)");
+        n += m;
         s.put(t, e, n);
     }
     return s.done(T, needed);
@@ -570,10 +583,15 @@ int qa_vcf_column_nipt(int32_t T, const double *m, const double *f, const double
     Sink s{buf, cap, 0, off};
     char e[320];
     for (int32_t t = 0; t < T; t++) {
-        int n = snprintf(e, sizeof e, "%d|%d|%d:", r_round_int(hd[t]), r_round_int(hd[(size_t)T + t]),
-                         r_round_int(hd[2 * (size_t)T + t]));
         const double v[8] = {m[3 * (size_t)t], m[3 * (size_t)t + 1], m[3 * (size_t)t + 2], mds[t],
                              f[3 * (size_t)t], f[3 * (size_t)t + 1], f[3 * (size_t)t + 2], fds[t]};
+        for (int i = 0; i < 3; i++)
+            if (!printable(hd[i * (size_t)T + t])) return bad_value("qa_vcf_column_nipt", t, "a haploid dosage");
+        for (int i = 0; i < 8; i++)
+            if (!bounded(v[i])) return bad_value("qa_vcf_column_nipt", t, "a posterior or dosage");
+        // (3 integers, then 8 numbers of at most 14 characters each: well inside e[320])
+        int n = snprintf(e, sizeof e, "%d|%d|%d:", r_round_int(hd[t]), r_round_int(hd[(size_t)T + t]),
+                         r_round_int(hd[2 * (size_t)T + t]));
         static const char sep[8] = {',', ',', ':', ':', ',', ',', ':', 0};
         for (int i = 0; i < 8; i++) {
             n += fmt_round3(e + n, v[i]);
@@ -592,6 +610,10 @@ int qa_vcf_info_column(int32_t T, const double *eaf, const double *info, const d
     char e[320];
     for (int32_t t = 0; t < T; t++) {
         int n = 0;
+        // (six fields of at most 16 characters each plus their keys: well inside e[320]; HWE may be any finite value)
+        const double chk[6] = {eaf[t], info[t], ac[t], ac[(size_t)T + t], ac[2 * (size_t)T + t], 0.0};
+        for (double x : chk)
+            if (!bounded(x)) return bad_value("qa_vcf_info_column", t, "EAF, INFO_SCORE or an allele count");
         memcpy(e + n, "EAF=", 4); n += 4; n += fmt_round5(e + n, eaf[t]);
         memcpy(e + n, ";INFO_SCORE=", 12); n += 12; n += fmt_round5(e + n, info[t]);
         // formatC(hwe, format = "e", digits = 2): C's %.2e (two-digit exponent at least)

@@ -145,11 +145,11 @@ int qa_find_good_matches(qa_panel_t *panel, int32_t n_query, const int32_t *Zs, 
         // queries in slabs that fit the handle's arena: per query G words + G symbols + 4 B per haplotype and index + results
         const size_t per_q = (size_t)G * 5 + (size_t)nindices * K * 4 + (size_t)nindices * (max_matches * 12 + 4) + 1024;
         qa::GateHold hold;
-        hold.acquire(panel->gate(), &panel->arena);
+        hold.acquire(panel->gate(), &panel->arena, 0, 0, /*express=*/true);
         qa::Arena &arena = hold.arena();
         const size_t budget = arena.budget_shared(panel->sharers());
         const int slab = (int)std::max<size_t>(1, std::min<size_t>(n_query, budget / per_q));
-        arena.require((size_t)slab * per_q + 4096);
+        hold.require((size_t)slab * per_q + 4096);
         for (int q0 = 0; q0 < n_query; q0 += slab) {
             const int nq = std::min(slab, n_query - q0);
             arena.reset();

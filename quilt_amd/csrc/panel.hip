@@ -42,6 +42,16 @@ DeviceGate &device_gate(int device) {
     static DeviceGate gates[16];
     return gates[device >= 0 && device < 16 ? device : 0];
 }
+// handles that opted in; the last one out frees the device-wide arena
+void gate_user(int device, int delta) {
+    DeviceGate &g = device_gate(device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.users += delta;
+    if (g.users <= 0 && g.active == 0 && g.queue.empty()) {
+        g.users = 0;
+        if (g.arena.base) { (void)hipFree(g.arena.base); g.arena.base = nullptr; g.arena.cap = g.arena.off = 0; }
+    }
+}
 double GateHold::now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -376,7 +386,15 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
     });
 }
 
-void qa_panel_destroy(qa_panel_t *panel) { delete panel; }
+void qa_panel_destroy(qa_panel_t *panel) {
+    if (panel && panel->exclusive) {
+        qa::drop_pass_scratch(panel);
+        panel->exclusive = false;
+        (void)hipSetDevice(panel->device);
+        qa::gate_user(panel->device, -1);
+    }
+    delete panel;
+}
 
 int qa_panel_set_device_share(qa_panel_t *panel, int32_t n_sharers) {
     if (!panel || n_sharers < 1 || n_sharers > 16) {
@@ -395,6 +413,7 @@ int qa_panel_set_exclusive(qa_panel_t *panel, int32_t on) {
     if ((on != 0) != panel->exclusive) {
         qa::drop_pass_scratch(panel);   // its buffers are views of the arena in use
         panel->exclusive = on != 0;
+        qa::gate_user(panel->device, on ? 1 : -1);
     }
     return QA_OK;
 }
@@ -414,6 +433,58 @@ int qa_gate_stats_reset(int32_t device) {
     std::lock_guard<std::mutex> lk(g.mu);
     g.held_ms = g.wait_ms = g.excl_ms = g.slot_ms = 0; g.n_holds = g.n_shared = g.slots_total = 0;
     return QA_OK;
+}
+
+// the admission rules on a gate of its own, without touching a device (no arena bytes are asked for)
+int qa_gate_selftest(void) {
+    return qa::guarded([&] {
+        qa::DeviceGate gate;
+        std::vector<int> order;
+        std::mutex om;
+        auto note = [&](int who) { std::lock_guard<std::mutex> lk(om); order.push_back(who); };
+        auto queued = [&](size_t n) {
+            for (int spin = 0; spin < 20000; spin++) {
+                { std::lock_guard<std::mutex> lk(gate.mu); if (gate.queue.size() >= n) return true; }
+                std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+            return false;
+        };
+        qa::Arena own;
+        qa::GateHold a;
+        a.acquire(&gate, &own, 600, 0);                 // a Gibbs launch on 600 SIMDs
+        qa::GateHold fits;
+        fits.acquire(&gate, &own, 400, 0);              // one that fits beside it: admitted at once
+        if (gate.active != 2 || gate.used_slots != 1000) throw std::runtime_error("gate selftest: co-running launches");
+        fits.release();
+        std::thread tb([&] { qa::GateHold h; h.acquire(&gate, &own, 1024, 0); note(2); });          // does not fit: waits
+        if (!queued(1)) throw std::runtime_error("gate selftest: queue");
+        std::thread tc([&] { qa::GateHold h; h.acquire(&gate, &own, 0, 0); note(3); });             // a full-panel set, behind it
+        if (!queued(2)) throw std::runtime_error("gate selftest: queue");
+        std::thread td([&] { qa::GateHold h; h.acquire(&gate, &own, 100, 0); note(4); });           // would fit now, but is not first
+        if (!queued(3)) throw std::runtime_error("gate selftest: queue");
+        std::thread te([&] { qa::GateHold h; h.acquire(&gate, &own, 0, 0, true); note(5); });       // express: before all of them
+        if (!queued(4)) throw std::runtime_error("gate selftest: queue");
+        if (gate.active != 1) throw std::runtime_error("gate selftest: a later launch overtook the queue");
+        a.release();
+        tb.join(); tc.join(); td.join(); te.join();
+        if (order != std::vector<int>{5, 2, 3, 4}) throw std::runtime_error("gate selftest: admission order");
+        if (gate.active != 0 || gate.used_slots != 0 || !gate.queue.empty() || gate.n_holds != 6)
+            throw std::runtime_error("gate selftest: bookkeeping");
+        return (int)QA_OK;
+    });
+}
+
+int qa_gate_trace(int32_t device, int32_t on, double *rows, int32_t cap_rows) {
+    if (device < 0 || device >= 16 || cap_rows < 0 || (cap_rows && !rows)) return QA_ERR_INVALID;
+    qa::DeviceGate &g = qa::device_gate(device);
+    std::lock_guard<std::mutex> lk(g.mu);
+    const int n = (int)std::min<size_t>(g.trace.size(), (size_t)cap_rows);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 6; j++) rows[(size_t)i * 6 + j] = g.trace[i][j];
+    const int total = (int)g.trace.size();
+    if (rows || !on) g.trace.clear();
+    g.tracing = on != 0;
+    return total;
 }
 
 int qa_panel_set_cu_partition(qa_panel_t *panel, int32_t index, int32_t count) {

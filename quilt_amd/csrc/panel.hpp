@@ -46,6 +46,14 @@ struct qa_panel {
     // size plans them (GateHold::arena() is the one they carve from)
     qa::DeviceGate *gate() { return exclusive ? &qa::device_gate(device) : nullptr; }
     qa::Arena &A() { return exclusive ? qa::device_gate(device).arena : arena; }
+    // at least `bytes` of scratch for the launch set in hand (an exclusive handle: the device-wide arena, grown to the
+    // planning budget at once -- the caller holds the device)
+    void require_scratch(size_t bytes) {
+        if (!exclusive) { arena.require(bytes); return; }
+        qa::DeviceGate &g = qa::device_gate(device);
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.grow_arena(bytes);
+    }
     int sharers() const { return exclusive ? 1 : share; }   // handles whose launch sets may be on the device at the same time
     qa::Arena aux;              // per-call index / list buffers of the driver-level entry points (grow-only: a call-local
                                 // hipMalloc / hipFree pair would synchronise the device with the other host threads' launches)

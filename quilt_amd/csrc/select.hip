@@ -129,12 +129,19 @@ size_t select_lds_bytes(const SelectParams &p) {
     return 4 * ((n_words + n_cand + 1) & ~(size_t)1) + 8 * std::max<size_t>(n_cand, p.Ksubset);
 }
 
-void launch_select(const SelectParams &p, int n_chain, hipStream_t st) {
+// false: the tables of one chain do not fit this device's LDS (160 KB per workgroup on gfx950; K, the thinned grids or Ksubset
+// too large) -- nothing is launched and the caller reports status 1 for every chain, which sends the driver down its exact
+// host path (the one it takes for truncated lists)
+bool launch_select(const SelectParams &p, int n_chain, hipStream_t st) {
     const size_t lds = select_lds_bytes(p);
-    if (lds > 160 * 1024) throw std::runtime_error("selection tables exceed the LDS (K, thinned grids or Ksubset too large)");
+    int dev = 0, lds_max = 0;
+    QA_HIP(hipGetDevice(&dev));
+    QA_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    if (lds > (size_t)lds_max) return false;
     QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_select, dim3(n_chain), dim3(64), lds, st, p);
     QA_HIP(hipGetLastError());
+    return true;
 }
 
 void launch_scatter_lists(const int32_t *src_idx, const int32_t *src_cnt, const int32_t *rows, int n, int n_thin, int top_cap,

@@ -670,9 +670,14 @@ class Driver:
         P = self.params
         T, nL = self.panel.nSNPs, self.n_label
         if return_dosage:
-            dosages = np.empty((len(chains), nL, T))
-            for ci, res in enumerate(results):
-                dosages[ci] = np.asarray(res["hapProbs_t"])[:nL]
+            allh = results[0].get("hap_major_all")
+            if (allh is not None and allh.shape == (len(chains), nL, T) and
+                    all(r.get("hap_major_all") is allh for r in results)):
+                dosages = allh   # the backend's [chain, label, SNP] buffer itself, in chain order: nothing to copy
+            else:
+                dosages = np.empty((len(chains), nL, T))
+                for ci, res in enumerate(results):
+                    dosages[ci] = np.asarray(res["hapProbs_t"])[:nL]
             for ci, ch in enumerate(chains):
                 ch.hap = [dosages[ci][l] for l in range(nL)]
         else:
@@ -742,6 +747,13 @@ class Driver:
                     n_gibbs_sample_its=P.n_gibbs_sample_its,
                     block_gibbs_iterations=P.small_ref_panel_block_gibbs_iterations,
                     maxDifferenceBetweenReads=md, Jmax_local=P.Jmax, **kw)
+                if len(groups) > 1 or n_try > 0:
+                    # the backend's dosage buffer is reused by its next call: results of a call that is not the round's only
+                    # one keep copies
+                    for o in out:
+                        if o.get("hap_major_all") is not None:
+                            o["hapProbs_t"] = np.array(o["hapProbs_t"])
+                            o["hap_major_all"] = None
                 for i, o in zip(idx, out):
                     if o["underflow_problem"]:
                         maxdiff[i] = max(1.0, maxdiff[i] / 10)   # functions.R:2704-2715
@@ -749,6 +761,11 @@ class Driver:
                         self.n_underflow_retries += 1
                     else:
                         results[i] = o
+            if nxt:   # another call follows and reuses the backend's dosage buffer: what has been accepted keeps copies
+                for o in results:
+                    if o is not None and o.get("hap_major_all") is not None:
+                        o["hapProbs_t"] = np.array(o["hapProbs_t"])
+                        o["hap_major_all"] = None
             pending = nxt
             n_try += 1
             if n_try > 10 and pending:
@@ -934,6 +951,7 @@ class HipBackend:
         self.dev = device_panel
         self.drc = device_rare_common   # quilt_amd.native.DeviceRareCommon, for impute_rare_common
         self._dosage_buf = None         # pinned host buffer of the dosage rounds (fullpass_reads_batch)
+        self._hap_buf = None            # the same for the Gibbs call's own haploid dosages (use_mspbwt = TRUE)
 
     def make_gl_bound(self, gl, minGLValue, to_fix):
         from .reference_single import Rcpp_make_gl_bound
@@ -948,11 +966,22 @@ class HipBackend:
                                                   seed_reads=seed_reads, seed_shard=seed_shards, return_hapProbs=True,
                                                   return_genProbs=False, disable_read_category_usage=True,
                                                   rare_common=self.drc, **kw)
+        want_hap = bool(kw.pop("return_hapProbs", False))   # use_mspbwt = TRUE: the call's own haploid dosages
+        hap_out = None
+        if want_hap:
+            # label by label into this backend's pinned buffer (no staging copy, no per-chain transposes on the host): valid
+            # until the next call that asks for dosages -- the driver consumes a round before it starts the next
+            n_label = 3 if np.ndim(kw.get("ff", 0.0)) > 0 or kw.get("ff", 0.0) != 0 else 2
+            need = len(samples) * n_label * self.dev.panel.nSNPs
+            if self._hap_buf is None or self._hap_buf.size < need:
+                from .native import pinned_empty
+                self._hap_buf = None
+                self._hap_buf = pinned_empty((need + need // 8,))
+            hap_out = self._hap_buf[:need].reshape(len(samples), n_label, self.dev.panel.nSNPs)
         return forwardBackwardGibbsNIPT_batch(self.dev, samples, which, starts, None, first_reads, None,
-                                              seed_reads=seed_reads, seed_shard=seed_shards,
-                                              return_hapProbs=bool(kw.pop("return_hapProbs", False)),   # use_mspbwt = TRUE
+                                              seed_reads=seed_reads, seed_shard=seed_shards, return_hapProbs=False,
                                               return_hap_words=bool(kw.pop("return_hap_words", False)),
-                                              return_genProbs=False, **kw)
+                                              return_genProbs=False, hap_major_out=hap_out, **kw)
 
     def find_good_matches(self, Zs, nindices, min_len, max_matches):
         from .mspbwt import find_good_matches

@@ -31,6 +31,7 @@ class GibbsOpts(C.Structure):
         ("class_sum_cutoff", C.c_double),
         ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int32), ("block_gibbs_quantile_prob", C.c_double),
         ("ff_chain", C.c_void_p), ("per_it_out", C.c_void_p), ("hap_words_out", C.c_void_p),
+        ("hap_major_out", C.c_void_p), ("hap_major_labels", C.c_int32),
     ]
 
 
@@ -47,7 +48,7 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                                    return_genProbs: bool = True, rare_common=None, runif_block=None,
                                    runif_resample=None, L_grid=None, shuffle_bin_radius: int = 5000,
                                    block_gibbs_quantile_prob: float = 0.95, return_per_it: bool = False,
-                                   return_hap_words: bool = False):
+                                   return_hap_words: bool = False, hap_major_out: Optional[np.ndarray] = None):
     """``n_chain`` independent calls of ``rcpp_forwardBackwardGibbsNIPT`` in one launch set.
 
     ``samples[c]`` is a :class:`quilt_amd.synth.SampleReads`-like object (``read_ptr``, ``u``, ``bq``,
@@ -60,6 +61,10 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
     NIPT (``ff`` > 0) with ``perform_block_gibbs``: ``runif_block[c]`` / ``runif_resample[c]`` hold
     ``len(block_gibbs_iterations) x nReads`` uniforms each (QUILT/src/gibbs-nipt.cpp:3016; gibbs-nipt-block.cpp:226-243)
     unless seeds are used; ``L_grid`` defaults to the panel's (the all-SNP grid's with ``rare_common``).
+
+    ``hap_major_out``: a C-contiguous float64 array [n_chain, n_label, nSNPs] (ideally from ``native.pinned_empty``) that
+    receives the haploid dosages label by label -- the layout the driver accumulates from -- instead of a per-chain
+    ``hapProbs_t``; the dicts then carry views of its rows.
     """
     lib().qa_gibbs_batch.restype = C.c_int
     lib().qa_gibbs_batch_rare_common.restype = C.c_int
@@ -122,6 +127,11 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
         raise ValueError("diploid read labels must be 1 or 2")
     Hc = np.zeros_like(H)
     # (np.empty: the library writes every entry of the rows it is asked for; zero-filling ~1 GB per call costs more than the copy)
+    if hap_major_out is not None:
+        if (hap_major_out.dtype != np.float64 or not hap_major_out.flags.c_contiguous or hap_major_out.ndim != 3 or
+                hap_major_out.shape[0] != Cn or hap_major_out.shape[2] != T or hap_major_out.shape[1] not in (2, 3)):
+            raise ValueError("hap_major_out must be a C-contiguous float64 array [n_chain, 2 or 3, nSNPs]")
+        return_hapProbs = False
     hap = np.empty((Cn, T, 3)) if return_hapProbs else None
     gm = np.empty((Cn, T, 3)) if return_genProbs else None
     gf = np.empty((Cn, T, 3)) if return_genProbs else None
@@ -133,7 +143,8 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
                      int(n_gibbs_burn_in_its), int(n_gibbs_sample_its), ptr(blocks), int(len(blocks)),
                      int(perform_block_gibbs), int(ff == 0), int(gibbs_initialize_iteratively),
                      int(disable_read_category_usage), float(class_sum_cutoff), ptr(Lg), int(shuffle_bin_radius),
-                     float(block_gibbs_quantile_prob), ptr(ffc), ptr(per_it), ptr(words))
+                     float(block_gibbs_quantile_prob), ptr(ffc), ptr(per_it), ptr(words), ptr(hap_major_out),
+                     0 if hap_major_out is None else int(hap_major_out.shape[1]))
     _t1 = time.perf_counter()
     tail = (C.byref(opts), C.c_int32(Cn), ptr(which), ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(ru),
             ptr(fr), ptr(rs), ptr(H), ptr(Hc), ptr(hap), ptr(gm), ptr(gf), ptr(uf), ptr(state), ptr(sr), ptr(ss))
@@ -157,6 +168,9 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
             d["hap_words"] = words[c]
         if hap is not None:
             d["hapProbs_t"] = np.asfortranarray(hap[c].T)
+        if hap_major_out is not None:
+            d["hapProbs_t"] = hap_major_out[c]   # [n_label, nSNPs] view
+            d["hap_major_all"] = hap_major_out   # (the whole [chain, label, SNP] array: lets a caller skip per-chain copies)
         if gm is not None:
             d["genProbsM_t"] = np.asfortranarray(gm[c].T)
             d["genProbsF_t"] = np.asfortranarray(gf[c].T)

@@ -274,6 +274,20 @@ def gate_stats(device: int = 0, reset: bool = False) -> dict:
                 gibbs_holds=int(out[5]), gibbs_slots=int(out[6]))
 
 
+def gate_trace(device: int = 0, on: bool = True, read: bool = True) -> np.ndarray:
+    """qa_gate_trace: the finished holds since the last read as rows (request, admit, kernels done, release [ms], SIMD slots
+    (0: exclusive), thread); ``read=False`` only switches the trace on / off."""
+    lib().qa_gate_trace.restype = C.c_int
+    if not read:
+        check(min(lib().qa_gate_trace(C.c_int32(device), C.c_int32(int(on)), None, C.c_int32(0)), 0))
+        return np.zeros((0, 6))
+    n = lib().qa_gate_trace(C.c_int32(device), C.c_int32(1), None, C.c_int32(0))
+    check(min(n, 0))
+    rows = np.zeros((max(n, 1) + 64, 6))
+    n = lib().qa_gate_trace(C.c_int32(device), C.c_int32(int(on)), ptr(rows), C.c_int32(len(rows)))
+    return rows[:min(n, len(rows))]
+
+
 def last_fullpass_timing_ms():
     out = (C.c_double * 5)()
     check(lib().qa_last_fullpass_timing_ms(out))

@@ -42,6 +42,21 @@ class PairGate:
                 self.count -= 1
             return ok
 
+    def reset(self, n: int):
+        with self.cv:
+            self.n, self.count = n, 0
+            self.gen += 1
+            self.cv.notify_all()
+
+    def leave(self):
+        """A thread that has no launches left (uneven number of batches): the others stop waiting for it."""
+        with self.cv:
+            self.n = max(self.n - 1, 1)
+            if self.count >= self.n:
+                self.gen += 1
+                self.count = 0
+                self.cv.notify_all()
+
 
 class DeviceWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
@@ -97,6 +112,8 @@ class DeviceWorkers:
         contiguous parts, one per worker thread; every worker pipelines its own parts."""
         batches = list(batches)
         outs = [queue.Queue() for _ in range(self.n)]
+        if self.drivers[0].gibbs_gate is not None:
+            self.drivers[0].gibbs_gate.reset(self.n)
         if self.split == "alternate":
             def work_alt(w: int):
                 try:
@@ -104,6 +121,9 @@ class DeviceWorkers:
                         outs[w].put(res)
                 except BaseException as e:   # surfaced by the consumer
                     outs[w].put(e)
+                finally:
+                    if self.drivers[w].gibbs_gate is not None:
+                        self.drivers[w].gibbs_gate.leave()
             threads = [threading.Thread(target=work_alt, args=(w,), daemon=True) for w in range(self.n)]
             for t in threads:
                 t.start()
@@ -126,6 +146,9 @@ class DeviceWorkers:
                     outs[w].put(res)
             except BaseException as e:   # surfaced by the consumer
                 outs[w].put(e)
+            finally:
+                if self.drivers[w].gibbs_gate is not None:
+                    self.drivers[w].gibbs_gate.leave()
 
         threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(self.n)]
         for t in threads:

@@ -12,22 +12,24 @@ ap.add_argument("--K", type=int, default=50000); ap.add_argument("--T", type=int
 ap.add_argument("--chains", type=int, default=224); ap.add_argument("--reads", type=int, default=20000)
 ap.add_argument("--Ks", type=int, default=600); ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--init-iter", action="store_true"); ap.add_argument("--samples", type=int, default=0)
+ap.add_argument("--nipt", action="store_true", help="three read labels, block Gibbs (ff = 0.2)")
 a = ap.parse_args()
 panel = make_synthetic_panel(K=a.K, nSNPs=a.T, seed=4916)
 dev = DevicePanel(panel)
 ns = a.samples or max(1, a.chains // 7)
-samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=a.reads) for i in range(ns)]
+samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=a.reads, **({"ff": 0.2} if a.nipt else {})) for i in range(ns)]
 rng = np.random.default_rng(0)
 S = [samples[c % ns] for c in range(a.chains)]
 which = [np.sort(rng.choice(panel.K, a.Ks, replace=False)).astype(np.int32) + 1 for _ in range(a.chains)]
-H0 = [rng.integers(1, 3, size=s.nReads).astype(np.int32) for s in S]
+H0 = [rng.integers(1, 4 if a.nipt else 3, size=s.nReads).astype(np.int32) for s in S]
 fr = [int(rng.integers(0, s.nReads)) for s in S]
 sr = rng.integers(0, 2**63, size=a.chains).astype(np.uint64); ss = rng.integers(0, 2**63, size=a.chains).astype(np.uint64)
 for r in range(a.reps):
     native.lib().qa_profile_reset()
     t0 = time.time()
     out = forwardBackwardGibbsNIPT_batch(dev, S, which, H0, None, fr, None, seed_reads=sr, seed_shard=ss,
-                                         gibbs_initialize_iteratively=a.init_iter)
+                                         gibbs_initialize_iteratively=a.init_iter, return_genProbs=False,
+                                         **({"ff": [0.2] * a.chains} if a.nipt else {}))
     wall = time.time() - t0
     res = []
     for k, name in ((4, "ematread"), (5, "gibbs"), (6, "happrobs")):

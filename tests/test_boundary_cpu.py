@@ -84,3 +84,14 @@ def test_c_harness_builds_and_reports_no_device_here():
     assert run.returncode == 0, run.stdout + run.stderr
     assert "HARNESS_OK" in run.stdout or "NO_DEVICE" in run.stdout
     assert "HOST_FORMATS_OK" in run.stdout   # include/quilt_amd_io.h from plain C: needs no device
+
+
+def test_device_gate_admission_rules():
+    """Device phases (include/quilt_amd.h, qa_panel_set_exclusive): Gibbs launches that fit run together, the queue is first
+    come first served with nobody overtaking a waiting launch set, express holds (the msPBWT search) go first."""
+    import ctypes
+    from quilt_amd import native
+    lib = native.lib()
+    lib.qa_gate_selftest.restype = ctypes.c_int
+    lib.qa_last_error.restype = ctypes.c_char_p
+    assert lib.qa_gate_selftest() == 0, lib.qa_last_error()

@@ -424,3 +424,26 @@ def test_diploid_block_gibbs_is_a_named_choice():
     assert DriverParams().resolved(1000).diploid_block_gibbs == "reference_noop"
     with pytest.raises(ValueError, match="reference_noop"):
         DriverParams(diploid_block_gibbs="active").resolved(1000)
+
+
+def test_pair_gate_lets_a_finished_thread_leave():
+    """workers.PairGate: threads meet before their Gibbs launches; one that has no launches left (uneven number of batches)
+    leaves, and the remaining thread no longer waits out the timeout."""
+    import threading
+    import time
+    from quilt_amd.workers import PairGate
+    gate = PairGate(2, timeout=5.0)
+    met = []
+    th = threading.Thread(target=lambda: met.append(gate.wait()))
+    th.start()
+    assert gate.wait() is True
+    th.join()
+    assert met == [True]
+    gate.leave()                      # the other thread is done
+    t0 = time.perf_counter()
+    assert gate.wait() is True        # alone now: no waiting
+    assert time.perf_counter() - t0 < 1.0
+    gate.reset(2)
+    t0 = time.perf_counter()
+    short = PairGate(2, timeout=0.2)
+    assert short.wait() is False and time.perf_counter() - t0 >= 0.19   # nobody came: goes alone after the timeout

@@ -480,3 +480,28 @@ def test_cram_is_refused_with_a_recipe(tmp_path):
     with pytest.raises(QuiltAmdError) as ei:
         loadBamAndConvert(p, "chr20", np.array([10, 20], dtype=np.int32), list("AA"), list("CC"))
     assert "samtools view -b" in str(ei.value) and "status -3" in str(ei.value)
+
+
+def test_vcf_columns_reject_values_they_cannot_print():
+    """The column writers format into fixed entries: a non-finite dosage or posterior (or one beyond 1e9) is refused with the SNP
+    named instead of being formatted past the entry."""
+    import ctypes as C
+    from quilt_amd.native import ptr
+    from quilt_amd.io import _io_lib
+    lib = _io_lib()
+    lib.qa_last_error.restype = C.c_char_p
+    T = 4
+    gp = np.tile(np.array([0.25, 0.5, 0.25]), T)
+    hd = np.full(2 * T, 0.5)
+    buf = np.zeros(4096, dtype=np.uint8)
+    off = np.zeros(T + 1, dtype=np.int64)
+    need = C.c_int64()
+    def call(gp_, hd_):
+        return lib.qa_vcf_column_diploid(C.c_int32(T), ptr(gp_), ptr(hd_), C.c_int32(1), ptr(buf), C.c_int64(len(buf)), ptr(off),
+                                         C.byref(need))
+    assert call(gp, hd) == 0
+    for bad in (np.nan, np.inf, 1e300):
+        h = hd.copy(); h[2] = bad
+        assert call(gp, h) == -2 and b"SNP 2" in lib.qa_last_error()
+        g = gp.copy(); g[3 * 1 + 1] = bad
+        assert call(g, hd) == -2 and b"SNP 1" in lib.qa_last_error()

@@ -102,3 +102,49 @@ def test_native_batch_selection_equals_the_numpy_text():
             for c in range(n_chain):
                 ref = select_new_haps_mspbwt_v3(lists[c * n_label:(c + 1) * n_label], Knew, Kfull, nGrids, seeds[c])
                 assert np.array_equal(got[c], ref), (n_label, Knew, n_avail, c)
+
+
+def _scan_queries(panel, n, err, seed):
+    from quilt_amd.mspbwt import rcpp_int_contract
+    from quilt_amd.synth import make_truth_haplotype
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        h = make_truth_haplotype(panel, rng).copy()
+        flip = rng.random(len(h)) < err
+        h[flip] = 1 - h[flip]
+        out.append(rcpp_int_contract(h))
+    return np.stack(out)
+
+
+def test_neighbour_scan_holds_the_prefix_order_property(small_panel, ragged_panel):
+    """tests/mspbwt_scan.py, the restated msPBWT query (parity unpinned: the package is not in the reference tree): with
+    check=True every position asserts that the haplotypes next to the query's insertion point carry the longest matches ending
+    there and that the lengths fall away on both sides -- the property of the positional prefix order the scan relies on."""
+    from tests.mspbwt_scan import find_good_matches_scan
+    for panel, nind in ((small_panel, 2), (ragged_panel, 3)):
+        Zs = _scan_queries(panel, 3, 0.01, 7)
+        found = find_good_matches_scan(panel, Zs, nind, L=3, M=1, check=True)
+        for per_index in found:
+            for i, m in enumerate(per_index):
+                n_pos = len(range(i, panel.nGrids, nind))
+                assert len(m) and (m[:, 2] >= 1).all() and (m[:, 1] + m[:, 2] <= n_pos).all()
+                assert len({(int(k), int(s)) for k, s, _ in m}) == len(m)      # one row per (haplotype, start)
+        # M: only matches at least that long are reported
+        for per_index in find_good_matches_scan(panel, Zs, nind, L=3, M=3):
+            assert all((m[:, 2] >= 3).all() for m in per_index)
+
+
+def test_selection_from_the_search_and_from_the_neighbour_scan(medium_panel):
+    """How far the next small panel chosen from this library's search definition (every haplotype's longest run, the longest
+    first) agrees with the one chosen from the msPBWT neighbour scan, on mosaic queries: stated bars, the same ones the GPU
+    test and bench.py --mspbwt report against."""
+    from tests.mspbwt_scan import find_good_matches_scan, selection_agreement
+    from tests.oracle_backend import find_good_matches_bruteforce
+    panel = medium_panel
+    for err, bar_sel, bar_long in ((0.0, 0.55, 0.95), (0.005, 0.45, 0.9)):
+        Zs = _scan_queries(panel, 2, err, 11)
+        sc = find_good_matches_scan(panel, Zs, 4, L=3, M=1)
+        bf = find_good_matches_bruteforce(panel, Zs, 4, 1, 150)
+        a = selection_agreement(sc, bf, 100, panel.K, panel.nGrids)
+        assert a["selected"] >= bar_sel and a["longest"] >= bar_long, (err, a)

@@ -87,3 +87,24 @@ def test_hap_words_formed_on_the_device(medium_panel):
     for o, w in zip(out, only):
         assert np.array_equal(o["hap_words"], int_contract_rows(np.asarray(o["hapProbs_t"])))
         assert np.array_equal(o["hap_words"], w["hap_words"]) and "hapProbs_t" not in w
+
+
+def test_selection_from_the_device_search_and_from_the_neighbour_scan(medium_panel):
+    """The device search's definition (every haplotype's longest run, the longest first) against the restated msPBWT neighbour
+    scan (tests/mspbwt_scan.py; parity with the mspbwt package itself is unpinned, the package is not in the reference tree):
+    share of the next small panel chosen from both (bar 0.55 on clean mosaic queries, 0.45 with 0.5 % of the alleles flipped) and
+    share of the scan's longest matches the device search reports (0.95 / 0.9).  bench.py --mspbwt reports the same statistic on
+    the K = 50 000 panel."""
+    from quilt_amd.mspbwt import find_good_matches, match_tables_as_lists
+    from quilt_amd.native import DevicePanel
+    from tests.mspbwt_scan import find_good_matches_scan, selection_agreement
+    from tests.test_mspbwt_cpu import _scan_queries
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    for err, bar_sel, bar_long in ((0.0, 0.55, 0.95), (0.005, 0.45, 0.9)):
+        Zs = _scan_queries(panel, 2, err, 11)
+        sc = find_good_matches_scan(panel, Zs, 4, L=3, M=1)
+        got = match_tables_as_lists(*find_good_matches(dev, Zs, 4, 1, 150))
+        a = selection_agreement(sc, got, 100, panel.K, panel.nGrids)
+        assert a["selected"] >= bar_sel and a["longest"] >= bar_long, (err, a)
+    dev.close()

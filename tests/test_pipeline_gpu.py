@@ -118,6 +118,36 @@ def test_two_host_threads_share_the_device(medium_panel):
     dev.close()
 
 
+@pytest.mark.parametrize("mspbwt", [False, True])
+def test_host_threads_take_the_device_in_phases(medium_panel, mspbwt):
+    """DeviceWorkers(exclusive=True), the bench's configuration: three threads, whole batches in turn, launch sets through the
+    device gate (full-panel sets exclusive, Gibbs launches side by side, the msPBWT search as an express hold), scratch from
+    the one device-wide arena.  Results equal the single-threaded, ungated driver's; the gate saw holds of both kinds."""
+    from quilt_amd import native
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    from quilt_amd.workers import DeviceWorkers
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=3100 + i, n_reads=500) for i in range(8)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=200, Knew=200, seed=14, use_mspbwt=mspbwt, mspbwt_nindices=2)
+    batches = [(samples[0:3], 0), (samples[3:5], 3), (samples[5:6], 5), (samples[6:8], 6)]
+    native.gate_stats(0, reset=True)
+    wk = DeviceWorkers(panel, prm, n_workers=3, exclusive=True, split="alternate")
+    got = list(wk.run_stream(batches))
+    wk.close()
+    st = native.gate_stats(0)
+    assert st["holds"] > st["gibbs_holds"] > 0 and st["held_ms"] > 0
+    dev = DevicePanel(panel)
+    for (smp, off), g_batch in zip(batches, got):
+        ref = Driver(panel, HipBackend(dev), prm).run(smp, sample_offset=off)
+        assert len(g_batch) == len(ref)
+        for g, r in zip(g_batch, ref):
+            assert np.array_equal(g.read_labels, r.read_labels)
+            assert np.abs(g.dosage - r.dosage).max() <= 1e-6
+    dev.close()
+
+
 def test_pipeline_ont_reads(medium_panel):
     """BASELINE configs[3] in small: long noisy reads (hundreds of SNPs each, Jmax path, reads spanning many grids)
     through the whole driver, GPU vs the same driver on the oracle."""
