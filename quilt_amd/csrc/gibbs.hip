@@ -1266,9 +1266,11 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
             std::vector<double> rate2;
             std::vector<int32_t> h_where, h_tab, h_n;
             int it0 = 0;
+            q.rebuild = 0;
             for (size_t j = 0; j < passes.size(); j++) {
                 q.it_begin = it0; q.it_end = passes[j] + 1;
                 qa::launch_gibbs3(&q, st);
+                q.rebuild = 1;   // (what follows a block pass starts by re-forming the state from its labels)
                 qa::launch_block_rate3(&q, st);
                 rate2.resize((size_t)C * G);
                 S.blk_rate2.download(rate2.data(), rate2.size(), st);
@@ -1304,7 +1306,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
                 qa::launch_block3(&q, st);
                 it0 = passes[j] + 1;
             }
-            if (passes.empty() || it0 < n_its) {
+            if (passes.empty() || it0 < n_its || q.rebuild) {   // (also with no sweeps left: the rebuild after the last pass)
                 q.it_begin = it0; q.it_end = n_its;
                 qa::launch_gibbs3(&q, st);
             }

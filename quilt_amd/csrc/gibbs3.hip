@@ -72,31 +72,46 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
     }   // first segment
     chain_sync<NW>();
 
-    // forward over all grids for every label (Rcpp_run_forward_haploid, copied-from-stitch.cpp:340-387)
+    // forward over all grids for every label (Rcpp_run_forward_haploid, copied-from-stitch.cpp:340-387): the next grid's
+    // eMatGrid columns fetched while this one computes, the transitions read and the normalisers written 64 grids at a
+    // time through lanes (GridStreams3)
     auto forward_full = [&]() {
         Col<NE> a[NH], e[NH];
+        GridStreams3<CH> gs;
+#pragma unroll
+        for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h]);
         for (int g = 0; g < G; g++) {
-            const double s0 = g > 0 ? ch.tm0(g - 1) : 1.0, s1 = g > 0 ? ch.tm1(g - 1) : 0.0;
+            if ((g & 63) == 0) {
+                if (g) gs.store_c(ch);
+                gs.load_fwd(ch, g);
+            }
+            const int j = g & 63;
+            Col<NE> en[NH];
+            const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: the loads stay unconditional
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
+            const double s0 = rl_f64(gs.t0, j), s1 = rl_f64(gs.t1, j);
 #pragma unroll
             for (int h = 0; h < NH; h++) {
-                ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
 #pragma unroll
                 for (int i = 0; i < NE; i++) {
                     if (g == 0) a[h].v[i] = valid[i] ? prior * e[h].v[i] : 0.0;
                     else a[h].v[i] = valid[i] ? e[h].v[i] * (s0 * a[h].v[i] + s1 * prior) : 0.0;
                 }
             }
-            double sm[NH];
+            double sm[NH], cc[NH];
             sum3(a, sm);
 #pragma unroll
             for (int h = 0; h < NH; h++) {
-                const double cc = 1 / sm[h];
+                cc[h] = 1 / sm[h];
 #pragma unroll
-                for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * cc;
+                for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * cc[h];
                 ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
-                if (t == 0) ch.cv[h][g] = cc;
+                e[h] = en[h];
             }
+            gs.set_c(ch.lane, j, cc[0], cc[1], cc[2]);
         }
+        gs.store_c(ch);
         chain_sync<NW>();
     };
     // Rcpp_run_backward_haploid (copied-from-stitch.cpp:392-409) or its QUILT_faster form (:417-440); beta(G-1) = c(G-1)
@@ -150,28 +165,33 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
         }
         chain_sync<NW>();
     };
-    auto emission_of = [&](Col<NE> &er, int r) {
-        typename CH::ErPre x;
-        ch.ld_pre(x, r);
-        ch.read_emission(er, x, uni_i(ch.dense_of[r]));
-    };
 
-    // ---- rcpp_gibbs_nipt_initialize (:1629-1750)
-    if (p.it_begin > 0) {
-        // (nothing to initialise)
-    } else if (!init_iteratively) {
+    // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281) from the labels in memory; reads are sorted by grid, only grids
+    // with reads are written (the others hold 1 since the call began).  The reads' scalars come from lane-held streams, the
+    // next read's compact emission is fetched a read ahead
+    auto build_emat_grid = [&]() {
+        ReadStreams<CH> rs;
+        rs.load(ch, 0, nullptr, 0);
+        typename CH::ErPre pre{};
+        if (R > 0) ch.ld_pre(pre, 0);
         int r = 0;
-        while (r < R) {   // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281): reads are sorted by grid
-            const int g = uni_i(ch.wif[r]);
+        while (r < R) {
+            if (r >= rs.base + 64) rs.load(ch, r, nullptr, 0);
+            const int g = rl_i32(rs.wif, r - rs.base);
             Col<NE> e[NH];
 #pragma unroll
             for (int h = 0; h < NH; h++)
 #pragma unroll
                 for (int i = 0; i < NE; i++) e[h].v[i] = 1.0;
-            while (r < R && uni_i(ch.wif[r]) == g) {
+            while (r < R) {
+                if (r >= rs.base + 64) rs.load(ch, r, nullptr, 0);
+                const int j = r - rs.base;
+                if (rl_i32(rs.wif, j) != g) break;
+                const typename CH::ErPre x = pre;
+                ch.ld_pre(pre, min(r + 1, R - 1));
                 Col<NE> er;
-                emission_of(er, r);
-                const int hh = uni_i(ch.H[r]) - 1;
+                ch.read_emission(er, x, rl_i32(rs.dn, j));
+                const int hh = rl_i32(rs.H, j) - 1;
 #pragma unroll
                 for (int h = 0; h < NH; h++)
                     if (hh == h) {
@@ -183,6 +203,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
 #pragma unroll
             for (int h = 0; h < NH; h++) ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
         }
+        chain_sync<NW>();
+    };
+
+    // ---- rcpp_gibbs_nipt_initialize (:1629-1750)
+    if (p.it_begin > 0) {
+        // a later segment: nothing to initialise -- unless a block pass came before it, which leaves new labels behind and
+        // eMatGrid, alpha, beta, c to be formed from them (Rcpp_block_gibbs_resampler's last steps, gibbs-nipt-block.cpp:1898-1954:
+        // eMatGrid, Rcpp_run_forward_haploid, Rcpp_run_backward_haploid_QUILT_faster from beta(G - 1) = c(G - 1)); done here, one
+        // wave per chain with the pipelined passes, instead of at the end of k_block3 (two waves, a barrier per sum)
+        if (p.rebuild && status == 0) {
+            build_emat_grid();
+            forward_full();
+            backward_full(true);
+        }
+    } else if (!init_iteratively) {
+        build_emat_grid();
         chain_sync<NW>();
         forward_full();
         backward_full(false);   // rcpp_initialize_gibbs_forward_backward (:453-487)
@@ -874,7 +910,7 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
         for (int h = 0; h < NH; h++) e[h] = en[h];
     }
     block_sync();
-    // ---- rcpp_sample_H_using_H_class (:213-246), then eMatGrid, forward and backward from scratch (:1898-1954)
+    // ---- rcpp_sample_H_using_H_class (:213-246)
     for (int r = t; r < R; r += NT) {
         const int hc = ch.Hc[r];
         int hn;
@@ -888,92 +924,7 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
         }
         ch.H[r] = hn;
     }
-    block_sync();
-    rb_base = -1;
-    {
-        int r = 0;
-        for (int g = 0; g < G; g++) {   // rcpp_make_eMatGrid_t: reads are sorted by grid
-            Col<NE> el[NH];
-#pragma unroll
-            for (int h = 0; h < NH; h++)
-#pragma unroll
-                for (int q = 0; q < NE; q++) el[h].v[q] = 1.0;
-            while (r < R && wif_of(r) == g) {
-                Col<NE> er;
-                emission_of(er, r);
-                const int hh = H_of(r) - 1;
-#pragma unroll
-                for (int h = 0; h < NH; h++)
-                    if (hh == h) {
-#pragma unroll
-                        for (int q = 0; q < NE; q++) el[h].v[q] *= er.v[q];
-                    }
-                r++;
-            }
-#pragma unroll
-            for (int h = 0; h < NH; h++) ch.st(el[h], ch.eg[h] + (size_t)g * Ksp);
-        }
-    }
-    {   // Rcpp_run_forward_haploid
-        Col<NE> a[NH], e[NH];
-        for (int g = 0; g < G; g++) {
-            const double s0 = g > 0 ? ch.tm0(g - 1) : 1.0, s1 = g > 0 ? ch.tm1(g - 1) : 0.0;
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-                ch.ld(e[h], ch.eg[h] + (size_t)g * Ksp);
-#pragma unroll
-                for (int q = 0; q < NE; q++) {
-                    if (g == 0) a[h].v[q] = valid[q] ? prior * e[h].v[q] : 0.0;
-                    else a[h].v[q] = valid[q] ? e[h].v[q] * (s0 * a[h].v[q] + s1 * prior) : 0.0;
-                }
-            }
-            double sm[NH];
-            sum3(a, sm);
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-                const double cc = 1 / sm[h];
-#pragma unroll
-                for (int q = 0; q < NE; q++) a[h].v[q] = a[h].v[q] * cc;
-                ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
-                if (t == 0) ch.cv[h][g] = cc;
-            }
-        }
-    }
-    block_sync();
-    {   // the backward pass that stays: Rcpp_run_backward_haploid_QUILT_faster from beta(G - 1) = c(G - 1) (:1939-1954)
-        Col<NE> b[NH], e[NH];
-#pragma unroll
-        for (int h = 0; h < NH; h++) {
-            const double cl = uni_d(&ch.cv[h][G - 1]);
-#pragma unroll
-            for (int q = 0; q < NE; q++) b[h].v[q] = valid[q] ? cl : 0.0;
-            ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
-        }
-        for (int g = G - 2; g >= 0; --g) {
-            const double s0 = ch.tm0(g), s1 = ch.tm1(g);
-            const bool has = uni_i(ch.ghr[g + 1]) != 0;
-            double x[NH];
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-                ch.ld(e[h], ch.eg[h] + (size_t)(g + 1) * Ksp);
-                x[h] = 0;
-#pragma unroll
-                for (int q = 0; q < NE; q++) {
-                    if (has) b[h].v[q] = e[h].v[q] * b[h].v[q];
-                    x[h] += b[h].v[q];
-                }
-            }
-            ch.template bsum<NH>(x);
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-                const double cg = uni_d(&ch.cv[h][g]);
-                const double xx = s1 * x[h] * one_over_K;
-#pragma unroll
-                for (int q = 0; q < NE; q++) b[h].v[q] = valid[q] ? cg * (xx + s0 * b[h].v[q]) : 0.0;
-                ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
-            }
-        }
-    }
+    // eMatGrid, forward and backward from the new labels (:1898-1954): the next k_gibbs3 launch does them first (p.rebuild)
 }
 
 template <int NE, int NW>

@@ -85,6 +85,7 @@ struct GibbsParams {
     // NIPT (three labels): a call is cut into segments of sweeps [it_begin, it_end) with a block-Gibbs pass between
     // them (gibbs3.hip); the state lives in HBM across the launches.  blk_*: the pass's block table per chain.
     int it_begin, it_end;
+    int rebuild;                // this segment follows a block pass: eMatGrid, forward, backward from the labels first
     const int32_t *blk_where;   // [C][G] consider_grid_where_0_based
     const int32_t *blk_tab;     // [C][4][G] per block: grid_start, grid_end, reads_start, reads_end
     const int32_t *blk_n;       // [C] n_blocks
