@@ -163,33 +163,94 @@ def test_pipeline_ont_reads(medium_panel):
         assert r2(g.dosage, r.dosage) >= 0.999
 
 
-def test_full_size_invariants():
+@pytest.fixture(scope="module")
+def full_size():
+    """BASELINE.json's headline panel (K = 50 000 haplotypes, 64 000 SNPs / 2 000 grids), built on the device as a production
+    run would build it."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel
+    panel = make_synthetic_panel(K=50000, nSNPs=64000, seed=4916)
+    dev = DevicePanel.from_rhb(panel)
+    yield panel, dev
+    dev.close()
+
+
+def _check_quilt_output(r, n_dosage):
+    """check_quilt_output (test-drivers.R:1-89) on one result: posteriors sum to 1 +- 0.002, dosages within range and
+    consistent with them, phased haplotypes are probabilities."""
+    assert r.nDosage == n_dosage
+    np.testing.assert_allclose(r.gp_t.sum(axis=0), 1.0, atol=2e-3)
+    assert r.dosage.min() >= -1e-9 and r.dosage.max() <= 2 + 1e-9
+    np.testing.assert_allclose(r.dosage, r.gp_t[1] + 2 * r.gp_t[2], atol=1e-9)
+    assert r.phasing_haps.min() >= 0 and r.phasing_haps.max() <= 1
+
+
+def test_full_size_invariants(full_size):
     """BASELINE.json's headline sizes (K = 50 000 haplotypes, 64 000 SNPs / 2 000 grids, 20 000 reads): the CPU path
     takes ~20 minutes per sample there, so the whole driver is checked through size-independent properties -- the
     acceptance criteria of the reference's own end-to-end tests (check_quilt_output, test-drivers.R:1-89): genotype
     probabilities sum to 1 +- 0.002, dosages within [0, 2] and consistent with them, imputed dosage close to the
     simulated truth; plus: every Gibbs label is 1 or 2, phased haplotypes in [0, 1], results independent of batching."""
     from quilt_amd.driver import Driver, DriverParams, HipBackend
-    from quilt_amd.native import DevicePanel
-    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
-    panel = make_synthetic_panel(K=50000, nSNPs=64000, seed=4916)
+    from quilt_amd.synth import make_synthetic_sample
+    panel, dev = full_size
     samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=20000) for i in range(2)]
-    dev = DevicePanel.from_rhb(panel)          # the device-built panel, as a production run would use it
     prm = DriverParams(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
     res = Driver(panel, HipBackend(dev), prm).run(samples)
     for s, r in zip(samples, res):
-        assert r.nDosage == 7
-        np.testing.assert_allclose(r.gp_t.sum(axis=0), 1.0, atol=2e-3)
-        assert r.dosage.min() >= -1e-9 and r.dosage.max() <= 2 + 1e-9
-        np.testing.assert_allclose(r.dosage, r.gp_t[1] + 2 * r.gp_t[2], atol=1e-9)
+        _check_quilt_output(r, 7)
         assert set(np.unique(r.read_labels)) <= {1, 2}
-        assert r.phasing_haps.min() >= 0 and r.phasing_haps.max() <= 1
         truth = s.truth_haps.sum(axis=0)
         assert r2(r.dosage, truth) >= 0.99
         assert np.mean(np.abs(r.dosage - truth) > 0.1) < 0.02    # "DS within 0.1 of truth" for nearly every site
     one = Driver(panel, HipBackend(dev), prm).run(samples[1:], sample_offset=1)[0]
     assert np.array_equal(one.read_labels, res[1].read_labels) and np.abs(one.dosage - res[1].dosage).max() <= 1e-6
-    dev.close()
+
+
+def test_full_size_invariants_ont(full_size):
+    """BASELINE configs[3] at the headline sizes: 300 long noisy reads per sample (hundreds of SNPs each, the Jmax path, reads
+    spanning many grids); same properties as above."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.synth import make_synthetic_sample
+    panel, dev = full_size
+    samples = [make_synthetic_sample(panel, seed=2000 + i, mode="ont", n_reads=300) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=2)
+    res = Driver(panel, HipBackend(dev), prm).run(samples)
+    for s, r in zip(samples, res):
+        _check_quilt_output(r, 7)
+        assert set(np.unique(r.read_labels)) <= {1, 2}
+        truth = s.truth_haps.sum(axis=0)
+        print("ont: r2 vs truth", r2(r.dosage, truth), "off by > 0.1:", np.mean(np.abs(r.dosage - truth) > 0.1))
+        assert r2(r.dosage, truth) >= 0.99
+    one = Driver(panel, HipBackend(dev), prm).run(samples[1:], sample_offset=1)[0]
+    assert np.array_equal(one.read_labels, res[1].read_labels) and np.abs(one.dosage - res[1].dosage).max() <= 1e-6
+
+
+def test_full_size_invariants_nipt(full_size):
+    """BASELINE configs[4] at the headline sizes: method = "nipt", mother + fetus from one read mixture (ff = 0.2), three read
+    labels, block Gibbs.  check_quilt_output's properties for the maternal AND the fetal output; all three labels in use; the
+    maternal dosage close to the simulated truth, the fetal one (a fifth of the reads carry it) correlated with it; results
+    independent of batching."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.synth import make_synthetic_sample
+    panel, dev = full_size
+    samples = [make_synthetic_sample(panel, seed=3000 + i, n_reads=20000, ff=0.2) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=3, method="nipt")
+    res = Driver(panel, HipBackend(dev), prm).run(samples)
+    for s, r in zip(samples, res):
+        _check_quilt_output(r, 7)
+        np.testing.assert_allclose(r.fet_gp_t.sum(axis=0), 1.0, atol=2e-3)
+        assert r.fet_dosage.min() >= -1e-9 and r.fet_dosage.max() <= 2 + 1e-9
+        np.testing.assert_allclose(r.fet_dosage, r.fet_gp_t[1] + 2 * r.fet_gp_t[2], atol=1e-9)
+        assert set(np.unique(r.read_labels)) == {1, 2, 3} and r.phasing_haps.shape[1] == 3
+        mat = s.truth_haps[0] + s.truth_haps[1]      # maternal transmitted + untransmitted
+        fet = s.truth_haps[0] + s.truth_haps[2]      # maternal transmitted + paternal transmitted (functions.R:1009-1016)
+        print("nipt: r2 vs truth, mother", r2(r.dosage, mat), "fetus", r2(r.fet_dosage, fet))
+        assert r2(r.dosage, mat) >= 0.95        # (0.981 / 0.978 observed)
+        assert r2(r.fet_dosage, fet) >= 0.8     # (0.888 / 0.893 observed)
+    one = Driver(panel, HipBackend(dev), prm).run(samples[1:], sample_offset=1)[0]
+    assert np.array_equal(one.read_labels, res[1].read_labels) and np.abs(one.dosage - res[1].dosage).max() <= 1e-6
+    assert np.abs(one.fet_dosage - res[1].fet_dosage).max() <= 1e-6
 
 
 def test_pipeline_nipt(medium_panel):
