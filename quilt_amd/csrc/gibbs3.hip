@@ -581,7 +581,7 @@ __device__ inline double log_p_H_class2(const int (&n)[6], double ff) {   // rcp
 }
 
 template <int NE, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) void k_block3(GibbsParams p) {
+__global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
     __shared__ double s_red[2 * NW * 4];
     const int c = blockIdx.x, t = threadIdx.x;
     using CH = Chain<NE, NW>;
@@ -599,6 +599,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
     auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     const int32_t *where = p.blk_where + (size_t)c * G;
     const int32_t *tab = p.blk_tab + (size_t)c * 4 * G;
+    const int n_blocks = uni_i(p.blk_n[c]);
     // the pass's uniforms: explicit (runif_shard doubles as [n_pass][2][R]: block choice, then label re-draw) or streams
     const double *ru = p.seed_shard ? nullptr : p.runif_shard + ((size_t)p.read_off[c] * p.blk_n_pass + (size_t)p.blk_pass * R) * 2;
     const uint64_t seed = p.seed_shard ? p.seed_shard[c] : 0;
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
     };
 
     Col<NE> aS[6][3];          // alphaStore
-    double inside_l = 0;       // lane 3 ir + h: sum of log_cStore(ir, h) over the current block, in grid order
+    double inside[6][3];       // sum of log_cStore over the current block, in grid order
     double logC_before[3] = {0, 0, 0}, logC_after[3];
     {
         double s[3] = {0, 0, 0};
@@ -670,6 +671,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
 #pragma unroll
         for (int h = 0; h < 3; h++) logC_after[h] = s[h];
     }
+#pragma unroll
+    for (int ir = 0; ir < 6; ir++)
+#pragma unroll
+        for (int h = 0; h < 3; h++) inside[ir][h] = 0;
     bool ever_changed = false;
 
     // the forward recursion's inputs are fetched a grid ahead (columns) or 64 grids at a time into lanes (block index,
@@ -686,6 +691,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
             t0_l = (gg < G && gg > 0) ? ch.tm0(gg - 1) : 1.0;
             t1_l = (gg < G && gg > 0) ? ch.tm1(gg - 1) : 0.0;
         }
+        Col<NE> en[NH];
+        {
+            const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
+#pragma unroll
+            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
+        }
         const double t0 = rl_f64(t0_l, g & 63), t1 = rl_f64(t1_l, g & 63);
         // the 18 normalisers of this grid (uniform values): lane 3 ir + h keeps d(ir, h), so that ONE logarithm per lane
         // replaces 18 per lane (the same function on the same inputs)
@@ -693,28 +704,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
         // ---- Rcpp_gibbs_block_forward_one (:1122-1253)
 #pragma unroll
         for (int ir = 0; ir < 6; ir++) {
-            // in place (slot h = rr0(ir, i) takes label i's emissions): a separate set of three columns for the unnormalised
-            // values is what pushed the loop past 256 registers
+            Col<NE> nx[NH];   // indexed by the slot h = rr0(ir, i)
 #pragma unroll
             for (int i = 0; i < 3; i++) {
+                constexpr int dummy = 0; (void)dummy;
                 const int h = RR[ir][i] - 1;
 #pragma unroll
                 for (int q = 0; q < NE; q++) {
-                    if (g == 0) aS[ir][h].v[q] = valid[q] ? prior * e[i].v[q] : 0.0;
-                    else aS[ir][h].v[q] = valid[q] ? e[i].v[q] * (t0 * aS[ir][h].v[q] + t1 * one_over_K) : 0.0;
+                    if (g == 0) nx[h].v[q] = valid[q] ? prior * e[i].v[q] : 0.0;
+                    else nx[h].v[q] = valid[q] ? e[i].v[q] * (t0 * aS[ir][h].v[q] + t1 * one_over_K) : 0.0;
                 }
             }
             double sm[NH];
-            sum3(aS[ir], sm);
+            sum3(nx, sm);
 #pragma unroll
             for (int h = 0; h < 3; h++) {
                 const double d = 1 / sm[h];
                 if (ch.lane == 3 * ir + h) d_of_lane = d;
 #pragma unroll
-                for (int q = 0; q < NE; q++) aS[ir][h].v[q] = d * aS[ir][h].v[q];
+                for (int q = 0; q < NE; q++) aS[ir][h].v[q] = d * nx[h].v[q];
             }
         }
-        inside_l += log(d_of_lane);   // (one logarithm per lane; the other lanes add log(1) = 0 to a value nobody reads)
+        {
+            const double lg = log(d_of_lane);
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++)
+#pragma unroll
+                for (int h = 0; h < 3; h++) inside[ir][h] += rl_f64(lg, 3 * ir + h);
+        }
         const int iBlock = rl_i32(where_l, g & 63);
         if (iBlock > -1) {
             const int grid_start = uni_i(tab[iBlock]), grid_end = uni_i(tab[G + iBlock]);
@@ -735,7 +752,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 P[ir] = 0;
 #pragma unroll
                 for (int i = 0; i < 3; i++)
-                    P[ir] += log(dot[i]) + -logC_before[i] + -rl_f64(inside_l, 3 * ir + i) + -logC_after[i];
+                    P[ir] += log(dot[i]) + -logC_before[i] + -inside[ir][i] + -logC_after[i];
             }
             // ... and of the read classes under it (rcpp_calculate_block_read_label_probabilities_using_H_class)
             int ns[8];
@@ -859,10 +876,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 block_sync();
                 rb_base = -1;
             }
-            // Rcpp_reset_local_variables (:1257-1292).  Also after the last block, where nothing reads the stores again: an
-            // unconditional reset ends the 18 columns' live range at the choice above, so the rebuild does not have to keep
-            // them beside its own columns (the difference between one and two waves per SIMD)
-            {
+            // Rcpp_reset_local_variables (:1257-1292)
+            if ((iBlock + 1) < n_blocks) {
                 if (!have_al) {
 #pragma unroll
                     for (int h = 0; h < NH; h++) ch.ld(al[h], ch.alpha[h] + (size_t)g * Ksp);
@@ -872,7 +887,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
 #pragma unroll
                     for (int h = 0; h < 3; h++) aS[ir][h] = al[h];
             }
-            inside_l = 0;
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++)
+#pragma unroll
+                for (int h = 0; h < 3; h++) inside[ir][h] = 0;
             for (int g2 = grid_start; g2 <= grid_end; g2++)
 #pragma unroll
                 for (int h = 0; h < 3; h++) logC_before[h] += log(uni_d(&ch.cv[h][g2]));
@@ -888,14 +906,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
 #pragma unroll
             for (int h = 0; h < 3; h++) logC_after[h] -= rl_f64(lg, h);
         }
-        // the next grid's eMatGrid columns straight into e (a block ending here never rewrites grid g + 1): fetched a grid
-        // ahead they were three more columns alive through the whole iteration, one too many for 256 registers; the other
-        // wave of the SIMD runs while these are in flight
-        {
-            const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
 #pragma unroll
-            for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h] + gn);
-        }
+        for (int h = 0; h < NH; h++) e[h] = en[h];
     }
     block_sync();
     // ---- rcpp_sample_H_using_H_class (:213-246)
