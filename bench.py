@@ -234,6 +234,9 @@ def main():
     ap.add_argument("--K", type=int, default=50000)
     ap.add_argument("--nsnps", type=int, default=64000)
     ap.add_argument("--batch", type=int, default=128, help="samples per step per GPU")
+    ap.add_argument("--fuse", type=int, default=None, metavar="N",
+                    help="steps a host thread takes per launch set (default 2; 1 with --mode ont / nipt): 2 x 128 samples are 2 048 "
+                         "Gibbs chains, two per SIMD, which the sampler's 256-register build keeps resident together")
     ap.add_argument("--reads", type=int, default=None, help="reads per sample (default 20000; 300 with --mode ont)")
     ap.add_argument("--mode", choices=["short", "ont", "nipt"], default="short",
                     help="read model (ont: BASELINE configs[3]; nipt: configs[4], method = nipt with ff = 0.2)")
@@ -295,6 +298,9 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if a.workers is None:
         a.workers = 4 if a.mspbwt else 3
+    if a.fuse is None:
+        a.fuse = 2 if a.mode == "short" else 1   # (ONT: short Gibbs launches, NIPT: three labels -- no 256-register build)
+    a.fuse = max(1, a.fuse)
     os.environ.setdefault("QA_HOST_THREADS", str(max(2, (os.cpu_count() or 16) // max(1, local_world * a.workers))))
     params = dict(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
     full_chains = params["nGibbsSamples"] + 1
@@ -380,7 +386,10 @@ def main():
             torch.cuda.synchronize()
 
     def stream(lo, hi):
-        return ((samples[st], (rank * n_steps + st) * a.batch) for st in range(lo, hi))
+        # a host thread takes `fuse` consecutive steps per launch set (their samples' global indices are consecutive)
+        for st in range(lo, hi, a.fuse):
+            top = min(st + a.fuse, hi)
+            yield [smp for q in range(st, top) for smp in samples[q]], (rank * n_steps + st) * a.batch
 
     alone = None
     if native is not None and rank == 0 and not a.no_alone and hasattr(drv, "drivers"):
@@ -403,7 +412,7 @@ def main():
         # the K timed steps are K whole batches: the driver pipelines consecutive batches (phasing rounds of one fused
         # with the main rounds of the next), and the pipeline is filled and drained inside the timed region
         for res in drv.run_stream(stream(a.warmup, n_steps)):
-            last = res
+            last = res[-a.batch:]   # (the results of the last STEP: the tail of the last launch set)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -519,12 +528,15 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                                + ("use_mspbwt=TRUE (mode M2: device haplotype search instead of the full-panel pass)" if a.mspbwt
                                   else "use_mspbwt=FALSE")
                                + (f", impute_rare_common=TRUE with {rc.nSNPs_all} SNPs in all ({rc.nGrids_all} grids)" if rc is not None else ""),
-                   "mode": a.mode, "K": a.K, "nSNPs": a.nsnps, "samples_per_step_per_gpu": a.batch,
+                   "mode": a.mode, "K": a.K, "nSNPs": a.nsnps, "samples_per_step_per_gpu": a.batch, "steps_per_launch_set": a.fuse,
                    "inputs": "host buffers cross PCIe inside the timed region (reads per call, labels, seeds; dosages and top "
                              "lists back): value is the PCIe-inclusive rate",
                    "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
                                   "GPU (" + ("whole batches in turn" if a.split == "alternate" else "every batch cut into one part per thread") +
                                   "), consecutive batches pipelined"
+                                  + (f"; a host thread's launch set carries {a.fuse} steps ({a.fuse * a.batch} samples: "
+                                     f"{a.fuse * a.batch * (params['nGibbsSamples'] + 1)} Gibbs chains with the phasing chains "
+                                     "of the set before it)" if a.fuse > 1 else "")
                                   + ("; device phases: full-panel launch sets exclusive, Gibbs launches that fit run together" if a.exclusive else "")},
     }
     if getattr(a, "bam_load_s", None) is not None:

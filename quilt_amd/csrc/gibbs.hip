@@ -148,8 +148,13 @@ __device__ void backward_both(Chain<NE, NW> &ch) {
     }
 }
 
-template <int NE, int NW>
-__global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
+// LEAN: the build for TWO chains per SIMD (256 registers per wave).  A chain is a serial string of dependent instructions --
+// one wave issues an instruction every ~11 cycles -- and a second wave on the SIMD fills most of the gaps (measured at
+// Ks = 256, whose columns fit 256 registers anyway: 2 048 chains take 1.13 x the time of 1 024).  At 10 rows per lane the
+// sweep therefore gives up what it held for its own latency hiding: the next grid's columns are not fetched a grid ahead
+// (the other wave runs while they arrive).
+template <int NE, int NW, bool LEAN>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : 1))) void k_gibbs(GibbsParams p) {
     __shared__ double s_red[2 * NW * 4];
     const int c = blockIdx.x, t = threadIdx.x;
     using CH = Chain<NE, NW>;
@@ -267,9 +272,10 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
             }
             const int jg = g & 63;
             const bool has = rl_i32(gs.has, jg) != 0;
-            // next grid's eMatGrid and beta columns: issued now, used after this grid's reads
-            Col<NE> en[2], bn[2];
-            {
+            // next grid's eMatGrid and beta columns: issued now, used after this grid's reads (LEAN: fetched at the end of
+            // the iteration, straight into the registers of this grid's)
+            Col<NE> en[LEAN ? 1 : 2], bn[LEAN ? 1 : 2];
+            if constexpr (!LEAN) {
                 const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: loads stay unconditional
                 ch.ldm(en[0], ch.eg[0] + gn);
                 ch.ldm(en[1], ch.eg[1] + gn);
@@ -475,8 +481,16 @@ __global__ __launch_bounds__(64 * NW) void k_gibbs(GibbsParams p) {
                 for (int h = 0; h < 2; h++) ch.stm(a[h], ch.alpha[h] + (size_t)g * Ksp);
             }
             gs.set_c(lane, jg, cg[0], cg[1]);
-            e[0] = en[0]; e[1] = en[1];
-            bt[0] = bn[0]; bt[1] = bn[1];
+            if constexpr (LEAN) {
+                const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
+                ch.ldm(e[0], ch.eg[0] + gn);
+                ch.ldm(e[1], ch.eg[1] + gn);
+                ch.ldm(bt[0], ch.beta[0] + gn);
+                ch.ldm(bt[1], ch.beta[1] + gn);
+            } else {
+                e[0] = en[0]; e[1] = en[1];
+                bt[0] = bn[0]; bt[1] = bn[1];
+            }
         }
         gs.store_c(ch);
         if (rs.base >= 0) rs.store(ch);
@@ -949,9 +963,9 @@ void launch_ematread(const GibbsParams &prm, int maxR, hipStream_t st) {
     QA_HIP(hipGetLastError());
 }
 
-template <int NE, int NW>
+template <int NE, int NW, bool LEAN = false>
 void launch_gibbs_kernel(const GibbsParams &prm, hipStream_t st) {
-    hipLaunchKernelGGL((k_gibbs<NE, NW>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
+    hipLaunchKernelGGL((k_gibbs<NE, NW, LEAN>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
     QA_HIP(hipGetLastError());
 }
 
@@ -971,6 +985,14 @@ int choose_gibbs_waves(int Ksp, int C, int share) {
         if (f == 1 || f == 2 || f == 5 || f == 10) nw = f;
     }
     return nw;
+}
+
+// More chains than SIMDs in one launch: the 256-register build, two chains per SIMD, all of them resident at once (2 048 chains:
+// 1.24 s against 2 x 0.72 s for two launches of the 512-register build; alone on a SIMD the lean build is the slower one,
+// 0.91 s).  QA_GIBBS_LEAN = 1 / 0: test hook forcing / forbidding it.
+bool use_lean_build(int C) {
+    if (const char *f = getenv("QA_GIBBS_LEAN")) return atoi(f) != 0;
+    return C > 1024;
 }
 
 void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *ev, bool want_probs, int nw,
@@ -1004,6 +1026,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
         if (nw == 10) launch_gibbs_kernel<1, 10>(prm, st);
         else if (nw == 5) launch_gibbs_kernel<2, 5>(prm, st);
         else if (nw == 2) launch_gibbs_kernel<5, 2>(prm, st);
+        else if (use_lean_build(prm.C)) launch_gibbs_kernel<10, 1, true>(prm, st);
         else launch_gibbs_kernel<10, 1>(prm, st);
     } else {
         switch (NE1) {
@@ -1451,15 +1474,18 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
         }
         const size_t budget = pn->A().budget_shared(pn->sharers());
-        // device bytes per chain: read emissions -- pattern bytes (<= 2560 B) + table (512 B) per read, a dense Ks-column for
-        // the reads with more bases than the pattern width (an upper bound of those that end up dense) -- and the state matrices
+        // device bytes per chain: read emissions -- pattern bytes + table (512 B) per read, a dense Ks-column for the reads
+        // with more bases than the pattern width (an upper bound of those that end up dense) -- and the state matrices.
+        // Pattern bytes per read: 64 lanes x padb_of(rows per lane) with one wave, 128 x 8 with two (the geometries the
+        // launcher picks: <= 1 024 B); the many-wave geometries of the QA_GIBBS_NW test hook take up to 2 560 B
+        const size_t pat_bytes = getenv("QA_GIBBS_NW") ? 2560 : 1024;
         std::vector<size_t> adds(n_chain);
         for (int c = 0; c < n_chain; c++) {
             const size_t R = read_off[c + 1] - read_off[c];
             const int32_t *rp = read_ptr + read_off[c] + c;
             size_t n_long = 0;
             for (size_t r = 0; r < R; r++) n_long += std::min(rp[r + 1] - rp[r], o->Jmax + 1) > kMaxPatternBits;
-            adds[c] = R * (2560 + 512) + n_long * Ksp * 8 + (size_t)(o->ff != 0.0 ? 9 : 6) * G * Ksp * 8 + (size_t)3 * G * 8 +
+            adds[c] = R * (pat_bytes + 512) + n_long * Ksp * 8 + (size_t)(o->ff != 0.0 ? 9 : 6) * G * Ksp * 8 + (size_t)3 * G * 8 +
                       (want_probs ? (size_t)9 * T * 8 : 0) + 8192;
         }
         // A launch costs a chain's serial latency whatever it carries, so when the chains do not fit one launch they are cut

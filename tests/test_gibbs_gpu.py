@@ -138,6 +138,24 @@ def test_gibbs_every_chain_geometry(medium_panel, oracle, nw, monkeypatch):
         _compare(got, ref, 600)
 
 
+def test_gibbs_two_chains_per_simd_build(medium_panel, oracle, monkeypatch):
+    """A launch with more chains than the device has SIMDs runs the 256-register build of the sampler (two chains per SIMD,
+    no columns fetched a grid ahead); QA_GIBBS_LEAN = 1 forces it for a small launch: the oracle's labels, classes and state,
+    with and without iterative initialisation, shard passes included."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    monkeypatch.setenv("QA_GIBBS_LEAN", "1")
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    s, which, H0, ru, rs, fr = _setup(panel, 37, 600, 900)
+    for init_iter in (False, True):
+        ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter)
+        got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, rs, gibbs_initialize_iteratively=init_iter,
+                                            return_state=True)
+        _compare(got, ref, 600)
+    dev.close()
+
+
 def test_gibbs_edge_inputs(small_panel, oracle):
     """Ragged and degenerate chains in one launch: a single read; all reads in one grid; reads of 6-8 SNPs (dense
     emission columns next to the compact table form); a read whose bases all have zero quality."""
