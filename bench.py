@@ -595,9 +595,10 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
         roof["limited_by"] = ("fp64 VALU issue and dependency latency of one wave per SIMD (a serial chain per Gibbs chain); the "
                               "counters show a fraction of the algorithmic bytes crossing HBM")
     elif dom["kernel"].startswith("k_gibbs"):
-        roof["limited_by"] = ("both: one launch alone is bound by the fp64 VALU issue of its one wave per SIMD (512 chains: 0.59 s, "
-                              "2.9 TB/s of counter traffic); with every SIMD holding a chain the launches together draw the "
-                              "aggregate.hbm_traffic_GBps above from HBM, and a launch then takes 0.7-0.8 s")
+        roof["limited_by"] = ("both: a chain is a serial string of dependent fp64 instructions (one wave issues one every ~11 cycles: "
+                              "1 024 chains, one per SIMD, take 0.72 s); a launch set of 2 048 chains runs the 256-register build, two "
+                              "chains per SIMD filling each other's gaps (1.24 s), and then draws the aggregate.hbm_traffic_GBps "
+                              "above from HBM")
     if dom["serial"] > 0:   # the serial chain's step time and the rate of read visits
         roof["us_per_grid_step"] = 1e3 * dom["ms"] / dom["serial"]
         roof["read_visits_and_grid_steps_per_s"] = dom["units"] / (dom["busy_ms"] / 1e3) if dom["busy_ms"] > 0 else None
