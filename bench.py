@@ -261,6 +261,12 @@ def main():
     ap.add_argument("--exclusive", type=int, default=1, choices=(0, 1),
                     help="exclusive device phases (qa_panel_set_exclusive): every Gibbs launch / full-panel launch set gets the whole "
                          "device and the device-wide arena, the host threads take turns")
+    ap.add_argument("--fuse-tails", type=int, default=1, choices=(0, 1),
+                    help="1: when the stream drains, the host threads' last batches run their phasing rounds together "
+                         "(driver.PhasingTail); 0: each thread runs its own, one after the other")
+    ap.add_argument("--split-remainder", type=int, default=1, choices=(0, 1),
+                    help="1: with --split alternate the launch sets left over when their number is not a multiple of the "
+                         "thread count are cut into one part per thread; 0: they go to the threads in turn like the others")
     ap.add_argument("--gibbs-gate", type=float, default=0.0, metavar="SEC",
                     help="host threads wait up to SEC for each other before a Gibbs launch, so that the two launches overlap fully")
     ap.add_argument("--split", choices=["halves", "alternate"], default="alternate",
@@ -375,7 +381,8 @@ def main():
         native.check(native.lib().qa_set_device(local_rank))
         drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
                             cu_partition=a.cu_partition, fp64_dosage=a.precision != "mixed", split=a.split, gibbs_gate=a.gibbs_gate,
-                            pass_priority=bool(a.pass_priority), exclusive=bool(a.exclusive))
+                            pass_priority=bool(a.pass_priority), exclusive=bool(a.exclusive),
+                            fuse_tails=bool(a.fuse_tails), split_remainder=bool(a.split_remainder))
 
     def barrier():
         if not a.stub:
@@ -537,7 +544,11 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                                   + (f"; a host thread's launch set carries {a.fuse} steps ({a.fuse * a.batch} samples: "
                                      f"{a.fuse * a.batch * (params['nGibbsSamples'] + 1)} Gibbs chains with the phasing chains "
                                      "of the set before it)" if a.fuse > 1 else "")
-                                  + ("; device phases: full-panel launch sets exclusive, Gibbs launches that fit run together" if a.exclusive else "")},
+                                  + ("; device phases: full-panel launch sets exclusive, Gibbs launches that fit run together" if a.exclusive else "")
+                                  + ("; when the stream drains the threads' last batches run their phasing rounds in one launch per round"
+                                     if a.fuse_tails and a.workers > 1 else "")
+                                  + ("; launch sets left over by the thread count are cut into one part per thread"
+                                     if a.split_remainder and a.split == "alternate" and a.workers > 1 else "")},
     }
     if getattr(a, "bam_load_s", None) is not None:
         out["bam_load_ms_per_sample"] = 1e3 * a.bam_load_s

@@ -505,6 +505,52 @@ def get_initial_read_labels_nipt(e: np.ndarray, ff: float, rng: np.random.Genera
     return H
 
 
+class PhasingTail:
+    """Meeting point of the host threads of one device for the END of their streams.
+
+    A thread's stream pipelines batch i's phasing rounds with batch i + 1's main rounds, so the last batch of every thread
+    is left with three rounds of one chain per sample -- a Gibbs launch that costs a chain's serial time for an eighth of
+    the device.  With several threads these tails would run one after the other, each between the launches of the threads
+    still in their main rounds.  Here a thread whose stream has drained leaves its last batch and waits; the thread that
+    drains LAST runs all the tails together (one launch per round) and hands every batch back to its owner, who finishes
+    it (``Driver._finish``) on its own thread.  Results are unchanged: every chain owns its random stream."""
+
+    def __init__(self, n_threads: int):
+        import threading
+        self.lock = threading.Lock()
+        self.n_active = n_threads       # threads that have not drained yet
+        self.waiting = []               # (batch, Future) left by drained threads
+        self.failed: Optional[BaseException] = None
+
+    def drained(self, batch):
+        """Called once per thread when its stream has no main rounds left; ``batch``: its last batch (phasing rounds
+        pending) or None.  Returns (run, fut): the last thread gets ``run`` = every waiting (batch, Future) and runs them with
+        its own; an earlier thread gets ``fut``, resolved (to the batch itself) once its rounds have been run."""
+        from concurrent.futures import Future
+        with self.lock:
+            if self.failed is not None:
+                raise RuntimeError("another host thread of this device failed") from self.failed
+            self.n_active -= 1
+            if self.n_active <= 0:
+                run, self.waiting = self.waiting, []
+                return run, None
+            if batch is None:
+                return [], None
+            fut = Future()
+            self.waiting.append((batch, fut))
+            return None, fut
+
+    def abort(self, exc: BaseException):
+        """A thread failed: nobody may wait for it (or for rounds it had taken over)."""
+        with self.lock:
+            if self.failed is None:
+                self.failed = exc
+            waiting, self.waiting = self.waiting, []
+        for _, fut in waiting:
+            if not fut.done():
+                fut.set_exception(exc)
+
+
 class Driver:
     """Runs ``get_and_impute_one_sample`` (quilt.R:688-996, functions.R:420-1259) for batches of samples, all chains of
     a batch in lock-step.
@@ -538,6 +584,7 @@ class Driver:
         self.n_device_selections = 0     # chains whose next small panel was chosen by csrc/select.hip
         self._zero_hap = None
         self.gibbs_gate = None           # workers.PairGate shared by the host threads of a device, or None
+        self.phasing_tail = None         # PhasingTail shared by the host threads of a device, or None
         self._round_dosages = None
         self._round_dosage_chains = []
 
@@ -883,56 +930,98 @@ class Driver:
 
     def run_stream(self, batches):
         """``batches``: iterable of ``(samples, sample_offset)``; yields one list of SampleResult per batch, in order.
-        The phasing rounds of a batch run fused with the main rounds of the next one (the last batch's run alone)."""
+        The phasing rounds of a batch run fused with the main rounds of the next one; the last batch's run alone, or -- with
+        a :class:`PhasingTail` shared by the host threads of a device -- together with the other threads' last batches."""
+        import time
         P = self.params
         prev: Optional[_Batch] = None
         it = iter(batches)
-        while True:
-            import time
-            nxt = next(it, None)
-            t_nb = time.perf_counter()
-            cur = self._new_batch(*nxt) if nxt is not None else None
-            self.timing["new_batch"] += time.perf_counter() - t_nb
-            if cur is None and prev is None:
-                return
-            for i_it in range(1, P.n_seek_its + 1):
-                chains = (cur.chains if cur else []) + (prev.phasing if prev else [])
-                with span("round"):
-                    stored = self._round(chains, i_it)
-                if stored and cur:   # functions.R:999-1020 (1009-1016: fetus = maternal transmitted + paternal transmitted)
-                    from .io import accumulate_dosage
-                    t_acc = time.perf_counter()
-                    n_cur = len(cur.chains)           # the round's chains: cur's first, then prev's phasing chains
-                    fetal = P.method == "nipt" and not P.impute_rare_common
-                    accumulate_dosage(np.ascontiguousarray(self._round_dosages[:n_cur], dtype=np.float64),
-                                      [ch.i_sample for ch in cur.chains], cur.dosage, cur.gp_t,
-                                      cur.fet_dosage if fetal else None, cur.fet_gp_t if fetal else None)
-                    for ch in cur.chains:
-                        cur.nDosage[ch.i_sample] += 1
-                    self.timing["accumulate"] += time.perf_counter() - t_acc
-            if P.impute_rare_common:   # functions.R:1042-1123
-                self._rare_common_round((cur.chains if cur else []) + (prev.phasing if prev else []))
-                for ch in (cur.chains if cur else []):
-                    h1, h2 = ch.hap_all[0], ch.hap_all[1]
-                    cur.dosage_all[ch.i_sample] += h1 + h2
-                    cur.gp_t_all[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
-                    if P.method == "nipt":   # functions.R:1113-1120
-                        h3 = ch.hap_all[2]
-                        cur.fet_dosage[ch.i_sample] += h1 + h3
-                        cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
-                    cur.nDosage_all[ch.i_sample] += 1
-            t0 = time.perf_counter()
-            with span("finish"):
-                done = self._finish(prev) if prev else None
-            t1 = time.perf_counter()
-            if cur:
-                with span("start_phasing"):
-                    self._start_phasing(cur)
-            self.timing["finish"] += t1 - t0
-            self.timing["consensus"] += time.perf_counter() - t1
-            prev = cur
-            if done is not None:
-                yield done
+        tail = self.phasing_tail
+        reported = False          # this thread has told the tail that its stream drained
+        try:
+            while True:
+                nxt = next(it, None)
+                t_nb = time.perf_counter()
+                cur = self._new_batch(*nxt) if nxt is not None else None
+                self.timing["new_batch"] += time.perf_counter() - t_nb
+                taken = []            # (batch, Future) of other threads' last batches run here
+                if cur is None and tail is not None and not reported:
+                    reported = True
+                    run, fut = tail.drained(prev)
+                    if fut is not None:   # a later thread runs prev's phasing rounds with its own
+                        if self.gibbs_gate is not None and not getattr(self, "_gate_left", False):
+                            self.gibbs_gate.leave()
+                            self._gate_left = True
+                        with span("tail:wait"):
+                            b = fut.result()
+                        t0 = time.perf_counter()
+                        with span("finish"):
+                            done = self._finish(b)
+                        self.timing["finish"] += time.perf_counter() - t0
+                        yield done
+                        return
+                    taken = run
+                if cur is None and prev is None and not taken:
+                    return
+                others = [ch for b, _ in taken for ch in b.phasing]
+                phasing = (prev.phasing if prev else []) + others
+                for i_it in range(1, P.n_seek_its + 1):
+                    chains = (cur.chains if cur else []) + phasing
+                    with span("round"):
+                        stored = self._round(chains, i_it)
+                    if stored and cur:   # functions.R:999-1020 (1009-1016: fetus = maternal transmitted + paternal transmitted)
+                        from .io import accumulate_dosage
+                        t_acc = time.perf_counter()
+                        n_cur = len(cur.chains)           # the round's chains: cur's first, then the phasing chains
+                        fetal = P.method == "nipt" and not P.impute_rare_common
+                        accumulate_dosage(np.ascontiguousarray(self._round_dosages[:n_cur], dtype=np.float64),
+                                          [ch.i_sample for ch in cur.chains], cur.dosage, cur.gp_t,
+                                          cur.fet_dosage if fetal else None, cur.fet_gp_t if fetal else None)
+                        for ch in cur.chains:
+                            cur.nDosage[ch.i_sample] += 1
+                        self.timing["accumulate"] += time.perf_counter() - t_acc
+                if P.impute_rare_common:   # functions.R:1042-1123
+                    self._rare_common_round((cur.chains if cur else []) + phasing)
+                    for ch in (cur.chains if cur else []):
+                        h1, h2 = ch.hap_all[0], ch.hap_all[1]
+                        cur.dosage_all[ch.i_sample] += h1 + h2
+                        cur.gp_t_all[ch.i_sample] += np.stack([(1 - h1) * (1 - h2), (1 - h1) * h2 + h1 * (1 - h2), h1 * h2])
+                        if P.method == "nipt":   # functions.R:1113-1120
+                            h3 = ch.hap_all[2]
+                            cur.fet_dosage[ch.i_sample] += h1 + h3
+                            cur.fet_gp_t[ch.i_sample] += np.stack([(1 - h1) * (1 - h3), (1 - h1) * h3 + h1 * (1 - h3), h1 * h3])
+                        cur.nDosage_all[ch.i_sample] += 1
+                # The other threads' batches go back to their owners, who finish them on their own threads.  Their phasing
+                # chains' dosages are rows of THIS backend's transfer buffer: it is not written again before the owners are
+                # done (this thread has no round left, and a later stream starts only after every result was handed out).
+                for b, fut in taken:
+                    fut.set_result(b)
+                t0 = time.perf_counter()
+                with span("finish"):
+                    done = self._finish(prev) if prev else None
+                t1 = time.perf_counter()
+                if cur:
+                    with span("start_phasing"):
+                        self._start_phasing(cur)
+                self.timing["finish"] += t1 - t0
+                self.timing["consensus"] += time.perf_counter() - t1
+                prev = cur
+                if done is not None:
+                    yield done
+        except BaseException as e:
+            if tail is not None and not isinstance(e, GeneratorExit):
+                tail.abort(e)
+            raise
+        finally:
+            if tail is not None and not reported:   # (a consumer that stopped early: the others must not wait for this thread)
+                try:
+                    run, _ = tail.drained(None)
+                    if run:
+                        err = RuntimeError("the thread that would have run the last batches' phasing rounds stopped early")
+                        for _, fut in run:
+                            fut.set_exception(err)
+                except RuntimeError:
+                    pass
 
     def run(self, samples, sample_offset: int = 0) -> List[SampleResult]:
         """One batch.  ``sample_offset``: global index of ``samples[0]`` (keys the random streams, so that a sample

@@ -13,7 +13,7 @@ import queue
 import threading
 from typing import Iterable, List, Optional, Tuple
 
-from .driver import Driver, DriverParams, HipBackend
+from .driver import Driver, DriverParams, HipBackend, PhasingTail
 from .native import DevicePanel, DeviceRareCommon
 from .sharding import get_sample_range
 
@@ -61,8 +61,12 @@ class PairGate:
 class DeviceWorkers:
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 2, rare_common=None,
                  cu_partition: bool = False, fp64_dosage: bool = False, split: str = "halves", gibbs_gate: float = 0.0,
-                 pass_priority: bool = False, exclusive: bool = False):
+                 pass_priority: bool = False, exclusive: bool = False, fuse_tails: bool = True,
+                 split_remainder: bool = True):
         self.n = n_workers
+        self.split_remainder = split_remainder   # split = "alternate": left-over batches are cut into one part per thread
+        # the last batches' phasing rounds of all threads run together (driver.PhasingTail) instead of one after the other
+        self.fuse_tails = fuse_tails and n_workers > 1
         # "halves": every batch is cut into one contiguous part per thread; "alternate": whole batches go to the threads in turn
         # (a thread's Gibbs launch then carries a whole batch's chains -- 1 024 at the defaults, one per SIMD -- instead of half)
         if split not in ("halves", "alternate"):
@@ -114,24 +118,54 @@ class DeviceWorkers:
         outs = [queue.Queue() for _ in range(self.n)]
         if self.drivers[0].gibbs_gate is not None:
             self.drivers[0].gibbs_gate.reset(self.n)
+        tail = PhasingTail(self.n) if self.fuse_tails else None
+        for d in self.drivers:
+            d.phasing_tail = tail
+            d._gate_left = False
         if self.split == "alternate":
+            # Whole batches in turn; the batches left over when their number is not a multiple of the thread count (the
+            # stragglers at the end of a finite stream) are cut into one part per thread instead: a straggler alone on one
+            # thread would expose that thread's host phases between its launch sets, with the other threads idle.
+            n_full = len(batches) // self.n * self.n if self.split_remainder else len(batches)
+            if n_full == 0:
+                n_full = len(batches)
+            rest = batches[n_full:]
+
+            def parts_of(w: int):
+                for samples, offset in rest:
+                    lo, hi = get_sample_range(len(samples), self.n)[w]
+                    if hi > lo:
+                        yield samples[lo:hi], offset + lo
+
             def work_alt(w: int):
                 try:
-                    for res in self.drivers[w].run_stream(batches[w::self.n]):
+                    for res in self.drivers[w].run_stream(batches[w:n_full:self.n] + list(parts_of(w))):
                         outs[w].put(res)
                 except BaseException as e:   # surfaced by the consumer
+                    if tail is not None:
+                        tail.abort(e)
                     outs[w].put(e)
                 finally:
-                    if self.drivers[w].gibbs_gate is not None:
+                    if self.drivers[w].gibbs_gate is not None and not self.drivers[w]._gate_left:
                         self.drivers[w].gibbs_gate.leave()
             threads = [threading.Thread(target=work_alt, args=(w,), daemon=True) for w in range(self.n)]
             for t in threads:
                 t.start()
-            for i in range(len(batches)):
-                res = outs[i % self.n].get()
+
+            def take(w: int):
+                res = outs[w].get()
                 if isinstance(res, BaseException):
                     raise res
-                yield res
+                return res
+            for i in range(n_full):
+                yield take(i % self.n)
+            for samples, _ in rest:
+                merged: List = []
+                for w in range(self.n):
+                    lo, hi = get_sample_range(len(samples), self.n)[w]
+                    if hi > lo:
+                        merged.extend(take(w))
+                yield merged
             for t in threads:
                 t.join()
             return
@@ -145,9 +179,11 @@ class DeviceWorkers:
                 for res in self.drivers[w].run_stream(p for p in parts() if len(p[0]) > 0):
                     outs[w].put(res)
             except BaseException as e:   # surfaced by the consumer
+                if tail is not None:
+                    tail.abort(e)
                 outs[w].put(e)
             finally:
-                if self.drivers[w].gibbs_gate is not None:
+                if self.drivers[w].gibbs_gate is not None and not self.drivers[w]._gate_left:
                     self.drivers[w].gibbs_gate.leave()
 
         threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(self.n)]

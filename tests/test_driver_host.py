@@ -447,3 +447,127 @@ def test_pair_gate_lets_a_finished_thread_leave():
     t0 = time.perf_counter()
     short = PairGate(2, timeout=0.2)
     assert short.wait() is False and time.perf_counter() - t0 >= 0.19   # nobody came: goes alone after the timeout
+
+
+def _threads_over_streams(panel, prm, streams, tail, fail_in=None):
+    """One Driver (oracle backend) per stream, each on its own host thread, sharing ``tail`` -- what DeviceWorkers does."""
+    import threading
+    from tests.oracle_backend import OracleBackend
+    out, err = [None] * len(streams), [None] * len(streams)
+
+    def work(w):
+        try:
+            drv = D.Driver(panel, OracleBackend(panel), prm)
+            drv.phasing_tail = tail
+            if fail_in == w:
+                def boom(*a, **k):
+                    raise RuntimeError("injected")
+                drv._round = boom
+            out[w] = list(drv.run_stream(streams[w]))
+        except BaseException as e:
+            err[w] = e
+
+    th = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(len(streams))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+        assert not t.is_alive(), "a host thread is still waiting at the tail"
+    return out, err
+
+
+@pytest.mark.parametrize("shape", ["4 batches over 3 threads", "2 batches over 3 threads", "even"])
+def test_last_batches_phasing_rounds_fused_across_threads(shape):
+    """PhasingTail: the threads' last batches leave their phasing rounds to the thread that drains last; per-sample results
+    are those of separate runs, every batch comes back through its own thread's stream."""
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=400, nSNPs=320, seed=22)
+    samples = [make_synthetic_sample(panel, seed=70 + i, n_reads=50) for i in range(6)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=4)
+    if shape == "4 batches over 3 threads":
+        streams = [[(samples[0:2], 0), (samples[4:5], 4)], [(samples[2:3], 2)], [(samples[3:4], 3)]]
+    elif shape == "2 batches over 3 threads":
+        streams = [[(samples[0:2], 0)], [(samples[2:5], 2)], []]
+    else:
+        streams = [[(samples[0:3], 0)], [(samples[3:6], 3)]]
+    tail = D.PhasingTail(len(streams))
+    seen_rounds = []
+    orig = D.Driver._round
+
+    def spy(self, chains, i_it):
+        seen_rounds.append((i_it, sum(ch.phasing for ch in chains), len(chains)))
+        return orig(self, chains, i_it)
+    D.Driver._round = spy
+    try:
+        out, err = _threads_over_streams(panel, prm, streams, tail)
+    finally:
+        D.Driver._round = orig
+    assert all(e is None for e in err), err
+    for st, got in zip(streams, out):
+        assert [len(b) for b in got] == [len(s) for s, _ in st]
+        for (smp, off), res in zip(st, got):
+            ref = D.Driver(panel, OracleBackend(panel), prm).run(smp, sample_offset=off)
+            for g, r in zip(res, ref):
+                assert np.array_equal(g.read_labels, r.read_labels) and g.nDosage == r.nDosage
+                assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
+                assert np.array_equal(g.gp_t, r.gp_t)
+    # exactly one set of phasing-only rounds, carrying the last batch of every thread that had one
+    only = [r for r in seen_rounds if r[1] == r[2]]
+    n_last = sum(len(st[-1][0]) for st in streams if st)
+    assert sorted(only) == [(i, n_last, n_last) for i in (1, 2, 3)]
+
+
+def test_tail_failure_reaches_the_waiting_threads():
+    """A thread that fails must not leave the others waiting for rounds nobody will run."""
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=400, nSNPs=320, seed=22)
+    samples = [make_synthetic_sample(panel, seed=70 + i, n_reads=50) for i in range(3)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=4)
+    streams = [[(samples[0:1], 0)], [(samples[1:2], 1), (samples[2:3], 2)]]
+    out, err = _threads_over_streams(panel, prm, streams, D.PhasingTail(2), fail_in=1)
+    assert isinstance(err[1], RuntimeError) and isinstance(err[0], RuntimeError)
+    # ... and a consumer that stops early counts as drained
+    tail = D.PhasingTail(2)
+    from tests.oracle_backend import OracleBackend
+    drv = D.Driver(panel, OracleBackend(panel), prm)
+    drv.phasing_tail = tail
+    g = drv.run_stream([(samples[0:1], 0), (samples[1:2], 1)])
+    next(g)
+    g.close()
+    assert tail.n_active == 1
+
+
+@pytest.mark.parametrize("n_batches", [4, 5, 2])
+def test_workers_cut_the_left_over_batches_into_parts(n_batches):
+    """DeviceWorkers.run_stream, split = "alternate": whole batches in turn, the batches left over by the thread count cut
+    into one part per thread (a part may be empty); every batch comes back whole, in order, with the results of separate
+    runs.  (The workers object is built around oracle-backed drivers: the threading logic needs no device.)"""
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from quilt_amd.workers import DeviceWorkers
+    from tests.oracle_backend import OracleBackend
+    panel = make_synthetic_panel(K=400, nSNPs=320, seed=23)
+    samples = [make_synthetic_sample(panel, seed=90 + i, n_reads=40) for i in range(9)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=6)
+    cuts = {4: [0, 2, 3, 5, 9], 5: [0, 2, 3, 5, 7, 9], 2: [0, 4, 9]}[n_batches]
+    batches = [(samples[a:b], a) for a, b in zip(cuts[:-1], cuts[1:])]
+    wk = object.__new__(DeviceWorkers)
+    wk.n, wk.split, wk.fuse_tails, wk.split_remainder = 3, "alternate", True, True
+    wk.drivers = [D.Driver(panel, OracleBackend(panel), prm) for _ in range(3)]
+    taken = [[] for _ in range(3)]
+    for w, d in enumerate(wk.drivers):
+        orig = d._new_batch
+        d._new_batch = (lambda samples, offset, _o=orig, _w=w: (taken[_w].append((offset, len(samples))), _o(samples, offset))[1])
+    got = list(wk.run_stream(batches))
+    assert [len(g) for g in got] == [len(s) for s, _ in batches]
+    if n_batches == 4:      # three whole batches in turn, the fourth (4 samples at offset 5) cut 1 + 2 + 1 (sharding.get_sample_range)
+        assert taken == [[(0, 2), (5, 1)], [(2, 1), (6, 2)], [(3, 2), (8, 1)]]
+    elif n_batches == 5:    # two left over, each cut into three parts: 1 + 1 + 0 samples each
+        assert taken == [[(0, 2), (5, 1), (7, 1)], [(2, 1), (6, 1), (8, 1)], [(3, 2)]]
+    else:                   # fewer batches than threads: nothing to cut
+        assert taken == [[(0, 4)], [(4, 5)], []]
+    for (smp, off), res in zip(batches, got):
+        ref = D.Driver(panel, OracleBackend(panel), prm).run(smp, sample_offset=off)
+        for g, r in zip(res, ref):
+            assert np.array_equal(g.read_labels, r.read_labels)
+            assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
