@@ -130,9 +130,17 @@ class DeviceWorkers:
             if n_full == 0:
                 n_full = len(batches)
             rest = batches[n_full:]
+            # left-over batches whose samples are consecutive (offset + length = the next one's offset) are cut as ONE run
+            # of samples -- two left-over batches over four threads make four launches' worth, not eight small ones
+            runs: List[Tuple[list, int, List[int]]] = []     # (samples, offset, lengths of the batches in the run)
+            for samples, offset in rest:
+                if runs and runs[-1][1] + len(runs[-1][0]) == offset:
+                    runs[-1] = (runs[-1][0] + list(samples), runs[-1][1], runs[-1][2] + [len(samples)])
+                else:
+                    runs.append((list(samples), offset, [len(samples)]))
 
             def parts_of(w: int):
-                for samples, offset in rest:
+                for samples, offset, _ in runs:
                     lo, hi = get_sample_range(len(samples), self.n)[w]
                     if hi > lo:
                         yield samples[lo:hi], offset + lo
@@ -159,13 +167,16 @@ class DeviceWorkers:
                 return res
             for i in range(n_full):
                 yield take(i % self.n)
-            for samples, _ in rest:
+            for samples, _, lengths in runs:
                 merged: List = []
                 for w in range(self.n):
                     lo, hi = get_sample_range(len(samples), self.n)[w]
                     if hi > lo:
                         merged.extend(take(w))
-                yield merged
+                at = 0
+                for n_b in lengths:     # back to the caller's batches
+                    yield merged[at:at + n_b]
+                    at += n_b
             for t in threads:
                 t.join()
             return

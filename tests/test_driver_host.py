@@ -538,7 +538,7 @@ def test_tail_failure_reaches_the_waiting_threads():
     assert tail.n_active == 1
 
 
-@pytest.mark.parametrize("n_batches", [4, 5, 2])
+@pytest.mark.parametrize("n_batches", [4, 5, 2, -5])
 def test_workers_cut_the_left_over_batches_into_parts(n_batches):
     """DeviceWorkers.run_stream, split = "alternate": whole batches in turn, the batches left over by the thread count cut
     into one part per thread (a part may be empty); every batch comes back whole, in order, with the results of separate
@@ -549,8 +549,10 @@ def test_workers_cut_the_left_over_batches_into_parts(n_batches):
     panel = make_synthetic_panel(K=400, nSNPs=320, seed=23)
     samples = [make_synthetic_sample(panel, seed=90 + i, n_reads=40) for i in range(9)]
     prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=6)
-    cuts = {4: [0, 2, 3, 5, 9], 5: [0, 2, 3, 5, 7, 9], 2: [0, 4, 9]}[n_batches]
+    cuts = {4: [0, 2, 3, 5, 9], 5: [0, 2, 3, 5, 7, 9], 2: [0, 4, 9]}[abs(n_batches)]
     batches = [(samples[a:b], a) for a, b in zip(cuts[:-1], cuts[1:])]
+    if n_batches < 0:       # the last batch's samples do not follow the one before it: the left-overs are cut one by one
+        batches[-1] = (batches[-1][0], 100)
     wk = object.__new__(DeviceWorkers)
     wk.n, wk.split, wk.fuse_tails, wk.split_remainder = 3, "alternate", True, True
     wk.drivers = [D.Driver(panel, OracleBackend(panel), prm) for _ in range(3)]
@@ -562,8 +564,10 @@ def test_workers_cut_the_left_over_batches_into_parts(n_batches):
     assert [len(g) for g in got] == [len(s) for s, _ in batches]
     if n_batches == 4:      # three whole batches in turn, the fourth (4 samples at offset 5) cut 1 + 2 + 1 (sharding.get_sample_range)
         assert taken == [[(0, 2), (5, 1)], [(2, 1), (6, 2)], [(3, 2), (8, 1)]]
-    elif n_batches == 5:    # two left over, each cut into three parts: 1 + 1 + 0 samples each
-        assert taken == [[(0, 2), (5, 1), (7, 1)], [(2, 1), (6, 1), (8, 1)], [(3, 2)]]
+    elif n_batches == 5:    # two left over, consecutive samples: cut as one run of four samples, 1 + 2 + 1
+        assert taken == [[(0, 2), (5, 1)], [(2, 1), (6, 2)], [(3, 2), (8, 1)]]
+    elif n_batches == -5:   # two left over, not consecutive: 2 samples each over three threads, 1 + 1 + 0
+        assert taken == [[(0, 2), (5, 1), (100, 1)], [(2, 1), (6, 1), (101, 1)], [(3, 2)]]
     else:                   # fewer batches than threads: nothing to cut
         assert taken == [[(0, 4)], [(4, 5)], []]
     for (smp, off), res in zip(batches, got):
