@@ -460,6 +460,18 @@ def main():
                                                                     "max_abs_diff": float(np.abs(a_ - b_).max())}
         if cpu_pipeline is not None:
             out["dosage_r2_vs_cpu_pipeline"] = r2_vs_cpu_pipeline(cpu_pipeline, main_reg["last"])
+            if out.get("cpu_baseline"):
+                # the composed figure checked against WHOLE samples: the r2 leg runs n samples through the whole per-sample
+                # pipeline on the CPU path (all chains, all rounds) on `threads` cores
+                n_, sec, thr = cpu_pipeline["n"], cpu_pipeline["cpu_seconds"], cpu_pipeline["threads"]
+                cores = out["cpu_baseline"]["cores"]
+                out["cpu_baseline"]["whole_sample_check"] = {
+                    "what": f"{n_} whole sample(s) through the entire per-sample pipeline on the CPU path (the dosage_r2_vs_cpu_pipeline "
+                            f"leg), its chains on {thr} threads: seconds, and the samples/sec that rate would give on all {cores} cores "
+                            "if it scaled with the cores (it has the device-free host logic of the driver in it, which the composed "
+                            "figure leaves out)",
+                    "samples": n_, "seconds": sec, "threads": thr,
+                    "samples_per_sec_scaled_to_cores": round(n_ / max(sec, 1e-9) * cores / thr, 3)}
             if mixed_reg is not None:
                 out["mixed_precision"]["dosage_r2_vs_cpu_pipeline"] = r2_vs_cpu_pipeline(cpu_pipeline, mixed_reg["last"])
         print(json.dumps(out))

@@ -585,6 +585,7 @@ class Driver:
         self._zero_hap = None
         self.gibbs_gate = None           # workers.PairGate shared by the host threads of a device, or None
         self.phasing_tail = None         # PhasingTail shared by the host threads of a device, or None
+        self.on_first_launch = None      # called once, right before this driver's next Gibbs call (workers: staggered start)
         self._round_dosages = None
         self._round_dosage_chains = []
 
@@ -787,6 +788,9 @@ class Driver:
                 if self.gibbs_gate is not None and n_try == 0:
                     self.gibbs_gate.wait()   # start together with the other host thread's launch (workers.PairGate)
                 self.n_gibbs_chain_calls += len(idx)
+                if self.on_first_launch is not None:
+                    cb, self.on_first_launch = self.on_first_launch, None
+                    cb()
                 out = self.backend.gibbs_batch(
                     [samples[i] for i in idx], [chains[i].which_haps_to_use for i in idx],
                     [starts[i] for i in idx], [seed_reads[i] for i in idx], [first_reads[i] for i in idx],

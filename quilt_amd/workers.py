@@ -122,6 +122,16 @@ class DeviceWorkers:
         for d in self.drivers:
             d.phasing_tail = tail
             d._gate_left = False
+        # Staggered start: thread w prepares its first launch once thread w - 1 has handed its own to the device.  The
+        # preparation (thousands of per-chain draws) is interpreter work: started together, the threads share the interpreter
+        # lock and the first launch leaves when ALL of them are done, n times later than it needs to.
+        started = [threading.Event() for _ in range(self.n)]
+        for w, d in enumerate(self.drivers):
+            d.on_first_launch = started[w].set
+
+        def my_turn(w: int):
+            if w > 0:
+                started[w - 1].wait(5.0)
         if self.split == "alternate":
             # Whole batches in turn; the batches left over when their number is not a multiple of the thread count (the
             # stragglers at the end of a finite stream) are cut into one part per thread instead: a straggler alone on one
@@ -147,6 +157,7 @@ class DeviceWorkers:
 
             def work_alt(w: int):
                 try:
+                    my_turn(w)
                     for res in self.drivers[w].run_stream(batches[w:n_full:self.n] + list(parts_of(w))):
                         outs[w].put(res)
                 except BaseException as e:   # surfaced by the consumer
@@ -154,6 +165,7 @@ class DeviceWorkers:
                         tail.abort(e)
                     outs[w].put(e)
                 finally:
+                    started[w].set()
                     if self.drivers[w].gibbs_gate is not None and not self.drivers[w]._gate_left:
                         self.drivers[w].gibbs_gate.leave()
             threads = [threading.Thread(target=work_alt, args=(w,), daemon=True) for w in range(self.n)]
@@ -187,6 +199,7 @@ class DeviceWorkers:
                     lo, hi = get_sample_range(len(samples), self.n)[w]
                     yield samples[lo:hi], offset + lo
             try:
+                my_turn(w)
                 for res in self.drivers[w].run_stream(p for p in parts() if len(p[0]) > 0):
                     outs[w].put(res)
             except BaseException as e:   # surfaced by the consumer
@@ -194,6 +207,7 @@ class DeviceWorkers:
                     tail.abort(e)
                 outs[w].put(e)
             finally:
+                started[w].set()
                 if self.drivers[w].gibbs_gate is not None and not self.drivers[w]._gate_left:
                     self.drivers[w].gibbs_gate.leave()
 

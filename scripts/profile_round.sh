@@ -43,6 +43,7 @@ if [[ $WHAT == all || $WHAT == lines ]]; then
 python bench.py --mode ont --steps 12 --warmup 4 --r2-vs-cpu 0 > $OUT/bench_line_ont.json 2> $OUT/bench_ont.err; tail -c 300 $OUT/bench_line_ont.json
 python bench.py --mode nipt --steps 12 --warmup 4 --r2-vs-cpu 0 > $OUT/bench_line_nipt.json 2> $OUT/bench_nipt.err; tail -c 300 $OUT/bench_line_nipt.json
 python bench.py --mspbwt --steps 12 --warmup 4 > $OUT/bench_line_mspbwt.json 2> $OUT/bench_mspbwt.err; tail -c 300 $OUT/bench_line_mspbwt.json
+python bench.py --mspbwt --steps 20 --warmup 5 --no-alone --precision fp64 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_mspbwt_steps20.json 2> $OUT/bench_mspbwt20.err; tail -c 300 $OUT/bench_line_mspbwt_steps20.json
 python bench.py --bam --steps 12 --warmup 4 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_from_bam.json 2> $OUT/bench_from_bam.err; tail -c 300 $OUT/bench_line_from_bam.json
 python bench.py --K 5000 --batch 32 --steps 12 --warmup 4 > $OUT/bench_line_configs1_K5000_b32.json 2> $OUT/bench_configs1.err; tail -c 300 $OUT/bench_line_configs1_K5000_b32.json
 python bench.py --exclusive 0 --workers 4 --steps 20 --warmup 5 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_no_device_phases.json 2> $OUT/bench_nophases.err; tail -c 300 $OUT/bench_line_no_device_phases.json
