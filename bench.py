@@ -280,6 +280,9 @@ def main():
     ap.add_argument("--gate-trace", default=None, metavar="NPY",
                     help="write the device gate's hold trace of the (first) timed region (request, admit, kernels done, release, "
                          "SIMD slots, thread) to this .npy file")
+    ap.add_argument("--pageable", action="store_true",
+                    help="the driver's large transfer buffers as ordinary (pageable) memory instead of qa_host_alloc: the staged path "
+                         "a caller that cannot allocate through the library gets (the R shim: R owns its vectors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan-check", action="store_true",
                     help="--mspbwt: skip the comparison of the device search with the msPBWT neighbour scan (CPU, ~20 s)")
@@ -304,6 +307,8 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if a.workers is None:
         a.workers = 4 if a.mspbwt else 3
+    if a.pageable:
+        os.environ["QUILT_AMD_PAGEABLE"] = "1"
     if a.fuse is None:
         a.fuse = 2 if a.mode == "short" else 1   # (ONT: short Gibbs launches, NIPT: three labels -- no 256-register build)
     a.fuse = max(1, a.fuse)
@@ -549,7 +554,9 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                                + (f", impute_rare_common=TRUE with {rc.nSNPs_all} SNPs in all ({rc.nGrids_all} grids)" if rc is not None else ""),
                    "mode": a.mode, "K": a.K, "nSNPs": a.nsnps, "samples_per_step_per_gpu": a.batch, "steps_per_launch_set": a.fuse,
                    "inputs": "host buffers cross PCIe inside the timed region (reads per call, labels, seeds; dosages and top "
-                             "lists back): value is the PCIe-inclusive rate",
+                             "lists back): value is the PCIe-inclusive rate"
+                             + ("; --pageable: the dosage rounds come back into pageable memory through the library's staging copy"
+                                if a.pageable else ""),
                    "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
                                   "GPU (" + ("whole batches in turn" if a.split == "alternate" else "every batch cut into one part per thread") +
                                   "), consecutive batches pipelined"

@@ -40,14 +40,18 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // k_emat: emission tables.  One block per (grid, pass); thread d computes the fp64 emission of
 // distinct word d-1 (reference-single.cpp:294-327), the block finds min / max, applies
-// normalize_emissions (:985-990) and writes fp32.  Row 0 is written as 0: haplotypes with code 0
+// normalize_emissions (:985-990) and writes the table.  Row 0 is written as 0: haplotypes with code 0
 // ("specials") get their own emission from `esp` (:1002-1042).
+// The per-SNP factors of the words' products are formed once per block (they do not depend on the
+// word) and the block's min / max are wave reductions plus one 4-entry exchange (min and max are
+// exact: any order gives the same value) -- the first form of this kernel evaluated the factors per
+// word and SNP and ran three 8-step LDS trees with a barrier per step.
 // ---------------------------------------------------------------------------------------------
 template <typename TS>
 __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     const int g = blockIdx.x, p = blockIdx.y, t = threadIdx.x;
-    __shared__ double2 s_gl[32];
-    __shared__ double s_red[256];
+    __shared__ double2 s_e[32];
+    __shared__ double s_red[3][4];
     __shared__ int s_var;
     const int s = 32 * g;
     const int nLocal = min(32, prm.T - s);
@@ -55,8 +59,9 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     if (t == 0) s_var = 0;
     __syncthreads();
     if (t < nLocal) {
-        double2 v = gl[t];
-        s_gl[t] = v;
+        const double2 v = gl[t];   // x = P(reads | ref), y = P(reads | alt)
+        const double eps = prm.ref_error, ome = 1.0 - eps;
+        s_e[t] = make_double2(v.x * ome + v.y * eps, v.x * eps + v.y * ome);
         if (v.x != 1.0 || v.y != 1.0) s_var = 1;  // benign race: all writers store 1
     }
     __syncthreads();
@@ -74,28 +79,19 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
         if (prm.lazy && t == 0) prm.emin[(size_t)p * prm.G + g] = -1.0;   // "no variant": the forward takes the shortcut
         return;  // (never taken for g == 0)
     }
+    const bool row = t >= 1 && t < prm.nrow;
     double e = 0;
-    if (t >= 1 && t < prm.nrow) {
-        uint32_t w = (uint32_t)prm.B[(size_t)g * prm.nMaxDH + (t - 1)];
-        e = word_emission(w, s_gl, nLocal, prm.ref_error);
-    }
-    // min over rows 1..nMaxDH (row 0 of the reference's table starts at 1 and takes the min)
-    s_red[t] = (t >= 1 && t < prm.nrow) ? e : 1.0;
+    if (row) e = word_emission((uint32_t)prm.B[(size_t)g * prm.nMaxDH + (t - 1)], s_e, nLocal);
+    // min over rows 1..nMaxDH (row 0 of the reference's table starts at 1 and takes the min), then the max with row 0 in it
+    const int wv = t >> 6;
+    const double wmin = wave_min(row ? e : 1.0);
+    if ((t & 63) == 0) s_red[0][wv] = wmin;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) s_red[t] = fmin(s_red[t], s_red[t + o]);
-        __syncthreads();
-    }
-    const double row0 = s_red[0];
+    const double row0 = fmin(fmin(s_red[0][0], s_red[0][1]), fmin(s_red[0][2], s_red[0][3]));
+    const double wmax = wave_max(row ? e : row0);
+    if ((t & 63) == 0) s_red[1][wv] = wmax;
     __syncthreads();
-    s_red[t] = (t >= 1 && t < prm.nrow) ? e : row0;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (t < o) s_red[t] = fmax(s_red[t], s_red[t + o]);
-        __syncthreads();
-    }
-    const double emax = s_red[0];
-    __syncthreads();
+    const double emax = fmax(fmax(s_red[1][0], s_red[1][1]), fmax(s_red[1][2], s_red[1][3]));
     double scale = 1.0, sp_scale = 1.0;
     if (prm.normalize_emissions) {
         if (emax < 1.0) scale = 1.0 / emax;
@@ -115,20 +111,18 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
     out[t] = t >= prm.nrow ? TS(0) : (t == 0) ? (sn > 0 ? TS(1) : TS(0)) : (TS)(e * scale);   // kMaxRow == blockDim
     double sp_min = 2.0;
     for (int i = t; i < sn; i += 256) {
-        double es = word_emission(prm.sp_word[so + i], s_gl, nLocal, prm.ref_error) * sp_scale;
+        double es = word_emission(prm.sp_word[so + i], s_e, nLocal) * sp_scale;
         esp_out[i] = (TS)es;
         sp_min = fmin(sp_min, es);
     }
     if (prm.lazy) {
         // min_emission_prob of the grid (:1044-1057): the smallest table row after normalisation (row 0 holds the column
         // minimum, the initial 1 included), then the specials
-        s_red[t] = sp_min;
+        const double wsp = wave_min(sp_min);
+        if ((t & 63) == 0) s_red[2][wv] = wsp;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (t < o) s_red[t] = fmin(s_red[t], s_red[t + o]);
-            __syncthreads();
-        }
-        if (t == 0) prm.emin[(size_t)p * prm.G + g] = fmin(row0 * scale, s_red[0]);
+        if (t == 0)
+            prm.emin[(size_t)p * prm.G + g] = fmin(row0 * scale, fmin(fmin(s_red[2][0], s_red[2][1]), fmin(s_red[2][2], s_red[2][3])));
     }
 }
 
@@ -656,55 +650,93 @@ __global__ __launch_bounds__(256) void k_topk(PassParams prm, int NT) {
 
 // ---------------------------------------------------------------------------------------------
 // k_dosage: dosage[32g + b] = sigma_g * ( sum_d IE[d, 32g+b] * mg[d] + sum_specials gamma * (bit ? 1-eps : eps) )
-// (reference-single.cpp:2092-2139).  One block of 32 x 8 threads per (grid, pass).
+// (reference-single.cpp:2092-2139).
+// One wave per four consecutive grids, a lane per (grid, pair of SNPs): the wave's 128 dosages are 1 KiB of consecutive
+// memory, stored with one instruction (16 bytes per lane), a block's four waves write 4 KiB -- the rows usually lie in the
+// caller's pinned buffer, across PCIe.  (The first form ran one block of 32 x 8 threads per grid, 256 bytes per block:
+// 512 000 blocks per 256 passes, 8 ms per launch for 131 MB.)  The sums keep that form's order: the codes d = 1 + q,
+// 9 + q, ... into partial sum q (q = 0..7), the partial sums added in order.
 // ---------------------------------------------------------------------------------------------
+constexpr int kDosageGridsPerBlock = 16;
+
 template <typename TS>
 __global__ __launch_bounds__(256) void k_dosage(PassParams prm) {
     using Hist = typename Vec<TS>::Hist;
-    const int g = blockIdx.x, p = blockIdx.y;
+    const int p = blockIdx.y;
     if (!(prm.flags[p] & 1)) return;
-    const int b = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts
-    __shared__ double s_acc[8][32], s_tot[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * kDosageGridsPerBlock + wave * 4 + (lane >> 4);
+    if (g >= prm.G) return;                 // (no barrier below)
+    const int b0 = 2 * (lane & 15), b1 = b0 + 1;   // this lane's SNPs of the grid
     const int s = 32 * g;
     const int nLocal = min(32, prm.T - s);
     const Hist *mg = static_cast<const Hist *>(prm.mg) + ((size_t)p * prm.G + g) * kMaxRow;
     const double eps = prm.ref_error, ome = 1.0 - eps;
     const double unit = sizeof(TS) == 8 ? prm.hist_unit : 1.0 / (double)kHistScale;
-    double acc = 0, acc_sp = 0;   // histogram part (already times sigma_g) and specials (raw gamma)
-    if (b < nLocal) {
-        for (int d = 1 + part; d < prm.nrow; d += 8) {
-            double ie;
-            if (prm.IE) {
-                ie = prm.IE[(size_t)(s + b) * prm.nMaxDH + (d - 1)];
-            } else {
-                const uint32_t w = (uint32_t)prm.B[(size_t)g * prm.nMaxDH + (d - 1)];
-                ie = ((w >> b) & 1u) ? ome : eps;
+    // per partial sum q: histogram part (already times sigma_g) of both SNPs, specials (raw gamma), the grid's mass
+    double acc0[8], acc1[8], sp0[8], sp1[8], mass[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc0[q] = acc1[q] = sp0[q] = sp1[q] = mass[q] = 0;
+    const int32_t *Bg = prm.B + (size_t)g * prm.nMaxDH;
+    const double *IE0 = prm.IE ? prm.IE + (size_t)(s + min(b0, nLocal - 1)) * prm.nMaxDH : nullptr;
+    const double *IE1 = prm.IE ? prm.IE + (size_t)(s + min(b1, nLocal - 1)) * prm.nMaxDH : nullptr;
+    mass[0] += (double)mg[0] * unit;        // bin 0 holds the specials' share of the grid's total gamma * sigma
+    for (int d0 = 1; d0 < prm.nrow; d0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int d = d0 + q;
+            if (d < prm.nrow) {
+                const double m = (double)mg[d] * unit;
+                mass[(q + 1) & 7] += m;     // (d & 7: d0 = 1 mod 8)
+                double ie0, ie1;
+                if (prm.IE) {
+                    ie0 = IE0[d - 1];
+                    ie1 = IE1[d - 1];
+                } else {
+                    const uint32_t w = (uint32_t)Bg[d - 1];
+                    ie0 = ((w >> b0) & 1u) ? ome : eps;
+                    ie1 = ((w >> b1) & 1u) ? ome : eps;
+                }
+                acc0[q] += ie0 * m;
+                acc1[q] += ie1 * m;
             }
-            acc += ie * ((double)mg[d] * unit);
-        }
-        const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
-        for (int i = part; i < sn; i += 8) {
-            const double gk = (double)static_cast<const TS *>(prm.gsp)[(size_t)p * prm.n_special + so + i];
-            acc_sp += gk * (((prm.sp_word[so + i] >> b) & 1u) ? ome : eps);
         }
     }
-    if (b == 0) {   // this part's share of the grid's total gamma * sigma (bin 0 holds the specials')
-        double tot = 0;
-        for (int d = part; d < prm.nrow; d += 8) tot += (double)mg[d] * unit;
-        s_tot[part] = tot;
+    const int so = prm.sp_off[g], sn = prm.sp_off[g + 1] - so;
+    for (int i0 = 0; i0 < sn; i0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = i0 + q;
+            if (i < sn) {
+                const double gk = (double)static_cast<const TS *>(prm.gsp)[(size_t)p * prm.n_special + so + i];
+                const uint32_t w = prm.sp_word[so + i];
+                sp0[q] += gk * (((w >> b0) & 1u) ? ome : eps);
+                sp1[q] += gk * (((w >> b1) & 1u) ? ome : eps);
+            }
+        }
     }
     const double sig = (g < prm.G - 1) ? prm.sigma[g] : 1.0;
-    s_acc[part][b] = acc + acc_sp * sig;
-    __syncthreads();
-    if (part == 0 && b < nLocal) {
-        double tot = 0, mass = 0;
-        for (int q = 0; q < 8; q++) { tot += s_acc[q][b]; mass += s_tot[q]; }
-        // gamma * sigma_g of a grid (what the histogram accumulates) sums to 1 (reference-single.cpp:2048-2091, :2170-2176;
-        // the reference's test suite checks colSums(gamma_t) == 1).  Dividing by the mass actually accumulated removes the
-        // common-mode drift of the state's scale (with fp32 state ~3e-8 per grid, 6e-5 over 2 000 grids), which is all
-        // the dosage of a long region would otherwise inherit from 2 000 renormalisations in single precision.
-        if (mass > 0) tot /= mass;
-        prm.dosage[(size_t)p * prm.T + s + b] = tot;
+    double tot0 = 0, tot1 = 0, ms = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        tot0 += acc0[q] + sp0[q] * sig;
+        tot1 += acc1[q] + sp1[q] * sig;
+        ms += mass[q];
+    }
+    // gamma * sigma_g of a grid (what the histogram accumulates) sums to 1 (reference-single.cpp:2048-2091, :2170-2176;
+    // the reference's test suite checks colSums(gamma_t) == 1).  Dividing by the mass actually accumulated removes the
+    // common-mode drift of the state's scale (with fp32 state ~3e-8 per grid, 6e-5 over 2 000 grids), which is all
+    // the dosage of a long region would otherwise inherit from 2 000 renormalisations in single precision.
+    if (ms > 0) {
+        tot0 /= ms;
+        tot1 /= ms;
+    }
+    double *dst = prm.dosage + (size_t)p * prm.T + s + b0;
+    if (b1 < nLocal && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        *reinterpret_cast<double2 *>(dst) = make_double2(tot0, tot1);
+    } else {
+        if (b0 < nLocal) dst[0] = tot0;
+        if (b1 < nLocal) dst[1] = tot1;
     }
 }
 
@@ -1063,7 +1095,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.hist_unit = kind == KIND_F64_DOS ? 1.0 / 2251799813685248.0 /* 2^-51: k_bwd64d */ : 1.0 / kHistScale64; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;
     prm.gamma_out = any_gamma ? S.gamma.p : nullptr; prm.beta_out = any_beta ? S.beta.p : nullptr;
     // Dosage rows that go to consecutive rows of a qa_host_alloc buffer are written there by k_dosage itself (every element
-    // once, 256 contiguous bytes per workgroup): the transfer rides under the kernel instead of following it.
+    // once, 4 KiB of consecutive bytes per workgroup): the transfer rides under the kernel instead of following it.
     bool dosage_direct = false;
     if (out.dosage && P > 0) {
         const size_t r0 = out.dosage_rows ? (size_t)out.dosage_rows[0] : 0;
@@ -1092,8 +1124,9 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     QA_HIP(hipEventRecord(S.ev[1], st));
     launch_fb_any(geo, prm, st, S.ev[2]);
     QA_HIP(hipEventRecord(S.ev[3], st));
-    if (f64) hipLaunchKernelGGL(k_dosage<double>, dim3(G, P), dim3(256), 0, st, prm);
-    else hipLaunchKernelGGL(k_dosage<float>, dim3(G, P), dim3(256), 0, st, prm);
+    const dim3 dgrid((G + kDosageGridsPerBlock - 1) / kDosageGridsPerBlock, P);
+    if (f64) hipLaunchKernelGGL(k_dosage<double>, dgrid, dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL(k_dosage<float>, dgrid, dim3(256), 0, st, prm);
     QA_HIP(hipGetLastError());
     QA_HIP(hipEventRecord(S.ev[4], st));
     std::vector<int32_t> cnt;

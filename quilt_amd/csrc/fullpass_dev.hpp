@@ -77,12 +77,14 @@ struct PassParams {
     const int32_t *topk_todo;  // k_topk: null (every (thinned column, pass)), or [n][2] = (pass, column) pairs to do
 };
 
-__device__ __forceinline__ double word_emission(uint32_t w, const double2 *gl, int nLocal, double eps) {
+// Emission of one distinct word (reference-single.cpp:294-327): the product over the grid's SNPs of P(reads | allele), with
+// e[b] = (P(reads | the haplotype carries ref at b), P(reads | alt)) = (gl.x * (1 - eps) + gl.y * eps, gl.x * eps + gl.y * (1 - eps))
+// formed ONCE per SNP by k_emat (the same expression every word would evaluate for itself: results unchanged).
+__device__ __forceinline__ double word_emission(uint32_t w, const double2 *e, int nLocal) {
     double prob = 1.0;
-    const double ome = 1.0 - eps;
     for (int b = 0; b < nLocal; b++) {
-        double2 v = gl[b];  // x = P(reads | ref), y = P(reads | alt)
-        prob *= ((w >> b) & 1u) ? (v.x * eps + v.y * ome) : (v.x * ome + v.y * eps);
+        const double2 v = e[b];
+        prob *= ((w >> b) & 1u) ? v.y : v.x;
     }
     return prob;
 }
@@ -90,6 +92,11 @@ __device__ __forceinline__ double word_emission(uint32_t w, const double2 *gl, i
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
     return v;
 }
 template <typename T>

@@ -107,6 +107,8 @@ def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
     """An uninitialised array in a ``qa_host_alloc`` buffer (pinned, device-visible): transfers from / to it skip the
     library's staging copy.  The buffer is released when the array and every view of it are gone."""
     import weakref
+    if os.environ.get("QUILT_AMD_PAGEABLE"):   # measurement hook (bench.py --pageable): what a caller that cannot use
+        return np.empty(shape, dtype=dtype)    # qa_host_alloc gets -- R allocates its own vectors -- the staged path
     L = lib()
     L.qa_host_alloc.restype = C.c_void_p
     L.qa_host_alloc.argtypes = [C.c_size_t]
