@@ -259,17 +259,17 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
             if (b == 0) continue;  // no base quality seen yet: factor 1 (host folded the carry-over rule)
             const int ab = b < 0 ? -b : b;
             const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
+            // the factor of a row is one of two values (its allele at the SNP): formed once, the expression the reference
+            // evaluates per row (gibbs-small.cpp:219-226) with e = 1 - ref_error resp. ref_error
+            const double f1 = (e1 * pA + (1 - e1) * pR), f0 = (e0 * pA + (1 - e0) * pR);
 #pragma unroll
             for (int i = 0; i < NEALL; i++) {
                 const uint32_t bit = (w[i] >> (snp & 31)) & 1u;
-                const double e = bit ? e1 : e0;
-                v[i] *= (e * pA + (1 - e) * pR);
+                v[i] *= bit ? f1 : f0;
                 pat[i] |= bit << min(n_inf, 7);
             }
-            {   // the same factor, in the same order, for this lane's pattern
-                const double e = ((lane >> min(n_inf, 31)) & 1) ? e1 : e0;
-                tv *= (e * pA + (1 - e) * pR);
-            }
+            // the same factor, in the same order, for this lane's pattern
+            tv *= ((lane >> min(n_inf, 31)) & 1) ? f1 : f0;
             n_inf++;
         }
         bool degenerate = false;
