@@ -449,7 +449,7 @@ def test_pair_gate_lets_a_finished_thread_leave():
     assert short.wait() is False and time.perf_counter() - t0 >= 0.19   # nobody came: goes alone after the timeout
 
 
-def _threads_over_streams(panel, prm, streams, tail, fail_in=None):
+def _threads_over_streams(panel, prm, streams, tail, fail_in=None, rare_common=None):
     """One Driver (oracle backend) per stream, each on its own host thread, sharing ``tail`` -- what DeviceWorkers does."""
     import threading
     from tests.oracle_backend import OracleBackend
@@ -457,7 +457,10 @@ def _threads_over_streams(panel, prm, streams, tail, fail_in=None):
 
     def work(w):
         try:
-            drv = D.Driver(panel, OracleBackend(panel), prm)
+            if rare_common is not None:
+                drv = D.Driver(panel, OracleBackend(panel, rare_common), prm, rare_common=rare_common)
+            else:
+                drv = D.Driver(panel, OracleBackend(panel), prm)
             drv.phasing_tail = tail
             if fail_in == w:
                 def boom(*a, **k):
@@ -575,3 +578,38 @@ def test_workers_cut_the_left_over_batches_into_parts(n_batches):
         for g, r in zip(res, ref):
             assert np.array_equal(g.read_labels, r.read_labels)
             assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
+
+
+@pytest.mark.parametrize("mode", ["nipt", "rare_common"])
+def test_fused_phasing_tail_in_the_other_modes(mode):
+    """The threads' last batches run their phasing rounds together also with three read labels (mother / fetus accumulators,
+    NIPT recast) and with impute_rare_common (the all-SNP Gibbs call after the rounds takes the other threads' phasing chains
+    too): results of separate runs."""
+    from quilt_amd.synth import (make_rare_common, make_synthetic_panel, make_synthetic_sample,
+                                 make_synthetic_sample_rare_common)
+    from tests.oracle_backend import OracleBackend
+    rc = None
+    if mode == "nipt":
+        panel = make_synthetic_panel(K=400, nSNPs=640, seed=21)
+        samples = [make_synthetic_sample(panel, seed=70 + i, n_reads=120, ff=0.15 + 0.05 * i) for i in range(4)]
+        prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method="nipt")
+    else:
+        panel = make_synthetic_panel(K=400, nSNPs=320, seed=21)
+        rc = make_rare_common(panel, 3)
+        samples = [make_synthetic_sample_rare_common(panel, rc, 50 + i, n_reads=100)[0] for i in range(4)]
+        prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, impute_rare_common=True)
+    streams = [[(samples[0:1], 0), (samples[3:4], 3)], [(samples[1:3], 1)]]
+    out, err = _threads_over_streams(panel, prm, streams, D.PhasingTail(2), rare_common=rc)
+    assert all(e is None for e in err), err
+    for st, got in zip(streams, out):
+        for (smp, off), res in zip(st, got):
+            if rc is not None:
+                ref = D.Driver(panel, OracleBackend(panel, rc), prm, rare_common=rc).run(smp, sample_offset=off)
+            else:
+                ref = D.Driver(panel, OracleBackend(panel), prm).run(smp, sample_offset=off)
+            assert len(res) == len(ref)
+            for g, r in zip(res, ref):
+                assert np.array_equal(g.read_labels, r.read_labels) and g.nDosage == r.nDosage
+                assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
+                if mode == "nipt":
+                    assert np.array_equal(g.fet_dosage, r.fet_dosage) and np.array_equal(g.fet_gp_t, r.fet_gp_t)
