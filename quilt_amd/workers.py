@@ -191,6 +191,8 @@ class DeviceWorkers:
                     at += n_b
             for t in threads:
                 t.join()
+            for d in self.drivers:
+                d.phasing_tail = None
             return
 
         def work(w: int):
@@ -227,6 +229,8 @@ class DeviceWorkers:
             yield merged
         for t in threads:
             t.join()
+        for d in self.drivers:
+            d.phasing_tail = None
 
 
 class StubWorkers:
