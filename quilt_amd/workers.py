@@ -112,97 +112,56 @@ class DeviceWorkers:
             d.close()
 
     def run_stream(self, batches: Iterable[Tuple[list, int]]):
-        """Like Driver.run_stream: yields one list of SampleResult per batch, in order.  Each batch is cut into
-        contiguous parts, one per worker thread; every worker pipelines its own parts."""
+        """Like Driver.run_stream: yields one list of SampleResult per batch, in order; every worker thread pipelines its own
+        stream of batches.  ``split = "alternate"``: whole batches go to the threads in turn, the batches left over by the
+        thread count are cut into one contiguous part per thread; ``"halves"``: every batch is cut that way."""
         batches = list(batches)
-        outs = [queue.Queue() for _ in range(self.n)]
+        n = self.n
+        if self.split == "alternate":
+            # a straggler batch alone on one thread at the end of a finite stream would expose that thread's host phases
+            # between its launch sets, with the other threads idle: the left-overs are cut across the threads instead
+            n_whole = len(batches) // n * n if self.split_remainder else len(batches)
+            if n_whole == 0:
+                n_whole = len(batches)
+        else:
+            n_whole = 0
+        whole, rest = batches[:n_whole], batches[n_whole:]
+        # `runs` of samples that are cut into one part per thread: (samples, offset, lengths of the caller's batches in it).
+        # Left-over batches whose samples are consecutive (offset + length = the next one's offset) make ONE run -- two
+        # left-over batches over four threads are four launches' worth, not eight small ones
+        runs: List[Tuple[list, int, List[int]]] = []
+        for samples, offset in rest:
+            if self.split == "alternate" and runs and runs[-1][1] + len(runs[-1][0]) == offset:
+                runs[-1] = (runs[-1][0] + list(samples), runs[-1][1], runs[-1][2] + [len(samples)])
+            else:
+                runs.append((list(samples), offset, [len(samples)]))
+
+        def stream_of(w: int):
+            out = whole[w::n]
+            for samples, offset, _ in runs:
+                lo, hi = get_sample_range(len(samples), n)[w]
+                if hi > lo:
+                    out.append((samples[lo:hi], offset + lo))
+            return out
+
+        outs = [queue.Queue() for _ in range(n)]
         if self.drivers[0].gibbs_gate is not None:
-            self.drivers[0].gibbs_gate.reset(self.n)
-        tail = PhasingTail(self.n) if self.fuse_tails else None
-        for d in self.drivers:
-            d.phasing_tail = tail
-            d._gate_left = False
+            self.drivers[0].gibbs_gate.reset(n)
+        tail = PhasingTail(n) if self.fuse_tails else None
         # Staggered start: thread w prepares its first launch once thread w - 1 has handed its own to the device.  The
         # preparation (thousands of per-chain draws) is interpreter work: started together, the threads share the interpreter
         # lock and the first launch leaves when ALL of them are done, n times later than it needs to.
-        started = [threading.Event() for _ in range(self.n)]
+        started = [threading.Event() for _ in range(n)]
         for w, d in enumerate(self.drivers):
+            d.phasing_tail = tail
+            d._gate_left = False
             d.on_first_launch = started[w].set
 
-        def my_turn(w: int):
-            if w > 0:
-                started[w - 1].wait(5.0)
-        if self.split == "alternate":
-            # Whole batches in turn; the batches left over when their number is not a multiple of the thread count (the
-            # stragglers at the end of a finite stream) are cut into one part per thread instead: a straggler alone on one
-            # thread would expose that thread's host phases between its launch sets, with the other threads idle.
-            n_full = len(batches) // self.n * self.n if self.split_remainder else len(batches)
-            if n_full == 0:
-                n_full = len(batches)
-            rest = batches[n_full:]
-            # left-over batches whose samples are consecutive (offset + length = the next one's offset) are cut as ONE run
-            # of samples -- two left-over batches over four threads make four launches' worth, not eight small ones
-            runs: List[Tuple[list, int, List[int]]] = []     # (samples, offset, lengths of the batches in the run)
-            for samples, offset in rest:
-                if runs and runs[-1][1] + len(runs[-1][0]) == offset:
-                    runs[-1] = (runs[-1][0] + list(samples), runs[-1][1], runs[-1][2] + [len(samples)])
-                else:
-                    runs.append((list(samples), offset, [len(samples)]))
-
-            def parts_of(w: int):
-                for samples, offset, _ in runs:
-                    lo, hi = get_sample_range(len(samples), self.n)[w]
-                    if hi > lo:
-                        yield samples[lo:hi], offset + lo
-
-            def work_alt(w: int):
-                try:
-                    my_turn(w)
-                    for res in self.drivers[w].run_stream(batches[w:n_full:self.n] + list(parts_of(w))):
-                        outs[w].put(res)
-                except BaseException as e:   # surfaced by the consumer
-                    if tail is not None:
-                        tail.abort(e)
-                    outs[w].put(e)
-                finally:
-                    started[w].set()
-                    if self.drivers[w].gibbs_gate is not None and not self.drivers[w]._gate_left:
-                        self.drivers[w].gibbs_gate.leave()
-            threads = [threading.Thread(target=work_alt, args=(w,), daemon=True) for w in range(self.n)]
-            for t in threads:
-                t.start()
-
-            def take(w: int):
-                res = outs[w].get()
-                if isinstance(res, BaseException):
-                    raise res
-                return res
-            for i in range(n_full):
-                yield take(i % self.n)
-            for samples, _, lengths in runs:
-                merged: List = []
-                for w in range(self.n):
-                    lo, hi = get_sample_range(len(samples), self.n)[w]
-                    if hi > lo:
-                        merged.extend(take(w))
-                at = 0
-                for n_b in lengths:     # back to the caller's batches
-                    yield merged[at:at + n_b]
-                    at += n_b
-            for t in threads:
-                t.join()
-            for d in self.drivers:
-                d.phasing_tail = None
-            return
-
         def work(w: int):
-            def parts():
-                for samples, offset in batches:
-                    lo, hi = get_sample_range(len(samples), self.n)[w]
-                    yield samples[lo:hi], offset + lo
             try:
-                my_turn(w)
-                for res in self.drivers[w].run_stream(p for p in parts() if len(p[0]) > 0):
+                if w > 0:
+                    started[w - 1].wait(5.0)
+                for res in self.drivers[w].run_stream(stream_of(w)):
                     outs[w].put(res)
             except BaseException as e:   # surfaced by the consumer
                 if tail is not None:
@@ -213,20 +172,27 @@ class DeviceWorkers:
                 if self.drivers[w].gibbs_gate is not None and not self.drivers[w]._gate_left:
                     self.drivers[w].gibbs_gate.leave()
 
-        threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(self.n)]
+        def take(w: int):
+            res = outs[w].get()
+            if isinstance(res, BaseException):
+                raise res
+            return res
+
+        threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in range(n)]
         for t in threads:
             t.start()
-        for samples, _ in batches:
+        for i in range(len(whole)):
+            yield take(i % n)
+        for samples, _, lengths in runs:
             merged: List = []
-            for w in range(self.n):
-                lo, hi = get_sample_range(len(samples), self.n)[w]
-                if hi <= lo:
-                    continue
-                res = outs[w].get()
-                if isinstance(res, BaseException):
-                    raise res
-                merged.extend(res)
-            yield merged
+            for w in range(n):
+                lo, hi = get_sample_range(len(samples), n)[w]
+                if hi > lo:
+                    merged.extend(take(w))
+            at = 0
+            for n_b in lengths:     # back to the caller's batches
+                yield merged[at:at + n_b]
+                at += n_b
         for t in threads:
             t.join()
         for d in self.drivers:

@@ -558,6 +558,12 @@ def test_workers_cut_the_left_over_batches_into_parts(n_batches):
         batches[-1] = (batches[-1][0], 100)
     wk = object.__new__(DeviceWorkers)
     wk.n, wk.split, wk.fuse_tails, wk.split_remainder = 3, "alternate", True, True
+    if n_batches == 2:      # (this shape also through split = "halves": every batch cut into parts)
+        wh = object.__new__(DeviceWorkers)
+        wh.n, wh.split, wh.fuse_tails, wh.split_remainder = 3, "halves", True, True
+        wh.drivers = [D.Driver(panel, OracleBackend(panel), prm) for _ in range(3)]
+        halves = list(wh.run_stream(batches))
+        assert [len(g) for g in halves] == [len(s) for s, _ in batches]
     wk.drivers = [D.Driver(panel, OracleBackend(panel), prm) for _ in range(3)]
     taken = [[] for _ in range(3)]
     for w, d in enumerate(wk.drivers):
@@ -573,11 +579,13 @@ def test_workers_cut_the_left_over_batches_into_parts(n_batches):
         assert taken == [[(0, 2), (5, 1), (100, 1)], [(2, 1), (6, 1), (101, 1)], [(3, 2)]]
     else:                   # fewer batches than threads: nothing to cut
         assert taken == [[(0, 4)], [(4, 5)], []]
-    for (smp, off), res in zip(batches, got):
+    for bi, ((smp, off), res) in enumerate(zip(batches, got)):
         ref = D.Driver(panel, OracleBackend(panel), prm).run(smp, sample_offset=off)
-        for g, r in zip(res, ref):
+        for si, (g, r) in enumerate(zip(res, ref)):
             assert np.array_equal(g.read_labels, r.read_labels)
             assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
+            if n_batches == 2:
+                assert np.array_equal(halves[bi][si].dosage, r.dosage) and np.array_equal(halves[bi][si].read_labels, r.read_labels)
 
 
 @pytest.mark.parametrize("mode", ["nipt", "rare_common"])
