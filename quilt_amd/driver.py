@@ -942,6 +942,7 @@ class Driver:
         it = iter(batches)
         tail = self.phasing_tail
         reported = False          # this thread has told the tail that its stream drained
+        taken = []                # (batch, Future) of other threads' last batches run here
         try:
             while True:
                 nxt = next(it, None)
@@ -1013,6 +1014,13 @@ class Driver:
                 if done is not None:
                     yield done
         except BaseException as e:
+            # Batches this thread took over live only in ``taken`` (the tail's waiting list is empty by then): their owners
+            # wait on these futures, so a failure inside the fused tail rounds must reach them here.
+            err = e if not isinstance(e, GeneratorExit) else RuntimeError(
+                "the thread running the last batches' phasing rounds stopped early")
+            for _, fut in taken:
+                if not fut.done():
+                    fut.set_exception(err)
             if tail is not None and not isinstance(e, GeneratorExit):
                 tail.abort(e)
             raise

@@ -45,7 +45,7 @@ def patched_rcppexports(text):
 
 def patched_makevars(text):
     add = ["# libquilt_amd (MI355X): set QUILT_AMD to the root of the quilt_amd repository",
-           "PKG_CPPFLAGS += -I$(QUILT_AMD)/include -DQA_HAVE_R",
+           "PKG_CPPFLAGS += -I$(QUILT_AMD)/include -DQA_HAVE_R -DQA_INSIDE_QUILT_SO",
            "PKG_LIBS += -L$(QUILT_AMD)/quilt_amd/csrc -lquilt_amd -Wl,-rpath,$(QUILT_AMD)/quilt_amd/csrc"]
     return text.rstrip("\n") + "\n" + "\n".join(add) + "\n"
 

@@ -60,7 +60,6 @@ void Rf_warning(const char *fmt, ...);
 void GetRNGstate(void);
 void PutRNGstate(void);
 double unif_rand(void);
-double R_unif_index(double dn);
 SEXP R_MakeExternalPtr(void *p, SEXP tag, SEXP prot);
 void *R_ExternalPtrAddr(SEXP s);
 void R_ClearExternalPtr(SEXP s);

@@ -24,8 +24,8 @@
  *
  * Random numbers.  The reference draws inside the native call from R's generator (`Rcpp::runif`, `Rcpp::sample`:
  * gibbs-nipt.cpp:2845-2848, 3013-3018; gibbs-nipt-block.cpp:2054) under `Rcpp::RNGScope` (RcppExports.cpp:971).  The
- * shim draws the same uniforms, in the same order, with unif_rand() (R_unif_index() for `sample(nReads, 1)`, as Rcpp's sugar
- * does) between GetRNGstate() / PutRNGstate() and passes them down; the device never generates R-incompatible numbers on this
+ * shim draws the same uniforms, in the same order, with unif_rand() (`sample(nReads, 1)` = one unif_rand() scaled by nReads,
+ * as Rcpp's sugar EmpiricalSample does) between GetRNGstate() / PutRNGstate() and passes them down; the device never generates R-incompatible numbers on this
  * path.  The shard pass draws nGrids - 1 uniforms per block iteration: what gibbs-nipt-block.cpp:2054 draws with
  * shard_check_every_pair = TRUE, the production value (quilt.R:178); FALSE is rejected.  Where the reference's draw count depends on
  * intermediate results (`Rcpp::sample(1:3, 1, prob)` per read in rcpp_sample_H_using_H_class, NIPT only) the stream
@@ -325,10 +325,15 @@ SEXP qa_QUILT_rcpp_forwardBackwardGibbsNIPT(
     /* ---- sampleReads -> CSR (sampleReads[[r]] = list(J, wif, bq matrix, u matrix): copied-from-stitch.cpp:153-160) */
     const int R = Rf_length(sampleReadsSEXP), Ks = Rf_length(which_haps_to_useSEXP);
     int32_t *read_ptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)R + 1));
+    if (!read_ptr) Rf_error("quilt_amd: rcpp_make_eMatRead_t: out of memory");
     read_ptr[0] = 0;
     for (int r = 0; r < R; r++) read_ptr[r + 1] = read_ptr[r] + Rf_length(VECTOR_ELT(VECTOR_ELT(sampleReadsSEXP, r), 3));
     const int nB = read_ptr[R];
     int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nB > 0 ? nB : 1)), *bq = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nB > 0 ? nB : 1));
+    if (!u || !bq) {
+        free(read_ptr); free(u); free(bq);
+        Rf_error("quilt_amd: rcpp_make_eMatRead_t: out of memory");
+    }
     for (int r = 0; r < R; r++) {
         SEXP rd = VECTOR_ELT(sampleReadsSEXP, r);
         const int n = read_ptr[r + 1] - read_ptr[r];
@@ -366,7 +371,10 @@ SEXP qa_QUILT_rcpp_forwardBackwardGibbsNIPT(
     GetRNGstate();
     for (size_t i = 0; i < (size_t)R * (size_t)n_its; i++) runif_reads[i] = unif_rand();         /* gibbs-nipt.cpp:2845 */
     if (!flag(pl, "gibbs_initialize_at_first_read", 0) && R > 0) {
-        first_read = (int32_t)R_unif_index((double)R);   /* :2846-2848 sample(nReads, 1) - 1: Rcpp's sugar draws R_unif_index(n) */
+        /* :2846-2848 Rcpp::sample(nReads, 1) - 1.  Rcpp's sugar (sugar/functions/sample.h, EmpiricalSample, size < 2) draws
+         * static_cast<int>(n * unif_rand() + 1): ONE unif_rand(), no rejection loop (R_unif_index under sample.kind =
+         * "Rejection" would consume a data-dependent number of draws and return another value). */
+        first_read = (int32_t)(unif_rand() * (double)R);
         if (first_read >= R) first_read = R - 1;
     }
     if (o.perform_block_gibbs) {
@@ -460,15 +468,30 @@ SEXP qa_QUILT_rcpp_forwardBackwardGibbsNIPT(
  * Read likelihoods against the K rows of eHapsCurrent_tc[, , s + 1] (copied-from-stitch.cpp:115-229), written into the
  * caller's K x nReads eMatRead_t; production caller: calculate_eMatRead_t_vs_haplotypes (functions.R:2975-3020, K = 2 or 3).
  * Needs the device context of a panel handle: the calls that precede it in the driver loop have created one. */
+#ifdef QA_INSIDE_QUILT_SO
+/* Compiled into QUILT.so (shim/QUILT-src.patch): the package's own Rcpp wrapper is still there and takes every call this
+ * entry does not cover -- the other callers of rcpp_make_eMatRead_t (K = KL rows: functions.R:2903, reference-single.R:545,
+ * gibbs-nipt.R:126/1634, the test drivers), pseudo-haploid mode, and calls made before any panel was uploaded. */
+extern SEXP _QUILT_rcpp_make_eMatRead_t(SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP, SEXP);
+#define QA_EMATREAD_NOT_COVERED(msg)                                                                                          \
+    return _QUILT_rcpp_make_eMatRead_t(eMatRead_tSEXP, sampleReadsSEXP, eHapsCurrent_tcSEXP, sSEXP, maxDifferenceBetweenReadsSEXP, \
+                                       JmaxSEXP, eMatHapOri_tSEXP, pRgivenH1SEXP, pRgivenH2SEXP, prevSEXP, suppressOutputSEXP,  \
+                                       prev_sectionSEXP, next_sectionSEXP, run_pseudo_haploidSEXP, rescale_eMatRead_tSEXP)
+#else
+#define QA_EMATREAD_NOT_COVERED(msg) Rf_error("quilt_amd: rcpp_make_eMatRead_t: " msg)
+#endif
+#define QA_EMATREAD_MAX_K 3   /* the device form serves the driver loop's caller (K = 2 or 3 sampled haplotypes) */
+
 SEXP qa_QUILT_rcpp_make_eMatRead_t(SEXP eMatRead_tSEXP, SEXP sampleReadsSEXP, SEXP eHapsCurrent_tcSEXP, SEXP sSEXP,
                                    SEXP maxDifferenceBetweenReadsSEXP, SEXP JmaxSEXP, SEXP eMatHapOri_tSEXP, SEXP pRgivenH1SEXP,
                                    SEXP pRgivenH2SEXP, SEXP prevSEXP, SEXP suppressOutputSEXP, SEXP prev_sectionSEXP,
                                    SEXP next_sectionSEXP, SEXP run_pseudo_haploidSEXP, SEXP rescale_eMatRead_tSEXP) {
     (void)eMatHapOri_tSEXP; (void)pRgivenH1SEXP; (void)pRgivenH2SEXP; (void)prevSEXP; (void)suppressOutputSEXP;
     (void)prev_sectionSEXP; (void)next_sectionSEXP;
-    if (Rf_asLogical(run_pseudo_haploidSEXP)) Rf_error("quilt_amd: rcpp_make_eMatRead_t with run_pseudo_haploid = TRUE is not supported");
-    if (!g_cache.panel) Rf_error("quilt_amd: rcpp_make_eMatRead_t needs the panel of an earlier full-panel or Gibbs call");
+    if (Rf_asLogical(run_pseudo_haploidSEXP)) QA_EMATREAD_NOT_COVERED("run_pseudo_haploid = TRUE is not supported");
+    if (!g_cache.panel) QA_EMATREAD_NOT_COVERED("needs the panel of an earlier full-panel or Gibbs call");
     const int K = Rf_nrows(eMatRead_tSEXP), R = Rf_length(sampleReadsSEXP), s = Rf_asInteger(sSEXP);
+    if (K > QA_EMATREAD_MAX_K) QA_EMATREAD_NOT_COVERED("more than 3 haplotype rows");
     SEXP dim = Rf_getAttrib(eHapsCurrent_tcSEXP, R_DimSymbol);
     if (Rf_length(dim) != 3 || INTEGER(dim)[0] != K || s < 0 || s >= INTEGER(dim)[2] || Rf_ncols(eMatRead_tSEXP) != R)
         Rf_error("quilt_amd: rcpp_make_eMatRead_t: eHapsCurrent_tc must be K x nSNPs x S with K = nrow(eMatRead_t), 0 <= s < S");

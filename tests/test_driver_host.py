@@ -449,8 +449,9 @@ def test_pair_gate_lets_a_finished_thread_leave():
     assert short.wait() is False and time.perf_counter() - t0 >= 0.19   # nobody came: goes alone after the timeout
 
 
-def _threads_over_streams(panel, prm, streams, tail, fail_in=None, rare_common=None):
-    """One Driver (oracle backend) per stream, each on its own host thread, sharing ``tail`` -- what DeviceWorkers does."""
+def _threads_over_streams(panel, prm, streams, tail, fail_in=None, rare_common=None, fail_in_tail_rounds=False):
+    """One Driver (oracle backend) per stream, each on its own host thread, sharing ``tail`` -- what DeviceWorkers does.
+    ``fail_in_tail_rounds``: whichever thread runs a phasing-only round (the fused tail) fails inside it."""
     import threading
     from tests.oracle_backend import OracleBackend
     out, err = [None] * len(streams), [None] * len(streams)
@@ -466,6 +467,14 @@ def _threads_over_streams(panel, prm, streams, tail, fail_in=None, rare_common=N
                 def boom(*a, **k):
                     raise RuntimeError("injected")
                 drv._round = boom
+            if fail_in_tail_rounds:
+                orig = drv._round
+
+                def boom_in_tail(chains, i_it):
+                    if all(ch.phasing for ch in chains):
+                        raise RuntimeError("injected in the tail rounds")
+                    return orig(chains, i_it)
+                drv._round = boom_in_tail
             out[w] = list(drv.run_stream(streams[w]))
         except BaseException as e:
             err[w] = e
@@ -539,6 +548,18 @@ def test_tail_failure_reaches_the_waiting_threads():
     next(g)
     g.close()
     assert tail.n_active == 1
+
+
+def test_failure_inside_the_fused_tail_rounds_reaches_the_owners():
+    """The thread that drains last holds the other threads' last batches only in its local list: when it fails INSIDE the
+    fused phasing rounds, the owners (blocked on their futures) must get the failure, not wait for ever."""
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=400, nSNPs=320, seed=22)
+    samples = [make_synthetic_sample(panel, seed=70 + i, n_reads=50) for i in range(4)]
+    prm = D.DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=4)
+    streams = [[(samples[0:1], 0)], [(samples[1:2], 1), (samples[2:3], 2)], [(samples[3:4], 3)]]
+    out, err = _threads_over_streams(panel, prm, streams, D.PhasingTail(3), fail_in_tail_rounds=True)
+    assert all(isinstance(e, RuntimeError) for e in err), err
 
 
 @pytest.mark.parametrize("n_batches", [4, 5, 2, -5])
