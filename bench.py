@@ -275,6 +275,9 @@ def main():
     ap.add_argument("--mspbwt", action="store_true",
                     help="use_mspbwt = TRUE (mode M2): no full-panel pass; the small panel is re-selected from long matches of the "
                          "Gibbs call's haploid dosages against the panel (device search, csrc/match.hip); no CPU baseline")
+    ap.add_argument("--mspbwt-search", choices=["scan", "exhaustive"], default="scan",
+                    help="--mspbwt: the query behind select_new_haps_mspbwt_v3 -- the msPBWT neighbour scan of the panel's indices "
+                         "(the reference's semantics; host, csrc/mspbwt.cpp) or the exhaustive device search (csrc/match.hip)")
     ap.add_argument("--cu-partition", action="store_true",
                     help="confine each host thread's Gibbs launches to its own half of the CUs (measured slower, DESIGN.md 5)")
     ap.add_argument("--gate-trace", default=None, metavar="NPY",
@@ -329,6 +332,7 @@ def main():
         params["impute_rare_common"] = True
     if a.mspbwt:
         params["use_mspbwt"] = True
+        params["mspbwt_search"] = a.mspbwt_search
     cpu, keep = None, None
     # The CPU legs run on rank 0 while the host cores are otherwise idle and before any HIP context exists in this process
     # (they fork / start threads).  With several ranks the others wait for rank 0, so that the baseline is measured "in the
@@ -671,28 +675,41 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
 
 
 def search_vs_scan(dev, panel, params, res):
-    """use_mspbwt = TRUE: the device search's definition of a good match (csrc/match.hip: every haplotype's longest run, the
-    longest first) against the restated msPBWT neighbour scan (tests/mspbwt_scan.py; the mspbwt package is not in the reference
-    tree, so parity with it is unpinned), on the two phased haplotypes of one result of the last batch."""
+    """use_mspbwt = TRUE: the product's query (``mspbwt_search``: the msPBWT neighbour scan of csrc/mspbwt.cpp by default, or the
+    exhaustive device search of csrc/match.hip) against the neighbour scan restated test-side (tests/mspbwt_scan.py, numpy; the
+    mspbwt package is not in the reference tree, so parity with the package itself is unpinned), on the two phased haplotypes of
+    one result of the last batch; the exhaustive device search's agreement is reported beside it either way."""
     from quilt_amd.driver import DriverParams
-    from quilt_amd.mspbwt import find_good_matches, int_contract_rows, match_tables_as_lists
+    from quilt_amd.mspbwt import find_good_matches, int_contract_rows, match_tables_as_lists, panel_mspbwt_index
     from tests.mspbwt_scan import find_good_matches_scan, selection_agreement
     P = DriverParams(**params)
     Zs = int_contract_rows(np.ascontiguousarray(res.phasing_haps.T[:2], dtype=np.float64))
     n_max = P.mspbwt_max_matches or 50 * P.mspbwtL
     t0 = time.perf_counter()
-    got = match_tables_as_lists(*find_good_matches(dev, Zs, P.mspbwt_nindices, P.mspbwtM, n_max))
+    exh = match_tables_as_lists(*find_good_matches(dev, Zs, P.mspbwt_nindices, P.mspbwtM, n_max))
     t1 = time.perf_counter()
-    scan = find_good_matches_scan(panel, Zs, P.mspbwt_nindices, P.mspbwtL, P.mspbwtM)
+    idx = panel_mspbwt_index(panel, P.mspbwt_nindices)
+    t1b = time.perf_counter()
+    nat = idx.find_good_matches(Zs, P.mspbwtL, P.mspbwtM)
     t2 = time.perf_counter()
+    scan = find_good_matches_scan(panel, Zs, P.mspbwt_nindices, P.mspbwtL, P.mspbwtM)
+    t3 = time.perf_counter()
+    rows_equal = all(np.array_equal(nat[q][i], scan[q][i]) for q in range(len(Zs)) for i in range(P.mspbwt_nindices))
+    got = nat if P.mspbwt_search == "scan" else exh
     agree = selection_agreement(scan, got, P.Knew, panel.K, panel.nGrids)
-    return dict(what="the next small panel (select_new_haps_mspbwt_v3, Knew haplotypes) chosen from the device search and from the "
-                     "restated msPBWT neighbour scan (mspbwtL up and down per grid, tests/mspbwt_scan.py) for the two phased "
-                     "haplotypes of sample 0 of the last batch: `selected` = share chosen by both; `longest` = share of the scan's "
-                     "Knew longest-matching haplotypes the device search reports at all; `length` = the same weighted by match "
-                     "length.  Parity with the mspbwt package itself is unpinned (not in the reference tree)",
+    other = selection_agreement(scan, exh, P.Knew, panel.K, panel.nGrids)
+    return dict(what="the next small panel (select_new_haps_mspbwt_v3, Knew haplotypes) chosen from the product's query "
+                     f"(mspbwt_search = {P.mspbwt_search}) and from the msPBWT neighbour scan restated test-side (mspbwtL up and down "
+                     "per grid, tests/mspbwt_scan.py) for the two phased haplotypes of sample 0 of the last batch: `selected` = "
+                     "share chosen by both; `longest` = share of the scan's Knew longest-matching haplotypes the product's query "
+                     "reports at all; `length` = the same weighted by match length; `rows_identical`: the native scan's "
+                     "(haplotype, start, length) rows equal the restatement's.  Parity with the mspbwt package itself is unpinned "
+                     "(not in the reference tree)",
+                search=P.mspbwt_search, rows_identical=bool(rows_equal),
                 **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in agree.items()},
-                device_search_ms=round((t1 - t0) * 1e3, 1), scan_cpu_s=round(t2 - t1, 1))
+                exhaustive_device_search={k: (round(v, 4) if isinstance(v, float) else v) for k, v in other.items()},
+                device_search_ms=round((t1 - t0) * 1e3, 1), native_scan_ms=round((t2 - t1b) * 1e3, 2),
+                index_bytes=idx.bytes, restated_scan_cpu_s=round(t3 - t2, 1))
 
 
 def cpu_pipeline_reference(a, panel, params, samples):

@@ -326,6 +326,36 @@ int qa_fullpass_reads_select_batch(qa_panel_t *panel, int32_t n_chain, int32_t n
 int qa_find_good_matches(qa_panel_t *panel, int32_t n_query, const int32_t *Zs, int32_t nindices, int32_t min_len,
                          int32_t max_matches, int32_t *match, int32_t *n_match);
 
+/*
+ * The msPBWT indices of the panel and the neighbour scan that queries them (host code; csrc/mspbwt.cpp).  Stands in for
+ * mspbwt::ms_BuildIndices_Algorithm5 (the `ms_indices` quilt-prepare-reference stores: all_symbols, usge_all, egs) and
+ * mspbwt::Rcpp_find_good_matches_without_a(Z, all_symbols, usge_all, egs, pbwtL = mspbwtL, pbwtM = mspbwtM, ...) as
+ * select_new_haps_mspbwt_v3 calls it (QUILT/R/mspbwt.R:297-310) -- the query of use_mspbwt = TRUE, QUILT2's default.  The
+ * mspbwt package is not in the reference tree: the algorithm is the published one (positional prefix order, the query's
+ * insertion point, mspbwtL haplotypes up and down per position, matches of at least mspbwtM positions), stated in
+ * tests/mspbwt_scan.py; PARITY UNPINNED against the package itself.  qa_find_good_matches above (every haplotype's longest
+ * run, on the device) remains as the exhaustive alternative.
+ *   hapMatcherR     K x nGrids uint8, R's column-major layout (element (k, g) at k + K g); distinctHapsB nMaxDH x nGrids int32
+ *   nindices        mspbwt_nindices: index i covers grids i, i + nindices, ...
+ * Memory: 8 K nGrids bytes + K nGrids (0.9 GB for K = 50 000 x 2 000 grids), host.  NULL + qa_last_error() on failure. */
+typedef struct qa_mspbwt qa_mspbwt_t;
+qa_mspbwt_t *qa_mspbwt_create(int32_t K, int32_t nGrids, const uint8_t *hapMatcherR, int32_t nMaxDH, const int32_t *distinctHapsB,
+                              int32_t nindices);
+void qa_mspbwt_destroy(qa_mspbwt_t *index);
+int64_t qa_mspbwt_bytes(const qa_mspbwt_t *index);
+/* The scan for n_query packed haplotypes (Zs n_query x nGrids, rcpp_int_contract of the rounded haploid dosage), CSR output:
+ * row_ptr [n_query x nindices + 1], rows (index0 = 0-based haplotype, start0 = 0-based first position, len1) in (haplotype,
+ * start) order, one row per (haplotype, start) -- the longest (mspbwt.R:330-345 drops the others).  Returns the number of rows
+ * found; when that exceeds cap_rows nothing beyond the capacity was written (row_ptr is complete): call again with room.
+ * 1 <= L <= 64, M >= 1.  Negative: QA_ERR_*. */
+int64_t qa_mspbwt_find_good_matches(const qa_mspbwt_t *index, int32_t n_query, const int32_t *Zs, int32_t L, int32_t M,
+                                    int64_t *row_ptr, int32_t *rows, int64_t cap_rows);
+/* The scan followed by select_new_haps_mspbwt_v3 (QUILT/R/mspbwt.R:225-474; qa_select_new_haps_mspbwt of quilt_amd_io.h) for
+ * every chain of a round, threaded over chains; the match tables stay on the native side.  Zs n_chain x n_label x nGrids,
+ * seed one selection-stream key per chain, out n_chain x Knew 1-based haplotypes. */
+int qa_mspbwt_select_new_haps(const qa_mspbwt_t *index, int32_t n_chain, int32_t n_label, const int32_t *Zs, int32_t L, int32_t M,
+                              int32_t Knew, const uint64_t *seed, int32_t *out);
+
 /* Timing of the most recent full-pass launch set on this thread, measured with HIP
  * events on the launch stream (ms): [0] emission build, [1] forward, [2] backward,
  * [3] dosage mat-vec, [4] total device.  Replaces print_times()

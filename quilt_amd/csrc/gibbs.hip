@@ -19,8 +19,8 @@
 //     with ds_bpermute; see GibbsParams) and fetched one read ahead.
 //   * fp64 throughout and no FMA contraction (-ffp-contract=off).  Deviations from the reference's
 //     per-element arithmetic, each <= 1 ulp: the order of the Ks-wide sums; x * (1 / e) with a refined
-//     v_rcp_f64 where the reference divides by a read's emission (and by P + Q); alpha * beta formed where
-//     it is summed.  Sampling thresholds are compared with 53-bit uniforms, so the sampled labels equal the
+//     v_rcp_f64 where the reference divides by a read's emission (and by P + Q).  alpha * beta of a grid is held
+//     and updated by the moves as the reference's ab_m is (round 4; it used to be re-formed per read).  Sampling thresholds are compared with 53-bit uniforms, so the sampled labels equal the
 //     CPU path's under the same uniforms in every test.
 //   * the uniforms the reference draws from R's RNG are inputs.
 //
@@ -153,9 +153,15 @@ __device__ void backward_both(Chain<NE, NW> &ch) {
 // Ks = 256, whose columns fit 256 registers anyway: 2 048 chains take 1.13 x the time of 1 024).  At 10 rows per lane the
 // sweep therefore gives up what it held for its own latency hiding: the next grid's columns are not fetched a grid ahead
 // (the other wave runs while they arrive).
+#ifndef QA_LEAN_WAVES
+#define QA_LEAN_WAVES 2
+#endif
 template <int NE, int NW, bool LEAN>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : 1))) void k_gibbs(GibbsParams p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? QA_LEAN_WAVES : 1))) void k_gibbs(GibbsParams p) {
     __shared__ double s_red[2 * NW * 4];
+    // LEAN: the current grid's eMatGrid columns wait in LDS while the grid's reads are sampled (10 KB per chain, 80 KB per
+    // compute unit at two chains per SIMD): a move updates them there, and their 4 * NE registers are free in the read loop
+    __shared__ double s_e[LEAN ? 2 * NE * 64 * NW : 1];
     const int c = blockIdx.x, t = threadIdx.x;
     using CH = Chain<NE, NW>;
     CH ch(p, c, t, s_red);
@@ -251,6 +257,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
         // H_class (record_read_set, :1142-1165) is overwritten for every sampled read in every sweep, so only
         // the last sweep's value is observable: it is computed there only.
         const bool last_sweep = it == p.n_its - 1;
+        const bool steady = !init_iteratively || it >= 2;   // every sampled read is in "normal progress" (:817-834)
         Col<NE> a[2];   // alpha of the current grid, both labels (also the reference's alphaHat_m)
         int iRead = 0;  // next unprocessed read
         // software pipeline over reads: the emission column of read iRead is always in flight one read
@@ -327,8 +334,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                 }
             }
             // ---- sample_reads_in_grid (:733-1295), diploid: labels 0 / 1, the third label has prior 0, pC(2) = 1
-            bool grid_started = false, changed = false;
+            bool changed = false;
+            // ab_m = alphaHat_m % betaHat_m and pC = its column sums (:853-858): the reference forms them at the grid's first
+            // sampled read; nothing changes alpha or beta before that, so they are formed here, for every grid with reads --
+            // beta's registers are then free for the whole read loop -- and kept up to date by the moves (:1088-1093)
+            Col<NE> ab[2];
             double pC[2] = {1, 1};
+            if (has) {
+                double s[2] = {0, 0};
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    ab[0].v[i] = a[0].v[i] * bt[0].v[i];
+                    ab[1].v[i] = a[1].v[i] * bt[1].v[i];
+                    s[0] += ab[0].v[i];
+                    s[1] += ab[1].v[i];
+                }
+                ch.template bsum<2>(s);
+                pC[0] = s[0]; pC[1] = s[1];
+                if constexpr (LEAN) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) s_e[(h * NE + i) * NT + t] = e[h].v[i];
+                    }
+                }
+            }
             int h_rC = 0, h_rA1 = 1;
             bool normal = false, ginit = false, pass = false;
             while (iRead < R) {
@@ -356,21 +386,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                 } else {
                     ch.expand_with_rcp(er, ri, cur_er);
                 }
-                if (!init_iteratively) normal = true;
+                if (steady) normal = true;   // (no iterative initialisation, or past its two sweeps: hoisted out of the loop)
                 else if (r < first_read && it == 0) pass = true;
                 else if (first_read <= r && it == 0) { pass = false; ginit = true; }
                 else if (r < first_read && it == 1) { pass = false; ginit = true; }
                 else { ginit = false; normal = true; }
-                // alpha * beta of the current grid is formed where it is summed (holding it in registers, as the
-                // reference's ab_m does, costs 4 * NE registers per lane)
-                if (!grid_started) {
-                    double s[2] = {0, 0};
-#pragma unroll
-                    for (int i = 0; i < NE; i++) { s[0] += a[0].v[i] * bt[0].v[i]; s[1] += a[1].v[i] * bt[1].v[i]; }
-                    ch.template bsum<2>(s);
-                    pC[0] = s[0]; pC[1] = s[1];
-                    grid_started = true;
-                }
                 double pA1[2] = {pC[0], pC[1]};
                 if (normal) {
                     h_rC = rl_i32(rs.H, jr) - 1;
@@ -387,17 +407,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
 #pragma unroll
                         for (int i = 0; i < NE; i++) {
                             double &u0 = (i & 1) ? s2[0] : s[0], &u1 = (i & 1) ? s2[1] : s[1];
-                            u0 += (a[0].v[i] * bt[0].v[i]) * ri.v[i];
-                            u1 += (a[1].v[i] * bt[1].v[i]) * er.v[i];
+                            u0 += ab[0].v[i] * ri.v[i];
+                            u1 += ab[1].v[i] * er.v[i];
                         }
+                        // (the sums pass through an asm of this branch's own: otherwise the two versions are sunk into one
+                        // block behind 2 * NE register copies)
+                        asm volatile("; current label 0" : "+v"(s[0]), "+v"(s[1]), "+v"(s2[0]), "+v"(s2[1]));
                     } else {
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < NE; i++) {
                             double &u0 = (i & 1) ? s2[0] : s[0], &u1 = (i & 1) ? s2[1] : s[1];
-                            u0 += (a[1].v[i] * bt[1].v[i]) * ri.v[i];
-                            u1 += (a[0].v[i] * bt[0].v[i]) * er.v[i];
+                            u0 += ab[1].v[i] * ri.v[i];
+                            u1 += ab[0].v[i] * er.v[i];
                         }
+                        asm volatile("; current label 1" : "+v"(s[0]), "+v"(s[1]), "+v"(s2[0]), "+v"(s2[1]));
                     }
                     s[0] += s2[0]; s[1] += s2[1];
                     ch.template bsum<2>(s);
@@ -408,8 +432,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     double s[2] = {0, 0};
 #pragma unroll
                     for (int i = 0; i < NE; i++) {
-                        s[0] += (a[0].v[i] * bt[0].v[i]) * er.v[i];
-                        s[1] += (a[1].v[i] * bt[1].v[i]) * er.v[i];
+                        s[0] += ab[0].v[i] * er.v[i];
+                        s[1] += ab[1].v[i] * er.v[i];
                     }
                     ch.template bsum<2>(s);
                     pC[0] = s[0];
@@ -428,21 +452,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                 if (((h_rN != h_rC) || ginit) && !pass) {
                     changed = true;
                     if (lane == jr) rs.H = h_rN + 1;
-                    if (normal) {
-                        if (h_rC == 0) {
+                    // eMatGrid's column: in registers, or (LEAN) where it waits in LDS
+                    auto mul_e = [&](int h, const Col<NE> &f) {
+                        if constexpr (LEAN) {
 #pragma unroll
-                            for (int i = 0; i < NE; i++) { a[0].v[i] *= ri.v[i]; e[0].v[i] *= ri.v[i]; }
+                            for (int i = 0; i < NE; i++) s_e[(h * NE + i) * NT + t] *= f.v[i];
                         } else {
 #pragma unroll
-                            for (int i = 0; i < NE; i++) { a[1].v[i] *= ri.v[i]; e[1].v[i] *= ri.v[i]; }
+                            for (int i = 0; i < NE; i++) e[h].v[i] *= f.v[i];
+                        }
+                    };
+                    if (normal) {   // alphaHat_m, ab_m, eMatGrid of the label that loses the read (:1086-1102)
+                        if (h_rC == 0) {
+#pragma unroll
+                            for (int i = 0; i < NE; i++) { a[0].v[i] *= ri.v[i]; ab[0].v[i] *= ri.v[i]; }
+                            mul_e(0, ri);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NE; i++) { a[1].v[i] *= ri.v[i]; ab[1].v[i] *= ri.v[i]; }
+                            mul_e(1, ri);
                         }
                     }
-                    if (h_rN == 0) {
+                    if (h_rN == 0) {   // ... and of the one that gains it (:1090-1108)
 #pragma unroll
-                        for (int i = 0; i < NE; i++) { a[0].v[i] *= er.v[i]; e[0].v[i] *= er.v[i]; }
+                        for (int i = 0; i < NE; i++) { a[0].v[i] *= er.v[i]; ab[0].v[i] *= er.v[i]; }
+                        mul_e(0, er);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < NE; i++) { a[1].v[i] *= er.v[i]; e[1].v[i] *= er.v[i]; }
+                        for (int i = 0; i < NE; i++) { a[1].v[i] *= er.v[i]; ab[1].v[i] *= er.v[i]; }
+                        mul_e(1, er);
                     }
                     if (normal || h_rN == 1) { pC[0] = pA1[0]; pC[1] = pA1[1]; }
                 }
@@ -471,6 +509,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     cg[h] *= alphaConst;
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
+                    if constexpr (LEAN) {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) e[h].v[i] = s_e[(h * NE + i) * NT + t];
+                    }
                     ch.stm(e[h], ch.eg[h] + (size_t)g * Ksp);
                 }
             }
@@ -549,11 +591,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                 }
                 const int jg = g & 63;
                 const double oc1 = rl_f64(ss.c0, jg), oc2 = rl_f64(ss.c1, jg);
+                // everything to the right of an accepted switch swaps haplotypes: the grid's eMatGrid columns are fetched
+                // crosswise then (a wave-uniform choice of address, not 4 * NE selects) and written back in their new places
                 Col<NE> e2[2];
-                ch.ldm(e2[0], ch.eg[0] + (size_t)g * Ksp);
-                ch.ldm(e2[1], ch.eg[1] + (size_t)g * Ksp);
+                ch.ldm(e2[0], ch.eg[flip ? 1 : 0] + (size_t)g * Ksp);
+                ch.ldm(e2[1], ch.eg[flip ? 0 : 1] + (size_t)g * Ksp);
+                // (LEAN: beta's columns are fetched where they are used, after the grid's eMatGrid columns are dead: fewer
+                // spilled registers in this loop)
                 Col<NE> b1, b2;
-                if (g < G - 1) {
+                if (!LEAN && g < G - 1) {
                     ch.ldm(b1, ch.beta[0] + (size_t)g * Ksp);
                     ch.ldm(b2, ch.beta[1] + (size_t)g * Ksp);
                 }
@@ -574,7 +620,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     }
                 } else {
                     if (flip) {
-                        Col<NE> tmp = e2[0]; e2[0] = e2[1]; e2[1] = tmp;
                         ch.stm(e2[0], ch.eg[0] + (size_t)g * Ksp);
                         ch.stm(e2[1], ch.eg[1] + (size_t)g * Ksp);
                     }
@@ -622,6 +667,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     ir++;
                 }
                 if (g < G - 1) {
+                    if constexpr (LEAN) {
+                        ch.ldm(b1, ch.beta[0] + (size_t)g * Ksp);
+                        ch.ldm(b2, ch.beta[1] + (size_t)g * Ksp);
+                    }
                     double s[4] = {0, 0, 0, 0};
 #pragma unroll
                     for (int i = 0; i < NE; i++) {

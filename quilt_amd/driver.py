@@ -62,6 +62,10 @@ class DriverParams:
     mspbwtL: int = 3                   # neighbours scanned up and down per grid in the reference's index; here it scales how
     mspbwtM: int = 1                   # many matches a search returns (mspbwt_max_matches); mspbwtM: minimum match length
     mspbwt_nindices: int = 4
+    # the query behind select_new_haps_mspbwt_v3: "scan" = the msPBWT neighbour scan of the panel's indices (the reference's
+    # mspbwt::Rcpp_find_good_matches_without_a semantics: mspbwtL neighbours up and down per grid; host, csrc/mspbwt.cpp);
+    # "exhaustive" = every haplotype's longest run, searched on the device (csrc/match.hip; this library's own definition)
+    mspbwt_search: str = "scan"
     mspbwt_max_matches: Optional[int] = None   # matches per (haplotype, index) from the device search; None: 50 * mspbwtL
 
     def resolved(self, K: int) -> "DriverParams":
@@ -90,6 +94,10 @@ class DriverParams:
                              "Ksubset (the reference's defaults: 600 / 600)")
         if p.use_mspbwt and (p.mspbwt_nindices < 1 or p.mspbwtM < 1 or p.mspbwtL < 1):
             raise ValueError("mspbwt_nindices, mspbwtM and mspbwtL must be >= 1")
+        if p.mspbwt_search not in ("scan", "exhaustive"):
+            raise ValueError("mspbwt_search is 'scan' (the msPBWT neighbour scan) or 'exhaustive' (the device search)")
+        if p.use_mspbwt and p.mspbwt_search == "scan" and p.mspbwtL > 64:
+            raise ValueError("mspbwtL <= 64")
         return p
 
 
@@ -748,10 +756,15 @@ class Driver:
             Zs = np.concatenate([np.asarray(results[ci]["hap_words"])[:nL] for ci in idx])
         else:
             Zs = int_contract_rows(np.concatenate([np.asarray(results[ci]["hapProbs_t"])[:nL] for ci in idx]))
-        n_max = P.mspbwt_max_matches or 50 * P.mspbwtL
-        match, n_match = self.backend.find_good_matches(Zs, P.mspbwt_nindices, P.mspbwtM, n_max)
-        new = select_new_haps_mspbwt_batch(match, n_match, nL, P.Knew, self.panel.K, self.panel.nGrids,
-                                           [seed_sel[ci] for ci in idx])
+        if P.mspbwt_search == "scan":
+            # the reference's query: the neighbour scan of the panel's msPBWT indices, then the selection, natively per chain
+            new = self.backend.mspbwt_select(Zs, nL, P.mspbwt_nindices, P.mspbwtL, P.mspbwtM, P.Knew,
+                                             [seed_sel[ci] for ci in idx])
+        else:
+            n_max = P.mspbwt_max_matches or 50 * P.mspbwtL
+            match, n_match = self.backend.find_good_matches(Zs, P.mspbwt_nindices, P.mspbwtM, n_max)
+            new = select_new_haps_mspbwt_batch(match, n_match, nL, P.Knew, self.panel.K, self.panel.nGrids,
+                                               [seed_sel[ci] for ci in idx])
         for a, ci in enumerate(idx):
             chains[ci].which_haps_to_use = new[a].copy()
 
@@ -1087,6 +1100,11 @@ class HipBackend:
     def find_good_matches(self, Zs, nindices, min_len, max_matches):
         from .mspbwt import find_good_matches
         return find_good_matches(self.dev, Zs, nindices, min_len, max_matches)
+
+    def mspbwt_select(self, Zs, n_label, nindices, L, M, Knew, seeds):
+        from .mspbwt import panel_mspbwt_index
+        with span("device:mspbwt_scan"):   # (host code: the name keeps the trace's columns)
+            return panel_mspbwt_index(self.dev.panel, nindices).select_new_haps(Zs, n_label, L, M, Knew, seeds)
 
     def read_likelihood_all_snps_batch(self, samples_all, haps, maxDifferenceBetweenReads):
         """rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100.

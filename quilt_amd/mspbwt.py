@@ -2,8 +2,9 @@
 
 ``select_new_haps_mspbwt_v3`` restates QUILT/R/mspbwt.R:225-474 line by line (heuristic_approach "A"); the positional-BWT
 query it calls -- ``mspbwt::Rcpp_find_good_matches_without_a``, a third-party package that is not in the reference tree --
-is replaced by the device search ``qa_find_good_matches`` (csrc/match.hip: the query against every haplotype at HBM rate;
-its definition of a "good match" is this library's, UNPINNED against mspbwt).  R's ``sample()`` draws are keyed draws from
+is the neighbour scan of the panel's msPBWT indices in the library's host code (:class:`MsPbwtIndex`, csrc/mspbwt.cpp: the
+published algorithm, stated in tests/mspbwt_scan.py; UNPINNED against the package) or, as an option, the exhaustive device
+search ``qa_find_good_matches`` (csrc/match.hip: every haplotype's longest run at HBM rate).  R's ``sample()`` draws are keyed draws from
 the chain's selection stream (quilt_amd/rng.py), as everywhere in the driver.
 """
 from __future__ import annotations
@@ -37,6 +38,93 @@ def find_good_matches(dev, Zs: np.ndarray, nindices: int, min_len: int, max_matc
     check(lib().qa_find_good_matches(dev.handle, C.c_int32(nq), ptr(Zs), C.c_int32(nindices), C.c_int32(min_len),
                                      C.c_int32(max_matches), ptr(match), ptr(n)))
     return match, n
+
+
+class MsPbwtIndex:
+    """The panel's msPBWT indices (``ms_indices`` of quilt-prepare-reference: mspbwt::ms_BuildIndices_Algorithm5) and the
+    neighbour scan that queries them -- ``mspbwt::Rcpp_find_good_matches_without_a`` as mspbwt.R:297-310 calls it -- in the
+    library's host code (csrc/mspbwt.cpp; the published algorithm as tests/mspbwt_scan.py states it, unpinned against the
+    package, which is not in the reference tree)."""
+
+    def __init__(self, panel, nindices: int):
+        from .native import lib
+        if panel.hapMatcherR is None:
+            raise ValueError("the msPBWT index is built from hapMatcherR (nMaxDH <= 255)")
+        L = lib()
+        L.qa_mspbwt_create.restype = C.c_void_p
+        L.qa_mspbwt_bytes.restype = C.c_int64
+        hm = np.asfortranarray(panel.hapMatcherR, dtype=np.uint8)
+        B = np.asfortranarray(panel.distinctHapsB, dtype=np.int32)
+        self.K, self.nGrids, self.nindices = int(hm.shape[0]), int(hm.shape[1]), int(nindices)
+        h = L.qa_mspbwt_create(C.c_int32(self.K), C.c_int32(self.nGrids), hm.ctypes.data_as(C.c_void_p), C.c_int32(B.shape[0]),
+                               B.ctypes.data_as(C.c_void_p), C.c_int32(nindices))
+        if not h:
+            L.qa_last_error.restype = C.c_char_p
+            raise ValueError((L.qa_last_error() or b"qa_mspbwt_create failed").decode())
+        self.handle = C.c_void_p(h)
+        self.bytes = int(L.qa_mspbwt_bytes(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            from .native import lib
+            lib().qa_mspbwt_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def find_good_matches(self, Zs: np.ndarray, L: int, M: int) -> List[List[np.ndarray]]:
+        """``out[query][index]``: (haplotype0, start0, len1) rows, as tests/mspbwt_scan.py::find_good_matches_scan."""
+        from .native import lib
+        lb = lib()
+        lb.qa_mspbwt_find_good_matches.restype = C.c_int64
+        Zs = np.ascontiguousarray(Zs, dtype=np.int32)
+        nq = Zs.shape[0]
+        row_ptr = np.zeros(nq * self.nindices + 1, dtype=np.int64)
+        cap = max(1024, 64 * nq * self.nindices)
+        while True:
+            rows = np.zeros((cap, 3), dtype=np.int32)
+            n = lb.qa_mspbwt_find_good_matches(self.handle, C.c_int32(nq), Zs.ctypes.data_as(C.c_void_p), C.c_int32(L), C.c_int32(M),
+                                               row_ptr.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+            if n < 0:
+                raise ValueError("qa_mspbwt_find_good_matches: invalid arguments")
+            if n <= cap:
+                break
+            cap = int(n)
+        return [[rows[row_ptr[q * self.nindices + i]:row_ptr[q * self.nindices + i + 1]].copy() for i in range(self.nindices)]
+                for q in range(nq)]
+
+    def select_new_haps(self, Zs: np.ndarray, n_label: int, L: int, M: int, Knew: int, seeds: Sequence[int]) -> np.ndarray:
+        """Scan + ``select_new_haps_mspbwt_v3`` for every chain of a round (``Zs``: the chains' ``n_label`` packed haplotypes back
+        to back).  Returns [chain, Knew] 1-based haplotypes."""
+        from .native import lib
+        lb = lib()
+        lb.qa_mspbwt_select_new_haps.restype = C.c_int
+        Zs = np.ascontiguousarray(Zs, dtype=np.int32)
+        n_chain = Zs.shape[0] // n_label
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        out = np.zeros((n_chain, Knew), dtype=np.int32)
+        st = lb.qa_mspbwt_select_new_haps(self.handle, C.c_int32(n_chain), C.c_int32(n_label), Zs.ctypes.data_as(C.c_void_p),
+                                          C.c_int32(L), C.c_int32(M), C.c_int32(Knew), sd.ctypes.data_as(C.c_void_p),
+                                          out.ctypes.data_as(C.c_void_p))
+        if st != 0:
+            raise ValueError("qa_mspbwt_select_new_haps failed (status %d)" % st)
+        return out
+
+
+_INDEX_LOCK = __import__("threading").Lock()
+
+
+def panel_mspbwt_index(panel, nindices: int) -> MsPbwtIndex:
+    """The panel's indices, built on first use and shared by every host thread working on the panel (queries only read them)."""
+    with _INDEX_LOCK:
+        cache = panel.__dict__.setdefault("_mspbwt_indices", {})
+        if nindices not in cache:
+            cache[nindices] = MsPbwtIndex(panel, nindices)
+        return cache[nindices]
 
 
 def match_tables_as_lists(match: np.ndarray, n: np.ndarray) -> List[List[np.ndarray]]:

@@ -14,20 +14,31 @@ import sys
 
 
 def main():
-    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))   # kernel, counter, file
     disp = collections.defaultdict(set)
+    wgs = collections.defaultdict(float)
     for path in sys.argv[1:]:
+        seen = set()
         for r in csv.DictReader(open(path)):
-            m = re.search(r"(k_\w+)", r["Kernel_Name"])
+            m = re.search(r"(k_\w+(?:<[^>]*>)?)", r["Kernel_Name"])   # per template instantiation
             if not m:
                 continue
             k = m.group(1)
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            acc[k][r["Counter_Name"]][path] += float(r["Counter_Value"])
             disp[(k, path)].add(r["Dispatch_Id"])
+            if (k, r["Dispatch_Id"]) not in seen:
+                seen.add((k, r["Dispatch_Id"]))
+                try:
+                    wgs[(k, path)] += max(1, int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
+                except (KeyError, ValueError):
+                    pass
     out = {}
     for k in sorted(acc):
         n = max(len(v) for (kk, _), v in disp.items() if kk == k)
-        out[k] = {"launches": n, **{c: v / n for c, v in sorted(acc[k].items())}}
+        w = max([v for (kk, _), v in wgs.items() if kk == k] or [0])
+        # a counter collected in several passes (SQ_WAVE_CYCLES) is averaged over them, not summed
+        out[k] = {"launches": n, "workgroups_per_launch": w / n if n else 0,
+                  **{c: sum(v.values()) / len(v) / n for c, v in sorted(acc[k].items())}}
     json.dump({"per_launch": out}, sys.stdout, indent=1)
 
 

@@ -13,7 +13,7 @@ import re
 import sys
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, pattern=r"(k_\w+)"):
     tot = collections.defaultdict(float)
     n = collections.Counter()
     ms = collections.defaultdict(float)
@@ -21,7 +21,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(k_\w+)", r["Kernel_Name"])
+        m = re.search(pattern, r["Kernel_Name"])
         if not m:
             continue
         k = m.group(1)
@@ -41,7 +41,19 @@ def main():
     f, nf, msf, wg = per_kernel(fetch_csv, "FETCH_SIZE")
     w, nw, _, _ = per_kernel(write_csv, "WRITE_SIZE")
     res = {"command": cmd, "units": "bytes; FETCH_SIZE (KB) x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE (KB) x 1024",
-           "kernels": {}}
+           "kernels": {}, "instantiations": {}}
+    # the same per template instantiation (k_gibbs<10, 1, true> -- two chains per SIMD -- and k_gibbs<10, 1, false> are
+    # different code: bench.py prices a launch with the figures of the build it actually ran)
+    INST = r"(k_\w+(?:<[^>]*>)?)"
+    fi, nfi, msfi, wgi = per_kernel(fetch_csv, "FETCH_SIZE", INST)
+    wi, _, _, _ = per_kernel(write_csv, "WRITE_SIZE", INST)
+    for k in sorted(fi):
+        if "<" not in k:
+            continue
+        fb, wb = fi[k] * 1024 * 2, wi.get(k, 0.0) * 1024
+        res["instantiations"][k] = {"launches": nfi[k], "hbm_bytes_per_launch": (fb + wb) / max(nfi[k], 1), "total_ms": msfi[k],
+                                    "workgroups": wgi.get(k, 0),
+                                    "hbm_bytes_per_workgroup": (fb + wb) / wgi[k] if wgi.get(k) else None}
     for k in sorted(f):
         fb = f[k] * 1024 * 2
         wb = w.get(k, 0.0) * 1024

@@ -104,6 +104,17 @@ class OracleBackend:
         return match_lists_as_tables(find_good_matches_bruteforce(self.panel, Zs, nindices, min_len, max_matches), max_matches)
 
 
+    def mspbwt_select(self, Zs, n_label, nindices, L, M, Knew, seeds):
+        """DriverParams.mspbwt_search = "scan": the restated neighbour scan (tests/mspbwt_scan.py, numpy, written apart from
+        csrc/mspbwt.cpp) followed by the numpy text of select_new_haps_mspbwt_v3."""
+        from quilt_amd.mspbwt import select_new_haps_mspbwt_v3
+        from tests.mspbwt_scan import find_good_matches_scan
+        found = find_good_matches_scan(self.panel, np.asarray(Zs), nindices, L, M)
+        n_chain = len(found) // n_label
+        return np.stack([select_new_haps_mspbwt_v3(found[c * n_label:(c + 1) * n_label], Knew, self.panel.K, self.panel.nGrids,
+                                                   int(seeds[c])) for c in range(n_chain)]).astype(np.int32)
+
+
 def find_good_matches_bruteforce(panel, Zs, nindices, min_len, max_matches):
     """The definition in csrc/match.hip / include/quilt_amd.h (qa_find_good_matches), written out with numpy: per haplotype its
     longest (earliest) run of matching positions within each interleaved index; the max_matches longest of those with at least

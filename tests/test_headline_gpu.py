@@ -200,3 +200,29 @@ def test_haplotype_search_headline_size(head_panel, head_dev):
         for i in range(4):
             assert np.array_equal(got[q][i], ref[q][i]), (q, i)
     assert got[0][0][:, 2].max() == len(range(0, head_panel.nGrids, 4)) or (np.asarray(head_panel.hapMatcherR)[12345, 0::4] == 0).any()
+
+
+def test_mspbwt_neighbour_scan_headline_size(head_panel):
+    """use_mspbwt = TRUE at K = 50 000 x 2 000 grids, QUILT's defaults (four indices, mspbwtL = 3, mspbwtM = 1): the product's
+    query -- the panel's msPBWT indices and their neighbour scan, csrc/mspbwt.cpp -- returns the rows of the restated scan
+    (tests/mspbwt_scan.py) and select_new_haps_mspbwt_v3 chooses the same next small panel from both (`selected` = 1.0)."""
+    from quilt_amd.mspbwt import panel_mspbwt_index, rcpp_int_contract
+    from quilt_amd.synth import make_truth_haplotype
+    from tests.mspbwt_scan import find_good_matches_scan, selection_agreement
+    rng = np.random.default_rng(3)
+    clean = make_truth_haplotype(head_panel, rng)
+    noisy = make_truth_haplotype(head_panel, rng)
+    flip = rng.random(len(noisy)) < 0.002
+    noisy[flip] = 1 - noisy[flip]
+    Zs = np.stack([rcpp_int_contract(clean), rcpp_int_contract(noisy)])
+    idx = panel_mspbwt_index(head_panel, 4)
+    got = idx.find_good_matches(Zs, 3, 1)
+    want = find_good_matches_scan(head_panel, Zs, 4, 3, 1)
+    for q in range(2):
+        for i in range(4):
+            assert np.array_equal(got[q][i], want[q][i]), (q, i)
+    a = selection_agreement(want, got, KS, head_panel.K, head_panel.nGrids)
+    assert a["selected"] == 1.0 and a["longest"] == 1.0
+    sel = idx.select_new_haps(Zs, 2, 3, 1, KS, [77])
+    from quilt_amd.mspbwt import select_new_haps_mspbwt_v3
+    assert np.array_equal(sel[0], select_new_haps_mspbwt_v3(want, KS, head_panel.K, head_panel.nGrids, 77))

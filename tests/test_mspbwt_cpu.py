@@ -2,6 +2,7 @@
 quilt_amd/mspbwt.py, on hand-made match tables, and the mode end to end on the CPU path (oracle Gibbs + the numpy statement
 of the device search)."""
 import numpy as np
+import pytest
 
 
 def test_int_contract_and_mtm_table():
@@ -148,3 +149,56 @@ def test_selection_from_the_search_and_from_the_neighbour_scan(medium_panel):
         bf = find_good_matches_bruteforce(panel, Zs, 4, 1, 150)
         a = selection_agreement(sc, bf, 100, panel.K, panel.nGrids)
         assert a["selected"] >= bar_sel and a["longest"] >= bar_long, (err, a)
+
+
+@pytest.mark.parametrize("which,nind,L,M", [("small", 4, 3, 1), ("ragged", 3, 5, 2), ("medium", 1, 2, 1), ("medium", 4, 3, 1),
+                                            ("small", 2, 64, 1)])
+def test_native_neighbour_scan_equals_the_restatement(small_panel, ragged_panel, medium_panel, which, nind, L, M):
+    """csrc/mspbwt.cpp (the panel's msPBWT indices + the neighbour scan: the product's query behind select_new_haps_mspbwt_v3,
+    host code) against tests/mspbwt_scan.py, written apart from it: the same (haplotype, start, length) rows for every query and
+    index -- mosaic queries, noisy ones (words in no dictionary: no symbol), a panel haplotype itself, the all-reference
+    haplotype -- and the same next small panel from the fused scan + selection call."""
+    from quilt_amd.mspbwt import MsPbwtIndex, rcpp_int_contract, select_new_haps_mspbwt_v3
+    from quilt_amd.synth import panel_hap_bits
+    from tests.mspbwt_scan import find_good_matches_scan
+    panel = dict(small=small_panel, ragged=ragged_panel, medium=medium_panel)[which]
+    Zs = np.concatenate([_scan_queries(panel, 2, 0.0, 3), _scan_queries(panel, 2, 0.02, 4),
+                         np.stack([rcpp_int_contract(panel_hap_bits(panel, 5)), rcpp_int_contract(np.zeros(panel.nSNPs))])])
+    idx = MsPbwtIndex(panel, nind)
+    got = idx.find_good_matches(Zs, L, M)
+    want = find_good_matches_scan(panel, Zs, nind, L, M)
+    for q in range(len(Zs)):
+        for i in range(nind):
+            assert np.array_equal(got[q][i], want[q][i]), (q, i)
+    assert sum(len(m) for per in got for m in per) > 0
+    Knew = min(60, panel.K // 2)
+    sel = idx.select_new_haps(Zs, 2, L, M, Knew, [5, 6, 7])
+    for c in range(3):
+        assert np.array_equal(sel[c], select_new_haps_mspbwt_v3(want[2 * c:2 * c + 2], Knew, panel.K, panel.nGrids, [5, 6, 7][c]))
+    idx.close()
+
+
+def test_native_scan_refuses_what_it_cannot_index(small_panel):
+    from quilt_amd.mspbwt import MsPbwtIndex
+    with pytest.raises(ValueError):
+        MsPbwtIndex(small_panel, 0)
+    idx = MsPbwtIndex(small_panel, 2)
+    with pytest.raises(ValueError):
+        idx.find_good_matches(np.zeros((1, small_panel.nGrids), dtype=np.int32), 65, 1)
+    idx.close()
+
+
+def test_pipeline_mspbwt_scan_equals_exhaustive_interface(medium_panel):
+    """Both queries drive the same driver: the scan (default, the reference's semantics) and the exhaustive device-search
+    definition give complete, valid small panels; on the oracle backend the scan path is the numpy restatement."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=900 + i, n_reads=300) for i in range(1)]
+    for search in ("scan", "exhaustive"):
+        prm = DriverParams(nGibbsSamples=2, Ksubset=100, Knew=100, seed=3, use_mspbwt=True, mspbwt_nindices=2, mspbwt_search=search)
+        res = Driver(panel, OracleBackend(panel), prm).run(samples)
+        assert res[0].nDosage > 0 and np.isfinite(res[0].dosage).all()
+    with pytest.raises(ValueError):
+        DriverParams(use_mspbwt=True, Ksubset=100, Knew=100, mspbwt_search="index").resolved(panel.K)

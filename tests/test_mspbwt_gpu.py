@@ -46,7 +46,10 @@ def test_device_search_equals_its_definition(small_panel, ragged_panel, medium_p
     dev.close()
 
 
-def test_pipeline_mspbwt_matches_the_cpu_path(medium_panel):
+@pytest.mark.parametrize("search", ["scan", "exhaustive"])
+def test_pipeline_mspbwt_matches_the_cpu_path(medium_panel, search):
+    """``scan``: the product's msPBWT neighbour scan (csrc/mspbwt.cpp) against the numpy restatement the oracle backend runs;
+    ``exhaustive``: the device search (csrc/match.hip) against its numpy definition."""
     from quilt_amd.driver import Driver, DriverParams, HipBackend
     from quilt_amd.native import DevicePanel
     from quilt_amd.synth import make_synthetic_sample
@@ -54,7 +57,7 @@ def test_pipeline_mspbwt_matches_the_cpu_path(medium_panel):
     from tests.util import r2
     panel = medium_panel
     samples = [make_synthetic_sample(panel, seed=900 + i, n_reads=600) for i in range(2)]
-    prm = DriverParams(nGibbsSamples=2, Ksubset=100, Knew=100, seed=3, use_mspbwt=True, mspbwt_nindices=2)
+    prm = DriverParams(nGibbsSamples=2, Ksubset=100, Knew=100, seed=3, use_mspbwt=True, mspbwt_nindices=2, mspbwt_search=search)
     dev = DevicePanel(panel)
     got = Driver(panel, HipBackend(dev), prm).run(samples)
     dev.close()
