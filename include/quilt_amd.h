@@ -127,6 +127,12 @@ int qa_panel_create_from_rhb(const int32_t *rhb_t, int32_t K, int32_t nGrids, in
  * last grid 0.  Packed on the device in slabs of whole grids. */
 int qa_make_rhb_t_from_rhi_t(const int32_t *rhi_t, int32_t K, int32_t nSNPs, int32_t *rhb_t);
 
+/* The handle's dimensions (any output may be NULL), and binding the calling host thread to the handle's device (HIP's current
+ * device is per thread: a thread that allocates qa_host_alloc buffers for a handle binds first; the compute entry points bind
+ * by themselves). */
+int qa_panel_get_dims(const qa_panel_t *panel, int32_t *K, int32_t *nGrids, int32_t *nSNPs);
+int qa_panel_bind_thread(const qa_panel_t *panel);
+
 int qa_panel_export_tables(qa_panel_t *panel, uint8_t *hapMatcherR, int32_t *distinctHapsB, int32_t *special_off,
                            int32_t *special_k, int32_t *special_word, int64_t special_cap);
 
@@ -534,6 +540,113 @@ int qa_gibbs_batch_rare_common(qa_panel_t *panel, const qa_rare_common_t *rc, co
                                int32_t *H, int32_t *H_class, double *hapProbs_t, double *genProbsM_t,
                                double *genProbsF_t, int32_t *underflow_problem, double *state_out,
                                const uint64_t *seed_reads, const uint64_t *seed_shard);
+
+/* ---- the per-sample driver loop for a range of samples ---------------------- */
+
+/*
+ * Arguments of QUILT() the hot path sees (QUILT/R/quilt.R:97-186), as get_and_impute_one_sample receives them.
+ * qa_impute_params_default fills in the reference's defaults.
+ */
+typedef struct {
+    int32_t nGibbsSamples;                      /* 7 */
+    int32_t n_seek_its;                         /* 3 */
+    int32_t n_burn_in_seek_its;                 /* -1 = NA: n_seek_its - 1 (quilt.R:248-250) */
+    int32_t Ksubset, Knew;                      /* 600, 600; a panel with K < Ksubset: one seek iteration on all of it (quilt.R:453-471) */
+    int32_t K_top_matches;                      /* 5 */
+    double heuristic_match_thin;                /* 0.1 */
+    int32_t small_ref_panel_gibbs_iterations;   /* 20 */
+    int32_t n_gibbs_sample_its;                 /* 1 */
+    const int32_t *small_ref_panel_block_gibbs_iterations;   /* {3, 6, 9} (0-based sweeps), */
+    int32_t n_block_gibbs_iterations;           /* 3 */
+    double maxDifferenceBetweenReads;           /* 1e10 */
+    double minGLValue;                          /* 1e-10 */
+    int32_t Jmax;                               /* 10000 */
+    uint64_t seed;                              /* keys every (sample, Gibbs sample) stream together with the GLOBAL sample index */
+    int32_t use_mspbwt;                         /* 0: full-panel passes (impute_using_everything); 1: msPBWT mode */
+    int32_t mspbwtL, mspbwtM;                   /* 3, 1 */
+    const qa_mspbwt_t *mspbwt_index;            /* use_mspbwt: qa_mspbwt_create(..., nindices = mspbwt_nindices) */
+    int32_t samples_per_launch_set;             /* samples whose chains advance in one launch set; 0 = 256 (2 048 Gibbs chains:
+                                                   two per SIMD) */
+    int32_t no_fused_tails;                     /* 1: the threads' last launch sets run their phasing rounds one after the other */
+} qa_impute_params_t;
+int qa_impute_params_default(qa_impute_params_t *params);
+
+/*
+ * get_and_impute_one_sample (QUILT/R/functions.R:3-1500) for samples [0, n_sample) of the caller's range, method = "diploid":
+ * the body of the reference's loop over a core's sample range (QUILT/R/quilt.R:688-996: `for(iSample in sampleRange[1]:
+ * sampleRange[2])` inside mclapply) as ONE call -- (nGibbsSamples + 1) x n_seek_its rounds of [small-panel Gibbs -> full-panel
+ * pass per read label -> new small panel] per sample, accumulation over the rounds past the burn-in (functions.R:999-1020),
+ * read confidence and consensus labels (:1615-1660, :1680-1784), the phasing iteration and recast_haps (:3180-3209); host C++
+ * in csrc/impute.cpp over the batched entry points above.  All chains of a launch set of samples advance in lock-step; launch
+ * sets are pipelined (one set's phasing rounds share launches with the next set's main rounds); n_panels host threads, one
+ * per handle (replicas of the panel on one device, qa_panel_set_exclusive(1) so that their launch sets take the device in
+ * turn), hide each other's host phases.
+ *
+ *   panels            n_panels (1..16) handles of the SAME panel; 3 is what the headline workload wants
+ *   sample_offset     global index of sample 0: (seed, sample_offset + i, Gibbs sample) keys the draws, so a sample gets
+ *                     the same result whichever range, rank or launch set it lands in
+ *   read_off          n_sample + 1: reads of sample i are read_off[i] .. read_off[i + 1] - 1 (every sample needs >= 1)
+ *   read_ptr          per sample R_i + 1 offsets (starting at 0) into that sample's bases; sample i's block starts at
+ *                     read_ptr[read_off[i] + i]
+ *   u, bq             bases of all samples back to back (0-based SNP index, signed base quality); wif: per read, 0-based grid
+ *                     -- the flattened sampleReads of qa_bam_load_sample_reads / qa_gibbs_batch
+ *   dosage            out n_sample x nSNPs: mean over the counted rounds of hap1 + hap2
+ *   gp_t              out n_sample x 3 x nSNPs: genotype posteriors
+ *   phasing_haps      out n_sample x 2 x nSNPs: the phasing iteration's haplotypes after recast_haps (R's phasing_haps is
+ *                     its transpose per sample)
+ *   read_labels       out, read_off[n_sample] entries: the consensus labels the phasing iteration started from
+ *   nDosage           out n_sample: rounds counted
+ *   stats             NULL, or 11 counters: [0] underflow retries, [1] chains that needed complete best-haplotype lists,
+ *                     [2] selections made on the device, [3] chains handed to qa_gibbs_batch, [4] Gibbs launch sets,
+ *                     [5..10] ms summed over the host threads: Gibbs calls, full-panel calls, host, consensus, finish, accumulation
+ * Random draws: R's stream cannot be reproduced without R; every draw the R code makes is defined on a counter stream
+ * (quilt_amd/rng.py::ChainStream = csrc/impute.cpp).  NIPT and impute_rare_common are not behind this entry point yet
+ * (quilt_amd/driver.py runs them over the same batched calls): QA_ERR_UNSUPPORTED is reserved for them.
+ */
+int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impute_params_t *params, int32_t n_sample,
+                      int64_t sample_offset, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                      const int32_t *wif, double *dosage, double *gp_t, double *phasing_haps, int32_t *read_labels,
+                      int32_t *nDosage, int64_t *stats);
+
+/*
+ * Test hook: the same loop over a caller-supplied table of the batched entry points it calls (signatures = the qa_*
+ * functions named in the comments, with an opaque handle in place of the panel).  The product table is the library's own
+ * functions; tests/ pass a checker's (the CPU oracle) to run this very host code without a device.  Nothing in the
+ * library calls it.
+ */
+typedef struct {
+    int (*gibbs_batch)(void *handle, const qa_gibbs_opts_t *opts, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif,
+                       const double *runif_reads, const int32_t *first_read, const double *runif_shard, int32_t *H,
+                       int32_t *H_class, double *hapProbs_t, double *genProbsM_t, double *genProbsF_t, int32_t *underflow_problem,
+                       double *state_out, const uint64_t *seed_reads, const uint64_t *seed_shard);   /* qa_gibbs_batch */
+    int (*fullpass_reads_select_batch)(void *handle, int32_t n_chain, int32_t n_label, int32_t n_sample, const int32_t *chain_sample,
+                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *H,
+                       const int32_t *want_dosage, const int32_t *want_top, const int32_t *gammaSmall_cols_to_get,
+                       int32_t K_top_matches, double minGLValue, double *dosage, int32_t top_width, int32_t *top_idx,
+                       float *top_val, int32_t *top_cnt, int32_t Ksubset, int32_t Knew, const int32_t *which_haps_to_use,
+                       const uint64_t *seed_select, int32_t *which_next, int32_t *select_status);   /* qa_fullpass_reads_select_batch */
+    int (*fullpass_batch)(void *handle, int32_t n_pass, const double *gl, const int32_t *want_dosage,
+                       const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double *dosage, int32_t *best_ptr,
+                       int32_t *best_idx, double *best_val, int64_t best_cap);                        /* qa_fullpass_batch */
+    int (*make_eMatRead_t_hap_major)(void *handle, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                       double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t, double *eMatRead_t);
+    int (*mspbwt_select_new_haps)(const qa_mspbwt_t *index, int32_t n_chain, int32_t n_label, const int32_t *Zs, int32_t L,
+                       int32_t M, int32_t Knew, const uint64_t *seed, int32_t *out);                  /* qa_mspbwt_select_new_haps */
+    int (*accumulate_dosage)(int32_t n_chain, int32_t n_label, int32_t nSNPs, const double *hap, const int32_t *chain_sample,
+                       int32_t n_sample, double *dosage, double *gp_t, double *fet_dosage, double *fet_gp_t);
+    int (*consensus_read_labels)(int32_t nReads, int32_t n, const int32_t *labels, const double *p, int32_t K, double minrp,
+                       int32_t can_hap, int32_t *out);
+    void *(*host_alloc)(size_t bytes);
+    int (*host_free)(void *p);
+    void (*bind_thread)(void *handle);   /* may be NULL */
+} qa_impute_backend_t;
+int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,
+                              int32_t nSNPs, const qa_impute_params_t *params, int32_t n_sample, int64_t sample_offset,
+                              const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                              const int32_t *wif, double *dosage, double *gp_t, double *phasing_haps, int32_t *read_labels,
+                              int32_t *nDosage, int64_t *stats);
 
 #ifdef __cplusplus
 }

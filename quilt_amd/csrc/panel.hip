@@ -541,6 +541,26 @@ int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits) {
     return QA_OK;
 }
 
+int qa_panel_get_dims(const qa_panel_t *panel, int32_t *K, int32_t *nGrids, int32_t *nSNPs) {
+    if (!panel) {
+        qa::set_error("qa_panel_get_dims: null handle");
+        return QA_ERR_INVALID;
+    }
+    if (K) *K = panel->K;
+    if (nGrids) *nGrids = panel->G;
+    if (nSNPs) *nSNPs = panel->T;
+    return QA_OK;
+}
+
+int qa_panel_bind_thread(const qa_panel_t *panel) {
+    if (!panel) {
+        qa::set_error("qa_panel_bind_thread: null handle");
+        return QA_ERR_INVALID;
+    }
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    return hipSetDevice(panel->device) == hipSuccess ? QA_OK : QA_ERR_HIP;
+}
+
 int qa_Rcpp_make_gl_bound(double *gl, double minGLValue, const int32_t *to_fix, int32_t n_to_fix) {
     // reference-single.cpp:68-94; O(n_to_fix) host arithmetic, not worth a launch
     if (!gl || (n_to_fix > 0 && !to_fix)) return QA_ERR_INVALID;

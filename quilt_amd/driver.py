@@ -117,9 +117,10 @@ def thinned_grid_columns(nGrids: int, heuristic_match_thin: float) -> np.ndarray
     return cols
 
 
-def chain_rng(seed: int, i_sample: int, i_chain: int) -> np.random.Generator:
-    """Counter-based stream of one (sample, Gibbs chain): Philox keyed by the triple."""
-    return np.random.Generator(np.random.Philox(key=[(seed << 20) ^ i_sample, i_chain]))
+def chain_rng(seed: int, i_sample: int, i_chain: int):
+    """Counter-based stream of one (sample, Gibbs chain): quilt_amd/rng.py::ChainStream, the draws csrc/impute.cpp makes."""
+    from .rng import ChainStream
+    return ChainStream(seed, i_sample, i_chain)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -421,7 +422,7 @@ class ChainState:
     sample: object                    # the chain's SampleReads
     i_sample: int                     # index of the sample within its batch
     i_chain: int                      # 1..nGibbsSamples, nGibbsSamples + 1 = phasing
-    rng: np.random.Generator
+    rng: object                       # quilt_amd.rng.ChainStream
     which_haps_to_use: Optional[np.ndarray] = None   # 1-based
     read_labels: Optional[np.ndarray] = None
     hap: Optional[List[np.ndarray]] = None           # dosage1, dosage2 of the latest full pass
@@ -484,7 +485,7 @@ def preserve_round(x: np.ndarray) -> np.ndarray:
     return y.astype(np.int64)
 
 
-def get_initial_read_labels_nipt(e: np.ndarray, ff: float, rng: np.random.Generator) -> np.ndarray:
+def get_initial_read_labels_nipt(e: np.ndarray, ff: float, rng) -> np.ndarray:
     """rare_common.R:104-105 with get_read_groupings_given_fetal_fraction_and_cov and sample_H_for_NIPT_given_groupings
     (gibbs-nipt.R:1655-1777, :1796-1849): ``e`` = 3 x nReads rescaled likelihoods of the all-SNP reads against
     (hap1, hap2, hap3).  A read is grouped by which haplotypes it fits (> 0.5); reads that fit exactly one take its label,

@@ -1,0 +1,96 @@
+"""Thin caller of the native per-sample driver ``qa_impute_samples`` (csrc/impute.cpp, include/quilt_amd.h): the body of
+the reference's loop over a core's sample range (QUILT/R/quilt.R:688-996, ``get_and_impute_one_sample``
+QUILT/R/functions.R:3-1500) as ONE native call.  Everything between the native compute calls -- the round loop, the
+hand-over of ``which_haps_to_use``, accumulation, consensus labels, ``recast_haps``, the host threads per device -- is C++
+there; this module only flattens ``SampleReads`` objects and wraps the outputs.  ``quilt_amd/driver.py`` keeps the same loop
+in Python for the modes the native entry point does not cover yet (NIPT, ``impute_rare_common``) and as the tested statement
+the native loop must equal bit for bit (tests/test_native_driver_cpu.py, tests/test_native_driver_gpu.py)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .driver import DriverParams, SampleResult
+from .native import check, lib, ptr
+
+
+class ImputeParams(C.Structure):
+    _fields_ = [
+        ("nGibbsSamples", C.c_int32), ("n_seek_its", C.c_int32), ("n_burn_in_seek_its", C.c_int32),
+        ("Ksubset", C.c_int32), ("Knew", C.c_int32), ("K_top_matches", C.c_int32),
+        ("heuristic_match_thin", C.c_double),
+        ("small_ref_panel_gibbs_iterations", C.c_int32), ("n_gibbs_sample_its", C.c_int32),
+        ("small_ref_panel_block_gibbs_iterations", C.c_void_p), ("n_block_gibbs_iterations", C.c_int32),
+        ("maxDifferenceBetweenReads", C.c_double), ("minGLValue", C.c_double), ("Jmax", C.c_int32),
+        ("seed", C.c_uint64),
+        ("use_mspbwt", C.c_int32), ("mspbwtL", C.c_int32), ("mspbwtM", C.c_int32),
+        ("mspbwt_index", C.c_void_p),
+        ("samples_per_launch_set", C.c_int32), ("no_fused_tails", C.c_int32),
+    ]
+
+
+STAT_NAMES = ("underflow_retries", "full_list_refetches", "device_selections", "gibbs_chain_calls", "gibbs_launches",
+              "ms_gibbs", "ms_fullpass", "ms_host", "ms_consensus", "ms_finish", "ms_accumulate")
+
+
+def flatten_samples(samples: Sequence):
+    """``sampleReads`` of a range of samples in the flattened form of include/quilt_amd.h: read_off [n + 1], per sample
+    R + 1 read_ptr entries, bases and wif back to back."""
+    n = len(samples)
+    read_off = np.zeros(n + 1, dtype=np.int32)
+    for i, s in enumerate(samples):
+        read_off[i + 1] = read_off[i] + s.nReads
+    cat = lambda name: (np.concatenate([np.asarray(getattr(s, name), dtype=np.int32) for s in samples])
+                        if n else np.zeros(0, dtype=np.int32))
+    return read_off, cat("read_ptr"), cat("u"), cat("bq"), cat("wif")
+
+
+def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None, fuse_tails: bool = True):
+    """(ImputeParams, keep-alive objects) from the Python driver's parameters (method = "diploid", no rare + common)."""
+    if P.method != "diploid" or P.impute_rare_common:
+        raise ValueError("qa_impute_samples covers method = 'diploid' without impute_rare_common; use quilt_amd.driver.Driver")
+    blocks = np.ascontiguousarray(P.small_ref_panel_block_gibbs_iterations, dtype=np.int32)
+    if P.use_mspbwt and P.mspbwt_search != "scan":
+        raise ValueError("qa_impute_samples runs the msPBWT neighbour scan (mspbwt_search = 'scan')")
+    q = ImputeParams(P.nGibbsSamples, P.n_seek_its, -1 if P.n_burn_in_seek_its is None else P.n_burn_in_seek_its,
+                     P.Ksubset, P.Knew, P.K_top_matches, P.heuristic_match_thin, P.small_ref_panel_gibbs_iterations,
+                     P.n_gibbs_sample_its, ptr(blocks), len(blocks), P.maxDifferenceBetweenReads, P.minGLValue, P.Jmax,
+                     P.seed, int(P.use_mspbwt), P.mspbwtL, P.mspbwtM,
+                     mspbwt_index.handle if (P.use_mspbwt and mspbwt_index is not None) else None,
+                     int(samples_per_launch_set), 0 if fuse_tails else 1)
+    return q, (blocks, mspbwt_index)
+
+
+def wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off) -> List[SampleResult]:
+    return [SampleResult(dosage[i], gp_t[i], np.ascontiguousarray(haps[i].T), labels[read_off[i]:read_off[i + 1]].copy(),
+                         int(nDosage[i])) for i in range(len(samples))]
+
+
+def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverParams] = None, sample_offset: int = 0,
+                   samples_per_launch_set: int = 256, fuse_tails: bool = True, return_stats: bool = False):
+    """``devs``: one :class:`quilt_amd.native.DevicePanel` per host thread (replicas of one panel on one device; with more
+    than one, switch ``set_exclusive`` on).  Returns one SampleResult per sample (and the native counters)."""
+    panel = devs[0].panel
+    P = (params or DriverParams())
+    idx = None
+    if P.use_mspbwt:
+        from .mspbwt import panel_mspbwt_index
+        idx = panel_mspbwt_index(panel, P.mspbwt_nindices)
+    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails)
+    read_off, read_ptr, u, bq, wif = flatten_samples(samples)
+    n, T = len(samples), panel.nSNPs
+    dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 2, T))
+    labels = np.zeros(int(read_off[-1]), dtype=np.int32)
+    nDosage = np.zeros(n, dtype=np.int32)
+    stats = np.zeros(11, dtype=np.int64)
+    handles = (C.c_void_p * len(devs))(*[d.handle for d in devs])
+    L = lib()
+    L.qa_impute_samples.restype = C.c_int
+    check(L.qa_impute_samples(handles, C.c_int32(len(devs)), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off),
+                              ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels),
+                              ptr(nDosage), ptr(stats)))
+    del keep
+    out = wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off)
+    return (out, dict(zip(STAT_NAMES, stats.tolist()))) if return_stats else out

@@ -16,7 +16,7 @@ of host logic is restated here from the R text it cites --
 
 The arithmetic (Gibbs call, full-panel pass, read likelihoods against two haplotypes) is the CPU oracle's, called one chain
 at a time.  R's Mersenne-Twister cannot be reproduced without R, so the random draws are the ONE convention shared with the
-product: the chain's Philox stream and the counter streams of quilt_amd/rng.py, consumed in the order the R code draws
+product: the chain's stream (quilt_amd.rng.ChainStream) and the counter streams of quilt_amd/rng.py, consumed in the order the R code draws
 (functions.R:580, :584, gibbs-nipt.cpp:2845-2848, gibbs-nipt-block.cpp:2054, functions.R:746, :2294, :2301).
 
 tests/test_driver_twin_cpu.py compares :class:`quilt_amd.driver.Driver` on the oracle backend with this, sample by sample.
@@ -52,8 +52,9 @@ def full_gammaSmall_cols_to_get(nGrids, heuristic_match_thin):
 
 
 def chain_rng(seed, i_sample, i_gibbs_sample):
-    """The chain's draws: Philox keyed by (seed, sample, Gibbs sample) -- the stand-in for R's stream."""
-    return np.random.Generator(np.random.Philox(key=[(seed << 20) ^ i_sample, i_gibbs_sample]))
+    """The chain's draws: the counter stream keyed by (seed, sample, Gibbs sample) -- the stand-in for R's stream."""
+    from quilt_amd.rng import ChainStream
+    return ChainStream(seed, i_sample, i_gibbs_sample)
 
 
 def everything_per_hap_rejig_haps(best):

@@ -1,0 +1,120 @@
+"""The native per-sample driver loop (csrc/impute.cpp behind qa_impute_samples) without a device: the product's host code run
+through qa_impute_samples_backend over the CPU oracle's entry points (tests/native_driver_backend.py) must equal, bit for bit,
+(i) quilt_amd/driver.py on the oracle backend and (ii) the literal restatement of the R loop nest (tests/r_driver_twin.py) --
+whatever the launch-set size, the number of host threads or the handling of the stream's end."""
+import numpy as np
+import pytest
+
+from tests.oracle_backend import OracleBackend
+
+
+@pytest.fixture(scope="module")
+def twin_panel():
+    from quilt_amd.synth import make_synthetic_panel
+    return make_synthetic_panel(K=400, nSNPs=3200, seed=77, ref_error=1e-3)
+
+
+def _same(a, b):
+    assert a.nDosage == b.nDosage
+    assert np.array_equal(a.read_labels, b.read_labels), "consensus read labels"
+    assert np.array_equal(a.dosage, b.dosage), "dosage"
+    assert np.array_equal(a.gp_t, b.gp_t), "genotype posteriors"
+    assert np.array_equal(a.phasing_haps, b.phasing_haps), "phased haplotypes"
+
+
+def test_chain_stream_matches_numpy_text():
+    """csrc/impute.cpp's ChainStream == quilt_amd/rng.py::ChainStream: seen through the first-round draws (the small panel's
+    rows and the starting labels decide everything downstream), here directly on the rule for subsets."""
+    from quilt_amd.rng import ChainStream, keyed_subset, stream_u64
+    s = ChainStream(7, 3, 2)
+    a = s.choice(1000, 50, replace=False)
+    assert len(set(a.tolist())) == 50 and s.ctr == 1000
+    assert np.array_equal(a, keyed_subset(s.key, 1000, 50, 0))
+    x = s.integers(0, 2 ** 63)
+    assert 0 <= x < 2 ** 63 and x == int(np.floor((int(stream_u64(s.key, 1, 1000)[0]) >> 11) / 2.0 ** 53 * 2.0 ** 63))
+    lab = s.integers(1, 3, size=4000)
+    assert set(lab.tolist()) == {1, 2} and abs(lab.mean() - 1.5) < 0.05
+
+
+@pytest.mark.parametrize("kw", [
+    dict(nGibbsSamples=7, n_seek_its=3, Ksubset=64, Knew=64),
+    dict(nGibbsSamples=3, n_seek_its=3, Ksubset=64, Knew=24),
+    dict(nGibbsSamples=4, n_seek_its=2, n_burn_in_seek_its=0, Ksubset=48, Knew=48),
+    dict(nGibbsSamples=2, n_seek_its=3, Ksubset=200, Knew=200, K_top_matches=1, heuristic_match_thin=0.03),
+], ids=["defaults", "Knew<Ksubset", "no-burn-in", "exhausted-ranks"])
+def test_native_loop_equals_python_driver_and_r_twin(twin_panel, kw):
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.native_driver_backend import impute_samples_on_oracle
+    from tests.r_driver_twin import get_and_impute_one_sample
+    panel = twin_panel
+    samples = [make_synthetic_sample(panel, seed=300 + i, n_reads=260) for i in range(3)]
+    common = dict(small_ref_panel_gibbs_iterations=6, small_ref_panel_block_gibbs_iterations=(1, 3), seed=11)
+    P = DriverParams(**common, **kw)
+    want = Driver(panel, OracleBackend(panel), P).run(samples, sample_offset=5)
+    got, stats, tab = impute_samples_on_oracle(panel, samples, P, sample_offset=5, samples_per_launch_set=2)
+    for a, b in zip(got, want):
+        _same(a, b)
+    tw = get_and_impute_one_sample(panel, samples[1], 6, **common, **kw)
+    np.testing.assert_allclose(got[1].dosage, tw["dosage"], rtol=0, atol=1e-13)
+    assert np.array_equal(got[1].read_labels, tw["read_labels"])
+    np.testing.assert_allclose(got[1].phasing_haps, tw["phasing_haps"], rtol=0, atol=1e-12)
+    if kw.get("K_top_matches") == 1:   # the complete-lists branch (functions.R:2276-2302) ran in the native loop
+        assert stats["full_list_refetches"] > 0 and tab.calls["fullpass"] == stats["full_list_refetches"]
+    assert stats["gibbs_chain_calls"] >= len(samples) * (P.nGibbsSamples + 1) * P.n_seek_its
+
+
+@pytest.mark.parametrize("n_threads,per_set,fuse", [(1, 256, True), (1, 2, True), (3, 2, True), (3, 2, False), (2, 3, True), (4, 1, True)])
+def test_native_loop_is_independent_of_threads_and_launch_sets(twin_panel, n_threads, per_set, fuse):
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = twin_panel
+    samples = [make_synthetic_sample(panel, seed=500 + i, n_reads=150 + 10 * i) for i in range(7)]
+    P = DriverParams(nGibbsSamples=3, n_seek_its=2, Ksubset=64, Knew=40, small_ref_panel_gibbs_iterations=4,
+                     small_ref_panel_block_gibbs_iterations=(2,), seed=3)
+    want = Driver(panel, OracleBackend(panel), P).run(samples, sample_offset=10)
+    got, stats, _ = impute_samples_on_oracle(panel, samples, P, sample_offset=10, samples_per_launch_set=per_set,
+                                             n_threads=n_threads, fuse_tails=fuse)
+    for a, b in zip(got, want):
+        _same(a, b)
+    # pipelining: a set's phasing rounds share launches with the next set's main rounds
+    if n_threads == 1 and per_set == 2:
+        assert stats["gibbs_launches"] == (4 + 1) * P.n_seek_its
+
+
+def test_native_loop_mspbwt_mode(twin_panel):
+    """use_mspbwt = TRUE: no full-panel pass; the next small panel from the neighbour scan of the Gibbs call's rounded haploid
+    dosages (the library's host index), the dosages from the Gibbs call itself."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = twin_panel
+    samples = [make_synthetic_sample(panel, seed=700 + i, n_reads=220) for i in range(4)]
+    P = DriverParams(nGibbsSamples=3, n_seek_its=3, Ksubset=64, Knew=64, small_ref_panel_gibbs_iterations=5,
+                     small_ref_panel_block_gibbs_iterations=(2,), seed=9, use_mspbwt=True, mspbwt_nindices=2)
+    want = Driver(panel, OracleBackend(panel), P).run(samples, sample_offset=0)
+    got, stats, tab = impute_samples_on_oracle(panel, samples, P, samples_per_launch_set=3, n_threads=2)
+    assert tab.calls["select"] == 0 and tab.calls["fullpass"] == 0
+    for a, b in zip(got, want):
+        _same(a, b)
+
+
+def test_native_loop_reports_failures(twin_panel):
+    """A hard error of an entry point inside a worker thread ends the call with that status and its text; the other
+    threads -- including one waiting for the fused tail rounds -- are released."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = twin_panel
+    samples = [make_synthetic_sample(panel, seed=800 + i, n_reads=120) for i in range(6)]
+    P = DriverParams(nGibbsSamples=2, n_seek_its=2, Ksubset=48, Knew=48, small_ref_panel_gibbs_iterations=3,
+                     small_ref_panel_block_gibbs_iterations=(1,), seed=5)
+    for at in (1, 4, 7):
+        with pytest.raises(RuntimeError, match="status -4"):
+            impute_samples_on_oracle(panel, samples, P, samples_per_launch_set=1, n_threads=3, fail_at_call=("gibbs", at))
+    with pytest.raises(RuntimeError, match="no reads"):
+        from tests.native_driver_backend import _Reads
+        z = np.zeros(0, dtype=np.int32)
+        empty = _Reads(np.zeros(1, dtype=np.int32), z, z, z)
+        impute_samples_on_oracle(panel, [samples[0], empty], P)
