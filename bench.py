@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; 6.3 TB/s is what a streaming copy achieves)
 _CPU_PANEL = None
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_INSTS_FILE = os.path.join("profiles", "r04_pmc_insts.json")
 
 WORKLOADS = {
     "short": "BASELINE.json configs[2] (the K=50k configuration the metric is quoted on), per-GPU share",
@@ -293,6 +294,15 @@ def main():
                     help="also impute the first N samples of the last batch with the whole pipeline on the CPU oracle (its chains on "
                          "a thread pool: about a minute per sample on a many-core host; before any HIP context exists, rank 0 at "
                          "N = 1 only) and report the metric's `dosage r2 vs CPU ref`; 0 switches it off")
+    ap.add_argument("--driver", choices=["native", "python"], default=None,
+                    help="the per-sample loop between the native compute calls: native = qa_impute_samples (csrc/impute.cpp: C++ host "
+                         "threads, one call per sample range; the default where it applies: diploid samples without --rare-common), "
+                         "python = quilt_amd/driver.py + workers.py (Python threads over the same batched entry points)")
+    ap.add_argument("--dotcall", type=int, default=None, metavar="W",
+                    help="after the timed regions, measure the `.Call` shim's path as well (scripts/dotcall_path.py: per sample, per "
+                         "Gibbs sample, one qa_gibbs_batch(n_chain = 1) and one qa_Rcpp_haploid_dosage_versus_refs per label, from W "
+                         "worker processes sharing the GPU; one timed sample per worker) and report it as `dotcall_path`; default 16 "
+                         "for the headline workload at N = 1, 0 = off")
     ap.add_argument("--stub", action="store_true",
                     help="test hook: no device work at all (gloo rendezvous, a driver that returns zeros); value is 0")
     a = ap.parse_args()
@@ -315,6 +325,11 @@ def main():
     if a.fuse is None:
         a.fuse = 2 if a.mode == "short" else 1   # (ONT: short Gibbs launches, NIPT: three labels -- no 256-register build)
     a.fuse = max(1, a.fuse)
+    native_ok = a.mode != "nipt" and a.rare_common <= 0 and not (a.mspbwt and a.mspbwt_search != "scan") and not a.stub
+    if a.driver is None:
+        a.driver = "native" if native_ok and a.split == "alternate" and a.exclusive and not a.gibbs_gate and not a.cu_partition else "python"
+    if a.driver == "native" and not native_ok:
+        raise SystemExit("--driver native covers diploid samples without --rare-common (msPBWT mode: the neighbour scan)")
     os.environ.setdefault("QA_HOST_THREADS", str(max(2, (os.cpu_count() or 16) // max(1, local_world * a.workers))))
     params = dict(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
     full_chains = params["nGibbsSamples"] + 1
@@ -388,7 +403,12 @@ def main():
         from quilt_amd import native
         from quilt_amd.workers import DeviceWorkers
         native.check(native.lib().qa_set_device(local_rank))
-        drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
+        if a.driver == "native":
+            from quilt_amd.workers import NativeWorkers
+            drv = NativeWorkers(panel, DriverParams(**params), n_workers=a.workers, fp64_dosage=a.precision != "mixed",
+                                exclusive=bool(a.exclusive), fuse_tails=bool(a.fuse_tails))
+        else:
+          drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
                             cu_partition=a.cu_partition, fp64_dosage=a.precision != "mixed", split=a.split, gibbs_gate=a.gibbs_gate,
                             pass_priority=bool(a.pass_priority), exclusive=bool(a.exclusive),
                             fuse_tails=bool(a.fuse_tails), split_remainder=bool(a.split_remainder))
@@ -467,6 +487,23 @@ def main():
             a_, b_ = main_reg["last"][0].dosage, mixed_reg["last"][0].dosage
             out["mixed_precision"]["dosage_vs_fp64_run_sample0"] = {"r2": float(np.corrcoef(a_, b_)[0, 1] ** 2),
                                                                     "max_abs_diff": float(np.abs(a_ - b_).max())}
+        if a.dotcall is None:
+            a.dotcall = 16 if (world == 1 and a.mode == "short" and not a.mspbwt and rc is None and native is not None and
+                               not a.no_cpu_baseline) else 0
+        if a.dotcall > 0 and native is not None and world == 1:
+            # the device-wide arena goes with the last handle: the workers are processes of their own and need the memory
+            drv.close()
+            import subprocess
+            cmd = [sys.executable, os.path.join(ROOT, "scripts", "dotcall_path.py"), "--workers", str(a.dotcall), "--samples", "1",
+                   "--K", str(a.K), "--nsnps", str(a.nsnps), "--reads", str(a.reads), "--device", str(local_rank)]
+            if a.precision == "mixed":
+                cmd.append("--mixed")
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                out["dotcall_path"] = json.loads(r.stdout.strip().splitlines()[-1])
+                out["dotcall_path"]["batched_over_dotcall"] = out["value"] / max(out["dotcall_path"]["value"], 1e-12)
+            except Exception as e:   # noqa: BLE001 -- a reported leg, never the reason a bench line is lost
+                out["dotcall_path"] = {"error": repr(e)[:300]}
         if cpu_pipeline is not None:
             out["dosage_r2_vs_cpu_pipeline"] = r2_vs_cpu_pipeline(cpu_pipeline, main_reg["last"])
             if out.get("cpu_baseline"):
@@ -499,12 +536,14 @@ def read_profile(native):
     prof = []
     for k in range(L.qa_profile_count()):
         ms, n, b, busy, units, serial = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        wgs = C.c_double()
         L.qa_profile_get(k, C.byref(ms), C.byref(n), C.byref(b))
         L.qa_profile_get_busy(k, C.byref(busy))
         L.qa_profile_get_work(k, C.byref(units), C.byref(serial))
+        L.qa_profile_get_workgroups(k, C.byref(wgs))
         if n.value:
             prof.append(dict(kernel=L.qa_profile_name(k).decode(), ms=ms.value, launches=n.value, alg_bytes=b.value,
-                             busy_ms=busy.value, units=units.value, serial=serial.value))
+                             busy_ms=busy.value, units=units.value, serial=serial.value, workgroups=wgs.value))
     return prof
 
 
@@ -561,6 +600,8 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                              "lists back): value is the PCIe-inclusive rate"
                              + ("; --pageable: the dosage rounds come back into pageable memory through the library's staging copy"
                                 if a.pageable else ""),
+                   "driver": ("native: qa_impute_samples (csrc/impute.cpp), one call per sample range, C++ host threads" if a.driver == "native"
+                              else "python: quilt_amd/driver.py + workers.py over the batched entry points"),
                    "parallelism": f"samples sharded over {world} GPU(s), no collective; {a.workers} host threads per "
                                   "GPU (" + ("whole batches in turn" if a.split == "alternate" else "every batch cut into one part per thread") +
                                   "), consecutive batches pipelined"
@@ -599,13 +640,15 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                          _flag("mode", "short") == a.mode and _flag("K", 50000) == str(a.K) and
                          "--mspbwt" not in pmc["command"])
         if same_workload and rc is None and not a.mspbwt:
-            pk = pmc["kernels"][dom["kernel"]]
-            chains = reg["chains"]
-            if "hbm_bytes_per_workgroup" in pk and chains and dom["kernel"].startswith("k_gibbs"):
-                # launches come in sizes (a whole batch's chains, the phasing chains alone when the stream drains): the
-                # counters' bytes per workgroup (= per chain) times this run's chains per launch
-                traffic = pk["hbm_bytes_per_workgroup"] * chains / max(dom["launches"], 1)
-                how = f"bytes per workgroup (one per chain) x this run's {chains / max(dom['launches'], 1):.0f} chains per launch"
+            # per template instantiation where the summary has it (the sampler's two builds are different code)
+            inst = pmc.get("instantiations", {})
+            key = dom["kernel"] if dom["kernel"] in inst else ("k_gibbs<10, 1, false>" if dom["kernel"] == "k_gibbs" else None)
+            pk = inst[key] if key in inst else pmc["kernels"][dom["kernel"].split("<")[0]]
+            if pk.get("hbm_bytes_per_workgroup") and dom.get("workgroups") and dom["kernel"].startswith("k_gibbs"):
+                # launches come in sizes: the counters' bytes per workgroup (= per chain) times this run's chains per launch
+                traffic = pk["hbm_bytes_per_workgroup"] * dom["workgroups"] / max(dom["launches"], 1)
+                how = (f"bytes per workgroup (one per chain) of {key or dom['kernel']} x this run's "
+                       f"{dom['workgroups'] / max(dom['launches'], 1):.0f} chains per launch")
             else:
                 traffic = pk["hbm_bytes_per_launch"]
                 how = "bytes per launch"
@@ -614,25 +657,62 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
     except (OSError, KeyError, ValueError):
         pass
     ratio = (traffic / per_launch) if traffic else None
-    bound = "hbm" if (ratio is None or ratio >= 0.5) else "latency"
-    roof = {"bound": bound, "priced_against": "hbm", "kernel": dom["kernel"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-            "traffic_over_algorithmic": ratio,
+    # What the fraction is priced on.  The algorithmic bytes of SURVEY 8(d) are a contract, not a measurement: where the
+    # counters show that a kernel moves FEWER bytes than that (the sampler carries alpha in registers and reads compact
+    # emissions: ratio ~0.6) the algorithmic rate can exceed what HBM carries -- even the chip's peak -- and says nothing about
+    # the memory system.  `achieved` / `frac` are then the counters' bytes over the launch time (what HBM actually carried);
+    # the algorithmic figure stays beside it, flagged.
+    alg = {"bytes_per_launch": per_launch, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+           "note": "SURVEY 8(d) contract bytes / launch time; exceeds the traffic-based figure where bytes stay on chip"}
+    if ratio is not None and ratio < 1.0:
+        ach_t = traffic / 1e9 / (avg_ms / 1e3) if avg_ms > 0 else 0.0
+        alg["flag"] = "not_all_moved: counter traffic / algorithmic bytes = %.2f" % ratio
+        priced = "hbm traffic (PMC counters, scaled to this run's launches)"
+    else:
+        ach_t = ach
+        priced = "algorithmic bytes"
+    issue = None
+    try:   # the instruction-issue side of the same kernel build, from the committed SQ counter passes
+        pi = json.load(open(os.path.join(ROOT, PMC_INSTS_FILE)))["per_launch"]
+        ki = pi.get(dom["kernel"]) or pi.get("k_gibbs<10, 1, false>" if dom["kernel"] == "k_gibbs" else dom["kernel"])
+        if ki and ki.get("SQ_WAVE_CYCLES") and ki.get("SQ_WAVES"):
+            waves_per_simd = 2 if dom["kernel"] == "k_gibbs<10, 1, true>" else 1
+            wc = ki["SQ_WAVE_CYCLES"]
+            visits = (dom["units"] / dom["workgroups"]) if dom.get("workgroups") else None   # read visits + grid steps per chain
+            issue = {"what": "SQ counters per launch (quad-cycles), summed over the launch's waves; a SIMD holds waves_per_simd of them",
+                     "source": PMC_INSTS_FILE, "waves_per_simd": waves_per_simd,
+                     "valu_busy_frac_of_simd_cycles": round(min(1.0, waves_per_simd * ki.get("SQ_ACTIVE_INST_VALU", 0) / wc), 3),
+                     "any_inst_busy_frac_of_simd_cycles": round(min(1.0, waves_per_simd * ki.get("SQ_ACTIVE_INST_ANY", 0) / wc), 3),
+                     "wave_wait_frac": round(ki.get("SQ_WAIT_ANY", 0) / wc, 3),
+                     "wave_issue_stall_frac": round(ki.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+                     "salu_per_valu": round(ki.get("SQ_INSTS_SALU", 0) / max(ki.get("SQ_INSTS_VALU", 1), 1), 3)}
+            if visits:
+                per_wave = lambda c: ki.get(c, 0) / ki["SQ_WAVES"] / visits
+                issue["insts_per_read_visit_or_grid_step"] = {k.replace("SQ_INSTS_", "").lower(): round(per_wave(k), 1)
+                                                             for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM")}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
+    hbm_frac = ach_t / HBM_PEAK_GBS
+    bound = "hbm"
+    if issue is not None and issue["any_inst_busy_frac_of_simd_cycles"] > hbm_frac and ratio is not None and ratio < 1.0:
+        bound = "issue"
+    elif ratio is not None and ratio < 0.5:
+        bound = "latency"
+    roof = {"bound": bound, "priced_against": priced, "kernel": dom["kernel"], "achieved": ach_t, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_over_algorithmic": ratio, "algorithmic": alg, "issue": issue,
             "avg_launch_ms": avg_ms, "launches": dom["launches"], "alg_bytes_per_launch": per_launch,
             "aggregate": {"achieved": agg, "frac": agg / HBM_PEAK_GBS, "busy_ms": dom["busy_ms"],
-                          "note": "all overlapping launches of the kernel together: algorithmic bytes / time with >= 1 launch running"}}
+                          "note": "all overlapping launches of the kernel together: ALGORITHMIC bytes / time with >= 1 launch running"}}
     if traffic and dom["busy_ms"] > 0:   # what HBM actually carries while >= 1 launch of the kernel runs (counter bytes)
         hbm = traffic * dom["launches"] / 1e9 / (dom["busy_ms"] / 1e3)
         roof["aggregate"]["hbm_traffic_GBps"] = hbm
         roof["aggregate"]["hbm_traffic_frac_of_peak"] = hbm / HBM_PEAK_GBS
-    if bound == "latency":
-        roof["limited_by"] = ("fp64 VALU issue and dependency latency of one wave per SIMD (a serial chain per Gibbs chain); the "
-                              "counters show a fraction of the algorithmic bytes crossing HBM")
-    elif dom["kernel"].startswith("k_gibbs"):
-        roof["limited_by"] = ("both: a chain is a serial string of dependent fp64 instructions (one wave issues one every ~11 cycles: "
-                              "1 024 chains, one per SIMD, take 0.72 s); a launch set of 2 048 chains runs the 256-register build, two "
-                              "chains per SIMD filling each other's gaps (1.24 s), and then draws the aggregate.hbm_traffic_GBps "
-                              "above from HBM")
+    if dom["kernel"].startswith("k_gibbs"):
+        roof["limited_by"] = ("a chain is a serial string of dependent fp64 instructions per read (sums over the small panel, a wave "
+                              "reduction, a reciprocal, the draw); two chains per SIMD (the 256-register build) fill each other's "
+                              "waits; `issue` says how busy the SIMDs' issue slots are, `frac` how much of the HBM peak the launch's "
+                              "counter traffic amounts to -- the larger of the two names the bound")
     if dom["serial"] > 0:   # the serial chain's step time and the rate of read visits
         roof["us_per_grid_step"] = 1e3 * dom["ms"] / dom["serial"]
         roof["read_visits_and_grid_steps_per_s"] = dom["units"] / (dom["busy_ms"] / 1e3) if dom["busy_ms"] > 0 else None
@@ -650,7 +730,7 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
             roof["alone"] = {"avg_launch_ms": da[0]["avg_launch_ms"], "achieved": da[0]["GBps_per_launch"],
                              "frac": da[0]["frac_of_hbm_peak"]}
     out["host_seconds"] = {k: round(v, 3) for k, v in reg["timing"].items()}
-    gib = [p for p in prof if p["kernel"] in ("k_gibbs", "k_gibbs3")]
+    gib = [p for p in prof if p["kernel"].startswith("k_gibbs")]
     if gib and reg["chains"]:
         out["gibbs_chains_per_launch"] = round(reg["chains"] / max(sum(p["launches"] for p in gib), 1), 1)
     if a.exclusive and reg.get("gate"):

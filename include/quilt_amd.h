@@ -74,6 +74,8 @@ int qa_profile_count(void);
 const char *qa_profile_name(int32_t kernel);
 int qa_profile_get(int32_t kernel, double *ms, int64_t *launches, double *alg_bytes);
 int qa_profile_get_work(int32_t kernel, double *units, double *serial);
+/* Workgroups of the kernel's launches since the reset (Gibbs: one per chain; 0 for kernels that do not record them). */
+int qa_profile_get_workgroups(int32_t kernel, double *workgroups);
 /* Device time during which at least one launch of the kernel was running (ms, union of the launch intervals over all
  * streams): with several host threads the per-launch times of concurrent launches overlap, and the aggregate rate of a
  * kernel is alg_bytes / busy time. */

@@ -29,10 +29,12 @@ bool device_ready();
 
 // per-kernel accumulators (HIP-event time on the launch stream, launches, algorithmic HBM bytes)
 enum ProfileKernel { PK_EMAT = 0, PK_FWD, PK_BWD, PK_DOSAGE, PK_EMATREAD, PK_GIBBS, PK_HAPPROBS, PK_FWD64, PK_BWD64, PK_TOPK,
-                     PK_FWD64G, PK_BWD64G, PK_GIBBS3, PK_BLOCK3, PK_SELECT, PK_MATCH, PK_FWD64D, PK_BWD64D, PK_COUNT };
+                     PK_FWD64G, PK_BWD64G, PK_GIBBS3, PK_BLOCK3, PK_SELECT, PK_MATCH, PK_FWD64D, PK_BWD64D, PK_GIBBS_LEAN, PK_COUNT };
 // units / serial: work units of the launch (Gibbs: read visits + grid steps over all chains) and the length of its serial
 // chain (Gibbs: read visits + grid steps of the longest chain), for rates other than bytes per second
-void profile_add(int kernel, double ms, double alg_bytes, double start_ms = -1, double units = 0, double serial = 0);
+// workgroups: of the launch (a Gibbs launch: one per chain) -- what the counters' bytes per workgroup are scaled by
+void profile_add(int kernel, double ms, double alg_bytes, double start_ms = -1, double units = 0, double serial = 0,
+                 double workgroups = 0);
 double profile_clock_ms(hipEvent_t completed_event);
 
 struct HipError : std::runtime_error {

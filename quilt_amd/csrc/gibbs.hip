@@ -1426,7 +1426,8 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
             const double units = (double)n_its * totR + passes * (double)C * G;
             const double serial = (double)n_its * maxR + passes * (double)G;
             qa::profile_add(qa::PK_EMATREAD, ms[0], (double)totR * Ks * 8.0, t_e);
-            qa::profile_add(nH == 3 ? qa::PK_GIBBS3 : qa::PK_GIBBS, ms[1], sweeps * (nH / 2.0), t_e + ms[0], units, serial);
+            qa::profile_add(nH == 3 ? qa::PK_GIBBS3 : ((Ksp / 64 == 10 && nw == 1 && use_lean_build(C)) ? qa::PK_GIBBS_LEAN : qa::PK_GIBBS), ms[1],
+                            sweeps * (nH / 2.0), t_e + ms[0], units, serial, (double)C);
             if (want_probs) qa::profile_add(qa::PK_HAPPROBS, ms[2], C * (double)nH * Ks * (double)G * 16.0, t_e + ms[0] + ms[1]);
             if (tmg)
                 fprintf(stderr, "[qa_gibbs C=%d] host prep %.3f s, tables+uploads %.3f s (of which queued for the device %.3f s), kernels %.3f s (events %.3f), downloads %.3f s\n", C,

@@ -75,7 +75,7 @@ int32_t reference_matrix_search(int val, const int32_t *mat, int nrow, int s1, i
 }
 
 struct ProfileSlot {
-    double ms = 0, bytes = 0, units = 0, serial = 0;
+    double ms = 0, bytes = 0, units = 0, serial = 0, workgroups = 0;
     long long launches = 0;
     std::vector<std::pair<double, double>> busy;   // [start, end) of every launch, ms since the process's reference event
 };
@@ -97,20 +97,22 @@ double profile_clock_ms(hipEvent_t ev) {
     return ms;
 }
 
-void profile_add(int kernel, double ms, double alg_bytes, double start_ms, double units, double serial) {
+void profile_add(int kernel, double ms, double alg_bytes, double start_ms, double units, double serial, double workgroups) {
     if (kernel < 0 || kernel >= PK_COUNT) return;
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     g_profile[kernel].ms += ms;
     g_profile[kernel].bytes += alg_bytes;
     g_profile[kernel].units += units;
     g_profile[kernel].serial += serial;
+    g_profile[kernel].workgroups += workgroups;
     g_profile[kernel].launches += 1;
     if (start_ms >= 0) g_profile[kernel].busy.emplace_back(start_ms, start_ms + ms);
 }
 
 static const char *const kProfileNames[PK_COUNT] = {
     "k_emat", "k_fwd", "k_bwd", "k_dosage", "k_ematread", "k_gibbs", "k_happrobs", "k_fwd64", "k_bwd64", "k_topk",
-    "k_fwd<double>", "k_bwd<double>", "k_gibbs3", "k_block3", "k_select", "k_best_run", "k_fwd64d", "k_bwd64d"};
+    "k_fwd<double>", "k_bwd<double>", "k_gibbs3", "k_block3", "k_select", "k_best_run", "k_fwd64d", "k_bwd64d",
+    "k_gibbs<10, 1, true>"};   // (the sampler's 256-register build, two chains per SIMD: different code, priced by itself)
 
 // sp_gidx / sp_chunk_at (see panel.hpp): one thread per (grid with specials, 16-haplotype chunk), lower bound of the
 // chunk's first haplotype in the grid's ascending special list, shifted into the padded per-pass layout
@@ -160,6 +162,13 @@ int qa_profile_count(void) { return qa::PK_COUNT; }
 
 const char *qa_profile_name(int32_t kernel) {
     return (kernel >= 0 && kernel < qa::PK_COUNT) ? qa::kProfileNames[kernel] : "";
+}
+
+int qa_profile_get_workgroups(int32_t kernel, double *workgroups) {
+    if (kernel < 0 || kernel >= qa::PK_COUNT) return QA_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(qa::g_profile_mutex);
+    if (workgroups) *workgroups = qa::g_profile[kernel].workgroups;
+    return QA_OK;
 }
 
 int qa_profile_get_work(int32_t kernel, double *units, double *serial) {

@@ -223,3 +223,60 @@ class StubWorkers:
         for samples, _ in batches:
             yield [SampleResult(np.zeros(T), np.zeros((3, T)), np.zeros((T, 2)), np.zeros(s.nReads, dtype=np.int32), 0)
                    for s in samples]
+
+
+class NativeWorkers:
+    """The DeviceWorkers surface over the native driver loop (``qa_impute_samples``, csrc/impute.cpp): the host threads, the
+    pipelining of launch sets and the handling of the stream's end are C++ there; a stream of batches becomes ONE native call
+    (the batches' samples must be consecutive: they are one sample range).  ``n_workers`` panel handles = host threads."""
+
+    def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 3, fp64_dosage: bool = False,
+                 exclusive: bool = True, fuse_tails: bool = True):
+        self.n = n_workers
+        self.panel = panel
+        self.params = (params or DriverParams()).resolved(panel.K)
+        self.fuse_tails = fuse_tails
+        self.devs = [DevicePanel(panel) for _ in range(n_workers)]
+        for d in self.devs:
+            d.set_device_share(n_workers)
+            if exclusive and n_workers > 1:
+                d.set_exclusive(True)
+            if fp64_dosage:
+                d.set_dosage_precision(64)
+        # (bench.py's stand-alone kernel timings drive single rounds through the Python statement of the loop)
+        self.drivers = [Driver(panel, HipBackend(self.devs[0]), params)]
+        self.stats = {}
+        self.reset_timing()
+
+    def reset_timing(self):
+        self.timing = {"gibbs": 0.0, "fullpass": 0.0, "host": 0.0, "consensus": 0.0, "finish": 0.0, "accumulate": 0.0,
+                       "new_batch": 0.0}
+        self.n_gibbs_chain_calls = 0
+        self.n_gibbs_launches = 0
+
+    def close(self):
+        for d in self.devs:
+            d.close()
+
+    def run_stream(self, batches: Iterable[Tuple[list, int]]):
+        from .impute import impute_samples
+        batches = list(batches)
+        if not batches:
+            return
+        flat, at = [], batches[0][1]
+        for samples, offset in batches:
+            if offset != at:
+                raise ValueError("NativeWorkers.run_stream takes consecutive batches (one sample range)")
+            flat.extend(samples)
+            at += len(samples)
+        res, st = impute_samples(self.devs, flat, self.params, sample_offset=batches[0][1],
+                                 samples_per_launch_set=len(batches[0][0]), fuse_tails=self.fuse_tails, return_stats=True)
+        self.stats = st
+        for k in ("gibbs", "fullpass", "host", "consensus", "finish", "accumulate"):
+            self.timing[k] += st["ms_" + k] / 1e3
+        self.n_gibbs_chain_calls += st["gibbs_chain_calls"]
+        self.n_gibbs_launches += st["gibbs_launches"]
+        at = 0
+        for samples, _ in batches:
+            yield res[at:at + len(samples)]
+            at += len(samples)

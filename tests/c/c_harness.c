@@ -163,6 +163,54 @@ int main(void) {
     CHECK(memcmp(pinned, dosage, sizeof(double) * NT) == 0, "pinned and staged dosages are identical");
     CHECK(qa_host_free(pinned) == QA_OK, "qa_host_free");
     CHECK(qa_host_free(dosage) == QA_ERR_INVALID, "qa_host_free rejects foreign pointers");
+    {   /* the per-sample driver loop behind the ABI: two samples (the same reads twice: different global indices, so different
+         * draws), two host threads = two handles taking the device in turn; then one thread: the same bytes */
+        qa_panel_t *panel2 = NULL;
+        CHECK(qa_panel_create(&d, &panel2) == QA_OK && panel2, "second handle");
+        CHECK(qa_panel_set_device_share(panel, 2) == QA_OK && qa_panel_set_device_share(panel2, 2) == QA_OK, "device share");
+        CHECK(qa_panel_set_exclusive(panel, 1) == QA_OK && qa_panel_set_exclusive(panel2, 1) == QA_OK, "device phases");
+        qa_impute_params_t ip;
+        CHECK(qa_impute_params_default(&ip) == QA_OK, "qa_impute_params_default");
+        ip.nGibbsSamples = 3; ip.Ksubset = NKS; ip.Knew = NKS; ip.seed = 7; ip.samples_per_launch_set = 1;
+        static int32_t i_read_off[3] = {0, NR, 2 * NR}, i_read_ptr[2 * (NR + 1)], i_u[4 * NR], i_bq[4 * NR], i_wif[2 * NR];
+        for (int s2 = 0; s2 < 2; s2++) {
+            memcpy(i_read_ptr + s2 * (NR + 1), read_ptr, sizeof read_ptr);
+            memcpy(i_u + s2 * 2 * NR, u, sizeof u);
+            memcpy(i_bq + s2 * 2 * NR, bq, sizeof bq);
+            memcpy(i_wif + s2 * NR, wif, sizeof wif);
+        }
+        static double i_dos[2][2 * NT], i_gp[2][2 * 3 * NT], i_ph[2][2 * 2 * NT];
+        static int32_t i_lab[2][2 * NR], i_nd[2][2];
+        int64_t stats[11];
+        qa_panel_t *both[2] = {panel, panel2};
+        st = qa_impute_samples(both, 2, &ip, 2, 100, i_read_off, i_read_ptr, i_u, i_bq, i_wif, i_dos[0], i_gp[0], i_ph[0], i_lab[0],
+                               i_nd[0], stats);
+        CHECK(st == QA_OK, "qa_impute_samples (two host threads)");
+        CHECK(stats[3] >= 2 * 4 * 3 && stats[4] >= 3, "chains handed to the Gibbs entry point");
+        for (int s2 = 0; s2 < 2; s2++) {
+            CHECK(i_nd[0][s2] == 3, "nGibbsSamples x (n_seek_its - n_burn_in_seek_its) rounds counted");
+            for (int t = 0; t < NT; t++) {
+                const double *g3 = i_gp[0] + (size_t)s2 * 3 * NT;
+                CHECK(i_dos[0][s2 * NT + t] >= -1e-6 && i_dos[0][s2 * NT + t] <= 2 + 1e-6, "dosage in [0, 2]");
+                CHECK(fabs(g3[t] + g3[NT + t] + g3[2 * NT + t] - 1) < 1e-6, "genotype posteriors sum to 1");
+                CHECK(fabs(g3[NT + t] + 2 * g3[2 * NT + t] - i_dos[0][s2 * NT + t]) < 1e-6, "dosage = E[genotype]");
+            }
+            for (int r = 0; r < NR; r++) CHECK(i_lab[0][s2 * NR + r] == 1 || i_lab[0][s2 * NR + r] == 2, "consensus labels");
+        }
+        CHECK(memcmp(i_dos[0], i_dos[0] + NT, sizeof(double) * NT) != 0, "samples draw from their own streams (global index)");
+        st = qa_impute_samples(both, 1, &ip, 2, 100, i_read_off, i_read_ptr, i_u, i_bq, i_wif, i_dos[1], i_gp[1], i_ph[1], i_lab[1],
+                               i_nd[1], NULL);
+        CHECK(st == QA_OK, "qa_impute_samples (one host thread)");
+        CHECK(memcmp(i_dos[0], i_dos[1], sizeof i_dos[0]) == 0 && memcmp(i_gp[0], i_gp[1], sizeof i_gp[0]) == 0 &&
+              memcmp(i_ph[0], i_ph[1], sizeof i_ph[0]) == 0 && memcmp(i_lab[0], i_lab[1], sizeof i_lab[0]) == 0,
+              "results do not depend on the number of host threads");
+        i_read_off[2] = NR;   /* a sample without reads */
+        st = qa_impute_samples(both, 1, &ip, 2, 100, i_read_off, i_read_ptr, i_u, i_bq, i_wif, i_dos[1], i_gp[1], i_ph[1], i_lab[1],
+                               i_nd[1], NULL);
+        CHECK(st == QA_ERR_INVALID && strstr(qa_last_error(), "no reads"), "a sample without reads is refused");
+        qa_panel_destroy(panel2);
+        printf("IMPUTE_SAMPLES_OK\n");
+    }
     qa_panel_destroy(panel);
     free(runif_reads); free(runif_shard);
     printf("HARNESS_OK\n");

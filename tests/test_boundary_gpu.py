@@ -14,7 +14,7 @@ def test_c_harness_on_device():
     assert out.returncode == 0, out.stderr[-3000:]
     run = subprocess.run([os.path.join(ROOT, "tests", "c", "c_harness")], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "HARNESS_OK" in run.stdout, run.stdout + run.stderr
+    assert "HARNESS_OK" in run.stdout and "IMPUTE_SAMPLES_OK" in run.stdout, run.stdout + run.stderr
 
 
 def test_pinned_host_buffers_take_the_same_bytes_as_staged_ones():

@@ -1,0 +1,86 @@
+"""qa_impute_samples on the device: the native loop over the library's own entry points equals quilt_amd/driver.py over the
+same entry points bit for bit (every chain owns its random stream; the kernels are deterministic), for one and for three
+host threads, M1 and msPBWT mode, and agrees with the whole pipeline on the CPU oracle as the Python driver does."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def medium_panel():
+    from quilt_amd.synth import make_synthetic_panel
+    return make_synthetic_panel(K=5000, nSNPs=3200, seed=11)
+
+
+def _same(a, b):
+    assert a.nDosage == b.nDosage
+    assert np.array_equal(a.read_labels, b.read_labels)
+    assert np.array_equal(a.dosage, b.dosage)
+    assert np.array_equal(a.gp_t, b.gp_t)
+    assert np.array_equal(a.phasing_haps, b.phasing_haps)
+
+
+@pytest.mark.parametrize("mspbwt", [False, True])
+@pytest.mark.parametrize("n_threads", [1, 3])
+def test_native_driver_equals_python_driver_on_the_device(medium_panel, mspbwt, n_threads):
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=4100 + i, n_reads=500) for i in range(7)]
+    prm = DriverParams(nGibbsSamples=3, Ksubset=200, Knew=200, seed=21, use_mspbwt=mspbwt, mspbwt_nindices=2)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    want = Driver(panel, HipBackend(dev), prm).run(samples, sample_offset=40)
+    devs = [DevicePanel(panel) for _ in range(n_threads)]
+    for d in devs:
+        d.set_device_share(n_threads)
+        d.set_dosage_precision(64)
+        if n_threads > 1:
+            d.set_exclusive(True)
+    got, st = impute_samples(devs, samples, prm, sample_offset=40, samples_per_launch_set=2, return_stats=True)
+    for d in devs:
+        d.close()
+    dev.close()
+    for a, b in zip(got, want):
+        _same(a, b)
+    assert st["gibbs_chain_calls"] >= 7 * 4 * 3
+    if not mspbwt:
+        assert st["device_selections"] > 0
+
+
+def test_native_driver_agrees_with_the_cpu_pipeline(medium_panel):
+    """The metric's `dosage r2 vs CPU ref` for the native path: labels identical, dosages to 1e-9 (fp64 dosage passes)."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.oracle_backend import OracleBackend
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=4200 + i, n_reads=400) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=5)
+    ref = Driver(panel, OracleBackend(panel, n_threads=4), prm).run(samples)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    got = impute_samples([dev], samples, prm)
+    dev.close()
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.read_labels, r.read_labels)
+        assert np.abs(g.dosage - r.dosage).max() <= 1e-9
+        assert np.corrcoef(g.dosage, r.dosage)[0, 1] ** 2 >= 0.999999
+
+
+def test_native_driver_refuses_bad_input(medium_panel):
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel, QuiltAmdError
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.native_driver_backend import _Reads
+    dev = DevicePanel(medium_panel)
+    z = np.zeros(0, dtype=np.int32)
+    with pytest.raises(QuiltAmdError, match="no reads"):
+        impute_samples([dev], [make_synthetic_sample(medium_panel, seed=1, n_reads=50), _Reads(np.zeros(1, dtype=np.int32), z, z, z)],
+                       DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64))
+    dev.close()

@@ -137,7 +137,8 @@ def test_host_threads_take_the_device_in_phases(medium_panel, mspbwt):
     got = list(wk.run_stream(batches))
     wk.close()
     st = native.gate_stats(0)
-    assert st["holds"] > st["gibbs_holds"] > 0 and st["held_ms"] > 0
+    # (msPBWT mode with the default neighbour scan has no device work besides the Gibbs launches: the query is host code)
+    assert st["gibbs_holds"] > 0 and st["held_ms"] > 0 and (st["holds"] == st["gibbs_holds"] if mspbwt else st["holds"] > st["gibbs_holds"])
     dev = DevicePanel(panel)
     for (smp, off), g_batch in zip(batches, got):
         ref = Driver(panel, HipBackend(dev), prm).run(smp, sample_offset=off)
