@@ -354,7 +354,7 @@ def main():
     # same run" at every N without the ranks' own sample generation competing for the cores (a flag file in /tmp keyed by the
     # launcher's pid and port: no process group -- and so no HIP context -- is needed yet)
     cpu_flag = None
-    if world > 1 and not a.stub:
+    if world > 1:
         cpu_flag = f"/tmp/quilt_amd_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.cpu_done"
     if rank == 0 and not a.no_cpu_baseline and rc is None and not a.stub:
         cpu, keep = cpu_baseline(panel, a.reads, params, full_chains, ff=ff, mspbwt=a.mspbwt)
@@ -365,6 +365,7 @@ def main():
             t_wait = time.time()
             while not os.path.exists(cpu_flag) and time.time() - t_wait < 600:
                 time.sleep(0.2)
+            a.waited_for_rank0_s = time.time() - t_wait
     n_steps = a.warmup + a.steps
     seeds = [1000 + (rank * n_steps + st) * a.batch + i for st in range(n_steps) for i in range(a.batch)]
     bam_dir, bam_load_s = None, None
@@ -451,11 +452,20 @@ def main():
             last = res[-a.batch:]   # (the results of the last STEP: the tail of the last launch set)
         barrier()
         elapsed = time.perf_counter() - t0
+        per_rank = None
         if world > 1:
+            # every rank's own clock around its K steps (the barrier on either side makes them nearly equal; what differs is a
+            # rank that finished early and waited), its host-thread budget and how long it waited for rank 0's CPU legs
+            mine = torch.tensor([elapsed, float(os.environ.get("QA_HOST_THREADS", "0")), float(getattr(a, "waited_for_rank0_s", 0.0))],
+                                dtype=torch.float64, device="cpu" if a.stub else "cuda")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [[float(x) for x in r.cpu()] for r in allr]
             t = torch.tensor([elapsed], device="cpu" if a.stub else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        reg = dict(elapsed=elapsed, last=last, timing=dict(drv.timing), chains=getattr(drv, "n_gibbs_chain_calls", 0))
+        reg = dict(elapsed=elapsed, last=last, timing=dict(drv.timing), chains=getattr(drv, "n_gibbs_chain_calls", 0),
+                   per_rank=per_rank)
         if native is not None:
             reg["prof"] = read_profile(native)
             reg["gate"] = native.gate_stats(local_rank)
@@ -614,6 +624,17 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                                   + ("; launch sets left over by the thread count are cut into one part per thread"
                                      if a.split_remainder and a.split == "alternate" and a.workers > 1 else "")},
     }
+    if reg.get("per_rank"):
+        el = [r[0] for r in reg["per_rank"]]
+        rate = [0.0 if a.stub else a.batch * a.steps / max(e, 1e-12) for e in el]
+        out["ranks"] = {"n": world, "elapsed_s": [round(e, 4) for e in el],
+                        "samples_per_sec_min": min(rate), "samples_per_sec_max": max(rate),
+                        "QA_HOST_THREADS": [int(r[1]) for r in reg["per_rank"]],
+                        "host_threads_per_rank": a.workers, "logical_cpus": os.cpu_count(),
+                        "waited_for_rank0_cpu_legs_s": [round(r[2], 2) for r in reg["per_rank"]],
+                        "what": "per rank: its own clock around the K timed steps (value uses the MAX), the host threads one native "
+                                "call may start (the node's cores divided between the ranks and their host threads), and how long "
+                                "the rank waited at the flag file for rank 0's CPU baseline legs before creating its HIP context"}
     if getattr(a, "bam_load_s", None) is not None:
         out["bam_load_ms_per_sample"] = 1e3 * a.bam_load_s
     if a.stub:

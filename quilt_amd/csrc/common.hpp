@@ -267,11 +267,24 @@ struct Arena {
     Arena &operator=(const Arena &) = delete;
     ~Arena() { if (base && owned) (void)hipFree(base); }
     void reset() { off = 0; }
+    // Share of the device's free memory the launch sets are planned against.  The rest (12 %: 34 GB of 288) is headroom for
+    // what lives outside the arena: the handles' own per-thread buffers (read tables, labels, lists: tens of MB each), the
+    // panel replicas (0.1 GB each) and the runtime's own allocations.  QA_ARENA_FRACTION (0.1 .. 0.95) overrides it.
+    static double fraction() {
+        static const double f = [] {
+            if (const char *e = getenv("QA_ARENA_FRACTION")) {
+                const double v = atof(e);
+                if (v >= 0.1 && v <= 0.95) return v;
+            }
+            return 0.88;
+        }();
+        return f;
+    }
     // bytes this arena may grow to: what is free now plus what it already holds, with headroom
     size_t budget() const {
         size_t free_b = 0, total_b = 0;
         QA_HIP(hipMemGetInfo(&free_b, &total_b));
-        return (size_t)((free_b + cap) * 0.88);
+        return (size_t)((free_b + cap) * fraction());
     }
     // the same for a handle that shares the device with `share` - 1 others: an equal part of the device at most, but not a
     // fraction of what is free NOW (the others' arenas are already out of `free`: dividing that again by `share` counted
@@ -279,7 +292,7 @@ struct Arena {
     size_t budget_shared(int share) const {
         size_t free_b = 0, total_b = 0;
         QA_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t mine = (size_t)((free_b + cap) * 0.88), part = (size_t)(total_b * 0.88 / (share > 0 ? share : 1));
+        const size_t mine = (size_t)((free_b + cap) * fraction()), part = (size_t)(total_b * fraction() / (share > 0 ? share : 1));
         return mine < part ? mine : part;
     }
     void require(size_t bytes) {

@@ -893,7 +893,7 @@ size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stor
 // how many homogeneous passes fit, and make the arena big enough for them
 int plan_chunk(qa_panel *pn, size_t per_pass, int remaining) {
     const size_t fixed = (size_t)pn->G * 8 + ((size_t)2 << 20);
-    const size_t budget = pn->A().budget_shared(pn->sharers());
+    const size_t budget = pn->plan_budget();
     long n = budget > fixed ? (long)((budget - fixed) / per_pass) : 0;
     n = std::max<long>(1, std::min<long>(n, remaining));
     // One pass is one workgroup and a compute unit holds one such workgroup: a launch runs in rounds of n_cu passes.  When

@@ -1523,7 +1523,7 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             const int R = read_off[c + 1] - read_off[c];
             base_of[c + 1] = base_of[c] + (size_t)(read_ptr + read_off[c] + c)[R];
         }
-        const size_t budget = pn->A().budget_shared(pn->sharers());
+        const size_t budget = pn->plan_budget();
         // device bytes per chain: read emissions -- pattern bytes + table (512 B) per read, a dense Ks-column for the reads
         // with more bases than the pattern width (an upper bound of those that end up dense) -- and the state matrices.
         // Pattern bytes per read: 64 lanes x padb_of(rows per lane) with one wave, 128 x 8 with two (the geometries the

@@ -39,7 +39,9 @@ bool device_ready() {
 }
 
 DeviceGate &device_gate(int device) {
-    static DeviceGate gates[16];
+    // never destroyed: a static's destructor would run after the HIP runtime may already be gone (hipFree at exit); the
+    // arena itself is freed by gate_user when the last handle that opted in goes
+    static DeviceGate *const gates = new DeviceGate[16];
     return gates[device >= 0 && device < 16 ? device : 0];
 }
 // handles that opted in; the last one out frees the device-wide arena

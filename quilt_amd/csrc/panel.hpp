@@ -54,6 +54,14 @@ struct qa_panel {
         std::lock_guard<std::mutex> lk(g.mu);
         g.grow_arena(bytes);
     }
+    // the bytes launch sets are planned against: the arena's budget, read under the gate's lock for an exclusive handle (another
+    // host thread's admission may be re-allocating the device-wide arena at this moment)
+    size_t plan_budget() {
+        if (!exclusive) return arena.budget_shared(share);
+        qa::DeviceGate &g = qa::device_gate(device);
+        std::lock_guard<std::mutex> lk(g.mu);
+        return g.arena.budget_shared(1);
+    }
     int sharers() const { return exclusive ? 1 : share; }   // handles whose launch sets may be on the device at the same time
     qa::Arena aux;              // per-call index / list buffers of the driver-level entry points (grow-only: a call-local
                                 // hipMalloc / hipFree pair would synchronise the device with the other host threads' launches)

@@ -43,30 +43,62 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+preload_note = ""   # what _preload_hip_runtime decided, for diagnostics
+
+
+def _soname_in(path: str, stem: bytes):
+    """The versioned soname ``<stem>.so.N`` a shared object carries (its own SONAME or a DT_NEEDED entry): the first match in
+    the file's string table."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            m = re.search(re.escape(stem) + rb"\.so\.\d+", f.read())
+        return m.group(0) if m else None
+    except OSError:
+        return None
+
+
 def _preload_hip_runtime():
-    """One HIP runtime per process.  libquilt_amd.so needs libamdhip64; PyTorch-ROCm ships its own copy (same soname) and
-    loads it when torch is imported.  Whichever copy is mapped first serves both -- but if THIS library came first with the
-    system's copy, torch's later import ended up with a second runtime that saw no device (the load-order trap of round 2).
-    So when a torch installation exists and has not been imported yet, its copy is mapped here first: this library binds to
-    it, and a later ``import torch`` finds it already there.  Hosts without torch (R) are not affected."""
+    """One HIP runtime per process.  libquilt_amd.so needs libamdhip64; PyTorch-ROCm ships its own copy and loads it when
+    torch is imported.  Whichever copy is mapped first serves both -- but if THIS library came first with the system's copy,
+    torch's later import ended up with a second runtime that saw no device (the load-order trap of round 2).  So when a
+    torch installation exists, has not been imported yet AND its runtime has the soname this library was linked against, its
+    copy is mapped here first: this library binds to it, and a later ``import torch`` finds it already there.  A torch built
+    against another ROCm major (another soname) is left alone -- two different runtimes cannot serve one process, and this
+    library must run on the one it was built with; callers that also need that torch import it first themselves.
+    ``QUILT_AMD_TORCH_HIP=0`` switches the preload off, ``=1`` forces it.  Hosts without torch (R) are not affected."""
     import importlib.util
     import sys
+    global preload_note
+    want = os.environ.get("QUILT_AMD_TORCH_HIP", "")
+    if want == "0":
+        preload_note = "off (QUILT_AMD_TORCH_HIP=0)"
+        return
     if "torch" in sys.modules:
+        preload_note = "torch already imported"
         return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if spec is None or not spec.submodule_search_locations:
+        preload_note = "no torch installation"
         return
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    theirs = _soname_in(os.path.join(libdir, "libamdhip64.so"), b"libamdhip64")
+    ours = _soname_in(LIB_PATH, b"libamdhip64")
+    if want != "1" and (theirs is None or ours is None or theirs != ours):
+        preload_note = f"skipped: torch ships {theirs}, this library needs {ours}"
+        return
     for name in ("libhsa-runtime64.so", "libamd_comgr.so", "libamdhip64.so"):
         path = os.path.join(libdir, name)
         if os.path.exists(path):
             try:
                 C.CDLL(path, mode=C.RTLD_GLOBAL)
             except OSError:
+                preload_note = f"could not map {path}"
                 return
+    preload_note = f"torch's {theirs.decode() if theirs else 'runtime'} mapped first"
 
 
 def lib() -> C.CDLL:

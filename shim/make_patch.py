@@ -9,6 +9,7 @@ What the patch does, and nothing else:
     functions (qa_QUILT_<fn>, same arities) instead of the Rcpp wrappers; four `extern "C"` declarations are added above the
     table.  The Rcpp wrappers stay defined (no duplicate symbol: the shim's functions have other names) and unregistered.
     `Rcpp::compileAttributes()` regenerates this file: re-apply the patch afterwards.
+  * the same table gets one NEW row, qa_impute_sample_range (5 arguments): the loop over a core's sample range as one call.
   * QUILT/src/Makevars -- the include path of include/quilt_amd.h, -DQA_HAVE_R (the shim then includes R's own headers) and
     the link line for libquilt_amd.so (QUILT_AMD = the root of this repository).
   * QUILT/src/quilt_amd_shim.c -- added by copying shim/quilt_amd_shim.c (R compiles every .c in src/); the patch carries a
@@ -25,19 +26,31 @@ ENTRIES = {"_QUILT_rcpp_make_eMatRead_t": 15, "_QUILT_Rcpp_make_gl_bound": 3, "_
            "_QUILT_Rcpp_haploid_dosage_versus_refs": 38}
 
 
+# routines the reference does not have: the loop over a core's sample range as one call (quilt.R:688-996 -> qa_impute_samples)
+EXTRA = {"qa_impute_sample_range": 5}
+
+
 def patched_rcppexports(text):
     lines = text.split("\n")
     out, seen = [], set()
+    in_table = False
     for ln in lines:
         if ln.startswith("static const R_CallMethodDef CallEntries[]"):
             out.append("// libquilt_amd: the hot path's entry points (quilt_amd_shim.c), registered below under the reference's names")
             for name, n in ENTRIES.items():
                 out.append('extern "C" SEXP qa%s(%s);' % (name, ", ".join(["SEXP"] * n)))
+            for name, n in EXTRA.items():
+                out.append('extern "C" SEXP %s(%s);' % (name, ", ".join(["SEXP"] * n)))
+            in_table = True
         m = re.match(r'\s*\{"(_QUILT_\w+)", \(DL_FUNC\) &(_QUILT_\w+), (\d+)\},', ln)
         if m and m.group(1) in ENTRIES:
             assert m.group(1) == m.group(2) and int(m.group(3)) == ENTRIES[m.group(1)], ln
             ln = '    {"%s", (DL_FUNC) &qa%s, %d},' % (m.group(1), m.group(1), ENTRIES[m.group(1)])
             seen.add(m.group(1))
+        if in_table and re.match(r"\s*\{NULL, NULL, 0\}", ln):   # new routines of the shim: rows of their own before the terminator
+            for name, n in EXTRA.items():
+                out.append('    {"%s", (DL_FUNC) &%s, %d},' % (name, name, n))
+            in_table = False
         out.append(ln)
     assert seen == set(ENTRIES), "CallEntries rows not found: %s" % (set(ENTRIES) - seen)
     return "\n".join(out)

@@ -45,6 +45,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "../include/quilt_amd.h"
@@ -516,6 +517,162 @@ SEXP qa_QUILT_rcpp_make_eMatRead_t(SEXP eMatRead_tSEXP, SEXP sampleReadsSEXP, SE
     return R_NilValue;
 }
 
+
+/* ---- qa_impute_sample_range: the body of QUILT()'s loop over a core's samples as ONE `.Call` -----------------------------
+ * QUILT/R/quilt.R:688-996 runs `for(iSample in sampleRange[1]:sampleRange[2]) get_and_impute_one_sample(...)` inside
+ * mclapply; with the GPU library the whole range goes to qa_impute_samples (include/quilt_amd.h; csrc/impute.cpp: the loop of
+ * functions.R:3-1500 in host C++ over the batched kernels), n_handles host threads sharing the device.  R-side (INTEGRATION.md
+ * 4a has the replacement of the mclapply body):
+ *     out <- .Call("qa_impute_sample_range", list_of_sampleReads, panel_objects, params, sample_offset, n_handles)
+ *   list_of_sampleReads   one sampleReads (list of list(J, wif, bq, u), copied-from-stitch.cpp:153-160) per sample of the range
+ *   panel_objects         named list: hapMatcherR, distinctHapsB, distinctHapsIE, eMatDH_special_matrix_helper,
+ *                         eMatDH_special_matrix, rhb_t, transMatRate_t (2 x (nGrids - 1)), ref_error, use_eMatDH_special_symbols
+ *   params                named list of QUILT()'s arguments the path sees (missing entries = the reference's defaults):
+ *                         nGibbsSamples, n_seek_its, n_burn_in_seek_its, Ksubset, Knew, K_top_matches, heuristic_match_thin,
+ *                         small_ref_panel_gibbs_iterations, small_ref_panel_block_gibbs_iterations (0-based), maxDifferenceBetweenReads,
+ *                         minGLValue, Jmax, seed, samples_per_launch_set
+ *   sample_offset         0-based index of the range's first sample among ALL samples (keys the random streams: a sample's
+ *                         result does not depend on the range it lands in)
+ * Returns list(dosage = nSNPs x n, gp_t = 3 nSNPs x n (per sample 3 x nSNPs, row-major as the library writes it),
+ * phasing_haps = 2 nSNPs x n, read_labels = list of integer vectors, nDosage, stats).  Draws: the library's counter streams
+ * (R's stream cannot be handed to 2 048 chains advancing in lock-step); `seed` plays set.seed's part. */
+
+static double num_or(SEXP list, const char *name, double dflt) {
+    SEXP v = list_get(list, name);
+    return (v == R_NilValue || Rf_length(v) < 1) ? dflt : Rf_asReal(v);
+}
+
+SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP, SEXP sample_offsetSEXP, SEXP n_handlesSEXP) {
+    const int n = Rf_length(readsListSEXP);
+    int n_handles = Rf_asInteger(n_handlesSEXP);
+    if (n_handles < 1) n_handles = 1;
+    if (n_handles > 16) n_handles = 16;
+    SEXP hapMatcherR = list_get(panelSEXP, "hapMatcherR"), distinctHapsB = list_get(panelSEXP, "distinctHapsB");
+    SEXP distinctHapsIE = list_get(panelSEXP, "distinctHapsIE"), tm = list_get(panelSEXP, "transMatRate_t");
+    SEXP helper = list_get(panelSEXP, "eMatDH_special_matrix_helper"), spmat = list_get(panelSEXP, "eMatDH_special_matrix");
+    SEXP rhb_t = list_get(panelSEXP, "rhb_t");
+    if (hapMatcherR == R_NilValue || distinctHapsB == R_NilValue || distinctHapsIE == R_NilValue || tm == R_NilValue ||
+        helper == R_NilValue || spmat == R_NilValue)
+        Rf_error("quilt_amd: qa_impute_sample_range: panel_objects needs hapMatcherR, distinctHapsB, distinctHapsIE, "
+                 "eMatDH_special_matrix_helper, eMatDH_special_matrix, transMatRate_t");
+    const int K = Rf_nrows(hapMatcherR), G = Rf_ncols(hapMatcherR), T = Rf_ncols(distinctHapsIE);
+    /* one handle per host thread: replicas of the panel on this process's device, taking the device in turn */
+    qa_panel_desc_t d;
+    memset(&d, 0, sizeof d);
+    d.K = K; d.nGrids = G; d.nSNPs = T; d.nMaxDH = Rf_nrows(distinctHapsB);
+    d.hapMatcherR = RAW(hapMatcherR);
+    const int have_rhb = rhb_t != R_NilValue && Rf_nrows(rhb_t) == K && Rf_ncols(rhb_t) == G;
+    d.rhb_t = have_rhb ? INTEGER(rhb_t) : NULL;
+    d.distinctHapsB = INTEGER(distinctHapsB);
+    d.distinctHapsIE = REAL(distinctHapsIE);
+    int *which = (int *)calloc((size_t)G, sizeof(int));
+    int nsp = 0;
+    for (int g = 0; g < G; g++)
+        if (Rf_nrows(helper) == G && INTEGER(helper)[g] > 0) which[g] = ++nsp;
+    d.eMatDH_special_grid_which = which;
+    d.eMatDH_special_matrix_helper = Rf_nrows(helper) == G ? INTEGER(helper) : NULL;
+    d.eMatDH_special_matrix = INTEGER(spmat);
+    d.eMatDH_special_matrix_nrow = Rf_nrows(spmat);
+    d.use_eMatDH_special_symbols = !have_rhb || (int)num_or(panelSEXP, "use_eMatDH_special_symbols", 0);
+    d.transMatRate_t = REAL(tm);
+    d.ref_error = num_or(panelSEXP, "ref_error", 1e-3);
+    qa_panel_t *handles[16];
+    int made = 0, st = QA_OK;
+    for (; made < n_handles && st == QA_OK; made++) {
+        handles[made] = NULL;
+        st = qa_panel_create(&d, &handles[made]);
+        if (st == QA_OK) st = qa_panel_set_device_share(handles[made], n_handles);
+        if (st == QA_OK && n_handles > 1) st = qa_panel_set_exclusive(handles[made], 1);
+        if (st == QA_OK) st = qa_panel_set_dosage_precision(handles[made], 64);   /* the reference computes in double */
+    }
+    free(which);
+    if (st != QA_OK) {
+        for (int i = 0; i < made; i++) if (handles[i]) qa_panel_destroy(handles[i]);
+        check_status(st, "qa_panel_create");
+    }
+    /* flatten the range's sampleReads */
+    int32_t *read_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    read_off[0] = 0;
+    size_t nbases = 0;
+    for (int i = 0; i < n; i++) {
+        SEXP sr = VECTOR_ELT(readsListSEXP, i);
+        const int R = Rf_length(sr);
+        read_off[i + 1] = read_off[i] + R;
+        for (int r = 0; r < R; r++) nbases += (size_t)Rf_length(VECTOR_ELT(VECTOR_ELT(sr, r), 3));
+    }
+    const int totR = read_off[n];
+    int32_t *read_ptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)totR + (size_t)n + 1));
+    int32_t *wif = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
+    int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1)), *bq = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1));
+    size_t at = 0;
+    for (int i = 0; i < n; i++) {
+        SEXP sr = VECTOR_ELT(readsListSEXP, i);
+        const int R = Rf_length(sr);
+        int32_t *rp = read_ptr + read_off[i] + i;
+        rp[0] = 0;
+        for (int r = 0; r < R; r++) {
+            SEXP rd = VECTOR_ELT(sr, r);
+            const int nb = Rf_length(VECTOR_ELT(rd, 3));
+            wif[read_off[i] + r] = Rf_asInteger(VECTOR_ELT(rd, 1));
+            memcpy(bq + at, INTEGER(VECTOR_ELT(rd, 2)), sizeof(int) * (size_t)nb);
+            memcpy(u + at, INTEGER(VECTOR_ELT(rd, 3)), sizeof(int) * (size_t)nb);
+            at += (size_t)nb;
+            rp[r + 1] = rp[r] + nb;
+        }
+    }
+    qa_impute_params_t ip;
+    qa_impute_params_default(&ip);
+    ip.nGibbsSamples = (int)num_or(paramsSEXP, "nGibbsSamples", ip.nGibbsSamples);
+    ip.n_seek_its = (int)num_or(paramsSEXP, "n_seek_its", ip.n_seek_its);
+    ip.n_burn_in_seek_its = (int)num_or(paramsSEXP, "n_burn_in_seek_its", -1);   /* NA -> n_seek_its - 1 (quilt.R:248-250) */
+    ip.Ksubset = (int)num_or(paramsSEXP, "Ksubset", ip.Ksubset);
+    ip.Knew = (int)num_or(paramsSEXP, "Knew", ip.Knew);
+    ip.K_top_matches = (int)num_or(paramsSEXP, "K_top_matches", ip.K_top_matches);
+    ip.heuristic_match_thin = num_or(paramsSEXP, "heuristic_match_thin", ip.heuristic_match_thin);
+    ip.small_ref_panel_gibbs_iterations = (int)num_or(paramsSEXP, "small_ref_panel_gibbs_iterations", ip.small_ref_panel_gibbs_iterations);
+    SEXP blocks = list_get(paramsSEXP, "small_ref_panel_block_gibbs_iterations");
+    if (blocks != R_NilValue && TYPEOF(blocks) == INTSXP) {
+        ip.small_ref_panel_block_gibbs_iterations = INTEGER(blocks);
+        ip.n_block_gibbs_iterations = Rf_length(blocks);
+    }
+    ip.maxDifferenceBetweenReads = num_or(paramsSEXP, "maxDifferenceBetweenReads", ip.maxDifferenceBetweenReads);
+    ip.minGLValue = num_or(paramsSEXP, "minGLValue", ip.minGLValue);
+    ip.Jmax = (int)num_or(paramsSEXP, "Jmax", ip.Jmax);
+    ip.seed = (uint64_t)num_or(paramsSEXP, "seed", 1);
+    ip.samples_per_launch_set = (int)num_or(paramsSEXP, "samples_per_launch_set", 0);
+    SEXP dosage = PROTECT(Rf_allocMatrix(REALSXP, T, n)), gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T, n));
+    SEXP haps = PROTECT(Rf_allocMatrix(REALSXP, 2 * T, n)), nDosage = PROTECT(Rf_allocVector(INTSXP, n));
+    SEXP stats = PROTECT(Rf_allocVector(REALSXP, 11));
+    int32_t *labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
+    int64_t st64[11] = {0};
+    st = qa_impute_samples(handles, n_handles, &ip, n, (int64_t)Rf_asReal(sample_offsetSEXP), read_off, read_ptr, u, bq, wif,
+                           REAL(dosage), REAL(gp_t), REAL(haps), labels, INTEGER(nDosage), st64);
+    char msg[512];
+    snprintf(msg, sizeof msg, "%s", qa_last_error());
+    for (int i = 0; i < n_handles; i++) qa_panel_destroy(handles[i]);
+    SEXP lab = PROTECT(Rf_allocVector(VECSXP, n));
+    if (st == QA_OK)
+        for (int i = 0; i < n; i++) {
+            const int R = read_off[i + 1] - read_off[i];
+            SEXP v = PROTECT(Rf_allocVector(INTSXP, R));
+            memcpy(INTEGER(v), labels + read_off[i], sizeof(int) * (size_t)R);
+            SET_VECTOR_ELT(lab, i, v);
+            UNPROTECT(1);
+        }
+    free(read_off); free(read_ptr); free(wif); free(u); free(bq); free(labels);
+    if (st != QA_OK) {
+        UNPROTECT(6);
+        Rf_error("quilt_amd: qa_impute_samples: %s", msg);
+    }
+    for (int i = 0; i < 11; i++) REAL(stats)[i] = (double)st64[i];
+    const char *names[] = {"dosage", "gp_t", "phasing_haps", "read_labels", "nDosage", "stats"};
+    SEXP out = PROTECT(named_list(6, names));
+    SET_VECTOR_ELT(out, 0, dosage); SET_VECTOR_ELT(out, 1, gp_t); SET_VECTOR_ELT(out, 2, haps);
+    SET_VECTOR_ELT(out, 3, lab); SET_VECTOR_ELT(out, 4, nDosage); SET_VECTOR_ELT(out, 5, stats);
+    UNPROTECT(7);
+    return out;
+}
+
 /* ---- registration (RcppExports.cpp:1703-1782) ----------------------------------------------------------------------
  * Inside QUILT.so (shim/QUILT-src.patch): RcppExports.cpp's own CallEntries[] names these functions in the four rows, and
  * R_init_QUILT registers them.  As a DLL of its own: R_init_quilt_amd_shim. */
@@ -526,6 +683,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_QUILT_Rcpp_make_gl_bound", (DL_FUNC)&qa_QUILT_Rcpp_make_gl_bound, 3},
     {"_QUILT_rcpp_make_eMatRead_t", (DL_FUNC)&qa_QUILT_rcpp_make_eMatRead_t, 15},
     {"qa_shim_release", (DL_FUNC)&qa_shim_release, 0},
+    {"qa_impute_sample_range", (DL_FUNC)&qa_impute_sample_range, 5},
     {NULL, NULL, 0}};
 
 void R_init_quilt_amd_shim(DllInfo *dll) {

@@ -99,3 +99,33 @@ def test_bench_gpus_flag_creates_the_ranks():
                          capture_output=True, text=True, timeout=600, env=env1, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_eight_ranks_plumbing_on_the_stub_backend():
+    """What the first real 8-GPU run must not fail on: eight ranks (gloo, stub driver), the host cores divided between ranks and
+    host threads (QA_HOST_THREADS), rank 0's CPU-leg flag file honoured by the other seven and removed afterwards, one JSON
+    line with per-rank rates.  Reference analogue: mclapply(mc.cores = nCores) over sampleRanges (quilt.R:688-692)."""
+    import glob
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "QA_HOST_THREADS")}
+    before = set(glob.glob("/tmp/quilt_amd_bench_*.cpu_done"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "8", "--K", "300", "--nsnps", "640",
+                          "--batch", "2", "--reads", "40", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak"
+    rk = rec["ranks"]
+    assert rk["n"] == 8 and len(rk["elapsed_s"]) == 8 and len(rk["QA_HOST_THREADS"]) == 8
+    assert "samples_per_sec_min" in rk and "samples_per_sec_max" in rk
+    # the cores are divided: every rank got the same budget, at least 2, and 8 ranks x host threads x budget fits the machine
+    # (or sits at the floor of 2 on a small one)
+    b = set(rk["QA_HOST_THREADS"])
+    assert len(b) == 1 and min(b) >= 2
+    budget = min(b)
+    assert budget == max(2, (os.cpu_count() or 16) // (8 * rk["host_threads_per_rank"]))
+    assert rk["waited_for_rank0_cpu_legs_s"][0] == 0.0 and all(w < 300 for w in rk["waited_for_rank0_cpu_legs_s"])
+    assert set(glob.glob("/tmp/quilt_amd_bench_*.cpu_done")) <= before, "rank 0 removes the flag file"
