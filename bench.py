@@ -323,7 +323,11 @@ def main():
     if a.pageable:
         os.environ["QUILT_AMD_PAGEABLE"] = "1"
     if a.fuse is None:
-        a.fuse = 2 if a.mode == "short" else 1   # (ONT: short Gibbs launches, NIPT: three labels -- no 256-register build)
+        # a launch set should carry enough Gibbs chains to fill the device whatever the batch: two chains per SIMD (2 048; the
+        # sampler's 256-register build) for short reads -- 2 steps of 128 samples, 8 of 32 (configs[1]); ONT: short Gibbs
+        # launches, NIPT: three labels, no 256-register build -- one chain per SIMD
+        per_step = a.batch * 8
+        a.fuse = max(1, min(16, round(2048 / per_step))) if a.mode == "short" else max(1, min(16, round(1024 / per_step)))
     a.fuse = max(1, a.fuse)
     native_ok = a.mode != "nipt" and a.rare_common <= 0 and not (a.mspbwt and a.mspbwt_search != "scan") and not a.stub
     if a.driver is None:
@@ -500,6 +504,12 @@ def main():
         if a.dotcall is None:
             a.dotcall = 16 if (world == 1 and a.mode == "short" and not a.mspbwt and rc is None and native is not None and
                                not a.no_cpu_baseline) else 0
+        if native is not None and world == 1 and a.driver == "native" and hasattr(drv, "devs"):
+            # one sample alone on the device (the quick-start's shape): the latency of the whole per-sample pipeline
+            from quilt_amd.impute import impute_samples
+            t_l = time.perf_counter()
+            impute_samples(drv.devs[:1], samples[-1][:1], DriverParams(**params), sample_offset=10 ** 6)
+            out["one_sample_latency_s"] = round(time.perf_counter() - t_l, 3)
         if a.dotcall > 0 and native is not None and world == 1:
             # the device-wide arena goes with the last handle: the workers are processes of their own and need the memory
             drv.close()

@@ -610,6 +610,10 @@ int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impu
                       const int32_t *wif, double *dosage, double *gp_t, double *phasing_haps, int32_t *read_labels,
                       int32_t *nDosage, int64_t *stats);
 
+/* The host threads' marshalling and pinned transfer buffers are kept per panel handle between calls (a launch set of 2 048
+ * chains moves ~3.5 GB through them): this frees them all.  Call it when no qa_impute_samples call is running. */
+int qa_impute_release_buffers(void);
+
 /*
  * Test hook: the same loop over a caller-supplied table of the batched entry points it calls (signatures = the qa_*
  * functions named in the comments, with an opaque handle in place of the panel).  The product table is the library's own

@@ -310,21 +310,51 @@ void recast_haps(double *hd1, double *hd2, const double *g0, const double *g1, c
 // ---------------------------------------------------------------------------------------------------------------------------
 // one host thread: its handle, its buffers, its stream of launch sets
 // ---------------------------------------------------------------------------------------------------------------------------
-struct Worker {
-    Ctx &cx;
-    void *handle;
-    int w;
-    int n_help;
+// A host thread's marshalling and transfer buffers.  With the product's entry points they outlive the call (kept per panel
+// handle, freed by qa_impute_release_buffers): a launch set of 2 048 chains carries ~1.5 GB of per-chain read copies and 2 GB
+// of pinned dosage rows, and allocating -- pinning, first-touching -- them anew inside every call cost 1.5 s of a 70 s run.
+struct WorkerBuffers {
     // marshalling buffers of the Gibbs call (per chain copies of the reads) and of the full-panel call (per sample)
     std::vector<int32_t> g_which, g_read_off, g_read_ptr, g_u, g_bq, g_wif, g_first, g_H, g_uf, g_words;
     std::vector<uint64_t> g_sr, g_ss, seed_sel;
     std::vector<int32_t> f_cs, f_read_off, f_read_ptr, f_u, f_bq, f_H, f_wd, f_wt, f_cnt, f_next, f_status;
     HostBuf<double> dos;          // the round's haploid dosages [chain][label][T]
     HostBuf<double> conf;         // read confidence [reads][K]
+    explicit WorkerBuffers(const qa_impute_backend_t *be) { dos.be = be; conf.be = be; }
+};
+std::mutex g_buf_mu;
+std::map<void *, std::unique_ptr<WorkerBuffers>> g_bufs;   // product backend only: handle -> its thread's buffers
+
+struct Worker {
+    Ctx &cx;
+    void *handle;
+    int w;
+    int n_help;
+    std::unique_ptr<WorkerBuffers> own;   // a caller-supplied table of entry points: buffers of this call only
+    WorkerBuffers &B;
+    std::vector<int32_t> &g_which, &g_read_off, &g_read_ptr, &g_u, &g_bq, &g_wif, &g_first, &g_H, &g_uf, &g_words;
+    std::vector<uint64_t> &g_sr, &g_ss, &seed_sel;
+    std::vector<int32_t> &f_cs, &f_read_off, &f_read_ptr, &f_u, &f_bq, &f_H, &f_wd, &f_wt, &f_cnt, &f_next, &f_status;
+    HostBuf<double> &dos, &conf;
     std::function<void()> on_first_launch;
     double t_gibbs = 0, t_fullpass = 0, t_host = 0, t_consensus = 0, t_finish = 0, t_accumulate = 0;
 
-    Worker(Ctx &c, void *h, int wi) : cx(c), handle(h), w(wi), n_help(helper_threads()) { dos.be = c.be; conf.be = c.be; }
+    static WorkerBuffers &buffers_for(Ctx &c, void *h, bool keep, std::unique_ptr<WorkerBuffers> &own) {
+        if (!keep) {
+            own.reset(new WorkerBuffers(c.be));
+            return *own;
+        }
+        std::lock_guard<std::mutex> g(g_buf_mu);
+        auto &slot = g_bufs[h];
+        if (!slot) slot.reset(new WorkerBuffers(c.be));
+        return *slot;
+    }
+    Worker(Ctx &c, void *h, int wi, bool keep)
+        : cx(c), handle(h), w(wi), n_help(helper_threads()), B(buffers_for(c, h, keep, own)), g_which(B.g_which),
+          g_read_off(B.g_read_off), g_read_ptr(B.g_read_ptr), g_u(B.g_u), g_bq(B.g_bq), g_wif(B.g_wif), g_first(B.g_first), g_H(B.g_H),
+          g_uf(B.g_uf), g_words(B.g_words), g_sr(B.g_sr), g_ss(B.g_ss), seed_sel(B.seed_sel), f_cs(B.f_cs), f_read_off(B.f_read_off),
+          f_read_ptr(B.f_read_ptr), f_u(B.f_u), f_bq(B.f_bq), f_H(B.f_H), f_wd(B.f_wd), f_wt(B.f_wt), f_cnt(B.f_cnt), f_next(B.f_next),
+          f_status(B.f_status), dos(B.dos), conf(B.conf) {}
 
     // ---- the Gibbs call of a round with impute_one_sample's underflow retry (functions.R:2612-2716)
     void gibbs_with_retry(std::vector<Chain *> &ch, const std::vector<std::vector<int32_t>> &starts, bool any_first, bool want_words,
@@ -851,7 +881,7 @@ std::vector<std::pair<int, int>> sample_ranges(int n, int parts) {
     return out;
 }
 
-int impute_impl(const qa_impute_backend_t *be, void *const *handles, int32_t n_handles, int32_t K, int32_t G, int32_t T,
+int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *handles, int32_t n_handles, int32_t K, int32_t G, int32_t T,
                 const qa_impute_params_t *params, int32_t n_sample, int64_t sample_offset, const int32_t *read_off,
                 const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif, double *dosage, double *gp_t,
                 double *phasing_haps, int32_t *read_labels, int32_t *nDosage, int64_t *stats) {
@@ -934,7 +964,7 @@ int impute_impl(const qa_impute_backend_t *be, void *const *handles, int32_t n_h
     cx.tail.n_active = W;
 
     std::vector<std::unique_ptr<Worker>> workers;
-    for (int w2 = 0; w2 < W; w2++) workers.emplace_back(new Worker(cx, handles[w2], w2));
+    for (int w2 = 0; w2 < W; w2++) workers.emplace_back(new Worker(cx, handles[w2], w2, keep_buffers));
     // staggered start: thread w prepares its first launch once thread w - 1 has handed its own to the device
     struct Started { std::mutex mu; std::condition_variable cv; bool set = false; };
     std::vector<Started> started((size_t)W);
@@ -1073,8 +1103,20 @@ int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impu
             return QA_ERR_INVALID;
         }
     }
-    return impute_impl(&kProduct, reinterpret_cast<void *const *>(panels), n_panels, K, G, T, params, n_sample, sample_offset, read_off,
+    for (int i = 0; i < n_panels; i++)
+        for (int j = 0; j < i; j++)
+            if (panels[i] == panels[j]) {
+                qa::set_error("qa_impute_samples: every host thread needs a handle of its own");
+                return QA_ERR_INVALID;
+            }
+    return impute_impl(true, &kProduct, reinterpret_cast<void *const *>(panels), n_panels, K, G, T, params, n_sample, sample_offset, read_off,
                        read_ptr, u, bq, wif, dosage, gp_t, phasing_haps, read_labels, nDosage, stats);
+}
+
+int qa_impute_release_buffers(void) {
+    std::lock_guard<std::mutex> g(g_buf_mu);
+    g_bufs.clear();
+    return QA_OK;
 }
 
 int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,
@@ -1088,7 +1130,7 @@ int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *h
         qa::set_error("qa_impute_samples_backend: incomplete table");
         return QA_ERR_INVALID;
     }
-    return impute_impl(backend, handles, n_handles, K, nGrids, nSNPs, params, n_sample, sample_offset, read_off, read_ptr, u, bq, wif,
+    return impute_impl(false, backend, handles, n_handles, K, nGrids, nSNPs, params, n_sample, sample_offset, read_off, read_ptr, u, bq, wif,
                        dosage, gp_t, phasing_haps, read_labels, nDosage, stats);
 }
 

@@ -255,6 +255,8 @@ class NativeWorkers:
         self.n_gibbs_launches = 0
 
     def close(self):
+        from .native import lib
+        lib().qa_impute_release_buffers()
         for d in self.devs:
             d.close()
 

@@ -47,8 +47,8 @@ def test_native_driver_equals_python_driver_on_the_device(medium_panel, mspbwt, 
     for a, b in zip(got, want):
         _same(a, b)
     assert st["gibbs_chain_calls"] >= 7 * 4 * 3
-    if not mspbwt:
-        assert st["device_selections"] > 0
+    if not mspbwt:   # (10 thinned grids x 2 labels x 5 ranks < Knew: these selections go on to the complete lists)
+        assert st["device_selections"] + st["full_list_refetches"] > 0
 
 
 def test_native_driver_agrees_with_the_cpu_pipeline(medium_panel):
