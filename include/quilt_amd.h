@@ -223,6 +223,13 @@ typedef struct {
  *
  * Like the reference it returns nothing and writes into the caller's buffers; any
  * output pointer may be NULL when the matching flag is 0.
+ *
+ * Panel size: dosage, c and best_haps_stuff_list are available for ANY K (up to K = 57 344 a pass keeps its whole state on
+ * one compute unit -- seven chunk rows of 8 192 haplotypes in registers and LDS; beyond that the chunk rows past the seventh
+ * stream their state through HBM: K = 65 536 reads and writes one row of eight per grid, K = 131 072 nine of sixteen, the
+ * same arithmetic).  The K x nGrids outputs -- alphaHat_t, betaHat_t, gamma_t, gammaSmall_t -- come from kernels that hold
+ * the state on chip and are limited to K <= 57 344: QA_ERR_UNSUPPORTED beyond (qa_last_error says so).  The batched entry
+ * points below (dosage + lists only) have no limit but the device's memory (QA_ERR_CAPACITY).
  *   gl                      2 x nSNPs
  *   gammaSmall_cols_to_get  nGrids, -1 or the 0-based thinned column
  *   alphaHat_t              K x nGrids (NULL: not copied back).  Columns are normalised

@@ -804,13 +804,13 @@ __global__ void k_unpermute(const TS *src, double *dst, int K, int Kq, int NT, i
 // host side
 // ---------------------------------------------------------------------------------------------
 struct qa_panel::Scratch {
-    qa::ABuf<double> gl, c, dosage, escale0, unperm, emin;
+    qa::ABuf<double> gl, c, dosage, escale0, unperm, emin, spill;
     qa::ABuf<char> emat, esp, alpha, gamma, beta, beta_thin, top_val, mg, gsp;   // fp32 or fp64 elements (the launch decides)
     qa::ABuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
     qa::DBuf<int32_t> todo;   // (grid, pass) pairs handed to k_topk: persistent, grow-only
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     explicit Scratch(qa::Arena *a) {
-        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = a;
+        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = spill.arena = a;
         emat.arena = esp.arena = alpha.arena = mg.arena = gsp.arena = gamma.arena = beta.arena = beta_thin.arena = top_val.arena = a;
         thin_col.arena = flags.arena = alpha_slot.arena = top_cnt.arena = top_idx.arena = a;
     }
@@ -887,6 +887,7 @@ size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stor
     if (gamma) b += G * Kq * es;
     if (beta) b += G * Kq * es;
     if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 8 + 64 * 12);   // (lists of up to 64 entries)
+    if (geo.kind == KIND_F64_RANK || geo.kind == KIND_F64_DOS) b += (size_t)qa::fb64_spill_rows(pn->K) * 8192 * 8;   // streamed chunk rows
     return b + 256 * 24;
 }
 
@@ -969,7 +970,8 @@ void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, h
 // the kernels behind the dosage passes of a handle: fp32 state, or (qa_panel_set_dosage_precision(64)) the fp64 dosage
 // kernels -- the generic fp64 kernels when K exceeds those kernels' on-chip capacity
 PassKind dosage_kind(const qa_panel *pn) {
-    if (!pn->dosage_fp64) return KIND_F32;
+    // (panels beyond the fp32 kernels' 98 304 haplotypes: the fp64 dosage kernels, whose chunk rows past the seventh stream)
+    if (!pn->dosage_fp64 && pick_geometry(pn->K, KIND_F32).NT) return KIND_F32;
     return pick_geometry(pn->K, KIND_F64_DOS).NT ? KIND_F64_DOS : KIND_F64_FULL;
 }
 
@@ -1078,6 +1080,8 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     if (any_top) S.beta_thin.ensure((size_t)P * n_thin * Kq * es);
     int top_cap = out.top_cap;
     S.top_cnt.ensure(std::max<size_t>((size_t)P * std::max(n_thin, 1), 1));
+    const size_t spill_stride = lazy ? (size_t)qa::fb64_spill_rows(K) * 8192 : 0;   // doubles per pass: chunk rows streamed through HBM
+    if (spill_stride) S.spill.ensure((size_t)P * spill_stride);
 
     PassParams prm{};
     prm.hm = pn->hm.p; prm.B = pn->B.p; prm.sp_off = pn->sp_off.p; prm.sp_k = pn->sp_k.p;
@@ -1090,6 +1094,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.lazy = lazy ? 1 : 0; prm.always_normalize = always_normalize; prm.norm_threshold = norm_threshold;
     prm.emin = S.emin.p; prm.esp_stride = (int)esp_stride;
 
+    prm.spill = spill_stride ? S.spill.p : nullptr; prm.spill_pass_stride = spill_stride;
     prm.emat = S.emat.p; prm.esp = S.esp.p; prm.escale0 = S.escale0.p; prm.alpha = S.alpha.p; prm.alpha_slot = S.alpha_slot.p;
     prm.alpha_pass_stride = alpha_stride; prm.Kq = Kq; prm.alpha_col_elems = alpha_col;
     prm.hist_unit = kind == KIND_F64_DOS ? 1.0 / 2251799813685248.0 /* 2^-51: k_bwd64d */ : 1.0 / kHistScale64; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;
@@ -1387,7 +1392,15 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         // fp64 dosage: the tuned kernels yield dosage and c; a call that also wants alpha / beta / gamma matrices takes the
         // generic fp64 kernels
         const bool matrices = alphaHat_t || o->return_betaHat_t || o->return_gamma_t || o->return_gammaSmall_t;
-        const PassKind main_kind = !panel->dosage_fp64 ? KIND_F32 : (matrices || !o->return_dosage) ? KIND_F64_FULL : dosage_kind(panel);
+        const bool f32_fits = pick_geometry(panel->K, KIND_F32).NT != 0;
+        const PassKind main_kind = (!panel->dosage_fp64 && f32_fits) ? KIND_F32 : (matrices || !o->return_dosage) ? KIND_F64_FULL : dosage_kind(panel);
+        if (pick_geometry(panel->K, main_kind).NT == 0 && !(want_lists && panel->rank_fp64 && only_thin)) {
+            // K x nGrids outputs (alphaHat_t / betaHat_t / gamma_t / gammaSmall_t) come from kernels that keep the whole state
+            // on chip; the dosage and the best-haplotype lists (what the driver path asks for) have no such limit
+            qa::set_error("K = %d: alphaHat_t / betaHat_t / gamma_t / gammaSmall_t outputs are limited to K <= 57 344 haplotypes (state on "
+                          "chip); dosage, c and best_haps_stuff_list are available for any K", panel->K);
+            return QA_ERR_UNSUPPORTED;
+        }
         int st;
         if (main_kind == KIND_F64_DOS) {
             std::vector<int32_t> no_thin(G, -1);

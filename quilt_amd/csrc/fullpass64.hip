@@ -38,7 +38,9 @@ constexpr int kNT = 512;          // threads per pass
 constexpr int kRowHaps = kNT * 16;
 constexpr int kNStream = 8;       // per-grid scalar streams staged in LDS, 64 grids at a time
 
-struct Geo64 { int NCH, NR, NL, n_last; };
+// NS: chunk rows beyond the on-chip seven, streamed through HBM (PassParams::spill) -- K > 57 344; all rows are then full
+// (the codes' row pitch Kp covers them: the padding has code 0, emission 0, state 0)
+struct Geo64 { int NCH, NR, NL, n_last, NS; };
 
 // LDS bytes besides the state rows: emission tables [2][256], block sums [2][16], scalar streams, picker scratch
 constexpr size_t kLdsFixed = 2 * kMaxRow * 8 + 2 * 16 * 8 + kNStream * 64 * 8 + 8 * kMaxTop * 8 + 64 + (size_t)kCandCap * 12;
@@ -53,7 +55,12 @@ inline Geo64 geo64(int K) {
     g.NR = std::min(g.NCH, 4);
     g.NL = g.NCH - g.NR;
     if (lds_bytes(g) > kLdsMax) { g.NR = 5; g.NL = g.NCH - 5; }
-    if (g.NCH > 7 || lds_bytes(g) > kLdsMax) g.NCH = 0;
+    if (g.NCH > 7) {   // 5 rows in registers, 2 in LDS (what 7 full rows take: 152 / 155 KB of LDS), the rest streamed
+        g.NS = g.NCH - 7;
+        g.NCH = 7; g.NR = 5; g.NL = 2; g.n_last = kNT;
+        return g;
+    }
+    if (lds_bytes(g) > kLdsMax) g.NCH = 0;
     return g;
 }
 
@@ -83,6 +90,11 @@ template <int NL, typename LT>
 __device__ __forceinline__ double2 *lds_row(const LT &L, int r, int t) { return L.state + (size_t)r * 8 * kNT + t; }
 template <int NL>
 __device__ __forceinline__ int lds_stride(int r, int n_last) { return r == NL - 1 ? n_last : kNT; }
+
+// state vectors of streamed row r (0-based among the streamed rows) of pass p for thread t: st[q * kNT], q = 0..7
+__device__ __forceinline__ double2 *spill_row(const PassParams &prm, int p, int r, int t) {
+    return reinterpret_cast<double2 *>(prm.spill + (size_t)p * prm.spill_pass_stride) + (size_t)r * 8 * kNT + t;
+}
 
 __device__ __forceinline__ bool has_zero_byte2(uint32_t a, uint32_t b) { return has_zero_byte(a) || has_zero_byte(b); }
 
@@ -257,9 +269,10 @@ __device__ __forceinline__ int fresh_tid(int wave) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int NR, int NL>
+template <int NR, int NL, bool SP = false>
 __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
     constexpr int NCH = NR + NL, NT = kNT, nwaves = NT >> 6;
+    const int NS = SP ? prm.Kq / kRowHaps - NCH : 0;   // chunk rows streamed through HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Lds L(smem);
     const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
@@ -291,6 +304,13 @@ __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
             for (int q = 0; q < 8; q++) st[q * stride] = make_double2(0.0, 0.0);
         }
         dh[j] = *reinterpret_cast<const uint4 *>(prm.hm + k0);
+    }
+    if constexpr (SP) {
+        for (int js = 0; js < NS; js++) {
+            double2 *st = spill_row(prm, blockIdx.x, js, t);
+#pragma unroll
+            for (int q = 0; q < 8; q++) st[q * NT] = make_double2(0.0, 0.0);
+        }
     }
     if (t < kMaxRow) L.etab[t] = emat[t];
     __syncthreads();
@@ -342,6 +362,14 @@ __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
             // the codes of the next grid: a whole grid ahead of their use
             dh[j] = reinterpret_cast<const uint4 *>(hm_next + j * kRowHaps)[tt];
         });
+        if constexpr (SP) {   // the streamed rows: codes of this grid fetched now, state read and written in place
+            const uint8_t *hm_cur = prm.hm + (size_t)g * prm.Kp;
+            for (int js = 0; js < NS; js++) {
+                const int jg = NCH + js, k0 = (jg * NT + tt) * 16;
+                const uint4 d = reinterpret_cast<const uint4 *>(hm_cur + (size_t)jg * kRowHaps)[tt];
+                psum += lds_chunk<false>(spill_row(prm, p, js, tt), NT, d, et, addend, 1.0, sp_at, esp, k0);
+            }
+        }
         double run_total = block_sum64<NCH>(psum, L.red + buf * 16, wave, lane, nwaves);
         double cg = 1.0;
         if (g > 0) {
@@ -369,6 +397,17 @@ __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
                     }
                 }
             }
+            if constexpr (SP) {
+                for (int js = 0; js < NS; js++) {
+                    double2 *st = spill_row(prm, p, js, tt);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        double2 v = st[q * NT];
+                        v.x *= xs; v.y *= xs;
+                        st[q * NT] = v;
+                    }
+                }
+            }
             cg = (g == 0) ? xs : cg / run_total;
             run_total = 1;
             running_min = 1;
@@ -388,6 +427,14 @@ __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
                     const int stride = lds_stride<NL>(r, n_last);
 #pragma unroll
                     for (int q = 0; q < 8; q++) dst[alpha_vec_index<8>(NR + r, q, NT, tt)] = st[q * stride];
+                }
+            }
+            if constexpr (SP) {
+                for (int js = 0; js < NS; js++) {
+                    if (((NCH + js) * NT + tt) * 16 >= K) continue;
+                    const double2 *st = spill_row(prm, p, js, tt);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) dst[alpha_vec_index<8>(NCH + js, q, NT, tt)] = st[q * NT];
                 }
             }
         }
@@ -413,9 +460,10 @@ __device__ __forceinline__ void wave_top(double v, int Ktop, double *out, int la
     }
 }
 
-template <int NR, int NL>
+template <int NR, int NL, bool SP = false>
 __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
     constexpr int NCH = NR + NL, NT = kNT, nwaves = NT >> 6;
+    const int NS = SP ? prm.Kq / kRowHaps - NCH : 0;   // chunk rows streamed through HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Lds L(smem);
     const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
@@ -447,6 +495,14 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
             for (int q = 0; q < 8; q++) st[q * stride] = make_double2(k0 + 2 * q < K ? 1.0 : 0.0, k0 + 2 * q + 1 < K ? 1.0 : 0.0);
         }
         dh[j] = *reinterpret_cast<const uint4 *>(prm.hm + (size_t)(G - 1) * prm.Kp + k0);   // (unconditional: see k_fwd64)
+    }
+    if constexpr (SP) {
+        for (int js = 0; js < NS; js++) {
+            double2 *st = spill_row(prm, p, js, t);
+            const int k0 = ((NCH + js) * NT + t) * 16;
+#pragma unroll
+            for (int q = 0; q < 8; q++) st[q * NT] = make_double2(k0 + 2 * q < K ? 1.0 : 0.0, k0 + 2 * q + 1 < K ? 1.0 : 0.0);
+        }
     }
     if (t < kMaxRow) L.etab[((G - 1) & 1) * kMaxRow + t] = emat[(size_t)(G - 1) * kMaxRow + t];
     if (t == 0) L.misc[0] = 0;
@@ -498,6 +554,14 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
                 }
                 dh[j] = reinterpret_cast<const uint4 *>(hm_next + j * kRowHaps)[tt];
             });
+            if constexpr (SP) {   // the streamed rows: codes of grid g + 1 fetched now
+                const uint8_t *hm_e = prm.hm + (size_t)(g + 1) * prm.Kp;
+                for (int js = 0; js < NS; js++) {
+                    const int jg = NCH + js, k0 = (jg * NT + tt) * 16;
+                    const uint4 d = reinterpret_cast<const uint4 *>(hm_e + (size_t)jg * kRowHaps)[tt];
+                    psum += lds_chunk<true>(spill_row(prm, p, js, tt), NT, d, et, val_prev, x_prev, sp_at, esp, k0);
+                }
+            }
             const double sum_e_times_b = block_sum64<NCH>(psum, L.red + (g & 1) * 16, wave, lane, nwaves);
             // (:1945-1982)
             if (has_variant) {
@@ -542,6 +606,21 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
                         mx = g1 > mx ? g1 : mx;
                     }
                 });
+                if constexpr (SP) {
+                    for (int js = 0; js < NS; js++) {
+                        const int k0 = ((NCH + js) * NT + tp) * 16;
+                        if (k0 >= K) continue;
+                        const double2 *st = spill_row(prm, p, js, tp);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const double2 a2 = av[alpha_vec_index<8>(NCH + js, q, NT, tp)];
+                            const double2 u = st[q * NT];
+                            const double g0 = a2.x * (u.x + val), g1 = a2.y * (u.y + val);
+                            mx = g0 > mx ? g0 : mx;
+                            mx = g1 > mx ? g1 : mx;
+                        }
+                    }
+                }
                 wave_top(mx, Ktop, L.wtop + wave * kMaxTop, lanep);
                 __syncthreads();
                 double T0;
@@ -578,6 +657,26 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
                         }
                     }
                 });
+                if constexpr (SP) {
+                    for (int js = 0; js < NS; js++) {
+                        const int k0 = ((NCH + js) * NT + tp) * 16;
+                        if (k0 >= K) continue;
+                        const double2 *st = spill_row(prm, p, js, tp);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const double2 a2 = av[alpha_vec_index<8>(NCH + js, q, NT, tp)];
+                            const double2 u = st[q * NT];
+                            const double gq[2] = {a2.x * (u.x + val), a2.y * (u.y + val)};
+#pragma unroll
+                            for (int r = 0; r < 2; r++) {
+                                if (gq[r] >= T0 && k0 + 2 * q + r < K) {
+                                    const int at = atomicAdd(&L.misc[0], 1);
+                                    if (at < kCandCap) { L.cand_v[at] = gq[r]; L.cand_k[at] = k0 + 2 * q + r; }
+                                }
+                            }
+                        }
+                    }
+                }
                 __syncthreads();
                 const int n_c = L.misc[0];
                 if (n_c > kCandCap) {
@@ -637,6 +736,17 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
 #pragma unroll
                     for (int q = 0; q < 8; q++) dst[alpha_vec_index<8>(j, q, NT, tp)] = beta_of(jc, q, st, stride);   // (entries beyond K are ignored by k_topk)
                 });
+                if constexpr (SP) {
+                    for (int js = 0; js < NS; js++) {
+                        if (((NCH + js) * NT + tp) * 16 >= K) continue;
+                        const double2 *st = spill_row(prm, p, js, tp);
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const double2 u = st[q * NT];
+                            dst[alpha_vec_index<8>(NCH + js, q, NT, tp)] = make_double2(u.x + val, u.y + val);
+                        }
+                    }
+                }
             }
         }
         val_prev = val;
@@ -729,9 +839,10 @@ __device__ __forceinline__ void special_gammas(const double (&x_before)[8], uint
     }
 }
 
-template <int NR, int NL>
+template <int NR, int NL, bool SP = false>
 __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
     constexpr int NCH = NR + NL, NT = kNT, nwaves = NT >> 6;
+    const int NS = SP ? prm.Kq / kRowHaps - NCH : 0;   // chunk rows streamed through HBM
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const LdsD L(smem);
     const int p = blockIdx.x, t = threadIdx.x, lane = t & 63;
@@ -763,6 +874,14 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
             for (int q = 0; q < 8; q++) st[q * stride] = make_double2(k0 + 2 * q < K ? 1.0 : 0.0, k0 + 2 * q + 1 < K ? 1.0 : 0.0);
         }
     }
+    if constexpr (SP) {
+        for (int js = 0; js < NS; js++) {
+            double2 *st = spill_row(prm, p, js, t);
+            const int k0 = ((NCH + js) * NT + t) * 16;
+#pragma unroll
+            for (int q = 0; q < 8; q++) st[q * NT] = make_double2(k0 + 2 * q < K ? 1.0 : 0.0, k0 + 2 * q + 1 < K ? 1.0 : 0.0);
+        }
+    }
     for (int i = t; i < kMaxRow * kHistCopiesD; i += NT) L.hist[i] = 0ull;
     if (t < kMaxRow) L.etab[((G - 1) & 1) * kMaxRow + t] = emat[(size_t)(G - 1) * kMaxRow + t];
 
@@ -772,7 +891,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
     uint4 d_nx;
     double2 a_nx[4];
     auto prefetch = [&](int gq, int j, int h, int tt) {
-        const bool real = j < NCH - 1 || last_row_wave;
+        const bool real = SP || j < NCH - 1 || last_row_wave;   // (streamed geometry: every row is full)
         // (the codes' row pitch covers whole chunk rows: beyond K they are the zero padding, whose emission is 0)
         if (h == 0) d_nx = reinterpret_cast<const uint4 *>(prm.hm + (size_t)gq * prm.Kp + (size_t)j * kRowHaps)[tt];
         const double2 *av = ain + (size_t)gq * col_vecs;
@@ -800,6 +919,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
             // the next half chunk (of this grid, or the first of the next grid down) is in flight while this one is consumed
             if constexpr (h == 0) prefetch(gp, j, 1, tt);
             else if constexpr (j + 1 < NCH) prefetch(gp, j + 1, 0, tt);
+            else if (SP && NS > 0) prefetch(gp, NCH, 0, tt);   // on to the streamed rows
             else prefetch(gp > 0 ? gp - 1 : 0, 0, 0, tt);
             const int k0 = (j * NT + tt) * 16;
             unsigned long long *hl = L.hist + (tt & (kHistCopiesD - 1));
@@ -840,6 +960,48 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
                 }
             }
         });
+        if constexpr (SP) {   // the streamed rows: the same half-chunk pipeline, the state read and written in place in HBM
+            for (int js = 0; js < NS; js++) {
+                const int j = NCH + js;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int tt = fresh_tid(wave);
+                    if (h == 0) d = d_nx;
+                    double2 a[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) a[q] = a_nx[q];
+                    if (h == 0) prefetch(gp, j, 1, tt);
+                    else if (js + 1 < NS) prefetch(gp, j + 1, 0, tt);
+                    else prefetch(gp > 0 ? gp - 1 : 0, 0, 0, tt);
+                    const int k0 = (j * NT + tt) * 16;
+                    unsigned long long *hl = L.hist + (tt & (kHistCopiesD - 1));
+                    const bool on = k0 < K;
+                    const uint32_t w0 = h ? d.z : d.x, w1 = h ? d.w : d.y;
+                    const bool sp = sp_at && (has_zero_byte(w0) || has_zero_byte(w1));
+                    double2 *st = spill_row(prm, p, js, tt) + (size_t)(4 * h) * NT;
+                    double x[8];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const double2 u = st[q * NT];
+                        x[2 * q] = u.x;
+                        x[2 * q + 1] = u.y;
+                    }
+                    if (h == 0) n_sp = 0;
+                    int at = 0;
+                    if (sp) {
+                        at = sp_at[k0 >> 4] + n_sp;
+                        if (on) special_gammas(x, w0, w1, v, a, gsp, at - 16 * sp_g, k0 + 8 * h, K);
+                    }
+                    half_step_dos<EMIT>(x, w0, w1, et, v, s, a, scale, hl, on);
+                    if (EMIT) {
+                        if (sp) n_sp += special_half(x, w0, w1, esp + at);
+                        psum += sum8(x);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) st[q * NT] = make_double2(x[2 * q], x[2 * q + 1]);
+                    }
+                }
+            }
+        }
         return psum;
     };
     // fold the eight copies of every bin into mg[gp] and clear them (after the barrier that ends gp's atomics; a barrier
@@ -915,27 +1077,27 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
     }
 }
 
-template <int NR, int NL>
+template <int NR, int NL, bool SP = false>
 void launch_dos(const PassParams &prm, const Geo64 &geo, hipStream_t s, hipEvent_t e_mid) {
     const size_t lds = lds_bytes(geo), lds_d = lds_bytes_d(geo);
-    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_fwd64<NR, NL>), dim3(prm.P), dim3(kNT), lds, s, prm, geo.n_last);
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd64<NR, NL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_fwd64<NR, NL, SP>), dim3(prm.P), dim3(kNT), lds, s, prm, geo.n_last);
     QA_HIP(hipGetLastError());
     if (e_mid) QA_HIP(hipEventRecord(e_mid, s));
-    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd64d<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
-    hipLaunchKernelGGL((k_bwd64d<NR, NL>), dim3(prm.P), dim3(kNT), lds_d, s, prm, geo.n_last);
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd64d<NR, NL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+    hipLaunchKernelGGL((k_bwd64d<NR, NL, SP>), dim3(prm.P), dim3(kNT), lds_d, s, prm, geo.n_last);
     QA_HIP(hipGetLastError());
 }
 
-template <int NR, int NL>
+template <int NR, int NL, bool SP = false>
 void launch(const PassParams &prm, const Geo64 &geo, hipStream_t s, hipEvent_t e_mid) {
     const size_t lds = lds_bytes(geo);
-    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_fwd64<NR, NL>), dim3(prm.P), dim3(kNT), lds, s, prm, geo.n_last);
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd64<NR, NL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_fwd64<NR, NL, SP>), dim3(prm.P), dim3(kNT), lds, s, prm, geo.n_last);
     QA_HIP(hipGetLastError());
     if (e_mid) QA_HIP(hipEventRecord(e_mid, s));
-    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd64<NR, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_bwd64<NR, NL>), dim3(prm.P), dim3(kNT), lds, s, prm, geo.n_last);
+    QA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bwd64<NR, NL, SP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_bwd64<NR, NL, SP>), dim3(prm.P), dim3(kNT), lds, s, prm, geo.n_last);
     QA_HIP(hipGetLastError());
 }
 
@@ -943,13 +1105,15 @@ void launch(const PassParams &prm, const Geo64 &geo, hipStream_t s, hipEvent_t e
 
 namespace qa {
 
-int fb64_chunks(int K) { return geo64(K).NCH; }
+int fb64_chunks(int K) { const Geo64 g = geo64(K); return g.NCH + g.NS; }   // chunk rows in all: on chip + streamed
+int fb64_spill_rows(int K) { return geo64(K).NS; }
 size_t fb64_lds_bytes(int K) { return lds_bytes(geo64(K)); }
 
 // elements per stored alpha column of the dosage passes: the lane-interleaved layout of the chunk rows in use, no padding to
 // whole rows (K = 50 000: 50 176 instead of 57 344 doubles -- 0.80 instead of 0.92 GB per pass over 2 000 grids)
 size_t fb64_alpha_col_elems(int K) {
     const Geo64 g = geo64(K);
+    if (g.NS > 0) return (size_t)(g.NCH + g.NS) * kRowHaps;   // streamed geometry: whole rows
     return g.NCH ? (size_t)(g.NCH - 1) * kRowHaps + (size_t)g.n_last * 16 : 0;
 }
 size_t fb64_dos_lds_bytes(int K) { return lds_bytes_d(geo64(K)); }
@@ -958,7 +1122,12 @@ void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mi
     const PassParams &prm = *static_cast<const PassParams *>(pass_params);
     const Geo64 geo = geo64(prm.K);
     if (geo.NCH == 0 || lds_bytes_d(geo) > kLdsMax) throw std::runtime_error("K exceeds the on-chip capacity of the fp64 dosage kernels");
-    if (prm.Kq != geo.NCH * kRowHaps) throw std::runtime_error("internal: Kq does not match the fp64 geometry");
+    if (prm.Kq != (geo.NCH + geo.NS) * kRowHaps) throw std::runtime_error("internal: Kq does not match the fp64 geometry");
+    if (geo.NS > 0) {
+        if (!prm.spill) throw std::runtime_error("internal: streamed chunk rows without their buffer");
+        launch_dos<5, 2, true>(prm, geo, st, e_mid);
+        return;
+    }
     switch (geo.NR * 10 + geo.NL) {
 #ifndef QA_FAST_BUILD
         case 10: launch_dos<1, 0>(prm, geo, st, e_mid); break;
@@ -978,7 +1147,12 @@ void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
     const PassParams &prm = *static_cast<const PassParams *>(pass_params);
     const Geo64 geo = geo64(prm.K);
     if (geo.NCH == 0) throw std::runtime_error("K exceeds the on-chip capacity of the fp64 ranking kernels");
-    if (prm.Kq != geo.NCH * kRowHaps) throw std::runtime_error("internal: Kq does not match the fp64 geometry");
+    if (prm.Kq != (geo.NCH + geo.NS) * kRowHaps) throw std::runtime_error("internal: Kq does not match the fp64 geometry");
+    if (geo.NS > 0) {
+        if (!prm.spill) throw std::runtime_error("internal: streamed chunk rows without their buffer");
+        launch<5, 2, true>(prm, geo, st, e_mid);
+        return;
+    }
     switch (geo.NR * 10 + geo.NL) {
 #ifndef QA_FAST_BUILD
         case 10: launch<1, 0>(prm, geo, st, e_mid); break;

@@ -75,6 +75,11 @@ struct PassParams {
     int32_t *top_idx;        // [P][n_thin][top_cap]
     void *top_val;          // [P][n_thin][top_cap]
     const int32_t *topk_todo;  // k_topk: null (every (thinned column, pass)), or [n][2] = (pass, column) pairs to do
+    // fp64 kernels of fullpass64.hip with K beyond their on-chip capacity (7 chunk rows of 8 192 haplotypes): the state of the
+    // chunk rows past the seventh lives here, [P][rows][8][512] double2 (a row in the layout of an LDS row), read and written by
+    // the thread that owns the elements once per grid
+    double *spill;
+    size_t spill_pass_stride;  // doubles
 };
 
 // Emission of one distinct word (reference-single.cpp:294-327): the product over the grid's SNPs of P(reads | allele), with
@@ -174,6 +179,8 @@ namespace qa {
 // fullpass64.hip: the fp64-state ranking passes.  fb64_chunks: chunk rows (of 512 x 16 haplotypes) the geometry needs for K
 // haplotypes, 0 when K exceeds its on-chip capacity.
 int fb64_chunks(int K);
+// chunk rows beyond the on-chip seven, whose state is streamed through HBM (PassParams::spill); 0 up to K = 57 344
+int fb64_spill_rows(int K);
 size_t fb64_lds_bytes(int K);
 void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
 // the fp64-state DOSAGE passes: k_fwd64 storing every column + k_bwd64d (gamma histogram for k_dosage)

@@ -322,8 +322,13 @@ struct WorkerBuffers {
     HostBuf<double> conf;         // read confidence [reads][K]
     explicit WorkerBuffers(const qa_impute_backend_t *be) { dos.be = be; conf.be = be; }
 };
-std::mutex g_buf_mu;
-std::map<void *, std::unique_ptr<WorkerBuffers>> g_bufs;   // product backend only: handle -> its thread's buffers
+// product backend only: handle -> its thread's buffers.  Never destroyed: a static's destructor would free pinned memory after
+// the HIP runtime (and the library's own registry of pinned regions) may be gone; qa_impute_release_buffers frees in time.
+std::mutex &buf_mu() { static std::mutex *m = new std::mutex; return *m; }
+std::map<void *, std::unique_ptr<WorkerBuffers>> &bufs() {
+    static auto *m = new std::map<void *, std::unique_ptr<WorkerBuffers>>;
+    return *m;
+}
 
 struct Worker {
     Ctx &cx;
@@ -344,8 +349,8 @@ struct Worker {
             own.reset(new WorkerBuffers(c.be));
             return *own;
         }
-        std::lock_guard<std::mutex> g(g_buf_mu);
-        auto &slot = g_bufs[h];
+        std::lock_guard<std::mutex> g(buf_mu());
+        auto &slot = bufs()[h];
         if (!slot) slot.reset(new WorkerBuffers(c.be));
         return *slot;
     }
@@ -1114,8 +1119,8 @@ int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impu
 }
 
 int qa_impute_release_buffers(void) {
-    std::lock_guard<std::mutex> g(g_buf_mu);
-    g_bufs.clear();
+    std::lock_guard<std::mutex> g(buf_mu());
+    bufs().clear();
     return QA_OK;
 }
 

@@ -208,6 +208,7 @@ int main(void) {
         st = qa_impute_samples(both, 1, &ip, 2, 100, i_read_off, i_read_ptr, i_u, i_bq, i_wif, i_dos[1], i_gp[1], i_ph[1], i_lab[1],
                                i_nd[1], NULL);
         CHECK(st == QA_ERR_INVALID && strstr(qa_last_error(), "no reads"), "a sample without reads is refused");
+        CHECK(qa_impute_release_buffers() == QA_OK, "qa_impute_release_buffers");
         qa_panel_destroy(panel2);
         printf("IMPUTE_SAMPLES_OK\n");
     }

@@ -268,3 +268,67 @@ def test_fp64_dosage_batch(medium_panel, oracle):
                     top_matches_values=bval[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]]) for j in range(n_thin)]
         check_best_haps(got, ref["best_haps"])
     dev.close()
+
+
+@pytest.mark.parametrize("K", [57344, 57345, 65536, 70001, 131072])
+def test_panels_beyond_the_on_chip_capacity(oracle, K):
+    """K above 57 344 haplotypes (seven chunk rows of 8 192: what one compute unit's registers and LDS hold): the chunk rows past
+    the seventh stream their state through HBM (PassParams::spill).  The reference has no limit on K
+    (reference-single.cpp:878-1131, :1781-2179); HRC is 64 976 haplotypes.  Dosage passes (fp64 state; also what a handle with
+    fp32 dosage passes falls back to beyond the fp32 kernels' 98 304) and ranking passes through the batched call: dosage to
+    1e-9, best-haplotype lists identical, against the oracle.  57 344 / 57 345: either side of the boundary."""
+    import ctypes as C
+    from quilt_amd.native import DevicePanel, check, lib, ptr
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=K, nSNPs=640, seed=515, nMaxDH=255)
+    s = make_synthetic_sample(panel, seed=3, n_reads=300)
+    cols = thin_cols(panel.nGrids, every=4)
+    n_thin = int((cols >= 0).sum())
+    for fp64_dosage in ((True, False) if K in (65536, 131072) else (True,)):
+        dev = DevicePanel(panel)
+        if fp64_dosage:
+            dev.set_dosage_precision(64)
+        gls = [label_gl(panel, s, 1, oracle), label_gl(panel, s, 2, oracle)]
+        want = [True, False]
+        gl = np.ascontiguousarray(np.stack([np.ascontiguousarray(g.T) for g in gls]))
+        wd = np.array(want, dtype=np.int32)
+        dosage = np.zeros((2, panel.nSNPs))
+        bptr = np.zeros(2 * n_thin + 1, dtype=np.int32)
+        cap = 2 * n_thin * 64
+        bidx, bval = np.zeros(cap, dtype=np.int32), np.zeros(cap)
+        check(lib().qa_fullpass_batch(dev.handle, C.c_int32(2), ptr(gl), ptr(wd), ptr(cols), C.c_int32(5), ptr(dosage), ptr(bptr),
+                                      ptr(bidx), ptr(bval), C.c_int64(cap)))
+        for i, g in enumerate(gls):
+            ref = oracle.haploid_dosage_versus_refs(panel, g, cols, return_dosage=bool(want[i]), get_best_haps_from_thinned_sites=True)
+            if want[i]:
+                tol = 1e-9 if (fp64_dosage or K > 98304) else 2e-4
+                assert np.abs(dosage[i] - ref["dosage"]).max() <= tol
+            got = [dict(top_matches=bidx[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]],
+                        top_matches_values=bval[bptr[i * n_thin + j]:bptr[i * n_thin + j + 1]]) for j in range(n_thin)]
+            check_best_haps(got, ref["best_haps"])
+        dev.close()
+
+
+def test_k_limit_that_remains_is_a_documented_status(oracle):
+    """What is still limited above K = 57 344: the K x nGrids outputs of the single-pass entry point (alphaHat_t / betaHat_t /
+    gamma_t come from kernels that hold the state on chip) -- QA_ERR_UNSUPPORTED with a text that says so (include/quilt_amd.h);
+    dosage, c and the lists of the same entry point work."""
+    from quilt_amd.native import DevicePanel, QuiltAmdError
+    from quilt_amd.reference_single import Rcpp_haploid_dosage_versus_refs
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=65536, nSNPs=320, seed=99, nMaxDH=255)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    s = make_synthetic_sample(panel, seed=4, n_reads=150)
+    gl = label_gl(panel, s, 1, oracle)
+    dosage = np.zeros(panel.nSNPs)
+    c = np.zeros(panel.nGrids)
+    Rcpp_haploid_dosage_versus_refs(dev, gl, dosage=dosage, c=c, return_betaHat_t=False, return_gamma_t=False, always_normalize=False)
+    ref = oracle.haploid_dosage_versus_refs(panel, gl, None, always_normalize=False)
+    assert np.abs(dosage - ref["dosage"]).max() <= 1e-9
+    np.testing.assert_allclose(c, ref["c"], rtol=1e-12)
+    with pytest.raises(QuiltAmdError, match="57 344") as e:
+        Rcpp_haploid_dosage_versus_refs(dev, gl, dosage=dosage, gamma_t=np.zeros((panel.K, panel.nGrids), order="F"),
+                                        return_betaHat_t=False, return_gamma_t=True)
+    assert e.value.status == -3   # QA_ERR_UNSUPPORTED
+    dev.close()
