@@ -334,10 +334,45 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
         if (mapq < o.bqFilter) { S->stats[2]++; continue; }
         if (std::abs((int64_t)tlen) > (int64_t)o.iSizeUpperLimit) { S->stats[3]++; continue; }
         const uint8_t *cig = &rec[32 + l_read_name], *seq = cig + 4 * (size_t)n_cigar, *qual = seq + (l_seq + 1) / 2;
+        // A CIGAR of more than 65 535 operations (long reads) does not fit n_cigar_op: the record then carries the placeholder
+        // <l_seq>S<reference length>N and the real CIGAR as the auxiliary array CG:B,I (SAM spec 4.2.2).
+        int64_t n_ops = n_cigar;
+        if (n_cigar == 2) {
+            uint32_t c0, c1;
+            memcpy(&c0, cig, 4);
+            memcpy(&c1, cig + 4, 4);
+            if ((c0 & 15) == 4 && (int64_t)(c0 >> 4) == l_seq && (c1 & 15) == 3) {
+                const uint8_t *a = qual + l_seq, *end = rec.data() + rec.size();
+                while (a + 3 <= end) {   // walk the auxiliary fields: tag[2] type value
+                    const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+                    a += 3;
+                    size_t len = 0;
+                    if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
+                    else if (ty == 's' || ty == 'S') len = 2;
+                    else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
+                    else if (ty == 'Z' || ty == 'H') { while (a + len < end && a[len]) len++; len++; }
+                    else if (ty == 'B') {
+                        if (a + 5 > end) break;
+                        const char sub = (char)a[0];
+                        uint32_t cnt;
+                        memcpy(&cnt, a + 1, 4);
+                        const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                        if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4 * (size_t)cnt <= end) {
+                            cig = a + 5;
+                            n_ops = cnt;
+                            break;
+                        }
+                        len = 5 + es * (size_t)cnt;
+                    } else break;   // unknown type: stop looking (the placeholder then stands: no base is used)
+                    if (a + len > end) break;
+                    a += len;
+                }
+            }
+        }
         // walk the CIGAR; a soft clip is laid out left of / right of the aligned part when its bases are to be used
         int64_t rpos = (int64_t)pos0 + 1;   // 1-based reference coordinate of the next reference-consuming base
         if (o.useSoftClippedBases) {   // the leading soft clip: the first operation that is not a hard clip (2H3S4M)
-            for (int ci = 0; ci < n_cigar; ci++) {
+            for (int64_t ci = 0; ci < n_ops; ci++) {
                 uint32_t c0;
                 memcpy(&c0, cig + 4 * (size_t)ci, 4);
                 if ((c0 & 15) == 5) continue;
@@ -350,7 +385,7 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
         std::vector<Base> bases;
         // first site at or after the alignment start
         int32_t t = (int32_t)(std::lower_bound(L, L + nSNPs, (int32_t)std::max<int64_t>(rpos, INT32_MIN)) - L);
-        for (int ci = 0; ci < n_cigar; ci++) {
+        for (int64_t ci = 0; ci < n_ops; ci++) {
             uint32_t c;
             memcpy(&c, cig + 4 * (size_t)ci, 4);
             const int op = c & 15;

@@ -505,3 +505,36 @@ def test_vcf_columns_reject_values_they_cannot_print():
         assert call(gp, h) == -2 and b"SNP 2" in lib.qa_last_error()
         g = gp.copy(); g[3 * 1 + 1] = bad
         assert call(g, hd) == -2 and b"SNP 1" in lib.qa_last_error()
+
+
+def test_aligner_like_bam_fixture():
+    """tests/golden/aligner_like.bam (make_aligner_like_bam.py, byte by byte from the SAM specification): what bwa mem + samtools
+    markdup and a long-read aligner emit and the other fixtures lack -- a 25-reference header with @RG / @PG, the target as
+    reference 19 between alignments on other chromosomes and unplaced unmapped reads, a placed unmapped mate, secondary /
+    supplementary / duplicate / QC-fail flags, MAPQ 0, `B`-array auxiliary fields ahead of others, a 70 000-operation CIGAR in
+    CG:B,I behind the <l_seq>S<ref_len>N placeholder (a 332 kB record across five BGZF blocks), an N and a low-quality base on
+    SNPs.  The expected pile-up is hand-derived in the generator.  BASELINE configs[0]'s real BAM cannot be had here (no data in
+    the image): this is its stand-in for the FORMAT; the numbers of configs[0] stay untested (README)."""
+    import gzip
+    import json
+    from quilt_amd.io import loadBamAndConvert
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    bam = os.path.join(gold, "aligner_like.bam")
+    z = json.load(open(os.path.join(gold, "aligner_like.json")))
+    raw = gzip.open(bam, "rb").read()
+    assert raw[:4] == b"BAM\x01" and len(raw) == z["stream_bytes"] and z["n_cigar_ops_long"] > 65535 and z["long_record_bytes"] > 4 * 65280
+    L, ref, alt = np.array(z["sites"]["L"], dtype=np.int32), list(z["sites"]["ref"]), list(z["sites"]["alt"])
+    want = lambda key: [dict(u=e["u"], bq=e["bq"]) for e in z["expect"][key]]
+    s, st = loadBamAndConvert(bam, z["chr"], L, ref, alt, downsampleToCov=0, return_stats=True)
+    assert _reads_of(s) == want("default")
+    e = z["expect"]["stats_default"]
+    assert (st["alignments_on_chr"], st["flagged"], st["low_mapq"], st["no_site"], st["mates_merged"]) == \
+        (e["seen"], e["by_flags"], e["low_mapq"], e["no_base"], e["mates_merged"])
+    # through the index (bins + linear index of reference 19) into a window that only the long read overlaps
+    got = loadBamAndConvert(bam, z["chr"], L, ref, alt, downsampleToCov=0, chrStart=2500, chrEnd=70000)
+    assert _reads_of(got) == want("window_2500_70000")
+    # and without the index (a copy without its .bai): the sequential scan gives the same reads
+    import shutil, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(bam, os.path.join(d, "x.bam"))
+        assert _reads_of(loadBamAndConvert(os.path.join(d, "x.bam"), z["chr"], L, ref, alt, downsampleToCov=0)) == want("default")
