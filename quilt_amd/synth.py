@@ -88,6 +88,57 @@ def make_synthetic_panel(K: int, nSNPs: int, seed: int = 4916, nMaxDH: int = 255
     )
 
 
+def make_1000g_like_panel(K: int = 5008, nSNPs: int = 3200, seed: int = 2504, nMaxDH: int = 255, ref_error: float = 1e-3,
+                          nGen: float = 100.0, expRate: float = 1.0, block: int = 256) -> Panel:
+    """A panel with the shape of the quick-start's (BASELINE configs[0]: 1000 Genomes phase 3, 2 504 samples = 5 008
+    haplotypes): a site-frequency spectrum dominated by rare variants -- the derived-allele count i of a SNP is drawn with
+    P(i) ~ 1 / i, the neutral expectation 1000G roughly follows -- and linkage disequilibrium from shared ancestry: within a
+    block of ``block`` SNPs the haplotypes have a fixed order and a SNP's carriers are a contiguous run of that order (nested and
+    overlapping clades); from block to block segments of the order are cut and moved (recombination).  No real data: the
+    stand-in for the panel whose file cannot be downloaded here."""
+    rng = np.random.default_rng(seed)
+    G = (nSNPs + 31) // 32
+    region_bp = nSNPs * 47
+    L = np.sort(rng.choice(np.arange(1, region_bp + 1), size=nSNPs, replace=False)).astype(np.int64)
+    grid = (np.arange(nSNPs) // 32).astype(np.int32)
+    starts = np.arange(0, nSNPs, 32)
+    L_grid = (np.add.reduceat(L, starts) // np.diff(np.r_[starts, nSNPs])).astype(np.int64)
+    sigma = _sigma_from_positions(L_grid, nGen, expRate)
+    transMatRate_t = np.asfortranarray(np.stack([sigma, 1.0 - sigma], axis=0))
+    counts = np.arange(1, K)
+    p_count = (1.0 / counts) / (1.0 / counts).sum()
+    order = rng.permutation(K)
+    hap = np.zeros((K, nSNPs), dtype=np.uint8)
+    for t in range(nSNPs):
+        if t % block == 0 and t > 0:   # a few recombinations: segments of the order move
+            for _ in range(6):
+                a, b = sorted(rng.integers(0, K, size=2))
+                if b - a > 1:
+                    seg = order[a:b].copy()
+                    rest = np.concatenate([order[:a], order[b:]])
+                    at = int(rng.integers(0, len(rest) + 1))
+                    order = np.concatenate([rest[:at], seg, rest[at:]])
+        i = int(rng.choice(counts, p=p_count))
+        a = int(rng.integers(0, K - i + 1))
+        hap[order[a:a + i], t] = 1
+    pad = np.zeros((K, G * 32), dtype=np.uint64)
+    pad[:, :nSNPs] = hap
+    w = (np.uint64(1) << np.arange(32, dtype=np.uint64))
+    rhb_t = np.asfortranarray((pad.reshape(K, G, 32) * w[None, None, :]).sum(axis=2).astype(np.uint32).view(np.int32))
+    t = make_rhb_t_equality(rhb_t, nMaxDH, nSNPs, ref_error, use_hapMatcherR=True)
+    return Panel(
+        K=K, nSNPs=nSNPs, nGrids=G, nMaxDH=t["nMaxDH"], ref_error=ref_error, rhb_t=rhb_t,
+        hapMatcher=t["hapMatcher"], hapMatcherR=t["hapMatcherR"],
+        distinctHapsB=t["distinctHapsB"], distinctHapsIE=t["distinctHapsIE"],
+        eMatDH_special_grid_which=t["eMatDH_special_grid_which"],
+        eMatDH_special_values_list=t["eMatDH_special_values_list"],
+        eMatDH_special_matrix=t["eMatDH_special_matrix"],
+        eMatDH_special_matrix_helper=t["eMatDH_special_matrix_helper"],
+        transMatRate_t=transMatRate_t, L=L, L_grid=L_grid, grid=grid,
+        extra=dict(seed=seed, nGen=nGen, expRate=expRate, spectrum="1/i"),
+    )
+
+
 @dataclass
 class SampleReads:
     """Flattened ``sampleReads`` (one sample)."""

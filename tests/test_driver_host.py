@@ -312,7 +312,7 @@ def test_underflowing_input_is_retried_by_the_cpu_path(small_panel):
     assert np.isfinite(res[0].dosage).all()
 
 
-def _bam_to_vcf(tmp_path, panel, backend, method="diploid", n_samples=3, n_reads=300, ff=None):
+def _bam_to_vcf(tmp_path, panel, backend, method="diploid", n_samples=3, n_reads=300, ff=None, prm=None):
     """Synthetic samples -> BAM files -> loader -> driver -> VCF; returns (parsed VCF rows, run record, truth dosages)."""
     import gzip
     from quilt_amd.driver import DriverParams
@@ -334,7 +334,8 @@ def _bam_to_vcf(tmp_path, panel, backend, method="diploid", n_samples=3, n_reads
     bamutil.write_bam(empty, [("chr20", int(panel.L[-1]) + 1000)], [])
     bams.insert(1, empty)
     names = [f"NA{i}" for i in range(len(bams))]
-    prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method=method)
+    if prm is None:
+        prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method=method)
     out = str(tmp_path / "quilt.vcf.gz")
     rec = impute_bams_to_vcf(panel, backend, bams, names, "chr20", ref, alt, out, params=prm,
                              ff=None if ff is None else [ff] * len(bams))

@@ -408,3 +408,34 @@ def test_bam_to_vcf_end_to_end_on_the_device(tmp_path, small_panel, method):
     from tests.util import r2
     assert r2(np.array(ds_g), np.array(ds_c)) >= 0.98
     assert np.mean(np.abs(np.array(ds_g) - np.array(ds_c)) <= 1.001e-3) >= 0.8
+
+
+def test_quick_start_shaped_run_bam_to_vcf(tmp_path):
+    """BASELINE configs[0]'s SHAPE (the quick-start: one 1x sample against the 1000 Genomes panel, ~5 000 haplotypes) with
+    stand-ins for the data that cannot be had here: a K = 5 008 panel with a rare-variant-dominated (1 / i) frequency spectrum
+    (quilt_amd.synth.make_1000g_like_panel) compressed ON THE DEVICE from its packed form (qa_panel_create_from_rhb: the step
+    quilt-prepare-reference.R:416-428 does with STITCH), one synthetic 1x sample through a BAM file, QUILT's defaults
+    (nGibbsSamples = 7, n_seek_its = 3, Ksubset = 600), fp64 dosage passes, BAM -> loader -> driver -> VCF.  The file equals the
+    one the CPU path writes from the same BAM: same text."""
+    from quilt_amd.driver import DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_1000g_like_panel
+    from tests.oracle_backend import OracleBackend
+    from tests.test_driver_host import _bam_to_vcf
+    panel = make_1000g_like_panel(K=5008, nSNPs=3200, seed=2504)
+    dev = DevicePanel.from_rhb(panel)
+    dev.set_dosage_precision(64)
+    prm = DriverParams(seed=3)
+    (tmp_path / "gpu").mkdir()
+    (tmp_path / "cpu").mkdir()
+    rows_g, rec_g, truth = _bam_to_vcf(tmp_path / "gpu", panel, HipBackend(dev), n_samples=1, n_reads=1000, prm=prm)
+    rows_c, rec_c, _ = _bam_to_vcf(tmp_path / "cpu", panel, OracleBackend(panel, n_threads=8), n_samples=1, n_reads=1000, prm=prm)
+    dev.close()
+    assert np.array_equal(rec_g["results"][0].read_labels, rec_c["results"][0].read_labels)
+    assert np.abs(rec_g["results"][0].dosage - rec_c["results"][0].dosage).max() <= 1e-9
+    diff = [(a, b) for a, b in zip(rows_g, rows_c) if a != b]
+    # (three-decimal strings of numbers that agree to 1e-9: a value within 1e-9 of a rounding boundary may print differently)
+    assert len(diff) <= 2, diff[:3]
+    from tests.util import r2
+    ds = np.array([float(r[9].split(":")[2]) for r in rows_g])
+    assert r2(ds, truth[0]) > 0.9
