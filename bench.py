@@ -327,7 +327,9 @@ def main():
         # sampler's 256-register build) for short reads -- 2 steps of 128 samples, 8 of 32 (configs[1]); ONT: short Gibbs
         # launches, NIPT: three labels, no 256-register build -- one chain per SIMD
         per_step = a.batch * 8
-        a.fuse = max(1, min(16, round(2048 / per_step))) if a.mode == "short" else max(1, min(16, round(1024 / per_step)))
+        # (impute_rare_common: the all-SNP Gibbs call's state is three times as long -- 1 024 chains per launch set)
+        a.fuse = (max(1, min(16, round(2048 / per_step))) if (a.mode == "short" and a.rare_common <= 0)
+                  else max(1, min(16, round(1024 / per_step))))
     a.fuse = max(1, a.fuse)
     native_ok = a.mode != "nipt" and a.rare_common <= 0 and not (a.mspbwt and a.mspbwt_search != "scan") and not a.stub
     if a.driver is None:
@@ -777,7 +779,7 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
     truth = (samples[-1][0].all_snp if rc is not None else samples[-1][0]).truth_haps[:2].sum(axis=0)
     out["dosage_r2_vs_truth_sample0"] = float(np.corrcoef(last[0].dosage, truth)[0, 1] ** 2)
     out["cpu_baseline"] = cpu
-    if a.mspbwt and fp64 and native is not None and not getattr(a, "no_scan_check", False):
+    if a.mspbwt and fp64 and native is not None and rc is None and not getattr(a, "no_scan_check", False):
         out["mspbwt_search_vs_neighbour_scan"] = search_vs_scan(drv.devs[0], panel, params, last[0])
     if keep is not None:
         dev = drv.devs[0]

@@ -73,7 +73,17 @@ inline void stage_copy_as(void *dst, const void *src, size_t bytes, hipStream_t 
                        static_cast<const unsigned char *>(src) + n * sizeof(V), static_cast<unsigned char *>(dst) + n * sizeof(V),
                        n_tail);
 }
+// QA_COPY_ENGINE=sdma: measurement switch -- the same transfers through the runtime's hipMemcpyAsync (the DMA engines where the
+// runtime uses them for pinned memory) instead of the one-wave copy kernel; DESIGN.md 5 has what it measured
+inline bool copy_by_runtime() {
+    static const bool v = [] { const char *e = getenv("QA_COPY_ENGINE"); return e && !strcmp(e, "sdma"); }();
+    return v;
+}
 inline void stage_copy(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    if (copy_by_runtime()) {
+        (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s);
+        return;
+    }
     const uintptr_t a = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src);
     if ((a & 15) == 0) stage_copy_as<uint4>(dst, src, bytes, s);
     else if ((a & 7) == 0) stage_copy_as<uint2>(dst, src, bytes, s);
