@@ -331,11 +331,11 @@ def main():
         a.fuse = (max(1, min(16, round(2048 / per_step))) if (a.mode == "short" and a.rare_common <= 0)
                   else max(1, min(16, round(1024 / per_step))))
     a.fuse = max(1, a.fuse)
-    native_ok = a.mode != "nipt" and a.rare_common <= 0 and not (a.mspbwt and a.mspbwt_search != "scan") and not a.stub
+    native_ok = a.mode != "nipt" and not (a.mspbwt and a.mspbwt_search != "scan") and not a.stub
     if a.driver is None:
         a.driver = "native" if native_ok and a.split == "alternate" and a.exclusive and not a.gibbs_gate and not a.cu_partition else "python"
     if a.driver == "native" and not native_ok:
-        raise SystemExit("--driver native covers diploid samples without --rare-common (msPBWT mode: the neighbour scan)")
+        raise SystemExit("--driver native covers diploid samples (msPBWT mode: the neighbour scan)")
     os.environ.setdefault("QA_HOST_THREADS", str(max(2, (os.cpu_count() or 16) // max(1, local_world * a.workers))))
     params = dict(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
     full_chains = params["nGibbsSamples"] + 1
@@ -413,7 +413,7 @@ def main():
         if a.driver == "native":
             from quilt_amd.workers import NativeWorkers
             drv = NativeWorkers(panel, DriverParams(**params), n_workers=a.workers, fp64_dosage=a.precision != "mixed",
-                                exclusive=bool(a.exclusive), fuse_tails=bool(a.fuse_tails))
+                                exclusive=bool(a.exclusive), fuse_tails=bool(a.fuse_tails), rare_common=rc)
         else:
           drv = DeviceWorkers(panel, DriverParams(**params), n_workers=a.workers, rare_common=rc,
                             cu_partition=a.cu_partition, fp64_dosage=a.precision != "mixed", split=a.split, gibbs_gate=a.gibbs_gate,
@@ -510,7 +510,7 @@ def main():
             # one sample alone on the device (the quick-start's shape): the latency of the whole per-sample pipeline
             from quilt_amd.impute import impute_samples
             t_l = time.perf_counter()
-            impute_samples(drv.devs[:1], samples[-1][:1], DriverParams(**params), sample_offset=10 ** 6)
+            impute_samples(drv.devs[:1], samples[-1][:1], DriverParams(**params), sample_offset=10 ** 6, drcs=drv.drcs[:1])
             out["one_sample_latency_s"] = round(time.perf_counter() - t_l, 3)
         if a.dotcall > 0 and native is not None and world == 1:
             # the device-wide arena goes with the last handle: the workers are processes of their own and need the memory

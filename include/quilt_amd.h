@@ -553,6 +553,22 @@ int qa_gibbs_batch_rare_common(qa_panel_t *panel, const qa_rare_common_t *rc, co
 /* ---- the per-sample driver loop for a range of samples ---------------------- */
 
 /*
+ * impute_rare_common = TRUE (QUILT/R/quilt.R:180; functions.R:1042-1123, rare_common.R:61-420): every Gibbs sample ends with one
+ * Gibbs call over ALL SNPs (impute_final_gibbs_with_rare_common), started from labels drawn from the all-SNP reads' likelihoods
+ * against the latest haploid dosages (get_initial_read_labels); results then cover all SNPs.
+ *   handles          one qa_rare_common_t per panel handle, in the panels' order (qa_rare_common_create)
+ *   snp_is_common    nSNPs_all flags (the common SNPs, in order, are the panel's)
+ *   read_off .. wif  allSNP_sampleReads of the same samples, flattened like the common-SNP reads (u: 0-based all-SNP index, wif:
+ *                    0-based all-SNP grid)
+ */
+typedef struct {
+    const qa_rare_common_t *const *handles;
+    int32_t nSNPs_all, nGrids_all;
+    const uint8_t *snp_is_common;
+    const int32_t *read_off, *read_ptr, *u, *bq, *wif;
+} qa_impute_rare_common_t;
+
+/*
  * Arguments of QUILT() the hot path sees (QUILT/R/quilt.R:97-186), as get_and_impute_one_sample receives them.
  * qa_impute_params_default fills in the reference's defaults.
  */
@@ -577,6 +593,8 @@ typedef struct {
     int32_t samples_per_launch_set;             /* samples whose chains advance in one launch set; 0 = 256 (2 048 Gibbs chains:
                                                    two per SIMD) */
     int32_t no_fused_tails;                     /* 1: the threads' last launch sets run their phasing rounds one after the other */
+    const qa_impute_rare_common_t *rare_common; /* NULL, or impute_rare_common = TRUE: dosage / gp_t / phasing_haps then cover
+                                                   nSNPs_all SNPs and nDosage counts the all-SNP rounds (functions.R:1305-1317) */
 } qa_impute_params_t;
 int qa_impute_params_default(qa_impute_params_t *params);
 
@@ -609,8 +627,8 @@ int qa_impute_params_default(qa_impute_params_t *params);
  *                     [2] selections made on the device, [3] chains handed to qa_gibbs_batch, [4] Gibbs launch sets,
  *                     [5..10] ms summed over the host threads: Gibbs calls, full-panel calls, host, consensus, finish, accumulation
  * Random draws: R's stream cannot be reproduced without R; every draw the R code makes is defined on a counter stream
- * (quilt_amd/rng.py::ChainStream = csrc/impute.cpp).  NIPT and impute_rare_common are not behind this entry point yet
- * (quilt_amd/driver.py runs them over the same batched calls): QA_ERR_UNSUPPORTED is reserved for them.
+ * (quilt_amd/rng.py::ChainStream = csrc/impute.cpp).  method = "nipt" is not behind this entry point yet (quilt_amd/driver.py
+ * runs it over the same batched calls).
  */
 int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impute_params_t *params, int32_t n_sample,
                       int64_t sample_offset, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
@@ -654,6 +672,16 @@ typedef struct {
     void *(*host_alloc)(size_t bytes);
     int (*host_free)(void *p);
     void (*bind_thread)(void *handle);   /* may be NULL */
+    /* impute_rare_common only (may be NULL otherwise): qa_gibbs_batch_rare_common and qa_rcpp_make_eMatRead_t_nsnps */
+    int (*gibbs_batch_rare_common)(void *handle, const void *rc, const qa_gibbs_opts_t *opts, int32_t n_chain,
+                       const int32_t *which_haps_to_use_1based, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
+                       const int32_t *bq, const int32_t *wif, const double *runif_reads, const int32_t *first_read,
+                       const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t, double *genProbsM_t,
+                       double *genProbsF_t, int32_t *underflow_problem, double *state_out, const uint64_t *seed_reads,
+                       const uint64_t *seed_shard);
+    int (*make_eMatRead_t_nsnps)(void *handle, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
+                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                       double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t, double *eMatRead_t);
 } qa_impute_backend_t;
 int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,
                               int32_t nSNPs, const qa_impute_params_t *params, int32_t n_sample, int64_t sample_offset,

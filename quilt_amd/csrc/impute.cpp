@@ -171,6 +171,11 @@ struct Ctx {
     int n_thin = 0, top_width = 8;
     int64_t sample_offset = 0;
     std::vector<Reads> reads;
+    // impute_rare_common: the all-SNP reads, the all-SNP dimensions (T_out = T_all then) and where the common SNPs sit
+    const qa_impute_rare_common_t *rc = nullptr;
+    std::vector<Reads> reads_all;
+    std::vector<int32_t> common_at;   // all-SNP index of common SNP j
+    int T_out = 0;
     // outputs
     double *dosage = nullptr, *gp_t = nullptr, *phasing_haps = nullptr;
     int32_t *read_labels = nullptr, *nDosage = nullptr;
@@ -320,7 +325,8 @@ struct WorkerBuffers {
     std::vector<int32_t> f_cs, f_read_off, f_read_ptr, f_u, f_bq, f_H, f_wd, f_wt, f_cnt, f_next, f_status;
     HostBuf<double> dos;          // the round's haploid dosages [chain][label][T]
     HostBuf<double> conf;         // read confidence [reads][K]
-    explicit WorkerBuffers(const qa_impute_backend_t *be) { dos.be = be; conf.be = be; }
+    HostBuf<double> dos_all;      // impute_rare_common: the all-SNP round's haploid dosages [chain][2][all SNPs]
+    explicit WorkerBuffers(const qa_impute_backend_t *be) { dos.be = be; conf.be = be; dos_all.be = be; }
 };
 // product backend only: handle -> its thread's buffers.  Never destroyed: a static's destructor would free pinned memory after
 // the HIP runtime (and the library's own registry of pinned regions) may be gone; qa_impute_release_buffers frees in time.
@@ -340,7 +346,7 @@ struct Worker {
     std::vector<int32_t> &g_which, &g_read_off, &g_read_ptr, &g_u, &g_bq, &g_wif, &g_first, &g_H, &g_uf, &g_words;
     std::vector<uint64_t> &g_sr, &g_ss, &seed_sel;
     std::vector<int32_t> &f_cs, &f_read_off, &f_read_ptr, &f_u, &f_bq, &f_H, &f_wd, &f_wt, &f_cnt, &f_next, &f_status;
-    HostBuf<double> &dos, &conf;
+    HostBuf<double> &dos, &conf, &dos_all;
     std::function<void()> on_first_launch;
     double t_gibbs = 0, t_fullpass = 0, t_host = 0, t_consensus = 0, t_finish = 0, t_accumulate = 0;
 
@@ -354,19 +360,24 @@ struct Worker {
         if (!slot) slot.reset(new WorkerBuffers(c.be));
         return *slot;
     }
+    const void *rc_handle = nullptr;   // this thread's qa_rare_common_t (impute_rare_common)
+    std::vector<double> eh;            // eHapsCurrent_tc of get_initial_read_labels: [chain][all SNPs][2]
     Worker(Ctx &c, void *h, int wi, bool keep)
         : cx(c), handle(h), w(wi), n_help(helper_threads()), B(buffers_for(c, h, keep, own)), g_which(B.g_which),
           g_read_off(B.g_read_off), g_read_ptr(B.g_read_ptr), g_u(B.g_u), g_bq(B.g_bq), g_wif(B.g_wif), g_first(B.g_first), g_H(B.g_H),
           g_uf(B.g_uf), g_words(B.g_words), g_sr(B.g_sr), g_ss(B.g_ss), seed_sel(B.seed_sel), f_cs(B.f_cs), f_read_off(B.f_read_off),
           f_read_ptr(B.f_read_ptr), f_u(B.f_u), f_bq(B.f_bq), f_H(B.f_H), f_wd(B.f_wd), f_wt(B.f_wt), f_cnt(B.f_cnt), f_next(B.f_next),
-          f_status(B.f_status), dos(B.dos), conf(B.conf) {}
+          f_status(B.f_status), dos(B.dos), conf(B.conf), dos_all(B.dos_all) {}
 
     // ---- the Gibbs call of a round with impute_one_sample's underflow retry (functions.R:2612-2716)
+    // rare: the all-SNP call (qa_gibbs_batch_rare_common on the samples' all-SNP reads, labels given, read categories off:
+    // impute_one_sample's defaults for it, functions.R:2385-2409); hap_out then [chain][2][all SNPs]
     void gibbs_with_retry(std::vector<Chain *> &ch, const std::vector<std::vector<int32_t>> &starts, bool any_first, bool want_words,
-                          double *hap_out) {
+                          double *hap_out, bool rare = false) {
         const auto &P = cx.P;
         const int C = (int)ch.size();
-        const int G = cx.G, T = cx.T;
+        const int G = cx.G, T = rare ? cx.T_out : cx.T;
+        const std::vector<Reads> &RD = rare ? cx.reads_all : cx.reads;
         std::vector<int> pending((size_t)C);
         for (int i = 0; i < C; i++) pending[(size_t)i] = i;
         std::vector<double> maxdiff((size_t)C, P.maxDifferenceBetweenReads);
@@ -387,7 +398,7 @@ struct Worker {
                 g_read_off.assign((size_t)n + 1, 0);
                 std::vector<int64_t> base_off((size_t)n + 1, 0);
                 for (int a = 0; a < n; a++) {
-                    const Reads &r = cx.reads[(size_t)ch[(size_t)idx[(size_t)a]]->sample];
+                    const Reads &r = RD[(size_t)ch[(size_t)idx[(size_t)a]]->sample];
                     g_read_off[(size_t)a + 1] = g_read_off[(size_t)a] + r.R;
                     base_off[(size_t)a + 1] = base_off[(size_t)a] + r.nb;
                 }
@@ -405,7 +416,7 @@ struct Worker {
                 parallel_for((size_t)n, n_help, [&](size_t a) {
                     const int i = idx[a];
                     const Chain &c = *ch[(size_t)i];
-                    const Reads &r = cx.reads[(size_t)c.sample];
+                    const Reads &r = RD[(size_t)c.sample];
                     std::memcpy(&g_which[a * P.Ksubset], c.which.data(), sizeof(int32_t) * (size_t)P.Ksubset);
                     std::memcpy(&g_read_ptr[(size_t)g_read_off[a] + a], r.read_ptr, sizeof(int32_t) * ((size_t)r.R + 1));
                     std::memcpy(&g_wif[(size_t)g_read_off[a]], r.wif, sizeof(int32_t) * (size_t)r.R);
@@ -432,7 +443,7 @@ struct Worker {
                 o.perform_block_gibbs = 1;
                 o.do_shard_block_gibbs = 1;
                 o.gibbs_initialize_iteratively = any_first ? 1 : 0;
-                o.disable_read_category_usage = 0;
+                o.disable_read_category_usage = rare ? 1 : 0;
                 o.class_sum_cutoff = 0.06;
                 o.L_grid = nullptr;
                 o.shuffle_bin_radius = 5000;
@@ -451,10 +462,14 @@ struct Worker {
                 if (on_first_launch) { auto cb = on_first_launch; on_first_launch = nullptr; cb(); }
                 cx.n_gibbs_chain_calls += n;
                 cx.n_gibbs_launches += 1;
-                const int st = cx.be->gibbs_batch(handle, &o, n, g_which.data(), g_read_off.data(), g_read_ptr.data(), g_u.data(),
-                                                  g_bq.data(), g_wif.data(), nullptr, g_first.data(), nullptr, g_H.data(), nullptr,
-                                                  nullptr, nullptr, nullptr, g_uf.data(), nullptr, g_sr.data(), g_ss.data());
-                if (st != QA_OK && st != QA_UNDERFLOW) check(st, "qa_gibbs_batch");
+                const int st = rare
+                    ? cx.be->gibbs_batch_rare_common(handle, rc_handle, &o, n, g_which.data(), g_read_off.data(), g_read_ptr.data(),
+                                                     g_u.data(), g_bq.data(), g_wif.data(), nullptr, g_first.data(), nullptr, g_H.data(),
+                                                     nullptr, nullptr, nullptr, nullptr, g_uf.data(), nullptr, g_sr.data(), g_ss.data())
+                    : cx.be->gibbs_batch(handle, &o, n, g_which.data(), g_read_off.data(), g_read_ptr.data(), g_u.data(),
+                                         g_bq.data(), g_wif.data(), nullptr, g_first.data(), nullptr, g_H.data(), nullptr,
+                                         nullptr, nullptr, nullptr, g_uf.data(), nullptr, g_sr.data(), g_ss.data());
+                if (st != QA_OK && st != QA_UNDERFLOW) check(st, rare ? "qa_gibbs_batch_rare_common" : "qa_gibbs_batch");
                 for (int a = 0; a < n; a++) {
                     const int i = idx[(size_t)a];
                     if (g_uf[(size_t)a]) {
@@ -464,8 +479,10 @@ struct Worker {
                         continue;
                     }
                     Chain &c = *ch[(size_t)i];
-                    const int R = cx.reads[(size_t)c.sample].R;
-                    c.labels.assign(g_H.begin() + g_read_off[(size_t)a], g_H.begin() + g_read_off[(size_t)a] + R);
+                    const int R = RD[(size_t)c.sample].R;
+                    // (the all-SNP call's ending labels are not carried on: the next Gibbs sample starts afresh, the phasing
+                    // iteration's result is its haplotypes)
+                    if (!rare) c.labels.assign(g_H.begin() + g_read_off[(size_t)a], g_H.begin() + g_read_off[(size_t)a] + R);
                     if (!whole) {
                         if (want_words) std::memcpy(&g_words[(size_t)i * 3 * G], &words_tmp[(size_t)a * 3 * G], sizeof(int32_t) * 3 * (size_t)G);
                         if (hap_out) std::memcpy(hap_out + (size_t)i * 2 * T, &hap_tmp[(size_t)a * 2 * T], sizeof(double) * 2 * (size_t)T);
@@ -582,7 +599,7 @@ struct Worker {
             // functions.R:784-893: the next small panel from the long matches of the call's rounded haploid dosages
             std::vector<int> idx;
             for (int i = 0; i < C; i++)
-                if (i_it < P.n_seek_its || (!ch[(size_t)i]->phasing && ch[(size_t)i]->i_chain == P.nGibbsSamples)) idx.push_back(i);
+                if (i_it < P.n_seek_its || cx.rc || (!ch[(size_t)i]->phasing && ch[(size_t)i]->i_chain == P.nGibbsSamples)) idx.push_back(i);
             if (!idx.empty()) {
                 std::vector<uint64_t> seeds(idx.size());
                 std::vector<int32_t> Zs(idx.size() * 2 * (size_t)G), out(idx.size() * (size_t)P.Knew);
@@ -640,7 +657,7 @@ struct Worker {
             f_wt.resize((size_t)C);
             bool any_top = false;
             for (int i = 0; i < C; i++) {
-                f_wt[(size_t)i] = (i_it < P.n_seek_its || (!ch[(size_t)i]->phasing && ch[(size_t)i]->i_chain == P.nGibbsSamples)) ? 1 : 0;
+                f_wt[(size_t)i] = (i_it < P.n_seek_its || cx.rc || (!ch[(size_t)i]->phasing && ch[(size_t)i]->i_chain == P.nGibbsSamples)) ? 1 : 0;
                 any_top |= f_wt[(size_t)i] != 0;
             }
             seed_sel.resize((size_t)C);
@@ -691,11 +708,11 @@ struct Worker {
             t_host += now_s() - t4;
         }
         // the phasing chains' haploid dosages are their samples' phased haplotypes (functions.R:1207-1217, before recast_haps)
-        if (return_dosage)
+        if (return_dosage && !cx.rc)
             for (int i = 0; i < C; i++)
                 if (ch[(size_t)i]->phasing)
                     std::memcpy(cx.phasing_haps + (size_t)ch[(size_t)i]->sample * 2 * T, hap + (size_t)i * 2 * T, sizeof(double) * 2 * (size_t)T);
-        if (return_dosage && cur && !cur->chains.empty()) {   // functions.R:999-1006
+        if (return_dosage && cur && !cur->chains.empty() && !cx.rc) {   // functions.R:999-1006 (rare + common: the all-SNP round counts)
             const double ta = now_s();
             const int n_cur = (int)cur->chains.size();
             std::vector<int32_t> cs((size_t)n_cur);
@@ -706,6 +723,79 @@ struct Worker {
             t_accumulate += now_s() - ta;
         }
         return return_dosage;
+    }
+
+    // impute_final_gibbs_with_rare_common (rare_common.R:109-420), once per Gibbs sample after its seek iterations
+    // (functions.R:1042-1098): starting labels from the all-SNP reads against the latest (hap1, hap2) spread over all SNPs
+    // (get_initial_read_labels, rare_common.R:61-107: 0.5 at the rare SNPs), then one Gibbs call over ALL SNPs with the
+    // haplotypes selected last.  `ch`: the chains of the last round in its order (their dosages are rows of `dos`).
+    void rare_common_round(std::vector<Chain *> &ch, Batch *cur) {
+        const auto &P = cx.P;
+        const int C = (int)ch.size(), T = cx.T, Ta = cx.T_out;
+        const double t0 = now_s();
+        const double *last = dos.p;   // [chain][2][T] of the last seek iteration
+        eh.resize((size_t)C * Ta * 2);
+        parallel_for((size_t)C, n_help, [&](size_t c) {
+            double *e = &eh[c * Ta * 2];
+            for (size_t t = 0; t < (size_t)Ta * 2; t++) e[t] = 0.5;
+            const double *h1 = last + c * 2 * T, *h2 = h1 + T;
+            for (int j = 0; j < T; j++) {
+                e[(size_t)cx.common_at[(size_t)j] * 2] = h1[j];
+                e[(size_t)cx.common_at[(size_t)j] * 2 + 1] = h2[j];
+            }
+        });
+        std::vector<int32_t> read_off((size_t)C + 1, 0);
+        std::vector<int64_t> boff((size_t)C + 1, 0);
+        for (int i = 0; i < C; i++) {
+            const Reads &r = cx.reads_all[(size_t)ch[(size_t)i]->sample];
+            read_off[(size_t)i + 1] = read_off[(size_t)i] + r.R;
+            boff[(size_t)i + 1] = boff[(size_t)i] + r.nb;
+        }
+        g_read_ptr.resize((size_t)read_off[(size_t)C] + C);
+        g_u.resize((size_t)boff[(size_t)C]);
+        g_bq.resize((size_t)boff[(size_t)C]);
+        parallel_for((size_t)C, n_help, [&](size_t i) {
+            const Reads &r = cx.reads_all[(size_t)ch[i]->sample];
+            std::memcpy(&g_read_ptr[(size_t)read_off[i] + i], r.read_ptr, sizeof(int32_t) * ((size_t)r.R + 1));
+            std::memcpy(&g_u[(size_t)boff[i]], r.u, sizeof(int32_t) * (size_t)r.nb);
+            std::memcpy(&g_bq[(size_t)boff[i]], r.bq, sizeof(int32_t) * (size_t)r.nb);
+        });
+        double *lik = conf.get((size_t)read_off[(size_t)C] * 2);
+        // rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100
+        check(cx.be->make_eMatRead_t_nsnps(handle, Ta, C, 2, eh.data(), read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
+                                           P.maxDifferenceBetweenReads, 100, 1, lik), "qa_rcpp_make_eMatRead_t_nsnps");
+        std::vector<std::vector<int32_t>> starts((size_t)C);
+        first_reads.assign((size_t)C, 0);
+        seed_reads.assign((size_t)C, 0);
+        seed_shards.assign((size_t)C, 0);
+        for (int i = 0; i < C; i++) {
+            Chain &c = *ch[(size_t)i];
+            const int R = cx.reads_all[(size_t)c.sample].R;
+            const double *e = lik + (size_t)read_off[(size_t)i] * 2;
+            starts[(size_t)i].resize((size_t)R);
+            for (int r = 0; r < R; r++)   // H <- as.integer(runif(nReads) < e[1, ] / colSums(e)) + 1
+                starts[(size_t)i][(size_t)r] = (c.rng.uniform() < e[(size_t)r * 2] / (e[(size_t)r * 2] + e[(size_t)r * 2 + 1])) ? 2 : 1;
+            seed_reads[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
+            seed_shards[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
+        }
+        const double t1 = now_s();
+        t_host += t1 - t0;
+        double *hall = dos_all.get((size_t)C * 2 * Ta);
+        gibbs_with_retry(ch, starts, false, false, hall, true);
+        const double t2 = now_s();
+        t_gibbs += t2 - t1;
+        for (int i = 0; i < C; i++)
+            if (ch[(size_t)i]->phasing)
+                std::memcpy(cx.phasing_haps + (size_t)ch[(size_t)i]->sample * 2 * Ta, hall + (size_t)i * 2 * Ta, sizeof(double) * 2 * (size_t)Ta);
+        if (cur && !cur->chains.empty()) {   // functions.R:1099-1123
+            const int n_cur = (int)cur->chains.size();
+            std::vector<int32_t> cs((size_t)n_cur);
+            for (int i = 0; i < n_cur; i++) cs[(size_t)i] = cur->chains[(size_t)i].sample - cur->lo;
+            check(cx.be->accumulate_dosage(n_cur, 2, Ta, hall, cs.data(), cur->hi - cur->lo, cx.dosage + (size_t)cur->lo * Ta,
+                                           cx.gp_t + (size_t)cur->lo * 3 * Ta, nullptr, nullptr), "qa_accumulate_dosage");
+            for (int i = 0; i < n_cur; i++) cx.nDosage[cur->chains[(size_t)i].sample] += 1;
+        }
+        t_accumulate += now_s() - t2;
     }
 
     Batch *new_batch(int lo, int hi) {
@@ -784,7 +874,7 @@ struct Worker {
     }
 
     void finish(Batch &b) {
-        const int T = cx.T;
+        const int T = cx.T_out;   // (impute_rare_common: the accumulators and the phasing haplotypes cover all SNPs)
         parallel_for((size_t)(b.hi - b.lo), n_help, [&](size_t si) {
             const int s = b.lo + (int)si;
             const double n = (double)cx.nDosage[s];
@@ -839,6 +929,12 @@ struct Worker {
                     if (cur) for (auto &c : cur->chains) ch.push_back(&c);
                     ch.insert(ch.end(), phasing.begin(), phasing.end());
                     round(ch, i_it, cur.get());
+                }
+                if (cx.rc) {   // functions.R:1042-1123: every Gibbs sample (and the phasing iteration) ends with the all-SNP call
+                    std::vector<Chain *> ch;
+                    if (cur) for (auto &c : cur->chains) ch.push_back(&c);
+                    ch.insert(ch.end(), phasing.begin(), phasing.end());
+                    rare_common_round(ch, cur.get());
                 }
                 if (!taken.empty()) {
                     std::lock_guard<std::mutex> g(cx.tail.mu);
@@ -943,9 +1039,43 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
             base += r.nb;
         }
     }
-    std::memset(dosage, 0, sizeof(double) * (size_t)n_sample * T);
-    std::memset(gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * T);
-    std::memset(phasing_haps, 0, sizeof(double) * (size_t)n_sample * 2 * T);
+    cx.T_out = T;
+    if (P.rare_common) {
+        const qa_impute_rare_common_t &rc = *P.rare_common;
+        if (!rc.handles || rc.nSNPs_all < T || rc.nGrids_all != (rc.nSNPs_all + 31) / 32 || !rc.snp_is_common || !rc.read_off || !rc.read_ptr ||
+            !rc.u || !rc.bq || !rc.wif || !be->gibbs_batch_rare_common || !be->make_eMatRead_t_nsnps) {
+            qa::set_error("qa_impute_samples: impute_rare_common needs the all-SNP handles, dimensions, flags and reads");
+            return QA_ERR_INVALID;
+        }
+        for (int i = 0; i < n_handles; i++)
+            if (!rc.handles[i]) { qa::set_error("qa_impute_samples: one qa_rare_common_t per panel handle"); return QA_ERR_INVALID; }
+        cx.rc = &rc;
+        cx.T_out = rc.nSNPs_all;
+        for (int t = 0; t < rc.nSNPs_all; t++)
+            if (rc.snp_is_common[t]) cx.common_at.push_back(t);
+        if ((int)cx.common_at.size() != T) {
+            qa::set_error("qa_impute_samples: snp_is_common marks %d SNPs, the panel has %d", (int)cx.common_at.size(), T);
+            return QA_ERR_INVALID;
+        }
+        cx.reads_all.resize((size_t)n_sample);
+        int64_t base = 0;
+        for (int s = 0; s < n_sample; s++) {
+            Reads &r = cx.reads_all[(size_t)s];
+            r.R = rc.read_off[s + 1] - rc.read_off[s];
+            if (r.R < 1) { qa::set_error("qa_impute_samples: sample %d has no all-SNP reads", s); return QA_ERR_INVALID; }
+            r.read_ptr = rc.read_ptr + rc.read_off[s] + s;
+            if (r.read_ptr[0] != 0) { qa::set_error("qa_impute_samples: all-SNP read_ptr of sample %d does not start at 0", s); return QA_ERR_INVALID; }
+            r.nb = r.read_ptr[r.R];
+            r.u = rc.u + base;
+            r.bq = rc.bq + base;
+            r.wif = rc.wif + rc.read_off[s];
+            base += r.nb;
+        }
+    }
+    const int To = cx.T_out;
+    std::memset(dosage, 0, sizeof(double) * (size_t)n_sample * To);
+    std::memset(gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * To);
+    std::memset(phasing_haps, 0, sizeof(double) * (size_t)n_sample * 2 * To);
     std::memset(nDosage, 0, sizeof(int32_t) * (size_t)n_sample);
     if (n_sample == 0) return QA_OK;
 
@@ -969,7 +1099,10 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     cx.tail.n_active = W;
 
     std::vector<std::unique_ptr<Worker>> workers;
-    for (int w2 = 0; w2 < W; w2++) workers.emplace_back(new Worker(cx, handles[w2], w2, keep_buffers));
+    for (int w2 = 0; w2 < W; w2++) {
+        workers.emplace_back(new Worker(cx, handles[w2], w2, keep_buffers));
+        if (cx.rc) workers.back()->rc_handle = cx.rc->handles[w2];
+    }
     // staggered start: thread w prepares its first launch once thread w - 1 has handed its own to the device
     struct Started { std::mutex mu; std::condition_variable cv; bool set = false; };
     std::vector<Started> started((size_t)W);
@@ -1055,9 +1188,23 @@ int be_ematread(void *h, int32_t nSNPs, int32_t n_chain, int32_t K, const double
                                              Jmax, rescale, out);
 }
 void be_bind(void *h) { (void)qa_panel_bind_thread(static_cast<qa_panel_t *>(h)); }
+int be_gibbs_rc(void *h, const void *rc, const qa_gibbs_opts_t *o, int32_t n, const int32_t *which, const int32_t *read_off,
+                const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif, const double *ru, const int32_t *fr,
+                const double *rs, int32_t *H, int32_t *Hc, double *hp, double *gm, double *gf, int32_t *uf, double *state,
+                const uint64_t *sr, const uint64_t *ss) {
+    return qa_gibbs_batch_rare_common(static_cast<qa_panel_t *>(h), static_cast<const qa_rare_common_t *>(rc), o, n, which, read_off,
+                                      read_ptr, u, bq, wif, ru, fr, rs, H, Hc, hp, gm, gf, uf, state, sr, ss);
+}
+int be_ematread_nsnps(void *h, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps, const int32_t *read_off,
+                      const int32_t *read_ptr, const int32_t *u, const int32_t *bq, double maxdiff, int32_t Jmax, int32_t rescale,
+                      double *out) {
+    return qa_rcpp_make_eMatRead_t_nsnps(static_cast<qa_panel_t *>(h), nSNPs, n_chain, K, eHaps, read_off, read_ptr, u, bq, maxdiff,
+                                         Jmax, rescale, out);
+}
 
 const qa_impute_backend_t kProduct = {be_gibbs, be_fullpass_select, be_fullpass, be_ematread, qa_mspbwt_select_new_haps,
-                                      qa_accumulate_dosage, qa_consensus_read_labels, qa_host_alloc, qa_host_free, be_bind};
+                                      qa_accumulate_dosage, qa_consensus_read_labels, qa_host_alloc, qa_host_free, be_bind,
+                                      be_gibbs_rc, be_ematread_nsnps};
 
 }   // namespace
 

@@ -28,7 +28,13 @@ class ImputeParams(C.Structure):
         ("use_mspbwt", C.c_int32), ("mspbwtL", C.c_int32), ("mspbwtM", C.c_int32),
         ("mspbwt_index", C.c_void_p),
         ("samples_per_launch_set", C.c_int32), ("no_fused_tails", C.c_int32),
+        ("rare_common", C.c_void_p),
     ]
+
+
+class ImputeRareCommon(C.Structure):
+    _fields_ = [("handles", C.c_void_p), ("nSNPs_all", C.c_int32), ("nGrids_all", C.c_int32), ("snp_is_common", C.c_void_p),
+                ("read_off", C.c_void_p), ("read_ptr", C.c_void_p), ("u", C.c_void_p), ("bq", C.c_void_p), ("wif", C.c_void_p)]
 
 
 STAT_NAMES = ("underflow_retries", "full_list_refetches", "device_selections", "gibbs_chain_calls", "gibbs_launches",
@@ -47,10 +53,24 @@ def flatten_samples(samples: Sequence):
     return read_off, cat("read_ptr"), cat("u"), cat("bq"), cat("wif")
 
 
-def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None, fuse_tails: bool = True):
-    """(ImputeParams, keep-alive objects) from the Python driver's parameters (method = "diploid", no rare + common)."""
-    if P.method != "diploid" or P.impute_rare_common:
-        raise ValueError("qa_impute_samples covers method = 'diploid' without impute_rare_common; use quilt_amd.driver.Driver")
+def make_rare_common(rc, rc_handles, samples):
+    """(ImputeRareCommon, keep-alive objects): the all-SNP side of the call -- ``rc`` a quilt_amd.panel.RareCommon, ``rc_handles``
+    one native handle (c_void_p) per panel handle, the samples' ``all_snp`` reads flattened."""
+    read_off, read_ptr, u, bq, wif = flatten_samples([s.all_snp for s in samples])
+    is_common = np.ascontiguousarray(rc.snp_is_common, dtype=np.uint8)
+    hs = (C.c_void_p * len(rc_handles))(*rc_handles)
+    q = ImputeRareCommon(C.cast(hs, C.c_void_p), rc.nSNPs_all, rc.nGrids_all, ptr(is_common), ptr(read_off), ptr(read_ptr), ptr(u),
+                         ptr(bq), ptr(wif))
+    return q, (hs, is_common, read_off, read_ptr, u, bq, wif)
+
+
+def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None, fuse_tails: bool = True, rare_common=None):
+    """(ImputeParams, keep-alive objects) from the Python driver's parameters (method = "diploid"); ``rare_common``: an
+    ImputeRareCommon (with impute_rare_common)."""
+    if P.method != "diploid":
+        raise ValueError("qa_impute_samples covers method = 'diploid'; use quilt_amd.driver.Driver")
+    if P.impute_rare_common and rare_common is None:
+        raise ValueError("impute_rare_common needs the all-SNP side (make_rare_common)")
     blocks = np.ascontiguousarray(P.small_ref_panel_block_gibbs_iterations, dtype=np.int32)
     if P.use_mspbwt and P.mspbwt_search != "scan":
         raise ValueError("qa_impute_samples runs the msPBWT neighbour scan (mspbwt_search = 'scan')")
@@ -59,8 +79,9 @@ def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None,
                      P.n_gibbs_sample_its, ptr(blocks), len(blocks), P.maxDifferenceBetweenReads, P.minGLValue, P.Jmax,
                      P.seed, int(P.use_mspbwt), P.mspbwtL, P.mspbwtM,
                      mspbwt_index.handle if (P.use_mspbwt and mspbwt_index is not None) else None,
-                     int(samples_per_launch_set), 0 if fuse_tails else 1)
-    return q, (blocks, mspbwt_index)
+                     int(samples_per_launch_set), 0 if fuse_tails else 1,
+                     C.cast(C.pointer(rare_common), C.c_void_p) if (P.impute_rare_common and rare_common is not None) else None)
+    return q, (blocks, mspbwt_index, rare_common)
 
 
 def wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off) -> List[SampleResult]:
@@ -69,18 +90,25 @@ def wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off) -> List
 
 
 def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverParams] = None, sample_offset: int = 0,
-                   samples_per_launch_set: int = 256, fuse_tails: bool = True, return_stats: bool = False):
+                   samples_per_launch_set: int = 256, fuse_tails: bool = True, return_stats: bool = False, drcs: Sequence = ()):
     """``devs``: one :class:`quilt_amd.native.DevicePanel` per host thread (replicas of one panel on one device; with more
-    than one, switch ``set_exclusive`` on).  Returns one SampleResult per sample (and the native counters)."""
+    than one, switch ``set_exclusive`` on).  ``drcs`` (with ``params.impute_rare_common``): one
+    :class:`quilt_amd.native.DeviceRareCommon` per entry of ``devs``; every sample then carries its all-SNP reads as
+    ``sample.all_snp`` and the results cover all SNPs.  Returns one SampleResult per sample (and the native counters)."""
     panel = devs[0].panel
     P = (params or DriverParams())
     idx = None
     if P.use_mspbwt:
         from .mspbwt import panel_mspbwt_index
         idx = panel_mspbwt_index(panel, P.mspbwt_nindices)
-    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails)
+    rcq = keep_rc = None
+    if P.impute_rare_common:
+        if len(drcs) != len(devs):
+            raise ValueError("impute_rare_common: one DeviceRareCommon per DevicePanel")
+        rcq, keep_rc = make_rare_common(drcs[0].rc, [d.handle for d in drcs], samples)
+    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)
-    n, T = len(samples), panel.nSNPs
+    n, T = len(samples), (drcs[0].rc.nSNPs_all if P.impute_rare_common else panel.nSNPs)
     dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 2, T))
     labels = np.zeros(int(read_off[-1]), dtype=np.int32)
     nDosage = np.zeros(n, dtype=np.int32)
@@ -91,6 +119,6 @@ def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverPar
     check(L.qa_impute_samples(handles, C.c_int32(len(devs)), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off),
                               ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels),
                               ptr(nDosage), ptr(stats)))
-    del keep
+    del keep, keep_rc
     out = wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off)
     return (out, dict(zip(STAT_NAMES, stats.tolist()))) if return_stats else out

@@ -231,10 +231,12 @@ class NativeWorkers:
     (the batches' samples must be consecutive: they are one sample range).  ``n_workers`` panel handles = host threads."""
 
     def __init__(self, panel, params: Optional[DriverParams] = None, n_workers: int = 3, fp64_dosage: bool = False,
-                 exclusive: bool = True, fuse_tails: bool = True):
+                 exclusive: bool = True, fuse_tails: bool = True, rare_common=None):
         self.n = n_workers
         self.panel = panel
         self.params = (params or DriverParams()).resolved(panel.K)
+        if self.params.impute_rare_common and rare_common is None:
+            raise ValueError("impute_rare_common needs the panel's rare/common tables")
         self.fuse_tails = fuse_tails
         self.devs = [DevicePanel(panel) for _ in range(n_workers)]
         for d in self.devs:
@@ -243,8 +245,9 @@ class NativeWorkers:
                 d.set_exclusive(True)
             if fp64_dosage:
                 d.set_dosage_precision(64)
+        self.drcs = [DeviceRareCommon(d, rare_common) for d in self.devs] if rare_common is not None else []
         # (bench.py's stand-alone kernel timings drive single rounds through the Python statement of the loop)
-        self.drivers = [Driver(panel, HipBackend(self.devs[0]), params)]
+        self.drivers = [Driver(panel, HipBackend(self.devs[0], self.drcs[0] if self.drcs else None), params, rare_common=rare_common)]
         self.stats = {}
         self.reset_timing()
 
@@ -257,6 +260,8 @@ class NativeWorkers:
     def close(self):
         from .native import lib
         lib().qa_impute_release_buffers()
+        for r in self.drcs:
+            r.close()
         for d in self.devs:
             d.close()
 
@@ -272,7 +277,8 @@ class NativeWorkers:
             flat.extend(samples)
             at += len(samples)
         res, st = impute_samples(self.devs, flat, self.params, sample_offset=batches[0][1],
-                                 samples_per_launch_set=len(batches[0][0]), fuse_tails=self.fuse_tails, return_stats=True)
+                                 samples_per_launch_set=len(batches[0][0]), fuse_tails=self.fuse_tails, return_stats=True,
+                                 drcs=self.drcs)
         self.stats = st
         for k in ("gibbs", "fullpass", "host", "consensus", "finish", "accumulate"):
             self.timing[k] += st["ms_" + k] / 1e3

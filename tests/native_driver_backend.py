@@ -9,7 +9,7 @@ import numpy as np
 
 from quilt_amd.driver import (ListsTruncated, everything_select_good_haps_dense, previously_selected)
 from quilt_amd.gibbs_nipt import GibbsOpts
-from quilt_amd.impute import ImputeParams, STAT_NAMES, flatten_samples, make_params, wrap_results
+from quilt_amd.impute import ImputeParams, STAT_NAMES, flatten_samples, make_params, make_rare_common, wrap_results
 from quilt_amd.native import lib, ptr
 from tests.oracle_backend import OracleBackend
 
@@ -22,6 +22,8 @@ SELECT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, I3
 FULLPASS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, F64P, I32P, I32P, C.c_int32, F64P, I32P, I32P, F64P, C.c_int64)
 EMAT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, F64P, I32P, I32P, I32P, I32P, C.c_double, C.c_int32,
                       C.c_int32, F64P)
+GIBBS_RC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(GibbsOpts), C.c_int32, I32P, I32P, I32P, I32P, I32P, I32P, F64P, I32P,
+                          F64P, I32P, I32P, F64P, F64P, F64P, I32P, F64P, U64P, U64P)
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t)
 FREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
@@ -29,7 +31,8 @@ FREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 class Backend(C.Structure):
     _fields_ = [("gibbs_batch", GIBBS_FN), ("fullpass_reads_select_batch", SELECT_FN), ("fullpass_batch", FULLPASS_FN),
                 ("make_eMatRead_t_hap_major", EMAT_FN), ("mspbwt_select_new_haps", C.c_void_p), ("accumulate_dosage", C.c_void_p),
-                ("consensus_read_labels", C.c_void_p), ("host_alloc", ALLOC_FN), ("host_free", FREE_FN), ("bind_thread", C.c_void_p)]
+                ("consensus_read_labels", C.c_void_p), ("host_alloc", ALLOC_FN), ("host_free", FREE_FN), ("bind_thread", C.c_void_p),
+                ("gibbs_batch_rare_common", GIBBS_RC_FN), ("make_eMatRead_t_nsnps", EMAT_FN)]
 
 
 def _arr(p, n, dtype):
@@ -45,9 +48,10 @@ class _Reads:   # the SampleReads surface the oracle needs
 class OracleTable:
     """Owns the callbacks (ctypes keeps no reference to them) and the oracle they call."""
 
-    def __init__(self, panel, fail_at_call=None):
+    def __init__(self, panel, fail_at_call=None, rare_common=None):
         self.panel = panel
-        self.ob = OracleBackend(panel)
+        self.rare_common = rare_common
+        self.ob = OracleBackend(panel, rare_common)
         self.calls = {"gibbs": 0, "select": 0, "fullpass": 0, "emat": 0}
         self.fail_at_call = fail_at_call   # ("gibbs", n): the n-th call of that entry reports a hard error (error-path tests)
         self.error = None
@@ -57,12 +61,15 @@ class OracleTable:
         libc.malloc.argtypes = [C.c_size_t]
         libc.free.argtypes = [C.c_void_p]
         self._malloc, self._free = libc.malloc, libc.free
+        self.calls.update(gibbs_rc=0, emat_all=0)
         self._cbs = (GIBBS_FN(self._guard(self.gibbs, "gibbs")), SELECT_FN(self._guard(self.select, "select")),
                      FULLPASS_FN(self._guard(self.fullpass, "fullpass")), EMAT_FN(self._guard(self.emat, "emat")),
-                     ALLOC_FN(lambda n: self._malloc(max(int(n), 1))), FREE_FN(lambda p: (self._free(p), 0)[1]))
+                     ALLOC_FN(lambda n: self._malloc(max(int(n), 1))), FREE_FN(lambda p: (self._free(p), 0)[1]),
+                     GIBBS_RC_FN(self._guard(self.gibbs_rc, "gibbs_rc")), EMAT_FN(self._guard(self.emat_all, "emat_all")))
         addr = lambda f: C.cast(f, C.c_void_p)
         self.table = Backend(self._cbs[0], self._cbs[1], self._cbs[2], self._cbs[3], addr(L.qa_mspbwt_select_new_haps),
-                             addr(L.qa_accumulate_dosage), addr(L.qa_consensus_read_labels), self._cbs[4], self._cbs[5], None)
+                             addr(L.qa_accumulate_dosage), addr(L.qa_consensus_read_labels), self._cbs[4], self._cbs[5], None,
+                             self._cbs[6], self._cbs[7])
 
     def _guard(self, f, name):
         def g(*a):
@@ -76,8 +83,33 @@ class OracleTable:
                 return -2
         return g
 
+    # ---- qa_gibbs_batch_rare_common: the same unflattening, the oracle's all-SNP call
+    def gibbs_rc(self, handle, rc, o, n, which, read_off, read_ptr, u, bq, wif, ru, fr, rs, H, Hc, hp, gm, gf, uf, state, sr, ss):
+        return self.gibbs(handle, o, n, which, read_off, read_ptr, u, bq, wif, ru, fr, rs, H, Hc, hp, gm, gf, uf, state, sr, ss, rare=True)
+
+    def emat_all(self, handle, nSNPs, n_chain, K, eHaps, read_off, read_ptr, u, bq, maxdiff, Jmax, rescale, out):
+        """qa_rcpp_make_eMatRead_t_nsnps: eHaps [chain][SNP][K] (R's K x nSNPs matrices, column-major)."""
+        ro = _arr(read_off, n_chain + 1, np.int32)
+        rp = _arr(read_ptr, int(ro[n_chain]) + n_chain, np.int32)
+        e = np.ctypeslib.as_array(eHaps, shape=(n_chain, nSNPs, K))
+        o = np.ctypeslib.as_array(out, shape=(int(ro[n_chain]), K))
+        base = 0
+        samples = []
+        for c in range(n_chain):
+            R = int(ro[c + 1] - ro[c])
+            p = rp[ro[c] + c: ro[c] + c + R + 1]
+            nb = int(p[-1])
+            samples.append(_Reads(p.copy(), _arr(C.cast(C.addressof(u.contents) + 4 * base, I32P), nb, np.int32).copy(),
+                                  _arr(C.cast(C.addressof(bq.contents) + 4 * base, I32P), nb, np.int32).copy()))
+            base += nb
+        assert rescale == 1 and Jmax == 100
+        lik = self.ob.read_likelihood_all_snps_batch(samples, e, maxdiff)
+        for c, m in enumerate(lik):
+            o[ro[c]:ro[c + 1]] = np.asarray(m).T
+        return 0
+
     # ---- qa_gibbs_batch on the oracle
-    def gibbs(self, handle, o, n, which, read_off, read_ptr, u, bq, wif, ru, fr, rs, H, Hc, hp, gm, gf, uf, state, sr, ss):
+    def gibbs(self, handle, o, n, which, read_off, read_ptr, u, bq, wif, ru, fr, rs, H, Hc, hp, gm, gf, uf, state, sr, ss, rare=False):
         o = o.contents
         ro = _arr(read_off, n + 1, np.int32)
         totR = int(ro[n])
@@ -101,8 +133,10 @@ class OracleTable:
                                   [int(fr[c]) for c in range(n)], [int(ss[c]) for c in range(n)],
                                   n_gibbs_burn_in_its=o.n_gibbs_burn_in_its, n_gibbs_sample_its=o.n_gibbs_sample_its,
                                   block_gibbs_iterations=blocks, gibbs_initialize_iteratively=bool(o.gibbs_initialize_iteratively),
-                                  maxDifferenceBetweenReads=o.maxDifferenceBetweenReads, Jmax_local=o.Jmax)
-        G, T = self.panel.nGrids, self.panel.nSNPs
+                                  maxDifferenceBetweenReads=o.maxDifferenceBetweenReads, Jmax_local=o.Jmax, rare_common=rare)
+        G, T = self.panel.nGrids, (self.rare_common.nSNPs_all if rare else self.panel.nSNPs)
+        if rare:
+            assert o.disable_read_category_usage == 1 and not o.gibbs_initialize_iteratively
         any_uf = False
         for c, r in enumerate(res):
             uf[c] = int(bool(r["underflow_problem"]))
@@ -217,17 +251,20 @@ class OracleTable:
 
 
 def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_per_launch_set=256, n_threads=1, fuse_tails=True,
-                             fail_at_call=None):
+                             fail_at_call=None, rare_common=None):
     """qa_impute_samples_backend over the oracle table: (results, native counters, the table)."""
     P = params
     idx = None
     if P.use_mspbwt:
         from quilt_amd.mspbwt import panel_mspbwt_index
         idx = panel_mspbwt_index(panel, P.mspbwt_nindices)
-    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails)
-    tab = OracleTable(panel, fail_at_call=fail_at_call)
+    rcq = keep_rc = None
+    if P.impute_rare_common:   # (the checker needs no native all-SNP handle: any non-null value per thread)
+        rcq, keep_rc = make_rare_common(rare_common, [C.c_void_p(100 + w) for w in range(n_threads)], samples)
+    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq)
+    tab = OracleTable(panel, fail_at_call=fail_at_call, rare_common=rare_common)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)
-    n, T = len(samples), panel.nSNPs
+    n, T = len(samples), (rare_common.nSNPs_all if P.impute_rare_common else panel.nSNPs)
     dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 2, T))
     labels = np.zeros(int(read_off[-1]), dtype=np.int32)
     nDosage = np.zeros(n, dtype=np.int32)
@@ -237,9 +274,9 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
     L.qa_impute_samples_backend.restype = C.c_int
     L.qa_last_error.restype = C.c_char_p
     st = L.qa_impute_samples_backend(C.byref(tab.table), handles, C.c_int32(n_threads), C.c_int32(panel.K), C.c_int32(panel.nGrids),
-                                     C.c_int32(T), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off), ptr(read_ptr),
+                                     C.c_int32(panel.nSNPs), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off), ptr(read_ptr),
                                      ptr(u), ptr(bq), ptr(wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels), ptr(nDosage), ptr(stats))
-    del keep
+    del keep, keep_rc
     if tab.error is not None:
         raise tab.error
     if st != 0:

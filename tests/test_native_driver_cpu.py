@@ -118,3 +118,25 @@ def test_native_loop_reports_failures(twin_panel):
         z = np.zeros(0, dtype=np.int32)
         empty = _Reads(np.zeros(1, dtype=np.int32), z, z, z)
         impute_samples_on_oracle(panel, [samples[0], empty], P)
+
+
+@pytest.mark.parametrize("mspbwt,n_threads", [(False, 1), (True, 2)])
+def test_native_loop_rare_common(mspbwt, n_threads):
+    """impute_rare_common (functions.R:1042-1123, rare_common.R:61-420) in the native loop: every Gibbs sample and the phasing
+    iteration end with the all-SNP Gibbs call, started from labels drawn against the latest haploid dosages spread over all SNPs;
+    accumulators, phased haplotypes and nDosage cover all SNPs -- equal to quilt_amd/driver.py on the oracle."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_rare_common, make_synthetic_panel, make_synthetic_sample_rare_common
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = make_synthetic_panel(K=300, nSNPs=640, seed=5)
+    rc = make_rare_common(panel, 3)
+    samples = [make_synthetic_sample_rare_common(panel, rc, 50 + i, n_reads=150)[0] for i in range(4)]
+    P = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, impute_rare_common=True, small_ref_panel_gibbs_iterations=5,
+                     small_ref_panel_block_gibbs_iterations=(2,), use_mspbwt=mspbwt, mspbwt_nindices=2)
+    want = Driver(panel, OracleBackend(panel, rc), P, rare_common=rc).run(samples, sample_offset=3)
+    got, stats, tab = impute_samples_on_oracle(panel, samples, P, sample_offset=3, samples_per_launch_set=2, n_threads=n_threads,
+                                               rare_common=rc)
+    assert tab.calls["gibbs_rc"] > 0 and tab.calls["emat_all"] == tab.calls["gibbs_rc"]
+    for a, b in zip(got, want):
+        assert a.dosage.shape == (rc.nSNPs_all,) and a.nDosage == b.nDosage == P.nGibbsSamples
+        _same(a, b)

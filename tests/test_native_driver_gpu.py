@@ -84,3 +84,34 @@ def test_native_driver_refuses_bad_input(medium_panel):
         impute_samples([dev], [make_synthetic_sample(medium_panel, seed=1, n_reads=50), _Reads(np.zeros(1, dtype=np.int32), z, z, z)],
                        DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64))
     dev.close()
+
+
+def test_native_driver_rare_common_on_the_device(medium_panel):
+    """impute_rare_common through qa_impute_samples on the device == quilt_amd/driver.py on the device, bit for bit (all-SNP
+    dosages, phased haplotypes, labels), with two host threads."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    panel = medium_panel
+    rc = make_rare_common(panel, 4)
+    samples = [make_synthetic_sample_rare_common(panel, rc, 2600 + i, n_reads=500)[0] for i in range(5)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=8, impute_rare_common=True)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    drc = DeviceRareCommon(dev, rc)
+    want = Driver(panel, HipBackend(dev, drc), prm, rare_common=rc).run(samples, sample_offset=7)
+    devs = [DevicePanel(panel) for _ in range(2)]
+    for d in devs:
+        d.set_device_share(2)
+        d.set_dosage_precision(64)
+        d.set_exclusive(True)
+    drcs = [DeviceRareCommon(d, rc) for d in devs]
+    got = impute_samples(devs, samples, prm, sample_offset=7, samples_per_launch_set=2, drcs=drcs)
+    for x in drcs + [drc]:
+        x.close()
+    for d in devs + [dev]:
+        d.close()
+    for a, b in zip(got, want):
+        assert a.dosage.shape == (rc.nSNPs_all,)
+        _same(a, b)
