@@ -569,6 +569,22 @@ typedef struct {
 } qa_impute_rare_common_t;
 
 /*
+ * method = "nipt" (mother + fetus, three read labels; functions.R:586, :1009-1016, :1218-1231, :1788-1829, :3214-3287): what the
+ * loop needs beyond the diploid case.  dosage / gp_t of qa_impute_samples are then the MOTHER's, phasing_haps has THREE rows per
+ * sample (n_sample x 3 x nSNPs: maternal transmitted, maternal untransmitted, paternal transmitted, after recast_nipt_haps).
+ *   ff                   n_sample fetal fractions in (0, 1) (ff_values[iSample], functions.R:128)
+ *   L_grid               nGrids grid positions (bp), shuffle_bin_radius (quilt.R:134: 5000): the block definition of the block Gibbs
+ *   fet_dosage, fet_gp_t OUT, n_sample x nSNPs and n_sample x 3 x nSNPs: the fetus' (maternal transmitted + paternal transmitted)
+ * Not combined with impute_rare_common here (quilt_amd/driver.py runs that combination).
+ */
+typedef struct {
+    const double *ff;
+    const int32_t *L_grid;
+    int32_t shuffle_bin_radius;
+    double *fet_dosage, *fet_gp_t;
+} qa_impute_nipt_t;
+
+/*
  * Arguments of QUILT() the hot path sees (QUILT/R/quilt.R:97-186), as get_and_impute_one_sample receives them.
  * qa_impute_params_default fills in the reference's defaults.
  */
@@ -595,6 +611,7 @@ typedef struct {
     int32_t no_fused_tails;                     /* 1: the threads' last launch sets run their phasing rounds one after the other */
     const qa_impute_rare_common_t *rare_common; /* NULL, or impute_rare_common = TRUE: dosage / gp_t / phasing_haps then cover
                                                    nSNPs_all SNPs and nDosage counts the all-SNP rounds (functions.R:1305-1317) */
+    const qa_impute_nipt_t *nipt;               /* NULL (method = "diploid"), or method = "nipt" */
 } qa_impute_params_t;
 int qa_impute_params_default(qa_impute_params_t *params);
 
@@ -627,8 +644,8 @@ int qa_impute_params_default(qa_impute_params_t *params);
  *                     [2] selections made on the device, [3] chains handed to qa_gibbs_batch, [4] Gibbs launch sets,
  *                     [5..10] ms summed over the host threads: Gibbs calls, full-panel calls, host, consensus, finish, accumulation
  * Random draws: R's stream cannot be reproduced without R; every draw the R code makes is defined on a counter stream
- * (quilt_amd/rng.py::ChainStream = csrc/impute.cpp).  method = "nipt" is not behind this entry point yet (quilt_amd/driver.py
- * runs it over the same batched calls).
+ * (quilt_amd/rng.py::ChainStream = csrc/impute.cpp).  method = "nipt" together with impute_rare_common is not behind this entry
+ * point (QA_ERR_UNSUPPORTED; quilt_amd/driver.py runs that combination over the same batched calls).
  */
 int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impute_params_t *params, int32_t n_sample,
                       int64_t sample_offset, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,

@@ -81,6 +81,16 @@ struct ChainStream {
     double uniform() { return (double)(u64() >> 11) * (1.0 / 9007199254740992.0); }
     // lo + floor(uniform * span); span as a double (2^63 for the seeds: the product stays below 2^63)
     int64_t integers(int64_t lo, double span) { return lo + (int64_t)std::floor(uniform() * span); }
+    // choice(3, p): the number of cumulative masses (normalised by the last) <= uniform, at most 2 (numpy's searchsorted(cdf, u, "right"))
+    int choice3(const double (&p)[3]) {
+        double cdf[3] = {p[0], p[0] + p[1], (p[0] + p[1]) + p[2]};
+        const double last = cdf[2];
+        for (double &c : cdf) c /= last;
+        const double u = uniform();
+        int k = 0;
+        while (k < 3 && cdf[k] <= u) k++;
+        return k < 2 ? k : 2;
+    }
     // choice(n, m, replace = False): the m smallest of the next n keys
     std::vector<int32_t> choice_without_replacement(int64_t n, int64_t m) {
         std::vector<int32_t> out = keyed_subset(key, n, m, ctr);
@@ -172,6 +182,8 @@ struct Ctx {
     int64_t sample_offset = 0;
     std::vector<Reads> reads;
     // impute_rare_common: the all-SNP reads, the all-SNP dimensions (T_out = T_all then) and where the common SNPs sit
+    const qa_impute_nipt_t *nipt = nullptr;   // method = "nipt": three labels, a fetal fraction per sample
+    int nL = 2;
     const qa_impute_rare_common_t *rc = nullptr;
     std::vector<Reads> reads_all;
     std::vector<int32_t> common_at;   // all-SNP index of common SNP j
@@ -312,6 +324,33 @@ void recast_haps(double *hd1, double *hd2, const double *g0, const double *g1, c
     }
 }
 
+// recast_nipt_haps (functions.R:3214-3287): the phased haplotypes of mother and fetus made to agree with the argmax genotypes;
+// mg / fg = mother's and fetus' gp_t (3 x T rows).  In place on hap1 (maternal transmitted), hap2 (maternal untransmitted), hap3
+// (paternal transmitted); every output is rounded.
+void recast_nipt_haps(double *hap1, double *hap2, double *hap3, const double *mg, const double *fg, int T) {
+    for (int t = 0; t < T; t++) {
+        int gm = 0, gf = 0;
+        double mxA = mg[t], mxB = fg[t];
+        for (int i = 1; i <= 2; i++) {
+            if (mg[(size_t)i * T + t] > mxA) { gm = i; mxA = mg[(size_t)i * T + t]; }
+            if (fg[(size_t)i * T + t] > mxB) { gf = i; mxB = fg[(size_t)i * T + t]; }
+        }
+        double a = hap1[t], b = hap2[t], c = hap3[t];
+        static const int conv[8][5] = {{0, 0, 0, 0, 0}, {0, 1, 0, 0, 1}, {0, 2, 0, 0, 1}, {1, 0, 0, 1, 0}, {1, 2, 1, 0, 1}, {2, 0, 1, 1, 0},
+                                       {2, 1, 1, 1, 0}, {2, 2, 1, 1, 1}};
+        bool done = false;
+        for (const auto &r : conv)
+            if (gm == r[0] && gf == r[1]) { a = r[2]; b = r[3]; c = r[4]; done = true; }
+        if (!done) {   // mother het, fetus het: keep the call if it is one of the two consistent ones, else round (functions.R:3262-3283)
+            const double r1 = std::nearbyint(a), r2 = std::nearbyint(b), r3 = std::nearbyint(c);
+            if (r1 == 1 && r2 == 0 && r3 == 0) { a = 1; b = 0; c = 0; }
+            else if (r1 == 0 && r2 == 1 && r3 == 1) { a = 0; b = 1; c = 1; }
+            else { a = r1; b = r2; c = 1 - a; }
+        }
+        hap1[t] = std::nearbyint(a); hap2[t] = std::nearbyint(b); hap3[t] = std::nearbyint(c);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // one host thread: its handle, its buffers, its stream of launch sets
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -378,6 +417,7 @@ struct Worker {
         const int C = (int)ch.size();
         const int G = cx.G, T = rare ? cx.T_out : cx.T;
         const std::vector<Reads> &RD = rare ? cx.reads_all : cx.reads;
+        const int nLh = rare ? 2 : cx.nL;   // labels of the call's haploid dosages
         std::vector<int> pending((size_t)C);
         for (int i = 0; i < C; i++) pending[(size_t)i] = i;
         std::vector<double> maxdiff((size_t)C, P.maxDifferenceBetweenReads);
@@ -431,8 +471,14 @@ struct Worker {
                 }
                 qa_gibbs_opts_t o{};
                 o.Ks = P.Ksubset;
-                o.ff = 0.0;
-                o.sample_is_diploid = 1;
+                std::vector<double> ffc;
+                if (cx.nipt) {   // every chain carries its sample's fetal fraction (functions.R:128)
+                    ffc.resize((size_t)n);
+                    for (int a = 0; a < n; a++) ffc[(size_t)a] = cx.nipt->ff[ch[(size_t)idx[(size_t)a]]->sample];
+                }
+                o.ff = cx.nipt ? ffc[0] : 0.0;
+                o.ff_chain = cx.nipt ? ffc.data() : nullptr;
+                o.sample_is_diploid = cx.nipt ? 0 : 1;
                 o.Jmax = P.Jmax;
                 o.maxDifferenceBetweenReads = grp.first;
                 o.rescale_eMatRead_t = 1;
@@ -441,12 +487,12 @@ struct Worker {
                 o.block_gibbs_iterations = cx.blocks.data();
                 o.n_block_gibbs_iterations = (int32_t)cx.blocks.size();
                 o.perform_block_gibbs = 1;
-                o.do_shard_block_gibbs = 1;
+                o.do_shard_block_gibbs = cx.nipt ? 0 : 1;   // (functions.R:2552-2556: no shard pass for ff > 0)
                 o.gibbs_initialize_iteratively = any_first ? 1 : 0;
                 o.disable_read_category_usage = rare ? 1 : 0;
                 o.class_sum_cutoff = 0.06;
-                o.L_grid = nullptr;
-                o.shuffle_bin_radius = 5000;
+                o.L_grid = cx.nipt ? cx.nipt->L_grid : nullptr;
+                o.shuffle_bin_radius = cx.nipt ? cx.nipt->shuffle_bin_radius : 5000;
                 o.block_gibbs_quantile_prob = 0.95;
                 std::vector<int32_t> words_tmp;
                 std::vector<double> hap_tmp;
@@ -456,8 +502,8 @@ struct Worker {
                 }
                 if (hap_out) {
                     if (whole) o.hap_major_out = hap_out;
-                    else { hap_tmp.resize((size_t)n * 2 * T); o.hap_major_out = hap_tmp.data(); }
-                    o.hap_major_labels = 2;
+                    else { hap_tmp.resize((size_t)n * nLh * T); o.hap_major_out = hap_tmp.data(); }
+                    o.hap_major_labels = nLh;
                 }
                 if (on_first_launch) { auto cb = on_first_launch; on_first_launch = nullptr; cb(); }
                 cx.n_gibbs_chain_calls += n;
@@ -485,7 +531,7 @@ struct Worker {
                     if (!rare) c.labels.assign(g_H.begin() + g_read_off[(size_t)a], g_H.begin() + g_read_off[(size_t)a] + R);
                     if (!whole) {
                         if (want_words) std::memcpy(&g_words[(size_t)i * 3 * G], &words_tmp[(size_t)a * 3 * G], sizeof(int32_t) * 3 * (size_t)G);
-                        if (hap_out) std::memcpy(hap_out + (size_t)i * 2 * T, &hap_tmp[(size_t)a * 2 * T], sizeof(double) * 2 * (size_t)T);
+                        if (hap_out) std::memcpy(hap_out + (size_t)i * nLh * T, &hap_tmp[(size_t)a * nLh * T], sizeof(double) * nLh * (size_t)T);
                     }
                 }
             }
@@ -504,7 +550,7 @@ struct Worker {
     // full-panel pass returning whole lists, ordered per thinned grid as everything_per_hap_rejig_haps does (functions.R:2161-2170)
     std::vector<int64_t> full_lists(const Chain &c, int &width_out) {
         const auto &P = cx.P;
-        const int T = cx.T, nL = 2, n_thin = cx.n_thin;
+        const int T = cx.T, nL = cx.nL, n_thin = cx.n_thin;
         const Reads &r = cx.reads[(size_t)c.sample];
         std::vector<double> gl((size_t)nL * 2 * T, 1.0);   // per label a 2 x T column-major matrix
         for (int l = 1; l <= nL; l++) {
@@ -559,7 +605,7 @@ struct Worker {
     // The first n_cur chains are the current launch set's main chains (their dosages are accumulated); the rest are phasing chains.
     bool round(std::vector<Chain *> &ch, int i_it, Batch *cur) {
         const auto &P = cx.P;
-        const int C = (int)ch.size(), K = cx.K, T = cx.T, G = cx.G;
+        const int C = (int)ch.size(), K = cx.K, T = cx.T, G = cx.G, nL = cx.nL;
         const double t0 = now_s();
         bool any_first = false;
         std::vector<std::vector<int32_t>> starts((size_t)C);
@@ -577,7 +623,13 @@ struct Worker {
                 std::sort(c.which.begin(), c.which.end());
                 for (auto &v : c.which) v += 1;
                 starts[(size_t)i].resize((size_t)R);
-                for (int r = 0; r < R; r++) starts[(size_t)i][(size_t)r] = (int32_t)c.rng.integers(1, 2.0);
+                if (cx.nipt) {   // functions.R:586: sample(1:3, nReads, prob = c(0.5, 0.5 - ff / 2, ff / 2))
+                    const double ff = cx.nipt->ff[c.sample];
+                    const double pr[3] = {0.5, 0.5 - ff / 2, ff / 2};
+                    for (int r = 0; r < R; r++) starts[(size_t)i][(size_t)r] = 1 + c.rng.choice3(pr);
+                } else {
+                    for (int r = 0; r < R; r++) starts[(size_t)i][(size_t)r] = (int32_t)c.rng.integers(1, 2.0);
+                }
             } else {
                 starts[(size_t)i] = c.labels;
             }
@@ -591,7 +643,7 @@ struct Worker {
         t_host += t1 - t0;
         const bool return_dosage = i_it > cx.n_burn;
         double *hap = nullptr;
-        if (return_dosage) hap = dos.get((size_t)C * 2 * T);
+        if (return_dosage) hap = dos.get((size_t)C * nL * T);
         if (P.use_mspbwt) {
             gibbs_with_retry(ch, starts, any_first, true, return_dosage ? hap : nullptr);
             const double t2 = now_s();
@@ -602,12 +654,12 @@ struct Worker {
                 if (i_it < P.n_seek_its || cx.rc || (!ch[(size_t)i]->phasing && ch[(size_t)i]->i_chain == P.nGibbsSamples)) idx.push_back(i);
             if (!idx.empty()) {
                 std::vector<uint64_t> seeds(idx.size());
-                std::vector<int32_t> Zs(idx.size() * 2 * (size_t)G), out(idx.size() * (size_t)P.Knew);
+                std::vector<int32_t> Zs(idx.size() * nL * (size_t)G), out(idx.size() * (size_t)P.Knew);
                 for (size_t a = 0; a < idx.size(); a++) {
                     seeds[a] = (uint64_t)ch[(size_t)idx[a]]->rng.integers(0, 9223372036854775808.0);
-                    std::memcpy(&Zs[a * 2 * G], &g_words[(size_t)idx[a] * 3 * G], sizeof(int32_t) * 2 * (size_t)G);
+                    std::memcpy(&Zs[a * nL * G], &g_words[(size_t)idx[a] * 3 * G], sizeof(int32_t) * nL * (size_t)G);
                 }
-                check(cx.be->mspbwt_select_new_haps(P.mspbwt_index, (int32_t)idx.size(), 2, Zs.data(), P.mspbwtL, P.mspbwtM, P.Knew,
+                check(cx.be->mspbwt_select_new_haps(P.mspbwt_index, (int32_t)idx.size(), nL, Zs.data(), P.mspbwtL, P.mspbwtM, P.Knew,
                                                     seeds.data(), out.data()), "qa_mspbwt_select_new_haps");
                 for (size_t a = 0; a < idx.size(); a++)
                     ch[(size_t)idx[a]]->which.assign(out.begin() + a * P.Knew, out.begin() + (a + 1) * P.Knew);
@@ -664,12 +716,12 @@ struct Worker {
             for (int i = 0; i < C; i++) seed_sel[(size_t)i] = (uint64_t)ch[(size_t)i]->rng.integers(0, 9223372036854775808.0);
             g_which.resize((size_t)C * P.Ksubset);
             for (int i = 0; i < C; i++) std::memcpy(&g_which[(size_t)i * P.Ksubset], ch[(size_t)i]->which.data(), sizeof(int32_t) * (size_t)P.Ksubset);
-            f_cnt.assign((size_t)C * 2 * cx.n_thin, 0);
+            f_cnt.assign((size_t)C * nL * cx.n_thin, 0);
             f_next.assign((size_t)C * P.Ksubset, 0);
             f_status.assign((size_t)C, -1);
             const double t3 = now_s();
             t_host += t3 - t2;
-            check(cx.be->fullpass_reads_select_batch(handle, C, 2, nS, f_cs.data(), f_read_off.data(), f_read_ptr.data(), f_u.data(),
+            check(cx.be->fullpass_reads_select_batch(handle, C, nL, nS, f_cs.data(), f_read_off.data(), f_read_ptr.data(), f_u.data(),
                                                      f_bq.data(), f_H.data(), f_wd.data(), f_wt.data(), cx.cols.data(), P.K_top_matches,
                                                      P.minGLValue, hap, cx.top_width, nullptr, nullptr, f_cnt.data(), P.Ksubset, P.Knew,
                                                      g_which.data(), seed_sel.data(), f_next.data(), f_status.data()),
@@ -679,8 +731,8 @@ struct Worker {
             if (return_dosage) {   // functions.R:2072-2075
                 std::atomic<bool> bad{false};
                 parallel_for((size_t)C, n_help, [&](size_t i) {
-                    const double *d = hap + i * 2 * T;
-                    for (size_t t = 0; t < (size_t)2 * T; t++)
+                    const double *d = hap + i * nL * T;
+                    for (size_t t = 0; t < (size_t)nL * T; t++)
                         if (!(d[t] >= -1e-5 && d[t] <= 1 + 1e-5)) { bad = true; break; }
                 });
                 if (bad) throw Failure(QA_ERR_INVALID, "Dosage observed outside of range of 0 to 1 on forward-backward full iteration");
@@ -701,7 +753,7 @@ struct Worker {
                 cx.n_full_list_refetches += 1;
                 int width = 1;
                 std::vector<int64_t> top = full_lists(c, width);
-                std::vector<int32_t> sel = select_good_haps_dense(P.Knew, P.K_top_matches, top, 2, cx.n_thin, width, prev, K, seed_sel[(size_t)i]);
+                std::vector<int32_t> sel = select_good_haps_dense(P.Knew, P.K_top_matches, top, nL, cx.n_thin, width, prev, K, seed_sel[(size_t)i]);
                 c.which = prev;
                 c.which.insert(c.which.end(), sel.begin(), sel.end());
             }
@@ -711,14 +763,16 @@ struct Worker {
         if (return_dosage && !cx.rc)
             for (int i = 0; i < C; i++)
                 if (ch[(size_t)i]->phasing)
-                    std::memcpy(cx.phasing_haps + (size_t)ch[(size_t)i]->sample * 2 * T, hap + (size_t)i * 2 * T, sizeof(double) * 2 * (size_t)T);
+                    std::memcpy(cx.phasing_haps + (size_t)ch[(size_t)i]->sample * nL * T, hap + (size_t)i * nL * T, sizeof(double) * nL * (size_t)T);
         if (return_dosage && cur && !cur->chains.empty() && !cx.rc) {   // functions.R:999-1006 (rare + common: the all-SNP round counts)
             const double ta = now_s();
             const int n_cur = (int)cur->chains.size();
             std::vector<int32_t> cs((size_t)n_cur);
             for (int i = 0; i < n_cur; i++) cs[(size_t)i] = cur->chains[(size_t)i].sample - cur->lo;
-            check(cx.be->accumulate_dosage(n_cur, 2, T, hap, cs.data(), cur->hi - cur->lo, cx.dosage + (size_t)cur->lo * T,
-                                           cx.gp_t + (size_t)cur->lo * 3 * T, nullptr, nullptr), "qa_accumulate_dosage");
+            // (functions.R:1009-1016: the fetus = maternal transmitted + paternal transmitted)
+            check(cx.be->accumulate_dosage(n_cur, nL, T, hap, cs.data(), cur->hi - cur->lo, cx.dosage + (size_t)cur->lo * T,
+                                           cx.gp_t + (size_t)cur->lo * 3 * T, cx.nipt ? cx.nipt->fet_dosage + (size_t)cur->lo * T : nullptr,
+                                           cx.nipt ? cx.nipt->fet_gp_t + (size_t)cur->lo * 3 * T : nullptr), "qa_accumulate_dosage");
             for (int i = 0; i < n_cur; i++) cx.nDosage[cur->chains[(size_t)i].sample] += 1;
             t_accumulate += now_s() - ta;
         }
@@ -819,7 +873,7 @@ struct Worker {
     // round's dosages, the batch's main chains first.
     void start_phasing(Batch &b, const double *hap) {
         const auto &P = cx.P;
-        const int n = (int)b.chains.size(), T = cx.T;
+        const int n = (int)b.chains.size(), T = cx.T, nL = cx.nL;
         std::vector<int32_t> read_off((size_t)n + 1, 0);
         std::vector<int64_t> boff((size_t)n + 1, 0);
         for (int i = 0; i < n; i++) {
@@ -836,9 +890,9 @@ struct Worker {
             std::memcpy(&g_u[(size_t)boff[i]], r.u, sizeof(int32_t) * (size_t)r.nb);
             std::memcpy(&g_bq[(size_t)boff[i]], r.bq, sizeof(int32_t) * (size_t)r.nb);
         });
-        double *e = conf.get((size_t)read_off[(size_t)n] * 2);
+        double *e = conf.get((size_t)read_off[(size_t)n] * nL);
         // calculate_eMatRead_t_vs_haplotypes (functions.R:2975-3020): not rescaled, Jmax = 1000
-        check(cx.be->make_eMatRead_t_hap_major(handle, T, n, 2, hap, read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
+        check(cx.be->make_eMatRead_t_hap_major(handle, T, n, nL, hap, read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
                                                P.maxDifferenceBetweenReads, 1000, 0, e), "qa_rcpp_make_eMatRead_t_hap_major");
         b.phasing.clear();
         b.phasing.resize((size_t)(b.hi - b.lo));
@@ -847,15 +901,13 @@ struct Worker {
             const int s = b.lo + (int)si;
             const int R = cx.reads[(size_t)s].R;
             std::vector<int32_t> labels((size_t)nG * R);
-            std::vector<double> p((size_t)nG * 2 * R);
+            std::vector<double> p((size_t)nG * nL * R);
             for (int c = 0; c < nG; c++) {
                 const size_t k = si * nG + c;   // chains are sample-major
                 std::memcpy(&labels[(size_t)c * R], b.chains[k].labels.data(), sizeof(int32_t) * (size_t)R);
-                const double *ek = e + (size_t)read_off[k] * 2;   // [read][2]
-                for (int r = 0; r < R; r++) {
-                    p[((size_t)c * 2) * R + r] = ek[(size_t)r * 2];
-                    p[((size_t)c * 2 + 1) * R + r] = ek[(size_t)r * 2 + 1];
-                }
+                const double *ek = e + (size_t)read_off[k] * nL;   // [read][label]
+                for (int r = 0; r < R; r++)
+                    for (int l = 0; l < nL; l++) p[((size_t)c * nL + l) * R + r] = ek[(size_t)r * nL + l];
             }
             Chain ph;
             ph.sample = s;
@@ -864,7 +916,7 @@ struct Worker {
             ph.rng = ChainStream(P.seed, cx.sample_offset + s, nG + 1);
             ph.which = b.chains[si * nG + (nG - 1)].which;
             ph.labels.resize((size_t)R);
-            if (cx.be->consensus_read_labels(R, nG, labels.data(), p.data(), 2, 0.95, nG, ph.labels.data()) != QA_OK)
+            if (cx.be->consensus_read_labels(R, nG, labels.data(), p.data(), nL, 0.95, nG, ph.labels.data()) != QA_OK)
                 throw Failure(QA_ERR_INVALID, "qa_consensus_read_labels failed");
             std::memcpy(cx.read_labels + cx.read_off[s], ph.labels.data(), sizeof(int32_t) * (size_t)R);
             b.phasing[si] = std::move(ph);
@@ -881,6 +933,14 @@ struct Worker {
             double *d = cx.dosage + (size_t)s * T, *g = cx.gp_t + (size_t)s * 3 * T;
             for (int t = 0; t < T; t++) d[t] /= n;
             for (int t = 0; t < 3 * T; t++) g[t] /= n;
+            if (cx.nipt) {   // functions.R:1218-1231, 1313-1317
+                double *fd = cx.nipt->fet_dosage + (size_t)s * T, *fg = cx.nipt->fet_gp_t + (size_t)s * 3 * T;
+                for (int t = 0; t < T; t++) fd[t] /= n;
+                for (int t = 0; t < 3 * T; t++) fg[t] /= n;
+                double *h = cx.phasing_haps + (size_t)s * 3 * T;
+                recast_nipt_haps(h, h + T, h + 2 * (size_t)T, g, fg, T);
+                return;
+            }
             double *h = cx.phasing_haps + (size_t)s * 2 * T;
             recast_haps(h, h + T, g, g + T, g + 2 * (size_t)T, T);
         });
@@ -1040,6 +1100,22 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
         }
     }
     cx.T_out = T;
+    if (P.nipt) {
+        if (P.rare_common) {
+            qa::set_error("qa_impute_samples: method = \"nipt\" with impute_rare_common is not behind this entry point (quilt_amd/driver.py runs it)");
+            return QA_ERR_UNSUPPORTED;
+        }
+        if (!P.nipt->ff || !P.nipt->L_grid || !P.nipt->fet_dosage || !P.nipt->fet_gp_t) {
+            qa::set_error("qa_impute_samples: method = \"nipt\" needs ff, L_grid and the fetus' output arrays");
+            return QA_ERR_INVALID;
+        }
+        for (int s2 = 0; s2 < n_sample; s2++)
+            if (!(P.nipt->ff[s2] > 0.0 && P.nipt->ff[s2] < 1.0)) { qa::set_error("qa_impute_samples: fetal fraction of sample %d outside (0, 1)", s2); return QA_ERR_INVALID; }
+        cx.nipt = P.nipt;
+        cx.nL = 3;
+        std::memset(P.nipt->fet_dosage, 0, sizeof(double) * (size_t)n_sample * T);
+        std::memset(P.nipt->fet_gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * T);
+    }
     if (P.rare_common) {
         const qa_impute_rare_common_t &rc = *P.rare_common;
         if (!rc.handles || rc.nSNPs_all < T || rc.nGrids_all != (rc.nSNPs_all + 31) / 32 || !rc.snp_is_common || !rc.read_off || !rc.read_ptr ||
@@ -1075,7 +1151,7 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     const int To = cx.T_out;
     std::memset(dosage, 0, sizeof(double) * (size_t)n_sample * To);
     std::memset(gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * To);
-    std::memset(phasing_haps, 0, sizeof(double) * (size_t)n_sample * 2 * To);
+    std::memset(phasing_haps, 0, sizeof(double) * (size_t)n_sample * cx.nL * To);
     std::memset(nDosage, 0, sizeof(int32_t) * (size_t)n_sample);
     if (n_sample == 0) return QA_OK;
 

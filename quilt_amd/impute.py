@@ -28,8 +28,13 @@ class ImputeParams(C.Structure):
         ("use_mspbwt", C.c_int32), ("mspbwtL", C.c_int32), ("mspbwtM", C.c_int32),
         ("mspbwt_index", C.c_void_p),
         ("samples_per_launch_set", C.c_int32), ("no_fused_tails", C.c_int32),
-        ("rare_common", C.c_void_p),
+        ("rare_common", C.c_void_p), ("nipt", C.c_void_p),
     ]
+
+
+class ImputeNipt(C.Structure):
+    _fields_ = [("ff", C.c_void_p), ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int32), ("fet_dosage", C.c_void_p),
+                ("fet_gp_t", C.c_void_p)]
 
 
 class ImputeRareCommon(C.Structure):
@@ -64,11 +69,21 @@ def make_rare_common(rc, rc_handles, samples):
     return q, (hs, is_common, read_off, read_ptr, u, bq, wif)
 
 
-def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None, fuse_tails: bool = True, rare_common=None):
-    """(ImputeParams, keep-alive objects) from the Python driver's parameters (method = "diploid"); ``rare_common``: an
-    ImputeRareCommon (with impute_rare_common)."""
-    if P.method != "diploid":
-        raise ValueError("qa_impute_samples covers method = 'diploid'; use quilt_amd.driver.Driver")
+def make_nipt(panel, samples, shuffle_bin_radius: int):
+    """(ImputeNipt, the fetus' output arrays, keep-alive objects) for method = "nipt": the samples' fetal fractions, the
+    panel's grid positions."""
+    n, T = len(samples), panel.nSNPs
+    ff = np.ascontiguousarray([float(s.ff) for s in samples], dtype=np.float64)
+    Lg = np.ascontiguousarray(panel.L_grid, dtype=np.int32)
+    fd, fg = np.zeros((n, T)), np.zeros((n, 3, T))
+    return ImputeNipt(ptr(ff), ptr(Lg), int(shuffle_bin_radius), ptr(fd), ptr(fg)), fd, fg, (ff, Lg)
+
+
+def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None, fuse_tails: bool = True, rare_common=None, nipt=None):
+    """(ImputeParams, keep-alive objects) from the Python driver's parameters; ``rare_common``: an ImputeRareCommon (with
+    impute_rare_common); ``nipt``: an ImputeNipt (method = "nipt")."""
+    if P.method == "nipt" and (nipt is None or P.impute_rare_common):
+        raise ValueError("method = 'nipt' needs make_nipt(...) and is not combined with impute_rare_common here (quilt_amd.driver.Driver)")
     if P.impute_rare_common and rare_common is None:
         raise ValueError("impute_rare_common needs the all-SNP side (make_rare_common)")
     blocks = np.ascontiguousarray(P.small_ref_panel_block_gibbs_iterations, dtype=np.int32)
@@ -80,13 +95,15 @@ def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None,
                      P.seed, int(P.use_mspbwt), P.mspbwtL, P.mspbwtM,
                      mspbwt_index.handle if (P.use_mspbwt and mspbwt_index is not None) else None,
                      int(samples_per_launch_set), 0 if fuse_tails else 1,
-                     C.cast(C.pointer(rare_common), C.c_void_p) if (P.impute_rare_common and rare_common is not None) else None)
-    return q, (blocks, mspbwt_index, rare_common)
+                     C.cast(C.pointer(rare_common), C.c_void_p) if (P.impute_rare_common and rare_common is not None) else None,
+                     C.cast(C.pointer(nipt), C.c_void_p) if (P.method == "nipt" and nipt is not None) else None)
+    return q, (blocks, mspbwt_index, rare_common, nipt)
 
 
-def wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off) -> List[SampleResult]:
+def wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off, fet_dosage=None, fet_gp_t=None) -> List[SampleResult]:
     return [SampleResult(dosage[i], gp_t[i], np.ascontiguousarray(haps[i].T), labels[read_off[i]:read_off[i + 1]].copy(),
-                         int(nDosage[i])) for i in range(len(samples))]
+                         int(nDosage[i]), fet_dosage=None if fet_dosage is None else fet_dosage[i],
+                         fet_gp_t=None if fet_gp_t is None else fet_gp_t[i]) for i in range(len(samples))]
 
 
 def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverParams] = None, sample_offset: int = 0,
@@ -106,10 +123,13 @@ def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverPar
         if len(drcs) != len(devs):
             raise ValueError("impute_rare_common: one DeviceRareCommon per DevicePanel")
         rcq, keep_rc = make_rare_common(drcs[0].rc, [d.handle for d in drcs], samples)
-    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq)
+    nq = fd = fg = keep_n = None
+    if P.method == "nipt":
+        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius)
+    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq, nq)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)
     n, T = len(samples), (drcs[0].rc.nSNPs_all if P.impute_rare_common else panel.nSNPs)
-    dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 2, T))
+    dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 3 if P.method == "nipt" else 2, T))
     labels = np.zeros(int(read_off[-1]), dtype=np.int32)
     nDosage = np.zeros(n, dtype=np.int32)
     stats = np.zeros(11, dtype=np.int64)
@@ -119,6 +139,6 @@ def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverPar
     check(L.qa_impute_samples(handles, C.c_int32(len(devs)), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off),
                               ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels),
                               ptr(nDosage), ptr(stats)))
-    del keep, keep_rc
-    out = wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off)
+    del keep, keep_rc, keep_n
+    out = wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off, fd, fg)
     return (out, dict(zip(STAT_NAMES, stats.tolist()))) if return_stats else out

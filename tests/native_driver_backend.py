@@ -9,7 +9,7 @@ import numpy as np
 
 from quilt_amd.driver import (ListsTruncated, everything_select_good_haps_dense, previously_selected)
 from quilt_amd.gibbs_nipt import GibbsOpts
-from quilt_amd.impute import ImputeParams, STAT_NAMES, flatten_samples, make_params, make_rare_common, wrap_results
+from quilt_amd.impute import ImputeParams, STAT_NAMES, flatten_samples, make_nipt, make_params, make_rare_common, wrap_results
 from quilt_amd.native import lib, ptr
 from tests.oracle_backend import OracleBackend
 
@@ -129,8 +129,14 @@ class OracleTable:
                                   wf[ro[c]:ro[c + 1]].copy()))
             starts.append(Ha[ro[c]:ro[c + 1]].copy())
             base += nb
+        nipt = {}
+        if o.ff != 0:   # method = "nipt": one fetal fraction per chain, the block definition's radius (L_grid is the panel's)
+            ffc = np.ctypeslib.as_array(C.cast(o.ff_chain, F64P), shape=(n,)) if o.ff_chain else np.full(n, o.ff)
+            assert not o.do_shard_block_gibbs and not o.sample_is_diploid and o.L_grid
+            assert np.array_equal(np.ctypeslib.as_array(C.cast(o.L_grid, I32P), shape=(self.panel.nGrids,)), self.panel.L_grid)
+            nipt = dict(ff=[float(x) for x in ffc], shuffle_bin_radius=int(o.shuffle_bin_radius))
         res = self.ob.gibbs_batch(samples, [wh[c].copy() for c in range(n)], starts, [int(sr[c]) for c in range(n)],
-                                  [int(fr[c]) for c in range(n)], [int(ss[c]) for c in range(n)],
+                                  [int(fr[c]) for c in range(n)], [int(ss[c]) for c in range(n)], **nipt,
                                   n_gibbs_burn_in_its=o.n_gibbs_burn_in_its, n_gibbs_sample_its=o.n_gibbs_sample_its,
                                   block_gibbs_iterations=blocks, gibbs_initialize_iteratively=bool(o.gibbs_initialize_iteratively),
                                   maxDifferenceBetweenReads=o.maxDifferenceBetweenReads, Jmax_local=o.Jmax, rare_common=rare)
@@ -261,11 +267,14 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
     rcq = keep_rc = None
     if P.impute_rare_common:   # (the checker needs no native all-SNP handle: any non-null value per thread)
         rcq, keep_rc = make_rare_common(rare_common, [C.c_void_p(100 + w) for w in range(n_threads)], samples)
-    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq)
+    nq = fd = fg = keep_n = None
+    if P.method == "nipt":
+        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius)
+    q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq, nq)
     tab = OracleTable(panel, fail_at_call=fail_at_call, rare_common=rare_common)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)
     n, T = len(samples), (rare_common.nSNPs_all if P.impute_rare_common else panel.nSNPs)
-    dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 2, T))
+    dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 3 if P.method == "nipt" else 2, T))
     labels = np.zeros(int(read_off[-1]), dtype=np.int32)
     nDosage = np.zeros(n, dtype=np.int32)
     stats = np.zeros(11, dtype=np.int64)
@@ -276,9 +285,9 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
     st = L.qa_impute_samples_backend(C.byref(tab.table), handles, C.c_int32(n_threads), C.c_int32(panel.K), C.c_int32(panel.nGrids),
                                      C.c_int32(panel.nSNPs), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off), ptr(read_ptr),
                                      ptr(u), ptr(bq), ptr(wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels), ptr(nDosage), ptr(stats))
-    del keep, keep_rc
+    del keep, keep_rc, keep_n
     if tab.error is not None:
         raise tab.error
     if st != 0:
         raise RuntimeError(f"qa_impute_samples_backend: status {st}: {L.qa_last_error().decode()}")
-    return wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off), dict(zip(STAT_NAMES, stats.tolist())), tab
+    return wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off, fd, fg), dict(zip(STAT_NAMES, stats.tolist())), tab

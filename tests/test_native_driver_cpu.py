@@ -140,3 +140,24 @@ def test_native_loop_rare_common(mspbwt, n_threads):
     for a, b in zip(got, want):
         assert a.dosage.shape == (rc.nSNPs_all,) and a.nDosage == b.nDosage == P.nGibbsSamples
         _same(a, b)
+
+
+@pytest.mark.parametrize("n_threads,per_set", [(1, 256), (2, 1)])
+def test_native_loop_nipt(twin_panel, n_threads, per_set):
+    """method = "nipt" in the native loop: three read labels drawn with the sample's fetal fraction (functions.R:586), one ff per
+    chain in the Gibbs call with its block passes, three full-panel passes per chain, mother / fetus accumulators
+    (:1009-1016), three-way read confidence and consensus labels (:1788-1829), recast_nipt_haps (:3214-3287) -- equal to
+    quilt_amd/driver.py on the oracle, samples with different fetal fractions in one launch set."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = twin_panel
+    samples = [make_synthetic_sample(panel, seed=900 + i, n_reads=220, ff=0.1 + 0.05 * i) for i in range(3)]
+    P = DriverParams(nGibbsSamples=2, n_seek_its=2, Ksubset=64, Knew=64, seed=4, method="nipt", small_ref_panel_gibbs_iterations=5,
+                     small_ref_panel_block_gibbs_iterations=(2,))
+    want = Driver(panel, OracleBackend(panel), P).run(samples, sample_offset=2)
+    got, stats, _ = impute_samples_on_oracle(panel, samples, P, sample_offset=2, samples_per_launch_set=per_set, n_threads=n_threads)
+    for a, b in zip(got, want):
+        assert a.phasing_haps.shape == (panel.nSNPs, 3) and (a.read_labels == 3).any()
+        _same(a, b)
+        assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)

@@ -115,3 +115,30 @@ def test_native_driver_rare_common_on_the_device(medium_panel):
     for a, b in zip(got, want):
         assert a.dosage.shape == (rc.nSNPs_all,)
         _same(a, b)
+
+
+def test_native_driver_nipt_on_the_device(medium_panel):
+    """method = "nipt" through qa_impute_samples on the device == quilt_amd/driver.py on the device, bit for bit (mother and fetus,
+    three phased haplotypes, consensus labels), samples with different fetal fractions, two host threads."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=4300 + i, n_reads=500, ff=0.1 + 0.04 * i) for i in range(5)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=12, method="nipt")
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    want = Driver(panel, HipBackend(dev), prm).run(samples, sample_offset=3)
+    devs = [DevicePanel(panel) for _ in range(2)]
+    for d in devs:
+        d.set_device_share(2)
+        d.set_dosage_precision(64)
+        d.set_exclusive(True)
+    got = impute_samples(devs, samples, prm, sample_offset=3, samples_per_launch_set=2)
+    for d in devs + [dev]:
+        d.close()
+    for a, b in zip(got, want):
+        assert a.phasing_haps.shape == (panel.nSNPs, 3)
+        _same(a, b)
+        assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
