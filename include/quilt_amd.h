@@ -616,7 +616,8 @@ typedef struct {
 int qa_impute_params_default(qa_impute_params_t *params);
 
 /*
- * get_and_impute_one_sample (QUILT/R/functions.R:3-1500) for samples [0, n_sample) of the caller's range, method = "diploid":
+ * get_and_impute_one_sample (QUILT/R/functions.R:3-1500) for samples [0, n_sample) of the caller's range (method = "diploid";
+ * params->nipt: method = "nipt"; params->rare_common: impute_rare_common = TRUE; params->use_mspbwt: use_mspbwt = TRUE):
  * the body of the reference's loop over a core's sample range (QUILT/R/quilt.R:688-996: `for(iSample in sampleRange[1]:
  * sampleRange[2])` inside mclapply) as ONE call -- (nGibbsSamples + 1) x n_seek_its rounds of [small-panel Gibbs -> full-panel
  * pass per read label -> new small panel] per sample, accumulation over the rounds past the burn-in (functions.R:999-1020),

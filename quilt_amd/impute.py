@@ -3,8 +3,8 @@ the reference's loop over a core's sample range (QUILT/R/quilt.R:688-996, ``get_
 QUILT/R/functions.R:3-1500) as ONE native call.  Everything between the native compute calls -- the round loop, the
 hand-over of ``which_haps_to_use``, accumulation, consensus labels, ``recast_haps``, the host threads per device -- is C++
 there; this module only flattens ``SampleReads`` objects and wraps the outputs.  ``quilt_amd/driver.py`` keeps the same loop
-in Python for the modes the native entry point does not cover yet (NIPT, ``impute_rare_common``) and as the tested statement
-the native loop must equal bit for bit (tests/test_native_driver_cpu.py, tests/test_native_driver_gpu.py)."""
+in Python for the one combination the native entry point does not cover (NIPT with ``impute_rare_common``) and as the tested
+statement the native loop must equal bit for bit (tests/test_native_driver_cpu.py, tests/test_native_driver_gpu.py)."""
 from __future__ import annotations
 
 import ctypes as C
