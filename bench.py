@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan-check", action="store_true",
                     help="--mspbwt: skip the comparison of the device search with the msPBWT neighbour scan (CPU, ~20 s)")
-    ap.add_argument("--r2-vs-cpu", type=int, default=1, metavar="N",
+    ap.add_argument("--r2-vs-cpu", type=int, default=4, metavar="N",
                     help="also impute the first N samples of the last batch with the whole pipeline on the CPU oracle (its chains on "
                          "a thread pool: about a minute per sample on a many-core host; before any HIP context exists, rank 0 at "
                          "N = 1 only) and report the metric's `dosage r2 vs CPU ref`; 0 switches it off")
@@ -834,7 +834,7 @@ def cpu_pipeline_reference(a, panel, params, samples):
     n_steps = a.warmup + a.steps
     n = min(a.r2_vs_cpu, len(samples[-1]))
     t0 = time.perf_counter()
-    n_thr = min(32, physical_cores())
+    n_thr = min(max(32, 8 * n), physical_cores())   # (n samples x 7 chains advance in lock-step: a thread per chain)
     ref = Driver(panel, OracleBackend(panel, n_threads=n_thr), DriverParams(**params)).run(samples[-1][:n],
                                                                                             sample_offset=(n_steps - 1) * a.batch)
     return dict(ref=ref, n=n, cpu_seconds=round(time.perf_counter() - t0, 1), threads=n_thr)

@@ -262,8 +262,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
         int iRead = 0;  // next unprocessed read
         // software pipeline over reads: the emission column of read iRead is always in flight one read
         // ahead of its use; all per-read scalars come from the lane-held streams
-        typename CH::ErPre pre_er;
+        // (LEAN: TWO reads ahead -- with two chains per SIMD the device draws 5.3 TB/s and a load issued one read visit, 2.4 us,
+        // ahead is not always back in time; five more registers)
+        typename CH::ErPre pre_er, pre_er2;
         if (R > 0) ch.ld_pre(pre_er, 0);
+        if constexpr (LEAN) { if (R > 0) ch.ld_pre(pre_er2, min(1, R - 1)); }
         ReadStreams<CH> rs;
         rs.base = -1;
         GridStreams<CH> gs;
@@ -375,7 +378,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                 iRead++;
                 // unconditional (clamped) so that no control-flow join forces the in-order vmcnt to drain
                 // (the next read's table size comes from the lane-held stream; across a stream boundary: the whole table)
-                ch.ld_pre(pre_er, min(iRead, R - 1), (iRead & 63) ? rl_i32(rs.nent, iRead & 63) : 64);
+                if constexpr (LEAN) {
+                    pre_er = pre_er2;
+                    const int q = min(iRead + 1, R - 1);
+                    ch.ld_pre(pre_er2, q, ((q >> 6) == (r >> 6)) ? rl_i32(rs.nent, q & 63) : 64);
+                } else {
+                    ch.ld_pre(pre_er, min(iRead, R - 1), (iRead & 63) ? rl_i32(rs.nent, iRead & 63) : 64);
+                }
                 if (rl_i32(rs.cat1, jr) != 0) continue;  // reads that cannot discriminate are skipped (:815)
                 Col<NE> er, ri;   // the read's emission column and 1 / it (used by normal reads)
                 const int dn_r = rl_i32(rs.dn, jr);
