@@ -262,11 +262,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
         int iRead = 0;  // next unprocessed read
         // software pipeline over reads: the emission column of read iRead is always in flight one read
         // ahead of its use; all per-read scalars come from the lane-held streams
-        // (LEAN: TWO reads ahead -- with two chains per SIMD the device draws 5.3 TB/s and a load issued one read visit, 2.4 us,
-        // ahead is not always back in time; five more registers)
-        typename CH::ErPre pre_er, pre_er2;
+        typename CH::ErPre pre_er;
         if (R > 0) ch.ld_pre(pre_er, 0);
-        if constexpr (LEAN) { if (R > 0) ch.ld_pre(pre_er2, min(1, R - 1)); }
         ReadStreams<CH> rs;
         rs.base = -1;
         GridStreams<CH> gs;
@@ -378,13 +375,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                 iRead++;
                 // unconditional (clamped) so that no control-flow join forces the in-order vmcnt to drain
                 // (the next read's table size comes from the lane-held stream; across a stream boundary: the whole table)
-                if constexpr (LEAN) {
-                    pre_er = pre_er2;
-                    const int q = min(iRead + 1, R - 1);
-                    ch.ld_pre(pre_er2, q, ((q >> 6) == (r >> 6)) ? rl_i32(rs.nent, q & 63) : 64);
-                } else {
-                    ch.ld_pre(pre_er, min(iRead, R - 1), (iRead & 63) ? rl_i32(rs.nent, iRead & 63) : 64);
-                }
+                // (measured and dropped in round 4: TWO reads ahead in the lean build -- 2 048 chains 1 115 -> 1 138 ms: the packs are
+                // not what the waves wait for)
+                ch.ld_pre(pre_er, min(iRead, R - 1), (iRead & 63) ? rl_i32(rs.nent, iRead & 63) : 64);
                 if (rl_i32(rs.cat1, jr) != 0) continue;  // reads that cannot discriminate are skipped (:815)
                 Col<NE> er, ri;   // the read's emission column and 1 / it (used by normal reads)
                 const int dn_r = rl_i32(rs.dn, jr);
@@ -533,11 +526,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             }
             gs.set_c(lane, jg, cg[0], cg[1]);
             if constexpr (LEAN) {
+#ifndef QA_DBG_NO_LATE_LOADS   // (developer timing build: what the exposed loads of the next grid's columns cost; results are wrong)
                 const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
                 ch.ldm(e[0], ch.eg[0] + gn);
                 ch.ldm(e[1], ch.eg[1] + gn);
                 ch.ldm(bt[0], ch.beta[0] + gn);
                 ch.ldm(bt[1], ch.beta[1] + gn);
+#endif
             } else {
                 e[0] = en[0]; e[1] = en[1];
                 bt[0] = bn[0]; bt[1] = bn[1];

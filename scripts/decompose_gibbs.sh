@@ -1,0 +1,12 @@
+#!/bin/bash
+# Developer aid: where a 2 048-chain launch of the sampler's 256-register build spends its time -- the tree's library against
+# builds with one part switched off (quilt_amd/csrc/libquilt_amd_dbg_<V>.so: -DQA_DBG_SKIP_BWD, -DQA_DBG_SKIP_SHARD,
+# -DQA_DBG_NO_LATE_LOADS; results of those builds are wrong, only their times mean something), at 20 000 and 5 000 reads.
+#   gpurun --timeout 1500 -- 'bash scripts/decompose_gibbs.sh'
+for V in full SKIP_BWD SKIP_SHARD NO_LATE_LOADS; do
+  if [ $V = full ]; then unset QUILT_AMD_LIB; else export QUILT_AMD_LIB=$PWD/quilt_amd/csrc/libquilt_amd_dbg_$V.so; fi
+  for R in 20000 5000; do
+    echo -n "$V reads $R: "
+    python scripts/perf_gibbs.py --chains 2048 --reads $R --init-iter --reps 2 2>&1 | grep "rep 1" | sed 's/.*gibbs \([0-9.]*\) ms.*/\1 ms/'
+  done
+done
