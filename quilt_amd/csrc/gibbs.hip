@@ -501,6 +501,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     if (lane == jr) rs.Hc = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
                 }
             }
+#ifdef QA_LEAN_EARLY_E
+            // LEAN: the next grid's eMatGrid columns are requested NOW -- e's registers are free (the grid's own columns wait in
+            // LDS) -- ahead of the changed columns' stores and of everything else the end of a grid does; beta's follow at the end.
+            // The columns a move changed go from LDS to memory through beta's registers (dead since alpha * beta was formed).
+            if constexpr (LEAN) {
+                const size_t gn0 = (size_t)min(g + 1, G - 1) * Ksp;
+                ch.ldm(e[0], ch.eg[0] + gn0);
+                ch.ldm(e[1], ch.eg[1] + gn0);
+            }
+#endif
             if (changed) {
                 // re-inject the moved columns and renormalise (:1262-1292)
                 double sm[2];
@@ -511,11 +521,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     cg[h] *= alphaConst;
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
+#ifdef QA_LEAN_EARLY_E
+                    if constexpr (LEAN) {
+#pragma unroll
+                        for (int i = 0; i < NE; i++) bt[h].v[i] = s_e[(h * NE + i) * NT + t];
+                        ch.stm(bt[h], ch.eg[h] + (size_t)g * Ksp);
+                    } else {
+                        ch.stm(e[h], ch.eg[h] + (size_t)g * Ksp);
+                    }
+#else
                     if constexpr (LEAN) {
 #pragma unroll
                         for (int i = 0; i < NE; i++) e[h].v[i] = s_e[(h * NE + i) * NT + t];
                     }
                     ch.stm(e[h], ch.eg[h] + (size_t)g * Ksp);
+#endif
                 }
             }
             // alphaHat_t is not read again inside the call (the shard pass runs its own forward): only the state left
@@ -528,8 +548,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             if constexpr (LEAN) {
 #ifndef QA_DBG_NO_LATE_LOADS   // (developer timing build: what the exposed loads of the next grid's columns cost; results are wrong)
                 const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
+#ifndef QA_LEAN_EARLY_E
                 ch.ldm(e[0], ch.eg[0] + gn);
                 ch.ldm(e[1], ch.eg[1] + gn);
+#endif
                 ch.ldm(bt[0], ch.beta[0] + gn);
                 ch.ldm(bt[1], ch.beta[1] + gn);
 #endif

@@ -226,3 +226,28 @@ def test_mspbwt_neighbour_scan_headline_size(head_panel):
     sel = idx.select_new_haps(Zs, 2, 3, 1, KS, [77])
     from quilt_amd.mspbwt import select_new_haps_mspbwt_v3
     assert np.array_equal(sel[0], select_new_haps_mspbwt_v3(want, KS, head_panel.K, head_panel.nGrids, 77))
+
+
+def test_hrc_sized_panel(oracle):
+    """The HRC panel's scale: K = 64 976 haplotypes (eight chunk rows: seven on chip, one streamed through HBM) over 500 grids
+    with the lazily normalised schedule at work; one dosage pass with fp64 state and one thin pass through the single-pass entry
+    point: dosage <= 1e-9, c to 1e-9, lists identical."""
+    from quilt_amd.driver import thinned_grid_columns
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    from tests.util import label_gl
+    panel = make_synthetic_panel(K=64976, nSNPs=16000, seed=64976)
+    s = make_synthetic_sample(panel, seed=12, n_reads=5000)
+    gl = label_gl(panel, s, 2, oracle)
+    cols = thinned_grid_columns(panel.nGrids, 0.1)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True,
+                                            always_normalize=False)
+    got = _run_gpu(dev, gl, cols, matrices=False, return_dosage=True, get_best_haps_from_thinned_sites=True, always_normalize=False)
+    dev.close()
+    assert np.abs(got["dosage"] - ref["dosage"]).max() <= 1e-9
+    np.testing.assert_allclose(got["c"], ref["c"], rtol=RTOL)
+    check_best_haps(got["best_haps_stuff_list"], ref["best_haps"])
+    n_renorm = int((np.abs(ref["c"][1:] * panel.transMatRate_t[0] - 1) > 1e-9).sum())
+    assert 1 < n_renorm < 400
