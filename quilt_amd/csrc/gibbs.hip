@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     if (lane == jr) rs.Hc = (local_min < p.class_sum_cutoff) ? which + 1 : 0;
                 }
             }
-#ifdef QA_LEAN_EARLY_E
+#ifndef QA_LEAN_LATE_E   // (round 4: 2 048 chains 1 134 -> 1 112 ms; -DQA_LEAN_LATE_E restores the late form for A/B runs)
             // LEAN: the next grid's eMatGrid columns are requested NOW -- e's registers are free (the grid's own columns wait in
             // LDS) -- ahead of the changed columns' stores and of everything else the end of a grid does; beta's follow at the end.
             // The columns a move changed go from LDS to memory through beta's registers (dead since alpha * beta was formed).
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     cg[h] *= alphaConst;
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
-#ifdef QA_LEAN_EARLY_E
+#ifndef QA_LEAN_LATE_E
                     if constexpr (LEAN) {
 #pragma unroll
                         for (int i = 0; i < NE; i++) bt[h].v[i] = s_e[(h * NE + i) * NT + t];
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             if constexpr (LEAN) {
 #ifndef QA_DBG_NO_LATE_LOADS   // (developer timing build: what the exposed loads of the next grid's columns cost; results are wrong)
                 const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;
-#ifndef QA_LEAN_EARLY_E
+#ifdef QA_LEAN_LATE_E
                 ch.ldm(e[0], ch.eg[0] + gn);
                 ch.ldm(e[1], ch.eg[1] + gn);
 #endif
