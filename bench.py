@@ -331,11 +331,11 @@ def main():
         a.fuse = (max(1, min(16, round(2048 / per_step))) if (a.mode == "short" and a.rare_common <= 0)
                   else max(1, min(16, round(1024 / per_step))))
     a.fuse = max(1, a.fuse)
-    native_ok = not (a.mode == "nipt" and a.rare_common > 0) and not (a.mspbwt and a.mspbwt_search != "scan") and not a.stub
+    native_ok = not (a.mspbwt and a.mspbwt_search != "scan") and not a.stub
     if a.driver is None:
         a.driver = "native" if native_ok and a.split == "alternate" and a.exclusive and not a.gibbs_gate and not a.cu_partition else "python"
     if a.driver == "native" and not native_ok:
-        raise SystemExit("--driver native: not NIPT together with --rare-common; msPBWT mode: the neighbour scan")
+        raise SystemExit("--driver native: msPBWT mode runs the neighbour scan (--mspbwt-search scan); not with --stub")
     os.environ.setdefault("QA_HOST_THREADS", str(max(2, (os.cpu_count() or 16) // max(1, local_world * a.workers))))
     params = dict(nGibbsSamples=7, n_seek_its=3, Ksubset=600, Knew=600, seed=1)
     full_chains = params["nGibbsSamples"] + 1

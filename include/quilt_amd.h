@@ -566,6 +566,7 @@ typedef struct {
     int32_t nSNPs_all, nGrids_all;
     const uint8_t *snp_is_common;
     const int32_t *read_off, *read_ptr, *u, *bq, *wif;
+    const int32_t *L_grid_all;   /* method = "nipt" only: nGrids_all positions (bp) of the all-SNP grid, for its block Gibbs */
 } qa_impute_rare_common_t;
 
 /*
@@ -574,8 +575,9 @@ typedef struct {
  * sample (n_sample x 3 x nSNPs: maternal transmitted, maternal untransmitted, paternal transmitted, after recast_nipt_haps).
  *   ff                   n_sample fetal fractions in (0, 1) (ff_values[iSample], functions.R:128)
  *   L_grid               nGrids grid positions (bp), shuffle_bin_radius (quilt.R:134: 5000): the block definition of the block Gibbs
- *   fet_dosage, fet_gp_t OUT, n_sample x nSNPs and n_sample x 3 x nSNPs: the fetus' (maternal transmitted + paternal transmitted)
- * Not combined with impute_rare_common here (quilt_amd/driver.py runs that combination).
+ *   fet_dosage, fet_gp_t OUT, n_sample x nSNPs and n_sample x 3 x nSNPs: the fetus' (maternal transmitted + paternal transmitted);
+ *                        over nSNPs_all with impute_rare_common (starting labels of the all-SNP call by read grouping:
+ *                        gibbs-nipt.R:1655-1849; rare_common->L_grid_all is then needed)
  */
 typedef struct {
     const double *ff;
@@ -645,8 +647,7 @@ int qa_impute_params_default(qa_impute_params_t *params);
  *                     [2] selections made on the device, [3] chains handed to qa_gibbs_batch, [4] Gibbs launch sets,
  *                     [5..10] ms summed over the host threads: Gibbs calls, full-panel calls, host, consensus, finish, accumulation
  * Random draws: R's stream cannot be reproduced without R; every draw the R code makes is defined on a counter stream
- * (quilt_amd/rng.py::ChainStream = csrc/impute.cpp).  method = "nipt" together with impute_rare_common is not behind this entry
- * point (QA_ERR_UNSUPPORTED; quilt_amd/driver.py runs that combination over the same batched calls).
+ * (quilt_amd/rng.py::ChainStream = csrc/impute.cpp).
  */
 int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impute_params_t *params, int32_t n_sample,
                       int64_t sample_offset, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,

@@ -354,6 +354,53 @@ void recast_nipt_haps(double *hap1, double *hap2, double *hap3, const double *mg
 // ---------------------------------------------------------------------------------------------------------------------------
 // one host thread: its handle, its buffers, its stream of launch sets
 // ---------------------------------------------------------------------------------------------------------------------------
+// get_initial_read_labels for method = "nipt" (rare_common.R:104-105 with get_read_groupings_given_fetal_fraction_and_cov and
+// sample_H_for_NIPT_given_groupings, gibbs-nipt.R:1655-1777, :1796-1849; the statement in quilt_amd/driver.py): e = the all-SNP
+// reads' rescaled likelihoods against (hap1, hap2, hap3), [read][3].  A read is grouped by which haplotypes it fits (> 0.5);
+// reads that fit all or none follow the label prior, reads that fit exactly one take its label, reads shared by two are split
+// between them in the ratio of the label priors (preserve_round) and drawn with those proportions.  Draws in the order of the
+// numpy text: one vector for the prior group, then one per pair (1,2), (1,3), (2,3) that has reads.
+void initial_read_labels_nipt(const double *e, int R, double ff, ChainStream &rng, std::vector<int32_t> &H) {
+    const double frp[3] = {0.5, 0.5 - ff / 2, ff / 2};
+    std::vector<uint8_t> m((size_t)R * 3);
+    std::vector<int> n_fit((size_t)R, 0);
+    for (int r = 0; r < R; r++)
+        for (int i = 0; i < 3; i++) {
+            const double v = e[(size_t)r * 3 + i];
+            const bool fit = !std::isnan(v) && v > 0.5;
+            m[(size_t)r * 3 + i] = fit;
+            n_fit[(size_t)r] += fit;
+        }
+    std::fill(H.begin(), H.end(), 0);
+    for (int r = 0; r < R; r++)
+        if (n_fit[(size_t)r] == 3 || n_fit[(size_t)r] == 0) H[(size_t)r] = 1 + rng.choice3(frp);
+    for (int r = 0; r < R; r++)
+        if (n_fit[(size_t)r] == 1)
+            for (int i = 0; i < 3; i++)
+                if (m[(size_t)r * 3 + i]) H[(size_t)r] = i + 1;
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++) {
+            std::vector<int> both;
+            for (int r = 0; r < R; r++)
+                if (n_fit[(size_t)r] == 2 && m[(size_t)r * 3 + i] && m[(size_t)r * 3 + j]) both.push_back(r);
+            const int n = (int)both.size();
+            if (n == 0) continue;
+            const double f1 = frp[i] / (frp[i] + frp[j]);
+            // preserve_round(n * c(f1, 1 - f1)) (gibbs-nipt.R:1779-1789): floors, then the largest fractional parts go up
+            const double x[2] = {n * f1, n * (1 - f1)};
+            double y[2] = {std::floor(x[0]), std::floor(x[1])};
+            const int n_up = (int)(std::nearbyint(x[0] + x[1]) - (y[0] + y[1]));
+            if (n_up > 0) {
+                // numpy: argsort(x - y, stable)[-n_up:] -- of two elements the larger fractional part (ties: the second) first
+                const double fr[2] = {x[0] - y[0], x[1] - y[1]};
+                const int order[2] = {fr[1] < fr[0] ? 1 : 0, fr[1] < fr[0] ? 0 : 1};   // ascending, stable
+                for (int q = 0; q < n_up && q < 2; q++) y[order[1 - q]] += 1;
+            }
+            const double thr = y[0] / (y[0] + y[1]);
+            for (int r : both) H[(size_t)r] = (rng.uniform() < thr) ? i + 1 : j + 1;
+        }
+}
+
 // A host thread's marshalling and transfer buffers.  With the product's entry points they outlive the call (kept per panel
 // handle, freed by qa_impute_release_buffers): a launch set of 2 048 chains carries ~1.5 GB of per-chain read copies and 2 GB
 // of pinned dosage rows, and allocating -- pinning, first-touching -- them anew inside every call cost 1.5 s of a 70 s run.
@@ -417,7 +464,7 @@ struct Worker {
         const int C = (int)ch.size();
         const int G = cx.G, T = rare ? cx.T_out : cx.T;
         const std::vector<Reads> &RD = rare ? cx.reads_all : cx.reads;
-        const int nLh = rare ? 2 : cx.nL;   // labels of the call's haploid dosages
+        const int nLh = cx.nL;   // labels of the call's haploid dosages
         std::vector<int> pending((size_t)C);
         for (int i = 0; i < C; i++) pending[(size_t)i] = i;
         std::vector<double> maxdiff((size_t)C, P.maxDifferenceBetweenReads);
@@ -491,7 +538,7 @@ struct Worker {
                 o.gibbs_initialize_iteratively = any_first ? 1 : 0;
                 o.disable_read_category_usage = rare ? 1 : 0;
                 o.class_sum_cutoff = 0.06;
-                o.L_grid = cx.nipt ? cx.nipt->L_grid : nullptr;
+                o.L_grid = cx.nipt ? (rare ? cx.rc->L_grid_all : cx.nipt->L_grid) : nullptr;
                 o.shuffle_bin_radius = cx.nipt ? cx.nipt->shuffle_bin_radius : 5000;
                 o.block_gibbs_quantile_prob = 0.95;
                 std::vector<int32_t> words_tmp;
@@ -785,17 +832,16 @@ struct Worker {
     // haplotypes selected last.  `ch`: the chains of the last round in its order (their dosages are rows of `dos`).
     void rare_common_round(std::vector<Chain *> &ch, Batch *cur) {
         const auto &P = cx.P;
-        const int C = (int)ch.size(), T = cx.T, Ta = cx.T_out;
+        const int C = (int)ch.size(), T = cx.T, Ta = cx.T_out, nL = cx.nL;
         const double t0 = now_s();
-        const double *last = dos.p;   // [chain][2][T] of the last seek iteration
-        eh.resize((size_t)C * Ta * 2);
+        const double *last = dos.p;   // [chain][label][T] of the last seek iteration
+        eh.resize((size_t)C * Ta * nL);
         parallel_for((size_t)C, n_help, [&](size_t c) {
-            double *e = &eh[c * Ta * 2];
-            for (size_t t = 0; t < (size_t)Ta * 2; t++) e[t] = 0.5;
-            const double *h1 = last + c * 2 * T, *h2 = h1 + T;
-            for (int j = 0; j < T; j++) {
-                e[(size_t)cx.common_at[(size_t)j] * 2] = h1[j];
-                e[(size_t)cx.common_at[(size_t)j] * 2 + 1] = h2[j];
+            double *e = &eh[c * Ta * nL];
+            for (size_t t = 0; t < (size_t)Ta * nL; t++) e[t] = 0.5;
+            for (int l = 0; l < nL; l++) {
+                const double *h = last + (c * nL + l) * T;
+                for (int j = 0; j < T; j++) e[(size_t)cx.common_at[(size_t)j] * nL + l] = h[j];
             }
         });
         std::vector<int32_t> read_off((size_t)C + 1, 0);
@@ -814,9 +860,9 @@ struct Worker {
             std::memcpy(&g_u[(size_t)boff[i]], r.u, sizeof(int32_t) * (size_t)r.nb);
             std::memcpy(&g_bq[(size_t)boff[i]], r.bq, sizeof(int32_t) * (size_t)r.nb);
         });
-        double *lik = conf.get((size_t)read_off[(size_t)C] * 2);
+        double *lik = conf.get((size_t)read_off[(size_t)C] * nL);
         // rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100
-        check(cx.be->make_eMatRead_t_nsnps(handle, Ta, C, 2, eh.data(), read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
+        check(cx.be->make_eMatRead_t_nsnps(handle, Ta, C, nL, eh.data(), read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
                                            P.maxDifferenceBetweenReads, 100, 1, lik), "qa_rcpp_make_eMatRead_t_nsnps");
         std::vector<std::vector<int32_t>> starts((size_t)C);
         first_reads.assign((size_t)C, 0);
@@ -825,28 +871,33 @@ struct Worker {
         for (int i = 0; i < C; i++) {
             Chain &c = *ch[(size_t)i];
             const int R = cx.reads_all[(size_t)c.sample].R;
-            const double *e = lik + (size_t)read_off[(size_t)i] * 2;
+            const double *e = lik + (size_t)read_off[(size_t)i] * nL;
             starts[(size_t)i].resize((size_t)R);
-            for (int r = 0; r < R; r++)   // H <- as.integer(runif(nReads) < e[1, ] / colSums(e)) + 1
-                starts[(size_t)i][(size_t)r] = (c.rng.uniform() < e[(size_t)r * 2] / (e[(size_t)r * 2] + e[(size_t)r * 2 + 1])) ? 2 : 1;
+            if (cx.nipt) {
+                initial_read_labels_nipt(e, R, cx.nipt->ff[c.sample], c.rng, starts[(size_t)i]);
+            } else {
+                for (int r = 0; r < R; r++)   // H <- as.integer(runif(nReads) < e[1, ] / colSums(e)) + 1
+                    starts[(size_t)i][(size_t)r] = (c.rng.uniform() < e[(size_t)r * 2] / (e[(size_t)r * 2] + e[(size_t)r * 2 + 1])) ? 2 : 1;
+            }
             seed_reads[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
             seed_shards[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
         }
         const double t1 = now_s();
         t_host += t1 - t0;
-        double *hall = dos_all.get((size_t)C * 2 * Ta);
+        double *hall = dos_all.get((size_t)C * nL * Ta);
         gibbs_with_retry(ch, starts, false, false, hall, true);
         const double t2 = now_s();
         t_gibbs += t2 - t1;
         for (int i = 0; i < C; i++)
             if (ch[(size_t)i]->phasing)
-                std::memcpy(cx.phasing_haps + (size_t)ch[(size_t)i]->sample * 2 * Ta, hall + (size_t)i * 2 * Ta, sizeof(double) * 2 * (size_t)Ta);
+                std::memcpy(cx.phasing_haps + (size_t)ch[(size_t)i]->sample * nL * Ta, hall + (size_t)i * nL * Ta, sizeof(double) * nL * (size_t)Ta);
         if (cur && !cur->chains.empty()) {   // functions.R:1099-1123
             const int n_cur = (int)cur->chains.size();
             std::vector<int32_t> cs((size_t)n_cur);
             for (int i = 0; i < n_cur; i++) cs[(size_t)i] = cur->chains[(size_t)i].sample - cur->lo;
-            check(cx.be->accumulate_dosage(n_cur, 2, Ta, hall, cs.data(), cur->hi - cur->lo, cx.dosage + (size_t)cur->lo * Ta,
-                                           cx.gp_t + (size_t)cur->lo * 3 * Ta, nullptr, nullptr), "qa_accumulate_dosage");
+            check(cx.be->accumulate_dosage(n_cur, nL, Ta, hall, cs.data(), cur->hi - cur->lo, cx.dosage + (size_t)cur->lo * Ta,
+                                           cx.gp_t + (size_t)cur->lo * 3 * Ta, cx.nipt ? cx.nipt->fet_dosage + (size_t)cur->lo * Ta : nullptr,
+                                           cx.nipt ? cx.nipt->fet_gp_t + (size_t)cur->lo * 3 * Ta : nullptr), "qa_accumulate_dosage");
             for (int i = 0; i < n_cur; i++) cx.nDosage[cur->chains[(size_t)i].sample] += 1;
         }
         t_accumulate += now_s() - t2;
@@ -1101,9 +1152,9 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     }
     cx.T_out = T;
     if (P.nipt) {
-        if (P.rare_common) {
-            qa::set_error("qa_impute_samples: method = \"nipt\" with impute_rare_common is not behind this entry point (quilt_amd/driver.py runs it)");
-            return QA_ERR_UNSUPPORTED;
+        if (P.rare_common && !P.rare_common->L_grid_all) {
+            qa::set_error("qa_impute_samples: method = \"nipt\" with impute_rare_common needs rare_common->L_grid_all");
+            return QA_ERR_INVALID;
         }
         if (!P.nipt->ff || !P.nipt->L_grid || !P.nipt->fet_dosage || !P.nipt->fet_gp_t) {
             qa::set_error("qa_impute_samples: method = \"nipt\" needs ff, L_grid and the fetus' output arrays");
@@ -1113,8 +1164,9 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
             if (!(P.nipt->ff[s2] > 0.0 && P.nipt->ff[s2] < 1.0)) { qa::set_error("qa_impute_samples: fetal fraction of sample %d outside (0, 1)", s2); return QA_ERR_INVALID; }
         cx.nipt = P.nipt;
         cx.nL = 3;
-        std::memset(P.nipt->fet_dosage, 0, sizeof(double) * (size_t)n_sample * T);
-        std::memset(P.nipt->fet_gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * T);
+        const size_t Tf = P.rare_common ? (size_t)P.rare_common->nSNPs_all : (size_t)T;   // (the fetus' outputs cover what dosage covers)
+        std::memset(P.nipt->fet_dosage, 0, sizeof(double) * (size_t)n_sample * Tf);
+        std::memset(P.nipt->fet_gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * Tf);
     }
     if (P.rare_common) {
         const qa_impute_rare_common_t &rc = *P.rare_common;

@@ -3,8 +3,7 @@ the reference's loop over a core's sample range (QUILT/R/quilt.R:688-996, ``get_
 QUILT/R/functions.R:3-1500) as ONE native call.  Everything between the native compute calls -- the round loop, the
 hand-over of ``which_haps_to_use``, accumulation, consensus labels, ``recast_haps``, the host threads per device -- is C++
 there; this module only flattens ``SampleReads`` objects and wraps the outputs.  ``quilt_amd/driver.py`` keeps the same loop
-in Python for the one combination the native entry point does not cover (NIPT with ``impute_rare_common``) and as the tested
-statement the native loop must equal bit for bit (tests/test_native_driver_cpu.py, tests/test_native_driver_gpu.py)."""
+in Python as the tested statement the native loop must equal bit for bit (tests/test_native_driver_cpu.py, tests/test_native_driver_gpu.py)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -39,7 +38,8 @@ class ImputeNipt(C.Structure):
 
 class ImputeRareCommon(C.Structure):
     _fields_ = [("handles", C.c_void_p), ("nSNPs_all", C.c_int32), ("nGrids_all", C.c_int32), ("snp_is_common", C.c_void_p),
-                ("read_off", C.c_void_p), ("read_ptr", C.c_void_p), ("u", C.c_void_p), ("bq", C.c_void_p), ("wif", C.c_void_p)]
+                ("read_off", C.c_void_p), ("read_ptr", C.c_void_p), ("u", C.c_void_p), ("bq", C.c_void_p), ("wif", C.c_void_p),
+                ("L_grid_all", C.c_void_p)]
 
 
 STAT_NAMES = ("underflow_retries", "full_list_refetches", "device_selections", "gibbs_chain_calls", "gibbs_launches",
@@ -64,15 +64,16 @@ def make_rare_common(rc, rc_handles, samples):
     read_off, read_ptr, u, bq, wif = flatten_samples([s.all_snp for s in samples])
     is_common = np.ascontiguousarray(rc.snp_is_common, dtype=np.uint8)
     hs = (C.c_void_p * len(rc_handles))(*rc_handles)
+    Lg = np.ascontiguousarray(rc.L_grid_all, dtype=np.int32)
     q = ImputeRareCommon(C.cast(hs, C.c_void_p), rc.nSNPs_all, rc.nGrids_all, ptr(is_common), ptr(read_off), ptr(read_ptr), ptr(u),
-                         ptr(bq), ptr(wif))
-    return q, (hs, is_common, read_off, read_ptr, u, bq, wif)
+                         ptr(bq), ptr(wif), ptr(Lg))
+    return q, (hs, is_common, read_off, read_ptr, u, bq, wif, Lg)
 
 
-def make_nipt(panel, samples, shuffle_bin_radius: int):
+def make_nipt(panel, samples, shuffle_bin_radius: int, nSNPs_out: Optional[int] = None):
     """(ImputeNipt, the fetus' output arrays, keep-alive objects) for method = "nipt": the samples' fetal fractions, the
-    panel's grid positions."""
-    n, T = len(samples), panel.nSNPs
+    panel's grid positions; ``nSNPs_out``: what the outputs cover (all SNPs with impute_rare_common)."""
+    n, T = len(samples), (panel.nSNPs if nSNPs_out is None else int(nSNPs_out))
     ff = np.ascontiguousarray([float(s.ff) for s in samples], dtype=np.float64)
     Lg = np.ascontiguousarray(panel.L_grid, dtype=np.int32)
     fd, fg = np.zeros((n, T)), np.zeros((n, 3, T))
@@ -82,8 +83,8 @@ def make_nipt(panel, samples, shuffle_bin_radius: int):
 def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None, fuse_tails: bool = True, rare_common=None, nipt=None):
     """(ImputeParams, keep-alive objects) from the Python driver's parameters; ``rare_common``: an ImputeRareCommon (with
     impute_rare_common); ``nipt``: an ImputeNipt (method = "nipt")."""
-    if P.method == "nipt" and (nipt is None or P.impute_rare_common):
-        raise ValueError("method = 'nipt' needs make_nipt(...) and is not combined with impute_rare_common here (quilt_amd.driver.Driver)")
+    if P.method == "nipt" and nipt is None:
+        raise ValueError("method = 'nipt' needs make_nipt(...)")
     if P.impute_rare_common and rare_common is None:
         raise ValueError("impute_rare_common needs the all-SNP side (make_rare_common)")
     blocks = np.ascontiguousarray(P.small_ref_panel_block_gibbs_iterations, dtype=np.int32)
@@ -125,7 +126,7 @@ def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverPar
         rcq, keep_rc = make_rare_common(drcs[0].rc, [d.handle for d in drcs], samples)
     nq = fd = fg = keep_n = None
     if P.method == "nipt":
-        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius)
+        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius, drcs[0].rc.nSNPs_all if P.impute_rare_common else None)
     q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq, nq)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)
     n, T = len(samples), (drcs[0].rc.nSNPs_all if P.impute_rare_common else panel.nSNPs)

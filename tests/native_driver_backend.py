@@ -133,7 +133,8 @@ class OracleTable:
         if o.ff != 0:   # method = "nipt": one fetal fraction per chain, the block definition's radius (L_grid is the panel's)
             ffc = np.ctypeslib.as_array(C.cast(o.ff_chain, F64P), shape=(n,)) if o.ff_chain else np.full(n, o.ff)
             assert not o.do_shard_block_gibbs and not o.sample_is_diploid and o.L_grid
-            assert np.array_equal(np.ctypeslib.as_array(C.cast(o.L_grid, I32P), shape=(self.panel.nGrids,)), self.panel.L_grid)
+            Lg = self.rare_common.L_grid_all if rare else self.panel.L_grid   # (the all-SNP call's blocks are cut on its own grid)
+            assert np.array_equal(np.ctypeslib.as_array(C.cast(o.L_grid, I32P), shape=(len(Lg),)), Lg)
             nipt = dict(ff=[float(x) for x in ffc], shuffle_bin_radius=int(o.shuffle_bin_radius))
         res = self.ob.gibbs_batch(samples, [wh[c].copy() for c in range(n)], starts, [int(sr[c]) for c in range(n)],
                                   [int(fr[c]) for c in range(n)], [int(ss[c]) for c in range(n)], **nipt,
@@ -269,7 +270,7 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
         rcq, keep_rc = make_rare_common(rare_common, [C.c_void_p(100 + w) for w in range(n_threads)], samples)
     nq = fd = fg = keep_n = None
     if P.method == "nipt":
-        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius)
+        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius, rare_common.nSNPs_all if P.impute_rare_common else None)
     q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq, nq)
     tab = OracleTable(panel, fail_at_call=fail_at_call, rare_common=rare_common)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)

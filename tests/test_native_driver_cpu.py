@@ -142,6 +142,35 @@ def test_native_loop_rare_common(mspbwt, n_threads):
         _same(a, b)
 
 
+@pytest.mark.parametrize("n_threads", [1, 2])
+def test_native_loop_nipt_rare_common(n_threads):
+    """method = "nipt" with impute_rare_common: the all-SNP call's starting labels come from the read grouping by which of
+    (hap1, hap2, hap3) a read fits (get_read_groupings_given_fetal_fraction_and_cov / sample_H_for_NIPT_given_groupings,
+    gibbs-nipt.R:1655-1849), its block passes are cut on the all-SNP grid, the mother's and the fetus' accumulators and the three
+    phased haplotypes cover all SNPs -- equal to quilt_amd/driver.py on the oracle."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.synth import make_rare_common, make_synthetic_panel, make_synthetic_sample_rare_common
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = make_synthetic_panel(K=300, nSNPs=640, seed=5)
+    rc = make_rare_common(panel, 3)
+    samples = []
+    for i in range(3):
+        s = make_synthetic_sample_rare_common(panel, rc, 70 + i, n_reads=160)[0]
+        s.ff = 0.1 + 0.07 * i
+        samples.append(s)
+    P = DriverParams(nGibbsSamples=2, n_seek_its=2, Ksubset=64, Knew=64, seed=11, method="nipt", impute_rare_common=True,
+                     small_ref_panel_gibbs_iterations=5, small_ref_panel_block_gibbs_iterations=(2,))
+    want = Driver(panel, OracleBackend(panel, rc), P, rare_common=rc).run(samples, sample_offset=1)
+    got, stats, tab = impute_samples_on_oracle(panel, samples, P, sample_offset=1, samples_per_launch_set=2, n_threads=n_threads,
+                                               rare_common=rc)
+    assert tab.calls["gibbs_rc"] > 0
+    for a, b in zip(got, want):
+        assert a.phasing_haps.shape == (rc.nSNPs_all, 3) and a.fet_dosage.shape == (rc.nSNPs_all,)
+        _same(a, b)
+        assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
+    assert len({tuple(np.unique(a.read_labels)) for a in got} & {(1, 2, 3)}) == 1
+
+
 @pytest.mark.parametrize("n_threads,per_set", [(1, 256), (2, 1)])
 def test_native_loop_nipt(twin_panel, n_threads, per_set):
     """method = "nipt" in the native loop: three read labels drawn with the sample's fetal fraction (functions.R:586), one ff per

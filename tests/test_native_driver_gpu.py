@@ -117,6 +117,34 @@ def test_native_driver_rare_common_on_the_device(medium_panel):
         _same(a, b)
 
 
+def test_native_driver_nipt_rare_common_on_the_device(medium_panel):
+    """method = "nipt" together with impute_rare_common through qa_impute_samples on the device == quilt_amd/driver.py on the
+    device, bit for bit (mother and fetus over all SNPs, three phased haplotypes, labels)."""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    panel = medium_panel
+    rc = make_rare_common(panel, 4)
+    samples = []
+    for i in range(3):
+        s = make_synthetic_sample_rare_common(panel, rc, 2700 + i, n_reads=500)[0]
+        s.ff = 0.12 + 0.05 * i
+        samples.append(s)
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=10, method="nipt", impute_rare_common=True)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    drc = DeviceRareCommon(dev, rc)
+    want = Driver(panel, HipBackend(dev, drc), prm, rare_common=rc).run(samples, sample_offset=2)
+    got = impute_samples([dev], samples, prm, sample_offset=2, samples_per_launch_set=2, drcs=[drc])
+    drc.close()
+    dev.close()
+    for a, b in zip(got, want):
+        assert a.dosage.shape == (rc.nSNPs_all,) and a.phasing_haps.shape == (rc.nSNPs_all, 3)
+        _same(a, b)
+        assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
+
+
 def test_native_driver_nipt_on_the_device(medium_panel):
     """method = "nipt" through qa_impute_samples on the device == quilt_amd/driver.py on the device, bit for bit (mother and fetus,
     three phased haplotypes, consensus labels), samples with different fetal fractions, two host threads."""
