@@ -17,8 +17,8 @@
 //   * launch sets are software-pipelined: the phasing rounds of set i (one chain per sample) share their launches with the
 //     main rounds of set i + 1 (nGibbsSamples chains per sample);
 //   * n_handles host threads, each with its own panel handle (stream, scratch), take whole launch sets in turn; what the
-//     thread count leaves over is cut into one part per thread; the threads' last sets run their phasing rounds together
-//     in one launch per round (the thread that drains last runs them).
+//     thread count leaves over goes whole to the first threads (a call with fewer sets than threads is cut across them); the
+//     threads' last sets run their phasing rounds together in one launch per round (the thread that drains last runs them).
 // Results do not depend on any of this: every (sample, Gibbs sample) owns its random stream (ChainStream below =
 // quilt_amd/rng.py::ChainStream), keyed by the GLOBAL sample index.
 #include <algorithm>
@@ -1212,8 +1212,13 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     std::vector<std::pair<int, int>> sets;
     for (int lo = 0; lo < n_sample; lo += per_set) sets.push_back({lo, std::min(n_sample, lo + per_set)});
     const int W = n_handles;
-    size_t n_whole = sets.size() / W * W;
-    if (n_whole == 0 && W > 1) n_whole = 0;   // fewer sets than threads: everything is cut across the threads
+    // Sets the thread count leaves over: a Gibbs launch costs nearly the same between 700 and 2 048 chains (a chain's serial
+    // time), so a set cut into W parts costs W launches per round where it would cost one -- the left-over sets go WHOLE to the
+    // first threads (the others drain, leave their last set's phasing rounds at the meeting point, and the thread that drains
+    // last runs all of them together).  Only a call with fewer sets than threads is cut across them (QA_IMPUTE_CUT_LEFTOVERS=1:
+    // always, the form of round 3).
+    static const bool cut_leftovers = [] { const char *e = std::getenv("QA_IMPUTE_CUT_LEFTOVERS"); return e && e[0] == '1'; }();
+    size_t n_whole = (cut_leftovers || sets.size() < (size_t)W) ? sets.size() / W * W : sets.size();
     std::vector<std::vector<std::pair<int, int>>> streams((size_t)W);
     for (size_t i = 0; i < n_whole; i++) streams[i % W].push_back(sets[i]);
     if (n_whole < sets.size()) {
