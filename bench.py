@@ -633,7 +633,9 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                                   + ("; device phases: full-panel launch sets exclusive, Gibbs launches that fit run together" if a.exclusive else "")
                                   + ("; when the stream drains the threads' last batches run their phasing rounds in one launch per round"
                                      if a.fuse_tails and a.workers > 1 else "")
-                                  + ("; launch sets left over by the thread count are cut into one part per thread"
+                                  + ("; launch sets left over by the thread count go whole to the first threads"
+                                     if a.driver == "native" and a.workers > 1 else
+                                     "; launch sets left over by the thread count are cut into one part per thread"
                                      if a.split_remainder and a.split == "alternate" and a.workers > 1 else "")},
     }
     if reg.get("per_rank"):
