@@ -9,7 +9,7 @@ What the patch does, and nothing else:
     functions (qa_QUILT_<fn>, same arities) instead of the Rcpp wrappers; four `extern "C"` declarations are added above the
     table.  The Rcpp wrappers stay defined (no duplicate symbol: the shim's functions have other names) and unregistered.
     `Rcpp::compileAttributes()` regenerates this file: re-apply the patch afterwards.
-  * the same table gets one NEW row, qa_impute_sample_range (5 arguments): the loop over a core's sample range as one call.
+  * the same table gets one NEW row, qa_impute_sample_range (6 arguments): the loop over a core's sample range as one call.
   * QUILT/src/Makevars -- the include path of include/quilt_amd.h, -DQA_HAVE_R (the shim then includes R's own headers) and
     the link line for libquilt_amd.so (QUILT_AMD = the root of this repository).
   * QUILT/src/quilt_amd_shim.c -- added by copying shim/quilt_amd_shim.c (R compiles every .c in src/); the patch carries a
@@ -27,7 +27,7 @@ ENTRIES = {"_QUILT_rcpp_make_eMatRead_t": 15, "_QUILT_Rcpp_make_gl_bound": 3, "_
 
 
 # routines the reference does not have: the loop over a core's sample range as one call (quilt.R:688-996 -> qa_impute_samples)
-EXTRA = {"qa_impute_sample_range": 5}
+EXTRA = {"qa_impute_sample_range": 6}
 
 
 def patched_rcppexports(text):

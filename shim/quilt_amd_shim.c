@@ -523,26 +523,73 @@ SEXP qa_QUILT_rcpp_make_eMatRead_t(SEXP eMatRead_tSEXP, SEXP sampleReadsSEXP, SE
  * mclapply; with the GPU library the whole range goes to qa_impute_samples (include/quilt_amd.h; csrc/impute.cpp: the loop of
  * functions.R:3-1500 in host C++ over the batched kernels), n_handles host threads sharing the device.  R-side (INTEGRATION.md
  * 4a has the replacement of the mclapply body):
- *     out <- .Call("qa_impute_sample_range", list_of_sampleReads, panel_objects, params, sample_offset, n_handles)
+ *     out <- .Call("qa_impute_sample_range", list_of_sampleReads, panel_objects, params, sample_offset, n_handles,
+ *                  list_of_allSNP_sampleReads)
  *   list_of_sampleReads   one sampleReads (list of list(J, wif, bq, u), copied-from-stitch.cpp:153-160) per sample of the range
  *   panel_objects         named list: hapMatcherR, distinctHapsB, distinctHapsIE, eMatDH_special_matrix_helper,
- *                         eMatDH_special_matrix, rhb_t, transMatRate_t (2 x (nGrids - 1)), ref_error, use_eMatDH_special_symbols
+ *                         eMatDH_special_matrix, rhb_t, transMatRate_t (2 x (nGrids - 1)), ref_error, use_eMatDH_special_symbols;
+ *                         method = "nipt": L_grid (nGrids);
+ *                         impute_rare_common = TRUE: rare_common = list(snp_is_common, rare_per_hap_info, transMatRate_t
+ *                         (2 x (nGrids_all - 1)), L_grid) of special_rare_common_objects (prepare_reference_functions.R:172-247)
  *   params                named list of QUILT()'s arguments the path sees (missing entries = the reference's defaults):
  *                         nGibbsSamples, n_seek_its, n_burn_in_seek_its, Ksubset, Knew, K_top_matches, heuristic_match_thin,
  *                         small_ref_panel_gibbs_iterations, small_ref_panel_block_gibbs_iterations (0-based), maxDifferenceBetweenReads,
- *                         minGLValue, Jmax, seed, samples_per_launch_set
+ *                         minGLValue, Jmax, seed, samples_per_launch_set; use_mspbwt, mspbwtL, mspbwtM, mspbwt_nindices;
+ *                         impute_rare_common; method ("diploid" / "nipt"), ff (one fetal fraction per sample), shuffle_bin_radius
  *   sample_offset         0-based index of the range's first sample among ALL samples (keys the random streams: a sample's
  *                         result does not depend on the range it lands in)
+ *   list_of_allSNP_sampleReads   impute_rare_common = TRUE: allSNP_sampleReads per sample (functions.R:162-172: u over all SNPs,
+ *                         wif on the all-SNP grid); NULL otherwise
  * Returns list(dosage = nSNPs x n, gp_t = 3 nSNPs x n (per sample 3 x nSNPs, row-major as the library writes it),
- * phasing_haps = 2 nSNPs x n, read_labels = list of integer vectors, nDosage, stats).  Draws: the library's counter streams
- * (R's stream cannot be handed to 2 048 chains advancing in lock-step); `seed` plays set.seed's part. */
+ * phasing_haps = 2 nSNPs x n (nipt: 3 nSNPs x n), read_labels = list of integer vectors, nDosage, stats[, fet_dosage, fet_gp_t]);
+ * nSNPs = all SNPs with impute_rare_common.  Draws: the library's counter streams (R's stream cannot be handed to 2 048 chains
+ * advancing in lock-step); `seed` plays set.seed's part.  use_mspbwt: the panel's msPBWT indices are built here by
+ * qa_mspbwt_create (the `ms_indices` the reference loads are the mspbwt package's own structures). */
 
 static double num_or(SEXP list, const char *name, double dflt) {
     SEXP v = list_get(list, name);
     return (v == R_NilValue || Rf_length(v) < 1) ? dflt : Rf_asReal(v);
 }
 
-SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP, SEXP sample_offsetSEXP, SEXP n_handlesSEXP) {
+/* a list of sampleReads in the flattened form of include/quilt_amd.h (read_off n + 1; read_ptr R + 1 per sample; bases back to back) */
+typedef struct { int32_t *read_off, *read_ptr, *wif, *u, *bq; } flat_reads_t;
+static void flat_reads_free(flat_reads_t *f) { free(f->read_off); free(f->read_ptr); free(f->wif); free(f->u); free(f->bq); }
+static void flatten_reads(SEXP readsListSEXP, flat_reads_t *f) {
+    const int n = Rf_length(readsListSEXP);
+    f->read_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    f->read_off[0] = 0;
+    size_t nbases = 0;
+    for (int i = 0; i < n; i++) {
+        SEXP sr = VECTOR_ELT(readsListSEXP, i);
+        const int R = Rf_length(sr);
+        f->read_off[i + 1] = f->read_off[i] + R;
+        for (int r = 0; r < R; r++) nbases += (size_t)Rf_length(VECTOR_ELT(VECTOR_ELT(sr, r), 3));
+    }
+    const int totR = f->read_off[n];
+    f->read_ptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)totR + (size_t)n + 1));
+    f->wif = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
+    f->u = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1));
+    f->bq = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1));
+    size_t at = 0;
+    for (int i = 0; i < n; i++) {
+        SEXP sr = VECTOR_ELT(readsListSEXP, i);
+        const int R = Rf_length(sr);
+        int32_t *rp = f->read_ptr + f->read_off[i] + i;
+        rp[0] = 0;
+        for (int r = 0; r < R; r++) {
+            SEXP rd = VECTOR_ELT(sr, r);
+            const int nb = Rf_length(VECTOR_ELT(rd, 3));
+            f->wif[f->read_off[i] + r] = Rf_asInteger(VECTOR_ELT(rd, 1));
+            memcpy(f->bq + at, INTEGER(VECTOR_ELT(rd, 2)), sizeof(int) * (size_t)nb);
+            memcpy(f->u + at, INTEGER(VECTOR_ELT(rd, 3)), sizeof(int) * (size_t)nb);
+            at += (size_t)nb;
+            rp[r + 1] = rp[r] + nb;
+        }
+    }
+}
+
+SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP, SEXP sample_offsetSEXP, SEXP n_handlesSEXP,
+                            SEXP allReadsListSEXP) {
     const int n = Rf_length(readsListSEXP);
     int n_handles = Rf_asInteger(n_handlesSEXP);
     if (n_handles < 1) n_handles = 1;
@@ -591,35 +638,10 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
         check_status(st, "qa_panel_create");
     }
     /* flatten the range's sampleReads */
-    int32_t *read_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
-    read_off[0] = 0;
-    size_t nbases = 0;
-    for (int i = 0; i < n; i++) {
-        SEXP sr = VECTOR_ELT(readsListSEXP, i);
-        const int R = Rf_length(sr);
-        read_off[i + 1] = read_off[i] + R;
-        for (int r = 0; r < R; r++) nbases += (size_t)Rf_length(VECTOR_ELT(VECTOR_ELT(sr, r), 3));
-    }
+    flat_reads_t fr;
+    flatten_reads(readsListSEXP, &fr);
+    const int32_t *read_off = fr.read_off;
     const int totR = read_off[n];
-    int32_t *read_ptr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)totR + (size_t)n + 1));
-    int32_t *wif = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
-    int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1)), *bq = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1));
-    size_t at = 0;
-    for (int i = 0; i < n; i++) {
-        SEXP sr = VECTOR_ELT(readsListSEXP, i);
-        const int R = Rf_length(sr);
-        int32_t *rp = read_ptr + read_off[i] + i;
-        rp[0] = 0;
-        for (int r = 0; r < R; r++) {
-            SEXP rd = VECTOR_ELT(sr, r);
-            const int nb = Rf_length(VECTOR_ELT(rd, 3));
-            wif[read_off[i] + r] = Rf_asInteger(VECTOR_ELT(rd, 1));
-            memcpy(bq + at, INTEGER(VECTOR_ELT(rd, 2)), sizeof(int) * (size_t)nb);
-            memcpy(u + at, INTEGER(VECTOR_ELT(rd, 3)), sizeof(int) * (size_t)nb);
-            at += (size_t)nb;
-            rp[r + 1] = rp[r] + nb;
-        }
-    }
     qa_impute_params_t ip;
     qa_impute_params_default(&ip);
     ip.nGibbsSamples = (int)num_or(paramsSEXP, "nGibbsSamples", ip.nGibbsSamples);
@@ -640,15 +662,110 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
     ip.Jmax = (int)num_or(paramsSEXP, "Jmax", ip.Jmax);
     ip.seed = (uint64_t)num_or(paramsSEXP, "seed", 1);
     ip.samples_per_launch_set = (int)num_or(paramsSEXP, "samples_per_launch_set", 0);
-    SEXP dosage = PROTECT(Rf_allocMatrix(REALSXP, T, n)), gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T, n));
-    SEXP haps = PROTECT(Rf_allocMatrix(REALSXP, 2 * T, n)), nDosage = PROTECT(Rf_allocVector(INTSXP, n));
+    char msg[512];
+    msg[0] = 0;
+    /* use_mspbwt = TRUE (QUILT2's default; mspbwt.R:225-474): the panel's indices, built here */
+    qa_mspbwt_t *index = NULL;
+    if (flag(paramsSEXP, "use_mspbwt", 0)) {
+        ip.use_mspbwt = 1;
+        ip.mspbwtL = (int)num_or(paramsSEXP, "mspbwtL", ip.mspbwtL);
+        ip.mspbwtM = (int)num_or(paramsSEXP, "mspbwtM", ip.mspbwtM);
+        index = qa_mspbwt_create(K, G, RAW(hapMatcherR), d.nMaxDH, INTEGER(distinctHapsB), (int)num_or(paramsSEXP, "mspbwt_nindices", 4));
+        if (!index) { st = QA_ERR_INVALID; snprintf(msg, sizeof msg, "qa_mspbwt_create: %s", qa_last_error()); }
+        ip.mspbwt_index = index;
+    }
+    /* impute_rare_common = TRUE (functions.R:1042-1123): one all-SNP handle per panel handle, the all-SNP reads */
+    qa_impute_rare_common_t rcq;
+    qa_rare_common_t *rcs[16];
+    int n_rc = 0, T_out = T;
+    flat_reads_t fa;
+    memset(&fa, 0, sizeof fa);
+    memset(&rcq, 0, sizeof rcq);
+    int64_t *rare_ptr = NULL;
+    int32_t *rare_snp = NULL, *L_grid_all = NULL;
+    uint8_t *is_common = NULL;
+    const int rare = flag(paramsSEXP, "impute_rare_common", 0);
+    if (st == QA_OK && rare) {
+        SEXP rc = list_get(panelSEXP, "rare_common");
+        SEXP sic = rc == R_NilValue ? R_NilValue : list_get(rc, "snp_is_common"), rph = rc == R_NilValue ? R_NilValue : list_get(rc, "rare_per_hap_info");
+        SEXP tma = rc == R_NilValue ? R_NilValue : list_get(rc, "transMatRate_t"), lga = rc == R_NilValue ? R_NilValue : list_get(rc, "L_grid");
+        if (sic == R_NilValue || rph == R_NilValue || tma == R_NilValue || Rf_length(rph) != K || allReadsListSEXP == R_NilValue ||
+            Rf_length(allReadsListSEXP) != n) {
+            st = QA_ERR_INVALID;
+            snprintf(msg, sizeof msg, "impute_rare_common: panel_objects$rare_common needs snp_is_common, rare_per_hap_info (one entry per "
+                                      "haplotype), transMatRate_t; and one allSNP_sampleReads per sample");
+        } else {
+            T_out = Rf_length(sic);
+            is_common = (uint8_t *)malloc((size_t)T_out);
+            for (int t = 0; t < T_out; t++) is_common[t] = LOGICAL(sic)[t] ? 1 : 0;
+            rare_ptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)K + 1));
+            rare_ptr[0] = 0;
+            for (int k = 0; k < K; k++) rare_ptr[k + 1] = rare_ptr[k] + Rf_length(VECTOR_ELT(rph, k));
+            rare_snp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rare_ptr[K] > 0 ? rare_ptr[K] : 1));
+            for (int k = 0; k < K; k++)
+                memcpy(rare_snp + rare_ptr[k], INTEGER(VECTOR_ELT(rph, k)), sizeof(int) * (size_t)(rare_ptr[k + 1] - rare_ptr[k]));
+            for (; n_rc < n_handles && st == QA_OK; n_rc++) {
+                rcs[n_rc] = NULL;
+                st = qa_rare_common_create(handles[n_rc], T_out, is_common, rare_ptr, rare_snp, REAL(tma), &rcs[n_rc]);
+            }
+            if (st != QA_OK) snprintf(msg, sizeof msg, "qa_rare_common_create: %s", qa_last_error());
+            flatten_reads(allReadsListSEXP, &fa);
+            rcq.handles = (const qa_rare_common_t *const *)rcs;
+            rcq.nSNPs_all = T_out;
+            rcq.nGrids_all = (T_out + 31) / 32;
+            rcq.snp_is_common = is_common;
+            rcq.read_off = fa.read_off; rcq.read_ptr = fa.read_ptr; rcq.u = fa.u; rcq.bq = fa.bq; rcq.wif = fa.wif;
+            if (lga != R_NilValue && Rf_length(lga) == rcq.nGrids_all) {
+                L_grid_all = (int32_t *)malloc(sizeof(int32_t) * (size_t)rcq.nGrids_all);
+                for (int g = 0; g < rcq.nGrids_all; g++) L_grid_all[g] = TYPEOF(lga) == INTSXP ? INTEGER(lga)[g] : (int32_t)REAL(lga)[g];
+                rcq.L_grid_all = L_grid_all;
+            }
+            ip.rare_common = &rcq;
+        }
+    }
+    /* method = "nipt" (functions.R:586, :1009-1016, :1218-1231): one fetal fraction per sample, the fetus' outputs */
+    qa_impute_nipt_t nq;
+    memset(&nq, 0, sizeof nq);
+    SEXP methodSEXP = list_get(paramsSEXP, "method");
+    const int nipt = methodSEXP != R_NilValue && TYPEOF(methodSEXP) == STRSXP && Rf_length(methodSEXP) == 1 &&
+                     strcmp(CHAR(STRING_ELT(methodSEXP, 0)), "nipt") == 0;
+    const int nL = nipt ? 3 : 2;
+    int32_t *L_grid = NULL;
+    SEXP fet_dosage = R_NilValue, fet_gp_t = R_NilValue;
+    int n_prot = 0;
+    if (st == QA_OK && nipt) {
+        SEXP ff = list_get(paramsSEXP, "ff"), lg = list_get(panelSEXP, "L_grid");
+        if (ff == R_NilValue || TYPEOF(ff) != REALSXP || Rf_length(ff) != n || lg == R_NilValue || Rf_length(lg) != G) {
+            st = QA_ERR_INVALID;
+            snprintf(msg, sizeof msg, "method = \"nipt\": params$ff (one per sample, numeric) and panel_objects$L_grid (nGrids) are needed");
+        } else {
+            L_grid = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
+            for (int g = 0; g < G; g++) L_grid[g] = TYPEOF(lg) == INTSXP ? INTEGER(lg)[g] : (int32_t)REAL(lg)[g];
+            fet_dosage = PROTECT(Rf_allocMatrix(REALSXP, T_out, n));
+            fet_gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T_out, n));
+            n_prot = 2;
+            nq.ff = REAL(ff);
+            nq.L_grid = L_grid;
+            nq.shuffle_bin_radius = (int)num_or(paramsSEXP, "shuffle_bin_radius", 5000);
+            nq.fet_dosage = REAL(fet_dosage);
+            nq.fet_gp_t = REAL(fet_gp_t);
+            ip.nipt = &nq;
+        }
+    }
+    SEXP dosage = PROTECT(Rf_allocMatrix(REALSXP, T_out, n)), gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T_out, n));
+    SEXP haps = PROTECT(Rf_allocMatrix(REALSXP, nL * T_out, n)), nDosage = PROTECT(Rf_allocVector(INTSXP, n));
     SEXP stats = PROTECT(Rf_allocVector(REALSXP, 11));
     int32_t *labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
     int64_t st64[11] = {0};
-    st = qa_impute_samples(handles, n_handles, &ip, n, (int64_t)Rf_asReal(sample_offsetSEXP), read_off, read_ptr, u, bq, wif,
-                           REAL(dosage), REAL(gp_t), REAL(haps), labels, INTEGER(nDosage), st64);
-    char msg[512];
-    snprintf(msg, sizeof msg, "%s", qa_last_error());
+    if (st == QA_OK) {
+        st = qa_impute_samples(handles, n_handles, &ip, n, (int64_t)Rf_asReal(sample_offsetSEXP), read_off, fr.read_ptr, fr.u, fr.bq, fr.wif,
+                               REAL(dosage), REAL(gp_t), REAL(haps), labels, INTEGER(nDosage), st64);
+        if (st != QA_OK) snprintf(msg, sizeof msg, "qa_impute_samples: %s", qa_last_error());
+    }
+    for (int i = 0; i < n_rc; i++) if (rcs[i]) qa_rare_common_destroy(rcs[i]);
+    if (index) qa_mspbwt_destroy(index);
+    free(rare_ptr); free(rare_snp); free(is_common); free(L_grid); free(L_grid_all);
+    if (fa.read_off) flat_reads_free(&fa);
     for (int i = 0; i < n_handles; i++) qa_panel_destroy(handles[i]);
     SEXP lab = PROTECT(Rf_allocVector(VECSXP, n));
     if (st == QA_OK)
@@ -659,17 +776,19 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
             SET_VECTOR_ELT(lab, i, v);
             UNPROTECT(1);
         }
-    free(read_off); free(read_ptr); free(wif); free(u); free(bq); free(labels);
+    flat_reads_free(&fr);
+    free(labels);
     if (st != QA_OK) {
-        UNPROTECT(6);
-        Rf_error("quilt_amd: qa_impute_samples: %s", msg);
+        UNPROTECT(6 + n_prot);
+        Rf_error("quilt_amd: qa_impute_sample_range: %s", msg);
     }
     for (int i = 0; i < 11; i++) REAL(stats)[i] = (double)st64[i];
-    const char *names[] = {"dosage", "gp_t", "phasing_haps", "read_labels", "nDosage", "stats"};
-    SEXP out = PROTECT(named_list(6, names));
+    const char *names[] = {"dosage", "gp_t", "phasing_haps", "read_labels", "nDosage", "stats", "fet_dosage", "fet_gp_t"};
+    SEXP out = PROTECT(named_list(nipt ? 8 : 6, names));
     SET_VECTOR_ELT(out, 0, dosage); SET_VECTOR_ELT(out, 1, gp_t); SET_VECTOR_ELT(out, 2, haps);
     SET_VECTOR_ELT(out, 3, lab); SET_VECTOR_ELT(out, 4, nDosage); SET_VECTOR_ELT(out, 5, stats);
-    UNPROTECT(7);
+    if (nipt) { SET_VECTOR_ELT(out, 6, fet_dosage); SET_VECTOR_ELT(out, 7, fet_gp_t); }
+    UNPROTECT(7 + n_prot);
     return out;
 }
 
@@ -683,7 +802,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_QUILT_Rcpp_make_gl_bound", (DL_FUNC)&qa_QUILT_Rcpp_make_gl_bound, 3},
     {"_QUILT_rcpp_make_eMatRead_t", (DL_FUNC)&qa_QUILT_rcpp_make_eMatRead_t, 15},
     {"qa_shim_release", (DL_FUNC)&qa_shim_release, 0},
-    {"qa_impute_sample_range", (DL_FUNC)&qa_impute_sample_range, 5},
+    {"qa_impute_sample_range", (DL_FUNC)&qa_impute_sample_range, 6},
     {NULL, NULL, 0}};
 
 void R_init_quilt_amd_shim(DllInfo *dll) {

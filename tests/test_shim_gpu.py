@@ -1,0 +1,256 @@
+"""shim/quilt_amd_shim.c EXECUTED on the device under the test runtime of R's C API subset (tests/c/mini_r.c, tests/mini_r.py):
+the registered `.Call` routines are called by name with R-shaped objects, as R's `.Call` would, and their results compared
+with the Python host side's calls of the same library.  (R itself is not in the image: this runs the shim's own marshalling,
+caching, error and registration code -- what `make -C shim check` only type-checks.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    from tests.mini_r import R as Runtime
+    r = Runtime()
+    yield r
+    r.dotcall("qa_shim_release")
+    r.reset()
+
+
+@pytest.fixture(scope="module")
+def panel():
+    from quilt_amd.synth import make_synthetic_panel
+    return make_synthetic_panel(K=1024, nSNPs=96 * 32, seed=21)
+
+
+def _params(R, prm, **more):
+    d = dict(nGibbsSamples=R.integer([prm.nGibbsSamples]), n_seek_its=R.integer([prm.n_seek_its]), Ksubset=R.integer([prm.Ksubset]),
+             Knew=R.integer([prm.Knew]), K_top_matches=R.integer([prm.K_top_matches]), heuristic_match_thin=R.real([prm.heuristic_match_thin]),
+             small_ref_panel_gibbs_iterations=R.integer([prm.small_ref_panel_gibbs_iterations]),
+             small_ref_panel_block_gibbs_iterations=R.integer(list(prm.small_ref_panel_block_gibbs_iterations)),
+             maxDifferenceBetweenReads=R.real([prm.maxDifferenceBetweenReads]), minGLValue=R.real([prm.minGLValue]), Jmax=R.integer([prm.Jmax]),
+             seed=R.real([float(prm.seed)]), samples_per_launch_set=R.integer([2]))
+    d.update(more)
+    return R.named(d)
+
+
+def _check(out, want, nL=2):
+    T = want[0].dosage.shape[0]
+    for i, w in enumerate(want):
+        assert np.array_equal(out["dosage"][:, i], w.dosage)
+        assert np.array_equal(out["gp_t"][:, i].reshape(3, T), w.gp_t)
+        assert np.array_equal(out["phasing_haps"][:, i].reshape(nL, T).T, w.phasing_haps)
+        assert np.array_equal(out["read_labels"][i], w.read_labels)
+        assert out["nDosage"][i] == w.nDosage
+
+
+def test_sample_range_call_equals_the_python_caller(R, panel):
+    """`.Call("qa_impute_sample_range", ...)` with sampleReads lists and the prepared-panel objects == quilt_amd.impute on the
+    same device, bit for bit; two host threads; the routine is registered with six arguments."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    samples = [make_synthetic_sample(panel, seed=810 + i, n_reads=300) for i in range(5)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=77)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    want = impute_samples([dev], samples, prm, sample_offset=4, samples_per_launch_set=2)
+    dev.close()
+    assert R.arity("qa_impute_sample_range") == 6
+    out = R.dotcall("qa_impute_sample_range", R.list([R.sample_reads(s) for s in samples]), R.panel_objects(panel), _params(R, prm),
+                    R.real([4.0]), R.integer([2]), R.nil)
+    assert out["dosage"].shape == (panel.nSNPs, 5) and out["stats"][3] > 0
+    _check(out, want)
+
+
+def test_sample_range_call_quilt2_defaults(R, panel):
+    """use_mspbwt = TRUE with impute_rare_common = TRUE through the routine: the msPBWT indices built inside the call, the
+    all-SNP handle from special_rare_common_objects' entries, allSNP_sampleReads as the sixth argument."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    rc = make_rare_common(panel, 6)
+    samples = [make_synthetic_sample_rare_common(panel, rc, 820 + i, n_reads=300)[0] for i in range(3)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=78, impute_rare_common=True, use_mspbwt=True, mspbwt_nindices=2)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    drc = DeviceRareCommon(dev, rc)
+    want = impute_samples([dev], samples, prm, samples_per_launch_set=2, drcs=[drc])
+    drc.close()
+    dev.close()
+    rare = [R.integer(rc.rare_snp[rc.rare_ptr[k]:rc.rare_ptr[k + 1]]) for k in range(panel.K)]
+    rco = R.named(dict(snp_is_common=R.logical(rc.snp_is_common), rare_per_hap_info=R.list(rare), transMatRate_t=R.real(rc.transMatRate_t_all),
+                       L_grid=R.integer(rc.L_grid_all)))
+    out = R.dotcall("qa_impute_sample_range", R.list([R.sample_reads(s) for s in samples]), R.panel_objects(panel, rare_common=rco),
+                    _params(R, prm, use_mspbwt=R.logical([1]), mspbwtL=R.integer([prm.mspbwtL]), mspbwtM=R.integer([prm.mspbwtM]),
+                            mspbwt_nindices=R.integer([2]), impute_rare_common=R.logical([1])),
+                    R.real([0.0]), R.integer([1]), R.list([R.sample_reads(s.all_snp) for s in samples]))
+    assert out["dosage"].shape == (rc.nSNPs_all, 3)
+    _check(out, want)
+
+
+def test_sample_range_call_nipt(R, panel):
+    """method = "nipt" through the routine: params$ff, panel_objects$L_grid, the fetus' outputs in the returned list."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    samples = [make_synthetic_sample(panel, seed=830 + i, n_reads=300, ff=0.1 + 0.05 * i) for i in range(3)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=79, method="nipt")
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    want = impute_samples([dev], samples, prm, samples_per_launch_set=2)
+    dev.close()
+    out = R.dotcall("qa_impute_sample_range", R.list([R.sample_reads(s) for s in samples]),
+                    R.panel_objects(panel, L_grid=R.integer(panel.L_grid)),
+                    _params(R, prm, method=R.string("nipt"), ff=R.real([s.ff for s in samples]), shuffle_bin_radius=R.integer([prm.shuffle_bin_radius])),
+                    R.real([0.0]), R.integer([1]), R.nil)
+    _check(out, want, nL=3)
+    T = panel.nSNPs
+    for i, w in enumerate(want):
+        assert np.array_equal(out["fet_dosage"][:, i], w.fet_dosage)
+        assert np.array_equal(out["fet_gp_t"][:, i].reshape(3, T), w.fet_gp_t)
+
+
+def test_sample_range_call_raises_r_errors(R, panel):
+    """What the library refuses comes back as an R error with its text (Rf_error), not as a crash or a silent result."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.mini_r import RError
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128)
+    s = make_synthetic_sample(panel, seed=840, n_reads=100)
+    with pytest.raises(RError, match="Incorrect number of arguments"):
+        R.dotcall("qa_impute_sample_range", R.nil, R.nil, R.nil)
+    with pytest.raises(RError, match="panel_objects needs"):
+        R.dotcall("qa_impute_sample_range", R.list([R.sample_reads(s)]), R.named({}), _params(R, prm), R.real([0.0]), R.integer([1]), R.nil)
+    with pytest.raises(RError, match="params.ff"):   # method = "nipt" without fetal fractions
+        R.dotcall("qa_impute_sample_range", R.list([R.sample_reads(s)]), R.panel_objects(panel), _params(R, prm, method=R.string("nipt")),
+                  R.real([0.0]), R.integer([1]), R.nil)
+    with pytest.raises(RError, match="no reads"):
+        R.dotcall("qa_impute_sample_range", R.list([R.sample_reads(s), R.list([])]), R.panel_objects(panel), _params(R, prm), R.real([0.0]),
+                  R.integer([1]), R.nil)
+
+
+def _entry_args(name):
+    import json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return json.load(open(os.path.join(root, "tests", "golden", "callentries.json")))[name]["args"]
+
+
+def _call_by_name(R, name, vals):
+    """`.Call(name, ...)` with the arguments in the reference's order (tests/golden/callentries.json, from RcppExports.cpp);
+    arguments the test does not name are NULL."""
+    order = _entry_args(name)
+    assert set(vals) <= set(order), set(vals) - set(order)
+    return R.dotcall(name, *[vals.get(a, R.nil) for a in order])
+
+
+def _panel_args(R, panel):
+    return dict(hapMatcher=R.integer(np.zeros((1, 1), dtype=np.int32)), hapMatcherR=R.raw(panel.hapMatcherR), use_hapMatcherR=R.logical([1]),
+                distinctHapsB=R.integer(panel.distinctHapsB), distinctHapsIE=R.real(panel.distinctHapsIE),
+                eMatDH_special_matrix_helper=R.integer(panel.eMatDH_special_matrix_helper), eMatDH_special_matrix=R.integer(panel.eMatDH_special_matrix),
+                rhb_t=R.integer(panel.rhb_t), ref_error=R.real([panel.ref_error]))
+
+
+def test_full_panel_entry_38_arguments(R, panel):
+    """`.Call("_QUILT_Rcpp_haploid_dosage_versus_refs", <38 arguments in RcppExports.cpp's order>)`: R's matrices are written in
+    place (dosage, c, alphaHat_t, betaHat_t, gamma_t, gammaSmall_t), best_haps_stuff_list is filled -- the same bytes as the Python
+    mirror's call of the library; a second call re-uses the cached panel handle."""
+    from quilt_amd.driver import thinned_grid_columns
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.reference_single import Rcpp_haploid_dosage_versus_refs
+    K, G, T = panel.K, panel.nGrids, panel.nSNPs
+    rng = np.random.default_rng(3)
+    gl = np.asfortranarray(rng.random((2, T)) * 0.9 + 0.05)
+    cols = thinned_grid_columns(G, 0.1)
+    n_thin = int((cols >= 0).sum())
+    dev = DevicePanel(panel)
+    w = dict(alphaHat_t=np.zeros((K, G), order="F"), betaHat_t=np.zeros((K, G), order="F"), c=np.ones(G), gamma_t=np.zeros((K, G), order="F"),
+             gammaSmall_t=np.zeros((K, n_thin), order="F"), dosage=np.zeros(T), best_haps_stuff_list=[None] * n_thin)
+    Rcpp_haploid_dosage_versus_refs(dev, gl, gammaSmall_cols_to_get=cols, K_top_matches=5, return_gammaSmall_t=True,
+                                    get_best_haps_from_thinned_sites=True, **w)
+    dev.close()
+    pa = _panel_args(R, panel)   # (the same R objects in both calls: the second one finds the cached handle by their identity)
+    pa["transMatRate_t"] = R.real(panel.transMatRate_t)
+    for rep in range(2):
+        a = dict(gl=R.real(gl), arma_alphaHat_t=R.real(np.zeros((K, G))), eigen_alphaHat_t=R.real(np.zeros((1, 1))), betaHat_t=R.real(np.zeros((K, G))),
+                 c=R.real(np.ones(G)), gamma_t=R.real(np.zeros((K, G))), gammaSmall_t=R.real(np.zeros((K, n_thin))),
+                 best_haps_stuff_list=R.list([R.nil] * n_thin), dosage=R.real(np.zeros(T)),
+                 use_eMatDH=R.logical([1]), use_eMatDH_special_symbols=R.logical([0]), gammaSmall_cols_to_get=R.integer(cols),
+                 eMatDH_special_grid_which=R.integer(panel.eMatDH_special_grid_which), eMatDH_special_values_list=R.list([]),
+                 K_top_matches=R.integer([5]), suppressOutput=R.integer([1]), min_emission_prob_normalization_threshold=R.real([1e-100]),
+                 return_betaHat_t=R.logical([1]), return_dosage=R.logical([1]), return_gamma_t=R.logical([1]), return_gammaSmall_t=R.logical([1]),
+                 get_best_haps_from_thinned_sites=R.logical([1]), is_version_2=R.logical([0]), is_version_3=R.logical([0]),
+                 return_extra=R.logical([0]), always_normalize=R.logical([1]), use_eigen=R.logical([0]), normalize_emissions=R.logical([1]))
+        a.update(pa)
+        assert _call_by_name(R, "_QUILT_Rcpp_haploid_dosage_versus_refs", a) is None
+        assert np.array_equal(R.value(a["dosage"]), w["dosage"]) and np.array_equal(R.value(a["c"]), w["c"])
+        for r_name, p_name in (("arma_alphaHat_t", "alphaHat_t"), ("betaHat_t", "betaHat_t"), ("gamma_t", "gamma_t"), ("gammaSmall_t", "gammaSmall_t")):
+            assert np.array_equal(R.value(a[r_name]), w[p_name]), r_name
+        lists = R.value(a["best_haps_stuff_list"])
+        for got, want in zip(lists, w["best_haps_stuff_list"]):
+            assert np.array_equal(got["top_matches"], want["top_matches"]) and np.array_equal(got["top_matches_values"], want["top_matches_values"])
+    assert w["dosage"].std() > 0 and all(len(x["top_matches"]) >= 5 for x in w["best_haps_stuff_list"])
+
+
+@pytest.mark.parametrize("ff", [0.0, 0.2])
+def test_gibbs_entry_63_arguments(R, panel, ff):
+    """`.Call("_QUILT_rcpp_forwardBackwardGibbsNIPT", <63 arguments>)` as impute_one_sample makes it (functions.R:2385-2700): the shim
+    draws the call's uniforms with unif_rand() in the reference's order (reads x sweeps, the first read, per block pass six + two
+    vectors over the reads and -- diploid -- nGrids - 1 for the shard pass; NIPT: the block choice and the label re-draws), between
+    GetRNGstate / PutRNGstate; labels, H_class, hapProbs / genProbs and the state matrices R passed in equal the Python mirror's call
+    with the same numbers."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    G, T = panel.nGrids, panel.nSNPs
+    s = make_synthetic_sample(panel, seed=850, n_reads=400, ff=ff)
+    Rn, Ks, n_burn, n_samp, blocks = s.nReads, 64, 6, 1, np.array([2, 4], dtype=np.int32)
+    n_its, nb = n_burn + n_samp, 2
+    rng = np.random.default_rng(9)
+    which = np.sort(rng.choice(panel.K, Ks, replace=False)).astype(np.int32) + 1
+    start = rng.integers(1, 4 if ff else 3, size=Rn).astype(np.int32)
+    per_block = 8 * Rn + (0 if ff else G - 1)
+    U = rng.random(Rn * n_its + 1 + nb * per_block)
+    ru = U[:Rn * n_its]
+    first_read = min(int(U[Rn * n_its] * Rn), Rn - 1)
+    base = Rn * n_its + 1
+    kw = {}
+    if ff:
+        kw["runif_block"] = np.stack([U[base + b * per_block + 6 * Rn: base + b * per_block + 7 * Rn] for b in range(nb)])
+        kw["runif_resample"] = np.stack([U[base + b * per_block + 7 * Rn: base + b * per_block + 8 * Rn] for b in range(nb)])
+        shard = np.zeros(1)
+    else:
+        shard = np.concatenate([U[base + b * per_block + 8 * Rn: base + (b + 1) * per_block] for b in range(nb)])
+    dev = DevicePanel(panel)
+    want = rcpp_forwardBackwardGibbsNIPT(dev, s, which, start, ru, first_read, shard, ff=ff, n_gibbs_burn_in_its=n_burn, n_gibbs_sample_its=n_samp,
+                                         block_gibbs_iterations=blocks, return_state=True, **kw)
+    dev.close()
+    assert not want["underflow_problem"]
+    R.load_unif(U)
+    z = lambda: R.real(np.zeros((Ks, G)))
+    pl = dict(perform_block_gibbs=R.logical([1]), do_shard_block_gibbs=R.logical([0 if ff else 1]), return_hapProbs=R.logical([1]),
+              return_genProbs=R.logical([1]), use_starting_read_labels=R.logical([1]), shard_check_every_pair=R.logical([1]),
+              gibbs_initialize_iteratively=R.logical([0]), sample_is_diploid=R.logical([0 if ff else 1]), rescale_eMatRead_t=R.logical([1]))
+    a = dict(sampleReads=R.sample_reads(s), transMatRate_tc_H=R.real(np.asarray(panel.transMatRate_t).reshape(2, G - 1, 1, order="F")), ff=R.real([ff]),
+             alphaHat_t1=z(), betaHat_t1=z(), alphaHat_t2=z(), betaHat_t2=z(), eMatGrid_t1=z(), eMatGrid_t2=z(),
+             which_haps_to_use=R.integer(which), wif0=R.integer(s.wif), L_grid=R.integer(panel.L_grid), param_list=R.named(pl),
+             Jmax_local=R.integer([10000]), maxDifferenceBetweenReads=R.real([1e10]), generate_fb_snp_offsets=R.logical([0]),
+             n_gibbs_starts=R.integer([1]), n_gibbs_sample_its=R.integer([n_samp]), n_gibbs_burn_in_its=R.integer([n_burn]),
+             double_list_of_starting_read_labels=R.list([R.list([R.integer(start)])]), class_sum_cutoff=R.real([0.06]),
+             shuffle_bin_radius=R.integer([5000]), block_gibbs_iterations=R.integer(blocks), block_gibbs_quantile_prob=R.real([0.95]))
+    a.update(_panel_args(R, panel))
+    out = _call_by_name(R, "_QUILT_rcpp_forwardBackwardGibbsNIPT", a)
+    assert R.L.mini_r_unif_drawn() == U.size and R.L.mini_r_rng_violations() == 0
+    assert out["underflow_problem"][0] == 0
+    assert np.array_equal(out["H"], want["H"]) and np.array_equal(out["H_class"], want["H_class"])
+    assert np.array_equal(out["double_list_of_ending_read_labels"][0][0], want["H"])
+    assert np.array_equal(out["hapProbs_t"], want["hapProbs_t"])
+    assert np.array_equal(out["genProbsM_t"], want["genProbsM_t"]) and np.array_equal(out["genProbsF_t"], want["genProbsF_t"])
+    for name in ("alphaHat_t1", "alphaHat_t2", "betaHat_t1", "betaHat_t2", "eMatGrid_t1", "eMatGrid_t2"):
+        assert np.array_equal(R.value(a[name]), want[name]), name
+    pit = out["per_it_likelihoods"]
+    assert pit.shape == (n_its, 13) and np.array_equal(pit[:, 2], np.arange(1, n_its + 1)) and np.isfinite(pit[:, 7]).all()
+    assert len(set(out["H"].tolist())) == (3 if ff else 2)
