@@ -1,7 +1,8 @@
 /*
  * qa_r_api.h -- DECLARATION-ONLY subset of R's C API (Rinternals.h / R_ext/Rdynload.h / R_ext/Random.h), used only to
- * type-check quilt_amd_shim.c (`make -C shim check`, gcc -fsyntax-only) on machines without R.  Nothing here is ever
- * linked: a real build includes R's own headers (`make -C shim` with R installed defines QA_HAVE_R).  Signatures follow the
+ * type-check quilt_amd_shim.c (`make -C shim check`, gcc -fsyntax-only) on machines without R.  A real build includes R's own
+ * headers (`make -C shim` with R installed defines QA_HAVE_R) and nothing here is linked; the one thing that implements these
+ * declarations is the TEST runtime tests/c/mini_r.c, under which the repository's tests execute the shim.  Signatures follow the
  * R 4.x headers.
  */
 #ifndef QA_R_API_H

@@ -31,7 +31,10 @@
  * intermediate results (`Rcpp::sample(1:3, 1, prob)` per read in rcpp_sample_H_using_H_class, NIPT only) the stream
  * cannot be pre-drawn in R's order: one uniform per read is drawn instead (documented deviation).
  *
- * Type-checked without R by `make -C shim check` against shim/qa_r_api.h (declarations only).
+ * Type-checked without R by `make -C shim check` against shim/qa_r_api.h (declarations only), and EXECUTED without R by
+ * tests/test_shim_gpu.py / tests/test_shim_cpu.py under tests/c/mini_r.c, a test runtime behind the same declarations (objects
+ * with type, length, names and dim; `.Call` by registered name with R's arity check; Rf_error as an exception; unif_rand() from a
+ * loaded sequence): every routine below is called with R-shaped arguments and compared with the Python mirror's call.
  */
 #ifdef QA_HAVE_R
 #include <R.h>

@@ -254,3 +254,109 @@ def test_gibbs_entry_63_arguments(R, panel, ff):
     pit = out["per_it_likelihoods"]
     assert pit.shape == (n_its, 13) and np.array_equal(pit[:, 2], np.arange(1, n_its + 1)) and np.isfinite(pit[:, 7]).all()
     assert len(set(out["H"].tolist())) == (3 if ff else 2)
+
+
+def _upload_panel_through_the_shim(R, panel):
+    """A common-SNP call of the 63-argument entry: the shim uploads and caches the panel (what a QUILT() run has always done
+    before the calls below are reached)."""
+    from quilt_amd.synth import make_synthetic_sample
+    G = panel.nGrids
+    s = make_synthetic_sample(panel, seed=860, n_reads=60)
+    Ks = 32
+    R.load_unif(np.random.default_rng(1).random(s.nReads * 2 + 1))
+    z = lambda: R.real(np.zeros((Ks, G)))
+    pl = dict(perform_block_gibbs=R.logical([0]), return_hapProbs=R.logical([1]))
+    a = dict(sampleReads=R.sample_reads(s), transMatRate_tc_H=R.real(np.asarray(panel.transMatRate_t).reshape(2, G - 1, 1, order="F")), ff=R.real([0.0]),
+             alphaHat_t1=z(), betaHat_t1=z(), alphaHat_t2=z(), betaHat_t2=z(), eMatGrid_t1=z(), eMatGrid_t2=z(),
+             which_haps_to_use=R.integer(np.arange(1, Ks + 1)), wif0=R.integer(s.wif), L_grid=R.integer(panel.L_grid), param_list=R.named(pl),
+             Jmax_local=R.integer([10000]), maxDifferenceBetweenReads=R.real([1e10]), generate_fb_snp_offsets=R.logical([0]),
+             n_gibbs_starts=R.integer([1]), n_gibbs_sample_its=R.integer([1]), n_gibbs_burn_in_its=R.integer([1]),
+             double_list_of_starting_read_labels=R.list([R.list([R.integer(np.ones(s.nReads, dtype=np.int32))])]), class_sum_cutoff=R.real([0.06]),
+             shuffle_bin_radius=R.integer([5000]), block_gibbs_iterations=R.integer([]), block_gibbs_quantile_prob=R.real([0.95]))
+    pa = _panel_args(R, panel)
+    a.update(pa)
+    out = _call_by_name(R, "_QUILT_rcpp_forwardBackwardGibbsNIPT", a)
+    assert out["underflow_problem"][0] == 0
+    return pa
+
+
+def test_read_likelihood_entry_15_arguments(R, panel):
+    """`.Call("_QUILT_rcpp_make_eMatRead_t", <15 arguments>)` as calculate_eMatRead_t_vs_haplotypes makes it (functions.R:2975-3020):
+    K = 2 sampled haplotypes, slice s of eHapsCurrent_tc, R's K x nReads matrix filled in place; what the entry does not cover
+    is an R error with its reason."""
+    import ctypes as C
+    from quilt_amd.native import DevicePanel, check, lib, ptr
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.mini_r import RError
+    _upload_panel_through_the_shim(R, panel)
+    T = panel.nSNPs
+    s = make_synthetic_sample(panel, seed=861, n_reads=250)
+    rng = np.random.default_rng(4)
+    eh = rng.random((2, T, 2))   # K x nSNPs x S
+    dev = DevicePanel(panel)
+    want = np.zeros((s.nReads, 2))
+    sl = np.ascontiguousarray(eh[:, :, 1].T)   # [SNP][K]: R's K x nSNPs slice, column-major
+    read_off = np.array([0, s.nReads], dtype=np.int32)
+    check(lib().qa_rcpp_make_eMatRead_t_nsnps(dev.handle, C.c_int32(T), C.c_int32(1), C.c_int32(2), ptr(sl), ptr(read_off),
+                                              ptr(np.asarray(s.read_ptr, dtype=np.int32)), ptr(np.asarray(s.u, dtype=np.int32)),
+                                              ptr(np.asarray(s.bq, dtype=np.int32)), C.c_double(1000.0), C.c_int32(1000), C.c_int32(0), ptr(want)))
+    dev.close()
+    em = R.real(np.zeros((2, s.nReads)))
+    args = [em, R.sample_reads(s), R.real(eh), R.integer([1]), R.real([1000.0]), R.integer([1000]), R.real(np.zeros((1, 1))), R.real([0.0]),
+            R.real([0.0]), R.integer([0]), R.integer([1]), R.string("N"), R.string("N"), R.logical([0]), R.logical([0])]
+    assert R.dotcall("_QUILT_rcpp_make_eMatRead_t", *args) is None
+    got = R.value(em)
+    assert np.array_equal(got.T, want) and want.std() > 0
+    args[13] = R.logical([1])
+    with pytest.raises(RError, match="pseudo_haploid"):
+        R.dotcall("_QUILT_rcpp_make_eMatRead_t", *args)
+    args[13], args[0] = R.logical([0]), R.real(np.zeros((5, s.nReads)))
+    with pytest.raises(RError, match="more than 3"):
+        R.dotcall("_QUILT_rcpp_make_eMatRead_t", *args)
+
+
+def test_gibbs_entry_63_arguments_rare_common(R, panel):
+    """The all-SNP call of impute_final_gibbs_with_rare_common (rare_common.R:325-398): make_eMatRead_t_rare_common = TRUE in
+    param_list, the all-SNP transition rates, snp_is_common and rare_per_hap_info as R holds them; the shim builds the all-SNP
+    handle beside the cached panel; hapProbs_t comes back 3 x nSNPs_all and equals the Python mirror's call."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    pa = _upload_panel_through_the_shim(R, panel)
+    rc = make_rare_common(panel, 6)
+    smp = make_synthetic_sample_rare_common(panel, rc, 870, n_reads=300)[0]
+    s = smp.all_snp
+    Ga, Ta = rc.nGrids_all, rc.nSNPs_all
+    Rn, Ks, n_burn, n_samp, blocks = s.nReads, 48, 4, 1, np.array([1], dtype=np.int32)
+    n_its, nb = n_burn + n_samp, 1
+    rng = np.random.default_rng(10)
+    which = np.sort(rng.choice(panel.K, Ks, replace=False)).astype(np.int32) + 1
+    start = rng.integers(1, 3, size=Rn).astype(np.int32)
+    U = rng.random(Rn * n_its + 1 + nb * (8 * Rn + Ga - 1))
+    base = Rn * n_its + 1
+    dev = DevicePanel(panel)
+    drc = DeviceRareCommon(dev, rc)
+    want = rcpp_forwardBackwardGibbsNIPT(dev, s, which, start, U[:Rn * n_its], min(int(U[Rn * n_its] * Rn), Rn - 1), U[base + 8 * Rn:],
+                                         n_gibbs_burn_in_its=n_burn, n_gibbs_sample_its=n_samp, block_gibbs_iterations=blocks,
+                                         disable_read_category_usage=True, rare_common=drc)
+    drc.close()
+    dev.close()
+    R.load_unif(U)
+    z = lambda: R.real(np.zeros((1, 1)))
+    pl = dict(perform_block_gibbs=R.logical([1]), do_shard_block_gibbs=R.logical([1]), return_hapProbs=R.logical([1]), return_genProbs=R.logical([1]),
+              make_eMatRead_t_rare_common=R.logical([1]), disable_read_category_usage=R.logical([1]))
+    rare = [R.integer(rc.rare_snp[rc.rare_ptr[k]:rc.rare_ptr[k + 1]]) for k in range(panel.K)]
+    a = dict(sampleReads=R.sample_reads(s), transMatRate_tc_H=R.real(np.asarray(rc.transMatRate_t_all).reshape(2, Ga - 1, 1, order="F")), ff=R.real([0.0]),
+             alphaHat_t1=z(), betaHat_t1=z(), alphaHat_t2=z(), betaHat_t2=z(), eMatGrid_t1=z(), eMatGrid_t2=z(),
+             which_haps_to_use=R.integer(which), wif0=R.integer(s.wif), L_grid=R.integer(rc.L_grid_all), param_list=R.named(pl),
+             Jmax_local=R.integer([10000]), maxDifferenceBetweenReads=R.real([1e10]), generate_fb_snp_offsets=R.logical([0]),
+             n_gibbs_starts=R.integer([1]), n_gibbs_sample_its=R.integer([n_samp]), n_gibbs_burn_in_its=R.integer([n_burn]),
+             double_list_of_starting_read_labels=R.list([R.list([R.integer(start)])]), class_sum_cutoff=R.real([0.06]),
+             shuffle_bin_radius=R.integer([5000]), block_gibbs_iterations=R.integer(blocks), block_gibbs_quantile_prob=R.real([0.95]),
+             rare_per_hap_info=R.list(rare), snp_is_common=R.logical(rc.snp_is_common))
+    a.update(pa)
+    out = _call_by_name(R, "_QUILT_rcpp_forwardBackwardGibbsNIPT", a)
+    assert R.L.mini_r_unif_drawn() == U.size
+    assert out["hapProbs_t"].shape == (3, Ta)
+    assert np.array_equal(out["H"], want["H"]) and np.array_equal(out["hapProbs_t"], want["hapProbs_t"])
+    assert np.array_equal(out["genProbsM_t"], want["genProbsM_t"])
