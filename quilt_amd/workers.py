@@ -265,20 +265,32 @@ class NativeWorkers:
         for d in self.devs:
             d.close()
 
-    def run_stream(self, batches: Iterable[Tuple[list, int]]):
-        from .impute import impute_samples
+    def prepare(self, batches: Iterable[Tuple[list, int]]):
+        """The stream's samples in the form the C ABI takes them (quilt_amd.impute.PreparedRange: reads back to back, parameter
+        structs): what a caller that holds flat host buffers hands over.  ``run_stream(prepared)`` then starts from there."""
+        from .impute import prepare_range
         batches = list(batches)
         if not batches:
-            return
+            return None
         flat, at = [], batches[0][1]
         for samples, offset in batches:
             if offset != at:
                 raise ValueError("NativeWorkers.run_stream takes consecutive batches (one sample range)")
             flat.extend(samples)
             at += len(samples)
-        res, st = impute_samples(self.devs, flat, self.params, sample_offset=batches[0][1],
-                                 samples_per_launch_set=len(batches[0][0]), fuse_tails=self.fuse_tails, return_stats=True,
-                                 drcs=self.drcs)
+        r = prepare_range(self.devs, flat, self.params, sample_offset=batches[0][1], samples_per_launch_set=len(batches[0][0]),
+                          fuse_tails=self.fuse_tails, drcs=self.drcs)
+        r.batch_sizes = [len(smp) for smp, _ in batches]
+        return r
+
+    def run_stream(self, batches):
+        """``batches``: an iterable of (samples, offset) with consecutive offsets, or what ``prepare`` made of one."""
+        from .impute import PreparedRange, run_prepared
+        prep = batches if isinstance(batches, PreparedRange) else self.prepare(batches)
+        if prep is None:
+            return
+        res, st = run_prepared(prep, return_stats=True)
+        batches = [(res[:n], None) for n in prep.batch_sizes]   # (only the sizes are used below)
         self.stats = st
         for k in ("gibbs", "fullpass", "host", "consensus", "finish", "accumulate"):
             self.timing[k] += st["ms_" + k] / 1e3
