@@ -95,7 +95,10 @@ _BAM_DIR = None
 def _sample_worker(args):
     from quilt_amd.synth import make_synthetic_sample, make_synthetic_sample_rare_common
     seed, n_reads, mode = args
-    if mode == "nipt":   # BASELINE configs[4]: mother + fetus, one fetal fraction for the batch
+    if mode == "nipt" and _CPU_RC is not None:   # NIPT with impute_rare_common: the mixture read over all SNPs as well
+        s = make_synthetic_sample_rare_common(_CPU_PANEL, _CPU_RC, seed, n_reads=n_reads, ff=0.2)[0]
+        s.ff = 0.2
+    elif mode == "nipt":   # BASELINE configs[4]: mother + fetus, one fetal fraction for the batch
         s = make_synthetic_sample(_CPU_PANEL, seed=seed, n_reads=n_reads, ff=0.2)
     elif _CPU_RC is not None:   # the sample read over the common SNPs, with its all-SNP reads attached
         s = make_synthetic_sample_rare_common(_CPU_PANEL, _CPU_RC, seed, n_reads=n_reads)[0]

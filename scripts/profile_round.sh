@@ -45,7 +45,8 @@ python bench.py --mode nipt --steps 12 --warmup 4 --r2-vs-cpu 0 > $OUT/bench_lin
 python bench.py --mspbwt --steps 12 --warmup 4 --dotcall 0 > $OUT/bench_line_mspbwt.json 2> $OUT/bench_mspbwt.err; tail -c 300 $OUT/bench_line_mspbwt.json
 python bench.py --mspbwt --steps 20 --warmup 5 --no-alone --precision fp64 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_mspbwt_steps20.json 2> $OUT/bench_mspbwt20.err; tail -c 300 $OUT/bench_line_mspbwt_steps20.json
 python bench.py --bam --steps 12 --warmup 4 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_from_bam.json 2> $OUT/bench_from_bam.err; tail -c 300 $OUT/bench_line_from_bam.json
-python bench.py --K 5000 --batch 32 --steps 24 --warmup 8 --dotcall 0 > $OUT/bench_line_configs1_K5000_b32.json 2> $OUT/bench_configs1.err; tail -c 300 $OUT/bench_line_configs1_K5000_b32.json
+python bench.py --K 5000 --batch 32 --steps 80 --warmup 16 --dotcall 0 > $OUT/bench_line_configs1_K5000_b32.json 2> $OUT/bench_configs1.err; tail -c 300 $OUT/bench_line_configs1_K5000_b32.json
+python bench.py --K 64976 --steps 8 --warmup 2 --no-alone --precision fp64 --no-cpu-baseline --r2-vs-cpu 0 --dotcall 0 > $OUT/bench_line_K64976.json 2> $OUT/bench_K64976.err; tail -c 300 $OUT/bench_line_K64976.json
+python bench.py --mode nipt --rare-common 2 --steps 4 --warmup 2 --no-alone --no-cpu-baseline --r2-vs-cpu 0 --dotcall 0 > $OUT/bench_line_nipt_rare_common.json 2> $OUT/bench_nipt_rc.err; tail -c 300 $OUT/bench_line_nipt_rare_common.json
 python bench.py --mspbwt --rare-common 2 --steps 8 --warmup 2 --no-alone --precision fp64 --dotcall 0 --r2-vs-cpu 0 > $OUT/bench_line_quilt2_default.json 2> $OUT/bench_quilt2.err; tail -c 300 $OUT/bench_line_quilt2_default.json
-python bench.py --exclusive 0 --workers 4 --steps 20 --warmup 5 --no-cpu-baseline --r2-vs-cpu 0 > $OUT/bench_line_no_device_phases.json 2> $OUT/bench_nophases.err; tail -c 300 $OUT/bench_line_no_device_phases.json
 fi

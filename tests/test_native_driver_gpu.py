@@ -170,3 +170,32 @@ def test_native_driver_nipt_on_the_device(medium_panel):
         assert a.phasing_haps.shape == (panel.nSNPs, 3)
         _same(a, b)
         assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
+
+
+def test_prepared_range_runs_again_with_the_same_result(medium_panel):
+    """quilt_amd.impute.prepare_range + run_prepared (what bench.py times: the range already in the C ABI's flat form) ==
+    impute_samples, and a second run over the same prepared range returns the same bytes -- the library zeroes a set's
+    accumulator rows itself, whatever the caller's arrays held."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_samples, prepare_range, run_prepared
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=4400 + i, n_reads=300) for i in range(5)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=21)
+    devs = [DevicePanel(panel) for _ in range(2)]
+    for d in devs:
+        d.set_device_share(2)
+        d.set_dosage_precision(64)
+        d.set_exclusive(True)
+    want = impute_samples(devs, samples, prm, sample_offset=9, samples_per_launch_set=2)
+    r = prepare_range(devs, samples, prm, sample_offset=9, samples_per_launch_set=2)
+    first, stats = run_prepared(r, return_stats=True)
+    again = run_prepared(r)
+    for d in devs:
+        d.close()
+    assert stats["gibbs_launches"] > 0
+    for a, b, c in zip(first, again, want):
+        _same(a, c)
+        _same(b, c)
+    assert not first[0].phasing_haps.flags.owndata and first[0].phasing_haps.shape == (panel.nSNPs, 2)
