@@ -643,6 +643,10 @@ int qa_impute_params_default(qa_impute_params_t *params);
  *                     its transpose per sample)
  *   read_labels       out, read_off[n_sample] entries: the consensus labels the phasing iteration started from
  *   nDosage           out n_sample: rounds counted
+ *                     (the output arrays need not be initialised: the accumulators' rows are zeroed when a sample's launch set
+ *                     starts, everything else is written whole)
+ *   Left-over launch sets (their number is not a multiple of n_panels) go whole to the first threads; a call with fewer sets
+ *   than threads is cut across them.  Results do not depend on the plan.
  *   stats             NULL, or 11 counters: [0] underflow retries, [1] chains that needed complete best-haplotype lists,
  *                     [2] selections made on the device, [3] chains handed to qa_gibbs_batch, [4] Gibbs launch sets,
  *                     [5..10] ms summed over the host threads: Gibbs calls, full-panel calls, host, consensus, finish, accumulation

@@ -55,6 +55,7 @@ inline Geo64 geo64(int K) {
     g.NR = std::min(g.NCH, 4);
     g.NL = g.NCH - g.NR;
     if (lds_bytes(g) > kLdsMax) { g.NR = 5; g.NL = g.NCH - 5; }
+
     if (g.NCH > 7) {   // 5 rows in registers, 2 in LDS (what 7 full rows take: 152 / 155 KB of LDS), the rest streamed
         g.NS = g.NCH - 7;
         g.NCH = 7; g.NR = 5; g.NL = 2; g.n_last = kNT;
@@ -1134,8 +1135,15 @@ void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mi
 
 void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
     const PassParams &prm = *static_cast<const PassParams *>(pass_params);
-    const Geo64 geo = geo64(prm.K);
+    Geo64 geo = geo64(prm.K);
     if (geo.NCH == 0) throw std::runtime_error("K exceeds the on-chip capacity of the fp64 ranking kernels");
+    // A seven-row panel (K = 50 000) fits as <4, 3> and as <5, 2>.  The ranking pair is bound by its LDS traffic (a row that lives
+    // in LDS costs a read and a write of 16 bytes per two cells beside the table gather), so it takes five rows in registers
+    // although that spills a little more: stand-alone, 256 passes, 200 thinned grids, k_fwd64 11.4 -> 10.6 ms, k_bwd64 16.9 -> 16.4
+    // (10 thinned grids: 9.0 -> 7.8, 9.5 -> 8.6).  The dosage pair streams alpha through HBM and does not care (31.4 / 41.1 against
+    // 32.0 / 40.9 ms): it keeps <4, 3>.  QA_FB64_FOUR_ROWS=1: the ranking pair as before.
+    static const bool four = [] { const char *e = getenv("QA_FB64_FOUR_ROWS"); return e && e[0] == '1'; }();
+    if (!four && geo.NS == 0 && geo.NCH == 7 && geo.NR == 4) { geo.NR = 5; geo.NL = 2; }
     if (prm.Kq != (geo.NCH + geo.NS) * kRowHaps) throw std::runtime_error("internal: Kq does not match the fp64 geometry");
     if (geo.NS > 0) {
         if (!prm.spill) throw std::runtime_error("internal: streamed chunk rows without their buffer");
@@ -1150,8 +1158,8 @@ void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
         case 40: launch<4, 0>(prm, geo, st, e_mid); break;
         case 41: launch<4, 1>(prm, geo, st, e_mid); break;
         case 42: launch<4, 2>(prm, geo, st, e_mid); break;
-        case 52: launch<5, 2>(prm, geo, st, e_mid); break;
 #endif
+        case 52: launch<5, 2>(prm, geo, st, e_mid); break;
         case 43: launch<4, 3>(prm, geo, st, e_mid); break;
         default: throw std::runtime_error("fp64 geometry not built");
     }
