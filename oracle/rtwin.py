@@ -41,13 +41,16 @@ import numpy as np
 def bq_to_probs(bq):
     """STITCH convertScaledBQtoProbs as QUILT uses it (reference-single.R:29; the same convention spelled out in
     make_eMatRead_t_using_binary, reference-single.R:451-459): column 0 = P(base | ref), column 1 = P(base | alt)."""
+    import math
     bq = np.asarray(bq, dtype=np.float64)
     out = np.ones((len(bq), 2))
+    # R's 10^x is the C library's pow(); numpy's vectorised power differs from it in the last bit for some qualities (22, 50, ...)
+    pw = lambda x: np.array([math.pow(10.0, float(v)) for v in x])
     w = bq < 0
-    eps = 10.0 ** (bq[w] / 10.0)
+    eps = pw(bq[w] / 10.0)
     out[w, 0], out[w, 1] = 1 - eps, eps / 3
     w = bq > 0
-    eps = 10.0 ** (-bq[w] / 10.0)
+    eps = pw(-bq[w] / 10.0)
     out[w, 0], out[w, 1] = eps / 3, 1 - eps
     return out
 

@@ -127,6 +127,24 @@ def chain_rng(seed: int, i_sample: int, i_chain: int):
 # host logic restated from the R driver
 # ---------------------------------------------------------------------------------------------
 
+def _phred_eps_table() -> np.ndarray:
+    """10^(-q / 10) for q = 0 .. 255 from the C library's pow(), entry by entry -- what R's ``10^x`` evaluates to
+    (convertScaledBQtoProbs), what the library's tables hold (csrc: "eps tables from the host libm") and what csrc/impute.cpp
+    uses.  numpy's vectorised ``10.0 ** x`` is NOT that function: it differs from pow() in the last bit at q = 22, 50, 61, 78 on
+    this machine, and a last bit in a genotype likelihood is enough to break an exact tie between two identical panel
+    haplotypes at a best-haplotype list's threshold differently (scripts/check_pipeline_seeds.py found it: 6 of 96 runs)."""
+    import math
+    return np.array([math.pow(10.0, -q / 10.0) for q in range(256)])
+
+
+PHRED_EPS = _phred_eps_table()
+
+
+def phred_eps(bq) -> np.ndarray:
+    """Error probability of signed base qualities (|bq| <= 255, the ABI's bound), libm-exact: see ``_phred_eps_table``."""
+    return PHRED_EPS[np.abs(np.asarray(bq)).astype(np.int64)]
+
+
 def make_gl_from_u_bq(u: np.ndarray, bq: np.ndarray, nSNPs: int, minGLValue: float, make_gl_bound) -> np.ndarray:
     """reference-single.R:19-42: per-label genotype likelihoods from the reads' bases (host code in the
     reference too); ``make_gl_bound`` is the native ``Rcpp_make_gl_bound``."""
@@ -137,7 +155,7 @@ def make_gl_from_u_bq(u: np.ndarray, bq: np.ndarray, nSNPs: int, minGLValue: flo
     u, bq = np.asarray(u)[keep], np.asarray(bq)[keep]
     if len(u) == 0:
         return gl
-    eps = 10.0 ** (-np.abs(bq) / 10.0)
+    eps = phred_eps(bq)
     ref = bq < 0
     pR = np.where(ref, 1 - eps, eps / 3)
     pA = np.where(ref, eps / 3, 1 - eps)

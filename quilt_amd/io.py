@@ -195,7 +195,8 @@ def per_sample_counts(gp_t: np.ndarray, sample: SampleReads, nSNPs: int):
     eij = np.round(gp_t[1] + 2 * gp_t[2], 3)
     fij = np.round(gp_t[1] + 4 * gp_t[2], 3)
     max_gen = np.argmax(gp_t, axis=0)
-    eps = 10.0 ** (-np.abs(sample.bq) / 10.0)
+    from .driver import phred_eps
+    eps = phred_eps(sample.bq)   # (pow() of the C library, as R's 10^x and the native code: driver._phred_eps_table)
     p_ref = np.where(sample.bq < 0, 1 - eps, eps / 3)   # STITCH::convertScaledBQtoProbs column 1
     p_alt = np.where(sample.bq < 0, eps / 3, 1 - eps)   # column 2
     c1 = np.bincount(sample.u, weights=p_ref, minlength=nSNPs)
