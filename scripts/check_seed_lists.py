@@ -12,9 +12,15 @@ from tests.oracle_backend import OracleBackend
 
 sd = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 kw = dict(Ksubset=int(sys.argv[2]) if len(sys.argv) > 2 else 128, Knew=int(sys.argv[3]) if len(sys.argv) > 3 else 128)
-panel = make_synthetic_panel(K=5000, nSNPs=3200, seed=11, ref_error=1e-3, nGen=100, expRate=1.0)
-samples = [make_synthetic_sample(panel, seed=5000 + 10 * sd + i, n_reads=800) for i in range(1)]
-prm = DriverParams(nGibbsSamples=3, seed=100 + sd, **kw)
+if os.environ.get("QA_CHECK_QUICK_START"):   # the panel of test_quick_start_shaped_run_bam_to_vcf, QUILT's defaults
+    from quilt_amd.synth import make_1000g_like_panel
+    panel = make_1000g_like_panel(K=5008, nSNPs=3200, seed=2504)
+    samples = [make_synthetic_sample(panel, seed=77, n_reads=1000)]
+    prm = DriverParams(seed=sd)
+else:
+    panel = make_synthetic_panel(K=5000, nSNPs=3200, seed=11, ref_error=1e-3, nGen=100, expRate=1.0)
+    samples = [make_synthetic_sample(panel, seed=5000 + 10 * sd + i, n_reads=800) for i in range(1)]
+    prm = DriverParams(nGibbsSamples=3, seed=100 + sd, **kw)
 log = {}
 orig = drv.everything_select_good_haps_dense
 def logged(Knew, K_top, top, prev, K, seed, truncated=False):
@@ -25,6 +31,8 @@ cur = ["oracle"]
 ref = Driver(panel, OracleBackend(panel), prm).run(samples)
 dev = DevicePanel(panel)
 dev.set_dosage_precision(64)
+n_dup = len(panel.hapMatcherR) - len(np.unique(np.asarray(panel.hapMatcherR), axis=0))
+print("haplotypes that repeat another one over the whole region:", n_dup, "of", panel.K)
 be = HipBackend(dev)
 be.select_on_device = False
 cur[0] = "device"

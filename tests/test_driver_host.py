@@ -643,3 +643,10 @@ def test_fused_phasing_tail_in_the_other_modes(mode):
                 assert np.array_equal(g.dosage, r.dosage) and np.array_equal(g.phasing_haps, r.phasing_haps)
                 if mode == "nipt":
                     assert np.array_equal(g.fet_dosage, r.fet_dosage) and np.array_equal(g.fet_gp_t, r.fet_gp_t)
+
+
+def test_phred_eps_is_the_c_librarys_pow():
+    import math
+    from quilt_amd.driver import phred_eps
+    q = np.arange(-93, 94)
+    assert all(float(e) == math.pow(10.0, -abs(int(v)) / 10.0) for e, v in zip(phred_eps(q), q))

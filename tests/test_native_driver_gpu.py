@@ -199,3 +199,28 @@ def test_prepared_range_runs_again_with_the_same_result(medium_panel):
         _same(a, c)
         _same(b, c)
     assert not first[0].phasing_haps.flags.owndata and first[0].phasing_haps.shape == (panel.nSNPs, 2)
+
+
+def test_native_loop_equals_python_loop_over_seeds_that_reach_the_complete_lists_branch():
+    """The panel and parameters of scripts/check_pipeline_seeds.py (K = 5 000 over 100 grids, Knew = Ksubset: the device selection
+    regularly runs out of ranked candidates and both host loops fetch complete lists from genotype likelihoods THEY build): the
+    native loop and the Python loop on the same device, seed after seed, bit for bit.  (Seeds 0 and 3 parted until the Python side
+    took 10^(-q/10) from the C library's pow() like the native side: driver.phred_eps.)"""
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=5000, nSNPs=3200, seed=11, ref_error=1e-3, nGen=100, expRate=1.0)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    refetches = 0
+    for sd in range(8):
+        samples = [make_synthetic_sample(panel, seed=5000 + 10 * sd + i, n_reads=800) for i in range(2)]
+        prm = DriverParams(nGibbsSamples=3, seed=100 + sd, Ksubset=128, Knew=128)
+        got, stats = impute_samples([dev], samples, prm, return_stats=True)
+        want = Driver(panel, HipBackend(dev), prm).run(samples)
+        refetches += stats["full_list_refetches"]
+        for a, b in zip(got, want):
+            _same(a, b)
+    dev.close()
+    assert refetches > 0
