@@ -1722,9 +1722,44 @@ static int make_eMatRead_t_impl(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, 
             base_off[c + 1] = base_off[c] + (read_ptr + read_off[c] + c)[R];
         }
         const int totR = read_off[C], totB = base_off[C];
-        for (int i = 0; i < totB; i++) if (u[i] < 0 || u[i] >= T) throw std::runtime_error("read SNP index out of range");
-        std::vector<int32_t> bq_eff(bq, bq + totB);
-        fold_zero_base_qualities(bq_eff, C, read_off, read_ptr, base_off, Jmax);
+        // validation, the copy of the qualities and the bq == 0 carry-over are per chain: on the call's host threads (the driver's
+        // read-confidence call carries every chain of a launch set: 90 M bases, 0.25 s on one thread -- and at the end of a
+        // stream nothing runs beside it)
+        std::vector<int32_t> bq_eff((size_t)std::max(totB, 1));
+        {
+            const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), C));
+            std::vector<std::string> errs(n_thr);
+            auto work = [&](int tid) {
+                try {
+                    for (int c = tid; c < C; c += n_thr) {
+                        const int R = read_off[c + 1] - read_off[c];
+                        const int32_t *rp = read_ptr + read_off[c] + c;
+                        const size_t b0 = (size_t)base_off[c];
+                        for (int i = 0; i < rp[R]; i++) {
+                            if (u[b0 + i] < 0 || u[b0 + i] >= T) throw std::runtime_error("read SNP index out of range");
+                            bq_eff[b0 + i] = bq[b0 + i];
+                        }
+                        int last = 0;   // fold_zero_base_qualities for this chain
+                        for (int r = 0; r < R; r++) {
+                            int J = rp[r + 1] - rp[r] - 1;
+                            if (J >= Jmax) J = Jmax;
+                            for (int j = 0; j <= J; j++) {
+                                int32_t &q = bq_eff[b0 + rp[r] + j];
+                                if (q == 0) q = last; else last = q;
+                                if (q > 255 || q < -255) throw std::runtime_error("|base quality| > 255");
+                            }
+                        }
+                    }
+                } catch (const std::exception &e) {
+                    errs[tid] = e.what();
+                }
+            };
+            std::vector<std::thread> th;
+            for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
+            work(0);
+            for (auto &t : th) t.join();
+            for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+        }
         const std::vector<double> tabs = base_quality_tables();
         // carved from the handle's arena (no launch set of this handle is in flight during this call): a call-local
         // hipMalloc / hipFree pair would synchronise the device with the other host threads' launches
