@@ -1137,9 +1137,9 @@ void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
     const PassParams &prm = *static_cast<const PassParams *>(pass_params);
     Geo64 geo = geo64(prm.K);
     if (geo.NCH == 0) throw std::runtime_error("K exceeds the on-chip capacity of the fp64 ranking kernels");
-    // A seven-row panel (K = 50 000) fits as <4, 3> and as <5, 2>.  The ranking pair is bound by its LDS traffic (a row that lives
-    // in LDS costs a read and a write of 16 bytes per two cells beside the table gather), so it takes five rows in registers
-    // although that spills a little more: stand-alone, 256 passes, 200 thinned grids, k_fwd64 11.4 -> 10.6 ms, k_bwd64 16.9 -> 16.4
+    // A seven-row panel (K = 50 000) fits as <4, 3> and as <5, 2>.  The ranking pair is bound by instruction issue (counters:
+    // VALU 54 %, everything 77 % of SIMD cycles) and a row that lives in LDS costs a ds_read and a ds_write per two cells beside the
+    // table gather, so it takes five rows in registers although that spills a little more: stand-alone, 256 passes, 200 thinned grids, k_fwd64 11.4 -> 10.6 ms, k_bwd64 16.9 -> 16.4
     // (10 thinned grids: 9.0 -> 7.8, 9.5 -> 8.6).  The dosage pair streams alpha through HBM and does not care (31.4 / 41.1 against
     // 32.0 / 40.9 ms): it keeps <4, 3>.  QA_FB64_FOUR_ROWS=1: the ranking pair as before.
     static const bool four = [] { const char *e = getenv("QA_FB64_FOUR_ROWS"); return e && e[0] == '1'; }();
