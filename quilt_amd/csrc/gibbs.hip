@@ -1000,23 +1000,8 @@ thread_local std::unique_ptr<GibbsHolder> g_gibbs;
 
 // the reference carries pR / pA over bases with bq == 0, even across reads (gibbs-small.cpp:139-181,
 // copied-from-stitch.cpp:139-175): fold that rule into an "effective" base quality (input marshalling)
-void fold_zero_base_qualities(std::vector<int32_t> &bq_eff, int C, const int32_t *read_off, const int32_t *read_ptr,
-                              const std::vector<int32_t> &base_off, int Jmax) {
-    for (int c = 0; c < C; c++) {
-        const int R = read_off[c + 1] - read_off[c];
-        const int32_t *rp = read_ptr + read_off[c] + c;
-        int last = 0;
-        for (int r = 0; r < R; r++) {
-            int J = rp[r + 1] - rp[r] - 1;
-            if (J >= Jmax) J = Jmax;
-            for (int j = 0; j <= J; j++) {
-                int32_t &b = bq_eff[(size_t)base_off[c] + rp[r] + j];
-                if (b == 0) b = last; else last = b;
-                if (b > 255 || b < -255) throw std::runtime_error("|base quality| > 255");
-            }
-        }
-    }
-}
+// The bq == 0 carry-over ("fold_zero_base_qualities"): a base without a quality takes the last quality seen in its chain's reads
+// (0 until one is seen); |bq| <= 255.  Applied per chain by the callers' host threads (gibbs_chunk, make_eMatRead_t_impl).
 
 // eps tables with the host libm (what the reference's pow() is), so the device needs no pow:
 // [0..255] pR for bq < 0, [256..511] pR for bq > 0, [512..767] pA for bq < 0, [768..1023] pA for bq > 0
