@@ -190,3 +190,39 @@ def test_native_loop_nipt(twin_panel, n_threads, per_set):
         assert a.phasing_haps.shape == (panel.nSNPs, 3) and (a.read_labels == 3).any()
         _same(a, b)
         assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
+
+
+def test_result_does_not_depend_on_the_plan_for_left_over_sets():
+    """Seven launch sets of three samples over three host threads leave one over: it goes whole to the first thread (the default) or is cut across
+    the threads (QA_IMPUTE_CUT_LEFTOVERS=1, read once per process: two child processes).  Same bytes either way."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+from quilt_amd.driver import DriverParams
+from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+from tests.native_driver_backend import impute_samples_on_oracle
+panel = make_synthetic_panel(K=200, nSNPs=320, seed=3)
+samples = [make_synthetic_sample(panel, seed=700 + i, n_reads=60) for i in range(21)]
+P = DriverParams(nGibbsSamples=2, n_seek_its=2, Ksubset=32, Knew=32, seed=5, small_ref_panel_gibbs_iterations=3,
+                 small_ref_panel_block_gibbs_iterations=(1,))
+got, stats, _ = impute_samples_on_oracle(panel, samples, P, samples_per_launch_set=3, n_threads=3)
+h = hashlib.sha256()
+for g in got:
+    for a in (g.dosage, g.gp_t, np.ascontiguousarray(g.phasing_haps), g.read_labels):
+        h.update(np.ascontiguousarray(a).tobytes())
+print("HASH", h.hexdigest(), stats["gibbs_launches"])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for cut in ("0", "1"):
+        env = dict(os.environ, QA_IMPUTE_CUT_LEFTOVERS=cut)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = [x for x in r.stdout.splitlines() if x.startswith("HASH")][0].split()
+        out[cut] = (line[1], int(line[2]))
+    assert out["0"][0] == out["1"][0]
+    assert out["1"][1] > out["0"][1]   # (the cut plan makes more, smaller launches)
