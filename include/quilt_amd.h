@@ -152,6 +152,17 @@ int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits);
  * both from the one fp64 state. */
 int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits);
 
+/* VALIDATION MODE.  reference_order = 1: every full-panel pass of this handle (lists, dosage, alphaHat_t / betaHat_t / gamma_t)
+ * runs on kernels that form each K-wide sum -- the forward column sum (reference-single.cpp:1002-1075), the backward
+ * sum_e_times_b (:1899-1955), alpha(0)'s sum (:2349-2353), matched_gammas (:2083-2091) -- in the reference's own order:
+ * the grid's special haplotypes first, then k = 0 .. K-1 one after the other, added by a single lane.  A floating-point sum in
+ * a prescribed order does not parallelise, so this mode is 20-50x slower than the default (block-wide tree sums, whose last
+ * bits differ from a sequential sum's).  Its purpose: on panels with many identical or exactly tied haplotypes the last bits of
+ * those sums decide which of the tied haplotypes make a best-haplotype list ("ties"); with this mode the
+ * device reproduces the CPU path's lists, c, alpha / beta and dosage bit for bit, which proves the order of the sums to be the
+ * only difference between the two.  K <= 57 344.  0 (default): the production kernels. */
+int qa_panel_set_sum_order(qa_panel_t *panel, int32_t reference_order);
+
 /* Tell the library that n_sharers panel handles (normally one per host thread, each with its own stream and arena)
  * work on this device at the same time: each then sizes its scratch for 1 / n_sharers of the free memory and its Gibbs
  * launches for 1 / n_sharers of the SIMDs.  Two host threads hide each other's host-side phases (marshalling, the R-level
@@ -661,56 +672,8 @@ int qa_impute_samples(qa_panel_t *const *panels, int32_t n_panels, const qa_impu
 /* The host threads' marshalling and pinned transfer buffers are kept per panel handle between calls (a launch set of 2 048
  * chains moves ~3.5 GB through them): this frees them all.  Call it when no qa_impute_samples call is running. */
 int qa_impute_release_buffers(void);
-
-/*
- * Test hook: the same loop over a caller-supplied table of the batched entry points it calls (signatures = the qa_*
- * functions named in the comments, with an opaque handle in place of the panel).  The product table is the library's own
- * functions; tests/ pass a checker's (the CPU oracle) to run this very host code without a device.  Nothing in the
- * library calls it.
- */
-typedef struct {
-    int (*gibbs_batch)(void *handle, const qa_gibbs_opts_t *opts, int32_t n_chain, const int32_t *which_haps_to_use_1based,
-                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif,
-                       const double *runif_reads, const int32_t *first_read, const double *runif_shard, int32_t *H,
-                       int32_t *H_class, double *hapProbs_t, double *genProbsM_t, double *genProbsF_t, int32_t *underflow_problem,
-                       double *state_out, const uint64_t *seed_reads, const uint64_t *seed_shard);   /* qa_gibbs_batch */
-    int (*fullpass_reads_select_batch)(void *handle, int32_t n_chain, int32_t n_label, int32_t n_sample, const int32_t *chain_sample,
-                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *H,
-                       const int32_t *want_dosage, const int32_t *want_top, const int32_t *gammaSmall_cols_to_get,
-                       int32_t K_top_matches, double minGLValue, double *dosage, int32_t top_width, int32_t *top_idx,
-                       float *top_val, int32_t *top_cnt, int32_t Ksubset, int32_t Knew, const int32_t *which_haps_to_use,
-                       const uint64_t *seed_select, int32_t *which_next, int32_t *select_status);   /* qa_fullpass_reads_select_batch */
-    int (*fullpass_batch)(void *handle, int32_t n_pass, const double *gl, const int32_t *want_dosage,
-                       const int32_t *gammaSmall_cols_to_get, int32_t K_top_matches, double *dosage, int32_t *best_ptr,
-                       int32_t *best_idx, double *best_val, int64_t best_cap);                        /* qa_fullpass_batch */
-    int (*make_eMatRead_t_hap_major)(void *handle, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
-                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
-                       double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t, double *eMatRead_t);
-    int (*mspbwt_select_new_haps)(const qa_mspbwt_t *index, int32_t n_chain, int32_t n_label, const int32_t *Zs, int32_t L,
-                       int32_t M, int32_t Knew, const uint64_t *seed, int32_t *out);                  /* qa_mspbwt_select_new_haps */
-    int (*accumulate_dosage)(int32_t n_chain, int32_t n_label, int32_t nSNPs, const double *hap, const int32_t *chain_sample,
-                       int32_t n_sample, double *dosage, double *gp_t, double *fet_dosage, double *fet_gp_t);
-    int (*consensus_read_labels)(int32_t nReads, int32_t n, const int32_t *labels, const double *p, int32_t K, double minrp,
-                       int32_t can_hap, int32_t *out);
-    void *(*host_alloc)(size_t bytes);
-    int (*host_free)(void *p);
-    void (*bind_thread)(void *handle);   /* may be NULL */
-    /* impute_rare_common only (may be NULL otherwise): qa_gibbs_batch_rare_common and qa_rcpp_make_eMatRead_t_nsnps */
-    int (*gibbs_batch_rare_common)(void *handle, const void *rc, const qa_gibbs_opts_t *opts, int32_t n_chain,
-                       const int32_t *which_haps_to_use_1based, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
-                       const int32_t *bq, const int32_t *wif, const double *runif_reads, const int32_t *first_read,
-                       const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t, double *genProbsM_t,
-                       double *genProbsF_t, int32_t *underflow_problem, double *state_out, const uint64_t *seed_reads,
-                       const uint64_t *seed_shard);
-    int (*make_eMatRead_t_nsnps)(void *handle, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
-                       const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
-                       double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t, double *eMatRead_t);
-} qa_impute_backend_t;
-int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,
-                              int32_t nSNPs, const qa_impute_params_t *params, int32_t n_sample, int64_t sample_offset,
-                              const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
-                              const int32_t *wif, double *dosage, double *gp_t, double *phasing_haps, int32_t *read_labels,
-                              int32_t *nDosage, int64_t *stats);
+/* Diagnostic: the number of panel handles that currently keep such buffers (qa_panel_destroy drops its handle's). */
+int qa_impute_kept_buffers(void);
 
 #ifdef __cplusplus
 }

@@ -121,8 +121,11 @@ __global__ __launch_bounds__(256) void k_emat(PassParams prm) {
         const double wsp = wave_min(sp_min);
         if ((t & 63) == 0) s_red[2][wv] = wsp;
         __syncthreads();
-        if (t == 0)
-            prm.emin[(size_t)p * prm.G + g] = fmin(row0 * scale, fmin(fmin(s_red[2][0], s_red[2][1]), fmin(s_red[2][2], s_red[2][3])));
+        if (t == 0) {
+            const double m = fmin(row0 * scale, fmin(fmin(s_red[2][0], s_red[2][1]), fmin(s_red[2][2], s_red[2][3])));
+            prm.emin[(size_t)p * prm.G + g] = m;
+            if (g == 1) prm.emin_b1[p] = s_var != 0 ? m : -1.0;   // the backward pass does not force grid 1 (:1866-1877)
+        }
     }
 }
 
@@ -804,13 +807,13 @@ __global__ void k_unpermute(const TS *src, double *dst, int K, int Kq, int NT, i
 // host side
 // ---------------------------------------------------------------------------------------------
 struct qa_panel::Scratch {
-    qa::ABuf<double> gl, c, dosage, escale0, unperm, emin, spill;
+    qa::ABuf<double> gl, c, dosage, escale0, unperm, emin, emin_b1, spill;
     qa::ABuf<char> emat, esp, alpha, gamma, beta, beta_thin, top_val, mg, gsp;   // fp32 or fp64 elements (the launch decides)
     qa::ABuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
     qa::DBuf<int32_t> todo;   // (grid, pass) pairs handed to k_topk: persistent, grow-only
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     explicit Scratch(qa::Arena *a) {
-        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = spill.arena = a;
+        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = emin_b1.arena = spill.arena = a;
         emat.arena = esp.arena = alpha.arena = mg.arena = gsp.arena = gamma.arena = beta.arena = beta_thin.arena = top_val.arena = a;
         thin_col.arena = flags.arena = alpha_slot.arena = top_cnt.arena = top_idx.arena = a;
     }
@@ -842,7 +845,9 @@ thread_local double g_timing[6] = {0, 0, 0, 0, 0, 0};   // emat, forward, backwa
 //                  (k_fwd64 + k_bwd64d, fullpass64.hip): the DOSAGE passes of qa_panel_set_dosage_precision(64)
 //   KIND_F64_FULL  fp64 state through the generic kernels (k_fwd / k_bwd<double>, one wave per SIMD): any output in
 //                  double (alphaHat_t / betaHat_t / gamma_t of the single-pass entry point in that mode); not tuned (it spills)
-enum PassKind { KIND_F32 = 0, KIND_F64_RANK = 1, KIND_F64_FULL = 2, KIND_F64_DOS = 3 };
+//   KIND_F64_REF   VALIDATION MODE (qa_panel_set_sum_order(panel, 1), fullpass_ref.hip): fp64 state, the reference's lazy
+//                  normalisation, every K-wide sum added in the reference's order by one lane; any output; slow on purpose
+enum PassKind { KIND_F32 = 0, KIND_F64_RANK = 1, KIND_F64_FULL = 2, KIND_F64_DOS = 3, KIND_F64_REF = 4 };
 struct Geometry { int NT, NCH; PassKind kind; bool f64() const { return kind != KIND_F32; } };
 
 // Register-resident geometry: NT threads (multiple of 64) x NCH chunks of 16 haplotypes per lane.  fp32 state:
@@ -858,7 +863,7 @@ Geometry pick_geometry(int K, PassKind kind = KIND_F32) {
         if (kind == KIND_F64_DOS && nch && qa::fb64_dos_lds_bytes(K) > 160 * 1024) nch = 0;
         return {nch ? 512 : 0, nch, kind};
     }
-    if (kind == KIND_F64_FULL) {
+    if (kind == KIND_F64_FULL || kind == KIND_F64_REF) {   // (the validation kernels write the generic kernels' layout)
         const int need = (K + 4095) / 4096;
         for (int nch : kNchList64) if (nch >= need) return {256, nch, kind};
         return {0, 0, kind};
@@ -888,6 +893,7 @@ size_t pass_bytes(const qa_panel *pn, const Geometry &geo, int n_thin, bool stor
     if (beta) b += G * Kq * es;
     if (n_thin > 0) b += (size_t)n_thin * Kq * es + (size_t)n_thin * (4 + 8 + 64 * 12);   // (lists of up to 64 entries)
     if (geo.kind == KIND_F64_RANK || geo.kind == KIND_F64_DOS) b += (size_t)qa::fb64_spill_rows(pn->K) * 8192 * 8;   // streamed chunk rows
+    if (geo.kind == KIND_F64_REF) b += qa::fb_ref_state_doubles((int)Kq) * 8;   // state + gamma column in k order
     return b + 256 * 24;
 }
 
@@ -933,6 +939,10 @@ void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, h
         qa::launch_fb64(&prm, st, e_mid);
         return;
     }
+    if (geo.kind == KIND_F64_REF) {
+        qa::launch_fb_ref(&prm, geo.NT, st, e_mid);
+        return;
+    }
     if (geo.kind == KIND_F64_FULL) {
         switch (geo.NCH) {
 #ifndef QA_FAST_BUILD
@@ -970,10 +980,14 @@ void launch_fb_any(const Geometry &geo, const PassParams &prm, hipStream_t st, h
 // the kernels behind the dosage passes of a handle: fp32 state, or (qa_panel_set_dosage_precision(64)) the fp64 dosage
 // kernels -- the generic fp64 kernels when K exceeds those kernels' on-chip capacity
 PassKind dosage_kind(const qa_panel *pn) {
+    if (pn->sum_order_ref) return KIND_F64_REF;
     // (panels beyond the fp32 kernels' 98 304 haplotypes: the fp64 dosage kernels, whose chunk rows past the seventh stream)
     if (!pn->dosage_fp64 && pick_geometry(pn->K, KIND_F32).NT) return KIND_F32;
     return pick_geometry(pn->K, KIND_F64_DOS).NT ? KIND_F64_DOS : KIND_F64_FULL;
 }
+
+// the kernels behind the best-haplotype lists of a handle with fp64 ranking
+PassKind rank_kind(const qa_panel *pn) { return pn->sum_order_ref ? KIND_F64_REF : KIND_F64_RANK; }
 
 struct BatchOut {
     double *dosage = nullptr;        // [P][T] (row p, or dosage_rows[p] when given)
@@ -1006,7 +1020,8 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     const Geometry geo = pick_geometry(pn->K, kind);
     if (geo.NT == 0) {
         qa::set_error("K = %d exceeds the on-chip capacity of the %s full-pass kernels", pn->K,
-                      kind == KIND_F32 ? "fp32" : kind == KIND_F64_RANK ? "fp64 ranking" : kind == KIND_F64_DOS ? "fp64 dosage" : "generic fp64");
+                      kind == KIND_F32 ? "fp32" : kind == KIND_F64_RANK ? "fp64 ranking" : kind == KIND_F64_DOS ? "fp64 dosage" :
+                      kind == KIND_F64_REF ? "reference-order validation" : "generic fp64");
         return QA_ERR_UNSUPPORTED;
     }
     const bool f64 = geo.f64();
@@ -1053,7 +1068,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     const bool fused = any_top && kind == KIND_F64_RANK && out.truncate_lists && out.top_cap <= 64;
     const size_t alpha_col = kind == KIND_F64_DOS ? qa::fb64_alpha_col_elems(K) : (size_t)Kq;
     const size_t alpha_stride = max_cols * alpha_col;
-    const bool lazy = kind == KIND_F64_RANK || kind == KIND_F64_DOS;
+    const bool lazy = kind == KIND_F64_RANK || kind == KIND_F64_DOS || kind == KIND_F64_REF;
     const size_t esp_stride = (size_t)pn->n_special + (lazy ? 16 * (size_t)pn->n_sp_grids : 0) + 16;
 
     if (gl) {   // host gl; otherwise the caller has filled S.gl on the device already (k_make_gl)
@@ -1069,6 +1084,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     S.emat.ensure((size_t)P * G * kMaxRow * es);
     S.escale0.ensure(P);
     S.emin.ensure((size_t)P * G);
+    S.emin_b1.ensure(P);
     S.esp.ensure((size_t)P * esp_stride * es);
     S.gsp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1) * es);
     S.alpha.ensure((size_t)P * alpha_stride * es + ((size_t)1 << 20));   // (slack: k_bwd64d's idle lanes fetch a fixed line past a short column)
@@ -1080,7 +1096,8 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     if (any_top) S.beta_thin.ensure((size_t)P * n_thin * Kq * es);
     int top_cap = out.top_cap;
     S.top_cnt.ensure(std::max<size_t>((size_t)P * std::max(n_thin, 1), 1));
-    const size_t spill_stride = lazy ? (size_t)qa::fb64_spill_rows(K) * 8192 : 0;   // doubles per pass: chunk rows streamed through HBM
+    const size_t spill_stride = kind == KIND_F64_REF ? qa::fb_ref_state_doubles(Kq)   // the validation kernels' state (when not in LDS)
+                                : lazy ? (size_t)qa::fb64_spill_rows(K) * 8192 : 0;   // doubles per pass: chunk rows streamed through HBM
     if (spill_stride) S.spill.ensure((size_t)P * spill_stride);
 
     PassParams prm{};
@@ -1092,7 +1109,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.P = P; prm.gl = S.gl.p; prm.thin_col = S.thin_col.p; prm.n_thin = n_thin; prm.flags = S.flags.p;
     prm.normalize_emissions = normalize_emissions;
     prm.lazy = lazy ? 1 : 0; prm.always_normalize = always_normalize; prm.norm_threshold = norm_threshold;
-    prm.emin = S.emin.p; prm.esp_stride = (int)esp_stride;
+    prm.emin = S.emin.p; prm.emin_b1 = S.emin_b1.p; prm.esp_stride = (int)esp_stride;
 
     prm.spill = spill_stride ? S.spill.p : nullptr; prm.spill_pass_stride = spill_stride;
     prm.emat = S.emat.p; prm.esp = S.esp.p; prm.escale0 = S.escale0.p; prm.alpha = S.alpha.p; prm.alpha_slot = S.alpha_slot.p;
@@ -1130,7 +1147,8 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     launch_fb_any(geo, prm, st, S.ev[2]);
     QA_HIP(hipEventRecord(S.ev[3], st));
     const dim3 dgrid((G + kDosageGridsPerBlock - 1) / kDosageGridsPerBlock, P);
-    if (f64) hipLaunchKernelGGL(k_dosage<double>, dgrid, dim3(256), 0, st, prm);
+    if (kind == KIND_F64_REF) { /* the validation backward kernel wrote the dosage itself, sums in the reference's order */ }
+    else if (f64) hipLaunchKernelGGL(k_dosage<double>, dgrid, dim3(256), 0, st, prm);
     else hipLaunchKernelGGL(k_dosage<float>, dgrid, dim3(256), 0, st, prm);
     QA_HIP(hipGetLastError());
     QA_HIP(hipEventRecord(S.ev[4], st));
@@ -1393,7 +1411,8 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         // generic fp64 kernels
         const bool matrices = alphaHat_t || o->return_betaHat_t || o->return_gamma_t || o->return_gammaSmall_t;
         const bool f32_fits = pick_geometry(panel->K, KIND_F32).NT != 0;
-        const PassKind main_kind = (!panel->dosage_fp64 && f32_fits) ? KIND_F32 : (matrices || !o->return_dosage) ? KIND_F64_FULL : dosage_kind(panel);
+        const PassKind main_kind = panel->sum_order_ref ? KIND_F64_REF   // validation mode: one pass of the reference-order kernels yields everything
+                                   : (!panel->dosage_fp64 && f32_fits) ? KIND_F32 : (matrices || !o->return_dosage) ? KIND_F64_FULL : dosage_kind(panel);
         if (pick_geometry(panel->K, main_kind).NT == 0 && !(want_lists && panel->rank_fp64 && only_thin)) {
             // K x nGrids outputs (alphaHat_t / betaHat_t / gamma_t / gammaSmall_t) come from kernels that keep the whole state
             // on chip; the dosage and the best-haplotype lists (what the driver path asks for) have no such limit
@@ -1412,7 +1431,7 @@ int qa_Rcpp_haploid_dosage_versus_refs(
                 BatchOut out2;
                 out2.lists = &lists;
                 const int32_t f0 = 0;
-                const PassKind rk = panel->rank_fp64 ? KIND_F64_RANK : KIND_F32;
+                const PassKind rk = panel->rank_fp64 ? rank_kind(panel) : KIND_F32;
                 plan(rk, 0);
                 st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, rk,
                                 o->always_normalize, o->min_emission_prob_normalization_threshold);
@@ -1421,8 +1440,8 @@ int qa_Rcpp_haploid_dosage_versus_refs(
             // only the lists (and alpha at the thinned grids, c): the fp64 ranking pass, which follows the reference's
             // normalisation schedule (always_normalize / min_emission_prob_normalization_threshold honoured)
             out.lists = &lists;
-            plan(KIND_F64_RANK, 0);
-            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, KIND_F64_RANK,
+            plan(rank_kind(panel), 0);
+            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, rank_kind(panel),
                             o->always_normalize, o->min_emission_prob_normalization_threshold);
         } else if (want_lists && panel->rank_fp64 && main_kind == KIND_F32) {
             // the best-haplotype lists come from a pass with fp64 state, so that their membership and order are
@@ -1433,14 +1452,15 @@ int qa_Rcpp_haploid_dosage_versus_refs(
             BatchOut out2;
             out2.lists = &lists;
             const int32_t f0 = 0;
-            plan(KIND_F64_RANK, 0);
-            st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, KIND_F64_RANK,
+            plan(rank_kind(panel), 0);
+            st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, rank_kind(panel),
                             o->always_normalize, o->min_emission_prob_normalization_threshold);
         } else {
             // one pass yields everything: fp32 state with fp32 ranking, or fp64 state (qa_panel_set_dosage_precision(64))
             if (want_lists) out.lists = &lists;
             plan(main_kind, f);
-            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, main_kind);
+            st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, main_kind,
+                            o->always_normalize, o->min_emission_prob_normalization_threshold);
         }
         if (st != QA_OK || !want_lists) return st;
         return pack_lists(lists, best_ptr, best_idx, best_val, best_cap);
@@ -1468,7 +1488,7 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
         // fp64 ranking passes beside the dosage passes (fp32 state, or the fp64 dosage kernels); with the generic fp64 kernels,
         // or fp32 ranking, one pass yields both
         const bool exact = panel->rank_fp64 && K_top_matches > 0 && main_kind != KIND_F64_FULL;
-        const Geometry geo = pick_geometry(panel->K, main_kind), geo64 = pick_geometry(panel->K, KIND_F64_RANK);
+        const Geometry geo = pick_geometry(panel->K, main_kind), geo64 = pick_geometry(panel->K, rank_kind(panel));
         if (geo.NT == 0 || (exact && geo64.NT == 0))
             throw std::runtime_error("K exceeds the on-chip capacity of the full-pass kernels");
         const int G = panel->G, T = panel->T;
@@ -1490,7 +1510,7 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
                 out.dosage = dosage ? dosage + (size_t)done * T : nullptr;
                 out.lists = &lists;
                 status = run_passes(panel, n, gl + (size_t)done * T * 2, f.data() + done, gammaSmall_cols_to_get,
-                                    K_top_matches, 1, out, rank ? KIND_F64_RANK : main_kind);
+                                    K_top_matches, 1, out, rank ? rank_kind(panel) : main_kind);
                 done += n;
                 continue;
             }
@@ -1508,7 +1528,7 @@ int qa_fullpass_batch(qa_panel_t *panel, int32_t n_pass, const double *gl, const
             BatchOut out2;
             out2.lists = &lists;
             status = run_passes(panel, n, gl + (size_t)done * T * 2, zeros.data(), gammaSmall_cols_to_get, K_top_matches, 1,
-                                out2, KIND_F64_RANK);
+                                out2, rank_kind(panel));
             done += n;
         }
         if (status != QA_OK) return status;
@@ -1627,7 +1647,7 @@ static int fullpass_reads_impl(qa_panel_t *panel, int32_t n_chain, int32_t n_lab
             if (main_kind == KIND_F64_DOS && !panel->rank_fp64) main_kind = KIND_F64_FULL;   // (lists from the dosage pass itself)
             const bool exact = panel->rank_fp64 && main_kind != KIND_F64_FULL;   // else one pass yields dosage and lists
             Group gd{{}, 1, 0, main_kind}, gdt{{}, 1, K_top_matches, main_kind},
-                gt{{}, 0, K_top_matches, panel->rank_fp64 ? KIND_F64_RANK : KIND_F32};
+                gt{{}, 0, K_top_matches, panel->rank_fp64 ? rank_kind(panel) : KIND_F32};
             for (int c = 0; c < n_chain; c++) {
                 const bool dos = want_dosage[c] != 0, top = K_top_matches > 0 && (!want_top || want_top[c] != 0);
                 for (int l = 0; l < n_label; l++) {

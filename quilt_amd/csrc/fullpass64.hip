@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
                 const int gi = clampi(gb + lane, 0, G - 1), g1 = clampi(gb + lane + 1, 0, G - 1), gs = clampi(gb + lane, 0, G > 1 ? G - 2 : 0);
                 L.sc[SC_SIG * 64 + lane] = G > 1 ? prm.sigma[gs] : 1.0;
                 L.sc[SC_TM1 * 64 + lane] = G > 1 ? prm.tm1[gs] : 0.0;
-                L.sc[SC_EMIN * 64 + lane] = emin[g1];                       // of grid + 1
+                L.sc[SC_EMIN * 64 + lane] = g1 == 1 ? prm.emin_b1[p] : emin[g1];   // of grid + 1 (grid 1: as the backward pass sees it)
                 L.sc[SC_SPG * 64 + lane] = (double)prm.sp_gidx[g1];        // of grid + 1
                 L.sc[SC_C * 64 + lane] = cvec[gi];
                 L.sc[SC_SLOT * 64 + lane] = (double)slot[gi];
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
                 const int gi = clampi(gb + lane, 0, G - 1), g1 = clampi(gb + lane + 1, 0, G - 1), gs = clampi(gb + lane, 0, G > 1 ? G - 2 : 0);
                 L.sc[SC_SIG * 64 + lane] = G > 1 ? prm.sigma[gs] : 1.0;
                 L.sc[SC_TM1 * 64 + lane] = G > 1 ? prm.tm1[gs] : 0.0;
-                L.sc[SC_EMIN * 64 + lane] = emin[g1];                       // of grid + 1
+                L.sc[SC_EMIN * 64 + lane] = g1 == 1 ? prm.emin_b1[p] : emin[g1];   // of grid + 1 (grid 1: as the backward pass sees it)
                 L.sc[SC_SPG * 64 + lane] = (double)prm.sp_gidx[g1];        // of grid + 1
                 L.sc[SC_C * 64 + lane] = cvec[gi];
             }

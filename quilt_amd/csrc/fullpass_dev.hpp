@@ -48,6 +48,9 @@ struct PassParams {
     int always_normalize;
     double norm_threshold;   // min_emission_prob_normalization_threshold
     double *emin;            // [P][G] min emission of the grid after normalisation (:1044-1057), -1: grid without variant
+    double *emin_b1;         // [P] emin of grid 1 as the BACKWARD pass reads it: -1 when grid 1 holds no variant.  The forward pass
+                             // forces grid 1 to count as a grid with a variant (:964-966, so emin[1] >= 0 always); the backward
+                             // pass tests grid g + 1 itself and does not (:1866-1877)
     // scratch / outputs
     void *emat;             // [P][G][kMaxRow]
     void *esp;              // [P][esp_stride]
@@ -187,6 +190,10 @@ void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
 size_t fb64_alpha_col_elems(int K);
 size_t fb64_dos_lds_bytes(int K);
 void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
+
+// fullpass_ref.hip: the VALIDATION kernels (qa_panel_set_sum_order): every K-wide sum in the reference's order
+size_t fb_ref_state_doubles(int Kq);
+void launch_fb_ref(const void *pass_params, int NT, hipStream_t st, hipEvent_t e_mid);
 
 // select.hip: everything_select_good_haps on the device (one wave per chain)
 struct SelectParams {

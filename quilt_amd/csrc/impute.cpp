@@ -9,7 +9,8 @@
 // (:3180-3209).  Host C++ (threads per device, no HIP here): every K-wide or read-wide piece of arithmetic is one of the
 // library's own batched entry points -- qa_gibbs_batch, qa_fullpass_reads_select_batch, qa_rcpp_make_eMatRead_t_hap_major,
 // qa_mspbwt_select_new_haps, qa_accumulate_dosage, qa_consensus_read_labels -- reached through a table of function pointers,
-// so that the tests can run this very loop on a checker's entry points without a device (qa_impute_samples_backend).
+// so that the tests can run this very loop on a checker's entry points without a device (qa_impute_samples_backend,
+// declared in the private impute_testhook.h -- not in the public header).
 //
 // How it is arranged for a GPU (the structure quilt_amd/driver.py + workers.py had in Python):
 //   * all chains of a launch set of samples advance in lock-step: a round = ONE batched Gibbs call + ONE batched full-panel
@@ -41,6 +42,7 @@
 
 #include "../../include/quilt_amd.h"
 #include "../../include/quilt_amd_io.h"
+#include "impute_testhook.h"   // the table of entry points this loop runs over (private: tests fill it with a checker's)
 
 namespace qa { void set_error(const char *fmt, ...); }
 
@@ -1433,6 +1435,19 @@ int qa_impute_release_buffers(void) {
     std::lock_guard<std::mutex> g(buf_mu());
     bufs().clear();
     return QA_OK;
+}
+
+int qa_impute_kept_buffers(void) {
+    std::lock_guard<std::mutex> g(buf_mu());
+    return (int)bufs().size();
+}
+
+// qa_panel_destroy's hook (panel.hip): the host thread's buffers kept for this handle go with it -- a caller that creates and
+// destroys its handles per call (the shim's qa_impute_sample_range) would otherwise leak gigabytes of pinned memory per call,
+// and a later handle allocated at the same address would inherit the stale entry.
+extern "C" void qa_impute_drop_handle_buffers(void *handle) {
+    std::lock_guard<std::mutex> g(buf_mu());
+    bufs().erase(handle);
 }
 
 int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,

@@ -397,7 +397,10 @@ int qa_panel_create(const qa_panel_desc_t *d, qa_panel_t **out) {
     });
 }
 
+extern "C" void qa_impute_drop_handle_buffers(void *handle);   // impute.cpp: the per-handle buffers of qa_impute_samples
+
 void qa_panel_destroy(qa_panel_t *panel) {
+    if (panel) qa_impute_drop_handle_buffers(panel);   // (pinned host memory: freed while the runtime is alive)
     if (panel && panel->exclusive) {
         qa::drop_pass_scratch(panel);
         panel->exclusive = false;
@@ -549,6 +552,15 @@ int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits) {
         return QA_ERR_INVALID;
     }
     panel->dosage_fp64 = bits == 64;
+    return QA_OK;
+}
+
+int qa_panel_set_sum_order(qa_panel_t *panel, int32_t reference_order) {
+    if (!panel || (reference_order != 0 && reference_order != 1)) {
+        qa::set_error("qa_panel_set_sum_order: reference_order must be 0 or 1");
+        return QA_ERR_INVALID;
+    }
+    panel->sum_order_ref = reference_order == 1;
     return QA_OK;
 }
 

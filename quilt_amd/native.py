@@ -13,7 +13,14 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.environ.get("QUILT_AMD_LIB") or os.path.join(CSRC, "libquilt_amd.so")   # (developer A/B builds)
+LIB_PATH = os.path.join(CSRC, "libquilt_amd.so")
+if os.environ.get("QUILT_AMD_LIB") and os.path.realpath(os.environ["QUILT_AMD_LIB"]) != os.path.realpath(LIB_PATH):
+    # another build of the library (developer A/B builds under build/, scripts/decompose_gibbs.sh): only on request -- some of
+    # those builds switch parts of the computation off, and a stray environment variable must not select one silently
+    if os.environ.get("QA_DEV") != "1":
+        raise ImportError(f"QUILT_AMD_LIB={os.environ['QUILT_AMD_LIB']} is not this tree's library ({LIB_PATH}); set QA_DEV=1 to "
+                          "load a developer build")
+    LIB_PATH = os.environ["QUILT_AMD_LIB"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "quilt_amd.h")
 
 QA_OK = 0
@@ -115,7 +122,7 @@ def lib() -> C.CDLL:
                      "qa_Rcpp_haploid_dosage_versus_refs", "qa_Rcpp_make_gl_bound", "qa_fullpass_batch",
                      "qa_last_fullpass_timing_ms", "qa_panel_set_ranking_precision", "qa_panel_set_device_share", "qa_profile_get_busy", "qa_panel_create_from_rhb",
                      "qa_panel_export_tables", "qa_rcpp_make_eMatRead_t_nsnps", "qa_rare_common_create", "qa_profile_count",
-                     "qa_profile_get_work", "qa_panel_set_dosage_precision",
+                     "qa_profile_get_work", "qa_panel_set_dosage_precision", "qa_panel_set_sum_order",
                      "qa_gibbs_batch_rare_common", "qa_nipt_block_table", "qa_panel_set_cu_partition"):
             getattr(L, name).restype = C.c_int
         L.qa_profile_name.restype = C.c_char_p
@@ -234,6 +241,12 @@ class DevicePanel:
         """32 (default): dosage / alpha / beta / gamma outputs from fp32 state (fp64 emissions and sums); 64: fp64 state
         throughout, as the reference (a verification mode, several times slower)."""
         check(lib().qa_panel_set_dosage_precision(self.handle, C.c_int32(bits)))
+
+    def set_sum_order(self, reference_order: bool):
+        """VALIDATION MODE (``True``): the full-panel passes form every K-wide sum in the reference's order (the grid's
+        special haplotypes first, then k = 0 .. K-1 by one lane; fullpass_ref.hip), 20-50x slower; lists, c, alpha / beta
+        and dosage then equal the CPU path's bit for bit.  ``False`` (default): the production kernels."""
+        check(lib().qa_panel_set_sum_order(self.handle, C.c_int32(1 if reference_order else 0)))
 
     def set_device_share(self, n_sharers: int):
         """This handle is one of ``n_sharers`` working on the device concurrently (one per host thread)."""

@@ -160,6 +160,7 @@ static qa_panel_t *panel_for(SEXP hapMatcher, SEXP hapMatcherR, int use_hapMatch
 
 SEXP qa_shim_release(void) {
     cache_drop();
+    (void)qa_impute_release_buffers();   /* pinned transfer buffers of qa_impute_samples, if any are still kept */
     return R_NilValue;
 }
 

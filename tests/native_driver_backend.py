@@ -1,4 +1,4 @@
-"""Test infrastructure: a ``qa_impute_backend_t`` (include/quilt_amd.h) whose entries are the CPU oracle, so that the native
+"""Test infrastructure: a ``qa_impute_backend_t`` (quilt_amd/csrc/impute_testhook.h, a private header) whose entries are the CPU oracle, so that the native
 driver loop of csrc/impute.cpp -- the product's host code -- can be run WITHOUT a device through ``qa_impute_samples_backend``
 and compared with quilt_amd/driver.py on the oracle backend and with tests/r_driver_twin.py.  Each callback unflattens the
 C arrays into what tests/oracle_backend.py::OracleBackend takes; the selection behind the full-panel call is the host text
