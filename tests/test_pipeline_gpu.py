@@ -25,44 +25,75 @@ def _run_both(panel, samples, prm):
     return got, ref
 
 
+# The medium runs: EVERY driver seed of a range, none chosen.  Round 4 ran one seed here and had to move it off a last-bit tie
+# (seed 5: one chain's first round meets several haplotypes whose gamma equals the K_top-th largest up to the last bits; device
+# list 7 entries, oracle list 5, both valid by reference-single.cpp:129-194).  Now: (i) in VALIDATION mode (K-wide sums in the
+# reference's order, csrc/fullpass_ref.hip) every seed -- seed 5 included -- ends bit-identical to the CPU pipeline; (ii) in
+# PRODUCTION mode a run either coincides with the CPU pipeline (labels identical, dosage to the fp32 dosage passes' rounding) or,
+# where it met such a tie, lies within the CPU pipeline's own seed-to-seed spread (tests/test_sum_order_gpu.py for the sweeps).
+MEDIUM_SEEDS = list(range(5, 13))
 _CACHE = {}
 
 
-def _medium_run(panel):
-    from quilt_amd.driver import DriverParams
+def _medium_run(panel, seed):
+    import dataclasses
+    from quilt_amd.driver import Driver, DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
     from quilt_amd.synth import make_synthetic_sample
-    if "run" not in _CACHE:
+    from tests.oracle_backend import OracleBackend
+    if seed not in _CACHE:
         samples = [make_synthetic_sample(panel, seed=1000 + i, n_reads=1000) for i in range(3)]
-        # (seed 6; with seed 5 and the round-4 draws one chain's first round meets a tie in the last bits at the K_top-th gamma of a
-        # thinned grid -- device list 7 entries, oracle list 5, both valid by reference-single.cpp:129-194 -- and that sample's
-        # dosages part: DESIGN.md 4.4, scripts/check_medium_lists.py; seeds 6-9 and the 36 runs of check_pipeline_seeds.py: none)
-        prm = DriverParams(nGibbsSamples=3, Ksubset=200, Knew=200, seed=6)
-        _CACHE["run"] = (samples,) + _run_both(panel, samples, prm)
-    return _CACHE["run"]
+        prm = DriverParams(nGibbsSamples=3, Ksubset=200, Knew=200, seed=seed)
+        got, ref = _run_both(panel, samples, prm)
+        dev = DevicePanel(panel)
+        dev.set_sum_order(True)
+        val = Driver(panel, HipBackend(dev), prm).run(samples)
+        dev.close()
+        ref2 = Driver(panel, OracleBackend(panel), dataclasses.replace(prm, seed=seed + 1000)).run(samples)
+        _CACHE[seed] = dict(samples=samples, got=got, ref=ref, val=val, ref2=ref2)
+    return _CACHE[seed]
 
 
 def test_pipeline_r2_bar_vs_cpu_path(medium_panel):
-    """BASELINE.json: dosage r2 vs the CPU path >= 0.999 for every sample."""
-    samples, got, ref = _medium_run(medium_panel)
-    for i, (g, r) in enumerate(zip(got, ref)):
-        assert r2(g.dosage, r.dosage) >= 0.999, (i, r2(g.dosage, r.dosage))
+    """BASELINE.json: dosage r2 vs the CPU path >= 0.999 -- for every sample of every seed whose chains coincide with the CPU
+    path's, and exactly 1 in validation mode; a production-mode run that met a last-bit tie (another realisation of the same
+    sampler) is held to the CPU path's own r2 between two driver seeds on the same reads instead."""
+    n = parted = 0
+    for seed in MEDIUM_SEEDS:
+        run = _medium_run(medium_panel, seed)
+        for i, (g, r, v, r2nd) in enumerate(zip(run["got"], run["ref"], run["val"], run["ref2"])):
+            n += 1
+            assert np.array_equal(v.read_labels, r.read_labels) and np.array_equal(v.dosage, r.dosage), (seed, i)
+            if np.array_equal(g.read_labels, r.read_labels) and np.abs(g.dosage - r.dosage).max() <= 1e-4:
+                assert r2(g.dosage, r.dosage) >= 0.999, (seed, i, r2(g.dosage, r.dosage))
+            else:
+                parted += 1
+                print(f"seed {seed} sample {i}: parted, r2(GPU, CPU) = {r2(g.dosage, r.dosage):.5f}, CPU seed-to-seed r2 = {r2(r2nd.dosage, r.dosage):.5f}")
+                assert r2(g.dosage, r.dosage) >= r2(r2nd.dosage, r.dosage), (seed, i)
+    print(f"{parted} of {n} production-mode sample runs parted from the CPU path")
+    assert parted <= n // 4
 
 
-def test_pipeline_matches_oracle(medium_panel):
-    samples, got, ref = _medium_run(medium_panel)
-    panel = medium_panel
-    for i, (g, r) in enumerate(zip(got, ref)):
-        assert g.nDosage == r.nDosage == 3
+@pytest.mark.parametrize("seed", MEDIUM_SEEDS)
+def test_pipeline_matches_oracle(medium_panel, seed):
+    run = _medium_run(medium_panel, seed)
+    samples = run["samples"]
+    for i, (g, r, v) in enumerate(zip(run["got"], run["ref"], run["val"])):
+        # validation mode: the CPU pipeline's results bit for bit
+        assert v.nDosage == r.nDosage == 3
+        assert np.array_equal(v.read_labels, r.read_labels)
+        assert np.array_equal(v.dosage, r.dosage) and np.array_equal(v.gp_t, r.gp_t) and np.array_equal(v.phasing_haps, r.phasing_haps)
+        # production mode
+        assert g.nDosage == 3
         np.testing.assert_allclose(g.gp_t.sum(axis=0), 1.0, atol=2e-3)   # check_quilt_output (test-drivers.R:38-61)
-        assert np.array_equal(g.read_labels, r.read_labels)
-        assert np.abs(g.dosage - r.dosage).max() <= 1e-4
-        # recast_haps (functions.R:1207-1217) takes argmax decisions on the genotype posteriors: an fp32-rounding-sized
-        # difference can flip one at a near-tie, so a handful of sites may differ
-        assert np.mean(np.abs(g.phasing_haps - r.phasing_haps) > 1e-4) <= 2e-3
         truth = samples[i].truth_haps.sum(axis=0)
         assert r2(g.dosage, truth) >= 0.9 and abs(r2(g.dosage, truth) - r2(r.dosage, truth)) < 0.02
         same = np.array_equal(g.read_labels, r.read_labels)
-        print(f"sample {i}: r2(gpu, oracle) = {r2(g.dosage, r.dosage):.6f}, max|d| = {np.abs(g.dosage - r.dosage).max():.2e}, "
+        if same and np.abs(g.dosage - r.dosage).max() <= 1e-4:   # (fp32 dosage passes: ~2e-6 observed)
+            # recast_haps (functions.R:1207-1217) takes argmax decisions on the genotype posteriors: an fp32-rounding-sized
+            # difference can flip one at a near-tie, so a handful of sites may differ
+            assert np.mean(np.abs(g.phasing_haps - r.phasing_haps) > 1e-4) <= 2e-3
+        print(f"seed {seed} sample {i}: r2(gpu, oracle) = {r2(g.dosage, r.dosage):.6f}, max|d| = {np.abs(g.dosage - r.dosage).max():.2e}, "
               f"consensus labels identical: {same}")
 
 
@@ -376,24 +407,27 @@ def test_underflow_retry_on_the_device(small_panel):
 @pytest.mark.parametrize("method", ["diploid", "nipt"])
 def test_bam_to_vcf_end_to_end_on_the_device(tmp_path, small_panel, method):
     """The formats either side of the path with the device in the middle: BAM files -> loader ->
-    driver on the HIP backend -> VCF.  The same file as the CPU path writes from the same BAMs, up to last-digit differences of
-    three-decimal strings and a few phase decisions (see below)."""
+    driver on the HIP backend -> VCF.  In validation mode (the K-wide sums in the reference's order) the file is the CPU path's,
+    row for row; in production mode this small panel (K = 1 000, Ksubset = 64), full of duplicated haplotypes, lets a last-bit
+    tie send a chain down another (equally valid) Gibbs path, so the file agrees closely, not entry by entry."""
     from quilt_amd.driver import HipBackend
     from quilt_amd.native import DevicePanel
     from tests.oracle_backend import OracleBackend
     from tests.test_driver_host import _bam_to_vcf
     ff = 0.2 if method == "nipt" else None
     dev = DevicePanel(small_panel)
-    (tmp_path / "gpu").mkdir()
-    (tmp_path / "cpu").mkdir()
+    for d in ("gpu", "val", "cpu"):
+        (tmp_path / d).mkdir()
     rows_g, rec_g, truth = _bam_to_vcf(tmp_path / "gpu", small_panel, HipBackend(dev), method=method, ff=ff)
+    dev.set_sum_order(True)
+    rows_v, rec_v, _ = _bam_to_vcf(tmp_path / "val", small_panel, HipBackend(dev), method=method, ff=ff)
     rows_c, rec_c, _ = _bam_to_vcf(tmp_path / "cpu", small_panel, OracleBackend(small_panel), method=method, ff=ff)
     dev.close()
+    assert rows_v == rows_c   # validation mode: the same text
+    for k in rec_c["results"]:
+        assert np.array_equal(rec_v["results"][k].read_labels, rec_c["results"][k].read_labels)
     assert len(rows_g) == len(rows_c)
-    # This small panel (K = 1 000, Ksubset = 64) is full of duplicated haplotypes: a tie broken the other way in one selection
-    # sends the two pipelines down different (equally valid) Gibbs paths, so the files agree closely, not entry by entry --
-    # numerical parity of the pipeline is test_pipeline_matches_oracle's job.  Here: same sites, same columns, well-formed
-    # entries, dosages that agree as a whole.
+    # production mode: same sites, same columns, well-formed entries, dosages that agree as a whole
     n_post = 2 if method == "diploid" else 4      # GP, DS | MGP, MDS, FGP, FDS
     ds_g, ds_c = [], []
     for a, b in zip(rows_g, rows_c):
@@ -413,35 +447,57 @@ def test_bam_to_vcf_end_to_end_on_the_device(tmp_path, small_panel, method):
     assert np.mean(np.abs(np.array(ds_g) - np.array(ds_c)) <= 1.001e-3) >= 0.8
 
 
-def test_quick_start_shaped_run_bam_to_vcf(tmp_path):
+@pytest.fixture(scope="module")
+def quick_start_panel():
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_1000g_like_panel
+    panel = make_1000g_like_panel(K=5008, nSNPs=3200, seed=2504)
+    dev = DevicePanel.from_rhb(panel)
+    yield panel, dev
+    dev.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_quick_start_shaped_run_bam_to_vcf(tmp_path, quick_start_panel, seed):
     """BASELINE configs[0]'s SHAPE (the quick-start: one 1x sample against the 1000 Genomes panel, ~5 000 haplotypes) with
     stand-ins for the data that cannot be had here: a K = 5 008 panel with a rare-variant-dominated (1 / i) frequency spectrum
     (quilt_amd.synth.make_1000g_like_panel) compressed ON THE DEVICE from its packed form (qa_panel_create_from_rhb: the step
     quilt-prepare-reference.R:416-428 does with STITCH), one synthetic 1x sample through a BAM file, QUILT's defaults
-    (nGibbsSamples = 7, n_seek_its = 3, Ksubset = 600), fp64 dosage passes, BAM -> loader -> driver -> VCF.  The file equals the
-    one the CPU path writes from the same BAM: same text."""
+    (nGibbsSamples = 7, n_seek_its = 3, Ksubset = 600), fp64 dosage passes, BAM -> loader -> driver -> VCF.
+    EVERY driver seed 1..8 (27 % of this panel's haplotypes repeat another one over the whole region: every best-haplotype list
+    is a long exact tie, the panel on which the device and the CPU path part most often).  Validation mode (the K-wide sums in the
+    reference's order): the file equals the one the CPU path writes from the same BAM -- same text, on every seed.  Production
+    mode: either that, or (a last-bit tie on the way) dosages within the CPU path's own spread between two driver seeds."""
+    import dataclasses
     from quilt_amd.driver import DriverParams, HipBackend
-    from quilt_amd.native import DevicePanel
-    from quilt_amd.synth import make_1000g_like_panel
     from tests.oracle_backend import OracleBackend
     from tests.test_driver_host import _bam_to_vcf
-    panel = make_1000g_like_panel(K=5008, nSNPs=3200, seed=2504)
-    dev = DevicePanel.from_rhb(panel)
-    dev.set_dosage_precision(64)
-    # (a seed on whose way no last-bit tie at a list's threshold parts the two arithmetics -- 27 % of this panel's haplotypes
-    # repeat another one over the whole region, every list is a long tie, and on six of ten seeds one haplotype a last bit off
-    # the tie shifts a list's window: DESIGN.md 4.4, scripts/check_quick_start_seeds.py, scripts/check_seed_lists.py)
-    prm = DriverParams(seed=5)
-    (tmp_path / "gpu").mkdir()
-    (tmp_path / "cpu").mkdir()
-    rows_g, rec_g, truth = _bam_to_vcf(tmp_path / "gpu", panel, HipBackend(dev), n_samples=1, n_reads=1000, prm=prm)
-    rows_c, rec_c, _ = _bam_to_vcf(tmp_path / "cpu", panel, OracleBackend(panel, n_threads=8), n_samples=1, n_reads=1000, prm=prm)
-    dev.close()
-    assert np.array_equal(rec_g["results"][0].read_labels, rec_c["results"][0].read_labels)
-    assert np.abs(rec_g["results"][0].dosage - rec_c["results"][0].dosage).max() <= 1e-9
-    diff = [(a, b) for a, b in zip(rows_g, rows_c) if a != b]
-    # (three-decimal strings of numbers that agree to 1e-9: a value within 1e-9 of a rounding boundary may print differently)
-    assert len(diff) <= 2, diff[:3]
     from tests.util import r2
+    panel, dev = quick_start_panel
+    prm = DriverParams(seed=seed)
+    for d in ("gpu", "val", "cpu", "cpu2"):
+        (tmp_path / d).mkdir()
+    dev.set_dosage_precision(64)
+    dev.set_sum_order(False)
+    rows_g, rec_g, truth = _bam_to_vcf(tmp_path / "gpu", panel, HipBackend(dev), n_samples=1, n_reads=1000, prm=prm)
+    dev.set_sum_order(True)
+    rows_v, rec_v, _ = _bam_to_vcf(tmp_path / "val", panel, HipBackend(dev), n_samples=1, n_reads=1000, prm=prm)
+    dev.set_sum_order(False)
+    cpu = OracleBackend(panel, n_threads=8)
+    rows_c, rec_c, _ = _bam_to_vcf(tmp_path / "cpu", panel, cpu, n_samples=1, n_reads=1000, prm=prm)
+    _, rec_c2, _ = _bam_to_vcf(tmp_path / "cpu2", panel, cpu, n_samples=1, n_reads=1000, prm=dataclasses.replace(prm, seed=seed + 1000))
+    g, v, c, c2 = (rec["results"][0] for rec in (rec_g, rec_v, rec_c, rec_c2))
+    # validation mode: bit for bit, and the same file
+    assert np.array_equal(v.read_labels, c.read_labels) and np.array_equal(v.dosage, c.dosage)
+    assert rows_v == rows_c
+    # production mode
     ds = np.array([float(r[9].split(":")[2]) for r in rows_g])
     assert r2(ds, truth[0]) > 0.9
+    if np.array_equal(g.read_labels, c.read_labels) and np.abs(g.dosage - c.dosage).max() <= 1e-9:
+        diff = [(a, b) for a, b in zip(rows_g, rows_c) if a != b]
+        # (three-decimal strings of numbers that agree to 1e-9: a value within 1e-9 of a rounding boundary may print differently)
+        assert len(diff) <= 2, diff[:3]
+    else:
+        print(f"seed {seed}: parted from the CPU path, r2(GPU, CPU) = {r2(g.dosage, c.dosage):.6f}, CPU seed-to-seed r2 = {r2(c2.dosage, c.dosage):.6f}")
+        assert r2(g.dosage, c.dosage) >= r2(c2.dosage, c.dosage)
+        assert abs(r2(g.dosage, truth[0]) - r2(c.dosage, truth[0])) <= 0.01
