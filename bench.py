@@ -31,11 +31,29 @@ _CPU_PANEL = None
 PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 PMC_INSTS_FILE = os.path.join("profiles", "r04_pmc_insts.json")
 
-WORKLOADS = {
-    "short": "BASELINE.json configs[2] (the K=50k configuration the metric is quoted on), per-GPU share",
-    "ont": "BASELINE.json configs[3] (ONT-style long reads, noisy base qualities), per-GPU share",
-    "nipt": "BASELINE.json configs[4] (NIPT: mother + fetus, three read labels, block Gibbs; ff = 0.2), per-GPU share",
-}
+def workload_label(mode, K, batch, mspbwt=False, rare_common=False):
+    """Which BASELINE.json configuration a run is (or that it is none): keyed on the read model AND the panel size / batch."""
+    if mode == "ont":
+        base = "BASELINE.json configs[3] (ONT-style long reads, noisy base qualities)" if K == 50000 else None
+    elif mode == "nipt":
+        base = "BASELINE.json configs[4] (NIPT: mother + fetus, three read labels, block Gibbs; ff = 0.2)" if K == 50000 else None
+    elif K == 50000:
+        base = "BASELINE.json configs[2] (the K=50k configuration the metric is quoted on)"
+    elif K == 5000 and batch == 32:
+        base = "BASELINE.json configs[1] (32 synthetic 1x short-read samples, K=5 000, one MI355X)"
+    elif K == 64976:
+        base = "not a BASELINE.json configuration: the HRC panel's size (K=64 976; the reference developers' profiling workload, scripts/profile.R:70-107)"
+    else:
+        base = None
+    if base is None:
+        base = f"not a BASELINE.json configuration (mode {mode}, K={K}, {batch} samples per step)"
+    if mspbwt and rare_common:
+        base += " in QUILT2's default mode (use_mspbwt=TRUE, impute_rare_common=TRUE)"
+    elif mspbwt:
+        base += " in mode M2 (use_mspbwt=TRUE)"
+    elif rare_common:
+        base += " with impute_rare_common=TRUE"
+    return base + ", per-GPU share"
 
 
 def physical_cores():
@@ -186,6 +204,72 @@ def cpu_baseline(panel, n_reads, params, full_chains, ff=0.0, mspbwt=False):
     return out, keep
 
 
+_WHOLE = None
+
+
+def _whole_worker(i):
+    """One host core: ONE WHOLE SAMPLE through the entire per-sample pipeline on the CPU path (the driver loop over the fp64
+    oracle's entry points, single-threaded) -- what one mclapply worker of the reference does for one sample."""
+    from quilt_amd.driver import Driver, DriverParams
+    from tests.oracle_backend import OracleBackend
+    smp, off, params, keep = _WHOLE[i]
+    t0 = time.perf_counter()
+    res = Driver(_CPU_PANEL, OracleBackend(_CPU_PANEL, n_threads=1), DriverParams(**params)).run([smp], sample_offset=off)
+    return i, time.perf_counter() - t0, (res[0] if keep else None)
+
+
+def cpu_baseline_whole(panel, params, work, cores, budget_s, n_keep):
+    """THE CPU baseline: `cores` whole samples, one per physical core, all at once (the reference's
+    mclapply(mc.cores = nCores), quilt.R:691-692), each through the whole per-sample pipeline on the CPU path.  `work` =
+    [(sample, global sample index)]: the samples of the last timed batch under the seeds the GPU run gives them, so that the
+    first n_keep results are also the metric's `dosage r2 vs CPU ref` reference.  Bounded by `budget_s` of wall time: workers
+    still running then are stopped and the figure comes from the samples that finished (flagged)."""
+    import multiprocessing as mp
+    global _CPU_PANEL, _WHOLE
+    from oracle import oracle as O
+    O.lib()
+    _CPU_PANEL = panel
+    n = min(cores, len(work))
+    _WHOLE = [(smp, off, params, i < n_keep) for i, (smp, off) in enumerate(work[:n])]
+    t0 = time.perf_counter()
+    secs, kept = {}, {}
+    pool = mp.get_context("fork").Pool(n)
+    try:
+        it = pool.imap_unordered(_whole_worker, range(n))
+        for _ in range(n):
+            left = budget_s - (time.perf_counter() - t0)
+            if left <= 0:
+                break
+            try:
+                i, t, res = it.next(timeout=left)
+            except mp.TimeoutError:
+                break
+            secs[i] = t
+            if res is not None:
+                kept[i] = res
+    finally:
+        pool.terminate()
+        pool.join()
+    wall = time.perf_counter() - t0
+    if not secs:
+        return None, None
+    t = np.array([secs[i] for i in sorted(secs)])
+    out = dict(value=float((1.0 / t).sum() * n / len(t)), unit="samples/sec", cores=n, logical_cpus=os.cpu_count(), kind="port",
+               whole_samples=len(t), seconds_per_sample_mean=float(t.mean()), seconds_per_sample_max=float(t.max()),
+               seconds_per_sample_min=float(t.min()), value_batch_wall=float(len(t) / wall), wall_s=round(wall, 1),
+               sample=f"WHOLE samples: {n} synthetic samples of the last timed batch, one per physical core, all {n} cores at once "
+                      f"(mclapply's sharding), each through the entire per-sample pipeline on the CPU path (every chain, every round, "
+                      f"the driver's host logic; fp64 C oracle, one thread per sample); {len(t)} finished: {t.mean():.1f} s per sample "
+                      f"mean ({t.min():.1f} .. {t.max():.1f}); value = sum over cores of 1 / seconds (each core's own rate); "
+                      f"{wall:.0f} s of wall time")
+    if len(t) < n:
+        out["incomplete"] = f"{n - len(t)} of {n} workers were stopped at the {budget_s:.0f} s budget; value scales the finished ones' rates to {n} cores"
+    ref = None
+    if len(kept) == n_keep and n_keep > 0:
+        ref = dict(ref=[kept[i] for i in range(n_keep)], n=n_keep, cpu_seconds=round(max(secs[i] for i in range(n_keep)), 1), threads=1)
+    return out, ref
+
+
 def parity_vs_cpu(dev, panel, n_reads, params, ff, keep):
     """The GPU re-runs core 0's baseline calls on the same inputs (same uniforms): read labels must be identical, the
     dosage of the following full-panel pass is compared by r2 and max |diff|, the best-haplotype lists by identity."""
@@ -278,7 +362,7 @@ def main():
                          "a whole batch's chains, one per SIMD at the defaults), or every batch cut into one part per thread")
     ap.add_argument("--mspbwt", action="store_true",
                     help="use_mspbwt = TRUE (mode M2): no full-panel pass; the small panel is re-selected from long matches of the "
-                         "Gibbs call's haploid dosages against the panel (device search, csrc/match.hip); no CPU baseline")
+                         "Gibbs call's haploid dosages against the panel (--mspbwt-search: the msPBWT neighbour scan by default)")
     ap.add_argument("--mspbwt-search", choices=["scan", "exhaustive"], default="scan",
                     help="--mspbwt: the query behind select_new_haps_mspbwt_v3 -- the msPBWT neighbour scan of the panel's indices "
                          "(the reference's semantics; host, csrc/mspbwt.cpp) or the exhaustive device search (csrc/match.hip)")
@@ -291,6 +375,12 @@ def main():
                     help="the driver's large transfer buffers as ordinary (pageable) memory instead of qa_host_alloc: the staged path "
                          "a caller that cannot allocate through the library gets (the R shim: R owns its vectors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["whole", "composed"], default="whole",
+                    help="whole (default): cpu_baseline.value is MEASURED on whole samples, one per physical core, all cores at once "
+                         "(minutes of wall; the composed figure is kept beside it); composed: only the composed figure (one Gibbs call "
+                         "+ one thin + one dosage pass per core, priced up to a sample)")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=480.0, metavar="SEC",
+                    help="wall-time bound of the whole-sample CPU baseline; workers still running then are stopped")
     ap.add_argument("--no-scan-check", action="store_true",
                     help="--mspbwt: skip the comparison of the device search with the msPBWT neighbour scan (CPU, ~20 s)")
     ap.add_argument("--r2-vs-cpu", type=int, default=4, metavar="N",
@@ -392,7 +482,21 @@ def main():
         shutil.rmtree(bam_dir, ignore_errors=True)
     samples = [flat[st * a.batch:(st + 1) * a.batch] for st in range(n_steps)]
     cpu_pipeline = None
-    if rank == 0 and world == 1 and a.r2_vs_cpu > 0 and rc is None and not a.stub and not a.mspbwt:
+    if rank == 0 and world == 1 and cpu is not None and a.cpu_baseline == "whole" and not a.mspbwt:
+        # the baseline proper: whole samples, one per physical core, all cores at once; the composed figure stays beside it
+        cores = physical_cores()
+        work, st = [], n_steps - 1
+        while len(work) < cores and st >= 0:   # the last timed batch first (its first samples double as the r2 reference)
+            work += [(smp, st * a.batch + i) for i, smp in enumerate(samples[st])]
+            st -= 1
+        whole, ref = cpu_baseline_whole(panel, params, work, cores, a.cpu_baseline_budget, min(a.r2_vs_cpu, len(samples[-1])))
+        if whole is not None:
+            whole["composed"] = cpu
+            whole["composed_over_whole"] = round(cpu["value"] / whole["value"], 3)
+            cpu = whole
+        if ref is not None:
+            cpu_pipeline = ref
+    if cpu_pipeline is None and rank == 0 and world == 1 and a.r2_vs_cpu > 0 and rc is None and not a.stub and not a.mspbwt:
         cpu_pipeline = cpu_pipeline_reference(a, panel, params, samples)
     import torch
     import torch.distributed as dist
@@ -535,7 +639,7 @@ def main():
                 out["dotcall_path"] = {"error": repr(e)[:300]}
         if cpu_pipeline is not None:
             out["dosage_r2_vs_cpu_pipeline"] = r2_vs_cpu_pipeline(cpu_pipeline, main_reg["last"])
-            if out.get("cpu_baseline"):
+            if out.get("cpu_baseline") and "composed" not in out["cpu_baseline"]:
                 # the composed figure checked against WHOLE samples: the r2 leg runs n samples through the whole per-sample
                 # pipeline on the CPU path (all chains, all rounds) on `threads` cores
                 n_, sec, thr = cpu_pipeline["n"], cpu_pipeline["cpu_seconds"], cpu_pipeline["threads"]
@@ -618,10 +722,13 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
         "dtype": "f64" if fp64 else "f64 (Gibbs sampler, ranking passes) / f32 state with f64 emissions and sums (dosage passes)",
         "data": "stub (no device work)" if a.stub else
                 ("synthetic, through BAM files read by the native loader before the timed region" if a.bam else "synthetic"),
-        "config": {"workload": f"{WORKLOADS[a.mode]}: {a.batch} synthetic 1x {a.mode}-read samples per GPU per step, "
+        "config": {"workload": f"{workload_label(a.mode, a.K, a.batch, a.mspbwt, rc is not None)}: {a.batch} synthetic 1x {a.mode}-read samples per GPU per step, "
                                f"{a.nsnps} SNPs ({panel.nGrids} grids, 2 Mb + buffers), K={a.K} haplotypes, {a.reads} reads/sample, "
                                "QUILT defaults (nGibbsSamples=7, n_seek_its=3, Ksubset=600), "
-                               + ("use_mspbwt=TRUE (mode M2: device haplotype search instead of the full-panel pass)" if a.mspbwt
+                               + (("use_mspbwt=TRUE (mode M2: no full-panel pass; the next small panel comes from the msPBWT neighbour scan of the "
+                                   "panel's indices, host C++, csrc/mspbwt.cpp)" if a.mspbwt_search == "scan" else
+                                   "use_mspbwt=TRUE (mode M2: no full-panel pass; the next small panel comes from the exhaustive device "
+                                   "search of csrc/match.hip -- this library's own definition, not the reference's query)") if a.mspbwt
                                   else "use_mspbwt=FALSE")
                                + (f", impute_rare_common=TRUE with {rc.nSNPs_all} SNPs in all ({rc.nGrids_all} grids)" if rc is not None else ""),
                    "mode": a.mode, "K": a.K, "nSNPs": a.nsnps, "samples_per_step_per_gpu": a.batch, "steps_per_launch_set": a.fuse,

@@ -2,9 +2,14 @@
 
 usage: python scripts/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<command>"
 
-Units and corrections (MI355X_MICROARCH.md, "HBM"): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-like units of 1024
-bytes... the counters count 64-byte requests; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads
-at 64 bytes, so the read side is doubled.  WRITE_SIZE is uncalibrated in the guide; it is reported as is.
+Units and corrections (MI355X_MICROARCH.md, "HBM"): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 bytes; on gfx950
+FETCH_SIZE tallies the 128-byte requests of coalesced reads at 64 bytes, so the read side is doubled.  The guide calibrates that
+for 16-byte-per-lane streaming only and leaves other widths and WRITE_SIZE open; CALIBRATED HERE (round 5) on this library's own
+access shapes -- scripts/micro/fetch_calibrate.hip under the same two counter passes, profiles/r05_fetch_calibration.json: known
+byte counts through a 4 GiB buffer give FETCH_SIZE x 1024 x 2.000 for 16-, 8- and 4-byte-per-lane contiguous loads alike, x 2
+on the 128-byte lines touched for the sampler's state columns (raw_buffer_load_b64, 600 of 640 rows of a 5 120-byte pitch:
+4 864 bytes fetched for 4 800 requested), and WRITE_SIZE x 1024 x 1.000 for 16- and 8-byte-per-lane stores and the column
+stores.  The factors below are read from that file when it is there (FETCH: rd8buf's line-level 2.0; WRITE: 1.0).
 """
 import collections
 import csv
@@ -36,11 +41,25 @@ def per_kernel(path, counter, pattern=r"(k_\w+)"):
     return tot, n, ms, wgs
 
 
+def calibration():
+    """(read factor, write factor, source) from the committed calibration, else the guide's 2 / 1."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_fetch_calibration.json")
+    try:
+        k = json.load(open(path))["kernels"]
+        rf = round(k["rd16"]["factor"], 2)   # (= rd8 = rd4; rd8buf fetches whole lines: 2.0 x the lines touched)
+        wf = round(k["wr8buf"]["factor"], 2)
+        return rf, wf, "profiles/r05_fetch_calibration.json (scripts/micro/fetch_calibrate.hip)"
+    except (OSError, KeyError, TypeError, ValueError):
+        return 2.0, 1.0, "MI355X_MICROARCH.md (16 B/lane streaming reads); WRITE_SIZE as reported"
+
+
 def main():
     fetch_csv, write_csv, out, cmd = sys.argv[1:5]
+    RF, WF, cal_src = calibration()
     f, nf, msf, wg = per_kernel(fetch_csv, "FETCH_SIZE")
     w, nw, _, _ = per_kernel(write_csv, "WRITE_SIZE")
-    res = {"command": cmd, "units": "bytes; FETCH_SIZE (KB) x 1024 x 2 (gfx950 wide-read correction), WRITE_SIZE (KB) x 1024",
+    res = {"command": cmd, "units": f"bytes; FETCH_SIZE x 1024 x {RF}, WRITE_SIZE x 1024 x {WF}", "calibration": cal_src,
            "kernels": {}, "instantiations": {}}
     # the same per template instantiation (k_gibbs<10, 1, true> -- two chains per SIMD -- and k_gibbs<10, 1, false> are
     # different code: bench.py prices a launch with the figures of the build it actually ran)
@@ -50,13 +69,13 @@ def main():
     for k in sorted(fi):
         if "<" not in k:
             continue
-        fb, wb = fi[k] * 1024 * 2, wi.get(k, 0.0) * 1024
+        fb, wb = fi[k] * 1024 * RF, wi.get(k, 0.0) * 1024 * WF
         res["instantiations"][k] = {"launches": nfi[k], "hbm_bytes_per_launch": (fb + wb) / max(nfi[k], 1), "total_ms": msfi[k],
                                     "workgroups": wgi.get(k, 0),
                                     "hbm_bytes_per_workgroup": (fb + wb) / wgi[k] if wgi.get(k) else None}
     for k in sorted(f):
-        fb = f[k] * 1024 * 2
-        wb = w.get(k, 0.0) * 1024
+        fb = f[k] * 1024 * RF
+        wb = w.get(k, 0.0) * 1024 * WF
         res["kernels"][k] = {"launches": nf[k], "fetch_bytes": fb, "write_bytes": wb,
                              "hbm_bytes_per_launch": (fb + wb) / max(nf[k], 1), "total_ms": msf[k]}
         if wg.get(k):   # launches of different sizes in one run (a Gibbs launch of a whole batch, of the phasing chains alone)
