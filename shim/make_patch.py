@@ -15,6 +15,16 @@ What the patch does, and nothing else:
   * QUILT/src/quilt_amd_shim.c -- added by copying shim/quilt_amd_shim.c (R compiles every .c in src/); the patch carries a
     one-line stub that includes it from $(QUILT_AMD) so that the file is not duplicated.
 The diff is written with zero lines of context: it holds the changed rows only, none of the reference's other text.
+
+It also writes shim/QUILT-R.patch: the R side of the FAST path.
+  * QUILT/R/quilt.R -- inside the mclapply body (:692-990), in front of the loop over a core's samples (:832), the whole range
+    goes through ONE `.Call("qa_impute_sample_range", ...)` (quilt_amd_impute_sample_range, new file below) whenever the run
+    asks for nothing the range call does not cover (quilt_amd_range_is_covered: no plots, no HLA run, no phasefile / genfile
+    truth, no per-read outputs, ...); the loop then takes each sample's result from that call instead of calling
+    get_and_impute_one_sample (:835).  Otherwise -- and always with QUILT_AMD_RANGE=0 -- the unpatched loop runs, through the
+    four per-call entries of QUILT-src.patch.
+  * QUILT/R/quilt-amd.R -- new: shim/quilt-amd.R (loading by the reference's own loader, the call, the per-sample VCF column
+    and counts by the reference's own functions).
 """
 import difflib
 import os
@@ -76,7 +86,64 @@ def make(ref_root):
             udiff("", stub, "QUILT/src/quilt_amd_shim.c"))
 
 
+R_ANCHOR_LOOP = "        for(iSample in sampleRange[1]:sampleRange[2]) {\n"
+R_ANCHOR_CALL = "            out <- get_and_impute_one_sample(\n"
+R_RANGE_CALL = '''        ## libquilt_amd: the whole sample range as ONE call (quilt-amd.R) when the run asks for nothing else
+        amd_results <- NULL
+        if (quilt_amd_range_is_covered(
+            method = method, make_plots = make_plots, make_plots_block_gibbs = make_plots_block_gibbs, hla_run = hla_run,
+            have_truth_haplotypes = have_truth_haplotypes, have_truth_genotypes = have_truth_genotypes,
+            record_interim_dosages = record_interim_dosages, output_read_label_prob = output_read_label_prob,
+            record_read_label_usage = record_read_label_usage, plot_per_sample_likelihoods = plot_per_sample_likelihoods,
+            plot_p1 = plot_p1, make_heuristic_plot = make_heuristic_plot,
+            estimate_bq_using_truth_read_labels = estimate_bq_using_truth_read_labels, addOptimalHapsToVCF = addOptimalHapsToVCF,
+            use_splitreadgl = use_splitreadgl, small_ref_panel_skip_equally_likely_reads = small_ref_panel_skip_equally_likely_reads,
+            shard_check_every_pair = shard_check_every_pair, use_hapMatcherR = use_hapMatcherR,
+            calculate_gamma_on_the_fly = calculate_gamma_on_the_fly, RData_objects_to_save = RData_objects_to_save
+        )) {
+            amd_results <- quilt_amd_impute_sample_range(
+                sampleRange = sampleRange, n_handles = 3L, device = iCore - 1L,
+                rhb_t = rhb_t, hapMatcherR = hapMatcherR, distinctHapsB = distinctHapsB, distinctHapsIE = distinctHapsIE,
+                eMatDH_special_matrix_helper = eMatDH_special_matrix_helper, eMatDH_special_matrix = eMatDH_special_matrix,
+                use_eMatDH_special_symbols = use_eMatDH_special_symbols, small_transMatRate_tc_H = small_transMatRate_tc_H,
+                ref_error = ref_error, L_grid = L_grid,
+                method = method, nGibbsSamples = nGibbsSamples, n_seek_its = n_seek_its, n_burn_in_seek_its = n_burn_in_seek_its,
+                Ksubset = Ksubset, Knew = Knew, K_top_matches = K_top_matches, heuristic_match_thin = heuristic_match_thin,
+                small_ref_panel_gibbs_iterations = small_ref_panel_gibbs_iterations,
+                small_ref_panel_block_gibbs_iterations = small_ref_panel_block_gibbs_iterations,
+                maxDifferenceBetweenReads = maxDifferenceBetweenReads, minGLValue = minGLValue,
+                shuffle_bin_radius = shuffle_bin_radius, seed = seed, ff_values = ff_values,
+                use_mspbwt = use_mspbwt, mspbwtL = mspbwtL, mspbwtM = mspbwtM, mspbwt_nindices = mspbwt_nindices,
+                impute_rare_common = impute_rare_common, special_rare_common_objects = special_rare_common_objects, pos_all = pos_all,
+                L = L, pos = pos, grid = grid, bam_files = bam_files, cram_files = cram_files, reference = reference,
+                iSizeUpperLimit = iSizeUpperLimit, bqFilter = bqFilter, useSoftClippedBases = useSoftClippedBases, chr = chr,
+                sampleNames = sampleNames, downsampleToCov = downsampleToCov, tempdir = tempdir, regionName = regionName,
+                chrStart = chrStart, chrEnd = chrEnd, use_bx_tag = use_bx_tag, bxTagUpperLimit = bxTagUpperLimit,
+                minimum_number_of_sample_reads = minimum_number_of_sample_reads,
+                output_gt_phased_genotypes = output_gt_phased_genotypes
+            )
+        }
+
+'''
+R_NEW_CALL = ("            out <- if (!is.null(amd_results)) amd_results[[iSample - sampleRange[1] + 1]] else get_and_impute_one_sample(\n")
+
+
+def patched_quilt_R(text):
+    assert text.count(R_ANCHOR_LOOP) == 1 and text.count(R_ANCHOR_CALL) == 1, "QUILT/R/quilt.R: the loop over a core's samples was not found"
+    assert text.index(R_ANCHOR_LOOP) < text.index(R_ANCHOR_CALL)
+    text = text.replace(R_ANCHOR_LOOP, R_RANGE_CALL + R_ANCHOR_LOOP)
+    return text.replace(R_ANCHOR_CALL, R_NEW_CALL)
+
+
+def make_R(ref_root):
+    q = open(os.path.join(ref_root, "QUILT", "R", "quilt.R")).read()
+    new_file = open(os.path.join(HERE, "quilt-amd.R")).read()
+    return udiff(q, patched_quilt_R(q), "QUILT/R/quilt.R") + udiff("", new_file, "QUILT/R/quilt-amd.R")
+
+
 if __name__ == "__main__":
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     open(os.path.join(HERE, "QUILT-src.patch"), "w").write(make(ref))
     print(open(os.path.join(HERE, "QUILT-src.patch")).read())
+    open(os.path.join(HERE, "QUILT-R.patch"), "w").write(make_R(ref))
+    print("shim/QUILT-R.patch written (%d lines)" % len(open(os.path.join(HERE, "QUILT-R.patch")).read().splitlines()))

@@ -558,9 +558,35 @@ static double num_or(SEXP list, const char *name, double dflt) {
 /* a list of sampleReads in the flattened form of include/quilt_amd.h (read_off n + 1; read_ptr R + 1 per sample; bases back to back) */
 typedef struct { int32_t *read_off, *read_ptr, *wif, *u, *bq; } flat_reads_t;
 static void flat_reads_free(flat_reads_t *f) { free(f->read_off); free(f->read_ptr); free(f->wif); free(f->u); free(f->bq); }
-static void flatten_reads(SEXP readsListSEXP, flat_reads_t *f) {
+/* Every R-level check of a list of sampleReads, BEFORE anything is allocated: an R error longjmps out of the routine, so it must
+ * not be raised (by INTEGER() on a REALSXP, say) while panel handles, the msPBWT index or malloc'd buffers are live. */
+static void validate_reads_list(SEXP readsListSEXP, const char *what) {
+    if (TYPEOF(readsListSEXP) != VECSXP) Rf_error("quilt_amd: qa_impute_sample_range: %s must be a list of sampleReads", what);
     const int n = Rf_length(readsListSEXP);
+    for (int i = 0; i < n; i++) {
+        SEXP sr = VECTOR_ELT(readsListSEXP, i);
+        if (TYPEOF(sr) != VECSXP) Rf_error("quilt_amd: qa_impute_sample_range: %s[[%d]] is not a list of reads", what, i + 1);
+        const int R = Rf_length(sr);
+        for (int r = 0; r < R; r++) {
+            SEXP rd = VECTOR_ELT(sr, r);
+            if (TYPEOF(rd) != VECSXP || Rf_length(rd) < 4)
+                Rf_error("quilt_amd: qa_impute_sample_range: %s[[%d]][[%d]] is not list(J, wif, bq, u)", what, i + 1, r + 1);
+            SEXP bq = VECTOR_ELT(rd, 2), u = VECTOR_ELT(rd, 3), wif = VECTOR_ELT(rd, 1);
+            if (TYPEOF(bq) != INTSXP || TYPEOF(u) != INTSXP || Rf_length(bq) != Rf_length(u))
+                Rf_error("quilt_amd: qa_impute_sample_range: %s[[%d]][[%d]]: bq and u must be integer vectors of one length "
+                         "(sampleReads as loadBamAndConvert writes them)", what, i + 1, r + 1);
+            if ((TYPEOF(wif) != INTSXP && TYPEOF(wif) != REALSXP) || Rf_length(wif) < 1)
+                Rf_error("quilt_amd: qa_impute_sample_range: %s[[%d]][[%d]]: the central grid (element 2) must be a number", what, i + 1, r + 1);
+        }
+    }
+}
+
+/* returns 0, or -1 when an allocation failed (everything it allocated is then freed again).  The list has been validated. */
+static int flatten_reads(SEXP readsListSEXP, flat_reads_t *f) {
+    const int n = Rf_length(readsListSEXP);
+    memset(f, 0, sizeof *f);
     f->read_off = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    if (!f->read_off) return -1;
     f->read_off[0] = 0;
     size_t nbases = 0;
     for (int i = 0; i < n; i++) {
@@ -574,6 +600,11 @@ static void flatten_reads(SEXP readsListSEXP, flat_reads_t *f) {
     f->wif = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
     f->u = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1));
     f->bq = (int32_t *)malloc(sizeof(int32_t) * (nbases > 0 ? nbases : 1));
+    if (!f->read_ptr || !f->wif || !f->u || !f->bq) {
+        flat_reads_free(f);
+        memset(f, 0, sizeof *f);
+        return -1;
+    }
     size_t at = 0;
     for (int i = 0; i < n; i++) {
         SEXP sr = VECTOR_ELT(readsListSEXP, i);
@@ -590,6 +621,7 @@ static void flatten_reads(SEXP readsListSEXP, flat_reads_t *f) {
             rp[r + 1] = rp[r] + nb;
         }
     }
+    return 0;
 }
 
 SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP, SEXP sample_offsetSEXP, SEXP n_handlesSEXP,
@@ -607,6 +639,41 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
         Rf_error("quilt_amd: qa_impute_sample_range: panel_objects needs hapMatcherR, distinctHapsB, distinctHapsIE, "
                  "eMatDH_special_matrix_helper, eMatDH_special_matrix, transMatRate_t");
     const int K = Rf_nrows(hapMatcherR), G = Rf_ncols(hapMatcherR), T = Rf_ncols(distinctHapsIE);
+    /* ---- every check that can raise an R error comes first: nothing is allocated yet, nothing can leak */
+    validate_reads_list(readsListSEXP, "list_of_sampleReads");
+    if (allReadsListSEXP != R_NilValue) validate_reads_list(allReadsListSEXP, "list_of_allSNP_sampleReads");
+    if (TYPEOF(hapMatcherR) != RAWSXP || TYPEOF(distinctHapsB) != INTSXP || TYPEOF(distinctHapsIE) != REALSXP || TYPEOF(tm) != REALSXP ||
+        TYPEOF(helper) != INTSXP || TYPEOF(spmat) != INTSXP || (rhb_t != R_NilValue && TYPEOF(rhb_t) != INTSXP))
+        Rf_error("quilt_amd: qa_impute_sample_range: panel_objects: hapMatcherR must be raw, distinctHapsB / eMatDH_special_matrix(_helper) / "
+                 "rhb_t integer, distinctHapsIE / transMatRate_t numeric");
+    if (Rf_length(tm) != 2 * (G > 1 ? G - 1 : 0))
+        Rf_error("quilt_amd: qa_impute_sample_range: panel_objects$transMatRate_t must be 2 x (nGrids - 1)");
+    {
+        SEXP rc0 = list_get(panelSEXP, "rare_common");
+        SEXP rph0 = rc0 == R_NilValue ? R_NilValue : list_get(rc0, "rare_per_hap_info");
+        if (rph0 != R_NilValue) {
+            if (TYPEOF(rph0) != VECSXP) Rf_error("quilt_amd: qa_impute_sample_range: rare_common$rare_per_hap_info must be a list");
+            for (int k = 0; k < Rf_length(rph0); k++)
+                if (TYPEOF(VECTOR_ELT(rph0, k)) != INTSXP && Rf_length(VECTOR_ELT(rph0, k)) > 0)
+                    Rf_error("quilt_amd: qa_impute_sample_range: rare_common$rare_per_hap_info[[%d]] must be an integer vector", k + 1);
+            SEXP sic0 = list_get(rc0, "snp_is_common"), tma0 = list_get(rc0, "transMatRate_t");
+            if ((sic0 != R_NilValue && TYPEOF(sic0) != LGLSXP) || (tma0 != R_NilValue && TYPEOF(tma0) != REALSXP))
+                Rf_error("quilt_amd: qa_impute_sample_range: rare_common$snp_is_common must be logical, $transMatRate_t numeric");
+        }
+    }
+    const double seed_d = num_or(paramsSEXP, "seed", 1);
+    if (!(seed_d >= 0) || seed_d > 9007199254740992.0 /* 2^53 */ || seed_d != floor(seed_d))   /* (NA / NaN fail the first test) */
+        Rf_error("quilt_amd: qa_impute_sample_range: params$seed must be a non-negative whole number below 2^53");
+    /* which GPU: params$device (0-based; taken modulo the number of devices, so that mclapply's iCore - 1 can be passed as it
+     * is); absent: the process's current device.  Forked workers must make their first HIP call after the fork -- this one. */
+    {
+        const double dev_d = num_or(paramsSEXP, "device", -1);
+        if (dev_d >= 0) {
+            const int n_dev = qa_device_count();
+            if (n_dev < 1) Rf_error("quilt_amd: qa_impute_sample_range: no gfx950 device (libquilt_amd has no CPU fallback)");
+            check_status(qa_set_device((int)dev_d % n_dev), "qa_set_device");
+        }
+    }
     /* one handle per host thread: replicas of the panel on this process's device, taking the device in turn */
     qa_panel_desc_t d;
     memset(&d, 0, sizeof d);
@@ -616,7 +683,8 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
     d.rhb_t = have_rhb ? INTEGER(rhb_t) : NULL;
     d.distinctHapsB = INTEGER(distinctHapsB);
     d.distinctHapsIE = REAL(distinctHapsIE);
-    int *which = (int *)calloc((size_t)G, sizeof(int));
+    int *which = (int *)calloc((size_t)(G > 0 ? G : 1), sizeof(int));
+    if (!which) Rf_error("quilt_amd: qa_impute_sample_range: out of memory");   /* (nothing else is live yet) */
     int nsp = 0;
     for (int g = 0; g < G; g++)
         if (Rf_nrows(helper) == G && INTEGER(helper)[g] > 0) which[g] = ++nsp;
@@ -641,9 +709,14 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
         for (int i = 0; i < made; i++) if (handles[i]) qa_panel_destroy(handles[i]);
         check_status(st, "qa_panel_create");
     }
+    char msg[512];
+    msg[0] = 0;
     /* flatten the range's sampleReads */
     flat_reads_t fr;
-    flatten_reads(readsListSEXP, &fr);
+    if (flatten_reads(readsListSEXP, &fr) != 0) {
+        for (int i = 0; i < made; i++) if (handles[i]) qa_panel_destroy(handles[i]);
+        Rf_error("quilt_amd: qa_impute_sample_range: out of memory flattening the sampleReads");
+    }
     const int32_t *read_off = fr.read_off;
     const int totR = read_off[n];
     qa_impute_params_t ip;
@@ -664,10 +737,8 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
     ip.maxDifferenceBetweenReads = num_or(paramsSEXP, "maxDifferenceBetweenReads", ip.maxDifferenceBetweenReads);
     ip.minGLValue = num_or(paramsSEXP, "minGLValue", ip.minGLValue);
     ip.Jmax = (int)num_or(paramsSEXP, "Jmax", ip.Jmax);
-    ip.seed = (uint64_t)num_or(paramsSEXP, "seed", 1);
+    ip.seed = (uint64_t)seed_d;   /* (range-checked above) */
     ip.samples_per_launch_set = (int)num_or(paramsSEXP, "samples_per_launch_set", 0);
-    char msg[512];
-    msg[0] = 0;
     /* use_mspbwt = TRUE (QUILT2's default; mspbwt.R:225-474): the panel's indices, built here */
     qa_mspbwt_t *index = NULL;
     if (flag(paramsSEXP, "use_mspbwt", 0)) {
@@ -700,20 +771,26 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
                                       "haplotype), transMatRate_t; and one allSNP_sampleReads per sample");
         } else {
             T_out = Rf_length(sic);
-            is_common = (uint8_t *)malloc((size_t)T_out);
-            for (int t = 0; t < T_out; t++) is_common[t] = LOGICAL(sic)[t] ? 1 : 0;
+            is_common = (uint8_t *)malloc((size_t)(T_out > 0 ? T_out : 1));
             rare_ptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)K + 1));
-            rare_ptr[0] = 0;
-            for (int k = 0; k < K; k++) rare_ptr[k + 1] = rare_ptr[k] + Rf_length(VECTOR_ELT(rph, k));
-            rare_snp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rare_ptr[K] > 0 ? rare_ptr[K] : 1));
-            for (int k = 0; k < K; k++)
-                memcpy(rare_snp + rare_ptr[k], INTEGER(VECTOR_ELT(rph, k)), sizeof(int) * (size_t)(rare_ptr[k + 1] - rare_ptr[k]));
+            if (is_common && rare_ptr) {
+                for (int t = 0; t < T_out; t++) is_common[t] = LOGICAL(sic)[t] ? 1 : 0;
+                rare_ptr[0] = 0;
+                for (int k = 0; k < K; k++) rare_ptr[k + 1] = rare_ptr[k] + Rf_length(VECTOR_ELT(rph, k));
+                rare_snp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rare_ptr[K] > 0 ? rare_ptr[K] : 1));
+            }
+            if (!is_common || !rare_ptr || !rare_snp || flatten_reads(allReadsListSEXP, &fa) != 0) {
+                st = QA_ERR_INVALID;
+                snprintf(msg, sizeof msg, "out of memory preparing the rare + common inputs");
+            }
+            for (int k = 0; st == QA_OK && k < K; k++)
+                if (rare_ptr[k + 1] > rare_ptr[k])
+                    memcpy(rare_snp + rare_ptr[k], INTEGER(VECTOR_ELT(rph, k)), sizeof(int) * (size_t)(rare_ptr[k + 1] - rare_ptr[k]));
             for (; n_rc < n_handles && st == QA_OK; n_rc++) {
                 rcs[n_rc] = NULL;
                 st = qa_rare_common_create(handles[n_rc], T_out, is_common, rare_ptr, rare_snp, REAL(tma), &rcs[n_rc]);
             }
-            if (st != QA_OK) snprintf(msg, sizeof msg, "qa_rare_common_create: %s", qa_last_error());
-            flatten_reads(allReadsListSEXP, &fa);
+            if (st != QA_OK && !msg[0]) snprintf(msg, sizeof msg, "qa_rare_common_create: %s", qa_last_error());
             rcq.handles = (const qa_rare_common_t *const *)rcs;
             rcq.nSNPs_all = T_out;
             rcq.nGrids_all = (T_out + 31) / 32;
@@ -721,7 +798,7 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
             rcq.read_off = fa.read_off; rcq.read_ptr = fa.read_ptr; rcq.u = fa.u; rcq.bq = fa.bq; rcq.wif = fa.wif;
             if (lga != R_NilValue && Rf_length(lga) == rcq.nGrids_all) {
                 L_grid_all = (int32_t *)malloc(sizeof(int32_t) * (size_t)rcq.nGrids_all);
-                for (int g = 0; g < rcq.nGrids_all; g++) L_grid_all[g] = TYPEOF(lga) == INTSXP ? INTEGER(lga)[g] : (int32_t)REAL(lga)[g];
+                for (int g = 0; L_grid_all && g < rcq.nGrids_all; g++) L_grid_all[g] = TYPEOF(lga) == INTSXP ? INTEGER(lga)[g] : (int32_t)REAL(lga)[g];
                 rcq.L_grid_all = L_grid_all;
             }
             ip.rare_common = &rcq;
@@ -744,7 +821,8 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
             snprintf(msg, sizeof msg, "method = \"nipt\": params$ff (one per sample, numeric) and panel_objects$L_grid (nGrids) are needed");
         } else {
             L_grid = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
-            for (int g = 0; g < G; g++) L_grid[g] = TYPEOF(lg) == INTSXP ? INTEGER(lg)[g] : (int32_t)REAL(lg)[g];
+            if (!L_grid) { st = QA_ERR_INVALID; snprintf(msg, sizeof msg, "out of memory"); }
+            for (int g = 0; L_grid && g < G; g++) L_grid[g] = TYPEOF(lg) == INTSXP ? INTEGER(lg)[g] : (int32_t)REAL(lg)[g];
             fet_dosage = PROTECT(Rf_allocMatrix(REALSXP, T_out, n));
             fet_gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T_out, n));
             n_prot = 2;
@@ -760,6 +838,7 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
     SEXP haps = PROTECT(Rf_allocMatrix(REALSXP, nL * T_out, n)), nDosage = PROTECT(Rf_allocVector(INTSXP, n));
     SEXP stats = PROTECT(Rf_allocVector(REALSXP, 11));
     int32_t *labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
+    if (!labels && st == QA_OK) { st = QA_ERR_INVALID; snprintf(msg, sizeof msg, "out of memory"); }
     int64_t st64[11] = {0};
     if (st == QA_OK) {
         st = qa_impute_samples(handles, n_handles, &ip, n, (int64_t)Rf_asReal(sample_offsetSEXP), read_off, fr.read_ptr, fr.u, fr.bq, fr.wif,
