@@ -333,11 +333,12 @@ def main():
     ap.add_argument("--rare-common", type=float, default=0.0, metavar="F",
                     help="impute_rare_common with F x nsnps rare SNPs: every Gibbs sample ends with a Gibbs call over all SNPs "
                          "(QUILT2; not the headline workload, no CPU baseline)")
-    ap.add_argument("--precision", choices=["both", "fp64", "mixed"], default="both",
+    ap.add_argument("--precision", choices=["both", "fp64", "mixed"], default="fp64",
                     help="fp64: every kernel of the path computes in double, as the reference (the headline `value`); mixed: dosage "
-                         "passes with fp32 state, fp64 emissions and sums (SURVEY 8(d)'s fp32 alpha checkpoint); both (default): the "
+                         "passes with fp32 state, fp64 emissions and sums (SURVEY 8(d)'s fp32 alpha checkpoint); both: the "
                          "K timed steps run at fp64 and are reported as `value`, then the same K steps run again with the mixed "
-                         "dosage passes in a second timed region of their own, reported under `mixed_precision`")
+                         "dosage passes in a second timed region of their own, reported under `mixed_precision` (the default until round 4; "
+                         "since the CPU baseline is measured on whole samples -- six minutes of wall -- the default run is the fp64 region alone)")
     ap.add_argument("--fp64-dosage", action="store_true", help="(older spelling of --precision fp64)")
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
@@ -394,8 +395,16 @@ def main():
     ap.add_argument("--dotcall", type=int, default=None, metavar="W",
                     help="after the timed regions, measure the `.Call` shim's path as well (scripts/dotcall_path.py: per sample, per "
                          "Gibbs sample, one qa_gibbs_batch(n_chain = 1) and one qa_Rcpp_haploid_dosage_versus_refs per label, from W "
-                         "worker processes sharing the GPU; one timed sample per worker) and report it as `dotcall_path`; default 16 "
-                         "for the headline workload at N = 1, 0 = off")
+                         "worker processes sharing the GPU; one timed sample per worker) and report it as `dotcall_path`; default 0 "
+                         "= off (16 is what the committed lines used)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the N-rank run on ONE GPU: every rank uses device 0 (set QA_ARENA_FRACTION so that N arenas fit) and "
+                         "the ranks synchronise over gloo (RCCL refuses several ranks on one device).  Exercises N processes' panel "
+                         "uploads, arenas, pinned buffers and gates at once; its samples/s is NOT a scaling figure")
+    ap.add_argument("--digest", default=None, metavar="DIR",
+                    help="write DIR/step_<global step>.sha256 for every timed step: a digest of the step's results (dosage, gp_t, phased "
+                         "haplotypes, read labels, sample by sample), keyed by the GLOBAL step index rank * (warmup + steps) + step -- "
+                         "an N-rank run and a 1-rank run over the same global steps must write the same files")
     ap.add_argument("--stub", action="store_true",
                     help="test hook: no device work at all (gloo rendezvous, a driver that returns zeros); value is 0")
     a = ap.parse_args()
@@ -500,13 +509,17 @@ def main():
         cpu_pipeline = cpu_pipeline_reference(a, panel, params, samples)
     import torch
     import torch.distributed as dist
+    if a.one_device:
+        local_rank_dev = 0
+    else:
+        local_rank_dev = local_rank
     if world > 1:
-        if a.stub:
+        if a.stub or a.one_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not a.stub:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank_dev)
 
     from quilt_amd.driver import DriverParams
     if a.stub:
@@ -516,7 +529,7 @@ def main():
     else:
         from quilt_amd import native
         from quilt_amd.workers import DeviceWorkers
-        native.check(native.lib().qa_set_device(local_rank))
+        native.check(native.lib().qa_set_device(local_rank_dev))
         if a.driver == "native":
             from quilt_amd.workers import NativeWorkers
             drv = NativeWorkers(panel, DriverParams(**params), n_workers=a.workers, fp64_dosage=a.precision != "mixed",
@@ -551,9 +564,9 @@ def main():
             pass
         if native is not None:
             native.lib().qa_profile_reset()
-            native.gate_stats(local_rank, reset=True)
+            native.gate_stats(local_rank_dev, reset=True)
             if a.gate_trace:
-                native.gate_trace(local_rank, on=True)
+                native.gate_trace(local_rank_dev, on=True)
         drv.reset_timing()
         # the native loop's caller holds the range's reads in the C ABI's flat form (include/quilt_amd.h: the samples' reads back
         # to back) before the clock starts -- host buffers, still to cross PCIe; concatenating 2 560 Python objects' arrays is
@@ -565,8 +578,20 @@ def main():
         last = None
         # the K timed steps are K whole batches: the driver pipelines consecutive batches (phasing rounds of one fused
         # with the main rounds of the next), and the pipeline is filled and drained inside the timed region
+        n_seen = 0
         for res in drv.run_stream(timed_input if timed_input is not None else stream(a.warmup, n_steps)):
             last = res[-a.batch:]   # (the results of the last STEP: the tail of the last launch set)
+            if a.digest:   # (launch sets come back in order, a.fuse steps each)
+                import hashlib
+                os.makedirs(a.digest, exist_ok=True)
+                for q in range(0, len(res), a.batch):
+                    h = hashlib.sha256()
+                    for r in res[q:q + a.batch]:
+                        for arr in (r.dosage, r.gp_t, r.phasing_haps, r.read_labels):
+                            h.update(np.ascontiguousarray(arr).tobytes())
+                    g_step = rank * n_steps + a.warmup + n_seen
+                    open(os.path.join(a.digest, f"step_{g_step}.sha256"), "w").write(h.hexdigest() + "\n")
+                    n_seen += 1
         barrier()
         elapsed = time.perf_counter() - t0
         per_rank = None
@@ -574,20 +599,20 @@ def main():
             # every rank's own clock around its K steps (the barrier on either side makes them nearly equal; what differs is a
             # rank that finished early and waited), its host-thread budget and how long it waited for rank 0's CPU legs
             mine = torch.tensor([elapsed, float(os.environ.get("QA_HOST_THREADS", "0")), float(getattr(a, "waited_for_rank0_s", 0.0))],
-                                dtype=torch.float64, device="cpu" if a.stub else "cuda")
+                                dtype=torch.float64, device="cpu" if (a.stub or a.one_device) else "cuda")
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
             per_rank = [[float(x) for x in r.cpu()] for r in allr]
-            t = torch.tensor([elapsed], device="cpu" if a.stub else "cuda")
+            t = torch.tensor([elapsed], device="cpu" if (a.stub or a.one_device) else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         reg = dict(elapsed=elapsed, last=last, timing=dict(drv.timing), chains=getattr(drv, "n_gibbs_chain_calls", 0),
                    per_rank=per_rank)
         if native is not None:
             reg["prof"] = read_profile(native)
-            reg["gate"] = native.gate_stats(local_rank)
+            reg["gate"] = native.gate_stats(local_rank_dev)
             if a.gate_trace and rank == 0:
-                tr = native.gate_trace(local_rank, on=False)
+                tr = native.gate_trace(local_rank_dev, on=False)
                 if len(tr):
                     np.save(a.gate_trace, np.column_stack([tr[:, :4] - t0_gate, tr[:, 4:]]))
                 a.gate_trace = None
@@ -605,6 +630,10 @@ def main():
     if rank == 0:
         out = report(a, panel, params, native, drv, samples, main_reg, world, rc, cpu, keep, ff, full_chains, alone,
                      fp64=a.precision != "mixed")
+        if a.one_device and world > 1:
+            out["one_device_rehearsal"] = (f"{world} ranks on ONE GPU (device 0, gloo rendezvous, QA_ARENA_FRACTION="
+                                           f"{os.environ.get('QA_ARENA_FRACTION', 'default')}): a rehearsal of the N-rank run's host side "
+                                           "and of N processes sharing a device -- `value` is NOT a scaling figure")
         if mixed_reg is not None:
             mx = report(a, panel, params, native, drv, samples, mixed_reg, world, rc, None, None, ff, full_chains, None, fp64=False)
             out["mixed_precision"] = {k: mx[k] for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "kernels", "host_seconds",
@@ -615,8 +644,7 @@ def main():
             out["mixed_precision"]["dosage_vs_fp64_run_sample0"] = {"r2": float(np.corrcoef(a_, b_)[0, 1] ** 2),
                                                                     "max_abs_diff": float(np.abs(a_ - b_).max())}
         if a.dotcall is None:
-            a.dotcall = 16 if (world == 1 and a.mode == "short" and not a.mspbwt and rc is None and native is not None and
-                               not a.no_cpu_baseline) else 0
+            a.dotcall = 0   # (80 s; off by default since round 5 -- `--dotcall 16` measures it: profiles/r05_bench_line_dotcall.json)
         if native is not None and world == 1 and a.driver == "native" and hasattr(drv, "devs"):
             # one sample alone on the device (the quick-start's shape): the latency of the whole per-sample pipeline
             from quilt_amd.impute import impute_samples
