@@ -439,6 +439,12 @@ typedef struct {
      * chain by chain on the host.  hap_major_labels: 2 or 3. */
     double *hap_major_out;
     int32_t hap_major_labels;
+    /* NULL, or n_chain indices: reads_same_as[c] = the first chain of THIS call whose reads (read_ptr block, u, bq) are the same
+     * as chain c's -- c itself for the first chain of a sample.  A batched driver's seven chains of one sample share their
+     * reads: with this the bases of a chain that names an earlier one are neither read nor uploaded (its u / bq block may be
+     * left unwritten, its read_ptr block and wif must still be there), which at 192 000 SNPs saves six of seven copies of
+     * 1.6 MB per chain on the host and over PCIe.  Results do not depend on it. */
+    const int32_t *reads_same_as;
 } qa_gibbs_opts_t;
 
 /*
@@ -542,6 +548,18 @@ int qa_rare_common_create(qa_panel_t *panel, int32_t nSNPs_all, const uint8_t *s
                           const int64_t *rare_ptr, const int32_t *rare_snp_1based,
                           const double *transMatRate_t_all, qa_rare_common_t **out);
 void qa_rare_common_destroy(qa_rare_common_t *rc);
+
+/* get_initial_read_labels' read likelihoods (QUILT/R/rare_common.R:61-107) for many chains WITHOUT the haplotypes spread over all
+ * SNPs on the host: hap_common is [n_chain][K][nSNPs_common] (hap-major: the layout the driver holds the last seek iteration's
+ * haploid dosages in); the kernel supplies the 0.5 of the rare SNPs through rare_common's all-SNP -> common index.  The all-SNP
+ * reads are given once per SAMPLE (n_sample, flattened as for qa_gibbs_batch) with chain_sample[c] (0-based) naming a chain's
+ * sample.  eMatRead_t: chain after chain, [reads of the chain's sample][K].  Same numbers as qa_rcpp_make_eMatRead_t_nsnps on the
+ * expanded haplotypes. */
+int qa_rcpp_make_eMatRead_t_rare_common(qa_panel_t *panel, const qa_rare_common_t *rare_common, int32_t n_chain, int32_t n_sample,
+                                        const int32_t *chain_sample, int32_t K, const double *hap_common, const int32_t *read_off,
+                                        const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                                        double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                                        double *eMatRead_t);
 
 /*
  * `_QUILT_rcpp_forwardBackwardGibbsNIPT` called with make_eMatRead_t_rare_common = TRUE

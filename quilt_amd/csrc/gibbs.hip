@@ -41,6 +41,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <memory>
 
 #include "gibbs_dev.hpp"
@@ -739,9 +740,13 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
     const int g = blockIdx.x, c = blockIdx.y;
     const int b = threadIdx.x & 31, part = threadIdx.x >> 5;
     __shared__ double s_g[3][8][32], s_t[3][8];
-    __shared__ uint32_t s_w[1024];
-    __shared__ double s_gk[3][1024];
+    // gamma columns and panel words sized by the call (nH x Ksp doubles + Ksp words: 18 KB at Ks = 600, two labels, against the
+    // 34 KB of fixed [3][1024] arrays): twice the workgroups per compute unit for a kernel that waits on gathers
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     const int Ks = p.Ks, Ksp = p.Ksp, G = p.G;
+    double *const s_gk0 = reinterpret_cast<double *>(s_dyn);
+    uint32_t *const s_w = reinterpret_cast<uint32_t *>(s_gk0 + (size_t)p.nH * Ksp);
+    auto gk = [&](int h, int k) -> double & { return s_gk0[(size_t)h * Ksp + k]; };
     const int32_t *which = p.which + (size_t)c * Ks;
     const size_t mat = (size_t)G * Ksp;
     // gamma once per (label, haplotype), read with consecutive lanes on consecutive haplotypes (it used to be re-formed by
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
         for (int h = 0; h < p.nH; h++) {
             const size_t o = ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp + k;
             const double x = 1 / p.cvec[((size_t)c * 3 + h) * G + g];
-            s_gk[h][k] = (p.alpha[o] * p.beta[o]) * x;
+            gk(h, k) = (p.alpha[o] * p.beta[o]) * x;
         }
     }
     __syncthreads();
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
     if (p.nH == 2) {
         for (int k = part; k < Ks; k += 8) {
             const bool on = (s_w[k] >> b) & 1u;
-            const double g0 = s_gk[0][k], g1 = s_gk[1][k];
+            const double g0 = gk(0, k), g1 = gk(1, k);
             tot[0] += g0; tot[1] += g1;
             if (on) { acc[0] += g0; acc[1] += g1; }
         }
@@ -769,9 +774,9 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
         for (int k = part; k < Ks; k += 8) {
             const bool on = (s_w[k] >> b) & 1u;
             for (int h = 0; h < p.nH; h++) {
-                const double gk = s_gk[h][k];
-                tot[h] += gk;
-                if (on) acc[h] += gk;
+                const double gv = gk(h, k);
+                tot[h] += gv;
+                if (on) acc[h] += gv;
             }
         }
     }
@@ -813,34 +818,43 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
 __global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
     const int g = blockIdx.x, c = blockIdx.y;
     const int b = threadIdx.x & 31, part = threadIdx.x >> 5;
-    __shared__ double s_gam[3][1024], s_on[3][8][32], s_all[3][8];
-    __shared__ uint32_t s_w[2][1024];
+    __shared__ double s_on[3][8][32], s_all[3][8];
     __shared__ int s_cg;
+    // gamma columns, the two common grids' panel words and the chain's haplotype list sized by the call (see k_happrobs)
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     const int Ks = p.Ks, Ksp = p.Ksp, G = p.G;
+    double *const s_gam0 = reinterpret_cast<double *>(s_dyn);
+    uint32_t *const s_w0 = reinterpret_cast<uint32_t *>(s_gam0 + (size_t)p.nH * Ksp);
+    int32_t *const s_which = reinterpret_cast<int32_t *>(s_w0 + 2 * (size_t)Ksp);
+    auto gam = [&](int h, int k) -> double & { return s_gam0[(size_t)h * Ksp + k]; };
+    auto sw = [&](int q, int k) -> uint32_t & { return s_w0[(size_t)q * Ksp + k]; };
     const int32_t *which = p.which + (size_t)c * Ks;
     const int s = 32 * g, nLocal = min(32, p.T - s);
-    if (threadIdx.x == 0) {
-        int cg = -1;
-        for (int i = 0; i < nLocal && cg < 0; i++) {
-            const int cs = p.rc_common[s + i];
-            if (cs >= 0) cg = cs >> 5;
-        }
-        s_cg = cg;
+    // the common grid of the block's first common SNP: the 32 SNPs looked at together by the first wave (it used to be one
+    // thread walking them with a dependent load each)
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        const int cs = i < nLocal ? p.rc_common[s + i] : -1;
+        const unsigned long long m = __ballot(cs >= 0);
+        const int first = m ? __ffsll((long long)m) - 1 : -1;
+        const int cs_first = __shfl(cs, first < 0 ? 0 : first, 64);
+        if (i == 0) s_cg = first < 0 ? -1 : (cs_first >> 5);
     }
     __syncthreads();
     const int cg = s_cg;
     const size_t mat = (size_t)G * Ksp;
     for (int k = threadIdx.x; k < Ks; k += 256) {
         const int kk = which[k];
+        s_which[k] = kk;
         for (int q = 0; q < 2; q++) {
             const int gq = cg + q;
-            s_w[q][k] = (cg >= 0 && gq < p.rc_Gc) ? panel_word(p, gq, kk, p.hm[(size_t)gq * p.Kp + kk]) : 0u;
+            sw(q, k) = (cg >= 0 && gq < p.rc_Gc) ? panel_word(p, gq, kk, p.hm[(size_t)gq * p.Kp + kk]) : 0u;
         }
         for (int h = 0; h < p.nH; h++) {
             const double *a = p.alpha + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
             const double *be = p.beta + ((size_t)c * p.nH + h) * mat + (size_t)g * Ksp;
             const double x = 1 / p.cvec[((size_t)c * 3 + h) * G + g];
-            s_gam[h][k] = (a[k] * be[k]) * x;
+            gam(h, k) = (a[k] * be[k]) * x;
         }
     }
     __syncthreads();
@@ -852,16 +866,16 @@ __global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
     if (b < nLocal && (!rare || any)) {
         const int q = rare ? 0 : (cs >> 5) - cg, bit = cs & 31;
         for (int k = part; k < Ks; k += 8) {
-            const bool alt = rare ? rare_has_alt(p, which[k], snp) : ((s_w[q][k] >> bit) & 1u);
+            const bool alt = rare ? rare_has_alt(p, s_which[k], snp) : ((sw(q, k) >> bit) & 1u);
             for (int h = 0; h < p.nH; h++) {
-                if (alt) on[h] += s_gam[h][k];
+                if (alt) on[h] += gam(h, k);
             }
         }
     }
     for (int h = 0; h < 3; h++) s_on[h][part][b] = on[h];
     if (b == 0) {   // the column total does not depend on the SNP
         double t[3] = {0, 0, 0};
-        for (int k = part; k < Ks; k += 8) for (int h = 0; h < p.nH; h++) t[h] += s_gam[h][k];
+        for (int k = part; k < Ks; k += 8) for (int h = 0; h < p.nH; h++) t[h] += gam(h, k);
         for (int h = 0; h < 3; h++) s_all[h][part] = t[h];
     }
     __syncthreads();
@@ -895,6 +909,12 @@ __global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
 // One thread per (read, chain): K is 2 or 3, the products run over the read's bases in order.
 // ---------------------------------------------------------------------------------------------
 struct DenseParams {
+    // rare + common form (qa_rcpp_make_eMatRead_t_rare_common): eHaps is [C][K][Tc] over the COMMON SNPs, a rare SNP's entry is
+    // 0.5 (get_initial_read_labels, rare_common.R:61-107), the reads are per SAMPLE with a chain -> sample map
+    const int32_t *common_index = nullptr;   // [T] all-SNP index -> common-SNP index or -1
+    const int32_t *chain_sample = nullptr;   // [C] or null (reads per chain)
+    const int32_t *out_off = nullptr;        // [C] first output row of the chain (with chain_sample)
+    int Tc = 0;
     int C, K, T, Jmax, rescale, hap_major;
     double inv_maxdiff;
     const double *eHaps;      // [C][T][K], or [C][K][T] with hap_major
@@ -905,12 +925,13 @@ struct DenseParams {
 
 __global__ __launch_bounds__(64) void k_ematread_dense(DenseParams p) {
     const int c = blockIdx.y;
-    const int R = p.read_off[c + 1] - p.read_off[c];
+    const int sr = p.chain_sample ? p.chain_sample[c] : c;   // whose reads
+    const int R = p.read_off[sr + 1] - p.read_off[sr];
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= R) return;
-    const int32_t *rp = p.read_ptr + p.read_off[c] + c;
-    const int32_t *u = p.u + p.base_off[c], *bq = p.bq + p.base_off[c];
-    const double *eh = p.eHaps + (size_t)c * p.T * p.K;
+    const int32_t *rp = p.read_ptr + p.read_off[sr] + sr;
+    const int32_t *u = p.u + p.base_off[sr], *bq = p.bq + p.base_off[sr];
+    const double *eh = p.eHaps + (size_t)c * (p.common_index ? p.Tc : p.T) * p.K;
     double v[3] = {1, 1, 1};
     const int s = rp[r];
     int J = rp[r + 1] - s - 1;
@@ -920,7 +941,10 @@ __global__ __launch_bounds__(64) void k_ematread_dense(DenseParams p) {
         if (b == 0) continue;
         const int ab = b < 0 ? -b : b;
         const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
-        if (p.hap_major) {
+        if (p.common_index) {
+            const int cs = p.common_index[u[s + j]];
+            for (int k = 0; k < p.K; k++) { const double ek = cs >= 0 ? eh[(size_t)k * p.Tc + cs] : 0.5; v[k] *= (ek * pA + (1 - ek) * pR); }
+        } else if (p.hap_major) {
             const double *e = eh + u[s + j];
             for (int k = 0; k < p.K; k++) { const double ek = e[(size_t)k * p.T]; v[k] *= (ek * pA + (1 - ek) * pR); }
         } else {
@@ -941,7 +965,7 @@ __global__ __launch_bounds__(64) void k_ematread_dense(DenseParams p) {
             }
         }
     }
-    double *o = p.out + (size_t)(p.read_off[c] + r) * p.K;
+    double *o = p.out + (size_t)((p.out_off ? p.out_off[c] : p.read_off[c]) + r) * p.K;
     for (int k = 0; k < p.K; k++) o[k] = v[k];
 }
 
@@ -1105,8 +1129,11 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
     }
     QA_HIP(hipEventRecord(ev[2], st));
     if (want_probs) {   // return_hapProbs / return_genProbs (functions.R:2566-2599): skipped when nobody asks
-        if (prm.rc_common) hipLaunchKernelGGL(k_happrobs_rc, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
-        else hipLaunchKernelGGL(k_happrobs, dim3(prm.G, prm.C), dim3(256), 0, st, prm);
+        // dynamic LDS: nH gamma columns of Ksp doubles + the panel words (+ the haplotype list for the rare + common form)
+        const size_t lds_hp = (size_t)prm.nH * prm.Ksp * 8 + (size_t)prm.Ksp * 4;
+        const size_t lds_rc = (size_t)prm.nH * prm.Ksp * 8 + (size_t)2 * prm.Ksp * 4 + (size_t)prm.Ksp * 4;
+        if (prm.rc_common) hipLaunchKernelGGL(k_happrobs_rc, dim3(prm.G, prm.C), dim3(256), lds_rc, st, prm);
+        else hipLaunchKernelGGL(k_happrobs, dim3(prm.G, prm.C), dim3(256), lds_hp, st, prm);
         QA_HIP(hipGetLastError());
     }
     QA_HIP(hipEventRecord(ev[3], st));
@@ -1114,7 +1141,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
 
 }  // namespace
 
-static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, int per_it_off, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, const int64_t *rep_off, int per_it_off, int32_t n_chain, const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
@@ -1154,7 +1181,27 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
             ixtot += (size_t)R * er_nt * er_padb;
         }
         const int totB = base_off[C];
-        bq_eff.assign(bq, bq + totB);
+        // opts->reads_same_as: chains that share their sample's reads.  rep[c] = the first chain OF THIS LAUNCH with chain c's
+        // reads (c itself without the option); only the representatives' bases are looked at and uploaded.
+        std::vector<int32_t> rep(C);
+        std::vector<int64_t> hbase(C);   // where a chain's bases are looked at on the host, relative to this launch's u / bq
+        bool aliased = false;
+        {
+            std::map<int64_t, int32_t> first_of;
+            for (int c = 0; c < C; c++) {
+                rep[c] = c;
+                hbase[c] = rep_off ? rep_off[c] : (int64_t)base_off[c];
+                if (!rep_off) continue;
+                auto it = first_of.find(rep_off[c]);
+                if (it == first_of.end()) { first_of.emplace(rep_off[c], c); aliased |= rep_off[c] != (int64_t)base_off[c]; continue; }
+                const int r0 = it->second;
+                if (read_off[r0 + 1] - read_off[r0] != read_off[c + 1] - read_off[c] || base_off[r0 + 1] - base_off[r0] != base_off[c + 1] - base_off[c])
+                    throw std::runtime_error("reads_same_as names a chain with other reads");
+                rep[c] = r0;
+                aliased = true;
+            }
+        }
+        bq_eff.resize((size_t)std::max(totB, 1));
         std::vector<int32_t> n_dense(C, 0);
         {
             // validation, grid_has_read, 0-based haplotypes, the bq == 0 carry-over (fold_zero_base_qualities) and the
@@ -1162,11 +1209,16 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
             // pattern width): independent per chain, spread over host threads
             const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), C));
             std::vector<std::string> errs(n_thr);
+            int pass = 0;   // 0: the representatives (they fold their base qualities in place); 1: the chains that share a representative's
             auto work = [&](int tid) {
                 try {
                     for (int c = tid; c < C; c += n_thr) {
+                        if ((rep[c] == c) != (pass == 0)) continue;
                         const int R = read_off[c + 1] - read_off[c];
                         const int32_t *rp = read_ptr + read_off[c] + c;
+                        const int64_t hb = hbase[c];          // where this chain's bases are looked at (u, bq)
+                        const size_t fb = (size_t)base_off[rep[c]];   // the representative's block of bq_eff
+                        if (pass == 0) std::memcpy(&bq_eff[fb], bq + hb, sizeof(int32_t) * (size_t)(base_off[c + 1] - base_off[c]));
                         for (int r = 0; r < R; r++) {
                             const int g = wif[read_off[c] + r];
                             if (g < 0 || g >= G) throw std::runtime_error("read grid index out of range");
@@ -1183,15 +1235,16 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
                                     rc_any[(size_t)c * rc_words + (t >> 5)] |= 1u << (t & 31);
                                 }
                         }
-                        const int32_t *cu = u + base_off[c];
+                        const int32_t *cu = u + hb;
                         int last = 0, nd = 0;
                         for (int r = 0; r < R; r++) {
                             int J = rp[r + 1] - rp[r] - 1;
                             if (J >= o->Jmax) J = o->Jmax;
                             int n_inf = 0;
                             for (int j = 0; j <= J; j++) {
-                                int32_t &b = bq_eff[(size_t)base_off[c] + rp[r] + j];
+                                int32_t b = bq_eff[fb + rp[r] + j];
                                 if (b == 0) b = last; else last = b;
+                                if (pass == 0) bq_eff[fb + rp[r] + j] = b;   // (a sharing chain reads the folded values: folding them again changes nothing)
                                 if (b > 255 || b < -255) throw std::runtime_error("|base quality| > 255");
                                 const int t = cu[rp[r] + j];
                                 if (t < 0 || t >= T) throw std::runtime_error("read SNP index out of range");
@@ -1208,11 +1261,13 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
                     errs[tid] = e.what();
                 }
             };
-            std::vector<std::thread> th;
-            for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
-            work(0);
-            for (auto &t : th) t.join();
-            for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+            for (pass = 0; pass < (aliased ? 2 : 1); pass++) {
+                std::vector<std::thread> th;
+                for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
+                work(0);
+                for (auto &t : th) t.join();
+                for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+            }
         }
         for (int c = 0; c < C; c++) {
             eoff[c] = etot;
@@ -1229,9 +1284,30 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         S.which.ensure(which0.size()); S.which.upload(which0.data(), which0.size(), st);
         S.read_off.ensure(C + 1); S.read_off.upload(read_off, C + 1, st);
         S.read_ptr.ensure(totR + C); S.read_ptr.upload(read_ptr, totR + C, st);
-        S.base_off.ensure(C + 1); S.base_off.upload(base_off.data(), C + 1, st);
-        S.u.ensure(std::max(totB, 1)); S.u.upload(u, totB, st);
-        S.bq.ensure(std::max(totB, 1)); S.bq.upload(bq_eff.data(), totB, st);
+        if (!aliased) {
+            S.base_off.ensure(C + 1); S.base_off.upload(base_off.data(), C + 1, st);
+            S.u.ensure(std::max(totB, 1)); S.u.upload(u, totB, st);
+            S.bq.ensure(std::max(totB, 1)); S.bq.upload(bq_eff.data(), totB, st);
+        } else {
+            // the representatives' bases back to back; every chain's device offset is its representative's (the kernels take
+            // base_off[c] as the start of the chain's bases and nothing else)
+            std::vector<int32_t> dev_off(C + 1, 0), cu_h, cb_h;
+            int at = 0;
+            for (int c = 0; c < C; c++)
+                if (rep[c] == c) { dev_off[c] = at; at += base_off[c + 1] - base_off[c]; }
+            for (int c = 0; c < C; c++) dev_off[c] = dev_off[rep[c]];
+            dev_off[C] = at;
+            cu_h.resize((size_t)std::max(at, 1)); cb_h.resize((size_t)std::max(at, 1));
+            for (int c = 0; c < C; c++)
+                if (rep[c] == c) {
+                    const size_t nb_c = (size_t)(base_off[c + 1] - base_off[c]);
+                    std::memcpy(&cu_h[(size_t)dev_off[c]], u + hbase[c], sizeof(int32_t) * nb_c);
+                    std::memcpy(&cb_h[(size_t)dev_off[c]], &bq_eff[(size_t)base_off[c]], sizeof(int32_t) * nb_c);
+                }
+            S.base_off.ensure(C + 1); S.base_off.upload(dev_off.data(), C + 1, st);
+            S.u.ensure(std::max(at, 1)); S.u.upload(cu_h.data(), at, st);
+            S.bq.ensure(std::max(at, 1)); S.bq.upload(cb_h.data(), at, st);
+        }
         S.wif.ensure(std::max(totR, 1)); S.wif.upload(wif, totR, st);
         S.ghr.ensure(ghr.size()); S.ghr.upload(ghr.data(), ghr.size(), st);
         S.tabs.ensure(tabs.size()); S.tabs.upload(tabs.data(), tabs.size(), st);
@@ -1518,6 +1594,14 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             return QA_ERR_INVALID;
         }
     }
+    if (o->reads_same_as)
+        for (int c = 0; c < n_chain; c++) {
+            const int r0 = o->reads_same_as[c];
+            if (r0 < 0 || r0 > c || o->reads_same_as[r0] != r0 || read_off[r0 + 1] - read_off[r0] != read_off[c + 1] - read_off[c]) {
+                qa::set_error("qa_gibbs_batch: reads_same_as[%d] must name an earlier chain (or the chain itself) that names itself and has as many reads", c);
+                return QA_ERR_INVALID;
+            }
+        }
     if (o->Ks <= 0 || o->Ks > 1024) {
         qa::set_error("qa_gibbs_batch: Ksubset = %d outside 1..1024", o->Ks);
         return QA_ERR_UNSUPPORTED;
@@ -1541,12 +1625,63 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
         // launcher picks: <= 1 024 B); the many-wave geometries of the QA_GIBBS_NW test hook take up to 2 560 B
         const size_t pat_bytes = getenv("QA_GIBBS_NW") ? 2560 : 1024;
         std::vector<size_t> adds(n_chain);
+        // Rare + common form: a read is dense only when it covers more than kMaxPatternBits INFORMATIVE SNPs -- common SNPs and
+        // rare SNPs some selected haplotype carries (gibbs_chunk below, k_ematread) -- which most all-SNP reads do not, although
+        // they cover three times the bases.  Counting bases here (the bound the common-SNP form uses) priced a chain at ~290 MB
+        // instead of ~230 MB and cut every all-SNP launch of 896 chains into two of 448, each at a chain's full serial time
+        // (round 5: 20 of the QUILT2-default bench's 44 launches).  So count as gibbs_chunk does, chains over host threads.
+        std::vector<size_t> n_long_of(n_chain, 0);
+        {
+            const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), n_chain));
+            const int rc_words = rc ? (T + 31) / 32 : 0;
+            std::vector<std::string> errs(n_thr);
+            auto work = [&](int tid) {
+                try {
+                    std::vector<uint32_t> any(rc_words);
+                    for (int c = tid; c < n_chain; c += n_thr) {
+                        const size_t R = read_off[c + 1] - read_off[c];
+                        const int32_t *rp = read_ptr + read_off[c] + c;
+                        size_t n_long = 0;
+                        if (!rc) {
+                            for (size_t r = 0; r < R; r++) n_long += std::min(rp[r + 1] - rp[r], o->Jmax + 1) > kMaxPatternBits;
+                        } else {
+                            std::fill(any.begin(), any.end(), 0u);
+                            for (int k = 0; k < Ks; k++) {
+                                const int v = which_haps_to_use_1based[(size_t)c * Ks + k] - 1;
+                                if (v < 0 || v >= pn->K) throw std::runtime_error("which_haps_to_use out of range");
+                                for (int64_t i = rc->h_rare_ptr[v]; i < rc->h_rare_ptr[v + 1]; i++) {
+                                    const int t = rc->h_rare_snp[i];
+                                    any[t >> 5] |= 1u << (t & 31);
+                                }
+                            }
+                            const int32_t *cu = u + base_of[o->reads_same_as ? o->reads_same_as[c] : c];
+                            for (size_t r = 0; r < R; r++) {
+                                const int nb_r = std::min(rp[r + 1] - rp[r], o->Jmax + 1);
+                                int n_inf = 0;
+                                for (int j = 0; j < nb_r; j++) {   // (an upper bound of gibbs_chunk's count: it also drops bases of quality 0)
+                                    const int t = cu[rp[r] + j];
+                                    if (t < 0 || t >= T) throw std::runtime_error("read SNP index out of range");
+                                    n_inf += rc->h_common_index[t] >= 0 || ((any[t >> 5] >> (t & 31)) & 1u);
+                                }
+                                n_long += n_inf > kMaxPatternBits;
+                            }
+                        }
+                        n_long_of[c] = n_long;
+                    }
+                } catch (const std::exception &e) {
+                    errs[tid] = e.what();
+                }
+            };
+            std::vector<std::thread> th;
+            for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
+            work(0);
+            for (auto &t : th) t.join();
+            for (const auto &e : errs)
+                if (!e.empty()) throw std::runtime_error(e);
+        }
         for (int c = 0; c < n_chain; c++) {
             const size_t R = read_off[c + 1] - read_off[c];
-            const int32_t *rp = read_ptr + read_off[c] + c;
-            size_t n_long = 0;
-            for (size_t r = 0; r < R; r++) n_long += std::min(rp[r + 1] - rp[r], o->Jmax + 1) > kMaxPatternBits;
-            adds[c] = R * (pat_bytes + 512) + n_long * Ksp * 8 + (size_t)(o->ff != 0.0 ? 9 : 6) * G * Ksp * 8 + (size_t)3 * G * 8 +
+            adds[c] = R * (pat_bytes + 512) + n_long_of[c] * Ksp * 8 + (size_t)(o->ff != 0.0 ? 9 : 6) * G * Ksp * 8 + (size_t)3 * G * 8 +
                       (want_probs ? (size_t)9 * T * 8 : 0) + 8192;
         }
         // A launch costs a chain's serial latency whatever it carries, so when the chains do not fit one launch they are cut
@@ -1572,8 +1707,13 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
             }
             std::vector<int32_t> ro(c1 - c0 + 1);
             for (int i = 0; i <= c1 - c0; i++) ro[i] = read_off[c0 + i] - read_off[c0];
+            std::vector<int64_t> rep_off;   // opts->reads_same_as: a chain's bases, relative to this launch's u / bq (may lie before them)
+            if (o->reads_same_as) {
+                rep_off.resize((size_t)(c1 - c0));
+                for (int c = c0; c < c1; c++) rep_off[(size_t)(c - c0)] = (int64_t)base_of[(size_t)o->reads_same_as[c]] - (int64_t)base_of[(size_t)c0];
+            }
             const int st = gibbs_chunk(
-                pn, need, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, c0, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
+                pn, need, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, o->reads_same_as ? rep_off.data() : nullptr, c0, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
                 u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
                 runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
                 runif_shard ? runif_shard + (o->ff != 0.0 ? (size_t)read_off[c0] * nb * 2 : (size_t)c0 * nb * (G - 1)) : nullptr,
@@ -1773,6 +1913,109 @@ static int make_eMatRead_t_impl(qa_panel_t *pn, int32_t nSNPs, int32_t n_chain, 
         hipLaunchKernelGGL(k_ematread_dense, dim3((maxR + 63) / 64, C), dim3(64), 0, st, prm);
         QA_HIP(hipGetLastError());
         d_out.download(eMatRead_t, (size_t)totR * K, st);
+        QA_HIP(hipStreamSynchronize(st));
+        return QA_OK;
+    });
+}
+
+// get_initial_read_labels' read likelihoods (rare_common.R:61-107) for many chains at once WITHOUT spreading the haplotypes over
+// all SNPs on the host: hap_common [n_chain][K][T_common] (hap-major, the last seek iteration's haploid dosages as the driver
+// holds them), 0.5 at the rare SNPs supplied by the kernel through the all-SNP -> common index of the qa_rare_common_t; the
+// all-SNP reads once per SAMPLE (n_sample of them, flattened as everywhere) with chain_sample[c] naming a chain's sample.
+// Output rows chain after chain, [reads of the chain's sample][K].  Same numbers as qa_rcpp_make_eMatRead_t_nsnps on the expanded
+// haplotypes (same products in the same order); what it saves per launch set of 896 chains at 192 000 SNPs: 2.75 GB of
+// host-side expansion and staged upload, and six of seven copies of the reads (2.8 GB).
+int qa_rcpp_make_eMatRead_t_rare_common(qa_panel_t *pn, const qa_rare_common_t *rc, int32_t n_chain, int32_t n_sample,
+                                        const int32_t *chain_sample, int32_t K, const double *hap_common, const int32_t *read_off,
+                                        const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                                        double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                                        double *eMatRead_t) {
+    if (!qa::device_ready()) return QA_ERR_NO_DEVICE;
+    if (!pn || !rc || n_chain <= 0 || n_sample <= 0 || !chain_sample || K < 1 || K > 3 || !hap_common || !read_off || !read_ptr || !u ||
+        !bq || !eMatRead_t || rc->K != pn->K) {
+        qa::set_error("qa_rcpp_make_eMatRead_t_rare_common: bad argument");
+        return QA_ERR_INVALID;
+    }
+    return qa::guarded([&] {
+        QA_HIP(hipSetDevice(pn->device));
+        hipStream_t st = pn->stream;
+        const int C = n_chain, NS = n_sample, T = rc->T_all, Tc = pn->T;
+        std::vector<int32_t> base_off(NS + 1, 0), out_off(C + 1, 0);
+        int maxR = 0;
+        for (int i = 0; i < NS; i++) {
+            const int R = read_off[i + 1] - read_off[i];
+            maxR = std::max(maxR, R);
+            base_off[i + 1] = base_off[i] + (read_ptr + read_off[i] + i)[R];
+        }
+        for (int c = 0; c < C; c++) {
+            if (chain_sample[c] < 0 || chain_sample[c] >= NS) throw std::runtime_error("chain_sample out of range");
+            out_off[c + 1] = out_off[c] + (read_off[chain_sample[c] + 1] - read_off[chain_sample[c]]);
+        }
+        const int totR = read_off[NS], totB = base_off[NS], totOut = out_off[C];
+        std::vector<int32_t> bq_eff((size_t)std::max(totB, 1));
+        {
+            const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), NS));
+            std::vector<std::string> errs(n_thr);
+            auto work = [&](int tid) {
+                try {
+                    for (int i = tid; i < NS; i += n_thr) {
+                        const int R = read_off[i + 1] - read_off[i];
+                        const int32_t *rp = read_ptr + read_off[i] + i;
+                        const size_t b0 = (size_t)base_off[i];
+                        for (int q = 0; q < rp[R]; q++) {
+                            if (u[b0 + q] < 0 || u[b0 + q] >= T) throw std::runtime_error("read SNP index out of range");
+                            bq_eff[b0 + q] = bq[b0 + q];
+                        }
+                        int last = 0;   // fold_zero_base_qualities, per sample (a chain's reads are its sample's)
+                        for (int r = 0; r < R; r++) {
+                            int J = rp[r + 1] - rp[r] - 1;
+                            if (J >= Jmax) J = Jmax;
+                            for (int j = 0; j <= J; j++) {
+                                int32_t &q = bq_eff[b0 + rp[r] + j];
+                                if (q == 0) q = last; else last = q;
+                                if (q > 255 || q < -255) throw std::runtime_error("|base quality| > 255");
+                            }
+                        }
+                    }
+                } catch (const std::exception &e) {
+                    errs[tid] = e.what();
+                }
+            };
+            std::vector<std::thread> th;
+            for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
+            work(0);
+            for (auto &t : th) t.join();
+            for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+        }
+        const std::vector<double> tabs = base_quality_tables();
+        qa::ABuf<double> d_e, d_tabs, d_out;
+        qa::ABuf<int32_t> d_ro, d_rp, d_bo, d_u, d_bq, d_cs, d_oo;
+        {
+            auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+            const size_t n_e = (size_t)C * Tc * K, n_out = std::max<size_t>((size_t)totOut * K, 1), n_b = std::max(totB, 1);
+            const size_t need = pad(n_e * 8) + pad(tabs.size() * 8) + pad(n_out * 8) + 2 * pad((size_t)(NS + 1) * 4) +
+                                pad((size_t)(totR + NS) * 4) + 2 * pad(n_b * 4) + 2 * pad((size_t)(C + 1) * 4) + 4096;
+            pn->arena.require(need);
+            pn->arena.reset();
+            for (auto *b : {&d_e, &d_tabs, &d_out}) b->arena = &pn->arena;
+            for (auto *b : {&d_ro, &d_rp, &d_bo, &d_u, &d_bq, &d_cs, &d_oo}) b->arena = &pn->arena;
+            d_e.ensure(n_e); d_tabs.ensure(tabs.size()); d_out.ensure(n_out);
+            d_ro.ensure(NS + 1); d_rp.ensure(totR + NS); d_bo.ensure(NS + 1); d_u.ensure(n_b); d_bq.ensure(n_b);
+            d_cs.ensure(C); d_oo.ensure(C + 1);
+        }
+        d_e.upload(hap_common, (size_t)C * Tc * K, st); d_tabs.upload(tabs.data(), tabs.size(), st);
+        d_ro.upload(read_off, NS + 1, st); d_rp.upload(read_ptr, totR + NS, st); d_bo.upload(base_off.data(), NS + 1, st);
+        d_u.upload(u, totB, st); d_bq.upload(bq_eff.data(), totB, st);
+        d_cs.upload(chain_sample, C, st); d_oo.upload(out_off.data(), C + 1, st);
+        DenseParams prm{};
+        prm.C = C; prm.K = K; prm.T = T; prm.Tc = Tc; prm.Jmax = Jmax; prm.rescale = rescale_eMatRead_t; prm.hap_major = 1;
+        prm.common_index = rc->common_index.p; prm.chain_sample = d_cs.p; prm.out_off = d_oo.p;
+        prm.inv_maxdiff = 1 / maxDifferenceBetweenReads; prm.eHaps = d_e.p; prm.read_off = d_ro.p;
+        prm.read_ptr = d_rp.p; prm.base_off = d_bo.p; prm.u = d_u.p; prm.bq = d_bq.p;
+        prm.pR_tab = d_tabs.p; prm.pA_tab = d_tabs.p + 512; prm.out = d_out.p;
+        hipLaunchKernelGGL(k_ematread_dense, dim3((maxR + 63) / 64, C), dim3(64), 0, st, prm);
+        QA_HIP(hipGetLastError());
+        d_out.download(eMatRead_t, (size_t)totOut * K, st);
         QA_HIP(hipStreamSynchronize(st));
         return QA_OK;
     });

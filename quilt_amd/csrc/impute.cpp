@@ -186,6 +186,7 @@ struct Tail {   // quilt_amd/driver.py::PhasingTail
 
 struct Ctx {
     const qa_impute_backend_t *be = nullptr;
+    bool product = false;   // the table is the library's own (qa_impute_samples): options only those entry points know may be used
     int K = 0, G = 0, T = 0;
     qa_impute_params_t P{};
     int n_burn = 0;
@@ -514,6 +515,19 @@ struct Worker {
                 g_sr.resize((size_t)n);
                 g_ss.resize((size_t)n);
                 g_uf.assign((size_t)n, 0);
+                // the chains of one sample share its reads: on the library's own entry points the bases travel once per sample
+                // (qa_gibbs_opts_t.reads_same_as); a caller-supplied table of entry points gets every chain's copy
+                std::vector<int32_t> same_as;
+                if (cx.product) {
+                    same_as.resize((size_t)n);
+                    std::map<int, int> first_of;
+                    for (int a = 0; a < n; a++) {
+                        const int sm = ch[(size_t)idx[(size_t)a]]->sample;
+                        auto it = first_of.find(sm);
+                        if (it == first_of.end()) it = first_of.emplace(sm, a).first;
+                        same_as[(size_t)a] = it->second;
+                    }
+                }
                 parallel_for((size_t)n, n_help, [&](size_t a) {
                     const int i = idx[a];
                     const Chain &c = *ch[(size_t)i];
@@ -522,6 +536,7 @@ struct Worker {
                     std::memcpy(&g_read_ptr[(size_t)g_read_off[a] + a], r.read_ptr, sizeof(int32_t) * ((size_t)r.R + 1));
                     std::memcpy(&g_wif[(size_t)g_read_off[a]], r.wif, sizeof(int32_t) * (size_t)r.R);
                     std::memcpy(&g_H[(size_t)g_read_off[a]], starts[(size_t)i].data(), sizeof(int32_t) * (size_t)r.R);
+                    if (!same_as.empty() && same_as[a] != (int32_t)a) return;   // (its bases are another chain's)
                     std::memcpy(&g_u[(size_t)base_off[a]], r.u, sizeof(int32_t) * (size_t)r.nb);
                     std::memcpy(&g_bq[(size_t)base_off[a]], r.bq, sizeof(int32_t) * (size_t)r.nb);
                 });
@@ -532,6 +547,7 @@ struct Worker {
                 }
                 qa_gibbs_opts_t o{};
                 o.Ks = P.Ksubset;
+                o.reads_same_as = same_as.empty() ? nullptr : same_as.data();
                 std::vector<double> ffc;
                 if (cx.nipt) {   // every chain carries its sample's fetal fraction (functions.R:128)
                     ffc.resize((size_t)n);
@@ -858,40 +874,73 @@ struct Worker {
         const int C = (int)ch.size(), T = cx.T, Ta = cx.T_out, nL = cx.nL;
         const double t0 = now_s();
         const double *last = dos.p;   // [chain][label][T] of the last seek iteration
-        eh.resize((size_t)C * Ta * nL);
-        parallel_for((size_t)C, n_help, [&](size_t c) {
-            double *e = &eh[c * Ta * nL];
-            for (size_t t = 0; t < (size_t)Ta * nL; t++) e[t] = 0.5;
-            for (int l = 0; l < nL; l++) {
-                const double *h = last + (c * nL + l) * T;
-                for (int j = 0; j < T; j++) e[(size_t)cx.common_at[(size_t)j] * nL + l] = h[j];
-            }
-        });
         std::vector<int32_t> read_off((size_t)C + 1, 0);
-        std::vector<int64_t> boff((size_t)C + 1, 0);
-        for (int i = 0; i < C; i++) {
-            const Reads &r = cx.reads_all[(size_t)ch[(size_t)i]->sample];
-            read_off[(size_t)i + 1] = read_off[(size_t)i] + r.R;
-            boff[(size_t)i + 1] = boff[(size_t)i] + r.nb;
-        }
-        g_read_ptr.resize((size_t)read_off[(size_t)C] + C);
-        g_u.resize((size_t)boff[(size_t)C]);
-        g_bq.resize((size_t)boff[(size_t)C]);
-        parallel_for((size_t)C, n_help, [&](size_t i) {
-            const Reads &r = cx.reads_all[(size_t)ch[i]->sample];
-            std::memcpy(&g_read_ptr[(size_t)read_off[i] + i], r.read_ptr, sizeof(int32_t) * ((size_t)r.R + 1));
-            std::memcpy(&g_u[(size_t)boff[i]], r.u, sizeof(int32_t) * (size_t)r.nb);
-            std::memcpy(&g_bq[(size_t)boff[i]], r.bq, sizeof(int32_t) * (size_t)r.nb);
-        });
+        for (int i = 0; i < C; i++) read_off[(size_t)i + 1] = read_off[(size_t)i] + cx.reads_all[(size_t)ch[(size_t)i]->sample].R;
         double *lik = conf.get((size_t)read_off[(size_t)C] * nL);
-        // rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100
-        check(cx.be->make_eMatRead_t_nsnps(handle, Ta, C, nL, eh.data(), read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
-                                           P.maxDifferenceBetweenReads, 100, 1, lik), "qa_rcpp_make_eMatRead_t_nsnps");
+        if (cx.be->make_eMatRead_t_rare_common) {
+            // the device spreads the haplotypes over all SNPs itself (0.5 at the rare ones) and reads a sample's all-SNP reads
+            // once for all of its chains: no 2.75 GB expansion, no seven copies of the reads (per launch set of 896 chains)
+            std::vector<int32_t> samples_of;            // the distinct samples of the chains, in order of first appearance
+            std::vector<int32_t> chain_sample((size_t)C);
+            {
+                std::map<int, int> at;
+                for (int i = 0; i < C; i++) {
+                    const int sm = ch[(size_t)i]->sample;
+                    auto it = at.find(sm);
+                    if (it == at.end()) { it = at.emplace(sm, (int)samples_of.size()).first; samples_of.push_back(sm); }
+                    chain_sample[(size_t)i] = it->second;
+                }
+            }
+            const int NS = (int)samples_of.size();
+            std::vector<int32_t> s_off((size_t)NS + 1, 0);
+            std::vector<int64_t> s_boff((size_t)NS + 1, 0);
+            for (int i = 0; i < NS; i++) {
+                const Reads &r = cx.reads_all[(size_t)samples_of[(size_t)i]];
+                s_off[(size_t)i + 1] = s_off[(size_t)i] + r.R;
+                s_boff[(size_t)i + 1] = s_boff[(size_t)i] + r.nb;
+            }
+            g_read_ptr.resize((size_t)s_off[(size_t)NS] + NS);
+            g_u.resize((size_t)s_boff[(size_t)NS]);
+            g_bq.resize((size_t)s_boff[(size_t)NS]);
+            parallel_for((size_t)NS, n_help, [&](size_t i) {
+                const Reads &r = cx.reads_all[(size_t)samples_of[i]];
+                std::memcpy(&g_read_ptr[(size_t)s_off[i] + i], r.read_ptr, sizeof(int32_t) * ((size_t)r.R + 1));
+                std::memcpy(&g_u[(size_t)s_boff[i]], r.u, sizeof(int32_t) * (size_t)r.nb);
+                std::memcpy(&g_bq[(size_t)s_boff[i]], r.bq, sizeof(int32_t) * (size_t)r.nb);
+            });
+            check(cx.be->make_eMatRead_t_rare_common(handle, rc_handle, C, NS, chain_sample.data(), nL, last, s_off.data(), g_read_ptr.data(),
+                                                     g_u.data(), g_bq.data(), P.maxDifferenceBetweenReads, 100, 1, lik),
+                  "qa_rcpp_make_eMatRead_t_rare_common");
+        } else {
+            eh.resize((size_t)C * Ta * nL);
+            parallel_for((size_t)C, n_help, [&](size_t c) {
+                double *e = &eh[c * Ta * nL];
+                for (size_t t = 0; t < (size_t)Ta * nL; t++) e[t] = 0.5;
+                for (int l = 0; l < nL; l++) {
+                    const double *h = last + (c * nL + l) * T;
+                    for (int j = 0; j < T; j++) e[(size_t)cx.common_at[(size_t)j] * nL + l] = h[j];
+                }
+            });
+            std::vector<int64_t> boff((size_t)C + 1, 0);
+            for (int i = 0; i < C; i++) boff[(size_t)i + 1] = boff[(size_t)i] + cx.reads_all[(size_t)ch[(size_t)i]->sample].nb;
+            g_read_ptr.resize((size_t)read_off[(size_t)C] + C);
+            g_u.resize((size_t)boff[(size_t)C]);
+            g_bq.resize((size_t)boff[(size_t)C]);
+            parallel_for((size_t)C, n_help, [&](size_t i) {
+                const Reads &r = cx.reads_all[(size_t)ch[i]->sample];
+                std::memcpy(&g_read_ptr[(size_t)read_off[i] + i], r.read_ptr, sizeof(int32_t) * ((size_t)r.R + 1));
+                std::memcpy(&g_u[(size_t)boff[i]], r.u, sizeof(int32_t) * (size_t)r.nb);
+                std::memcpy(&g_bq[(size_t)boff[i]], r.bq, sizeof(int32_t) * (size_t)r.nb);
+            });
+            // rcpp_make_eMatRead_t as get_initial_read_labels calls it (rare_common.R:82-98): rescaled, Jmax = 100
+            check(cx.be->make_eMatRead_t_nsnps(handle, Ta, C, nL, eh.data(), read_off.data(), g_read_ptr.data(), g_u.data(), g_bq.data(),
+                                               P.maxDifferenceBetweenReads, 100, 1, lik), "qa_rcpp_make_eMatRead_t_nsnps");
+        }
         std::vector<std::vector<int32_t>> starts((size_t)C);
         first_reads.assign((size_t)C, 0);
         seed_reads.assign((size_t)C, 0);
         seed_shards.assign((size_t)C, 0);
-        for (int i = 0; i < C; i++) {
+        parallel_for((size_t)C, n_draw, [&](size_t i) {   // (every chain draws from its own stream: order between chains is free)
             Chain &c = *ch[(size_t)i];
             const int R = cx.reads_all[(size_t)c.sample].R;
             const double *e = lik + (size_t)read_off[(size_t)i] * nL;
@@ -904,9 +953,10 @@ struct Worker {
             }
             seed_reads[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
             seed_shards[(size_t)i] = (uint64_t)c.rng.integers(0, 9223372036854775808.0);
-        }
+        });
         const double t1 = now_s();
         t_host += t1 - t0;
+        if (CallSpan::on()) std::fprintf(stderr, "[impute-trace] rc_prep thr %d n %d %.1f %.1f\n", w, C, t0 * 1e3, t1 * 1e3);
         double *hall = dos_all.get((size_t)C * nL * Ta);
         gibbs_with_retry(ch, starts, false, false, hall, true);
         const double t2 = now_s();
@@ -924,6 +974,7 @@ struct Worker {
             for (int i = 0; i < n_cur; i++) cx.nDosage[cur->chains[(size_t)i].sample] += 1;
         }
         t_accumulate += now_s() - t2;
+        if (CallSpan::on()) std::fprintf(stderr, "[impute-trace] rc_post thr %d n %d %.1f %.1f\n", w, C, t2 * 1e3, now_s() * 1e3);
     }
 
     Batch *new_batch(int lo, int hi) {
@@ -1145,6 +1196,7 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     }
     Ctx cx;
     cx.be = be;
+    cx.product = keep_buffers;
     cx.K = K; cx.G = G; cx.T = T;
     cx.P = *params;
     auto &P = cx.P;
@@ -1368,9 +1420,16 @@ int be_ematread_nsnps(void *h, int32_t nSNPs, int32_t n_chain, int32_t K, const 
                                          Jmax, rescale, out);
 }
 
+int be_ematread_rc(void *h, const void *rc, int32_t n_chain, int32_t n_sample, const int32_t *chain_sample, int32_t K,
+                   const double *hap_common, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
+                   double maxdiff, int32_t Jmax, int32_t rescale, double *out) {
+    return qa_rcpp_make_eMatRead_t_rare_common(static_cast<qa_panel_t *>(h), static_cast<const qa_rare_common_t *>(rc), n_chain, n_sample,
+                                               chain_sample, K, hap_common, read_off, read_ptr, u, bq, maxdiff, Jmax, rescale, out);
+}
+
 const qa_impute_backend_t kProduct = {be_gibbs, be_fullpass_select, be_fullpass, be_ematread, qa_mspbwt_select_new_haps,
                                       qa_accumulate_dosage, qa_consensus_read_labels, qa_host_alloc, qa_host_free, be_bind,
-                                      be_gibbs_rc, be_ematread_nsnps};
+                                      be_gibbs_rc, be_ematread_nsnps, be_ematread_rc};
 
 }   // namespace
 

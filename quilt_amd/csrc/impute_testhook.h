@@ -55,6 +55,12 @@ typedef struct {
     int (*make_eMatRead_t_nsnps)(void *handle, int32_t nSNPs, int32_t n_chain, int32_t K, const double *eHaps,
                        const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                        double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t, double *eMatRead_t);
+    /* optional (may be NULL: the loop then spreads the haplotypes over all SNPs itself and calls make_eMatRead_t_nsnps):
+     * qa_rcpp_make_eMatRead_t_rare_common */
+    int (*make_eMatRead_t_rare_common)(void *handle, const void *rc, int32_t n_chain, int32_t n_sample, const int32_t *chain_sample,
+                       int32_t K, const double *hap_common, const int32_t *read_off, const int32_t *read_ptr, const int32_t *u,
+                       const int32_t *bq, double maxDifferenceBetweenReads, int32_t Jmax, int32_t rescale_eMatRead_t,
+                       double *eMatRead_t);
 } qa_impute_backend_t;
 int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,
                               int32_t nSNPs, const qa_impute_params_t *params, int32_t n_sample, int64_t sample_offset,

@@ -32,7 +32,8 @@ class Backend(C.Structure):
     _fields_ = [("gibbs_batch", GIBBS_FN), ("fullpass_reads_select_batch", SELECT_FN), ("fullpass_batch", FULLPASS_FN),
                 ("make_eMatRead_t_hap_major", EMAT_FN), ("mspbwt_select_new_haps", C.c_void_p), ("accumulate_dosage", C.c_void_p),
                 ("consensus_read_labels", C.c_void_p), ("host_alloc", ALLOC_FN), ("host_free", FREE_FN), ("bind_thread", C.c_void_p),
-                ("gibbs_batch_rare_common", GIBBS_RC_FN), ("make_eMatRead_t_nsnps", EMAT_FN)]
+                ("gibbs_batch_rare_common", GIBBS_RC_FN), ("make_eMatRead_t_nsnps", EMAT_FN),
+                ("make_eMatRead_t_rare_common", C.c_void_p)]   # optional: left NULL, the loop takes its expansion path
 
 
 def _arr(p, n, dtype):
