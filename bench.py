@@ -28,8 +28,34 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; 6.3 TB/s is what a streaming copy achieves)
 _CPU_PANEL = None
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
 PMC_INSTS_FILE = os.path.join("profiles", "r04_pmc_insts.json")
+
+
+def pmc_file_for(mode, K, batch, mspbwt, rare_common):
+    """The committed counter summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/pmc_summary.py) of THIS workload, newest
+    round first -- every bench line prices its dominant kernel on counter traffic of its own workload, or says it has none."""
+    if mspbwt and rare_common:
+        names = ["r05_pmc_traffic_quilt2_default.json"]
+    elif mspbwt and mode == "short" and K == 50000:
+        names = ["r05_pmc_traffic_mspbwt.json"]
+    elif mspbwt or rare_common:
+        names = []
+    elif mode == "ont" and K == 50000:
+        names = ["r05_pmc_traffic_ont.json"]
+    elif mode == "short" and K == 64976:
+        names = ["r05_pmc_traffic_K64976.json"]
+    elif mode == "nipt" and K == 50000:
+        names = ["r05_pmc_traffic_nipt.json"]
+    elif mode == "short" and K == 5000 and batch == 32:
+        names = ["r05_pmc_traffic_configs1.json"]
+    elif mode == "short" and K == 50000 and batch == 128:
+        names = ["r05_pmc_traffic.json", "r04_pmc_traffic.json"]
+    else:
+        names = []
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return os.path.join("profiles", n)
+    return None
 
 def workload_label(mode, K, batch, mspbwt=False, rare_common=False):
     """Which BASELINE.json configuration a run is (or that it is none): keyed on the read model AND the panel size / batch."""
@@ -810,30 +836,24 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
     ach = per_launch / 1e9 / (avg_ms / 1e3) if avg_ms > 0 else 0.0
     agg = dom["alg_bytes"] / 1e9 / (dom["busy_ms"] / 1e3) if dom["busy_ms"] > 0 else 0.0
     traffic, traffic_source = None, None
+    pmc_path = pmc_file_for(a.mode, a.K, a.batch, a.mspbwt, rc is not None)
     try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same workload
-        pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
-        def _flag(name, default):   # the value a flag had in the profiled command (absent = bench.py's default)
-            m = re.search(rf"--{name}[ =](\S+)", pmc["command"])
-            return m.group(1) if m else str(default)
-        same_workload = (_flag("batch", 128) == str(a.batch) and
-                         _flag("mode", "short") == a.mode and _flag("K", 50000) == str(a.K) and
-                         "--mspbwt" not in pmc["command"])
-        if same_workload and rc is None and not a.mspbwt:
-            # per template instantiation where the summary has it (the sampler's two builds are different code)
-            inst = pmc.get("instantiations", {})
-            key = dom["kernel"] if dom["kernel"] in inst else ("k_gibbs<10, 1, false>" if dom["kernel"] == "k_gibbs" else None)
-            pk = inst[key] if key in inst else pmc["kernels"][dom["kernel"].split("<")[0]]
-            if pk.get("hbm_bytes_per_workgroup") and dom.get("workgroups") and dom["kernel"].startswith("k_gibbs"):
-                # launches come in sizes: the counters' bytes per workgroup (= per chain) times this run's chains per launch
-                traffic = pk["hbm_bytes_per_workgroup"] * dom["workgroups"] / max(dom["launches"], 1)
-                how = (f"bytes per workgroup (one per chain) of {key or dom['kernel']} x this run's "
-                       f"{dom['workgroups'] / max(dom['launches'], 1):.0f} chains per launch")
-            else:
-                traffic = pk["hbm_bytes_per_launch"]
-                how = "bytes per launch"
-            traffic_source = (f"{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `{pmc['command']}`, "
-                              f"{how}; not measured in this run")
-    except (OSError, KeyError, ValueError):
+        pmc = json.load(open(os.path.join(ROOT, pmc_path)))
+        # per template instantiation where the summary has it (the sampler's builds are different code)
+        inst = pmc.get("instantiations", {})
+        key = dom["kernel"] if dom["kernel"] in inst else ("k_gibbs<10, 1, false>" if dom["kernel"] == "k_gibbs" else None)
+        pk = inst[key] if key in inst else pmc["kernels"][dom["kernel"].split("<")[0]]
+        if pk.get("hbm_bytes_per_workgroup") and dom.get("workgroups") and dom["kernel"].startswith("k_gibbs"):
+            # launches come in sizes: the counters' bytes per workgroup (= per chain) times this run's chains per launch
+            traffic = pk["hbm_bytes_per_workgroup"] * dom["workgroups"] / max(dom["launches"], 1)
+            how = (f"bytes per workgroup (one per chain) of {key or dom['kernel']} x this run's "
+                   f"{dom['workgroups'] / max(dom['launches'], 1):.0f} chains per launch")
+        else:
+            traffic = pk["hbm_bytes_per_launch"]
+            how = "bytes per launch"
+        traffic_source = (f"{pmc_path}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; factors calibrated, "
+                          f"profiles/r05_fetch_calibration.json) of `{pmc['command']}`, {how}; not measured in this run")
+    except (OSError, KeyError, ValueError, TypeError):
         pass
     ratio = (traffic / per_launch) if traffic else None
     # What the fraction is priced on.  The algorithmic bytes of SURVEY 8(d) are a contract, not a measurement: where the
@@ -849,7 +869,8 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
         priced = "hbm traffic (PMC counters, scaled to this run's launches)"
     else:
         ach_t = ach
-        priced = "algorithmic bytes"
+        priced = "algorithmic bytes" + ("" if traffic else " (no counter summary of this workload is committed: an upper bound of what HBM carried -- the "
+                                        "sampler keeps alpha in registers and reads compact emissions)")
     issue = None
     try:   # the instruction-issue side of the same kernel build, from the committed SQ counter passes
         pi = json.load(open(os.path.join(ROOT, PMC_INSTS_FILE)))["per_launch"]

@@ -1332,25 +1332,34 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     std::vector<std::exception_ptr> errs((size_t)W);
     std::vector<std::string> err_text((size_t)W);
     std::vector<int> err_status((size_t)W, 0);
+    std::vector<int> err_order((size_t)W, -1);   // the order in which the threads failed: the report names the FIRST failure
+    std::atomic<int> n_failed{0};
+    std::atomic<bool> stagger_timed_out{false};
     auto body = [&](int w2) {
         try {
             if (w2 > 0) {
                 std::unique_lock<std::mutex> lk(started[(size_t)w2 - 1].mu);
-                started[(size_t)w2 - 1].cv.wait_for(lk, std::chrono::seconds(5), [&] { return started[(size_t)w2 - 1].set; });
+                // (staggered start: a launch plan, not a dependency -- a predecessor whose first launch takes longer than this is
+                // not waited for; results do not depend on it, QA_TIMING says when it happened)
+                if (!started[(size_t)w2 - 1].cv.wait_for(lk, std::chrono::seconds(5), [&] { return started[(size_t)w2 - 1].set; }))
+                    stagger_timed_out.store(true);
             }
             workers[(size_t)w2]->on_first_launch = [&, w2] { signal(w2); };
             if (be->bind_thread) be->bind_thread(handles[w2]);
             workers[(size_t)w2]->run_stream(streams[(size_t)w2]);
         } catch (const Failure &f) {
             errs[(size_t)w2] = std::current_exception();
+            err_order[(size_t)w2] = n_failed.fetch_add(1);
             err_text[(size_t)w2] = f.what();
             err_status[(size_t)w2] = f.status;
         } catch (const std::exception &e) {
             errs[(size_t)w2] = std::current_exception();
+            err_order[(size_t)w2] = n_failed.fetch_add(1);
             err_text[(size_t)w2] = e.what();
             err_status[(size_t)w2] = QA_ERR_HIP;
         } catch (...) {
             errs[(size_t)w2] = std::current_exception();
+            err_order[(size_t)w2] = n_failed.fetch_add(1);
             err_text[(size_t)w2] = "unknown failure";
             err_status[(size_t)w2] = QA_ERR_HIP;
         }
@@ -1371,12 +1380,19 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
         stats[5] = (int64_t)(tg * 1e3); stats[6] = (int64_t)(tf * 1e3); stats[7] = (int64_t)(th2 * 1e3); stats[8] = (int64_t)(tc * 1e3);
         stats[9] = (int64_t)(tfi * 1e3); stats[10] = (int64_t)(ta * 1e3);
     }
-    for (int w2 = 0; w2 < W; w2++)
-        if (errs[(size_t)w2]) {
-            // the first failure that is not the echo of another thread's ("another host thread failed")
-            qa::set_error("qa_impute_samples: %s", err_text[(size_t)w2].c_str());
-            return err_status[(size_t)w2] ? err_status[(size_t)w2] : QA_ERR_HIP;
+    if (stagger_timed_out.load() && std::getenv("QA_TIMING"))
+        std::fprintf(stderr, "[qa_impute_samples] a host thread's first launch took more than 5 s: the staggered start was skipped for its successor\n");
+    {
+        // the failure that happened FIRST (a thread that only rethrows a failed tail's exception carries that same exception:
+        // text and status are the originator's either way)
+        int first = -1;
+        for (int w2 = 0; w2 < W; w2++)
+            if (errs[(size_t)w2] && (first < 0 || err_order[(size_t)w2] < err_order[(size_t)first])) first = w2;
+        if (first >= 0) {
+            qa::set_error("qa_impute_samples: %s", err_text[(size_t)first].c_str());
+            return err_status[(size_t)first] ? err_status[(size_t)first] : QA_ERR_HIP;
         }
+    }
     return QA_OK;
 }
 

@@ -27,6 +27,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -67,18 +69,32 @@ void parallel_tasks(size_t n, F &&f) {
         for (size_t i = 0; i < n; i++) f(i);
         return;
     }
+    // an exception inside a task (std::bad_alloc: the index is 0.8 GB at K = 50 000) must not escape its thread -- that is
+    // std::terminate, and the host is R or Python: the first one is kept, the other tasks are skipped, and it is rethrown on the
+    // calling thread, whose callers map it to a status with qa::set_error
     std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr err;
+    std::mutex mu;
     std::vector<std::thread> th;
     auto work = [&] {
         for (;;) {
             const size_t i = next.fetch_add(1);
-            if (i >= n) return;
-            f(i);
+            if (i >= n || failed.load()) return;
+            try {
+                f(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu);
+                if (!err) err = std::current_exception();
+                failed.store(true);
+                return;
+            }
         }
     };
     for (int t = 1; t < nt; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+    if (err) std::rethrow_exception(err);
 }
 
 struct Rep { int32_t k, s0, n; };
@@ -235,6 +251,7 @@ int64_t qa_mspbwt_bytes(const qa_mspbwt_t *m) {
 int64_t qa_mspbwt_find_good_matches(const qa_mspbwt_t *m, int32_t n_query, const int32_t *Zs, int32_t L, int32_t M,
                                     int64_t *row_ptr, int32_t *rows, int64_t cap_rows) {
     if (!scan_args_ok(m, n_query, Zs, L, M) || !row_ptr || (cap_rows > 0 && !rows)) return QA_ERR_INVALID;
+    try {
     const int ni = m->nindices;
     std::vector<std::vector<Rep>> found((size_t)n_query * ni);
     std::vector<uint8_t> zq((size_t)n_query * m->G);
@@ -252,6 +269,10 @@ int64_t qa_mspbwt_find_good_matches(const qa_mspbwt_t *m, int32_t n_query, const
     }
     row_ptr[found.size()] = total;
     return total;
+    } catch (const std::exception &e) {
+        qa::set_error("qa_mspbwt_find_good_matches: %s", e.what());
+        return QA_ERR_INVALID;
+    }
 }
 
 // The scan followed by select_new_haps_mspbwt_v3 (QUILT/R/mspbwt.R:225-474) for every chain of a round: the match tables
@@ -260,6 +281,7 @@ int qa_mspbwt_select_new_haps(const qa_mspbwt_t *m, int32_t n_chain, int32_t n_l
                               int32_t Knew, const uint64_t *seed, int32_t *out) {
     if (!scan_args_ok(m, n_chain, Zs, L, M) || n_label < 1 || n_label > 3 || Knew < 1 || Knew > m->K || !seed || !out)
         return QA_ERR_INVALID;
+    try {
     const int ni = m->nindices, G = m->G;
     std::atomic<int> status{QA_OK};
     parallel_tasks((size_t)n_chain, [&](size_t c) {
@@ -284,6 +306,10 @@ int qa_mspbwt_select_new_haps(const qa_mspbwt_t *m, int32_t n_chain, int32_t n_l
         if (st != QA_OK) status = st;
     });
     return status;
+    } catch (const std::exception &e) {
+        qa::set_error("qa_mspbwt_select_new_haps: %s", e.what());
+        return QA_ERR_INVALID;
+    }
 }
 
 }  // extern "C"
