@@ -56,15 +56,8 @@ inline Geo64 geo64(int K) {
     g.NL = g.NCH - g.NR;
     if (lds_bytes(g) > kLdsMax) { g.NR = 5; g.NL = g.NCH - 5; }
 
-    if (g.NCH == 8 && !getenv("QA_FB64_NO_SIX_ROWS")) {
-        // eight rows (K up to 65 536: the HRC panel's 64 976) all on chip: SIX rows in registers (96 doubles a lane), two in LDS.
-        // Round 4 streamed the eighth row through HBM (131 KB of state per grid and pass beside 65 KB of codes: -25 % at K = 64 976).
-        Geo64 h = g;
-        h.NR = 6; h.NL = 2;
-        // (the dosage backward's fixed part, kLdsFixedD below: tables, block sums, six scalar streams, the 256 x 8 histogram)
-        const size_t fixed_d = 2 * kMaxRow * 8 + 2 * 16 * 8 + 6 * 64 * 8 + (size_t)kMaxRow * 8 * 8;
-        if (lds_bytes(h) <= kLdsMax && fixed_d + ((size_t)(h.NL - 1) * kNT + h.n_last) * 128 <= kLdsMax) return h;
-    }
+    // (Round 5 tried eight rows on chip for K up to 65 536 -- SIX rows in registers, two in LDS -- instead of streaming the eighth:
+    // the <6, 2> kernels spill 112-132 registers (against 16) and the HRC-size bench line fell from 30.1 to 28.3 samples/s; not kept.)
     if (g.NCH > 7) {   // 5 rows in registers, 2 in LDS (what 7 full rows take: 152 / 155 KB of LDS), the rest streamed
         g.NS = g.NCH - 7;
         g.NCH = 7; g.NR = 5; g.NL = 2; g.n_last = kNT;
@@ -1137,7 +1130,6 @@ void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mi
         case 42: launch_dos<4, 2>(prm, geo, st, e_mid); break;
         case 52: launch_dos<5, 2>(prm, geo, st, e_mid); break;
 #endif
-        case 62: launch_dos<6, 2>(prm, geo, st, e_mid); break;
         case 43: launch_dos<4, 3>(prm, geo, st, e_mid); break;
         default: throw std::runtime_error("fp64 geometry not built");
     }
@@ -1170,7 +1162,6 @@ void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
         case 42: launch<4, 2>(prm, geo, st, e_mid); break;
 #endif
         case 52: launch<5, 2>(prm, geo, st, e_mid); break;
-        case 62: launch<6, 2>(prm, geo, st, e_mid); break;
         case 43: launch<4, 3>(prm, geo, st, e_mid); break;
         default: throw std::runtime_error("fp64 geometry not built");
     }
