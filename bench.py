@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md; 6.3 TB/s is what a streaming copy achieves)
 _CPU_PANEL = None
-PMC_INSTS_FILE = os.path.join("profiles", "r04_pmc_insts.json")
+PMC_INSTS_FILE = os.path.join("profiles", "r05_pmc_insts.json")
 
 
 def pmc_file_for(mode, K, batch, mspbwt, rare_common):
@@ -843,7 +843,18 @@ def report(a, panel, params, native, drv, samples, reg, world, rc, cpu, keep, ff
         inst = pmc.get("instantiations", {})
         key = dom["kernel"] if dom["kernel"] in inst else ("k_gibbs<10, 1, false>" if dom["kernel"] == "k_gibbs" else None)
         pk = inst[key] if key in inst else pmc["kernels"][dom["kernel"].split("<")[0]]
-        if pk.get("hbm_bytes_per_workgroup") and dom.get("workgroups") and dom["kernel"].startswith("k_gibbs"):
+        if dom["kernel"] == "k_gibbs3" and all(k in pmc["kernels"] for k in ("k_gibbs3", "k_ematread")) and dom.get("workgroups"):
+            # NIPT: the library's k_gibbs3 entry is a whole CALL -- the sampler's segments (cut at the block-Gibbs iterations), the
+            # switch-rate kernel and the block kernel between them, the host's block definition -- while rocprof sees every launch:
+            # bytes per chain and call = the three kernels' bytes / (chains x calls), calls = k_ematread's launches (one per call)
+            kk = pmc["kernels"]
+            seg = kk["k_gibbs3"]["launches"] / max(kk["k_ematread"]["launches"], 1)
+            tot = sum(kk[k]["fetch_bytes"] + kk[k]["write_bytes"] for k in ("k_gibbs3", "k_block3", "k_block_rate3") if k in kk)
+            per_chain_call = tot / (kk["k_gibbs3"]["workgroups"] / seg)
+            traffic = per_chain_call * dom["workgroups"] / max(dom["launches"], 1)
+            how = (f"k_gibbs3 + k_block3 + k_block_rate3 bytes per chain and call ({per_chain_call / 1e9:.2f} GB: {seg:.0f} sampler segments "
+                   f"with the block passes between them) x this run's {dom['workgroups'] / max(dom['launches'], 1):.0f} chains per call")
+        elif pk.get("hbm_bytes_per_workgroup") and dom.get("workgroups") and dom["kernel"].startswith("k_gibbs"):
             # launches come in sizes: the counters' bytes per workgroup (= per chain) times this run's chains per launch
             traffic = pk["hbm_bytes_per_workgroup"] * dom["workgroups"] / max(dom["launches"], 1)
             how = (f"bytes per workgroup (one per chain) of {key or dom['kernel']} x this run's "

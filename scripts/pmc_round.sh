@@ -3,7 +3,7 @@
 #   gpurun --timeout 1500 -- 'bash scripts/pmc_round.sh r04'
 # Launch sets of two steps (the default --fuse 2) with --steps 6 --warmup 2 (three launch sets: one whole set per host thread), so every main-round Gibbs launch is the lean build.
 # One counter group per pass, --kernel-trace only (no --stats, no other trace domain).  Summaries per template instantiation.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
