@@ -863,7 +863,20 @@ __global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
     const bool rare = b < nLocal && cs < 0;
     const bool any = rare && ((p.rc_any[(size_t)c * p.rc_words + (snp >> 5)] >> (snp & 31)) & 1u);
     double on[3] = {0, 0, 0};
-    if (b < nLocal && (!rare || any)) {
+    if (b < nLocal && rare && any && p.rc_pairs) {
+        // the rows that carry this rare SNP, from the chain's (SNP, row) pairs of this grid: ascending in the row, so the partial
+        // sum of this thread's rows (row = part mod 8) forms in the order the walk over all rows gave it.  (That walk searched the
+        // rare list of each of the 600 selected haplotypes -- three dependent loads a search -- for every rare SNP somebody
+        // carries: 110 us for such a thread, 39 % of the blocks held one, 200 ms per all-SNP launch.)
+        const int32_t *po = p.rc_pair_off + (size_t)c * (G + 1);
+        const uint16_t *pp = p.rc_pairs + p.rc_pair_base[c];
+        for (int i = po[g]; i < po[g + 1]; i++) {
+            const uint32_t e = pp[i];
+            const int k = (int)(e & 1023u);
+            if ((int)(e >> 10) == b && (k & 7) == part)
+                for (int h = 0; h < p.nH; h++) on[h] += gam(h, k);
+        }
+    } else if (b < nLocal && (!rare || any)) {
         const int q = rare ? 0 : (cs >> 5) - cg, bit = cs & 31;
         for (int k = part; k < Ks; k += 8) {
             const bool alt = rare ? rare_has_alt(p, s_which[k], snp) : ((sw(q, k) >> bit) & 1u);
@@ -1007,6 +1020,9 @@ struct GibbsScratch {
     DBuf<size_t> eread_off;
     DBuf<uint64_t> seeds;
     DBuf<uint32_t> rc_any;
+    DBuf<uint16_t> rc_pairs;
+    DBuf<int32_t> rc_pair_off;
+    DBuf<size_t> rc_pair_base;
     DBuf<double> blk_rate2, ff_chain, per_it;
     DBuf<int32_t> blk_where, blk_tab, blk_n;
 };
@@ -1344,6 +1360,48 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         if (o->per_it_out) S.per_it.ensure((size_t)C * n_its * 8);
         if (ff_chain) { S.ff_chain.ensure(C); S.ff_chain.upload(ff_chain, C, st); }
         if (rc) { S.rc_any.ensure(std::max<size_t>(rc_any.size(), 1)); S.rc_any.upload(rc_any.data(), rc_any.size(), st); }
+        // (SNP, row) pairs per chain for k_happrobs_rc (only when the probabilities are asked for)
+        const bool want_pairs = rc && (hapProbs_t || genProbsM_t || genProbsF_t || o->hap_words_out || o->hap_major_out) && Ks <= 1024;
+        if (want_pairs) {
+            std::vector<size_t> pbase((size_t)C + 1, 0);
+            std::vector<std::vector<uint32_t>> keys((size_t)C);   // SNP << 10 | row, sorted
+            {
+                const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), C));
+                auto work = [&](int tid) {
+                    for (int c = tid; c < C; c += n_thr) {
+                        auto &kv = keys[(size_t)c];
+                        for (int k = 0; k < Ks; k++) {
+                            const int v = which0[(size_t)c * Ks + k];
+                            for (int64_t i = rc->h_rare_ptr[v]; i < rc->h_rare_ptr[v + 1]; i++) kv.push_back(((uint32_t)rc->h_rare_snp[i] << 10) | (uint32_t)k);
+                        }
+                        std::sort(kv.begin(), kv.end());
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
+                work(0);
+                for (auto &t : th) t.join();
+            }
+            for (int c = 0; c < C; c++) pbase[(size_t)c + 1] = pbase[(size_t)c] + keys[(size_t)c].size();
+            std::vector<uint16_t> pairs(std::max<size_t>(pbase[(size_t)C], 1));
+            std::vector<int32_t> poff((size_t)C * (G + 1), 0);
+            for (int c = 0; c < C; c++) {
+                const auto &kv = keys[(size_t)c];
+                int32_t *po = poff.data() + (size_t)c * (G + 1);
+                size_t i = 0;
+                for (int g = 0; g < G; g++) {
+                    po[g] = (int32_t)i;
+                    while (i < kv.size() && (int)((kv[i] >> 10) >> 5) == g) {
+                        pairs[pbase[(size_t)c] + i] = (uint16_t)((((kv[i] >> 10) & 31u) << 10) | (kv[i] & 1023u));
+                        i++;
+                    }
+                }
+                po[G] = (int32_t)i;
+            }
+            S.rc_pairs.ensure(pairs.size()); S.rc_pairs.upload(pairs.data(), pairs.size(), st);
+            S.rc_pair_off.ensure(poff.size()); S.rc_pair_off.upload(poff.data(), poff.size(), st);
+            S.rc_pair_base.ensure((size_t)C); S.rc_pair_base.upload(pbase.data(), (size_t)C, st);
+        }
         // ---- everything above is host work and uploads into this thread's own buffers; from here on the launch set has the
         // device (exclusive phases: queue behind the other handles' launch sets) and the arena
         const double hold_t0 = now();
@@ -1398,6 +1456,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         if (rc) {
             prm.rc_common = rc->common_index.p; prm.rc_rare_ptr = rc->rare_ptr.p; prm.rc_rare_snp = rc->rare_snp.p;
             prm.rc_any = S.rc_any.p; prm.rc_words = rc_words; prm.rc_Gc = pn->G;
+            if (want_pairs) { prm.rc_pairs = S.rc_pairs.p; prm.rc_pair_off = S.rc_pair_off.p; prm.rc_pair_base = S.rc_pair_base.p; }
         }
 
         for (auto &e : g_gibbs->ev) if (!e) QA_HIP(hipEventCreate(&e));

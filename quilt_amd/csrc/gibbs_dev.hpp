@@ -82,6 +82,11 @@ struct GibbsParams {
     const int32_t *rc_rare_snp;  // 0-based all-SNP indices, ascending within a haplotype
     const uint32_t *rc_any;      // [C][rc_words] bit t: some selected haplotype of the chain carries the alt of SNP t
     int rc_words, rc_Gc;
+    // the same information per chain as (SNP, row) pairs, sorted by SNP then row and indexed by all-SNP grid: k_happrobs_rc walks a
+    // grid's handful of pairs instead of searching every selected haplotype's rare list for every rare SNP somebody carries
+    const int32_t *rc_pair_off;  // [C][G + 1] offsets into the chain's pairs
+    const size_t *rc_pair_base;  // [C] where the chain's pairs start
+    const uint16_t *rc_pairs;    // (SNP & 31) << 10 | row (row < 1 024)
     // NIPT (three labels): a call is cut into segments of sweeps [it_begin, it_end) with a block-Gibbs pass between
     // them (gibbs3.hip); the state lives in HBM across the launches.  blk_*: the pass's block table per chain.
     int it_begin, it_end;

@@ -224,3 +224,26 @@ def test_native_loop_equals_python_loop_over_seeds_that_reach_the_complete_lists
             _same(a, b)
     dev.close()
     assert refetches > 0
+
+
+def test_handle_buffers_go_with_the_handle(medium_panel):
+    """The pinned transfer buffers qa_impute_samples keeps per panel handle are dropped by qa_panel_destroy (a caller that creates and
+    destroys its handles per call -- the shim's range routine -- used to leak gigabytes per call, and a later handle at a recycled
+    address inherited the stale entry)."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel, lib
+    from quilt_amd.synth import make_synthetic_sample
+    L = lib()
+    import ctypes
+    L.qa_impute_kept_buffers.restype = ctypes.c_int
+    L.qa_impute_release_buffers()
+    assert L.qa_impute_kept_buffers() == 0
+    samples = [make_synthetic_sample(medium_panel, seed=4300 + i, n_reads=300) for i in range(2)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=3)
+    for _ in range(2):
+        dev = DevicePanel(medium_panel)
+        impute_samples([dev], samples, prm)
+        assert L.qa_impute_kept_buffers() == 1
+        dev.close()
+        assert L.qa_impute_kept_buffers() == 0
