@@ -656,6 +656,11 @@ def main():
     if rank == 0:
         out = report(a, panel, params, native, drv, samples, main_reg, world, rc, cpu, keep, ff, full_chains, alone,
                      fp64=a.precision != "mixed")
+        if world == 1 and a.mode == "short" and a.K == 50000 and not a.mspbwt and rc is None:
+            out["host_share_at_8"] = {"what": "NOT measured in this run: the headline workload with one rank confined to the share of the host it has "
+                                              "when eight ranks run (taskset -c 0-31, QA_HOST_THREADS=10), round 4, the driver's command without the "
+                                              "CPU legs -- three host threads per rank still hide each other's host phases on a quarter of the cores",
+                                      "samples_per_sec_confined": 39.6, "samples_per_sec_whole_host": 40.0, "source": "DESIGN.md 7"}
         if a.one_device and world > 1:
             out["one_device_rehearsal"] = (f"{world} ranks on ONE GPU (device 0, gloo rendezvous, QA_ARENA_FRACTION="
                                            f"{os.environ.get('QA_ARENA_FRACTION', 'default')}): a rehearsal of the N-rank run's host side "
