@@ -154,6 +154,29 @@ def test_thin_pass_headline_size(head_panel, head_dev, head_gl, oracle):
         np.testing.assert_allclose(got["alphaHat_t"][:, g], ref["alphaHat_t"][:, g], rtol=RTOL, atol=1e-300)
 
 
+def test_validation_mode_headline_size(head_panel, head_dev, head_gl, oracle):
+    """qa_panel_set_sum_order(1) at K = 50 000 x 2 000 grids (state in the pass's HBM scratch, one lane adding 50 000 values per grid in
+    the reference's order): a thin pass and a dosage pass equal the oracle BIT FOR BIT -- lists, c, alpha at the thinned grids,
+    dosage.  No tolerance."""
+    from quilt_amd.driver import thinned_grid_columns
+    cols = thinned_grid_columns(head_panel.nGrids, 0.1)
+    head_dev.set_sum_order(True)
+    try:
+        ref = oracle.haploid_dosage_versus_refs(head_panel, head_gl, cols, return_dosage=False, get_best_haps_from_thinned_sites=True)
+        got = _run_gpu(head_dev, head_gl, cols, return_dosage=False, get_best_haps_from_thinned_sites=True, always_normalize=False)
+        assert np.array_equal(got["c"], ref["c"])
+        for g, (oi, ov) in zip(got["best_haps_stuff_list"], ref["best_haps"]):
+            assert np.array_equal(g["top_matches"], oi) and np.array_equal(g["top_matches_values"], ov)
+        for g in np.nonzero(cols >= 0)[0][::20]:
+            assert np.array_equal(got["alphaHat_t"][:, g], ref["alphaHat_t"][:, g])
+        refd = oracle.haploid_dosage_versus_refs(head_panel, head_gl, cols, return_dosage=True, get_best_haps_from_thinned_sites=True)
+        gotd = _run_gpu(head_dev, head_gl, cols, matrices=False, return_dosage=True, get_best_haps_from_thinned_sites=True,
+                        always_normalize=False)
+        assert np.array_equal(gotd["dosage"], refd["dosage"]) and np.array_equal(gotd["c"], refd["c"])
+    finally:
+        head_dev.set_sum_order(False)
+
+
 def test_dosage_pass_headline_size(head_panel, head_dev, head_gl, oracle):
     """One dosage pass at K = 50 000 x 2 000 grids: fp32 state (default) and fp64 state (qa_panel_set_dosage_precision)."""
     from quilt_amd.driver import thinned_grid_columns
