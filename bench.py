@@ -42,8 +42,10 @@ def pmc_file_for(mode, K, batch, mspbwt, rare_common):
         names = []
     elif mode == "ont" and K == 50000:
         names = ["r05_pmc_traffic_ont.json"]
-    elif mode == "short" and K == 64976:
-        names = ["r05_pmc_traffic_K64976.json"]
+    elif mode == "short" and batch == 128 and not rare_common:
+        # (any panel size: the dominant kernel is the small-panel sampler, whose work -- Ks = 600 haplotypes, 2 000 grids, the
+        # sample's reads -- does not depend on K; the full-panel kernels' traffic does, and is in the K = 50 000 summary only)
+        names = ["r05_pmc_traffic.json", "r04_pmc_traffic.json"]
     elif mode == "nipt" and K == 50000:
         names = ["r05_pmc_traffic_nipt.json"]
     elif mode == "short" and K == 5000 and batch == 32:
