@@ -1080,6 +1080,11 @@ int choose_gibbs_waves(int Ksp, int C, int share) {
     // share: host threads sharing the device; 0: device phases (qa_panel_set_exclusive) -- launches that fit run together, one
     // SIMD slot per wave, and a phase lasts as long as its slowest launch: one wave per chain always
     if (share > 0 && (long)C * 2 <= 1024 / share) nw = 2;
+    // device phases, a handful of chains (one to eight samples: the quick-start's shape): nothing shares the phase that two waves
+    // per chain could hold up, and a chain's serial time is all there is -- one sample through the whole pipeline 3.53 -> 3.15 s
+    // (scripts/perf_latency.py; labels identical in every geometry).  Larger launches keep one wave: a set's 128 / 256 phasing
+    // chains run beside another set's main chains only while their waves fit the 1 024 SIMD slots together.
+    if (share == 0 && C <= 64) nw = 2;
     if (const char *forced = getenv("QA_GIBBS_NW")) {   // test hook: exercise every geometry
         const int f = atoi(forced);
         if (f == 1 || f == 2 || f == 5 || f == 10) nw = f;

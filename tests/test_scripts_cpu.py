@@ -66,3 +66,47 @@ def test_trace_state_scripts_run_on_small_inputs(tmp_path, capsys, monkeypatch):
     _load("host_trace_states").main()
     out = capsys.readouterr().out
     assert "2:" in out and "1:" in out
+
+
+def test_bench_names_its_workload_and_its_counter_summary():
+    """bench.py: `config.workload` says which BASELINE configuration a run is (or that it is none), and every workload is priced on the
+    committed counter summary of THAT workload (profiles/r05_pmc_traffic_<workload>.json), never on another's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert "configs[2]" in bench.workload_label("short", 50000, 128)
+    assert "configs[1]" in bench.workload_label("short", 5000, 32)
+    assert bench.workload_label("short", 64976, 128).startswith("not a BASELINE.json configuration") and "HRC" in bench.workload_label("short", 64976, 128)
+    assert "configs[4]" in bench.workload_label("nipt", 50000, 128) and "configs[3]" in bench.workload_label("ont", 50000, 128)
+    assert "QUILT2's default mode" in bench.workload_label("short", 50000, 128, True, True)
+    assert bench.workload_label("short", 20000, 64).startswith("not a BASELINE.json configuration")
+    want = {("short", 50000, 128, False, False): "r05_pmc_traffic.json", ("short", 5000, 32, False, False): "r05_pmc_traffic_configs1.json",
+            ("nipt", 50000, 128, False, False): "r05_pmc_traffic_nipt.json", ("ont", 50000, 128, False, False): "r05_pmc_traffic_ont.json",
+            ("short", 50000, 128, True, False): "r05_pmc_traffic_mspbwt.json", ("short", 50000, 128, True, True): "r05_pmc_traffic_quilt2_default.json"}
+    for key, name in want.items():
+        got = bench.pmc_file_for(*key)
+        assert got is not None and os.path.basename(got) == name and os.path.exists(os.path.join(ROOT, got)), (key, got)
+        d = json.load(open(os.path.join(ROOT, got)))
+        assert "calibration" in d and "x 1024 x 2.0" in d["units"]   # the calibrated factors, from profiles/r05_fetch_calibration.json
+    assert bench.pmc_file_for("nipt", 50000, 128, False, True) is None   # no summary of NIPT with rare + common: the line must say so
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r05_fetch_calibration.json")))["kernels"]
+    for k in ("rd16", "rd8", "rd4"):
+        assert abs(cal[k]["factor"] - 2.0) < 0.01
+    assert abs(cal["rd8buf"]["factor"] - 2.0 * 4800 / 4864) < 0.01   # the sampler's column shape: x 2 on the 128-byte lines touched
+    for k in ("wr16", "wr8", "wr8buf"):
+        assert abs(cal[k]["factor"] - 1.0) < 0.01
+
+
+def test_bench_whole_sample_cpu_baseline_small():
+    """cpu_baseline_whole: whole samples, one per worker, through the entire pipeline on the CPU path; the first n_keep results are the
+    r2 reference; a budget that runs out stops the workers and reports nothing rather than a partial sample."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=1000, nSNPs=640, seed=4916)
+    params = dict(nGibbsSamples=2, n_seek_its=2, Ksubset=64, Knew=64, seed=1)
+    work = [(make_synthetic_sample(panel, seed=1000 + i, n_reads=120), i) for i in range(3)]
+    out, ref = bench.cpu_baseline_whole(panel, params, work, 2, 120, 1)
+    assert out["whole_samples"] == 2 and out["cores"] == 2 and out["kind"] == "port" and out["value"] > 0
+    assert ref["n"] == 1 and ref["ref"][0].dosage.shape == (panel.nSNPs,)
+    out2, ref2 = bench.cpu_baseline_whole(panel, params, work, 2, 0.01, 1)
+    assert out2 is None and ref2 is None
