@@ -538,7 +538,9 @@ SEXP qa_QUILT_rcpp_make_eMatRead_t(SEXP eMatRead_tSEXP, SEXP sampleReadsSEXP, SE
  *   params                named list of QUILT()'s arguments the path sees (missing entries = the reference's defaults):
  *                         nGibbsSamples, n_seek_its, n_burn_in_seek_its, Ksubset, Knew, K_top_matches, heuristic_match_thin,
  *                         small_ref_panel_gibbs_iterations, small_ref_panel_block_gibbs_iterations (0-based), maxDifferenceBetweenReads,
- *                         minGLValue, Jmax, seed, samples_per_launch_set; use_mspbwt, mspbwtL, mspbwtM, mspbwt_nindices;
+ *                         minGLValue, Jmax, seed (a non-negative whole number below 2^53), samples_per_launch_set, device (0-based GPU of
+ *                         this worker, taken modulo the number of devices: mclapply's iCore - 1; absent: the current device);
+ *                         use_mspbwt, mspbwtL, mspbwtM, mspbwt_nindices;
  *                         impute_rare_common; method ("diploid" / "nipt"), ff (one fetal fraction per sample), shuffle_bin_radius
  *   sample_offset         0-based index of the range's first sample among ALL samples (keys the random streams: a sample's
  *                         result does not depend on the range it lands in)
