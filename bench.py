@@ -408,8 +408,9 @@ def main():
                     help="whole (default): cpu_baseline.value is MEASURED on whole samples, one per physical core, all cores at once "
                          "(minutes of wall; the composed figure is kept beside it); composed: only the composed figure (one Gibbs call "
                          "+ one thin + one dosage pass per core, priced up to a sample)")
-    ap.add_argument("--cpu-baseline-budget", type=float, default=480.0, metavar="SEC",
-                    help="wall-time bound of the whole-sample CPU baseline; workers still running then are stopped")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=420.0, metavar="SEC",
+                    help="wall-time bound of the whole-sample CPU baseline (measured: 355-389 s on 128 cores); workers still running then are "
+                         "stopped, and when none has finished the composed figure stands alone")
     ap.add_argument("--no-scan-check", action="store_true",
                     help="--mspbwt: skip the comparison of the device search with the msPBWT neighbour scan (CPU, ~20 s)")
     ap.add_argument("--r2-vs-cpu", type=int, default=4, metavar="N",
