@@ -247,3 +247,51 @@ def test_handle_buffers_go_with_the_handle(medium_panel):
         assert L.qa_impute_kept_buffers() == 1
         dev.close()
         assert L.qa_impute_kept_buffers() == 0
+
+
+_SPLIT_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+from quilt_amd.driver import DriverParams
+from quilt_amd.impute import impute_samples
+from quilt_amd.native import DevicePanel
+from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+panel = make_synthetic_panel(K=3000, nSNPs=64000, seed=12)
+samples = [make_synthetic_sample(panel, seed=5200 + i, n_reads=3000) for i in range(80)]
+dev = DevicePanel(panel)
+dev.set_dosage_precision(64)
+dev.set_exclusive(True)
+res = impute_samples([dev], samples, DriverParams(nGibbsSamples=7, n_seek_its=2, Ksubset=600, Knew=600, seed=4), samples_per_launch_set=80)
+h = hashlib.sha256()
+for r in res:
+    for a in (r.dosage, r.gp_t, r.phasing_haps, r.read_labels):
+        h.update(np.ascontiguousarray(a).tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_launches_cut_by_memory_give_the_same_results():
+    """A Gibbs call that does not fit the arena is cut into equal launches; with qa_gibbs_opts_t.reads_same_as a chain's bases may
+    then lie in ANOTHER launch's part of the caller's arrays (its sample's first chain went with the launch before).  Same samples
+    with the arena at 10 %% of the device (the 560-chain calls cut in two: 61 MB of state per chain against 28 GB) and at the default:
+    identical results."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for frac in ("0.1", None):
+        env = dict(os.environ)
+        env.pop("QA_ARENA_FRACTION", None)
+        env["QA_TIMING"] = "1"   # ([qa_gibbs C=<chains of the launch>] ... on stderr)
+        if frac:
+            env["QA_ARENA_FRACTION"] = frac
+        r = subprocess.run([sys.executable, "-c", _SPLIT_SCRIPT % root], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0].split()
+        import re
+        chains = [int(x) for x in re.findall(r"\[qa_gibbs C=(\d+)\]", r.stderr)]
+        out[frac] = (line[1], max(chains), len(chains))
+    assert out["0.1"][0] == out[None][0]
+    assert out[None][1] == 560 and out["0.1"][1] < 560 and out["0.1"][2] > out[None][2], out
