@@ -28,7 +28,16 @@ def _medium():
                            DriverParams(nGibbsSamples=3, seed=100 + sd, Ksubset=128, Knew=128)) for sd in range(1, 25)]
 
 
-CASES = {"quick_start": _quick_start, "medium": _medium}
+def _medium_nipt():
+    """method = "nipt" (mother + fetus, three full-panel passes per chain, block Gibbs) on the K = 5 000 panel: eight seeds."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=5000, nSNPs=3200, seed=11, ref_error=1e-3, nGen=100, expRate=1.0)
+    return panel, False, [(sd, make_synthetic_sample(panel, seed=7000 + 10 * sd, n_reads=1000, ff=0.2),
+                           DriverParams(nGibbsSamples=3, seed=300 + sd, Ksubset=128, Knew=128, method="nipt")) for sd in range(1, 9)]
+
+
+CASES = {"quick_start": _quick_start, "medium": _medium, "medium_nipt": _medium_nipt}
 
 
 def run_case(name, verbose=False):

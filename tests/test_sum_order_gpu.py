@@ -105,18 +105,18 @@ def _rows(name):
     return _ROWS[name]
 
 
-@pytest.mark.parametrize("case", ["quick_start", "medium"])
+@pytest.mark.parametrize("case", ["quick_start", "medium", "medium_nipt"])
 def test_validation_mode_equals_the_cpu_pipeline_on_every_seed(case):
     """(a) With the K-wide sums in the reference's order the native loop on the device ends with the CPU pipeline's read labels,
     dosages, genotype posteriors and phased haplotypes -- BIT FOR BIT, on every seed of both sweeps (no seed is skipped or
     chosen).  Hence the order of those sums is the only thing that separates the production mode from the CPU path."""
     rows = _rows(case)
-    assert len(rows) == (10 if case == "quick_start" else 24)
+    assert len(rows) == {"quick_start": 10, "medium": 24, "medium_nipt": 8}[case]
     for r in rows:
         assert r["val_labels_identical"] and r["val_dosage_identical"] and r["val_gp_identical"] and r["val_phase_identical"], r
 
 
-@pytest.mark.parametrize("case", ["quick_start", "medium"])
+@pytest.mark.parametrize("case", ["quick_start", "medium", "medium_nipt"])
 def test_production_mode_parts_within_the_samplers_own_spread(case):
     """(b) What a user of the production mode gets on such panels.  A run whose chains met a last-bit tie is another valid
     realisation of the sampler, not a worse one:
