@@ -1473,6 +1473,14 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         auto nipt_sweeps = [&]() {
             GibbsParams q = prm;
             q.ff = o->ff;
+            // The three-label sampler's 256-register build (two chains per SIMD, gibbs3.hip) is built and tested but NOT chosen by
+            // default: alone on the device 1 792 chains take 2.33-2.58 s in it against 2 x 1.24 s for two launches of 896 at one
+            // chain per SIMD -- a sweep's grid steps are HBM-bound either way (5.6 TB/s) and the read visits, which two waves per
+            // SIMD should overlap, pay for eMatGrid's trips through LDS and ~600 bytes of scratch per lane.
+            // QA_GIBBS3_LEAN=1 selects it (tests, measurements).
+            const char *lean3_env = getenv("QA_GIBBS3_LEAN");   // (read per call: the tests switch it inside one process)
+            const bool lean3_on = lean3_env && atoi(lean3_env) != 0;
+            q.lean3 = (Ksp == 640 && nw == 1 && lean3_on) ? 1 : 0;
             q.blk_n_pass = std::max(o->n_block_gibbs_iterations, 1);
             std::vector<int> passes;
             if (o->perform_block_gibbs)
@@ -1500,6 +1508,7 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
                 std::vector<int32_t> seg_status(C);
                 S.status.download(seg_status.data(), C, st);
                 QA_HIP(hipStreamSynchronize(st));
+                const double tg0 = now();
                 h_where.assign((size_t)C * G, -1); h_tab.assign((size_t)C * 4 * G, 0); h_n.assign(C, 0);
                 const int n_thr = std::max(1, std::min<int>(qa::host_threads_cap(), C));
                 auto work = [&](int tid) {
@@ -1522,11 +1531,14 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
                 for (int i = 1; i < n_thr; i++) th.emplace_back(work, i);
                 work(0);
                 for (auto &t : th) t.join();
+                const double tg1 = now();
                 S.blk_where.upload(h_where.data(), h_where.size(), st);
                 S.blk_tab.upload(h_tab.data(), h_tab.size(), st);
                 S.blk_n.upload(h_n.data(), h_n.size(), st);
                 q.blk_pass = (int)j;
                 qa::launch_block3(&q, st);
+                if (tmg) fprintf(stderr, "[qa_gibbs C=%d] block pass %d: device idle for the host's block tables %.1f ms (tables %.1f on %d threads, uploads enqueued %.1f)\n",
+                                 C, (int)j, (now() - tg0) * 1e3, (tg1 - tg0) * 1e3, n_thr, (now() - tg1) * 1e3);
                 it0 = passes[j] + 1;
             }
             if (passes.empty() || it0 < n_its || q.rebuild) {   // (also with no sweeps left: the rebuild after the last pass)

@@ -12,13 +12,21 @@
 // not skipped in this mode (:815) but leave every probability unchanged.
 #include "gibbs_dev.hpp"
 
+#include <type_traits>
+
 namespace {
 
 // (two waves per chain must also mean two waves per SIMD -- 256 registers each -- or 1024 chains would not be resident
 // together: amdgpu_waves_per_eu)
-template <int NE, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) void k_gibbs3(GibbsParams p) {
+// LEAN: the build for TWO chains per SIMD at ten rows per lane (256 registers per wave), as the two-label kernel's (gibbs.hip):
+// the grid steps of a sweep run at what HBM delivers and the read visits at a wave's serial latency, so two chains on a SIMD
+// overlap the one with the other.  What makes it fit: eMatGrid's three columns wait in LDS while a grid's reads are sampled
+// (15 KB per chain, 120 KB per compute unit), alpha * beta is formed in beta's registers, the next grid's columns are fetched
+// at the end of the grid instead of a grid ahead, and the class prototypes live in scalar registers.
+template <int NE, int NW, bool LEAN = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : NW))) void k_gibbs3(GibbsParams p) {
     __shared__ double s_red[2 * NW * 4];
+    __shared__ double s_e[LEAN ? 3 * NE * 64 * NW : 1];
     const int c = blockIdx.x, t = threadIdx.x;
     using CH = Chain<NE, NW>;
     CH ch(p, c, t, s_red);
@@ -47,12 +55,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
     auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
     // prior over labels and the read-label class prototypes (gibbs-nipt.cpp:2707-2729) of this chain's fetal fraction
+    // (wave-uniform values computed on the vector unit come back through v_readlane: they then live in scalar registers for
+    // the whole kernel instead of 50 vector registers)
+    auto sc = [](double v) { return rl_f64(v, 0); };
     const double ffc = p.ff_chain ? uni_d(&p.ff_chain[c]) : p.ff;
-    const double pp[3] = {0.5, (1 - ffc) * 0.5, ffc * 0.5};
+    const double pp[3] = {0.5, sc((1 - ffc) * 0.5), sc(ffc * 0.5)};
     const double rlc[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1},
-                              {pp[0] / (pp[0] + pp[1]), pp[1] / (pp[0] + pp[1]), 0},
-                              {pp[0] / (pp[0] + pp[2]), 0, pp[2] / (pp[0] + pp[2])},
-                              {0, pp[1] / (pp[1] + pp[2]), pp[2] / (pp[1] + pp[2])},
+                              {sc(pp[0] / (pp[0] + pp[1])), sc(pp[1] / (pp[0] + pp[1])), 0},
+                              {sc(pp[0] / (pp[0] + pp[2])), 0, sc(pp[2] / (pp[0] + pp[2]))},
+                              {0, sc(pp[1] / (pp[1] + pp[2])), sc(pp[2] / (pp[1] + pp[2]))},
                               {pp[0], pp[1], pp[2]}};
     int status = 0;
     if (p.it_begin > 0) {   // a later segment of the call: the state is in HBM, a chain that underflowed stays stopped
@@ -282,10 +293,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
             }
             const int jg = g & 63;
             double cg[NH];
-            Col<NE> en[NH];
+            Col<NE> en[LEAN ? 1 : NH];   // (LEAN: the next grid's columns are fetched at the end of this one, into e's own registers)
             const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: the loads stay unconditional
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
+                for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
+            }
             if (g > 0) {
                 // rcpp_alpha_forward_one_QUILT_faster (:671-707), normalize = true
                 const double x = rl_f64(gs.t0, jg), t1 = rl_f64(gs.t1, jg);
@@ -328,15 +341,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 }
             }
             // alpha * beta of the grid (the reference's ab_m), formed once the forward step is done; beta's registers then
-            // take the next grid's columns
-            Col<NE> ab[NH];
+            // take the next grid's columns (LEAN: the product is formed IN beta's registers, the next columns come at the end
+            // of the grid; eMatGrid's columns go to LDS for the time of the read loop when the grid has reads)
+            Col<NE> ab_own[LEAN ? 1 : NH];
+            auto &ab = [&]() -> Col<NE> (&)[NH] { if constexpr (LEAN) return bt; else return ab_own; }();
 #pragma unroll
             for (int h = 0; h < NH; h++) {
 #pragma unroll
                 for (int i = 0; i < NE; i++) ab[h].v[i] = a[h].v[i] * bt[h].v[i];
             }
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + gn);
+                for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + gn);
+            }
             // ---- sample_reads_in_grid (:733-1295), three labels
             bool grid_started = false, changed = false;
             double pC[3] = {1, 1, 1};
@@ -359,6 +376,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                 if (!grid_started) {
                     sum3(ab, pC);
                     grid_started = true;
+                    if constexpr (LEAN) {   // the grid has reads: its eMatGrid columns wait in LDS from here on
+#pragma unroll
+                        for (int h = 0; h < NH; h++)
+#pragma unroll
+                            for (int i = 0; i < NE; i++) s_e[(h * NE + i) * NT + t] = e[h].v[i];
+                    }
                 }
                 Col<NE> er, rer;   // the read's emission column and its reciprocal (x * (1 / e) for the reference's x / e,
                 {                  // as in the two-label kernel: <= 1 ulp apart)
@@ -373,74 +396,104 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                         ch.expand_with_rcp(er, rer, x);   // reciprocal once per table entry, gathered like the emission
                     }
                 }
-                int h_rC = 0, h_rA1 = 1, h_rA2 = 2;
+                // The three candidate labels in compile-time positions: one straight-line version of everything from the sums to
+                // the draw per current label, behind a wave-uniform branch, instead of a select per element and label in the sums
+                // (6 NE v_cndmask per read) and per probability after them (~40); the asm comments keep the compiler from folding
+                // the versions back into one block of selects (as in the two-label kernel, gibbs.hip).
+                int h_rC = 0, h_rA1 = 1, h_rN = 0;
                 double pA1[3] = {pC[0], pC[1], pC[2]}, pA2[3] = {pC[0], pC[1], pC[2]};
-                if (normal) {
-                    h_rC = rl_i32(rs.H, j) - 1;
-                    if (h_rC == 0) { h_rA1 = 1; h_rA2 = 2; }
-                    else if (h_rC == 1) { h_rA1 = 0; h_rA2 = 2; }
-                    else { h_rA1 = 0; h_rA2 = 1; }
+                double x3[3];
+                const double chance = rl_f64(rs.u, j);
+                // products, normalisation and the draw (:998-1076) with the current label hc, the lower other label a1, the higher a2
+                auto draw = [&](auto HC) {
+                    constexpr int hc = decltype(HC)::value, a1 = hc == 0 ? 1 : 0, a2 = hc == 2 ? 1 : 2;
+                    const double prod_pC = (pC[0] * pC[1] * pC[2]) * pp[hc];
+                    const double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * pp[a1];
+                    const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * pp[a2];
+                    const double denom = prod_pC + prod_pA1 + prod_pA2;
+                    const double rden = fast_rcp(denom);   // (x * (1 / d) for the reference's x / d, as in the two-label kernel)
+                    x3[hc] = prod_pC * rden; x3[a1] = prod_pA1 * rden; x3[a2] = prod_pA2 * rden;
+                    const double cs0 = x3[0], cs1 = x3[1] + cs0, cs2 = x3[2] + cs1;
+                    h_rN = 0;
+                    if (chance < cs2) h_rN = 2;
+                    if (chance < cs1) h_rN = 1;
+                    if (chance < cs0) h_rN = 0;
+                };
+                // a read in normal progress whose current label is hc: pA1 = the read leaves hc for a1, pA2 = for a2 (:905-960);
+                // dense form for categories 0, 2 and 3 (the sparse updates of 2 / 3 are the same sums), category 1 changes no sum
+                auto normal_read = [&](auto HC) {
+                    constexpr int hc = decltype(HC)::value, a1 = hc == 0 ? 1 : 0, a2 = hc == 2 ? 1 : 2;
+                    h_rA1 = a1;
                     if (rl_i32(rs.cat1, j) == 0) {
-                        // dense form for categories 0, 2 and 3 (the sparse updates of 2 / 3 are the same sums)
                         double s[3] = {0, 0, 0};
 #pragma unroll
-                        for (int h = 0; h < NH; h++) {
-                            double acc = 0;
-#pragma unroll
-                            for (int i = 0; i < NE; i++) acc += ab[h].v[i] * ((h == h_rC) ? rer.v[i] : er.v[i]);
-                            s[h] = acc;
+                        for (int i = 0; i < NE; i++) {
+                            s[0] += ab[0].v[i] * (hc == 0 ? rer.v[i] : er.v[i]);
+                            s[1] += ab[1].v[i] * (hc == 1 ? rer.v[i] : er.v[i]);
+                            s[2] += ab[2].v[i] * (hc == 2 ? rer.v[i] : er.v[i]);
                         }
                         ch.template bsum<3>(s);
-                        // pA1: the read leaves h_rC for h_rA1; pA2: for h_rA2 (:905-960).  Written label by label with
-                        // selects: a dynamically indexed local array would live in scratch memory
-#pragma unroll
-                        for (int h = 0; h < 3; h++) {
-                            pA1[h] = (h == h_rC || h == h_rA1) ? s[h] : pC[h];
-                            pA2[h] = (h == h_rC || h == h_rA2) ? s[h] : pC[h];
-                        }
+                        pA1[hc] = s[hc]; pA1[a1] = s[a1];
+                        pA2[hc] = s[hc]; pA2[a2] = s[a2];
                     }
-                } else if (ginit) {
-                    double s[3] = {0, 0, 0};
+                    draw(HC);
+                };
+                if (normal) {
+                    h_rC = rl_i32(rs.H, j) - 1;
+                    if (h_rC == 0) {
+                        asm volatile("; current label 0" ::: "memory");
+                        normal_read(std::integral_constant<int, 0>{});
+                        asm volatile("; current label 0 done" ::: "memory");
+                    } else if (h_rC == 1) {
+                        asm volatile("; current label 1" ::: "memory");
+                        normal_read(std::integral_constant<int, 1>{});
+                        asm volatile("; current label 1 done" ::: "memory");
+                    } else {
+                        asm volatile("; current label 2" ::: "memory");
+                        normal_read(std::integral_constant<int, 2>{});
+                        asm volatile("; current label 2 done" ::: "memory");
+                    }
+                } else {
+                    if (ginit) {
+                        double s[3] = {0, 0, 0};
 #pragma unroll
-                    for (int h = 0; h < NH; h++)
+                        for (int h = 0; h < NH; h++)
 #pragma unroll
-                        for (int i = 0; i < NE; i++) s[h] += ab[h].v[i] * er.v[i];
-                    ch.template bsum<3>(s);
-                    pC[0] = s[0];
-                    pA1[1] = s[1];
-                    pA2[2] = s[2];
+                            for (int i = 0; i < NE; i++) s[h] += ab[h].v[i] * er.v[i];
+                        ch.template bsum<3>(s);
+                        pC[0] = s[0];
+                        pA1[1] = s[1];
+                        pA2[2] = s[2];
+                    }
+                    draw(std::integral_constant<int, 0>{});
                 }
-                const double prod_pC = (pC[0] * pC[1] * pC[2]) * (h_rC == 0 ? pp[0] : h_rC == 1 ? pp[1] : pp[2]);
-                const double prod_pA1 = (pA1[0] * pA1[1] * pA1[2]) * (h_rA1 == 0 ? pp[0] : h_rA1 == 1 ? pp[1] : pp[2]);
-                const double prod_pA2 = (pA2[0] * pA2[1] * pA2[2]) * (h_rA2 == 0 ? pp[0] : h_rA2 == 1 ? pp[1] : pp[2]);
-                const double denom = prod_pC + prod_pA1 + prod_pA2;
-                const double rden = fast_rcp(denom);   // (x * (1 / d) for the reference's x / d, as in the two-label kernel)
-                const double norm_pC = prod_pC * rden, norm_pA1 = prod_pA1 * rden, norm_pA2 = prod_pA2 * rden;
-                const double chance = rl_f64(rs.u, j);
-                double x3[3];
-#pragma unroll
-                for (int h = 0; h < 3; h++) x3[h] = (h == h_rC) ? norm_pC : ((h == h_rA1) ? norm_pA1 : norm_pA2);
-                const double cs0 = x3[0], cs1 = x3[1] + cs0, cs2 = x3[2] + cs1;
-                int h_rN = 0;
-                if (chance < cs2) h_rN = 2;
-                if (chance < cs1) h_rN = 1;
-                if (chance < cs0) h_rN = 0;
                 if (((h_rN != h_rC) || ginit) && !pass) {
                     changed = true;
                     if (ch.lane == j) rs.H = h_rN + 1;
                     rs_dirty = true;
+                    auto mul_e = [&](int h, const Col<NE> &f) {   // eMatGrid's column: in registers, or (LEAN) where it waits in LDS
+                        if constexpr (LEAN) {
+#pragma unroll
+                            for (int i = 0; i < NE; i++) s_e[(h * NE + i) * NT + t] *= f.v[i];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NE; i++) e[h].v[i] *= f.v[i];
+                        }
+                    };
 #pragma unroll
                     for (int h = 0; h < NH; h++) {
                         if (normal && h == h_rC) {
 #pragma unroll
-                            for (int i = 0; i < NE; i++) { a[h].v[i] *= rer.v[i]; ab[h].v[i] *= rer.v[i]; e[h].v[i] *= rer.v[i]; }
+                            for (int i = 0; i < NE; i++) { a[h].v[i] *= rer.v[i]; ab[h].v[i] *= rer.v[i]; }
+                            mul_e(h, rer);
                         }
                     }
 #pragma unroll
                     for (int h = 0; h < NH; h++) {
                         if (h == h_rN) {
 #pragma unroll
-                            for (int i = 0; i < NE; i++) { a[h].v[i] *= er.v[i]; ab[h].v[i] *= er.v[i]; e[h].v[i] *= er.v[i]; }
+                            for (int i = 0; i < NE; i++) { a[h].v[i] *= er.v[i]; ab[h].v[i] *= er.v[i]; }
+                            mul_e(h, er);
                         }
                     }
                     if (normal) {
@@ -466,6 +519,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                     rs_dirty = true;
                 }
             }
+            if constexpr (LEAN) {   // the next grid's eMatGrid columns: e's registers are free (this grid's wait in LDS or are dead)
+#pragma unroll
+                for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h] + gn);
+            }
             if (changed) {
                 // re-inject the moved columns and renormalise (:1262-1292)
                 double sm[NH];
@@ -476,13 +533,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW))) v
                     cg[h] *= alphaConst;
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
-                    ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+                    if constexpr (LEAN) {   // from LDS to memory through the registers of alpha * beta, dead by now
+#pragma unroll
+                        for (int i = 0; i < NE; i++) ab[h].v[i] = s_e[(h * NE + i) * NT + t];
+                        ch.st(ab[h], ch.eg[h] + (size_t)g * Ksp);
+                    } else {
+                        ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+                    }
                 }
             }
+            // alphaHat_t is not read inside a segment of sweeps (every sweep carries alpha in registers from grid 0 on); what
+            // follows a segment -- the block pass's rate, hapProbs -- sees the state its last sweep leaves: only that one writes it
+            if (it == p.it_end - 1) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) {
-                ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
-                e[h] = en[h];
+                for (int h = 0; h < NH; h++) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+            }
+            if constexpr (LEAN) {
+#pragma unroll
+                for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + gn);
+            } else {
+#pragma unroll
+                for (int h = 0; h < NH; h++) e[h] = en[h];
             }
             gs.set_c(ch.lane, jg, cg[0], cg[1], cg[2]);
         }
@@ -659,8 +730,13 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
         ch.template bsum<NH>(s);
     };
 
-    Col<NE> aS[6][3];          // alphaStore
-    double inside[6][3];       // sum of log_cStore over the current block, in grid order
+    // alphaStore / log_cStore of the six relabellings: relabelling ir runs slot h on emission column EM[ir][h], every
+    // relabelling restarts a block from the same alpha, and slot h's recursion sees nothing but its own column -- so the 18
+    // recursions are 9 distinct ones, each shared by two relabellings (same operations on the same inputs: the same values).
+    // aS[h][i] / inside[h][i]: slot h fed with emission column i.
+    constexpr int EM[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}};   // i with RR[ir][i] - 1 == h
+    Col<NE> aS[3][3];
+    double inside[3][3];       // sum of log_cStore over the current block, in grid order
     double logC_before[3] = {0, 0, 0}, logC_after[3];
     {
         double s[3] = {0, 0, 0};
@@ -672,9 +748,9 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
         for (int h = 0; h < 3; h++) logC_after[h] = s[h];
     }
 #pragma unroll
-    for (int ir = 0; ir < 6; ir++)
+    for (int h = 0; h < 3; h++)
 #pragma unroll
-        for (int h = 0; h < 3; h++) inside[ir][h] = 0;
+        for (int i = 0; i < 3; i++) inside[h][i] = 0;
     bool ever_changed = false;
 
     // the forward recursion's inputs are fetched a grid ahead (columns) or 64 grids at a time into lanes (block index,
@@ -698,39 +774,37 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
             for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
         }
         const double t0 = rl_f64(t0_l, g & 63), t1 = rl_f64(t1_l, g & 63);
-        // the 18 normalisers of this grid (uniform values): lane 3 ir + h keeps d(ir, h), so that ONE logarithm per lane
-        // replaces 18 per lane (the same function on the same inputs)
+        // the 9 normalisers of this grid (uniform values): lane 3 h + i keeps d(h, i), so that ONE logarithm per lane
+        // replaces 9 per lane (the same function on the same inputs)
         double d_of_lane = 1.0;
         // ---- Rcpp_gibbs_block_forward_one (:1122-1253)
 #pragma unroll
-        for (int ir = 0; ir < 6; ir++) {
-            Col<NE> nx[NH];   // indexed by the slot h = rr0(ir, i)
+        for (int h = 0; h < 3; h++) {
+            Col<NE> nx[NH];   // indexed by the emission column i
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                constexpr int dummy = 0; (void)dummy;
-                const int h = RR[ir][i] - 1;
 #pragma unroll
                 for (int q = 0; q < NE; q++) {
-                    if (g == 0) nx[h].v[q] = valid[q] ? prior * e[i].v[q] : 0.0;
-                    else nx[h].v[q] = valid[q] ? e[i].v[q] * (t0 * aS[ir][h].v[q] + t1 * one_over_K) : 0.0;
+                    if (g == 0) nx[i].v[q] = valid[q] ? prior * e[i].v[q] : 0.0;
+                    else nx[i].v[q] = valid[q] ? e[i].v[q] * (t0 * aS[h][i].v[q] + t1 * one_over_K) : 0.0;
                 }
             }
             double sm[NH];
             sum3(nx, sm);
 #pragma unroll
-            for (int h = 0; h < 3; h++) {
-                const double d = 1 / sm[h];
-                if (ch.lane == 3 * ir + h) d_of_lane = d;
+            for (int i = 0; i < 3; i++) {
+                const double d = 1 / sm[i];
+                if (ch.lane == 3 * h + i) d_of_lane = d;
 #pragma unroll
-                for (int q = 0; q < NE; q++) aS[ir][h].v[q] = d * nx[h].v[q];
+                for (int q = 0; q < NE; q++) aS[h][i].v[q] = d * nx[i].v[q];
             }
         }
         {
             const double lg = log(d_of_lane);
 #pragma unroll
-            for (int ir = 0; ir < 6; ir++)
+            for (int h = 0; h < 3; h++)
 #pragma unroll
-                for (int h = 0; h < 3; h++) inside[ir][h] += rl_f64(lg, 3 * ir + h);
+                for (int i = 0; i < 3; i++) inside[h][i] += rl_f64(lg, 3 * h + i);
         }
         const int iBlock = rl_i32(where_l, g & 63);
         if (iBlock > -1) {
@@ -740,19 +814,24 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
             Col<NE> bt[NH];
 #pragma unroll
             for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + (size_t)g * Ksp);
-            double P[6];
+            double P[6], ldot[3][3];   // log of sum_k alphaStore(slot h fed with column i) * beta(slot h)
 #pragma unroll
-            for (int ir = 0; ir < 6; ir++) {
+            for (int h = 0; h < 3; h++) {
                 double dot[3] = {0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < 3; i++)
 #pragma unroll
-                    for (int q = 0; q < NE; q++) dot[i] += aS[ir][i].v[q] * bt[i].v[q];
+                    for (int q = 0; q < NE; q++) dot[i] += aS[h][i].v[q] * bt[h].v[q];
                 ch.template bsum<3>(dot);
+#pragma unroll
+                for (int i = 0; i < 3; i++) ldot[h][i] = log(dot[i]);
+            }
+#pragma unroll
+            for (int ir = 0; ir < 6; ir++) {
                 P[ir] = 0;
 #pragma unroll
-                for (int i = 0; i < 3; i++)
-                    P[ir] += log(dot[i]) + -logC_before[i] + -inside[ir][i] + -logC_after[i];
+                for (int h = 0; h < 3; h++)
+                    P[ir] += ldot[h][EM[ir][h]] + -logC_before[h] + -inside[h][EM[ir][h]] + -logC_after[h];
             }
             // ... and of the read classes under it (rcpp_calculate_block_read_label_probabilities_using_H_class)
             int ns[8];
@@ -883,14 +962,14 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
                     for (int h = 0; h < NH; h++) ch.ld(al[h], ch.alpha[h] + (size_t)g * Ksp);
                 }
 #pragma unroll
-                for (int ir = 0; ir < 6; ir++)
+                for (int h = 0; h < 3; h++)
 #pragma unroll
-                    for (int h = 0; h < 3; h++) aS[ir][h] = al[h];
+                    for (int i = 0; i < 3; i++) aS[h][i] = al[h];
             }
 #pragma unroll
-            for (int ir = 0; ir < 6; ir++)
+            for (int h = 0; h < 3; h++)
 #pragma unroll
-                for (int h = 0; h < 3; h++) inside[ir][h] = 0;
+                for (int i = 0; i < 3; i++) inside[h][i] = 0;
             for (int g2 = grid_start; g2 <= grid_end; g2++)
 #pragma unroll
                 for (int h = 0; h < 3; h++) logC_before[h] += log(uni_d(&ch.cv[h][g2]));
@@ -933,9 +1012,9 @@ void launch_block(const GibbsParams &prm, hipStream_t st) {
     QA_HIP(hipGetLastError());
 }
 
-template <int NE, int NW>
+template <int NE, int NW, bool LEAN = false>
 void launch_one(const GibbsParams &prm, hipStream_t st) {
-    hipLaunchKernelGGL((k_gibbs3<NE, NW>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
+    hipLaunchKernelGGL((k_gibbs3<NE, NW, LEAN>), dim3(prm.C), dim3(64 * NW), 0, st, prm);
     QA_HIP(hipGetLastError());
 }
 
@@ -966,7 +1045,8 @@ void launch_gibbs3(const void *params, hipStream_t st) {
         case 6: launch_one<6, 1>(prm, st); break;
         case 8: launch_one<8, 1>(prm, st); break;
         case 10:
-            if (prm.er_nt == 64) launch_one<10, 1>(prm, st);
+            if (prm.er_nt == 64 && prm.lean3) launch_one<10, 1, true>(prm, st);
+            else if (prm.er_nt == 64) launch_one<10, 1>(prm, st);
             else launch_one<5, 2>(prm, st);
             break;
         default: throw std::runtime_error("NIPT sampler: Ksubset geometry not built (Ksubset / 64 rounded up must be 1..6, 8 or 10)");

@@ -91,6 +91,7 @@ struct GibbsParams {
     // them (gibbs3.hip); the state lives in HBM across the launches.  blk_*: the pass's block table per chain.
     int it_begin, it_end;
     int rebuild;                // this segment follows a block pass: eMatGrid, forward, backward from the labels first
+    int lean3;                  // the three-label sampler's 256-register build (two chains per SIMD): launches of more than 1 024 chains
     const int32_t *blk_where;   // [C][G] consider_grid_where_0_based
     const int32_t *blk_tab;     // [C][4][G] per block: grid_start, grid_end, reads_start, reads_end
     const int32_t *blk_n;       // [C] n_blocks
@@ -430,8 +431,11 @@ struct Chain {
         H = p.H + p.read_off[c];
         Hc = p.H_class + p.read_off[c];
         prior = 1.0 / Ks;
+        // Ksp is Ks rounded up to 64 rows (gibbs.hip), so only a thread's LAST row can lie beyond Ks: rows t + NT i with
+        // i < NE - 1 end at Ksp - NT - 1 < Ksp - 64 < Ks.  Written so that the compiler sees it: the per-element selects
+        // on valid[i] of the grid steps (2 v_cndmask per fp64 element) fold away for all rows but the last.
 #pragma unroll
-        for (int i = 0; i < NE; i++) valid[i] = (t + NT * i) < Ks;
+        for (int i = 0; i < NE; i++) valid[i] = (i < NE - 1) ? true : (t + NT * i) < Ks;
     }
     // A read's emission column, compact form: this thread's pattern bytes and the lane's table entry (one load each,
     // issued a read ahead), expanded by a cross-lane gather (ds_bpermute: no memory traffic).

@@ -348,6 +348,46 @@ def test_nipt_every_chain_geometry(medium_panel, oracle, nw, monkeypatch):
 
 
 
+@pytest.mark.parametrize("init_iter", [False, True])
+def test_nipt_two_chains_per_simd_build(medium_panel, oracle, init_iter, monkeypatch):
+    """The three-label sampler's 256-register build (two chains per SIMD: eMatGrid's three columns in LDS during a grid's
+    reads, alpha * beta formed in beta's registers, no columns fetched a grid ahead; not the default -- it measured no faster
+    than two launches at one chain per SIMD -- selected by QA_GIBBS3_LEAN = 1): labels and classes identical to the oracle,
+    block passes included, with both initialisations."""
+    from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    monkeypatch.setenv("QA_GIBBS_NW", "1")
+    monkeypatch.setenv("QA_GIBBS3_LEAN", "1")
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    rng = np.random.default_rng(18)
+    samples, whichs, H0s, rus, rbs, rrs, frs, refs = [], [], [], [], [], [], [], []
+    ffs = [0.2, 0.1, 0.3]
+    for c, ff in enumerate(ffs):
+        s = make_synthetic_sample(panel, seed=60 + c, n_reads=600 + 150 * c, ff=ff)
+        which = np.sort(rng.choice(panel.K, 600, replace=False)).astype(np.int32) + 1
+        R = s.nReads
+        H0 = rng.choice([1, 2, 3], p=[0.5, 0.4, 0.1], size=R).astype(np.int32)
+        ru, rb, rr = rng.random(R * 21), rng.random(3 * R), rng.random(3 * R)
+        fr = int(rng.integers(0, R))
+        refs.append(oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, np.zeros(3 * panel.nGrids), ff=ff,
+                                                    gibbs_initialize_iteratively=init_iter, runif_block=rb, runif_resample=rr))
+        samples.append(s); whichs.append(which); H0s.append(H0); rus.append(ru); rbs.append(rb); rrs.append(rr); frs.append(fr)
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    for c in range(3):
+        got = rcpp_forwardBackwardGibbsNIPT(dev, samples[c], whichs[c], H0s[c], rus[c], frs[c], None, ff=ffs[c],
+                                            gibbs_initialize_iteratively=init_iter, runif_block=rbs[c], runif_resample=rrs[c])
+        r = refs[c]
+        assert r["status"] == 0 and not got["underflow_problem"]
+        assert np.array_equal(got["H"], r["H"]), f"{(got['H'] != r['H']).sum()} labels differ"
+        assert np.array_equal(got["H_class"], r["H_class"])
+        np.testing.assert_allclose(got["hapProbs_t"], r["hapProbs_t"], rtol=RTOL, atol=1e-14)
+        np.testing.assert_allclose(got["genProbsM_t"], r["genProbsM_t"], rtol=RTOL, atol=1e-14)
+        np.testing.assert_allclose(got["genProbsF_t"], r["genProbsF_t"], rtol=RTOL, atol=1e-14)
+    dev.close()
+
+
 def test_nipt_edge_inputs(small_panel, oracle):
     """NIPT block Gibbs on awkward inputs: a handful of reads (blocks without reads are merged away, possibly all but
     one), reads piled on the first / last grid, a single block."""
