@@ -83,50 +83,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
     }   // first segment
     chain_sync<NW>();
 
-    // forward over all grids for every label (Rcpp_run_forward_haploid, copied-from-stitch.cpp:340-387): the next grid's
-    // eMatGrid columns fetched while this one computes, the transitions read and the normalisers written 64 grids at a
-    // time through lanes (GridStreams3)
-    auto forward_full = [&]() {
-        Col<NE> a[NH], e[NH];
-        GridStreams3<CH> gs;
-#pragma unroll
-        for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h]);
-        for (int g = 0; g < G; g++) {
-            if ((g & 63) == 0) {
-                if (g) gs.store_c(ch);
-                gs.load_fwd(ch, g);
-            }
-            const int j = g & 63;
-            Col<NE> en[NH];
-            const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: the loads stay unconditional
-#pragma unroll
-            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
-            const double s0 = rl_f64(gs.t0, j), s1 = rl_f64(gs.t1, j);
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-#pragma unroll
-                for (int i = 0; i < NE; i++) {
-                    if (g == 0) a[h].v[i] = valid[i] ? prior * e[h].v[i] : 0.0;
-                    else a[h].v[i] = valid[i] ? e[h].v[i] * (s0 * a[h].v[i] + s1 * prior) : 0.0;
-                }
-            }
-            double sm[NH], cc[NH];
-            sum3(a, sm);
-#pragma unroll
-            for (int h = 0; h < NH; h++) {
-                cc[h] = 1 / sm[h];
-#pragma unroll
-                for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * cc[h];
-                ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
-                e[h] = en[h];
-            }
-            gs.set_c(ch.lane, j, cc[0], cc[1], cc[2]);
-        }
-        gs.store_c(ch);
-        chain_sync<NW>();
-    };
-    // Rcpp_run_backward_haploid (copied-from-stitch.cpp:392-409) or its QUILT_faster form (:417-440); beta(G-1) = c(G-1)
-    auto backward_full = [&](bool faster) {
+    // `masked`: only the Ks real rows of a column move (Chain::ldm / stm) -- for every call but a first segment's first one, which
+    // is what gives the padding rows of beta their zeros
+    auto backward_full = [&](bool faster, bool masked) {
         // per-grid scalars from lane-held streams, the next grid's eMatGrid columns fetched while this one computes
         // (as backward_both of the two-label kernel, gibbs.hip)
         Col<NE> b[NH], e[NH];
@@ -137,18 +96,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             const double cl = gs.c_of(h, (G - 1) & 63);
 #pragma unroll
             for (int i = 0; i < NE; i++) b[h].v[i] = valid[i] ? cl : 0.0;
-            ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
+            if (masked) ch.stm(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
+            else ch.st(b[h], ch.beta[h] + (size_t)(G - 1) * Ksp);
         }
         if (G >= 2) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h] + (size_t)(G - 1) * Ksp);
+            for (int h = 0; h < NH; h++) ch.ldm(e[h], ch.eg[h] + (size_t)(G - 1) * Ksp);
         }
         for (int g = G - 2; g >= 0; --g) {
             if ((g & 63) == 63) gs.load_bwd(ch, g & ~63);
             const int j = g & 63;
             Col<NE> en[NH];   // the next iteration's emission columns (grid g)
 #pragma unroll
-            for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + (size_t)g * Ksp);
+            for (int h = 0; h < NH; h++) ch.ldm(en[h], ch.eg[h] + (size_t)g * Ksp);
             const double s0 = rl_f64(gs.t0, j), s1 = rl_f64(gs.t1, j);
             const bool has = !faster || rl_i32(gs.has, j) != 0;
             double x[NH];
@@ -169,7 +129,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                 const double xx = faster ? s1 * x[h] * one_over_K : s1 * x[h];
 #pragma unroll
                 for (int i = 0; i < NE; i++) b[h].v[i] = valid[i] ? cg * (xx + s0 * b[h].v[i]) : 0.0;
-                ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
+                if (masked) ch.stm(b[h], ch.beta[h] + (size_t)g * Ksp);
+                else ch.st(b[h], ch.beta[h] + (size_t)g * Ksp);
             }
 #pragma unroll
             for (int h = 0; h < NH; h++) e[h] = en[h];
@@ -177,23 +138,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
         chain_sync<NW>();
     };
 
-    // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281) from the labels in memory; reads are sorted by grid, only grids
-    // with reads are written (the others hold 1 since the call began).  The reads' scalars come from lane-held streams, the
-    // next read's compact emission is fetched a read ahead
-    auto build_emat_grid = [&]() {
+    // rcpp_make_eMatGrid_t (copied-from-stitch.cpp:262-281) from the labels in memory and Rcpp_run_forward_haploid (:340-387) in
+    // ONE pass over the grids: a grid's eMatGrid columns go from the reads (sorted by grid; their scalars come from lane-held
+    // streams, the next read's compact emission is fetched a read ahead) straight into the forward step -- and to memory when the
+    // grid has reads: the others hold 1 since the call began -- instead of being written by one pass and read back by the next.  alphaHat_t is written only when no sweep follows in this launch (a
+    // sweep carries alpha in registers from grid 0 on and the segment's last one writes it).
+    auto build_forward = [&](bool store_alpha) {
         ReadStreams<CH> rs;
         rs.load(ch, 0, nullptr, 0);
         typename CH::ErPre pre{};
         if (R > 0) ch.ld_pre(pre, 0);
         int r = 0;
-        while (r < R) {
-            if (r >= rs.base + 64) rs.load(ch, r, nullptr, 0);
-            const int g = rl_i32(rs.wif, r - rs.base);
+        Col<NE> a[NH];
+        GridStreams3<CH> gs;
+        for (int g = 0; g < G; g++) {
+            if ((g & 63) == 0) {
+                if (g) gs.store_c(ch);
+                gs.load_fwd(ch, g);
+            }
+            const int jg = g & 63;
             Col<NE> e[NH];
 #pragma unroll
             for (int h = 0; h < NH; h++)
 #pragma unroll
                 for (int i = 0; i < NE; i++) e[h].v[i] = 1.0;
+            bool any = false;
             while (r < R) {
                 if (r >= rs.base + 64) rs.load(ch, r, nullptr, 0);
                 const int j = r - rs.base;
@@ -209,13 +178,37 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
 #pragma unroll
                         for (int i = 0; i < NE; i++) e[h].v[i] *= er.v[i];
                     }
+                any = true;
                 r++;
             }
+            if (any) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+                for (int h = 0; h < NH; h++) ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+            }
+            const double s0 = rl_f64(gs.t0, jg), s1 = rl_f64(gs.t1, jg);
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    if (g == 0) a[h].v[i] = valid[i] ? prior * e[h].v[i] : 0.0;
+                    else a[h].v[i] = valid[i] ? e[h].v[i] * (s0 * a[h].v[i] + s1 * prior) : 0.0;
+                }
+            }
+            double sm[NH], cc[NH];
+            sum3(a, sm);
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                cc[h] = 1 / sm[h];
+#pragma unroll
+                for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * cc[h];
+                if (store_alpha) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+            }
+            gs.set_c(ch.lane, jg, cc[0], cc[1], cc[2]);
         }
+        gs.store_c(ch);
         chain_sync<NW>();
     };
+    const bool sweeps_follow = p.it_begin < p.it_end;
 
     // ---- rcpp_gibbs_nipt_initialize (:1629-1750)
     if (p.it_begin > 0) {
@@ -224,15 +217,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
         // eMatGrid, Rcpp_run_forward_haploid, Rcpp_run_backward_haploid_QUILT_faster from beta(G - 1) = c(G - 1)); done here, one
         // wave per chain with the pipelined passes, instead of at the end of k_block3 (two waves, a barrier per sum)
         if (p.rebuild && status == 0) {
-            build_emat_grid();
-            forward_full();
-            backward_full(true);
+            build_forward(!sweeps_follow);
+            backward_full(true, true);
         }
     } else if (!init_iteratively) {
-        build_emat_grid();
-        chain_sync<NW>();
-        forward_full();
-        backward_full(false);   // rcpp_initialize_gibbs_forward_backward (:453-487)
+        build_forward(true);   // (the call's first pass over alpha: it also gives the padding rows their zeros)
+        backward_full(false, false);   // rcpp_initialize_gibbs_forward_backward (:453-487)
     } else {
         // alpha = beta = 1, c = 1, then only column 0 of alpha is initialised (:1725-1740)
         Col<NE> one;
@@ -281,10 +271,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
         // be waited for before use, which (in-order vmcnt) would also drain the column prefetches
         GridStreams3<CH> gs;
         Col<NE> e[NH], bt[NH];
+        // (state columns in the sweeps: only the Ks real rows move; the padding rows keep what the first segment's initialisation
+        // stored -- 0 for alpha and beta, 1 for eMatGrid -- and read as 0 here: every use is masked by `valid` or multiplies a 0)
 #pragma unroll
         for (int h = 0; h < NH; h++) {
-            ch.ld(e[h], ch.eg[h]);
-            ch.ld(bt[h], ch.beta[h]);
+            ch.ldm(e[h], ch.eg[h]);
+            ch.ldm(bt[h], ch.beta[h]);
         }
         for (int g = 0; g < G; g++) {
             if ((g & 63) == 0) {
@@ -297,7 +289,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             const size_t gn = (size_t)min(g + 1, G - 1) * Ksp;   // clamped: the loads stay unconditional
             if constexpr (!LEAN) {
 #pragma unroll
-                for (int h = 0; h < NH; h++) ch.ld(en[h], ch.eg[h] + gn);
+                for (int h = 0; h < NH; h++) ch.ldm(en[h], ch.eg[h] + gn);
             }
             if (g > 0) {
                 // rcpp_alpha_forward_one_QUILT_faster (:671-707), normalize = true
@@ -352,10 +344,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             }
             if constexpr (!LEAN) {
 #pragma unroll
-                for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + gn);
+                for (int h = 0; h < NH; h++) ch.ldm(bt[h], ch.beta[h] + gn);
             }
             // ---- sample_reads_in_grid (:733-1295), three labels
             bool grid_started = false, changed = false;
+            int moved = 0;   // bit h: a move changed eMatGrid's column of label h (only those go back to memory)
             double pC[3] = {1, 1, 1};
             bool normal = false, ginit = false, pass = false;
             while (iRead < R) {
@@ -486,6 +479,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
 #pragma unroll
                             for (int i = 0; i < NE; i++) { a[h].v[i] *= rer.v[i]; ab[h].v[i] *= rer.v[i]; }
                             mul_e(h, rer);
+                            moved |= 1 << h;
                         }
                     }
 #pragma unroll
@@ -494,6 +488,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
 #pragma unroll
                             for (int i = 0; i < NE; i++) { a[h].v[i] *= er.v[i]; ab[h].v[i] *= er.v[i]; }
                             mul_e(h, er);
+                            moved |= 1 << h;
                         }
                     }
                     if (normal) {
@@ -521,7 +516,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             }
             if constexpr (LEAN) {   // the next grid's eMatGrid columns: e's registers are free (this grid's wait in LDS or are dead)
 #pragma unroll
-                for (int h = 0; h < NH; h++) ch.ld(e[h], ch.eg[h] + gn);
+                for (int h = 0; h < NH; h++) ch.ldm(e[h], ch.eg[h] + gn);
             }
             if (changed) {
                 // re-inject the moved columns and renormalise (:1262-1292)
@@ -533,12 +528,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
                     cg[h] *= alphaConst;
 #pragma unroll
                     for (int i = 0; i < NE; i++) a[h].v[i] = a[h].v[i] * alphaConst;
-                    if constexpr (LEAN) {   // from LDS to memory through the registers of alpha * beta, dead by now
+                    if ((moved >> h) & 1) {
+                        if constexpr (LEAN) {   // from LDS to memory through the registers of alpha * beta, dead by now
 #pragma unroll
-                        for (int i = 0; i < NE; i++) ab[h].v[i] = s_e[(h * NE + i) * NT + t];
-                        ch.st(ab[h], ch.eg[h] + (size_t)g * Ksp);
-                    } else {
-                        ch.st(e[h], ch.eg[h] + (size_t)g * Ksp);
+                            for (int i = 0; i < NE; i++) ab[h].v[i] = s_e[(h * NE + i) * NT + t];
+                            ch.stm(ab[h], ch.eg[h] + (size_t)g * Ksp);
+                        } else {
+                            ch.stm(e[h], ch.eg[h] + (size_t)g * Ksp);
+                        }
                     }
                 }
             }
@@ -546,11 +543,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
             // follows a segment -- the block pass's rate, hapProbs -- sees the state its last sweep leaves: only that one writes it
             if (it == p.it_end - 1) {
 #pragma unroll
-                for (int h = 0; h < NH; h++) ch.st(a[h], ch.alpha[h] + (size_t)g * Ksp);
+                for (int h = 0; h < NH; h++) ch.stm(a[h], ch.alpha[h] + (size_t)g * Ksp);
             }
             if constexpr (LEAN) {
 #pragma unroll
-                for (int h = 0; h < NH; h++) ch.ld(bt[h], ch.beta[h] + gn);
+                for (int h = 0; h < NH; h++) ch.ldm(bt[h], ch.beta[h] + gn);
             } else {
 #pragma unroll
                 for (int h = 0; h < NH; h++) e[h] = en[h];
@@ -560,7 +557,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(LEAN ? 
         gs.store_c(ch);
         if (rs_dirty) rs.store(ch);
         chain_sync<NW>();
-        backward_full(true);
+        backward_full(true, true);
         // ---- underflow check (:2959-2969): with ff != 0 the third label's c is not looked at
         {
             double s[2] = {0, 0};
