@@ -770,28 +770,32 @@ __global__ __launch_bounds__(256) void k_happrobs(GibbsParams p) {
             tot[0] += g0; tot[1] += g1;
             if (on) { acc[0] += g0; acc[1] += g1; }
         }
-    } else {
+    } else {   // three labels, written out like the two: a loop over a run-time label count indexes acc / tot dynamically (scratch)
         for (int k = part; k < Ks; k += 8) {
             const bool on = (s_w[k] >> b) & 1u;
-            for (int h = 0; h < p.nH; h++) {
-                const double gv = gk(h, k);
-                tot[h] += gv;
-                if (on) acc[h] += gv;
-            }
+            const double g0 = gk(0, k), g1 = gk(1, k), g2 = gk(2, k);
+            tot[0] += g0; tot[1] += g1; tot[2] += g2;
+            if (on) { acc[0] += g0; acc[1] += g1; acc[2] += g2; }
         }
     }
-    for (int h = 0; h < p.nH; h++) {
-        s_g[h][part][b] = acc[h];
-        if (b == 0) s_t[h][part] = tot[h];
+#pragma unroll
+    for (int h = 0; h < 3; h++) {
+        if (h < p.nH) {
+            s_g[h][part][b] = acc[h];
+            if (b == 0) s_t[h][part] = tot[h];
+        }
     }
     __syncthreads();
     if (part == 0 && b < nLocal) {
         double g1[3] = {0, 0, 0.0 * (1 - p.ref_error) + 0.0 * p.ref_error};
-        for (int h = 0; h < p.nH; h++) {
-            double on = 0, all = 0;
-            for (int q = 0; q < 8; q++) { on += s_g[h][q][b]; all += s_t[h][q]; }
-            const double off = all - on;  // sum over haplotypes whose bit is 0
-            g1[h] = on * (1 - p.ref_error) + off * p.ref_error;
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            if (h < p.nH) {
+                double on = 0, all = 0;
+                for (int q = 0; q < 8; q++) { on += s_g[h][q][b]; all += s_t[h][q]; }
+                const double off = all - on;  // sum over haplotypes whose bit is 0
+                g1[h] = on * (1 - p.ref_error) + off * p.ref_error;
+            }
         }
         const double g0 = g1[0], gB = g1[1], g2 = g1[2];
         double *hp = p.hapProbs + ((size_t)c * p.T + s + b) * 3;
