@@ -866,6 +866,7 @@ __global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
     const int cs = b < nLocal ? p.rc_common[snp] : -1;
     const bool rare = b < nLocal && cs < 0;
     const bool any = rare && ((p.rc_any[(size_t)c * p.rc_words + (snp >> 5)] >> (snp & 31)) & 1u);
+    const int nH = p.nH;
     double on[3] = {0, 0, 0};
     if (b < nLocal && rare && any && p.rc_pairs) {
         // the rows that carry this rare SNP, from the chain's (SNP, row) pairs of this grid: ascending in the row, so the partial
@@ -877,33 +878,42 @@ __global__ __launch_bounds__(256) void k_happrobs_rc(GibbsParams p) {
         for (int i = po[g]; i < po[g + 1]; i++) {
             const uint32_t e = pp[i];
             const int k = (int)(e & 1023u);
-            if ((int)(e >> 10) == b && (k & 7) == part)
-                for (int h = 0; h < p.nH; h++) on[h] += gam(h, k);
+            if ((int)(e >> 10) == b && (k & 7) == part) {
+#pragma unroll
+                for (int h = 0; h < 3; h++) if (h < nH) on[h] += gam(h, k);   // (compile-time label index: on[] stays in registers)
+            }
         }
     } else if (b < nLocal && (!rare || any)) {
         const int q = rare ? 0 : (cs >> 5) - cg, bit = cs & 31;
         for (int k = part; k < Ks; k += 8) {
             const bool alt = rare ? rare_has_alt(p, s_which[k], snp) : ((sw(q, k) >> bit) & 1u);
-            for (int h = 0; h < p.nH; h++) {
-                if (alt) on[h] += gam(h, k);
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+                if (h < nH && alt) on[h] += gam(h, k);
             }
         }
     }
     for (int h = 0; h < 3; h++) s_on[h][part][b] = on[h];
     if (b == 0) {   // the column total does not depend on the SNP
         double t[3] = {0, 0, 0};
-        for (int k = part; k < Ks; k += 8) for (int h = 0; h < p.nH; h++) t[h] += gam(h, k);
+        for (int k = part; k < Ks; k += 8) {
+#pragma unroll
+            for (int h = 0; h < 3; h++) if (h < nH) t[h] += gam(h, k);
+        }
         for (int h = 0; h < 3; h++) s_all[h][part] = t[h];
     }
     __syncthreads();
     if (part == 0 && b < nLocal) {
         double g1[3] = {0, 0, 0};
-        for (int h = 0; h < p.nH; h++) {
-            double o = 0, t = 0;
-            for (int q = 0; q < 8; q++) { o += s_on[h][q][b]; t += s_all[h][q]; }
-            if (!rare) g1[h] = o * (1 - p.ref_error) + (t - o) * p.ref_error;
-            else if (!any) g1[h] = p.ref_error;
-            else g1[h] = t * p.ref_error + o * (1 - 2 * p.ref_error);
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+            if (h < nH) {
+                double o = 0, t = 0;
+                for (int q = 0; q < 8; q++) { o += s_on[h][q][b]; t += s_all[h][q]; }
+                if (!rare) g1[h] = o * (1 - p.ref_error) + (t - o) * p.ref_error;
+                else if (!any) g1[h] = p.ref_error;
+                else g1[h] = t * p.ref_error + o * (1 - 2 * p.ref_error);
+            }
         }
         const double g0 = g1[0], gB = g1[1], g2 = g1[2];
         double *hp = p.hapProbs + ((size_t)c * p.T + snp) * 3;
