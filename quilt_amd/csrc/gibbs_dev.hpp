@@ -150,6 +150,37 @@ __device__ __forceinline__ void wsum2(double &a, double &b) {
     a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 31), __builtin_amdgcn_readlane(__double2loint(v), 31));
     b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// Three or four 64-lane sums in one 16-lane butterfly: v_permlane32_swap folds each value's halves (two values per register, as
+// in wsum2), v_permlane16_swap then puts one value's two 16-lane rows side by side with another's (row 0: a, row 1: c, row 2: b,
+// row 3: d after the add), and four row shifts finish all of them at once -- 27 / 29 instructions with the v_readlanes instead
+// of 42 / 44 (scripts/micro/permlane_sum4.hip checks the lane map on the device).  Order: (l, l + 32) pairs, then (l, l + 16)
+// pairs, then within 16-lane rows.
+__device__ __forceinline__ double fold32(double a, double b) {   // lanes 0..31: a(l) + a(l + 32); lanes 32..63: b(l - 32) + b(l)
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double fold16_rows(double ab, double cd) {   // rows of 16 lanes hold the partial sums of a, c, b, d
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(ab), __double2loint(cd), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(ab), __double2hiint(cd), false, false);
+    double v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    v += dpp_get<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_get<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_get<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_get<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row's total
+    return v;
+}
+__device__ __forceinline__ double lane_of(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ void wsum3(double &a, double &b, double &c) {
+    const double v = fold16_rows(fold32(a, b), fold32(c, c));
+    a = lane_of(v, 15); b = lane_of(v, 47); c = lane_of(v, 31);
+}
+__device__ __forceinline__ void wsum4(double &a, double &b, double &c, double &d) {
+    const double v = fold16_rows(fold32(a, b), fold32(c, d));
+    a = lane_of(v, 15); b = lane_of(v, 47); c = lane_of(v, 31); d = lane_of(v, 63);
+}
 __device__ __forceinline__ double wmax(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -505,10 +536,10 @@ struct Chain {
     // prefetches in flight on vmcnt must not be drained here, which __syncthreads() would do).
     template <int N>
     __device__ __forceinline__ void bsum(double (&x)[N]) {
-        if constexpr (N >= 2) wsum2(x[0], x[1]);
-        if constexpr (N == 4) wsum2(x[2], x[3]);
         if constexpr (N == 1) x[0] = wsum(x[0]);
-        if constexpr (N == 3) x[2] = wsum(x[2]);
+        if constexpr (N == 2) wsum2(x[0], x[1]);
+        if constexpr (N == 3) wsum3(x[0], x[1], x[2]);
+        if constexpr (N == 4) wsum4(x[0], x[1], x[2], x[3]);
         static_assert(N >= 1 && N <= 4, "bsum handles 1..4 values");
         if (NW == 1) return;
         double *buf = red + (size_t)par * NW * 4;
