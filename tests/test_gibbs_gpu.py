@@ -3,6 +3,7 @@
 Bar: sampled read labels and H_class IDENTICAL under the same uniforms; fp64 state (alpha, beta,
 eMatGrid, c) and hapProbs / genProbs within 1e-9 relative (only the order of the Ks-wide sums differs).
 """
+import os
 import numpy as np
 import pytest
 
@@ -445,3 +446,28 @@ def test_nipt_underflow_is_reported(small_panel, oracle):
     assert ref["status"] == 1, "the test input is meant to underflow"
     assert got["underflow_problem"]
     dev.close()
+
+
+def test_wave_sum_lane_maps_on_the_device(tmp_path):
+    """The samplers' two- and four-value wave sums rest on what v_permlane32_swap / v_permlane16_swap do with the lanes
+    (gibbs_dev.hpp: wsum2, wsum3, wsum4); scripts/micro/permlane_sum2.hip / permlane_sum4.hip state the expected lane of every
+    total and print what the device delivers."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("permlane_sum2", "permlane_sum4"):
+        exe = str(tmp_path / name)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", os.path.join(root, "scripts", "micro", name + ".hip"), "-o", exe],
+                       check=True, capture_output=True, timeout=300)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=60).stdout
+        if name == "permlane_sum4":
+            got = [float(v) for v in re.search(r"lanes 15 31 47 63 = (.*)", out).group(1).split()]
+            a, b, c, d = [float(v) for v in re.search(r"expected a b c d\s*= (.*)", out).group(1).split()]
+            assert got == [a, c, b, d], out   # rows 0..3 of the butterfly hold a, c, b, d
+        else:
+            m = re.search(r"lane31 (\S+) lane63 (\S+) ; expected sum\(a\) (\S+) sum\(b\) (\S+)", out)
+            assert float(m.group(1)) == float(m.group(3)) and float(m.group(2)) == float(m.group(4)), out
