@@ -807,13 +807,13 @@ __global__ void k_unpermute(const TS *src, double *dst, int K, int Kq, int NT, i
 // host side
 // ---------------------------------------------------------------------------------------------
 struct qa_panel::Scratch {
-    qa::ABuf<double> gl, c, dosage, escale0, unperm, emin, emin_b1, spill;
+    qa::ABuf<double> gl, c, dosage, escale0, unperm, emin, emin_b1, spill, fw_add, fw_xs;
     qa::ABuf<char> emat, esp, alpha, gamma, beta, beta_thin, top_val, mg, gsp;   // fp32 or fp64 elements (the launch decides)
     qa::ABuf<int32_t> thin_col, flags, alpha_slot, top_cnt, top_idx;
     qa::DBuf<int32_t> todo;   // (grid, pass) pairs handed to k_topk: persistent, grow-only
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     explicit Scratch(qa::Arena *a) {
-        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = emin_b1.arena = spill.arena = a;
+        gl.arena = c.arena = dosage.arena = escale0.arena = unperm.arena = emin.arena = emin_b1.arena = spill.arena = fw_add.arena = fw_xs.arena = a;
         emat.arena = esp.arena = alpha.arena = mg.arena = gsp.arena = gamma.arena = beta.arena = beta_thin.arena = top_val.arena = a;
         thin_col.arena = flags.arena = alpha_slot.arena = top_cnt.arena = top_idx.arena = a;
     }
@@ -1051,7 +1051,10 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     for (int p = 0; p < P; p++) {
         const int f = h_flags[p];
         size_t cols;
-        if (f & 15) {
+        if ((f & 15) && kind == KIND_F64_DOS) {   // every second column: k_bwd64d re-forms the odd grids' (PassParams::fw_add)
+            for (int g = 0; g < G; g += 2) slot[(size_t)p * G + g] = g / 2;
+            cols = (G + 1) / 2;
+        } else if (f & 15) {
             for (int g = 0; g < G; g++) slot[(size_t)p * G + g] = g;
             cols = G;
         } else {
@@ -1089,6 +1092,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     S.gsp.ensure(std::max<size_t>((size_t)P * pn->n_special, 1) * es);
     S.alpha.ensure((size_t)P * alpha_stride * es + ((size_t)1 << 20));   // (slack: k_bwd64d's idle lanes fetch a fixed line past a short column)
     S.c.ensure((size_t)P * G);
+    if (kind == KIND_F64_DOS) { S.fw_add.ensure((size_t)P * G); S.fw_xs.ensure((size_t)P * G); }
     S.mg.ensure((size_t)P * G * kMaxRow * (f64 ? 8 : 4));
     S.dosage.ensure((size_t)P * T);
     if (any_gamma) S.gamma.ensure((size_t)P * G * Kq * es);
@@ -1112,6 +1116,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.emin = S.emin.p; prm.emin_b1 = S.emin_b1.p; prm.esp_stride = (int)esp_stride;
 
     prm.spill = spill_stride ? S.spill.p : nullptr; prm.spill_pass_stride = spill_stride;
+    prm.fw_add = kind == KIND_F64_DOS ? S.fw_add.p : nullptr; prm.fw_xs = kind == KIND_F64_DOS ? S.fw_xs.p : nullptr;
     prm.emat = S.emat.p; prm.esp = S.esp.p; prm.escale0 = S.escale0.p; prm.alpha = S.alpha.p; prm.alpha_slot = S.alpha_slot.p;
     prm.alpha_pass_stride = alpha_stride; prm.Kq = Kq; prm.alpha_col_elems = alpha_col;
     prm.hist_unit = kind == KIND_F64_DOS ? 1.0 / 2251799813685248.0 /* 2^-51: k_bwd64d */ : 1.0 / kHistScale64; prm.c = S.c.p; prm.mg = S.mg.p; prm.gsp = S.gsp.p;

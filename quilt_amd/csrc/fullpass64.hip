@@ -380,8 +380,10 @@ __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
             else run_total = uniform(prev_sum / sig);   // (:1078-1088): every emission is 1, the sum is known
             cg = cg / sig;
         }
+        double xs_of_grid = 1.0;   // (for k_bwd64d, which re-forms the columns of the odd grids: PassParams::fw_add)
         if (g == 0 || prm.always_normalize || running_min < prm.norm_threshold || g == G - 1) {
             const double xs = 1 / run_total;
+            xs_of_grid = xs;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
 #pragma unroll
@@ -416,7 +418,13 @@ __global__ __launch_bounds__(kNT) void k_fwd64(PassParams prm, int n_last) {
             running_min = 1;
         }
         prev_sum = run_total;
-        if (tt == 0) L.sc[SC_C * 64 + jl] = cg;
+        if (tt == 0) {
+            L.sc[SC_C * 64 + jl] = cg;
+            if (prm.fw_add) {
+                prm.fw_add[(size_t)p * G + g] = addend;
+                prm.fw_xs[(size_t)p * G + g] = xs_of_grid;
+            }
+        }
         const int sl = (int)uniform(L.sc[SC_SLOT * 64 + jl]);
         if (sl >= 0) {   // a thinned grid: the column goes out as the reference stores it (:1109-1113)
             double2 *dst = aout + (size_t)sl * col_vecs;
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
 //     the order the waves reach them.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHistCopiesD = 8;
-constexpr int kNStreamD = 6;   // SC_SIG .. SC_C
+constexpr int kNStreamD = 7;   // SC_SIG .. SC_C, SC_TCOL (here: the forward pass's rescaling factor of the grid; SC_SLOT holds its addend)
 constexpr size_t kLdsFixedD = 2 * kMaxRow * 8 + 2 * 16 * 8 + kNStreamD * 64 * 8 + (size_t)kMaxRow * kHistCopiesD * 8;
 inline size_t lds_bytes_d(const Geo64 &g) { return kLdsFixedD + (g.NL > 0 ? ((size_t)(g.NL - 1) * kNT + g.n_last) * 128 : 0); }
 
@@ -831,6 +839,25 @@ __device__ __forceinline__ void special_gammas(const double (&x_before)[8], uint
     }
 }
 
+// alpha of half a chunk at an odd grid from the even grid's below it: k_fwd64's step (half_step<false>, special_half, the
+// rescaling) on the eight values
+__device__ __forceinline__ void reform_alpha(double2 (&a)[4], uint32_t w0, uint32_t w1, const double *et, const double *esp_at, bool sp,
+                                             double add, double xs) {
+    const uint32_t w[2] = {w0, w1};
+    int at = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t code = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+        double y = (((i & 1) ? a[i >> 1].y : a[i >> 1].x) + add) * et[code];
+        if (sp && code == 0) {
+            y *= esp_at[at];
+            at++;
+        }
+        y *= xs;
+        if (i & 1) a[i >> 1].y = y; else a[i >> 1].x = y;
+    }
+}
+
 template <int NR, int NL, bool SP = false>
 __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
     constexpr int NCH = NR + NL, NT = kNT, nwaves = NT >> 6;
@@ -851,6 +878,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
     unsigned long long *mg = static_cast<unsigned long long *>(prm.mg) + (size_t)p * G * kMaxRow;
     const double double_K = uniform((double)K);
     const bool last_row_wave = wave * 64 < n_last;   // the last chunk row holds n_last lanes only
+    const bool half_cols = prm.fw_add != nullptr;    // alpha handed over at the even grids only
 
     double b[NR][16];
 #pragma unroll
@@ -886,7 +914,8 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
         const bool real = SP || j < NCH - 1 || last_row_wave;   // (streamed geometry: every row is full)
         // (the codes' row pitch covers whole chunk rows: beyond K they are the zero padding, whose emission is 0)
         if (h == 0) d_nx = reinterpret_cast<const uint4 *>(prm.hm + (size_t)gq * prm.Kp + (size_t)j * kRowHaps)[tt];
-        const double2 *av = ain + (size_t)gq * col_vecs;
+        // (every second column handed over: grid gq's own when gq is even, else the one of grid gq - 1, from which process() re-forms it)
+        const double2 *av = ain + (size_t)(half_cols ? gq >> 1 : gq) * col_vecs;
 #pragma unroll
         for (int q = 0; q < 4; q++) a_nx[q] = av[real ? alpha_vec_index<8>(j, 4 * h + q, NT, tt) : (size_t)(q * 64 + (tt & 63))];
     };
@@ -895,7 +924,12 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
 
     // one pass over the state: gamma of grid gp (its alpha, its codes) into the histogram and, unless gp == 0, the update
     // with grid gp's emissions.  Returns this thread's share of sum(e * beta).
-    auto process = [&](auto emit_c, int gp, const double *et, const int32_t *sp_at, int sp_g, double v, double s, double fs) -> double {
+    // `recomp`: gp is an odd grid of a pass whose alpha was handed over at the even grids only -- the vectors fetched are grid
+    // gp - 1's, and grid gp's are re-formed from them as k_fwd64 formed them: (a + addend) * e[code], times the special's own
+    // emission, times the grid's rescaling factor (1 where the forward pass did not renormalise): the same operations on the
+    // same values in the same order, so the same bits.
+    auto process = [&](auto emit_c, int gp, const double *et, const int32_t *sp_at, int sp_g, double v, double s, double fs,
+                       bool recomp, double f_add, double f_xs) -> double {
         constexpr bool EMIT = decltype(emit_c)::value;
         const double scale = uniform(fs * 2251799813685248.0);   // sigma_gp * 2^51
         double psum = 0;
@@ -921,8 +955,9 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
             auto body = [&](double (&x)[8]) {
                 if (h == 0) n_sp = 0;
                 int at = 0;
+                if (sp) at = sp_at[k0 >> 4] + n_sp;   // position in the pass's (lazily padded) special-emission array
+                if (recomp) reform_alpha(a, w0, w1, et, esp + at, sp, f_add, f_xs);
                 if (sp) {
-                    at = sp_at[k0 >> 4] + n_sp;   // position in the pass's (lazily padded) special-emission array
                     if (on) special_gammas(x, w0, w1, v, a, gsp, at - 16 * sp_g, k0 + 8 * h, K);
                 }
                 half_step_dos<EMIT>(x, w0, w1, et, v, s, a, scale, hl, on);
@@ -980,8 +1015,9 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
                     }
                     if (h == 0) n_sp = 0;
                     int at = 0;
+                    if (sp) at = sp_at[k0 >> 4] + n_sp;
+                    if (recomp) reform_alpha(a, w0, w1, et, esp + at, sp, f_add, f_xs);
                     if (sp) {
-                        at = sp_at[k0 >> 4] + n_sp;
                         if (on) special_gammas(x, w0, w1, v, a, gsp, at - 16 * sp_g, k0 + 8 * h, K);
                     }
                     half_step_dos<EMIT>(x, w0, w1, et, v, s, a, scale, hl, on);
@@ -1025,6 +1061,10 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
                 L.sc[SC_EMIN * 64 + lane] = g1 == 1 ? prm.emin_b1[p] : emin[g1];   // of grid + 1 (grid 1: as the backward pass sees it)
                 L.sc[SC_SPG * 64 + lane] = (double)prm.sp_gidx[g1];        // of grid + 1
                 L.sc[SC_C * 64 + lane] = cvec[gi];
+                if (half_cols) {   // the forward pass's addend and rescaling factor, of grid + 1 (the grid process() handles)
+                    L.sc[SC_SLOT * 64 + lane] = prm.fw_add[(size_t)p * G + g1];
+                    L.sc[SC_TCOL * 64 + lane] = prm.fw_xs[(size_t)p * G + g1];
+                }
             }
             __syncthreads();
         }
@@ -1040,7 +1080,9 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
             const int sp_g = (int)uniform(L.sc[SC_SPG * 64 + jl]);
             const int32_t *sp_at = sp_g >= 0 ? prm.sp_chunk_at + (size_t)sp_g * (prm.Kq >> 4) : nullptr;
             const bool has_variant = uniform(L.sc[SC_EMIN * 64 + jl]) >= 0;
-            const double psum = process(std::true_type{}, g + 1, et, sp_at, sp_g, val_prev, x_prev, sig_prev);
+            const bool recomp = half_cols && ((g + 1) & 1);
+            const double f_add = half_cols ? uniform(L.sc[SC_SLOT * 64 + jl]) : 0.0, f_xs = half_cols ? uniform(L.sc[SC_TCOL * 64 + jl]) : 1.0;
+            const double psum = process(std::true_type{}, g + 1, et, sp_at, sp_g, val_prev, x_prev, sig_prev, recomp, f_add, f_xs);
             // (the table DMA is older than the 5 loads of the half chunk fetched ahead: wait for all but those)
             const double sum_e_times_b = block_sum64<5>(psum, L.red + (g & 1) * 16, wave, lane, nwaves);
             fold(g + 1);
@@ -1061,7 +1103,7 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
     {
         const int sp_g = prm.sp_gidx[0];
         const int32_t *sp_at = sp_g >= 0 ? prm.sp_chunk_at + (size_t)sp_g * (prm.Kq >> 4) : nullptr;
-        process(std::false_type{}, 0, L.etab, sp_at, sp_g, val_prev, x_prev, sig_prev);
+        process(std::false_type{}, 0, L.etab, sp_at, sp_g, val_prev, x_prev, sig_prev, false, 0.0, 1.0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

@@ -81,6 +81,10 @@ struct PassParams {
     // fp64 kernels of fullpass64.hip with K beyond their on-chip capacity (7 chunk rows of 8 192 haplotypes): the state of the
     // chunk rows past the seventh lives here, [P][rows][8][512] double2 (a row in the layout of an LDS row), read and written by
     // the thread that owns the elements once per grid
+    // fp64 dosage passes (k_fwd64 + k_bwd64d): alpha is handed over at every SECOND grid only (alpha_slot[g] = g / 2 for even g,
+    // -1 for odd g) and k_bwd64d re-forms an odd grid's column from the even grid's below it, repeating the forward step's
+    // operations with the grid's two scalars kept here: the addend and the rescaling factor (1 where the grid was not renormalised)
+    double *fw_add, *fw_xs;  // [P][G] or null (every column handed over)
     double *spill;
     size_t spill_pass_stride;  // doubles
 };
