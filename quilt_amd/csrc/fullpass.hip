@@ -841,7 +841,8 @@ thread_local double g_timing[6] = {0, 0, 0, 0, 0, 0};   // emat, forward, backwa
 // Three families of kernels run a pass:
 //   KIND_F32       fp32 state (k_fwd / k_bwd<float>): the dosage passes, any output
 //   KIND_F64_RANK  fp64 state, the reference's lazy normalisation, fused top-K (fullpass64.hip): best-haplotype lists only
-//   KIND_F64_DOS   fp64 state, the reference's lazy normalisation, alpha stored at every grid, gamma histogram for the dosage
+//   KIND_F64_DOS   fp64 state, the reference's lazy normalisation, alpha stored at every second grid (k_bwd64d re-forms the
+//                  others: PassParams::fw_add), gamma histogram for the dosage
 //                  (k_fwd64 + k_bwd64d, fullpass64.hip): the DOSAGE passes of qa_panel_set_dosage_precision(64)
 //   KIND_F64_FULL  fp64 state through the generic kernels (k_fwd / k_bwd<double>, one wave per SIMD): any output in
 //                  double (alphaHat_t / betaHat_t / gamma_t of the single-pass entry point in that mode); not tuned (it spills)
