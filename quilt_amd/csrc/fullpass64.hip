@@ -757,12 +757,15 @@ __global__ __launch_bounds__(kNT) void k_bwd64(PassParams prm, int n_last) {
 
 // ---------------------------------------------------------------------------------------------
 // backward of a DOSAGE pass with fp64 state (qa_panel_set_dosage_precision(64)): the reference's arithmetic throughout
-// (reference-single.cpp:1781-2179 with the lazily normalised alpha of k_fwd64, stored at EVERY grid), gamma = alpha * beta
-// histogrammed by haplotype code for k_dosage (:2083-2139).
+// (reference-single.cpp:1781-2179 with the lazily normalised alpha of k_fwd64), gamma = alpha * beta histogrammed by haplotype
+// code for k_dosage (:2083-2139).  Since the end of round 5 k_fwd64 hands alpha over at every SECOND grid (PassParams::fw_add):
+// at an odd grid this kernel fetches the column of the even grid below it and re-forms its own from it (reform_alpha: the forward
+// step is elementwise given the grid's two scalars, and the codes and the emission table it needs are the ones the beta update
+// decodes and gathers anyway) -- the forward kernel's operations on the forward kernel's values, the same bits.
 //
 // Bytes: 1 B code + 8 B alpha per cell -- with the forward's 1 + 8 the 18 K G of SURVEY.md 8(d) ("fp64 alpha as in the
-// reference").  At 0.8 GB of alpha per pass the kernel is bound by that stream (one pass per compute unit, 256 at a time:
-// 205 GB per launch), not by its arithmetic, so the structure differs from k_bwd64's:
+// reference"; the forward now writes half of its 8).  At 0.8 GB of alpha per pass the kernel is bound by that stream (one pass
+// per compute unit, 256 at a time: 205 GB per launch), not by its arithmetic, so the structure differs from k_bwd64's:
 //   * gamma of grid g is formed when the state is next touched anyway -- in the chunk loop that applies grid g's
 //     emissions (iteration g - 1), where beta_g = state + val is a by-product and the haplotype codes of grid g are already
 //     decoded for the emission look-up: one pass over the state per grid, one decode per cell.  Grid 0 gets an epilogue.

@@ -190,7 +190,7 @@ int fb64_chunks(int K);
 int fb64_spill_rows(int K);
 size_t fb64_lds_bytes(int K);
 void launch_fb64(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
-// the fp64-state DOSAGE passes: k_fwd64 storing every column + k_bwd64d (gamma histogram for k_dosage)
+// the fp64-state DOSAGE passes: k_fwd64 storing every second column + k_bwd64d (re-forms the others; gamma histogram for k_dosage)
 size_t fb64_alpha_col_elems(int K);
 size_t fb64_dos_lds_bytes(int K);
 void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mid);
