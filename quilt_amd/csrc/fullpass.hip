@@ -1224,7 +1224,9 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
         qa::profile_add(qa::PK_EMAT, g_timing[0], (double)P * T * 16.0 + (double)P * G * kMaxRow * es, at); at += g_timing[0];
         const int pk_f = kind == KIND_F32 ? qa::PK_FWD : kind == KIND_F64_RANK ? qa::PK_FWD64 : kind == KIND_F64_DOS ? qa::PK_FWD64D : qa::PK_FWD64G;
         const int pk_b = kind == KIND_F32 ? qa::PK_BWD : kind == KIND_F64_RANK ? qa::PK_BWD64 : kind == KIND_F64_DOS ? qa::PK_BWD64D : qa::PK_BWD64G;
-        qa::profile_add(pk_f, g_timing[1], per_dir, at); at += g_timing[1];
+        // (the fp64 dosage forward stores every second column: half of the state bytes; its backward reads each stored column twice)
+        const double per_dir_fwd = kind == KIND_F64_DOS ? cells_all * (1.0 + es * 0.5) : per_dir;
+        qa::profile_add(pk_f, g_timing[1], per_dir_fwd, at); at += g_timing[1];
         qa::profile_add(pk_b, g_timing[2], per_dir, at); at += g_timing[2];
         if (n_dos > 0) qa::profile_add(qa::PK_DOSAGE, g_timing[3], n_dos * G * kMaxRow * (f64 ? 8.0 : 4.0) + n_dos * T * 8.0, at);
         at += g_timing[3];
