@@ -153,11 +153,17 @@ int qa_panel_set_ranking_precision(qa_panel_t *panel, int32_t bits);
 int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits);
 
 /* VALIDATION MODE.  reference_order = 1: every full-panel pass of this handle (lists, dosage, alphaHat_t / betaHat_t / gamma_t)
- * runs on kernels that form each K-wide sum -- the forward column sum (reference-single.cpp:1002-1075), the backward
- * sum_e_times_b (:1899-1955), alpha(0)'s sum (:2349-2353), matched_gammas (:2083-2091) -- in the reference's own order:
- * the grid's special haplotypes first, then k = 0 .. K-1 one after the other, added by a single lane.  A floating-point sum in
- * a prescribed order does not parallelise, so this mode is 20-50x slower than the default (block-wide tree sums, whose last
- * bits differ from a sequential sum's).  Its purpose: on panels with many identical or exactly tied haplotypes the last bits of
+ * runs on kernels that form each K-wide sum in the order the reference's code adds it, by a single lane:
+ *   - the forward column sum run_total (reference-single.cpp:1002-1075), the backward sum_e_times_b (:1899-1955) and
+ *     matched_gammas / the dosage sums (:2083-2139) are explicit C++ loops: the grid's special haplotypes first, in list
+ *     order, then k = 0 .. K-1 one after the other;
+ *   - c(0) = 1 / sum(alphaHat_t_col) (:2347) is Armadillo's sum() of an arma::colvec, which without -ffast-math runs two
+ *     accumulators (arrayops::accumulate: even k into one, odd k into the other, acc1 + acc2) -- restated from Armadillo's
+ *     published source, which is not in the build image.  reference_order = 2 is the same mode with that one sum added
+ *     left to right instead (what this library did before round 6): a maintainer with R decides between 1 and 2 by
+ *     printing one c(0) at full precision (oracle/quilt_oracle.h, "Armadillo's sum()").
+ * A floating-point sum in a prescribed order does not parallelise, so this mode is 20-50x slower than the default (block-wide
+ * tree sums, whose last bits differ from either order's).  Its purpose: on panels with many identical or exactly tied haplotypes the last bits of
  * those sums decide which of the tied haplotypes make a best-haplotype list ("ties"); with this mode the
  * device reproduces the CPU path's lists, c, alpha / beta and dosage bit for bit, which proves the order of the sums to be the
  * only difference between the two.  K <= 57 344.  0 (default): the production kernels. */
@@ -219,11 +225,16 @@ typedef struct {
     int32_t K_top_matches;
     int32_t return_betaHat_t, return_dosage, return_gamma_t, return_gammaSmall_t;
     int32_t get_best_haps_from_thinned_sites;
-    int32_t always_normalize;     /* accepted; the device path always normalises per grid,
-                                     which the reference proves equivalent for dosage,
-                                     gamma and sum(log c) (test-unit-reference-single.R:588-642) */
+    int32_t always_normalize;     /* honoured by every pass with fp64 state (the ranking passes, the dosage passes of a handle
+                                     with qa_panel_set_dosage_precision(64), the validation mode): they follow the reference's
+                                     lazy normalisation, reference-single.cpp:1096-1107.  Passes with fp32 state always
+                                     normalise per grid, which the reference proves equivalent for dosage, gamma and
+                                     sum(log c) (test-unit-reference-single.R:588-642) */
     int32_t normalize_emissions;
-    double min_emission_prob_normalization_threshold; /* accepted, unused (see above) */
+    double min_emission_prob_normalization_threshold; /* honoured by the same passes: renormalise when the running product of the
+                                     per-grid minimum emissions falls below it.  Reference default 1e-100 (:2216); a value that
+                                     is not positive -- e.g. a zero-initialised struct -- is read as that default, because 0
+                                     would mean "never renormalise" and underflow to NaN dosages over a long region */
     int32_t suppressOutput;
 } qa_fullpass_opts_t;
 

@@ -5,6 +5,14 @@
  * QUILT/src/reference-single.cpp, in the reference's arithmetic order
  * (version 3 == version 2 arithmetic), use_eMatDH = TRUE.
  *
+ * ORDER OF THE K-WIDE SUMS, site by site.  run_total (:1002-1075), sum_e_times_b (:1899-1955), matched_gammas and the
+ * dosage sums (:2083-2139) are explicit C++ loops in the reference: the special haplotypes in list order, then
+ * k = 0 .. K-1, left to right -- restated as such.  c(0) = 1 / sum(alphaHat_t_col) (:2347) is Armadillo's sum() of an
+ * arma::colvec, i.e. arrayops::accumulate: even-indexed elements into one accumulator, odd-indexed ones into a second,
+ * acc1 + acc2 at the end (quilt_oracle.h says which Armadillo routine, why that cannot be observed in this image, and how
+ * a maintainer with R settles it from one printed c(0)).  Rounds 1-5 added that sum left to right as well and called it
+ * "the reference's order": it was this file's order.  qo_set_sum_order(1) restores it.
+ *
  * PIN: the reference cannot be built or run in this container (no R, Rcpp, Armadillo, Eigen) and its tests hold no golden
  * vectors, so this file is pinned by (1) oracle/rtwin.py -- an independent NumPy restatement of the reference's R twin of
  * this code (QUILT/R/reference-single.R:94-372), cross-checked by tests/golden/make_golden_rtwin.py and on every CPU run by
@@ -22,6 +30,10 @@
 /* ------------------------------------------------------------------------ */
 /* reference-single.cpp:68-94: rescale a (ref, alt) likelihood pair so that
  * its larger member is 1 and its smaller member is at least minGLValue. */
+int qo_sum_left_to_right = 0;
+void qo_set_sum_order(int left_to_right) { qo_sum_left_to_right = left_to_right ? 1 : 0; }
+int qo_get_sum_order(void) { return qo_sum_left_to_right; }
+
 void qo_make_gl_bound(double *gl, double minGLValue, const int *to_fix, int n_to_fix)
 {
     for (int i = 0; i < n_to_fix; i++) {
@@ -327,7 +339,9 @@ int qo_haploid_dosage_versus_refs(
             }
             alpha_col[k] = prob * one_over_K;
         }
-        for (int k = 0; k < K; k++) sum += alpha_col[k];
+        /* c(0) = 1 / sum(alphaHat_t_col) (:2347): an arma::colvec, i.e. arrayops::accumulate's two accumulators
+         * (quilt_oracle.h, "Armadillo's sum()") -- the one sum of the full pass that is not an explicit loop */
+        QO_ARMA_SUM(sum, K, k, alpha_col[k]);
         c[0] = 1 / sum;
         for (int k = 0; k < K; k++) alphaHat_t[k] = alpha_col[k] * c[0];
     }

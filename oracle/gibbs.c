@@ -1,7 +1,9 @@
 /*
  * oracle/gibbs.c -- CPU oracle (TEST INFRASTRUCTURE ONLY; see quilt_oracle.h).
  *
- * fp64 restatement, in the reference's operation order, of the small-panel Gibbs
+ * fp64 restatement, in the reference's operation order (its Ks-wide sums are Armadillo sum() calls: two accumulators, even
+ * and odd elements -- quilt_oracle.h lists the sites and states what is assumed about Armadillo, which is not in this
+ * image; qo_set_sum_order(1) restores the left-to-right sums of rounds 1-5), of the small-panel Gibbs
  * read-label sampler: QUILT/src/gibbs-nipt.cpp (rcpp_forwardBackwardGibbsNIPT and
  * its helpers), QUILT/src/gibbs-small.cpp (packed-panel emissions and
  * hapProbs/genProbs), QUILT/src/copied-from-stitch.cpp (haploid forward/backward)
@@ -148,10 +150,11 @@ void qo_evaluate_read_variability(const double *eMatRead_t, int Ks, int nReads,
 
 /* ---- haploid forward / backward (copied-from-stitch.cpp) ------------------- */
 
+/* sum() of an arma column (a .col() view or a colvec): arrayops::accumulate, two accumulators (quilt_oracle.h) */
 static double col_sum(const double *x, int n)
 {
-    double s = 0;
-    for (int i = 0; i < n; i++) s += x[i];
+    double s;
+    QO_ARMA_SUM(s, n, i, x[i]);
     return s;
 }
 
@@ -182,9 +185,9 @@ static void run_backward_haploid(double *beta, const double *c, const double *eM
     for (int g = G - 2; g >= 0; --g) {
         const double *e = eMatGrid + (size_t)Ks * (g + 1), *bn = beta + (size_t)Ks * (g + 1);
         double *b = beta + (size_t)Ks * g;
-        double s = 0;
+        double s;
         for (int k = 0; k < Ks; k++) etb[k] = e[k] * bn[k];
-        for (int k = 0; k < Ks; k++) s += am * etb[k];
+        QO_ARMA_SUM(s, Ks, k, am * etb[k]);   /* sum(alphaMatCurrent_tc.slice(s).col(iGrid) % e_times_b), :405 */
         double x = tm[2 * (size_t)g + 1] * s;
         for (int k = 0; k < Ks; k++) b[k] = c[g] * (x + tm[2 * (size_t)g] * etb[k]);
     }
@@ -309,13 +312,14 @@ static void sample_reads_in_grid(sweep_t *S, int *iRead_io, int g, int *done_rea
                 double *abC = ab + (size_t)Ks * h_rC, *abA1 = ab + (size_t)Ks * h_rA1;
                 double *abA2 = (nH == 3) ? ab + (size_t)Ks * h_rA2 : NULL;
                 if (cat == 0) {
-                    double s1 = 0, s2 = 0, s3 = 0;
-                    for (int k = 0; k < Ks; k++) s1 += abC[k] / er[k];
-                    for (int k = 0; k < Ks; k++) s2 += abA1[k] * er[k];
+                    /* sum(ab_m.col(h) / eMatRead_t_col), sum(ab_m.col(h) % eMatRead_t_col) (:909-912): accu_proxy_linear */
+                    double s1, s2, s3;
+                    QO_ARMA_SUM(s1, Ks, k, abC[k] / er[k]);
+                    QO_ARMA_SUM(s2, Ks, k, abA1[k] * er[k]);
                     pA1[h_rC] = s1;
                     pA1[h_rA1] = s2;
                     if (!S->sample_is_diploid) {
-                        for (int k = 0; k < Ks; k++) s3 += abA2[k] * er[k];
+                        QO_ARMA_SUM(s3, Ks, k, abA2[k] * er[k]);
                         pA2[h_rA2] = s3;
                     }
                 } else if (cat == 2) {
@@ -346,13 +350,13 @@ static void sample_reads_in_grid(sweep_t *S, int *iRead_io, int g, int *done_rea
             } else if (ginit) {
                 h_rC = 0; h_rA1 = 1; h_rA2 = 2;
                 for (int h = 0; h < 3; h++) pA1[h] = pA2[h] = pC[h];
-                double s1 = 0, s2 = 0, s3 = 0;
-                for (int k = 0; k < Ks; k++) s1 += ab[k] * er[k];
-                for (int k = 0; k < Ks; k++) s2 += ab[(size_t)Ks + k] * er[k];
+                double s1, s2, s3;   /* (:971-974) */
+                QO_ARMA_SUM(s1, Ks, k, ab[k] * er[k]);
+                QO_ARMA_SUM(s2, Ks, k, ab[(size_t)Ks + k] * er[k]);
                 pC[h_rC] = s1;
                 pA1[h_rA1] = s2;
                 if (!S->sample_is_diploid) {
-                    for (int k = 0; k < Ks; k++) s3 += ab[(size_t)2 * Ks + k] * er[k];
+                    QO_ARMA_SUM(s3, Ks, k, ab[(size_t)2 * Ks + k] * er[k]);
                     pA2[h_rA2] = s3;
                 }
             } else {
@@ -520,11 +524,11 @@ static void shard_block_gibbs_diploid(sweep_t *S, const double *runif_block /* G
         }
         if (g < G - 1) {
             const double *b1 = S->beta[0] + (size_t)Ks * g, *b2 = S->beta[1] + (size_t)Ks * g;
-            double s11 = 0, s22 = 0, s21 = 0, s12 = 0;
-            for (int k = 0; k < Ks; k++) s11 += a1[k] * b1[k];
-            for (int k = 0; k < Ks; k++) s22 += a2[k] * b2[k];
-            for (int k = 0; k < Ks; k++) s21 += a2[k] * b1[k];
-            for (int k = 0; k < Ks; k++) s12 += a1[k] * b2[k];
+            double s11, s22, s21, s12;   /* sum(alphaHat_t?.col(iGrid) % betaHat_t?.col(iGrid)), :2235-2238 */
+            QO_ARMA_SUM(s11, Ks, k, a1[k] * b1[k]);
+            QO_ARMA_SUM(s22, Ks, k, a2[k] * b2[k]);
+            QO_ARMA_SUM(s21, Ks, k, a2[k] * b1[k]);
+            QO_ARMA_SUM(s12, Ks, k, a1[k] * b2[k]);
             double pA1 = mlc1 + mloc1 + log(s11);
             double pA2 = mlc2 + mloc2 + log(s22);
             double pB1 = mlc2 + mloc1 + log(s21);
@@ -879,7 +883,8 @@ static void block_gibbs_resampler_nipt(sweep_t *S, double ff, const int32_t *blo
     double *log_cStore = (double *)calloc((size_t)18 * G, sizeof(double));    /* [ir][h][g] */
     double *eLocal = (double *)malloc(sizeof(double) * (size_t)3 * Ks);
     double logC_before[3] = {0, 0, 0}, logC_after[3] = {0, 0, 0};
-    for (int h = 0; h < 3; h++) for (int g = 0; g < G; g++) logC_after[h] += log(S->c[h][g]);
+    /* logC_after(h) = sum(log(c_h)) (:1819-1821): c_h is an arma::rowvec, log() an element-wise expression */
+    for (int h = 0; h < 3; h++) QO_ARMA_SUM(logC_after[h], G, g, log(S->c[h][g]));
     double sum_H[3] = {0, 0, 0};
     for (int r = 0; r < R; r++) sum_H[S->H[r] - 1] += 1;
     int ever_changed = 0;
@@ -913,8 +918,8 @@ static void block_gibbs_resampler_nipt(sweep_t *S, double ff, const int32_t *blo
                     double logC_inside = 0;
                     for (int g2 = grid_start; g2 <= grid_end; g2++) logC_inside += LC(ir, i, g2);
                     const double *a = AS(ir, i), *b = S->beta[i] + (size_t)Ks * g;
-                    double dot = 0;
-                    for (int k = 0; k < Ks; k++) dot += a[k] * b[k];
+                    double dot;   /* sum(alphaStore.slice(ir).col(i) % betaHatLocal.col(i)), :669 */
+                    QO_ARMA_SUM(dot, Ks, k, a[k] * b[k]);
                     Pm[ir][i] = log(dot) + -logC_before[i] + -logC_inside + -logC_after[i];
                     P[ir] += Pm[ir][i];
                 }
@@ -1038,8 +1043,8 @@ static void block_rate2(const sweep_t *S, double ff, double *rate2 /* G - 1 */)
             const double d = S->tm[2 * (size_t)g];
             const double *a = S->alpha[h] + (size_t)Ks * g, *b = S->beta[h] + (size_t)Ks * (g + 1);
             const double *e = S->eg[h] + (size_t)Ks * (g + 1);
-            double s = 0;
-            for (int k = 0; k < Ks; k++) s += a[k] * b[k] * e[k];
+            double s;   /* sum(alphaHat_t.col(iGrid) % betaHat_t.col(iGrid + 1) % eMatGrid_t.col(iGrid + 1)), :353-362 */
+            QO_ARMA_SUM(s, Ks, k, a[k] * b[k] * e[k]);
             rate2[g] += 1 - d * s;
         }
 }

@@ -35,6 +35,17 @@ def lib():
     return _LIB
 
 
+def set_sum_order(left_to_right: bool) -> None:
+    """How the oracle adds the sums the reference forms with Armadillo's ``sum()`` (quilt_oracle.h, "Armadillo's sum()"):
+    False (the default) = Armadillo's two accumulators over the even / odd elements; True = left to right, the form rounds 1-5
+    used.  Process-wide (a C global): tests that flip it restore it."""
+    lib().qo_set_sum_order(C.c_int(1 if left_to_right else 0))
+
+
+def get_sum_order() -> bool:
+    return bool(lib().qo_get_sum_order())
+
+
 def _p(a, ctype=None):
     if a is None:
         return None

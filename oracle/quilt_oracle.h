@@ -31,6 +31,63 @@
 extern "C" {
 #endif
 
+/* ---- Armadillo's sum() ------------------------------------------------------
+ *
+ * Wherever the reference writes sum(x) on a dense Armadillo vector (arma::colvec / arma::rowvec, a .col() view of an
+ * arma::mat) or on an element-wise expression of such vectors (x % y, x / y, log(x)), Armadillo does NOT add left to right.
+ * For a vector argument sum() is accu() (armadillo_bits/fn_sum.hpp: "resolves_to_vector" -> accu(X)), and
+ *   - accu() of a Mat / subview_col is arrayops::accumulate(mem, n_elem) (armadillo_bits/arrayops_meat.hpp),
+ *   - accu() of an element-wise expression is accu_proxy_linear(P)            (armadillo_bits/fn_accu.hpp),
+ * both of which, when the translation unit is NOT compiled with -ffast-math (__FINITE_MATH_ONLY__ unset: QUILT/src/Makevars
+ * has plain -O3) and without OpenMP (Makevars has no -fopenmp, so arma_config::openmp is false), run TWO accumulators:
+ *
+ *     acc1 = acc2 = 0;
+ *     for (i = 0, j = 1; j < n; i += 2, j += 2) { acc1 += x[i]; acc2 += x[j]; }
+ *     if (i < n) acc1 += x[i];                 // odd tail
+ *     return acc1 + acc2;
+ *
+ * i.e. the even-indexed elements are added in order into one chain, the odd-indexed ones into another, and the two chains
+ * meet once.  The compiler may not re-associate either chain, so this IS the arithmetic of those call sites.  Armadillo is
+ * not in this image: the form above is restated from the library's published source (the routine has had this shape since
+ * Armadillo 3.x through 14.x), not observed by running it.  Because that cannot be checked here, the left-to-right form
+ * that rounds 1-5 of this oracle used stays available behind qo_set_sum_order(1); a maintainer with R can tell which is
+ * right from ONE number printed at full precision -- c(0) of Rcpp_haploid_dosage_versus_refs (reference-single.cpp:2347)
+ * for any gl with K >= 3: print it with sprintf("%a") and compare with the oracle's two settings.
+ *
+ * Sites restated with QO_ARMA_SUM (every other accumulation of the reference on this path is an explicit C++ loop --
+ * run_total / sum_e_times_b / matched_gammas / minus_log_c*_sum / logC_inside, or Rcpp sugar's sum() on a NumericVector,
+ * e.g. choice_probs -- and stays left to right):
+ *   reference-single.cpp:2347                                             sum(alphaHat_t_col), grid 0 of the full pass
+ *   copied-from-stitch.cpp:367, 383, 405, 432, 435                        haploid forward / backward
+ *   gibbs-nipt.cpp:644, 655, 688, 700, 724, 854-857, 909-912, 971-974, 1270-1287   the sampler's K-wide sums
+ *   gibbs-nipt-block.cpp:353-362, 669, 915-920, 1226, 1245, 1819-1821, 2123-2131, 2235-2238   block / shard passes
+ * The R twins (oracle/rtwin.py) restate R code, whose sum() is neither: R accumulates left to right in a long double
+ * (src/main/summary.c: rsum, LDOUBLE) and rounds once at the end; rtwin.py says so where it sums.
+ */
+void qo_set_sum_order(int left_to_right);   /* 0 (default): Armadillo's two accumulators; 1: left to right (rounds 1-5) */
+int qo_get_sum_order(void);
+extern int qo_sum_left_to_right;
+
+/* out = sum over I = 0 .. n-1 of EXPR (an expression in I), in the order Armadillo's accu() adds it */
+#define QO_ARMA_SUM(out, n, I, EXPR)                                                   \
+    do {                                                                               \
+        double qo_acc1_ = 0, qo_acc2_ = 0;                                             \
+        int I = 0;                                                                     \
+        const int qo_n_ = (n);                                                         \
+        if (qo_sum_left_to_right) {                                                    \
+            for (; I < qo_n_; I++) qo_acc1_ += (EXPR);                                 \
+        } else {                                                                       \
+            while (I + 1 < qo_n_) {                                                    \
+                qo_acc1_ += (EXPR);                                                    \
+                I++;                                                                   \
+                qo_acc2_ += (EXPR);                                                    \
+                I++;                                                                   \
+            }                                                                          \
+            if (I < qo_n_) qo_acc1_ += (EXPR);                                         \
+        }                                                                              \
+        (out) = qo_acc1_ + qo_acc2_;                                                   \
+    } while (0)
+
 /* ---- small helpers ------------------------------------------------------ */
 
 /* reference-single.cpp:68-94 */

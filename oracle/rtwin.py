@@ -28,10 +28,30 @@ terms) -- is the strongest pin available in a container without R.
 generates the committed fixtures from THIS file and cross-checks oracle/*.c against it.
 
 Plain numpy, loops over grids and reads (small cases only).  Never imported by the product.
+
+SUMS.  Every sum()/colSums()/rowSums() of the R text is `_rsum` here: R adds left to right in a long double and rounds once
+(src/main/summary.c rsum / array.c, LDOUBLE).  That is a THIRD order beside the C++'s two -- explicit loops (left to right in
+double) and Armadillo's sum() (two accumulators over even / odd elements: oracle/quilt_oracle.h) -- so the twins agree with
+oracle/*.c to rounding (the tolerances of tests/golden/make_golden_rtwin.py), never bit for bit, exactly as R's twins agree
+with the package's C++ in the reference's own tests (expect_equal, tolerance 1.5e-8).
 """
 from __future__ import annotations
 
 import numpy as np
+
+
+def _rsum(x, axis=None):
+    """R's sum() / colSums() / rowSums(): NOT numpy's pairwise tree and NOT Armadillo's two accumulators (oracle/quilt_oracle.h)
+    -- R adds left to right in a long double (src/main/summary.c: rsum, LDOUBLE; src/main/array.c for colSums / rowSums) and
+    rounds to double once at the end.  np.cumsum is a sequential recurrence, and np.longdouble is the x87 80-bit type on this
+    platform, which is what LDOUBLE is on x86-64 Linux builds of R."""
+    x = np.asarray(x)
+    if x.dtype.kind in "biu":
+        return x.sum(axis=axis)
+    if axis is None:
+        x = x.ravel(order="F")
+        return np.float64(np.cumsum(x, dtype=np.longdouble)[-1]) if x.size else np.float64(0.0)
+    return np.cumsum(x, axis=axis, dtype=np.longdouble).take(-1, axis=axis).astype(np.float64)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -68,7 +88,7 @@ def make_gl_from_u_bq(u, bq, nSNPs, minGLValue=1e-10):
     for i in range(len(u)):
         gl[:, u[i]] = gl[:, u[i]] * probs[i]
     if minGLValue > 0:
-        for t in np.nonzero((gl < minGLValue).sum(axis=0) > 0)[0]:
+        for t in np.nonzero(_rsum((gl < minGLValue), axis=0) > 0)[0]:
             a, b = gl[0, t], gl[1, t]
             if a > b:
                 gl[0, t], gl[1, t] = 1.0, max(b / a, minGLValue)
@@ -137,21 +157,21 @@ def R_haploid_dosage_versus_refs(panel, gl, gammaSmall_cols_to_get=None, K_top_m
     c = np.ones(G)
     emis = [_emission_column(panel, gl, g) for g in range(G)]
     alpha[:, 0] = emis[0] * (1 / K)
-    c[0] = 1 / alpha[:, 0].sum()
+    c[0] = 1 / _rsum(alpha[:, 0])
     alpha[:, 0] *= c[0]
     running = 1.0
     for g in range(1, G):
         jump_prob = tm[1, g - 1] / K
-        jump_prob_plus = jump_prob if always_normalize else jump_prob * alpha[:, g - 1].sum()
+        jump_prob_plus = jump_prob if always_normalize else jump_prob * _rsum(alpha[:, g - 1])
         not_jump_prob = tm[0, g - 1]
         alpha[:, g] = (jump_prob_plus + not_jump_prob * alpha[:, g - 1]) * emis[g]
         if always_normalize:
-            c[g] = 1 / alpha[:, g].sum()
+            c[g] = 1 / _rsum(alpha[:, g])
             alpha[:, g] *= c[g]
         else:
             running *= min(1.0, emis[g].min())
             if g == G - 1 or running < min_emission_prob_normalization_threshold:
-                c[g] = 1 / alpha[:, g].sum()
+                c[g] = 1 / _rsum(alpha[:, g])
                 alpha[:, g] *= c[g]
                 running = 1.0
     beta = np.zeros((K, G))
@@ -164,7 +184,7 @@ def R_haploid_dosage_versus_refs(panel, gl, gammaSmall_cols_to_get=None, K_top_m
             jump_prob = tm[1, g] / K
             not_jump_prob = tm[0, g]
             e_times_b = bcol * emis[g + 1]
-            bcol = not_jump_prob * e_times_b + jump_prob * e_times_b.sum()
+            bcol = not_jump_prob * e_times_b + jump_prob * _rsum(e_times_b)
         if gammaSmall_cols_to_get is not None and gammaSmall_cols_to_get[g] >= 0:
             best[int(gammaSmall_cols_to_get[g])] = get_top_K_or_more_matches(alpha[:, g], bcol, K_top_matches)
         gcol = alpha[:, g] * bcol
@@ -262,13 +282,13 @@ def _forward_haploid(eMatGrid, tm, K, initialize_only=False):
     alpha = np.ones((K, G)) if initialize_only else np.zeros((K, G))
     c = np.ones(G) if initialize_only else np.zeros(G)
     alpha[:, 0] = (1 / K) * eMatGrid[:, 0]
-    c[0] = 1 / alpha[:, 0].sum()
+    c[0] = 1 / _rsum(alpha[:, 0])
     alpha[:, 0] *= c[0]
     if initialize_only:
         return alpha, c
     for t in range(1, G):
-        alpha[:, t] = eMatGrid[:, t] * (tm[0, t - 1] * alpha[:, t - 1] + tm[1, t - 1] * alpha[:, t - 1].sum() * (1 / K))
-        c[t] = 1 / alpha[:, t].sum()
+        alpha[:, t] = eMatGrid[:, t] * (tm[0, t - 1] * alpha[:, t - 1] + tm[1, t - 1] * _rsum(alpha[:, t - 1]) * (1 / K))
+        c[t] = 1 / _rsum(alpha[:, t])
         alpha[:, t] *= c[t]
     return alpha, c
 
@@ -279,7 +299,7 @@ def _backward_haploid(beta, c, eMatGrid, tm, K):
     G = eMatGrid.shape[1]
     for t in range(G - 2, -1, -1):
         e_times_b = eMatGrid[:, t + 1] * beta[:, t + 1]
-        beta[:, t] = c[t] * (tm[1, t] * e_times_b.sum() * (1 / K) + tm[0, t] * e_times_b)
+        beta[:, t] = c[t] * (tm[1, t] * _rsum(e_times_b) * (1 / K) + tm[0, t] * e_times_b)
     return beta
 
 
@@ -336,18 +356,18 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use_1based, H_start, r
             g = iGrid - 1
             for h in range(3):
                 if iGrid > 1:   # alpha_forward_one, then the previous normalisation and the new one (:567-586)
-                    al[h][:, g] = eg[h][:, g] * (tm[0, g - 1] * al[h][:, g - 1] + al[h][:, g - 1].sum() * tm[1, g - 1] * (1 / K))
+                    al[h][:, g] = eg[h][:, g] * (tm[0, g - 1] * al[h][:, g - 1] + _rsum(al[h][:, g - 1]) * tm[1, g - 1] * (1 / K))
                     al[h][:, g] *= cc[h][g]
-                    a = 1 / al[h][:, g].sum()
+                    a = 1 / _rsum(al[h][:, g])
                     cc[h][g] *= a
                     al[h][:, g] *= a
                 else:           # rcpp_reinitialize_in_iterations
                     al[h][:, 0] = (1 / K) * eg[h][:, 0]
-                    cc[h][0] = 1 / al[h][:, 0].sum()
+                    cc[h][0] = 1 / _rsum(al[h][:, 0])
                     al[h][:, 0] *= cc[h][0]
             alphaHat_m = np.stack([al[h][:, g] for h in range(3)])
             betaHat_m = np.stack([be[h][:, g] for h in range(3)])
-            pC = (alphaHat_m * betaHat_m).sum(axis=1)
+            pC = _rsum((alphaHat_m * betaHat_m), axis=1)
             while iRead < R and wif1[iRead] == iGrid:
                 iRead += 1   # now the 1-based index of the read being processed
                 r = iRead - 1
@@ -373,30 +393,30 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use_1based, H_start, r
                         pA1, pA2 = pC.copy(), pC.copy()
                         ab = alphaHat_m * betaHat_m
                         if read_category[r] == 0:
-                            pA1[h_rC - 1] = (ab[h_rC - 1] / er).sum()
-                            pA1[h_rA1 - 1] = (ab[h_rA1 - 1] * er).sum()
-                            pA2[h_rA2 - 1] = (ab[h_rA2 - 1] * er).sum()
+                            pA1[h_rC - 1] = _rsum((ab[h_rC - 1] / er))
+                            pA1[h_rA1 - 1] = _rsum((ab[h_rA1 - 1] * er))
+                            pA2[h_rA2 - 1] = _rsum((ab[h_rA2 - 1] * er))
                         elif read_category[r] == 1:
                             pass   # (NIPT only) nothing to add or remove: the emission is 1 for every haplotype
                         elif read_category[r] == 2:
                             w = non1[r]
                             v = er[w[-1]]
-                            pA1[h_rC - 1] += ab[h_rC - 1, w].sum() * (1 / v - 1)
-                            pA1[h_rA1 - 1] += ab[h_rA1 - 1, w].sum() * (v - 1)
-                            pA2[h_rA2 - 1] += ab[h_rA2 - 1, w].sum() * (v - 1)
+                            pA1[h_rC - 1] += _rsum(ab[h_rC - 1, w]) * (1 / v - 1)
+                            pA1[h_rA1 - 1] += _rsum(ab[h_rA1 - 1, w]) * (v - 1)
+                            pA2[h_rA2 - 1] += _rsum(ab[h_rA2 - 1, w]) * (v - 1)
                         else:
                             w = non1[r]
-                            pA1[h_rC - 1] += (ab[h_rC - 1, w] * (1 / er[w] - 1)).sum()
-                            pA1[h_rA1 - 1] += (ab[h_rA1 - 1, w] * (er[w] - 1)).sum()
-                            pA2[h_rA2 - 1] += (ab[h_rA2 - 1, w] * (er[w] - 1)).sum()
+                            pA1[h_rC - 1] += _rsum((ab[h_rC - 1, w] * (1 / er[w] - 1)))
+                            pA1[h_rA1 - 1] += _rsum((ab[h_rA1 - 1, w] * (er[w] - 1)))
+                            pA2[h_rA2 - 1] += _rsum((ab[h_rA2 - 1, w] * (er[w] - 1)))
                         pA2[h_rC - 1] = pA1[h_rC - 1]
                     elif ginit:
                         h_rC, h_rA1, h_rA2 = 1, 2, 3
                         pA1, pA2 = pC.copy(), pC.copy()
                         ab = alphaHat_m * betaHat_m
-                        pC[0] = (ab[0] * er).sum()
-                        pA1[1] = (ab[1] * er).sum()
-                        pA2[2] = (ab[2] * er).sum()
+                        pC[0] = _rsum((ab[0] * er))
+                        pA1[1] = _rsum((ab[1] * er))
+                        pA2[2] = _rsum((ab[2] * er))
                     else:
                         h_rC, h_rA1, h_rA2 = 1, 2, 3
                         pA1, pA2 = pC.copy(), pC.copy()
@@ -428,13 +448,13 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use_1based, H_start, r
                             if h_rN == 3:
                                 pC = pA2.copy()
                     x = np.array([norm[1], norm[2], norm[3]])
-                    y = np.abs(rlc - x[None, :]).sum(axis=1)
+                    y = _rsum(np.abs(rlc - x[None, :]), axis=1)
                     with np.errstate(invalid="ignore"):
                         m = np.nanmin(y)
                     H_class[r] = (int(np.nanargmin(y)) + 1) if m < class_sum_cutoff else 0
             for h in range(3):   # inject back and renormalise (:903-916)
                 al[h][:, g] = alphaHat_m[h]
-                a = 1 / al[h][:, g].sum()
+                a = 1 / _rsum(al[h][:, g])
                 cc[h][g] *= a
                 al[h][:, g] *= a
         for h in range(3):
@@ -566,8 +586,8 @@ def R_define_blocked_snps_using_gamma_on_the_fly(al, be, cc, eg, tm, shuffle_bin
     diff2 = np.zeros((3, nGrids - 1))
     for iGrid in range(nGrids - 2):
         for h in range(3 if ff != 0 else 2):
-            diff2[h, iGrid] = 1 - (tm[0, iGrid] * (al[h][:, iGrid] * be[h][:, iGrid + 1] * eg[h][:, iGrid + 1])).sum()
-    rate2 = diff2.sum(axis=0)
+            diff2[h, iGrid] = 1 - _rsum((tm[0, iGrid] * (al[h][:, iGrid] * be[h][:, iGrid + 1] * eg[h][:, iGrid + 1])))
+    rate2 = _rsum(diff2, axis=0)
     smoothed_rate = make_smoothed_rate(rate2, L_grid, shuffle_bin_radius)
     break_thresh = 1.0
     d = simple_quantile(smoothed_rate, block_gibbs_quantile_prob)
@@ -578,10 +598,10 @@ def R_define_blocked_snps_using_gamma_on_the_fly(al, be, cc, eg, tm, shuffle_bin
     available = smoothed_rate > break_thresh          # the C++ rule (see the docstring)
     agree = bool(np.array_equal(available, available_R))
     blocked_grid = np.zeros(nGrids, dtype=np.int64)
-    if available.sum() == 0:
+    if _rsum(available) == 0:
         return dict(blocked_snps=np.zeros(len(grid), dtype=np.int64), blocked_grid=blocked_grid, smoothed_rate=smoothed_rate,
                     break_thresh=break_thresh, available_rules_agree=agree)
-    nAvailable = int(available.sum())
+    nAvailable = int(_rsum(available))
     best = np.argsort(-smoothed_rate, kind="stable")[:nAvailable]   # R's order(decreasing = TRUE) keeps ties in place
     available = available.copy()
     to_keep = []
@@ -590,7 +610,7 @@ def R_define_blocked_snps_using_gamma_on_the_fly(al, be, cc, eg, tm, shuffle_bin
         if available[snp_best]:
             a = max(snp_best - 1, 0)
             b = min(snp_best + 1, nGrids - 2)
-            if int(available[a:b + 1].sum()) == 3:
+            if int(_rsum(available[a:b + 1])) == 3:
                 snp_left = determine_where_to_stop(smoothed_rate, available, snp_best, break_thresh, nGrids, True)
                 snp_right = determine_where_to_stop(smoothed_rate, available, snp_best, break_thresh, nGrids, False)
                 available[snp_left:snp_right + 1] = False
@@ -732,7 +752,7 @@ def R_block_gibbs_resampler(al, be, cc, eg, H, H_class, eMatRead_t, blocked_snps
     prior_probs = np.array([0.5, (1 - ff) / 2, ff / 2])
     logC_before = np.zeros(3)
     with np.errstate(divide="ignore"):
-        logC_after = np.array([np.log(cc[h]).sum() for h in range(3)])
+        logC_after = np.array([_rsum(np.log(cc[h])) for h in range(3)])
     ever_changed = 0
     alphaStore = np.zeros((K, 3, 6))
     log_cStore = np.zeros((nGrids, 3, 6))
@@ -748,7 +768,7 @@ def R_block_gibbs_resampler(al, be, cc, eg, H, H_class, eMatRead_t, blocked_snps
                     alphaStore[:, h, ir] = (1 / K) * eLocal[:, i]
                 else:
                     alphaStore[:, h, ir] = eLocal[:, i] * (tm[0, g - 1] * alphaStore[:, h, ir] + tm[1, g - 1] * (1 / K))
-                d = 1 / alphaStore[:, h, ir].sum()
+                d = 1 / _rsum(alphaStore[:, h, ir])
                 log_cStore[g, h, ir] = np.log(d)
                 alphaStore[:, h, ir] = d * alphaStore[:, h, ir]
         if con["grid_where"][g] > -1:
@@ -764,7 +784,7 @@ def R_block_gibbs_resampler(al, be, cc, eg, H, H_class, eMatRead_t, blocked_snps
                         logC_inside = 0.0
                         for g2 in range(gs, ge + 1):
                             logC_inside = logC_inside + log_cStore[g2, i, ir]
-                        P[ir] = P[ir] + (np.log((alphaStore[:, i, ir] * betaLocal[:, i]).sum()) + -logC_before[i] + -logC_inside +
+                        P[ir] = P[ir] + (np.log(_rsum((alphaStore[:, i, ir] * betaLocal[:, i]))) + -logC_before[i] + -logC_inside +
                                          -logC_after[i])
                 Hterm = _block_read_label_probabilities_using_H_class(rs, re, H_class, ff)
                 clp = P + Hterm
@@ -774,7 +794,7 @@ def R_block_gibbs_resampler(al, be, cc, eg, H, H_class, eMatRead_t, blocked_snps
                 probs[np.isnan(probs)] = 0
                 if ff == 0:
                     probs[[1, 3, 4, 5]] = 0
-                probs = probs / probs.sum()
+                probs = probs / _rsum(probs)
             chance = runif_block[iBlock]
             cum = np.cumsum(probs)
             ir_chosen = 0
@@ -807,7 +827,7 @@ def R_block_gibbs_resampler(al, be, cc, eg, H, H_class, eMatRead_t, blocked_snps
                         else:
                             al[h][:, iGrid2 - 1] = eg[h][:, iGrid2 - 1] * (tm[0, iGrid2 - 2] * al[h][:, iGrid2 - 2] +
                                                                              tm[1, iGrid2 - 2] * (1 / K))
-                        cc[h][iGrid2 - 1] = 1 / al[h][:, iGrid2 - 1].sum()
+                        cc[h][iGrid2 - 1] = 1 / _rsum(al[h][:, iGrid2 - 1])
                         al[h][:, iGrid2 - 1] = cc[h][iGrid2 - 1] * al[h][:, iGrid2 - 1]
                 for iRead0 in range(rs, re + 1):
                     H_class[iRead0] = one_based_swap[H_class[iRead0]] - 1
@@ -845,7 +865,7 @@ def sample_H_using_H_class(H_class, ff, u):
         if hc in (1, 2, 3):
             H[r] = hc
             continue
-        p = table[hc] / table[hc].sum()
+        p = table[hc] / _rsum(table[hc])
         order = np.argsort(-p, kind="stable")
         mass, pick = 0.0, order[-1]
         for j in order:
@@ -874,7 +894,7 @@ def R_shard_block_gibbs_resampler(al, be, cc, eg, H, wif0, tm, K, runif):
         if iGrid == 0:
             for h in range(2):
                 al[h][:, 0] = (1 / K) * eg[h][:, 0]
-                cc[h][0] = 1 / al[h][:, 0].sum()
+                cc[h][0] = 1 / _rsum(al[h][:, 0])
                 al[h][:, 0] = al[h][:, 0] * cc[h][0]
                 minus_log_c_sum[h] = minus_log_c_sum[h] - np.log(cc[h][0])
         else:
@@ -884,9 +904,9 @@ def R_shard_block_gibbs_resampler(al, be, cc, eg, H, wif0, tm, K, runif):
                 eg[1][:, iGrid] = x
             for h in range(2):   # alpha_forward_one, the previous normalisation, the new one (:3143-3159)
                 al[h][:, iGrid] = eg[h][:, iGrid] * (tm[0, iGrid - 1] * al[h][:, iGrid - 1] +
-                                                      al[h][:, iGrid - 1].sum() * tm[1, iGrid - 1] * (1 / K))
+                                                      _rsum(al[h][:, iGrid - 1]) * tm[1, iGrid - 1] * (1 / K))
                 al[h][:, iGrid] = al[h][:, iGrid] * cc[h][iGrid]
-                a = 1 / al[h][:, iGrid].sum()
+                a = 1 / _rsum(al[h][:, iGrid])
                 cc[h][iGrid] = cc[h][iGrid] * a
                 al[h][:, iGrid] = al[h][:, iGrid] * a
                 minus_log_c_sum[h] = minus_log_c_sum[h] - np.log(cc[h][iGrid])
@@ -897,14 +917,14 @@ def R_shard_block_gibbs_resampler(al, be, cc, eg, H, wif0, tm, K, runif):
         if iGrid < nGrids - 1:
             w1 = slice(0, iGrid + 1)
             w2 = slice(iGrid, nGrids)
-            mlo = [-np.log(original_c[h][w2]).sum() for h in range(2)]   # (the R carries these as running sums: the same terms)
-            pA1 = minus_log_c_sum[0] + mlo[0] + np.log((al[0][:, iGrid] * be[0][:, iGrid]).sum())
-            pA2 = -np.log(cc[1][w1]).sum() - np.log(original_c[1][w2]).sum() + np.log((al[1][:, iGrid] * be[1][:, iGrid]).sum())
-            pB1 = -np.log(cc[1][w1]).sum() - np.log(original_c[0][w2]).sum() + np.log((al[1][:, iGrid] * be[0][:, iGrid]).sum())
-            pB2 = -np.log(cc[0][w1]).sum() - np.log(original_c[1][w2]).sum() + np.log((al[0][:, iGrid] * be[1][:, iGrid]).sum())
+            mlo = [-_rsum(np.log(original_c[h][w2])) for h in range(2)]   # (the R carries these as running sums: the same terms)
+            pA1 = minus_log_c_sum[0] + mlo[0] + np.log(_rsum((al[0][:, iGrid] * be[0][:, iGrid])))
+            pA2 = -_rsum(np.log(cc[1][w1])) - _rsum(np.log(original_c[1][w2])) + np.log(_rsum((al[1][:, iGrid] * be[1][:, iGrid])))
+            pB1 = -_rsum(np.log(cc[1][w1])) - _rsum(np.log(original_c[0][w2])) + np.log(_rsum((al[1][:, iGrid] * be[0][:, iGrid])))
+            pB2 = -_rsum(np.log(cc[0][w1])) - _rsum(np.log(original_c[1][w2])) + np.log(_rsum((al[0][:, iGrid] * be[1][:, iGrid])))
             calculated_difference = (pB1 + pB2) - (pA1 + pA2)
             probs = np.array([1.0, np.exp(calculated_difference)])
-            probs = probs / probs.sum()
+            probs = probs / _rsum(probs)
             in_flip_mode = bool(runif[iGrid] > probs[0])
             flips.append(in_flip_mode)
             p_stay.append(probs[0])

@@ -1114,6 +1114,7 @@ int run_passes(qa_panel *pn, int P, const double *gl, const int32_t *h_flags, co
     prm.P = P; prm.gl = S.gl.p; prm.thin_col = S.thin_col.p; prm.n_thin = n_thin; prm.flags = S.flags.p;
     prm.normalize_emissions = normalize_emissions;
     prm.lazy = lazy ? 1 : 0; prm.always_normalize = always_normalize; prm.norm_threshold = norm_threshold;
+    prm.grid0_left_to_right = pn->sum_order_grid0_ltr ? 1 : 0;
     prm.emin = S.emin.p; prm.emin_b1 = S.emin_b1.p; prm.esp_stride = (int)esp_stride;
 
     prm.spill = spill_stride ? S.spill.p : nullptr; prm.spill_pass_stride = spill_stride;
@@ -1380,6 +1381,10 @@ int qa_Rcpp_haploid_dosage_versus_refs(
         qa::set_error("qa_Rcpp_haploid_dosage_versus_refs: null argument");
         return QA_ERR_INVALID;
     }
+    // A C caller that zero-initialises the options would ask the lazily normalised fp64 passes never to renormalise between
+    // grid 0 and the last grid: alpha underflows over a long region, 1 / run_total = inf, NaN dosages.  A threshold that is not
+    // positive (or NaN) is therefore read as "not set" = the reference's default (reference-single.cpp:2216, 1e-100).
+    const double norm_threshold = o->min_emission_prob_normalization_threshold > 0 ? o->min_emission_prob_normalization_threshold : 1e-100;
     return qa::guarded([&] {
         qa::GateHold hold;
         hold.acquire(panel->gate(), &panel->arena);
@@ -1434,7 +1439,7 @@ int qa_Rcpp_haploid_dosage_versus_refs(
             const int32_t f1 = 1;
             plan(KIND_F64_DOS, f1);
             st = run_passes(panel, 1, gl, &f1, no_thin.data(), 0, o->normalize_emissions, out, KIND_F64_DOS,
-                            o->always_normalize, o->min_emission_prob_normalization_threshold);
+                            o->always_normalize, norm_threshold);
             if (st == QA_OK && want_lists) {
                 BatchOut out2;
                 out2.lists = &lists;
@@ -1442,7 +1447,7 @@ int qa_Rcpp_haploid_dosage_versus_refs(
                 const PassKind rk = panel->rank_fp64 ? rank_kind(panel) : KIND_F32;
                 plan(rk, 0);
                 st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, rk,
-                                o->always_normalize, o->min_emission_prob_normalization_threshold);
+                                o->always_normalize, norm_threshold);
             }
         } else if (want_lists && panel->rank_fp64 && only_thin) {
             // only the lists (and alpha at the thinned grids, c): the fp64 ranking pass, which follows the reference's
@@ -1450,7 +1455,7 @@ int qa_Rcpp_haploid_dosage_versus_refs(
             out.lists = &lists;
             plan(rank_kind(panel), 0);
             st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, rank_kind(panel),
-                            o->always_normalize, o->min_emission_prob_normalization_threshold);
+                            o->always_normalize, norm_threshold);
         } else if (want_lists && panel->rank_fp64 && main_kind == KIND_F32) {
             // the best-haplotype lists come from a pass with fp64 state, so that their membership and order are
             // the reference's; every other output comes from the fp32 pass
@@ -1462,13 +1467,13 @@ int qa_Rcpp_haploid_dosage_versus_refs(
             const int32_t f0 = 0;
             plan(rank_kind(panel), 0);
             st = run_passes(panel, 1, gl, &f0, thin.data(), K_top, o->normalize_emissions, out2, rank_kind(panel),
-                            o->always_normalize, o->min_emission_prob_normalization_threshold);
+                            o->always_normalize, norm_threshold);
         } else {
             // one pass yields everything: fp32 state with fp32 ranking, or fp64 state (qa_panel_set_dosage_precision(64))
             if (want_lists) out.lists = &lists;
             plan(main_kind, f);
             st = run_passes(panel, 1, gl, &f, thin.data(), K_top, o->normalize_emissions, out, main_kind,
-                            o->always_normalize, o->min_emission_prob_normalization_threshold);
+                            o->always_normalize, norm_threshold);
         }
         if (st != QA_OK || !want_lists) return st;
         return pack_lists(lists, best_ptr, best_idx, best_val, best_cap);

@@ -46,6 +46,8 @@ struct PassParams {
     // fp64 ranking passes (fullpass64.hip): the reference's own normalisation schedule (reference-single.cpp:1096-1107)
     int lazy;                // k_emat: raw grid-0 emissions and emin (the lazily normalised forward needs both)
     int always_normalize;
+    int grid0_left_to_right; // validation kernels only (fullpass_ref.hip): 0 = grid 0's sum(alphaHat_t_col) as Armadillo's sum() adds it
+                             // (two accumulators over the even / odd k), 1 = left to right (qa_panel_set_sum_order(panel, 2))
     double norm_threshold;   // min_emission_prob_normalization_threshold
     double *emin;            // [P][G] min emission of the grid after normalisation (:1044-1057), -1: grid without variant
     double *emin_b1;         // [P] emin of grid 1 as the BACKWARD pass reads it: -1 when grid 1 holds no variant.  The forward pass

@@ -2,7 +2,12 @@
 // per-element arithmetic as the production kernels (fullpass64.hip), but every K-wide sum is formed IN THE REFERENCE'S ORDER:
 //   * forward  run_total  (QUILT/src/reference-single.cpp:1002-1075): the grid's special haplotypes first, in list order,
 //     then k = 0 .. K-1 one after the other (specials contribute an exact 0 there and are subtracted as an exact 0);
-//   * grid 0   sum(alphaHat_t_col) (:2349-2353): k = 0 .. K-1;
+//   * grid 0   c(0) = 1 / sum(alphaHat_t_col) (:2347): NOT an explicit loop but Armadillo's sum() of an arma::colvec, i.e.
+//     arrayops::accumulate (armadillo_bits/arrayops_meat.hpp; no -ffast-math): the even-indexed k into one accumulator, the
+//     odd-indexed k into a second, each in increasing k, acc1 + acc2 at the end (serial_sum_arma).  Armadillo is not in the
+//     build image, so this is restated from the library's published source, not observed; mode 2 of qa_panel_set_sum_order
+//     adds grid 0 left to right like the explicit loops (what rounds 4-5 did), so that a maintainer with R can tell which is
+//     right from one c(0) printed at full precision (oracle/quilt_oracle.h, "Armadillo's sum()");
 //   * backward sum_e_times_b (:1899-1955): specials first, then k = 0 .. K-1;
 //   * dosage   matched_gammas(dh) += gamma(k), k = 0 .. K-1 (:2083-2091), the specials' terms in list order (:2096-2128),
 //     then dh = 0 .. nMaxDH-1 per SNP (:2129-2139).
@@ -59,6 +64,21 @@ __device__ double serial_sum(const double *v, const uint8_t *code, int K, double
         s = add_lanes_in_order(s, x);
     }
     return s;
+}
+// Armadillo's arrayops::accumulate over v[0 .. K-1]: acc1 = v[0] + v[2] + ..., acc2 = v[1] + v[3] + ... (each left to right; an
+// odd K's last element has an even index and so lands in acc1, which is the routine's "tail" rule), result acc1 + acc2.  A
+// block of 64 consecutive k starts at an even k, so even lanes feed acc1 and odd lanes acc2: two chains of 32 dependent adds.
+__device__ double serial_sum_arma(const double *v, int K, int lane) {
+    double acc1 = 0.0, acc2 = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const double x = k < K ? v[k] : 0.0;   // (lanes past K add +0.0: a + 0.0 == a)
+        static_for<32>([&](auto ic) {
+            acc1 += lane_value<2 * decltype(ic)::value>(x);
+            acc2 += lane_value<2 * decltype(ic)::value + 1>(x);
+        });
+    }
+    return acc1 + acc2;
 }
 // s + v[list[0]] + v[list[1]] + ... (the grid's special haplotypes, in list order)
 __device__ double serial_gather_sum(const double *v, const int32_t *list, int n, double s, int lane) {
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(kRT) void k_fwd_ro(PassParams prm, int NT, int stat
                     s = serial_gather_sum(state, E.sp_k, E.sn, s, lane);
                     s = serial_sum<true>(state, code, K, s, lane);
                 } else {
-                    s = serial_sum<false>(state, code, K, s, lane);
+                    s = prm.grid0_left_to_right ? serial_sum<false>(state, code, K, s, lane) : serial_sum_arma(state, K, lane);
                 }
                 if (lane == 0) L.x[0] = s;
             }

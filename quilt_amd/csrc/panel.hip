@@ -556,11 +556,12 @@ int qa_panel_set_dosage_precision(qa_panel_t *panel, int32_t bits) {
 }
 
 int qa_panel_set_sum_order(qa_panel_t *panel, int32_t reference_order) {
-    if (!panel || (reference_order != 0 && reference_order != 1)) {
-        qa::set_error("qa_panel_set_sum_order: reference_order must be 0 or 1");
+    if (!panel || reference_order < 0 || reference_order > 2) {
+        qa::set_error("qa_panel_set_sum_order: reference_order must be 0, 1 or 2");
         return QA_ERR_INVALID;
     }
-    panel->sum_order_ref = reference_order == 1;
+    panel->sum_order_ref = reference_order != 0;
+    panel->sum_order_grid0_ltr = reference_order == 2;
     return QA_OK;
 }
 

@@ -35,6 +35,7 @@ struct qa_panel {
     bool rank_fp64 = true;      // best-haplotype lists from fp64-state passes (qa_panel_set_ranking_precision)
     bool dosage_fp64 = false;   // dosage / alpha / beta / gamma outputs from fp64-state passes (qa_panel_set_dosage_precision)
     bool sum_order_ref = false; // VALIDATION MODE: full-panel passes by the reference-order kernels (qa_panel_set_sum_order, fullpass_ref.hip)
+    bool sum_order_grid0_ltr = false; // ... with grid 0's sum(alphaHat_t_col) left to right instead of Armadillo's two accumulators (mode 2)
     int n_special = 0;
     std::vector<double> h_sigma, h_tm1;  // transMatRate_t rows 0 and 1 as passed
     std::vector<int32_t> h_sp_off;

@@ -242,11 +242,14 @@ class DevicePanel:
         throughout, as the reference (a verification mode, several times slower)."""
         check(lib().qa_panel_set_dosage_precision(self.handle, C.c_int32(bits)))
 
-    def set_sum_order(self, reference_order: bool):
-        """VALIDATION MODE (``True``): the full-panel passes form every K-wide sum in the reference's order (the grid's
-        special haplotypes first, then k = 0 .. K-1 by one lane; fullpass_ref.hip), 20-50x slower; lists, c, alpha / beta
-        and dosage then equal the CPU path's bit for bit.  ``False`` (default): the production kernels."""
-        check(lib().qa_panel_set_sum_order(self.handle, C.c_int32(1 if reference_order else 0)))
+    def set_sum_order(self, reference_order):
+        """VALIDATION MODE (``True`` / 1): the full-panel passes form every K-wide sum in the order the reference's code adds
+        it, by one lane (fullpass_ref.hip): the explicit loops with the grid's special haplotypes first, then k = 0 .. K-1;
+        grid 0's ``sum(alphaHat_t_col)`` as Armadillo's ``sum()`` adds it (two accumulators over the even / odd k).  20-50x
+        slower; lists, c, alpha / beta and dosage then equal the CPU path's bit for bit.  2: the same with grid 0's sum left to
+        right as well (the library's order before round 6; include/quilt_amd.h says how a maintainer with R decides between
+        the two).  ``False`` / 0 (default): the production kernels."""
+        check(lib().qa_panel_set_sum_order(self.handle, C.c_int32(int(reference_order))))
 
     def set_device_share(self, n_sharers: int):
         """This handle is one of ``n_sharers`` working on the device concurrently (one per host thread)."""

@@ -236,6 +236,40 @@ def test_fp64_dosage_kernels_production_geometry(oracle, K):
     dev.close()
 
 
+def test_zeroed_options_take_the_references_threshold(oracle):
+    """A C caller that zero-initialises qa_fullpass_opts_t hands over min_emission_prob_normalization_threshold = 0, which read
+    literally would mean "never renormalise between grid 0 and the last grid" in the lazily normalised fp64 passes (alpha
+    underflows, NaN dosages over a long region).  A threshold that is not positive is read as the reference's default, 1e-100
+    (reference-single.cpp:2216): the same bytes as a call that passes 1e-100, on a region long enough for the schedule to
+    renormalise in between."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.reference_single import Rcpp_haploid_dosage_versus_refs
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    panel = make_synthetic_panel(K=2000, nSNPs=6400, seed=31)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    sample = make_synthetic_sample(panel, seed=9, n_reads=4000)
+    gl = label_gl(panel, sample, 1, oracle)
+    cols = thin_cols(panel.nGrids)
+    res = {}
+    for thr in (1e-100, 0.0, -1.0):
+        out = dict(dosage=np.zeros(panel.nSNPs), c=np.ones(panel.nGrids), best_haps_stuff_list=[None] * int((cols >= 0).sum()))
+        Rcpp_haploid_dosage_versus_refs(dev, gl, gammaSmall_cols_to_get=cols, return_dosage=True, return_gamma_t=False,
+                                        return_betaHat_t=False, get_best_haps_from_thinned_sites=True, always_normalize=False,
+                                        min_emission_prob_normalization_threshold=thr, **out)
+        res[thr] = out
+    sigma = panel.transMatRate_t[0]
+    inner = res[1e-100]["c"][1:-1]
+    assert (inner != 1 / sigma[:-1]).any(), "the region must be long enough for a renormalisation between the ends"
+    for thr in (0.0, -1.0):
+        assert np.isfinite(res[thr]["dosage"]).all()
+        assert np.array_equal(res[thr]["dosage"], res[1e-100]["dosage"])
+        assert np.array_equal(res[thr]["c"], res[1e-100]["c"])
+    ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, always_normalize=False)
+    assert np.abs(res[0.0]["dosage"] - ref["dosage"]).max() <= 1e-10
+    dev.close()
+
+
 def test_fp64_dosage_batch(medium_panel, oracle):
     """qa_fullpass_batch with fp64 dosage precision: dosage passes (k_fwd64 + k_bwd64d) and ranking passes in one call."""
     import ctypes as C

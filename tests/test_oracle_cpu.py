@@ -226,3 +226,69 @@ def test_nipt_block_gibbs_invariants(medium_panel):
     rate[[20, 21, 22, 60]] = 0.9
     blocked = O.define_blocked_grids(rate, p.L_grid)
     assert blocked[0] == 0 and np.all(np.diff(blocked) >= 0) and np.all(np.diff(blocked) <= 1) and blocked[-1] >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Armadillo's sum(): the order the oracle adds the reference's arma sum() sites in (oracle/quilt_oracle.h)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _arma_accumulate(x):
+    """arrayops::accumulate / accu_proxy_linear without -ffast-math, stated independently of the C macro: the even-indexed
+    elements added left to right into one accumulator, the odd-indexed ones into a second, acc1 + acc2.  (np.cumsum is a
+    sequential recurrence, unlike np.sum's pairwise tree.)"""
+    x = np.asarray(x, dtype=np.float64)
+    acc1 = np.cumsum(x[0::2])[-1] if len(x[0::2]) else 0.0
+    acc2 = np.cumsum(x[1::2])[-1] if len(x[1::2]) else 0.0
+    return np.float64(acc1) + np.float64(acc2)
+
+
+def _left_to_right(x):
+    return np.cumsum(np.asarray(x, dtype=np.float64))[-1]
+
+
+@pytest.mark.parametrize("K_keep", [None, 501])   # an even and an odd length (the odd tail goes into the first accumulator)
+def test_grid0_sum_is_armadillos_two_accumulator_sum(small_panel, K_keep):
+    """c(0) = 1 / sum(alphaHat_t_col), reference-single.cpp:2347: alphaHat_t_col is an arma::colvec, sum() of it is
+    arrayops::accumulate.  The oracle's default must be that order, its switch the left-to-right sum of rounds 1-5, and the
+    two must be told apart by this input (they differ in the last bits)."""
+    from quilt_amd.synth import make_synthetic_panel, make_synthetic_sample
+    p = small_panel if K_keep is None else make_synthetic_panel(K=K_keep, nSNPs=320, seed=11)
+    s = make_synthetic_sample(p, seed=1001, n_reads=125)
+    gl = label_gl(p, s, 1, O)
+    cols = thin_cols(p.nGrids)
+    # alpha(0) before normalisation, from the oracle's own emission table: prob(k) / K
+    e0 = O.build_eMatDH(p.distinctHapsB, gl, p.nGrids, p.nSNPs, p.ref_error, add_zero_row=True)[:, 0]
+    code0 = p.hapMatcherR[:, 0].astype(np.int64)
+    assert (code0 > 0).all(), "pick a panel whose grid 0 has no special haplotypes for this check"
+    a0 = e0[code0] * (1 / float(p.K))
+    assert O.get_sum_order() is False
+    try:
+        arma = O.haploid_dosage_versus_refs(p, gl, cols)["c"][0]
+        O.set_sum_order(True)
+        ltr = O.haploid_dosage_versus_refs(p, gl, cols)["c"][0]
+    finally:
+        O.set_sum_order(False)
+    assert arma == 1 / _arma_accumulate(a0)
+    assert ltr == 1 / _left_to_right(a0)
+
+
+def test_gibbs_sums_follow_the_switch(medium_panel):
+    """The sampler's Ks-wide sums are Armadillo sum() calls as well (gibbs-nipt.cpp:644-724, 854-974, 1270-1287;
+    copied-from-stitch.cpp:367-435): with the same uniforms the two summation orders give the same labels and states that
+    agree to rounding -- but not the same bits, which shows the switch reaches the sampler."""
+    from quilt_amd.synth import make_synthetic_sample
+    p = medium_panel
+    s = make_synthetic_sample(p, seed=3, n_reads=400)
+    rng = np.random.default_rng(5)
+    which = np.sort(rng.choice(p.K, 150, replace=False)).astype(np.int32) + 1
+    R, G = s.nReads, p.nGrids
+    H0 = rng.integers(1, 3, size=R)
+    ru, rs = rng.random(R * 21), rng.random(3 * (G - 1))
+    try:
+        a = O.forwardBackwardGibbsNIPT(p, s, which, H0, ru, 7, rs)
+        O.set_sum_order(True)
+        b = O.forwardBackwardGibbsNIPT(p, s, which, H0, ru, 7, rs)
+    finally:
+        O.set_sum_order(False)
+    assert np.array_equal(a["H"], b["H"])
+    np.testing.assert_allclose(a["alphaHat_t"][0], b["alphaHat_t"][0], rtol=1e-10, atol=1e-300)
+    assert not np.array_equal(a["alphaHat_t"][0], b["alphaHat_t"][0])

@@ -1,10 +1,12 @@
 """The validation mode of the full-panel passes (qa_panel_set_sum_order(panel, 1), csrc/fullpass_ref.hip): every K-wide sum
-formed in the reference's order (QUILT/src/reference-single.cpp:1002-1075, :1899-1955, :2349-2353, :2083-2139).
+formed in the order the reference's code adds it (QUILT/src/reference-single.cpp:1002-1075, :1899-1955, :2083-2139: explicit
+loops, left to right; :2347: Armadillo's sum(), two accumulators -- restated from Armadillo's source, not observed: see
+oracle/quilt_oracle.h and test_both_readings_of_the_grid0_sum).
 
 What it proves.  The production kernels form those sums as block-wide trees; their last bits differ from a sequential sum's,
 and on panels with exactly tied haplotypes (duplicates, or values absorbed into the recombination term) the last bits decide
 which of the tied haplotypes make a best-haplotype list.  In validation mode the device equals the CPU restatement
-(oracle/fullpass.c, a sequential sum like the reference's) BIT FOR BIT in c, alphaHat_t, betaHat_t, gamma_t, dosage and the
+(oracle/fullpass.c, the same orders on the CPU) BIT FOR BIT in c, alphaHat_t, betaHat_t, gamma_t, dosage and the
 lists -- so the order of the sums is the ONLY difference between the production mode and the CPU path.  Tolerance: none
 (array_equal), fp64.
 """
@@ -67,6 +69,38 @@ def test_every_output_equals_the_oracle_bit_for_bit(request, oracle, panel_name,
         assert np.array_equal(got["dosage"], ref["dosage"])
         _lists_equal(got["best_haps_stuff_list"], ref["best_haps"])
     dev.close()
+
+
+def test_both_readings_of_the_grid0_sum(medium_panel, oracle):
+    """c(0) = 1 / sum(alphaHat_t_col) (reference-single.cpp:2347) is the one K-wide sum of the full pass that is an Armadillo
+    sum() and not an explicit loop.  Mode 1 adds it as arrayops::accumulate does (two accumulators, even / odd k: the oracle's
+    default); mode 2 left to right (the oracle under set_sum_order(True)).  Each mode equals the oracle's matching setting bit
+    for bit, and the two readings do differ on this input -- so whichever a maintainer with R finds to be Armadillo's, the
+    device has a mode that reproduces it."""
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    dev = DevicePanel(panel)
+    sample = make_synthetic_sample(panel, seed=77, n_reads=max(40, panel.nSNPs // 4))
+    cols = thin_cols(panel.nGrids)
+    gl = label_gl(panel, sample, 1, oracle)
+    c0 = {}
+    try:
+        for mode, ltr in ((1, False), (2, True)):
+            oracle.set_sum_order(ltr)
+            dev.set_sum_order(mode)
+            ref = oracle.haploid_dosage_versus_refs(panel, gl, cols, return_gamma_t=True, return_betaHat_t=True,
+                                                    always_normalize=False, get_best_haps_from_thinned_sites=True)
+            got = _run_gpu(dev, gl, cols, return_dosage=True, return_gamma_t=True, return_betaHat_t=True,
+                           get_best_haps_from_thinned_sites=True, always_normalize=False)
+            for key in ("c", "alphaHat_t", "betaHat_t", "gamma_t", "dosage"):
+                assert np.array_equal(got[key], ref[key]), (mode, key)
+            _lists_equal(got["best_haps_stuff_list"], ref["best_haps"])
+            c0[mode] = ref["c"][0]
+    finally:
+        oracle.set_sum_order(False)
+        dev.close()
+    assert c0[1] != c0[2], "the two readings coincide on this input: pick another seed, the test must discriminate"
 
 
 def test_thin_pass_and_label_without_reads(small_panel, oracle):
