@@ -654,6 +654,10 @@ typedef struct {
     const qa_impute_rare_common_t *rare_common; /* NULL, or impute_rare_common = TRUE: dosage / gp_t / phasing_haps then cover
                                                    nSNPs_all SNPs and nDosage counts the all-SNP rounds (functions.R:1305-1317) */
     const qa_impute_nipt_t *nipt;               /* NULL (method = "diploid"), or method = "nipt" */
+    const int64_t *sample_index;                /* NULL: sample i of the call is global sample sample_offset + i.  Else n_sample
+                                                   global indices (ABI 5): the call's samples need not be consecutive among ALL
+                                                   samples -- a range from which samples with too few reads were dropped
+                                                   (functions.R:274-287) keeps every remaining sample's own streams */
 } qa_impute_params_t;
 int qa_impute_params_default(qa_impute_params_t *params);
 
@@ -671,7 +675,8 @@ int qa_impute_params_default(qa_impute_params_t *params);
  *
  *   panels            n_panels (1..16) handles of the SAME panel; 3 is what the headline workload wants
  *   sample_offset     global index of sample 0: (seed, sample_offset + i, Gibbs sample) keys the draws, so a sample gets
- *                     the same result whichever range, rank or launch set it lands in
+ *                     the same result whichever range, rank or launch set it lands in (params->sample_index, when set,
+                     names each sample's global index itself and sample_offset is ignored)
  *   read_off          n_sample + 1: reads of sample i are read_off[i] .. read_off[i + 1] - 1 (every sample needs >= 1)
  *   read_ptr          per sample R_i + 1 offsets (starting at 0) into that sample's bases; sample i's block starts at
  *                     read_ptr[read_off[i] + i]

@@ -134,6 +134,70 @@ int qa_vcf_write_body(const char *path, int32_t bgzf, int32_t finish, const char
 int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const char *text, int64_t n);
 
 /* ------------------------------------------------------------------------------------------------------------------------
+ * f3 + the path + f4 for a whole sample range: BAM paths in, VCF columns and the range's count arrays out
+ *
+ * The body of QUILT()'s loop over a core's sample range (QUILT/R/quilt.R:832-982) with get_and_impute_one_sample's own I/O
+ * either side of the imputation (functions.R:243-298 load, :1380-1463 counts and column) as ONE native call: the BAM files are
+ * read on host threads (qa_bam_load_sample_reads), the samples with at least minimum_number_of_sample_reads reads go through
+ * qa_impute_samples (include/quilt_amd.h), their columns are formatted on the same host threads (qa_vcf_column_*), and the
+ * four per-SNP count arrays the loop keeps (quilt.R:955-961) are summed over the imputed samples in sample order.  Serially in
+ * R these two ends cost about a second per sample; the device imputes ~40 samples per second.
+ * ---------------------------------------------------------------------------------------------------------------------- */
+#include "quilt_amd.h"
+
+typedef struct {
+    const char *chr;
+    int32_t nSNPs;                  /* the panel's (common) SNPs: L ascending 1-based positions, ref / alt one byte per site, */
+    const int32_t *L;               /* grid the 0-based grid of every site -- the arguments of qa_bam_load_sample_reads       */
+    const char *ref, *alt;
+    const int32_t *grid;
+    int32_t nSNPs_all;              /* impute_rare_common (params->rare_common set): the same four over ALL SNPs (pos_all,     */
+    const int32_t *L_all;           /* special_rare_common_objects$grid; functions.R:132-172); else 0 / NULL                   */
+    const char *ref_all, *alt_all;
+    const int32_t *grid_all;
+    qa_bam_opts_t bam;              /* loader options (qa_bam_opts_default) */
+    int32_t minimum_number_of_sample_reads;   /* 2 (quilt.R:132): samples below it are not imputed (functions.R:274-287) */
+    int32_t output_gt_phased_genotypes;       /* 1 (quilt.R:153) */
+    int32_t n_io_threads;                     /* host threads for loading and formatting; 0 = min(32, hardware threads) */
+} qa_bam_range_io_t;
+
+typedef struct qa_bam_range_result qa_bam_range_result_t;   /* opaque; owned by the library */
+
+/*   panels, n_panels, params   as for qa_impute_samples.  params->sample_index, the read arrays inside params->rare_common, and ff /
+ *                              fet_dosage / fet_gp_t inside params->nipt are ignored: this call fills them for the samples it keeps
+ *                              (params->rare_common: handles, nSNPs_all, nGrids_all, snp_is_common, L_grid_all; params->nipt:
+ *                              L_grid, shuffle_bin_radius are the caller's)
+ *   bam_paths                  n_sample files, one sample each (bamlist order)
+ *   sample_index               n_sample GLOBAL 0-based indices (iSample - 1): every sample keeps its own random streams whichever
+ *                              samples of the range are dropped for too few reads
+ *   ff                         method = "nipt": n_sample fetal fractions (ff_values[iSample]); else NULL
+ * A file that cannot be read fails the call (QA_ERR_INVALID / QA_ERR_UNSUPPORTED for CRAM, qa_last_error names the file). */
+int qa_impute_bam_range(qa_panel_t *const *panels, int32_t n_panels, const qa_impute_params_t *params, const qa_bam_range_io_t *io,
+                        int32_t n_sample, const char *const *bam_paths, const int64_t *sample_index, const double *ff,
+                        qa_bam_range_result_t **out);
+
+int32_t qa_bam_range_n_samples(const qa_bam_range_result_t *r);
+int32_t qa_bam_range_n_snps(const qa_bam_range_result_t *r);              /* all SNPs with impute_rare_common */
+int32_t qa_bam_range_imputed(const qa_bam_range_result_t *r, int32_t i); /* sample_was_imputed */
+int32_t qa_bam_range_n_reads(const qa_bam_range_result_t *r, int32_t i); /* reads loaded (the number the log line of functions.R:280 prints) */
+/* per_sample_vcf_col of sample i: entries back to back, NUL-terminated, off[t] = start of entry t, off[nSNPs] = bytes (the layout
+ * of qa_vcf_column_* and qa_vcf_write_body); *buf = *off = NULL for a sample that was not imputed (qa_vcf_missing_entry) */
+int qa_bam_range_column(const qa_bam_range_result_t *r, int32_t i, const char **buf, const int64_t **off);
+/* the numbers behind the column, in qa_impute_samples' layouts (dosage nSNPs, gp_t 3 x nSNPs row by row, phasing_haps 2 (nipt: 3)
+ * x nSNPs row by row; fet_*: nipt only), the consensus read labels and the rounds counted; any pointer may be NULL; NULL / 0 come
+ * back for a sample that was not imputed */
+int qa_bam_range_sample(const qa_bam_range_result_t *r, int32_t i, const double **dosage, const double **gp_t, const double **phasing_haps,
+                        const double **fet_dosage, const double **fet_gp_t, const int32_t **read_labels, int32_t *n_labels, int32_t *nDosage);
+/* the range's sums over its imputed samples, in sample order (quilt.R:955-961), column-major like R's arrays:
+ * infoCount nSNPs x 2 (sum eij, sum fij - eij^2), afCount nSNPs (sum eij / 2), hweCount nSNPs x 3 (most likely genotype counts),
+ * alleleCount nSNPs x 2 (pile-up: alt, ref + alt); any pointer may be NULL */
+int qa_bam_range_counts(const qa_bam_range_result_t *r, double *infoCount, double *afCount, double *hweCount, double *alleleCount);
+/* seconds: [0] loading, [1] qa_impute_samples, [2] formatting + counts, [3] the whole call; impute_stats: qa_impute_samples' 11
+ * counters; load_stats: qa_sample_reads_stats summed over the files */
+void qa_bam_range_timings(const qa_bam_range_result_t *r, double seconds[4], int64_t impute_stats[11], int64_t load_stats[8]);
+void qa_bam_range_destroy(qa_bam_range_result_t *r);
+
+/* ------------------------------------------------------------------------------------------------------------------------
  * driver-side accumulation (QUILT/R/functions.R:999-1020): all chains of a round in one pass
  *   hap            n_chain x n_label x nSNPs haploid dosages of the round's full-panel passes (as qa_fullpass_reads_batch
  *                  returns them); chain_sample: the sample of each chain

@@ -1,0 +1,423 @@
+// bamrange.cpp -- qa_impute_bam_range (include/quilt_amd_io.h): a core's sample range from BAM paths to VCF columns in ONE
+// native call.
+//
+// What it replaces: per sample of the range, get_and_impute_one_sample's own I/O either side of the imputation
+// (QUILT/R/functions.R:243-298: STITCH::loadBamAndConvert + load() of the per-sample RData temp file +
+// snap_sampleReads_to_grid; :1380-1463: allele counts from the pile-up, eij / fij / max_gen, rcpp_make_column_of_vcf and the
+// paste0 assembly of the column) and the range's part of the loop body around it (quilt.R:955-961: the four count arrays
+// summed over the samples of the core).  In R these run one sample after the other on the worker that owns the GPU: about a
+// sample per second, against the ~40 samples per second the device imputes -- the R loader, not the device, would set the
+// throughput a QUILT2.R user sees.  Here
+//   1. the BAM files are read by qa_bam_load_sample_reads on n_io_threads host threads (17 ms per 1x sample and thread);
+//   2. the kept samples go through qa_impute_samples (csrc/impute.cpp) -- params->sample_index names every kept sample's
+//      GLOBAL index, so a sample dropped for too few reads does not shift the streams of the samples behind it;
+//   3. the columns are formatted by qa_vcf_column_diploid / _nipt on the same host threads, and the four count arrays are
+//      summed over the imputed samples in sample order (the order of the reference's loop: floating-point sums).
+// Host code only: no HIP here (the device work is inside qa_impute_samples).
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/quilt_amd.h"
+#include "../../include/quilt_amd_io.h"
+#include "impute_testhook.h"   // (qa_impute_bam_range_backend: the same host code over a checker's entry points, for tests/)
+
+namespace qa { void set_error(const char *fmt, ...); }
+
+struct qa_bam_range_result {
+    int n = 0, n_kept = 0, T_out = 0, nL = 2;
+    bool nipt = false;
+    std::vector<uint8_t> imputed;        // per file
+    std::vector<int32_t> n_reads;        // per file: reads the loader returned (before the minimum test)
+    std::vector<int32_t> slot;           // per file: index among the kept samples, or -1
+    std::vector<int32_t> kept;           // per kept sample: its file
+    std::vector<int32_t> read_off;       // kept + 1
+    std::vector<int32_t> labels, nDosage;
+    std::vector<double> dosage, gp_t, haps, fet_dosage, fet_gp_t;   // kept-major, the layouts of qa_impute_samples
+    std::vector<std::vector<char>> col_buf;
+    std::vector<std::vector<int64_t>> col_off;
+    std::vector<double> infoCount, afCount, hweCount, alleleCount;
+    double seconds[4] = {0, 0, 0, 0};    // load, impute, format + counts, whole call
+    int64_t stats[11] = {0};
+    int64_t load_stats[8] = {0};         // the loader's counters summed over the files (qa_sample_reads_stats)
+};
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+// run f(i) for i in [0, n) on up to n_threads threads; the first failure (status, text) wins
+template <class F>
+int parallel_for(int n, int n_threads, std::string &err, F f) {
+    std::atomic<int> next{0};
+    std::atomic<int> status{QA_OK};
+    std::mutex mu;
+    auto body = [&] {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n || status.load() != QA_OK) return;
+            std::string e;
+            int st;
+            try {
+                st = f(i, e);
+            } catch (const std::exception &ex) {
+                st = QA_ERR_INVALID;
+                e = ex.what();
+            }
+            if (st != QA_OK) {
+                std::lock_guard<std::mutex> g(mu);
+                if (status.load() == QA_OK) { status.store(st); err = e; }
+            }
+        }
+    };
+    const int W = std::max(1, std::min(n_threads, n));
+    if (W == 1) {
+        body();
+    } else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < W; w++) th.emplace_back(body);
+        for (auto &t : th) t.join();
+    }
+    return status.load();
+}
+
+struct Loaded {
+    std::vector<int32_t> read_ptr, u, bq, wif;
+    int32_t R = 0;
+};
+
+int load_one(const char *path, const char *chr, int32_t T, const int32_t *L, const char *ref, const char *alt, const int32_t *grid,
+             const qa_bam_opts_t *o, Loaded &out, int64_t stats[8], std::string &err) {
+    qa_sample_reads_t *h = nullptr;
+    const int st = qa_bam_load_sample_reads(path, chr, T, L, ref, alt, grid, o, &h);
+    if (st != QA_OK) {
+        err = std::string("cannot load ") + path + ": " + qa_last_error();
+        return st;
+    }
+    out.R = qa_sample_reads_n_reads(h);
+    const int64_t nb = qa_sample_reads_n_bases(h);
+    out.read_ptr.assign((size_t)out.R + 1, 0);
+    out.u.resize((size_t)nb);
+    out.bq.resize((size_t)nb);
+    out.wif.resize((size_t)out.R);
+    int32_t dummy = 0;   // (export wants non-null pointers only for what it writes; empty vectors have a null data())
+    const int st2 = qa_sample_reads_export(h, out.read_ptr.data(), nb ? out.u.data() : &dummy, nb ? out.bq.data() : &dummy,
+                                           out.R ? out.wif.data() : &dummy, nullptr);
+    if (stats) qa_sample_reads_stats(h, stats);
+    qa_sample_reads_destroy(h);
+    if (st2 != QA_OK) err = std::string("cannot export the reads of ") + path;
+    return st2;
+}
+
+// the flattened form of include/quilt_amd.h for the kept samples
+void flatten(const std::vector<Loaded> &all, const std::vector<int32_t> &kept, std::vector<int32_t> &read_off,
+             std::vector<int32_t> &read_ptr, std::vector<int32_t> &u, std::vector<int32_t> &bq, std::vector<int32_t> &wif) {
+    const size_t n = kept.size();
+    read_off.assign(n + 1, 0);
+    size_t nb = 0;
+    for (size_t j = 0; j < n; j++) {
+        const Loaded &s = all[(size_t)kept[j]];
+        read_off[j + 1] = read_off[j] + s.R;
+        nb += s.u.size();
+    }
+    read_ptr.clear(); u.clear(); bq.clear(); wif.clear();
+    read_ptr.reserve((size_t)read_off[n] + n);
+    u.reserve(nb); bq.reserve(nb); wif.reserve((size_t)read_off[n]);
+    for (size_t j = 0; j < n; j++) {
+        const Loaded &s = all[(size_t)kept[j]];
+        read_ptr.insert(read_ptr.end(), s.read_ptr.begin(), s.read_ptr.end());
+        u.insert(u.end(), s.u.begin(), s.u.end());
+        bq.insert(bq.end(), s.bq.begin(), s.bq.end());
+        wif.insert(wif.end(), s.wif.begin(), s.wif.end());
+    }
+}
+
+// qa_impute_samples, or the test hook's form of it, on the kept samples
+using ImputeFn = std::function<int(const qa_impute_params_t *, int32_t, const int32_t *, const int32_t *, const int32_t *, const int32_t *,
+                                   const int32_t *, double *, double *, double *, int32_t *, int32_t *, int64_t *)>;
+
+int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, const qa_bam_range_io_t *io, int32_t n_sample,
+                   const char *const *bam_paths, const int64_t *sample_index, const double *ff, qa_bam_range_result_t **out) {
+    if (out) *out = nullptr;
+    if (!params || !io || n_sample < 0 || (n_sample > 0 && (!bam_paths || !sample_index)) || !out ||
+        !io->chr || io->nSNPs < 1 || !io->L || !io->ref || !io->alt || !io->grid) {
+        qa::set_error("qa_impute_bam_range: missing argument");
+        return QA_ERR_INVALID;
+    }
+    const bool rare = params->rare_common != nullptr, nipt = params->nipt != nullptr;
+    if (rare && (io->nSNPs_all < io->nSNPs || !io->L_all || !io->ref_all || !io->alt_all || !io->grid_all ||
+                 params->rare_common->nSNPs_all != io->nSNPs_all)) {
+        qa::set_error("qa_impute_bam_range: impute_rare_common needs the all-SNP sites (L_all, ref_all, alt_all, grid_all; nSNPs_all as in "
+                      "params->rare_common)");
+        return QA_ERR_INVALID;
+    }
+    if (nipt && n_sample > 0 && !ff) {
+        qa::set_error("qa_impute_bam_range: method = \"nipt\" needs one fetal fraction per file");
+        return QA_ERR_INVALID;
+    }
+    for (int i = 0; i < n_sample; i++)
+        if (!bam_paths[i]) { qa::set_error("qa_impute_bam_range: bam_paths[%d] is null", i); return QA_ERR_INVALID; }
+    const auto t_all = Clock::now();
+    int n_io = io->n_io_threads > 0 ? io->n_io_threads : (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    const int T = io->nSNPs, T_out = rare ? io->nSNPs_all : T, nL = nipt ? 3 : 2;
+    const int min_reads = io->minimum_number_of_sample_reads > 0 ? io->minimum_number_of_sample_reads : 1;   // (an empty sample cannot be imputed)
+    std::unique_ptr<qa_bam_range_result> R(new qa_bam_range_result);
+    R->n = n_sample; R->T_out = T_out; R->nL = nL; R->nipt = nipt;
+    R->imputed.assign((size_t)n_sample, 0);
+    R->n_reads.assign((size_t)n_sample, 0);
+    R->slot.assign((size_t)n_sample, -1);
+    R->infoCount.assign((size_t)T_out * 2, 0.0);
+    R->afCount.assign((size_t)T_out, 0.0);
+    R->hweCount.assign((size_t)T_out * 3, 0.0);
+    R->alleleCount.assign((size_t)T_out * 2, 0.0);
+
+    // ---- 1. the reads of every file (functions.R:251-298; with impute_rare_common also over all SNPs, :132-172)
+    auto t0 = Clock::now();
+    std::vector<Loaded> common((size_t)n_sample), all_snps(rare ? (size_t)n_sample : 0);
+    std::vector<std::array<int64_t, 8>> lstats((size_t)n_sample);
+    std::string err;
+    int st = parallel_for(n_sample, n_io, err, [&](int i, std::string &e) {
+        int s1 = load_one(bam_paths[i], io->chr, T, io->L, io->ref, io->alt, io->grid, &io->bam, common[(size_t)i], lstats[(size_t)i].data(), e);
+        if (s1 != QA_OK) return s1;
+        // (the all-SNP pile-up only for samples that will be imputed: the minimum test is on the common-SNP reads, functions.R:274)
+        if (rare && common[(size_t)i].R >= min_reads)
+            s1 = load_one(bam_paths[i], io->chr, io->nSNPs_all, io->L_all, io->ref_all, io->alt_all, io->grid_all, &io->bam, all_snps[(size_t)i], nullptr, e);
+        return s1;
+    });
+    if (st != QA_OK) { qa::set_error("qa_impute_bam_range: %s", err.c_str()); return st; }
+    for (int i = 0; i < n_sample; i++) {
+        R->n_reads[(size_t)i] = common[(size_t)i].R;
+        for (int q = 0; q < 8; q++) R->load_stats[q] += lstats[(size_t)i][(size_t)q];
+        bool keep = common[(size_t)i].R >= min_reads;
+        if (keep && rare && all_snps[(size_t)i].R < 1) keep = false;   // (cannot happen: every common SNP is among the all-SNP sites)
+        if (keep) {
+            R->slot[(size_t)i] = (int32_t)R->kept.size();
+            R->kept.push_back(i);
+            R->imputed[(size_t)i] = 1;
+        }
+    }
+    R->seconds[0] = since(t0);
+    const int nk = R->n_kept = (int)R->kept.size();
+
+    // ---- 2. the ONE call for every chain of every kept sample
+    t0 = Clock::now();
+    std::vector<int32_t> read_ptr, u, bq, wif, a_off, a_ptr, a_u, a_bq, a_wif;
+    flatten(common, R->kept, R->read_off, read_ptr, u, bq, wif);
+    std::vector<int64_t> index((size_t)nk);
+    std::vector<double> ffk((size_t)nk);
+    for (int j = 0; j < nk; j++) {
+        index[(size_t)j] = sample_index[R->kept[(size_t)j]];
+        if (nipt) ffk[(size_t)j] = ff[R->kept[(size_t)j]];
+    }
+    R->dosage.assign((size_t)nk * T_out, 0.0);
+    R->gp_t.assign((size_t)nk * 3 * T_out, 0.0);
+    R->haps.assign((size_t)nk * nL * T_out, 0.0);
+    R->labels.assign((size_t)std::max(R->read_off[(size_t)nk], 1), 0);
+    R->nDosage.assign((size_t)std::max(nk, 1), 0);
+    qa_impute_params_t P = *params;
+    P.sample_index = index.data();
+    qa_impute_rare_common_t rcq;
+    qa_impute_nipt_t nq;
+    if (rare) {
+        flatten(all_snps, R->kept, a_off, a_ptr, a_u, a_bq, a_wif);
+        rcq = *params->rare_common;
+        rcq.read_off = a_off.data(); rcq.read_ptr = a_ptr.data(); rcq.u = a_u.data(); rcq.bq = a_bq.data(); rcq.wif = a_wif.data();
+        P.rare_common = &rcq;
+    }
+    if (nipt) {
+        R->fet_dosage.assign((size_t)nk * T_out, 0.0);
+        R->fet_gp_t.assign((size_t)nk * 3 * T_out, 0.0);
+        nq = *params->nipt;
+        nq.ff = ffk.data();
+        nq.fet_dosage = R->fet_dosage.data();
+        nq.fet_gp_t = R->fet_gp_t.data();
+        P.nipt = &nq;
+    }
+    if (nk > 0) {
+        st = impute(&P, nk, R->read_off.data(), read_ptr.data(), u.data(), bq.data(), wif.data(), R->dosage.data(), R->gp_t.data(), R->haps.data(),
+                    R->labels.data(), R->nDosage.data(), R->stats);
+        if (st != QA_OK) return st;   // (qa_last_error holds qa_impute_samples' text)
+    }
+    R->seconds[1] = since(t0);
+
+    // ---- 3. per kept sample: its VCF column (functions.R:1408-1463) and its share of the four count arrays (:1380-1418)
+    t0 = Clock::now();
+    R->col_buf.resize((size_t)nk);
+    R->col_off.resize((size_t)nk);
+    std::vector<std::vector<double>> eij((size_t)nk), fij((size_t)nk), ac((size_t)nk);
+    std::vector<std::vector<uint8_t>> maxg((size_t)nk);
+    st = parallel_for(nk, n_io, err, [&](int j, std::string &e) {
+        const double *gp = R->gp_t.data() + (size_t)j * 3 * T_out;          // [3][T_out]
+        const double *hd = R->haps.data() + (size_t)j * nL * T_out;         // [nL][T_out] == T_out x nL column-major
+        std::vector<double> gpc((size_t)3 * T_out), fgc;                    // 3 x T_out column-major, as the column writers take it
+        for (int t = 0; t < T_out; t++)
+            for (int g = 0; g < 3; g++) gpc[(size_t)3 * t + g] = gp[(size_t)g * T_out + t];
+        auto &buf = R->col_buf[(size_t)j];
+        auto &off = R->col_off[(size_t)j];
+        off.assign((size_t)T_out + 1, 0);
+        int64_t need = 0, cap = (int64_t)48 * T_out + 64;
+        for (int pass = 0; pass < 2; pass++) {
+            buf.assign((size_t)cap, 0);
+            int s1;
+            if (nipt) {
+                if (fgc.empty()) {
+                    const double *fg = R->fet_gp_t.data() + (size_t)j * 3 * T_out;
+                    fgc.resize((size_t)3 * T_out);
+                    for (int t = 0; t < T_out; t++)
+                        for (int g = 0; g < 3; g++) fgc[(size_t)3 * t + g] = fg[(size_t)g * T_out + t];
+                }
+                s1 = qa_vcf_column_nipt(T_out, gpc.data(), fgc.data(), hd, R->dosage.data() + (size_t)j * T_out,
+                                        R->fet_dosage.data() + (size_t)j * T_out, buf.data(), cap, off.data(), &need);
+            } else {
+                s1 = qa_vcf_column_diploid(T_out, gpc.data(), hd, io->output_gt_phased_genotypes, buf.data(), cap, off.data(), &need);
+            }
+            if (s1 == QA_ERR_CAPACITY && pass == 0) { cap = need; continue; }
+            if (s1 != QA_OK) { e = "VCF column of a sample could not be formatted"; return s1; }
+            break;
+        }
+        buf.resize((size_t)off[(size_t)T_out]);
+        // eij, fij (functions.R:1399-1400: round(x, 3)), max_gen (STITCH::get_max_gen_rapid: the first maximum), the pile-up's
+        // allele counts (increment2N over STITCH::convertScaledBQtoProbs of the reads as loaded, :1382-1398)
+        auto &E = eij[(size_t)j]; auto &F = fij[(size_t)j]; auto &M = maxg[(size_t)j]; auto &A = ac[(size_t)j];
+        E.resize((size_t)T_out); F.resize((size_t)T_out); M.resize((size_t)T_out); A.assign((size_t)2 * T_out, 0.0);
+        for (int t = 0; t < T_out; t++) {
+            const double g0 = gp[t], g1 = gp[(size_t)T_out + t], g2 = gp[(size_t)2 * T_out + t];
+            E[(size_t)t] = std::nearbyint((g1 + 2 * g2) * 1000.0) / 1000.0;
+            F[(size_t)t] = std::nearbyint((g1 + 4 * g2) * 1000.0) / 1000.0;
+            M[(size_t)t] = (uint8_t)((g1 > g0) ? ((g2 > g1) ? 2 : 1) : ((g2 > g0) ? 2 : 0));
+        }
+        const Loaded &s = rare ? all_snps[(size_t)R->kept[(size_t)j]] : common[(size_t)R->kept[(size_t)j]];
+        double *c1 = A.data(), *c2 = A.data() + T_out;   // sums of P(ref), P(alt) per site, bases in the order they were loaded
+        for (size_t b = 0; b < s.u.size(); b++) {
+            const int q = s.bq[b];
+            const double eps = std::pow(10.0, -std::fabs((double)q) / 10.0);
+            c1[s.u[b]] += q < 0 ? 1 - eps : eps / 3;
+            c2[s.u[b]] += q < 0 ? eps / 3 : 1 - eps;
+        }
+        return (int)QA_OK;
+    });
+    if (st != QA_OK) { qa::set_error("qa_impute_bam_range: %s", err.c_str()); return st; }
+    // the range's sums, sample after sample as the reference's loop adds them (quilt.R:955-961)
+    {
+        double *i0 = R->infoCount.data(), *i1 = i0 + T_out, *af = R->afCount.data(), *hw = R->hweCount.data();
+        double *a0 = R->alleleCount.data(), *a1 = a0 + T_out;
+        for (int j = 0; j < nk; j++) {
+            const double *E = eij[(size_t)j].data(), *F = fij[(size_t)j].data(), *c1 = ac[(size_t)j].data(), *c2 = c1 + T_out;
+            const uint8_t *M = maxg[(size_t)j].data();
+            for (int t = 0; t < T_out; t++) {
+                i0[t] += E[t];
+                i1[t] += F[t] - E[t] * E[t];
+                af[t] += E[t] / 2;
+                hw[(size_t)M[t] * T_out + t] += 1;
+                a0[t] += c2[t];              // per_sample_alleleCount = cbind(c2, c1 + c2) (functions.R:1398)
+                a1[t] += c1[t] + c2[t];
+            }
+        }
+    }
+    R->seconds[2] = since(t0);
+    R->seconds[3] = since(t_all);
+    *out = R.release();
+    return QA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qa_impute_bam_range(qa_panel_t *const *panels, int32_t n_panels, const qa_impute_params_t *params, const qa_bam_range_io_t *io,
+                        int32_t n_sample, const char *const *bam_paths, const int64_t *sample_index, const double *ff,
+                        qa_bam_range_result_t **out) {
+    if (!panels || n_panels < 1 || !panels[0]) {
+        if (out) *out = nullptr;
+        qa::set_error("qa_impute_bam_range: no panel handle");
+        return QA_ERR_INVALID;
+    }
+    return bam_range_impl(
+        [&](const qa_impute_params_t *P, int32_t n, const int32_t *ro, const int32_t *rp, const int32_t *u, const int32_t *bq, const int32_t *wif,
+            double *dosage, double *gp_t, double *haps, int32_t *labels, int32_t *nDosage, int64_t *stats) {
+            return qa_impute_samples(panels, n_panels, P, n, 0, ro, rp, u, bq, wif, dosage, gp_t, haps, labels, nDosage, stats);
+        },
+        params, io, n_sample, bam_paths, sample_index, ff, out);
+}
+
+// test hook (impute_testhook.h): the same host code -- loader, kept-sample bookkeeping, formatting, counts -- with the imputation
+// running over a checker's entry points instead of the device
+int qa_impute_bam_range_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,
+                                const qa_impute_params_t *params, const qa_bam_range_io_t *io, int32_t n_sample, const char *const *bam_paths,
+                                const int64_t *sample_index, const double *ff, qa_bam_range_result_t **out) {
+    if (!backend || !handles || !io) {
+        if (out) *out = nullptr;
+        qa::set_error("qa_impute_bam_range_backend: missing argument");
+        return QA_ERR_INVALID;
+    }
+    const int32_t T = io->nSNPs;
+    return bam_range_impl(
+        [&](const qa_impute_params_t *P, int32_t n, const int32_t *ro, const int32_t *rp, const int32_t *u, const int32_t *bq, const int32_t *wif,
+            double *dosage, double *gp_t, double *haps, int32_t *labels, int32_t *nDosage, int64_t *stats) {
+            return qa_impute_samples_backend(backend, handles, n_handles, K, nGrids, T, P, n, 0, ro, rp, u, bq, wif, dosage, gp_t, haps, labels,
+                                             nDosage, stats);
+        },
+        params, io, n_sample, bam_paths, sample_index, ff, out);
+}
+
+int32_t qa_bam_range_n_samples(const qa_bam_range_result_t *r) { return r ? r->n : 0; }
+int32_t qa_bam_range_n_snps(const qa_bam_range_result_t *r) { return r ? r->T_out : 0; }
+int32_t qa_bam_range_imputed(const qa_bam_range_result_t *r, int32_t i) { return (r && i >= 0 && i < r->n) ? r->imputed[(size_t)i] : 0; }
+int32_t qa_bam_range_n_reads(const qa_bam_range_result_t *r, int32_t i) { return (r && i >= 0 && i < r->n) ? r->n_reads[(size_t)i] : 0; }
+
+int qa_bam_range_column(const qa_bam_range_result_t *r, int32_t i, const char **buf, const int64_t **off) {
+    if (!r || i < 0 || i >= r->n || !buf || !off) return QA_ERR_INVALID;
+    const int j = r->slot[(size_t)i];
+    *buf = j < 0 ? nullptr : r->col_buf[(size_t)j].data();
+    *off = j < 0 ? nullptr : r->col_off[(size_t)j].data();
+    return QA_OK;
+}
+
+int qa_bam_range_sample(const qa_bam_range_result_t *r, int32_t i, const double **dosage, const double **gp_t, const double **phasing_haps,
+                        const double **fet_dosage, const double **fet_gp_t, const int32_t **read_labels, int32_t *n_labels, int32_t *nDosage) {
+    if (!r || i < 0 || i >= r->n) return QA_ERR_INVALID;
+    const int j = r->slot[(size_t)i];
+    const size_t T = (size_t)r->T_out;
+    if (dosage) *dosage = j < 0 ? nullptr : r->dosage.data() + (size_t)j * T;
+    if (gp_t) *gp_t = j < 0 ? nullptr : r->gp_t.data() + (size_t)j * 3 * T;
+    if (phasing_haps) *phasing_haps = j < 0 ? nullptr : r->haps.data() + (size_t)j * r->nL * T;
+    if (fet_dosage) *fet_dosage = (j < 0 || !r->nipt) ? nullptr : r->fet_dosage.data() + (size_t)j * T;
+    if (fet_gp_t) *fet_gp_t = (j < 0 || !r->nipt) ? nullptr : r->fet_gp_t.data() + (size_t)j * 3 * T;
+    if (read_labels) *read_labels = j < 0 ? nullptr : r->labels.data() + r->read_off[(size_t)j];
+    if (n_labels) *n_labels = j < 0 ? 0 : r->read_off[(size_t)j + 1] - r->read_off[(size_t)j];
+    if (nDosage) *nDosage = j < 0 ? 0 : r->nDosage[(size_t)j];
+    return QA_OK;
+}
+
+int qa_bam_range_counts(const qa_bam_range_result_t *r, double *infoCount, double *afCount, double *hweCount, double *alleleCount) {
+    if (!r) return QA_ERR_INVALID;
+    const size_t T = (size_t)r->T_out;
+    if (infoCount) std::memcpy(infoCount, r->infoCount.data(), sizeof(double) * 2 * T);
+    if (afCount) std::memcpy(afCount, r->afCount.data(), sizeof(double) * T);
+    if (hweCount) std::memcpy(hweCount, r->hweCount.data(), sizeof(double) * 3 * T);
+    if (alleleCount) std::memcpy(alleleCount, r->alleleCount.data(), sizeof(double) * 2 * T);
+    return QA_OK;
+}
+
+void qa_bam_range_timings(const qa_bam_range_result_t *r, double seconds[4], int64_t impute_stats[11], int64_t load_stats[8]) {
+    if (!r) return;
+    if (seconds) std::memcpy(seconds, r->seconds, sizeof r->seconds);
+    if (impute_stats) std::memcpy(impute_stats, r->stats, sizeof r->stats);
+    if (load_stats) std::memcpy(load_stats, r->load_stats, sizeof r->load_stats);
+}
+
+void qa_bam_range_destroy(qa_bam_range_result_t *r) { delete r; }
+
+}  // extern "C"

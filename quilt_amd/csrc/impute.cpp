@@ -194,6 +194,8 @@ struct Ctx {
     std::vector<int32_t> cols;
     int n_thin = 0, top_width = 8;
     int64_t sample_offset = 0;
+    const int64_t *sample_index = nullptr;   // params->sample_index
+    int64_t global_index(int s) const { return sample_index ? sample_index[s] : sample_offset + s; }
     std::vector<Reads> reads;
     // impute_rare_common: the all-SNP reads, the all-SNP dimensions (T_out = T_all then) and where the common SNPs sit
     const qa_impute_nipt_t *nipt = nullptr;   // method = "nipt": three labels, a fetal fraction per sample
@@ -1004,7 +1006,7 @@ struct Worker {
                 Chain ch;
                 ch.sample = s;
                 ch.i_chain = c;
-                ch.rng = ChainStream(P.seed, cx.sample_offset + s, c);
+                ch.rng = ChainStream(P.seed, cx.global_index(s), c);
                 b->chains.push_back(std::move(ch));
             }
         return b;
@@ -1056,7 +1058,7 @@ struct Worker {
             ph.sample = s;
             ph.i_chain = nG + 1;
             ph.phasing = true;
-            ph.rng = ChainStream(P.seed, cx.sample_offset + s, nG + 1);
+            ph.rng = ChainStream(P.seed, cx.global_index(s), nG + 1);
             ph.which = b.chains[si * nG + (nG - 1)].which;
             ph.labels.resize((size_t)R);
             if (cx.be->consensus_read_labels(R, nG, labels.data(), p.data(), nL, 0.95, nG, ph.labels.data()) != QA_OK)
@@ -1222,6 +1224,7 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     for (int32_t c : cx.cols) cx.n_thin += c >= 0;
     cx.top_width = std::max(8, P.K_top_matches);
     cx.sample_offset = sample_offset;
+    cx.sample_index = P.sample_index;
     cx.dosage = dosage; cx.gp_t = gp_t; cx.phasing_haps = phasing_haps; cx.read_labels = read_labels; cx.nDosage = nDosage;
     cx.read_off = read_off;
     cx.reads.resize((size_t)n_sample);

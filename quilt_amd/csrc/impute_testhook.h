@@ -68,6 +68,14 @@ int qa_impute_samples_backend(const qa_impute_backend_t *backend, void *const *h
                               const int32_t *wif, double *dosage, double *gp_t, double *phasing_haps, int32_t *read_labels,
                               int32_t *nDosage, int64_t *stats);
 
+
+/* qa_impute_bam_range (include/quilt_amd_io.h) with its imputation step on a caller's table: the loader, the bookkeeping of
+ * kept / dropped samples and their global indices, the column formatting and the count arrays are the product's own code */
+#include "../../include/quilt_amd_io.h"
+int qa_impute_bam_range_backend(const qa_impute_backend_t *backend, void *const *handles, int32_t n_handles, int32_t K, int32_t nGrids,
+                                const qa_impute_params_t *params, const qa_bam_range_io_t *io, int32_t n_sample, const char *const *bam_paths,
+                                const int64_t *sample_index, const double *ff, qa_bam_range_result_t **out);
+
 #ifdef __cplusplus
 }
 #endif

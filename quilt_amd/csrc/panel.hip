@@ -270,7 +270,7 @@ int qa_profile_get_busy(int32_t kernel, double *busy_ms) {
     return QA_OK;
 }
 
-int qa_abi_version(void) { return 4; }   // 4: qa_gibbs_opts_t.reads_same_as, qa_panel_set_sum_order, qa_rcpp_make_eMatRead_t_rare_common (round 5)
+int qa_abi_version(void) { return 5; }   // 5: qa_impute_params_t.sample_index, qa_impute_bam_range, qa_panel_set_sum_order mode 2 (round 6); 4: qa_gibbs_opts_t.reads_same_as, qa_panel_set_sum_order, qa_rcpp_make_eMatRead_t_rare_common (round 5)
 
 const char *qa_last_error(void) { return qa::g_err; }
 

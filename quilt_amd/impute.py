@@ -27,7 +27,7 @@ class ImputeParams(C.Structure):
         ("use_mspbwt", C.c_int32), ("mspbwtL", C.c_int32), ("mspbwtM", C.c_int32),
         ("mspbwt_index", C.c_void_p),
         ("samples_per_launch_set", C.c_int32), ("no_fused_tails", C.c_int32),
-        ("rare_common", C.c_void_p), ("nipt", C.c_void_p),
+        ("rare_common", C.c_void_p), ("nipt", C.c_void_p), ("sample_index", C.c_void_p),
     ]
 
 
@@ -166,3 +166,128 @@ def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverPar
     :class:`quilt_amd.native.DeviceRareCommon` per entry of ``devs``; every sample then carries its all-SNP reads as
     ``sample.all_snp`` and the results cover all SNPs.  Returns one SampleResult per sample (and the native counters)."""
     return run_prepared(prepare_range(devs, samples, params, sample_offset, samples_per_launch_set, fuse_tails, drcs), return_stats)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a sample range from BAM paths to VCF columns in one native call (qa_impute_bam_range, include/quilt_amd_io.h)
+# ---------------------------------------------------------------------------------------------------------------------------
+class BamRangeIo(C.Structure):
+    from .io import BamOpts as _BamOpts
+    _fields_ = [("chr", C.c_char_p), ("nSNPs", C.c_int32), ("L", C.c_void_p), ("ref", C.c_char_p), ("alt", C.c_char_p),
+                ("grid", C.c_void_p), ("nSNPs_all", C.c_int32), ("L_all", C.c_void_p), ("ref_all", C.c_char_p),
+                ("alt_all", C.c_char_p), ("grid_all", C.c_void_p), ("bam", _BamOpts), ("minimum_number_of_sample_reads", C.c_int32),
+                ("output_gt_phased_genotypes", C.c_int32), ("n_io_threads", C.c_int32)]
+
+
+def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, alt, params: Optional[DriverParams] = None,
+                     sample_index: Optional[Sequence[int]] = None, ff: Optional[Sequence[float]] = None, *,
+                     minimum_number_of_sample_reads: int = 2, output_gt_phased_genotypes: bool = True, n_io_threads: int = 0,
+                     samples_per_launch_set: int = 256, fuse_tails: bool = True, drcs: Sequence = (), all_sites=None,
+                     bqFilter: int = 17, iSizeUpperLimit: float = 1e6, useSoftClippedBases: bool = False, downsampleToCov: int = 30,
+                     chrStart: int = 0, chrEnd: int = 0, merge_mates: bool = True, seed: int = 1, _entry=None) -> dict:
+    """The body of QUILT()'s loop over a core's sample range (quilt.R:832-982) as ONE native call: the BAM files are loaded on
+    host threads, the samples with enough reads imputed together on the device, their VCF columns formatted on host threads and
+    the four per-SNP count arrays summed over the range.  ``sample_index``: the files' global 0-based sample indices (default
+    0 .. n - 1).  ``all_sites`` (with ``params.impute_rare_common`` and ``drcs``): ``(L_all, ref_all, alt_all, grid_all)``.
+    Returns dict(imputed, n_reads, columns [VcfColumn or None], results {file index: SampleResult}, counts SummaryCounts,
+    seconds {load, impute, format, total}, stats)."""
+    from .io import BamOpts, SummaryCounts, VcfColumn
+    panel = devs[0].panel
+    P = params or DriverParams()
+    if panel.L is None:
+        raise ValueError("the panel carries no SNP positions (Panel.L)")
+    n = len(bam_files)
+    T = panel.nSNPs
+    Lc = np.ascontiguousarray(panel.L, dtype=np.int32)
+    grid = np.ascontiguousarray(panel.grid if panel.grid is not None else np.arange(T, dtype=np.int32) // 32, dtype=np.int32)
+    as_bytes = lambda a: bytes(a) if isinstance(a, (bytes, bytearray)) else "".join(a).encode()
+    refb, altb = as_bytes(ref), as_bytes(alt)
+    if len(refb) != T or len(altb) != T:
+        raise ValueError("ref / alt: one character per SNP of the panel")
+    idx = None
+    if P.use_mspbwt:
+        from .mspbwt import panel_mspbwt_index
+        idx = panel_mspbwt_index(panel, P.mspbwt_nindices)
+    rcq = nq = None
+    keep = []
+    T_out = T
+    io = BamRangeIo()
+    if P.impute_rare_common:
+        if len(drcs) != len(devs) or all_sites is None:
+            raise ValueError("impute_rare_common: one DeviceRareCommon per DevicePanel, and the all-SNP sites")
+        rc = drcs[0].rc
+        T_out = rc.nSNPs_all
+        hs = (C.c_void_p * len(drcs))(*[d.handle for d in drcs])
+        is_common = np.ascontiguousarray(rc.snp_is_common, dtype=np.uint8)
+        Lga = np.ascontiguousarray(rc.L_grid_all, dtype=np.int32)
+        rcq = ImputeRareCommon(C.cast(hs, C.c_void_p), rc.nSNPs_all, rc.nGrids_all, ptr(is_common), None, None, None, None, None, ptr(Lga))
+        La, refa, alta, grida = all_sites
+        La = np.ascontiguousarray(La, dtype=np.int32)
+        grida = np.ascontiguousarray(grida, dtype=np.int32)
+        refa, alta = as_bytes(refa), as_bytes(alta)
+        io.nSNPs_all, io.L_all, io.ref_all, io.alt_all, io.grid_all = T_out, La.ctypes.data, refa, alta, grida.ctypes.data
+        keep += [hs, is_common, Lga, La, grida, refa, alta]
+    if P.method == "nipt":
+        if ff is None or len(ff) != n:
+            raise ValueError("method = 'nipt': one fetal fraction per file")
+        Lg = np.ascontiguousarray(panel.L_grid, dtype=np.int32)
+        nq = ImputeNipt(None, ptr(Lg), int(P.shuffle_bin_radius), None, None)
+        keep.append(Lg)
+    q, keep_q = make_params(P, samples_per_launch_set, idx, fuse_tails, rcq, nq)
+    io.chr, io.nSNPs, io.L, io.ref, io.alt, io.grid = chr.encode(), T, Lc.ctypes.data, refb, altb, grid.ctypes.data
+    io.bam = BamOpts(int(bqFilter), int(min(iSizeUpperLimit, 2**31 - 1)), int(bool(useSoftClippedBases)), int(downsampleToCov),
+                     int(chrStart), int(chrEnd), int(bool(merge_mates)), int(seed))
+    io.minimum_number_of_sample_reads = int(minimum_number_of_sample_reads)
+    io.output_gt_phased_genotypes = int(bool(output_gt_phased_genotypes))
+    io.n_io_threads = int(n_io_threads)
+    paths = (C.c_char_p * max(n, 1))(*[p.encode() for p in bam_files])
+    sidx = np.ascontiguousarray(np.arange(n) if sample_index is None else sample_index, dtype=np.int64)
+    ffv = None if ff is None else np.ascontiguousarray(ff, dtype=np.float64)
+    handles = (C.c_void_p * len(devs))(*[getattr(d, "handle", None) for d in devs])
+    L = lib()
+    for name in ("qa_impute_bam_range", "qa_bam_range_column", "qa_bam_range_sample", "qa_bam_range_counts", "qa_bam_range_imputed",
+                 "qa_bam_range_n_reads", "qa_bam_range_n_snps"):
+        getattr(L, name).restype = C.c_int
+    L.qa_bam_range_destroy.restype = None
+    L.qa_bam_range_timings.restype = None
+    h = C.c_void_p()
+    if _entry is not None:   # (tests: the same native host code with its imputation step on a checker -- impute_testhook.h)
+        _entry(q, io, n, paths, sidx, ffv, h)
+    else:
+        check(L.qa_impute_bam_range(handles, C.c_int32(len(devs)), C.byref(q), C.byref(io), C.c_int32(n), paths, ptr(sidx), ptr(ffv),
+                                    C.byref(h)))
+    try:
+        assert L.qa_bam_range_n_snps(h) == T_out
+        nL = 3 if P.method == "nipt" else 2
+        imputed = [bool(L.qa_bam_range_imputed(h, C.c_int32(i))) for i in range(n)]
+        n_reads = [int(L.qa_bam_range_n_reads(h, C.c_int32(i))) for i in range(n)]
+        columns, results = [None] * n, {}
+        for i in range(n):
+            if not imputed[i]:
+                continue
+            buf, off = C.c_void_p(), C.c_void_p()
+            check(L.qa_bam_range_column(h, C.c_int32(i), C.byref(buf), C.byref(off)))
+            o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_int64)), shape=(T_out + 1,)).copy()
+            b = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(int(o[-1]),)).copy()
+            columns[i] = VcfColumn(b, o)
+            pd, pg, ph, pfd, pfg, pl = (C.c_void_p() for _ in range(6))
+            nl, nd = C.c_int32(), C.c_int32()
+            check(L.qa_bam_range_sample(h, C.c_int32(i), C.byref(pd), C.byref(pg), C.byref(ph), C.byref(pfd), C.byref(pfg), C.byref(pl),
+                                        C.byref(nl), C.byref(nd)))
+            arr = lambda p, shape, t=C.c_double: np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), shape=shape).copy()
+            results[i] = SampleResult(arr(pd, (T_out,)), arr(pg, (3, T_out)), arr(ph, (nL, T_out)).T,
+                                      arr(pl, (nl.value,), C.c_int32) if nl.value else np.zeros(0, dtype=np.int32), int(nd.value),
+                                      fet_dosage=arr(pfd, (T_out,)) if pfd.value else None,
+                                      fet_gp_t=arr(pfg, (3, T_out)) if pfg.value else None)
+        info, af, hwe, ac = np.zeros((T_out, 2), order="F"), np.zeros(T_out), np.zeros((T_out, 3), order="F"), np.zeros((T_out, 2), order="F")
+        check(L.qa_bam_range_counts(h, ptr(info), ptr(af), ptr(hwe), ptr(ac)))
+        counts = SummaryCounts(T_out, hweCount=np.ascontiguousarray(hwe), infoCount=np.ascontiguousarray(info), afCount=af,
+                               alleleCount=np.ascontiguousarray(ac))
+        sec, st, ls = np.zeros(4), np.zeros(11, dtype=np.int64), np.zeros(8, dtype=np.int64)
+        L.qa_bam_range_timings(h, ptr(sec), ptr(st), ptr(ls))
+    finally:
+        L.qa_bam_range_destroy(h)
+    del keep, keep_q
+    return dict(imputed=imputed, n_reads=n_reads, columns=columns, results=results, counts=counts,
+                seconds=dict(zip(("load", "impute", "format", "total"), sec.tolist())), stats=dict(zip(STAT_NAMES, st.tolist())),
+                load_stats=ls.tolist())

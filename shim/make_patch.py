@@ -9,7 +9,8 @@ What the patch does, and nothing else:
     functions (qa_QUILT_<fn>, same arities) instead of the Rcpp wrappers; four `extern "C"` declarations are added above the
     table.  The Rcpp wrappers stay defined (no duplicate symbol: the shim's functions have other names) and unregistered.
     `Rcpp::compileAttributes()` regenerates this file: re-apply the patch afterwards.
-  * the same table gets one NEW row, qa_impute_sample_range (6 arguments): the loop over a core's sample range as one call.
+  * the same table gets two NEW rows: qa_impute_sample_range (6 arguments: the loop over a core's sample range as one call, reads
+    loaded by R) and qa_impute_bam_range (6 arguments: the same from BAM paths to VCF columns, I/O on native host threads).
   * QUILT/src/Makevars -- the include path of include/quilt_amd.h, -DQA_HAVE_R (the shim then includes R's own headers) and
     the link line for libquilt_amd.so (QUILT_AMD = the root of this repository).
   * QUILT/src/quilt_amd_shim.c -- added by copying shim/quilt_amd_shim.c (R compiles every .c in src/); the patch carries a
@@ -37,7 +38,9 @@ ENTRIES = {"_QUILT_rcpp_make_eMatRead_t": 15, "_QUILT_Rcpp_make_gl_bound": 3, "_
 
 
 # routines the reference does not have: the loop over a core's sample range as one call (quilt.R:688-996 -> qa_impute_samples)
-EXTRA = {"qa_impute_sample_range": 6}
+EXTRA = {"qa_impute_sample_range": 6, "qa_impute_bam_range_call": 6}
+# (name registered with R -> the C function, where they differ: the C ABI already has a qa_impute_bam_range)
+EXTRA_REGISTERED_AS = {"qa_impute_bam_range_call": "qa_impute_bam_range"}
 
 
 def patched_rcppexports(text):
@@ -59,7 +62,7 @@ def patched_rcppexports(text):
             seen.add(m.group(1))
         if in_table and re.match(r"\s*\{NULL, NULL, 0\}", ln):   # new routines of the shim: rows of their own before the terminator
             for name, n in EXTRA.items():
-                out.append('    {"%s", (DL_FUNC) &%s, %d},' % (name, name, n))
+                out.append('    {"%s", (DL_FUNC) &%s, %d},' % (EXTRA_REGISTERED_AS.get(name, name), name, n))
             in_table = False
         out.append(ln)
     assert seen == set(ENTRIES), "CallEntries rows not found: %s" % (set(ENTRIES) - seen)
@@ -122,6 +125,15 @@ R_RANGE_CALL = '''        ## libquilt_amd: the whole sample range as ONE call (q
                 minimum_number_of_sample_reads = minimum_number_of_sample_reads,
                 output_gt_phased_genotypes = output_gt_phased_genotypes
             )
+            ## native I/O (quilt-amd.R, form (a)): the range's four count arrays come back summed (in sample order) -- added here
+            ## once; the per-sample entries the loop below adds are exact zeros then
+            amd_counts <- attr(amd_results, "quilt_amd_counts")
+            if (!is.null(amd_counts)) {
+                infoCount <- infoCount + amd_counts[["infoCount"]]
+                afCount <- afCount + amd_counts[["afCount"]]
+                hweCount <- hweCount + amd_counts[["hweCount"]]
+                alleleCount <- alleleCount + amd_counts[["alleleCount"]]
+            }
         }
 
 '''

@@ -7,9 +7,20 @@
 ## functions.R:330-1300, in host C++ over the batched kernels).  This file holds
 ##   quilt_amd_range_is_covered()   -- may this run take the range call?  Anything it does not cover falls back to the
 ##                                     unpatched loop (plots, HLA, truth haplotypes / genotypes, per-read outputs, ...)
-##   quilt_amd_impute_sample_range() -- per sample: the reference's own loader (functions.R:132-172, :251-298), then the ONE
-##                                     call, then per sample what get_and_impute_one_sample returns (functions.R:1380-1463)
-## Nothing here computes a probability: loading and VCF formatting are the reference's own functions, the imputation is the call.
+##   quilt_amd_impute_sample_range() -- the range's samples through the ONE call.  Two forms:
+##       (a) NATIVE I/O (the fast one; quilt_amd_native_io_is_covered): `.Call("qa_impute_bam_range", bam_files, ...)` reads the
+##           BAM files on host threads (csrc/hostio.cpp), imputes, formats every sample's VCF column and sums the range's four
+##           count arrays natively -- the loop body of quilt.R:832-982 with get_and_impute_one_sample's own I/O
+##           (functions.R:243-298, :1380-1463) in one call.  R's serial loader and formatter handle about one sample per second;
+##           the device imputes about forty.
+##       (b) R I/O (the fallback: CRAM input, bx tags, QUILT_AMD_NATIVE_IO=0): per sample the reference's own loader
+##           (functions.R:132-172, :251-298), then `.Call("qa_impute_sample_range", ...)`, then per sample what
+##           get_and_impute_one_sample returns (functions.R:1380-1463) by the reference's own functions.
+## Nothing in this FILE computes a probability.
+##
+## QUILT_AMD_SUM_ORDER (environment, default 0): 1 runs the full-panel passes in the library's VALIDATION MODE -- every K-wide sum
+## in the order the reference's C++ adds it, bit-identical best-haplotype lists to the CPU package's on tie-rich panels, 20-50x
+## slower passes (INTEGRATION.md 3a); 2: the same with grid 0's Armadillo sum() read left to right (include/quilt_amd.h).
 ##
 ## Random draws: 2 048 chains advancing together cannot consume ONE R stream in the reference's order, so the range call uses
 ## the library's counter streams keyed by (seed, global sample index, Gibbs sample); `seed` plays set.seed's part, and a
@@ -35,6 +46,18 @@ quilt_amd_range_is_covered <- function(
         !use_splitreadgl && !small_ref_panel_skip_equally_likely_reads &&
         shard_check_every_pair && use_hapMatcherR && calculate_gamma_on_the_fly &&
         is.null(RData_objects_to_save) && n_gibbs_sample_its == 1
+    return(isTRUE(ok))
+}
+
+
+## may the range's I/O run natively?  Everything the native loader does not implement keeps the reference's R loader.
+quilt_amd_native_io_is_covered <- function(bam_files, cram_files, use_bx_tag, pos, pos_all, impute_rare_common) {
+    if (Sys.getenv("QUILT_AMD_NATIVE_IO", "1") == "0") return(FALSE)
+    if (!is.loaded("qa_impute_bam_range", PACKAGE = "QUILT")) return(FALSE)
+    one_letter <- function(p) all(nchar(as.character(p[, 3])) == 1) && all(nchar(as.character(p[, 4])) == 1)
+    ok <- length(cram_files) == 0 || all(cram_files == "") || all(is.na(cram_files))   ## CRAM: not decoded natively
+    ok <- ok && length(bam_files) > 0 && !any(is.na(bam_files)) && !isTRUE(use_bx_tag) ## bx tags: STITCH's loader only
+    ok <- ok && one_letter(pos) && (!impute_rare_common || one_letter(pos_all))        ## biallelic SNPs, single letters
     return(isTRUE(ok))
 }
 
@@ -79,6 +102,86 @@ quilt_amd_impute_sample_range <- function(
 ) {
     w <- sampleRange[1]:sampleRange[2]
     n <- length(w)
+    sum_order <- as.integer(Sys.getenv("QUILT_AMD_SUM_ORDER", "0"))
+    panel_objects <- list(
+        hapMatcherR = hapMatcherR, distinctHapsB = distinctHapsB, distinctHapsIE = distinctHapsIE,
+        eMatDH_special_matrix_helper = eMatDH_special_matrix_helper, eMatDH_special_matrix = eMatDH_special_matrix,
+        rhb_t = rhb_t, transMatRate_t = small_transMatRate_tc_H[, , 1], ref_error = ref_error,
+        use_eMatDH_special_symbols = as.integer(use_eMatDH_special_symbols)
+    )
+    params <- list(
+        nGibbsSamples = nGibbsSamples, n_seek_its = n_seek_its, Ksubset = Ksubset, Knew = Knew,
+        K_top_matches = K_top_matches, heuristic_match_thin = heuristic_match_thin,
+        small_ref_panel_gibbs_iterations = small_ref_panel_gibbs_iterations,
+        small_ref_panel_block_gibbs_iterations = as.integer(small_ref_panel_block_gibbs_iterations - 1L),   ## 0-based, as impute_one_sample passes them on
+        maxDifferenceBetweenReads = maxDifferenceBetweenReads, minGLValue = minGLValue, Jmax = 10000,   ## functions.R:688
+        seed = if (is.na(seed)) 1 else as.numeric(seed),
+        device = as.numeric(device),   ## 0-based, modulo the number of GPUs: mclapply's iCore - 1 (one R worker per GPU: nCores = GPUs)
+        sum_order = sum_order
+    )
+    if (!is.na(n_burn_in_seek_its)) params[["n_burn_in_seek_its"]] <- n_burn_in_seek_its
+    if (use_mspbwt) {
+        params <- c(params, list(use_mspbwt = TRUE, mspbwtL = mspbwtL, mspbwtM = mspbwtM, mspbwt_nindices = mspbwt_nindices))
+    }
+    if (method == "nipt") {
+        params <- c(params, list(method = "nipt", shuffle_bin_radius = shuffle_bin_radius))
+        panel_objects[["L_grid"]] <- as.numeric(L_grid)
+    }
+    if (impute_rare_common) {
+        params[["impute_rare_common"]] <- TRUE
+        panel_objects[["rare_common"]] <- list(
+            snp_is_common = special_rare_common_objects[["snp_is_common"]],
+            rare_per_hap_info = special_rare_common_objects[["rare_per_hap_info"]],
+            transMatRate_t = special_rare_common_objects[["small_transMatRate_tc_H"]][, , 1],
+            L_grid = as.numeric(special_rare_common_objects[["L_grid"]])
+        )
+    }
+    ## ---- (a) native I/O: BAM paths in, VCF columns and the range's counts out (one call)
+    if (quilt_amd_native_io_is_covered(bam_files, cram_files, use_bx_tag, pos, pos_all, impute_rare_common)) {
+        sites <- list(
+            chr = chr, L = as.integer(L), ref = as.character(pos[, 3]), alt = as.character(pos[, 4]), grid = as.integer(grid),
+            bqFilter = bqFilter, iSizeUpperLimit = iSizeUpperLimit, useSoftClippedBases = useSoftClippedBases,
+            downsampleToCov = downsampleToCov, chrStart = chrStart, chrEnd = chrEnd,
+            minimum_number_of_sample_reads = minimum_number_of_sample_reads,
+            output_gt_phased_genotypes = output_gt_phased_genotypes
+        )
+        if (impute_rare_common) {
+            sites <- c(sites, list(
+                L_all = as.integer(pos_all[, 2]), ref_all = as.character(pos_all[, 3]), alt_all = as.character(pos_all[, 4]),
+                grid_all = as.integer(special_rare_common_objects[["grid"]])
+            ))
+        }
+        if (method == "nipt") params[["ff"]] <- as.numeric(ff_values[w])
+        print_message(paste0("Imputing samples ", w[1], " to ", w[n], " on the GPU from their BAM files (", n, " samples in one call)"))
+        out <- .Call("qa_impute_bam_range", as.character(bam_files[w]), sites, panel_objects, params, as.numeric(w - 1L),
+                     as.integer(n_handles), PACKAGE = "QUILT")
+        results <- as.list(1:n)
+        nS <- length(out[["afCount"]])
+        ## The loop of quilt.R:955-961 adds eij / fij / max_gen / per_sample_alleleCount of every imputed sample to the core's four
+        ## count arrays.  The call returns those sums for the whole range, formed in sample order (the same floating-point sums):
+        ## the patched loop adds them ONCE (attribute "quilt_amd_counts", QUILT-R.patch) and every sample contributes exact zeros
+        ## here -- one shared zero vector, nothing per sample and SNP crosses into R but the column itself.
+        zero1 <- rep(0, nS)
+        zero2 <- array(0, c(nS, 2))
+        no_gen <- matrix(0L, nrow = 0, ncol = 2)
+        for(i in 1:n) {
+            if (!out[["sample_was_imputed"]][i]) {
+                print_message(paste0("Sample number ", w[i], " with sample name ", sampleNames[w[i]], " has ", out[["n_reads"]][i], " reads which is fewer than the minimum ", minimum_number_of_sample_reads, ". This sample will therefore not be imputed and all results will be set to missing"))
+                results[[i]] <- list(sample_was_imputed = FALSE, per_sample_vcf_col = "./.:.,.,.:.:.,.")
+                next
+            }
+            results[[i]] <- list(
+                sample_was_imputed = TRUE, eij = zero1, fij = zero1, max_gen = no_gen, per_sample_alleleCount = zero2,
+                per_sample_vcf_col = out[["per_sample_vcf_col"]][[i]],
+                super_out_hap_dosages = NULL, super_out_read_labels = out[["read_labels"]][[i]],
+                super_out_dosage_matrix = NULL, final_read_labels_prob = as.list(1:3)
+            )
+        }
+        attr(results, "quilt_amd_counts") <- out[c("infoCount", "afCount", "hweCount", "alleleCount")]
+        attr(results, "quilt_amd_seconds") <- out[["seconds"]]
+        return(results)
+    }
+    ## ---- (b) R I/O around the call
     load1 <- function(iSample, L, pos, grid) {
         quilt_amd_load_sample(
             iSample = iSample, L = L, pos = pos, bam_files = bam_files, cram_files = cram_files, reference = reference,
@@ -107,45 +210,16 @@ quilt_amd_impute_sample_range <- function(
         return(results)
     }
     ## ---- 2. the ONE call: every chain of every kept sample of the range, in lock-step on the device
-    panel_objects <- list(
-        hapMatcherR = hapMatcherR, distinctHapsB = distinctHapsB, distinctHapsIE = distinctHapsIE,
-        eMatDH_special_matrix_helper = eMatDH_special_matrix_helper, eMatDH_special_matrix = eMatDH_special_matrix,
-        rhb_t = rhb_t, transMatRate_t = small_transMatRate_tc_H[, , 1], ref_error = ref_error,
-        use_eMatDH_special_symbols = as.integer(use_eMatDH_special_symbols)
-    )
-    params <- list(
-        nGibbsSamples = nGibbsSamples, n_seek_its = n_seek_its, Ksubset = Ksubset, Knew = Knew,
-        K_top_matches = K_top_matches, heuristic_match_thin = heuristic_match_thin,
-        small_ref_panel_gibbs_iterations = small_ref_panel_gibbs_iterations,
-        small_ref_panel_block_gibbs_iterations = as.integer(small_ref_panel_block_gibbs_iterations - 1L),   ## 0-based, as impute_one_sample passes them on
-        maxDifferenceBetweenReads = maxDifferenceBetweenReads, minGLValue = minGLValue, Jmax = 10000,   ## functions.R:688
-        seed = if (is.na(seed)) 1 else as.numeric(seed),
-        device = as.numeric(device)   ## 0-based, modulo the number of GPUs: mclapply's iCore - 1 (one R worker per GPU: nCores = GPUs)
-    )
-    if (!is.na(n_burn_in_seek_its)) params[["n_burn_in_seek_its"]] <- n_burn_in_seek_its
-    if (use_mspbwt) {
-        params <- c(params, list(use_mspbwt = TRUE, mspbwtL = mspbwtL, mspbwtM = mspbwtM, mspbwt_nindices = mspbwt_nindices))
-    }
-    if (method == "nipt") {
-        params <- c(params, list(method = "nipt", ff = as.numeric(ff_values[w[keep]]), shuffle_bin_radius = shuffle_bin_radius))
-        panel_objects[["L_grid"]] <- as.numeric(L_grid)
-    }
+    if (method == "nipt") params[["ff"]] <- as.numeric(ff_values[w[keep]])
     all_reads <- NULL
     if (impute_rare_common) {
-        params[["impute_rare_common"]] <- TRUE
-        panel_objects[["rare_common"]] <- list(
-            snp_is_common = special_rare_common_objects[["snp_is_common"]],
-            rare_per_hap_info = special_rare_common_objects[["rare_per_hap_info"]],
-            transMatRate_t = special_rare_common_objects[["small_transMatRate_tc_H"]][, , 1],
-            L_grid = as.numeric(special_rare_common_objects[["L_grid"]])
-        )
         all_reads <- lapply(loaded_all[keep], "[[", "sampleReads")
     }
     print_message(paste0("Imputing samples ", w[keep[1]], " to ", w[keep[length(keep)]], " on the GPU (", length(keep), " samples in one call)"))
     out <- .Call(
         "qa_impute_sample_range", lapply(loaded[keep], "[[", "sampleReads"), panel_objects, params,
-        as.numeric(w[keep[1]] - 1L),   ## (streams are keyed by the global sample index: kept samples of a range are consecutive
-                                       ##  in the call; a skipped sample shifts the later ones' streams, not their validity)
+        as.numeric(w[keep] - 1L),      ## every kept sample's own global index: its streams do not depend on which other samples
+                                       ## of the range were skipped
         as.integer(n_handles), all_reads, PACKAGE = "QUILT"
     )
     ## ---- 3. per sample, what get_and_impute_one_sample returns (functions.R:1304-1463)

@@ -52,6 +52,7 @@
 #include <string.h>
 
 #include "../include/quilt_amd.h"
+#include "../include/quilt_amd_io.h"   /* qa_impute_bam_range */
 
 /* ---- small helpers ---------------------------------------------------------------------------------------------- */
 
@@ -152,6 +153,11 @@ static qa_panel_t *panel_for(SEXP hapMatcher, SEXP hapMatcherR, int use_hapMatch
     const int st = qa_panel_create(&d, &p);
     free(which);
     check_status(st, "qa_panel_create");
+    {   /* QUILT_AMD_SUM_ORDER (Sys.setenv before the first call; read when the panel is uploaded): 1 / 2 = the VALIDATION MODE of
+         * the full-panel passes (include/quilt_amd.h, qa_panel_set_sum_order) for the per-call entries as well */
+        const char *e = getenv("QUILT_AMD_SUM_ORDER");
+        if (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) check_status(qa_panel_set_sum_order(p, e[0] - '0'), "qa_panel_set_sum_order");
+    }
     g_cache.panel = p; g_cache.key_B = kB; g_cache.key_hm = kh;
     g_cache.K = K; g_cache.G = G; g_cache.T = T; g_cache.nMaxDH = nMaxDH;
     g_cache.ref_error = ref_error; g_cache.checksum = sum;
@@ -626,56 +632,92 @@ static int flatten_reads(SEXP readsListSEXP, flat_reads_t *f) {
     return 0;
 }
 
-SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP, SEXP sample_offsetSEXP, SEXP n_handlesSEXP,
-                            SEXP allReadsListSEXP) {
-    const int n = Rf_length(readsListSEXP);
-    int n_handles = Rf_asInteger(n_handlesSEXP);
-    if (n_handles < 1) n_handles = 1;
-    if (n_handles > 16) n_handles = 16;
+/* What the two range routines share: the panel handles (one per host thread), the parameter struct with its msPBWT index,
+ * all-SNP handles and NIPT block, from the R objects `panel_objects` and `params`. */
+typedef struct {
+    int K, G, T, T_out, n_handles, nipt, rare;
+    qa_panel_t *handles[16];
+    int made;
+    qa_impute_params_t ip;
+    qa_mspbwt_t *index;
+    qa_impute_rare_common_t rcq;
+    qa_rare_common_t *rcs[16];
+    int n_rc;
+    int64_t *rare_ptr;
+    int32_t *rare_snp, *L_grid_all, *L_grid;
+    uint8_t *is_common;
+    qa_impute_nipt_t nq;
+    char msg[512];
+} range_ctx_t;
+
+/* Every check that can raise an R error comes first: nothing is allocated yet, nothing can leak (an R error longjmps). */
+static void range_validate(SEXP panelSEXP, SEXP paramsSEXP, const char *who) {
     SEXP hapMatcherR = list_get(panelSEXP, "hapMatcherR"), distinctHapsB = list_get(panelSEXP, "distinctHapsB");
     SEXP distinctHapsIE = list_get(panelSEXP, "distinctHapsIE"), tm = list_get(panelSEXP, "transMatRate_t");
     SEXP helper = list_get(panelSEXP, "eMatDH_special_matrix_helper"), spmat = list_get(panelSEXP, "eMatDH_special_matrix");
     SEXP rhb_t = list_get(panelSEXP, "rhb_t");
     if (hapMatcherR == R_NilValue || distinctHapsB == R_NilValue || distinctHapsIE == R_NilValue || tm == R_NilValue ||
         helper == R_NilValue || spmat == R_NilValue)
-        Rf_error("quilt_amd: qa_impute_sample_range: panel_objects needs hapMatcherR, distinctHapsB, distinctHapsIE, "
-                 "eMatDH_special_matrix_helper, eMatDH_special_matrix, transMatRate_t");
-    const int K = Rf_nrows(hapMatcherR), G = Rf_ncols(hapMatcherR), T = Rf_ncols(distinctHapsIE);
-    /* ---- every check that can raise an R error comes first: nothing is allocated yet, nothing can leak */
-    validate_reads_list(readsListSEXP, "list_of_sampleReads");
-    if (allReadsListSEXP != R_NilValue) validate_reads_list(allReadsListSEXP, "list_of_allSNP_sampleReads");
+        Rf_error("quilt_amd: %s: panel_objects needs hapMatcherR, distinctHapsB, distinctHapsIE, "
+                 "eMatDH_special_matrix_helper, eMatDH_special_matrix, transMatRate_t", who);
     if (TYPEOF(hapMatcherR) != RAWSXP || TYPEOF(distinctHapsB) != INTSXP || TYPEOF(distinctHapsIE) != REALSXP || TYPEOF(tm) != REALSXP ||
         TYPEOF(helper) != INTSXP || TYPEOF(spmat) != INTSXP || (rhb_t != R_NilValue && TYPEOF(rhb_t) != INTSXP))
-        Rf_error("quilt_amd: qa_impute_sample_range: panel_objects: hapMatcherR must be raw, distinctHapsB / eMatDH_special_matrix(_helper) / "
-                 "rhb_t integer, distinctHapsIE / transMatRate_t numeric");
+        Rf_error("quilt_amd: %s: panel_objects: hapMatcherR must be raw, distinctHapsB / eMatDH_special_matrix(_helper) / "
+                 "rhb_t integer, distinctHapsIE / transMatRate_t numeric", who);
+    const int G = Rf_ncols(hapMatcherR);
     if (Rf_length(tm) != 2 * (G > 1 ? G - 1 : 0))
-        Rf_error("quilt_amd: qa_impute_sample_range: panel_objects$transMatRate_t must be 2 x (nGrids - 1)");
-    {
-        SEXP rc0 = list_get(panelSEXP, "rare_common");
-        SEXP rph0 = rc0 == R_NilValue ? R_NilValue : list_get(rc0, "rare_per_hap_info");
-        if (rph0 != R_NilValue) {
-            if (TYPEOF(rph0) != VECSXP) Rf_error("quilt_amd: qa_impute_sample_range: rare_common$rare_per_hap_info must be a list");
-            for (int k = 0; k < Rf_length(rph0); k++)
-                if (TYPEOF(VECTOR_ELT(rph0, k)) != INTSXP && Rf_length(VECTOR_ELT(rph0, k)) > 0)
-                    Rf_error("quilt_amd: qa_impute_sample_range: rare_common$rare_per_hap_info[[%d]] must be an integer vector", k + 1);
-            SEXP sic0 = list_get(rc0, "snp_is_common"), tma0 = list_get(rc0, "transMatRate_t");
-            if ((sic0 != R_NilValue && TYPEOF(sic0) != LGLSXP) || (tma0 != R_NilValue && TYPEOF(tma0) != REALSXP))
-                Rf_error("quilt_amd: qa_impute_sample_range: rare_common$snp_is_common must be logical, $transMatRate_t numeric");
-        }
+        Rf_error("quilt_amd: %s: panel_objects$transMatRate_t must be 2 x (nGrids - 1)", who);
+    SEXP rc0 = list_get(panelSEXP, "rare_common");
+    SEXP rph0 = rc0 == R_NilValue ? R_NilValue : list_get(rc0, "rare_per_hap_info");
+    if (rph0 != R_NilValue) {
+        if (TYPEOF(rph0) != VECSXP) Rf_error("quilt_amd: %s: rare_common$rare_per_hap_info must be a list", who);
+        for (int k = 0; k < Rf_length(rph0); k++)
+            if (TYPEOF(VECTOR_ELT(rph0, k)) != INTSXP && Rf_length(VECTOR_ELT(rph0, k)) > 0)
+                Rf_error("quilt_amd: %s: rare_common$rare_per_hap_info[[%d]] must be an integer vector", who, k + 1);
+        SEXP sic0 = list_get(rc0, "snp_is_common"), tma0 = list_get(rc0, "transMatRate_t");
+        if ((sic0 != R_NilValue && TYPEOF(sic0) != LGLSXP) || (tma0 != R_NilValue && TYPEOF(tma0) != REALSXP))
+            Rf_error("quilt_amd: %s: rare_common$snp_is_common must be logical, $transMatRate_t numeric", who);
     }
     const double seed_d = num_or(paramsSEXP, "seed", 1);
     if (!(seed_d >= 0) || seed_d > 9007199254740992.0 /* 2^53 */ || seed_d != floor(seed_d))   /* (NA / NaN fail the first test) */
-        Rf_error("quilt_amd: qa_impute_sample_range: params$seed must be a non-negative whole number below 2^53");
+        Rf_error("quilt_amd: %s: params$seed must be a non-negative whole number below 2^53", who);
+    const double so = num_or(paramsSEXP, "sum_order", 0);
+    if (!(so == 0 || so == 1 || so == 2)) Rf_error("quilt_amd: %s: params$sum_order must be 0, 1 or 2 (include/quilt_amd.h: qa_panel_set_sum_order)", who);
+    SEXP blocks = list_get(paramsSEXP, "small_ref_panel_block_gibbs_iterations");
+    if (blocks != R_NilValue && TYPEOF(blocks) != INTSXP)
+        Rf_error("quilt_amd: %s: params$small_ref_panel_block_gibbs_iterations must be an integer vector (0-based sweeps)", who);
     /* which GPU: params$device (0-based; taken modulo the number of devices, so that mclapply's iCore - 1 can be passed as it
      * is); absent: the process's current device.  Forked workers must make their first HIP call after the fork -- this one. */
-    {
-        const double dev_d = num_or(paramsSEXP, "device", -1);
-        if (dev_d >= 0) {
-            const int n_dev = qa_device_count();
-            if (n_dev < 1) Rf_error("quilt_amd: qa_impute_sample_range: no gfx950 device (libquilt_amd has no CPU fallback)");
-            check_status(qa_set_device((int)dev_d % n_dev), "qa_set_device");
-        }
+    const double dev_d = num_or(paramsSEXP, "device", -1);
+    if (dev_d >= 0) {
+        const int n_dev = qa_device_count();
+        if (n_dev < 1) Rf_error("quilt_amd: %s: no gfx950 device (libquilt_amd has no CPU fallback)", who);
+        check_status(qa_set_device((int)dev_d % n_dev), "qa_set_device");
     }
+}
+
+static void range_teardown(range_ctx_t *cx) {
+    for (int i = 0; i < cx->n_rc; i++) if (cx->rcs[i]) qa_rare_common_destroy(cx->rcs[i]);
+    if (cx->index) qa_mspbwt_destroy(cx->index);
+    free(cx->rare_ptr); free(cx->rare_snp); free(cx->is_common); free(cx->L_grid); free(cx->L_grid_all);
+    for (int i = 0; i < cx->made; i++) if (cx->handles[i]) qa_panel_destroy(cx->handles[i]);
+    cx->n_rc = 0; cx->made = 0; cx->index = NULL;
+    cx->rare_ptr = NULL; cx->rare_snp = NULL; cx->is_common = NULL; cx->L_grid = NULL; cx->L_grid_all = NULL;
+}
+
+/* Raises no R error: returns a QA status with the text in cx->msg; on failure everything made so far is torn down again.
+ * `n_sample`: what params$ff must have one entry of (method = "nipt"); the fetus' outputs and ff are the caller's to set. */
+static int range_setup(range_ctx_t *cx, SEXP panelSEXP, SEXP paramsSEXP, int n_handles, int n_sample) {
+    memset(cx, 0, sizeof *cx);
+    SEXP hapMatcherR = list_get(panelSEXP, "hapMatcherR"), distinctHapsB = list_get(panelSEXP, "distinctHapsB");
+    SEXP distinctHapsIE = list_get(panelSEXP, "distinctHapsIE"), tm = list_get(panelSEXP, "transMatRate_t");
+    SEXP helper = list_get(panelSEXP, "eMatDH_special_matrix_helper"), spmat = list_get(panelSEXP, "eMatDH_special_matrix");
+    SEXP rhb_t = list_get(panelSEXP, "rhb_t");
+    const int K = cx->K = Rf_nrows(hapMatcherR), G = cx->G = Rf_ncols(hapMatcherR), T = cx->T = Rf_ncols(distinctHapsIE);
+    cx->T_out = T;
+    if (n_handles < 1) n_handles = 1;
+    if (n_handles > 16) n_handles = 16;
+    cx->n_handles = n_handles;
     /* one handle per host thread: replicas of the panel on this process's device, taking the device in turn */
     qa_panel_desc_t d;
     memset(&d, 0, sizeof d);
@@ -686,7 +728,7 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
     d.distinctHapsB = INTEGER(distinctHapsB);
     d.distinctHapsIE = REAL(distinctHapsIE);
     int *which = (int *)calloc((size_t)(G > 0 ? G : 1), sizeof(int));
-    if (!which) Rf_error("quilt_amd: qa_impute_sample_range: out of memory");   /* (nothing else is live yet) */
+    if (!which) { snprintf(cx->msg, sizeof cx->msg, "out of memory"); return QA_ERR_INVALID; }
     int nsp = 0;
     for (int g = 0; g < G; g++)
         if (Rf_nrows(helper) == G && INTEGER(helper)[g] > 0) which[g] = ++nsp;
@@ -697,161 +739,186 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
     d.use_eMatDH_special_symbols = !have_rhb || (int)num_or(panelSEXP, "use_eMatDH_special_symbols", 0);
     d.transMatRate_t = REAL(tm);
     d.ref_error = num_or(panelSEXP, "ref_error", 1e-3);
-    qa_panel_t *handles[16];
-    int made = 0, st = QA_OK;
-    for (; made < n_handles && st == QA_OK; made++) {
-        handles[made] = NULL;
-        st = qa_panel_create(&d, &handles[made]);
-        if (st == QA_OK) st = qa_panel_set_device_share(handles[made], n_handles);
-        if (st == QA_OK && n_handles > 1) st = qa_panel_set_exclusive(handles[made], 1);
-        if (st == QA_OK) st = qa_panel_set_dosage_precision(handles[made], 64);   /* the reference computes in double */
+    /* params$sum_order (quilt-amd.R takes it from QUILT_AMD_SUM_ORDER): 0 = production kernels; 1 = VALIDATION MODE, every K-wide
+     * sum of the full-panel passes in the order the reference's code adds it (bit-identical to the CPU package's lists, 20-50x
+     * slower passes); 2 = the same with grid 0's Armadillo sum read left to right (include/quilt_amd.h) */
+    const int sum_order = (int)num_or(paramsSEXP, "sum_order", 0);
+    int st = QA_OK;
+    for (; cx->made < n_handles && st == QA_OK; cx->made++) {
+        cx->handles[cx->made] = NULL;
+        st = qa_panel_create(&d, &cx->handles[cx->made]);
+        if (st == QA_OK) st = qa_panel_set_device_share(cx->handles[cx->made], n_handles);
+        if (st == QA_OK && n_handles > 1) st = qa_panel_set_exclusive(cx->handles[cx->made], 1);
+        if (st == QA_OK) st = qa_panel_set_dosage_precision(cx->handles[cx->made], 64);   /* the reference computes in double */
+        if (st == QA_OK && sum_order) st = qa_panel_set_sum_order(cx->handles[cx->made], sum_order);
     }
     free(which);
     if (st != QA_OK) {
-        for (int i = 0; i < made; i++) if (handles[i]) qa_panel_destroy(handles[i]);
-        check_status(st, "qa_panel_create");
+        snprintf(cx->msg, sizeof cx->msg, "qa_panel_create: %s", qa_last_error());
+        range_teardown(cx);
+        return st;
     }
-    char msg[512];
-    msg[0] = 0;
-    /* flatten the range's sampleReads */
-    flat_reads_t fr;
-    if (flatten_reads(readsListSEXP, &fr) != 0) {
-        for (int i = 0; i < made; i++) if (handles[i]) qa_panel_destroy(handles[i]);
-        Rf_error("quilt_amd: qa_impute_sample_range: out of memory flattening the sampleReads");
-    }
-    const int32_t *read_off = fr.read_off;
-    const int totR = read_off[n];
-    qa_impute_params_t ip;
-    qa_impute_params_default(&ip);
-    ip.nGibbsSamples = (int)num_or(paramsSEXP, "nGibbsSamples", ip.nGibbsSamples);
-    ip.n_seek_its = (int)num_or(paramsSEXP, "n_seek_its", ip.n_seek_its);
-    ip.n_burn_in_seek_its = (int)num_or(paramsSEXP, "n_burn_in_seek_its", -1);   /* NA -> n_seek_its - 1 (quilt.R:248-250) */
-    ip.Ksubset = (int)num_or(paramsSEXP, "Ksubset", ip.Ksubset);
-    ip.Knew = (int)num_or(paramsSEXP, "Knew", ip.Knew);
-    ip.K_top_matches = (int)num_or(paramsSEXP, "K_top_matches", ip.K_top_matches);
-    ip.heuristic_match_thin = num_or(paramsSEXP, "heuristic_match_thin", ip.heuristic_match_thin);
-    ip.small_ref_panel_gibbs_iterations = (int)num_or(paramsSEXP, "small_ref_panel_gibbs_iterations", ip.small_ref_panel_gibbs_iterations);
+    qa_impute_params_t *ip = &cx->ip;
+    qa_impute_params_default(ip);
+    ip->nGibbsSamples = (int)num_or(paramsSEXP, "nGibbsSamples", ip->nGibbsSamples);
+    ip->n_seek_its = (int)num_or(paramsSEXP, "n_seek_its", ip->n_seek_its);
+    ip->n_burn_in_seek_its = (int)num_or(paramsSEXP, "n_burn_in_seek_its", -1);   /* NA -> n_seek_its - 1 (quilt.R:248-250) */
+    ip->Ksubset = (int)num_or(paramsSEXP, "Ksubset", ip->Ksubset);
+    ip->Knew = (int)num_or(paramsSEXP, "Knew", ip->Knew);
+    ip->K_top_matches = (int)num_or(paramsSEXP, "K_top_matches", ip->K_top_matches);
+    ip->heuristic_match_thin = num_or(paramsSEXP, "heuristic_match_thin", ip->heuristic_match_thin);
+    ip->small_ref_panel_gibbs_iterations = (int)num_or(paramsSEXP, "small_ref_panel_gibbs_iterations", ip->small_ref_panel_gibbs_iterations);
     SEXP blocks = list_get(paramsSEXP, "small_ref_panel_block_gibbs_iterations");
     if (blocks != R_NilValue && TYPEOF(blocks) == INTSXP) {
-        ip.small_ref_panel_block_gibbs_iterations = INTEGER(blocks);
-        ip.n_block_gibbs_iterations = Rf_length(blocks);
+        ip->small_ref_panel_block_gibbs_iterations = INTEGER(blocks);
+        ip->n_block_gibbs_iterations = Rf_length(blocks);
     }
-    ip.maxDifferenceBetweenReads = num_or(paramsSEXP, "maxDifferenceBetweenReads", ip.maxDifferenceBetweenReads);
-    ip.minGLValue = num_or(paramsSEXP, "minGLValue", ip.minGLValue);
-    ip.Jmax = (int)num_or(paramsSEXP, "Jmax", ip.Jmax);
-    ip.seed = (uint64_t)seed_d;   /* (range-checked above) */
-    ip.samples_per_launch_set = (int)num_or(paramsSEXP, "samples_per_launch_set", 0);
+    ip->maxDifferenceBetweenReads = num_or(paramsSEXP, "maxDifferenceBetweenReads", ip->maxDifferenceBetweenReads);
+    ip->minGLValue = num_or(paramsSEXP, "minGLValue", ip->minGLValue);
+    ip->Jmax = (int)num_or(paramsSEXP, "Jmax", ip->Jmax);
+    ip->seed = (uint64_t)num_or(paramsSEXP, "seed", 1);   /* (range-checked by range_validate) */
+    ip->samples_per_launch_set = (int)num_or(paramsSEXP, "samples_per_launch_set", 0);
     /* use_mspbwt = TRUE (QUILT2's default; mspbwt.R:225-474): the panel's indices, built here */
-    qa_mspbwt_t *index = NULL;
     if (flag(paramsSEXP, "use_mspbwt", 0)) {
-        ip.use_mspbwt = 1;
-        ip.mspbwtL = (int)num_or(paramsSEXP, "mspbwtL", ip.mspbwtL);
-        ip.mspbwtM = (int)num_or(paramsSEXP, "mspbwtM", ip.mspbwtM);
-        index = qa_mspbwt_create(K, G, RAW(hapMatcherR), d.nMaxDH, INTEGER(distinctHapsB), (int)num_or(paramsSEXP, "mspbwt_nindices", 4));
-        if (!index) { st = QA_ERR_INVALID; snprintf(msg, sizeof msg, "qa_mspbwt_create: %s", qa_last_error()); }
-        ip.mspbwt_index = index;
+        ip->use_mspbwt = 1;
+        ip->mspbwtL = (int)num_or(paramsSEXP, "mspbwtL", ip->mspbwtL);
+        ip->mspbwtM = (int)num_or(paramsSEXP, "mspbwtM", ip->mspbwtM);
+        cx->index = qa_mspbwt_create(K, G, RAW(hapMatcherR), d.nMaxDH, INTEGER(distinctHapsB), (int)num_or(paramsSEXP, "mspbwt_nindices", 4));
+        if (!cx->index) { st = QA_ERR_INVALID; snprintf(cx->msg, sizeof cx->msg, "qa_mspbwt_create: %s", qa_last_error()); }
+        ip->mspbwt_index = cx->index;
     }
-    /* impute_rare_common = TRUE (functions.R:1042-1123): one all-SNP handle per panel handle, the all-SNP reads */
-    qa_impute_rare_common_t rcq;
-    qa_rare_common_t *rcs[16];
-    int n_rc = 0, T_out = T;
-    flat_reads_t fa;
-    memset(&fa, 0, sizeof fa);
-    memset(&rcq, 0, sizeof rcq);
-    int64_t *rare_ptr = NULL;
-    int32_t *rare_snp = NULL, *L_grid_all = NULL;
-    uint8_t *is_common = NULL;
-    const int rare = flag(paramsSEXP, "impute_rare_common", 0);
-    if (st == QA_OK && rare) {
+    /* impute_rare_common = TRUE (functions.R:1042-1123): one all-SNP handle per panel handle (the all-SNP reads are the caller's) */
+    cx->rare = flag(paramsSEXP, "impute_rare_common", 0);
+    if (st == QA_OK && cx->rare) {
         SEXP rc = list_get(panelSEXP, "rare_common");
         SEXP sic = rc == R_NilValue ? R_NilValue : list_get(rc, "snp_is_common"), rph = rc == R_NilValue ? R_NilValue : list_get(rc, "rare_per_hap_info");
         SEXP tma = rc == R_NilValue ? R_NilValue : list_get(rc, "transMatRate_t"), lga = rc == R_NilValue ? R_NilValue : list_get(rc, "L_grid");
-        if (sic == R_NilValue || rph == R_NilValue || tma == R_NilValue || Rf_length(rph) != K || allReadsListSEXP == R_NilValue ||
-            Rf_length(allReadsListSEXP) != n) {
+        if (sic == R_NilValue || rph == R_NilValue || tma == R_NilValue || Rf_length(rph) != K) {
             st = QA_ERR_INVALID;
-            snprintf(msg, sizeof msg, "impute_rare_common: panel_objects$rare_common needs snp_is_common, rare_per_hap_info (one entry per "
-                                      "haplotype), transMatRate_t; and one allSNP_sampleReads per sample");
+            snprintf(cx->msg, sizeof cx->msg, "impute_rare_common: panel_objects$rare_common needs snp_is_common, rare_per_hap_info (one entry per "
+                                              "haplotype), transMatRate_t");
         } else {
-            T_out = Rf_length(sic);
-            is_common = (uint8_t *)malloc((size_t)(T_out > 0 ? T_out : 1));
-            rare_ptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)K + 1));
-            if (is_common && rare_ptr) {
-                for (int t = 0; t < T_out; t++) is_common[t] = LOGICAL(sic)[t] ? 1 : 0;
-                rare_ptr[0] = 0;
-                for (int k = 0; k < K; k++) rare_ptr[k + 1] = rare_ptr[k] + Rf_length(VECTOR_ELT(rph, k));
-                rare_snp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rare_ptr[K] > 0 ? rare_ptr[K] : 1));
+            const int T_out = cx->T_out = Rf_length(sic);
+            cx->is_common = (uint8_t *)malloc((size_t)(T_out > 0 ? T_out : 1));
+            cx->rare_ptr = (int64_t *)malloc(sizeof(int64_t) * ((size_t)K + 1));
+            if (cx->is_common && cx->rare_ptr) {
+                for (int t = 0; t < T_out; t++) cx->is_common[t] = LOGICAL(sic)[t] ? 1 : 0;
+                cx->rare_ptr[0] = 0;
+                for (int k = 0; k < K; k++) cx->rare_ptr[k + 1] = cx->rare_ptr[k] + Rf_length(VECTOR_ELT(rph, k));
+                cx->rare_snp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cx->rare_ptr[K] > 0 ? cx->rare_ptr[K] : 1));
             }
-            if (!is_common || !rare_ptr || !rare_snp || flatten_reads(allReadsListSEXP, &fa) != 0) {
+            if (!cx->is_common || !cx->rare_ptr || !cx->rare_snp) {
                 st = QA_ERR_INVALID;
-                snprintf(msg, sizeof msg, "out of memory preparing the rare + common inputs");
+                snprintf(cx->msg, sizeof cx->msg, "out of memory preparing the rare + common inputs");
             }
             for (int k = 0; st == QA_OK && k < K; k++)
-                if (rare_ptr[k + 1] > rare_ptr[k])
-                    memcpy(rare_snp + rare_ptr[k], INTEGER(VECTOR_ELT(rph, k)), sizeof(int) * (size_t)(rare_ptr[k + 1] - rare_ptr[k]));
-            for (; n_rc < n_handles && st == QA_OK; n_rc++) {
-                rcs[n_rc] = NULL;
-                st = qa_rare_common_create(handles[n_rc], T_out, is_common, rare_ptr, rare_snp, REAL(tma), &rcs[n_rc]);
+                if (cx->rare_ptr[k + 1] > cx->rare_ptr[k])
+                    memcpy(cx->rare_snp + cx->rare_ptr[k], INTEGER(VECTOR_ELT(rph, k)), sizeof(int) * (size_t)(cx->rare_ptr[k + 1] - cx->rare_ptr[k]));
+            for (; cx->n_rc < n_handles && st == QA_OK; cx->n_rc++) {
+                cx->rcs[cx->n_rc] = NULL;
+                st = qa_rare_common_create(cx->handles[cx->n_rc], T_out, cx->is_common, cx->rare_ptr, cx->rare_snp, REAL(tma), &cx->rcs[cx->n_rc]);
             }
-            if (st != QA_OK && !msg[0]) snprintf(msg, sizeof msg, "qa_rare_common_create: %s", qa_last_error());
-            rcq.handles = (const qa_rare_common_t *const *)rcs;
-            rcq.nSNPs_all = T_out;
-            rcq.nGrids_all = (T_out + 31) / 32;
-            rcq.snp_is_common = is_common;
-            rcq.read_off = fa.read_off; rcq.read_ptr = fa.read_ptr; rcq.u = fa.u; rcq.bq = fa.bq; rcq.wif = fa.wif;
-            if (lga != R_NilValue && Rf_length(lga) == rcq.nGrids_all) {
-                L_grid_all = (int32_t *)malloc(sizeof(int32_t) * (size_t)rcq.nGrids_all);
-                for (int g = 0; L_grid_all && g < rcq.nGrids_all; g++) L_grid_all[g] = TYPEOF(lga) == INTSXP ? INTEGER(lga)[g] : (int32_t)REAL(lga)[g];
-                rcq.L_grid_all = L_grid_all;
+            if (st != QA_OK && !cx->msg[0]) snprintf(cx->msg, sizeof cx->msg, "qa_rare_common_create: %s", qa_last_error());
+            cx->rcq.handles = (const qa_rare_common_t *const *)cx->rcs;
+            cx->rcq.nSNPs_all = T_out;
+            cx->rcq.nGrids_all = (T_out + 31) / 32;
+            cx->rcq.snp_is_common = cx->is_common;
+            if (st == QA_OK && lga != R_NilValue && Rf_length(lga) == cx->rcq.nGrids_all) {
+                cx->L_grid_all = (int32_t *)malloc(sizeof(int32_t) * (size_t)cx->rcq.nGrids_all);
+                for (int g = 0; cx->L_grid_all && g < cx->rcq.nGrids_all; g++)
+                    cx->L_grid_all[g] = TYPEOF(lga) == INTSXP ? INTEGER(lga)[g] : (int32_t)REAL(lga)[g];
+                cx->rcq.L_grid_all = cx->L_grid_all;
             }
-            ip.rare_common = &rcq;
+            ip->rare_common = &cx->rcq;
         }
     }
-    /* method = "nipt" (functions.R:586, :1009-1016, :1218-1231): one fetal fraction per sample, the fetus' outputs */
-    qa_impute_nipt_t nq;
-    memset(&nq, 0, sizeof nq);
+    /* method = "nipt" (functions.R:586, :1009-1016, :1218-1231): one fetal fraction per sample, the block definition's grid */
     SEXP methodSEXP = list_get(paramsSEXP, "method");
-    const int nipt = methodSEXP != R_NilValue && TYPEOF(methodSEXP) == STRSXP && Rf_length(methodSEXP) == 1 &&
-                     strcmp(CHAR(STRING_ELT(methodSEXP, 0)), "nipt") == 0;
-    const int nL = nipt ? 3 : 2;
-    int32_t *L_grid = NULL;
-    SEXP fet_dosage = R_NilValue, fet_gp_t = R_NilValue;
-    int n_prot = 0;
-    if (st == QA_OK && nipt) {
+    cx->nipt = methodSEXP != R_NilValue && TYPEOF(methodSEXP) == STRSXP && Rf_length(methodSEXP) == 1 &&
+               strcmp(CHAR(STRING_ELT(methodSEXP, 0)), "nipt") == 0;
+    if (st == QA_OK && cx->nipt) {
         SEXP ff = list_get(paramsSEXP, "ff"), lg = list_get(panelSEXP, "L_grid");
-        if (ff == R_NilValue || TYPEOF(ff) != REALSXP || Rf_length(ff) != n || lg == R_NilValue || Rf_length(lg) != G) {
+        if (ff == R_NilValue || TYPEOF(ff) != REALSXP || Rf_length(ff) != n_sample || lg == R_NilValue || Rf_length(lg) != G) {
             st = QA_ERR_INVALID;
-            snprintf(msg, sizeof msg, "method = \"nipt\": params$ff (one per sample, numeric) and panel_objects$L_grid (nGrids) are needed");
+            snprintf(cx->msg, sizeof cx->msg, "method = \"nipt\": params$ff (one per sample, numeric) and panel_objects$L_grid (nGrids) are needed");
         } else {
-            L_grid = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
-            if (!L_grid) { st = QA_ERR_INVALID; snprintf(msg, sizeof msg, "out of memory"); }
-            for (int g = 0; L_grid && g < G; g++) L_grid[g] = TYPEOF(lg) == INTSXP ? INTEGER(lg)[g] : (int32_t)REAL(lg)[g];
-            fet_dosage = PROTECT(Rf_allocMatrix(REALSXP, T_out, n));
-            fet_gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T_out, n));
-            n_prot = 2;
-            nq.ff = REAL(ff);
-            nq.L_grid = L_grid;
-            nq.shuffle_bin_radius = (int)num_or(paramsSEXP, "shuffle_bin_radius", 5000);
-            nq.fet_dosage = REAL(fet_dosage);
-            nq.fet_gp_t = REAL(fet_gp_t);
-            ip.nipt = &nq;
+            cx->L_grid = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
+            if (!cx->L_grid) { st = QA_ERR_INVALID; snprintf(cx->msg, sizeof cx->msg, "out of memory"); }
+            for (int g = 0; cx->L_grid && g < G; g++) cx->L_grid[g] = TYPEOF(lg) == INTSXP ? INTEGER(lg)[g] : (int32_t)REAL(lg)[g];
+            cx->nq.ff = REAL(ff);
+            cx->nq.L_grid = cx->L_grid;
+            cx->nq.shuffle_bin_radius = (int)num_or(paramsSEXP, "shuffle_bin_radius", 5000);
+            ip->nipt = &cx->nq;
         }
+    }
+    if (st != QA_OK) range_teardown(cx);
+    return st;
+}
+
+/* sample_offset: ONE number (sample i of the call is global sample offset + i) or one 0-based global index PER SAMPLE -- the
+ * form quilt-amd.R uses, so that a sample skipped for too few reads does not shift the streams of the samples behind it */
+static int64_t *sample_index_of(SEXP sample_offsetSEXP, int n) {
+    if (Rf_length(sample_offsetSEXP) != n || n <= 1) return NULL;   /* (n == 1: offset and index are the same thing) */
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    for (int i = 0; idx && i < n; i++)
+        idx[i] = TYPEOF(sample_offsetSEXP) == INTSXP ? (int64_t)INTEGER(sample_offsetSEXP)[i] : (int64_t)REAL(sample_offsetSEXP)[i];
+    return idx;
+}
+
+SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP, SEXP sample_offsetSEXP, SEXP n_handlesSEXP,
+                            SEXP allReadsListSEXP) {
+    static const char *who = "qa_impute_sample_range";
+    const int n = Rf_length(readsListSEXP);
+    validate_reads_list(readsListSEXP, "list_of_sampleReads");
+    if (allReadsListSEXP != R_NilValue) validate_reads_list(allReadsListSEXP, "list_of_allSNP_sampleReads");
+    range_validate(panelSEXP, paramsSEXP, who);
+    if ((TYPEOF(sample_offsetSEXP) != REALSXP && TYPEOF(sample_offsetSEXP) != INTSXP) ||
+        (Rf_length(sample_offsetSEXP) != 1 && Rf_length(sample_offsetSEXP) != n))
+        Rf_error("quilt_amd: %s: sample_offset must be one number or one global index per sample", who);
+    if (flag(paramsSEXP, "impute_rare_common", 0) && (allReadsListSEXP == R_NilValue || Rf_length(allReadsListSEXP) != n))
+        Rf_error("quilt_amd: %s: impute_rare_common needs one allSNP_sampleReads per sample", who);
+    range_ctx_t cx;
+    int st = range_setup(&cx, panelSEXP, paramsSEXP, Rf_asInteger(n_handlesSEXP), n);
+    if (st != QA_OK) Rf_error("quilt_amd: %s: %s", who, cx.msg);
+    const int T_out = cx.T_out, nL = cx.nipt ? 3 : 2;
+    /* flatten the range's sampleReads */
+    flat_reads_t fr, fa;
+    memset(&fa, 0, sizeof fa);
+    if (flatten_reads(readsListSEXP, &fr) != 0 || (cx.rare && flatten_reads(allReadsListSEXP, &fa) != 0)) {
+        if (fr.read_off) flat_reads_free(&fr);
+        range_teardown(&cx);
+        Rf_error("quilt_amd: %s: out of memory flattening the sampleReads", who);
+    }
+    if (cx.rare) { cx.rcq.read_off = fa.read_off; cx.rcq.read_ptr = fa.read_ptr; cx.rcq.u = fa.u; cx.rcq.bq = fa.bq; cx.rcq.wif = fa.wif; }
+    const int32_t *read_off = fr.read_off;
+    const int totR = read_off[n];
+    int n_prot = 0;
+    SEXP fet_dosage = R_NilValue, fet_gp_t = R_NilValue;
+    if (cx.nipt) {
+        fet_dosage = PROTECT(Rf_allocMatrix(REALSXP, T_out, n));
+        fet_gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T_out, n));
+        n_prot = 2;
+        cx.nq.fet_dosage = REAL(fet_dosage);
+        cx.nq.fet_gp_t = REAL(fet_gp_t);
     }
     SEXP dosage = PROTECT(Rf_allocMatrix(REALSXP, T_out, n)), gp_t = PROTECT(Rf_allocMatrix(REALSXP, 3 * T_out, n));
     SEXP haps = PROTECT(Rf_allocMatrix(REALSXP, nL * T_out, n)), nDosage = PROTECT(Rf_allocVector(INTSXP, n));
     SEXP stats = PROTECT(Rf_allocVector(REALSXP, 11));
     int32_t *labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)(totR > 0 ? totR : 1));
-    if (!labels && st == QA_OK) { st = QA_ERR_INVALID; snprintf(msg, sizeof msg, "out of memory"); }
+    int64_t *sidx = sample_index_of(sample_offsetSEXP, n);
+    char msg[512];
+    msg[0] = 0;
+    if (!labels || (Rf_length(sample_offsetSEXP) == n && n > 1 && !sidx)) { st = QA_ERR_INVALID; snprintf(msg, sizeof msg, "out of memory"); }
     int64_t st64[11] = {0};
     if (st == QA_OK) {
-        st = qa_impute_samples(handles, n_handles, &ip, n, (int64_t)Rf_asReal(sample_offsetSEXP), read_off, fr.read_ptr, fr.u, fr.bq, fr.wif,
-                               REAL(dosage), REAL(gp_t), REAL(haps), labels, INTEGER(nDosage), st64);
+        cx.ip.sample_index = sidx;
+        st = qa_impute_samples(cx.handles, cx.n_handles, &cx.ip, n, sidx ? 0 : (int64_t)Rf_asReal(sample_offsetSEXP), read_off, fr.read_ptr, fr.u,
+                               fr.bq, fr.wif, REAL(dosage), REAL(gp_t), REAL(haps), labels, INTEGER(nDosage), st64);
         if (st != QA_OK) snprintf(msg, sizeof msg, "qa_impute_samples: %s", qa_last_error());
     }
-    for (int i = 0; i < n_rc; i++) if (rcs[i]) qa_rare_common_destroy(rcs[i]);
-    if (index) qa_mspbwt_destroy(index);
-    free(rare_ptr); free(rare_snp); free(is_common); free(L_grid); free(L_grid_all);
+    range_teardown(&cx);
+    free(sidx);
     if (fa.read_off) flat_reads_free(&fa);
-    for (int i = 0; i < n_handles; i++) qa_panel_destroy(handles[i]);
     SEXP lab = PROTECT(Rf_allocVector(VECSXP, n));
     if (st == QA_OK)
         for (int i = 0; i < n; i++) {
@@ -865,15 +932,169 @@ SEXP qa_impute_sample_range(SEXP readsListSEXP, SEXP panelSEXP, SEXP paramsSEXP,
     free(labels);
     if (st != QA_OK) {
         UNPROTECT(6 + n_prot);
-        Rf_error("quilt_amd: qa_impute_sample_range: %s", msg);
+        Rf_error("quilt_amd: %s: %s", who, msg);
     }
     for (int i = 0; i < 11; i++) REAL(stats)[i] = (double)st64[i];
     const char *names[] = {"dosage", "gp_t", "phasing_haps", "read_labels", "nDosage", "stats", "fet_dosage", "fet_gp_t"};
-    SEXP out = PROTECT(named_list(nipt ? 8 : 6, names));
+    SEXP out = PROTECT(named_list(cx.nipt ? 8 : 6, names));
     SET_VECTOR_ELT(out, 0, dosage); SET_VECTOR_ELT(out, 1, gp_t); SET_VECTOR_ELT(out, 2, haps);
     SET_VECTOR_ELT(out, 3, lab); SET_VECTOR_ELT(out, 4, nDosage); SET_VECTOR_ELT(out, 5, stats);
-    if (nipt) { SET_VECTOR_ELT(out, 6, fet_dosage); SET_VECTOR_ELT(out, 7, fet_gp_t); }
+    if (cx.nipt) { SET_VECTOR_ELT(out, 6, fet_dosage); SET_VECTOR_ELT(out, 7, fet_gp_t); }
     UNPROTECT(7 + n_prot);
+    return out;
+}
+
+/* ---- qa_impute_bam_range: the same loop body from BAM PATHS to VCF COLUMNS, natively ------------------------------------------
+ * qa_impute_sample_range above leaves both ends of get_and_impute_one_sample to R: STITCH's loadBamAndConvert + load() +
+ * snap_sampleReads_to_grid per sample in front of the call (functions.R:243-298) and the per-sample column / count code behind
+ * it (functions.R:1380-1463) -- about a second per sample on the R worker that owns a GPU which imputes ~40 per second.  This
+ * routine is the whole body of the loop over a core's samples (quilt.R:832-982) behind one `.Call`:
+ *     out <- .Call("qa_impute_bam_range", bam_files, sites, panel_objects, params, sample_index, n_handles)
+ *   bam_files       character vector: the range's BAM files (bamlist order)
+ *   sites           named list: chr; L (pos[, 2]), ref, alt (pos[, 3:4] as character vectors of single letters), grid (0-based);
+ *                   impute_rare_common: L_all / ref_all / alt_all / grid_all (pos_all, special_rare_common_objects$grid);
+ *                   loader options bqFilter, iSizeUpperLimit, useSoftClippedBases, downsampleToCov, chrStart, chrEnd (the
+ *                   window of functions.R:262-263); minimum_number_of_sample_reads, output_gt_phased_genotypes, n_io_threads
+ *   panel_objects, params, n_handles   as for qa_impute_sample_range (params$ff: one per FILE)
+ *   sample_index    0-based global index of every file's sample (iSample - 1)
+ * Returns list(sample_was_imputed (logical), n_reads (integer), per_sample_vcf_col (list: character vector per imputed sample,
+ * NULL otherwise), read_labels (list), infoCount (nSNPs x 2), afCount, hweCount (nSNPs x 3), alleleCount (nSNPs x 2): the
+ * range's sums in sample order as quilt.R:955-961 forms them; seconds (load, impute, format, total), stats).  The loader is
+ * csrc/hostio.cpp's (include/quilt_amd_io.h says where it is unpinned against STITCH: CRAM is refused); quilt-amd.R calls this
+ * routine only for the options it implements and falls back to the R loader otherwise. */
+static const char *one_string(SEXP list, const char *name) {
+    SEXP v = list_get(list, name);
+    return (v != R_NilValue && TYPEOF(v) == STRSXP && Rf_length(v) == 1) ? CHAR(STRING_ELT(v, 0)) : NULL;
+}
+/* a character vector of single letters -> n bytes; NULL when an entry is not one letter (nothing allocated then) */
+static char *letters_of(SEXP v, int n) {
+    if (v == R_NilValue || TYPEOF(v) != STRSXP || Rf_length(v) != n) return NULL;
+    for (int i = 0; i < n; i++) if (strlen(CHAR(STRING_ELT(v, i))) != 1) return NULL;
+    char *out = (char *)malloc((size_t)(n > 0 ? n : 1));
+    for (int i = 0; out && i < n; i++) out[i] = CHAR(STRING_ELT(v, i))[0];
+    return out;
+}
+static void range_result_finalizer(SEXP p) {
+    qa_bam_range_result_t *r = (qa_bam_range_result_t *)R_ExternalPtrAddr(p);
+    if (r) qa_bam_range_destroy(r);
+    R_ClearExternalPtr(p);
+}
+static int32_t *ints_of(SEXP v, int n) {
+    if (v == R_NilValue || (TYPEOF(v) != INTSXP && TYPEOF(v) != REALSXP) || Rf_length(v) != n) return NULL;
+    int32_t *out = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; out && i < n; i++) out[i] = TYPEOF(v) == INTSXP ? INTEGER(v)[i] : (int32_t)REAL(v)[i];
+    return out;
+}
+
+SEXP qa_impute_bam_range_call(SEXP bamFilesSEXP, SEXP sitesSEXP, SEXP panelSEXP, SEXP paramsSEXP, SEXP sample_indexSEXP, SEXP n_handlesSEXP) {
+    static const char *who = "qa_impute_bam_range";
+    if (TYPEOF(bamFilesSEXP) != STRSXP) Rf_error("quilt_amd: %s: bam_files must be a character vector", who);
+    const int n = Rf_length(bamFilesSEXP);
+    if ((TYPEOF(sample_indexSEXP) != REALSXP && TYPEOF(sample_indexSEXP) != INTSXP) || Rf_length(sample_indexSEXP) != n)
+        Rf_error("quilt_amd: %s: sample_index must hold one 0-based global index per file", who);
+    range_validate(panelSEXP, paramsSEXP, who);
+    const char *chr = one_string(sitesSEXP, "chr");
+    SEXP Lx = list_get(sitesSEXP, "L");
+    if (!chr || Lx == R_NilValue) Rf_error("quilt_amd: %s: sites needs chr, L, ref, alt, grid", who);
+    const int T = Rf_length(Lx);
+    if (T != Rf_ncols(list_get(panelSEXP, "distinctHapsIE"))) Rf_error("quilt_amd: %s: sites$L must have one entry per SNP of the panel", who);
+    const int rare = flag(paramsSEXP, "impute_rare_common", 0);
+    const int Ta = rare ? Rf_length(list_get(sitesSEXP, "L_all")) : 0;
+    /* the sites as plain arrays (malloc: freed below on every path; R errors are raised only before or after) */
+    int32_t *L = ints_of(Lx, T), *grid = ints_of(list_get(sitesSEXP, "grid"), T);
+    char *ref = letters_of(list_get(sitesSEXP, "ref"), T), *alt = letters_of(list_get(sitesSEXP, "alt"), T);
+    int32_t *La = rare ? ints_of(list_get(sitesSEXP, "L_all"), Ta) : NULL, *grida = rare ? ints_of(list_get(sitesSEXP, "grid_all"), Ta) : NULL;
+    char *refa = rare ? letters_of(list_get(sitesSEXP, "ref_all"), Ta) : NULL, *alta = rare ? letters_of(list_get(sitesSEXP, "alt_all"), Ta) : NULL;
+    const char **paths = (const char **)malloc(sizeof(char *) * (size_t)(n > 0 ? n : 1));
+    int64_t *sidx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    const int sites_ok = L && grid && ref && alt && paths && sidx && (!rare || (La && grida && refa && alta));
+    range_ctx_t cx;
+    memset(&cx, 0, sizeof cx);
+    int st = QA_OK;
+    char msg[512];
+    msg[0] = 0;
+    if (!sites_ok) {
+        st = QA_ERR_INVALID;
+        snprintf(msg, sizeof msg, "sites: L / grid numeric, ref / alt character vectors of single letters, all of the panel's length%s",
+                 rare ? " (and L_all / grid_all / ref_all / alt_all over all SNPs)" : "");
+    }
+    if (st == QA_OK) {
+        st = range_setup(&cx, panelSEXP, paramsSEXP, Rf_asInteger(n_handlesSEXP), n);
+        if (st != QA_OK) snprintf(msg, sizeof msg, "%s", cx.msg);
+    }
+    qa_bam_range_result_t *res = NULL;
+    if (st == QA_OK) {
+        for (int i = 0; i < n; i++) {
+            paths[i] = CHAR(STRING_ELT(bamFilesSEXP, i));
+            sidx[i] = TYPEOF(sample_indexSEXP) == INTSXP ? (int64_t)INTEGER(sample_indexSEXP)[i] : (int64_t)REAL(sample_indexSEXP)[i];
+        }
+        qa_bam_range_io_t io;
+        memset(&io, 0, sizeof io);
+        io.chr = chr; io.nSNPs = T; io.L = L; io.ref = ref; io.alt = alt; io.grid = grid;
+        io.nSNPs_all = Ta; io.L_all = La; io.ref_all = refa; io.alt_all = alta; io.grid_all = grida;
+        qa_bam_opts_default(&io.bam);
+        io.bam.bqFilter = (int)num_or(sitesSEXP, "bqFilter", io.bam.bqFilter);
+        {
+            const double isz = num_or(sitesSEXP, "iSizeUpperLimit", io.bam.iSizeUpperLimit);
+            io.bam.iSizeUpperLimit = isz > 2147483647.0 ? 2147483647 : (int)isz;
+        }
+        io.bam.useSoftClippedBases = flag(sitesSEXP, "useSoftClippedBases", 0);
+        io.bam.downsampleToCov = (int)num_or(sitesSEXP, "downsampleToCov", io.bam.downsampleToCov);
+        io.bam.chrStart = (int)num_or(sitesSEXP, "chrStart", 0);
+        io.bam.chrEnd = (int)num_or(sitesSEXP, "chrEnd", 0);
+        io.minimum_number_of_sample_reads = (int)num_or(sitesSEXP, "minimum_number_of_sample_reads", 2);
+        io.output_gt_phased_genotypes = flag(sitesSEXP, "output_gt_phased_genotypes", 1);
+        io.n_io_threads = (int)num_or(sitesSEXP, "n_io_threads", 0);
+        st = qa_impute_bam_range(cx.handles, cx.n_handles, &cx.ip, &io, n, paths, sidx, cx.nipt ? cx.nq.ff : NULL, &res);
+        if (st != QA_OK) snprintf(msg, sizeof msg, "%s", qa_last_error());
+        range_teardown(&cx);
+    }
+    free(L); free(grid); free(ref); free(alt); free(La); free(grida); free(refa); free(alta); free((void *)paths); free(sidx);
+    if (st != QA_OK) {
+        if (res) qa_bam_range_destroy(res);
+        Rf_error("quilt_amd: %s: %s", who, msg);
+    }
+    /* results as R objects.  (An allocation failure inside R longjmps past the end of this routine: the result is handed to an
+     * external pointer with a finalizer first, so that the collector frees it in that case; it is freed explicitly below otherwise.) */
+    SEXP guard = PROTECT(R_MakeExternalPtr(res, R_NilValue, R_NilValue));
+    R_RegisterCFinalizerEx(guard, range_result_finalizer, TRUE);
+    const int T_out = qa_bam_range_n_snps(res);
+    const char *names[] = {"sample_was_imputed", "n_reads", "per_sample_vcf_col", "read_labels", "infoCount", "afCount", "hweCount",
+                           "alleleCount", "seconds", "stats"};
+    SEXP out = PROTECT(named_list(10, names));
+    SEXP imputed = PROTECT(Rf_allocVector(LGLSXP, n)), n_reads = PROTECT(Rf_allocVector(INTSXP, n));
+    SEXP cols = PROTECT(Rf_allocVector(VECSXP, n)), labs = PROTECT(Rf_allocVector(VECSXP, n));
+    SET_VECTOR_ELT(out, 0, imputed); SET_VECTOR_ELT(out, 1, n_reads); SET_VECTOR_ELT(out, 2, cols); SET_VECTOR_ELT(out, 3, labs);
+    for (int i = 0; i < n; i++) {
+        LOGICAL(imputed)[i] = qa_bam_range_imputed(res, i);
+        INTEGER(n_reads)[i] = qa_bam_range_n_reads(res, i);
+        const char *buf = NULL;
+        const int64_t *off = NULL;
+        qa_bam_range_column(res, i, &buf, &off);
+        if (!buf) continue;
+        SEXP col = PROTECT(Rf_allocVector(STRSXP, T_out));
+        for (int t = 0; t < T_out; t++) SET_STRING_ELT(col, t, Rf_mkChar(buf + off[t]));
+        SET_VECTOR_ELT(cols, i, col);
+        UNPROTECT(1);
+        const int32_t *rl = NULL;
+        int32_t nl = 0;
+        qa_bam_range_sample(res, i, NULL, NULL, NULL, NULL, NULL, &rl, &nl, NULL);
+        SEXP v = PROTECT(Rf_allocVector(INTSXP, nl));
+        if (nl > 0) memcpy(INTEGER(v), rl, sizeof(int) * (size_t)nl);
+        SET_VECTOR_ELT(labs, i, v);
+        UNPROTECT(1);
+    }
+    SEXP info = PROTECT(Rf_allocMatrix(REALSXP, T_out, 2)), af = PROTECT(Rf_allocVector(REALSXP, T_out));
+    SEXP hwe = PROTECT(Rf_allocMatrix(REALSXP, T_out, 3)), ac = PROTECT(Rf_allocMatrix(REALSXP, T_out, 2));
+    qa_bam_range_counts(res, REAL(info), REAL(af), REAL(hwe), REAL(ac));
+    SET_VECTOR_ELT(out, 4, info); SET_VECTOR_ELT(out, 5, af); SET_VECTOR_ELT(out, 6, hwe); SET_VECTOR_ELT(out, 7, ac);
+    SEXP sec = PROTECT(Rf_allocVector(REALSXP, 4)), stats = PROTECT(Rf_allocVector(REALSXP, 11));
+    int64_t st64[11] = {0};
+    qa_bam_range_timings(res, REAL(sec), st64, NULL);
+    for (int i = 0; i < 11; i++) REAL(stats)[i] = (double)st64[i];
+    SET_VECTOR_ELT(out, 8, sec); SET_VECTOR_ELT(out, 9, stats);
+    range_result_finalizer(guard);
+    UNPROTECT(12);
     return out;
 }
 
@@ -888,6 +1109,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"_QUILT_rcpp_make_eMatRead_t", (DL_FUNC)&qa_QUILT_rcpp_make_eMatRead_t, 15},
     {"qa_shim_release", (DL_FUNC)&qa_shim_release, 0},
     {"qa_impute_sample_range", (DL_FUNC)&qa_impute_sample_range, 6},
+    {"qa_impute_bam_range", (DL_FUNC)&qa_impute_bam_range_call, 6},
     {NULL, NULL, 0}};
 
 void R_init_quilt_amd_shim(DllInfo *dll) {

@@ -32,7 +32,8 @@ class R:
                                 ("mini_r_set_names", None, [P, C.c_int, C.POINTER(C.c_char_p)]), ("SET_VECTOR_ELT", P, [P, C.c_ssize_t, P]),
                                 ("VECTOR_ELT", P, [P, C.c_ssize_t]), ("STRING_ELT", P, [P, C.c_ssize_t]), ("CHAR", C.c_char_p, [P]),
                                 ("TYPEOF", C.c_int, [P]), ("Rf_xlength", C.c_ssize_t, [P]), ("Rf_nrows", C.c_int, [P]),
-                                ("Rf_ncols", C.c_int, [P]), ("Rf_getAttrib", P, [P, P]), ("Rf_mkString", P, [C.c_char_p]),
+                                ("Rf_ncols", C.c_int, [P]), ("Rf_getAttrib", P, [P, P]), ("Rf_mkString", P, [C.c_char_p]), ("Rf_mkChar", P, [C.c_char_p]),
+                                ("SET_STRING_ELT", None, [P, C.c_ssize_t, P]),
                                 ("mini_r_dotcall", P, [C.c_char_p, C.c_int, C.POINTER(P)]), ("mini_r_last_error", C.c_char_p, []),
                                 ("mini_r_arity", C.c_int, [C.c_char_p]), ("mini_r_load_unif", None, [C.POINTER(C.c_double), C.c_size_t]),
                                 ("mini_r_unif_drawn", C.c_size_t, []), ("mini_r_rng_violations", C.c_int, []),
@@ -73,6 +74,13 @@ class R:
     def string(self, s: str):
         return C.c_void_p(self.L.Rf_mkString(s.encode()))
 
+    def strings(self, items):
+        """A character vector."""
+        v = C.c_void_p(self.L.Rf_allocVector(STRSXP, len(items)))
+        for i, x in enumerate(items):
+            self.L.SET_STRING_ELT(v, i, C.c_void_p(self.L.Rf_mkChar(x.encode())))
+        return v
+
     def list(self, items, names=None):
         v = C.c_void_p(self.L.Rf_allocVector(VECSXP, len(items)))
         for i, x in enumerate(items):
@@ -97,6 +105,8 @@ class R:
             if nm.value != self.nil.value:
                 return {self.L.CHAR(self.L.STRING_ELT(nm, i)).decode(): items[i] for i in range(n)}
             return items
+        if t == STRSXP:
+            return [self.L.CHAR(self.L.STRING_ELT(x, i)).decode() for i in range(n)]
         dt = {LGLSXP: np.int32, INTSXP: np.int32, REALSXP: np.float64, RAWSXP: np.uint8}.get(t)
         if dt is None:
             raise TypeError(f"mini_r: type {t}")

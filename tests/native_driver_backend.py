@@ -293,3 +293,29 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
     if st != 0:
         raise RuntimeError(f"qa_impute_samples_backend: status {st}: {L.qa_last_error().decode()}")
     return wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off, fd, fg), dict(zip(STAT_NAMES, stats.tolist())), tab
+
+
+def impute_bam_range_on_oracle(panel, bam_files, chr, ref, alt, params, n_threads=1, **kw):
+    """qa_impute_bam_range_backend (csrc/bamrange.cpp through the private test hook): the product's loader, kept-sample
+    bookkeeping, column formatting and count arrays, with the imputation step on the oracle table."""
+    from quilt_amd.impute import impute_bam_range
+
+    class _Dev:   # (what impute_bam_range reads of a DevicePanel: the panel; there is no native handle on this path)
+        def __init__(self, p):
+            self.panel, self.handle = p, None
+
+    tab = OracleTable(panel)
+    handles = (C.c_void_p * n_threads)(*[C.c_void_p(w + 1) for w in range(n_threads)])
+    L = lib()
+    L.qa_impute_bam_range_backend.restype = C.c_int
+    L.qa_last_error.restype = C.c_char_p
+
+    def entry(q, io, n, paths, sidx, ffv, h):
+        st = L.qa_impute_bam_range_backend(C.byref(tab.table), handles, C.c_int32(n_threads), C.c_int32(panel.K), C.c_int32(panel.nGrids),
+                                           C.byref(q), C.byref(io), C.c_int32(n), paths, ptr(sidx), ptr(ffv), C.byref(h))
+        if tab.error is not None:
+            raise tab.error
+        if st != 0:
+            raise RuntimeError(f"qa_impute_bam_range_backend: status {st}: {L.qa_last_error().decode()}")
+
+    return impute_bam_range([_Dev(panel)] * n_threads, bam_files, chr, ref, alt, params, _entry=entry, **kw)

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 10
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
-    assert lib.qa_abi_version() == 4
+    assert lib.qa_abi_version() == 5
 
 
 def test_no_cpu_fallback_without_a_device(lib):

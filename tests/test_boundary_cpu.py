@@ -44,7 +44,7 @@ def test_r_shim_defines_no_symbol_of_rcppexports(tmp_path):
     defined = [ln.split()[-1] for ln in nm.splitlines() if ln.strip()]
     assert defined, nm
     assert not [d for d in defined if d.startswith("_QUILT_")], defined
-    allowed = {"qa" + n for n, _ in ENTRIES} | {"qa_shim_release", "R_init_quilt_amd_shim", "qa_impute_sample_range"}
+    allowed = {"qa" + n for n, _ in ENTRIES} | {"qa_shim_release", "R_init_quilt_amd_shim", "qa_impute_sample_range", "qa_impute_bam_range_call"}
     assert set(defined) == allowed, sorted(set(defined) ^ allowed)
 
 

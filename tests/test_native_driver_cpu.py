@@ -226,3 +226,39 @@ print("HASH", h.hexdigest(), stats["gibbs_launches"])
         out[cut] = (line[1], int(line[2]))
     assert out["0"][0] == out["1"][0]
     assert out["1"][1] > out["0"][1]   # (the cut plan makes more, smaller launches)
+
+
+@pytest.mark.parametrize("method", ["diploid", "nipt"])
+def test_bam_range_call_equals_the_python_bam_to_vcf_path(tmp_path, small_panel, method):
+    """qa_impute_bam_range (csrc/bamrange.cpp: BAM paths in, VCF columns and the range's count arrays out, one native call --
+    what shim/quilt-amd.R's fast path calls) against quilt_amd.io.impute_bams_to_vcf (loader -> Python driver -> column writers ->
+    SummaryCounts), both on the oracle's entry points: the same column TEXT for every sample, the unimputed sample reported as
+    such, the same read labels, and the four count arrays (quilt.R:955-961) equal bit for bit.  The dropped file sits in the
+    middle of the range: the kept samples' global indices are handed over one by one (qa_impute_params_t.sample_index), so its
+    absence does not shift anyone's random streams."""
+    from quilt_amd.driver import DriverParams
+    from tests.native_driver_backend import impute_bam_range_on_oracle
+    from tests.oracle_backend import OracleBackend
+    from tests.test_driver_host import _bam_to_vcf
+    ff = 0.2 if method == "nipt" else None
+    prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method=method)
+    rows, rec, _ = _bam_to_vcf(tmp_path, small_panel, OracleBackend(small_panel), method=method, ff=ff, prm=prm)
+    # the same files, alleles and parameters (test_driver_host._bam_to_vcf draws the alleles from this stream)
+    rng = np.random.default_rng(21)
+    alleles = [tuple(rng.choice(list("ACGT"), size=2, replace=False)) for _ in range(small_panel.nSNPs)]
+    ref, alt = [a for a, _ in alleles], [b for _, b in alleles]
+    bams = [str(tmp_path / n) for n in ("s0.bam", "empty.bam", "s1.bam", "s2.bam")]
+    # impute_bams_to_vcf numbers the samples it keeps 0, 1, 2: the global indices of the kept files here (the dropped one's is unused)
+    got = impute_bam_range_on_oracle(small_panel, bams, "chr20", ref, alt, prm, sample_index=[0, 99, 1, 2],
+                                     ff=None if ff is None else [ff] * 4, n_io_threads=3, samples_per_launch_set=2)
+    assert got["imputed"] == [True, False, True, True] and got["n_reads"][1] == 0 and got["columns"][1] is None
+    for i in (0, 2, 3):
+        assert got["columns"][i].tolist() == rec["columns"][i].tolist() == [r[9 + i] for r in rows]
+        assert np.array_equal(got["results"][i].read_labels, rec["results"][i].read_labels)
+        assert np.array_equal(got["results"][i].gp_t, rec["results"][i].gp_t)
+    for name in ("infoCount", "afCount", "hweCount", "alleleCount"):
+        assert np.array_equal(getattr(got["counts"], name), getattr(rec["counts"], name)), name
+    # and with other global indices the draws differ (the indices are what keys them)
+    other = impute_bam_range_on_oracle(small_panel, bams, "chr20", ref, alt, prm, sample_index=[5, 99, 6, 7],
+                                       ff=None if ff is None else [ff] * 4)
+    assert not all(np.array_equal(other["results"][i].read_labels, got["results"][i].read_labels) for i in (0, 2, 3))

@@ -360,3 +360,60 @@ def test_gibbs_entry_63_arguments_rare_common(R, panel):
     assert out["hapProbs_t"].shape == (3, Ta)
     assert np.array_equal(out["H"], want["H"]) and np.array_equal(out["hapProbs_t"], want["hapProbs_t"])
     assert np.array_equal(out["genProbsM_t"], want["genProbsM_t"])
+
+
+@pytest.mark.parametrize("method", ["diploid", "nipt"])
+def test_bam_range_call_from_paths_to_columns(R, tmp_path, method):
+    """`.Call("qa_impute_bam_range", bam_files, sites, panel_objects, params, sample_index, n_handles)` -- what shim/quilt-amd.R's
+    fast path calls: the BAM files are loaded, imputed, formatted and counted natively behind one call.
+      * production mode: every sample's per_sample_vcf_col is the TEXT the Python BAM -> VCF path (quilt_amd.io.impute_bams_to_vcf:
+        loader, Python driver on the same device, column writers) puts into its file, the file without reads comes back as not
+        imputed, and the range's four count arrays equal SummaryCounts' bit for bit;
+      * params$sum_order = 1 (the validation knob R reaches through QUILT_AMD_SUM_ORDER): the text equals the CPU path's.
+    """
+    from quilt_amd.driver import DriverParams, HipBackend
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_panel
+    from tests.oracle_backend import OracleBackend
+    from tests.test_driver_host import _bam_to_vcf
+    small = make_synthetic_panel(K=1000, nSNPs=640, seed=4916)
+    ff = 0.2 if method == "nipt" else None
+    prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, method=method)
+    for d in ("gpu", "cpu"):
+        (tmp_path / d).mkdir()
+    dev = DevicePanel(small)
+    dev.set_dosage_precision(64)
+    rows_g, rec_g, _ = _bam_to_vcf(tmp_path / "gpu", small, HipBackend(dev), method=method, ff=ff, prm=prm)
+    dev.close()
+    rows_c, rec_c, _ = _bam_to_vcf(tmp_path / "cpu", small, OracleBackend(small), method=method, ff=ff, prm=prm)
+    rng = np.random.default_rng(21)   # (the alleles test_driver_host._bam_to_vcf drew)
+    alleles = [tuple(rng.choice(list("ACGT"), size=2, replace=False)) for _ in range(small.nSNPs)]
+    ref, alt = [a for a, _ in alleles], [b for _, b in alleles]
+    bams = [str(tmp_path / "gpu" / n) for n in ("s0.bam", "empty.bam", "s1.bam", "s2.bam")]
+    sites = dict(chr=R.string("chr20"), L=R.integer(small.L), ref=R.strings(ref), alt=R.strings(alt),
+                 grid=R.integer(np.arange(small.nSNPs) // 32), minimum_number_of_sample_reads=R.integer([2]),
+                 output_gt_phased_genotypes=R.logical([1]), n_io_threads=R.integer([3]))
+    more = dict(method=R.string("nipt"), ff=R.real([ff] * 4), shuffle_bin_radius=R.integer([prm.shuffle_bin_radius])) if ff else {}
+    pan = lambda: R.panel_objects(small, **(dict(L_grid=R.real(np.asarray(small.L_grid, dtype=np.float64))) if ff else {}))
+    assert R.arity("qa_impute_bam_range") == 6
+    # impute_bams_to_vcf numbers the samples it keeps 0, 1, 2: the kept files' global indices here
+    out = R.dotcall("qa_impute_bam_range", R.strings(bams), R.named(sites), pan(), _params(R, prm, **more), R.real([0.0, 99.0, 1.0, 2.0]),
+                    R.integer([2]))
+    assert out["sample_was_imputed"].tolist() == [1, 0, 1, 1] and out["n_reads"][1] == 0 and out["per_sample_vcf_col"][1] is None
+    for i in (0, 2, 3):
+        assert out["per_sample_vcf_col"][i] == [r[9 + i] for r in rows_g]
+        assert np.array_equal(out["read_labels"][i], rec_g["results"][i].read_labels)
+    for name in ("infoCount", "afCount", "hweCount", "alleleCount"):
+        assert np.array_equal(out[name], getattr(rec_g["counts"], name)), name
+    assert out["seconds"][3] >= out["seconds"][1] > 0
+    val = R.dotcall("qa_impute_bam_range", R.strings(bams), R.named(sites), pan(), _params(R, prm, sum_order=R.integer([1]), **more),
+                    R.real([0.0, 99.0, 1.0, 2.0]), R.integer([2]))
+    for i in (0, 2, 3):
+        assert val["per_sample_vcf_col"][i] == [r[9 + i] for r in rows_c]
+    from tests.mini_r import RError
+    with pytest.raises(RError, match="cannot load"):
+        R.dotcall("qa_impute_bam_range", R.strings([str(tmp_path / "nope.bam")]), R.named(sites), pan(),
+                  _params(R, prm, **(dict(more, ff=R.real([ff])) if ff else {})), R.real([0.0]), R.integer([1]))
+    with pytest.raises(RError, match="sum_order"):
+        R.dotcall("qa_impute_bam_range", R.strings(bams), R.named(sites), pan(), _params(R, prm, sum_order=R.integer([7]), **more),
+                  R.real([0.0, 99.0, 1.0, 2.0]), R.integer([2]))
