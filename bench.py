@@ -368,6 +368,8 @@ def main():
                          "dosage passes in a second timed region of their own, reported under `mixed_precision` (the default until round 4; "
                          "since the CPU baseline is measured on whole samples -- six minutes of wall -- the default run is the fp64 region alone)")
     ap.add_argument("--fp64-dosage", action="store_true", help="(older spelling of --precision fp64)")
+    ap.add_argument("--io-threads", type=int, default=0,
+                    help="--bam: host threads of qa_impute_bam_range's loading and formatting (0 = min(32, hardware threads))")
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
@@ -516,8 +518,7 @@ def main():
         import torch  # noqa: F401  (before libquilt_amd.so is loaded: both must resolve the HIP runtime torch ships, see main())
         flat, bam_load_s = reload_from_bams(panel, flat, seeds, bam_dir)
         a.bam_load_s = bam_load_s
-        import shutil
-        shutil.rmtree(bam_dir, ignore_errors=True)
+        a.bam_dir = bam_dir   # (kept for the I/O-inclusive leg after the timed region; removed there)
     samples = [flat[st * a.batch:(st + 1) * a.batch] for st in range(n_steps)]
     cpu_pipeline = None
     if rank == 0 and world == 1 and cpu is not None and a.cpu_baseline == "whole" and not a.mspbwt:
@@ -685,6 +686,37 @@ def main():
             t_l = time.perf_counter()
             impute_samples(drv.devs[:1], samples[-1][:1], DriverParams(**params), sample_offset=10 ** 6, drcs=drv.drcs[:1])
             out["one_sample_latency_s"] = round(time.perf_counter() - t_l, 3)
+        if getattr(a, "bam_dir", None) and native is not None and world == 1 and a.driver == "native" and hasattr(drv, "devs"):
+            # --bam: the SAME K timed steps once more through qa_impute_bam_range (csrc/bamrange.cpp: what shim/quilt-amd.R's fast path
+            # calls) -- BAM paths in, VCF columns and count arrays out, loading and formatting on host threads INSIDE the clock.
+            # `value` stays the compute-only rate (inputs resident in host memory); this is the rate with the I/O either side.
+            from quilt_amd.impute import impute_bam_range
+            from quilt_amd.synth import synthetic_alleles
+            ref, alt = synthetic_alleles(panel.nSNPs, 1)
+            t_seeds = seeds[a.warmup * a.batch:n_steps * a.batch]
+            files = [os.path.join(a.bam_dir, f"s{sd}.bam") for sd in t_seeds]
+            t_io = time.perf_counter()
+            r_io = impute_bam_range(drv.devs, files, "chr20", ref, alt, DriverParams(**params),
+                                    sample_index=[(rank * n_steps + a.warmup) * a.batch + i for i in range(len(files))],
+                                    ff=[0.2] * len(files) if a.mode == "nipt" else None, samples_per_launch_set=a.batch * a.fuse,
+                                    fuse_tails=bool(a.fuse_tails), downsampleToCov=0, bqFilter=1, n_io_threads=a.io_threads)
+            t_io = time.perf_counter() - t_io
+            same = all(np.array_equal(r_io["results"][len(files) - a.batch + i].dosage, main_reg["last"][i].dosage) for i in range(a.batch))
+            sec = r_io["seconds"]
+            out["from_bam_files"] = {
+                "value": len(files) / t_io, "unit": "samples/sec", "samples": len(files), "wall_s": round(t_io, 3),
+                "seconds": {k: round(v, 3) for k, v in sec.items()},
+                "io_threads": a.io_threads or "min(32, hardware threads)",
+                "share_of_wall": {"load": round(sec["load"] / t_io, 4), "impute": round(sec["impute"] / t_io, 4),
+                                  "format_and_counts": round(sec["format"] / t_io, 4)},
+                "compute_only_value": out["value"],
+                "last_step_dosages_equal_the_timed_region": bool(same),
+                "vcf_bytes_per_sample": int(np.mean([len(c.buf) for c in r_io["columns"] if c is not None])),
+                "what": "qa_impute_bam_range over the timed steps' BAM files: load (host threads) -> qa_impute_samples -> VCF columns + "
+                        "the range's count arrays (host threads), one native call, everything inside the clock; the Python wrapper's "
+                        "copies of the results out of the library are inside wall_s too"}
+            import shutil
+            shutil.rmtree(a.bam_dir, ignore_errors=True)
         if a.dotcall > 0 and native is not None and world == 1:
             # the device-wide arena goes with the last handle: the workers are processes of their own and need the memory
             drv.close()
