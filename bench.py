@@ -368,8 +368,9 @@ def main():
                          "dosage passes in a second timed region of their own, reported under `mixed_precision` (the default until round 4; "
                          "since the CPU baseline is measured on whole samples -- six minutes of wall -- the default run is the fp64 region alone)")
     ap.add_argument("--fp64-dosage", action="store_true", help="(older spelling of --precision fp64)")
-    ap.add_argument("--io-threads", type=int, default=0,
-                    help="--bam: host threads of qa_impute_bam_range's loading and formatting (0 = min(32, hardware threads))")
+    ap.add_argument("--io-threads", type=int, default=64,
+                    help="--bam: host threads of qa_impute_bam_range's loading and formatting (0 = min(32, hardware threads)); divided by the "
+                         "number of ranks")
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
@@ -699,22 +700,24 @@ def main():
             r_io = impute_bam_range(drv.devs, files, "chr20", ref, alt, DriverParams(**params),
                                     sample_index=[(rank * n_steps + a.warmup) * a.batch + i for i in range(len(files))],
                                     ff=[0.2] * len(files) if a.mode == "nipt" else None, samples_per_launch_set=a.batch * a.fuse,
-                                    fuse_tails=bool(a.fuse_tails), downsampleToCov=0, bqFilter=1, n_io_threads=a.io_threads)
+                                    fuse_tails=bool(a.fuse_tails), downsampleToCov=0, bqFilter=1, n_io_threads=max(1, a.io_threads // max(world, 1)) if a.io_threads else 0,
+                                    copy_out=range(len(files) - a.batch, len(files)))
             t_io = time.perf_counter() - t_io
             same = all(np.array_equal(r_io["results"][len(files) - a.batch + i].dosage, main_reg["last"][i].dosage) for i in range(a.batch))
             sec = r_io["seconds"]
             out["from_bam_files"] = {
                 "value": len(files) / t_io, "unit": "samples/sec", "samples": len(files), "wall_s": round(t_io, 3),
                 "seconds": {k: round(v, 3) for k, v in sec.items()},
-                "io_threads": a.io_threads or "min(32, hardware threads)",
+                "io_threads": (max(1, a.io_threads // max(world, 1)) if a.io_threads else "min(32, hardware threads)"),
                 "share_of_wall": {"load": round(sec["load"] / t_io, 4), "impute": round(sec["impute"] / t_io, 4),
                                   "format_and_counts": round(sec["format"] / t_io, 4)},
                 "compute_only_value": out["value"],
                 "last_step_dosages_equal_the_timed_region": bool(same),
                 "vcf_bytes_per_sample": int(np.mean([len(c.buf) for c in r_io["columns"] if c is not None])),
-                "what": "qa_impute_bam_range over the timed steps' BAM files: load (host threads) -> qa_impute_samples -> VCF columns + "
-                        "the range's count arrays (host threads), one native call, everything inside the clock; the Python wrapper's "
-                        "copies of the results out of the library are inside wall_s too"}
+                "results_copied_into_python": a.batch,
+                "what": "qa_impute_bam_range over the timed steps' BAM files: load (host threads) -> qa_impute_samples, the columns of "
+                        "finished launch sets formatted on host threads beside it -> the last sets' columns + the range's count arrays; one "
+                        "native call, everything inside the clock (seconds.format = what is left after the device work ends)"}
             import shutil
             shutil.rmtree(a.bam_dir, ignore_errors=True)
         if a.dotcall > 0 and native is not None and world == 1:

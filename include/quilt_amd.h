@@ -658,6 +658,12 @@ typedef struct {
                                                    global indices (ABI 5): the call's samples need not be consecutive among ALL
                                                    samples -- a range from which samples with too few reads were dropped
                                                    (functions.R:274-287) keeps every remaining sample's own streams */
+    void (*on_samples_done)(void *ctx, int32_t lo, int32_t hi);   /* NULL, or called from a host thread of the call when samples
+                                                   [lo, hi) of the call are FINAL (every output row of theirs written): a caller that
+                                                   formats or writes results can do so while later launch sets are still on the device
+                                                   (qa_impute_bam_range formats VCF columns this way).  Must not call back into the
+                                                   library's device entry points; may be called concurrently for disjoint ranges */
+    void *on_samples_done_ctx;
 } qa_impute_params_t;
 int qa_impute_params_default(qa_impute_params_t *params);
 

@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -48,7 +49,8 @@ struct qa_bam_range_result {
     std::vector<std::vector<char>> col_buf;
     std::vector<std::vector<int64_t>> col_off;
     std::vector<double> infoCount, afCount, hweCount, alleleCount;
-    double seconds[4] = {0, 0, 0, 0};    // load, impute, format + counts, whole call
+    double seconds[4] = {0, 0, 0, 0};    // load, impute (the columns of finished launch sets are formatted beside it), what is left of formatting + counts, whole call
+    double format_busy_s = 0;            // thread-seconds spent formatting (most of them inside seconds[1])
     int64_t stats[11] = {0};
     int64_t load_stats[8] = {0};         // the loader's counters summed over the files (qa_sample_reads_stats)
 };
@@ -245,20 +247,14 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
         nq.fet_gp_t = R->fet_gp_t.data();
         P.nipt = &nq;
     }
-    if (nk > 0) {
-        st = impute(&P, nk, R->read_off.data(), read_ptr.data(), u.data(), bq.data(), wif.data(), R->dosage.data(), R->gp_t.data(), R->haps.data(),
-                    R->labels.data(), R->nDosage.data(), R->stats);
-        if (st != QA_OK) return st;   // (qa_last_error holds qa_impute_samples' text)
-    }
-    R->seconds[1] = since(t0);
-
-    // ---- 3. per kept sample: its VCF column (functions.R:1408-1463) and its share of the four count arrays (:1380-1418)
-    t0 = Clock::now();
+    // ---- 3. (beside 2.) per kept sample: its VCF column (functions.R:1408-1463), eij / fij / max_gen and the pile-up's allele counts
+    // (:1380-1418).  qa_impute_samples reports every launch set whose samples are final (params->on_samples_done); a pool of host
+    // threads formats those samples while later launch sets are still on the device.
     R->col_buf.resize((size_t)nk);
     R->col_off.resize((size_t)nk);
     std::vector<std::vector<double>> eij((size_t)nk), fij((size_t)nk), ac((size_t)nk);
     std::vector<std::vector<uint8_t>> maxg((size_t)nk);
-    st = parallel_for(nk, n_io, err, [&](int j, std::string &e) {
+    auto format_one = [&](int j, std::string &e) -> int {
         const double *gp = R->gp_t.data() + (size_t)j * 3 * T_out;          // [3][T_out]
         const double *hd = R->haps.data() + (size_t)j * nL * T_out;         // [nL][T_out] == T_out x nL column-major
         std::vector<double> gpc((size_t)3 * T_out), fgc;                    // 3 x T_out column-major, as the column writers take it
@@ -284,10 +280,11 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
                 s1 = qa_vcf_column_diploid(T_out, gpc.data(), hd, io->output_gt_phased_genotypes, buf.data(), cap, off.data(), &need);
             }
             if (s1 == QA_ERR_CAPACITY && pass == 0) { cap = need; continue; }
-            if (s1 != QA_OK) { e = "VCF column of a sample could not be formatted"; return s1; }
+            if (s1 != QA_OK) { e = std::string("VCF column of a sample could not be formatted: ") + qa_last_error(); return s1; }
             break;
         }
         buf.resize((size_t)off[(size_t)T_out]);
+        buf.shrink_to_fit();
         // eij, fij (functions.R:1399-1400: round(x, 3)), max_gen (STITCH::get_max_gen_rapid: the first maximum), the pile-up's
         // allele counts (increment2N over STITCH::convertScaledBQtoProbs of the reads as loaded, :1382-1398)
         auto &E = eij[(size_t)j]; auto &F = fij[(size_t)j]; auto &M = maxg[(size_t)j]; auto &A = ac[(size_t)j];
@@ -307,25 +304,90 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
             c2[s.u[b]] += q < 0 ? eps / 3 : 1 - eps;
         }
         return (int)QA_OK;
-    });
-    if (st != QA_OK) { qa::set_error("qa_impute_bam_range: %s", err.c_str()); return st; }
-    // the range's sums, sample after sample as the reference's loop adds them (quilt.R:955-961)
+    };
+    struct Pool {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<int> queue;
+        size_t head = 0;
+        bool closed = false;
+        int status = QA_OK;
+        std::string err;
+        double busy_s = 0;
+    } pool;
+    auto pool_body = [&] {
+        for (;;) {
+            int j;
+            {
+                std::unique_lock<std::mutex> lk(pool.mu);
+                pool.cv.wait(lk, [&] { return pool.head < pool.queue.size() || pool.closed; });
+                if (pool.head >= pool.queue.size()) return;
+                j = pool.queue[pool.head++];
+            }
+            const auto tj = Clock::now();
+            std::string e;
+            int s1;
+            try { s1 = format_one(j, e); } catch (const std::exception &ex) { s1 = QA_ERR_INVALID; e = ex.what(); }
+            std::lock_guard<std::mutex> g(pool.mu);
+            pool.busy_s += since(tj);
+            if (s1 != QA_OK && pool.status == QA_OK) { pool.status = s1; pool.err = e; }
+        }
+    };
+    struct Hook {
+        Pool *pool;
+        static void done(void *ctx, int32_t lo, int32_t hi) {
+            Pool *p = static_cast<Hook *>(ctx)->pool;
+            {
+                std::lock_guard<std::mutex> g(p->mu);
+                for (int j = lo; j < hi; j++) p->queue.push_back(j);
+            }
+            p->cv.notify_all();
+        }
+    } hook{&pool};
+    P.on_samples_done = &Hook::done;
+    P.on_samples_done_ctx = &hook;
+    std::vector<std::thread> formatters;
+    for (int w = 0; w < std::max(1, std::min(n_io, nk)); w++) formatters.emplace_back(pool_body);
+    auto close_pool = [&] {
+        { std::lock_guard<std::mutex> g(pool.mu); pool.closed = true; }
+        pool.cv.notify_all();
+        for (auto &t : formatters) t.join();
+    };
+    if (nk > 0) {
+        st = impute(&P, nk, R->read_off.data(), read_ptr.data(), u.data(), bq.data(), wif.data(), R->dosage.data(), R->gp_t.data(), R->haps.data(),
+                    R->labels.data(), R->nDosage.data(), R->stats);
+        if (st != QA_OK) { close_pool(); return st; }   // (qa_last_error holds qa_impute_samples' text)
+    }
+    R->seconds[1] = since(t0);
+    t0 = Clock::now();
+    close_pool();   // (what is still queued when the device work ends: the last launch sets' samples)
+    if (pool.status != QA_OK) { qa::set_error("qa_impute_bam_range: %s", pool.err.c_str()); return pool.status; }
+    if ((int)pool.queue.size() != nk) { qa::set_error("qa_impute_bam_range: %d of %d samples were reported final", (int)pool.queue.size(), nk); return QA_ERR_INVALID; }
+    // the range's sums, per SNP over the samples IN SAMPLE ORDER, as the reference's loop adds them (quilt.R:955-961); SNP blocks on
+    // the host threads (the order of a floating-point sum is per SNP: blocks of SNPs do not interact)
     {
         double *i0 = R->infoCount.data(), *i1 = i0 + T_out, *af = R->afCount.data(), *hw = R->hweCount.data();
         double *a0 = R->alleleCount.data(), *a1 = a0 + T_out;
-        for (int j = 0; j < nk; j++) {
-            const double *E = eij[(size_t)j].data(), *F = fij[(size_t)j].data(), *c1 = ac[(size_t)j].data(), *c2 = c1 + T_out;
-            const uint8_t *M = maxg[(size_t)j].data();
-            for (int t = 0; t < T_out; t++) {
-                i0[t] += E[t];
-                i1[t] += F[t] - E[t] * E[t];
-                af[t] += E[t] / 2;
-                hw[(size_t)M[t] * T_out + t] += 1;
-                a0[t] += c2[t];              // per_sample_alleleCount = cbind(c2, c1 + c2) (functions.R:1398)
-                a1[t] += c1[t] + c2[t];
+        const int n_blocks = std::max(1, std::min(n_io, (T_out + 4095) / 4096));
+        st = parallel_for(n_blocks, n_io, err, [&](int blk, std::string &) {
+            const int lo = (int)((int64_t)T_out * blk / n_blocks), hi = (int)((int64_t)T_out * (blk + 1) / n_blocks);
+            for (int j = 0; j < nk; j++) {
+                const double *E = eij[(size_t)j].data(), *F = fij[(size_t)j].data(), *c1 = ac[(size_t)j].data(), *c2 = c1 + T_out;
+                const uint8_t *M = maxg[(size_t)j].data();
+                for (int t = lo; t < hi; t++) {
+                    i0[t] += E[t];
+                    i1[t] += F[t] - E[t] * E[t];
+                    af[t] += E[t] / 2;
+                    hw[(size_t)M[t] * T_out + t] += 1;
+                    a0[t] += c2[t];              // per_sample_alleleCount = cbind(c2, c1 + c2) (functions.R:1398)
+                    a1[t] += c1[t] + c2[t];
+                }
             }
-        }
+            return (int)QA_OK;
+        });
+        if (st != QA_OK) { qa::set_error("qa_impute_bam_range: %s", err.c_str()); return st; }
     }
+    R->format_busy_s = pool.busy_s;
     R->seconds[2] = since(t0);
     R->seconds[3] = since(t_all);
     *out = R.release();

@@ -1089,6 +1089,7 @@ struct Worker {
             double *h = cx.phasing_haps + (size_t)s * 2 * T;
             recast_haps(h, h + T, g, g + T, g + 2 * (size_t)T, T);
         });
+        if (cx.P.on_samples_done) cx.P.on_samples_done(cx.P.on_samples_done_ctx, b.lo, b.hi);   // every row of [lo, hi) is final
     }
 
     // quilt_amd/driver.py::Driver.run_stream

@@ -28,6 +28,7 @@ class ImputeParams(C.Structure):
         ("mspbwt_index", C.c_void_p),
         ("samples_per_launch_set", C.c_int32), ("no_fused_tails", C.c_int32),
         ("rare_common", C.c_void_p), ("nipt", C.c_void_p), ("sample_index", C.c_void_p),
+        ("on_samples_done", C.c_void_p), ("on_samples_done_ctx", C.c_void_p),
     ]
 
 
@@ -184,11 +185,14 @@ def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, al
                      minimum_number_of_sample_reads: int = 2, output_gt_phased_genotypes: bool = True, n_io_threads: int = 0,
                      samples_per_launch_set: int = 256, fuse_tails: bool = True, drcs: Sequence = (), all_sites=None,
                      bqFilter: int = 17, iSizeUpperLimit: float = 1e6, useSoftClippedBases: bool = False, downsampleToCov: int = 30,
-                     chrStart: int = 0, chrEnd: int = 0, merge_mates: bool = True, seed: int = 1, _entry=None) -> dict:
+                     chrStart: int = 0, chrEnd: int = 0, merge_mates: bool = True, seed: int = 1, copy_out: Optional[Sequence[int]] = None,
+                     _entry=None) -> dict:
     """The body of QUILT()'s loop over a core's sample range (quilt.R:832-982) as ONE native call: the BAM files are loaded on
     host threads, the samples with enough reads imputed together on the device, their VCF columns formatted on host threads and
     the four per-SNP count arrays summed over the range.  ``sample_index``: the files' global 0-based sample indices (default
     0 .. n - 1).  ``all_sites`` (with ``params.impute_rare_common`` and ``drcs``): ``(L_all, ref_all, alt_all, grid_all)``.
+    ``copy_out``: the files whose columns and arrays are copied out of the library into numpy objects (default: all; a caller
+    that only wants the counts or a few samples saves the copies -- 2.5 MB of text and 4 MB of numbers per sample).
     Returns dict(imputed, n_reads, columns [VcfColumn or None], results {file index: SampleResult}, counts SummaryCounts,
     seconds {load, impute, format, total}, stats)."""
     from .io import BamOpts, SummaryCounts, VcfColumn
@@ -262,8 +266,9 @@ def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, al
         imputed = [bool(L.qa_bam_range_imputed(h, C.c_int32(i))) for i in range(n)]
         n_reads = [int(L.qa_bam_range_n_reads(h, C.c_int32(i))) for i in range(n)]
         columns, results = [None] * n, {}
+        wanted = set(range(n)) if copy_out is None else set(int(i) for i in copy_out)
         for i in range(n):
-            if not imputed[i]:
+            if not imputed[i] or i not in wanted:
                 continue
             buf, off = C.c_void_p(), C.c_void_p()
             check(L.qa_bam_range_column(h, C.c_int32(i), C.byref(buf), C.byref(off)))

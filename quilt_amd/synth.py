@@ -121,10 +121,10 @@ def make_1000g_like_panel(K: int = 5008, nSNPs: int = 3200, seed: int = 2504, nM
         i = int(rng.choice(counts, p=p_count))
         a = int(rng.integers(0, K - i + 1))
         hap[order[a:a + i], t] = 1
-    pad = np.zeros((K, G * 32), dtype=np.uint64)
+    pad = np.zeros((K, G * 32), dtype=np.uint8)
     pad[:, :nSNPs] = hap
-    w = (np.uint64(1) << np.arange(32, dtype=np.uint64))
-    rhb_t = np.asfortranarray((pad.reshape(K, G, 32) * w[None, None, :]).sum(axis=2).astype(np.uint32).view(np.int32))
+    # bit b of word g = the allele at SNP 32 g + b, least significant bit first (packbits: 1 byte per 8 SNPs; 4 bytes = a word)
+    rhb_t = np.asfortranarray(np.packbits(pad, axis=1, bitorder="little").view("<u4").view(np.int32))
     t = make_rhb_t_equality(rhb_t, nMaxDH, nSNPs, ref_error, use_hapMatcherR=True)
     return Panel(
         K=K, nSNPs=nSNPs, nGrids=G, nMaxDH=t["nMaxDH"], ref_error=ref_error, rhb_t=rhb_t,
