@@ -42,16 +42,14 @@ def pmc_file_for(mode, K, batch, mspbwt, rare_common):
         names = []
     elif mode == "ont" and K == 50000:
         names = ["r05_pmc_traffic_ont.json"]
-    elif mode == "short" and batch == 128 and not rare_common:
-        # (any panel size: the dominant kernel is the small-panel sampler, whose work -- Ks = 600 haplotypes, 2 000 grids, the
-        # sample's reads -- does not depend on K; the full-panel kernels' traffic does, and is in the K = 50 000 summary only)
-        names = ["r05_pmc_traffic.json", "r04_pmc_traffic.json"]
+    elif mode == "short" and batch == 128 and K == 64976:
+        names = ["r05_pmc_traffic_K64976.json"]
     elif mode == "nipt" and K == 50000:
         names = ["r05_pmc_traffic_nipt.json"]
     elif mode == "short" and K == 5000 and batch == 32:
         names = ["r05_pmc_traffic_configs1.json"]
     elif mode == "short" and K == 50000 and batch == 128:
-        names = ["r05_pmc_traffic.json", "r04_pmc_traffic.json"]
+        names = ["r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"]
     else:
         names = []
     for n in names:
@@ -368,6 +366,9 @@ def main():
                          "dosage passes in a second timed region of their own, reported under `mixed_precision` (the default until round 4; "
                          "since the CPU baseline is measured on whole samples -- six minutes of wall -- the default run is the fp64 region alone)")
     ap.add_argument("--fp64-dosage", action="store_true", help="(older spelling of --precision fp64)")
+    ap.add_argument("--host-share", type=int, default=1,
+                    help="N > 1: confine this run to 1 / N of the host's logical CPUs and give it the host-thread budget of one rank of an "
+                         "N-rank run -- measures, on one GPU, what a rank's share of the host costs (the 8-GPU node's host side)")
     ap.add_argument("--io-threads", type=int, default=64,
                     help="--bam: host threads of qa_impute_bam_range's loading and formatting (0 = min(32, hardware threads)); divided by the "
                          "number of ranks")
@@ -452,6 +453,11 @@ def main():
     # the native calls' own host threads (per-chain tables, validation): the machine's cores divided between the ranks of this
     # node and the host threads of each rank, so that 8 ranks x 4 threads do not start 16 helpers each at the same moment
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if a.host_share > 1 and world == 1:
+        # one rank's share of the host at N ranks: the first 1 / N of the logical CPUs, before any worker process or thread exists
+        cpus = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(cpus[:max(1, len(cpus) // a.host_share)]))
+        local_world = a.host_share
     if a.workers is None:
         a.workers = 4 if a.mspbwt else 3
     if a.pageable:
@@ -661,11 +667,13 @@ def main():
     if rank == 0:
         out = report(a, panel, params, native, drv, samples, main_reg, world, rc, cpu, keep, ff, full_chains, alone,
                      fp64=a.precision != "mixed")
-        if world == 1 and a.mode == "short" and a.K == 50000 and not a.mspbwt and rc is None:
-            out["host_share_at_8"] = {"what": "NOT measured in this run: the headline workload with one rank confined to the share of the host it has "
-                                              "when eight ranks run (taskset -c 0-31, QA_HOST_THREADS=10), round 4, the driver's command without the "
-                                              "CPU legs -- three host threads per rank still hide each other's host phases on a quarter of the cores",
-                                      "samples_per_sec_confined": 39.6, "samples_per_sec_whole_host": 40.0, "source": "DESIGN.md 7"}
+        if a.host_share > 1:
+            out["host_share"] = {"of": a.host_share, "logical_cpus_used": len(os.sched_getaffinity(0)),
+                                 "QA_HOST_THREADS": int(os.environ.get("QA_HOST_THREADS", "0")),
+                                 "what": f"this whole run was confined to 1 / {a.host_share} of the host's logical CPUs (sched_setaffinity before anything "
+                                         f"else started) with the host-thread budget a rank has when {a.host_share} ranks share the node: `value` is "
+                                         f"what ONE rank of such a run achieves on its share of the host (the other {a.host_share - 1} ranks' memory "
+                                         "traffic is absent)"}
         if a.one_device and world > 1:
             out["one_device_rehearsal"] = (f"{world} ranks on ONE GPU (device 0, gloo rendezvous, QA_ARENA_FRACTION="
                                            f"{os.environ.get('QA_ARENA_FRACTION', 'default')}): a rehearsal of the N-rank run's host side "

@@ -783,6 +783,10 @@ constexpr int kHistCopiesD = 8;
 constexpr int kNStreamD = 7;   // SC_SIG .. SC_C, SC_TCOL (here: the forward pass's rescaling factor of the grid; SC_SLOT holds its addend)
 constexpr size_t kLdsFixedD = 2 * kMaxRow * 8 + 2 * 16 * 8 + kNStreamD * 64 * 8 + (size_t)kMaxRow * kHistCopiesD * 8;
 inline size_t lds_bytes_d(const Geo64 &g) { return kLdsFixedD + (g.NL > 0 ? ((size_t)(g.NL - 1) * kNT + g.n_last) * 128 : 0); }
+// geo64() sizes NR / NL by the ranking kernels' LDS; the dosage backward's fixed part is its own.  The tightest <4, 3> case (seven
+// rows, a one-wave last row: K = 49 153 .. 50 176) must fit, or a band of K just below 50 176 would stop working while its
+// neighbours still do; wider last rows go to <5, 2> in launch_fb64_dosage.
+static_assert(kLdsFixedD + (2 * (size_t)kNT + 64) * 128 <= kLdsMax, "k_bwd64d: one more staged scalar stream does not fit beside three LDS rows");
 
 struct LdsD {
     double *etab;                // [2][256]
@@ -1157,7 +1161,10 @@ size_t fb64_dos_lds_bytes(int K) { return lds_bytes_d(geo64(K)); }
 
 void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mid) {
     const PassParams &prm = *static_cast<const PassParams *>(pass_params);
-    const Geo64 geo = geo64(prm.K);
+    Geo64 geo = geo64(prm.K);
+    // (the dosage backward's LDS, not the ranking kernels', decides here: a <4, 3> geometry whose three LDS rows do not fit beside
+    // k_bwd64d's histogram takes five rows in registers, as the ranking pair does)
+    if (geo.NCH == 7 && geo.NS == 0 && geo.NR == 4 && lds_bytes_d(geo) > kLdsMax) { geo.NR = 5; geo.NL = 2; }
     if (geo.NCH == 0 || lds_bytes_d(geo) > kLdsMax) throw std::runtime_error("K exceeds the on-chip capacity of the fp64 dosage kernels");
     if (prm.Kq != (geo.NCH + geo.NS) * kRowHaps) throw std::runtime_error("internal: Kq does not match the fp64 geometry");
     if (geo.NS > 0) {
@@ -1173,8 +1180,8 @@ void launch_fb64_dosage(const void *pass_params, hipStream_t st, hipEvent_t e_mi
         case 40: launch_dos<4, 0>(prm, geo, st, e_mid); break;
         case 41: launch_dos<4, 1>(prm, geo, st, e_mid); break;
         case 42: launch_dos<4, 2>(prm, geo, st, e_mid); break;
-        case 52: launch_dos<5, 2>(prm, geo, st, e_mid); break;
 #endif
+        case 52: launch_dos<5, 2>(prm, geo, st, e_mid); break;
         case 43: launch_dos<4, 3>(prm, geo, st, e_mid); break;
         default: throw std::runtime_error("fp64 geometry not built");
     }

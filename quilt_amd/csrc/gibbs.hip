@@ -1176,7 +1176,7 @@ void launch_gibbs(const GibbsParams &prm, int maxR, hipStream_t st, hipEvent_t *
 
 }  // namespace
 
-static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, const int64_t *rep_off, int per_it_off, int32_t n_chain, const int32_t *which_haps_to_use_1based,
+static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *rc, const qa_gibbs_opts_t *o, const double *ff_chain, const int64_t *rep_off, const int32_t *rep_id, int per_it_off, int32_t n_chain, const int32_t *which_haps_to_use_1based,
                    const int32_t *read_off, const int32_t *read_ptr, const int32_t *u, const int32_t *bq,
                    const int32_t *wif, const double *runif_reads, const int32_t *first_read,
                    const double *runif_shard, int32_t *H, int32_t *H_class, double *hapProbs_t,
@@ -1222,15 +1222,20 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         std::vector<int64_t> hbase(C);   // where a chain's bases are looked at on the host, relative to this launch's u / bq
         bool aliased = false;
         {
-            std::map<int64_t, int32_t> first_of;
+            // keyed on the representative's INDEX in the call (reads_same_as[c]), not on where its bases lie: a chain without
+            // bases has the offset of the chain behind it and would be taken for sharing that chain's reads
+            std::map<int32_t, int32_t> first_of;
             for (int c = 0; c < C; c++) {
                 rep[c] = c;
                 hbase[c] = rep_off ? rep_off[c] : (int64_t)base_off[c];
                 if (!rep_off) continue;
-                auto it = first_of.find(rep_off[c]);
-                if (it == first_of.end()) { first_of.emplace(rep_off[c], c); aliased |= rep_off[c] != (int64_t)base_off[c]; continue; }
+                auto it = first_of.find(rep_id[c]);
+                if (it == first_of.end()) { first_of.emplace(rep_id[c], c); aliased |= rep_off[c] != (int64_t)base_off[c]; continue; }
                 const int r0 = it->second;
-                if (read_off[r0 + 1] - read_off[r0] != read_off[c + 1] - read_off[c] || base_off[r0 + 1] - base_off[r0] != base_off[c + 1] - base_off[c])
+                const int R = read_off[c + 1] - read_off[c];
+                // the same reads means the same read boundaries, not just as many reads and bases
+                if (read_off[r0 + 1] - read_off[r0] != R || base_off[r0 + 1] - base_off[r0] != base_off[c + 1] - base_off[c] ||
+                    std::memcmp(read_ptr + read_off[r0] + r0, read_ptr + read_off[c] + c, sizeof(int32_t) * ((size_t)R + 1)) != 0)
                     throw std::runtime_error("reads_same_as names a chain with other reads");
                 rep[c] = r0;
                 aliased = true;
@@ -1803,7 +1808,7 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
                 for (int c = c0; c < c1; c++) rep_off[(size_t)(c - c0)] = (int64_t)base_of[(size_t)o->reads_same_as[c]] - (int64_t)base_of[(size_t)c0];
             }
             const int st = gibbs_chunk(
-                pn, need, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, o->reads_same_as ? rep_off.data() : nullptr, c0, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
+                pn, need, rc, o, o->ff_chain ? o->ff_chain + c0 : nullptr, o->reads_same_as ? rep_off.data() : nullptr, o->reads_same_as ? o->reads_same_as + c0 : nullptr, c0, c1 - c0, which_haps_to_use_1based + (size_t)c0 * Ks, ro.data(), read_ptr + read_off[c0] + c0,
                 u + base_of[c0], bq + base_of[c0], wif + read_off[c0],
                 runif_reads ? runif_reads + (size_t)read_off[c0] * n_its : nullptr, first_read + c0,
                 runif_shard ? runif_shard + (o->ff != 0.0 ? (size_t)read_off[c0] * nb * 2 : (size_t)c0 * nb * (G - 1)) : nullptr,
