@@ -238,13 +238,25 @@ def _whole_worker(i):
     oracle's entry points, single-threaded) -- what one mclapply worker of the reference does for one sample."""
     from quilt_amd.driver import Driver, DriverParams
     from tests.oracle_backend import OracleBackend
+
+    class Backend(OracleBackend):
+        # use_mspbwt = TRUE: the reference answers its msPBWT queries with the mspbwt package's C++ on the host; the CPU path here
+        # uses this library's host C++ for the same query (csrc/mspbwt.cpp: no device involved) -- the numpy restatement the tests
+        # check it against would understate the CPU reference by an order of magnitude.  The panel's indices were built once in
+        # the parent (copy-on-write after the fork), as QUILT loads `ms_indices` once per run.
+        def mspbwt_select(self, Zs, n_label, nindices, L, M, Knew, seeds):
+            from quilt_amd.mspbwt import panel_mspbwt_index
+            return panel_mspbwt_index(self.panel, nindices).select_new_haps(Zs, n_label, L, M, Knew, seeds)
+
     smp, off, params, keep = _WHOLE[i]
+    os.environ["QA_HOST_THREADS"] = "1"   # (this worker process only: a query's scan runs on the worker's own core, like the rest of its sample)
     t0 = time.perf_counter()
-    res = Driver(_CPU_PANEL, OracleBackend(_CPU_PANEL, n_threads=1), DriverParams(**params)).run([smp], sample_offset=off)
+    drv = Driver(_CPU_PANEL, Backend(_CPU_PANEL, _CPU_RC, n_threads=1), DriverParams(**params), rare_common=_CPU_RC)
+    res = drv.run([smp], sample_offset=off)
     return i, time.perf_counter() - t0, (res[0] if keep else None)
 
 
-def cpu_baseline_whole(panel, params, work, cores, budget_s, n_keep):
+def cpu_baseline_whole(panel, params, work, cores, budget_s, n_keep, rare_common=None):
     """THE CPU baseline: `cores` whole samples, one per physical core, all at once (the reference's
     mclapply(mc.cores = nCores), quilt.R:691-692), each through the whole per-sample pipeline on the CPU path.  `work` =
     [(sample, global sample index)]: the samples of the last timed batch under the seeds the GPU run gives them, so that the
@@ -253,8 +265,13 @@ def cpu_baseline_whole(panel, params, work, cores, budget_s, n_keep):
     import multiprocessing as mp
     global _CPU_PANEL, _WHOLE
     from oracle import oracle as O
+    global _CPU_RC
     O.lib()
     _CPU_PANEL = panel
+    _CPU_RC = rare_common
+    if params.get("use_mspbwt"):
+        from quilt_amd.mspbwt import panel_mspbwt_index
+        panel_mspbwt_index(panel, params.get("mspbwt_nindices", 4))   # built before the fork: shared by the workers
     n = min(cores, len(work))
     _WHOLE = [(smp, off, params, i < n_keep) for i, (smp, off) in enumerate(work[:n])]
     t0 = time.perf_counter()
@@ -528,14 +545,14 @@ def main():
         a.bam_dir = bam_dir   # (kept for the I/O-inclusive leg after the timed region; removed there)
     samples = [flat[st * a.batch:(st + 1) * a.batch] for st in range(n_steps)]
     cpu_pipeline = None
-    if rank == 0 and world == 1 and cpu is not None and a.cpu_baseline == "whole" and not a.mspbwt:
+    if rank == 0 and world == 1 and cpu is not None and a.cpu_baseline == "whole" and (not a.mspbwt or a.mspbwt_search == "scan"):
         # the baseline proper: whole samples, one per physical core, all cores at once; the composed figure stays beside it
         cores = physical_cores()
         work, st = [], n_steps - 1
         while len(work) < cores and st >= 0:   # the last timed batch first (its first samples double as the r2 reference)
             work += [(smp, st * a.batch + i) for i, smp in enumerate(samples[st])]
             st -= 1
-        whole, ref = cpu_baseline_whole(panel, params, work, cores, a.cpu_baseline_budget, min(a.r2_vs_cpu, len(samples[-1])))
+        whole, ref = cpu_baseline_whole(panel, params, work, cores, a.cpu_baseline_budget, min(a.r2_vs_cpu, len(samples[-1])), rc)
         if whole is not None:
             whole["composed"] = cpu
             whole["composed_over_whole"] = round(cpu["value"] / whole["value"], 3)
