@@ -538,3 +538,29 @@ def test_aligner_like_bam_fixture():
     with tempfile.TemporaryDirectory() as d:
         shutil.copy(bam, os.path.join(d, "x.bam"))
         assert _reads_of(loadBamAndConvert(os.path.join(d, "x.bam"), z["chr"], L, ref, alt, downsampleToCov=0)) == want("default")
+
+
+def test_fixed_three_decimals_equal_printf_on_ties_and_their_neighbours():
+    """The diploid column's six numbers per SNP are written by an integer formatter (csrc/hostio.cpp fmt_fixed3: the decimal
+    expansion of a double is exact, so "%.3f" is the mantissa times 1000 rounded on its exact remainder, ties to even) instead of
+    snprintf.  It must print what printf prints -- on random values, on every multiple of 1 / 8000 (exact ties at the fourth
+    decimal), on the doubles either side of every odd multiple of 0.0005 (decimal ties that are NOT ties in binary), on
+    subnormals and on large values."""
+    import ctypes as C
+    from quilt_amd.io import _io_lib
+    from quilt_amd.native import ptr
+    lib = _io_lib()
+    rng = np.random.default_rng(0)
+    t = np.arange(1, 4000, 2) / 2000.0
+    vals = np.concatenate([rng.random(30000), rng.random(15000) * 2, np.arange(0, 4001) / 8000.0, np.arange(0, 2001) / 2000.0,
+                           [0.0, 1.0, 2.0, 0.0005, 0.0015, 0.0025, 0.00049999999999999, 0.9995, 1.9995, 1e-320, 0.5, 0.0625, 0.1875,
+                            1.0005, 1e8, 123456.7895, 0.0004999999999999999], np.nextafter(t, 0), np.nextafter(t, 10), t])
+    n = len(vals) // 3
+    gp = np.ascontiguousarray(vals[:3 * n])           # 3 x n column-major: entry i holds gp[3 i .. 3 i + 2]
+    hd = np.concatenate([vals[:n], vals[n:2 * n]])
+    buf, off, need = np.zeros(200 * n, dtype=np.uint8), np.zeros(n + 1, dtype=np.int64), C.c_int64()
+    assert lib.qa_vcf_column_diploid(C.c_int32(n), ptr(gp), ptr(hd), C.c_int32(0), ptr(buf), C.c_int64(len(buf)), ptr(off), C.byref(need)) == 0
+    txt = bytes(buf[:off[-1]]).decode().split("\0")[:-1]
+    for i in range(n):
+        g0, g1, g2 = gp[3 * i:3 * i + 3]
+        assert txt[i][3:] == ":%.3f,%.3f,%.3f:%.3f:%.3f,%.3f" % (g0, g1, g2, g1 + 2 * g2, hd[i], hd[n + i]), i
