@@ -678,6 +678,13 @@ static void range_validate(SEXP panelSEXP, SEXP paramsSEXP, const char *who) {
         if ((sic0 != R_NilValue && TYPEOF(sic0) != LGLSXP) || (tma0 != R_NilValue && TYPEOF(tma0) != REALSXP))
             Rf_error("quilt_amd: %s: rare_common$snp_is_common must be logical, $transMatRate_t numeric", who);
     }
+    {   /* grid positions (method = "nipt": the block definition): numbers, wherever they are given */
+        SEXP lg = list_get(panelSEXP, "L_grid"), lga = rc0 == R_NilValue ? R_NilValue : list_get(rc0, "L_grid");
+        if ((lg != R_NilValue && TYPEOF(lg) != INTSXP && TYPEOF(lg) != REALSXP) || (lga != R_NilValue && TYPEOF(lga) != INTSXP && TYPEOF(lga) != REALSXP))
+            Rf_error("quilt_amd: %s: L_grid must be numeric", who);
+        SEXP ff = list_get(paramsSEXP, "ff");
+        if (ff != R_NilValue && TYPEOF(ff) != REALSXP) Rf_error("quilt_amd: %s: params$ff must be numeric (as.numeric)", who);
+    }
     const double seed_d = num_or(paramsSEXP, "seed", 1);
     if (!(seed_d >= 0) || seed_d > 9007199254740992.0 /* 2^53 */ || seed_d != floor(seed_d))   /* (NA / NaN fail the first test) */
         Rf_error("quilt_amd: %s: params$seed must be a non-negative whole number below 2^53", who);
