@@ -456,6 +456,17 @@ typedef struct {
      * left unwritten, its read_ptr block and wif must still be there), which at 192 000 SNPs saves six of seven copies of
      * 1.6 MB per chain on the host and over PCIe.  Results do not depend on it. */
     const int32_t *reads_same_as;
+    /* NULL, or (NIPT, ff > 0, explicit uniforms) a source of the block passes' uniforms IN THE ORDER THE REFERENCE DRAWS THEM
+     * (ABI 5).  The reference draws, at every block iteration, runif_block (gibbs-nipt.cpp:3016) before the pass and then, inside
+     * rcpp_sample_H_using_H_class (gibbs-nipt-block.cpp:213-246), ONE uniform (Rcpp::sample(1:3, 1, prob)) for every read whose
+     * class leaves a choice -- a number that depends on the pass's own result, so it cannot be drawn ahead.  With this set the
+     * library asks for them when the reference would draw them, from the calling thread, chain by chain:
+     *     what = 0   before block pass `pass` of chain `chain`: n = nReads uniforms, the pass's runif_block
+     *     what = 1   after its relabelling: n = the number of reads with H_class in {0, 4, 5, 6, 7}, in read order
+     * and the per-read re-draw slots of runif_shard are not read.  An R caller draws them with unif_rand() (and burns the
+     * reference's unused runif_proposed / runif_total around what = 0), which keeps set.seed's stream in step with the CPU package. */
+    void (*draw_uniforms)(void *ctx, int32_t chain, int32_t pass, int32_t what, int32_t n, double *out);
+    void *draw_uniforms_ctx;
 } qa_gibbs_opts_t;
 
 /*

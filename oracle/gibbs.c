@@ -872,7 +872,7 @@ int qo_sample3(const double probs[3], double u)
  *   runif_resample  one uniform per read, used by the reads whose class leaves a choice (:226-243)
  */
 static void block_gibbs_resampler_nipt(sweep_t *S, double ff, const int32_t *blocked_grid, const double *runif_block,
-                                       const double *runif_resample)
+                                       const double *runif_resample, const double **draw_next /* NULL, or the sequential stream */)
 {
     const int Ks = S->Ks, G = S->G, R = S->R;
     const double one_over_K = 1 / (double)Ks, prior = 1.0 / Ks;
@@ -1009,11 +1009,13 @@ static void block_gibbs_resampler_nipt(sweep_t *S, double ff, const int32_t *blo
         const double probs5[3] = {0.5, 0, 0.5 * ff}, probs6[3] = {0, 0.5 - ff * 0.5, ff * 0.5};
         for (int r = 0; r < R; r++) {
             const int hc = S->H_class[r];
-            if (hc == 0 || hc == 7) S->H[r] = qo_sample3(probs07, runif_resample[r]);
-            else if (hc <= 3) S->H[r] = hc;
-            else if (hc == 4) S->H[r] = qo_sample3(probs4, runif_resample[r]);
-            else if (hc == 5) S->H[r] = qo_sample3(probs5, runif_resample[r]);
-            else S->H[r] = qo_sample3(probs6, runif_resample[r]);
+            if (hc >= 1 && hc <= 3) { S->H[r] = hc; continue; }
+            /* (only these reads draw: with a sequential stream the uniform is the NEXT one, as Rcpp::sample takes it from R) */
+            const double u = draw_next ? *(*draw_next)++ : runif_resample[r];
+            if (hc == 0 || hc == 7) S->H[r] = qo_sample3(probs07, u);
+            else if (hc == 4) S->H[r] = qo_sample3(probs4, u);
+            else if (hc == 5) S->H[r] = qo_sample3(probs5, u);
+            else S->H[r] = qo_sample3(probs6, u);
         }
         for (int h = 0; h < 3; h++) for (size_t i = 0; i < (size_t)Ks * G; i++) S->eg[h][i] = 1;
         for (int r = 0; r < R; r++) {
@@ -1302,6 +1304,7 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
 
     int status = 0;
     int shard_it = 0;
+    const double *stream_at = a->runif_stream;
     for (int it = 0; it < n_its; it++) {
         gibbs_iterate(&S, it, a->runif_reads, a->gibbs_initialize_iteratively, a->first_read, work);
         /* underflow check (:2959-2969): sum(c3) is only looked at when ff == 0 */
@@ -1318,13 +1321,19 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
         if (to_block && !(a->sample_is_diploid && ff == 0)) {
             /* NIPT (gibbs-nipt.cpp:3003-3021): define the blocks from the current state, then the block resampler;
              * do_shard_block_gibbs is FALSE for ff > 0 (functions.R:2552-2556) */
-            if (!a->L_grid || !a->runif_block || !a->runif_resample) { status = -2; break; }
+            if (!a->L_grid || (!a->runif_stream && (!a->runif_block || !a->runif_resample))) { status = -2; break; }
             double *rate2 = (double *)malloc(sizeof(double) * (size_t)(G > 1 ? G - 1 : 1));
             int32_t *blocked = (int32_t *)malloc(sizeof(int32_t) * (size_t)G);
             block_rate2(&S, ff, rate2);
             qo_define_blocked_grids(rate2, a->L_grid, G, a->shuffle_bin_radius, a->block_gibbs_quantile_prob, blocked);
-            block_gibbs_resampler_nipt(&S, ff, blocked, a->runif_block + (size_t)shard_it * R,
-                                       a->runif_resample + (size_t)shard_it * R);
+            if (a->runif_stream) {
+                const double *blk = stream_at;   /* this pass's runif_block, then its draws */
+                stream_at += R;
+                block_gibbs_resampler_nipt(&S, ff, blocked, blk, NULL, &stream_at);
+            } else {
+                block_gibbs_resampler_nipt(&S, ff, blocked, a->runif_block + (size_t)shard_it * R,
+                                           a->runif_resample + (size_t)shard_it * R, NULL);
+            }
             shard_it++;
             free(rate2); free(blocked);
         } else if (to_block) {
@@ -1343,6 +1352,7 @@ int qo_gibbs(const qo_panel_t *p, const qo_gibbs_args_t *a, int32_t *H, int32_t 
     }
     (void)T; (void)c3_local;
     free(work); free(n_non1); free(idx_non1); free(cat);
+    if (a->runif_stream && a->runif_stream_used) *a->runif_stream_used = (int64_t)(stream_at - a->runif_stream);
     return status;
 }
 

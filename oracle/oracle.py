@@ -194,6 +194,7 @@ class _GibbsArgs(C.Structure):
         ("rc", C.c_void_p),
         ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int), ("block_gibbs_quantile_prob", C.c_double),
         ("runif_block", C.c_void_p), ("runif_resample", C.c_void_p),
+        ("runif_stream", C.c_void_p), ("runif_stream_used", C.c_void_p),
     ]
 
 
@@ -264,14 +265,16 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
                              disable_read_category_usage=False, maxDifferenceBetweenReads=1e10, Jmax=10000,
                              class_sum_cutoff=0.06, use_eMatDH_special_symbols=None, rare_common=None,
                              runif_block=None, runif_resample=None, shuffle_bin_radius=5000,
-                             block_gibbs_quantile_prob=0.95, L_grid=None):
+                             block_gibbs_quantile_prob=0.95, L_grid=None, runif_stream=None):
     """Oracle twin of ``rcpp_forwardBackwardGibbsNIPT`` (gibbs-nipt.cpp:2395-3307), production path.
 
     ``H``: starting labels (1-based); returns a dict holding the ending labels and every state
     matrix the reference mutates in place.  ``rare_common``: the all-SNP side of the panel for the final
     rare + common Gibbs (``make_eMatRead_t_rare_common = TRUE``); ``sample`` then holds the all-SNP reads.
     NIPT (``ff`` > 0) with block Gibbs: ``runif_block`` / ``runif_resample`` hold ``len(block_gibbs_iterations) x
-    nReads`` uniforms (gibbs-nipt.cpp:3016; gibbs-nipt-block.cpp:226-243).
+    nReads`` uniforms (gibbs-nipt.cpp:3016; gibbs-nipt-block.cpp:226-243); or ``runif_stream``: ONE stream consumed in the
+    reference's order -- per block pass nReads of runif_block, then one uniform per read whose class leaves a choice
+    (``out["runif_stream_used"]`` = how many were consumed).
     """
     lib().qo_gibbs.restype = C.c_int
     which = np.ascontiguousarray(which_haps_to_use, dtype=np.int32)
@@ -295,8 +298,15 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
                       int(ff == 0), int(gibbs_initialize_iteratively), int(sample_is_diploid),
                       int(disable_read_category_usage), 1, float(class_sum_cutoff), _p(runif_reads),
                       int(first_read), _p(runif_shard), C.cast(C.pointer(rs), C.c_void_p) if rs is not None else None,
-                      None, int(shuffle_bin_radius), float(block_gibbs_quantile_prob), None, None)
+                      None, int(shuffle_bin_radius), float(block_gibbs_quantile_prob), None, None, None, None)
     keep_nipt = None
+    stream_used = np.zeros(1, dtype=np.int64)
+    if ff != 0 and perform_block_gibbs and len(blocks) and runif_stream is not None:
+        Lg = np.ascontiguousarray(panel.L_grid if L_grid is None else L_grid, dtype=np.int32)
+        rst = np.ascontiguousarray(runif_stream, dtype=np.float64)
+        assert rst.size >= len(blocks) * 2 * R and len(Lg) == G
+        keep_nipt = (Lg, rst)
+        args.L_grid, args.runif_stream, args.runif_stream_used = Lg.ctypes.data, rst.ctypes.data, stream_used.ctypes.data
     if ff != 0 and perform_block_gibbs and len(blocks) and runif_block is not None:
         Lg = np.ascontiguousarray(panel.L_grid if L_grid is None else L_grid, dtype=np.int32)
         rb = np.ascontiguousarray(runif_block, dtype=np.float64)
@@ -322,7 +332,7 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
                         arr3(mats["eg"]), arr3(cs), _p(eMatRead), _p(cat), _p(hap), _p(gm), _p(gf))
     return dict(status=st, underflow_problem=(st == 1), H=Hout, H_class=Hc, alphaHat_t=mats["alpha"],
                 betaHat_t=mats["beta"], eMatGrid_t=mats["eg"], c=cs, eMatRead_t=eMatRead, read_category=cat,
-                hapProbs_t=hap, genProbsM_t=gm, genProbsF_t=gf)
+                hapProbs_t=hap, genProbsM_t=gm, genProbsF_t=gf, runif_stream_used=int(stream_used[0]))
 
 
 def calculate_eMatRead_t_vs_haplotypes(sample, haps, maxDifferenceBetweenReads, rescale_eMatRead_t=False, Jmax=1000):

@@ -227,6 +227,13 @@ typedef struct {
     int shuffle_bin_radius;
     double block_gibbs_quantile_prob;
     const double *runif_block, *runif_resample;
+    /* NULL, or the block passes' uniforms as ONE stream in the order the reference consumes R's generator at a block iteration:
+     * nReads of runif_block (gibbs-nipt.cpp:3016), then one uniform for every read whose class leaves a choice, in read order
+     * (Rcpp::sample(1:3, 1, prob) inside rcpp_sample_H_using_H_class, gibbs-nipt-block.cpp:213-246) -- a count that depends on
+     * the pass's own result.  runif_block / runif_resample are then not read; *runif_stream_used comes back with the number
+     * consumed.  (The reference's unused draws around them -- runif_proposed, runif_total -- are the caller's to skip.) */
+    const double *runif_stream;
+    int64_t *runif_stream_used;
 } qo_gibbs_args_t;
 
 /* pieces of the NIPT block Gibbs with known answers in the reference's tests (test-unit-gibbs-block-nipt.R) */

@@ -52,6 +52,7 @@ int gibbs3_waves(int Ksp, int C, int share);
 void launch_gibbs3(const void *gibbs_params, hipStream_t st);
 void launch_block_rate3(const void *gibbs_params, hipStream_t st);
 void launch_block3(const void *gibbs_params, hipStream_t st);
+void launch_resample3(const void *gibbs_params, hipStream_t st);
 }
 
 namespace {
@@ -1098,7 +1099,10 @@ int choose_gibbs_waves(int Ksp, int C, int share) {
     // per chain could hold up, and a chain's serial time is all there is -- one sample through the whole pipeline 3.53 -> 3.15 s
     // (scripts/perf_latency.py; labels identical in every geometry).  Larger launches keep one wave: a set's 128 / 256 phasing
     // chains run beside another set's main chains only while their waves fit the 1 024 SIMD slots together.
-    if (share == 0 && C <= 64) nw = 2;
+    // Round 6: up to 256 chains (a single job of 32 samples -- BASELINE configs[1] as stated -- is one launch set of 224 + 32
+    // chains): two waves per chain still leave half of the 1 024 SIMD slots to whatever shares the phase, and such a job is all
+    // serial time (tests/test_configs_gpu.py records it).
+    if (share == 0 && C <= 256) nw = 2;
     if (const char *forced = getenv("QA_GIBBS_NW")) {   // test hook: exercise every geometry
         const int f = atoi(forced);
         if (f == 1 || f == 2 || f == 5 || f == 10) nw = f;
@@ -1555,7 +1559,43 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
                 S.blk_tab.upload(h_tab.data(), h_tab.size(), st);
                 S.blk_n.upload(h_n.data(), h_n.size(), st);
                 q.blk_pass = (int)j;
+                // opts->draw_uniforms: the pass's uniforms come from the caller WHEN THE REFERENCE DRAWS THEM -- runif_block now
+                // (gibbs-nipt.cpp:3016), the per-read re-draws after the relabelling, one for every read whose class leaves a choice, in
+                // read order (rcpp_sample_H_using_H_class, gibbs-nipt-block.cpp:213-246): an R caller's stream then stays in step
+                // with the CPU package's.  Chain by chain, from this (the calling) thread.
+                const bool draw_cb = o->draw_uniforms != nullptr;
+                q.defer_resample = draw_cb ? 1 : 0;
+                std::vector<double> ub;
+                if (draw_cb) {
+                    for (int c = 0; c < C; c++) {
+                        const int R = read_off[c + 1] - read_off[c];
+                        if (R < 1) continue;
+                        ub.assign((size_t)R, 0.0);
+                        o->draw_uniforms(o->draw_uniforms_ctx, per_it_off + c, (int)j, 0, R, ub.data());
+                        qa::staged_upload(S.runif_shard.p + ((size_t)read_off[c] * q.blk_n_pass + (size_t)j * R) * 2, ub.data(), sizeof(double) * (size_t)R, st);
+                    }
+                }
                 qa::launch_block3(&q, st);
+                if (draw_cb) {
+                    std::vector<int32_t> hc((size_t)std::max(totR, 1));
+                    S.H_class.download(hc.data(), totR, st);
+                    QA_HIP(hipStreamSynchronize(st));
+                    std::vector<double> draws;
+                    for (int c = 0; c < C; c++) {
+                        const int R = read_off[c + 1] - read_off[c];
+                        if (R < 1 || seg_status[c] != 0) continue;
+                        const int32_t *h = hc.data() + read_off[c];
+                        int n = 0;
+                        for (int r = 0; r < R; r++) n += !(h[r] >= 1 && h[r] <= 3);
+                        draws.assign((size_t)std::max(n, 1), 0.0);
+                        if (n > 0) o->draw_uniforms(o->draw_uniforms_ctx, per_it_off + c, (int)j, 1, n, draws.data());
+                        ub.assign((size_t)R, 0.0);
+                        for (int r = 0, k = 0; r < R; r++)
+                            if (!(h[r] >= 1 && h[r] <= 3)) ub[(size_t)r] = draws[(size_t)k++];
+                        qa::staged_upload(S.runif_shard.p + ((size_t)read_off[c] * q.blk_n_pass + (size_t)j * R) * 2 + R, ub.data(), sizeof(double) * (size_t)R, st);
+                    }
+                    qa::launch_resample3(&q, st);
+                }
                 if (tmg) fprintf(stderr, "[qa_gibbs C=%d] block pass %d: device idle for the host's block tables %.1f ms (tables %.1f on %d threads, uploads enqueued %.1f)\n",
                                  C, (int)j, (now() - tg0) * 1e3, (tg1 - tg0) * 1e3, n_thr, (now() - tg1) * 1e3);
                 it0 = passes[j] + 1;
@@ -1662,9 +1702,14 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
     }
     if (o->ff != 0.0 && o->perform_block_gibbs && o->n_block_gibbs_iterations > 0 &&
         (!o->L_grid || o->shuffle_bin_radius <= 0 || !(o->block_gibbs_quantile_prob > 0 && o->block_gibbs_quantile_prob < 1) ||
-         (!runif_shard && !seed_shard && !seed_reads))) {
+         (!runif_shard && !seed_shard && !seed_reads && !o->draw_uniforms))) {
         qa::set_error("qa_gibbs_batch: the NIPT block Gibbs needs opts->L_grid, shuffle_bin_radius, block_gibbs_quantile_prob "
-                      "and the block passes' uniforms (runif_shard or seeds)");
+                      "and the block passes' uniforms (runif_shard, seeds, or opts->draw_uniforms)");
+        return QA_ERR_INVALID;
+    }
+    if (o->draw_uniforms && (o->ff == 0.0 || seed_reads || seed_shard)) {
+        qa::set_error("qa_gibbs_batch: opts->draw_uniforms serves the NIPT block passes (ff > 0) of a call with explicit uniforms "
+                      "(runif_reads given, no seeds)");
         return QA_ERR_INVALID;
     }
     // the uniforms of the shard passes (diploid) / block passes (NIPT): explicit, or the per-chain seed of the counter-based
@@ -1675,7 +1720,7 @@ static int gibbs_batch_impl(qa_panel_t *pn, const qa_rare_common *rc, const qa_g
     }
     {
         const bool passes = o->perform_block_gibbs && o->n_block_gibbs_iterations > 0 && (o->ff != 0.0 || o->do_shard_block_gibbs);
-        if (passes && !runif_shard && !(seed_reads && seed_shard)) {
+        if (passes && !runif_shard && !(seed_reads && seed_shard) && !(o->ff != 0.0 && o->draw_uniforms)) {
             qa::set_error("qa_gibbs_batch: block / shard passes requested without their uniforms (runif_shard, or seed_reads and "
                           "seed_shard)");
             return QA_ERR_INVALID;

@@ -625,6 +625,15 @@ __device__ __forceinline__ void block_sync() {
 
 // Rcpp::sample(1:3, 1, FALSE, probs) from its one uniform (Rcpp sugar: mass normalised, decreasing order, first
 // cumulative mass >= u)
+__device__ inline int sample3(double p0, double p1, double p2, double u);
+// a read's new label from its class (gibbs-nipt-block.cpp:226-243): classes 1-3 fix it, the others draw
+__device__ inline int resample_label(int hc, double ff, double u) {
+    if (hc >= 1 && hc <= 3) return hc;
+    if (hc == 0 || hc == 7) return sample3(0.5, 0.5 - ff * 0.5, ff * 0.5, u);
+    if (hc == 4) return sample3(0.5, 0.5 - 0.5 * ff, 0, u);
+    if (hc == 5) return sample3(0.5, 0, 0.5 * ff, u);
+    return sample3(0, 0.5 - ff * 0.5, ff * 0.5, u);
+}
 __device__ inline int sample3(double p0, double p1, double p2, double u) {
     double p[3] = {p0, p1, p2};
     int perm[3] = {1, 2, 3};
@@ -986,21 +995,23 @@ __global__ __launch_bounds__(64 * NW) void k_block3(GibbsParams p) {
         for (int h = 0; h < NH; h++) e[h] = en[h];
     }
     block_sync();
-    // ---- rcpp_sample_H_using_H_class (:213-246)
-    for (int r = t; r < R; r += NT) {
-        const int hc = ch.Hc[r];
-        int hn;
-        if (hc >= 1 && hc <= 3) hn = hc;
-        else {
-            const double u = u_draw(r);
-            if (hc == 0 || hc == 7) hn = sample3(0.5, 0.5 - ff * 0.5, ff * 0.5, u);
-            else if (hc == 4) hn = sample3(0.5, 0.5 - 0.5 * ff, 0, u);
-            else if (hc == 5) hn = sample3(0.5, 0, 0.5 * ff, u);
-            else hn = sample3(0, 0.5 - ff * 0.5, ff * 0.5, u);
-        }
-        ch.H[r] = hn;
+    // ---- rcpp_sample_H_using_H_class (:213-246); with p.defer_resample the caller draws the uniforms first (in the reference's
+    // order: only the reads whose class leaves a choice draw) and k_resample3 does this loop
+    if (!p.defer_resample) {
+        for (int r = t; r < R; r += NT) ch.H[r] = resample_label(ch.Hc[r], ff, u_draw(r));
     }
     // eMatGrid, forward and backward from the new labels (:1898-1954): the next k_gibbs3 launch does them first (p.rebuild)
+}
+
+// rcpp_sample_H_using_H_class (gibbs-nipt-block.cpp:213-246) on its own: one workgroup per chain, the pass's per-read uniforms
+// from the explicit buffer (the caller has just written them: qa_gibbs_opts_t.draw_uniforms)
+__global__ __launch_bounds__(256) void k_resample3(GibbsParams p) {
+    const int c = blockIdx.x, R = p.read_off[c + 1] - p.read_off[c];
+    const double ff = p.ff_chain ? p.ff_chain[c] : p.ff;
+    const double *ru = p.runif_shard + ((size_t)p.read_off[c] * p.blk_n_pass + (size_t)p.blk_pass * R) * 2;
+    int32_t *H = p.H + p.read_off[c];
+    const int32_t *Hc = p.H_class + p.read_off[c];
+    for (int r = threadIdx.x; r < R; r += blockDim.x) H[r] = resample_label(Hc[r], ff, ru[R + r]);
 }
 
 template <int NE, int NW>
@@ -1053,6 +1064,12 @@ void launch_gibbs3(const void *params, hipStream_t st) {
 void launch_block_rate3(const void *params, hipStream_t st) {
     const GibbsParams &prm = *static_cast<const GibbsParams *>(params);
     hipLaunchKernelGGL(k_block_rate3, dim3((prm.G - 1 + 3) / 4, prm.C), dim3(256), 0, st, prm);
+    QA_HIP(hipGetLastError());
+}
+
+void launch_resample3(const void *params, hipStream_t st) {
+    const GibbsParams &prm = *static_cast<const GibbsParams *>(params);
+    hipLaunchKernelGGL(k_resample3, dim3(prm.C), dim3(256), 0, st, prm);
     QA_HIP(hipGetLastError());
 }
 

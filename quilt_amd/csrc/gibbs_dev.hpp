@@ -97,6 +97,7 @@ struct GibbsParams {
     const int32_t *blk_n;       // [C] n_blocks
     double *blk_rate2;          // [C][G] rate2 of the block definition (k_block_rate3)
     int blk_pass, blk_n_pass;   // this pass / passes per call (indexes the pass's uniforms)
+    int defer_resample;         // k_block3 leaves rcpp_sample_H_using_H_class to k_resample3 (the caller draws its uniforms in between)
     double ff;
     const double *ff_chain;     // [C] or null: per-chain fetal fraction overriding ff
     double *per_it;             // [C][n_its][8] or null: per sweep -sum(log c_h) and the label counts (qa_gibbs_opts_t.per_it_out)

@@ -32,6 +32,7 @@ class GibbsOpts(C.Structure):
         ("L_grid", C.c_void_p), ("shuffle_bin_radius", C.c_int32), ("block_gibbs_quantile_prob", C.c_double),
         ("ff_chain", C.c_void_p), ("per_it_out", C.c_void_p), ("hap_words_out", C.c_void_p),
         ("hap_major_out", C.c_void_p), ("hap_major_labels", C.c_int32), ("reads_same_as", C.c_void_p),
+        ("draw_uniforms", C.c_void_p), ("draw_uniforms_ctx", C.c_void_p),
     ]
 
 

@@ -28,8 +28,11 @@
  * as Rcpp's sugar EmpiricalSample does) between GetRNGstate() / PutRNGstate() and passes them down; the device never generates R-incompatible numbers on this
  * path.  The shard pass draws nGrids - 1 uniforms per block iteration: what gibbs-nipt-block.cpp:2054 draws with
  * shard_check_every_pair = TRUE, the production value (quilt.R:178); FALSE is rejected.  Where the reference's draw count depends on
- * intermediate results (`Rcpp::sample(1:3, 1, prob)` per read in rcpp_sample_H_using_H_class, NIPT only) the stream
- * cannot be pre-drawn in R's order: one uniform per read is drawn instead (documented deviation).
+ * intermediate results (`Rcpp::sample(1:3, 1, prob)` per read whose class leaves a choice, in rcpp_sample_H_using_H_class, NIPT
+ * only) the stream cannot be pre-drawn: since round 6 the library asks for those uniforms WHEN the reference draws them
+ * (qa_gibbs_opts_t.draw_uniforms -> draw_uniforms_from_R below: runif_proposed / runif_block / runif_total before a block pass,
+ * one unif_rand() per drawing read after its relabelling), so the NIPT entry consumes R's generator in the reference's order and
+ * number as well (tests/test_shim_gpu.py counts them against the oracle run on the same stream).
  *
  * Type-checked without R by `make -C shim check` against shim/qa_r_api.h (declarations only), and EXECUTED without R by
  * tests/test_shim_gpu.py / tests/test_shim_cpu.py under tests/c/mini_r.c, a test runtime behind the same declarations (objects
@@ -254,6 +257,23 @@ SEXP qa_QUILT_Rcpp_haploid_dosage_versus_refs(
 /* ---- _QUILT_rcpp_forwardBackwardGibbsNIPT: the 63 arguments of RcppExports.cpp:968, in order -------------------------- */
 
 /* calculate_likelihoods_values + add_to_per_it_likelihoods (gibbs-nipt.cpp:1463-1621) from the per-sweep record */
+/* qa_gibbs_opts_t.draw_uniforms for the 63-argument entry (NIPT): the block passes' uniforms drawn from R's generator WHEN the
+ * reference draws them.  At a block iteration the reference draws runif_proposed (6 x nReads, unused by block_approach 6),
+ * runif_block (nReads) and runif_total (nReads, read only by the total relabelling, which is off) -- gibbs-nipt.cpp:3013-3017 --
+ * and then, inside rcpp_sample_H_using_H_class (gibbs-nipt-block.cpp:213-246), one uniform per Rcpp::sample(1:3, 1, prob), i.e.
+ * per read whose class leaves a choice, in read order.  The library asks for the first kind before the pass (what = 0) and for
+ * the second after its relabelling (what = 1), from the thread that made the .Call. */
+static void draw_uniforms_from_R(void *ctx, int32_t chain, int32_t pass, int32_t what, int32_t n, double *out) {
+    (void)ctx; (void)chain; (void)pass;
+    if (what == 0) {
+        for (long i = 0; i < 6L * n; i++) (void)unif_rand();   /* :3013-3015 runif_proposed */
+        for (int r = 0; r < n; r++) out[r] = unif_rand();     /* :3016 runif_block */
+        for (int r = 0; r < n; r++) (void)unif_rand();        /* :3017 runif_total */
+    } else {
+        for (int r = 0; r < n; r++) out[r] = unif_rand();     /* Rcpp::sample(one_through_3, 1, false, probs): one unif_rand() each */
+    }
+}
+
 static double lgamma1(double x) { return lgamma(x + 1.0); }
 static void fill_per_it_row(double *m, int nrow, int row, const double *rec, double ff, int it, double p_H_class) {
     const double prior[3] = {0.5, (1 - ff) / 2, ff / 2};
@@ -377,7 +397,7 @@ SEXP qa_QUILT_rcpp_forwardBackwardGibbsNIPT(
     /* ---- the reference's draws, in its order (RcppExports.cpp:971 RNGScope) */
     const size_t n_pass_unif = ff != 0 ? (size_t)nb * 2 * (size_t)R : (size_t)nb * (size_t)(G - 1);
     double *runif_reads = (double *)malloc(sizeof(double) * ((size_t)R * (size_t)n_its + 1));
-    double *runif_pass = (double *)malloc(sizeof(double) * (n_pass_unif + 1));
+    double *runif_pass = (double *)calloc(n_pass_unif + 1, sizeof(double));   /* (NIPT: filled by the library through draw_uniforms) */
     int32_t first_read = 0;
     GetRNGstate();
     for (size_t i = 0; i < (size_t)R * (size_t)n_its; i++) runif_reads[i] = unif_rand();         /* gibbs-nipt.cpp:2845 */
@@ -388,20 +408,23 @@ SEXP qa_QUILT_rcpp_forwardBackwardGibbsNIPT(
         first_read = (int32_t)(unif_rand() * (double)R);
         if (first_read >= R) first_read = R - 1;
     }
-    if (o.perform_block_gibbs) {
+    if (o.perform_block_gibbs && ff != 0) {
+        /* NIPT: the block passes' draws depend on the passes' own results (one Rcpp::sample per read whose class leaves a choice),
+         * so they are made when the reference makes them, through the library's callback; the generator stays open until the call
+         * returns (PutRNGstate below the call) */
+        o.draw_uniforms = draw_uniforms_from_R;
+        o.draw_uniforms_ctx = NULL;
+    }
+    if (o.perform_block_gibbs && ff == 0) {
         for (int ib = 0; ib < nb; ib++) {
             for (size_t i = 0; i < 6 * (size_t)R; i++) (void)unif_rand();                        /* :3013-3015 runif_proposed (unused by approach 6) */
-            if (ff != 0) {
-                for (int r = 0; r < R; r++) runif_pass[((size_t)ib * 2 + 0) * R + r] = unif_rand();   /* :3016 runif_block */
-                for (int r = 0; r < R; r++) runif_pass[((size_t)ib * 2 + 1) * R + r] = unif_rand();   /* :3017 runif_total: here the per-read re-draws */
-            } else {
+            {
                 for (size_t i = 0; i < 2 * (size_t)R; i++) (void)unif_rand();                    /* :3016-3017, no effect for diploid samples */
                 if (o.do_shard_block_gibbs)
                     for (int g = 0; g < G - 1; g++) runif_pass[(size_t)ib * (G - 1) + g] = unif_rand();   /* gibbs-nipt-block.cpp:2054 */
             }
         }
     }
-    PutRNGstate();
 
     /* ---- starting labels in, ending labels out */
     SEXP start = VECTOR_ELT(VECTOR_ELT(double_list_of_starting_read_labelsSEXP, 0), 0);
@@ -419,6 +442,7 @@ SEXP qa_QUILT_rcpp_forwardBackwardGibbsNIPT(
         : qa_gibbs_batch(panel, &o, 1, INTEGER(which_haps_to_useSEXP), read_off, read_ptr, u, bq, INTEGER(wif0SEXP), runif_reads,
                          &first_read, runif_pass, H, H_class, (want_hap || want_gen) ? REAL(hap) : NULL,
                          want_gen ? REAL(gm) : NULL, want_gen ? REAL(gf) : NULL, &underflow, state, NULL, NULL);
+    PutRNGstate();   /* (after the call: with NIPT block passes the library draws through draw_uniforms_from_R while it runs) */
     SEXP out = R_NilValue;
     if (st >= 0 && !underflow) {
         /* the matrices the reference mutates in place (pass_in_alphaBeta = TRUE: R's buffers, quilt.R:731-745) */

@@ -79,7 +79,7 @@ def test_bench_names_its_workload_and_its_counter_summary():
     assert "configs[4]" in bench.workload_label("nipt", 50000, 128) and "configs[3]" in bench.workload_label("ont", 50000, 128)
     assert "QUILT2's default mode" in bench.workload_label("short", 50000, 128, True, True)
     assert bench.workload_label("short", 20000, 64).startswith("not a BASELINE.json configuration")
-    want = {("short", 50000, 128, False, False): "r05_pmc_traffic.json", ("short", 5000, 32, False, False): "r05_pmc_traffic_configs1.json",
+    want = {("short", 50000, 128, False, False): "r06_pmc_traffic.json", ("short", 5000, 32, False, False): "r05_pmc_traffic_configs1.json",
             ("nipt", 50000, 128, False, False): "r05_pmc_traffic_nipt.json", ("ont", 50000, 128, False, False): "r05_pmc_traffic_ont.json",
             ("short", 50000, 128, True, False): "r05_pmc_traffic_mspbwt.json", ("short", 50000, 128, True, True): "r05_pmc_traffic_quilt2_default.json"}
     for key, name in want.items():

@@ -199,9 +199,13 @@ def test_full_panel_entry_38_arguments(R, panel):
 def test_gibbs_entry_63_arguments(R, panel, ff):
     """`.Call("_QUILT_rcpp_forwardBackwardGibbsNIPT", <63 arguments>)` as impute_one_sample makes it (functions.R:2385-2700): the shim
     draws the call's uniforms with unif_rand() in the reference's order (reads x sweeps, the first read, per block pass six + two
-    vectors over the reads and -- diploid -- nGrids - 1 for the shard pass; NIPT: the block choice and the label re-draws), between
-    GetRNGstate / PutRNGstate; labels, H_class, hapProbs / genProbs and the state matrices R passed in equal the Python mirror's call
-    with the same numbers."""
+    vectors over the reads and -- diploid -- nGrids - 1 for the shard pass), between GetRNGstate / PutRNGstate; labels, H_class,
+    hapProbs / genProbs and the state matrices R passed in equal the Python mirror's call with the same numbers.
+    NIPT (round 6): after a block pass's relabelling the reference draws ONE uniform per read whose class leaves a choice
+    (Rcpp::sample inside rcpp_sample_H_using_H_class) -- a count that depends on the pass's result.  The library asks the shim for
+    those when the reference draws them (qa_gibbs_opts_t.draw_uniforms), so R's generator is consumed in the reference's order AND
+    NUMBER: checked against the oracle run on the same stream (labels and classes identical, the count of uniforms exactly the
+    oracle's)."""
     from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
     from quilt_amd.native import DevicePanel
     from quilt_amd.synth import make_synthetic_sample
@@ -213,21 +217,33 @@ def test_gibbs_entry_63_arguments(R, panel, ff):
     which = np.sort(rng.choice(panel.K, Ks, replace=False)).astype(np.int32) + 1
     start = rng.integers(1, 4 if ff else 3, size=Rn).astype(np.int32)
     per_block = 8 * Rn + (0 if ff else G - 1)
-    U = rng.random(Rn * n_its + 1 + nb * per_block)
+    U = rng.random(Rn * n_its + 1 + nb * (per_block + (Rn if ff else 0)))   # (NIPT: room for up to nReads re-draws per pass)
     ru = U[:Rn * n_its]
     first_read = min(int(U[Rn * n_its] * Rn), Rn - 1)
     base = Rn * n_its + 1
-    kw = {}
+    n_expected = U.size
     if ff:
-        kw["runif_block"] = np.stack([U[base + b * per_block + 6 * Rn: base + b * per_block + 7 * Rn] for b in range(nb)])
-        kw["runif_resample"] = np.stack([U[base + b * per_block + 7 * Rn: base + b * per_block + 8 * Rn] for b in range(nb)])
-        shard = np.zeros(1)
+        # R's stream at a block iteration: 6 x nReads (runif_proposed), nReads (runif_block), nReads (runif_total), then the
+        # re-draws.  The oracle takes [runif_block, re-draws] per pass as one stream; how many re-draws a pass makes is its own
+        # result, so the stream is built pass by pass (a pass's count does not depend on what lies behind it).
+        from oracle import oracle as O
+        at, n_draw, stream = base, [], []
+        for j in range(nb):
+            stream_j = stream + [U[at + 6 * Rn: at + 7 * Rn], U[at + 8 * Rn: at + 9 * Rn]]   # this pass: block, then up to nReads draws
+            want = O.forwardBackwardGibbsNIPT(panel, s, which, start, ru, first_read, np.zeros(max(nb * (G - 1), 1)), ff=ff,
+                                              n_gibbs_burn_in_its=n_burn, n_gibbs_sample_its=n_samp, block_gibbs_iterations=blocks[:j + 1],
+                                              runif_stream=np.concatenate(stream_j))
+            n_draw.append(want["runif_stream_used"] - sum(Rn + n for n in n_draw) - Rn)
+            stream += [U[at + 6 * Rn: at + 7 * Rn], U[at + 8 * Rn: at + 8 * Rn + n_draw[-1]]]
+            at += 8 * Rn + n_draw[-1]
+        assert all(0 < n < Rn for n in n_draw), n_draw   # (some reads' classes fix their label, some draw: the case worth testing)
+        n_expected = at
     else:
         shard = np.concatenate([U[base + b * per_block + 8 * Rn: base + (b + 1) * per_block] for b in range(nb)])
-    dev = DevicePanel(panel)
-    want = rcpp_forwardBackwardGibbsNIPT(dev, s, which, start, ru, first_read, shard, ff=ff, n_gibbs_burn_in_its=n_burn, n_gibbs_sample_its=n_samp,
-                                         block_gibbs_iterations=blocks, return_state=True, **kw)
-    dev.close()
+        dev = DevicePanel(panel)
+        want = rcpp_forwardBackwardGibbsNIPT(dev, s, which, start, ru, first_read, shard, ff=ff, n_gibbs_burn_in_its=n_burn,
+                                             n_gibbs_sample_its=n_samp, block_gibbs_iterations=blocks, return_state=True)
+        dev.close()
     assert not want["underflow_problem"]
     R.load_unif(U)
     z = lambda: R.real(np.zeros((Ks, G)))
@@ -243,14 +259,20 @@ def test_gibbs_entry_63_arguments(R, panel, ff):
              shuffle_bin_radius=R.integer([5000]), block_gibbs_iterations=R.integer(blocks), block_gibbs_quantile_prob=R.real([0.95]))
     a.update(_panel_args(R, panel))
     out = _call_by_name(R, "_QUILT_rcpp_forwardBackwardGibbsNIPT", a)
-    assert R.L.mini_r_unif_drawn() == U.size and R.L.mini_r_rng_violations() == 0
+    assert R.L.mini_r_unif_drawn() == n_expected and R.L.mini_r_rng_violations() == 0
     assert out["underflow_problem"][0] == 0
     assert np.array_equal(out["H"], want["H"]) and np.array_equal(out["H_class"], want["H_class"])
     assert np.array_equal(out["double_list_of_ending_read_labels"][0][0], want["H"])
-    assert np.array_equal(out["hapProbs_t"], want["hapProbs_t"])
-    assert np.array_equal(out["genProbsM_t"], want["genProbsM_t"]) and np.array_equal(out["genProbsF_t"], want["genProbsF_t"])
-    for name in ("alphaHat_t1", "alphaHat_t2", "betaHat_t1", "betaHat_t2", "eMatGrid_t1", "eMatGrid_t2"):
-        assert np.array_equal(R.value(a[name]), want[name]), name
+    if ff:   # against the oracle (fp64 CPU, other summation order): to rounding
+        np.testing.assert_allclose(out["hapProbs_t"], want["hapProbs_t"], rtol=1e-9, atol=1e-14)
+        np.testing.assert_allclose(out["genProbsM_t"], want["genProbsM_t"], rtol=1e-9, atol=1e-14)
+        for i, name in enumerate(("alphaHat_t1", "alphaHat_t2")):
+            np.testing.assert_allclose(R.value(a[name]), want["alphaHat_t"][i], rtol=1e-9, atol=1e-300)
+    else:    # against the Python mirror's call of the same library: bit for bit
+        assert np.array_equal(out["hapProbs_t"], want["hapProbs_t"])
+        assert np.array_equal(out["genProbsM_t"], want["genProbsM_t"]) and np.array_equal(out["genProbsF_t"], want["genProbsF_t"])
+        for name in ("alphaHat_t1", "alphaHat_t2", "betaHat_t1", "betaHat_t2", "eMatGrid_t1", "eMatGrid_t2"):
+            assert np.array_equal(R.value(a[name]), want[name]), name
     pit = out["per_it_likelihoods"]
     assert pit.shape == (n_its, 13) and np.array_equal(pit[:, 2], np.arange(1, n_its + 1)) and np.isfinite(pit[:, 7]).all()
     assert len(set(out["H"].tolist())) == (3 if ff else 2)
