@@ -303,8 +303,10 @@ def forwardBackwardGibbsNIPT(panel, sample, which_haps_to_use, H, runif_reads, f
     stream_used = np.zeros(1, dtype=np.int64)
     if ff != 0 and perform_block_gibbs and len(blocks) and runif_stream is not None:
         Lg = np.ascontiguousarray(panel.L_grid if L_grid is None else L_grid, dtype=np.int32)
-        rst = np.ascontiguousarray(runif_stream, dtype=np.float64)
-        assert rst.size >= len(blocks) * 2 * R and len(Lg) == G
+        # (padded with NaN: a pass may draw up to nReads uniforms, a count only its own result fixes; a stream that is too short
+        # shows as NaN-driven labels and a `runif_stream_used` beyond its length instead of a read past the buffer)
+        rst = np.concatenate([np.asarray(runif_stream, dtype=np.float64).ravel(), np.full(len(blocks) * 2 * R, np.nan)])
+        assert len(Lg) == G
         keep_nipt = (Lg, rst)
         args.L_grid, args.runif_stream, args.runif_stream_used = Lg.ctypes.data, rst.ctypes.data, stream_used.ctypes.data
     if ff != 0 and perform_block_gibbs and len(blocks) and runif_block is not None:
