@@ -545,7 +545,8 @@ def main():
         a.bam_dir = bam_dir   # (kept for the I/O-inclusive leg after the timed region; removed there)
     samples = [flat[st * a.batch:(st + 1) * a.batch] for st in range(n_steps)]
     cpu_pipeline = None
-    if rank == 0 and world == 1 and cpu is not None and a.cpu_baseline == "whole" and (not a.mspbwt or a.mspbwt_search == "scan"):
+    if (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stub and a.cpu_baseline == "whole" and
+            (not a.mspbwt or a.mspbwt_search == "scan")):
         # the baseline proper: whole samples, one per physical core, all cores at once; the composed figure stays beside it
         cores = physical_cores()
         work, st = [], n_steps - 1
@@ -554,8 +555,9 @@ def main():
             st -= 1
         whole, ref = cpu_baseline_whole(panel, params, work, cores, a.cpu_baseline_budget, min(a.r2_vs_cpu, len(samples[-1])), rc)
         if whole is not None:
-            whole["composed"] = cpu
-            whole["composed_over_whole"] = round(cpu["value"] / whole["value"], 3)
+            if cpu is not None:   # (no composed figure with impute_rare_common: its all-SNP calls are not in the composition)
+                whole["composed"] = cpu
+                whole["composed_over_whole"] = round(cpu["value"] / whole["value"], 3)
             cpu = whole
         if ref is not None:
             cpu_pipeline = ref
