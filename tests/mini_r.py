@@ -37,6 +37,8 @@ class R:
                                 ("mini_r_dotcall", P, [C.c_char_p, C.c_int, C.POINTER(P)]), ("mini_r_last_error", C.c_char_p, []),
                                 ("mini_r_arity", C.c_int, [C.c_char_p]), ("mini_r_load_unif", None, [C.POINTER(C.c_double), C.c_size_t]),
                                 ("mini_r_unif_drawn", C.c_size_t, []), ("mini_r_rng_violations", C.c_int, []),
+                                ("mini_r_gc_violations", C.c_int, []), ("mini_r_gc_report", C.c_char_p, []),
+                                ("mini_r_protect_imbalance", C.c_int, []), ("mini_r_gc_selftest", C.c_int, []),
                                 ("mini_r_init", None, []), ("mini_r_reset", None, [])]:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
@@ -120,6 +122,10 @@ class R:
     def dotcall(self, name: str, *args):
         arr = (C.c_void_p * max(len(args), 1))(*args)
         out = self.L.mini_r_dotcall(name.encode(), len(args), arr)
+        # the emulated gctorture (tests/c/mini_r.c): an object used after a collection would have freed it, or a PROTECT stack left
+        # unbalanced, fails the call that did it -- whatever the test was looking at
+        if self.L.mini_r_gc_violations() or self.L.mini_r_protect_imbalance():
+            raise AssertionError("R memory protocol: " + self.L.mini_r_gc_report().decode())
         if not out:
             raise RError(self.L.mini_r_last_error().decode())
         return self.value(out)

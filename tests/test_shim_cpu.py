@@ -55,3 +55,14 @@ def test_compute_routine_without_a_device_is_an_r_error(R):
     prm = R.named(dict(nGibbsSamples=R.integer([2])))
     with pytest.raises(RError, match="(?i)device"):
         R.dotcall("qa_impute_sample_range", R.list([R.sample_reads(s)]), R.panel_objects(panel), prm, R.real([0.0]), R.integer([1]), R.nil)
+
+
+def test_the_runtime_catches_the_two_classic_r_memory_mistakes(R):
+    """tests/c/mini_r.c emulates R's gctorture(TRUE): inside a `.Call` every allocation collects what the call made and left
+    unreachable from the PROTECT stack, any later use of such an object is a violation, and the stack must be empty at return --
+    so every shim test also exercises PROTECT discipline (tests/mini_r.py fails the call that breaks it).  The emulation itself:
+    an object used across an allocation it was not protected for is caught (bit 0), a routine that returns with a PROTECT too many
+    is caught (bit 1), the correct forms raise nothing (bit 2 stays clear)."""
+    assert R.L.mini_r_gc_selftest() == 3
+    assert R.L.mini_r_gc_violations() == 0 and R.L.mini_r_protect_imbalance() == 0
+    assert R.arity("qa_impute_bam_range") == 6
