@@ -61,6 +61,8 @@ static int g_n_call_objs = 0, g_cap_call_objs = 0;
 static SEXP *g_preserved = NULL;
 static int g_n_preserved = 0, g_cap_preserved = 0;
 static const char *g_routine = "";
+static SEXP *g_args = NULL;        /* the current call's arguments: the caller protects them, and with them whatever the routine */
+static int g_n_args = 0;           /* stores INTO them (best_haps_stuff_list[[i]] <- ...) */
 
 static void gc_mark(SEXP x) {
     if (!x || x->mark || x->type == NILSXP || x->type == SYMSXP) return;
@@ -83,10 +85,12 @@ static void gc_collect(void) {
     if (!g_in_call) return;
     for (int i = 0; i < g_pdepth; i++) gc_mark(g_pstack[i]);
     for (int i = 0; i < g_n_preserved; i++) gc_mark(g_preserved[i]);
+    for (int i = 0; i < g_n_args; i++) gc_mark(g_args[i]);
     for (int i = 0; i < g_n_call_objs; i++)
         if (!g_call_objs[i]->mark) g_call_objs[i]->dead = 1;
     for (int i = 0; i < g_pdepth; i++) gc_unmark(g_pstack[i]);
     for (int i = 0; i < g_n_preserved; i++) gc_unmark(g_preserved[i]);
+    for (int i = 0; i < g_n_args; i++) gc_unmark(g_args[i]);
 }
 /* every API entry that touches an object passes through here */
 static SEXP use(SEXP x, const char *where) {
@@ -326,6 +330,16 @@ int mini_r_gc_selftest(void) {
         SEXP b = Rf_allocVector(REALSXP, 2);
         INTEGER(a)[0] = 1; REAL(VECTOR_ELT(l, 0))[0] = REAL(b)[0];
         Rf_unprotect(2);
+        /* ... and an object stored INTO an argument (the caller's list) lives on without a PROTECT of its own */
+        SEXP arg = Rf_allocVector(VECSXP, 1);
+        arg->epoch = 0;
+        g_n_call_objs -= 1;   /* (pretend the caller made it) */
+        SEXP args1[1] = {arg};
+        g_args = args1; g_n_args = 1;
+        SET_VECTOR_ELT(arg, 0, Rf_allocVector(INTSXP, 3));
+        (void)Rf_allocVector(REALSXP, 1);
+        INTEGER(VECTOR_ELT(arg, 0))[0] = 7;
+        g_n_args = 0;
         if (g_gc_violations != v0) found |= 4;   /* a false positive */
     }
     {   /* wrong: a is not protected while b is allocated */
@@ -395,10 +409,13 @@ SEXP mini_r_dotcall(const char *name, int n, SEXP *a) {
     g_routine = c->name;
     g_n_call_objs = 0;
     g_pdepth = 0;
+    g_args = a;
+    g_n_args = n;
     if (setjmp(g_jmp)) {
         g_jmp_set = 0;
         g_rng_open = 0;
         g_in_call = 0;
+        g_n_args = 0;
         g_pdepth = 0;   /* (R unwinds the PROTECT stack on an error) */
         return NULL;
     }
@@ -414,6 +431,7 @@ SEXP mini_r_dotcall(const char *name, int n, SEXP *a) {
     }
     g_jmp_set = 0;
     g_in_call = 0;
+    g_n_args = 0;
     if (g_pdepth != 0) {   /* R: "Warning: stack imbalance in '.Call'" */
         if (g_protect_imbalance++ == 0 && !g_gc_report[0])
             snprintf(g_gc_report, sizeof g_gc_report, "%s returned with %d object(s) left on the PROTECT stack", c->name, g_pdepth);
