@@ -928,6 +928,10 @@ __global__ __launch_bounds__(kNT) void k_bwd64d(PassParams prm, int n_last) {
     };
     prefetch(G - 1, 0, 0, t);
     __syncthreads();
+    // (Round 6, what bounds this kernel: 256 / 128 / 64 passes per launch take 39.0 / 35.9 / 33.6 ms -- a workgroup's own serial
+    // progress, i.e. the latency of its half-chunk-ahead loads against 1.2 us of work per half chunk, not the device's bandwidth.
+    // Measured and dropped: touching the half chunk TWO steps ahead with one dword per 128-byte line, so that the real loads hit
+    // L2 -- three more live registers and the in-order vmcnt waits on the touches: 35 -> 70 spilled registers, 39.0 -> 53 ms.)
 
     // one pass over the state: gamma of grid gp (its alpha, its codes) into the histogram and, unless gp == 0, the update
     // with grid gp's emissions.  Returns this thread's share of sum(e * beta).
