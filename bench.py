@@ -736,15 +736,19 @@ def main():
                 "value": len(files) / t_io, "unit": "samples/sec", "samples": len(files), "wall_s": round(t_io, 3),
                 "seconds": {k: round(v, 3) for k, v in sec.items()},
                 "io_threads": (max(1, a.io_threads // max(world, 1)) if a.io_threads else "min(32, hardware threads)"),
-                "share_of_wall": {"load": round(sec["load"] / t_io, 4), "impute": round(sec["impute"] / t_io, 4),
-                                  "format_and_counts": round(sec["format"] / t_io, 4)},
+                "share_of_wall": {"impute_with_loading_and_formatting_beside_it": round(sec["impute"] / t_io, 4),
+                                  "format_and_counts_left_at_the_end": round(sec["format"] / t_io, 4),
+                                  "outside_the_native_call": round(1 - sec["total"] / t_io, 4)},
+                "last_file_loaded_at_s": round(sec["load"], 3),
                 "compute_only_value": out["value"],
                 "last_step_dosages_equal_the_timed_region": bool(same),
                 "vcf_bytes_per_sample": int(np.mean([len(c.buf) for c in r_io["columns"] if c is not None])),
                 "results_copied_into_python": a.batch,
-                "what": "qa_impute_bam_range over the timed steps' BAM files: load (host threads) -> qa_impute_samples, the columns of "
-                        "finished launch sets formatted on host threads beside it -> the last sets' columns + the range's count arrays; one "
-                        "native call, everything inside the clock (seconds.format = what is left after the device work ends)"}
+                "what": "qa_impute_bam_range over the timed steps' BAM files, one native call, everything inside the clock: the files are "
+                        "loaded on host threads in file order BESIDE the imputation (qa_impute_samples is handed each sample when its "
+                        "launch set is taken; seconds.load = when the last file was in), the columns of finished launch sets are "
+                        "formatted on host threads beside it too; seconds.format = the last sets' columns + the range's count arrays, "
+                        "after the device work ends"}
             import shutil
             shutil.rmtree(a.bam_dir, ignore_errors=True)
         if a.dotcall > 0 and native is not None and world == 1:

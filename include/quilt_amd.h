@@ -638,6 +638,41 @@ typedef struct {
 } qa_impute_nipt_t;
 
 /*
+ * The reads of the call's samples handed over ONE SAMPLE AT A TIME, when the loop reaches them (params->sample_source) -- the
+ * reference's loop loads a sample's BAM inside the loop body too (functions.R:251-298: get_sampleReads_from_dir_for_sample is the
+ * first thing get_and_impute_one_sample does), so a range's first samples are on the device while its last ones are still on disk.
+ *
+ *   acquire(ctx, s, view)   called by the host thread that takes the launch set holding sample s, before anything of s is read;
+ *                           for every s of a set in ascending order, once per s; concurrently for samples of DIFFERENT sets.  It
+ *                           blocks until the sample is there and fills *view.  Returns
+ *                             QA_OK              view filled: n_reads >= 1 reads in the per-sample form of the flat arrays (read_ptr
+ *                                                n_reads + 1 offsets from 0 into u / bq; wif n_reads), with impute_rare_common the
+ *                                                all-SNP reads too, and read_labels = where the sample's n_reads labels go
+ *                             QA_END_OF_SAMPLES  the range ends BEFORE s: n_sample was an upper bound (a caller that drops samples
+ *                                                with too few reads, functions.R:274-287, learns the count while loading).  Every
+ *                                                later s ends too.
+ *                             < 0                failure: the call fails with that status (the callback's text via qa_last_error
+ *                                                if it set one)
+ *   The views' arrays must stay valid until on_samples_done has covered the sample, or the call has returned.
+ *   What is indexed by the sample -- params->sample_index[s], nipt->ff[s] -- is read only AFTER acquire(s) returned: the caller
+ *   may fill those entries as it learns them.
+ * With a source the flat read arrays and read_labels of qa_impute_samples may be NULL (they are not read); everything else --
+ * results, random streams, launch plan -- is the same as for the same samples handed over flat.
+ */
+#define QA_END_OF_SAMPLES 2
+typedef struct {
+    int32_t n_reads;
+    const int32_t *read_ptr, *u, *bq, *wif;
+    int32_t n_reads_all;                                  /* impute_rare_common only */
+    const int32_t *read_ptr_all, *u_all, *bq_all, *wif_all;
+    int32_t *read_labels;
+} qa_sample_view_t;
+typedef struct {
+    int (*acquire)(void *ctx, int32_t s, qa_sample_view_t *view);
+    void *ctx;
+} qa_sample_source_t;
+
+/*
  * Arguments of QUILT() the hot path sees (QUILT/R/quilt.R:97-186), as get_and_impute_one_sample receives them.
  * qa_impute_params_default fills in the reference's defaults.
  */
@@ -675,6 +710,9 @@ typedef struct {
                                                    (qa_impute_bam_range formats VCF columns this way).  Must not call back into the
                                                    library's device entry points; may be called concurrently for disjoint ranges */
     void *on_samples_done_ctx;
+    const qa_sample_source_t *sample_source;    /* NULL: every sample's reads are in the flat arrays of the call.  Else the reads are
+                                                   handed over sample by sample WHEN THE LOOP REACHES THEM (qa_sample_source_t above):
+                                                   the first launch set starts while later samples are still being read from disk */
 } qa_impute_params_t;
 int qa_impute_params_default(qa_impute_params_t *params);
 

@@ -138,10 +138,13 @@ int qa_vcf_write_text(const char *path, int32_t bgzf, int32_t truncate, const ch
  *
  * The body of QUILT()'s loop over a core's sample range (QUILT/R/quilt.R:832-982) with get_and_impute_one_sample's own I/O
  * either side of the imputation (functions.R:243-298 load, :1380-1463 counts and column) as ONE native call: the BAM files are
- * read on host threads (qa_bam_load_sample_reads), the samples with at least minimum_number_of_sample_reads reads go through
- * qa_impute_samples (include/quilt_amd.h), their columns are formatted on the same host threads (qa_vcf_column_*), and the
- * four per-SNP count arrays the loop keeps (quilt.R:955-961) are summed over the imputed samples in sample order.  Serially in
- * R these two ends cost about a second per sample; the device imputes ~40 samples per second.
+ * read on host threads in file order (qa_bam_load_sample_reads) BESIDE the imputation, the samples with at least
+ * minimum_number_of_sample_reads reads go through ONE qa_impute_samples call (include/quilt_amd.h) that is handed each sample when
+ * the launch set holding it is taken (qa_sample_source_t: the first launches start when their own files are read, not when the
+ * last file of the range is), the columns of every finished launch set are formatted on host threads (qa_vcf_column_*) while
+ * later sets are on the device, and the four per-SNP count arrays the loop keeps (quilt.R:955-961) are summed over the imputed
+ * samples in sample order.  Serially in R these two ends cost about a second per sample; the device imputes ~40 samples per
+ * second.
  * ---------------------------------------------------------------------------------------------------------------------- */
 #include "quilt_amd.h"
 
@@ -163,7 +166,7 @@ typedef struct {
 
 typedef struct qa_bam_range_result qa_bam_range_result_t;   /* opaque; owned by the library */
 
-/*   panels, n_panels, params   as for qa_impute_samples.  params->sample_index, the read arrays inside params->rare_common, and ff /
+/*   panels, n_panels, params   as for qa_impute_samples.  params->sample_index, params->sample_source, the read arrays inside params->rare_common, and ff /
  *                              fet_dosage / fet_gp_t inside params->nipt are ignored: this call fills them for the samples it keeps
  *                              (params->rare_common: handles, nSNPs_all, nGrids_all, snp_is_common, L_grid_all; params->nipt:
  *                              L_grid, shuffle_bin_radius are the caller's)
@@ -192,7 +195,8 @@ int qa_bam_range_sample(const qa_bam_range_result_t *r, int32_t i, const double 
  * infoCount nSNPs x 2 (sum eij, sum fij - eij^2), afCount nSNPs (sum eij / 2), hweCount nSNPs x 3 (most likely genotype counts),
  * alleleCount nSNPs x 2 (pile-up: alt, ref + alt); any pointer may be NULL */
 int qa_bam_range_counts(const qa_bam_range_result_t *r, double *infoCount, double *afCount, double *hweCount, double *alleleCount);
-/* seconds: [0] loading, [1] qa_impute_samples, [2] formatting + counts, [3] the whole call; impute_stats: qa_impute_samples' 11
+/* seconds: [0] when the last file was loaded (the loading runs beside the imputation), [1] qa_impute_samples, [2] the formatting
+ * and counts left when it returned, [3] the whole call; impute_stats: qa_impute_samples' 11
  * counters; load_stats: qa_sample_reads_stats summed over the files */
 void qa_bam_range_timings(const qa_bam_range_result_t *r, double seconds[4], int64_t impute_stats[11], int64_t load_stats[8]);
 void qa_bam_range_destroy(qa_bam_range_result_t *r);

@@ -8,11 +8,14 @@
 // summed over the samples of the core).  In R these run one sample after the other on the worker that owns the GPU: about a
 // sample per second, against the ~40 samples per second the device imputes -- the R loader, not the device, would set the
 // throughput a QUILT2.R user sees.  Here
-//   1. the BAM files are read by qa_bam_load_sample_reads on n_io_threads host threads (17 ms per 1x sample and thread);
-//   2. the kept samples go through qa_impute_samples (csrc/impute.cpp) -- params->sample_index names every kept sample's
-//      GLOBAL index, so a sample dropped for too few reads does not shift the streams of the samples behind it;
-//   3. the columns are formatted by qa_vcf_column_diploid / _nipt on the same host threads, and the four count arrays are
-//      summed over the imputed samples in sample order (the order of the reference's loop: floating-point sums).
+//   1. the BAM files are read by qa_bam_load_sample_reads on n_io_threads host threads (17 ms per 1x sample and thread), in file
+//      order and BESIDE the imputation: the first launch set starts as soon as its own files are read;
+//   2. the kept samples go through ONE qa_impute_samples call (csrc/impute.cpp) that is handed each sample when the launch set
+//      holding it is taken (params->sample_source) -- params->sample_index names every kept sample's GLOBAL index, so a sample
+//      dropped for too few reads does not shift the streams of the samples behind it;
+//   3. the columns of every finished launch set are formatted by qa_vcf_column_diploid / _nipt on host threads while later sets
+//      are on the device (params->on_samples_done), and the four count arrays are summed over the imputed samples in sample
+//      order (the order of the reference's loop: floating-point sums).
 // Host code only: no HIP here (the device work is inside qa_impute_samples).
 #include <algorithm>
 #include <array>
@@ -21,6 +24,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -36,6 +40,15 @@
 
 namespace qa { void set_error(const char *fmt, ...); }
 
+// The imputation's result arrays: 48 bytes per sample and SNP (7.9 GB at 2 560 samples x 64 000 SNPs).  qa_impute_samples does not
+// ask for them zeroed (it zeroes a launch set's rows itself, on the thread that takes the set), so they are allocated WITHOUT a
+// fill: std::vector's zero fill touched every page on the calling thread before the first launch -- 2.4 s of the 70 s job.
+struct RawDoubles {
+    std::unique_ptr<double[]> p;
+    void alloc(size_t n) { p.reset(new double[std::max<size_t>(n, 1)]); }
+    double *data() const { return p.get(); }
+};
+
 struct qa_bam_range_result {
     int n = 0, n_kept = 0, T_out = 0, nL = 2;
     bool nipt = false;
@@ -43,9 +56,9 @@ struct qa_bam_range_result {
     std::vector<int32_t> n_reads;        // per file: reads the loader returned (before the minimum test)
     std::vector<int32_t> slot;           // per file: index among the kept samples, or -1
     std::vector<int32_t> kept;           // per kept sample: its file
-    std::vector<int32_t> read_off;       // kept + 1
-    std::vector<int32_t> labels, nDosage;
-    std::vector<double> dosage, gp_t, haps, fet_dosage, fet_gp_t;   // kept-major, the layouts of qa_impute_samples
+    std::vector<std::vector<int32_t>> labels_of;   // per kept sample: its reads' consensus labels
+    std::vector<int32_t> nDosage;
+    RawDoubles dosage, gp_t, haps, fet_dosage, fet_gp_t;            // kept-major, the layouts of qa_impute_samples
     std::vector<std::vector<char>> col_buf;
     std::vector<std::vector<int64_t>> col_off;
     std::vector<double> infoCount, afCount, hweCount, alleleCount;
@@ -123,29 +136,6 @@ int load_one(const char *path, const char *chr, int32_t T, const int32_t *L, con
     return st2;
 }
 
-// the flattened form of include/quilt_amd.h for the kept samples
-void flatten(const std::vector<Loaded> &all, const std::vector<int32_t> &kept, std::vector<int32_t> &read_off,
-             std::vector<int32_t> &read_ptr, std::vector<int32_t> &u, std::vector<int32_t> &bq, std::vector<int32_t> &wif) {
-    const size_t n = kept.size();
-    read_off.assign(n + 1, 0);
-    size_t nb = 0;
-    for (size_t j = 0; j < n; j++) {
-        const Loaded &s = all[(size_t)kept[j]];
-        read_off[j + 1] = read_off[j] + s.R;
-        nb += s.u.size();
-    }
-    read_ptr.clear(); u.clear(); bq.clear(); wif.clear();
-    read_ptr.reserve((size_t)read_off[n] + n);
-    u.reserve(nb); bq.reserve(nb); wif.reserve((size_t)read_off[n]);
-    for (size_t j = 0; j < n; j++) {
-        const Loaded &s = all[(size_t)kept[j]];
-        read_ptr.insert(read_ptr.end(), s.read_ptr.begin(), s.read_ptr.end());
-        u.insert(u.end(), s.u.begin(), s.u.end());
-        bq.insert(bq.end(), s.bq.begin(), s.bq.end());
-        wif.insert(wif.end(), s.wif.begin(), s.wif.end());
-    }
-}
-
 // qa_impute_samples, or the test hook's form of it, on the kept samples
 using ImputeFn = std::function<int(const qa_impute_params_t *, int32_t, const int32_t *, const int32_t *, const int32_t *, const int32_t *,
                                    const int32_t *, double *, double *, double *, int32_t *, int32_t *, int64_t *)>;
@@ -185,75 +175,149 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
     R->hweCount.assign((size_t)T_out * 3, 0.0);
     R->alleleCount.assign((size_t)T_out * 2, 0.0);
 
-    // ---- 1. the reads of every file (functions.R:251-298; with impute_rare_common also over all SNPs, :132-172)
+    // ---- 1. the reads of every file (functions.R:251-298; with impute_rare_common also over all SNPs, :132-172), on host threads
+    // BESIDE the imputation: the files are loaded in order, and the imputation's host threads are handed each sample when the
+    // launch set holding it is taken (qa_sample_source_t) -- as the reference's loop reads a sample's BAM at the top of its own
+    // iteration.  Whether a file is imputed (functions.R:274-287) is known once it is loaded; the kept samples are numbered in
+    // file order as the files before them are settled.
     auto t0 = Clock::now();
+    const bool trace = std::getenv("QA_BAM_RANGE_TRACE") != nullptr;   // (phase times on stderr)
+    double tr_setup = 0, tr_call = 0, tr_drain = 0, tr_sums = 0;
     std::vector<Loaded> common((size_t)n_sample), all_snps(rare ? (size_t)n_sample : 0);
     std::vector<std::array<int64_t, 8>> lstats((size_t)n_sample);
-    std::string err;
-    int st = parallel_for(n_sample, n_io, err, [&](int i, std::string &e) {
-        int s1 = load_one(bam_paths[i], io->chr, T, io->L, io->ref, io->alt, io->grid, &io->bam, common[(size_t)i], lstats[(size_t)i].data(), e);
-        if (s1 != QA_OK) return s1;
-        // (the all-SNP pile-up only for samples that will be imputed: the minimum test is on the common-SNP reads, functions.R:274)
-        if (rare && common[(size_t)i].R >= min_reads)
-            s1 = load_one(bam_paths[i], io->chr, io->nSNPs_all, io->L_all, io->ref_all, io->alt_all, io->grid_all, &io->bam, all_snps[(size_t)i], nullptr, e);
-        return s1;
-    });
-    if (st != QA_OK) { qa::set_error("qa_impute_bam_range: %s", err.c_str()); return st; }
-    for (int i = 0; i < n_sample; i++) {
-        R->n_reads[(size_t)i] = common[(size_t)i].R;
-        for (int q = 0; q < 8; q++) R->load_stats[q] += lstats[(size_t)i][(size_t)q];
-        bool keep = common[(size_t)i].R >= min_reads;
-        if (keep && rare && all_snps[(size_t)i].R < 1) keep = false;   // (cannot happen: every common SNP is among the all-SNP sites)
-        if (keep) {
-            R->slot[(size_t)i] = (int32_t)R->kept.size();
-            R->kept.push_back(i);
-            R->imputed[(size_t)i] = 1;
+    std::vector<int64_t> index((size_t)std::max(n_sample, 1));     // per kept sample, filled as the files are settled
+    std::vector<double> ffk((size_t)std::max(n_sample, 1));
+    R->kept.assign((size_t)n_sample, -1);                          // (entry j is written before kept sample j is handed to anyone; cut to n_kept at the end)
+    R->labels_of.resize((size_t)n_sample);
+    struct Loader {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<uint8_t> loaded;
+        int settled = 0;            // files [0, settled) are loaded and sorted into kept / dropped
+        int n_kept = 0;
+        int status = QA_OK;
+        std::string err;
+        std::atomic<int> next{0};
+        std::atomic<bool> stop{false};
+        double done_s = 0;
+    } ld;
+    ld.loaded.assign((size_t)n_sample, 0);
+    auto loader_body = [&] {
+        for (;;) {
+            const int i = ld.next.fetch_add(1);
+            if (i >= n_sample || ld.stop.load()) return;
+            std::string e;
+            int s1;
+            try {
+                s1 = load_one(bam_paths[i], io->chr, T, io->L, io->ref, io->alt, io->grid, &io->bam, common[(size_t)i], lstats[(size_t)i].data(), e);
+                // (the all-SNP pile-up only for samples that will be imputed: the minimum test is on the common-SNP reads, functions.R:274)
+                if (s1 == QA_OK && rare && common[(size_t)i].R >= min_reads)
+                    s1 = load_one(bam_paths[i], io->chr, io->nSNPs_all, io->L_all, io->ref_all, io->alt_all, io->grid_all, &io->bam,
+                                  all_snps[(size_t)i], nullptr, e);
+            } catch (const std::exception &ex) {
+                s1 = QA_ERR_INVALID;
+                e = ex.what();
+            }
+            std::lock_guard<std::mutex> g(ld.mu);
+            if (s1 != QA_OK) {
+                if (ld.status == QA_OK) { ld.status = s1; ld.err = e; }
+                ld.stop.store(true);
+                ld.cv.notify_all();
+                return;
+            }
+            ld.loaded[(size_t)i] = 1;
+            while (ld.settled < n_sample && ld.loaded[(size_t)ld.settled]) {
+                const int f = ld.settled;
+                R->n_reads[(size_t)f] = common[(size_t)f].R;
+                for (int q = 0; q < 8; q++) R->load_stats[q] += lstats[(size_t)f][(size_t)q];
+                bool keep = common[(size_t)f].R >= min_reads;
+                if (keep && rare && all_snps[(size_t)f].R < 1) keep = false;   // (cannot happen: every common SNP is among the all-SNP sites)
+                if (keep) {
+                    const size_t j = (size_t)ld.n_kept;
+                    index[j] = sample_index[f];
+                    if (nipt) ffk[j] = ff[f];
+                    R->labels_of[j].assign((size_t)common[(size_t)f].R, 0);
+                    R->slot[(size_t)f] = (int32_t)j;
+                    R->imputed[(size_t)f] = 1;
+                    R->kept[j] = f;
+                    ld.n_kept++;
+                }
+                ld.settled++;
+            }
+            if (ld.settled == n_sample) ld.done_s = since(t0);
+            ld.cv.notify_all();
         }
-    }
-    R->seconds[0] = since(t0);
-    const int nk = R->n_kept = (int)R->kept.size();
+    };
+    struct Source {
+        Loader *ld;
+        qa_bam_range_result *R;
+        const std::vector<Loaded> *common, *all_snps;
+        int n_files;
+        bool rare;
+        static int acquire(void *ctx, int32_t s, qa_sample_view_t *v) {
+            Source &S = *static_cast<Source *>(ctx);
+            int f;
+            {
+                std::unique_lock<std::mutex> lk(S.ld->mu);
+                S.ld->cv.wait(lk, [&] { return S.ld->n_kept > s || S.ld->settled == S.n_files || S.ld->status != QA_OK; });
+                if (S.ld->status != QA_OK) { qa::set_error("%s", S.ld->err.c_str()); return S.ld->status; }
+                if (S.ld->n_kept <= s) return QA_END_OF_SAMPLES;
+                f = S.R->kept[(size_t)s];
+            }
+            const Loaded &c = (*S.common)[(size_t)f];
+            static const int32_t none = 0;   // (a read-less base array is never dereferenced; the pointers must not be null)
+            v->n_reads = c.R; v->read_ptr = c.read_ptr.data(); v->u = c.u.empty() ? &none : c.u.data(); v->bq = c.bq.empty() ? &none : c.bq.data();
+            v->wif = c.wif.data();
+            v->read_labels = S.R->labels_of[(size_t)s].data();
+            if (S.rare) {
+                const Loaded &a = (*S.all_snps)[(size_t)f];
+                v->n_reads_all = a.R; v->read_ptr_all = a.read_ptr.data(); v->u_all = a.u.empty() ? &none : a.u.data();
+                v->bq_all = a.bq.empty() ? &none : a.bq.data(); v->wif_all = a.wif.data();
+            }
+            return QA_OK;
+        }
+    } src{&ld, R.get(), &common, &all_snps, n_sample, rare};
+    const qa_sample_source_t source{&Source::acquire, &src};
+    std::vector<std::thread> loaders;
+    for (int w = 0; w < std::max(1, std::min(n_io, n_sample)); w++) loaders.emplace_back(loader_body);
+    auto join_loaders = [&] {
+        ld.stop.store(true);
+        for (auto &t : loaders) t.join();
+        loaders.clear();
+    };
 
-    // ---- 2. the ONE call for every chain of every kept sample
-    t0 = Clock::now();
-    std::vector<int32_t> read_ptr, u, bq, wif, a_off, a_ptr, a_u, a_bq, a_wif;
-    flatten(common, R->kept, R->read_off, read_ptr, u, bq, wif);
-    std::vector<int64_t> index((size_t)nk);
-    std::vector<double> ffk((size_t)nk);
-    for (int j = 0; j < nk; j++) {
-        index[(size_t)j] = sample_index[R->kept[(size_t)j]];
-        if (nipt) ffk[(size_t)j] = ff[R->kept[(size_t)j]];
-    }
-    R->dosage.assign((size_t)nk * T_out, 0.0);
-    R->gp_t.assign((size_t)nk * 3 * T_out, 0.0);
-    R->haps.assign((size_t)nk * nL * T_out, 0.0);
-    R->labels.assign((size_t)std::max(R->read_off[(size_t)nk], 1), 0);
-    R->nDosage.assign((size_t)std::max(nk, 1), 0);
+    // ---- 2. the ONE call for every chain of every kept sample (n_sample = the files: an upper bound, the source ends the range)
+    R->dosage.alloc((size_t)n_sample * T_out);   // (untouched pages of rows that no kept sample takes cost nothing)
+    R->gp_t.alloc((size_t)n_sample * 3 * T_out);
+    R->haps.alloc((size_t)n_sample * nL * T_out);
+    R->nDosage.assign((size_t)std::max(n_sample, 1), 0);
     qa_impute_params_t P = *params;
     P.sample_index = index.data();
+    P.sample_source = &source;
     qa_impute_rare_common_t rcq;
     qa_impute_nipt_t nq;
     if (rare) {
-        flatten(all_snps, R->kept, a_off, a_ptr, a_u, a_bq, a_wif);
         rcq = *params->rare_common;
-        rcq.read_off = a_off.data(); rcq.read_ptr = a_ptr.data(); rcq.u = a_u.data(); rcq.bq = a_bq.data(); rcq.wif = a_wif.data();
+        rcq.read_off = rcq.read_ptr = rcq.u = rcq.bq = rcq.wif = nullptr;
         P.rare_common = &rcq;
     }
     if (nipt) {
-        R->fet_dosage.assign((size_t)nk * T_out, 0.0);
-        R->fet_gp_t.assign((size_t)nk * 3 * T_out, 0.0);
+        R->fet_dosage.alloc((size_t)n_sample * T_out);
+        R->fet_gp_t.alloc((size_t)n_sample * 3 * T_out);
         nq = *params->nipt;
         nq.ff = ffk.data();
         nq.fet_dosage = R->fet_dosage.data();
         nq.fet_gp_t = R->fet_gp_t.data();
         P.nipt = &nq;
     }
+    const int nk_max = n_sample;
     // ---- 3. (beside 2.) per kept sample: its VCF column (functions.R:1408-1463), eij / fij / max_gen and the pile-up's allele counts
     // (:1380-1418).  qa_impute_samples reports every launch set whose samples are final (params->on_samples_done); a pool of host
     // threads formats those samples while later launch sets are still on the device.
-    R->col_buf.resize((size_t)nk);
-    R->col_off.resize((size_t)nk);
-    std::vector<std::vector<double>> eij((size_t)nk), fij((size_t)nk), ac((size_t)nk);
-    std::vector<std::vector<uint8_t>> maxg((size_t)nk);
+    R->col_buf.resize((size_t)nk_max);
+    R->col_off.resize((size_t)nk_max);
+    std::vector<std::vector<double>> eij((size_t)nk_max), fij((size_t)nk_max), ac((size_t)nk_max);
+    std::vector<std::vector<uint8_t>> maxg((size_t)nk_max);
     auto format_one = [&](int j, std::string &e) -> int {
         const double *gp = R->gp_t.data() + (size_t)j * 3 * T_out;          // [3][T_out]
         const double *hd = R->haps.data() + (size_t)j * nL * T_out;         // [nL][T_out] == T_out x nL column-major
@@ -295,7 +359,8 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
             F[(size_t)t] = std::nearbyint((g1 + 4 * g2) * 1000.0) / 1000.0;
             M[(size_t)t] = (uint8_t)((g1 > g0) ? ((g2 > g1) ? 2 : 1) : ((g2 > g0) ? 2 : 0));
         }
-        const Loaded &s = rare ? all_snps[(size_t)R->kept[(size_t)j]] : common[(size_t)R->kept[(size_t)j]];
+        const int file = R->kept[(size_t)j];   // (settled before the sample was handed to the imputation)
+        const Loaded &s = rare ? all_snps[(size_t)file] : common[(size_t)file];
         double *c1 = A.data(), *c2 = A.data() + T_out;   // sums of P(ref), P(alt) per site, bases in the order they were loaded
         for (size_t b = 0; b < s.u.size(); b++) {
             const int q = s.bq[b];
@@ -303,6 +368,9 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
             c1[s.u[b]] += q < 0 ? 1 - eps : eps / 3;
             c2[s.u[b]] += q < 0 ? eps / 3 : 1 - eps;
         }
+        // the sample is final: its reads are not needed again (released here, on this thread, not in one sweep at the end)
+        common[(size_t)file] = Loaded();
+        if (rare) all_snps[(size_t)file] = Loaded();
         return (int)QA_OK;
     };
     struct Pool {
@@ -347,20 +415,29 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
     P.on_samples_done = &Hook::done;
     P.on_samples_done_ctx = &hook;
     std::vector<std::thread> formatters;
-    for (int w = 0; w < std::max(1, std::min(n_io, nk)); w++) formatters.emplace_back(pool_body);
+    for (int w = 0; w < std::max(1, std::min(n_io, nk_max)); w++) formatters.emplace_back(pool_body);
     auto close_pool = [&] {
         { std::lock_guard<std::mutex> g(pool.mu); pool.closed = true; }
         pool.cv.notify_all();
         for (auto &t : formatters) t.join();
     };
-    if (nk > 0) {
-        st = impute(&P, nk, R->read_off.data(), read_ptr.data(), u.data(), bq.data(), wif.data(), R->dosage.data(), R->gp_t.data(), R->haps.data(),
-                    R->labels.data(), R->nDosage.data(), R->stats);
-        if (st != QA_OK) { close_pool(); return st; }   // (qa_last_error holds qa_impute_samples' text)
-    }
+    tr_setup = since(t0);
+    int st = QA_OK;
+    std::string err;
+    if (n_sample > 0)
+        st = impute(&P, n_sample, nullptr, nullptr, nullptr, nullptr, nullptr, R->dosage.data(), R->gp_t.data(), R->haps.data(), nullptr,
+                    R->nDosage.data(), R->stats);
+    join_loaders();
+    if (ld.status != QA_OK) { close_pool(); qa::set_error("qa_impute_bam_range: %s", ld.err.c_str()); return ld.status; }
+    if (st != QA_OK) { close_pool(); return st; }   // (qa_last_error holds qa_impute_samples' text)
+    const int nk = R->n_kept = ld.n_kept;
+    R->kept.resize((size_t)nk);
+    R->seconds[0] = ld.done_s;
     R->seconds[1] = since(t0);
+    tr_call = R->seconds[1] - tr_setup;
     t0 = Clock::now();
     close_pool();   // (what is still queued when the device work ends: the last launch sets' samples)
+    tr_drain = since(t0);
     if (pool.status != QA_OK) { qa::set_error("qa_impute_bam_range: %s", pool.err.c_str()); return pool.status; }
     if ((int)pool.queue.size() != nk) { qa::set_error("qa_impute_bam_range: %d of %d samples were reported final", (int)pool.queue.size(), nk); return QA_ERR_INVALID; }
     // the range's sums, per SNP over the samples IN SAMPLE ORDER, as the reference's loop adds them (quilt.R:955-961); SNP blocks on
@@ -368,7 +445,7 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
     {
         double *i0 = R->infoCount.data(), *i1 = i0 + T_out, *af = R->afCount.data(), *hw = R->hweCount.data();
         double *a0 = R->alleleCount.data(), *a1 = a0 + T_out;
-        const int n_blocks = std::max(1, std::min(n_io, (T_out + 4095) / 4096));
+        const int n_blocks = std::max(1, std::min(4 * n_io, (T_out + 511) / 512));
         st = parallel_for(n_blocks, n_io, err, [&](int blk, std::string &) {
             const int lo = (int)((int64_t)T_out * blk / n_blocks), hi = (int)((int64_t)T_out * (blk + 1) / n_blocks);
             for (int j = 0; j < nk; j++) {
@@ -389,7 +466,12 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
     }
     R->format_busy_s = pool.busy_s;
     R->seconds[2] = since(t0);
+    tr_sums = R->seconds[2] - tr_drain;
     R->seconds[3] = since(t_all);
+    if (trace)
+        std::fprintf(stderr, "qa_impute_bam_range: %d files (%d kept), %d host threads: last file loaded at %.3f s (beside the imputation), setup %.3f, "
+                     "qa_impute_samples %.3f, formatters' drain %.3f (busy %.3f thread-s), sums %.3f, whole call %.3f\n", n_sample, nk, n_io,
+                     R->seconds[0], tr_setup, tr_call, tr_drain, pool.busy_s, tr_sums, R->seconds[3]);
     *out = R.release();
     return QA_OK;
 }
@@ -457,8 +539,8 @@ int qa_bam_range_sample(const qa_bam_range_result_t *r, int32_t i, const double 
     if (phasing_haps) *phasing_haps = j < 0 ? nullptr : r->haps.data() + (size_t)j * r->nL * T;
     if (fet_dosage) *fet_dosage = (j < 0 || !r->nipt) ? nullptr : r->fet_dosage.data() + (size_t)j * T;
     if (fet_gp_t) *fet_gp_t = (j < 0 || !r->nipt) ? nullptr : r->fet_gp_t.data() + (size_t)j * 3 * T;
-    if (read_labels) *read_labels = j < 0 ? nullptr : r->labels.data() + r->read_off[(size_t)j];
-    if (n_labels) *n_labels = j < 0 ? 0 : r->read_off[(size_t)j + 1] - r->read_off[(size_t)j];
+    if (read_labels) *read_labels = j < 0 ? nullptr : r->labels_of[(size_t)j].data();
+    if (n_labels) *n_labels = j < 0 ? 0 : (int32_t)r->labels_of[(size_t)j].size();
     if (nDosage) *nDosage = j < 0 ? 0 : r->nDosage[(size_t)j];
     return QA_OK;
 }

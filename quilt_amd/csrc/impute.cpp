@@ -208,6 +208,9 @@ struct Ctx {
     double *dosage = nullptr, *gp_t = nullptr, *phasing_haps = nullptr;
     int32_t *read_labels = nullptr, *nDosage = nullptr;
     const int32_t *read_off = nullptr;
+    // params->sample_source: reads[s] / reads_all[s] / label_dst[s] are filled when the set holding s is taken (Worker::new_batch)
+    const qa_sample_source_t *source = nullptr;
+    std::vector<int32_t *> label_dst;   // where sample s's consensus read labels go
     std::atomic<int64_t> n_underflow_retries{0}, n_full_list_refetches{0}, n_device_selections{0}, n_gibbs_chain_calls{0},
         n_gibbs_launches{0};
     std::mutex stat_mu;
@@ -979,7 +982,44 @@ struct Worker {
         if (CallSpan::on()) std::fprintf(stderr, "[impute-trace] rc_post thr %d n %d %.1f %.1f\n", w, C, t2 * 1e3, now_s() * 1e3);
     }
 
+    // the reads of one sample as the caller describes them: the checks of the flat form
+    static void check_reads(const Reads &r, int s, const char *what) {
+        if (r.R < 1) throw Failure(QA_ERR_INVALID, "sample " + std::to_string(s) + " has no " + what + "reads (the reference drops such samples before imputing, functions.R:300-310)");
+        if (!r.read_ptr || !r.u || !r.bq || !r.wif) throw Failure(QA_ERR_INVALID, std::string("sample ") + std::to_string(s) + ": missing " + what + "read arrays");
+        if (r.read_ptr[0] != 0) throw Failure(QA_ERR_INVALID, std::string(what) + "read_ptr of sample " + std::to_string(s) + " does not start at 0");
+    }
+
+    // params->sample_source: samples [lo, hi) from the caller, in order; returns where the range ends (hi, or the first s the
+    // source reports as beyond its last sample)
+    int acquire_samples(int lo, int hi) {
+        for (int s = lo; s < hi; s++) {
+            qa_sample_view_t v{};
+            const int st = cx.source->acquire(cx.source->ctx, s, &v);
+            if (st == QA_END_OF_SAMPLES) return s;
+            if (st != QA_OK) throw Failure(st < 0 ? st : QA_ERR_INVALID, std::string("the sample source failed at sample ") + std::to_string(s) + ": " + qa_last_error());
+            Reads &r = cx.reads[(size_t)s];
+            r.R = v.n_reads; r.read_ptr = v.read_ptr; r.u = v.u; r.bq = v.bq; r.wif = v.wif;
+            check_reads(r, s, "");
+            r.nb = r.read_ptr[r.R];
+            if (!v.read_labels) throw Failure(QA_ERR_INVALID, "the sample source gave sample " + std::to_string(s) + " no place for its read labels");
+            cx.label_dst[(size_t)s] = v.read_labels;
+            if (cx.rc) {
+                Reads &a = cx.reads_all[(size_t)s];
+                a.R = v.n_reads_all; a.read_ptr = v.read_ptr_all; a.u = v.u_all; a.bq = v.bq_all; a.wif = v.wif_all;
+                check_reads(a, s, "all-SNP ");
+                a.nb = a.read_ptr[a.R];
+            }
+            if (cx.nipt && !(cx.nipt->ff[s] > 0.0 && cx.nipt->ff[s] < 1.0))
+                throw Failure(QA_ERR_INVALID, "fetal fraction of sample " + std::to_string(s) + " outside (0, 1)");
+        }
+        return hi;
+    }
+
     Batch *new_batch(int lo, int hi) {
+        if (cx.source) {
+            hi = acquire_samples(lo, hi);
+            if (hi <= lo) return nullptr;   // the range ended before this set
+        }
         Batch *b = new Batch;
         b->lo = lo;
         b->hi = hi;
@@ -1063,7 +1103,7 @@ struct Worker {
             ph.labels.resize((size_t)R);
             if (cx.be->consensus_read_labels(R, nG, labels.data(), p.data(), nL, 0.95, nG, ph.labels.data()) != QA_OK)
                 throw Failure(QA_ERR_INVALID, "qa_consensus_read_labels failed");
-            std::memcpy(cx.read_labels + cx.read_off[s], ph.labels.data(), sizeof(int32_t) * (size_t)R);
+            std::memcpy(cx.label_dst[(size_t)s], ph.labels.data(), sizeof(int32_t) * (size_t)R);
             b.phasing[si] = std::move(ph);
         });
         b.chains.clear();
@@ -1102,7 +1142,10 @@ struct Worker {
         try {
             while (true) {
                 std::unique_ptr<Batch> cur;
-                if (at < sets.size()) { cur.reset(new_batch(sets[at].first, sets[at].second)); at++; }
+                if (at < sets.size()) {
+                    cur.reset(new_batch(sets[at].first, sets[at].second));
+                    at = cur ? at + 1 : sets.size();   // (a sample source's range ended: the later sets are beyond it too)
+                }
                 taken.clear();
                 if (!cur && cx.use_tail && !reported) {
                     reported = true;
@@ -1192,8 +1235,10 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
                 const qa_impute_params_t *params, int32_t n_sample, int64_t sample_offset, const int32_t *read_off,
                 const int32_t *read_ptr, const int32_t *u, const int32_t *bq, const int32_t *wif, double *dosage, double *gp_t,
                 double *phasing_haps, int32_t *read_labels, int32_t *nDosage, int64_t *stats) {
-    if (!be || !handles || n_handles < 1 || n_handles > 16 || !params || n_sample < 0 || !read_off || !read_ptr || !u || !bq || !wif ||
-        !dosage || !gp_t || !phasing_haps || !read_labels || !nDosage || K < 1 || G < 1 || T < 1) {
+    const bool flat = !(params && params->sample_source);
+    if (!be || !handles || n_handles < 1 || n_handles > 16 || !params || n_sample < 0 ||
+        (flat && (!read_off || !read_ptr || !u || !bq || !wif || !read_labels)) || (!flat && !params->sample_source->acquire) ||
+        !dosage || !gp_t || !phasing_haps || !nDosage || K < 1 || G < 1 || T < 1) {
         qa::set_error("qa_impute_samples: missing argument");
         return QA_ERR_INVALID;
     }
@@ -1228,10 +1273,13 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
     cx.sample_index = P.sample_index;
     cx.dosage = dosage; cx.gp_t = gp_t; cx.phasing_haps = phasing_haps; cx.read_labels = read_labels; cx.nDosage = nDosage;
     cx.read_off = read_off;
+    cx.source = P.sample_source;
     cx.reads.resize((size_t)n_sample);
-    {
+    cx.label_dst.assign((size_t)n_sample, nullptr);
+    if (flat) {
         int64_t base = 0;
         for (int s = 0; s < n_sample; s++) {
+            cx.label_dst[(size_t)s] = read_labels + read_off[s];
             Reads &r = cx.reads[(size_t)s];
             r.R = read_off[s + 1] - read_off[s];
             if (r.R < 1) {
@@ -1257,15 +1305,15 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
             qa::set_error("qa_impute_samples: method = \"nipt\" needs ff, L_grid and the fetus' output arrays");
             return QA_ERR_INVALID;
         }
-        for (int s2 = 0; s2 < n_sample; s2++)
+        for (int s2 = 0; flat && s2 < n_sample; s2++)   // (a sample source: checked as the samples arrive)
             if (!(P.nipt->ff[s2] > 0.0 && P.nipt->ff[s2] < 1.0)) { qa::set_error("qa_impute_samples: fetal fraction of sample %d outside (0, 1)", s2); return QA_ERR_INVALID; }
         cx.nipt = P.nipt;
         cx.nL = 3;
     }
     if (P.rare_common) {
         const qa_impute_rare_common_t &rc = *P.rare_common;
-        if (!rc.handles || rc.nSNPs_all < T || rc.nGrids_all != (rc.nSNPs_all + 31) / 32 || !rc.snp_is_common || !rc.read_off || !rc.read_ptr ||
-            !rc.u || !rc.bq || !rc.wif || !be->gibbs_batch_rare_common || !be->make_eMatRead_t_nsnps) {
+        if (!rc.handles || rc.nSNPs_all < T || rc.nGrids_all != (rc.nSNPs_all + 31) / 32 || !rc.snp_is_common ||
+            (flat && (!rc.read_off || !rc.read_ptr || !rc.u || !rc.bq || !rc.wif)) || !be->gibbs_batch_rare_common || !be->make_eMatRead_t_nsnps) {
             qa::set_error("qa_impute_samples: impute_rare_common needs the all-SNP handles, dimensions, flags and reads");
             return QA_ERR_INVALID;
         }
@@ -1281,7 +1329,7 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
         }
         cx.reads_all.resize((size_t)n_sample);
         int64_t base = 0;
-        for (int s = 0; s < n_sample; s++) {
+        for (int s = 0; flat && s < n_sample; s++) {
             Reads &r = cx.reads_all[(size_t)s];
             r.R = rc.read_off[s + 1] - rc.read_off[s];
             if (r.R < 1) { qa::set_error("qa_impute_samples: sample %d has no all-SNP reads", s); return QA_ERR_INVALID; }

@@ -28,8 +28,59 @@ class ImputeParams(C.Structure):
         ("mspbwt_index", C.c_void_p),
         ("samples_per_launch_set", C.c_int32), ("no_fused_tails", C.c_int32),
         ("rare_common", C.c_void_p), ("nipt", C.c_void_p), ("sample_index", C.c_void_p),
-        ("on_samples_done", C.c_void_p), ("on_samples_done_ctx", C.c_void_p),
+        ("on_samples_done", C.c_void_p), ("on_samples_done_ctx", C.c_void_p), ("sample_source", C.c_void_p),
     ]
+
+
+class SampleView(C.Structure):
+    """qa_sample_view_t (include/quilt_amd.h): one sample's reads as a qa_sample_source_t hands them over."""
+    _fields_ = [("n_reads", C.c_int32), ("read_ptr", C.c_void_p), ("u", C.c_void_p), ("bq", C.c_void_p), ("wif", C.c_void_p),
+                ("n_reads_all", C.c_int32), ("read_ptr_all", C.c_void_p), ("u_all", C.c_void_p), ("bq_all", C.c_void_p),
+                ("wif_all", C.c_void_p), ("read_labels", C.c_void_p)]
+
+
+ACQUIRE_SAMPLE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(SampleView))
+QA_END_OF_SAMPLES = 2
+
+
+class SampleSource(C.Structure):
+    """qa_sample_source_t: ``acquire(ctx, s, view)`` blocks until sample ``s`` of the call is there (QA_OK, view filled), reports
+    that the range ended before it (QA_END_OF_SAMPLES) or fails (< 0)."""
+    _fields_ = [("acquire", ACQUIRE_SAMPLE), ("ctx", C.c_void_p)]
+
+
+def sample_source_over(samples, labels_out, n_available=None, fail_at=None, order_log=None):
+    """A SampleSource over samples already in memory (what a loader thread would hand over one by one): sample ``s`` of the call is
+    ``samples[s]``, its labels go to ``labels_out[s]`` (int32 arrays of nReads); the range ends at ``n_available`` (default: all).
+    Returns (SampleSource, keep-alive objects)."""
+    n_av = len(samples) if n_available is None else int(n_available)
+    hold = {}
+
+    def arrays(r):
+        return tuple(np.ascontiguousarray(getattr(r, k), dtype=np.int32) for k in ("read_ptr", "u", "bq", "wif"))
+
+    def acquire(_ctx, s, view):
+        if order_log is not None:
+            order_log.append(int(s))
+        if fail_at is not None and s == fail_at:
+            return -2
+        if s >= n_av:
+            return QA_END_OF_SAMPLES
+        smp = samples[s]
+        a = hold[s] = arrays(smp)
+        v = view.contents
+        v.n_reads = int(smp.nReads)
+        v.read_ptr, v.u, v.bq, v.wif = (x.ctypes.data for x in a)
+        v.read_labels = labels_out[s].ctypes.data
+        al = getattr(smp, "all_snp", None)
+        if al is not None:
+            b = hold[(s, "all")] = arrays(al)
+            v.n_reads_all = int(al.nReads)
+            v.read_ptr_all, v.u_all, v.bq_all, v.wif_all = (x.ctypes.data for x in b)
+        return 0
+
+    cb = ACQUIRE_SAMPLE(acquire)
+    return SampleSource(cb, None), (cb, hold, labels_out)
 
 
 class ImputeNipt(C.Structure):
@@ -145,7 +196,9 @@ def prepare_range(devs: Sequence, samples: Sequence, params: Optional[DriverPara
                          handles=(C.c_void_p * len(devs))(*[d.handle for d in devs]))
 
 
-def run_prepared(r: PreparedRange, return_stats: bool = False):
+def run_prepared(r: PreparedRange, return_stats: bool = False, one_by_one: bool = False):
+    """``one_by_one``: the samples' reads are handed to the call through a qa_sample_source_t (include/quilt_amd.h: each sample
+    when the launch set holding it is taken) instead of the flat arrays -- same results."""
     n, T = r.n, r.T
     dosage, gp_t, haps = np.empty((n, T)), np.empty((n, 3, T)), np.empty((n, r.nL, T))
     labels = np.empty(int(r.read_off[-1]), dtype=np.int32)
@@ -153,20 +206,31 @@ def run_prepared(r: PreparedRange, return_stats: bool = False):
     stats = np.zeros(11, dtype=np.int64)
     L = lib()
     L.qa_impute_samples.restype = C.c_int
-    check(L.qa_impute_samples(r.handles, C.c_int32(len(r.devs)), C.byref(r.q), C.c_int32(n), C.c_int64(r.sample_offset), ptr(r.read_off),
-                              ptr(r.read_ptr), ptr(r.u), ptr(r.bq), ptr(r.wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels),
-                              ptr(nDosage), ptr(stats)))
+    flat = (ptr(r.read_off), ptr(r.read_ptr), ptr(r.u), ptr(r.bq), ptr(r.wif))
+    keep_s = None
+    if one_by_one:
+        views = [labels[r.read_off[i]:r.read_off[i + 1]] for i in range(n)]   # (contiguous slices of the flat label array)
+        src, keep_s = sample_source_over(r.samples, views)
+        r.q.sample_source = C.cast(C.pointer(src), C.c_void_p)
+        flat = (None,) * 5
+    try:
+        check(L.qa_impute_samples(r.handles, C.c_int32(len(r.devs)), C.byref(r.q), C.c_int32(n), C.c_int64(r.sample_offset), *flat,
+                                  ptr(dosage), ptr(gp_t), ptr(haps), None if one_by_one else ptr(labels), ptr(nDosage), ptr(stats)))
+    finally:
+        r.q.sample_source = None
+        del keep_s
     out = wrap_results(r.samples, dosage, gp_t, haps, labels, nDosage, r.read_off, r.fd, r.fg)
     return (out, dict(zip(STAT_NAMES, stats.tolist()))) if return_stats else out
 
 
 def impute_samples(devs: Sequence, samples: Sequence, params: Optional[DriverParams] = None, sample_offset: int = 0,
-                   samples_per_launch_set: int = 256, fuse_tails: bool = True, return_stats: bool = False, drcs: Sequence = ()):
+                   samples_per_launch_set: int = 256, fuse_tails: bool = True, return_stats: bool = False, drcs: Sequence = (),
+                   one_by_one: bool = False):
     """``devs``: one :class:`quilt_amd.native.DevicePanel` per host thread (replicas of one panel on one device; with more
     than one, switch ``set_exclusive`` on).  ``drcs`` (with ``params.impute_rare_common``): one
     :class:`quilt_amd.native.DeviceRareCommon` per entry of ``devs``; every sample then carries its all-SNP reads as
     ``sample.all_snp`` and the results cover all SNPs.  Returns one SampleResult per sample (and the native counters)."""
-    return run_prepared(prepare_range(devs, samples, params, sample_offset, samples_per_launch_set, fuse_tails, drcs), return_stats)
+    return run_prepared(prepare_range(devs, samples, params, sample_offset, samples_per_launch_set, fuse_tails, drcs), return_stats, one_by_one)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -259,8 +259,12 @@ class OracleTable:
 
 
 def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_per_launch_set=256, n_threads=1, fuse_tails=True,
-                             fail_at_call=None, rare_common=None):
-    """qa_impute_samples_backend over the oracle table: (results, native counters, the table)."""
+                             fail_at_call=None, rare_common=None, source=None):
+    """qa_impute_samples_backend over the oracle table: (results, native counters, the table).
+
+    ``source``: None = the reads in the call's flat arrays; a dict(n_upper=..., fail_at=..., order_log=...) = the same samples handed
+    over one by one through a qa_sample_source_t (params->sample_source), the call's n_sample being the upper bound ``n_upper``
+    (default: the samples) and the range ending where the samples do."""
     P = params
     idx = None
     if P.use_mspbwt:
@@ -276,6 +280,23 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
     tab = OracleTable(panel, fail_at_call=fail_at_call, rare_common=rare_common)
     read_off, read_ptr, u, bq, wif = flatten_samples(samples)
     n, T = len(samples), (rare_common.nSNPs_all if P.impute_rare_common else panel.nSNPs)
+    keep_s = None
+    if source is not None:
+        from quilt_amd.impute import sample_source_over
+        n_given = n
+        n = int(source.get("n_upper", n))   # (the call's n_sample: an upper bound; the output arrays are sized by it)
+        per_sample_labels = [np.zeros(s.nReads, dtype=np.int32) for s in samples]
+        src, keep_s = sample_source_over(samples, per_sample_labels, n_available=n_given, fail_at=source.get("fail_at"),
+                                         order_log=source.get("order_log"))
+        q.sample_source = C.cast(C.pointer(src), C.c_void_p)
+        if rcq is not None:   # (the flat all-SNP arrays are not read with a source)
+            rcq.read_off = rcq.read_ptr = rcq.u = rcq.bq = rcq.wif = None
+        if nq is not None and n != n_given:
+            ffu = np.full(n, np.nan)
+            ffu[:n_given] = [float(s.ff) for s in samples]
+            fd, fg = np.zeros((n, T)), np.zeros((n, 3, T))
+            nq.ff, nq.fet_dosage, nq.fet_gp_t = ptr(ffu), ptr(fd), ptr(fg)
+            keep_s = (keep_s, ffu)
     dosage, gp_t, haps = np.zeros((n, T)), np.zeros((n, 3, T)), np.zeros((n, 3 if P.method == "nipt" else 2, T))
     labels = np.zeros(int(read_off[-1]), dtype=np.int32)
     nDosage = np.zeros(n, dtype=np.int32)
@@ -285,9 +306,12 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
     L.qa_impute_samples_backend.restype = C.c_int
     L.qa_last_error.restype = C.c_char_p
     st = L.qa_impute_samples_backend(C.byref(tab.table), handles, C.c_int32(n_threads), C.c_int32(panel.K), C.c_int32(panel.nGrids),
-                                     C.c_int32(panel.nSNPs), C.byref(q), C.c_int32(n), C.c_int64(sample_offset), ptr(read_off), ptr(read_ptr),
-                                     ptr(u), ptr(bq), ptr(wif), ptr(dosage), ptr(gp_t), ptr(haps), ptr(labels), ptr(nDosage), ptr(stats))
-    del keep, keep_rc, keep_n
+                                     C.c_int32(panel.nSNPs), C.byref(q), C.c_int32(n), C.c_int64(sample_offset),
+                                     *((None,) * 5 if source is not None else (ptr(read_off), ptr(read_ptr), ptr(u), ptr(bq), ptr(wif))),
+                                     ptr(dosage), ptr(gp_t), ptr(haps), None if source is not None else ptr(labels), ptr(nDosage), ptr(stats))
+    if source is not None:
+        labels = np.concatenate(per_sample_labels) if per_sample_labels else labels
+    del keep, keep_rc, keep_n, keep_s
     if tab.error is not None:
         raise tab.error
     if st != 0:

@@ -192,6 +192,67 @@ def test_native_loop_nipt(twin_panel, n_threads, per_set):
         assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
 
 
+@pytest.mark.parametrize("n_threads,per_set,n_upper", [(1, 256, 7), (1, 2, 7), (3, 2, 10), (2, 3, 9), (3, 1, 16)])
+def test_samples_handed_over_one_by_one_equal_the_flat_call(twin_panel, n_threads, per_set, n_upper):
+    """params->sample_source (qa_sample_source_t): the reads handed over when the launch set holding the sample is taken, the call's
+    n_sample an UPPER BOUND the source ends early (a caller that learns which samples it keeps while loading them).  Same bytes as
+    the flat call, whatever the threads and the launch sets; every sample is acquired once, in ascending order within its set."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_synthetic_sample
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = twin_panel
+    samples = [make_synthetic_sample(panel, seed=500 + i, n_reads=150 + 10 * i) for i in range(7)]
+    P = DriverParams(nGibbsSamples=3, n_seek_its=2, Ksubset=64, Knew=40, small_ref_panel_gibbs_iterations=4,
+                     small_ref_panel_block_gibbs_iterations=(2,), seed=3)
+    want, _, _ = impute_samples_on_oracle(panel, samples, P, sample_offset=10, samples_per_launch_set=per_set, n_threads=n_threads)
+    log = []
+    got, stats, _ = impute_samples_on_oracle(panel, samples, P, sample_offset=10, samples_per_launch_set=per_set, n_threads=n_threads,
+                                             source=dict(n_upper=n_upper, order_log=log))
+    for a, b in zip(got, want):
+        _same(a, b)
+    served = [s for s in log if s < len(samples)]
+    assert sorted(served) == list(range(len(samples))), log      # once each
+    for lo in range(0, len(samples), per_set):                     # ascending within a launch set
+        mine = [s for s in served if lo <= s < lo + per_set]
+        assert mine == sorted(mine)
+    assert all(s <= n_upper - 1 for s in log)
+    assert stats["gibbs_chain_calls"] >= len(samples) * (P.nGibbsSamples + 1) * P.n_seek_its
+
+
+def test_sample_source_modes_and_failures(twin_panel):
+    """The source with method = "nipt" (the fetal fraction of a sample read after it was acquired) and with impute_rare_common (the
+    all-SNP reads in the same view); a source that fails ends the call with its status; a range that ends before its first
+    sample is an empty, successful call."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.synth import make_rare_common, make_synthetic_panel, make_synthetic_sample, make_synthetic_sample_rare_common
+    from tests.native_driver_backend import impute_samples_on_oracle
+    panel = twin_panel
+    samples = [make_synthetic_sample(panel, seed=900 + i, n_reads=200, ff=0.1 + 0.05 * i) for i in range(3)]
+    P = DriverParams(nGibbsSamples=2, n_seek_its=2, Ksubset=64, Knew=64, seed=4, method="nipt", small_ref_panel_gibbs_iterations=4,
+                     small_ref_panel_block_gibbs_iterations=(2,))
+    want, _, _ = impute_samples_on_oracle(panel, samples, P, sample_offset=2, samples_per_launch_set=2, n_threads=2)
+    got, _, _ = impute_samples_on_oracle(panel, samples, P, sample_offset=2, samples_per_launch_set=2, n_threads=2, source=dict(n_upper=5))
+    for a, b in zip(got, want):
+        _same(a, b)
+        assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
+    P2 = DriverParams(nGibbsSamples=2, n_seek_its=2, Ksubset=48, Knew=48, small_ref_panel_gibbs_iterations=3,
+                      small_ref_panel_block_gibbs_iterations=(1,), seed=5)
+    with pytest.raises(RuntimeError, match="status -2.*sample source failed at sample 2"):
+        impute_samples_on_oracle(panel, samples, P2, samples_per_launch_set=1, n_threads=3, source=dict(fail_at=2))
+    none, stats, tab = impute_samples_on_oracle(panel, [], P2, n_threads=2, source=dict(n_upper=4))
+    assert none == [] and tab.calls["gibbs"] == 0
+    small = make_synthetic_panel(K=300, nSNPs=640, seed=5)
+    rc = make_rare_common(small, 3)
+    rs = [make_synthetic_sample_rare_common(small, rc, 50 + i, n_reads=150)[0] for i in range(3)]
+    P3 = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, impute_rare_common=True, small_ref_panel_gibbs_iterations=4,
+                      small_ref_panel_block_gibbs_iterations=(2,))
+    want, _, _ = impute_samples_on_oracle(small, rs, P3, sample_offset=3, samples_per_launch_set=2, n_threads=2, rare_common=rc)
+    got, _, _ = impute_samples_on_oracle(small, rs, P3, sample_offset=3, samples_per_launch_set=2, n_threads=2, rare_common=rc,
+                                         source=dict(n_upper=4))
+    for a, b in zip(got, want):
+        _same(a, b)
+
+
 def test_result_does_not_depend_on_the_plan_for_left_over_sets():
     """Seven launch sets of three samples over three host threads leave one over: it goes whole to the first thread (the default) or is cut across
     the threads (QA_IMPUTE_CUT_LEFTOVERS=1, read once per process: two child processes).  Same bytes either way."""

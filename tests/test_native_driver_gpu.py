@@ -201,6 +201,33 @@ def test_prepared_range_runs_again_with_the_same_result(medium_panel):
     assert not first[0].phasing_haps.flags.owndata and first[0].phasing_haps.shape == (panel.nSNPs, 2)
 
 
+@pytest.mark.parametrize("method", ["diploid", "nipt"])
+def test_samples_handed_over_one_by_one_on_the_device(medium_panel, method):
+    """params->sample_source on the device: qa_impute_samples handed each sample when its launch set is taken (what
+    qa_impute_bam_range does while its loader threads are still reading later files) returns the bytes of the flat call."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_samples
+    from quilt_amd.native import DevicePanel
+    from quilt_amd.synth import make_synthetic_sample
+    panel = medium_panel
+    samples = [make_synthetic_sample(panel, seed=4500 + i, n_reads=300 + 20 * i, ff=(0.1 + 0.03 * i) if method == "nipt" else 0.0)
+               for i in range(7)]
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=23, method=method)
+    devs = [DevicePanel(panel) for _ in range(3)]
+    for d in devs:
+        d.set_device_share(3)
+        d.set_dosage_precision(64)
+        d.set_exclusive(True)
+    want = impute_samples(devs, samples, prm, sample_offset=5, samples_per_launch_set=2)
+    got = impute_samples(devs, samples, prm, sample_offset=5, samples_per_launch_set=2, one_by_one=True)
+    for d in devs:
+        d.close()
+    for a, b in zip(got, want):
+        _same(a, b)
+        if method == "nipt":
+            assert np.array_equal(a.fet_dosage, b.fet_dosage) and np.array_equal(a.fet_gp_t, b.fet_gp_t)
+
+
 def test_native_loop_equals_python_loop_over_seeds_that_reach_the_complete_lists_branch():
     """The panel and parameters of scripts/check_pipeline_seeds.py (K = 5 000 over 100 grids, Knew = Ksubset: the device selection
     regularly runs out of ranked candidates and both host loops fetch complete lists from genotype likelihoods THEY build): the
