@@ -118,7 +118,8 @@ class OracleTable:
         wh = _arr(which, n * o.Ks, np.int32).reshape(n, o.Ks)
         Ha = _arr(H, totR, np.int32)
         wf = _arr(wif, totR, np.int32)
-        blocks = [int(x) for x in np.ctypeslib.as_array(C.cast(o.block_gibbs_iterations, I32P), shape=(o.n_block_gibbs_iterations,))]
+        blocks = ([int(x) for x in np.ctypeslib.as_array(C.cast(o.block_gibbs_iterations, I32P), shape=(o.n_block_gibbs_iterations,))]
+                  if o.n_block_gibbs_iterations > 0 else [])   # (no block passes: the pointer may be null)
         base = 0
         samples, starts = [], []
         for c in range(n):
