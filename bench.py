@@ -386,9 +386,10 @@ def main():
     ap.add_argument("--host-share", type=int, default=1,
                     help="N > 1: confine this run to 1 / N of the host's logical CPUs and give it the host-thread budget of one rank of an "
                          "N-rank run -- measures, on one GPU, what a rank's share of the host costs (the 8-GPU node's host side)")
-    ap.add_argument("--io-threads", type=int, default=64,
-                    help="--bam: host threads of qa_impute_bam_range's loading and formatting (0 = min(32, hardware threads)); divided by the "
-                         "number of ranks")
+    ap.add_argument("--io-threads", type=int, default=0,
+                    help="--bam: host threads of qa_impute_bam_range's loading and of its formatting (0 = the library's default: min(16, "
+                         "hardware threads) per rank; more get in each other's and the imputation's way: csrc/bamrange.cpp); divided by "
+                         "the number of ranks")
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
@@ -735,7 +736,7 @@ def main():
             out["from_bam_files"] = {
                 "value": len(files) / t_io, "unit": "samples/sec", "samples": len(files), "wall_s": round(t_io, 3),
                 "seconds": {k: round(v, 3) for k, v in sec.items()},
-                "io_threads": (max(1, a.io_threads // max(world, 1)) if a.io_threads else "min(32, hardware threads)"),
+                "io_threads": (max(1, a.io_threads // max(world, 1)) if a.io_threads else "min(16, hardware threads)"),
                 "share_of_wall": {"impute_with_loading_and_formatting_beside_it": round(sec["impute"] / t_io, 4),
                                   "format_and_counts_left_at_the_end": round(sec["format"] / t_io, 4),
                                   "outside_the_native_call": round(1 - sec["total"] / t_io, 4)},

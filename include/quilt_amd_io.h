@@ -161,7 +161,7 @@ typedef struct {
     qa_bam_opts_t bam;              /* loader options (qa_bam_opts_default) */
     int32_t minimum_number_of_sample_reads;   /* 2 (quilt.R:132): samples below it are not imputed (functions.R:274-287) */
     int32_t output_gt_phased_genotypes;       /* 1 (quilt.R:153) */
-    int32_t n_io_threads;                     /* host threads for loading and formatting; 0 = min(32, hardware threads) */
+    int32_t n_io_threads;                     /* host threads for loading and for formatting (each); 0 = min(16, hardware threads) */
 } qa_bam_range_io_t;
 
 typedef struct qa_bam_range_result qa_bam_range_result_t;   /* opaque; owned by the library */
