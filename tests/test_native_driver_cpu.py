@@ -323,3 +323,48 @@ def test_bam_range_call_equals_the_python_bam_to_vcf_path(tmp_path, small_panel,
     other = impute_bam_range_on_oracle(small_panel, bams, "chr20", ref, alt, prm, sample_index=[5, 99, 6, 7],
                                        ff=None if ff is None else [ff] * 4)
     assert not all(np.array_equal(other["results"][i].read_labels, got["results"][i].read_labels) for i in (0, 2, 3))
+
+
+def test_bam_range_call_at_its_edges(tmp_path, small_panel):
+    """The range call where its bookkeeping could go wrong: dropped files first, last, all of them, next to each other; the same
+    file twice; no file at all; one host thread and more threads than files; an unreadable file in the middle (the call fails
+    naming it, whichever thread met it) -- every kept sample equal to itself in the plain four-file range."""
+    from quilt_amd.driver import DriverParams
+    from tests.native_driver_backend import impute_bam_range_on_oracle
+    from tests.oracle_backend import OracleBackend
+    from tests.test_driver_host import _bam_to_vcf
+    prm = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9)
+    _bam_to_vcf(tmp_path, small_panel, OracleBackend(small_panel), prm=prm)   # (writes s0 / empty / s1 / s2 .bam)
+    rng = np.random.default_rng(21)
+    alleles = [tuple(rng.choice(list("ACGT"), size=2, replace=False)) for _ in range(small_panel.nSNPs)]
+    ref, alt = [a for a, _ in alleles], [b for _, b in alleles]
+    path = lambda n: str(tmp_path / (n + ".bam"))
+    run = lambda names, idx, **kw: impute_bam_range_on_oracle(small_panel, [path(n) for n in names], "chr20", ref, alt, prm,
+                                                              sample_index=idx, samples_per_launch_set=2, **kw)
+    base = run(["s0", "empty", "s1", "s2"], [0, 1, 2, 3], n_io_threads=3)
+    col = {"s0": base["columns"][0].tolist(), "s1": base["columns"][2].tolist(), "s2": base["columns"][3].tolist()}
+    gidx = {"s0": 0, "s1": 2, "s2": 3, "empty": 1}
+
+    def check(names, **kw):
+        got = run(names, [gidx[n] for n in names], **kw)
+        assert got["imputed"] == [n != "empty" for n in names]
+        for i, n in enumerate(names):
+            if n == "empty":
+                assert got["columns"][i] is None and got["n_reads"][i] == 0 and i not in got["results"]
+            else:
+                assert got["columns"][i].tolist() == col[n], (names, i)
+        assert got["counts"].hweCount.sum() == small_panel.nSNPs * sum(n != "empty" for n in names)
+        return got
+
+    check(["empty", "s0", "s1", "s2"], n_io_threads=1)             # dropped first; one loader
+    check(["s0", "s1", "s2", "empty"], n_io_threads=8)             # dropped last; more threads than files
+    check(["empty", "empty", "s1", "empty", "s0", "empty"], n_io_threads=2)
+    none = check(["empty", "empty"], n_io_threads=2)               # nothing to impute: a successful call
+    assert none["stats"]["gibbs_chain_calls"] == 0
+    nothing = run([], [])
+    assert nothing["imputed"] == [] and nothing["counts"].afCount.sum() == 0
+    twice = check(["s1", "s1"], n_io_threads=2)                    # the same file (and global index) twice: the same column twice
+    assert twice["columns"][0].tolist() == twice["columns"][1].tolist()
+    for n_io in (1, 4):
+        with pytest.raises(RuntimeError, match="missing.bam"):
+            run(["s0", "missing", "s1", "s2"], [0, 1, 2, 3], n_io_threads=n_io)
