@@ -1393,7 +1393,10 @@ int impute_impl(bool keep_buffers, const qa_impute_backend_t *be, void *const *h
                 std::unique_lock<std::mutex> lk(started[(size_t)w2 - 1].mu);
                 // (staggered start: a launch plan, not a dependency -- a predecessor whose first launch takes longer than this is
                 // not waited for; results do not depend on it, QA_TIMING says when it happened)
-                if (!started[(size_t)w2 - 1].cv.wait_for(lk, std::chrono::seconds(5), [&] { return started[(size_t)w2 - 1].set; }))
+                // (wait_until on the system clock = pthread_cond_timedwait, which ThreadSanitizer follows; wait_for's
+                // pthread_cond_clockwait it does not -- tests/test_tsan_cpu.py.  A clock step only moves this 5 s plan.)
+                if (!started[(size_t)w2 - 1].cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::seconds(5),
+                                                           [&] { return started[(size_t)w2 - 1].set; }))
                     stagger_timed_out.store(true);
             }
             workers[(size_t)w2]->on_first_launch = [&, w2] { signal(w2); };
