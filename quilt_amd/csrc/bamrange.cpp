@@ -377,6 +377,37 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
         if (rare) all_snps[(size_t)file] = Loaded();
         return (int)QA_OK;
     };
+    // The range's sums, per SNP over the samples IN SAMPLE ORDER, as the reference's loop adds them (quilt.R:955-961: floating-point
+    // sums, so the order is part of the result).  Launch sets finish nearly in order: whichever formatter completes the next sample
+    // in line adds it -- and every formatted sample behind it -- to the sums and releases its per-SNP vectors, beside the device
+    // work; nothing is left to sum, and 2 MB per sample less to hand back, when the call ends.
+    struct Sums {
+        std::mutex mu;
+        std::vector<uint8_t> formatted;
+        int next = 0;
+    } sums;
+    sums.formatted.assign((size_t)nk_max, 0);
+    auto add_in_order = [&](int j_done) {
+        std::lock_guard<std::mutex> g(sums.mu);
+        sums.formatted[(size_t)j_done] = 1;
+        double *i0 = R->infoCount.data(), *i1 = i0 + T_out, *af = R->afCount.data(), *hw = R->hweCount.data();
+        double *a0 = R->alleleCount.data(), *a1 = a0 + T_out;
+        while (sums.next < nk_max && sums.formatted[(size_t)sums.next]) {
+            const size_t j = (size_t)sums.next++;
+            const double *E = eij[j].data(), *F = fij[j].data(), *c1 = ac[j].data(), *c2 = c1 + T_out;
+            const uint8_t *M = maxg[j].data();
+            for (int t = 0; t < T_out; t++) {
+                i0[t] += E[t];
+                i1[t] += F[t] - E[t] * E[t];
+                af[t] += E[t] / 2;
+                hw[(size_t)M[t] * T_out + t] += 1;
+                a0[t] += c2[t];              // per_sample_alleleCount = cbind(c2, c1 + c2) (functions.R:1398)
+                a1[t] += c1[t] + c2[t];
+            }
+            std::vector<double>().swap(eij[j]); std::vector<double>().swap(fij[j]); std::vector<double>().swap(ac[j]);
+            std::vector<uint8_t>().swap(maxg[j]);
+        }
+    };
     struct Pool {
         std::mutex mu;
         std::condition_variable cv;
@@ -400,6 +431,7 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
             std::string e;
             int s1;
             try { s1 = format_one(j, e); } catch (const std::exception &ex) { s1 = QA_ERR_INVALID; e = ex.what(); }
+            if (s1 == QA_OK) add_in_order(j);
             std::lock_guard<std::mutex> g(pool.mu);
             pool.busy_s += since(tj);
             if (s1 != QA_OK && pool.status == QA_OK) { pool.status = s1; pool.err = e; }
@@ -444,30 +476,7 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
     tr_drain = since(t0);
     if (pool.status != QA_OK) { qa::set_error("qa_impute_bam_range: %s", pool.err.c_str()); return pool.status; }
     if ((int)pool.queue.size() != nk) { qa::set_error("qa_impute_bam_range: %d of %d samples were reported final", (int)pool.queue.size(), nk); return QA_ERR_INVALID; }
-    // the range's sums, per SNP over the samples IN SAMPLE ORDER, as the reference's loop adds them (quilt.R:955-961); SNP blocks on
-    // the host threads (the order of a floating-point sum is per SNP: blocks of SNPs do not interact)
-    {
-        double *i0 = R->infoCount.data(), *i1 = i0 + T_out, *af = R->afCount.data(), *hw = R->hweCount.data();
-        double *a0 = R->alleleCount.data(), *a1 = a0 + T_out;
-        const int n_blocks = std::max(1, std::min(4 * n_io, (T_out + 511) / 512));
-        st = parallel_for(n_blocks, n_io, err, [&](int blk, std::string &) {
-            const int lo = (int)((int64_t)T_out * blk / n_blocks), hi = (int)((int64_t)T_out * (blk + 1) / n_blocks);
-            for (int j = 0; j < nk; j++) {
-                const double *E = eij[(size_t)j].data(), *F = fij[(size_t)j].data(), *c1 = ac[(size_t)j].data(), *c2 = c1 + T_out;
-                const uint8_t *M = maxg[(size_t)j].data();
-                for (int t = lo; t < hi; t++) {
-                    i0[t] += E[t];
-                    i1[t] += F[t] - E[t] * E[t];
-                    af[t] += E[t] / 2;
-                    hw[(size_t)M[t] * T_out + t] += 1;
-                    a0[t] += c2[t];              // per_sample_alleleCount = cbind(c2, c1 + c2) (functions.R:1398)
-                    a1[t] += c1[t] + c2[t];
-                }
-            }
-            return (int)QA_OK;
-        });
-        if (st != QA_OK) { qa::set_error("qa_impute_bam_range: %s", err.c_str()); return st; }
-    }
+    if (sums.next != nk) { qa::set_error("qa_impute_bam_range: %d of %d samples were added to the range's sums", sums.next, nk); return QA_ERR_INVALID; }
     R->format_busy_s = pool.busy_s;
     R->seconds[2] = since(t0);
     tr_sums = R->seconds[2] - tr_drain;
