@@ -31,7 +31,7 @@ extern "C" const char *qa_last_error(void) { return qa::g_err; }
 
 namespace {
 
-int g_T = 0;   // SNPs of the panel (the table's functions do not get it everywhere)
+int g_T = 0, g_T_all = 0, g_G = 0;   // SNPs of the panel / of the all-SNP call, grids (the table's functions do not get them everywhere)
 std::atomic<long> n_gibbs{0}, n_full{0};
 
 int f_gibbs(void *, const qa_gibbs_opts_t *o, int32_t n, const int32_t *, const int32_t *read_off, const int32_t *, const int32_t *,
@@ -43,6 +43,19 @@ int f_gibbs(void *, const qa_gibbs_opts_t *o, int32_t n, const int32_t *, const 
     for (int r = 0; r < read_off[n]; r++) H[r] = 1 + (H[r] % nl);   // (labels stay in 1 .. n_label)
     if (o->hap_major_out)
         for (size_t i = 0; i < (size_t)n * o->hap_major_labels * g_T; i++) o->hap_major_out[i] = 0.25;
+    if (o->hap_words_out)
+        for (size_t i = 0; i < (size_t)n * 3 * g_G; i++) o->hap_words_out[i] = (int32_t)i;
+    return QA_OK;
+}
+int f_gibbs_rc(void *, const void *, const qa_gibbs_opts_t *o, int32_t n, const int32_t *, const int32_t *read_off, const int32_t *,
+               const int32_t *, const int32_t *, const int32_t *, const double *, const int32_t *, const double *, int32_t *H, int32_t *,
+               double *, double *, double *, int32_t *uf, double *, const uint64_t *, const uint64_t *) {
+    n_gibbs += n;
+    for (int a = 0; a < n; a++) uf[a] = 0;
+    const int nl = o->sample_is_diploid ? 2 : 3;
+    for (int r = 0; r < read_off[n]; r++) H[r] = 1 + (H[r] % nl);
+    if (o->hap_major_out)
+        for (size_t i = 0; i < (size_t)n * o->hap_major_labels * g_T_all; i++) o->hap_major_out[i] = 0.25;
     return QA_OK;
 }
 int f_fullpass_select(void *, int32_t n_chain, int32_t n_label, int32_t, const int32_t *, const int32_t *, const int32_t *, const int32_t *,
@@ -64,7 +77,11 @@ int f_emat(void *, int32_t, int32_t n_chain, int32_t K, const double *, const in
     for (size_t i = 0; i < (size_t)read_off[n_chain] * K; i++) e[i] = 0.5;
     return QA_OK;
 }
-int f_mspbwt(const qa_mspbwt_t *, int32_t, int32_t, const int32_t *, int32_t, int32_t, int32_t, const uint64_t *, int32_t *) { return QA_ERR_INVALID; }
+int f_mspbwt(const qa_mspbwt_t *, int32_t n_chain, int32_t, const int32_t *, int32_t, int32_t, int32_t Knew, const uint64_t *, int32_t *out) {
+    for (int a = 0; a < n_chain; a++)
+        for (int j = 0; j < Knew; j++) out[(size_t)a * Knew + j] = 1 + j;
+    return QA_OK;
+}
 void *f_alloc(size_t b) { return std::malloc(b ? b : 1); }
 int f_free(void *p) { std::free(p); return QA_OK; }
 
@@ -75,6 +92,8 @@ qa_impute_backend_t table() {
     t.fullpass_batch = f_fullpass;
     t.make_eMatRead_t_hap_major = f_emat;
     t.mspbwt_select_new_haps = f_mspbwt;
+    t.gibbs_batch_rare_common = f_gibbs_rc;
+    t.make_eMatRead_t_nsnps = f_emat;   // (same signature: the all-SNP likelihoods, constant here)
     t.accumulate_dosage = qa_accumulate_dosage;          // (the library's own: host functions of csrc/hostio.cpp)
     t.consensus_read_labels = qa_consensus_read_labels;
     t.host_alloc = f_alloc;
@@ -139,7 +158,7 @@ int main(int argc, char **argv) {
     void *handles[W] = {(void *)1, (void *)2, (void *)3};
     {
         const int T = 640, G = 20, n = 23;
-        g_T = T;
+        g_T = T; g_G = G;
         Samples S = make_samples(n, T);
         for (int per_set : {2, 5, 256}) {
             P.samples_per_launch_set = per_set;
@@ -166,6 +185,48 @@ int main(int argc, char **argv) {
             REQUIRE(d2[(size_t)n * T] == -1);   // rows beyond the range's end are not touched
         }
     }
+    {   // the other modes' branches of the loop: msPBWT selection, three labels (NIPT), the all-SNP round (rare + common)
+        const int T = 640, G = 20, n = 11;
+        g_T = T; g_G = G;
+        Samples S = make_samples(n, T);
+        int64_t stats[11];
+        P.sample_source = nullptr; P.on_samples_done = nullptr; P.samples_per_launch_set = 2;
+        std::vector<int32_t> lab((size_t)S.read_off[(size_t)n]), nd((size_t)n);
+        {
+            qa_impute_params_t Q = P;
+            Q.use_mspbwt = 1; Q.mspbwt_index = reinterpret_cast<const qa_mspbwt_t *>(0x10); Q.mspbwtL = 3; Q.mspbwtM = 1;
+            std::vector<double> d((size_t)n * T), g((size_t)n * 3 * T), h((size_t)n * 2 * T);
+            REQUIRE(qa_impute_samples_backend(&tab, handles, W, K, G, T, &Q, n, 0, S.read_off.data(), S.read_ptr.data(), S.u.data(), S.bq.data(),
+                                              S.wif.data(), d.data(), g.data(), h.data(), lab.data(), nd.data(), stats) == QA_OK);
+        }
+        {
+            qa_impute_params_t Q = P;
+            std::vector<double> ff((size_t)n, 0.2), fd((size_t)n * T), fg((size_t)n * 3 * T);
+            std::vector<int32_t> Lg((size_t)G);
+            for (int i = 0; i < G; i++) Lg[(size_t)i] = 1000 * (i + 1);
+            qa_impute_nipt_t nq{ff.data(), Lg.data(), 5000, fd.data(), fg.data()};
+            Q.nipt = &nq;
+            std::vector<double> d((size_t)n * T), g((size_t)n * 3 * T), h((size_t)n * 3 * T);
+            REQUIRE(qa_impute_samples_backend(&tab, handles, W, K, G, T, &Q, n, 0, S.read_off.data(), S.read_ptr.data(), S.u.data(), S.bq.data(),
+                                              S.wif.data(), d.data(), g.data(), h.data(), lab.data(), nd.data(), stats) == QA_OK);
+        }
+        {
+            qa_impute_params_t Q = P;
+            const int Ta = 2 * T, Ga = (Ta + 31) / 32;
+            g_T_all = Ta;
+            Samples A = make_samples(n, Ta);
+            std::vector<uint8_t> is_common((size_t)Ta, 0);
+            for (int t = 0; t < T; t++) is_common[(size_t)2 * t] = 1;
+            const qa_rare_common_t *rch[W] = {reinterpret_cast<const qa_rare_common_t *>(0x20), reinterpret_cast<const qa_rare_common_t *>(0x30),
+                                              reinterpret_cast<const qa_rare_common_t *>(0x40)};
+            qa_impute_rare_common_t rc{rch, Ta, Ga, is_common.data(), A.read_off.data(), A.read_ptr.data(), A.u.data(), A.bq.data(), A.wif.data(), nullptr};
+            Q.rare_common = &rc;
+            std::vector<double> d((size_t)n * Ta), g((size_t)n * 3 * Ta), h((size_t)n * 2 * Ta);
+            REQUIRE(qa_impute_samples_backend(&tab, handles, W, K, G, T, &Q, n, 0, S.read_off.data(), S.read_ptr.data(), S.u.data(), S.bq.data(),
+                                              S.wif.data(), d.data(), g.data(), h.data(), lab.data(), nd.data(), stats) == QA_OK);
+            REQUIRE(nd[0] == Q.nGibbsSamples);
+        }
+    }
     if (argc >= 3) {
         FILE *f = std::fopen(argv[1], "rb");
         REQUIRE(f != nullptr);
@@ -178,6 +239,7 @@ int main(int argc, char **argv) {
         std::fclose(f);
         g_T = T;
         const int G = grid[(size_t)T - 1] + 1, n = argc - 2;
+        g_G = G;
         qa_bam_range_io_t io{};
         io.chr = "chr20"; io.nSNPs = T; io.L = L.data(); io.ref = ref.data(); io.alt = alt.data(); io.grid = grid.data();
         qa_bam_opts_default(&io.bam);
