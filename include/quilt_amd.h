@@ -489,7 +489,9 @@ typedef struct {
  *                             chain n_block_gibbs_iterations x 2 x R_c at offset read_off[c] * n_block_gibbs_iterations
  *                             * 2: per pass R_c `runif_block` values (gibbs-nipt.cpp:3016; entry b decides block b),
  *                             then one uniform per read for the reads whose class leaves a choice in
- *                             rcpp_sample_H_using_H_class (gibbs-nipt-block.cpp:226-243)
+ *                             rcpp_sample_H_using_H_class (gibbs-nipt-block.cpp:226-243).
+ *                             Read only when a pass draws from it (perform_block_gibbs, n_block_gibbs_iterations > 0, and
+ *                             ff > 0 or do_shard_block_gibbs); it must then hold all of the above.
  *   H                         in: starting read labels (double_list_of_starting_read_labels), 1-based;
  *                             out: ending labels (double_list_of_ending_read_labels)
  *   H_class                   out (may be NULL)

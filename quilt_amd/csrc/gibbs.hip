@@ -1373,7 +1373,9 @@ static int gibbs_chunk(qa_panel_t *pn, size_t arena_need, const qa_rare_common *
         const size_t nshard_used = nipt ? (size_t)totR * o->n_block_gibbs_iterations * 2
                                         : (size_t)C * o->n_block_gibbs_iterations * (G - 1);
         S.runif_shard.ensure(std::max<size_t>(nshard_used, 1));
-        if (runif_shard && !seed_shard && o->n_block_gibbs_iterations > 0 && (!nipt || o->perform_block_gibbs))
+        // (read only when a pass will draw from it: a caller that switches the passes off may hand over anything -- an array
+        // shorter than the passes would need was read past its end here until round 6: found by AddressSanitizer on the host code)
+        if (runif_shard && !seed_shard && o->n_block_gibbs_iterations > 0 && o->perform_block_gibbs && (nipt || o->do_shard_block_gibbs))
             S.runif_shard.upload(runif_shard, nshard_used, st);
         S.eread_off.ensure(C); S.eread_off.upload(eoff.data(), C, st);
         S.eridx_off.ensure(C); S.eridx_off.upload(ixoff.data(), C, st);

@@ -117,9 +117,13 @@ def forwardBackwardGibbsNIPT_batch(panel: DevicePanel, samples: Sequence, which_
             rs = np.concatenate(parts)
         else:
             rs = np.zeros(1)
+    elif nb > 0 and not use_seeds and perform_block_gibbs:   # (ff == 0: the shard passes, do_shard_block_gibbs below)
+        parts = [np.ascontiguousarray(r, dtype=np.float64).ravel()[: nb * (G - 1)] for r in runif_shard]
+        if len(parts) != Cn or any(len(x) != nb * (G - 1) for x in parts):   # (the library reads all of them)
+            raise ValueError(f"runif_shard: {nb * (G - 1)} uniforms per chain (block iterations x (nGrids - 1))")
+        rs = np.concatenate(parts)
     else:
-        rs = (np.concatenate([np.ascontiguousarray(r, dtype=np.float64).ravel()[: nb * (G - 1)] for r in runif_shard])
-              if (nb > 0 and not use_seeds) else np.zeros(1))
+        rs = np.zeros(1)   # (not read: no shard pass draws)
     if L_grid is None:
         L_grid = rare_common.rc.L_grid_all if rare_common is not None else P.L_grid
     Lg = np.ascontiguousarray(L_grid, dtype=np.int32) if L_grid is not None else None

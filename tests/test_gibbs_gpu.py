@@ -106,6 +106,24 @@ def test_gibbs_no_block_no_burn(small_panel, oracle):
         np.testing.assert_allclose(got[f"betaHat_t{h + 1}"], ref["betaHat_t"][h], rtol=RTOL, atol=1e-300)
 
 
+def test_shard_uniforms_are_checked_when_read_and_ignored_when_not(small_panel, oracle):
+    """runif_shard is read only when a shard pass draws from it: with the passes switched off a one-element array is fine (the
+    library read 45 doubles of it anyway until round 6 -- found by AddressSanitizer on the host code, scripts/asan_host.sh); with
+    the passes on, the wrapper refuses an array shorter than block iterations x (nGrids - 1)."""
+    from quilt_amd.gibbs_nipt import rcpp_forwardBackwardGibbsNIPT
+    from quilt_amd.native import DevicePanel
+    panel = small_panel
+    dev = DevicePanel(panel)
+    s, which, H0, ru, rs, fr = _setup(panel, 3, 50, 80)
+    short = np.zeros(1)
+    got = rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, short, n_gibbs_burn_in_its=2, n_gibbs_sample_its=1, perform_block_gibbs=False)
+    ref = oracle.forwardBackwardGibbsNIPT(panel, s, which, H0, ru, fr, rs, n_gibbs_burn_in_its=2, n_gibbs_sample_its=1, perform_block_gibbs=False)
+    assert np.array_equal(got["H"], ref["H"])
+    with pytest.raises(ValueError, match="runif_shard"):
+        rcpp_forwardBackwardGibbsNIPT(dev, s, which, H0, ru, fr, short, n_gibbs_burn_in_its=2, n_gibbs_sample_its=1)
+    dev.close()
+
+
 def test_gibbs_seeded_streams_match_explicit_uniforms(small_panel, oracle):
     """The device counter-based stream == quilt_amd.rng.stream_uniform fed to the oracle as arrays."""
     from quilt_amd.gibbs_nipt import forwardBackwardGibbsNIPT_batch
