@@ -320,7 +320,7 @@ def impute_samples_on_oracle(panel, samples, params, sample_offset=0, samples_pe
     return wrap_results(samples, dosage, gp_t, haps, labels, nDosage, read_off, fd, fg), dict(zip(STAT_NAMES, stats.tolist())), tab
 
 
-def impute_bam_range_on_oracle(panel, bam_files, chr, ref, alt, params, n_threads=1, **kw):
+def impute_bam_range_on_oracle(panel, bam_files, chr, ref, alt, params, n_threads=1, rare_common=None, **kw):
     """qa_impute_bam_range_backend (csrc/bamrange.cpp through the private test hook): the product's loader, kept-sample
     bookkeeping, column formatting and count arrays, with the imputation step on the oracle table."""
     from quilt_amd.impute import impute_bam_range
@@ -329,8 +329,13 @@ def impute_bam_range_on_oracle(panel, bam_files, chr, ref, alt, params, n_thread
         def __init__(self, p):
             self.panel, self.handle = p, None
 
-    tab = OracleTable(panel)
+    tab = OracleTable(panel, rare_common=rare_common)
     handles = (C.c_void_p * n_threads)(*[C.c_void_p(w + 1) for w in range(n_threads)])
+    if rare_common is not None:   # (the checker needs no native all-SNP handle: any non-null value per thread)
+        class _Drc:
+            def __init__(self, w):
+                self.rc, self.handle = rare_common, C.c_void_p(100 + w)
+        kw = dict(kw, drcs=[_Drc(w) for w in range(n_threads)])
     L = lib()
     L.qa_impute_bam_range_backend.restype = C.c_int
     L.qa_last_error.restype = C.c_char_p

@@ -368,3 +368,67 @@ def test_bam_range_call_at_its_edges(tmp_path, small_panel):
     for n_io in (1, 4):
         with pytest.raises(RuntimeError, match="missing.bam"):
             run(["s0", "missing", "s1", "s2"], [0, 1, 2, 3], n_io_threads=n_io)
+
+
+@pytest.mark.parametrize("mspbwt", [False, True])
+def test_bam_range_call_with_rare_and_common_snps(tmp_path, mspbwt):
+    """impute_rare_common = TRUE through the range call (QUILT2's default mode with use_mspbwt): every file is piled up TWICE -- at
+    the common SNPs and at all SNPs (functions.R:132-172) -- the all-SNP reads ride in the same per-sample view
+    (qa_sample_view_t), columns and count arrays cover ALL SNPs, the allele counts come from the all-SNP pile-up.  Against the same
+    steps taken one by one in Python: loader twice per file, quilt_amd/driver.py on the oracle, the column writer, SummaryCounts."""
+    from quilt_amd.driver import Driver, DriverParams
+    from quilt_amd.io import SummaryCounts, loadBamAndConvert, make_per_sample_vcf_col, per_sample_counts
+    from quilt_amd.synth import make_rare_common, make_synthetic_panel, make_synthetic_sample_rare_common
+    from tests import bamutil
+    from tests.native_driver_backend import impute_bam_range_on_oracle
+    panel = make_synthetic_panel(K=300, nSNPs=640, seed=5)
+    rc = make_rare_common(panel, 3)
+    Ta = rc.nSNPs_all
+    rng = np.random.default_rng(8)
+    alleles = [tuple(rng.choice(list("ACGT"), size=2, replace=False)) for _ in range(Ta)]
+    ref_all, alt_all = [a for a, _ in alleles], [b for _, b in alleles]
+    common = np.flatnonzero(rc.snp_is_common == 1)
+    ref, alt = [ref_all[i] for i in common], [alt_all[i] for i in common]
+    grid_all = (np.arange(Ta) // 32).astype(np.int32)
+    header = [("chr20", int(rc.L_all[-1]) + 1000)]
+    files = []
+    for i in range(3):
+        s_all = make_synthetic_sample_rare_common(panel, rc, 60 + i, n_reads=160)[0].all_snp
+        f = str(tmp_path / f"r{i}.bam")
+        bamutil.write_bam(f, header, bamutil.sample_to_alignments(s_all, rc.L_all, ref_all, alt_all, rng))
+        files.append(f)
+    empty = str(tmp_path / "none.bam")
+    bamutil.write_bam(empty, header, [])
+    files.insert(2, empty)
+    P = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, impute_rare_common=True, small_ref_panel_gibbs_iterations=4,
+                     small_ref_panel_block_gibbs_iterations=(2,), use_mspbwt=mspbwt, mspbwt_nindices=2)
+    opts = dict(downsampleToCov=0, bqFilter=1)
+    # step by step in Python
+    grid = panel.grid if panel.grid is not None else np.arange(panel.nSNPs, dtype=np.int32) // 32
+    samples, kept = [], []
+    for i, f in enumerate(files):
+        s = loadBamAndConvert(f, "chr20", panel.L, ref, alt, grid, **opts)
+        if s.nReads < 2:
+            continue
+        s.all_snp = loadBamAndConvert(f, "chr20", rc.L_all, ref_all, alt_all, grid_all, **opts)
+        samples.append(s)
+        kept.append(i)
+    assert kept == [0, 1, 3]
+    drv = Driver(panel, OracleBackend(panel, rc), P, rare_common=rc)
+    want = [drv.run([s], sample_offset=10 + i)[0] for i, s in zip(kept, samples)]
+    counts = SummaryCounts(Ta)
+    cols = []
+    for s, r in zip(samples, want):
+        counts.add_sample(*per_sample_counts(r.gp_t, s.all_snp, Ta))
+        cols.append(make_per_sample_vcf_col(r.gp_t, r.phasing_haps, True))
+    # the one native call
+    got = impute_bam_range_on_oracle(panel, files, "chr20", ref, alt, P, n_threads=2, rare_common=rc, sample_index=[10, 11, 12, 13],
+                                     all_sites=(rc.L_all, ref_all, alt_all, grid_all), n_io_threads=3, samples_per_launch_set=2, **opts)
+    assert got["imputed"] == [True, True, False, True]
+    for j, i in enumerate(kept):
+        g = got["results"][i]
+        assert g.dosage.shape == (Ta,) and np.array_equal(g.dosage, want[j].dosage) and np.array_equal(g.gp_t, want[j].gp_t)
+        assert np.array_equal(g.read_labels, want[j].read_labels) and np.array_equal(g.phasing_haps, want[j].phasing_haps)
+        assert got["columns"][i].tolist() == cols[j].tolist()
+    for name in ("infoCount", "afCount", "hweCount", "alleleCount"):
+        assert np.array_equal(getattr(got["counts"], name), getattr(counts, name)), name

@@ -322,3 +322,57 @@ def test_launches_cut_by_memory_give_the_same_results():
         out[frac] = (line[1], max(chains), len(chains))
     assert out["0.1"][0] == out[None][0]
     assert out[None][1] == 560 and out["0.1"][1] < 560 and out["0.1"][2] > out[None][2], out
+
+
+def test_bam_range_call_with_rare_and_common_snps_on_the_device(tmp_path, medium_panel):
+    """qa_impute_bam_range with impute_rare_common (+ use_mspbwt: QUILT2's default mode) on the device: every file piled up at the
+    common SNPs and at all SNPs by the native loader, the all-SNP reads handed over in the same per-sample view -- equal to
+    qa_impute_samples on the same files loaded through the Python binding of that loader, flat; columns cover all SNPs."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_bam_range, impute_samples
+    from quilt_amd.io import loadBamAndConvert, make_per_sample_vcf_col
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    from tests import bamutil
+    panel = medium_panel
+    rc = make_rare_common(panel, 4)
+    Ta = rc.nSNPs_all
+    rng = np.random.default_rng(8)
+    alleles = [tuple(rng.choice(list("ACGT"), size=2, replace=False)) for _ in range(Ta)]
+    ref_all, alt_all = [a for a, _ in alleles], [b for _, b in alleles]
+    common = np.flatnonzero(rc.snp_is_common == 1)
+    ref, alt = [ref_all[i] for i in common], [alt_all[i] for i in common]
+    grid_all = (np.arange(Ta) // 32).astype(np.int32)
+    grid = panel.grid if panel.grid is not None else np.arange(panel.nSNPs, dtype=np.int32) // 32
+    header = [("chr20", int(rc.L_all[-1]) + 1000)]
+    files, samples = [], []
+    opts = dict(downsampleToCov=0, bqFilter=1)
+    for i in range(5):
+        s_all = make_synthetic_sample_rare_common(panel, rc, 2800 + i, n_reads=400)[0].all_snp
+        f = str(tmp_path / f"r{i}.bam")
+        bamutil.write_bam(f, header, bamutil.sample_to_alignments(s_all, rc.L_all, ref_all, alt_all, rng))
+        files.append(f)
+        s = loadBamAndConvert(f, "chr20", panel.L, ref, alt, grid, **opts)
+        s.all_snp = loadBamAndConvert(f, "chr20", rc.L_all, ref_all, alt_all, grid_all, **opts)
+        samples.append(s)
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=8, impute_rare_common=True, use_mspbwt=True, mspbwt_nindices=2)
+    devs = [DevicePanel(panel) for _ in range(2)]
+    for d in devs:
+        d.set_device_share(2)
+        d.set_dosage_precision(64)
+        d.set_exclusive(True)
+    drcs = [DeviceRareCommon(d, rc) for d in devs]
+    want = impute_samples(devs, samples, prm, sample_offset=20, samples_per_launch_set=2, drcs=drcs)
+    got = impute_bam_range(devs, files, "chr20", ref, alt, prm, sample_index=list(range(20, 25)), drcs=drcs,
+                           all_sites=(rc.L_all, ref_all, alt_all, grid_all), samples_per_launch_set=2, n_io_threads=3, **opts)
+    for x in drcs:
+        x.close()
+    for d in devs:
+        d.close()
+    assert all(got["imputed"])
+    for i, w in enumerate(want):
+        g = got["results"][i]
+        assert g.dosage.shape == (Ta,)
+        _same(g, w)
+        assert got["columns"][i].tolist() == make_per_sample_vcf_col(w.gp_t, w.phasing_haps, True).tolist()
+    assert got["counts"].hweCount.sum() == 5 * Ta
