@@ -439,3 +439,56 @@ def test_bam_range_call_from_paths_to_columns(R, tmp_path, method):
     with pytest.raises(RError, match="sum_order"):
         R.dotcall("qa_impute_bam_range", R.strings(bams), R.named(sites), pan(), _params(R, prm, sum_order=R.integer([7]), **more),
                   R.real([0.0, 99.0, 1.0, 2.0]), R.integer([2]))
+
+
+def test_bam_range_call_quilt2_defaults(R, panel, tmp_path):
+    """`.Call("qa_impute_bam_range", ...)` in QUILT2's default mode (use_mspbwt + impute_rare_common): sites$L_all / ref_all / alt_all /
+    grid_all name the all-SNP sites, panel_objects$rare_common the all-SNP side of the panel; every file is piled up twice by the
+    native loader, the columns and the count arrays cover all SNPs -- equal to quilt_amd.impute.impute_bam_range on the device."""
+    from quilt_amd.driver import DriverParams
+    from quilt_amd.impute import impute_bam_range
+    from quilt_amd.native import DevicePanel, DeviceRareCommon
+    from quilt_amd.synth import make_rare_common, make_synthetic_sample_rare_common
+    from tests import bamutil
+    rc = make_rare_common(panel, 6)
+    Ta = rc.nSNPs_all
+    rng = np.random.default_rng(3)
+    alleles = [tuple(rng.choice(list("ACGT"), size=2, replace=False)) for _ in range(Ta)]
+    ref_all, alt_all = [a for a, _ in alleles], [b for _, b in alleles]
+    common = np.flatnonzero(rc.snp_is_common == 1)
+    ref, alt = [ref_all[i] for i in common], [alt_all[i] for i in common]
+    grid_all = (np.arange(Ta) // 32).astype(np.int32)
+    header = [("chr20", int(rc.L_all[-1]) + 1000)]
+    files = []
+    for i in range(3):
+        s_all = make_synthetic_sample_rare_common(panel, rc, 880 + i, n_reads=300)[0].all_snp
+        f = str(tmp_path / f"q{i}.bam")
+        bamutil.write_bam(f, header, bamutil.sample_to_alignments(s_all, rc.L_all, ref_all, alt_all, rng))
+        files.append(f)
+    prm = DriverParams(nGibbsSamples=2, Ksubset=128, Knew=128, seed=78, impute_rare_common=True, use_mspbwt=True, mspbwt_nindices=2)
+    dev = DevicePanel(panel)
+    dev.set_dosage_precision(64)
+    drc = DeviceRareCommon(dev, rc)
+    want = impute_bam_range([dev], files, "chr20", ref, alt, prm, sample_index=[5, 6, 7], drcs=[drc],
+                            all_sites=(rc.L_all, ref_all, alt_all, grid_all), samples_per_launch_set=2, n_io_threads=2,
+                            downsampleToCov=30, bqFilter=17)
+    drc.close()
+    dev.close()
+    rare = [R.integer(rc.rare_snp[rc.rare_ptr[k]:rc.rare_ptr[k + 1]]) for k in range(panel.K)]
+    rco = R.named(dict(snp_is_common=R.logical(rc.snp_is_common), rare_per_hap_info=R.list(rare), transMatRate_t=R.real(rc.transMatRate_t_all),
+                       L_grid=R.integer(rc.L_grid_all)))
+    sites = dict(chr=R.string("chr20"), L=R.integer(panel.L), ref=R.strings(ref), alt=R.strings(alt),
+                 grid=R.integer(np.arange(panel.nSNPs) // 32), L_all=R.integer(rc.L_all), ref_all=R.strings(ref_all), alt_all=R.strings(alt_all),
+                 grid_all=R.integer(grid_all), minimum_number_of_sample_reads=R.integer([2]), output_gt_phased_genotypes=R.logical([1]),
+                 n_io_threads=R.integer([2]))
+    out = R.dotcall("qa_impute_bam_range", R.strings(files), R.named(sites), R.panel_objects(panel, rare_common=rco),
+                    _params(R, prm, use_mspbwt=R.logical([1]), mspbwtL=R.integer([prm.mspbwtL]), mspbwtM=R.integer([prm.mspbwtM]),
+                            mspbwt_nindices=R.integer([2]), impute_rare_common=R.logical([1])),
+                    R.real([5.0, 6.0, 7.0]), R.integer([1]))
+    assert out["sample_was_imputed"].tolist() == [1, 1, 1]
+    for i in range(3):
+        assert len(out["per_sample_vcf_col"][i]) == Ta
+        assert out["per_sample_vcf_col"][i] == want["columns"][i].tolist()
+        assert np.array_equal(out["read_labels"][i], want["results"][i].read_labels)
+    for name in ("infoCount", "afCount", "hweCount", "alleleCount"):
+        assert out[name].shape[0] == Ta and np.array_equal(out[name], getattr(want["counts"], name)), name
