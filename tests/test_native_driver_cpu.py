@@ -370,14 +370,14 @@ def test_bam_range_call_at_its_edges(tmp_path, small_panel):
             run(["s0", "missing", "s1", "s2"], [0, 1, 2, 3], n_io_threads=n_io)
 
 
-@pytest.mark.parametrize("mspbwt", [False, True])
-def test_bam_range_call_with_rare_and_common_snps(tmp_path, mspbwt):
+@pytest.mark.parametrize("mspbwt,method", [(False, "diploid"), (True, "diploid"), (False, "nipt")])
+def test_bam_range_call_with_rare_and_common_snps(tmp_path, mspbwt, method):
     """impute_rare_common = TRUE through the range call (QUILT2's default mode with use_mspbwt): every file is piled up TWICE -- at
     the common SNPs and at all SNPs (functions.R:132-172) -- the all-SNP reads ride in the same per-sample view
     (qa_sample_view_t), columns and count arrays cover ALL SNPs, the allele counts come from the all-SNP pile-up.  Against the same
     steps taken one by one in Python: loader twice per file, quilt_amd/driver.py on the oracle, the column writer, SummaryCounts."""
     from quilt_amd.driver import Driver, DriverParams
-    from quilt_amd.io import SummaryCounts, loadBamAndConvert, make_per_sample_vcf_col, per_sample_counts
+    from quilt_amd.io import SummaryCounts, loadBamAndConvert, make_per_sample_vcf_col, make_per_sample_vcf_col_nipt, per_sample_counts
     from quilt_amd.synth import make_rare_common, make_synthetic_panel, make_synthetic_sample_rare_common
     from tests import bamutil
     from tests.native_driver_backend import impute_bam_range_on_oracle
@@ -401,7 +401,8 @@ def test_bam_range_call_with_rare_and_common_snps(tmp_path, mspbwt):
     bamutil.write_bam(empty, header, [])
     files.insert(2, empty)
     P = DriverParams(nGibbsSamples=2, Ksubset=64, Knew=64, seed=9, impute_rare_common=True, small_ref_panel_gibbs_iterations=4,
-                     small_ref_panel_block_gibbs_iterations=(2,), use_mspbwt=mspbwt, mspbwt_nindices=2)
+                     small_ref_panel_block_gibbs_iterations=(2,), use_mspbwt=mspbwt, mspbwt_nindices=2, method=method)
+    ffs = [0.12, 0.2, 0.3, 0.17] if method == "nipt" else None
     opts = dict(downsampleToCov=0, bqFilter=1)
     # step by step in Python
     grid = panel.grid if panel.grid is not None else np.arange(panel.nSNPs, dtype=np.int32) // 32
@@ -411,6 +412,8 @@ def test_bam_range_call_with_rare_and_common_snps(tmp_path, mspbwt):
         if s.nReads < 2:
             continue
         s.all_snp = loadBamAndConvert(f, "chr20", rc.L_all, ref_all, alt_all, grid_all, **opts)
+        if ffs:
+            s.ff = ffs[i]
         samples.append(s)
         kept.append(i)
     assert kept == [0, 1, 3]
@@ -420,10 +423,11 @@ def test_bam_range_call_with_rare_and_common_snps(tmp_path, mspbwt):
     cols = []
     for s, r in zip(samples, want):
         counts.add_sample(*per_sample_counts(r.gp_t, s.all_snp, Ta))
-        cols.append(make_per_sample_vcf_col(r.gp_t, r.phasing_haps, True))
+        cols.append(make_per_sample_vcf_col_nipt(r.gp_t, r.fet_gp_t, r.phasing_haps, r.dosage, r.fet_dosage) if ffs
+                    else make_per_sample_vcf_col(r.gp_t, r.phasing_haps, True))
     # the one native call
     got = impute_bam_range_on_oracle(panel, files, "chr20", ref, alt, P, n_threads=2, rare_common=rc, sample_index=[10, 11, 12, 13],
-                                     all_sites=(rc.L_all, ref_all, alt_all, grid_all), n_io_threads=3, samples_per_launch_set=2, **opts)
+                                     all_sites=(rc.L_all, ref_all, alt_all, grid_all), n_io_threads=3, samples_per_launch_set=2, ff=ffs, **opts)
     assert got["imputed"] == [True, True, False, True]
     for j, i in enumerate(kept):
         g = got["results"][i]
