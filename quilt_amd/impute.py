@@ -314,7 +314,7 @@ def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, al
     handles = (C.c_void_p * len(devs))(*[getattr(d, "handle", None) for d in devs])
     L = lib()
     for name in ("qa_impute_bam_range", "qa_bam_range_column", "qa_bam_range_sample", "qa_bam_range_counts", "qa_bam_range_imputed",
-                 "qa_bam_range_n_reads", "qa_bam_range_n_snps"):
+                 "qa_bam_range_n_reads", "qa_bam_range_n_snps", "qa_bam_range_n_samples"):
         getattr(L, name).restype = C.c_int
     L.qa_bam_range_destroy.restype = None
     L.qa_bam_range_timings.restype = None
@@ -325,7 +325,7 @@ def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, al
         check(L.qa_impute_bam_range(handles, C.c_int32(len(devs)), C.byref(q), C.byref(io), C.c_int32(n), paths, ptr(sidx), ptr(ffv),
                                     C.byref(h)))
     try:
-        assert L.qa_bam_range_n_snps(h) == T_out
+        assert L.qa_bam_range_n_snps(h) == T_out and L.qa_bam_range_n_samples(h) == n
         nL = 3 if P.method == "nipt" else 2
         imputed = [bool(L.qa_bam_range_imputed(h, C.c_int32(i))) for i in range(n)]
         n_reads = [int(L.qa_bam_range_n_reads(h, C.c_int32(i))) for i in range(n)]
