@@ -162,6 +162,10 @@ typedef struct {
     int32_t minimum_number_of_sample_reads;   /* 2 (quilt.R:132): samples below it are not imputed (functions.R:274-287) */
     int32_t output_gt_phased_genotypes;       /* 1 (quilt.R:153) */
     int32_t n_io_threads;                     /* host threads for loading and for formatting (each); 0 = min(16, hardware threads) */
+    int32_t discard_sample_arrays;            /* 1: a caller that wants the columns, labels and counts only (the R fast path): the pages
+                                                 of a sample's dosage / gp_t / phasing_haps rows (48 bytes per SNP; 7.9 GB at 2 560
+                                                 samples x 64 000 SNPs) go back to the system once its column is formatted, and
+                                                 qa_bam_range_sample returns NULL for those arrays */
 } qa_bam_range_io_t;
 
 typedef struct qa_bam_range_result qa_bam_range_result_t;   /* opaque; owned by the library */

@@ -34,6 +34,9 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "../../include/quilt_amd.h"
 #include "../../include/quilt_amd_io.h"
 #include "impute_testhook.h"   // (qa_impute_bam_range_backend: the same host code over a checker's entry points, for tests/)
@@ -51,7 +54,7 @@ struct RawDoubles {
 
 struct qa_bam_range_result {
     int n = 0, n_kept = 0, T_out = 0, nL = 2;
-    bool nipt = false;
+    bool nipt = false, discarded = false;
     std::vector<uint8_t> imputed;        // per file
     std::vector<int32_t> n_reads;        // per file: reads the loader returned (before the minimum test)
     std::vector<int32_t> slot;           // per file: index among the kept samples, or -1
@@ -322,6 +325,13 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
     R->col_off.resize((size_t)nk_max);
     std::vector<std::vector<double>> eij((size_t)nk_max), fij((size_t)nk_max), ac((size_t)nk_max);
     std::vector<std::vector<uint8_t>> maxg((size_t)nk_max);
+    R->discarded = io->discard_sample_arrays != 0;
+    // the whole pages inside [p, p + n): their memory goes back to the system now (the addresses stay valid and read as zeros)
+    auto give_back = [](double *p, size_t n) {
+        static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t lo = ((uintptr_t)p + page - 1) / page * page, hi = ((uintptr_t)(p + n)) / page * page;
+        if (hi > lo) madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED);
+    };
     auto format_one = [&](int j, std::string &e) -> int {
         const double *gp = R->gp_t.data() + (size_t)j * 3 * T_out;          // [3][T_out]
         const double *hd = R->haps.data() + (size_t)j * nL * T_out;         // [nL][T_out] == T_out x nL column-major
@@ -373,6 +383,15 @@ int bam_range_impl(const ImputeFn &impute, const qa_impute_params_t *params, con
             c2[s.u[b]] += q < 0 ? eps / 3 : 1 - eps;
         }
         // the sample is final: its reads are not needed again (released here, on this thread, not in one sweep at the end)
+        if (R->discarded) {   // nor are its result rows, for a caller that asked for columns, labels and counts only
+            give_back(R->dosage.data() + (size_t)j * T_out, (size_t)T_out);
+            give_back(R->gp_t.data() + (size_t)j * 3 * T_out, (size_t)3 * T_out);
+            give_back(R->haps.data() + (size_t)j * nL * T_out, (size_t)nL * T_out);
+            if (nipt) {
+                give_back(R->fet_dosage.data() + (size_t)j * T_out, (size_t)T_out);
+                give_back(R->fet_gp_t.data() + (size_t)j * 3 * T_out, (size_t)3 * T_out);
+            }
+        }
         common[(size_t)file] = Loaded();
         if (rare) all_snps[(size_t)file] = Loaded();
         return (int)QA_OK;
@@ -547,11 +566,11 @@ int qa_bam_range_sample(const qa_bam_range_result_t *r, int32_t i, const double 
     if (!r || i < 0 || i >= r->n) return QA_ERR_INVALID;
     const int j = r->slot[(size_t)i];
     const size_t T = (size_t)r->T_out;
-    if (dosage) *dosage = j < 0 ? nullptr : r->dosage.data() + (size_t)j * T;
-    if (gp_t) *gp_t = j < 0 ? nullptr : r->gp_t.data() + (size_t)j * 3 * T;
-    if (phasing_haps) *phasing_haps = j < 0 ? nullptr : r->haps.data() + (size_t)j * r->nL * T;
-    if (fet_dosage) *fet_dosage = (j < 0 || !r->nipt) ? nullptr : r->fet_dosage.data() + (size_t)j * T;
-    if (fet_gp_t) *fet_gp_t = (j < 0 || !r->nipt) ? nullptr : r->fet_gp_t.data() + (size_t)j * 3 * T;
+    if (dosage) *dosage = (j < 0 || r->discarded) ? nullptr : r->dosage.data() + (size_t)j * T;
+    if (gp_t) *gp_t = (j < 0 || r->discarded) ? nullptr : r->gp_t.data() + (size_t)j * 3 * T;
+    if (phasing_haps) *phasing_haps = (j < 0 || r->discarded) ? nullptr : r->haps.data() + (size_t)j * r->nL * T;
+    if (fet_dosage) *fet_dosage = (j < 0 || !r->nipt || r->discarded) ? nullptr : r->fet_dosage.data() + (size_t)j * T;
+    if (fet_gp_t) *fet_gp_t = (j < 0 || !r->nipt || r->discarded) ? nullptr : r->fet_gp_t.data() + (size_t)j * 3 * T;
     if (read_labels) *read_labels = j < 0 ? nullptr : r->labels_of[(size_t)j].data();
     if (n_labels) *n_labels = j < 0 ? 0 : (int32_t)r->labels_of[(size_t)j].size();
     if (nDosage) *nDosage = j < 0 ? 0 : r->nDosage[(size_t)j];

@@ -241,7 +241,7 @@ class BamRangeIo(C.Structure):
     _fields_ = [("chr", C.c_char_p), ("nSNPs", C.c_int32), ("L", C.c_void_p), ("ref", C.c_char_p), ("alt", C.c_char_p),
                 ("grid", C.c_void_p), ("nSNPs_all", C.c_int32), ("L_all", C.c_void_p), ("ref_all", C.c_char_p),
                 ("alt_all", C.c_char_p), ("grid_all", C.c_void_p), ("bam", _BamOpts), ("minimum_number_of_sample_reads", C.c_int32),
-                ("output_gt_phased_genotypes", C.c_int32), ("n_io_threads", C.c_int32)]
+                ("output_gt_phased_genotypes", C.c_int32), ("n_io_threads", C.c_int32), ("discard_sample_arrays", C.c_int32)]
 
 
 def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, alt, params: Optional[DriverParams] = None,
@@ -250,13 +250,15 @@ def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, al
                      samples_per_launch_set: int = 256, fuse_tails: bool = True, drcs: Sequence = (), all_sites=None,
                      bqFilter: int = 17, iSizeUpperLimit: float = 1e6, useSoftClippedBases: bool = False, downsampleToCov: int = 30,
                      chrStart: int = 0, chrEnd: int = 0, merge_mates: bool = True, seed: int = 1, copy_out: Optional[Sequence[int]] = None,
-                     _entry=None) -> dict:
+                     discard_sample_arrays: bool = False, _entry=None) -> dict:
     """The body of QUILT()'s loop over a core's sample range (quilt.R:832-982) as ONE native call: the BAM files are loaded on
     host threads, the samples with enough reads imputed together on the device, their VCF columns formatted on host threads and
     the four per-SNP count arrays summed over the range.  ``sample_index``: the files' global 0-based sample indices (default
     0 .. n - 1).  ``all_sites`` (with ``params.impute_rare_common`` and ``drcs``): ``(L_all, ref_all, alt_all, grid_all)``.
     ``copy_out``: the files whose columns and arrays are copied out of the library into numpy objects (default: all; a caller
     that only wants the counts or a few samples saves the copies -- 2.5 MB of text and 4 MB of numbers per sample).
+    ``discard_sample_arrays``: the library gives a sample's dosage / gp_t / phasing_haps rows back to the system once its column is
+    formatted (what the R fast path asks for); ``results`` then carry the read labels and ``nDosage`` only.
     Returns dict(imputed, n_reads, columns [VcfColumn or None], results {file index: SampleResult}, counts SummaryCounts,
     seconds {load, impute, format, total}, stats)."""
     from .io import BamOpts, SummaryCounts, VcfColumn
@@ -308,6 +310,7 @@ def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, al
     io.minimum_number_of_sample_reads = int(minimum_number_of_sample_reads)
     io.output_gt_phased_genotypes = int(bool(output_gt_phased_genotypes))
     io.n_io_threads = int(n_io_threads)
+    io.discard_sample_arrays = int(bool(discard_sample_arrays))
     paths = (C.c_char_p * max(n, 1))(*[p.encode() for p in bam_files])
     sidx = np.ascontiguousarray(np.arange(n) if sample_index is None else sample_index, dtype=np.int64)
     ffv = None if ff is None else np.ascontiguousarray(ff, dtype=np.float64)
@@ -343,8 +346,9 @@ def impute_bam_range(devs: Sequence, bam_files: Sequence[str], chr: str, ref, al
             nl, nd = C.c_int32(), C.c_int32()
             check(L.qa_bam_range_sample(h, C.c_int32(i), C.byref(pd), C.byref(pg), C.byref(ph), C.byref(pfd), C.byref(pfg), C.byref(pl),
                                         C.byref(nl), C.byref(nd)))
-            arr = lambda p, shape, t=C.c_double: np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), shape=shape).copy()
-            results[i] = SampleResult(arr(pd, (T_out,)), arr(pg, (3, T_out)), arr(ph, (nL, T_out)).T,
+            arr = lambda p, shape, t=C.c_double: (np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), shape=shape).copy() if p.value else None)
+            hp = arr(ph, (nL, T_out))
+            results[i] = SampleResult(arr(pd, (T_out,)), arr(pg, (3, T_out)), None if hp is None else hp.T,
                                       arr(pl, (nl.value,), C.c_int32) if nl.value else np.zeros(0, dtype=np.int32), int(nd.value),
                                       fet_dosage=arr(pfd, (T_out,)) if pfd.value else None,
                                       fet_gp_t=arr(pfg, (3, T_out)) if pfg.value else None)

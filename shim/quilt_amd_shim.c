@@ -1076,6 +1076,7 @@ SEXP qa_impute_bam_range_call(SEXP bamFilesSEXP, SEXP sitesSEXP, SEXP panelSEXP,
         io.minimum_number_of_sample_reads = (int)num_or(sitesSEXP, "minimum_number_of_sample_reads", 2);
         io.output_gt_phased_genotypes = flag(sitesSEXP, "output_gt_phased_genotypes", 1);
         io.n_io_threads = (int)num_or(sitesSEXP, "n_io_threads", 0);
+        io.discard_sample_arrays = 1;   /* (columns, labels and counts go back to R: the per-SNP numbers behind them are not kept) */
         st = qa_impute_bam_range(cx.handles, cx.n_handles, &cx.ip, &io, n, paths, sidx, cx.nipt ? cx.nq.ff : NULL, &res);
         if (st != QA_OK) snprintf(msg, sizeof msg, "%s", qa_last_error());
         range_teardown(&cx);

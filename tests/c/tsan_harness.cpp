@@ -251,6 +251,7 @@ int main(int argc, char **argv) {
         std::string first;
         for (int n_io : {1, 4, 9}) {
             io.n_io_threads = n_io;
+            io.discard_sample_arrays = n_io == 4;   // (the rows' pages handed back by the formatter threads)
             P.samples_per_launch_set = n_io == 4 ? 3 : 2;
             qa_bam_range_result_t *res = nullptr;
             REQUIRE(qa_impute_bam_range_backend(&tab, handles, W, K, G, &P, &io, n, argv + 2, idx.data(), nullptr, &res) == QA_OK);

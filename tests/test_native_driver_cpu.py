@@ -361,6 +361,15 @@ def test_bam_range_call_at_its_edges(tmp_path, small_panel):
     check(["empty", "empty", "s1", "empty", "s0", "empty"], n_io_threads=2)
     none = check(["empty", "empty"], n_io_threads=2)               # nothing to impute: a successful call
     assert none["stats"]["gibbs_chain_calls"] == 0
+    # a caller that wants columns, labels and counts only: the same text and counts, no per-SNP arrays (their pages went back)
+    lean = run(["s0", "empty", "s1", "s2"], [0, 1, 2, 3], n_io_threads=3, discard_sample_arrays=True)
+    for i, n in ((0, "s0"), (2, "s1"), (3, "s2")):
+        assert lean["columns"][i].tolist() == col[n]
+        r = lean["results"][i]
+        assert r.dosage is None and r.gp_t is None and r.phasing_haps is None
+        assert np.array_equal(r.read_labels, base["results"][i].read_labels) and r.nDosage == base["results"][i].nDosage
+    for name in ("infoCount", "afCount", "hweCount", "alleleCount"):
+        assert np.array_equal(getattr(lean["counts"], name), getattr(base["counts"], name)), name
     nothing = run([], [])
     assert nothing["imputed"] == [] and nothing["counts"].afCount.sum() == 0
     twice = check(["s1", "s1"], n_io_threads=2)                    # the same file (and global index) twice: the same column twice
