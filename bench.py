@@ -390,6 +390,10 @@ def main():
                     help="--bam: host threads of qa_impute_bam_range's loading and of its formatting (0 = the library's default: min(16, "
                          "hardware threads) per rank; more get in each other's and the imputation's way: csrc/bamrange.cpp); divided by "
                          "the number of ranks")
+    ap.add_argument("--bam-lean", action="store_true",
+                    help="--bam as the R fast path calls it: discard_sample_arrays (columns, labels and counts come back; a sample's "
+                         "per-SNP arrays go back to the system once its column is formatted); the check against the timed region is then on "
+                         "the last step's column TEXT")
     ap.add_argument("--bam", action="store_true",
                     help="the synthetic samples go through BAM files: written before the run, read back by the native loader "
                          "(qa_bam_load_sample_reads) outside the timed region; the loader's time per sample is reported")
@@ -533,6 +537,7 @@ def main():
     n_steps = a.warmup + a.steps
     seeds = [1000 + (rank * n_steps + st) * a.batch + i for st in range(n_steps) for i in range(a.batch)]
     bam_dir, bam_load_s = None, None
+    a.bam = a.bam or a.bam_lean
     if a.bam:
         import tempfile
         if rc is not None:
@@ -729,9 +734,14 @@ def main():
                                     sample_index=[(rank * n_steps + a.warmup) * a.batch + i for i in range(len(files))],
                                     ff=[0.2] * len(files) if a.mode == "nipt" else None, samples_per_launch_set=a.batch * a.fuse,
                                     fuse_tails=bool(a.fuse_tails), downsampleToCov=0, bqFilter=1, n_io_threads=max(1, a.io_threads // max(world, 1)) if a.io_threads else 0,
-                                    copy_out=range(len(files) - a.batch, len(files)))
+                                    copy_out=range(len(files) - a.batch, len(files)), discard_sample_arrays=bool(a.bam_lean))
             t_io = time.perf_counter() - t_io
-            same = all(np.array_equal(r_io["results"][len(files) - a.batch + i].dosage, main_reg["last"][i].dosage) for i in range(a.batch))
+            if a.bam_lean:
+                from quilt_amd.io import make_per_sample_vcf_col
+                same = all(r_io["columns"][len(files) - a.batch + i].tolist() ==
+                           make_per_sample_vcf_col(main_reg["last"][i].gp_t, main_reg["last"][i].phasing_haps, True).tolist() for i in range(a.batch))
+            else:
+                same = all(np.array_equal(r_io["results"][len(files) - a.batch + i].dosage, main_reg["last"][i].dosage) for i in range(a.batch))
             sec = r_io["seconds"]
             out["from_bam_files"] = {
                 "value": len(files) / t_io, "unit": "samples/sec", "samples": len(files), "wall_s": round(t_io, 3),
@@ -744,7 +754,7 @@ def main():
                 "compute_only_value": out["value"],
                 "last_step_dosages_equal_the_timed_region": bool(same),
                 "vcf_bytes_per_sample": int(np.mean([len(c.buf) for c in r_io["columns"] if c is not None])),
-                "results_copied_into_python": a.batch,
+                "results_copied_into_python": a.batch, "discard_sample_arrays": bool(a.bam_lean),
                 "what": "qa_impute_bam_range over the timed steps' BAM files, one native call, everything inside the clock: the files are "
                         "loaded on host threads in file order BESIDE the imputation (qa_impute_samples is handed each sample when its "
                         "launch set is taken; seconds.load = when the last file was in), the columns of finished launch sets are "
