@@ -209,12 +209,24 @@ __device__ __forceinline__ uint32_t panel_word(const GibbsParams &p, int g, int 
     return p.sp_word[lo];
 }
 
+__device__ __forceinline__ double rl_f64(double v, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int rl_i32(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
+
 // ---------------------------------------------------------------------------------------------
 // k_ematread: P(read r | small-panel haplotype k) (gibbs-small.cpp:148-263).  One wave per
 // (block of kReadsPerWave consecutive reads, chain); lane l owns rows l, l+64, ...  The chain's haplotype
 // list and the panel words of the current grid stay in registers across the block's reads (reads are sorted
 // by grid).  Products run over the read's bases in order, so each entry is bit-identical to the
 // reference's; then divide by the column max and floor (:235-262).
+// The walk over a read's bases is serial (a product in the reference's order) and every operand of a step used to be a load
+// that depended on the one before it -- offset, then position and quality, then the two table values of the quality: four
+// round trips per base with nothing else in flight.  Now the block's read offsets sit in lanes (one load), and the bases come
+// in chunks of 64 -- position, quality and the quality's two table values, one base per lane, gathered side by side -- so a
+// step takes its operands from registers (v_readlane with a wave-uniform lane).  Same values, same order of multiplications.
 // ---------------------------------------------------------------------------------------------
 constexpr int kReadsPerWave = 32;
 constexpr int kMaxPatternBits = 5;
@@ -239,28 +251,47 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
     int g_prev = -1;
     uint32_t w[NEALL];
     const double e1 = 1 - p.ref_error, e0 = p.ref_error;
-    for (int r = r0; r < min(r0 + kReadsPerWave, R); r++) {
+    const int nblk = min(kReadsPerWave, R - r0);
+    static_assert(kReadsPerWave < 64, "lane l holds the offset of read r0 + l, lane nblk the block's end");
+    const int my_s = (lane <= nblk) ? rp[r0 + lane] : 0;
+    const int my_dense = (lane < nblk) ? p.dense_of[p.read_off[c] + r0 + lane] : -1;
+    const int b_end = rl_i32(my_s, nblk);   // one past the block's last base
+    int chunk0 = rl_i32(my_s, 0), c_u = 0, c_b = 0;
+    double c_R = 0, c_A = 0;
+    auto load_chunk = [&](int base) {
+        chunk0 = base;
+        const int idx = base + lane;
+        const bool ok = idx < b_end;
+        c_u = ok ? u[idx] : 0;
+        c_b = ok ? bq[idx] : 0;
+        const int ab = c_b < 0 ? -c_b : c_b;
+        c_R = p.pR_tab[(c_b > 0 ? 256 : 0) + ab];
+        c_A = p.pA_tab[(c_b > 0 ? 256 : 0) + ab];
+    };
+    load_chunk(chunk0);
+    for (int r = r0; r < r0 + nblk; r++) {
         double v[NEALL];
         uint32_t pat[NEALL];
 #pragma unroll
         for (int i = 0; i < NEALL; i++) { v[i] = 1.0; pat[i] = 0; }
-        const int s = rp[r];
-        int J = rp[r + 1] - s - 1;
+        const int s = rl_i32(my_s, r - r0);
+        int J = rl_i32(my_s, r - r0 + 1) - s - 1;
         if (J >= p.Jmax) J = p.Jmax;
-        const int dense = p.dense_of[p.read_off[c] + r];
+        const int dense = rl_i32(my_dense, r - r0);
         int n_inf = 0;
         double tv = 1.0;   // lane l: the product for allele pattern l (bit j = allele at the read's j-th informative SNP)
         for (int j = 0; j <= J; j++) {
-            const int b = bq[s + j];
-            int snp = u[s + j];
+            if (s + j >= chunk0 + 64) load_chunk(s + j);
+            const int li = s + j - chunk0;
+            const int b = rl_i32(c_b, li);
+            int snp = rl_i32(c_u, li);
             if (p.rc_common) {   // all-SNP read: a common SNP maps to its panel column, a rare one has no column
                 const int all_snp = snp;
                 snp = p.rc_common[all_snp];
                 if (snp < 0) {
                     // rare SNP (gibbs-small.cpp:382-401): everyone as ref, then the carriers re-done -- in that order
                     if (b == 0) continue;
-                    const int ab = b < 0 ? -b : b;
-                    const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
+                    const double pR = rl_f64(c_R, li), pA = rl_f64(c_A, li);
                     const double xe1 = e0 * pA + e1 * pR;
                     const bool any = (p.rc_any[(size_t)c * p.rc_words + (all_snp >> 5)] >> (all_snp & 31)) & 1u;
                     if (!any) {   // no selected haplotype carries it: a common factor, dropped under rescaling
@@ -295,8 +326,7 @@ __global__ __launch_bounds__(64) void k_ematread(GibbsParams p) {
                 g_prev = g;
             }
             if (b == 0) continue;  // no base quality seen yet: factor 1 (host folded the carry-over rule)
-            const int ab = b < 0 ? -b : b;
-            const double pR = p.pR_tab[(b > 0 ? 256 : 0) + ab], pA = p.pA_tab[(b > 0 ? 256 : 0) + ab];
+            const double pR = rl_f64(c_R, li), pA = rl_f64(c_A, li);
             // the factor of a row is one of two values (its allele at the SNP): formed once, the expression the reference
             // evaluates per row (gibbs-small.cpp:219-226) with e = 1 - ref_error resp. ref_error
             const double f1 = (e1 * pA + (1 - e1) * pR), f0 = (e0 * pA + (1 - e0) * pR);
@@ -414,13 +444,6 @@ __device__ __forceinline__ double fast_rcp(double e) {
     r = __builtin_fma(__builtin_fma(-e, r, 1.0), r, r);
     return r;
 }
-
-__device__ __forceinline__ double rl_f64(double v, int j) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ int rl_i32(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
 
 template <int NE, int NW>
 struct Chain {
