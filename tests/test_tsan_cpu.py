@@ -1,5 +1,5 @@
-"""The product's host threading under ThreadSanitizer: csrc/impute.cpp, csrc/bamrange.cpp and csrc/hostio.cpp compiled with
-g++ -fsanitize=thread into tests/c/tsan_harness.cpp (trivial compute, the real threads: three host threads taking launch sets in
+"""The product's host threading under ThreadSanitizer, and once more under AddressSanitizer + UBSan: csrc/impute.cpp,
+csrc/bamrange.cpp and csrc/hostio.cpp compiled with g++ -fsanitize=... into tests/c/tsan_harness.cpp (trivial compute, the real threads: three host threads taking launch sets in
 turn, helper threads, staggered start, fused tails, the sample source, loader threads settling files in order beside the call,
 formatter pool, count sums; an unreadable file in the middle).  No report, exit code 0."""
 import os
@@ -13,23 +13,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "quilt_amd", "csrc")
 
 
-def _tsan_works(tmp_path):
+def _sanitizer_works(tmp_path, san):
     src = tmp_path / "probe.cpp"
     src.write_text("#include <thread>\nint main(){ std::thread t([]{}); t.join(); return 0; }\n")
     exe = tmp_path / "probe"
-    r = subprocess.run(["g++", "-fsanitize=thread", str(src), "-o", str(exe), "-pthread"], capture_output=True)
-    return r.returncode == 0 and subprocess.run([str(exe)], capture_output=True).returncode == 0
+    r = subprocess.run(["g++", "-fsanitize=" + san, str(src), "-o", str(exe), "-pthread"], capture_output=True)
+    return r.returncode == 0 and subprocess.run([str(exe)], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0")).returncode == 0
 
 
-def test_host_threads_are_race_free_under_threadsanitizer(tmp_path, small_panel):
-    if shutil.which("g++") is None or not _tsan_works(tmp_path):
-        pytest.skip("no working g++ -fsanitize=thread here")
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_host_threads_are_clean_under_the_sanitizers(tmp_path, small_panel, san):
+    if shutil.which("g++") is None or not _sanitizer_works(tmp_path, san):
+        pytest.skip(f"no working g++ -fsanitize={san} here")
     from quilt_amd.synth import make_synthetic_sample
     from tests import bamutil
     exe = tmp_path / "tsan_harness"
     stubs = tmp_path / "stubs.o"
     subprocess.run(["gcc", "-c", os.path.join(ROOT, "tests", "c", "tsan_stubs.c"), "-o", str(stubs)], check=True)
-    build = subprocess.run(["g++", "-fsanitize=thread", "-g", "-O1", "-std=c++17", os.path.join(CSRC, "impute.cpp"),
+    build = subprocess.run(["g++", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-g", "-O1" if san == "thread" else "-O0", "-std=c++17", os.path.join(CSRC, "impute.cpp"),
                             os.path.join(CSRC, "bamrange.cpp"), os.path.join(CSRC, "hostio.cpp"),
                             os.path.join(ROOT, "tests", "c", "tsan_harness.cpp"), str(stubs), "-lz", "-pthread", "-o", str(exe)],
                            capture_output=True, text=True)
@@ -58,8 +59,10 @@ def test_host_threads_are_race_free_under_threadsanitizer(tmp_path, small_panel)
         f.write("".join(ref).encode())
         f.write("".join(alt).encode())
         f.write(grid.tobytes())
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:exitcode=67",
+               UBSAN_OPTIONS="print_stacktrace=1")
     run = subprocess.run([str(exe), str(tmp_path / "sites.bin")] + paths, capture_output=True, text=True, env=env, timeout=600)
-    assert "ThreadSanitizer" not in run.stderr, run.stderr[-6000:]
+    for mark in ("ThreadSanitizer", "AddressSanitizer", "runtime error:"):
+        assert mark not in run.stderr, run.stderr[-6000:]
     assert run.returncode == 0, (run.returncode, run.stderr[-3000:])
     assert "tsan harness: ok" in run.stdout
