@@ -193,8 +193,25 @@ int main(int argc, char **argv) {
         P.sample_source = nullptr; P.on_samples_done = nullptr; P.samples_per_launch_set = 2;
         std::vector<int32_t> lab((size_t)S.read_off[(size_t)n]), nd((size_t)n);
         {
+            // use_mspbwt with the library's own host index and neighbour scan (csrc/mspbwt.cpp: threaded over indices and chains),
+            // called concurrently by the loop's host threads
+            std::vector<uint8_t> hm((size_t)K * G);
+            std::vector<int32_t> B((size_t)16 * G);
+            for (size_t i = 0; i < hm.size(); i++) hm[i] = (uint8_t)(1 + (i * 2654435761u >> 7) % 16);
+            for (size_t i = 0; i < B.size(); i++) B[i] = (int32_t)(i * 40503u);
+            qa_mspbwt_t *index = qa_mspbwt_create(K, G, hm.data(), 16, B.data(), 2);
+            REQUIRE(index != nullptr);
+            qa_impute_backend_t tab2 = tab;
+            tab2.mspbwt_select_new_haps = qa_mspbwt_select_new_haps;
             qa_impute_params_t Q = P;
-            Q.use_mspbwt = 1; Q.mspbwt_index = reinterpret_cast<const qa_mspbwt_t *>(0x10); Q.mspbwtL = 3; Q.mspbwtM = 1;
+            Q.use_mspbwt = 1; Q.mspbwt_index = index; Q.mspbwtL = 3; Q.mspbwtM = 1;
+            {
+                std::vector<double> d((size_t)n * T), g((size_t)n * 3 * T), h((size_t)n * 2 * T);
+                REQUIRE(qa_impute_samples_backend(&tab2, handles, W, K, G, T, &Q, n, 0, S.read_off.data(), S.read_ptr.data(), S.u.data(),
+                                                  S.bq.data(), S.wif.data(), d.data(), g.data(), h.data(), lab.data(), nd.data(), stats) == QA_OK);
+            }
+            qa_mspbwt_destroy(index);
+            Q.mspbwt_index = reinterpret_cast<const qa_mspbwt_t *>(0x10);   // (and once with the trivial selection of the table)
             std::vector<double> d((size_t)n * T), g((size_t)n * 3 * T), h((size_t)n * 2 * T);
             REQUIRE(qa_impute_samples_backend(&tab, handles, W, K, G, T, &Q, n, 0, S.read_off.data(), S.read_ptr.data(), S.u.data(), S.bq.data(),
                                               S.wif.data(), d.data(), g.data(), h.data(), lab.data(), nd.data(), stats) == QA_OK);

@@ -1,5 +1,5 @@
 /* tsan_stubs.c -- link-time stand-ins for the library's DEVICE entry points, for tests/c/tsan_harness.cpp only: the harness links
- * the product's host sources (csrc/impute.cpp, bamrange.cpp, hostio.cpp) without the HIP objects, and csrc/impute.cpp's own table
+ * the product's host sources (csrc/impute.cpp, bamrange.cpp, hostio.cpp, mspbwt.cpp) without the HIP objects, and csrc/impute.cpp's own table
  * names these functions.  None of them is ever called there (the harness runs the loop over its own table); each fails loudly if it
  * were.  No prototypes on purpose: C linkage, the arguments are not looked at. */
 #include <stdio.h>
@@ -12,7 +12,6 @@ STUB(qa_gibbs_batch)
 STUB(qa_gibbs_batch_rare_common)
 STUB(qa_host_alloc)
 STUB(qa_host_free)
-STUB(qa_mspbwt_select_new_haps)
 STUB(qa_panel_bind_thread)
 STUB(qa_panel_get_dims)
 STUB(qa_rcpp_make_eMatRead_t_hap_major)

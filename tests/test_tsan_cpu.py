@@ -1,5 +1,5 @@
 """The product's host threading under ThreadSanitizer, and once more under AddressSanitizer + UBSan: csrc/impute.cpp,
-csrc/bamrange.cpp and csrc/hostio.cpp compiled with g++ -fsanitize=... into tests/c/tsan_harness.cpp (trivial compute, the real threads: three host threads taking launch sets in
+csrc/bamrange.cpp, csrc/hostio.cpp and csrc/mspbwt.cpp compiled with g++ -fsanitize=... into tests/c/tsan_harness.cpp (trivial compute, the real threads: three host threads taking launch sets in
 turn, helper threads, staggered start, fused tails, the sample source, loader threads settling files in order beside the call,
 formatter pool, count sums; an unreadable file in the middle).  No report, exit code 0."""
 import os
@@ -31,7 +31,7 @@ def test_host_threads_are_clean_under_the_sanitizers(tmp_path, small_panel, san)
     stubs = tmp_path / "stubs.o"
     subprocess.run(["gcc", "-c", os.path.join(ROOT, "tests", "c", "tsan_stubs.c"), "-o", str(stubs)], check=True)
     build = subprocess.run(["g++", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-g", "-O1" if san == "thread" else "-O0", "-std=c++17", os.path.join(CSRC, "impute.cpp"),
-                            os.path.join(CSRC, "bamrange.cpp"), os.path.join(CSRC, "hostio.cpp"),
+                            os.path.join(CSRC, "bamrange.cpp"), os.path.join(CSRC, "hostio.cpp"), os.path.join(CSRC, "mspbwt.cpp"),
                             os.path.join(ROOT, "tests", "c", "tsan_harness.cpp"), str(stubs), "-lz", "-pthread", "-o", str(exe)],
                            capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
