@@ -254,8 +254,18 @@ void qa_bam_opts_default(qa_bam_opts_t *o) {
 
 int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNPs, const int32_t *L, const char *ref,
                              const char *alt, const int32_t *grid, const qa_bam_opts_t *opts, qa_sample_reads_t **out) {
-    if (!bam_path || !chr || nSNPs < 1 || !L || !ref || !alt || !grid || !out) return QA_ERR_INVALID;
-    for (int32_t t = 1; t < nSNPs; t++) if (L[t] <= L[t - 1]) return QA_ERR_INVALID;
+    if (out) *out = nullptr;
+    if (!bam_path || !chr || nSNPs < 1 || !L || !ref || !alt || !grid || !out) {
+        qa::set_error("qa_bam_load_sample_reads: missing argument");
+        return QA_ERR_INVALID;
+    }
+    for (int32_t t = 1; t < nSNPs; t++)
+        if (L[t] <= L[t - 1]) { qa::set_error("qa_bam_load_sample_reads: the site positions must ascend (L[%d] <= L[%d])", t, t - 1); return QA_ERR_INVALID; }
+    // every refusal says which file and what about it (qa_impute_bam_range reports it as "cannot load <file>: <this>")
+    auto refuse = [&](const char *what) {
+        qa::set_error("%s: %s", bam_path, what);
+        return (int)QA_ERR_INVALID;
+    };
     qa_bam_opts_t o;
     if (opts) o = *opts; else qa_bam_opts_default(&o);
     {   // CRAM (cramlist + reference, quilt.R:106-108): not decoded here -- say so, with the way round it
@@ -272,30 +282,31 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
         }
     }
     BgzfReader bz(bam_path);
-    if (bz.bad) return QA_ERR_INVALID;
+    if (bz.bad) return refuse("cannot be opened");
     char magic[4];
     int32_t l_text, n_ref;
-    if (!bz.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !bz.read(&l_text, 4) || l_text < 0) return QA_ERR_INVALID;
+    if (!bz.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !bz.read(&l_text, 4) || l_text < 0)
+        return refuse("not a BAM file (no BGZF block with the BAM magic at its start)");
     std::string text((size_t)l_text, '\0');
-    if (l_text && !bz.read(&text[0], (size_t)l_text)) return QA_ERR_INVALID;
+    if (l_text && !bz.read(&text[0], (size_t)l_text)) return refuse("the header text is cut short");
     const bool sorted = text.find("SO:coordinate") != std::string::npos;
-    if (!bz.read(&n_ref, 4) || n_ref < 0) return QA_ERR_INVALID;
+    if (!bz.read(&n_ref, 4) || n_ref < 0) return refuse("the reference dictionary is cut short");
     int32_t target = -1;
     for (int32_t i = 0; i < n_ref; i++) {
         int32_t l_name, l_ref;
-        if (!bz.read(&l_name, 4) || l_name < 1 || l_name > 65536) return QA_ERR_INVALID;
+        if (!bz.read(&l_name, 4) || l_name < 1 || l_name > 65536) return refuse("the reference dictionary is damaged");
         std::string name((size_t)l_name, '\0');
-        if (!bz.read(&name[0], (size_t)l_name) || !bz.read(&l_ref, 4)) return QA_ERR_INVALID;
+        if (!bz.read(&name[0], (size_t)l_name) || !bz.read(&l_ref, 4)) return refuse("the reference dictionary is cut short");
         if (strcmp(name.c_str(), chr) == 0) target = i;
     }
-    if (target < 0) return QA_ERR_INVALID;
+    if (target < 0) { qa::set_error("%s: no reference sequence named %s", bam_path, chr); return QA_ERR_INVALID; }
     // A coordinate-sorted file with a BAI index next to it (<file>.bai or <file without .bam>.bai): start at the linear
     // index's offset for the window's first 16 kb interval -- the first alignment overlapping it (SAM spec 5.1.3) --, tightened
     // by the bin index's chunks (bai_start_offset), instead of scanning from the top of a whole-genome file.  Any problem with the index just means the sequential scan.
     if (sorted) {
         const uint64_t voff = bai_start_offset(bam_path, target, o.chrStart > 0 ? o.chrStart - 1 : 0,
                                                o.chrEnd > 0 ? o.chrEnd : INT32_MAX);
-        if (voff != 0 && !bz.seek_virtual(voff)) return QA_ERR_INVALID;
+        if (voff != 0 && !bz.seek_virtual(voff)) return refuse("the index points outside the file");
     }
 
     auto *S = new qa_sample_reads;
@@ -307,7 +318,7 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
     for (;;) {
         int32_t block_size;
         if (!bz.read(&block_size, 4)) break;
-        if (block_size < 32) { bz.bad = true; break; }
+        if (block_size < 32 || block_size > (1 << 28)) { bz.bad = true; break; }   // (no alignment record is a quarter of a GB: a damaged length)
         rec.resize((size_t)block_size);
         if (!bz.read(rec.data(), rec.size())) { bz.bad = true; break; }
         int32_t refID, pos0, next_ref, next_pos, tlen, l_seq;
@@ -449,7 +460,7 @@ int qa_bam_load_sample_reads(const char *bam_path, const char *chr, int32_t nSNP
         reads.emplace_back();
         reads.back().b = std::move(bases);
     }
-    if (bz.bad) { delete S; return QA_ERR_INVALID; }
+    if (bz.bad) { delete S; return refuse("damaged or cut short (a BGZF block or an alignment record does not decode)"); }
 
     // coverage cap (quilt.R:54): sites in ascending order; at a site above the cap the covering reads with the smallest
     // stream keys go, until the site is at the cap

@@ -287,6 +287,53 @@ int main(int argc, char **argv) {
             if (first.empty()) first = all;
             REQUIRE(all == first);             // the text does not depend on the threads
         }
+        // damaged files: the loader answers with a status (or reads what is still readable), never with a fault -- the first file cut at
+        // 60 lengths and with one byte changed at 400 places, under the sanitizers
+        if (const char *scratch = std::getenv("QA_HARNESS_SCRATCH")) {
+            std::vector<unsigned char> bytes;
+            {
+                FILE *fb = std::fopen(argv[2], "rb");
+                REQUIRE(fb != nullptr);
+                unsigned char buf[65536];
+                size_t got;
+                while ((got = std::fread(buf, 1, sizeof buf, fb)) > 0) bytes.insert(bytes.end(), buf, buf + got);
+                std::fclose(fb);
+            }
+            REQUIRE(bytes.size() > 1000);
+            const std::string mut = std::string(scratch) + "/damaged.bam";
+            int n_ok = 0, n_refused = 0;
+            uint64_t lcg = 12345;
+            for (int it = 0; it < 460; it++) {
+                std::vector<unsigned char> m = bytes;
+                if (it < 60) {
+                    m.resize(bytes.size() * (size_t)it / 60);
+                } else {
+                    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                    const size_t at = (size_t)((lcg >> 20) % bytes.size());
+                    m[at] ^= (unsigned char)(1u << ((lcg >> 12) & 7));
+                    if (it % 3 == 0) m[at] = (unsigned char)(lcg >> 40);
+                }
+                FILE *fm = std::fopen(mut.c_str(), "wb");
+                REQUIRE(fm != nullptr);
+                if (!m.empty()) REQUIRE(std::fwrite(m.data(), 1, m.size(), fm) == m.size());
+                std::fclose(fm);
+                qa_sample_reads_t *h = nullptr;
+                qa::set_error("%s", "");
+                const int st = qa_bam_load_sample_reads(mut.c_str(), "chr20", T, L.data(), ref.data(), alt.data(), grid.data(), &io.bam, &h);
+                if (st == QA_OK) {
+                    n_ok++;
+                    REQUIRE(h != nullptr && qa_sample_reads_n_reads(h) >= 0);
+                    qa_sample_reads_destroy(h);
+                } else {
+                    n_refused++;
+                    if (h != nullptr || qa_last_error()[0] == 0)
+                        std::fprintf(stderr, "tsan harness: damaged file %d: status %d, handle %p, text '%s'\n", it, st, (void *)h, qa_last_error());
+                    REQUIRE(h == nullptr && qa_last_error()[0] != 0);
+                }
+            }
+            std::printf("tsan harness: %d damaged files read, %d refused\n", n_ok, n_refused);
+            REQUIRE(n_refused >= 30);   // (every truncation inside the data is refused; a changed byte may be harmless)
+        }
         // an unreadable file: the call fails, the loaders and formatters are joined
         std::vector<const char *> bad(argv + 2, argv + argc);
         bad[(size_t)n / 2] = "/nonexistent/file.bam";

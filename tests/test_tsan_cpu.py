@@ -59,7 +59,8 @@ def test_host_threads_are_clean_under_the_sanitizers(tmp_path, small_panel, san)
         f.write("".join(ref).encode())
         f.write("".join(alt).encode())
         f.write(grid.tobytes())
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:exitcode=67",
+    (tmp_path / "scratch").mkdir()
+    env = dict(os.environ, QA_HARNESS_SCRATCH=str(tmp_path / "scratch"), TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:exitcode=67",
                UBSAN_OPTIONS="print_stacktrace=1")
     run = subprocess.run([str(exe), str(tmp_path / "sites.bin")] + paths, capture_output=True, text=True, env=env, timeout=600)
     for mark in ("ThreadSanitizer", "AddressSanitizer", "runtime error:"):
