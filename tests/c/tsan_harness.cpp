@@ -334,6 +334,52 @@ int main(int argc, char **argv) {
             std::printf("tsan harness: %d damaged files read, %d refused\n", n_ok, n_refused);
             REQUIRE(n_refused >= 30);   // (every truncation inside the data is refused; a changed byte may be harmless)
         }
+        // a damaged INDEX next to a sound file: "any problem with the index just means the sequential scan" -- or a refusal -- never a fault
+        if (const char *scratch = std::getenv("QA_HARNESS_SCRATCH")) {
+            const char *indexed = std::getenv("QA_HARNESS_INDEXED");
+            if (indexed) {
+                auto slurp = [](const std::string &path, std::vector<unsigned char> &out) {
+                    FILE *fb = std::fopen(path.c_str(), "rb");
+                    if (!fb) return false;
+                    unsigned char buf[65536];
+                    size_t got;
+                    while ((got = std::fread(buf, 1, sizeof buf, fb)) > 0) out.insert(out.end(), buf, buf + got);
+                    std::fclose(fb);
+                    return true;
+                };
+                auto spill = [](const std::string &path, const std::vector<unsigned char> &b) {
+                    FILE *fm = std::fopen(path.c_str(), "wb");
+                    if (!fm) return false;
+                    const bool ok = b.empty() || std::fwrite(b.data(), 1, b.size(), fm) == b.size();
+                    std::fclose(fm);
+                    return ok;
+                };
+                std::vector<unsigned char> bam, bai;
+                REQUIRE(slurp(indexed, bam) && slurp(std::string(indexed) + ".bai", bai) && bai.size() > 16);
+                const std::string copy = std::string(scratch) + "/indexed.bam";
+                REQUIRE(spill(copy, bam));
+                qa_bam_opts_t w = io.bam;
+                w.chrStart = L[(size_t)T / 2]; w.chrEnd = L[(size_t)T - 1];   // (a window: the index is consulted)
+                int sound_reads = -1, n_ok = 0, n_refused = 0;
+                uint64_t lcg = 777;
+                for (int it = -1; it < 300; it++) {
+                    std::vector<unsigned char> m = bai;
+                    if (it >= 0 && it < 40) m.resize(bai.size() * (size_t)it / 40);
+                    else if (it >= 40) {
+                        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                        const size_t at = (size_t)((lcg >> 20) % bai.size());
+                        m[at] = (unsigned char)(lcg >> 40);
+                        if (it % 2) m[(at + 1) % bai.size()] ^= 0xff;
+                    }
+                    REQUIRE(spill(copy + ".bai", m));
+                    qa_sample_reads_t *h = nullptr;
+                    const int st = qa_bam_load_sample_reads(copy.c_str(), "chr20", T, L.data(), ref.data(), alt.data(), grid.data(), &w, &h);
+                    if (it < 0) { REQUIRE(st == QA_OK); sound_reads = qa_sample_reads_n_reads(h); REQUIRE(sound_reads > 0); }
+                    if (st == QA_OK) { n_ok++; qa_sample_reads_destroy(h); } else { n_refused++; REQUIRE(h == nullptr && qa_last_error()[0] != 0); }
+                }
+                std::printf("tsan harness: damaged index: %d loads went through, %d refused (sound: %d reads)\n", n_ok, n_refused, sound_reads);
+            }
+        }
         // an unreadable file: the call fails, the loaders and formatters are joined
         std::vector<const char *> bad(argv + 2, argv + argc);
         bad[(size_t)n / 2] = "/nonexistent/file.bam";

@@ -52,6 +52,11 @@ def test_host_threads_are_clean_under_the_sanitizers(tmp_path, small_panel, san)
         p = str(tmp_path / f"empty{at}.bam")
         bamutil.write_bam(p, header, [])
         paths.insert(at, p)
+    # one coordinate-sorted file with its .bai, whose index the harness damages (QA_HARNESS_INDEXED)
+    s_idx = make_synthetic_sample(panel, seed=990, n_reads=400)
+    alns = sorted(bamutil.sample_to_alignments(s_idx, panel.L, ref, alt, rng), key=lambda a: a["pos"])
+    indexed = str(tmp_path / "indexed.bam")
+    bamutil.write_bam(indexed, header, alns, index=True, block=2048)
     grid = np.ascontiguousarray(panel.grid if panel.grid is not None else np.arange(T) // 32, dtype=np.int32)
     with open(tmp_path / "sites.bin", "wb") as f:
         f.write(np.int32(T).tobytes())
@@ -60,7 +65,7 @@ def test_host_threads_are_clean_under_the_sanitizers(tmp_path, small_panel, san)
         f.write("".join(alt).encode())
         f.write(grid.tobytes())
     (tmp_path / "scratch").mkdir()
-    env = dict(os.environ, QA_HARNESS_SCRATCH=str(tmp_path / "scratch"), TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:exitcode=67",
+    env = dict(os.environ, QA_HARNESS_SCRATCH=str(tmp_path / "scratch"), QA_HARNESS_INDEXED=indexed, TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=0:exitcode=67",
                UBSAN_OPTIONS="print_stacktrace=1")
     run = subprocess.run([str(exe), str(tmp_path / "sites.bin")] + paths, capture_output=True, text=True, env=env, timeout=600)
     for mark in ("ThreadSanitizer", "AddressSanitizer", "runtime error:"):
